@@ -1,0 +1,154 @@
+/*
+ * vgmi.h -- C ABI of the MI355X (gfx950) implementation of varigraph's per-sample genotyping
+ * hot path.  This is the drop-in boundary: plain pointers and sizes, no C++ types, no torch.
+ *
+ * The reference has no plugin/FFI layer; its own CPU<->GPU seam is a pair of C++ classes whose
+ * CUDA twins override one method each.  Every entry point below names the reference interface
+ * it replaces (file:line relative to the reference tree).  INTEGRATION.md shows the C++ adapter
+ * (`FastqKmerHip : FastqKmer`, `BloomFilterHip : BloomFilter`) a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative vgmi_status; vgmi_last_error() has text.
+ *   - one context per (host thread, device); a context is not thread-safe; contexts are
+ *     independent.  Nothing throws, nothing exits (the reference prints and exit()s; the CLI
+ *     adapter reproduces that on top of the codes).
+ *   - "host" pointers are ordinary host memory owned by the caller; "dev" pointers are device
+ *     memory on the context's device, owned by the caller (e.g. a torch tensor), 16-byte aligned.
+ *   - a *read block* is the '\n'-joined concatenation of read sequences (ASCII, any case, as in
+ *     a FASTQ sequence line): every read is followed by exactly one '\n'.  This is the layout
+ *     the reference GPU path builds on the host with 'N' separators (src/fastq_kmer.cu:171-175).
+ *   - keys are the reference's graph k-mer keys: hash64(min(fwd,rc), 2^(2k)-1) << 8 | k
+ *     (src/kmer.cpp:135-138, include/hash64.hpp:5-14), exactly as stored in graph.bin.
+ */
+#ifndef VGMI_H
+#define VGMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vgmi_ctx vgmi_ctx;
+
+typedef enum vgmi_status {
+    VGMI_OK = 0,
+    VGMI_E_INVALID = -1,      /* bad argument (NULL, k out of 1..28, misaligned device pointer ...) */
+    VGMI_E_NO_DEVICE = -2,    /* no HIP device / bad ordinal  (reference: cudaSetDevice failure, main.cu:221,444) */
+    VGMI_E_HIP = -3,          /* a HIP runtime call failed    (reference: gpuErrchk, include/cuda_error_handling.hpp:10-16) */
+    VGMI_E_STATE = -4,        /* call order violated (e.g. reads before a table) */
+    VGMI_E_DUPLICATE_KEY = -5,/* table keys not unique (the reference map cannot hold duplicates) */
+    VGMI_E_BAD_KEY = -6,      /* key low byte != k or payload >= 2^(2k) */
+    VGMI_E_EMPTY_READ = -7,   /* a zero-length read: the reference aborts on assert(len>0), src/kmer.cpp:124 */
+    VGMI_E_NOMEM = -8
+} vgmi_status;
+
+/* ---- device / context -------------------------------------------------------------------
+ * replaces: cudaSetDevice(config.gpu) + VarigraphKernelConfig{gpu,buffer}
+ *           (main.cu:221-229,444-452; include/varigraph.cuh:19-28; flags --gpu/--buffer main.cu:99-100) */
+int vgmi_device_count(void);
+int vgmi_create(int device, size_t buffer_mib, vgmi_ctx **out);
+void vgmi_destroy(vgmi_ctx *ctx);
+const char *vgmi_last_error(const vgmi_ctx *ctx); /* ctx may be NULL: error of the last failed vgmi_create */
+/* the HIP stream every kernel of this context is launched on (hipStream_t), for event timing */
+void *vgmi_stream(vgmi_ctx *ctx);
+
+/* ---- graph k-mer table (immutable after upload) -----------------------------------------
+ * replaces: the `unordered_map<uint64_t,kmerCovFreBitVec>& GraphKmerHashHapStrMap` argument of
+ *           FastqKmer / FastqKmerKernel (include/fastq_kmer.hpp:57-62, include/fastq_kmer.cuh:15-36):
+ *           membership test of src/kmer.cpp:140 and the `.c` counters of src/fastq_kmer.cpp:132-138.
+ * keys[i] keeps its index i: every per-key output below is in this order. */
+int vgmi_table_upload(vgmi_ctx *ctx, const uint64_t *host_keys, size_t n_keys, uint32_t k);
+/* Device image of the table (for one RCCL broadcast from the rank that parsed graph.bin;
+ * the reference is single-device).  export copies it into a caller-owned device
+ * buffer of vgmi_table_image_bytes(); import adopts such a buffer's contents on another rank. */
+int vgmi_table_image_bytes(vgmi_ctx *ctx, size_t *bytes);
+int vgmi_table_export(vgmi_ctx *ctx, void *dev_dst, size_t bytes);
+int vgmi_table_import(vgmi_ctx *ctx, const void *dev_src, size_t bytes);
+int vgmi_table_info(vgmi_ctx *ctx, size_t *n_keys, uint32_t *k, size_t *n_slots, size_t *filter_bits);
+
+/* Per-node k-mer lists in CSR form.
+ * replaces: nodeSrt::GraphKmerHashHapStrMapIterVec built by ConstructIndex::graph2node
+ *           (src/construct_index.cpp:710-751,1572-1603): node v owns key_index[node_off[v]..node_off[v+1]). */
+int vgmi_nodes_upload(vgmi_ctx *ctx, const uint64_t *host_node_off, const uint32_t *host_key_index,
+                      size_t n_nodes);
+/* flag[i] != 0 iff key i has f<=1 and is carried by all vcfPloidy haplotypes of at least one VCF
+ * sample: the sample-independent part of Varigraph::get_hom_kmer (src/varigraph.cpp:263-287). */
+int vgmi_flags_upload(vgmi_ctx *ctx, const uint8_t *host_hom_flag);
+
+/* ---- per sample ---------------------------------------------------------------------------
+ * replaces: FastqKmer::build_fastq_index / FastqKmerKernel::build_fastq_index_kernel
+ *           (src/fastq_kmer.cpp:41-187, src/fastq_kmer.cu:20-274) and ConstructIndex::reset
+ *           (include/construct_index.hpp:317-331). */
+int vgmi_counts_reset(vgmi_ctx *ctx);
+/* One read block from host memory (copied to pinned staging, sent asynchronously; returns
+ * before the kernel has run).  read_off[n_reads+1] = byte offset of each read start
+ * (read_off[n_reads] == n_bytes); may be NULL, it is then derived from the '\n's when needed
+ * (even k only). */
+int vgmi_reads_submit(vgmi_ctx *ctx, const char *host_bases, size_t n_bytes,
+                      const uint64_t *host_read_off, size_t n_reads);
+/* Same, block already resident in device memory (no copy).  dev_read_off is required for even k. */
+int vgmi_reads_submit_device(vgmi_ctx *ctx, const char *dev_bases, size_t n_bytes,
+                             const uint64_t *dev_read_off, size_t n_reads);
+/* Sum of read lengths submitted since the last reset: FastqKmer::mReadBase
+ * (include/fastq_kmer.hpp:42, src/fastq_kmer.cpp:105). */
+int vgmi_read_base(vgmi_ctx *ctx, uint64_t *read_base);
+/* Waits for all submitted blocks, then (any output may be NULL)
+ *   cov_out[n_keys]        c of every key = min(255, occurrences)             (src/fastq_kmer.cpp:133-137)
+ *   cov_node_out[node_off[n_nodes]]  c gathered in node order: the per-node depth lookup
+ *                          `iter->second.c` of src/genotype.cpp:546,660,1405-1408
+ *   hist256_out[256]       #flagged keys per non-zero c: Varigraph::get_hom_kmer (src/varigraph.cpp:253-296)
+ * Returns VGMI_E_EMPTY_READ if any submitted block held a zero-length read. */
+int vgmi_counts_finish(vgmi_ctx *ctx, uint8_t *host_cov_out, uint8_t *host_cov_node_out,
+                       uint64_t *host_hist256_out);
+/* Device-side variant: leaves the results in device buffers of the same shapes (no D2H). */
+int vgmi_counts_finish_device(vgmi_ctx *ctx, uint8_t *dev_cov_out, uint8_t *dev_cov_node_out,
+                              uint64_t *dev_hist256_out);
+/* Accumulated GPU time (HIP events on the context stream) of the read-counting kernel since
+ * the last reset, and the number of launches; for roofline accounting. */
+int vgmi_count_kernel_ms(vgmi_ctx *ctx, float *ms, uint64_t *launches);
+
+/* K1 alone: the key every position of a read block emits, for emitter parity tests.
+ * keys_out[i] = key of the k-mer ENDING at byte i, or UINT64_MAX when the reference emits nothing
+ * there (kmerBit::kmer_sketch_* loop, src/kmer.cpp:126-146).  Host buffers. */
+int vgmi_sketch_keys(vgmi_ctx *ctx, const char *host_bases, size_t n_bytes,
+                     const uint64_t *host_read_off, size_t n_reads, uint32_t k,
+                     uint64_t *host_keys_out);
+
+/* ---- construct-side counting Bloom filter ------------------------------------------------
+ * replaces: BloomFilter(n,p)/add/count/find (include/counting_bloom_filter.hpp:43-77,
+ *           src/counting_bloom_filter.cpp:28-98) and BloomFilterKernel::add_kernel
+ *           (include/counting_bloom_filter.cuh:56-82), driven by ConstructIndex::make_mbf via
+ *           kmerBit::kmer_sketch_bf (src/construct_index.cpp:150-177, src/kmer.cpp:20-53). */
+/* m and n_hash as BloomFilter::_calculate_size/_calculate_num_hashes give them */
+int vgmi_bloom_params(uint64_t n, double p, uint64_t *m, uint32_t *n_hash);
+/* seeds: the 64-bit values the reference stores; only their low 32 bits reach MurmurHash3
+ * (`unsigned int seed`, src/counting_bloom_filter.cpp:90) */
+int vgmi_bloom_create(vgmi_ctx *ctx, uint64_t m, uint32_t n_hash, const uint64_t *host_seeds);
+/* one contiguous sequence (a chromosome); the emitter state spans the whole call */
+int vgmi_bloom_add_seq(vgmi_ctx *ctx, const char *host_bases, uint64_t len, uint32_t k);
+int vgmi_bloom_add_seq_device(vgmi_ctx *ctx, const char *dev_bases, uint64_t len, uint32_t k);
+int vgmi_bloom_fetch(vgmi_ctx *ctx, uint8_t *host_filter_out /* m bytes */);
+int vgmi_bloom_load(vgmi_ctx *ctx, const uint8_t *host_filter /* m bytes */);
+/* batch BloomFilter::count (min over hashes) and ::find (all non-zero); outputs may be NULL */
+int vgmi_bloom_query(vgmi_ctx *ctx, const uint64_t *host_keys, size_t n, uint8_t *host_min_out,
+                     uint8_t *host_all_nonzero_out);
+
+/* ---- bench / test tooling (not part of the reference seam) -------------------------------
+ * Seeded synthetic reads (varigraph_amd/csrc/vg_synth.h) written straight into device memory:
+ * reads [first_read, first_read+n_reads) of the stream `seed`, each `read_len` bases + '\n'.
+ * dev_haps: n_hap device pointers' worth of ASCII haplotypes, given as one concatenated device
+ * buffer `dev_hap_cat` with offsets hap_off[n_hap+1] (host array). */
+int vgmi_synth_reads_device(vgmi_ctx *ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads,
+                            uint32_t read_len, const char *dev_hap_cat, const uint64_t *host_hap_off,
+                            uint32_t n_hap, char *dev_out);
+/* same generator on the host (no device needed; ctx may be NULL) */
+int vgmi_synth_reads_host(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                          const char *hap_cat, const uint64_t *hap_off, uint32_t n_hap, char *out);
+int vgmi_synth_reference_host(uint64_t seed, uint64_t len, char *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGMI_H */

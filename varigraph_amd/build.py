@@ -1,0 +1,90 @@
+"""Build the native libraries in-tree.
+
+  varigraph_amd/libvgmi.so   HIP kernels + C ABI (include/vgmi.h), hipcc --offload-arch=gfx950
+  oracle/liboracle.so        the CPU checker (test infrastructure; see oracle/vg_oracle.h)
+  oracle/_ref/*              the real reference, only when /root/reference is present
+
+hipcc cross-compiles without a GPU, so this runs in the build container too.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "varigraph_amd", "csrc")
+LIB = os.path.join(ROOT, "varigraph_amd", "libvgmi.so")
+HOSTLIB = os.path.join(ROOT, "varigraph_amd", "libvghost.so")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+
+
+def build_vgmi(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, f) for f in ("vgmi_kernels.hip", "vgmi_api.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("vgmi_kernels.h", "vgmi_device.h", "vg_synth.h")] + [
+        os.path.join(ROOT, "include", "vgmi.h")]
+    if not force and not _newer(LIB, deps):
+        return LIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
+           "-Wno-unused-function", *srcs, "-o", LIB]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=ROOT)
+    return LIB
+
+
+def build_host(force=False, verbose=False):
+    hdir = os.path.join(CSRC, "host")
+    if not os.path.isdir(hdir):
+        return None
+    srcs = sorted(os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith(".cpp") and not f.startswith("main_"))
+    if not srcs:
+        return None
+    deps = srcs + [os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith(".hpp") or f.endswith(".h")] + [
+        os.path.join(ROOT, "include", "vgmi.h"), os.path.join(ROOT, "include", "vghost.h")]
+    deps = [d for d in deps if os.path.exists(d)]
+    if not force and not _newer(HOSTLIB, deps + [LIB]):
+        return HOSTLIB
+    cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall", "-I", os.path.join(ROOT, "include"), *srcs,
+           "-o", HOSTLIB, "-L", os.path.dirname(LIB), "-lvgmi", "-Wl,-rpath,$ORIGIN", "-lz", "-lpthread"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=ROOT)
+    return HOSTLIB
+
+
+def build_oracle(force=False, with_ref=None):
+    """Compile the checker. Building it is not using it (only tests/smoke/cpu_baseline call it)."""
+    args = ["make", "-s", "-C", ORACLE_DIR, "all"]
+    if with_ref is None:
+        with_ref = os.path.isdir("/root/reference/src")
+    if with_ref:
+        args.append("ref")
+    if force:
+        args.insert(1, "-B")
+    subprocess.run(args, check=True)
+    return ORACLE_LIB
+
+
+def build_all(force=False, verbose=False):
+    build_vgmi(force, verbose)
+    build_host(force, verbose)
+    build_oracle(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,867 @@
+// vgmi_api.cpp -- the C ABI of include/vgmi.h over the gfx950 kernels (vgmi_kernels.hip).
+//
+// Host-side plumbing only: contexts, device memory, pinned double-buffered staging, streams and
+// events.  There is no CPU implementation of any compute path in here -- without a HIP device
+// vgmi_create fails with VGMI_E_NO_DEVICE.
+#include "../../include/vgmi.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vg_synth.h"
+#include "vgmi_device.h"
+#include "vgmi_kernels.h"
+
+using namespace vgk;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct ImageHeader {  // first 256 bytes of the table image
+    char magic[8];    // "VGMITBL1"
+    uint32_t k;
+    uint32_t filter_words_log2;
+    uint64_t n_keys;
+    uint64_t cap;
+    uint64_t off_slots, off_key_slot, off_filter, total_bytes;
+    uint8_t pad[256 - 8 - 4 - 4 - 8 - 8 - 32];
+};
+static_assert(sizeof(ImageHeader) == 256, "image header is 256 bytes");
+
+struct Stage {
+    char* h = nullptr;        // pinned
+    char* d = nullptr;
+    uint64_t* d_off = nullptr;
+    size_t d_off_cap = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;  // last kernel that used this stage
+    bool busy = false;
+};
+
+}  // namespace
+
+struct vgmi_ctx {
+    int device = 0;
+    int n_cu = 0;
+    size_t buffer_bytes = 0;
+    std::string err;
+    hipStream_t stream = nullptr;  // main stream: table build, device submits, finish
+
+    // table image (one allocation) and views into it
+    uint8_t* d_image = nullptr;
+    size_t image_bytes = 0;
+    ImageHeader hdr{};
+    bool has_table = false;
+    TableView tv{};
+    uint32_t* d_key_slot = nullptr;
+    bool filter_in_lds = false;
+
+    // nodes / flags / outputs
+    size_t n_nodes = 0;
+    uint64_t n_node_entries = 0;
+    uint32_t* d_node_key_index = nullptr;
+    uint8_t* d_flag = nullptr;
+    uint8_t* d_cov = nullptr;
+    uint8_t* d_cov_node = nullptr;
+    unsigned long long* d_hist = nullptr;
+    uint32_t* d_status = nullptr;
+
+    // per-sample state
+    uint64_t read_base = 0;
+    Stage stage[2];
+    int next_stage = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;  // (start, stop) of count launches
+    std::vector<hipEvent_t> event_pool;
+    float kernel_ms = 0.f;
+    uint64_t launches = 0;
+
+    // bloom
+    bool has_bloom = false;
+    BloomView bv{};
+    size_t bloom_alloc = 0;
+};
+
+namespace {
+
+int fail(vgmi_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            char b_[512];                                                                          \
+            snprintf(b_, sizeof b_, "%s:%d: %s failed: %s", __FILE__, __LINE__, #call,             \
+                     hipGetErrorString(e_));                                                       \
+            return fail((c), VGMI_E_HIP, b_);                                                      \
+        }                                                                                          \
+    } while (0)
+
+uint32_t ceil_log2(uint64_t x)
+{
+    uint32_t l = 0;
+    while ((1ULL << l) < x) ++l;
+    return l;
+}
+
+hipEvent_t get_event(vgmi_ctx* c)
+{
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+void free_table(vgmi_ctx* c)
+{
+    if (c->d_image) (void)hipFree(c->d_image);
+    c->d_image = nullptr;
+    c->image_bytes = 0;
+    c->has_table = false;
+    if (c->d_cov) (void)hipFree(c->d_cov);
+    c->d_cov = nullptr;
+    if (c->d_flag) (void)hipFree(c->d_flag);
+    c->d_flag = nullptr;
+}
+
+void free_nodes(vgmi_ctx* c)
+{
+    if (c->d_node_key_index) (void)hipFree(c->d_node_key_index);
+    if (c->d_cov_node) (void)hipFree(c->d_cov_node);
+    c->d_node_key_index = nullptr;
+    c->d_cov_node = nullptr;
+    c->n_nodes = 0;
+    c->n_node_entries = 0;
+}
+
+void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
+{
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "VGMITBL1", 8);
+    h.k = k;
+    h.n_keys = n_keys;
+    uint64_t cap = 64;
+    while (cap < 2 * n_keys) cap <<= 1;  // load factor <= 0.5
+    h.cap = cap;
+    // prefilter: >= 16 bits per key, power of two, at least 128 bits
+    uint64_t bits = 128;
+    while (bits < 16 * n_keys) bits <<= 1;
+    h.filter_words_log2 = ceil_log2(bits) - 5;
+    auto align = [](uint64_t x) { return (x + 255) & ~255ULL; };
+    h.off_slots = 256;
+    h.off_key_slot = align(h.off_slots + cap * sizeof(VgSlot));
+    h.off_filter = align(h.off_key_slot + (n_keys ? n_keys : 1) * 4);
+    h.total_bytes = align(h.off_filter + (4ULL << h.filter_words_log2));
+}
+
+// LDS budget of the count kernel with an LDS-resident filter: filter + 16 wave queues + LUTs
+bool filter_fits_lds(uint32_t words_log2) { return (4ULL << words_log2) + 16 * 128 * 8 + 512 <= 160 * 1024; }
+
+int adopt_image(vgmi_ctx* c)
+{
+    const ImageHeader& h = c->hdr;
+    c->tv.slots = reinterpret_cast<VgSlot*>(c->d_image + h.off_slots);
+    c->tv.cap_mask = h.cap - 1;
+    c->tv.filter = reinterpret_cast<const uint32_t*>(c->d_image + h.off_filter);
+    c->tv.filter_words_log2 = h.filter_words_log2;
+    c->tv.filter_shift = 32 - h.filter_words_log2;
+    c->d_key_slot = reinterpret_cast<uint32_t*>(c->d_image + h.off_key_slot);
+    c->filter_in_lds = filter_fits_lds(h.filter_words_log2);
+    HIPCHK(c, hipMalloc(&c->d_cov, h.n_keys ? h.n_keys : 1));
+    c->has_table = true;
+    free_nodes(c);
+    return VGMI_OK;
+}
+
+RowParams row_params(vgmi_ctx* c, const char* d_bases, size_t n_bytes, uint32_t k)
+{
+    RowParams p{};
+    p.bases = reinterpret_cast<const uint8_t*>(d_bases);
+    p.n_bytes = n_bytes;
+    p.k = k;
+    p.status = c->d_status;
+    p.table = c->tv;
+    p.keys_out = nullptr;
+    p.bloom = c->bv;
+    return p;
+}
+
+// launch geometry of the row kernel
+void rows_geometry(vgmi_ctx* c, bool flds, uint32_t& grid, uint32_t& block)
+{
+    if (flds) { block = 1024; grid = (uint32_t)c->n_cu; }
+    else      { block = 256;  grid = (uint32_t)c->n_cu * 8; }
+}
+
+int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_t* d_read_off, size_t n_reads,
+                 hipStream_t st)
+{
+    if (n_bytes == 0) return VGMI_OK;
+    const uint32_t k = c->hdr.k;
+    RowParams p = row_params(c, d_bases, n_bytes, k);
+    hipEvent_t e0 = get_event(c), e1 = get_event(c);
+    if (!e0 || !e1) return fail(c, VGMI_E_HIP, "hipEventCreate failed");
+    HIPCHK(c, hipEventRecord(e0, st));
+    if (k & 1) {
+        uint32_t grid, block;
+        rows_geometry(c, c->filter_in_lds, grid, block);
+        HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, grid, block, st));
+    } else {
+        if (!d_read_off) return fail(c, VGMI_E_INVALID, "even k needs read offsets");
+        HIPCHK(c, launch_seq(K_MODE_COUNT, p, d_read_off, n_reads, st));
+    }
+    HIPCHK(c, hipEventRecord(e1, st));
+    c->timed.emplace_back(e0, e1);
+    c->launches++;
+    return VGMI_OK;
+}
+
+int collect_timing(vgmi_ctx* c)
+{
+    for (auto& pr : c->timed) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventSynchronize(pr.second));
+        HIPCHK(c, hipEventElapsedTime(&ms, pr.first, pr.second));
+        c->kernel_ms += ms;
+        c->event_pool.push_back(pr.first);
+        c->event_pool.push_back(pr.second);
+    }
+    c->timed.clear();
+    return VGMI_OK;
+}
+
+int ensure_stage(vgmi_ctx* c, Stage& s)
+{
+    if (s.h) return VGMI_OK;
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&s.h), c->buffer_bytes, hipHostMallocDefault));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&s.d), c->buffer_bytes + 16));
+    HIPCHK(c, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    return VGMI_OK;
+}
+
+int sync_stages(vgmi_ctx* c)
+{
+    for (auto& s : c->stage) {
+        if (s.busy) {
+            HIPCHK(c, hipEventSynchronize(s.done));
+            s.busy = false;
+        }
+    }
+    return VGMI_OK;
+}
+
+std::vector<uint64_t> offsets_from_newlines(const char* b, size_t n)
+{
+    std::vector<uint64_t> off;
+    off.push_back(0);
+    const char* p = b;
+    const char* end = b + n;
+    while (p < end) {
+        const char* nl = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+        if (!nl) { off.push_back(n + 1); break; }  // unterminated last read: pretend a '\n' follows
+        off.push_back((uint64_t)(nl - b) + 1);
+        p = nl + 1;
+    }
+    return off;
+}
+
+int check_status(vgmi_ctx* c)
+{
+    uint32_t st = 0;
+    HIPCHK(c, hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
+    if (st & 2u) return fail(c, VGMI_E_BAD_KEY, "table key with low byte != k or payload >= 2^(2k)");
+    if (st & 4u) return fail(c, VGMI_E_DUPLICATE_KEY, "duplicate key in table upload");
+    if (st & 1u) return fail(c, VGMI_E_EMPTY_READ, "zero-length read in a read block (reference: assert(len > 0), kmer.cpp:124)");
+    return VGMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vgmi_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int vgmi_create(int device, size_t buffer_mib, vgmi_ctx** out)
+{
+    if (!out) return fail(nullptr, VGMI_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(nullptr, VGMI_E_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail(nullptr, VGMI_E_NO_DEVICE, "device ordinal out of range");
+    vgmi_ctx* c = new (std::nothrow) vgmi_ctx();
+    if (!c) return fail(nullptr, VGMI_E_NOMEM, "out of host memory");
+    c->device = device;
+    if (buffer_mib == 0) buffer_mib = 100;  // reference default --buffer 100 (include/varigraph.cuh:28)
+    c->buffer_bytes = buffer_mib << 20;
+    auto bail = [&](const char* what, hipError_t e) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(e);
+        vgmi_destroy(c);
+        return (int)VGMI_E_HIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipMalloc(&c->d_status, 4)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(c->d_status, 0, 4)) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipMalloc(&c->d_hist, 256 * 8)) != hipSuccess) return bail("hipMalloc", e);
+    *out = c;
+    return VGMI_OK;
+}
+
+void vgmi_destroy(vgmi_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    free_table(c);
+    free_nodes(c);
+    for (auto& s : c->stage) {
+        if (s.h) (void)hipHostFree(s.h);
+        if (s.d) (void)hipFree(s.d);
+        if (s.d_off) (void)hipFree(s.d_off);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    for (auto& pr : c->timed) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto& e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->bv.filter) (void)hipFree(c->bv.filter);
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->d_hist) (void)hipFree(c->d_hist);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* vgmi_last_error(const vgmi_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+void* vgmi_stream(vgmi_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+/* ---------------------------------------------------------------- table */
+
+int vgmi_table_upload(vgmi_ctx* c, const uint64_t* keys, size_t n_keys, uint32_t k)
+{
+    if (!c) return VGMI_E_INVALID;
+    if (k < 1 || k > 28) return fail(c, VGMI_E_INVALID, "k must be in 1..28 (reference assert, kmer.cpp:124)");
+    if (n_keys && !keys) return fail(c, VGMI_E_INVALID, "keys is NULL");
+    if (n_keys >= (1ULL << 31)) return fail(c, VGMI_E_INVALID, "too many keys");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_table(c);
+    layout_image(c->hdr, k, n_keys);
+    c->image_bytes = c->hdr.total_bytes;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_image), c->image_bytes));
+    HIPCHK(c, hipMemsetAsync(c->d_image, 0, c->image_bytes, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_image, &c->hdr, sizeof c->hdr, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4, c->stream));
+    int rc = adopt_image(c);
+    if (rc) return rc;
+    HIPCHK(c, launch_table_clear(c->tv.slots, c->hdr.cap, c->stream));
+    uint64_t* d_keys = nullptr;
+    if (n_keys) {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_keys), n_keys * 8));
+        HIPCHK(c, hipMemcpyAsync(d_keys, keys, n_keys * 8, hipMemcpyHostToDevice, c->stream));
+        hipError_t e = launch_table_insert(c->tv, d_keys, n_keys, k, c->d_key_slot,
+                                           const_cast<uint32_t*>(c->tv.filter), c->d_status, c->stream);
+        if (e != hipSuccess) { (void)hipFree(d_keys); HIPCHK(c, e); }
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (d_keys) (void)hipFree(d_keys);
+    HIPCHK(c, e);
+    rc = check_status(c);
+    if (rc) { free_table(c); return rc; }
+    c->read_base = 0;
+    return VGMI_OK;
+}
+
+int vgmi_table_image_bytes(vgmi_ctx* c, size_t* bytes)
+{
+    if (!c || !bytes) return VGMI_E_INVALID;
+    if (!c->has_table) return fail(c, VGMI_E_STATE, "no table");
+    *bytes = c->image_bytes;
+    return VGMI_OK;
+}
+
+int vgmi_table_export(vgmi_ctx* c, void* dev_dst, size_t bytes)
+{
+    if (!c || !dev_dst) return VGMI_E_INVALID;
+    if (!c->has_table) return fail(c, VGMI_E_STATE, "no table");
+    if (bytes < c->image_bytes) return fail(c, VGMI_E_INVALID, "destination smaller than the image");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dev_dst, c->d_image, c->image_bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VGMI_OK;
+}
+
+int vgmi_table_import(vgmi_ctx* c, const void* dev_src, size_t bytes)
+{
+    if (!c || !dev_src) return VGMI_E_INVALID;
+    if (bytes < sizeof(ImageHeader)) return fail(c, VGMI_E_INVALID, "image too small");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ImageHeader h;
+    HIPCHK(c, hipMemcpy(&h, dev_src, sizeof h, hipMemcpyDeviceToHost));
+    if (memcmp(h.magic, "VGMITBL1", 8) != 0 || h.total_bytes > bytes || h.k < 1 || h.k > 28)
+        return fail(c, VGMI_E_INVALID, "not a table image");
+    ImageHeader chk;
+    layout_image(chk, h.k, h.n_keys);
+    if (memcmp(&chk, &h, sizeof h) != 0) return fail(c, VGMI_E_INVALID, "table image layout mismatch");
+    free_table(c);
+    c->hdr = h;
+    c->image_bytes = h.total_bytes;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_image), c->image_bytes));
+    HIPCHK(c, hipMemcpy(c->d_image, dev_src, c->image_bytes, hipMemcpyDeviceToDevice));
+    int rc = adopt_image(c);
+    if (rc) return rc;
+    HIPCHK(c, launch_counts_reset(c->tv.slots, c->hdr.cap, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->read_base = 0;
+    return VGMI_OK;
+}
+
+int vgmi_table_info(vgmi_ctx* c, size_t* n_keys, uint32_t* k, size_t* n_slots, size_t* filter_bits)
+{
+    if (!c) return VGMI_E_INVALID;
+    if (!c->has_table) return fail(c, VGMI_E_STATE, "no table");
+    if (n_keys) *n_keys = c->hdr.n_keys;
+    if (k) *k = c->hdr.k;
+    if (n_slots) *n_slots = c->hdr.cap;
+    if (filter_bits) *filter_bits = 32ULL << c->hdr.filter_words_log2;
+    return VGMI_OK;
+}
+
+int vgmi_nodes_upload(vgmi_ctx* c, const uint64_t* node_off, const uint32_t* key_index, size_t n_nodes)
+{
+    if (!c || !node_off) return VGMI_E_INVALID;
+    if (!c->has_table) return fail(c, VGMI_E_STATE, "upload the table first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t total = node_off[n_nodes];
+    if (total && !key_index) return fail(c, VGMI_E_INVALID, "key_index is NULL");
+    for (uint64_t i = 0; i < total; ++i)
+        if (key_index[i] >= c->hdr.n_keys) return fail(c, VGMI_E_INVALID, "node key index out of range");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_nodes(c);
+    c->n_nodes = n_nodes;
+    c->n_node_entries = total;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_node_key_index), (total ? total : 1) * 4));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_cov_node), total ? total : 1));
+    if (total) HIPCHK(c, hipMemcpy(c->d_node_key_index, key_index, total * 4, hipMemcpyHostToDevice));
+    return VGMI_OK;
+}
+
+int vgmi_flags_upload(vgmi_ctx* c, const uint8_t* flag)
+{
+    if (!c || !flag) return VGMI_E_INVALID;
+    if (!c->has_table) return fail(c, VGMI_E_STATE, "upload the table first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!c->d_flag) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_flag), c->hdr.n_keys ? c->hdr.n_keys : 1));
+    if (c->hdr.n_keys) HIPCHK(c, hipMemcpy(c->d_flag, flag, c->hdr.n_keys, hipMemcpyHostToDevice));
+    return VGMI_OK;
+}
+
+/* ---------------------------------------------------------------- per sample */
+
+int vgmi_counts_reset(vgmi_ctx* c)
+{
+    if (!c) return VGMI_E_INVALID;
+    if (!c->has_table) return fail(c, VGMI_E_STATE, "no table");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = sync_stages(c);
+    if (rc) return rc;
+    rc = collect_timing(c);
+    if (rc) return rc;
+    HIPCHK(c, launch_counts_reset(c->tv.slots, c->hdr.cap, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4, c->stream));
+    c->read_base = 0;
+    c->kernel_ms = 0.f;
+    c->launches = 0;
+    return VGMI_OK;
+}
+
+int vgmi_reads_submit_device(vgmi_ctx* c, const char* dev_bases, size_t n_bytes, const uint64_t* dev_read_off,
+                             size_t n_reads)
+{
+    if (!c) return VGMI_E_INVALID;
+    if (!c->has_table) return fail(c, VGMI_E_STATE, "no table");
+    if (n_bytes && !dev_bases) return fail(c, VGMI_E_INVALID, "dev_bases is NULL");
+    if (reinterpret_cast<uintptr_t>(dev_bases) & 15) return fail(c, VGMI_E_INVALID, "dev_bases must be 16-byte aligned");
+    if (n_reads > n_bytes) return fail(c, VGMI_E_INVALID, "n_reads > n_bytes");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = launch_count(c, dev_bases, n_bytes, dev_read_off, n_reads, c->stream);
+    if (rc) return rc;
+    c->read_base += n_bytes - n_reads;
+    return VGMI_OK;
+}
+
+int vgmi_reads_submit(vgmi_ctx* c, const char* bases, size_t n_bytes, const uint64_t* read_off, size_t n_reads)
+{
+    if (!c) return VGMI_E_INVALID;
+    if (!c->has_table) return fail(c, VGMI_E_STATE, "no table");
+    if (n_bytes == 0) return VGMI_OK;
+    if (!bases) return fail(c, VGMI_E_INVALID, "bases is NULL");
+    if (bases[n_bytes - 1] != '\n') return fail(c, VGMI_E_INVALID, "a read block must end with '\\n'");
+    if (n_reads > n_bytes) return fail(c, VGMI_E_INVALID, "n_reads > n_bytes");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool need_off = (c->hdr.k & 1) == 0;
+    std::vector<uint64_t> derived;
+    if (need_off && !read_off) {
+        derived = offsets_from_newlines(bases, n_bytes);
+        if (derived.size() != n_reads + 1) return fail(c, VGMI_E_INVALID, "n_reads does not match the number of '\\n'");
+        read_off = derived.data();
+    }
+    // cut the block into staging-buffer sized pieces at read boundaries
+    size_t pos = 0, read_i = 0;
+    while (pos < n_bytes) {
+        size_t len = n_bytes - pos;
+        size_t piece_reads = n_reads - read_i;
+        if (len > c->buffer_bytes) {
+            len = c->buffer_bytes;
+            while (len > 0 && bases[pos + len - 1] != '\n') --len;
+            if (len == 0) return fail(c, VGMI_E_INVALID, "a single read exceeds the staging buffer (--buffer)");
+            if (need_off) {
+                size_t j = read_i;
+                while (read_off[j] < pos + len) ++j;
+                piece_reads = j - read_i;
+            } else {
+                piece_reads = 0;  // not needed by the odd-k kernel
+            }
+        }
+        Stage& s = c->stage[c->next_stage];
+        c->next_stage ^= 1;
+        int rc = ensure_stage(c, s);
+        if (rc) return rc;
+        if (s.busy) { HIPCHK(c, hipEventSynchronize(s.done)); s.busy = false; }
+        memcpy(s.h, bases + pos, len);
+        HIPCHK(c, hipMemcpyAsync(s.d, s.h, len, hipMemcpyHostToDevice, s.stream));
+        const uint64_t* d_off = nullptr;
+        if (need_off) {
+            if (s.d_off_cap < piece_reads + 1) {
+                if (s.d_off) (void)hipFree(s.d_off);
+                s.d_off_cap = (piece_reads + 1) * 2;
+                HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&s.d_off), s.d_off_cap * 8));
+            }
+            std::vector<uint64_t> rel(piece_reads + 1);
+            for (size_t j = 0; j <= piece_reads; ++j) rel[j] = read_off[read_i + j] - pos;
+            HIPCHK(c, hipMemcpy(s.d_off, rel.data(), rel.size() * 8, hipMemcpyHostToDevice));
+            d_off = s.d_off;
+        }
+        rc = launch_count(c, s.d, len, d_off, piece_reads, s.stream);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(s.done, s.stream));
+        s.busy = true;
+        pos += len;
+        read_i += piece_reads;
+    }
+    c->read_base += n_bytes - n_reads;
+    return VGMI_OK;
+}
+
+int vgmi_read_base(vgmi_ctx* c, uint64_t* rb)
+{
+    if (!c || !rb) return VGMI_E_INVALID;
+    *rb = c->read_base;
+    return VGMI_OK;
+}
+
+static int finish_common(vgmi_ctx* c, uint8_t* d_cov, uint8_t* d_cov_node, unsigned long long* d_hist)
+{
+    // the main stream must see every staged kernel
+    for (auto& s : c->stage)
+        if (s.busy) HIPCHK(c, hipStreamWaitEvent(c->stream, s.done, 0));
+    if (d_hist) HIPCHK(c, hipMemsetAsync(d_hist, 0, 256 * 8, c->stream));
+    HIPCHK(c, launch_cov(c->tv.slots, c->d_key_slot, c->hdr.n_keys, c->d_flag, d_cov, d_hist, c->stream));
+    if (d_cov_node && c->n_node_entries)
+        HIPCHK(c, launch_node_gather(d_cov, c->d_node_key_index, c->n_node_entries, d_cov_node, c->stream));
+    return VGMI_OK;
+}
+
+int vgmi_counts_finish(vgmi_ctx* c, uint8_t* cov_out, uint8_t* cov_node_out, uint64_t* hist_out)
+{
+    if (!c) return VGMI_E_INVALID;
+    if (!c->has_table) return fail(c, VGMI_E_STATE, "no table");
+    if (cov_node_out && !c->d_node_key_index) return fail(c, VGMI_E_STATE, "no nodes uploaded");
+    if (hist_out && !c->d_flag) return fail(c, VGMI_E_STATE, "no flags uploaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = finish_common(c, c->d_cov, cov_node_out ? c->d_cov_node : nullptr, hist_out ? c->d_hist : nullptr);
+    if (rc) return rc;
+    if (cov_out && c->hdr.n_keys)
+        HIPCHK(c, hipMemcpyAsync(cov_out, c->d_cov, c->hdr.n_keys, hipMemcpyDeviceToHost, c->stream));
+    if (cov_node_out && c->n_node_entries)
+        HIPCHK(c, hipMemcpyAsync(cov_node_out, c->d_cov_node, c->n_node_entries, hipMemcpyDeviceToHost, c->stream));
+    if (hist_out) HIPCHK(c, hipMemcpyAsync(hist_out, c->d_hist, 256 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = sync_stages(c);
+    if (rc) return rc;
+    rc = collect_timing(c);
+    if (rc) return rc;
+    return check_status(c);
+}
+
+int vgmi_counts_finish_device(vgmi_ctx* c, uint8_t* dev_cov, uint8_t* dev_cov_node, uint64_t* dev_hist)
+{
+    if (!c) return VGMI_E_INVALID;
+    if (!c->has_table) return fail(c, VGMI_E_STATE, "no table");
+    if (dev_cov_node && !c->d_node_key_index) return fail(c, VGMI_E_STATE, "no nodes uploaded");
+    if (dev_hist && !c->d_flag) return fail(c, VGMI_E_STATE, "no flags uploaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = finish_common(c, dev_cov ? dev_cov : c->d_cov, dev_cov_node,
+                           reinterpret_cast<unsigned long long*>(dev_hist));
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = sync_stages(c);
+    if (rc) return rc;
+    rc = collect_timing(c);
+    if (rc) return rc;
+    return check_status(c);
+}
+
+int vgmi_count_kernel_ms(vgmi_ctx* c, float* ms, uint64_t* launches)
+{
+    if (!c) return VGMI_E_INVALID;
+    int rc = collect_timing(c);
+    if (rc) return rc;
+    if (ms) *ms = c->kernel_ms;
+    if (launches) *launches = c->launches;
+    return VGMI_OK;
+}
+
+/* ---------------------------------------------------------------- K1 trace */
+
+int vgmi_sketch_keys(vgmi_ctx* c, const char* bases, size_t n_bytes, const uint64_t* read_off, size_t n_reads,
+                     uint32_t k, uint64_t* keys_out)
+{
+    if (!c) return VGMI_E_INVALID;
+    if (k < 1 || k > 28) return fail(c, VGMI_E_INVALID, "k must be in 1..28");
+    if (n_bytes == 0) return VGMI_OK;
+    if (!bases || !keys_out) return fail(c, VGMI_E_INVALID, "NULL buffer");
+    if (bases[n_bytes - 1] != '\n') return fail(c, VGMI_E_INVALID, "a read block must end with '\\n'");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint64_t> derived;
+    if (!(k & 1) && !read_off) {
+        derived = offsets_from_newlines(bases, n_bytes);
+        if (derived.size() != n_reads + 1) return fail(c, VGMI_E_INVALID, "n_reads does not match the number of '\\n'");
+        read_off = derived.data();
+    }
+    char* d_b = nullptr;
+    uint64_t* d_k = nullptr;
+    uint64_t* d_off = nullptr;
+    int rc = VGMI_OK;
+    auto cleanup = [&]() {
+        if (d_b) (void)hipFree(d_b);
+        if (d_k) (void)hipFree(d_k);
+        if (d_off) (void)hipFree(d_off);
+    };
+#define HIPCHK_CL(call) do { hipError_t ecl_ = (call); if (ecl_ != hipSuccess) { cleanup(); HIPCHK(c, ecl_); } } while (0)
+    HIPCHK_CL(hipMalloc(reinterpret_cast<void**>(&d_b), n_bytes + 16));
+    HIPCHK_CL(hipMalloc(reinterpret_cast<void**>(&d_k), n_bytes * 8));
+    HIPCHK_CL(hipMemcpyAsync(d_b, bases, n_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK_CL(hipMemsetAsync(c->d_status, 0, 4, c->stream));
+    RowParams p = row_params(c, d_b, n_bytes, k);
+    p.keys_out = d_k;
+    if (k & 1) {
+        uint32_t grid, block;
+        rows_geometry(c, false, grid, block);
+        HIPCHK_CL(launch_rows(K_MODE_KEYS, false, p, grid, block, c->stream));
+    } else {
+        HIPCHK_CL(hipMalloc(reinterpret_cast<void**>(&d_off), (n_reads + 1) * 8));
+        HIPCHK_CL(hipMemcpyAsync(d_off, read_off, (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK_CL(launch_seq(K_MODE_KEYS, p, d_off, n_reads, c->stream));
+    }
+    HIPCHK_CL(hipMemcpyAsync(keys_out, d_k, n_bytes * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK_CL(hipStreamSynchronize(c->stream));
+    rc = check_status(c);
+    cleanup();
+    return rc;
+}
+
+/* ---------------------------------------------------------------- Bloom */
+
+int vgmi_bloom_params(uint64_t n, double p, uint64_t* m, uint32_t* n_hash)
+{
+    // BloomFilter::_calculate_size / _calculate_num_hashes (src/counting_bloom_filter.cpp:70-77)
+    const uint64_t mm = (uint64_t)std::ceil(((double)n * std::log(p)) / std::log(1.0 / std::pow(2.0, std::log(2.0))));
+    if (m) *m = mm;
+    if (n_hash) *n_hash = (uint32_t)std::round((double)mm * std::log(2.0) / (double)n);
+    return VGMI_OK;
+}
+
+int vgmi_bloom_create(vgmi_ctx* c, uint64_t m, uint32_t n_hash, const uint64_t* seeds)
+{
+    if (!c || !seeds) return VGMI_E_INVALID;
+    if (m == 0 || n_hash == 0 || n_hash > VG_BLOOM_MAX_HASH) return fail(c, VGMI_E_INVALID, "bad Bloom geometry");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->bv.filter) (void)hipFree(c->bv.filter);
+    c->bv = BloomView{};
+    c->has_bloom = false;
+    c->bloom_alloc = ((m + 3) & ~3ULL) + 16;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->bv.filter), c->bloom_alloc));
+    HIPCHK(c, hipMemset(c->bv.filter, 0, c->bloom_alloc));
+    c->bv.m = m;
+    c->bv.magic = UINT64_MAX / m;
+    c->bv.n_hash = n_hash;
+    for (uint32_t i = 0; i < n_hash; ++i) c->bv.seeds[i] = (uint32_t)seeds[i];  // `unsigned int seed`
+    c->has_bloom = true;
+    return VGMI_OK;
+}
+
+int vgmi_bloom_add_seq_device(vgmi_ctx* c, const char* dev_bases, uint64_t len, uint32_t k)
+{
+    if (!c) return VGMI_E_INVALID;
+    if (!c->has_bloom) return fail(c, VGMI_E_STATE, "no Bloom filter");
+    if (k < 1 || k > 28) return fail(c, VGMI_E_INVALID, "k must be in 1..28");
+    if (len == 0) return fail(c, VGMI_E_EMPTY_READ, "empty sequence (reference: assert(len > 0), kmer.cpp:27)");
+    if (reinterpret_cast<uintptr_t>(dev_bases) & 15) return fail(c, VGMI_E_INVALID, "dev_bases must be 16-byte aligned");
+    HIPCHK(c, hipSetDevice(c->device));
+    RowParams p = row_params(c, dev_bases, len, k);
+    if (k & 1) {
+        uint32_t grid, block;
+        rows_geometry(c, false, grid, block);
+        HIPCHK(c, launch_rows(K_MODE_BLOOM, false, p, grid, block, c->stream));
+    } else {
+        uint64_t off[2] = {0, len};
+        uint64_t* d_off = nullptr;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_off), 16));
+        hipError_t e = hipMemcpy(d_off, off, 16, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = launch_seq(K_MODE_BLOOM, p, d_off, 1, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d_off);
+        HIPCHK(c, e);
+    }
+    return VGMI_OK;
+}
+
+int vgmi_bloom_add_seq(vgmi_ctx* c, const char* bases, uint64_t len, uint32_t k)
+{
+    if (!c) return VGMI_E_INVALID;
+    if (!c->has_bloom) return fail(c, VGMI_E_STATE, "no Bloom filter");
+    if (len == 0) return fail(c, VGMI_E_EMPTY_READ, "empty sequence (reference: assert(len > 0), kmer.cpp:27)");
+    if (!bases) return fail(c, VGMI_E_INVALID, "bases is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    char* d = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), len + 16));
+    hipError_t e = hipMemcpy(d, bases, len, hipMemcpyHostToDevice);
+    int rc = VGMI_OK;
+    if (e == hipSuccess) {
+        rc = vgmi_bloom_add_seq_device(c, d, len, k);
+        if (rc == VGMI_OK) e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(d);
+    if (rc) return rc;
+    HIPCHK(c, e);
+    return VGMI_OK;
+}
+
+int vgmi_bloom_fetch(vgmi_ctx* c, uint8_t* out)
+{
+    if (!c || !out) return VGMI_E_INVALID;
+    if (!c->has_bloom) return fail(c, VGMI_E_STATE, "no Bloom filter");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->bv.filter, c->bv.m, hipMemcpyDeviceToHost));
+    return VGMI_OK;
+}
+
+int vgmi_bloom_load(vgmi_ctx* c, const uint8_t* in)
+{
+    if (!c || !in) return VGMI_E_INVALID;
+    if (!c->has_bloom) return fail(c, VGMI_E_STATE, "no Bloom filter");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->bv.filter, in, c->bv.m, hipMemcpyHostToDevice));
+    return VGMI_OK;
+}
+
+int vgmi_bloom_query(vgmi_ctx* c, const uint64_t* keys, size_t n, uint8_t* min_out, uint8_t* nz_out)
+{
+    if (!c) return VGMI_E_INVALID;
+    if (!c->has_bloom) return fail(c, VGMI_E_STATE, "no Bloom filter");
+    if (n == 0) return VGMI_OK;
+    if (!keys) return fail(c, VGMI_E_INVALID, "keys is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t* d_k = nullptr;
+    uint8_t* d_o = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_k), n * 8));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_o), 2 * n);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_k, keys, n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_bloom_query(c->bv, d_k, n, d_o, d_o + n, c->stream);
+    if (e == hipSuccess && min_out) e = hipMemcpyAsync(min_out, d_o, n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && nz_out) e = hipMemcpyAsync(nz_out, d_o + n, n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_k);
+    if (d_o) (void)hipFree(d_o);
+    HIPCHK(c, e);
+    return VGMI_OK;
+}
+
+/* ---------------------------------------------------------------- tooling */
+
+int vgmi_synth_reads_device(vgmi_ctx* c, uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                            const char* dev_hap_cat, const uint64_t* hap_off, uint32_t n_hap, char* dev_out)
+{
+    if (!c || !dev_hap_cat || !hap_off || !dev_out) return VGMI_E_INVALID;
+    if (n_hap < 1 || n_hap > VG_SYNTH_MAX_HAPS) return fail(c, VGMI_E_INVALID, "1..8 haplotypes");
+    if (read_len < 1 || read_len > VGS_INSERT) return fail(c, VGMI_E_INVALID, "read_len must be in 1..350");
+    SynthHaps h{};
+    h.n = n_hap;
+    for (uint32_t i = 0; i < n_hap; ++i) {
+        h.off[i] = hap_off[i];
+        h.len[i] = hap_off[i + 1] - hap_off[i];
+        if (h.len[i] < VGS_INSERT) return fail(c, VGMI_E_INVALID, "haplotype shorter than the insert size");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, launch_synth_reads(seed, first_read, n_reads, read_len, dev_hap_cat, h, dev_out, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VGMI_OK;
+}
+
+int vgmi_synth_reads_host(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, const char* hap_cat,
+                          const uint64_t* hap_off, uint32_t n_hap, char* out)
+{
+    if (!hap_cat || !hap_off || !out || n_hap < 1 || n_hap > VG_SYNTH_MAX_HAPS) return VGMI_E_INVALID;
+    if (read_len < 1 || read_len > VGS_INSERT) return VGMI_E_INVALID;
+    const char* hp[VG_SYNTH_MAX_HAPS];
+    uint64_t hl[VG_SYNTH_MAX_HAPS];
+    for (uint32_t i = 0; i < n_hap; ++i) {
+        hp[i] = hap_cat + hap_off[i];
+        hl[i] = hap_off[i + 1] - hap_off[i];
+        if (hl[i] < VGS_INSERT) return VGMI_E_INVALID;
+    }
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        char* o = out + r * (read_len + 1);
+        for (uint32_t j = 0; j < read_len; ++j) o[j] = vgs_read_base(seed, first_read + r, j, read_len, hp, hl, n_hap);
+        o[read_len] = '\n';
+    }
+    return VGMI_OK;
+}
+
+int vgmi_synth_reference_host(uint64_t seed, uint64_t len, char* out)
+{
+    if (!out) return VGMI_E_INVALID;
+    for (uint64_t i = 0; i < len; ++i) out[i] = vgs_ref_base(seed, i);
+    return VGMI_OK;
+}
+
+}  // extern "C"

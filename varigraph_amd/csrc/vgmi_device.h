@@ -1,0 +1,133 @@
+// vgmi_device.h -- arithmetic shared by host and gfx950 device code.
+//
+// Reference semantics restated here (file:line under the reference tree):
+//   hash64                include/hash64.hpp:5-14
+//   seq_nt4_table         include/seq_nt4_table.hpp:5-22
+//   MurmurHash3_x64_128   src/MurmurHash3.cpp:255-332 (len == 8 path), summed as in
+//                         src/counting_bloom_filter.cpp:90-98
+// plus the inverse of hash64 (not in the reference): hash64 is a bijection of [0, 2^(2k)), so
+// the device table stores canonical k-mers instead of hashed keys and the read kernel never
+// evaluates hash64 -- same membership, same counters, ~40 fewer integer ops per k-mer.
+#ifndef VGMI_DEVICE_H
+#define VGMI_DEVICE_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define VG_HD __host__ __device__ static inline
+#else
+#define VG_HD static inline
+#endif
+
+#define VG_EMPTY 0xFFFFFFFFFFFFFFFFULL
+
+// One slot of the open-addressing table (16 B, one dwordx4 per probe).
+struct __attribute__((aligned(16))) VgSlot {
+    unsigned long long canon;  // canonical k-mer = hash64^-1(key >> 8), or VG_EMPTY
+    unsigned int count;        // occurrences seen this sample (clamped to 255 on read-out)
+    unsigned int key_index;    // index of the key in the uploaded keys[]
+};
+
+// include/hash64.hpp:5-14
+VG_HD uint64_t vg_hash64(uint64_t key, uint64_t mask)
+{
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+
+// multiplicative inverse of an odd a modulo 2^64 (Newton)
+VG_HD uint64_t vg_inv_odd(uint64_t a)
+{
+    uint64_t x = a;  // correct to 3 bits
+    for (int i = 0; i < 6; ++i) x *= 2 - a * x;
+    return x;
+}
+
+// inverse of vg_hash64 on [0, mask]; mask = 2^(2k)-1
+VG_HD uint64_t vg_hash64_inv(uint64_t h, uint64_t mask)
+{
+    uint64_t x;
+    // key + (key << 31) = key * (2^31 + 1)
+    h = (h * vg_inv_odd((1ULL << 31) + 1)) & mask;
+    // key ^ key >> 28
+    x = h; x = h ^ (x >> 28); x = h ^ (x >> 28); h = x;
+    // key * 21
+    h = (h * vg_inv_odd(21)) & mask;
+    // key ^ key >> 14
+    x = h; x = h ^ (x >> 14); x = h ^ (x >> 14); x = h ^ (x >> 14); x = h ^ (x >> 14); h = x;
+    // key * 265
+    h = (h * vg_inv_odd(265)) & mask;
+    // key ^ key >> 24
+    x = h; x = h ^ (x >> 24); x = h ^ (x >> 24); x = h ^ (x >> 24); h = x;
+    // ~key + (key << 21) = key * (2^21 - 1) - 1
+    h = ((h + 1) * vg_inv_odd((1ULL << 21) - 1)) & mask;
+    return h;
+}
+
+// include/seq_nt4_table.hpp:5-22 as a function (the kernels stage the table in LDS)
+VG_HD uint32_t vg_nt4(uint32_t c)
+{
+    if (c < 4) return c;
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': case 'U': case 'u': return 3;
+        default: return 4;
+    }
+}
+
+VG_HD uint64_t vg_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+VG_HD uint64_t vg_fmix64(uint64_t k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
+}
+// h1+h2 of MurmurHash3_x64_128(&key, 8, (uint32_t)seed)
+VG_HD uint64_t vg_murmur_sum(uint64_t key, uint32_t seed32)
+{
+    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    uint64_t h1 = seed32, h2 = seed32;
+    uint64_t k1 = key;
+    k1 *= c1; k1 = vg_rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    h1 ^= 8; h2 ^= 8;
+    h1 += h2; h2 += h1;
+    h1 = vg_fmix64(h1); h2 = vg_fmix64(h2);
+    h1 += h2; h2 += h1;
+    return h1 + h2;
+}
+
+// ---- hashes of the device table (not in the reference; any function works, both sides of the
+// table -- build and probe -- use these) ------------------------------------------------------
+// Filter hash: three 24-bit multiplies (full-rate v_mul_u32_u24 / v_mad_u32_u24 on CDNA).
+VG_HD uint32_t vg_mul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+// word selector: use the TOP bits
+VG_HD uint32_t vg_fhash_word(uint64_t canon)
+{
+    const uint32_t lo = (uint32_t)canon, mid = (uint32_t)(canon >> 24), hi = (uint32_t)(canon >> 48);
+    return vg_mul24(lo, 0x9E3779u) + vg_mul24(mid, 0x85EBCBu) + vg_mul24(hi, 0xC2B2AFu);
+}
+// bit selector inside the 32-bit word: two 5-bit fields taken from the top of a second product
+VG_HD uint32_t vg_fhash_bits(uint64_t canon)
+{
+    const uint32_t lo = (uint32_t)canon, mid = (uint32_t)(canon >> 24);
+    const uint32_t g = vg_mul24(lo, 0x5BD1E9u) + vg_mul24(mid, 0x27D4EBu);
+    return (1u << (g >> 27)) | (1u << ((g >> 22) & 31u));
+}
+// slot hash of the exact table (evaluated only for filter passes)
+VG_HD uint64_t vg_thash(uint64_t canon)
+{
+    uint64_t x = canon * 0x9E3779B97F4A7C15ULL;
+    return x ^ (x >> 29);
+}
+
+#endif

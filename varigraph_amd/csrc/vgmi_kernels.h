@@ -1,0 +1,62 @@
+// vgmi_kernels.h -- host-visible launch interface of vgmi_kernels.hip
+#ifndef VGMI_KERNELS_H
+#define VGMI_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vgmi_device.h"
+
+namespace vgk {
+
+enum { K_MODE_COUNT = 0, K_MODE_KEYS = 1, K_MODE_BLOOM = 2 };
+
+struct TableView {
+    VgSlot* slots;              // cap entries
+    uint64_t cap_mask;          // cap - 1 (cap is a power of two)
+    const uint32_t* filter;     // blocked-Bloom prefilter, 1 << filter_words_log2 words
+    uint32_t filter_words_log2; // >= 2
+    uint32_t filter_shift;      // 32 - filter_words_log2
+};
+
+#define VG_BLOOM_MAX_HASH 32
+struct BloomView {
+    uint8_t* filter;  // m bytes (+ padding to a multiple of 4)
+    uint64_t m;
+    uint64_t magic;   // floor((2^64-1)/m)
+    uint32_t n_hash;
+    uint32_t seeds[VG_BLOOM_MAX_HASH];  // low 32 bits of the reference's stored seeds
+};
+
+struct RowParams {
+    const uint8_t* bases;
+    uint64_t n_bytes;
+    uint32_t k;
+    uint32_t* status;     // bit0 empty read, bit1 bad key, bit2 duplicate key
+    TableView table;      // MODE_COUNT
+    uint64_t* keys_out;   // MODE_KEYS
+    BloomView bloom;      // MODE_BLOOM
+};
+
+#define VG_SYNTH_MAX_HAPS 8
+struct SynthHaps {
+    uint32_t n;
+    uint64_t off[VG_SYNTH_MAX_HAPS];
+    uint64_t len[VG_SYNTH_MAX_HAPS];
+};
+
+hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
+hipError_t launch_seq(int mode, const RowParams& p, const uint64_t* read_off, uint64_t n_reads, hipStream_t st);
+hipError_t launch_table_clear(VgSlot* slots, uint64_t cap, hipStream_t st);
+hipError_t launch_table_insert(const TableView& t, const uint64_t* keys, uint64_t n, uint32_t k, uint32_t* key_slot,
+                               uint32_t* filter_rw, uint32_t* status, hipStream_t st);
+hipError_t launch_counts_reset(VgSlot* slots, uint64_t cap, hipStream_t st);
+hipError_t launch_cov(const VgSlot* slots, const uint32_t* key_slot, uint64_t n, const uint8_t* flag, uint8_t* cov,
+                      unsigned long long* hist, hipStream_t st);
+hipError_t launch_node_gather(const uint8_t* cov, const uint32_t* key_index, uint64_t n, uint8_t* cov_node, hipStream_t st);
+hipError_t launch_bloom_query(const BloomView& b, const uint64_t* keys, uint64_t n, uint8_t* min_out, uint8_t* nz_out,
+                              hipStream_t st);
+hipError_t launch_synth_reads(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, const char* hap_cat,
+                              const SynthHaps& haps, char* out, hipStream_t st);
+
+}  // namespace vgk
+#endif

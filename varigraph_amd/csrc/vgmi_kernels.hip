@@ -1,0 +1,593 @@
+// vgmi_kernels.hip -- hand-written gfx950 kernels of the varigraph genotyping hot path.
+//
+// Reference behaviour implemented (file:line under the reference tree):
+//   K1  rolling canonical k-mer emitter            src/kmer.cpp:110-149 (and :20-53 for the Bloom driver)
+//   K2  exact table membership + saturating count  src/kmer.cpp:140-142, src/fastq_kmer.cpp:128-139
+//   K3  counting-Bloom update                      src/counting_bloom_filter.cpp:28-36,90-98
+//   K4  counting-Bloom count/find                  src/counting_bloom_filter.cpp:40-67
+//   K5  clamp + per-node depth gather              src/genotype.cpp:546,660,1405-1408 (via node iterators)
+//   K6  masked coverage histogram                  src/varigraph.cpp:253-296
+//
+// Design (DESIGN.md has the full story).  The read block is a '\n'-joined ASCII byte stream.
+// A wavefront walks contiguous 1 KiB rows of it: lane l owns the 16 bytes [16l, 16l+16) of the
+// row (one coalesced dwordx4 per lane), encodes them to 2 bits/base through an LDS-resident
+// copy of seq_nt4_table, and receives the previous 32 bases from lanes l-1 / l-2 (and from the
+// previous row for lanes 0/1) by cross-lane permutes.  From that 48-base window every lane
+// extracts its 16 forward and reverse-complement k-mers with funnel shifts -- no per-read
+// state, no halo recomputation.  For odd k a k-mer can never equal its own reverse complement,
+// so the reference's state machine reduces exactly to "emit iff the last k bases are all
+// valid" (even k takes the sequential kernel below, which restates the machine
+// literally).  The canonical k-mer is tested against a blocked Bloom prefilter held in LDS
+// (when the graph is small enough) so that the ~97 % of read k-mers that are not graph k-mers
+// never leave the CU; survivors are compacted per wavefront into an LDS queue and probed
+// 64 at a time against the exact open-addressing table, whose hits bump 32-bit counters with
+// atomicAdd (skipped once a counter has reached the 255 clamp).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vg_synth.h"
+#include "vgmi_device.h"
+#include "vgmi_kernels.h"
+
+namespace vgk {
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+    // (hi:lo) >> sh, low 32 bits; sh in [0,31]  (v_alignbit_b32)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+
+// reverse the order of the sixteen 2-bit fields of x and complement them
+__device__ __forceinline__ uint32_t rc_word(uint32_t x)
+{
+    uint32_t r = __builtin_bitreverse32(x);
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+    return ~r;
+}
+
+__device__ __forceinline__ uint64_t mod_u64(uint64_t x, uint64_t m, uint64_t magic)
+{
+    uint64_t q = __umul64hi(x, magic);
+    uint64_t r = x - q * m;
+    while (r >= m) r -= m;
+    return r;
+}
+
+// saturating byte increment: filter[pos] = min(255, filter[pos] + 1)
+// (src/counting_bloom_filter.cpp:32-34; the reference CUDA twin does the same CAS, counting_bloom_filter.cu:5-17)
+__device__ __forceinline__ void bloom_inc(uint8_t* filter, uint64_t pos)
+{
+    uint32_t* w = reinterpret_cast<uint32_t*>(filter + (pos & ~3ULL));
+    const uint32_t sh = (uint32_t)(pos & 3) * 8;
+    uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (((old >> sh) & 0xFFu) == 0xFFu) return;
+        const uint32_t prev = atomicCAS(w, old, old + (1u << sh));
+        if (prev == old) return;
+        old = prev;
+    }
+}
+
+__device__ __forceinline__ void bloom_add_key(const BloomView& b, uint64_t key)
+{
+    for (uint32_t i = 0; i < b.n_hash; ++i) {
+        const uint64_t pos = mod_u64(vg_murmur_sum(key, b.seeds[i]), b.m, b.magic);
+        bloom_inc(b.filter, pos);
+    }
+}
+
+// exact-table probe + saturating count of one canonical k-mer
+__device__ __forceinline__ void table_count(const TableView& t, uint64_t canon)
+{
+    uint64_t s = vg_thash(canon) & t.cap_mask;
+    for (;;) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&t.slots[s]);
+        const uint64_t c = ((uint64_t)v.y << 32) | v.x;
+        if (c == canon) {
+            if (v.z < 255u) atomicAdd(&t.slots[s].count, 1u);
+            return;
+        }
+        if (c == VG_EMPTY) return;
+        s = (s + 1) & t.cap_mask;
+    }
+}
+
+__device__ __forceinline__ bool filter_test_global(const TableView& t, uint64_t canon)
+{
+    const uint32_t w = t.filter[vg_fhash_word(canon) >> t.filter_shift];
+    const uint32_t m = vg_fhash_bits(canon);
+    return (w & m) == m;
+}
+
+// ------------------------------------------------------------------------------------------
+// row kernel: position-parallel emitter for ODD k, three sinks
+// ------------------------------------------------------------------------------------------
+enum { MODE_COUNT = 0, MODE_KEYS = 1, MODE_BLOOM = 2 };
+
+#define VG_QCAP 128u  // per-wave pass queue entries (power of two, >= 2*64)
+
+struct RowLds {
+    uint32_t* filter;   // FLDS only
+    uint64_t* queue;    // this wave's ring
+    const uint8_t* lut_code;
+    const uint8_t* lut_inv;
+};
+
+__device__ __forceinline__ uint4 load_chunk(const uint8_t* bases, uint64_t n_bytes, uint64_t off)
+{
+    if (off + 16 <= n_bytes) return *reinterpret_cast<const uint4*>(bases + off);
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint64_t o = off + 4 * i + b;
+            const uint32_t c = o < n_bytes ? bases[o] : (uint32_t)'\n';
+            x |= c << (8 * b);
+        }
+        w[i] = x;
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// 16 ASCII bytes -> be: base t at bits [2(15-t), +2);  inv: bit t set iff byte t is not a base
+__device__ __forceinline__ void encode16(const uint4 raw, const uint8_t* lut_code, const uint8_t* lut_inv,
+                                         uint32_t& be, uint32_t& inv)
+{
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+    be = 0;
+    inv = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t c = (w[i] >> (8 * b)) & 0xFFu;
+            const int t = 4 * i + b;
+            be |= (uint32_t)lut_code[c] << (2 * (15 - t));
+            inv |= (uint32_t)lut_inv[c] << t;
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void drain_queue(const TableView& t, uint64_t* queue, uint32_t head, uint32_t n, uint32_t lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < n) {
+        const uint64_t canon = queue[(head + lane) & (VG_QCAP - 1)];
+        table_count(t, canon);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+template <int MODE, bool FLDS>
+__global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint32_t nwaves = blockDim.x >> 6;
+
+    // ---- LDS carve: [filter][queues][lut_code][lut_inv]
+    size_t off = 0;
+    uint32_t* s_filter = reinterpret_cast<uint32_t*>(smem);
+    if (FLDS) off += (size_t)4 << p.table.filter_words_log2;
+    uint64_t* s_queue = reinterpret_cast<uint64_t*>(smem + off) + (size_t)wave * VG_QCAP;
+    if (MODE == MODE_COUNT) off += (size_t)nwaves * VG_QCAP * 8;
+    uint8_t* s_lut_code = smem + off;
+    uint8_t* s_lut_inv = s_lut_code + 256;
+
+    // stage seq_nt4_table (include/seq_nt4_table.hpp:5-22) as code / invalid-flag byte tables
+    for (uint32_t i = tid; i < 256; i += blockDim.x) {
+        const uint32_t c = vg_nt4(i);
+        s_lut_code[i] = (uint8_t)(c & 3u);
+        s_lut_inv[i] = (uint8_t)(c >> 2);
+    }
+    if (FLDS) {
+        const uint32_t nq = 1u << (p.table.filter_words_log2 - 2);  // uint4 count (>= 1: words >= 4)
+        const uint4* src = reinterpret_cast<const uint4*>(p.table.filter);
+        uint4* dst = reinterpret_cast<uint4*>(s_filter);
+        for (uint32_t i = tid; i < nq; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    // ---- this wave's contiguous row range
+    const uint64_t total_rows = (p.n_bytes + 1023) >> 10;
+    const uint64_t total_waves = (uint64_t)gridDim.x * nwaves;
+    const uint64_t rpw = (total_rows + total_waves - 1) / total_waves;
+    const uint64_t gw = (uint64_t)blockIdx.x * nwaves + wave;
+    uint64_t r0 = gw * rpw;
+    uint64_t r1 = r0 + rpw < total_rows ? r0 + rpw : total_rows;
+    if (r0 >= r1) return;
+
+    const uint32_t K = p.k;                      // odd, 1..27
+    const uint64_t mask = (1ULL << (2 * K)) - 1; // 2k-bit mask
+    const uint32_t mask_lo = (uint32_t)mask, mask_hi = (uint32_t)(mask >> 32);
+    const uint32_t rc_off = 2 * (33 - K);        // bit offset of the rc window for j = 0
+    const uint32_t src1 = (lane + 63u) & 63u, src2 = (lane + 62u) & 63u;
+
+    // carry from the row before r0 (values already rotated by 1 and 2 lanes)
+    uint32_t pr1_be = 0, pr2_be = 0, pr1_rc = ~0u, pr2_rc = ~0u, pr1_inv = 0xFFFFu, pr2_inv = 0xFFFFu;
+    if (r0 > 0) {
+        const uint4 raw = load_chunk(p.bases, p.n_bytes, ((r0 - 1) << 10) + lane * 16);
+        uint32_t be, inv;
+        encode16(raw, s_lut_code, s_lut_inv, be, inv);
+        const uint32_t rcw = rc_word(be);
+        pr1_be = __shfl(be, src1);   pr2_be = __shfl(be, src2);
+        pr1_rc = __shfl(rcw, src1);  pr2_rc = __shfl(rcw, src2);
+        pr1_inv = __shfl(inv, src1); pr2_inv = __shfl(inv, src2);
+    }
+
+    uint32_t qhead = 0, qtail = 0;  // wave-uniform ring indices (MODE_COUNT)
+
+    uint4 raw_next = load_chunk(p.bases, p.n_bytes, (r0 << 10) + lane * 16);
+    for (uint64_t r = r0; r < r1; ++r) {
+        const uint4 raw = raw_next;
+        if (r + 1 < r1) raw_next = load_chunk(p.bases, p.n_bytes, ((r + 1) << 10) + lane * 16);
+
+        uint32_t be, inv;
+        encode16(raw, s_lut_code, s_lut_inv, be, inv);
+        const uint32_t rcw = rc_word(be);
+        // neighbours: lane-1 / lane-2 of this row, or the tail of the previous row
+        const uint32_t r1_be = __shfl(be, src1), r2_be = __shfl(be, src2);
+        const uint32_t r1_rc = __shfl(rcw, src1), r2_rc = __shfl(rcw, src2);
+        const uint32_t r1_inv = __shfl(inv, src1), r2_inv = __shfl(inv, src2);
+        const uint32_t F0 = be;
+        const uint32_t F1 = lane >= 1 ? r1_be : pr1_be;
+        const uint32_t F2 = lane >= 2 ? r2_be : pr2_be;
+        const uint32_t R2 = rcw;
+        const uint32_t R1 = lane >= 1 ? r1_rc : pr1_rc;
+        const uint32_t R0 = lane >= 2 ? r2_rc : pr2_rc;
+        const uint32_t i1 = lane >= 1 ? r1_inv : pr1_inv;
+        const uint32_t i2 = lane >= 2 ? r2_inv : pr2_inv;
+        pr1_be = r1_be; pr2_be = r2_be; pr1_rc = r1_rc; pr2_rc = r2_rc; pr1_inv = r1_inv; pr2_inv = r2_inv;
+
+        // invalid-base mask of the 48-base window (bit i = window base i), smeared forward by
+        // k-1 so that bit (32+j) says "some base of the k-mer ending at own base j is invalid"
+        uint64_t sm = ((uint64_t)inv << 32) | ((uint64_t)i1 << 16) | (uint64_t)i2;
+        {
+            uint32_t span = 1;
+            while (2 * span <= K) { sm |= sm << span; span *= 2; }
+            if (span < K) sm |= sm << (K - span);
+        }
+        const uint32_t bad = (uint32_t)(sm >> 32);  // bit j
+
+        // empty-read check (reference: assert(len > 0), src/kmer.cpp:124).  Cheap necessary
+        // condition first (two adjacent non-base bytes), exact test on the raw bytes only then.
+        {
+            const uint32_t prev_bit = (i1 >> 15) & 1u;
+            const uint32_t adj = inv & ((inv << 1) | prev_bit);
+            if (__builtin_expect(__ballot(adj != 0) != 0, 0)) {
+                if (adj) {
+                    const uint64_t base_off = (r << 10) + lane * 16;
+                    for (uint32_t t = 0; t < 16; ++t) {
+                        if (!((adj >> t) & 1u)) continue;
+                        const uint64_t o = base_off + t;
+                        if (o >= p.n_bytes) continue;
+                        if (p.bases[o] == '\n' && (o == 0 || p.bases[o - 1] == '\n')) atomicOr(p.status, 1u);
+                    }
+                }
+            }
+        }
+        for (uint32_t j = 0; j < 16; ++j) {
+            // forward k-mer ending at own base j: bits [2(15-j), +2k) of F2:F1:F0
+            const uint32_t fs = 2 * (15 - j);
+            const uint32_t f_lo = funnel(F1, F0, fs) & mask_lo;
+            const uint32_t f_hi = funnel(F2, F1, fs) & mask_hi;
+            // reverse complement: bits [rc_off + 2j, +2k) of R2:R1:R0
+            const uint32_t rs = rc_off + 2 * j;
+            uint32_t r_lo, r_hi;
+            if (rs < 32) {
+                r_lo = funnel(R1, R0, rs);
+                r_hi = funnel(R2, R1, rs);
+            } else if (rs < 64) {
+                r_lo = funnel(R2, R1, rs - 32);
+                r_hi = R2 >> (rs - 32);
+            } else {
+                r_lo = R2 >> (rs - 64);
+                r_hi = 0;
+            }
+            r_lo &= mask_lo;
+            r_hi &= mask_hi;
+            const uint64_t fwd = ((uint64_t)f_hi << 32) | f_lo;
+            const uint64_t rc = ((uint64_t)r_hi << 32) | r_lo;
+            const uint64_t canon = fwd < rc ? fwd : rc;
+            const bool valid = ((bad >> j) & 1u) == 0;
+
+            if (MODE == MODE_KEYS) {
+                const uint64_t pos = (r << 10) + lane * 16 + j;
+                if (pos < p.n_bytes) p.keys_out[pos] = valid ? (vg_hash64(canon, mask) << 8 | K) : ~0ULL;
+            } else if (MODE == MODE_BLOOM) {
+                const uint64_t pos = (r << 10) + lane * 16 + j;
+                if (valid && pos < p.n_bytes) bloom_add_key(p.bloom, vg_hash64(canon, mask) << 8 | K);
+            } else {
+                bool pass;
+                if (FLDS) {
+                    const uint32_t w = s_filter[vg_fhash_word(canon) >> p.table.filter_shift];
+                    const uint32_t m = vg_fhash_bits(canon);
+                    pass = valid && ((w & m) == m);
+                } else {
+                    pass = valid && filter_test_global(p.table, canon);
+                }
+                const uint64_t ball = __ballot(pass);
+                if (ball) {
+                    if (pass) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
+                                              __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
+                        s_queue[(qtail + rank) & (VG_QCAP - 1)] = canon;
+                    }
+                    qtail += (uint32_t)__popcll(ball);
+                    if (qtail - qhead >= 64u) {
+                        drain_queue<MODE>(p.table, s_queue, qhead, 64u, lane);
+                        qhead += 64u;
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == MODE_COUNT) {
+        if (qtail != qhead) drain_queue<MODE>(p.table, s_queue, qhead, qtail - qhead, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// sequential kernel: literal restatement of the reference state machine, any k in 1..28.
+// One lane per read (read r = bytes [off[r], off[r+1]-1), followed by its '\n'); used for even
+// k, where palindromic k-mers and stale registers make emission history-dependent
+// (src/kmer.cpp:134 `continue` before ++l; :145 only l is reset).
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void seq_kernel(RowParams p, const uint64_t* read_off, uint64_t n_reads)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint64_t s = read_off[r];
+    const uint64_t e = read_off[r + 1] - (MODE == MODE_BLOOM ? 0 : 1);  // reads end with '\n'; a Bloom sequence does not
+    if (e <= s) {
+        atomicOr(p.status, 1u);
+        return;
+    }
+    const uint32_t K = p.k;
+    const uint64_t mask = (1ULL << (2 * K)) - 1, shift1 = 2 * (uint64_t)(K - 1);
+    uint64_t fwd = 0, rc = 0;
+    uint32_t l = 0;
+    for (uint64_t i = s; i < e; ++i) {
+        const uint32_t c = vg_nt4(p.bases[i]);
+        uint64_t out = ~0ULL;
+        if (c < 4) {
+            fwd = (fwd << 2 | c) & mask;
+            rc = (rc >> 2) | (uint64_t)(3u ^ c) << shift1;
+            if (fwd != rc) {
+                ++l;
+                if (l >= K) {
+                    const uint64_t canon = fwd < rc ? fwd : rc;
+                    if (MODE == MODE_COUNT) {
+                        if (filter_test_global(p.table, canon)) table_count(p.table, canon);
+                    } else if (MODE == MODE_BLOOM) {
+                        bloom_add_key(p.bloom, vg_hash64(canon, mask) << 8 | K);
+                    } else {
+                        out = vg_hash64(canon, mask) << 8 | K;
+                    }
+                }
+            }
+        } else {
+            l = 0;
+        }
+        if (MODE == MODE_KEYS) p.keys_out[i] = out;
+    }
+    if (MODE == MODE_KEYS) p.keys_out[e] = ~0ULL;  // the separator position
+}
+
+// ------------------------------------------------------------------------------------------
+// table build (once per graph) and per-sample reset / read-out
+// ------------------------------------------------------------------------------------------
+__global__ void table_clear_kernel(VgSlot* slots, uint64_t cap)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) {
+        uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu);
+        *reinterpret_cast<uint4*>(&slots[i]) = v;
+    }
+}
+
+__global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t n, uint32_t k,
+                                    uint32_t* key_slot, uint32_t* filter_rw, uint32_t* status)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = keys[i];
+    const uint64_t mask = (1ULL << (2 * k)) - 1;
+    if ((key & 0xFFu) != k || (key >> 8) > mask) {
+        atomicOr(status, 2u);
+        return;
+    }
+    const uint64_t canon = vg_hash64_inv(key >> 8, mask);
+    uint64_t s = vg_thash(canon) & t.cap_mask;
+    for (;;) {
+        unsigned long long* cell = &t.slots[s].canon;
+        const unsigned long long prev = atomicCAS(cell, (unsigned long long)VG_EMPTY, (unsigned long long)canon);
+        if (prev == VG_EMPTY) break;
+        if (prev == canon) {
+            atomicOr(status, 4u);  // duplicate key
+            return;
+        }
+        s = (s + 1) & t.cap_mask;
+    }
+    t.slots[s].key_index = (uint32_t)i;
+    key_slot[i] = (uint32_t)s;
+    atomicOr(&filter_rw[vg_fhash_word(canon) >> t.filter_shift], vg_fhash_bits(canon));
+}
+
+__global__ void counts_reset_kernel(VgSlot* slots, uint64_t cap)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) slots[i].count = 0;
+}
+
+// K5 part 1 + K6: cov[i] = min(255, count(key i)); hist[c] += 1 for flagged keys with c != 0
+__global__ void cov_kernel(const VgSlot* slots, const uint32_t* key_slot, uint64_t n, const uint8_t* flag,
+                           uint8_t* cov, unsigned long long* hist)
+{
+    __shared__ unsigned int s_hist[256];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t c32 = slots[key_slot[i]].count;
+        const uint32_t c = c32 < 255u ? c32 : 255u;
+        cov[i] = (uint8_t)c;
+        if (hist && c != 0 && flag && flag[i]) atomicAdd(&s_hist[c], 1u);
+    }
+    __syncthreads();
+    if (hist)
+        for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x)
+            if (s_hist[i]) atomicAdd(&hist[i], (unsigned long long)s_hist[i]);
+}
+
+// K5 part 2: per-node depth gather in CSR order
+__global__ void node_gather_kernel(const uint8_t* cov, const uint32_t* key_index, uint64_t n, uint8_t* cov_node)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        cov_node[i] = cov[key_index[i]];
+}
+
+// K4: BloomFilter::count (min) and ::find (all non-zero) for a batch of keys
+__global__ void bloom_query_kernel(BloomView b, const uint64_t* keys, uint64_t n, uint8_t* min_out, uint8_t* nz_out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t mn = 255, nz = 1;
+    for (uint32_t h = 0; h < b.n_hash; ++h) {
+        const uint32_t v = b.filter[mod_u64(vg_murmur_sum(keys[i], b.seeds[h]), b.m, b.magic)];
+        mn = v < mn ? v : mn;
+        nz &= v != 0;
+    }
+    if (min_out) min_out[i] = (uint8_t)mn;
+    if (nz_out) nz_out[i] = (uint8_t)nz;
+}
+
+// bench/test tooling: seeded synthetic read block (vg_synth.h)
+__global__ void synth_reads_kernel(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                                   const char* hap_cat, SynthHaps haps, char* out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t total = n_reads * (read_len + 1);
+    const char* hp[VG_SYNTH_MAX_HAPS];
+    for (uint32_t h = 0; h < haps.n; ++h) hp[h] = hap_cat + haps.off[h];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const uint64_t r = i / (read_len + 1);
+        const uint32_t j = (uint32_t)(i - r * (read_len + 1));
+        out[i] = j == read_len ? '\n' : vgs_read_base(seed, first_read + r, j, read_len, hp, haps.len, haps.n);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers (called from vgmi_api.cpp through vgmi_kernels.h)
+// ------------------------------------------------------------------------------------------
+static size_t rows_lds_bytes(int mode, bool flds, uint32_t filter_words_log2, uint32_t block)
+{
+    size_t b = 512;
+    if (flds) b += (size_t)4 << filter_words_log2;
+    if (mode == MODE_COUNT) b += (size_t)(block / 64) * VG_QCAP * 8;
+    return b;
+}
+
+template <int MODE, bool FLDS>
+static hipError_t launch_rows_t(const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)
+{
+    const size_t lds = rows_lds_bytes(MODE, FLDS, p.table.filter_words_log2, block);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_kernel<MODE, FLDS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((rows_kernel<MODE, FLDS>), dim3(grid), dim3(block), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)
+{
+    if (mode == MODE_COUNT) return flds ? launch_rows_t<MODE_COUNT, true>(p, grid, block, st)
+                                        : launch_rows_t<MODE_COUNT, false>(p, grid, block, st);
+    if (mode == MODE_KEYS) return launch_rows_t<MODE_KEYS, false>(p, grid, block, st);
+    return launch_rows_t<MODE_BLOOM, false>(p, grid, block, st);
+}
+
+hipError_t launch_seq(int mode, const RowParams& p, const uint64_t* read_off, uint64_t n_reads, hipStream_t st)
+{
+    const uint32_t block = 256;
+    const uint32_t grid = (uint32_t)((n_reads + block - 1) / block);
+    if (grid == 0) return hipSuccess;
+    if (mode == MODE_COUNT) hipLaunchKernelGGL((seq_kernel<MODE_COUNT>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
+    else if (mode == MODE_KEYS) hipLaunchKernelGGL((seq_kernel<MODE_KEYS>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
+    else hipLaunchKernelGGL((seq_kernel<MODE_BLOOM>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
+    return hipGetLastError();
+}
+
+static uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap)
+{
+    uint64_t g = (n + block - 1) / block;
+    if (g == 0) g = 1;
+    return (uint32_t)(g < cap ? g : cap);
+}
+
+hipError_t launch_table_clear(VgSlot* slots, uint64_t cap, hipStream_t st)
+{
+    hipLaunchKernelGGL(table_clear_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, slots, cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_table_insert(const TableView& t, const uint64_t* keys, uint64_t n, uint32_t k, uint32_t* key_slot,
+                               uint32_t* filter_rw, uint32_t* status, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(table_insert_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, t, keys, n, k, key_slot,
+                       filter_rw, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_counts_reset(VgSlot* slots, uint64_t cap, hipStream_t st)
+{
+    hipLaunchKernelGGL(counts_reset_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, slots, cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_cov(const VgSlot* slots, const uint32_t* key_slot, uint64_t n, const uint8_t* flag, uint8_t* cov,
+                      unsigned long long* hist, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(cov_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, slots, key_slot, n, flag, cov, hist);
+    return hipGetLastError();
+}
+
+hipError_t launch_node_gather(const uint8_t* cov, const uint32_t* key_index, uint64_t n, uint8_t* cov_node, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(node_gather_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, cov, key_index, n, cov_node);
+    return hipGetLastError();
+}
+
+hipError_t launch_bloom_query(const BloomView& b, const uint64_t* keys, uint64_t n, uint8_t* min_out, uint8_t* nz_out,
+                              hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(bloom_query_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, b, keys, n, min_out, nz_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_reads(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, const char* hap_cat,
+                              const SynthHaps& haps, char* out, hipStream_t st)
+{
+    if (n_reads == 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_reads_kernel, dim3(grid_for(n_reads * (read_len + 1), 256, 8192)), dim3(256), 0, st, seed,
+                       first_read, n_reads, read_len, hap_cat, haps, out);
+    return hipGetLastError();
+}
+
+}  // namespace vgk

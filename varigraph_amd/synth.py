@@ -1,0 +1,117 @@
+"""Seeded synthetic cohorts for tests and bench.
+
+The reference ships no data, so every workload is generated: an iid
+uniform reference (native mixer, vg_synth.h), uniformly placed variants, phased VCF samples
+whose first sample is heterozygous everywhere, and reads drawn from that sample's haplotypes
+by the native generator (vgmi_synth_reads_host / _device).
+"""
+import gzip
+import os
+
+import numpy as np
+
+from . import vgmi
+
+REF_SEED = 20241022
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_CODE = np.full(256, 4, dtype=np.uint8)
+for _i, _c in enumerate(b"ACGT"):
+    _CODE[_c] = _i
+
+
+def make_reference(length, seed=REF_SEED):
+    return vgmi.synth_reference(seed, length)
+
+
+def make_cohort(ref, n_variants, n_samples=7, ploidy=2, seed=1, indel_frac=0.0, sv_frac=0.0, margin=100):
+    """Returns (variants, gts): variants = list of (pos0, ref_allele bytes, alt_allele bytes) sorted,
+    non-overlapping; gts = uint8 [n_variants, n_samples*ploidy] allele index (0/1) per haplotype.
+    Sample 0 carries 0 on its first ploidy/2 haplotypes and 1 on the rest (all-het)."""
+    rng = np.random.default_rng(seed)
+    L = len(ref)
+    # spaced positions so that variants (incl. deletions up to 20 bp) never overlap
+    min_gap = 32
+    slots = (L - 2 * margin) // min_gap
+    assert n_variants <= slots, "too many variants for this reference"
+    chosen = np.sort(rng.choice(slots, size=n_variants, replace=False))
+    pos = margin + chosen * min_gap + rng.integers(0, min_gap - 24, size=n_variants)
+    kind = rng.random(n_variants)
+    variants = []
+    for p, u in zip(pos.tolist(), kind.tolist()):
+        rc = int(_CODE[ref[p]])
+        if u < sv_frac:  # long insertion 60..300 bp
+            n = int(rng.integers(60, 301))
+            ins = _ACGT[rng.integers(0, 4, size=n)].tobytes()
+            variants.append((p, bytes([ref[p]]), bytes([ref[p]]) + ins))
+        elif u < sv_frac + indel_frac:
+            n = int(rng.integers(1, 21))
+            if rng.random() < 0.5:  # insertion
+                ins = _ACGT[rng.integers(0, 4, size=n)].tobytes()
+                variants.append((p, bytes([ref[p]]), bytes([ref[p]]) + ins))
+            else:  # deletion
+                variants.append((p, ref[p:p + 1 + n].tobytes(), bytes([ref[p]])))
+        else:  # SNP
+            alt = int(_ACGT[(rc + int(rng.integers(1, 4))) % 4])
+            variants.append((p, bytes([ref[p]]), bytes([alt])))
+    gts = rng.integers(0, 2, size=(n_variants, n_samples * ploidy)).astype(np.uint8)
+    gts[:, : ploidy // 2 if ploidy > 1 else 0] = 0
+    gts[:, max(ploidy // 2, 0):ploidy] = 1
+    if ploidy == 1:
+        gts[:, 0] = 1
+    return variants, gts
+
+
+def haplotype(ref, variants, gts, hap_col):
+    """Apply the ALT alleles carried by haplotype column `hap_col`."""
+    out = []
+    prev = 0
+    for (p, ra, aa), g in zip(variants, gts[:, hap_col]):
+        if g:
+            out.append(ref[prev:p])
+            out.append(np.frombuffer(aa, dtype=np.uint8))
+            prev = p + len(ra)
+    out.append(ref[prev:])
+    return np.ascontiguousarray(np.concatenate(out))
+
+
+def write_fasta(path, chrom, ref, width=60):
+    with open(path, "wb") as f:
+        f.write(b">" + chrom.encode() + b"\n")
+        b = ref.tobytes()
+        for i in range(0, len(b), width):
+            f.write(b[i:i + width] + b"\n")
+
+
+def write_vcf(path, chrom, ref_len, variants, gts, n_samples, ploidy):
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "wt") as f:
+        f.write("##fileformat=VCFv4.2\n")
+        f.write(f"##contig=<ID={chrom},length={ref_len}>\n")
+        f.write('##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n')
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" +
+                "\t".join(f"S{i}" for i in range(n_samples)) + "\n")
+        for vi, (p, ra, aa) in enumerate(variants):
+            cols = ["|".join(str(int(x)) for x in gts[vi, s * ploidy:(s + 1) * ploidy]) for s in range(n_samples)]
+            f.write(f"{chrom}\t{p + 1}\tv{vi}\t{ra.decode()}\t{aa.decode()}\t.\tPASS\t.\tGT\t" + "\t".join(cols) + "\n")
+
+
+def write_fastq_pair(prefix, block, n_reads, read_len, gz=False):
+    """Split an interleaved '\\n'-joined read block (read 2p = mate 1, 2p+1 = mate 2) into two FASTQ files."""
+    rec = block.reshape(n_reads, read_len + 1)[:, :read_len]
+    qual = b"I" * read_len
+    paths = []
+    for mate in (0, 1):
+        path = f"{prefix}_{mate + 1}.fq" + (".gz" if gz else "")
+        opener = gzip.open if gz else open
+        with opener(path, "wb") as f:
+            rows = rec[mate::2]
+            buf = bytearray()
+            for i, r in enumerate(rows):
+                buf += b"@r%d/%d\n" % (i, mate + 1) + r.tobytes() + b"\n+\n" + qual + b"\n"
+            f.write(bytes(buf))
+        paths.append(path)
+    return paths
+
+
+def sample_haplotypes(ref, variants, gts, sample=0, ploidy=2):
+    return [haplotype(ref, variants, gts, sample * ploidy + h) for h in range(ploidy)]

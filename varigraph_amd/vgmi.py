@@ -1,0 +1,263 @@
+"""ctypes binding of include/vgmi.h (libvgmi.so).  No fallback: a missing library raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvgmi.so")
+
+OK = 0
+E_INVALID, E_NO_DEVICE, E_HIP, E_STATE, E_DUPLICATE_KEY, E_BAD_KEY, E_EMPTY_READ, E_NOMEM = range(-1, -9, -1)
+
+
+class VgmiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"vgmi error {code}: {msg}")
+        self.code = code
+
+
+def load_library():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m varigraph_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, u32, sz, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int
+    sig = {
+        "vgmi_device_count": (i32, []),
+        "vgmi_create": (i32, [i32, sz, C.POINTER(vp)]),
+        "vgmi_destroy": (None, [vp]),
+        "vgmi_last_error": (C.c_char_p, [vp]),
+        "vgmi_stream": (vp, [vp]),
+        "vgmi_table_upload": (i32, [vp, vp, sz, u32]),
+        "vgmi_table_image_bytes": (i32, [vp, C.POINTER(sz)]),
+        "vgmi_table_export": (i32, [vp, vp, sz]),
+        "vgmi_table_import": (i32, [vp, vp, sz]),
+        "vgmi_table_info": (i32, [vp, C.POINTER(sz), C.POINTER(u32), C.POINTER(sz), C.POINTER(sz)]),
+        "vgmi_nodes_upload": (i32, [vp, vp, vp, sz]),
+        "vgmi_flags_upload": (i32, [vp, vp]),
+        "vgmi_counts_reset": (i32, [vp]),
+        "vgmi_reads_submit": (i32, [vp, vp, sz, vp, sz]),
+        "vgmi_reads_submit_device": (i32, [vp, vp, sz, vp, sz]),
+        "vgmi_read_base": (i32, [vp, C.POINTER(u64)]),
+        "vgmi_counts_finish": (i32, [vp, vp, vp, vp]),
+        "vgmi_counts_finish_device": (i32, [vp, vp, vp, vp]),
+        "vgmi_count_kernel_ms": (i32, [vp, C.POINTER(C.c_float), C.POINTER(u64)]),
+        "vgmi_sketch_keys": (i32, [vp, vp, sz, vp, sz, u32, vp]),
+        "vgmi_bloom_params": (i32, [u64, C.c_double, C.POINTER(u64), C.POINTER(u32)]),
+        "vgmi_bloom_create": (i32, [vp, u64, u32, vp]),
+        "vgmi_bloom_add_seq": (i32, [vp, vp, u64, u32]),
+        "vgmi_bloom_add_seq_device": (i32, [vp, vp, u64, u32]),
+        "vgmi_bloom_fetch": (i32, [vp, vp]),
+        "vgmi_bloom_load": (i32, [vp, vp]),
+        "vgmi_bloom_query": (i32, [vp, vp, sz, vp, vp]),
+        "vgmi_synth_reads_device": (i32, [vp, u64, u64, u64, u32, vp, vp, u32, vp]),
+        "vgmi_synth_reads_host": (i32, [u64, u64, u64, u32, vp, vp, u32, vp]),
+        "vgmi_synth_reference_host": (i32, [u64, u64, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sorted(sig)
+
+
+_lib = None
+SYMBOLS = None
+
+
+def lib():
+    global _lib, SYMBOLS
+    if _lib is None:
+        _lib, SYMBOLS = load_library()
+    return _lib
+
+
+def _ptr(a):
+    """numpy array / torch tensor / int / None -> void*"""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return C.c_void_p(a.ctypes.data)
+    if isinstance(a, (bytes, bytearray)):
+        return C.cast(C.c_char_p(bytes(a)), C.c_void_p)
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    raise TypeError(type(a))
+
+
+def bloom_params(n, p):
+    m, nh = C.c_uint64(), C.c_uint32()
+    lib().vgmi_bloom_params(n, p, C.byref(m), C.byref(nh))
+    return m.value, nh.value
+
+
+def synth_reference(seed, length):
+    out = np.empty(length, dtype=np.uint8)
+    rc = lib().vgmi_synth_reference_host(seed, length, _ptr(out))
+    if rc:
+        raise VgmiError(rc, "synth_reference")
+    return out
+
+
+def synth_reads_host(seed, first_read, n_reads, read_len, haps):
+    """haps: list of uint8 arrays (ASCII haplotypes). Returns the '\\n'-joined read block (uint8)."""
+    cat = np.ascontiguousarray(np.concatenate(haps))
+    off = np.zeros(len(haps) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(h) for h in haps])
+    out = np.empty(n_reads * (read_len + 1), dtype=np.uint8)
+    rc = lib().vgmi_synth_reads_host(seed, first_read, n_reads, read_len, _ptr(cat), _ptr(off), len(haps), _ptr(out))
+    if rc:
+        raise VgmiError(rc, "synth_reads_host")
+    return out
+
+
+class Context:
+    """One vgmi context (one GPU)."""
+
+    def __init__(self, device=0, buffer_mib=100):
+        self._l = lib()
+        h = C.c_void_p()
+        rc = self._l.vgmi_create(device, buffer_mib, C.byref(h))
+        if rc:
+            raise VgmiError(rc, (self._l.vgmi_last_error(None) or b"").decode())
+        self._h = h
+        self.n_keys = 0
+        self.n_node_entries = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.vgmi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise VgmiError(rc, (self._l.vgmi_last_error(self._h) or b"").decode())
+
+    @property
+    def stream(self):
+        return self._l.vgmi_stream(self._h)
+
+    # ---- table
+    def table_upload(self, keys, k):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        self._chk(self._l.vgmi_table_upload(self._h, _ptr(keys), keys.size, k))
+        self.n_keys = keys.size
+        self.n_node_entries = 0
+
+    def table_image_bytes(self):
+        n = C.c_size_t()
+        self._chk(self._l.vgmi_table_image_bytes(self._h, C.byref(n)))
+        return n.value
+
+    def table_export(self, dev_tensor):
+        self._chk(self._l.vgmi_table_export(self._h, _ptr(dev_tensor), dev_tensor.numel()))
+
+    def table_import(self, dev_tensor):
+        self._chk(self._l.vgmi_table_import(self._h, _ptr(dev_tensor), dev_tensor.numel()))
+        self.n_keys = self.table_info()["n_keys"]
+        self.n_node_entries = 0
+
+    def table_info(self):
+        n, k, s, f = C.c_size_t(), C.c_uint32(), C.c_size_t(), C.c_size_t()
+        self._chk(self._l.vgmi_table_info(self._h, C.byref(n), C.byref(k), C.byref(s), C.byref(f)))
+        return {"n_keys": n.value, "k": k.value, "n_slots": s.value, "filter_bits": f.value}
+
+    def nodes_upload(self, node_off, key_index):
+        node_off = np.ascontiguousarray(node_off, dtype=np.uint64)
+        key_index = np.ascontiguousarray(key_index, dtype=np.uint32)
+        self._chk(self._l.vgmi_nodes_upload(self._h, _ptr(node_off), _ptr(key_index), node_off.size - 1))
+        self.n_node_entries = int(node_off[-1])
+
+    def flags_upload(self, flags):
+        flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        assert flags.size == self.n_keys
+        self._chk(self._l.vgmi_flags_upload(self._h, _ptr(flags)))
+
+    # ---- per sample
+    def counts_reset(self):
+        self._chk(self._l.vgmi_counts_reset(self._h))
+
+    def reads_submit(self, block, n_reads, read_off=None):
+        block = np.ascontiguousarray(block, dtype=np.uint8)
+        if read_off is not None:
+            read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        self._chk(self._l.vgmi_reads_submit(self._h, _ptr(block), block.size, _ptr(read_off), n_reads))
+
+    def reads_submit_device(self, dev_block, n_bytes, n_reads, dev_read_off=None):
+        self._chk(self._l.vgmi_reads_submit_device(self._h, _ptr(dev_block), n_bytes, _ptr(dev_read_off), n_reads))
+
+    def read_base(self):
+        v = C.c_uint64()
+        self._chk(self._l.vgmi_read_base(self._h, C.byref(v)))
+        return v.value
+
+    def counts_finish(self, nodes=False, hist=False):
+        cov = np.empty(self.n_keys, dtype=np.uint8)
+        cov_node = np.empty(self.n_node_entries, dtype=np.uint8) if nodes else None
+        h = np.zeros(256, dtype=np.uint64) if hist else None
+        self._chk(self._l.vgmi_counts_finish(self._h, _ptr(cov), _ptr(cov_node), _ptr(h)))
+        return cov, cov_node, h
+
+    def counts_finish_device(self, dev_cov=None, dev_cov_node=None, dev_hist=None):
+        self._chk(self._l.vgmi_counts_finish_device(self._h, _ptr(dev_cov), _ptr(dev_cov_node), _ptr(dev_hist)))
+
+    def count_kernel_ms(self):
+        ms, n = C.c_float(), C.c_uint64()
+        self._chk(self._l.vgmi_count_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def sketch_keys(self, block, n_reads, k, read_off=None):
+        block = np.ascontiguousarray(block, dtype=np.uint8)
+        if read_off is not None:
+            read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        out = np.empty(block.size, dtype=np.uint64)
+        self._chk(self._l.vgmi_sketch_keys(self._h, _ptr(block), block.size, _ptr(read_off), n_reads, k, _ptr(out)))
+        return out
+
+    # ---- bloom
+    def bloom_create(self, m, n_hash, seeds):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert seeds.size == n_hash
+        self._chk(self._l.vgmi_bloom_create(self._h, m, n_hash, _ptr(seeds)))
+        self._bloom_m = m
+
+    def bloom_add_seq(self, seq, k):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        self._chk(self._l.vgmi_bloom_add_seq(self._h, _ptr(seq), seq.size, k))
+
+    def bloom_add_seq_device(self, dev_seq, length, k):
+        self._chk(self._l.vgmi_bloom_add_seq_device(self._h, _ptr(dev_seq), length, k))
+
+    def bloom_fetch(self):
+        out = np.empty(self._bloom_m, dtype=np.uint8)
+        self._chk(self._l.vgmi_bloom_fetch(self._h, _ptr(out)))
+        return out
+
+    def bloom_load(self, filt):
+        filt = np.ascontiguousarray(filt, dtype=np.uint8)
+        assert filt.size == self._bloom_m
+        self._chk(self._l.vgmi_bloom_load(self._h, _ptr(filt)))
+
+    def bloom_query(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        mn = np.empty(keys.size, dtype=np.uint8)
+        nz = np.empty(keys.size, dtype=np.uint8)
+        self._chk(self._l.vgmi_bloom_query(self._h, _ptr(keys), keys.size, _ptr(mn), _ptr(nz)))
+        return mn, nz
+
+    # ---- tooling
+    def synth_reads_device(self, seed, first_read, n_reads, read_len, dev_hap_cat, hap_off, dev_out):
+        hap_off = np.ascontiguousarray(hap_off, dtype=np.uint64)
+        self._chk(self._l.vgmi_synth_reads_device(self._h, seed, first_read, n_reads, read_len, _ptr(dev_hap_cat),
+                                                  _ptr(hap_off), hap_off.size - 1, _ptr(dev_out)))
