@@ -1,0 +1,382 @@
+"""GPU parity tests (-m gpu): the HIP path through the C ABI (include/vgmi.h) against
+ (a) the golden vectors dumped from the real reference and (b) the oracle on seeded inputs.
+Bit-exact: everything on this path is integer work."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as o
+from conftest import GOLDEN, block_from_seqs, get_cohort
+from varigraph_amd import vgmi
+
+pytestmark = pytest.mark.gpu
+
+KATS = json.load(open(os.path.join(GOLDEN, "kats.json")))
+BLOOM = json.load(open(os.path.join(GOLDEN, "bloom.json")))
+NOKEY = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = vgmi.Context(0, buffer_mib=64)
+    yield c
+    c.close()
+
+
+# ----------------------------------------------------------------------------- K1 emitter
+@pytest.mark.parametrize("case", KATS["sketch"], ids=lambda c: f"k{c['k']}")
+def test_sketch_keys_match_reference_traces(ctx, case):
+    """Ordered key list per read == reference kmer_sketch_fastq trace (odd k: row kernel, even k:
+    sequential kernel), including lower case, U, N, raw 0..3 bytes, short reads, palindromes."""
+    k = case["k"]
+    seqs = [bytes.fromhex(t["seq_hex"]) for t in case["traces"]]
+    block = block_from_seqs(seqs)
+    keys = ctx.sketch_keys(block, len(seqs), k)
+    start = 0
+    for s, t in zip(seqs, case["traces"]):
+        got = keys[start:start + len(s)]
+        got = got[got != NOKEY]
+        want = np.array([int(x, 16) for x in t["keys"]], dtype=np.uint64)
+        assert np.array_equal(got, want), (k, s)
+        assert keys[start + len(s)] == NOKEY
+        start += len(s) + 1
+
+
+@pytest.mark.parametrize("k", [1, 3, 5, 11, 21, 25, 27])
+def test_sketch_keys_positions_random_block(ctx, k):
+    """Per-position keys on a ragged random block spanning many 1 KiB rows and wave ranges."""
+    rng = np.random.default_rng(k)
+    alphabet = np.frombuffer(b"ACGTACGTACGTACGTACGTACGTacgtNnU", dtype=np.uint8)
+    seqs = [alphabet[rng.integers(0, alphabet.size, size=int(n))].tobytes()
+            for n in rng.integers(1, 400, size=600)]
+    block = block_from_seqs(seqs)
+    got = ctx.sketch_keys(block, len(seqs), k)
+    want = o.sketch_block_positions(block, k)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("k", [2, 6, 22, 28])
+def test_sketch_keys_even_k_random_block(ctx, k):
+    rng = np.random.default_rng(100 + k)
+    alphabet = np.frombuffer(b"ACGTACGTACGTNacgt", dtype=np.uint8)
+    seqs = [alphabet[rng.integers(0, alphabet.size, size=int(n))].tobytes()
+            for n in rng.integers(1, 300, size=200)]
+    block = block_from_seqs(seqs)
+    got = ctx.sketch_keys(block, len(seqs), k)
+    want = o.sketch_block_positions(block, k)
+    assert np.array_equal(got, want)
+
+
+# ----------------------------------------------------------------------------- K1+K2 counting
+def _upload(ctx, cohort, nodes=False, flags=False):
+    g = cohort.graph
+    ctx.table_upload(g.keys, cohort.k)
+    if nodes:
+        order = np.argsort(g.keys)
+        off = [0]
+        idx = []
+        for name, start, kh in cohort.ref_nodes:
+            pos = order[np.searchsorted(g.keys[order], kh)]
+            assert np.array_equal(g.keys[pos], kh)
+            idx.append(pos)
+            off.append(off[-1] + len(kh))
+        ctx.nodes_upload(np.array(off, dtype=np.uint64),
+                         np.concatenate(idx).astype(np.uint32) if idx else np.zeros(0, np.uint32))
+    if flags:
+        ctx.flags_upload(_hom_flags(g))
+
+
+def _hom_flags(g):
+    """sample-independent predicate of Varigraph::get_hom_kmer (src/varigraph.cpp:263-287)"""
+    n = g.keys.size
+    flag = np.zeros(n, dtype=np.uint8)
+    bits = np.unpackbits(g.bitvec.view(np.uint8), axis=1, bitorder="little")
+    p = g.vcf_ploidy
+    for s in range((g.hap_num - 1) // p):
+        cols = [1 + s * p + h for h in range(p)]
+        flag |= bits[:, cols].all(axis=1).astype(np.uint8)
+    flag &= (g.f <= 1).astype(np.uint8)
+    return flag
+
+
+def test_cohort_counts_match_reference(ctx, cohort):
+    """c[] after the HIP path == c[] dumped from the reference FastqKmer::build_fastq_index."""
+    _upload(ctx, cohort, nodes=True, flags=True)
+    ctx.counts_reset()
+    block = cohort.block()
+    ctx.reads_submit(block, cohort.n_reads)
+    cov, cov_node, hist = ctx.counts_finish(nodes=True, hist=True)
+    want = cohort.ref_c_in_graph_order()
+    assert np.array_equal(cov, want)
+    assert ctx.read_base() == cohort.ref_read_base
+    # per-node depth gather in the reference's node/k-mer order
+    order = np.argsort(cohort.graph.keys)
+    exp = []
+    for _, _, kh in cohort.ref_nodes:
+        exp.append(want[order[np.searchsorted(cohort.graph.keys[order], kh)]])
+    exp = np.concatenate(exp) if exp else np.zeros(0, np.uint8)
+    assert np.array_equal(cov_node, exp)
+    assert hist.tolist() == cohort.meta["hist"]
+    ms, launches = ctx.count_kernel_ms()
+    assert launches >= 1 and ms > 0
+
+
+def test_counts_chunked_host_submit_and_device_submit(cohort):
+    """Small staging buffer (block is cut at read boundaries, two streams) and the device-resident
+    entry point give the same counters."""
+    import torch
+    want = cohort.ref_c_in_graph_order()
+    block = cohort.block()
+    c = vgmi.Context(0, buffer_mib=1)
+    try:
+        c.table_upload(cohort.graph.keys, cohort.k)
+        c.counts_reset()
+        c.reads_submit(block, cohort.n_reads)
+        cov, _, _ = c.counts_finish()
+        assert np.array_equal(cov, want)
+        # device-resident block (+ offsets for even k)
+        c.counts_reset()
+        d_block = torch.from_numpy(block).cuda()
+        d_off = None
+        if cohort.k % 2 == 0:
+            nl = np.flatnonzero(block == 10)
+            off = np.concatenate([[0], nl + 1]).astype(np.uint64)
+            d_off = torch.from_numpy(off.view(np.int64)).cuda()
+        c.reads_submit_device(d_block, block.size, cohort.n_reads, d_off)
+        cov2, _, _ = c.counts_finish()
+        assert np.array_equal(cov2, want)
+        assert c.read_base() == cohort.ref_read_base
+    finally:
+        c.close()
+
+
+def test_counts_reset_split_and_saturation(ctx):
+    """reset zeroes; split submission == single submission; repeated blocks saturate at 255."""
+    cohort = get_cohort("cohort_snp")
+    _upload(ctx, cohort)
+    block = cohort.block()
+    want = cohort.ref_c_in_graph_order().astype(np.int64)
+    nl = np.flatnonzero(block == 10)
+    cut = int(nl[len(nl) // 3]) + 1
+    ctx.counts_reset()
+    ctx.reads_submit(block[:cut], len(nl) // 3 + 1)
+    ctx.reads_submit(block[cut:], cohort.n_reads - (len(nl) // 3 + 1))
+    cov, _, _ = ctx.counts_finish()
+    assert np.array_equal(cov, want)
+    ctx.counts_reset()
+    cov0, _, _ = ctx.counts_finish()
+    assert not cov0.any()
+    reps = 40
+    ctx.counts_reset()
+    for _ in range(reps):
+        ctx.reads_submit(block, cohort.n_reads)
+    cov, _, _ = ctx.counts_finish()
+    # per-key occurrences are not clamped in the reference dump only when < 255; use the oracle total
+    t = o.Table(cohort.graph.keys)
+    for _ in range(reps):
+        t.count_block(block, cohort.k)
+    assert np.array_equal(cov, t.counts())
+    assert (cov == 255).any()
+
+
+def test_table_export_import_roundtrip(ctx):
+    import torch
+    cohort = get_cohort("cohort_sv")
+    _upload(ctx, cohort)
+    nbytes = ctx.table_image_bytes()
+    img = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    ctx.table_export(img)
+    c2 = vgmi.Context(0, buffer_mib=16)
+    try:
+        c2.table_import(img)
+        assert c2.table_info() == ctx.table_info()
+        c2.counts_reset()
+        c2.reads_submit(cohort.block(), cohort.n_reads)
+        cov, _, _ = c2.counts_finish()
+        assert np.array_equal(cov, cohort.ref_c_in_graph_order())
+    finally:
+        c2.close()
+
+
+def test_error_paths(ctx):
+    cohort = get_cohort("cohort_snp")
+    keys = cohort.graph.keys
+    with pytest.raises(vgmi.VgmiError) as e:
+        ctx.table_upload(np.concatenate([keys[:10], keys[:1]]), 27)
+    assert e.value.code == vgmi.E_DUPLICATE_KEY
+    with pytest.raises(vgmi.VgmiError) as e:
+        ctx.table_upload(keys[:10], 25)          # low byte says 27
+    assert e.value.code == vgmi.E_BAD_KEY
+    with pytest.raises(vgmi.VgmiError) as e:
+        ctx.table_upload(keys[:10], 29)
+    assert e.value.code == vgmi.E_INVALID
+    with pytest.raises(vgmi.VgmiError) as e:
+        ctx.counts_reset()                        # failed uploads leave no table
+    assert e.value.code == vgmi.E_STATE
+    ctx.table_upload(keys, 27)
+    ctx.counts_reset()
+    # zero-length read: the reference aborts on assert(len > 0) (src/kmer.cpp:124)
+    for bad in (b"ACGT\n\nACGT\n", b"\nACGT\n", b"ACGTN\n\n"):
+        ctx.counts_reset()
+        ctx.reads_submit(np.frombuffer(bad, dtype=np.uint8), bad.count(b"\n"))
+        with pytest.raises(vgmi.VgmiError) as e:
+            ctx.counts_finish()
+        assert e.value.code == vgmi.E_EMPTY_READ
+    # 'N' right before the separator is NOT an empty read
+    ctx.counts_reset()
+    ok = b"ACGTN\nNN\nN\nACGT\n"
+    ctx.reads_submit(np.frombuffer(ok, dtype=np.uint8), 4)
+    ctx.counts_finish()
+    with pytest.raises(vgmi.VgmiError) as e:
+        ctx.reads_submit(np.frombuffer(b"ACGT", dtype=np.uint8), 1)   # no trailing '\n'
+    assert e.value.code == vgmi.E_INVALID
+
+
+def test_empty_table_and_tiny_inputs(ctx):
+    ctx.table_upload(np.zeros(0, dtype=np.uint64), 27)
+    ctx.counts_reset()
+    ctx.reads_submit(np.frombuffer(b"ACGTACGTACGTACGTACGTACGTACGTACGT\n", dtype=np.uint8), 1)
+    cov, _, _ = ctx.counts_finish()
+    assert cov.size == 0
+    key = o.sketch(b"ACGTACGTTGCAAGCTTAGCGATCGAT", 27)
+    ctx.table_upload(key, 27)
+    ctx.counts_reset()
+    ctx.reads_submit(np.frombuffer(b"ACGTACGTTGCAAGCTTAGCGATCGAT\nATCGATCGCTAAGCTTGCAACGTACGT\nAC\n", dtype=np.uint8), 3)
+    cov, _, _ = ctx.counts_finish()
+    assert cov.tolist() == [2]     # forward and reverse-complement read hit the same canonical key
+
+
+# ----------------------------------------------------------------------------- Bloom (K3/K4)
+@pytest.mark.parametrize("case", BLOOM, ids=lambda c: c["name"])
+def test_bloom_filter_matches_reference(ctx, case):
+    want = np.load(os.path.join(GOLDEN, f"bloom_{case['name']}_filter.npy"))
+    m, nh = vgmi.bloom_params(case["n"], 0.01)
+    assert (m, nh) == (case["m"], case["n_hash"])
+    ctx.bloom_create(m, nh, np.array([int(s, 16) for s in case["seeds"]], dtype=np.uint64))
+    for s in case["seqs"]:
+        ctx.bloom_add_seq(np.frombuffer(s.encode(), dtype=np.uint8), case["k"])
+    got = ctx.bloom_fetch()
+    assert np.array_equal(got, want)
+    mn, nz = ctx.bloom_query(np.array([int(x, 16) for x in case["query_keys"]], dtype=np.uint64))
+    assert mn.tolist() == case["query_count"]
+    assert nz.tolist() == case["query_find"]
+
+
+@pytest.mark.parametrize("k", [27, 12])
+def test_bloom_saturation_and_oracle(ctx, k):
+    """A repetitive 200 kb sequence drives counters to the 255 clamp; bytes must equal the oracle's."""
+    rng = np.random.default_rng(3)
+    unit = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=300)]
+    seq = np.concatenate([np.tile(unit, 400), np.frombuffer(b"NNN", dtype=np.uint8),
+                          np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=80000)]])
+    n = seq.size - k + 1
+    m, nh = vgmi.bloom_params(n, 0.01)
+    seeds = rng.integers(1, 1 << 63, size=nh).astype(np.uint64)
+    ctx.bloom_create(m, nh, seeds)
+    ctx.bloom_add_seq(seq, k)
+    got = ctx.bloom_fetch()
+    want = np.zeros(m, dtype=np.uint8)
+    o.bloom_add_seq(want, seeds, seq, k)
+    assert np.array_equal(got, want)
+    assert (got == 255).any()
+
+
+# ----------------------------------------------------------------------------- tooling
+def test_synth_device_equals_host(ctx):
+    import torch
+    cohort = get_cohort("cohort_sv")
+    haps = cohort.haplotypes()
+    cat = np.concatenate(haps)
+    off = np.concatenate([[0], np.cumsum([len(h) for h in haps])]).astype(np.uint64)
+    n_reads, L = 5000, 150
+    host = vgmi.synth_reads_host(77, 123, n_reads, L, haps)
+    d_cat = torch.from_numpy(cat).cuda()
+    d_out = torch.empty(n_reads * (L + 1), dtype=torch.uint8, device="cuda")
+    ctx.synth_reads_device(77, 123, n_reads, L, d_cat, off, d_out)
+    assert np.array_equal(d_out.cpu().numpy(), host)
+
+
+def test_large_block_properties(ctx):
+    """4 M reads of the C1/C2 workload generated on the device: the counters must equal the oracle's on a
+    64 k-read prefix submitted alone, be invariant under splitting the block, and be monotone in the input."""
+    import torch
+    cohort = get_cohort("c1")
+    haps = cohort.haplotypes()
+    cat = np.concatenate(haps)
+    off = np.concatenate([[0], np.cumsum([len(h) for h in haps])]).astype(np.uint64)
+    n_reads, L = 4_000_000, 150
+    d_cat = torch.from_numpy(cat).cuda()
+    d_out = torch.empty(n_reads * (L + 1), dtype=torch.uint8, device="cuda")
+    ctx.synth_reads_device(2024, 0, n_reads, L, d_cat, off, d_out)
+    ctx.table_upload(cohort.graph.keys, 27)
+    ctx.counts_reset()
+    ctx.reads_submit_device(d_out, d_out.numel(), n_reads)
+    full, _, _ = ctx.counts_finish()
+    # split at a multiple of 16 bytes that is a read boundary: 16 reads * 151 B
+    cut_reads = 16 * 100_003
+    cut = cut_reads * (L + 1)
+    ctx.counts_reset()
+    ctx.reads_submit_device(d_out, cut, cut_reads)
+    ctx.reads_submit_device(d_out[cut:], d_out.numel() - cut, n_reads - cut_reads)
+    split, _, _ = ctx.counts_finish()
+    assert np.array_equal(full, split)
+    pre_reads = 65536
+    ctx.counts_reset()
+    ctx.reads_submit_device(d_out, pre_reads * (L + 1), pre_reads)
+    pre, _, _ = ctx.counts_finish()
+    t = o.Table(cohort.graph.keys)
+    t.count_block(d_out[: pre_reads * (L + 1)].cpu().numpy(), 27)
+    assert np.array_equal(pre, t.counts())
+    assert (full >= pre).all()
+    assert ctx.read_base() == pre_reads * L
+
+
+# ----------------------------------------------------------------------------- host pipeline (C++)
+@pytest.mark.parametrize("name", ["cohort_snp", "cohort_sv", "cohort_k22", "cohort_tetra"])
+@pytest.mark.parametrize("use_depth", [False, True])
+def test_sample_pipeline_fastq_to_coverage(name, use_depth):
+    """FastqKmerHip::build_fastq_index over the fixture's FASTQ.gz files (C++ reader threads ->
+    pinned staging -> HIP) + coverage statistics == the reference's counters, ReadDepth_,
+    homCoverage and hapKmerCoverage_ (bit patterns of the floats)."""
+    from varigraph_amd import host
+    cohort = get_cohort(name)
+    m = cohort.meta
+    g = host.Graph(os.path.join(cohort.dir, "graph.bin.gz"))
+    c = vgmi.Context(0, buffer_mib=1)   # small staging buffer: blocks are cut and double-buffered
+    try:
+        g.upload(c)
+        fq = [os.path.join(cohort.dir, f"reads_{i}.fq.gz") for i in (1, 2)]
+        cov, cov_node, hist, st = g.sample_count(c, fq, threads=2, sample_ploidy=m["sample_ploidy"], use_depth=use_depth)
+        want = cohort.ref_c_in_graph_order()
+        assert np.array_equal(cov, want)
+        a = g.arrays()
+        assert np.array_equal(cov_node, want[a["node_key_index"]])
+        assert hist.tolist() == m["hist"]
+        assert st["read_base"] == cohort.ref_read_base and st["n_reads"] == cohort.n_reads
+        assert np.float32(st["read_depth"]).view(np.uint32) == int(m["read_depth_bits"], 16)
+        assert st["max_coverage"] == int(m["max_cov"])
+        pre = "use_depth_" if use_depth else ""
+        assert st["hom_coverage"] == int(m[pre + "hom_cov"])
+        assert np.float32(st["hap_kmer_coverage"]).view(np.uint32) == int(m[pre + "hap_kmer_cov_bits"], 16)
+    finally:
+        c.close()
+        g.close()
+
+
+def test_sample_pipeline_rejects_empty_read(tmp_path):
+    from varigraph_amd import host
+    cohort = get_cohort("cohort_snp")
+    p = tmp_path / "bad.fq"
+    p.write_bytes(b"@r1\nACGTACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n@r2\n\n+\n\n")
+    g = host.Graph(os.path.join(cohort.dir, "graph.bin.gz"))
+    c = vgmi.Context(0)
+    try:
+        g.upload(c)
+        with pytest.raises(vgmi.VgmiError) as e:
+            g.sample_count(c, [str(p)])
+        assert e.value.code == vgmi.E_EMPTY_READ
+    finally:
+        c.close()
+        g.close()

@@ -1,0 +1,158 @@
+"""CPU tests of the C++ host side (libvghost.so) and of the C-ABI surface."""
+import gzip
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import graphbin_py
+from conftest import GOLDEN, ROOT, block_from_seqs, get_cohort, read_fastq_seqs
+from varigraph_amd import host, vgmi
+
+
+def test_cabi_exports_every_declared_symbol():
+    """libvgmi.so / libvghost.so load and export every function include/*.h declares."""
+    for header, libpath in (("vgmi.h", vgmi.LIB_PATH), ("vghost.h", host.LIB_PATH)):
+        txt = open(os.path.join(ROOT, "include", header)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        declared = set(re.findall(r"\b(vg[mh]i?_[a-z0-9_]+)\s*\(", txt))
+        assert len(declared) >= 10
+        vgmi.lib(); host.lib()
+        out = subprocess.run(["nm", "-D", "--defined-only", libpath], capture_output=True, text=True, check=True).stdout
+        exported = set(re.findall(r" T (vg[mh]i?_[a-z0-9_]+)", out))
+        missing = declared - exported
+        assert not missing, f"{header}: not exported: {sorted(missing)}"
+    assert set(vgmi.SYMBOLS) <= exported | set(re.findall(r" T (vgmi_[a-z0-9_]+)", subprocess.run(
+        ["nm", "-D", "--defined-only", vgmi.LIB_PATH], capture_output=True, text=True).stdout))
+
+
+def test_no_gpu_fails_loudly():
+    """Without a device the product path must refuse to run (no CPU fallback)."""
+    if vgmi.lib().vgmi_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(vgmi.VgmiError) as e:
+        vgmi.Context(0)
+    assert e.value.code == vgmi.E_NO_DEVICE
+
+
+def test_bloom_params_match_reference_kats():
+    import json
+    for c in json.load(open(os.path.join(GOLDEN, "kats.json")))["bloom_size"]:
+        assert vgmi.bloom_params(c["n"], c["p"]) == (c["m"], c["n_hash"])
+
+
+def test_graph_loader_matches_python_parser(cohort):
+    g = cohort.graph
+    a = host.load_graph(os.path.join(cohort.dir, "graph.bin.gz"))
+    assert (a["k"], a["vcf_ploidy"], a["hap_num"], a["genome_size"]) == (g.k, g.vcf_ploidy, g.hap_num, g.genome_size)
+    assert np.array_equal(a["keys"], g.keys)
+    assert np.array_equal(a["f"], g.f)
+    assert np.array_equal(a["bitvec"], g.bitvec)
+
+
+def test_graph2node_matches_reference_dump(cohort):
+    """Node order and per-node k-mer order (incl. the >128 std::sort-by-frequency truncation)
+    equal what the reference holds after ConstructIndex::graph2node."""
+    a = host.load_graph(os.path.join(cohort.dir, "graph.bin.gz"))
+    ref_nodes = cohort.ref_nodes
+    assert len(ref_nodes) == len(a["node_start"])
+    n_big = 0
+    for i, (name, start, kh) in enumerate(ref_nodes):
+        assert a["chr_names"][a["node_chr"][i]] == name
+        assert a["node_start"][i] == start
+        lo, hi = int(a["node_off"][i]), int(a["node_off"][i + 1])
+        assert np.array_equal(a["keys"][a["node_key_index"][lo:hi]], kh), (name, start)
+        n_big += (hi - lo) == 128
+    if cohort.meta["name"] == "cohort_sv":
+        assert n_big > 0, "the SV cohort must exercise the >128 k-mer branch"
+
+
+def test_hom_flags_match_oracle_histogram(cohort):
+    """flag & (c != 0) histogram == reference get_hom_kmer histogram."""
+    a = host.load_graph(os.path.join(cohort.dir, "graph.bin.gz"))
+    c = cohort.ref_c_in_graph_order()
+    sel = (a["hom_flag"] != 0) & (c != 0)
+    hist = np.bincount(c[sel], minlength=256)
+    assert hist.tolist() == cohort.meta["hist"]
+
+
+def test_fastx_reader_matches_fixture(cohort):
+    fq = [os.path.join(cohort.dir, f"reads_{m}.fq.gz") for m in (1, 2)]
+    if not os.path.exists(fq[0]):
+        pytest.skip("reads are regenerated for this cohort")
+    tot = 0
+    for p in fq:
+        block, n, rb = host.fastx_read_all(p)
+        seqs = read_fastq_seqs(p)
+        assert n == len(seqs)
+        assert np.array_equal(block, block_from_seqs(seqs))
+        tot += rb
+    assert tot == cohort.ref_read_base
+
+
+def test_fastx_reader_edge_cases(tmp_path):
+    """kseq_read semantics: FASTA, multi-line, CRLF, truncated quality stops the file, junk before
+    the first header, '@' inside quality."""
+    def rd(data, gz=False):
+        p = tmp_path / ("x.fq.gz" if gz else "x.fq")
+        (gzip.open if gz else open)(p, "wb").write(data)
+        b, n, rb = host.fastx_read_all(str(p))
+        return bytes(b), n, rb
+    assert rd(b">a desc\nACGT\nTTGA\n>b\nGG\n") == (b"ACGTTTGA\nGG\n", 2, 10)
+    assert rd(b"@r1\nACGT\n+\nIIII\n@r2\nTTTT\n+r2\nIIII\n", gz=True) == (b"ACGT\nTTTT\n", 2, 8)
+    assert rd(b"junk\n@r1\r\nACGT\r\n+\r\nIIII\r\n") == (b"ACGT\n", 1, 4)
+    # quality starting with '@' must not be taken for a header
+    assert rd(b"@r1\nACGT\n+\n@III\n@r2\nGGCC\n+\nIIII\n") == (b"ACGT\nGGCC\n", 2, 8)
+    # truncated last record (-2): the reference stops there and keeps what it had
+    assert rd(b"@r1\nACGT\n+\nIIII\n@r2\nGGCC\n+\nII\n") == (b"ACGT\n", 1, 4)
+    assert rd(b"@r1\nACGT\n+\nIIII\n@r2\nGGCC\n") == (b"ACGT\nGGCC\n", 2, 8)   # FASTA-style tail is accepted by kseq
+    assert rd(b"") == (b"", 0, 0)
+    # multi-line FASTQ
+    assert rd(b"@r1\nAC\nGT\n+\nII\nII\n") == (b"ACGT\n", 1, 4)
+
+
+def test_hash64_inverse_roundtrip(tmp_path):
+    """vg_hash64_inv (product, used by the table build) inverts the reference hash64 for every k."""
+    src = tmp_path / "t.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstdint>
+#include "vgmi_device.h"
+int main() {
+    uint64_t x = 88172645463325252ULL;
+    for (int k = 1; k <= 28; ++k) {
+        uint64_t mask = (1ULL << (2 * k)) - 1;
+        for (int i = 0; i < 20000; ++i) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            uint64_t v = x & mask;
+            if (vg_hash64_inv(vg_hash64(v, mask), mask) != v) { printf("FAIL k=%d v=%llx\n", k, (unsigned long long)v); return 1; }
+            if (vg_hash64(vg_hash64_inv(v, mask), mask) != v) { printf("FAIL2 k=%d\n", k); return 1; }
+        }
+    }
+    // KAT from the reference: ACGTACGTTGCAAGCTTAGCGATCGAT, k=27 -> 0x2df5c044b3f1eb1b
+    printf("%llx\n", (unsigned long long)vg_hash64_inv(0x2df5c044b3f1eb1bULL >> 8, (1ULL << 54) - 1));
+    return 0;
+}''')
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "varigraph_amd", "csrc"), str(src), "-o", str(exe)],
+                   check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    # canonical 2-bit value of the k-mer (min of forward / reverse complement)
+    seq = "ACGTACGTTGCAAGCTTAGCGATCGAT"
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    fwd = 0
+    for ch in seq:
+        fwd = (fwd << 2) | code[ch]
+    rc = 0
+    for ch in reversed(seq):
+        rc = (rc << 2) | (3 - code[ch])
+    assert int(out.stdout.strip(), 16) == min(fwd, rc)
+
+
+def test_synth_generator_is_stable():
+    """The seeded generator must keep producing the block the c1 fixture was made from."""
+    c = get_cohort("c1")
+    c.regenerate_block()  # asserts the md5

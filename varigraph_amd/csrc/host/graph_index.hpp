@@ -1,0 +1,59 @@
+// graph_index.hpp -- the genome-graph index as flat arrays (host side of the MI355X build).
+//
+// Restates, for the needs of `genotype --load-graph`:
+//   ConstructIndex::load_index   src/construct_index.cpp:911-1105  (byte layout: SURVEY.md App. A)
+//   ConstructIndex::graph2node   src/construct_index.cpp:710-751, graph2node_run :1572-1603
+//   the sample-independent half of Varigraph::get_hom_kmer  src/varigraph.cpp:263-287
+// The reference keeps the k-mer table as unordered_map<uint64_t,kmerCovFreBitVec> with a heap
+// vector per k-mer and reads BitVec one byte per read() call; here everything is bulk-read into
+// contiguous arrays that can be handed to vgmi_table_upload / vgmi_nodes_upload as they are.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+struct vgmi_ctx;
+
+namespace vgh {
+
+struct GraphNode {  // one nodeSrt (include/construct_index.hpp:105-121) without per-sample state
+    uint32_t start = 0;
+    std::vector<std::string> seqs;      // seqVec
+    std::vector<uint16_t> hap_gt;       // hapGtVec
+    std::vector<uint64_t> kmer_hash;    // kmerHashVec (graph.bin order)
+};
+
+struct GraphIndex {
+    uint64_t graph_base_num = 0;
+    uint32_t k = 0, vcf_ploidy = 0;
+    std::string vcf_head;
+    std::map<std::string, uint32_t> chr_len;                                       // mFastaLenMap
+    std::map<std::string, std::map<uint32_t, std::vector<std::string>>> vcf_info;  // mVcfInfoMap
+    uint64_t genome_size = 0;
+    uint16_t hap_num = 0;
+    std::map<uint16_t, std::string> hap_names;                                     // mHapMap
+    std::map<std::string, std::map<uint32_t, GraphNode>> graph;                    // mGraphMap
+
+    // k-mer table, file record order
+    std::vector<uint64_t> keys;
+    std::vector<uint8_t> f;
+    std::vector<int8_t> bitvec;  // keys.size() * bitlen
+    uint64_t bitlen = 0;
+    std::vector<uint8_t> hom_flag;
+
+    // variant nodes in mGraphMap order (chromosome lexicographic, start ascending) and their
+    // k-mer lists after graph2node, as CSR over key indices
+    std::vector<std::string> chr_names;
+    std::vector<uint32_t> node_chr, node_start;
+    std::vector<uint64_t> node_off;
+    std::vector<uint32_t> node_key_index;
+
+    // throws std::runtime_error
+    void load(const std::string& path);
+    void graph2node();
+    void compute_hom_flags();
+    int upload(vgmi_ctx* ctx) const;
+};
+
+}  // namespace vgh

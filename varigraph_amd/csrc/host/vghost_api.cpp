@@ -1,0 +1,152 @@
+// vghost_api.cpp -- C API of include/vghost.h over the C++ host classes
+#include "vghost.h"
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "fastq_kmer_hip.hpp"
+#include "fastx_reader.hpp"
+#include "graph_index.hpp"
+
+struct vgh_graph {
+    vgh::GraphIndex g;
+};
+
+static thread_local std::string g_err;
+
+extern "C" {
+
+const char* vgh_last_error(void) { return g_err.c_str(); }
+
+int vgh_graph_load(const char* path, vgh_graph** out)
+{
+    if (!path || !out) return VGMI_E_INVALID;
+    *out = nullptr;
+    try {
+        auto* h = new vgh_graph();
+        try {
+            h->g.load(path);
+        } catch (...) {
+            delete h;
+            throw;
+        }
+        *out = h;
+        return VGMI_OK;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return VGMI_E_INVALID;
+    }
+}
+
+void vgh_graph_free(vgh_graph* g) { delete g; }
+
+int vgh_graph_get_info(const vgh_graph* h, vgh_graph_info* info)
+{
+    if (!h || !info) return VGMI_E_INVALID;
+    const vgh::GraphIndex& g = h->g;
+    info->graph_base_num = g.graph_base_num;
+    info->genome_size = g.genome_size;
+    info->n_keys = g.keys.size();
+    info->bitlen = g.bitlen;
+    info->n_variant_nodes = g.node_off.size() - 1;
+    info->n_node_entries = g.node_key_index.size();
+    info->k = g.k;
+    info->vcf_ploidy = g.vcf_ploidy;
+    info->hap_num = g.hap_num;
+    info->n_chromosomes = (uint32_t)g.chr_names.size();
+    return VGMI_OK;
+}
+
+const uint64_t* vgh_graph_keys(const vgh_graph* h) { return h->g.keys.data(); }
+const uint8_t* vgh_graph_f(const vgh_graph* h) { return h->g.f.data(); }
+const int8_t* vgh_graph_bitvec(const vgh_graph* h) { return h->g.bitvec.data(); }
+const uint8_t* vgh_graph_hom_flag(const vgh_graph* h) { return h->g.hom_flag.data(); }
+const uint64_t* vgh_graph_node_off(const vgh_graph* h) { return h->g.node_off.data(); }
+const uint32_t* vgh_graph_node_key_index(const vgh_graph* h) { return h->g.node_key_index.data(); }
+const uint32_t* vgh_graph_node_start(const vgh_graph* h) { return h->g.node_start.data(); }
+const uint32_t* vgh_graph_node_chr(const vgh_graph* h) { return h->g.node_chr.data(); }
+const char* vgh_graph_chr_name(const vgh_graph* h, uint32_t chr)
+{
+    return chr < h->g.chr_names.size() ? h->g.chr_names[chr].c_str() : nullptr;
+}
+
+int vgh_graph_upload(const vgh_graph* h, vgmi_ctx* ctx)
+{
+    if (!h || !ctx) return VGMI_E_INVALID;
+    int rc = h->g.upload(ctx);
+    if (rc) g_err = vgmi_last_error(ctx);
+    return rc;
+}
+
+int64_t vgh_fastx_read_all(const char* path, char** block_out, size_t* n_bytes_out, uint64_t* read_base)
+{
+    if (!path || !block_out || !n_bytes_out) return VGMI_E_INVALID;
+    try {
+        vgh::FastxReader rd(path);
+        std::string block;
+        int64_t n = 0;
+        uint64_t rb = 0;
+        while (rd.next() >= 0) {
+            const std::string& s = rd.seq();
+            block.append(s.data(), strnlen(s.data(), s.size()));
+            block.push_back('\n');
+            rb += s.size();
+            ++n;
+        }
+        char* p = static_cast<char*>(malloc(block.size() ? block.size() : 1));
+        if (!p) return VGMI_E_NOMEM;
+        memcpy(p, block.data(), block.size());
+        *block_out = p;
+        *n_bytes_out = block.size();
+        if (read_base) *read_base = rb;
+        return n;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return VGMI_E_INVALID;
+    }
+}
+
+void vgh_free(void* p) { free(p); }
+
+int vgh_sample_count(const vgh_graph* h, vgmi_ctx* ctx, const char* const* fastq_paths, size_t n_files, uint32_t threads,
+                     uint32_t sample_ploidy, int use_depth, uint8_t* cov_out, uint8_t* cov_node_out, uint64_t* hist_out,
+                     vgh_sample_stats* stats)
+{
+    if (!h || !ctx || (!fastq_paths && n_files)) return VGMI_E_INVALID;
+    try {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<std::string> files(fastq_paths, fastq_paths + n_files);
+        vgh::FastqKmerHip fk(ctx, files, h->g.k, threads);
+        fk.build_fastq_index();
+        uint64_t hist[256];
+        fk.fetch(cov_out, cov_node_out, hist);
+        if (hist_out) memcpy(hist_out, hist, sizeof hist);
+        if (stats) {
+            memset(stats, 0, sizeof *stats);
+            stats->read_base = fk.mReadBase;
+            stats->n_reads = fk.mReadNum;
+            vgh::CoverageStats cs;
+            const bool ok = vgh::coverage_stats(hist, fk.mReadBase, h->g.genome_size, sample_ploidy, use_depth != 0, cs);
+            stats->read_depth = cs.read_depth;
+            stats->hap_kmer_coverage = cs.hap_kmer_coverage;
+            stats->max_coverage = cs.max_coverage;
+            stats->hom_coverage = cs.hom_coverage;
+            stats->seconds_kernel = fk.kernel_seconds();
+            stats->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (!ok) {
+                g_err = "Failed to retrieve depth information of k-mers from the sequencing data. Please verify your data.";
+                return VGMI_E_STATE;
+            }
+        }
+        return VGMI_OK;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        const std::string m = e.what();
+        return m.find("empty read") != std::string::npos || m.find("zero-length") != std::string::npos ? VGMI_E_EMPTY_READ
+                                                                                                       : VGMI_E_INVALID;
+    }
+}
+
+}  // extern "C"

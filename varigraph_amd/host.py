@@ -1,0 +1,148 @@
+"""ctypes binding of include/vghost.h (libvghost.so): graph.bin reader, FASTA/Q reader and the
+sample-counting driver (C++17 host side).  No fallback: a missing library raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import vgmi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvghost.so")
+_lib = None
+
+
+class GraphInfo(C.Structure):
+    _fields_ = [("graph_base_num", C.c_uint64), ("genome_size", C.c_uint64), ("n_keys", C.c_uint64),
+                ("bitlen", C.c_uint64), ("n_variant_nodes", C.c_uint64), ("n_node_entries", C.c_uint64),
+                ("k", C.c_uint32), ("vcf_ploidy", C.c_uint32), ("hap_num", C.c_uint32), ("n_chromosomes", C.c_uint32)]
+
+
+class SampleStats(C.Structure):
+    _fields_ = [("read_base", C.c_uint64), ("n_reads", C.c_uint64), ("read_depth", C.c_float),
+                ("hap_kmer_coverage", C.c_float), ("max_coverage", C.c_uint8), ("hom_coverage", C.c_uint8),
+                ("seconds_total", C.c_double), ("seconds_kernel", C.c_double)]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    vgmi.lib()  # libvgmi.so first (libvghost links against it)
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m varigraph_amd.build`")
+    l = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    l.vgh_last_error.restype = C.c_char_p
+    l.vgh_graph_load.restype = C.c_int; l.vgh_graph_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    l.vgh_graph_free.restype = None; l.vgh_graph_free.argtypes = [vp]
+    l.vgh_graph_get_info.restype = C.c_int; l.vgh_graph_get_info.argtypes = [vp, C.POINTER(GraphInfo)]
+    for name in ("keys", "f", "bitvec", "hom_flag", "node_off", "node_key_index", "node_start", "node_chr"):
+        fn = getattr(l, "vgh_graph_" + name)
+        fn.restype = vp
+        fn.argtypes = [vp]
+    l.vgh_graph_chr_name.restype = C.c_char_p; l.vgh_graph_chr_name.argtypes = [vp, C.c_uint32]
+    l.vgh_graph_upload.restype = C.c_int; l.vgh_graph_upload.argtypes = [vp, vp]
+    l.vgh_fastx_read_all.restype = C.c_int64
+    l.vgh_fastx_read_all.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]
+    l.vgh_free.restype = None; l.vgh_free.argtypes = [vp]
+    l.vgh_sample_count.restype = C.c_int
+    l.vgh_sample_count.argtypes = [vp, vp, C.POINTER(C.c_char_p), C.c_size_t, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp,
+                                   C.POINTER(SampleStats)]
+    _lib = l
+    return l
+
+
+def _arr(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).copy()
+
+
+class Graph:
+    """A loaded graph.bin (host arrays stay in the C++ object; numpy copies on request)."""
+
+    def __init__(self, path):
+        self._l = lib()
+        h = C.c_void_p()
+        rc = self._l.vgh_graph_load(os.fsencode(path), C.byref(h))
+        if rc:
+            raise RuntimeError(self._l.vgh_last_error().decode())
+        self._h = h
+        info = GraphInfo()
+        self._l.vgh_graph_get_info(h, C.byref(info))
+        self.info = {f[0]: getattr(info, f[0]) for f in GraphInfo._fields_}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.vgh_graph_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def arrays(self):
+        i = self.info
+        l, h = self._l, self._h
+        n, nv, ne = i["n_keys"], i["n_variant_nodes"], i["n_node_entries"]
+        return {
+            "k": i["k"], "vcf_ploidy": i["vcf_ploidy"], "hap_num": i["hap_num"], "genome_size": i["genome_size"],
+            "keys": _arr(l.vgh_graph_keys(h), n, np.uint64),
+            "f": _arr(l.vgh_graph_f(h), n, np.uint8),
+            "bitvec": _arr(l.vgh_graph_bitvec(h), n * i["bitlen"], np.int8).reshape(n, i["bitlen"]),
+            "hom_flag": _arr(l.vgh_graph_hom_flag(h), n, np.uint8),
+            "node_off": _arr(l.vgh_graph_node_off(h), nv + 1, np.uint64),
+            "node_key_index": _arr(l.vgh_graph_node_key_index(h), ne, np.uint32),
+            "node_start": _arr(l.vgh_graph_node_start(h), nv, np.uint32),
+            "node_chr": _arr(l.vgh_graph_node_chr(h), nv, np.uint32),
+            "chr_names": [l.vgh_graph_chr_name(h, c).decode() for c in range(i["n_chromosomes"])],
+        }
+
+    def upload(self, ctx):
+        rc = self._l.vgh_graph_upload(self._h, ctx._h)
+        if rc:
+            raise vgmi.VgmiError(rc, self._l.vgh_last_error().decode())
+        ctx.n_keys = self.info["n_keys"]
+        ctx.n_node_entries = self.info["n_node_entries"]
+
+    def sample_count(self, ctx, fastq_paths, threads=4, sample_ploidy=2, use_depth=False):
+        """FastqKmerHip::build_fastq_index + coverage statistics for one sample."""
+        i = self.info
+        cov = np.empty(i["n_keys"], dtype=np.uint8)
+        cov_node = np.empty(i["n_node_entries"], dtype=np.uint8)
+        hist = np.zeros(256, dtype=np.uint64)
+        st = SampleStats()
+        arr = (C.c_char_p * len(fastq_paths))(*[os.fsencode(p) for p in fastq_paths])
+        rc = self._l.vgh_sample_count(self._h, ctx._h, arr, len(fastq_paths), threads, sample_ploidy, int(use_depth),
+                                      vgmi._ptr(cov), vgmi._ptr(cov_node), vgmi._ptr(hist), C.byref(st))
+        if rc:
+            raise vgmi.VgmiError(rc, self._l.vgh_last_error().decode())
+        stats = {f[0]: getattr(st, f[0]) for f in SampleStats._fields_}
+        return cov, cov_node, hist, stats
+
+
+def load_graph(path):
+    """graph.bin -> dict of numpy arrays (keys, f, bitvec, hom_flag, node CSR, ...)."""
+    g = Graph(path)
+    try:
+        return g.arrays()
+    finally:
+        g.close()
+
+
+def fastx_read_all(path):
+    """All records of a FASTA/Q(.gz) file as a '\\n'-joined block (kseq_read semantics)."""
+    l = lib()
+    p, n, rb = C.c_void_p(), C.c_size_t(), C.c_uint64()
+    cnt = l.vgh_fastx_read_all(os.fsencode(path), C.byref(p), C.byref(n), C.byref(rb))
+    if cnt < 0:
+        raise RuntimeError(l.vgh_last_error().decode())
+    try:
+        block = _arr(p.value, n.value, np.uint8)
+    finally:
+        l.vgh_free(p)
+    return block, int(cnt), rb.value
