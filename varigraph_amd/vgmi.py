@@ -22,6 +22,12 @@ def load_library():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m varigraph_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch wheels bundle their own libamdhip64; load torch FIRST so the process ends up with one
+    # HIP runtime (torch is only plumbing here: device buffers and torch.distributed)
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, u64, u32, sz, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int
     sig = {
