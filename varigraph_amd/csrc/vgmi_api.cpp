@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -61,6 +62,7 @@ struct vgmi_ctx {
     TableView tv{};
     uint32_t* d_key_slot = nullptr;
     bool filter_in_lds = false;
+    bool force_generic = false;  // VGMI_GENERIC_KERNEL=1: take the generic row kernel (A/B testing)
 
     // nodes / flags / outputs
     size_t n_nodes = 0;
@@ -154,7 +156,7 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     h.k = k;
     h.n_keys = n_keys;
     uint64_t cap = 64;
-    while (cap < 2 * n_keys) cap <<= 1;  // load factor <= 0.5
+    while (cap < 4 * n_keys) cap <<= 1;  // load factor <= 0.25: ~88 % of probes end at the first slot
     h.cap = cap;
     // prefilter: >= 16 bits per key, power of two, at least 128 bits
     uint64_t bits = 128;
@@ -218,7 +220,10 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
     if (k & 1) {
         uint32_t grid, block;
         rows_geometry(c, c->filter_in_lds, grid, block);
-        HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, grid, block, st));
+        if (k == 27 && c->filter_in_lds && !c->force_generic)
+            HIPCHK(c, launch_count27_lds(p, grid, block, st));
+        else
+            HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, grid, block, st));
     } else {
         if (!d_read_off) return fail(c, VGMI_E_INVALID, "even k needs read offsets");
         HIPCHK(c, launch_seq(K_MODE_COUNT, p, d_read_off, n_reads, st));
@@ -323,6 +328,7 @@ int vgmi_create(int device, size_t buffer_mib, vgmi_ctx** out)
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* g = getenv("VGMI_GENERIC_KERNEL")) c->force_generic = g[0] == '1';
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipMalloc(&c->d_status, 4)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(c->d_status, 0, 4)) != hipSuccess) return bail("hipMemset", e);

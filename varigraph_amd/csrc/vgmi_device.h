@@ -116,12 +116,22 @@ VG_HD uint32_t vg_fhash_word(uint64_t canon)
     const uint32_t lo = (uint32_t)canon, mid = (uint32_t)(canon >> 24), hi = (uint32_t)(canon >> 48);
     return vg_mul24(lo, 0x9E3779u) + vg_mul24(mid, 0x85EBCBu) + vg_mul24(hi, 0xC2B2AFu);
 }
-// bit selector inside the 32-bit word: two 5-bit fields taken from the top of a second product
-VG_HD uint32_t vg_fhash_bits(uint64_t canon)
+// bit selector inside the 32-bit word (two bits per key).  Small filters (<= 2^15 words, the
+// LDS-resident case) index with the top <= 15 bits of the word hash, so bits [7,17) of the same
+// hash are free to pick the two bit positions; larger filters take them from a second product.
+VG_HD uint32_t vg_fhash_bits_small(uint32_t word_hash)
+{
+    return (1u << ((word_hash >> 12) & 31u)) | (1u << ((word_hash >> 7) & 31u));
+}
+VG_HD uint32_t vg_fhash_bits_large(uint64_t canon)
 {
     const uint32_t lo = (uint32_t)canon, mid = (uint32_t)(canon >> 24);
     const uint32_t g = vg_mul24(lo, 0x5BD1E9u) + vg_mul24(mid, 0x27D4EBu);
     return (1u << (g >> 27)) | (1u << ((g >> 22) & 31u));
+}
+VG_HD uint32_t vg_fhash_bits(uint64_t canon, uint32_t filter_words_log2)
+{
+    return filter_words_log2 <= 15 ? vg_fhash_bits_small(vg_fhash_word(canon)) : vg_fhash_bits_large(canon);
 }
 // slot hash of the exact table (evaluated only for filter passes)
 VG_HD uint64_t vg_thash(uint64_t canon)

@@ -44,6 +44,7 @@ struct SynthHaps {
     uint64_t len[VG_SYNTH_MAX_HAPS];
 };
 
+hipError_t launch_count27_lds(const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t launch_seq(int mode, const RowParams& p, const uint64_t* read_off, uint64_t n_reads, hipStream_t st);
 hipError_t launch_table_clear(VgSlot* slots, uint64_t cap, hipStream_t st);

@@ -100,7 +100,7 @@ __device__ __forceinline__ void table_count(const TableView& t, uint64_t canon)
 __device__ __forceinline__ bool filter_test_global(const TableView& t, uint64_t canon)
 {
     const uint32_t w = t.filter[vg_fhash_word(canon) >> t.filter_shift];
-    const uint32_t m = vg_fhash_bits(canon);
+    const uint32_t m = vg_fhash_bits(canon, t.filter_words_log2);
     return (w & m) == m;
 }
 
@@ -310,8 +310,9 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
             } else {
                 bool pass;
                 if (FLDS) {
-                    const uint32_t w = s_filter[vg_fhash_word(canon) >> p.table.filter_shift];
-                    const uint32_t m = vg_fhash_bits(canon);
+                    const uint32_t h = vg_fhash_word(canon);
+                    const uint32_t w = s_filter[h >> p.table.filter_shift];
+                    const uint32_t m = vg_fhash_bits_small(h);
                     pass = valid && ((w & m) == m);
                 } else {
                     pass = valid && filter_test_global(p.table, canon);
@@ -334,6 +335,252 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
     }
     if (MODE == MODE_COUNT) {
         if (qtail != qhead) drain_queue<MODE>(p.table, s_queue, qhead, qtail - qhead, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fast count kernel: k = 27 (every BASELINE.json configuration), prefilter resident in LDS.
+//
+// Same row walk as rows_kernel, restructured for instruction-level parallelism:
+//   phase A  all 16 canonical k-mers of the lane's chunk are extracted with compile-time funnel
+//            shifts and their 16 prefilter words are requested from LDS back to back;
+//   phase B  16 ballots give the per-step pass masks and the row's total;
+//   phase C  passing k-mers are compacted into the wave's LDS ring (rank = mbcnt over the step's
+//            mask, no atomics);
+//   drain    whenever >= 64 k-mers are queued, 64 exact-table probes are ISSUED (one 16-byte
+//            load per lane) and the previous batch, whose loads have been in flight for ~25
+//            steps, is FINISHED (compare, saturating atomicAdd, rare second probe).
+// A row whose passes would overflow the ring (reads made of graph k-mers only) takes a slow,
+// obviously-correct path: flush, then push+probe one step at a time.
+// ------------------------------------------------------------------------------------------
+struct Pending {
+    uint64_t canon;
+    uint64_t slot;
+    uint4 v;
+    bool active;
+};
+
+__device__ __forceinline__ void probe_issue(const TableView& t, const uint64_t* queue, uint32_t head, uint32_t n,
+                                            uint32_t lane, Pending& pd)
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    pd.active = lane < n;
+    if (pd.active) {
+        pd.canon = queue[(head + lane) & (VG_QCAP - 1)];
+        pd.slot = vg_thash(pd.canon) & t.cap_mask;
+        pd.v = *reinterpret_cast<const uint4*>(&t.slots[pd.slot]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+__device__ __forceinline__ void probe_finish(const TableView& t, Pending& pd)
+{
+    if (pd.active) {
+        uint64_t s = pd.slot;
+        uint4 v = pd.v;
+        for (;;) {
+            const uint64_t c = ((uint64_t)v.y << 32) | v.x;
+            if (c == pd.canon) {
+                if (v.z < 255u) atomicAdd(&t.slots[s].count, 1u);
+                break;
+            }
+            if (c == VG_EMPTY) break;
+            s = (s + 1) & t.cap_mask;
+            v = *reinterpret_cast<const uint4*>(&t.slots[s]);
+        }
+    }
+    pd.active = false;
+}
+
+__global__ __launch_bounds__(1024) void count27_lds_kernel(RowParams p)
+{
+    constexpr uint32_t K = 27;
+    constexpr uint32_t MASK_HI = (1u << (2 * K - 32)) - 1;  // 54-bit k-mer: low word full, 22 bits high
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint32_t nwaves = blockDim.x >> 6;
+
+    uint32_t* s_filter = reinterpret_cast<uint32_t*>(smem);
+    size_t off = (size_t)4 << p.table.filter_words_log2;
+    uint64_t* s_queue = reinterpret_cast<uint64_t*>(smem + off) + (size_t)wave * VG_QCAP;
+    off += (size_t)nwaves * VG_QCAP * 8;
+    uint8_t* s_lut_code = smem + off;
+    uint8_t* s_lut_inv = s_lut_code + 256;
+    for (uint32_t i = tid; i < 256; i += blockDim.x) {
+        const uint32_t c = vg_nt4(i);
+        s_lut_code[i] = (uint8_t)(c & 3u);
+        s_lut_inv[i] = (uint8_t)(c >> 2);
+    }
+    {
+        const uint32_t nq = 1u << (p.table.filter_words_log2 - 2);
+        const uint4* src = reinterpret_cast<const uint4*>(p.table.filter);
+        uint4* dst = reinterpret_cast<uint4*>(s_filter);
+        for (uint32_t i = tid; i < nq; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const uint64_t total_rows = (p.n_bytes + 1023) >> 10;
+    const uint64_t total_waves = (uint64_t)gridDim.x * nwaves;
+    const uint64_t rpw = (total_rows + total_waves - 1) / total_waves;
+    const uint64_t gw = (uint64_t)blockIdx.x * nwaves + wave;
+    const uint64_t r0 = gw * rpw;
+    const uint64_t r1 = r0 + rpw < total_rows ? r0 + rpw : total_rows;
+    if (r0 >= r1) return;
+
+    const uint32_t fshift = p.table.filter_shift;
+    const uint32_t src1 = (lane + 63u) & 63u, src2 = (lane + 62u) & 63u;
+    uint32_t pr1_be = 0, pr2_be = 0, pr1_rc = ~0u, pr2_rc = ~0u, pr1_inv = 0xFFFFu, pr2_inv = 0xFFFFu;
+    if (r0 > 0) {
+        const uint4 raw = load_chunk(p.bases, p.n_bytes, ((r0 - 1) << 10) + lane * 16);
+        uint32_t be, inv;
+        encode16(raw, s_lut_code, s_lut_inv, be, inv);
+        const uint32_t rcw = rc_word(be);
+        pr1_be = __shfl(be, src1);   pr2_be = __shfl(be, src2);
+        pr1_rc = __shfl(rcw, src1);  pr2_rc = __shfl(rcw, src2);
+        pr1_inv = __shfl(inv, src1); pr2_inv = __shfl(inv, src2);
+    }
+
+    uint32_t qhead = 0, qtail = 0;
+    Pending pd;
+    pd.active = false;
+    pd.canon = 0; pd.slot = 0; pd.v = make_uint4(0, 0, 0, 0);
+
+    uint4 raw_next = load_chunk(p.bases, p.n_bytes, (r0 << 10) + lane * 16);
+    for (uint64_t r = r0; r < r1; ++r) {
+        const uint4 raw = raw_next;
+        if (r + 1 < r1) raw_next = load_chunk(p.bases, p.n_bytes, ((r + 1) << 10) + lane * 16);
+
+        uint32_t be, inv;
+        encode16(raw, s_lut_code, s_lut_inv, be, inv);
+        const uint32_t rcw = rc_word(be);
+        const uint32_t r1_be = __shfl(be, src1), r2_be = __shfl(be, src2);
+        const uint32_t r1_rc = __shfl(rcw, src1), r2_rc = __shfl(rcw, src2);
+        const uint32_t r1_inv = __shfl(inv, src1), r2_inv = __shfl(inv, src2);
+        const uint32_t F0 = be;
+        const uint32_t F1 = lane >= 1 ? r1_be : pr1_be;
+        const uint32_t F2 = lane >= 2 ? r2_be : pr2_be;
+        const uint32_t R2 = rcw;
+        const uint32_t R1 = lane >= 1 ? r1_rc : pr1_rc;
+        const uint32_t R0 = lane >= 2 ? r2_rc : pr2_rc;
+        const uint32_t i1 = lane >= 1 ? r1_inv : pr1_inv;
+        const uint32_t i2 = lane >= 2 ? r2_inv : pr2_inv;
+        pr1_be = r1_be; pr2_be = r2_be; pr1_rc = r1_rc; pr2_rc = r2_rc; pr1_inv = r1_inv; pr2_inv = r2_inv;
+
+        // bit (32+j) of sm: some base of the 27-mer ending at own base j is not a base
+        uint64_t sm = ((uint64_t)inv << 32) | ((uint64_t)i1 << 16) | (uint64_t)i2;
+        sm |= sm << 1; sm |= sm << 2; sm |= sm << 4; sm |= sm << 8; sm |= sm << 11;
+        const uint32_t ok = ~(uint32_t)(sm >> 32);  // bit j set: window valid
+
+        {   // empty-read check, see rows_kernel
+            const uint32_t prev_bit = (i1 >> 15) & 1u;
+            const uint32_t adj = inv & ((inv << 1) | prev_bit);
+            if (__builtin_expect(__ballot(adj != 0) != 0, 0)) {
+                if (adj) {
+                    const uint64_t base_off = (r << 10) + lane * 16;
+                    for (uint32_t t = 0; t < 16; ++t) {
+                        if (!((adj >> t) & 1u)) continue;
+                        const uint64_t o = base_off + t;
+                        if (o >= p.n_bytes) continue;
+                        if (p.bases[o] == '\n' && (o == 0 || p.bases[o - 1] == '\n')) atomicOr(p.status, 1u);
+                    }
+                }
+            }
+        }
+
+        // ---- phase A: 16 canonical k-mers, 16 prefilter words in flight
+        uint64_t canon[16];
+        uint32_t fw[16], fm[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            constexpr int dummy = 0; (void)dummy;
+            const uint32_t fs = 2 * (15 - j);          // forward: bits [fs, fs+54) of F2:F1:F0
+            const uint32_t f_lo = funnel(F1, F0, fs);
+            const uint32_t f_hi = funnel(F2, F1, fs) & MASK_HI;
+            const uint32_t rs = 12 + 2 * j;            // reverse complement: bits [rs, rs+54) of R2:R1:R0
+            uint32_t r_lo, r_hi;
+            if (rs < 32) {
+                r_lo = funnel(R1, R0, rs);
+                r_hi = funnel(R2, R1, rs) & MASK_HI;
+            } else {
+                r_lo = funnel(R2, R1, rs - 32);
+                r_hi = (R2 >> (rs - 32)) & MASK_HI;
+            }
+            const uint64_t fwd = ((uint64_t)f_hi << 32) | f_lo;
+            const uint64_t rc = ((uint64_t)r_hi << 32) | r_lo;
+            canon[j] = fwd < rc ? fwd : rc;
+            const uint32_t h = vg_fhash_word(canon[j]);
+            fw[j] = s_filter[h >> fshift];
+            fm[j] = vg_fhash_bits_small(h);
+        }
+        // ---- phase B: pass masks
+        uint64_t ball[16];
+        uint32_t total = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t sel = (uint32_t)((int32_t)(ok << (31 - j)) >> 31);  // all ones iff window j valid
+            const bool pass = (fw[j] & fm[j] & sel) == fm[j];
+            ball[j] = __ballot(pass);
+            total += (uint32_t)__popcll(ball[j]);
+        }
+        if (total == 0) continue;
+        if (__builtin_expect(qtail - qhead + total <= VG_QCAP, 1)) {
+            // ---- phase C: compact into the ring
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (ball[j]) {
+                    if ((ball[j] >> lane) & 1ull) {
+                        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball[j] >> 32),
+                                             __builtin_amdgcn_mbcnt_lo((uint32_t)ball[j], qtail));
+                        s_queue[pos & (VG_QCAP - 1)] = canon[j];
+                    }
+                    qtail += (uint32_t)__popcll(ball[j]);
+                }
+            }
+            while (qtail - qhead >= 64u) {
+                probe_finish(p.table, pd);
+                probe_issue(p.table, s_queue, qhead, 64u, lane, pd);
+                qhead += 64u;
+            }
+        } else {
+            // ---- slow path: flush, then one step at a time
+            probe_finish(p.table, pd);
+            while (qtail != qhead) {
+                const uint32_t n = qtail - qhead < 64u ? qtail - qhead : 64u;
+                probe_issue(p.table, s_queue, qhead, n, lane, pd);
+                probe_finish(p.table, pd);
+                qhead += n;
+            }
+#pragma unroll 1
+            for (int j = 0; j < 16; ++j) {
+                // select step j's values without unrolling (keeps the cold path small)
+                uint64_t cj = canon[0];
+                uint64_t bj = ball[0];
+#pragma unroll
+                for (int q = 1; q < 16; ++q) {
+                    if (q == j) { cj = canon[q]; bj = ball[q]; }
+                }
+                if (!bj) continue;
+                if ((bj >> lane) & 1ull) {
+                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bj >> 32),
+                                         __builtin_amdgcn_mbcnt_lo((uint32_t)bj, qtail));
+                    s_queue[pos & (VG_QCAP - 1)] = cj;
+                }
+                const uint32_t n = (uint32_t)__popcll(bj);
+                qtail += n;
+                probe_issue(p.table, s_queue, qhead, n, lane, pd);
+                probe_finish(p.table, pd);
+                qhead += n;
+            }
+        }
+    }
+    probe_finish(p.table, pd);
+    while (qtail != qhead) {
+        const uint32_t n = qtail - qhead < 64u ? qtail - qhead : 64u;
+        probe_issue(p.table, s_queue, qhead, n, lane, pd);
+        probe_finish(p.table, pd);
+        qhead += n;
     }
 }
 
@@ -422,7 +669,7 @@ __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t 
     }
     t.slots[s].key_index = (uint32_t)i;
     key_slot[i] = (uint32_t)s;
-    atomicOr(&filter_rw[vg_fhash_word(canon) >> t.filter_shift], vg_fhash_bits(canon));
+    atomicOr(&filter_rw[vg_fhash_word(canon) >> t.filter_shift], vg_fhash_bits(canon, t.filter_words_log2));
 }
 
 __global__ void counts_reset_kernel(VgSlot* slots, uint64_t cap)
@@ -508,6 +755,16 @@ static hipError_t launch_rows_t(const RowParams& p, uint32_t grid, uint32_t bloc
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((rows_kernel<MODE, FLDS>), dim3(grid), dim3(block), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_count27_lds(const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)
+{
+    const size_t lds = rows_lds_bytes(MODE_COUNT, true, p.table.filter_words_log2, block);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&count27_lds_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(count27_lds_kernel, dim3(grid), dim3(block), lds, st, p);
     return hipGetLastError();
 }
 
