@@ -407,4 +407,4 @@ def test_dense_hits_overflow_path(ctx, k):
     t = o.Table(keys)
     t.count_block(block, k)
     assert np.array_equal(cov, t.counts())
-    assert (cov == 255).any() and cov.min() > 0
+    assert (cov == 255).any()

@@ -18,7 +18,7 @@ def kernel_stats(db):
     return "\n".join(out)
 
 
-def pmc_stats(db, kernel_filter="rows_kernel"):
+def pmc_stats(db, kernel_filter=("rows_kernel", "count27", "seq_kernel")):
     cur = sqlite3.connect(db).cursor()
     try:
         rows = cur.execute(
@@ -28,7 +28,7 @@ def pmc_stats(db, kernel_filter="rows_kernel"):
         return ""
     out = [f"## PMC: {db}", f"{'dispatches':>10} {'sum':>22} {'per_dispatch':>22}  counter  kernel"]
     for kn, cn, nd, s in rows:
-        if kernel_filter and kernel_filter not in kn:
+        if kernel_filter and not any(f in kn for f in kernel_filter):
             continue
         out.append(f"{nd:10d} {s:22.1f} {s / max(nd, 1):22.1f}  {cn}  {kn[:60]}")
     return "\n".join(out) if len(out) > 2 else ""

@@ -30,8 +30,8 @@ struct ImageHeader {  // first 256 bytes of the table image
     uint32_t filter_words_log2;
     uint64_t n_keys;
     uint64_t cap;
-    uint64_t off_slots, off_key_slot, off_filter, total_bytes;
-    uint8_t pad[256 - 8 - 4 - 4 - 8 - 8 - 32];
+    uint64_t off_slots, off_key_slot, off_filter, off_sfx, total_bytes;
+    uint8_t pad[256 - 8 - 4 - 4 - 8 - 8 - 40];
 };
 static_assert(sizeof(ImageHeader) == 256, "image header is 256 bytes");
 
@@ -62,6 +62,7 @@ struct vgmi_ctx {
     TableView tv{};
     uint32_t* d_key_slot = nullptr;
     bool filter_in_lds = false;
+    bool fast27 = false;         // k = 27 and a sparse suffix bitmap: count27_lds_kernel
     bool force_generic = false;  // VGMI_GENERIC_KERNEL=1: take the generic row kernel (A/B testing)
 
     // nodes / flags / outputs
@@ -166,7 +167,10 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     h.off_slots = 256;
     h.off_key_slot = align(h.off_slots + cap * sizeof(VgSlot));
     h.off_filter = align(h.off_key_slot + (n_keys ? n_keys : 1) * 4);
-    h.total_bytes = align(h.off_filter + (4ULL << h.filter_words_log2));
+    // suffix bitmap of the fast kernel (128 KiB); present whenever k-mers are at least 10 bases
+    h.off_sfx = k >= VG_SFX_BASES ? align(h.off_filter + (4ULL << h.filter_words_log2)) : 0;
+    h.total_bytes = h.off_sfx ? align(h.off_sfx + (uint64_t)VG_SFX_WORDS * 4)
+                              : align(h.off_filter + (4ULL << h.filter_words_log2));
 }
 
 // LDS budget of the count kernel with an LDS-resident filter: filter + 16 wave queues + LUTs
@@ -180,6 +184,9 @@ int adopt_image(vgmi_ctx* c)
     c->tv.filter = reinterpret_cast<const uint32_t*>(c->d_image + h.off_filter);
     c->tv.filter_words_log2 = h.filter_words_log2;
     c->tv.filter_shift = 32 - h.filter_words_log2;
+    c->tv.sfx = h.off_sfx ? reinterpret_cast<const uint32_t*>(c->d_image + h.off_sfx) : nullptr;
+    // the fast kernel pays off while the 2^20-bit suffix bitmap is sparse (2 entries per key)
+    c->fast27 = h.k == 27 && h.off_sfx && 2 * h.n_keys <= VG_SFX_BITS / 8;
     c->d_key_slot = reinterpret_cast<uint32_t*>(c->d_image + h.off_key_slot);
     c->filter_in_lds = filter_fits_lds(h.filter_words_log2);
     HIPCHK(c, hipMalloc(&c->d_cov, h.n_keys ? h.n_keys : 1));
@@ -197,6 +204,7 @@ RowParams row_params(vgmi_ctx* c, const char* d_bases, size_t n_bytes, uint32_t 
     p.status = c->d_status;
     p.table = c->tv;
     p.keys_out = nullptr;
+    if (const char* d = getenv("VGMI_DBG")) p.dbg = (uint32_t)atoi(d);
     p.bloom = c->bv;
     return p;
 }
@@ -220,10 +228,22 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
     if (k & 1) {
         uint32_t grid, block;
         rows_geometry(c, c->filter_in_lds, grid, block);
-        if (k == 27 && c->filter_in_lds && !c->force_generic)
-            HIPCHK(c, launch_count27_lds(p, grid, block, st));
-        else
+        if (c->fast27 && !c->force_generic) {
+            // complete 1 KiB rows -> fast kernel; the ragged tail row (if any) -> generic kernel,
+            // which takes its halo from the last complete row
+            p.row_end = n_bytes >> 10;
+            if (p.row_end) {
+                rows_geometry(c, true, grid, block);
+                HIPCHK(c, launch_count27_lds(p, grid, block, st));
+            }
+            if (n_bytes & 1023) {
+                p.row_begin = p.row_end;
+                rows_geometry(c, c->filter_in_lds, grid, block);
+                HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, 1, block, st));
+            }
+        } else {
             HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, grid, block, st));
+        }
     } else {
         if (!d_read_off) return fail(c, VGMI_E_INVALID, "even k needs read offsets");
         HIPCHK(c, launch_seq(K_MODE_COUNT, p, d_read_off, n_reads, st));
@@ -389,7 +409,8 @@ int vgmi_table_upload(vgmi_ctx* c, const uint64_t* keys, size_t n_keys, uint32_t
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_keys), n_keys * 8));
         HIPCHK(c, hipMemcpyAsync(d_keys, keys, n_keys * 8, hipMemcpyHostToDevice, c->stream));
         hipError_t e = launch_table_insert(c->tv, d_keys, n_keys, k, c->d_key_slot,
-                                           const_cast<uint32_t*>(c->tv.filter), c->d_status, c->stream);
+                                           const_cast<uint32_t*>(c->tv.filter), const_cast<uint32_t*>(c->tv.sfx),
+                                           c->d_status, c->stream);
         if (e != hipSuccess) { (void)hipFree(d_keys); HIPCHK(c, e); }
     }
     hipError_t e = hipStreamSynchronize(c->stream);

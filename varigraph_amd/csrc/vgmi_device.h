@@ -133,6 +133,28 @@ VG_HD uint32_t vg_fhash_bits(uint64_t canon, uint32_t filter_words_log2)
 {
     return filter_words_log2 <= 15 ? vg_fhash_bits_small(vg_fhash_word(canon)) : vg_fhash_bits_large(canon);
 }
+// reverse complement of a 2-bit packed k-mer (first base most significant)
+VG_HD uint64_t vg_revcomp(uint64_t x, uint32_t k)
+{
+    uint64_t r = ~x;
+    // reverse the order of the 32 two-bit fields of the 64-bit word
+    r = ((r >> 2) & 0x3333333333333333ULL) | ((r & 0x3333333333333333ULL) << 2);
+    r = ((r >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((r & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    r = ((r >> 8) & 0x00FF00FF00FF00FFULL) | ((r & 0x00FF00FF00FF00FFULL) << 8);
+    r = ((r >> 16) & 0x0000FFFF0000FFFFULL) | ((r & 0x0000FFFF0000FFFFULL) << 16);
+    r = (r >> 32) | (r << 32);
+    return r >> (64 - 2 * k);
+}
+
+// Suffix bitmap of the fast read kernel: one bit per 10-mer (2^20 bits = 128 KiB, LDS resident).
+// Bit s is set iff s is the 2-bit value of the LAST 10 bases of a graph k-mer in EITHER
+// orientation, so a read k-mer is tested in the orientation it is read in (no reverse
+// complement, no hash) and can only pass if its last 10 bases occur at the end of some graph
+// k-mer or of its reverse complement.
+#define VG_SFX_BASES 10u
+#define VG_SFX_BITS (1u << (2 * VG_SFX_BASES))
+#define VG_SFX_WORDS (VG_SFX_BITS / 32)
+
 // slot hash of the exact table (evaluated only for filter passes)
 VG_HD uint64_t vg_thash(uint64_t canon)
 {

@@ -16,6 +16,7 @@ struct TableView {
     const uint32_t* filter;     // blocked-Bloom prefilter, 1 << filter_words_log2 words
     uint32_t filter_words_log2; // >= 2
     uint32_t filter_shift;      // 32 - filter_words_log2
+    const uint32_t* sfx;        // suffix bitmap (VG_SFX_WORDS words) or nullptr, see vgmi_device.h
 };
 
 #define VG_BLOOM_MAX_HASH 32
@@ -30,7 +31,10 @@ struct BloomView {
 struct RowParams {
     const uint8_t* bases;
     uint64_t n_bytes;
+    uint64_t row_begin;   // rows_kernel: first 1 KiB row to process (earlier rows only provide the halo)
+    uint64_t row_end;     // count27_lds_kernel: one past the last row; every row below it is complete
     uint32_t k;
+    uint32_t dbg;         // tuning experiments only (VGMI_DBG): 1 = drop queued k-mers unprobed, 2 = skip compaction
     uint32_t* status;     // bit0 empty read, bit1 bad key, bit2 duplicate key
     TableView table;      // MODE_COUNT
     uint64_t* keys_out;   // MODE_KEYS
@@ -49,7 +53,7 @@ hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, u
 hipError_t launch_seq(int mode, const RowParams& p, const uint64_t* read_off, uint64_t n_reads, hipStream_t st);
 hipError_t launch_table_clear(VgSlot* slots, uint64_t cap, hipStream_t st);
 hipError_t launch_table_insert(const TableView& t, const uint64_t* keys, uint64_t n, uint32_t k, uint32_t* key_slot,
-                               uint32_t* filter_rw, uint32_t* status, hipStream_t st);
+                               uint32_t* filter_rw, uint32_t* sfx_rw, uint32_t* status, hipStream_t st);
 hipError_t launch_counts_reset(VgSlot* slots, uint64_t cap, hipStream_t st);
 hipError_t launch_cov(const VgSlot* slots, const uint32_t* key_slot, uint64_t n, const uint8_t* flag, uint8_t* cov,
                       unsigned long long* hist, hipStream_t st);

@@ -198,12 +198,14 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
     }
     __syncthreads();
 
-    // ---- this wave's contiguous row range
+    // ---- this wave's contiguous row range within [row_begin, total_rows)
     const uint64_t total_rows = (p.n_bytes + 1023) >> 10;
+    if (p.row_begin >= total_rows) return;
+    const uint64_t span = total_rows - p.row_begin;
     const uint64_t total_waves = (uint64_t)gridDim.x * nwaves;
-    const uint64_t rpw = (total_rows + total_waves - 1) / total_waves;
+    const uint64_t rpw = (span + total_waves - 1) / total_waves;
     const uint64_t gw = (uint64_t)blockIdx.x * nwaves + wave;
-    uint64_t r0 = gw * rpw;
+    uint64_t r0 = p.row_begin + gw * rpw;
     uint64_t r1 = r0 + rpw < total_rows ? r0 + rpw : total_rows;
     if (r0 >= r1) return;
 
@@ -339,54 +341,97 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
 }
 
 // ------------------------------------------------------------------------------------------
-// fast count kernel: k = 27 (every BASELINE.json configuration), prefilter resident in LDS.
+// fast count kernel: k = 27 (every BASELINE.json configuration), small graph (<= 65 536 k-mers).
 //
-// Same row walk as rows_kernel, restructured for instruction-level parallelism:
-//   phase A  all 16 canonical k-mers of the lane's chunk are extracted with compile-time funnel
-//            shifts and their 16 prefilter words are requested from LDS back to back;
-//   phase B  16 ballots give the per-step pass masks and the row's total;
-//   phase C  passing k-mers are compacted into the wave's LDS ring (rank = mbcnt over the step's
-//            mask, no atomics);
-//   drain    whenever >= 64 k-mers are queued, 64 exact-table probes are ISSUED (one 16-byte
-//            load per lane) and the previous batch, whose loads have been in flight for ~25
-//            steps, is FINISHED (compare, saturating atomicAdd, rare second probe).
+// C2-class workloads are bound by the integer ALU, not by HBM (the whole index is on-chip), so
+// this kernel minimises VALU instructions per k-mer.  Same row walk as rows_kernel, but
+//   phase A  the prefilter is a direct-indexed SUFFIX BITMAP in LDS (vgmi_device.h): the index is
+//            simply the low 20 bits of the forward k-mer, one funnel shift -- no reverse
+//            complement, no canonical min, no hash; the 16 words are requested back to back;
+//   phase B  16 ballots give the per-step pass masks (valid window && bit set) and the row total;
+//   phase C  passing k-mers (forward orientation, high word extracted only now) are compacted
+//            into the wave's LDS ring (rank = mbcnt over the step's mask);
+//   drain    whenever >= 64 k-mers are queued, 64 lanes canonicalise (min with the reverse
+//            complement), hash and ISSUE one 16-byte exact-table load each, and the previous
+//            batch -- in flight since the last drain -- is FINISHED (compare, saturating
+//            atomicAdd, rare second probe).
 // A row whose passes would overflow the ring (reads made of graph k-mers only) takes a slow,
 // obviously-correct path: flush, then push+probe one step at a time.
 // ------------------------------------------------------------------------------------------
 struct Pending {
-    uint64_t canon;
+    uint64_t canon;   // canonical k-mer | probe distance << 54
     uint64_t slot;
     uint4 v;
     bool active;
 };
 
+#define VG_Q_KMER_MASK ((1ULL << 54) - 1)
+
+// Ring entries are 64-bit: bits [0,54) a k-mer (forward orientation when first queued, canonical
+// when re-queued), bits [54,64) the probe distance already covered.
+template <uint32_t K>
 __device__ __forceinline__ void probe_issue(const TableView& t, const uint64_t* queue, uint32_t head, uint32_t n,
                                             uint32_t lane, Pending& pd)
 {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // The ring is written and read by lanes of ONE wave: DS operations of a wave execute in
+    // order, so no memory fence is needed (a fence here would also drain vmcnt and serialise
+    // the probe loads that are deliberately left in flight); the wave barrier only stops the
+    // compiler from moving the read above the writes.
+    __builtin_amdgcn_wave_barrier();
     pd.active = lane < n;
     if (pd.active) {
-        pd.canon = queue[(head + lane) & (VG_QCAP - 1)];
-        pd.slot = vg_thash(pd.canon) & t.cap_mask;
+        const uint64_t e = queue[(head + lane) & (VG_QCAP - 1)];
+        const uint64_t x = e & VG_Q_KMER_MASK;
+        const uint64_t rc = vg_revcomp(x, K);
+        const uint64_t canon = x < rc ? x : rc;   // idempotent for re-queued (already canonical) entries
+        pd.canon = canon | (e & ~VG_Q_KMER_MASK);
+        pd.slot = (vg_thash(canon) + (e >> 54)) & t.cap_mask;
         pd.v = *reinterpret_cast<const uint4*>(&t.slots[pd.slot]);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ void probe_finish(const TableView& t, Pending& pd)
+// Finish the batch issued earlier.  A lane whose slot holds another k-mer does NOT chase the
+// chain (that would stall the whole wave for a memory round trip on almost every batch): it puts
+// its k-mer back into the ring with the probe distance advanced, to ride with a later batch.
+__device__ __forceinline__ void probe_finish(const TableView& t, Pending& pd, uint64_t* queue, uint32_t qhead,
+                                             uint32_t& qtail)
 {
+    bool again = false;
     if (pd.active) {
-        uint64_t s = pd.slot;
-        uint4 v = pd.v;
-        for (;;) {
-            const uint64_t c = ((uint64_t)v.y << 32) | v.x;
-            if (c == pd.canon) {
-                if (v.z < 255u) atomicAdd(&t.slots[s].count, 1u);
-                break;
+        const uint64_t c = ((uint64_t)pd.v.y << 32) | pd.v.x;
+        const uint64_t canon = pd.canon & VG_Q_KMER_MASK;
+        if (c == canon) {
+            if (pd.v.z < 255u) atomicAdd(&t.slots[pd.slot].count, 1u);
+        } else if (c != VG_EMPTY) {
+            again = true;
+        }
+    }
+    const uint64_t ball = __builtin_amdgcn_ballot_w64(again);
+    if (__builtin_expect(ball != 0, 0)) {
+        const uint32_t n = (uint32_t)__builtin_popcountll(ball);
+        const bool fits = qtail - qhead + n <= VG_QCAP && (pd.canon >> 54) < 1023u;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(again && !fits) == 0, 1)) {
+            if (again) {
+                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)ball, qtail));
+                queue[pos & (VG_QCAP - 1)] = pd.canon + (1ULL << 54);
             }
-            if (c == VG_EMPTY) break;
-            s = (s + 1) & t.cap_mask;
-            v = *reinterpret_cast<const uint4*>(&t.slots[s]);
+            qtail += n;
+        } else if (again) {
+            // no room (or an absurdly long chain): chase it here
+            const uint64_t canon = pd.canon & VG_Q_KMER_MASK;
+            uint64_t sl = pd.slot;
+            for (;;) {
+                sl = (sl + 1) & t.cap_mask;
+                const uint4 v = *reinterpret_cast<const uint4*>(&t.slots[sl]);
+                const uint64_t c = ((uint64_t)v.y << 32) | v.x;
+                if (c == canon) {
+                    if (v.z < 255u) atomicAdd(&t.slots[sl].count, 1u);
+                    break;
+                }
+                if (c == VG_EMPTY) break;
+            }
         }
     }
     pd.active = false;
@@ -402,8 +447,8 @@ __global__ __launch_bounds__(1024) void count27_lds_kernel(RowParams p)
     const uint32_t wave = tid >> 6;
     const uint32_t nwaves = blockDim.x >> 6;
 
-    uint32_t* s_filter = reinterpret_cast<uint32_t*>(smem);
-    size_t off = (size_t)4 << p.table.filter_words_log2;
+    uint32_t* s_sfx = reinterpret_cast<uint32_t*>(smem);
+    size_t off = (size_t)VG_SFX_WORDS * 4;
     uint64_t* s_queue = reinterpret_cast<uint64_t*>(smem + off) + (size_t)wave * VG_QCAP;
     off += (size_t)nwaves * VG_QCAP * 8;
     uint8_t* s_lut_code = smem + off;
@@ -414,31 +459,30 @@ __global__ __launch_bounds__(1024) void count27_lds_kernel(RowParams p)
         s_lut_inv[i] = (uint8_t)(c >> 2);
     }
     {
-        const uint32_t nq = 1u << (p.table.filter_words_log2 - 2);
-        const uint4* src = reinterpret_cast<const uint4*>(p.table.filter);
-        uint4* dst = reinterpret_cast<uint4*>(s_filter);
-        for (uint32_t i = tid; i < nq; i += blockDim.x) dst[i] = src[i];
+        const uint4* src = reinterpret_cast<const uint4*>(p.table.sfx);
+        uint4* dst = reinterpret_cast<uint4*>(s_sfx);
+        for (uint32_t i = tid; i < VG_SFX_WORDS / 4; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
 
-    const uint64_t total_rows = (p.n_bytes + 1023) >> 10;
+    // rows [0, row_end) are complete 1 KiB rows, so every load below is an unconditional,
+    // perfectly coalesced dwordx4 (the ragged tail row goes to rows_kernel, see vgmi_api.cpp)
+    const uint64_t total_rows = p.row_end;
     const uint64_t total_waves = (uint64_t)gridDim.x * nwaves;
     const uint64_t rpw = (total_rows + total_waves - 1) / total_waves;
     const uint64_t gw = (uint64_t)blockIdx.x * nwaves + wave;
     const uint64_t r0 = gw * rpw;
     const uint64_t r1 = r0 + rpw < total_rows ? r0 + rpw : total_rows;
     if (r0 >= r1) return;
+    const uint4* rows = reinterpret_cast<const uint4*>(p.bases) + lane;  // row r, this lane: rows[r * 64]
 
-    const uint32_t fshift = p.table.filter_shift;
     const uint32_t src1 = (lane + 63u) & 63u, src2 = (lane + 62u) & 63u;
-    uint32_t pr1_be = 0, pr2_be = 0, pr1_rc = ~0u, pr2_rc = ~0u, pr1_inv = 0xFFFFu, pr2_inv = 0xFFFFu;
+    uint32_t pr1_be = 0, pr2_be = 0, pr1_inv = 0xFFFFu, pr2_inv = 0xFFFFu;
     if (r0 > 0) {
-        const uint4 raw = load_chunk(p.bases, p.n_bytes, ((r0 - 1) << 10) + lane * 16);
+        const uint4 raw = rows[(r0 - 1) * 64];
         uint32_t be, inv;
         encode16(raw, s_lut_code, s_lut_inv, be, inv);
-        const uint32_t rcw = rc_word(be);
         pr1_be = __shfl(be, src1);   pr2_be = __shfl(be, src2);
-        pr1_rc = __shfl(rcw, src1);  pr2_rc = __shfl(rcw, src2);
         pr1_inv = __shfl(inv, src1); pr2_inv = __shfl(inv, src2);
     }
 
@@ -447,26 +491,21 @@ __global__ __launch_bounds__(1024) void count27_lds_kernel(RowParams p)
     pd.active = false;
     pd.canon = 0; pd.slot = 0; pd.v = make_uint4(0, 0, 0, 0);
 
-    uint4 raw_next = load_chunk(p.bases, p.n_bytes, (r0 << 10) + lane * 16);
+    uint4 raw_next = rows[r0 * 64];
     for (uint64_t r = r0; r < r1; ++r) {
         const uint4 raw = raw_next;
-        if (r + 1 < r1) raw_next = load_chunk(p.bases, p.n_bytes, ((r + 1) << 10) + lane * 16);
+        raw_next = rows[(r + 1 < r1 ? r + 1 : r) * 64];  // prefetch (the last iteration re-reads its own row)
 
         uint32_t be, inv;
         encode16(raw, s_lut_code, s_lut_inv, be, inv);
-        const uint32_t rcw = rc_word(be);
         const uint32_t r1_be = __shfl(be, src1), r2_be = __shfl(be, src2);
-        const uint32_t r1_rc = __shfl(rcw, src1), r2_rc = __shfl(rcw, src2);
         const uint32_t r1_inv = __shfl(inv, src1), r2_inv = __shfl(inv, src2);
         const uint32_t F0 = be;
         const uint32_t F1 = lane >= 1 ? r1_be : pr1_be;
         const uint32_t F2 = lane >= 2 ? r2_be : pr2_be;
-        const uint32_t R2 = rcw;
-        const uint32_t R1 = lane >= 1 ? r1_rc : pr1_rc;
-        const uint32_t R0 = lane >= 2 ? r2_rc : pr2_rc;
         const uint32_t i1 = lane >= 1 ? r1_inv : pr1_inv;
         const uint32_t i2 = lane >= 2 ? r2_inv : pr2_inv;
-        pr1_be = r1_be; pr2_be = r2_be; pr1_rc = r1_rc; pr2_rc = r2_rc; pr1_inv = r1_inv; pr2_inv = r2_inv;
+        pr1_be = r1_be; pr2_be = r2_be; pr1_inv = r1_inv; pr2_inv = r2_inv;
 
         // bit (32+j) of sm: some base of the 27-mer ending at own base j is not a base
         uint64_t sm = ((uint64_t)inv << 32) | ((uint64_t)i1 << 16) | (uint64_t)i2;
@@ -489,98 +528,94 @@ __global__ __launch_bounds__(1024) void count27_lds_kernel(RowParams p)
             }
         }
 
-        // ---- phase A: 16 canonical k-mers, 16 prefilter words in flight
-        uint64_t canon[16];
-        uint32_t fw[16], fm[16];
+        // ---- phase A: low word of the 16 forward k-mers, 16 bitmap words in flight
+        uint32_t flo[16], fw[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            constexpr int dummy = 0; (void)dummy;
-            const uint32_t fs = 2 * (15 - j);          // forward: bits [fs, fs+54) of F2:F1:F0
-            const uint32_t f_lo = funnel(F1, F0, fs);
-            const uint32_t f_hi = funnel(F2, F1, fs) & MASK_HI;
-            const uint32_t rs = 12 + 2 * j;            // reverse complement: bits [rs, rs+54) of R2:R1:R0
-            uint32_t r_lo, r_hi;
-            if (rs < 32) {
-                r_lo = funnel(R1, R0, rs);
-                r_hi = funnel(R2, R1, rs) & MASK_HI;
-            } else {
-                r_lo = funnel(R2, R1, rs - 32);
-                r_hi = (R2 >> (rs - 32)) & MASK_HI;
-            }
-            const uint64_t fwd = ((uint64_t)f_hi << 32) | f_lo;
-            const uint64_t rc = ((uint64_t)r_hi << 32) | r_lo;
-            canon[j] = fwd < rc ? fwd : rc;
-            const uint32_t h = vg_fhash_word(canon[j]);
-            fw[j] = s_filter[h >> fshift];
-            fm[j] = vg_fhash_bits_small(h);
+            flo[j] = funnel(F1, F0, 2 * (15 - j));        // bits [2(15-j), +32) of F2:F1:F0
+            fw[j] = s_sfx[(flo[j] >> 5) & (VG_SFX_WORDS - 1)];
         }
-        // ---- phase B: pass masks
+        // ---- phase B: pass masks (per-lane bools live in SGPR pairs; the ballot is the same mask)
+        bool pass[16];
         uint64_t ball[16];
-        uint32_t total = 0;
+        uint32_t cnt[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const uint32_t sel = (uint32_t)((int32_t)(ok << (31 - j)) >> 31);  // all ones iff window j valid
-            const bool pass = (fw[j] & fm[j] & sel) == fm[j];
-            ball[j] = __ballot(pass);
-            total += (uint32_t)__popcll(ball[j]);
+            pass[j] = ((ok >> j) & 1u) && ((fw[j] >> (flo[j] & 31u)) & 1u);
+            ball[j] = __builtin_amdgcn_ballot_w64(pass[j]);
+            cnt[j] = (uint32_t)__builtin_popcountll(ball[j]);
         }
-        if (total == 0) continue;
-        if (__builtin_expect(qtail - qhead + total <= VG_QCAP, 1)) {
-            // ---- phase C: compact into the ring
+        // ---- phase C: compact the forward k-mers into the ring, four steps at a time so that the
+        // ring (128 entries) is checked for space often enough; a segment that would not fit
+        // (dense hits) hands the rest of the row to the slow path below.
+        int slow_from = 16;
+        if (p.dbg & 2u) continue;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (ball[j]) {
-                    if ((ball[j] >> lane) & 1ull) {
-                        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball[j] >> 32),
-                                             __builtin_amdgcn_mbcnt_lo((uint32_t)ball[j], qtail));
-                        s_queue[pos & (VG_QCAP - 1)] = canon[j];
-                    }
-                    qtail += (uint32_t)__popcll(ball[j]);
-                }
+        for (int seg = 0; seg < 4; ++seg) {
+            if (slow_from != 16) break;
+            const uint32_t seg_total = cnt[4 * seg] + cnt[4 * seg + 1] + cnt[4 * seg + 2] + cnt[4 * seg + 3];
+            if (seg_total == 0) continue;
+            if (__builtin_expect(qtail - qhead + seg_total > VG_QCAP, 0)) {
+                slow_from = 4 * seg;
+                break;
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = 4 * seg + q;
+                if (pass[j]) {
+                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball[j] >> 32),
+                                         __builtin_amdgcn_mbcnt_lo((uint32_t)ball[j], qtail));
+                    const uint32_t f_hi = funnel(F2, F1, 2 * (15 - j)) & MASK_HI;
+                    s_queue[pos & (VG_QCAP - 1)] = ((uint64_t)f_hi << 32) | flo[j];
+                }
+                qtail += cnt[j];
+            }
+            if (p.dbg & 1u) { qhead = qtail; continue; }
             while (qtail - qhead >= 64u) {
-                probe_finish(p.table, pd);
-                probe_issue(p.table, s_queue, qhead, 64u, lane, pd);
+                probe_finish(p.table, pd, s_queue, qhead, qtail);
+                probe_issue<K>(p.table, s_queue, qhead, 64u, lane, pd);
                 qhead += 64u;
             }
-        } else {
+        }
+        if (__builtin_expect(slow_from != 16, 0)) {
             // ---- slow path: flush, then one step at a time
-            probe_finish(p.table, pd);
+            probe_finish(p.table, pd, s_queue, qhead, qtail);
             while (qtail != qhead) {
                 const uint32_t n = qtail - qhead < 64u ? qtail - qhead : 64u;
-                probe_issue(p.table, s_queue, qhead, n, lane, pd);
-                probe_finish(p.table, pd);
+                probe_issue<K>(p.table, s_queue, qhead, n, lane, pd);
                 qhead += n;
+                probe_finish(p.table, pd, s_queue, qhead, qtail);
             }
 #pragma unroll 1
-            for (int j = 0; j < 16; ++j) {
-                // select step j's values without unrolling (keeps the cold path small)
-                uint64_t cj = canon[0];
-                uint64_t bj = ball[0];
-#pragma unroll
-                for (int q = 1; q < 16; ++q) {
-                    if (q == j) { cj = canon[q]; bj = ball[q]; }
-                }
+            for (int j = slow_from; j < 16; ++j) {
+                const uint32_t fs = 2 * (15 - j);
+                const uint32_t f_lo = funnel(F1, F0, fs);
+                const uint32_t f_hi = funnel(F2, F1, fs) & MASK_HI;
+                const uint32_t w = s_sfx[(f_lo >> 5) & (VG_SFX_WORDS - 1)];
+                const bool ps = ((ok >> j) & 1u) && ((w >> (f_lo & 31u)) & 1u);
+                const uint64_t bj = __builtin_amdgcn_ballot_w64(ps);
                 if (!bj) continue;
-                if ((bj >> lane) & 1ull) {
+                if (ps) {
                     const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bj >> 32),
                                          __builtin_amdgcn_mbcnt_lo((uint32_t)bj, qtail));
-                    s_queue[pos & (VG_QCAP - 1)] = cj;
+                    s_queue[pos & (VG_QCAP - 1)] = ((uint64_t)f_hi << 32) | f_lo;
                 }
-                const uint32_t n = (uint32_t)__popcll(bj);
-                qtail += n;
-                probe_issue(p.table, s_queue, qhead, n, lane, pd);
-                probe_finish(p.table, pd);
-                qhead += n;
+                qtail += (uint32_t)__builtin_popcountll(bj);
+                while (qtail != qhead) {
+                    const uint32_t n = qtail - qhead < 64u ? qtail - qhead : 64u;
+                    probe_issue<K>(p.table, s_queue, qhead, n, lane, pd);
+                    qhead += n;
+                    probe_finish(p.table, pd, s_queue, qhead, qtail);
+                }
             }
         }
     }
-    probe_finish(p.table, pd);
+    probe_finish(p.table, pd, s_queue, qhead, qtail);
     while (qtail != qhead) {
         const uint32_t n = qtail - qhead < 64u ? qtail - qhead : 64u;
-        probe_issue(p.table, s_queue, qhead, n, lane, pd);
-        probe_finish(p.table, pd);
+        probe_issue<K>(p.table, s_queue, qhead, n, lane, pd);
         qhead += n;
+        probe_finish(p.table, pd, s_queue, qhead, qtail);
     }
 }
 
@@ -645,7 +680,7 @@ __global__ void table_clear_kernel(VgSlot* slots, uint64_t cap)
 }
 
 __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t n, uint32_t k,
-                                    uint32_t* key_slot, uint32_t* filter_rw, uint32_t* status)
+                                    uint32_t* key_slot, uint32_t* filter_rw, uint32_t* sfx_rw, uint32_t* status)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -670,6 +705,12 @@ __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t 
     t.slots[s].key_index = (uint32_t)i;
     key_slot[i] = (uint32_t)s;
     atomicOr(&filter_rw[vg_fhash_word(canon) >> t.filter_shift], vg_fhash_bits(canon, t.filter_words_log2));
+    if (sfx_rw) {
+        const uint32_t a = (uint32_t)canon & (VG_SFX_BITS - 1);
+        const uint32_t b = (uint32_t)vg_revcomp(canon, k) & (VG_SFX_BITS - 1);
+        atomicOr(&sfx_rw[a >> 5], 1u << (a & 31u));
+        atomicOr(&sfx_rw[b >> 5], 1u << (b & 31u));
+    }
 }
 
 __global__ void counts_reset_kernel(VgSlot* slots, uint64_t cap)
@@ -760,7 +801,7 @@ static hipError_t launch_rows_t(const RowParams& p, uint32_t grid, uint32_t bloc
 
 hipError_t launch_count27_lds(const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)
 {
-    const size_t lds = rows_lds_bytes(MODE_COUNT, true, p.table.filter_words_log2, block);
+    const size_t lds = (size_t)VG_SFX_WORDS * 4 + (size_t)(block / 64) * VG_QCAP * 8 + 512;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&count27_lds_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -801,11 +842,11 @@ hipError_t launch_table_clear(VgSlot* slots, uint64_t cap, hipStream_t st)
 }
 
 hipError_t launch_table_insert(const TableView& t, const uint64_t* keys, uint64_t n, uint32_t k, uint32_t* key_slot,
-                               uint32_t* filter_rw, uint32_t* status, hipStream_t st)
+                               uint32_t* filter_rw, uint32_t* sfx_rw, uint32_t* status, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(table_insert_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, t, keys, n, k, key_slot,
-                       filter_rw, status);
+                       filter_rw, sfx_rw, status);
     return hipGetLastError();
 }
 
