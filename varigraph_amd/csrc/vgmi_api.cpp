@@ -157,7 +157,9 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     h.k = k;
     h.n_keys = n_keys;
     uint64_t cap = 64;
-    while (cap < 4 * n_keys) cap <<= 1;  // load factor <= 0.25: ~88 % of probes end at the first slot
+    uint64_t lf_mul = 4;  // load factor <= 0.25: ~88 % of probes end at the first slot
+    if (const char* e = getenv("VGMI_TABLE_MUL")) lf_mul = (uint64_t)atoi(e) > 1 ? (uint64_t)atoi(e) : 2;
+    while (cap < lf_mul * n_keys) cap <<= 1;
     h.cap = cap;
     // prefilter: >= 16 bits per key, power of two, at least 128 bits
     uint64_t bits = 128;

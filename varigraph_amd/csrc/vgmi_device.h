@@ -137,12 +137,17 @@ VG_HD uint32_t vg_fhash_bits(uint64_t canon, uint32_t filter_words_log2)
 VG_HD uint64_t vg_revcomp(uint64_t x, uint32_t k)
 {
     uint64_t r = ~x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    r = __builtin_bitreverse64(r);  // two v_bfrev_b32; bits of each 2-bit field are now swapped
+    r = ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
+#else
     // reverse the order of the 32 two-bit fields of the 64-bit word
     r = ((r >> 2) & 0x3333333333333333ULL) | ((r & 0x3333333333333333ULL) << 2);
     r = ((r >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((r & 0x0F0F0F0F0F0F0F0FULL) << 4);
     r = ((r >> 8) & 0x00FF00FF00FF00FFULL) | ((r & 0x00FF00FF00FF00FFULL) << 8);
     r = ((r >> 16) & 0x0000FFFF0000FFFFULL) | ((r & 0x0000FFFF0000FFFFULL) << 16);
     r = (r >> 32) | (r << 32);
+#endif
     return r >> (64 - 2 * k);
 }
 

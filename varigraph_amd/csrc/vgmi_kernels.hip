@@ -475,11 +475,18 @@ __global__ __launch_bounds__(1024) void count27_lds_kernel(RowParams p)
     const uint64_t r1 = r0 + rpw < total_rows ? r0 + rpw : total_rows;
     if (r0 >= r1) return;
     const uint4* rows = reinterpret_cast<const uint4*>(p.bases) + lane;  // row r, this lane: rows[r * 64]
+    // the read block streams through once: non-temporal loads keep it from evicting the k-mer
+    // table out of the XCD's L2
+    auto load_row = [rows](uint64_t r) -> uint4 {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rows + r * 64));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
 
     const uint32_t src1 = (lane + 63u) & 63u, src2 = (lane + 62u) & 63u;
     uint32_t pr1_be = 0, pr2_be = 0, pr1_inv = 0xFFFFu, pr2_inv = 0xFFFFu;
     if (r0 > 0) {
-        const uint4 raw = rows[(r0 - 1) * 64];
+        const uint4 raw = load_row(r0 - 1);
         uint32_t be, inv;
         encode16(raw, s_lut_code, s_lut_inv, be, inv);
         pr1_be = __shfl(be, src1);   pr2_be = __shfl(be, src2);
@@ -491,10 +498,10 @@ __global__ __launch_bounds__(1024) void count27_lds_kernel(RowParams p)
     pd.active = false;
     pd.canon = 0; pd.slot = 0; pd.v = make_uint4(0, 0, 0, 0);
 
-    uint4 raw_next = rows[r0 * 64];
+    uint4 raw_next = load_row(r0);
     for (uint64_t r = r0; r < r1; ++r) {
         const uint4 raw = raw_next;
-        raw_next = rows[(r + 1 < r1 ? r + 1 : r) * 64];  // prefetch (the last iteration re-reads its own row)
+        raw_next = load_row(r + 1 < r1 ? r + 1 : r);  // prefetch (the last iteration re-reads its own row)
 
         uint32_t be, inv;
         encode16(raw, s_lut_code, s_lut_inv, be, inv);
@@ -541,7 +548,7 @@ __global__ __launch_bounds__(1024) void count27_lds_kernel(RowParams p)
         uint32_t cnt[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            pass[j] = ((ok >> j) & 1u) && ((fw[j] >> (flo[j] & 31u)) & 1u);
+            pass[j] = ((fw[j] >> (flo[j] & 31u)) & __builtin_amdgcn_ubfe(ok, j, 1)) != 0;
             ball[j] = __builtin_amdgcn_ballot_w64(pass[j]);
             cnt[j] = (uint32_t)__builtin_popcountll(ball[j]);
         }
