@@ -31,7 +31,8 @@ struct ImageHeader {  // first 256 bytes of the table image
     uint64_t n_keys;
     uint64_t cap;
     uint64_t off_slots, off_key_slot, off_filter, off_sfx, total_bytes;
-    uint8_t pad[256 - 8 - 4 - 4 - 8 - 8 - 40];
+    uint32_t sfx_bits_log2, reserved;
+    uint8_t pad[256 - 8 - 4 - 4 - 8 - 8 - 40 - 8];
 };
 static_assert(sizeof(ImageHeader) == 256, "image header is 256 bytes");
 
@@ -62,7 +63,8 @@ struct vgmi_ctx {
     TableView tv{};
     uint32_t* d_key_slot = nullptr;
     bool filter_in_lds = false;
-    bool fast27 = false;         // k = 27 and a sparse suffix bitmap: count27_lds_kernel
+    bool fast27 = false;         // k = 27: count27_kernel
+    bool fast27_lds = false;     // ... with the 2^20-bit suffix bitmap resident in LDS
     bool force_generic = false;  // VGMI_GENERIC_KERNEL=1: take the generic row kernel (A/B testing)
 
     // nodes / flags / outputs
@@ -169,10 +171,24 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     h.off_slots = 256;
     h.off_key_slot = align(h.off_slots + cap * sizeof(VgSlot));
     h.off_filter = align(h.off_key_slot + (n_keys ? n_keys : 1) * 4);
-    // suffix bitmap of the fast kernel (128 KiB); present whenever k-mers are at least 10 bases
-    h.off_sfx = k >= VG_SFX_BASES ? align(h.off_filter + (4ULL << h.filter_words_log2)) : 0;
-    h.total_bytes = h.off_sfx ? align(h.off_sfx + (uint64_t)VG_SFX_WORDS * 4)
-                              : align(h.off_filter + (4ULL << h.filter_words_log2));
+    // suffix bitmap of the fast kernels (vgmi_device.h): 2^20 bits (LDS resident) while that stays
+    // sparse, else >= 32 bits per key (2 entries per key -> <= ~6 % fill), at most 2k bits
+    h.sfx_bits_log2 = 0;
+    h.off_sfx = 0;
+    uint64_t end = h.off_filter + (4ULL << h.filter_words_log2);
+    if (k >= VG_SFX_BASES) {
+        uint32_t b = VG_SFX_LDS_LOG2;
+        if (2 * n_keys > VG_SFX_BITS / 8) {
+            // large graphs: grid bitmap (vgmi_device.h), ~3 distinct 16-mers per key -> >= 32 bits per key
+            b = ceil_log2(32 * n_keys);
+            if (b < VG_SFX_LDS_LOG2 + 1) b = VG_SFX_LDS_LOG2 + 1;
+            if (b > 40) b = 40;
+        }
+        h.sfx_bits_log2 = b;
+        h.off_sfx = align(end);
+        end = h.off_sfx + ((1ULL << b) >> 3);
+    }
+    h.total_bytes = align(end);
 }
 
 // LDS budget of the count kernel with an LDS-resident filter: filter + 16 wave queues + LUTs
@@ -187,8 +203,9 @@ int adopt_image(vgmi_ctx* c)
     c->tv.filter_words_log2 = h.filter_words_log2;
     c->tv.filter_shift = 32 - h.filter_words_log2;
     c->tv.sfx = h.off_sfx ? reinterpret_cast<const uint32_t*>(c->d_image + h.off_sfx) : nullptr;
-    // the fast kernel pays off while the 2^20-bit suffix bitmap is sparse (2 entries per key)
-    c->fast27 = h.k == 27 && h.off_sfx && 2 * h.n_keys <= VG_SFX_BITS / 8;
+    c->tv.sfx_bits_log2 = h.sfx_bits_log2;
+    c->fast27 = h.k == 27 && h.off_sfx;                       // count27_kernel applies
+    c->fast27_lds = c->fast27 && h.sfx_bits_log2 == VG_SFX_LDS_LOG2;  // with the bitmap in LDS
     c->d_key_slot = reinterpret_cast<uint32_t*>(c->d_image + h.off_key_slot);
     c->filter_in_lds = filter_fits_lds(h.filter_words_log2);
     HIPCHK(c, hipMalloc(&c->d_cov, h.n_keys ? h.n_keys : 1));
@@ -235,8 +252,9 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
             // which takes its halo from the last complete row
             p.row_end = n_bytes >> 10;
             if (p.row_end) {
-                rows_geometry(c, true, grid, block);
-                HIPCHK(c, launch_count27_lds(p, grid, block, st));
+                if (c->fast27_lds) { block = 1024; grid = (uint32_t)c->n_cu; }
+                else               { block = 256;  grid = (uint32_t)c->n_cu * 8; }
+                HIPCHK(c, launch_count27(c->fast27_lds, p, grid, block, st));
             }
             if (n_bytes & 1023) {
                 p.row_begin = p.row_end;

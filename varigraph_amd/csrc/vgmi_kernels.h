@@ -16,7 +16,8 @@ struct TableView {
     const uint32_t* filter;     // blocked-Bloom prefilter, 1 << filter_words_log2 words
     uint32_t filter_words_log2; // >= 2
     uint32_t filter_shift;      // 32 - filter_words_log2
-    const uint32_t* sfx;        // suffix bitmap (VG_SFX_WORDS words) or nullptr, see vgmi_device.h
+    const uint32_t* sfx;        // suffix bitmap (2^sfx_bits_log2 bits) or nullptr, see vgmi_device.h
+    uint32_t sfx_bits_log2;     // VG_SFX_LDS_LOG2 (LDS-resident variant) .. 2k
 };
 
 #define VG_BLOOM_MAX_HASH 32
@@ -48,7 +49,7 @@ struct SynthHaps {
     uint64_t len[VG_SYNTH_MAX_HAPS];
 };
 
-hipError_t launch_count27_lds(const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
+hipError_t launch_count27(bool lds_bitmap, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t launch_seq(int mode, const RowParams& p, const uint64_t* read_off, uint64_t n_reads, hipStream_t st);
 hipError_t launch_table_clear(VgSlot* slots, uint64_t cap, hipStream_t st);

@@ -369,7 +369,7 @@ struct Pending {
 
 // Ring entries are 64-bit: bits [0,54) a k-mer (forward orientation when first queued, canonical
 // when re-queued), bits [54,64) the probe distance already covered.
-template <uint32_t K>
+template <uint32_t K, uint32_t QC>
 __device__ __forceinline__ void probe_issue(const TableView& t, const uint64_t* queue, uint32_t head, uint32_t n,
                                             uint32_t lane, Pending& pd)
 {
@@ -380,7 +380,7 @@ __device__ __forceinline__ void probe_issue(const TableView& t, const uint64_t* 
     __builtin_amdgcn_wave_barrier();
     pd.active = lane < n;
     if (pd.active) {
-        const uint64_t e = queue[(head + lane) & (VG_QCAP - 1)];
+        const uint64_t e = queue[(head + lane) & (QC - 1)];
         const uint64_t x = e & VG_Q_KMER_MASK;
         const uint64_t rc = vg_revcomp(x, K);
         const uint64_t canon = x < rc ? x : rc;   // idempotent for re-queued (already canonical) entries
@@ -394,6 +394,7 @@ __device__ __forceinline__ void probe_issue(const TableView& t, const uint64_t* 
 // Finish the batch issued earlier.  A lane whose slot holds another k-mer does NOT chase the
 // chain (that would stall the whole wave for a memory round trip on almost every batch): it puts
 // its k-mer back into the ring with the probe distance advanced, to ride with a later batch.
+template <uint32_t QC>
 __device__ __forceinline__ void probe_finish(const TableView& t, Pending& pd, uint64_t* queue, uint32_t qhead,
                                              uint32_t& qtail)
 {
@@ -410,12 +411,12 @@ __device__ __forceinline__ void probe_finish(const TableView& t, Pending& pd, ui
     const uint64_t ball = __builtin_amdgcn_ballot_w64(again);
     if (__builtin_expect(ball != 0, 0)) {
         const uint32_t n = (uint32_t)__builtin_popcountll(ball);
-        const bool fits = qtail - qhead + n <= VG_QCAP && (pd.canon >> 54) < 1023u;
+        const bool fits = qtail - qhead + n <= QC && (pd.canon >> 54) < 1023u;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(again && !fits) == 0, 1)) {
             if (again) {
                 const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
                                      __builtin_amdgcn_mbcnt_lo((uint32_t)ball, qtail));
-                queue[pos & (VG_QCAP - 1)] = pd.canon + (1ULL << 54);
+                queue[pos & (QC - 1)] = pd.canon + (1ULL << 54);
             }
             qtail += n;
         } else if (again) {
@@ -437,7 +438,11 @@ __device__ __forceinline__ void probe_finish(const TableView& t, Pending& pd, ui
     pd.active = false;
 }
 
-__global__ __launch_bounds__(1024) void count27_lds_kernel(RowParams p)
+// LDS_SFX: suffix bitmap of 2^20 bits staged in LDS (small graphs, one 1024-thread workgroup per CU)
+//          or probed in global memory (large graphs, 256-thread workgroups, as many as fit).
+// QC:      entries of the per-wave pass ring.
+template <bool LDS_SFX, uint32_t QC>
+__global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams p)
 {
     constexpr uint32_t K = 27;
     constexpr uint32_t MASK_HI = (1u << (2 * K - 32)) - 1;  // 54-bit k-mer: low word full, 22 bits high
@@ -448,9 +453,9 @@ __global__ __launch_bounds__(1024) void count27_lds_kernel(RowParams p)
     const uint32_t nwaves = blockDim.x >> 6;
 
     uint32_t* s_sfx = reinterpret_cast<uint32_t*>(smem);
-    size_t off = (size_t)VG_SFX_WORDS * 4;
-    uint64_t* s_queue = reinterpret_cast<uint64_t*>(smem + off) + (size_t)wave * VG_QCAP;
-    off += (size_t)nwaves * VG_QCAP * 8;
+    size_t off = LDS_SFX ? (size_t)VG_SFX_WORDS * 4 : 0;
+    uint64_t* s_queue = reinterpret_cast<uint64_t*>(smem + off) + (size_t)wave * QC;
+    off += (size_t)nwaves * QC * 8;
     uint8_t* s_lut_code = smem + off;
     uint8_t* s_lut_inv = s_lut_code + 256;
     for (uint32_t i = tid; i < 256; i += blockDim.x) {
@@ -458,12 +463,13 @@ __global__ __launch_bounds__(1024) void count27_lds_kernel(RowParams p)
         s_lut_code[i] = (uint8_t)(c & 3u);
         s_lut_inv[i] = (uint8_t)(c >> 2);
     }
-    {
+    if (LDS_SFX) {
         const uint4* src = reinterpret_cast<const uint4*>(p.table.sfx);
         uint4* dst = reinterpret_cast<uint4*>(s_sfx);
         for (uint32_t i = tid; i < VG_SFX_WORDS / 4; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
+    const uint32_t* g_sfx = p.table.sfx;
 
     // rows [0, row_end) are complete 1 KiB rows, so every load below is an unconditional,
     // perfectly coalesced dwordx4 (the ragged tail row goes to rows_kernel, see vgmi_api.cpp)
@@ -484,22 +490,18 @@ __global__ __launch_bounds__(1024) void count27_lds_kernel(RowParams p)
     };
 
     const uint32_t src1 = (lane + 63u) & 63u, src2 = (lane + 62u) & 63u;
-    uint32_t pr1_be = 0, pr2_be = 0, pr1_inv = 0xFFFFu, pr2_inv = 0xFFFFu;
-    if (r0 > 0) {
-        const uint4 raw = load_row(r0 - 1);
-        uint32_t be, inv;
-        encode16(raw, s_lut_code, s_lut_inv, be, inv);
-        pr1_be = __shfl(be, src1);   pr2_be = __shfl(be, src2);
-        pr1_inv = __shfl(inv, src1); pr2_inv = __shfl(inv, src2);
-    }
+    uint32_t pr1_be = 0, pr2_be = 0, pr1_inv = 0xFFFFu, pr2_inv = 0xFFFFu, pr_spill = 0;
+    // the row before the range is walked first as a warm-up: it only provides the halo (and the
+    // grid variant's candidate spill) of the range's first row
+    const uint64_t rs = r0 > 0 ? r0 - 1 : r0;
 
     uint32_t qhead = 0, qtail = 0;
     Pending pd;
     pd.active = false;
     pd.canon = 0; pd.slot = 0; pd.v = make_uint4(0, 0, 0, 0);
 
-    uint4 raw_next = load_row(r0);
-    for (uint64_t r = r0; r < r1; ++r) {
+    uint4 raw_next = load_row(rs);
+    for (uint64_t r = rs; r < r1; ++r) {
         const uint4 raw = raw_next;
         raw_next = load_row(r + 1 < r1 ? r + 1 : r);  // prefetch (the last iteration re-reads its own row)
 
@@ -519,7 +521,8 @@ __global__ __launch_bounds__(1024) void count27_lds_kernel(RowParams p)
         sm |= sm << 1; sm |= sm << 2; sm |= sm << 4; sm |= sm << 8; sm |= sm << 11;
         const uint32_t ok = ~(uint32_t)(sm >> 32);  // bit j set: window valid
 
-        {   // empty-read check, see rows_kernel
+        const bool warm = r < r0;
+        if (!warm) {   // empty-read check, see rows_kernel
             const uint32_t prev_bit = (i1 >> 15) & 1u;
             const uint32_t adj = inv & ((inv << 1) | prev_bit);
             if (__builtin_expect(__ballot(adj != 0) != 0, 0)) {
@@ -535,22 +538,59 @@ __global__ __launch_bounds__(1024) void count27_lds_kernel(RowParams p)
             }
         }
 
-        // ---- phase A: low word of the 16 forward k-mers, 16 bitmap words in flight
-        uint32_t flo[16], fw[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            flo[j] = funnel(F1, F0, 2 * (15 - j));        // bits [2(15-j), +32) of F2:F1:F0
-            fw[j] = s_sfx[(flo[j] >> 5) & (VG_SFX_WORDS - 1)];
-        }
-        // ---- phase B: pass masks (per-lane bools live in SGPR pairs; the ballot is the same mask)
+        uint32_t flo[16];
         bool pass[16];
         uint64_t ball[16];
         uint32_t cnt[16];
+        if (LDS_SFX) {
+            if (warm) continue;
+            // ---- phase A: low word of the 16 forward k-mers, 16 bitmap words in flight
+            uint32_t fw[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            pass[j] = ((fw[j] >> (flo[j] & 31u)) & __builtin_amdgcn_ubfe(ok, j, 1)) != 0;
-            ball[j] = __builtin_amdgcn_ballot_w64(pass[j]);
-            cnt[j] = (uint32_t)__builtin_popcountll(ball[j]);
+            for (int j = 0; j < 16; ++j) {
+                flo[j] = funnel(F1, F0, 2 * (15 - j));        // bits [2(15-j), +32) of F2:F1:F0
+                fw[j] = s_sfx[(flo[j] >> 5) & (VG_SFX_WORDS - 1)];
+            }
+            // ---- phase B: pass masks (per-lane bools live in SGPR pairs; the ballot is the same mask)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                pass[j] = ((fw[j] >> (flo[j] & 31u)) & __builtin_amdgcn_ubfe(ok, j, 1)) != 0;
+                ball[j] = __builtin_amdgcn_ballot_w64(pass[j]);
+                cnt[j] = (uint32_t)__builtin_popcountll(ball[j]);
+            }
+        } else {
+            // ---- grid variant (vgmi_device.h): probe the global bitmap only with the 16-mers that
+            // end at stream positions divisible by 12.  1024 % 12 == 16 % 12 == 4, so the first
+            // grid offset of this lane's chunk is 0, 8 or 4 for (r + lane) % 3 == 0, 1, 2, and only
+            // the first case has a second grid point (offset 12).
+            const uint32_t ph = ((uint32_t)(r % 3) + lane % 3) % 3;
+            const uint32_t j1 = ph == 0 ? 0u : (ph == 1 ? 8u : 4u);
+            const uint64_t inv48 = ((uint64_t)inv << 32) | ((uint64_t)i1 << 16) | (uint64_t)i2;
+            const uint32_t m1 = funnel(F1, F0, 2 * (15 - j1));                    // the 16 bases ending at offset j1
+            const bool v1 = ((uint32_t)(inv48 >> (17 + j1)) & 0xFFFFu) == 0;
+            const bool two = ph == 0;
+            const uint32_t m2 = funnel(F1, F0, 2 * (15 - 12));
+            const bool v2 = two && ((uint32_t)(inv48 >> (17 + 12)) & 0xFFFFu) == 0;
+            const uint32_t gb = p.table.sfx_bits_log2;
+            const uint64_t x1 = vg_grid_index(m1, gb), x2 = vg_grid_index(m2, gb);
+            uint32_t w1 = 0, w2 = 0;
+            if (v1) w1 = g_sfx[x1 >> 5];
+            if (v2) w2 = g_sfx[x2 >> 5];
+            const bool h1 = v1 && ((w1 >> (uint32_t)(x1 & 31u)) & 1u);
+            const bool h2 = v2 && ((w2 >> (uint32_t)(x2 & 31u)) & 1u);
+            const uint32_t cand32 = (h1 ? 0xFFFu << j1 : 0u) | (h2 ? 0xFFFu << 12 : 0u);
+            const uint32_t spill = cand32 >> 16;                                   // runs into the next lane's chunk
+            const uint32_t sp_in = __shfl(spill, src1);
+            const uint32_t cand = ((cand32 & 0xFFFFu) | (lane >= 1 ? sp_in : pr_spill)) & ok;
+            pr_spill = sp_in;                                                      // lane 0 keeps lane 63's spill for the next row
+            if (warm) continue;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                flo[j] = funnel(F1, F0, 2 * (15 - j));
+                pass[j] = ((cand >> j) & 1u) != 0;
+                ball[j] = __builtin_amdgcn_ballot_w64(pass[j]);
+                cnt[j] = (uint32_t)__builtin_popcountll(ball[j]);
+            }
         }
         // ---- phase C: compact the forward k-mers into the ring, four steps at a time so that the
         // ring (128 entries) is checked for space often enough; a segment that would not fit
@@ -562,7 +602,7 @@ __global__ __launch_bounds__(1024) void count27_lds_kernel(RowParams p)
             if (slow_from != 16) break;
             const uint32_t seg_total = cnt[4 * seg] + cnt[4 * seg + 1] + cnt[4 * seg + 2] + cnt[4 * seg + 3];
             if (seg_total == 0) continue;
-            if (__builtin_expect(qtail - qhead + seg_total > VG_QCAP, 0)) {
+            if (__builtin_expect(qtail - qhead + seg_total > QC, 0)) {
                 slow_from = 4 * seg;
                 break;
             }
@@ -573,56 +613,64 @@ __global__ __launch_bounds__(1024) void count27_lds_kernel(RowParams p)
                     const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball[j] >> 32),
                                          __builtin_amdgcn_mbcnt_lo((uint32_t)ball[j], qtail));
                     const uint32_t f_hi = funnel(F2, F1, 2 * (15 - j)) & MASK_HI;
-                    s_queue[pos & (VG_QCAP - 1)] = ((uint64_t)f_hi << 32) | flo[j];
+                    s_queue[pos & (QC - 1)] = ((uint64_t)f_hi << 32) | flo[j];
                 }
                 qtail += cnt[j];
             }
             if (p.dbg & 1u) { qhead = qtail; continue; }
             while (qtail - qhead >= 64u) {
-                probe_finish(p.table, pd, s_queue, qhead, qtail);
-                probe_issue<K>(p.table, s_queue, qhead, 64u, lane, pd);
+                probe_finish<QC>(p.table, pd, s_queue, qhead, qtail);
+                probe_issue<K, QC>(p.table, s_queue, qhead, 64u, lane, pd);
                 qhead += 64u;
             }
         }
         if (__builtin_expect(slow_from != 16, 0)) {
             // ---- slow path: flush, then one step at a time
-            probe_finish(p.table, pd, s_queue, qhead, qtail);
+            probe_finish<QC>(p.table, pd, s_queue, qhead, qtail);
             while (qtail != qhead) {
                 const uint32_t n = qtail - qhead < 64u ? qtail - qhead : 64u;
-                probe_issue<K>(p.table, s_queue, qhead, n, lane, pd);
+                probe_issue<K, QC>(p.table, s_queue, qhead, n, lane, pd);
                 qhead += n;
-                probe_finish(p.table, pd, s_queue, qhead, qtail);
+                probe_finish<QC>(p.table, pd, s_queue, qhead, qtail);
             }
 #pragma unroll 1
             for (int j = slow_from; j < 16; ++j) {
                 const uint32_t fs = 2 * (15 - j);
                 const uint32_t f_lo = funnel(F1, F0, fs);
                 const uint32_t f_hi = funnel(F2, F1, fs) & MASK_HI;
-                const uint32_t w = s_sfx[(f_lo >> 5) & (VG_SFX_WORDS - 1)];
-                const bool ps = ((ok >> j) & 1u) && ((w >> (f_lo & 31u)) & 1u);
+                bool ps;
+                if (LDS_SFX) {
+                    const uint32_t w = s_sfx[(f_lo >> 5) & (VG_SFX_WORDS - 1)];
+                    ps = ((ok >> j) & 1u) && ((w >> (f_lo & 31u)) & 1u);
+                } else {
+                    uint64_t bj0 = ball[0];
+#pragma unroll
+                    for (int q = 1; q < 16; ++q) bj0 = q == j ? ball[q] : bj0;
+                    ps = (bj0 >> lane) & 1ull;
+                }
                 const uint64_t bj = __builtin_amdgcn_ballot_w64(ps);
                 if (!bj) continue;
                 if (ps) {
                     const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bj >> 32),
                                          __builtin_amdgcn_mbcnt_lo((uint32_t)bj, qtail));
-                    s_queue[pos & (VG_QCAP - 1)] = ((uint64_t)f_hi << 32) | f_lo;
+                    s_queue[pos & (QC - 1)] = ((uint64_t)f_hi << 32) | f_lo;
                 }
                 qtail += (uint32_t)__builtin_popcountll(bj);
                 while (qtail != qhead) {
                     const uint32_t n = qtail - qhead < 64u ? qtail - qhead : 64u;
-                    probe_issue<K>(p.table, s_queue, qhead, n, lane, pd);
+                    probe_issue<K, QC>(p.table, s_queue, qhead, n, lane, pd);
                     qhead += n;
-                    probe_finish(p.table, pd, s_queue, qhead, qtail);
+                    probe_finish<QC>(p.table, pd, s_queue, qhead, qtail);
                 }
             }
         }
     }
-    probe_finish(p.table, pd, s_queue, qhead, qtail);
+    probe_finish<QC>(p.table, pd, s_queue, qhead, qtail);
     while (qtail != qhead) {
         const uint32_t n = qtail - qhead < 64u ? qtail - qhead : 64u;
-        probe_issue<K>(p.table, s_queue, qhead, n, lane, pd);
+        probe_issue<K, QC>(p.table, s_queue, qhead, n, lane, pd);
         qhead += n;
-        probe_finish(p.table, pd, s_queue, qhead, qtail);
+        probe_finish<QC>(p.table, pd, s_queue, qhead, qtail);
     }
 }
 
@@ -713,10 +761,20 @@ __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t 
     key_slot[i] = (uint32_t)s;
     atomicOr(&filter_rw[vg_fhash_word(canon) >> t.filter_shift], vg_fhash_bits(canon, t.filter_words_log2));
     if (sfx_rw) {
-        const uint32_t a = (uint32_t)canon & (VG_SFX_BITS - 1);
-        const uint32_t b = (uint32_t)vg_revcomp(canon, k) & (VG_SFX_BITS - 1);
-        atomicOr(&sfx_rw[a >> 5], 1u << (a & 31u));
-        atomicOr(&sfx_rw[b >> 5], 1u << (b & 31u));
+        const uint64_t rcv = vg_revcomp(canon, k);
+        if (t.sfx_bits_log2 == VG_SFX_LDS_LOG2) {           // suffix bitmap (LDS variant)
+            const uint32_t a = (uint32_t)canon & (VG_SFX_BITS - 1);
+            const uint32_t b = (uint32_t)rcv & (VG_SFX_BITS - 1);
+            atomicOr(&sfx_rw[a >> 5], 1u << (a & 31u));
+            atomicOr(&sfx_rw[b >> 5], 1u << (b & 31u));
+        } else {                                             // grid bitmap (global variant), k = 27 only
+            for (uint32_t off = 0; off < VG_GRID_STEP; ++off) {
+                const uint64_t a = vg_grid_index((uint32_t)(canon >> (2 * off)), t.sfx_bits_log2);
+                const uint64_t b = vg_grid_index((uint32_t)(rcv >> (2 * off)), t.sfx_bits_log2);
+                atomicOr(&sfx_rw[a >> 5], 1u << (uint32_t)(a & 31u));
+                atomicOr(&sfx_rw[b >> 5], 1u << (uint32_t)(b & 31u));
+            }
+        }
     }
 }
 
@@ -806,14 +864,23 @@ static hipError_t launch_rows_t(const RowParams& p, uint32_t grid, uint32_t bloc
     return hipGetLastError();
 }
 
-hipError_t launch_count27_lds(const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)
+#define VG_QCAP_GLOBAL 512u  // ring entries per wave of the global-bitmap variant (dense hits expected)
+
+template <bool LDS_SFX, uint32_t QC>
+static hipError_t launch_count27_t(const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)
 {
-    const size_t lds = (size_t)VG_SFX_WORDS * 4 + (size_t)(block / 64) * VG_QCAP * 8 + 512;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&count27_lds_kernel),
+    const size_t lds = (LDS_SFX ? (size_t)VG_SFX_WORDS * 4 : 0) + (size_t)(block / 64) * QC * 8 + 512;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&count27_kernel<LDS_SFX, QC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(count27_lds_kernel, dim3(grid), dim3(block), lds, st, p);
+    hipLaunchKernelGGL((count27_kernel<LDS_SFX, QC>), dim3(grid), dim3(block), lds, st, p);
     return hipGetLastError();
+}
+
+hipError_t launch_count27(bool lds_bitmap, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)
+{
+    return lds_bitmap ? launch_count27_t<true, VG_QCAP>(p, grid, block, st)
+                      : launch_count27_t<false, VG_QCAP_GLOBAL>(p, grid, block, st);
 }
 
 hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)

@@ -115,3 +115,46 @@ def write_fastq_pair(prefix, block, n_reads, read_len, gz=False):
 
 def sample_haplotypes(ref, variants, gts, sample=0, ploidy=2):
     return [haplotype(ref, variants, gts, sample * ploidy + h) for h in range(ploidy)]
+
+
+# ---- synthetic graph key sets for large-table performance runs (no reference `construct` involved)
+def hash64_np(x, k):
+    """include/hash64.hpp:5-14 vectorised (uint64 numpy)."""
+    mask = np.uint64((1 << (2 * k)) - 1)
+    x = x.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        x = (~x + (x << np.uint64(21))) & mask
+        x = x ^ (x >> np.uint64(24))
+        x = ((x + (x << np.uint64(3))) + (x << np.uint64(8))) & mask
+        x = x ^ (x >> np.uint64(14))
+        x = ((x + (x << np.uint64(2))) + (x << np.uint64(4))) & mask
+        x = x ^ (x >> np.uint64(28))
+        x = (x + (x << np.uint64(31))) & mask
+    return x
+
+
+def snp_kmer_keys(ref, positions, alts, k=27):
+    """Keys (hash64(canonical)<<8|k) of every k-mer that covers a SNP site, for the reference and
+    the alternative allele -- what a SNP node of the reference's index holds in essence (about
+    2k keys per site).  SNP-only cohorts; sites closer than k share context through the reference."""
+    codes = _CODE[ref].astype(np.uint64)
+    pos = np.asarray(positions, dtype=np.int64)
+    alt = _CODE[np.asarray(alts, dtype=np.uint8)].astype(np.uint64)
+    span = 2 * k - 1
+    idx = pos[:, None] + np.arange(-(k - 1), k)[None, :]
+    ctx = codes[idx]                                  # (n, 2k-1)
+    out = []
+    for allele in (0, 1):
+        c = ctx.copy()
+        if allele:
+            c[:, k - 1] = alt
+        for s in range(k):                            # window c[:, s:s+k]
+            w = c[:, s:s + k]
+            fwd = np.zeros(len(pos), dtype=np.uint64)
+            rc = np.zeros(len(pos), dtype=np.uint64)
+            for j in range(k):
+                fwd = (fwd << np.uint64(2)) | w[:, j]
+                rc = (rc << np.uint64(2)) | (np.uint64(3) - w[:, k - 1 - j])
+            canon = np.minimum(fwd, rc)
+            out.append((hash64_np(canon, k) << np.uint64(8)) | np.uint64(k))
+    return np.unique(np.concatenate(out))
