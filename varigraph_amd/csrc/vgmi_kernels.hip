@@ -491,9 +491,16 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
 
     const uint32_t src1 = (lane + 63u) & 63u, src2 = (lane + 62u) & 63u;
     uint32_t pr1_be = 0, pr2_be = 0, pr1_inv = 0xFFFFu, pr2_inv = 0xFFFFu, pr_spill = 0;
-    // the row before the range is walked first as a warm-up: it only provides the halo (and the
-    // grid variant's candidate spill) of the range's first row
-    const uint64_t rs = r0 > 0 ? r0 - 1 : r0;
+    // halo of the range's first row: the LDS variant encodes the previous row once up front; the
+    // grid variant walks it as a warm-up iteration (it also needs that row's candidate spill)
+    const uint64_t rs = (!LDS_SFX && r0 > 0) ? r0 - 1 : r0;
+    if (LDS_SFX && r0 > 0) {
+        const uint4 raw = load_row(r0 - 1);
+        uint32_t be, inv;
+        encode16(raw, s_lut_code, s_lut_inv, be, inv);
+        pr1_be = __shfl(be, src1);   pr2_be = __shfl(be, src2);
+        pr1_inv = __shfl(inv, src1); pr2_inv = __shfl(inv, src2);
+    }
 
     uint32_t qhead = 0, qtail = 0;
     Pending pd;
@@ -521,7 +528,7 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
         sm |= sm << 1; sm |= sm << 2; sm |= sm << 4; sm |= sm << 8; sm |= sm << 11;
         const uint32_t ok = ~(uint32_t)(sm >> 32);  // bit j set: window valid
 
-        const bool warm = r < r0;
+        const bool warm = !LDS_SFX && r < r0;
         if (!warm) {   // empty-read check, see rows_kernel
             const uint32_t prev_bit = (i1 >> 15) & 1u;
             const uint32_t adj = inv & ((inv << 1) | prev_bit);
@@ -543,7 +550,6 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
         uint64_t ball[16];
         uint32_t cnt[16];
         if (LDS_SFX) {
-            if (warm) continue;
             // ---- phase A: low word of the 16 forward k-mers, 16 bitmap words in flight
             uint32_t fw[16];
 #pragma unroll
