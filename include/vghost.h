@@ -62,6 +62,14 @@ int vgh_graph_upload(const vgh_graph *g, vgmi_ctx *ctx);
 int64_t vgh_fastx_read_all(const char *path, char **block_out, size_t *n_bytes_out, uint64_t *read_base);
 void vgh_free(void *p);
 
+/* construct side: ConstructIndex::build_fasta_index + make_mbf (src/construct_index.cpp:85-139,150-177)
+ * with the Bloom filter on the device.  seeds == NULL: the seeds BloomFilter::_init_seeds
+ * (src/counting_bloom_filter.cpp:80-87) would draw if std::random_device returned
+ * random_device_value.  The filter stays in ctx (vgmi_bloom_fetch / vgmi_bloom_query). */
+int vgh_bloom_reference_seeds(uint32_t random_device_value, uint32_t n_hash, uint64_t *seeds_out);
+int vgh_make_mbf(vgmi_ctx *ctx, const char *fasta_path, uint32_t k, const uint64_t *seeds, uint32_t n_seeds,
+                 uint32_t random_device_value, uint64_t *genome_size, uint64_t *m, uint32_t *n_hash);
+
 typedef struct vgh_sample_stats {
     uint64_t read_base;       /* FastqKmer::mReadBase */
     uint64_t n_reads;

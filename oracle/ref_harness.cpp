@@ -17,6 +17,8 @@
 //   murmur                        stdin: "key_hex seed_hex" -> sum hex
 //   bloom K N P seed0,seed1,.. OUT  stdin: sequences -> BloomFilter::save() dump in OUT; then for
 //                                 each stdin line after a line "Q": key_hex -> "count find"
+//   mbf FASTA K OUT               ConstructIndex::build_fasta_index + make_mbf, then BloomFilter::save(OUT)
+//                                 (seeds are random unless this is the det_shim build, ref_harness_det)
 //   count GRAPH THREADS OUT FQ...  load_index + build_fastq_index; writes OUT (see below); prints timing
 //   sample GRAPH THREADS PLOIDY USEDEPTH OUT FQ...   count + graph2node + hom-kmer statistics
 #include <chrono>
@@ -133,6 +135,18 @@ static int cmd_bloom(int argc, char** argv) {
     return 0;
 }
 
+static int cmd_mbf(int argc, char** argv) {
+    string fasta = argv[2], none, out = argv[4];
+    uint32_t k = atoi(argv[3]);
+    ConstructIndex ci(fasta, none, none, none, false, false, k, 2, false, 1);
+    ci.build_fasta_index();
+    ci.make_mbf();
+    ci.mbf->save(out);
+    printf("genome_size %llu\nm %llu\nn_hash %u\n", (unsigned long long)ci.mGenomeSize,
+           (unsigned long long)ci.mbf->get_size(), ci.mbf->get_num());
+    return 0;
+}
+
 // OUT layout for count/sample:
 //   u64 readBase | u64 genomeSize | u64 n | n * { u64 key | u8 c | u8 f }   (unordered_map iteration order)
 static void dump_counts(const string& out, uint64_t readBase, ConstructIndex* ci) {
@@ -220,6 +234,7 @@ int main(int argc, char** argv) {
     if (c == "bloomsize" && argc >= 4) return cmd_bloomsize(argc, argv);
     if (c == "murmur") return cmd_murmur(argc, argv);
     if (c == "bloom" && argc >= 7) return cmd_bloom(argc, argv);
+    if (c == "mbf" && argc >= 5) return cmd_mbf(argc, argv);
     if (c == "count" && argc >= 6) return cmd_count(argc, argv, false);
     if (c == "sample" && argc >= 8) return cmd_count(argc, argv, true);
     fprintf(stderr, "bad command line\n");

@@ -131,6 +131,42 @@ def make_bloom():
         json.dump(cases, f)
 
 
+def mbf_fasta(path):
+    """Two-record FASTA (multi-line second record with lower case, an N run and a duplicate name)."""
+    ref = synth.make_reference(100_000, seed=synth.REF_SEED + 1)
+    ref2 = synth.make_reference(30_000, seed=99)
+    with open(path, "wb") as f:
+        f.write(b">chr1 first\n" + ref.tobytes() + b"\n>chr2\n" + ref2[:15000].tobytes() + b"\n" +
+                ref2[15000:].tobytes().lower() + b"NNNN\n>chr1 duplicate name: counted in the size, sequence ignored\n" +
+                ref2[:500].tobytes() + b"\n")
+
+
+def make_mbf_fixture():
+    """Whole-reference counting Bloom filter from the reference's own build_fasta_index + make_mbf
+    (det build: seeds are what _init_seeds draws when random_device returns 20241022)."""
+    import hashlib
+    fa = tempfile.mktemp(suffix=".fa")
+    out = tempfile.mktemp()
+    mbf_fasta(fa)
+    cases = []
+    for k in (27, 21):
+        txt = run([os.path.join(REF, "ref_harness_det"), "mbf", fa, str(k), out])
+        vals = dict(ln.split() for ln in txt.splitlines())
+        d = open(out, "rb").read()
+        m = int.from_bytes(d[:8], "little")
+        nh = int.from_bytes(d[8:12], "little")
+        seeds = [int.from_bytes(d[12 + 8 * i:20 + 8 * i], "little") for i in range(nh)]
+        filt = np.frombuffer(d, dtype=np.uint8, offset=12 + 8 * nh)
+        assert filt.size == m == int(vals["m"])
+        cases.append({"k": k, "genome_size": int(vals["genome_size"]), "m": m, "n_hash": nh, "random_device_value": 20241022,
+                      "seeds": [f"{x:x}" for x in seeds], "sha256": hashlib.sha256(filt.tobytes()).hexdigest(),
+                      "sum": int(filt.sum()), "nonzero": int((filt != 0).sum()), "max": int(filt.max())})
+        print("mbf", k, m, nh, cases[-1]["sum"])
+    with open(os.path.join(HERE, "mbf.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+    os.unlink(fa); os.unlink(out)
+
+
 def genotype_modes(workdir, graph, sample_cfg_line, modes):
     out = {}
     for name, extra in modes.items():
@@ -217,6 +253,7 @@ def main():
             raise SystemExit(f"{p} missing: run `make -C oracle ref` (needs /root/reference)")
     make_kats()
     make_bloom()
+    make_mbf_fixture()
     modes = {"het": [], "hom": ["-g", "hom"], "use_depth": ["--use-depth"], "n5": ["-n", "5"]}
     # G4: tiny SNP cohort, 3 diploid VCF samples (7 haplotypes)
     make_cohort("cohort_snp", 100_000, 100, 3, 2, 3000, seed=1, modes=modes)

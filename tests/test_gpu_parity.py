@@ -454,3 +454,21 @@ def test_large_graph_grid_variant_matches_oracle(k):
         assert np.array_equal(cov2, want)
     finally:
         c.close()
+
+
+def test_make_mbf_matches_reference_whole_genome_bloom(ctx, tmp_path):
+    """vgh_make_mbf (FASTA -> device Bloom, seeds as the reference draws them for the det build's
+    random_device value) == the reference's build_fasta_index + make_mbf, byte for byte (sha256)."""
+    import hashlib
+    import importlib.util
+    from varigraph_amd import host
+    spec = importlib.util.spec_from_file_location("mg", os.path.join(GOLDEN, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    fa = str(tmp_path / "mbf.fa")
+    mg.mbf_fasta(fa)
+    for c in json.load(open(os.path.join(GOLDEN, "mbf.json"))):
+        gs, m, nh = host.make_mbf(ctx, fa, c["k"], seeds=None, random_device_value=c["random_device_value"])
+        assert (gs, m, nh) == (c["genome_size"], c["m"], c["n_hash"])
+        filt = ctx.bloom_fetch()
+        assert hashlib.sha256(filt.tobytes()).hexdigest() == c["sha256"]

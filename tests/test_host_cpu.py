@@ -156,3 +156,51 @@ def test_synth_generator_is_stable():
     """The seeded generator must keep producing the block the c1 fixture was made from."""
     c = get_cohort("c1")
     c.regenerate_block()  # asserts the md5
+
+
+def _mbf_fasta(tmp_path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mg", os.path.join(GOLDEN, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    fa = str(tmp_path / "mbf.fa")
+    mg.mbf_fasta(fa)
+    return fa
+
+
+def test_reference_bloom_seed_draw():
+    """BloomFilter::_init_seeds restated with explicit entropy == seeds of the det reference build."""
+    import json
+    for c in json.load(open(os.path.join(GOLDEN, "mbf.json"))):
+        got = host.bloom_reference_seeds(c["random_device_value"], c["n_hash"])
+        assert [f"{int(x):x}" for x in got] == c["seeds"]
+
+
+def test_oracle_whole_reference_bloom_matches_make_mbf(tmp_path):
+    """oracle Bloom over the FASTA == the reference's build_fasta_index + make_mbf (sha256 of the filter)."""
+    import hashlib
+    import json
+    import oracle_lib as o
+    fa = _mbf_fasta(tmp_path)
+    recs = {}
+    name = None
+    size = 0
+    for ln in open(fa, "rb").read().split(b"\n"):
+        if ln.startswith(b">"):
+            name = ln[1:].split()[0]
+            if name in recs:
+                name = (name, "dup")          # emplace keeps the first sequence of a name
+            recs[name] = b""
+        elif name is not None:
+            recs[name] += ln
+            size += len(ln)
+    for c in json.load(open(os.path.join(GOLDEN, "mbf.json"))):
+        assert size == c["genome_size"]
+        filt = np.zeros(c["m"], dtype=np.uint8)
+        seeds = np.array([int(s, 16) for s in c["seeds"]], dtype=np.uint64)
+        for nm, seq in recs.items():
+            if isinstance(nm, tuple):
+                continue
+            o.bloom_add_seq(filt, seeds, np.frombuffer(seq, dtype=np.uint8), c["k"])
+        assert hashlib.sha256(filt.tobytes()).hexdigest() == c["sha256"]
+        assert int(filt.sum()) == c["sum"] and int((filt != 0).sum()) == c["nonzero"]

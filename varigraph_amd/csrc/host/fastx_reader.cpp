@@ -68,11 +68,13 @@ long FastxReader::next()
     // name up to the first whitespace, then the rest of the header line (comment)
     {
         bool any = false;
+        name_.clear();
         for (;;) {
             c = getc();
             if (c == -1) break;
             any = true;
             if (c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r') break;
+            name_.push_back((char)c);
         }
         if (!any) return -1;  // EOF right after the header character
         if (c != '\n' && c != -1) {

@@ -26,6 +26,7 @@ public:
     // >= 0: sequence length (seq() holds it); -1: end of file; -2: truncated quality
     long next();
     const std::string& seq() const { return seq_; }
+    const std::string& name() const { return name_; }  // up to the first whitespace of the header line
 
 private:
     int getc();
@@ -37,7 +38,7 @@ private:
     int begin_ = 0, end_ = 0;
     bool eof_ = false;
     int last_char_ = 0;
-    std::string seq_, qual_;
+    std::string seq_, qual_, name_;
 };
 
 }  // namespace vgh

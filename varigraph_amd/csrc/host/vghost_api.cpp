@@ -9,6 +9,7 @@
 #include "fastq_kmer_hip.hpp"
 #include "fastx_reader.hpp"
 #include "graph_index.hpp"
+#include "make_mbf.hpp"
 
 struct vgh_graph {
     vgh::GraphIndex g;
@@ -109,6 +110,31 @@ int64_t vgh_fastx_read_all(const char* path, char** block_out, size_t* n_bytes_o
 }
 
 void vgh_free(void* p) { free(p); }
+
+int vgh_bloom_reference_seeds(uint32_t random_device_value, uint32_t n_hash, uint64_t* seeds_out)
+{
+    if (!seeds_out) return VGMI_E_INVALID;
+    const auto s = vgh::reference_bloom_seeds(random_device_value, n_hash);
+    memcpy(seeds_out, s.data(), s.size() * 8);
+    return VGMI_OK;
+}
+
+int vgh_make_mbf(vgmi_ctx* ctx, const char* fasta_path, uint32_t k, const uint64_t* seeds, uint32_t n_seeds,
+                 uint32_t random_device_value, uint64_t* genome_size, uint64_t* m, uint32_t* n_hash)
+{
+    if (!ctx || !fasta_path) return VGMI_E_INVALID;
+    try {
+        std::vector<uint64_t> sv(seeds, seeds + (seeds ? n_seeds : 0));
+        const vgh::MbfResult r = vgh::make_mbf(ctx, fasta_path, k, sv, random_device_value);
+        if (genome_size) *genome_size = r.genome_size;
+        if (m) *m = r.m;
+        if (n_hash) *n_hash = r.n_hash;
+        return VGMI_OK;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return VGMI_E_INVALID;
+    }
+}
 
 int vgh_sample_count(const vgh_graph* h, vgmi_ctx* ctx, const char* const* fastq_paths, size_t n_files, uint32_t threads,
                      uint32_t sample_ploidy, int use_depth, uint8_t* cov_out, uint8_t* cov_node_out, uint64_t* hist_out,

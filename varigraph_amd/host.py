@@ -49,6 +49,11 @@ def lib():
     l.vgh_sample_count.restype = C.c_int
     l.vgh_sample_count.argtypes = [vp, vp, C.POINTER(C.c_char_p), C.c_size_t, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp,
                                    C.POINTER(SampleStats)]
+    l.vgh_bloom_reference_seeds.restype = C.c_int
+    l.vgh_bloom_reference_seeds.argtypes = [C.c_uint32, C.c_uint32, vp]
+    l.vgh_make_mbf.restype = C.c_int
+    l.vgh_make_mbf.argtypes = [vp, C.c_char_p, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64),
+                               C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     _lib = l
     return l
 
@@ -146,3 +151,25 @@ def fastx_read_all(path):
     finally:
         l.vgh_free(p)
     return block, int(cnt), rb.value
+
+
+def bloom_reference_seeds(random_device_value, n_hash):
+    out = np.zeros(n_hash, dtype=np.uint64)
+    rc = lib().vgh_bloom_reference_seeds(random_device_value, n_hash, vgmi._ptr(out))
+    if rc:
+        raise RuntimeError("vgh_bloom_reference_seeds")
+    return out
+
+
+def make_mbf(ctx, fasta_path, k, seeds=None, random_device_value=0):
+    """build_fasta_index + make_mbf with the Bloom filter on the device; returns (genome_size, m, n_hash)."""
+    l = lib()
+    gs, m, nh = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    if seeds is not None:
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    rc = l.vgh_make_mbf(ctx._h, os.fsencode(fasta_path), k, vgmi._ptr(seeds), 0 if seeds is None else seeds.size,
+                        random_device_value, C.byref(gs), C.byref(m), C.byref(nh))
+    if rc:
+        raise vgmi.VgmiError(rc, l.vgh_last_error().decode())
+    ctx._bloom_m = m.value
+    return gs.value, m.value, nh.value
