@@ -1,0 +1,81 @@
+"""End-to-end drop-in check (-m gpu): the UNMODIFIED reference compiled together with this repo's
+adapter (integration/varigraph_hip.hpp -> oracle/_ref/varigraph_hip) runs `genotype` with the read
+counting on the MI355X; the VCF it writes must be byte-identical (after gunzip) to the VCF the
+all-CPU reference (oracle/_ref/varigraph_det, same deterministic flavour) writes ON THE SAME HOST
+for the same graph, reads and options.
+
+Same host matters: the reference's HMM is x87 `long double` and its GQ goes through log10l, whose
+x87 transcendental instructions are not bit-identical across CPU vendors -- the all-CPU reference
+itself prints GQ 99.0 vs 192.7 at a few sites on the GPU box's EPYC vs the build container's Xeon
+(genotypes and every other field agree).  The committed expected_*.vcf (made in the build
+container) are therefore compared field-wise without GQ."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+BIN = os.path.join(ROOT, "oracle", "_ref", "varigraph_hip")
+REF = os.path.join(ROOT, "oracle", "_ref", "varigraph_det")
+
+
+def _strip_gq(vcf):
+    out = []
+    for ln in vcf.split(b"\n"):
+        if ln and not ln.startswith(b"#"):
+            cols = ln.split(b"\t")
+            f = cols[9].split(b":")
+            f[1] = b"GQ"
+            cols[9] = b":".join(f)
+            ln = b"\t".join(cols)
+        out.append(ln)
+    return b"\n".join(out)
+
+CASES = [
+    ("cohort_snp", "het", []), ("cohort_snp", "hom", ["-g", "hom"]), ("cohort_snp", "use_depth", ["--use-depth"]),
+    ("cohort_snp", "n5", ["-n", "5"]),
+    ("cohort_sv", "het", []), ("cohort_sv", "hom", ["-g", "hom"]), ("cohort_sv", "use_depth", ["--use-depth"]),
+    ("cohort_sv", "n5", ["-n", "5"]),
+    ("cohort_k22", "het", []),
+    ("cohort_tetra", "p4_use_depth", ["--sample-ploidy", "4", "--use-depth"]),
+]
+
+
+@pytest.mark.parametrize("cohort,mode,extra", CASES, ids=[f"{c}-{m}" for c, m, _ in CASES])
+def test_genotype_vcf_identical_to_reference(cohort, mode, extra, tmp_path):
+    if not (os.path.exists(BIN) and os.path.exists(REF)):
+        pytest.skip("integration binary not built (needs /root/reference at build time: make -C oracle ref)")
+    d = os.path.join(GOLDEN, cohort)
+    graph = tmp_path / "graph.bin"
+    graph.write_bytes(gzip.open(os.path.join(d, "graph.bin.gz"), "rb").read())
+    fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
+    (tmp_path / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
+    r = subprocess.run([BIN, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4",
+                        "--gpu", "0", "--buffer", "8"] + extra, cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = gzip.open(tmp_path / "sample0.varigraph.vcf.gz", "rb").read()
+    assert got.count(b"\n") > 20
+    # (1) byte-identical to the all-CPU reference on this host
+    cpu = tmp_path / "cpu"
+    cpu.mkdir()
+    (cpu / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
+    r2 = subprocess.run([REF, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4"] + extra,
+                        cwd=cpu, capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    want_here = gzip.open(cpu / "sample0.varigraph.vcf.gz", "rb").read()
+    assert got == want_here
+    # (2) equal to the committed fixture from the build container in everything but GQ
+    want = open(os.path.join(d, f"expected_{mode}.vcf"), "rb").read()
+    assert _strip_gq(got) == _strip_gq(want)
+
+
+def test_integration_binary_fails_loudly_on_bad_input(tmp_path):
+    if not os.path.exists(BIN):
+        pytest.skip("integration binary not built")
+    r = subprocess.run([BIN, "genotype", "--load-graph", str(tmp_path / "nope.bin"), "-s", "nope.cfg"],
+                       cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode != 0
