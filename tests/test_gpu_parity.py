@@ -472,3 +472,48 @@ def test_make_mbf_matches_reference_whole_genome_bloom(ctx, tmp_path):
         assert (gs, m, nh) == (c["genome_size"], c["m"], c["n_hash"])
         filt = ctx.bloom_fetch()
         assert hashlib.sha256(filt.tobytes()).hexdigest() == c["sha256"]
+
+
+def test_full_size_c2_properties(ctx):
+    """BASELINE.json configs[1] at full size: 1e8 reads (50 M pairs) of the C2 workload, generated on the
+    device.  Size-independent properties: (1) one launch == five ragged sub-launches, (2) the first
+    2 M reads alone equal the oracle, (3) counters are monotone in the input, (4) at 15 000x coverage
+    every graph k-mer carried by the sequenced sample's two haplotypes is saturated at 255."""
+    import torch
+    cohort = get_cohort("c1")
+    haps = cohort.haplotypes()
+    cat = np.concatenate(haps)
+    off = np.concatenate([[0], np.cumsum([len(h) for h in haps])]).astype(np.uint64)
+    n_reads, L = 100_000_000, 150
+    d_cat = torch.from_numpy(cat).cuda()
+    d_out = torch.empty(n_reads * (L + 1), dtype=torch.uint8, device="cuda")
+    for first in range(0, n_reads, 10_000_000):
+        ctx.synth_reads_device(1000, first, 10_000_000, L, d_cat, off, d_out[first * (L + 1):])
+    keys = cohort.graph.keys
+    ctx.table_upload(keys, 27)
+    ctx.counts_reset()
+    ctx.reads_submit_device(d_out, d_out.numel(), n_reads)
+    full, _, _ = ctx.counts_finish()
+    assert ctx.read_base() == n_reads * L
+    # (1) ragged split at read boundaries that are multiples of 16 reads (keeps 16-byte alignment)
+    cuts = [0, 16 * 1_000_003, 16 * 2_500_001, 16 * 2_500_002, 16 * 5_999_999, n_reads]
+    ctx.counts_reset()
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        ctx.reads_submit_device(d_out[a * (L + 1):], (b - a) * (L + 1), b - a)
+    split, _, _ = ctx.counts_finish()
+    assert np.array_equal(full, split)
+    # (2) prefix against the oracle
+    pre = 2_000_000
+    ctx.counts_reset()
+    ctx.reads_submit_device(d_out, pre * (L + 1), pre)
+    part, _, _ = ctx.counts_finish()
+    t = o.Table(keys)
+    t.count_block(d_out[: pre * (L + 1)].cpu().numpy(), 27)
+    assert np.array_equal(part, t.counts())
+    # (3) monotone
+    assert (full >= part).all()
+    # (4) saturation of the sample's own k-mers
+    hk = np.unique(np.concatenate([o.sketch(h.tobytes(), 27) for h in haps]))
+    on_sample = np.isin(keys, hk)
+    assert on_sample.sum() > 0.9 * keys.size
+    assert (full[on_sample] == 255).all()

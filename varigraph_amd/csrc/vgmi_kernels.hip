@@ -34,8 +34,6 @@ namespace vgk {
 // ------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
 __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh)
 {
     // (hi:lo) >> sh, low 32 bits; sh in [0,31]  (v_alignbit_b32)
@@ -110,13 +108,6 @@ __device__ __forceinline__ bool filter_test_global(const TableView& t, uint64_t 
 enum { MODE_COUNT = 0, MODE_KEYS = 1, MODE_BLOOM = 2 };
 
 #define VG_QCAP 128u  // per-wave pass queue entries (power of two, >= 2*64)
-
-struct RowLds {
-    uint32_t* filter;   // FLDS only
-    uint64_t* queue;    // this wave's ring
-    const uint8_t* lut_code;
-    const uint8_t* lut_inv;
-};
 
 __device__ __forceinline__ uint4 load_chunk(const uint8_t* bases, uint64_t n_bytes, uint64_t off)
 {
