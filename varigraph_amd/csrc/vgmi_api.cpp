@@ -62,6 +62,7 @@ struct vgmi_ctx {
     bool has_table = false;
     TableView tv{};
     uint32_t* d_key_slot = nullptr;
+    uint32_t* d_counts = nullptr;   // dense per-key counters of large graphs (per-sample state, not part of the image)
     bool filter_in_lds = false;
     bool fast27 = false;         // k = 27: count27_kernel
     bool fast27_lds = false;     // ... with the 2^20-bit suffix bitmap resident in LDS
@@ -140,6 +141,8 @@ void free_table(vgmi_ctx* c)
     c->d_cov = nullptr;
     if (c->d_flag) (void)hipFree(c->d_flag);
     c->d_flag = nullptr;
+    if (c->d_counts) (void)hipFree(c->d_counts);
+    c->d_counts = nullptr;
 }
 
 void free_nodes(vgmi_ctx* c)
@@ -209,6 +212,12 @@ int adopt_image(vgmi_ctx* c)
     c->d_key_slot = reinterpret_cast<uint32_t*>(c->d_image + h.off_key_slot);
     c->filter_in_lds = filter_fits_lds(h.filter_words_log2);
     HIPCHK(c, hipMalloc(&c->d_cov, h.n_keys ? h.n_keys : 1));
+    c->tv.counts = nullptr;
+    if (2 * h.n_keys > VG_SFX_BITS / 8) {   // large graph: 4 B/key dense counters stay Infinity-Cache resident
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_counts), h.n_keys * 4));
+        HIPCHK(c, hipMemset(c->d_counts, 0, h.n_keys * 4));
+        c->tv.counts = c->d_counts;
+    }
     c->has_table = true;
     free_nodes(c);
     return VGMI_OK;
@@ -539,7 +548,8 @@ int vgmi_counts_reset(vgmi_ctx* c)
     if (rc) return rc;
     rc = collect_timing(c);
     if (rc) return rc;
-    HIPCHK(c, launch_counts_reset(c->tv.slots, c->hdr.cap, c->stream));
+    if (c->d_counts) HIPCHK(c, hipMemsetAsync(c->d_counts, 0, c->hdr.n_keys * 4, c->stream));
+    else HIPCHK(c, launch_counts_reset(c->tv.slots, c->hdr.cap, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4, c->stream));
     c->read_base = 0;
     c->kernel_ms = 0.f;
@@ -638,7 +648,7 @@ static int finish_common(vgmi_ctx* c, uint8_t* d_cov, uint8_t* d_cov_node, unsig
     for (auto& s : c->stage)
         if (s.busy) HIPCHK(c, hipStreamWaitEvent(c->stream, s.done, 0));
     if (d_hist) HIPCHK(c, hipMemsetAsync(d_hist, 0, 256 * 8, c->stream));
-    HIPCHK(c, launch_cov(c->tv.slots, c->d_key_slot, c->hdr.n_keys, c->d_flag, d_cov, d_hist, c->stream));
+    HIPCHK(c, launch_cov(c->tv.slots, c->d_key_slot, c->d_counts, c->hdr.n_keys, c->d_flag, d_cov, d_hist, c->stream));
     if (d_cov_node && c->n_node_entries)
         HIPCHK(c, launch_node_gather(d_cov, c->d_node_key_index, c->n_node_entries, d_cov_node, c->stream));
     return VGMI_OK;

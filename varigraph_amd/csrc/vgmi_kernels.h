@@ -18,6 +18,8 @@ struct TableView {
     uint32_t filter_shift;      // 32 - filter_words_log2
     const uint32_t* sfx;        // suffix bitmap (2^sfx_bits_log2 bits) or nullptr, see vgmi_device.h
     uint32_t sfx_bits_log2;     // VG_SFX_LDS_LOG2 (LDS-resident variant) .. 2k
+    uint32_t* counts;           // large graphs: dense per-key counters (4 B/key, Infinity-Cache sized) instead of the
+                                // in-slot ones; nullptr for small graphs
 };
 
 #define VG_BLOOM_MAX_HASH 32
@@ -56,8 +58,8 @@ hipError_t launch_table_clear(VgSlot* slots, uint64_t cap, hipStream_t st);
 hipError_t launch_table_insert(const TableView& t, const uint64_t* keys, uint64_t n, uint32_t k, uint32_t* key_slot,
                                uint32_t* filter_rw, uint32_t* sfx_rw, uint32_t* status, hipStream_t st);
 hipError_t launch_counts_reset(VgSlot* slots, uint64_t cap, hipStream_t st);
-hipError_t launch_cov(const VgSlot* slots, const uint32_t* key_slot, uint64_t n, const uint8_t* flag, uint8_t* cov,
-                      unsigned long long* hist, hipStream_t st);
+hipError_t launch_cov(const VgSlot* slots, const uint32_t* key_slot, const uint32_t* counts, uint64_t n, const uint8_t* flag,
+                      uint8_t* cov, unsigned long long* hist, hipStream_t st);
 hipError_t launch_node_gather(const uint8_t* cov, const uint32_t* key_index, uint64_t n, uint8_t* cov_node, hipStream_t st);
 hipError_t launch_bloom_query(const BloomView& b, const uint64_t* keys, uint64_t n, uint8_t* min_out, uint8_t* nz_out,
                               hipStream_t st);

@@ -87,7 +87,8 @@ __device__ __forceinline__ void table_count(const TableView& t, uint64_t canon)
         const uint4 v = *reinterpret_cast<const uint4*>(&t.slots[s]);
         const uint64_t c = ((uint64_t)v.y << 32) | v.x;
         if (c == canon) {
-            if (v.z < 255u) atomicAdd(&t.slots[s].count, 1u);
+            if (t.counts) atomicAdd(&t.counts[v.w], 1u);
+            else if (v.z < 255u) atomicAdd(&t.slots[s].count, 1u);
             return;
         }
         if (c == VG_EMPTY) return;
@@ -394,7 +395,8 @@ __device__ __forceinline__ void probe_finish(const TableView& t, Pending& pd, ui
         const uint64_t c = ((uint64_t)pd.v.y << 32) | pd.v.x;
         const uint64_t canon = pd.canon & VG_Q_KMER_MASK;
         if (c == canon) {
-            if (pd.v.z < 255u) atomicAdd(&t.slots[pd.slot].count, 1u);
+            if (t.counts) atomicAdd(&t.counts[pd.v.w], 1u);     // dense counters, clamped at read-out
+            else if (pd.v.z < 255u) atomicAdd(&t.slots[pd.slot].count, 1u);
         } else if (c != VG_EMPTY) {
             again = true;
         }
@@ -419,7 +421,8 @@ __device__ __forceinline__ void probe_finish(const TableView& t, Pending& pd, ui
                 const uint4 v = *reinterpret_cast<const uint4*>(&t.slots[sl]);
                 const uint64_t c = ((uint64_t)v.y << 32) | v.x;
                 if (c == canon) {
-                    if (v.z < 255u) atomicAdd(&t.slots[sl].count, 1u);
+                    if (t.counts) atomicAdd(&t.counts[v.w], 1u);
+                    else if (v.z < 255u) atomicAdd(&t.slots[sl].count, 1u);
                     break;
                 }
                 if (c == VG_EMPTY) break;
@@ -537,8 +540,7 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
         }
 
         uint32_t flo[16];
-        bool pass[16];
-        uint64_t ball[16];
+        uint64_t ball[16];  // per-step pass masks; inverse_ballot turns them back into lane predicates for free
         uint32_t cnt[16];
         if (LDS_SFX) {
             // ---- phase A: low word of the 16 forward k-mers, 16 bitmap words in flight
@@ -551,8 +553,7 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
             // ---- phase B: pass masks (per-lane bools live in SGPR pairs; the ballot is the same mask)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                pass[j] = ((fw[j] >> (flo[j] & 31u)) & __builtin_amdgcn_ubfe(ok, j, 1)) != 0;
-                ball[j] = __builtin_amdgcn_ballot_w64(pass[j]);
+                ball[j] = __builtin_amdgcn_ballot_w64(((fw[j] >> (flo[j] & 31u)) & __builtin_amdgcn_ubfe(ok, j, 1)) != 0);
                 cnt[j] = (uint32_t)__builtin_popcountll(ball[j]);
             }
         } else {
@@ -584,8 +585,7 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 flo[j] = funnel(F1, F0, 2 * (15 - j));
-                pass[j] = ((cand >> j) & 1u) != 0;
-                ball[j] = __builtin_amdgcn_ballot_w64(pass[j]);
+                ball[j] = __builtin_amdgcn_ballot_w64(((cand >> j) & 1u) != 0);
                 cnt[j] = (uint32_t)__builtin_popcountll(ball[j]);
             }
         }
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int j = 4 * seg + q;
-                if (pass[j]) {
+                if (__builtin_amdgcn_inverse_ballot_w64(ball[j])) {
                     const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball[j] >> 32),
                                          __builtin_amdgcn_mbcnt_lo((uint32_t)ball[j], qtail));
                     const uint32_t f_hi = funnel(F2, F1, 2 * (15 - j)) & MASK_HI;
@@ -782,15 +782,15 @@ __global__ void counts_reset_kernel(VgSlot* slots, uint64_t cap)
 }
 
 // K5 part 1 + K6: cov[i] = min(255, count(key i)); hist[c] += 1 for flagged keys with c != 0
-__global__ void cov_kernel(const VgSlot* slots, const uint32_t* key_slot, uint64_t n, const uint8_t* flag,
-                           uint8_t* cov, unsigned long long* hist)
+__global__ void cov_kernel(const VgSlot* slots, const uint32_t* key_slot, const uint32_t* counts, uint64_t n,
+                           const uint8_t* flag, uint8_t* cov, unsigned long long* hist)
 {
     __shared__ unsigned int s_hist[256];
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_hist[i] = 0;
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t c32 = slots[key_slot[i]].count;
+        const uint32_t c32 = counts ? counts[i] : slots[key_slot[i]].count;
         const uint32_t c = c32 < 255u ? c32 : 255u;
         cov[i] = (uint8_t)c;
         if (hist && c != 0 && flag && flag[i]) atomicAdd(&s_hist[c], 1u);
@@ -927,11 +927,11 @@ hipError_t launch_counts_reset(VgSlot* slots, uint64_t cap, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_cov(const VgSlot* slots, const uint32_t* key_slot, uint64_t n, const uint8_t* flag, uint8_t* cov,
-                      unsigned long long* hist, hipStream_t st)
+hipError_t launch_cov(const VgSlot* slots, const uint32_t* key_slot, const uint32_t* counts, uint64_t n, const uint8_t* flag,
+                      uint8_t* cov, unsigned long long* hist, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(cov_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, slots, key_slot, n, flag, cov, hist);
+    hipLaunchKernelGGL(cov_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, slots, key_slot, counts, n, flag, cov, hist);
     return hipGetLastError();
 }
 
