@@ -66,6 +66,7 @@ struct vgmi_ctx {
     bool filter_in_lds = false;
     bool fast27 = false;         // k = 27: count27_kernel
     bool fast27_lds = false;     // ... with the 2^20-bit suffix bitmap resident in LDS
+    uint32_t wgs_per_cu = 0;     // VGMI_WGS_PER_CU: tuning override for the global-bitmap variant
     bool force_generic = false;  // VGMI_GENERIC_KERNEL=1: take the generic row kernel (A/B testing)
 
     // nodes / flags / outputs
@@ -262,7 +263,12 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
             p.row_end = n_bytes >> 10;
             if (p.row_end) {
                 if (c->fast27_lds) { block = 1024; grid = (uint32_t)c->n_cu; }
-                else               { block = 256;  grid = (uint32_t)c->n_cu * 8; }
+                else {
+                    // global-bitmap variant: random-access bound; more than ~16 waves per CU only adds
+                    // L2 thrash (measured: 8 workgroups/CU 37 ms vs 4 workgroups/CU 31 ms, chr20 class)
+                    block = 256;
+                    grid = (uint32_t)c->n_cu * (c->wgs_per_cu ? c->wgs_per_cu : 4);
+                }
                 HIPCHK(c, launch_count27(c->fast27_lds, p, grid, block, st));
             }
             if (n_bytes & 1023) {
@@ -378,6 +384,7 @@ int vgmi_create(int device, size_t buffer_mib, vgmi_ctx** out)
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* g = getenv("VGMI_GENERIC_KERNEL")) c->force_generic = g[0] == '1';
+    if (const char* g = getenv("VGMI_WGS_PER_CU")) c->wgs_per_cu = (uint32_t)atoi(g);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipMalloc(&c->d_status, 4)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(c->d_status, 0, 4)) != hipSuccess) return bail("hipMemset", e);

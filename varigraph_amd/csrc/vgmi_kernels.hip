@@ -128,22 +128,33 @@ __device__ __forceinline__ uint4 load_chunk(const uint8_t* bases, uint64_t n_byt
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// 16 ASCII bytes -> be: base t at bits [2(15-t), +2);  inv: bit t set iff byte t is not a base
-__device__ __forceinline__ void encode16(const uint4 raw, const uint8_t* lut_code, const uint8_t* lut_inv,
-                                         uint32_t& be, uint32_t& inv)
+// 16 ASCII bytes -> be: base t at bits [2(15-t), +2);  inv: bit t set iff byte t is not a base.
+// One 512-byte LDS table (seq_nt4_table, include/seq_nt4_table.hpp:5-22): [c] = 2-bit code,
+// [256 + c] = invalid flag, so both reads share one address register (the second uses the DS
+// offset field) and each result is merged with a single shift-or.
+__device__ __forceinline__ void encode16(const uint4 raw, const uint8_t* lut, uint32_t& be, uint32_t& inv)
 {
     const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-    be = 0;
-    inv = 0;
+    uint32_t acc = 0, flags = 0;  // flags: bit (15 - t) = invalid(t), reversed below
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const uint32_t c = (w[i] >> (8 * b)) & 0xFFu;
-            const int t = 4 * i + b;
-            be |= (uint32_t)lut_code[c] << (2 * (15 - t));
-            inv |= (uint32_t)lut_inv[c] << t;
+            const uint8_t* e = lut + ((w[i] >> (8 * b)) & 0xFFu);
+            acc = (acc << 2) | e[0];
+            flags = (flags << 1) | e[256];
         }
+    }
+    be = acc;
+    inv = __builtin_bitreverse32(flags) >> 16;
+}
+
+__device__ __forceinline__ void stage_lut(uint8_t* lut, uint32_t tid, uint32_t nthreads)
+{
+    for (uint32_t i = tid; i < 256; i += nthreads) {
+        const uint32_t c = vg_nt4(i);
+        lut[i] = (uint8_t)(c & 3u);
+        lut[256 + i] = (uint8_t)(c >> 2);
     }
 }
 
@@ -173,15 +184,8 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
     if (FLDS) off += (size_t)4 << p.table.filter_words_log2;
     uint64_t* s_queue = reinterpret_cast<uint64_t*>(smem + off) + (size_t)wave * VG_QCAP;
     if (MODE == MODE_COUNT) off += (size_t)nwaves * VG_QCAP * 8;
-    uint8_t* s_lut_code = smem + off;
-    uint8_t* s_lut_inv = s_lut_code + 256;
-
-    // stage seq_nt4_table (include/seq_nt4_table.hpp:5-22) as code / invalid-flag byte tables
-    for (uint32_t i = tid; i < 256; i += blockDim.x) {
-        const uint32_t c = vg_nt4(i);
-        s_lut_code[i] = (uint8_t)(c & 3u);
-        s_lut_inv[i] = (uint8_t)(c >> 2);
-    }
+    uint8_t* s_lut = smem + off;
+    stage_lut(s_lut, tid, blockDim.x);
     if (FLDS) {
         const uint32_t nq = 1u << (p.table.filter_words_log2 - 2);  // uint4 count (>= 1: words >= 4)
         const uint4* src = reinterpret_cast<const uint4*>(p.table.filter);
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
     if (r0 > 0) {
         const uint4 raw = load_chunk(p.bases, p.n_bytes, ((r0 - 1) << 10) + lane * 16);
         uint32_t be, inv;
-        encode16(raw, s_lut_code, s_lut_inv, be, inv);
+        encode16(raw, s_lut, be, inv);
         const uint32_t rcw = rc_word(be);
         pr1_be = __shfl(be, src1);   pr2_be = __shfl(be, src2);
         pr1_rc = __shfl(rcw, src1);  pr2_rc = __shfl(rcw, src2);
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
         if (r + 1 < r1) raw_next = load_chunk(p.bases, p.n_bytes, ((r + 1) << 10) + lane * 16);
 
         uint32_t be, inv;
-        encode16(raw, s_lut_code, s_lut_inv, be, inv);
+        encode16(raw, s_lut, be, inv);
         const uint32_t rcw = rc_word(be);
         // neighbours: lane-1 / lane-2 of this row, or the tail of the previous row
         const uint32_t r1_be = __shfl(be, src1), r2_be = __shfl(be, src2);
@@ -450,13 +454,8 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
     size_t off = LDS_SFX ? (size_t)VG_SFX_WORDS * 4 : 0;
     uint64_t* s_queue = reinterpret_cast<uint64_t*>(smem + off) + (size_t)wave * QC;
     off += (size_t)nwaves * QC * 8;
-    uint8_t* s_lut_code = smem + off;
-    uint8_t* s_lut_inv = s_lut_code + 256;
-    for (uint32_t i = tid; i < 256; i += blockDim.x) {
-        const uint32_t c = vg_nt4(i);
-        s_lut_code[i] = (uint8_t)(c & 3u);
-        s_lut_inv[i] = (uint8_t)(c >> 2);
-    }
+    uint8_t* s_lut = smem + off;
+    stage_lut(s_lut, tid, blockDim.x);
     if (LDS_SFX) {
         const uint4* src = reinterpret_cast<const uint4*>(p.table.sfx);
         uint4* dst = reinterpret_cast<uint4*>(s_sfx);
@@ -470,7 +469,8 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
     const uint64_t total_rows = p.row_end;
     const uint64_t total_waves = (uint64_t)gridDim.x * nwaves;
     const uint64_t rpw = (total_rows + total_waves - 1) / total_waves;
-    const uint64_t gw = (uint64_t)blockIdx.x * nwaves + wave;
+    // the wave index is uniform: keep the row counters in SGPRs
+    const uint64_t gw = (uint64_t)blockIdx.x * nwaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
     const uint64_t r0 = gw * rpw;
     const uint64_t r1 = r0 + rpw < total_rows ? r0 + rpw : total_rows;
     if (r0 >= r1) return;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
     if (LDS_SFX && r0 > 0) {
         const uint4 raw = load_row(r0 - 1);
         uint32_t be, inv;
-        encode16(raw, s_lut_code, s_lut_inv, be, inv);
+        encode16(raw, s_lut, be, inv);
         pr1_be = __shfl(be, src1);   pr2_be = __shfl(be, src2);
         pr1_inv = __shfl(inv, src1); pr2_inv = __shfl(inv, src2);
     }
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
         raw_next = load_row(r + 1 < r1 ? r + 1 : r);  // prefetch (the last iteration re-reads its own row)
 
         uint32_t be, inv;
-        encode16(raw, s_lut_code, s_lut_inv, be, inv);
+        encode16(raw, s_lut, be, inv);
         const uint32_t r1_be = __shfl(be, src1), r2_be = __shfl(be, src2);
         const uint32_t r1_inv = __shfl(inv, src1), r2_inv = __shfl(inv, src2);
         const uint32_t F0 = be;
