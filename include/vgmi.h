@@ -105,6 +105,12 @@ int vgmi_counts_finish(vgmi_ctx *ctx, uint8_t *host_cov_out, uint8_t *host_cov_n
 /* Device-side variant: leaves the results in device buffers of the same shapes (no D2H). */
 int vgmi_counts_finish_device(vgmi_ctx *ctx, uint8_t *dev_cov_out, uint8_t *dev_cov_node_out,
                               uint64_t *dev_hist256_out);
+/* Strong-scaling mode for ONE huge sample (not in the reference): the reads are sharded
+ * over ranks, every rank counts its shard, then the raw 32-bit counters (key order, not yet clamped)
+ * are summed with one all-reduce (RCCL) and written back before vgmi_counts_finish clamps them:
+ * min(255, sum over ranks) is exactly the single-GPU result. */
+int vgmi_counts_export_device(vgmi_ctx *ctx, uint32_t *dev_counts_out /* n_keys */);
+int vgmi_counts_import_device(vgmi_ctx *ctx, const uint32_t *dev_counts /* n_keys */);
 /* Accumulated GPU time (HIP events on the context stream) of the read-counting kernel since
  * the last reset, and the number of launches; for roofline accounting. */
 int vgmi_count_kernel_ms(vgmi_ctx *ctx, float *ms, uint64_t *launches);

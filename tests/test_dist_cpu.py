@@ -13,11 +13,19 @@ from varigraph_amd import dist as vdist
 
 
 class FakeCtx:
-    """Stands in for vgmi.Context: same three table-image methods over CPU tensors."""
+    """Stands in for vgmi.Context: same table-image and counter methods over CPU tensors."""
 
-    def __init__(self, image=None):
+    def __init__(self, image=None, counts=None):
         self.image = image
         self.imported = None
+        self.counts = counts
+        self.n_keys = 0 if counts is None else counts.numel()
+
+    def counts_export_device(self, t):
+        t.copy_(self.counts)
+
+    def counts_import_device(self, t):
+        self.counts = t.clone()
 
     def table_image_bytes(self):
         return int(self.image.numel())
@@ -46,6 +54,10 @@ def _worker(rank, world, port, q):
         got = vdist.broadcast_arrays(arrays, dist, rank, dev)
         ok_arr = (got["node_off"].dtype == np.uint64 and got["node_off"][-1] == 30 and got["idx"][0] == 29
                   and got["flags"].sum() == 15)
+        # read-sharded sample: raw counters summed over ranks
+        cctx = FakeCtx(counts=torch.arange(10, dtype=torch.int32) * (rank + 1))
+        vdist.allreduce_counts(cctx, dist, dev)
+        ok_arr = ok_arr and bool(torch.equal(cctx.counts, torch.arange(10, dtype=torch.int32) * 3))
         t = vdist.max_over_ranks(1.0 + rank, dist, dev)
         s = vdist.sum_over_ranks(10.0 * (rank + 1), dist, dev)
         q.put((rank, ok_img, ok_arr, t, s, vdist.shard_samples(8, world, rank)))

@@ -517,3 +517,44 @@ def test_full_size_c2_properties(ctx):
     on_sample = np.isin(keys, hk)
     assert on_sample.sum() > 0.9 * keys.size
     assert (full[on_sample] == 255).all()
+
+
+@pytest.mark.parametrize("name", ["cohort_snp", "c1"])
+def test_read_sharded_sample_sums_to_single_gpu_result(name):
+    """Strong-scaling mode: two contexts count the two halves of one sample, their raw counters are
+    summed (what the RCCL all-reduce does across ranks) and imported: clamped result == single pass."""
+    import torch
+    cohort = get_cohort(name)
+    block = cohort.block()
+    if name == "cohort_snp":
+        block = np.tile(block, 30)           # push some counters past 255 so the clamp matters
+        n_reads = cohort.n_reads * 30
+    else:
+        n_reads = cohort.n_reads
+    nl = np.flatnonzero(block == 10)
+    half = int(nl[len(nl) // 2]) + 1
+    a, b = vgmi.Context(0, buffer_mib=16), vgmi.Context(0, buffer_mib=16)
+    try:
+        for c in (a, b):
+            c.table_upload(cohort.graph.keys, cohort.k)
+            c.counts_reset()
+        a.reads_submit(block, n_reads)
+        want, _, _ = a.counts_finish()
+        a.counts_reset()
+        a.reads_submit(block[:half], len(nl) // 2 + 1)
+        b.reads_submit(block[half:], n_reads - (len(nl) // 2 + 1))
+        ta = torch.empty(cohort.graph.keys.size, dtype=torch.int32, device="cuda")
+        tb = torch.empty_like(ta)
+        a.counts_finish()                    # drain the staged kernels before exporting
+        b.counts_finish()
+        a.counts_export_device(ta)
+        b.counts_export_device(tb)
+        tot = ta + tb
+        for c in (a, b):
+            c.counts_import_device(tot)
+            got, _, _ = c.counts_finish()
+            assert np.array_equal(got, want)
+        assert (want == 255).any()
+    finally:
+        a.close()
+        b.close()

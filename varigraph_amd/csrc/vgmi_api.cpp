@@ -701,6 +701,26 @@ int vgmi_counts_finish_device(vgmi_ctx* c, uint8_t* dev_cov, uint8_t* dev_cov_no
     return check_status(c);
 }
 
+static int counts_xfer(vgmi_ctx* c, uint32_t* dev, bool import)
+{
+    if (!c || !dev) return VGMI_E_INVALID;
+    if (!c->has_table) return fail(c, VGMI_E_STATE, "no table");
+    if (reinterpret_cast<uintptr_t>(dev) & 3) return fail(c, VGMI_E_INVALID, "device pointer must be 4-byte aligned");
+    HIPCHK(c, hipSetDevice(c->device));
+    for (auto& s : c->stage)
+        if (s.busy) HIPCHK(c, hipStreamWaitEvent(c->stream, s.done, 0));
+    HIPCHK(c, launch_counts_xfer(c->tv.slots, c->d_key_slot, c->d_counts, dev, c->hdr.n_keys, import, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VGMI_OK;
+}
+
+int vgmi_counts_export_device(vgmi_ctx* c, uint32_t* dev_counts_out) { return counts_xfer(c, dev_counts_out, false); }
+
+int vgmi_counts_import_device(vgmi_ctx* c, const uint32_t* dev_counts)
+{
+    return counts_xfer(c, const_cast<uint32_t*>(dev_counts), true);
+}
+
 int vgmi_count_kernel_ms(vgmi_ctx* c, float* ms, uint64_t* launches)
 {
     if (!c) return VGMI_E_INVALID;

@@ -60,6 +60,8 @@ hipError_t launch_table_insert(const TableView& t, const uint64_t* keys, uint64_
 hipError_t launch_counts_reset(VgSlot* slots, uint64_t cap, hipStream_t st);
 hipError_t launch_cov(const VgSlot* slots, const uint32_t* key_slot, const uint32_t* counts, uint64_t n, const uint8_t* flag,
                       uint8_t* cov, unsigned long long* hist, hipStream_t st);
+hipError_t launch_counts_xfer(VgSlot* slots, const uint32_t* key_slot, uint32_t* dense, uint32_t* ext, uint64_t n, bool import,
+                              hipStream_t st);
 hipError_t launch_node_gather(const uint8_t* cov, const uint32_t* key_index, uint64_t n, uint8_t* cov_node, hipStream_t st);
 hipError_t launch_bloom_query(const BloomView& b, const uint64_t* keys, uint64_t n, uint8_t* min_out, uint8_t* nz_out,
                               hipStream_t st);

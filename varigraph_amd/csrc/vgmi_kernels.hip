@@ -801,6 +801,18 @@ __global__ void cov_kernel(const VgSlot* slots, const uint32_t* key_slot, const 
             if (s_hist[i]) atomicAdd(&hist[i], (unsigned long long)s_hist[i]);
 }
 
+// raw 32-bit counters <-> dense key-ordered array (all-reduce of a read-sharded sample)
+__global__ void counts_xfer_kernel(VgSlot* slots, const uint32_t* key_slot, uint32_t* dense, uint32_t* ext, uint64_t n,
+                                   bool import)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t* cell = dense ? &dense[i] : &slots[key_slot[i]].count;
+        if (import) *cell = ext[i];
+        else ext[i] = *cell;
+    }
+}
+
 // K5 part 2: per-node depth gather in CSR order
 __global__ void node_gather_kernel(const uint8_t* cov, const uint32_t* key_index, uint64_t n, uint8_t* cov_node)
 {
@@ -932,6 +944,14 @@ hipError_t launch_cov(const VgSlot* slots, const uint32_t* key_slot, const uint3
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(cov_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, slots, key_slot, counts, n, flag, cov, hist);
+    return hipGetLastError();
+}
+
+hipError_t launch_counts_xfer(VgSlot* slots, const uint32_t* key_slot, uint32_t* dense, uint32_t* ext, uint64_t n, bool import,
+                              hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(counts_xfer_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, slots, key_slot, dense, ext, n, import);
     return hipGetLastError();
 }
 

@@ -68,3 +68,14 @@ def sum_over_ranks(value, dist, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def allreduce_counts(ctx, dist, device):
+    """Read-sharded single sample: sum the raw per-key counters over all ranks (one RCCL all-reduce)
+    and write the totals back, so that counts_finish() on any rank yields min(255, global total)."""
+    import torch
+    t = torch.empty(max(ctx.n_keys, 1), dtype=torch.int32, device=device)
+    ctx.counts_export_device(t)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    ctx.counts_import_device(t)
+    return t

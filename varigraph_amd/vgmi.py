@@ -50,6 +50,8 @@ def load_library():
         "vgmi_counts_finish": (i32, [vp, vp, vp, vp]),
         "vgmi_counts_finish_device": (i32, [vp, vp, vp, vp]),
         "vgmi_count_kernel_ms": (i32, [vp, C.POINTER(C.c_float), C.POINTER(u64)]),
+        "vgmi_counts_export_device": (i32, [vp, vp]),
+        "vgmi_counts_import_device": (i32, [vp, vp]),
         "vgmi_sketch_keys": (i32, [vp, vp, sz, vp, sz, u32, vp]),
         "vgmi_bloom_params": (i32, [u64, C.c_double, C.POINTER(u64), C.POINTER(u32)]),
         "vgmi_bloom_create": (i32, [vp, u64, u32, vp]),
@@ -217,6 +219,12 @@ class Context:
 
     def counts_finish_device(self, dev_cov=None, dev_cov_node=None, dev_hist=None):
         self._chk(self._l.vgmi_counts_finish_device(self._h, _ptr(dev_cov), _ptr(dev_cov_node), _ptr(dev_hist)))
+
+    def counts_export_device(self, dev_u32):
+        self._chk(self._l.vgmi_counts_export_device(self._h, _ptr(dev_u32)))
+
+    def counts_import_device(self, dev_u32):
+        self._chk(self._l.vgmi_counts_import_device(self._h, _ptr(dev_u32)))
 
     def count_kernel_ms(self):
         ms, n = C.c_float(), C.c_uint64()
