@@ -554,7 +554,8 @@ def test_read_sharded_sample_sums_to_single_gpu_result(name):
             c.counts_import_device(tot)
             got, _, _ = c.counts_finish()
             assert np.array_equal(got, want)
-        assert (want == 255).any()
+        if name == "cohort_snp":
+            assert (want == 255).any()
     finally:
         a.close()
         b.close()
