@@ -15,6 +15,14 @@ def env_rank_world():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
+def _sync(device):
+    """Collectives on the nccl/RCCL backend are asynchronous to the host; the vgmi context works on
+    its own HIP streams, so make the collective's result visible before handing buffers over."""
+    import torch
+    if getattr(device, "type", str(device)) == "cuda" or str(device).startswith("cuda"):
+        torch.cuda.synchronize(device)
+
+
 def shard_samples(n_samples, world, rank):
     """Indices of the samples rank `rank` genotypes (round robin: sample s -> rank s mod world)."""
     return list(range(rank, n_samples, world))
@@ -33,6 +41,7 @@ def broadcast_table_image(ctx, dist, rank, device, src=0):
     if rank == src:
         ctx.table_export(img)
     dist.broadcast(img, src)
+    _sync(device)
     if rank != src:
         ctx.table_import(img)
     return nbytes
@@ -77,5 +86,6 @@ def allreduce_counts(ctx, dist, device):
     t = torch.empty(max(ctx.n_keys, 1), dtype=torch.int32, device=device)
     ctx.counts_export_device(t)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    _sync(device)
     ctx.counts_import_device(t)
     return t
