@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--reads", type=int, default=100_000_000, help="reads per sample (2 per pair)")
     ap.add_argument("--cpu-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo + VGMI_BENCH_DEVICE=0 lets several ranks share one GPU "
+                         "to exercise the N>1 control flow on a single-GPU box (debug only)")
     ap.add_argument("--shard-reads", action="store_true",
                     help="strong scaling: ONE sample of --reads reads sharded over the ranks, raw counters summed "
                          "with one RCCL all-reduce per step (default: one sample per rank, weak scaling)")
@@ -136,10 +139,17 @@ def main():
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
+    if "VGMI_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["VGMI_BENCH_DEVICE"])
     torch.cuda.set_device(local)
+    comm_dev = torch.device("cuda", local) if args.backend == "nccl" else torch.device("cpu")
+    ctx_dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=ctx_dev)
+        else:
+            dist.init_process_group("gloo")
     if rank == 0:
         build.build_vgmi()
         build.build_host()
@@ -153,10 +163,10 @@ def main():
     if rank == 0:
         ctx.table_upload(g["keys"], g["k"])
     if dist:
-        vdist.broadcast_table_image(ctx, dist, rank, torch.device("cuda", local))
+        vdist.broadcast_table_image(ctx, dist, rank, comm_dev, ctx_device=ctx_dev)
         # node CSR + flags: small host-side graph data every rank needs for the gather
         arrs = {k: g[k] for k in ("node_off", "node_key_index", "hom_flag")} if rank == 0 else None
-        arrs = vdist.broadcast_arrays(arrs, dist, rank, torch.device("cuda", local))
+        arrs = vdist.broadcast_arrays(arrs, dist, rank, comm_dev)
         node_off, node_key_index, hom_flag = arrs["node_off"], arrs["node_key_index"], arrs["hom_flag"]
     else:
         node_off, node_key_index, hom_flag = g["node_off"], g["node_key_index"], g["hom_flag"]
@@ -188,7 +198,7 @@ def main():
         ctx.counts_reset()
         ctx.reads_submit_device(d_block, n_bytes, n_reads)
         if shard:
-            vdist.allreduce_counts(ctx, dist, torch.device("cuda", local))
+            vdist.allreduce_counts(ctx, dist, comm_dev, ctx_device=ctx_dev)
         ctx.counts_finish_device(d_cov, d_cov_node, d_hist)
 
     def fence():
@@ -210,7 +220,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist:
-        elapsed = vdist.max_over_ranks(elapsed, dist, torch.device("cuda", local))
+        elapsed = vdist.max_over_ranks(elapsed, dist, comm_dev)
 
     # sanity: the sample must have produced coverage
     cov_sum = int(d_cov.to(torch.int64).sum().item())

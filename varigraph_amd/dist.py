@@ -28,21 +28,26 @@ def shard_samples(n_samples, world, rank):
     return list(range(rank, n_samples, world))
 
 
-def broadcast_table_image(ctx, dist, rank, device, src=0):
+def broadcast_table_image(ctx, dist, rank, device, src=0, ctx_device=None):
     """Rank `src` exports its device table image, everybody else imports it.
-    `ctx` needs table_image_bytes() / table_export(tensor) / table_import(tensor)."""
+    `ctx` needs table_image_bytes() / table_export(tensor) / table_import(tensor).
+    `device` is where the collective runs (cuda for RCCL); `ctx_device` is where the context lives,
+    if different (debug runs over gloo stage through host memory)."""
     import torch
+    ctx_device = ctx_device or device
     sz = torch.zeros(1, dtype=torch.int64, device=device)
     if rank == src:
         sz[0] = ctx.table_image_bytes()
     dist.broadcast(sz, src)
     nbytes = int(sz.item())
-    img = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    img = torch.empty(nbytes, dtype=torch.uint8, device=ctx_device)
     if rank == src:
         ctx.table_export(img)
-    dist.broadcast(img, src)
+    wire = img if str(ctx_device) == str(device) else img.to(device)
+    dist.broadcast(wire, src)
     _sync(device)
     if rank != src:
+        img = wire if wire is img else wire.to(ctx_device)
         ctx.table_import(img)
     return nbytes
 
@@ -79,13 +84,16 @@ def sum_over_ranks(value, dist, device):
     return float(t.item())
 
 
-def allreduce_counts(ctx, dist, device):
+def allreduce_counts(ctx, dist, device, ctx_device=None):
     """Read-sharded single sample: sum the raw per-key counters over all ranks (one RCCL all-reduce)
     and write the totals back, so that counts_finish() on any rank yields min(255, global total)."""
     import torch
-    t = torch.empty(max(ctx.n_keys, 1), dtype=torch.int32, device=device)
+    ctx_device = ctx_device or device
+    t = torch.empty(max(ctx.n_keys, 1), dtype=torch.int32, device=ctx_device)
     ctx.counts_export_device(t)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    wire = t if str(ctx_device) == str(device) else t.to(device)
+    dist.all_reduce(wire, op=dist.ReduceOp.SUM)
     _sync(device)
+    t = wire if wire is t else wire.to(ctx_device)
     ctx.counts_import_device(t)
     return t
