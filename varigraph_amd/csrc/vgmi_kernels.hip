@@ -548,7 +548,10 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 flo[j] = funnel(F1, F0, 2 * (15 - j));        // bits [2(15-j), +32) of F2:F1:F0
-                fw[j] = s_sfx[(flo[j] >> 5) & (VG_SFX_WORDS - 1)];
+                // the bitmap sits at LDS byte offset 0 (this kernel has no static __shared__), so the
+                // word's byte address is the index itself: no base add per lookup
+                typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+                fw[j] = *reinterpret_cast<lds_u32*>((uintptr_t)((flo[j] >> 3) & ((VG_SFX_WORDS - 1) << 2)));
             }
             // ---- phase B: pass masks (per-lane bools live in SGPR pairs; the ballot is the same mask)
 #pragma unroll
