@@ -390,17 +390,21 @@ __device__ __forceinline__ void probe_issue(const TableView& t, const uint64_t* 
 // Finish the batch issued earlier.  A lane whose slot holds another k-mer does NOT chase the
 // chain (that would stall the whole wave for a memory round trip on almost every batch): it puts
 // its k-mer back into the ring with the probe distance advanced, to ride with a later batch.
+// Result of finishing a batch: where the hit's counter lives (nullptr: nothing to add).  The
+// atomic itself is issued by the caller AFTER the next batch's loads (probe_bump), so that the
+// vmcnt wait in front of the next compare is the first one to see it.
 template <uint32_t QC>
-__device__ __forceinline__ void probe_finish(const TableView& t, Pending& pd, uint64_t* queue, uint32_t qhead,
-                                             uint32_t& qtail)
+__device__ __forceinline__ uint32_t* probe_finish(const TableView& t, Pending& pd, uint64_t* queue, uint32_t qhead,
+                                                  uint32_t& qtail)
 {
     bool again = false;
+    uint32_t* bump = nullptr;
     if (pd.active) {
         const uint64_t c = ((uint64_t)pd.v.y << 32) | pd.v.x;
         const uint64_t canon = pd.canon & VG_Q_KMER_MASK;
         if (c == canon) {
-            if (t.counts) atomicAdd(&t.counts[pd.v.w], 1u);     // dense counters, clamped at read-out
-            else if (pd.v.z < 255u) atomicAdd(&t.slots[pd.slot].count, 1u);
+            if (t.counts) bump = &t.counts[pd.v.w];                 // dense counters, clamped at read-out
+            else if (pd.v.z < 255u) bump = &t.slots[pd.slot].count;
         } else if (c != VG_EMPTY) {
             again = true;
         }
@@ -425,8 +429,8 @@ __device__ __forceinline__ void probe_finish(const TableView& t, Pending& pd, ui
                 const uint4 v = *reinterpret_cast<const uint4*>(&t.slots[sl]);
                 const uint64_t c = ((uint64_t)v.y << 32) | v.x;
                 if (c == canon) {
-                    if (t.counts) atomicAdd(&t.counts[v.w], 1u);
-                    else if (v.z < 255u) atomicAdd(&t.slots[sl].count, 1u);
+                    if (t.counts) bump = &t.counts[v.w];
+                    else if (v.z < 255u) bump = &t.slots[sl].count;
                     break;
                 }
                 if (c == VG_EMPTY) break;
@@ -434,6 +438,12 @@ __device__ __forceinline__ void probe_finish(const TableView& t, Pending& pd, ui
         }
     }
     pd.active = false;
+    return bump;
+}
+
+__device__ __forceinline__ void probe_bump(uint32_t* bump)
+{
+    if (bump) atomicAdd(bump, 1u);
 }
 
 // LDS_SFX: suffix bitmap of 2^20 bits staged in LDS (small graphs, one 1024-thread workgroup per CU)
@@ -619,19 +629,20 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
             }
             if (p.dbg & 1u) { qhead = qtail; continue; }
             while (qtail - qhead >= 64u) {
-                probe_finish<QC>(p.table, pd, s_queue, qhead, qtail);
+                uint32_t* bump = probe_finish<QC>(p.table, pd, s_queue, qhead, qtail);
                 probe_issue<K, QC>(p.table, s_queue, qhead, 64u, lane, pd);
+                probe_bump(bump);
                 qhead += 64u;
             }
         }
         if (__builtin_expect(slow_from != 16, 0)) {
             // ---- slow path: flush, then one step at a time
-            probe_finish<QC>(p.table, pd, s_queue, qhead, qtail);
+            probe_bump(probe_finish<QC>(p.table, pd, s_queue, qhead, qtail));
             while (qtail != qhead) {
                 const uint32_t n = qtail - qhead < 64u ? qtail - qhead : 64u;
                 probe_issue<K, QC>(p.table, s_queue, qhead, n, lane, pd);
                 qhead += n;
-                probe_finish<QC>(p.table, pd, s_queue, qhead, qtail);
+                probe_bump(probe_finish<QC>(p.table, pd, s_queue, qhead, qtail));
             }
 #pragma unroll 1
             for (int j = slow_from; j < 16; ++j) {
@@ -660,17 +671,17 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
                     const uint32_t n = qtail - qhead < 64u ? qtail - qhead : 64u;
                     probe_issue<K, QC>(p.table, s_queue, qhead, n, lane, pd);
                     qhead += n;
-                    probe_finish<QC>(p.table, pd, s_queue, qhead, qtail);
+                    probe_bump(probe_finish<QC>(p.table, pd, s_queue, qhead, qtail));
                 }
             }
         }
     }
-    probe_finish<QC>(p.table, pd, s_queue, qhead, qtail);
+    probe_bump(probe_finish<QC>(p.table, pd, s_queue, qhead, qtail));
     while (qtail != qhead) {
         const uint32_t n = qtail - qhead < 64u ? qtail - qhead : 64u;
         probe_issue<K, QC>(p.table, s_queue, qhead, n, lane, pd);
         qhead += n;
-        probe_finish<QC>(p.table, pd, s_queue, qhead, qtail);
+        probe_bump(probe_finish<QC>(p.table, pd, s_queue, qhead, qtail));
     }
 }
 
