@@ -30,8 +30,8 @@ struct ImageHeader {  // first 256 bytes of the table image
     uint32_t filter_words_log2;
     uint64_t n_keys;
     uint64_t cap;
-    uint64_t off_slots, off_key_slot, off_filter, off_sfx, total_bytes;
-    uint32_t sfx_bits_log2, reserved;
+    uint64_t off_slots, off_key_slot, off_filter, off_grid, total_bytes;
+    uint32_t grid_words_log2, reserved;
     uint8_t pad[256 - 8 - 4 - 4 - 8 - 8 - 40 - 8];
 };
 static_assert(sizeof(ImageHeader) == 256, "image header is 256 bytes");
@@ -175,22 +175,21 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     h.off_slots = 256;
     h.off_key_slot = align(h.off_slots + cap * sizeof(VgSlot));
     h.off_filter = align(h.off_key_slot + (n_keys ? n_keys : 1) * 4);
-    // suffix bitmap of the fast kernels (vgmi_device.h): 2^20 bits (LDS resident) while that stays
-    // sparse, else >= 32 bits per key (2 entries per key -> <= ~6 % fill), at most 2k bits
-    h.sfx_bits_log2 = 0;
-    h.off_sfx = 0;
+    // grid filter of the k = 27 kernels (vgmi_device.h): 2^15 words in LDS while the graph is small,
+    // else >= 32 bits per key in global memory (~2.8 sixteen-mers per key, 3 bits each)
+    h.grid_words_log2 = 0;
+    h.off_grid = 0;
     uint64_t end = h.off_filter + (4ULL << h.filter_words_log2);
-    if (k >= VG_SFX_BASES) {
-        uint32_t b = VG_SFX_LDS_LOG2;
-        if (2 * n_keys > VG_SFX_BITS / 8) {
-            // large graphs: grid bitmap (vgmi_device.h), ~3 distinct 16-mers per key -> >= 32 bits per key
-            b = ceil_log2(32 * n_keys);
-            if (b < VG_SFX_LDS_LOG2 + 1) b = VG_SFX_LDS_LOG2 + 1;
-            if (b > 40) b = 40;
+    if (k == 27) {
+        uint32_t b = VG_GRID_LDS_WORDS_LOG2;
+        if (n_keys > VG_GRID_LDS_MAX_KEYS) {
+            b = ceil_log2(32 * n_keys) - 5;
+            if (b < VG_GRID_LDS_WORDS_LOG2 + 1) b = VG_GRID_LDS_WORDS_LOG2 + 1;
+            if (b > 33) b = 33;
         }
-        h.sfx_bits_log2 = b;
-        h.off_sfx = align(end);
-        end = h.off_sfx + ((1ULL << b) >> 3);
+        h.grid_words_log2 = b;
+        h.off_grid = align(end);
+        end = h.off_grid + (4ULL << b);
     }
     h.total_bytes = align(end);
 }
@@ -206,15 +205,15 @@ int adopt_image(vgmi_ctx* c)
     c->tv.filter = reinterpret_cast<const uint32_t*>(c->d_image + h.off_filter);
     c->tv.filter_words_log2 = h.filter_words_log2;
     c->tv.filter_shift = 32 - h.filter_words_log2;
-    c->tv.sfx = h.off_sfx ? reinterpret_cast<const uint32_t*>(c->d_image + h.off_sfx) : nullptr;
-    c->tv.sfx_bits_log2 = h.sfx_bits_log2;
-    c->fast27 = h.k == 27 && h.off_sfx;                       // count27_kernel applies
-    c->fast27_lds = c->fast27 && h.sfx_bits_log2 == VG_SFX_LDS_LOG2;  // with the bitmap in LDS
+    c->tv.grid = h.off_grid ? reinterpret_cast<const uint32_t*>(c->d_image + h.off_grid) : nullptr;
+    c->tv.grid_words_log2 = h.grid_words_log2;
+    c->fast27 = h.k == 27 && h.off_grid;                       // count27_kernel applies
+    c->fast27_lds = c->fast27 && h.grid_words_log2 == VG_GRID_LDS_WORDS_LOG2;  // with the filter in LDS
     c->d_key_slot = reinterpret_cast<uint32_t*>(c->d_image + h.off_key_slot);
     c->filter_in_lds = filter_fits_lds(h.filter_words_log2);
     HIPCHK(c, hipMalloc(&c->d_cov, h.n_keys ? h.n_keys : 1));
     c->tv.counts = nullptr;
-    if (2 * h.n_keys > VG_SFX_BITS / 8) {   // large graph: 4 B/key dense counters stay Infinity-Cache resident
+    if (h.n_keys > VG_GRID_LDS_MAX_KEYS) {   // large graph: 4 B/key dense counters stay Infinity-Cache resident
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_counts), h.n_keys * 4));
         HIPCHK(c, hipMemset(c->d_counts, 0, h.n_keys * 4));
         c->tv.counts = c->d_counts;
@@ -445,7 +444,7 @@ int vgmi_table_upload(vgmi_ctx* c, const uint64_t* keys, size_t n_keys, uint32_t
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_keys), n_keys * 8));
         HIPCHK(c, hipMemcpyAsync(d_keys, keys, n_keys * 8, hipMemcpyHostToDevice, c->stream));
         hipError_t e = launch_table_insert(c->tv, d_keys, n_keys, k, c->d_key_slot,
-                                           const_cast<uint32_t*>(c->tv.filter), const_cast<uint32_t*>(c->tv.sfx),
+                                           const_cast<uint32_t*>(c->tv.filter), const_cast<uint32_t*>(c->tv.grid),
                                            c->d_status, c->stream);
         if (e != hipSuccess) { (void)hipFree(d_keys); HIPCHK(c, e); }
     }

@@ -151,27 +151,24 @@ VG_HD uint64_t vg_revcomp(uint64_t x, uint32_t k)
     return r >> (64 - 2 * k);
 }
 
-// Suffix bitmap of the fast read kernels: one bit per value of the low `sfx_bits_log2` bits of a
-// k-mer (its last sfx_bits_log2/2 bases).  Bit s is set iff s is the suffix of a graph k-mer in
-// EITHER orientation, so a read k-mer is tested in the orientation it is read in (no reverse
-// complement, no hash) and can only pass if its suffix ends some graph k-mer or its reverse
-// complement.  Small graphs use 2^20 bits (128 KiB, LDS resident); larger graphs a global bitmap
-// sized for <= ~6 % fill (2 entries per key, >= 32 bits per key).
-#define VG_SFX_BASES 10u
-#define VG_SFX_LDS_LOG2 (2 * VG_SFX_BASES)
-#define VG_SFX_BITS (1u << VG_SFX_LDS_LOG2)
-#define VG_SFX_WORDS (VG_SFX_BITS / 32)
-
-// Grid bitmap of the large-graph read kernel.  Every 27-mer contains exactly one 16-mer that ENDS
-// at a stream position divisible by 12 (27 - 16 + 1 = 12).  The bitmap holds a hash of every
-// 16-mer found at any of the 12 offsets of any graph k-mer, in both orientations, so a read only
-// probes it at every 12th position (10x fewer random accesses than one probe per k-mer); a hit
-// makes the 12 k-mers containing that 16-mer candidates for the exact table.
+// Grid filter of the fast read kernels (k = 27).  Every 27-mer contains exactly one 16-mer that
+// ENDS at a stream position divisible by 12 (27 - 16 + 1 = 12).  The filter is a blocked Bloom
+// filter (3 bits in one 32-bit word) over every 16-mer found at any of the 12 offsets of any graph
+// k-mer, in both orientations.  A read therefore probes it only at every 12th position -- in the
+// orientation it is read in, no reverse complement, no canonical min -- and a hit makes the 12
+// k-mers containing that 16-mer candidates for the exact table.  Small graphs keep 2^15 words
+// (128 KiB) in LDS; larger graphs use a global bitmap of >= 32 bits per key.
 #define VG_GRID_STEP 12u
 #define VG_GRID_MER 16u
-VG_HD uint64_t vg_grid_index(uint32_t mer16, uint32_t bits_log2)
+#define VG_GRID_LDS_WORDS_LOG2 15u
+#define VG_GRID_LDS_WORDS (1u << VG_GRID_LDS_WORDS_LOG2)
+#define VG_GRID_LDS_MAX_KEYS 65536u
+VG_HD void vg_grid_probe(uint32_t mer16, uint32_t words_log2, uint64_t& word, uint32_t& mask)
 {
-    return ((uint64_t)mer16 * 0x9E3779B97F4A7C15ULL) >> (64 - bits_log2);
+    const uint64_t x = (uint64_t)mer16 * 0x9E3779B97F4A7C15ULL;
+    word = x >> (64 - words_log2);
+    const uint32_t y = (uint32_t)(x >> 8);   // bits below the word index of even the largest filter (2^33 words)
+    mask = (1u << (y & 31u)) | (1u << ((y >> 5) & 31u)) | (1u << ((y >> 10) & 31u));
 }
 
 // slot hash of the exact table (evaluated only for filter passes)

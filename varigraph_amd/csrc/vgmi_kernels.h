@@ -16,8 +16,8 @@ struct TableView {
     const uint32_t* filter;     // blocked-Bloom prefilter, 1 << filter_words_log2 words
     uint32_t filter_words_log2; // >= 2
     uint32_t filter_shift;      // 32 - filter_words_log2
-    const uint32_t* sfx;        // suffix bitmap (2^sfx_bits_log2 bits) or nullptr, see vgmi_device.h
-    uint32_t sfx_bits_log2;     // VG_SFX_LDS_LOG2 (LDS-resident variant) .. 2k
+    const uint32_t* grid;       // grid filter (1 << grid_words_log2 words) or nullptr, see vgmi_device.h
+    uint32_t grid_words_log2;   // VG_GRID_LDS_WORDS_LOG2 (LDS-resident variant) or larger (global variant)
     uint32_t* counts;           // large graphs: dense per-key counters (4 B/key, Infinity-Cache sized) instead of the
                                 // in-slot ones; nullptr for small graphs
 };
@@ -56,7 +56,7 @@ hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, u
 hipError_t launch_seq(int mode, const RowParams& p, const uint64_t* read_off, uint64_t n_reads, hipStream_t st);
 hipError_t launch_table_clear(VgSlot* slots, uint64_t cap, hipStream_t st);
 hipError_t launch_table_insert(const TableView& t, const uint64_t* keys, uint64_t n, uint32_t k, uint32_t* key_slot,
-                               uint32_t* filter_rw, uint32_t* sfx_rw, uint32_t* status, hipStream_t st);
+                               uint32_t* filter_rw, uint32_t* grid_rw, uint32_t* status, hipStream_t st);
 hipError_t launch_counts_reset(VgSlot* slots, uint64_t cap, hipStream_t st);
 hipError_t launch_cov(const VgSlot* slots, const uint32_t* key_slot, const uint32_t* counts, uint64_t n, const uint8_t* flag,
                       uint8_t* cov, unsigned long long* hist, hipStream_t st);

@@ -446,11 +446,11 @@ __device__ __forceinline__ void probe_bump(uint32_t* bump)
     if (bump) atomicAdd(bump, 1u);
 }
 
-// LDS_SFX: suffix bitmap of 2^20 bits staged in LDS (small graphs, one 1024-thread workgroup per CU)
-//          or probed in global memory (large graphs, 256-thread workgroups, as many as fit).
-// QC:      entries of the per-wave pass ring.
-template <bool LDS_SFX, uint32_t QC>
-__global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams p)
+// LDS_BM: grid filter (2^15 words) staged in LDS (small graphs, one 1024-thread workgroup per CU)
+//         or probed in global memory (large graphs, 256-thread workgroups).
+// QC:     entries of the per-wave candidate ring.
+template <bool LDS_BM, uint32_t QC>
+__global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams p)
 {
     constexpr uint32_t K = 27;
     constexpr uint32_t MASK_HI = (1u << (2 * K - 32)) - 1;  // 54-bit k-mer: low word full, 22 bits high
@@ -460,19 +460,19 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
     const uint32_t wave = tid >> 6;
     const uint32_t nwaves = blockDim.x >> 6;
 
-    uint32_t* s_sfx = reinterpret_cast<uint32_t*>(smem);
-    size_t off = LDS_SFX ? (size_t)VG_SFX_WORDS * 4 : 0;
+    size_t off = LDS_BM ? (size_t)VG_GRID_LDS_WORDS * 4 : 0;  // the LDS filter sits at LDS byte offset 0
     uint64_t* s_queue = reinterpret_cast<uint64_t*>(smem + off) + (size_t)wave * QC;
     off += (size_t)nwaves * QC * 8;
     uint8_t* s_lut = smem + off;
     stage_lut(s_lut, tid, blockDim.x);
-    if (LDS_SFX) {
-        const uint4* src = reinterpret_cast<const uint4*>(p.table.sfx);
-        uint4* dst = reinterpret_cast<uint4*>(s_sfx);
-        for (uint32_t i = tid; i < VG_SFX_WORDS / 4; i += blockDim.x) dst[i] = src[i];
+    if (LDS_BM) {
+        const uint4* src = reinterpret_cast<const uint4*>(p.table.grid);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = tid; i < VG_GRID_LDS_WORDS / 4; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
-    const uint32_t* g_sfx = p.table.sfx;
+    const uint32_t* g_grid = p.table.grid;
+    const uint32_t gwl = LDS_BM ? VG_GRID_LDS_WORDS_LOG2 : p.table.grid_words_log2;
 
     // rows [0, row_end) are complete 1 KiB rows, so every load below is an unconditional,
     // perfectly coalesced dwordx4 (the ragged tail row goes to rows_kernel, see vgmi_api.cpp)
@@ -495,16 +495,9 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
 
     const uint32_t src1 = (lane + 63u) & 63u, src2 = (lane + 62u) & 63u;
     uint32_t pr1_be = 0, pr2_be = 0, pr1_inv = 0xFFFFu, pr2_inv = 0xFFFFu, pr_spill = 0;
-    // halo of the range's first row: the LDS variant encodes the previous row once up front; the
-    // grid variant walks it as a warm-up iteration (it also needs that row's candidate spill)
-    const uint64_t rs = (!LDS_SFX && r0 > 0) ? r0 - 1 : r0;
-    if (LDS_SFX && r0 > 0) {
-        const uint4 raw = load_row(r0 - 1);
-        uint32_t be, inv;
-        encode16(raw, s_lut, be, inv);
-        pr1_be = __shfl(be, src1);   pr2_be = __shfl(be, src2);
-        pr1_inv = __shfl(inv, src1); pr2_inv = __shfl(inv, src2);
-    }
+    // the row before the range is walked first as a warm-up iteration: it provides the halo and the
+    // candidate spill of the range's first row
+    const uint64_t rs = r0 > 0 ? r0 - 1 : r0;
 
     uint32_t qhead = 0, qtail = 0;
     Pending pd;
@@ -532,7 +525,7 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
         sm |= sm << 1; sm |= sm << 2; sm |= sm << 4; sm |= sm << 8; sm |= sm << 11;
         const uint32_t ok = ~(uint32_t)(sm >> 32);  // bit j set: window valid
 
-        const bool warm = !LDS_SFX && r < r0;
+        const bool warm = r < r0;
         if (!warm) {   // empty-read check, see rows_kernel
             const uint32_t prev_bit = (i1 >> 15) & 1u;
             const uint32_t adj = inv & ((inv << 1) | prev_bit);
@@ -549,31 +542,15 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
             }
         }
 
+        // ---- phases A+B: probe the grid filter with the 16-mers that END at stream positions
+        // divisible by 12.  1024 % 12 == 16 % 12 == 4, so the first grid offset of this lane's chunk
+        // is 0, 8 or 4 for (r + lane) % 3 == 0, 1, 2, and only the first case has a second grid
+        // point (offset 12).  A hit marks the 12 k-mers ending at offsets [g, g + 11] (spilling
+        // into the next lane's chunk, or the next row for lane 63) as candidates.
         uint32_t flo[16];
-        uint64_t ball[16];  // per-step pass masks; inverse_ballot turns them back into lane predicates for free
+        uint64_t ball[16];  // per-step candidate masks; inverse_ballot turns them back into lane predicates
         uint32_t cnt[16];
-        if (LDS_SFX) {
-            // ---- phase A: low word of the 16 forward k-mers, 16 bitmap words in flight
-            uint32_t fw[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                flo[j] = funnel(F1, F0, 2 * (15 - j));        // bits [2(15-j), +32) of F2:F1:F0
-                // the bitmap sits at LDS byte offset 0 (this kernel has no static __shared__), so the
-                // word's byte address is the index itself: no base add per lookup
-                typedef __attribute__((address_space(3))) const uint32_t lds_u32;
-                fw[j] = *reinterpret_cast<lds_u32*>((uintptr_t)((flo[j] >> 3) & ((VG_SFX_WORDS - 1) << 2)));
-            }
-            // ---- phase B: pass masks (per-lane bools live in SGPR pairs; the ballot is the same mask)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                ball[j] = __builtin_amdgcn_ballot_w64(((fw[j] >> (flo[j] & 31u)) & __builtin_amdgcn_ubfe(ok, j, 1)) != 0);
-                cnt[j] = (uint32_t)__builtin_popcountll(ball[j]);
-            }
-        } else {
-            // ---- grid variant (vgmi_device.h): probe the global bitmap only with the 16-mers that
-            // end at stream positions divisible by 12.  1024 % 12 == 16 % 12 == 4, so the first
-            // grid offset of this lane's chunk is 0, 8 or 4 for (r + lane) % 3 == 0, 1, 2, and only
-            // the first case has a second grid point (offset 12).
+        {
             const uint32_t ph = ((uint32_t)(r % 3) + lane % 3) % 3;
             const uint32_t j1 = ph == 0 ? 0u : (ph == 1 ? 8u : 4u);
             const uint64_t inv48 = ((uint64_t)inv << 32) | ((uint64_t)i1 << 16) | (uint64_t)i2;
@@ -582,13 +559,20 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
             const bool two = ph == 0;
             const uint32_t m2 = funnel(F1, F0, 2 * (15 - 12));
             const bool v2 = two && ((uint32_t)(inv48 >> (17 + 12)) & 0xFFFFu) == 0;
-            const uint32_t gb = p.table.sfx_bits_log2;
-            const uint64_t x1 = vg_grid_index(m1, gb), x2 = vg_grid_index(m2, gb);
-            uint32_t w1 = 0, w2 = 0;
-            if (v1) w1 = g_sfx[x1 >> 5];
-            if (v2) w2 = g_sfx[x2 >> 5];
-            const bool h1 = v1 && ((w1 >> (uint32_t)(x1 & 31u)) & 1u);
-            const bool h2 = v2 && ((w2 >> (uint32_t)(x2 & 31u)) & 1u);
+            uint64_t x1, x2;
+            uint32_t k1, k2, w1 = 0, w2 = 0;
+            vg_grid_probe(m1, gwl, x1, k1);
+            vg_grid_probe(m2, gwl, x2, k2);
+            if (LDS_BM) {
+                typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+                if (v1) w1 = *reinterpret_cast<lds_u32*>((uintptr_t)((uint32_t)x1 << 2));
+                if (v2) w2 = *reinterpret_cast<lds_u32*>((uintptr_t)((uint32_t)x2 << 2));
+            } else {
+                if (v1) w1 = g_grid[x1];
+                if (v2) w2 = g_grid[x2];
+            }
+            const bool h1 = v1 && (w1 & k1) == k1;
+            const bool h2 = v2 && (w2 & k2) == k2;
             const uint32_t cand32 = (h1 ? 0xFFFu << j1 : 0u) | (h2 ? 0xFFFu << 12 : 0u);
             const uint32_t spill = cand32 >> 16;                                   // runs into the next lane's chunk
             const uint32_t sp_in = __shfl(spill, src1);
@@ -649,16 +633,10 @@ __global__ __launch_bounds__(LDS_SFX ? 1024 : 256) void count27_kernel(RowParams
                 const uint32_t fs = 2 * (15 - j);
                 const uint32_t f_lo = funnel(F1, F0, fs);
                 const uint32_t f_hi = funnel(F2, F1, fs) & MASK_HI;
-                bool ps;
-                if (LDS_SFX) {
-                    const uint32_t w = s_sfx[(f_lo >> 5) & (VG_SFX_WORDS - 1)];
-                    ps = ((ok >> j) & 1u) && ((w >> (f_lo & 31u)) & 1u);
-                } else {
-                    uint64_t bj0 = ball[0];
+                uint64_t bj0 = ball[0];
 #pragma unroll
-                    for (int q = 1; q < 16; ++q) bj0 = q == j ? ball[q] : bj0;
-                    ps = (bj0 >> lane) & 1ull;
-                }
+                for (int q = 1; q < 16; ++q) bj0 = q == j ? ball[q] : bj0;
+                const bool ps = (bj0 >> lane) & 1ull;
                 const uint64_t bj = __builtin_amdgcn_ballot_w64(ps);
                 if (!bj) continue;
                 if (ps) {
@@ -746,7 +724,7 @@ __global__ void table_clear_kernel(VgSlot* slots, uint64_t cap)
 }
 
 __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t n, uint32_t k,
-                                    uint32_t* key_slot, uint32_t* filter_rw, uint32_t* sfx_rw, uint32_t* status)
+                                    uint32_t* key_slot, uint32_t* filter_rw, uint32_t* grid_rw, uint32_t* status)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -771,20 +749,15 @@ __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t 
     t.slots[s].key_index = (uint32_t)i;
     key_slot[i] = (uint32_t)s;
     atomicOr(&filter_rw[vg_fhash_word(canon) >> t.filter_shift], vg_fhash_bits(canon, t.filter_words_log2));
-    if (sfx_rw) {
+    if (grid_rw) {   // k = 27 only: 12 + 12 sixteen-mers of the k-mer and of its reverse complement
         const uint64_t rcv = vg_revcomp(canon, k);
-        if (t.sfx_bits_log2 == VG_SFX_LDS_LOG2) {           // suffix bitmap (LDS variant)
-            const uint32_t a = (uint32_t)canon & (VG_SFX_BITS - 1);
-            const uint32_t b = (uint32_t)rcv & (VG_SFX_BITS - 1);
-            atomicOr(&sfx_rw[a >> 5], 1u << (a & 31u));
-            atomicOr(&sfx_rw[b >> 5], 1u << (b & 31u));
-        } else {                                             // grid bitmap (global variant), k = 27 only
-            for (uint32_t off = 0; off < VG_GRID_STEP; ++off) {
-                const uint64_t a = vg_grid_index((uint32_t)(canon >> (2 * off)), t.sfx_bits_log2);
-                const uint64_t b = vg_grid_index((uint32_t)(rcv >> (2 * off)), t.sfx_bits_log2);
-                atomicOr(&sfx_rw[a >> 5], 1u << (uint32_t)(a & 31u));
-                atomicOr(&sfx_rw[b >> 5], 1u << (uint32_t)(b & 31u));
-            }
+        for (uint32_t off = 0; off < VG_GRID_STEP; ++off) {
+            uint64_t w;
+            uint32_t m;
+            vg_grid_probe((uint32_t)(canon >> (2 * off)), t.grid_words_log2, w, m);
+            atomicOr(&grid_rw[w], m);
+            vg_grid_probe((uint32_t)(rcv >> (2 * off)), t.grid_words_log2, w, m);
+            atomicOr(&grid_rw[w], m);
         }
     }
 }
@@ -889,14 +862,14 @@ static hipError_t launch_rows_t(const RowParams& p, uint32_t grid, uint32_t bloc
 
 #define VG_QCAP_GLOBAL 512u  // ring entries per wave of the global-bitmap variant (dense hits expected)
 
-template <bool LDS_SFX, uint32_t QC>
+template <bool LDS_BM, uint32_t QC>
 static hipError_t launch_count27_t(const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)
 {
-    const size_t lds = (LDS_SFX ? (size_t)VG_SFX_WORDS * 4 : 0) + (size_t)(block / 64) * QC * 8 + 512;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&count27_kernel<LDS_SFX, QC>),
+    const size_t lds = (LDS_BM ? (size_t)VG_GRID_LDS_WORDS * 4 : 0) + (size_t)(block / 64) * QC * 8 + 512;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&count27_kernel<LDS_BM, QC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((count27_kernel<LDS_SFX, QC>), dim3(grid), dim3(block), lds, st, p);
+    hipLaunchKernelGGL((count27_kernel<LDS_BM, QC>), dim3(grid), dim3(block), lds, st, p);
     return hipGetLastError();
 }
 
@@ -939,11 +912,11 @@ hipError_t launch_table_clear(VgSlot* slots, uint64_t cap, hipStream_t st)
 }
 
 hipError_t launch_table_insert(const TableView& t, const uint64_t* keys, uint64_t n, uint32_t k, uint32_t* key_slot,
-                               uint32_t* filter_rw, uint32_t* sfx_rw, uint32_t* status, hipStream_t st)
+                               uint32_t* filter_rw, uint32_t* grid_rw, uint32_t* status, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(table_insert_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, t, keys, n, k, key_slot,
-                       filter_rw, sfx_rw, status);
+                       filter_rw, grid_rw, status);
     return hipGetLastError();
 }
 
