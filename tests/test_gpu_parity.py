@@ -559,3 +559,34 @@ def test_read_sharded_sample_sums_to_single_gpu_result(name):
     finally:
         a.close()
         b.close()
+
+
+@pytest.mark.parametrize("table_mul", ["4", "2"])
+def test_every_kmer_counted_once_at_any_alignment(table_mul, monkeypatch):
+    """A 400-base sequence whose k-mers are all graph k-mers, placed at assorted stream offsets (row
+    boundaries, wave-range boundaries, the last positions before the ragged tail): every k-mer must be
+    counted exactly once.  Regression for (a) the flush of a wave that owns a single row while probes
+    collide in the table (re-queue path; load factor 0.5 makes collisions frequent) and (b) k-mers
+    ending in the last <= 11 positions of the last complete row (no grid offset left in the fast
+    kernel's rows: they belong to the generic tail launch)."""
+    monkeypatch.setenv("VGMI_TABLE_MUL", table_mul)
+    rng = np.random.default_rng(1)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    S = acgt[rng.integers(0, 4, size=400)].tobytes()
+    keys_pos = o.sketch(S, 27)
+    uk, inv = np.unique(keys_pos, return_inverse=True)
+    want = np.bincount(inv, minlength=uk.size).astype(np.uint8)
+    c = vgmi.Context(0)
+    try:
+        c.table_upload(uk, 27)
+        for pre in [0, 1, 5, 13, 100, 623, 624, 635, 1000, 1019, 2047, 3000, 5000]:
+            for post in [0, 3000]:
+                filler = (b"N" * pre + b"\n") if pre else b""
+                tail = (b"N" * post + b"\n") if post else b""
+                blk = np.frombuffer(filler + S + b"\n" + tail, dtype=np.uint8)
+                c.counts_reset()
+                c.reads_submit(blk, 1 + (1 if pre else 0) + (1 if post else 0))
+                cov, _, _ = c.counts_finish()
+                assert np.array_equal(cov, want), (pre, post, int((cov != want).sum()))
+    finally:
+        c.close()

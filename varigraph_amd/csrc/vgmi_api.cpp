@@ -257,21 +257,26 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
         uint32_t grid, block;
         rows_geometry(c, c->filter_in_lds, grid, block);
         if (c->fast27 && !c->force_generic) {
-            // complete 1 KiB rows -> fast kernel; the ragged tail row (if any) -> generic kernel,
-            // which takes its halo from the last complete row
+            // complete 1 KiB rows -> fast kernel.  It covers every k-mer ending at or before its last
+            // grid offset (largest position = 11 mod 12 inside those rows); the generic kernel takes
+            // the ends after that: the ragged tail row plus at most 11 positions of the last full row.
             p.row_end = n_bytes >> 10;
+            uint64_t emit_from = 0;
             if (p.row_end) {
                 if (c->fast27_lds) { block = 1024; grid = (uint32_t)c->n_cu; }
                 else {
-                    // global-bitmap variant: random-access bound; more than ~16 waves per CU only adds
-                    // L2 thrash (measured: 8 workgroups/CU 37 ms vs 4 workgroups/CU 31 ms, chr20 class)
+                    // global-filter variant: random-access bound; more than ~16 waves per CU only adds
+                    // L2 thrash
                     block = 256;
                     grid = (uint32_t)c->n_cu * (c->wgs_per_cu ? c->wgs_per_cu : 4);
                 }
                 HIPCHK(c, launch_count27(c->fast27_lds, p, grid, block, st));
+                const uint64_t m = p.row_end * 1024 - 1;
+                emit_from = m - ((m - 11) % 12) + 1;
             }
-            if (n_bytes & 1023) {
-                p.row_begin = p.row_end;
+            if (emit_from < n_bytes) {
+                p.emit_from = emit_from;
+                p.row_begin = emit_from >> 10;
                 rows_geometry(c, c->filter_in_lds, grid, block);
                 HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, 1, block, st));
             }

@@ -35,7 +35,9 @@ struct RowParams {
     const uint8_t* bases;
     uint64_t n_bytes;
     uint64_t row_begin;   // rows_kernel: first 1 KiB row to process (earlier rows only provide the halo)
-    uint64_t row_end;     // count27_lds_kernel: one past the last row; every row below it is complete
+    uint64_t row_end;     // count27_kernel: one past the last row; every row below it is complete
+    uint64_t emit_from;   // rows_kernel<COUNT>: only k-mers ENDING at stream position >= emit_from are counted (the
+                          // fast kernel covers the ends up to its last grid offset)
     uint32_t k;
     uint32_t dbg;         // tuning experiments only (VGMI_DBG): 1 = drop queued k-mers unprobed, 2 = skip compaction
     uint32_t* status;     // bit0 empty read, bit1 bad key, bit2 duplicate key

@@ -306,14 +306,15 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
                 const uint64_t pos = (r << 10) + lane * 16 + j;
                 if (valid && pos < p.n_bytes) bloom_add_key(p.bloom, vg_hash64(canon, mask) << 8 | K);
             } else {
+                const bool emit = valid && (r << 10) + lane * 16 + j >= p.emit_from;
                 bool pass;
                 if (FLDS) {
                     const uint32_t h = vg_fhash_word(canon);
                     const uint32_t w = s_filter[h >> p.table.filter_shift];
                     const uint32_t m = vg_fhash_bits_small(h);
-                    pass = valid && ((w & m) == m);
+                    pass = emit && ((w & m) == m);
                 } else {
-                    pass = valid && filter_test_global(p.table, canon);
+                    pass = emit && filter_test_global(p.table, canon);
                 }
                 const uint64_t ball = __ballot(pass);
                 if (ball) {
@@ -337,22 +338,25 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
 }
 
 // ------------------------------------------------------------------------------------------
-// fast count kernel: k = 27 (every BASELINE.json configuration), small graph (<= 65 536 k-mers).
+// fast count kernels: k = 27 (every BASELINE.json configuration)
 //
-// C2-class workloads are bound by the integer ALU, not by HBM (the whole index is on-chip), so
-// this kernel minimises VALU instructions per k-mer.  Same row walk as rows_kernel, but
-//   phase A  the prefilter is a direct-indexed SUFFIX BITMAP in LDS (vgmi_device.h): the index is
-//            simply the low 20 bits of the forward k-mer, one funnel shift -- no reverse
-//            complement, no canonical min, no hash; the 16 words are requested back to back;
-//   phase B  16 ballots give the per-step pass masks (valid window && bit set) and the row total;
-//   phase C  passing k-mers (forward orientation, high word extracted only now) are compacted
-//            into the wave's LDS ring (rank = mbcnt over the step's mask);
-//   drain    whenever >= 64 k-mers are queued, 64 lanes canonicalise (min with the reverse
-//            complement), hash and ISSUE one 16-byte exact-table load each, and the previous
-//            batch -- in flight since the last drain -- is FINISHED (compare, saturating
-//            atomicAdd, rare second probe).
-// A row whose passes would overflow the ring (reads made of graph k-mers only) takes a slow,
-// obviously-correct path: flush, then push+probe one step at a time.
+// Same row walk as rows_kernel (1 KiB rows, 16 bytes per lane, neighbours by ds_bpermute), built
+// around the GRID FILTER (vgmi_device.h):
+//   * a lane looks at its own offsets t whose stream position is 11 mod 12 (one or two per row):
+//     the 16-mer that ends 11 bases earlier sits on the grid; it is tested against the blocked
+//     Bloom filter (LDS for small graphs, global for large ones) -- forward orientation only;
+//   * a hit makes the 12 k-mers ending at t-11 .. t candidates.  They are all substrings of the 38
+//     bases ending at t, which the lane holds (own 16 + 48 halo bases), so the lane queues ONE
+//     entry for the whole RUN: 76 bits of bases + a 12-bit validity mask (windows containing a
+//     non-base are dropped) -- 12x fewer compaction operations than one entry per k-mer, and a
+//     row can never overflow the ring (<= 86 runs per row, 128 slots);
+//   * drain: whenever >= 5 runs are queued, lanes 0..59 expand 5 runs into 60 k-mers (lane ->
+//     run = lane / 12, window = lane % 12), canonicalise (min with the v_bfrev reverse
+//     complement), hash and ISSUE one 16-byte exact-table load each; the previous batch, in flight
+//     since the last drain, is FINISHED: compare, saturating atomicAdd (issued after the new loads
+//     so that no wait ever sees it), and a lane whose slot holds another k-mer re-queues its
+//     k-mer with the probe distance advanced (a dependent load would stall the whole wave);
+//     re-queued k-mers ride in a second small ring and get their own batches.
 // ------------------------------------------------------------------------------------------
 struct Pending {
     uint64_t canon;   // canonical k-mer | probe distance << 54
@@ -362,40 +366,25 @@ struct Pending {
 };
 
 #define VG_Q_KMER_MASK ((1ULL << 54) - 1)
+#define VG_RUNQ 96u       // run ring: entries of 3 dwords {bases[31:0], bases[63:32], bases[75:64] | valid12 << 12};
+                          // a row adds <= 86 runs and <= 4 are left over, so it cannot overflow (LDS: 128 KiB filter +
+                          // 16 waves x (96 x 12 + 64 x 8) B + LUT = 158 208 B of the 160 KiB)
+#define VG_RUN_BATCH 5u   // runs per probe batch (60 k-mers)
+#define VG_REQ 64u        // re-queue ring: 64-bit entries (canonical k-mer | probe distance << 54)
 
-// Ring entries are 64-bit: bits [0,54) a k-mer (forward orientation when first queued, canonical
-// when re-queued), bits [54,64) the probe distance already covered.
-template <uint32_t K, uint32_t QC>
-__device__ __forceinline__ void probe_issue(const TableView& t, const uint64_t* queue, uint32_t head, uint32_t n,
-                                            uint32_t lane, Pending& pd)
+__device__ __forceinline__ void probe_load(const TableView& t, uint64_t kmer, uint64_t dist, Pending& pd)
 {
-    // The ring is written and read by lanes of ONE wave: DS operations of a wave execute in
-    // order, so no memory fence is needed (a fence here would also drain vmcnt and serialise
-    // the probe loads that are deliberately left in flight); the wave barrier only stops the
-    // compiler from moving the read above the writes.
-    __builtin_amdgcn_wave_barrier();
-    pd.active = lane < n;
-    if (pd.active) {
-        const uint64_t e = queue[(head + lane) & (QC - 1)];
-        const uint64_t x = e & VG_Q_KMER_MASK;
-        const uint64_t rc = vg_revcomp(x, K);
-        const uint64_t canon = x < rc ? x : rc;   // idempotent for re-queued (already canonical) entries
-        pd.canon = canon | (e & ~VG_Q_KMER_MASK);
-        pd.slot = (vg_thash(canon) + (e >> 54)) & t.cap_mask;
-        pd.v = *reinterpret_cast<const uint4*>(&t.slots[pd.slot]);
-    }
-    __builtin_amdgcn_wave_barrier();
+    const uint64_t rc = vg_revcomp(kmer, 27);
+    const uint64_t canon = kmer < rc ? kmer : rc;     // idempotent for re-queued (already canonical) entries
+    pd.canon = canon | (dist << 54);
+    pd.slot = (vg_thash(canon) + dist) & t.cap_mask;
+    pd.v = *reinterpret_cast<const uint4*>(&t.slots[pd.slot]);
 }
 
-// Finish the batch issued earlier.  A lane whose slot holds another k-mer does NOT chase the
-// chain (that would stall the whole wave for a memory round trip on almost every batch): it puts
-// its k-mer back into the ring with the probe distance advanced, to ride with a later batch.
-// Result of finishing a batch: where the hit's counter lives (nullptr: nothing to add).  The
-// atomic itself is issued by the caller AFTER the next batch's loads (probe_bump), so that the
-// vmcnt wait in front of the next compare is the first one to see it.
-template <uint32_t QC>
-__device__ __forceinline__ uint32_t* probe_finish(const TableView& t, Pending& pd, uint64_t* queue, uint32_t qhead,
-                                                  uint32_t& qtail)
+// Finish the batch issued earlier: returns where the hit's counter lives (nullptr: nothing to add);
+// collisions go to the re-queue ring (or are chased right here when that ring is full).
+__device__ __forceinline__ uint32_t* probe_finish(const TableView& t, Pending& pd, uint64_t* req, uint32_t req_head,
+                                                  uint32_t& req_tail)
 {
     bool again = false;
     uint32_t* bump = nullptr;
@@ -412,16 +401,15 @@ __device__ __forceinline__ uint32_t* probe_finish(const TableView& t, Pending& p
     const uint64_t ball = __builtin_amdgcn_ballot_w64(again);
     if (__builtin_expect(ball != 0, 0)) {
         const uint32_t n = (uint32_t)__builtin_popcountll(ball);
-        const bool fits = qtail - qhead + n <= QC && (pd.canon >> 54) < 1023u;
+        const bool fits = req_tail - req_head + n <= VG_REQ && (pd.canon >> 54) < 1023u;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(again && !fits) == 0, 1)) {
             if (again) {
                 const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
-                                     __builtin_amdgcn_mbcnt_lo((uint32_t)ball, qtail));
-                queue[pos & (QC - 1)] = pd.canon + (1ULL << 54);
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)ball, req_tail));
+                req[pos & (VG_REQ - 1)] = pd.canon + (1ULL << 54);
             }
-            qtail += n;
+            req_tail += n;
         } else if (again) {
-            // no room (or an absurdly long chain): chase it here
             const uint64_t canon = pd.canon & VG_Q_KMER_MASK;
             uint64_t sl = pd.slot;
             for (;;) {
@@ -448,21 +436,22 @@ __device__ __forceinline__ void probe_bump(uint32_t* bump)
 
 // LDS_BM: grid filter (2^15 words) staged in LDS (small graphs, one 1024-thread workgroup per CU)
 //         or probed in global memory (large graphs, 256-thread workgroups).
-// QC:     entries of the per-wave candidate ring.
-template <bool LDS_BM, uint32_t QC>
+template <bool LDS_BM>
 __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams p)
 {
-    constexpr uint32_t K = 27;
-    constexpr uint32_t MASK_HI = (1u << (2 * K - 32)) - 1;  // 54-bit k-mer: low word full, 22 bits high
+    constexpr uint32_t MASK_HI = (1u << (2 * 27 - 32)) - 1;  // 54-bit k-mer: low word full, 22 bits high
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
     const uint32_t nwaves = blockDim.x >> 6;
 
-    size_t off = LDS_BM ? (size_t)VG_GRID_LDS_WORDS * 4 : 0;  // the LDS filter sits at LDS byte offset 0
-    uint64_t* s_queue = reinterpret_cast<uint64_t*>(smem + off) + (size_t)wave * QC;
-    off += (size_t)nwaves * QC * 8;
+    // LDS carve: [grid filter (LDS_BM, at byte offset 0)][run rings][re-queue rings][LUT]
+    size_t off = LDS_BM ? (size_t)VG_GRID_LDS_WORDS * 4 : 0;
+    uint32_t* s_runs = reinterpret_cast<uint32_t*>(smem + off) + (size_t)wave * VG_RUNQ * 3;
+    off += (size_t)nwaves * VG_RUNQ * 12;
+    uint64_t* s_req = reinterpret_cast<uint64_t*>(smem + off) + (size_t)wave * VG_REQ;
+    off += (size_t)nwaves * VG_REQ * 8;
     uint8_t* s_lut = smem + off;
     stage_lut(s_lut, tid, blockDim.x);
     if (LDS_BM) {
@@ -493,16 +482,61 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
         return make_uint4(v.x, v.y, v.z, v.w);
     };
 
-    const uint32_t src1 = (lane + 63u) & 63u, src2 = (lane + 62u) & 63u;
-    uint32_t pr1_be = 0, pr2_be = 0, pr1_inv = 0xFFFFu, pr2_inv = 0xFFFFu, pr_spill = 0;
-    // the row before the range is walked first as a warm-up iteration: it provides the halo and the
-    // candidate spill of the range's first row
+    const uint32_t src1 = (lane + 63u) & 63u, src2 = (lane + 62u) & 63u, src3 = (lane + 61u) & 63u;
+    // previous row's words, already rotated by 1 / 2 / 3 lanes (lanes 0..2 take them)
+    uint32_t pr1_be = 0, pr2_be = 0, pr3_be = 0, pr1_inv = 0xFFFFu, pr2_inv = 0xFFFFu, pr3_inv = 0xFFFFu;
+    // the row before the range is walked first as a warm-up iteration: it only provides the halo
     const uint64_t rs = r0 > 0 ? r0 - 1 : r0;
 
-    uint32_t qhead = 0, qtail = 0;
+    // drain bookkeeping: which run / window of a 5-run batch this lane expands
+    const uint32_t my_run = lane / 12u, my_win = lane % 12u;
+    uint32_t run_head = 0, run_tail = 0, req_head = 0, req_tail = 0;
     Pending pd;
     pd.active = false;
     pd.canon = 0; pd.slot = 0; pd.v = make_uint4(0, 0, 0, 0);
+
+    auto issue_runs = [&](uint32_t n_runs) {
+        __builtin_amdgcn_wave_barrier();
+        pd.active = false;
+        if (my_run < n_runs) {
+            const uint32_t* e = s_runs + ((run_head + my_run) % VG_RUNQ) * 3;
+            const uint32_t d0 = e[0], d1 = e[1], d2 = e[2];
+            if ((d2 >> (12 + my_win)) & 1u) {
+                // k-mer ending at window my_win of the run: bits [2(11 - win), +54) of the 76 run bits
+                const uint32_t sh = 2 * (11 - my_win);
+                const uint32_t lo = funnel(d1, d0, sh);
+                const uint32_t hi = funnel(d2, d1, sh) & MASK_HI;
+                pd.active = true;
+                probe_load(p.table, ((uint64_t)hi << 32) | lo, 0, pd);
+            }
+        }
+        run_head += n_runs;
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto issue_requeued = [&](uint32_t n) {
+        __builtin_amdgcn_wave_barrier();
+        pd.active = lane < n;
+        if (pd.active) {
+            const uint64_t e = s_req[(req_head + lane) & (VG_REQ - 1)];
+            probe_load(p.table, e & VG_Q_KMER_MASK, e >> 54, pd);
+        }
+        req_head += n;
+        __builtin_amdgcn_wave_barrier();
+    };
+    // one drain step: finish the batch in flight, issue the next one, then bump the finished hits
+    auto drain_step = [&](bool flush) -> bool {
+        const uint32_t n_runs = run_tail - run_head, n_req = req_tail - req_head;
+        const bool do_req = n_req >= 32u || (flush && n_runs == 0 && n_req > 0);
+        const bool do_runs = !do_req && (n_runs >= VG_RUN_BATCH || (flush && n_runs > 0));
+        // every condition here must be wave-uniform: pd.active is per lane
+        const bool in_flight = __builtin_amdgcn_ballot_w64(pd.active) != 0;
+        if (!do_req && !do_runs && !(flush && in_flight)) return false;
+        uint32_t* bump = probe_finish(p.table, pd, s_req, req_head, req_tail);
+        if (do_req) issue_requeued(n_req < 64u ? n_req : 64u);
+        else if (do_runs) issue_runs(n_runs < VG_RUN_BATCH ? n_runs : VG_RUN_BATCH);
+        probe_bump(bump);
+        return true;
+    };
 
     uint4 raw_next = load_row(rs);
     for (uint64_t r = rs; r < r1; ++r) {
@@ -511,22 +545,21 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
 
         uint32_t be, inv;
         encode16(raw, s_lut, be, inv);
-        const uint32_t r1_be = __shfl(be, src1), r2_be = __shfl(be, src2);
-        const uint32_t r1_inv = __shfl(inv, src1), r2_inv = __shfl(inv, src2);
+        const uint32_t r1_be = __shfl(be, src1), r2_be = __shfl(be, src2), r3_be = __shfl(be, src3);
+        const uint32_t r1_inv = __shfl(inv, src1), r2_inv = __shfl(inv, src2), r3_inv = __shfl(inv, src3);
+        // 64-base window, later bases in lower bits: F0 = own chunk, F1..F3 = the three chunks before
         const uint32_t F0 = be;
         const uint32_t F1 = lane >= 1 ? r1_be : pr1_be;
         const uint32_t F2 = lane >= 2 ? r2_be : pr2_be;
+        const uint32_t F3 = lane >= 3 ? r3_be : pr3_be;
         const uint32_t i1 = lane >= 1 ? r1_inv : pr1_inv;
         const uint32_t i2 = lane >= 2 ? r2_inv : pr2_inv;
-        pr1_be = r1_be; pr2_be = r2_be; pr1_inv = r1_inv; pr2_inv = r2_inv;
-
-        // bit (32+j) of sm: some base of the 27-mer ending at own base j is not a base
-        uint64_t sm = ((uint64_t)inv << 32) | ((uint64_t)i1 << 16) | (uint64_t)i2;
-        sm |= sm << 1; sm |= sm << 2; sm |= sm << 4; sm |= sm << 8; sm |= sm << 11;
-        const uint32_t ok = ~(uint32_t)(sm >> 32);  // bit j set: window valid
-
+        const uint32_t i3 = lane >= 3 ? r3_inv : pr3_inv;
+        pr1_be = r1_be; pr2_be = r2_be; pr3_be = r3_be; pr1_inv = r1_inv; pr2_inv = r2_inv; pr3_inv = r3_inv;
         const bool warm = r < r0;
-        if (!warm) {   // empty-read check, see rows_kernel
+        if (warm) continue;
+
+        {   // empty-read check, see rows_kernel
             const uint32_t prev_bit = (i1 >> 15) & 1u;
             const uint32_t adj = inv & ((inv << 1) | prev_bit);
             if (__builtin_expect(__ballot(adj != 0) != 0, 0)) {
@@ -542,125 +575,56 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
             }
         }
 
-        // ---- phases A+B: probe the grid filter with the 16-mers that END at stream positions
-        // divisible by 12.  1024 % 12 == 16 % 12 == 4, so the first grid offset of this lane's chunk
-        // is 0, 8 or 4 for (r + lane) % 3 == 0, 1, 2, and only the first case has a second grid
-        // point (offset 12).  A hit marks the 12 k-mers ending at offsets [g, g + 11] (spilling
-        // into the next lane's chunk, or the next row for lane 63) as candidates.
-        uint32_t flo[16];
-        uint64_t ball[16];  // per-step candidate masks; inverse_ballot turns them back into lane predicates
-        uint32_t cnt[16];
-        {
-            const uint32_t ph = ((uint32_t)(r % 3) + lane % 3) % 3;
-            const uint32_t j1 = ph == 0 ? 0u : (ph == 1 ? 8u : 4u);
-            const uint64_t inv48 = ((uint64_t)inv << 32) | ((uint64_t)i1 << 16) | (uint64_t)i2;
-            const uint32_t m1 = funnel(F1, F0, 2 * (15 - j1));                    // the 16 bases ending at offset j1
-            const bool v1 = ((uint32_t)(inv48 >> (17 + j1)) & 0xFFFFu) == 0;
-            const bool two = ph == 0;
-            const uint32_t m2 = funnel(F1, F0, 2 * (15 - 12));
-            const bool v2 = two && ((uint32_t)(inv48 >> (17 + 12)) & 0xFFFFu) == 0;
-            uint64_t x1, x2;
-            uint32_t k1, k2, w1 = 0, w2 = 0;
-            vg_grid_probe(m1, gwl, x1, k1);
-            vg_grid_probe(m2, gwl, x2, k2);
+        // invalid-base bits of the 64-base window (bit i = window base i, own chunk = bits 48..63),
+        // smeared forward by 26: bit E of sm set <=> the 27-mer ending at window base E holds a non-base
+        const uint64_t inv64 = ((uint64_t)inv << 48) | ((uint64_t)i1 << 32) | ((uint64_t)i2 << 16) | (uint64_t)i3;
+        uint64_t sm = inv64;
+        sm |= sm << 1; sm |= sm << 2; sm |= sm << 4; sm |= sm << 8; sm |= sm << 11;
+
+        // grid offsets of this lane: stream position = 11 (mod 12).  1024 % 12 == 16 % 12 == 4, so with
+        // ph = (r + lane) % 3 they are t = 11 (ph 0), t = 7 (ph 1), t = 3 and t = 15 (ph 2).
+        const uint32_t ph = ((uint32_t)(r % 3) + lane % 3) % 3;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const uint32_t t = which == 0 ? (ph == 0 ? 11u : (ph == 1 ? 7u : 3u)) : 15u;
+            const bool have = which == 0 || ph == 2;
+            // grid 16-mer: window bases [22 + t, 37 + t]  ->  bits [2(26 - t), +32) of F3:F2:F1:F0
+            const uint32_t gs = 2 * (26 - t);
+            const uint32_t g_hi = gs < 32 ? F1 : F2, g_lo = gs < 32 ? F0 : F1;
+            const uint32_t mer = funnel(g_hi, g_lo, gs & 31u);
+            const bool gv = have && ((uint32_t)(inv64 >> (22 + t)) & 0xFFFFu) == 0;
+            uint64_t gx;
+            uint32_t gm, gw32 = 0;
+            vg_grid_probe(mer, gwl, gx, gm);
             if (LDS_BM) {
                 typedef __attribute__((address_space(3))) const uint32_t lds_u32;
-                if (v1) w1 = *reinterpret_cast<lds_u32*>((uintptr_t)((uint32_t)x1 << 2));
-                if (v2) w2 = *reinterpret_cast<lds_u32*>((uintptr_t)((uint32_t)x2 << 2));
+                if (gv) gw32 = *reinterpret_cast<lds_u32*>((uintptr_t)((uint32_t)gx << 2));
             } else {
-                if (v1) w1 = g_grid[x1];
-                if (v2) w2 = g_grid[x2];
+                if (gv) gw32 = g_grid[gx];
             }
-            const bool h1 = v1 && (w1 & k1) == k1;
-            const bool h2 = v2 && (w2 & k2) == k2;
-            const uint32_t cand32 = (h1 ? 0xFFFu << j1 : 0u) | (h2 ? 0xFFFu << 12 : 0u);
-            const uint32_t spill = cand32 >> 16;                                   // runs into the next lane's chunk
-            const uint32_t sp_in = __shfl(spill, src1);
-            const uint32_t cand = ((cand32 & 0xFFFFu) | (lane >= 1 ? sp_in : pr_spill)) & ok;
-            pr_spill = sp_in;                                                      // lane 0 keeps lane 63's spill for the next row
-            if (warm) continue;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                flo[j] = funnel(F1, F0, 2 * (15 - j));
-                ball[j] = __builtin_amdgcn_ballot_w64(((cand >> j) & 1u) != 0);
-                cnt[j] = (uint32_t)__builtin_popcountll(ball[j]);
+            // validity of the run's 12 windows (ending at window bases 37 + t .. 48 + t)
+            const uint32_t vm = ~(uint32_t)(sm >> (37 + t)) & 0xFFFu;
+            const bool hit = gv && (gw32 & gm) == gm && vm != 0;
+            const uint64_t ball = __builtin_amdgcn_ballot_w64(hit);
+            if (ball) {
+                if (__builtin_amdgcn_inverse_ballot_w64(ball)) {
+                    // run bases: window bases [11 + t, 48 + t] -> bits [2(15 - t), +76) of F3:F2:F1:F0
+                    const uint32_t rsft = 2 * (15 - t);
+                    const uint32_t d0 = funnel(F1, F0, rsft);
+                    const uint32_t d1 = funnel(F2, F1, rsft);
+                    const uint32_t d2 = (funnel(F3, F2, rsft) & 0xFFFu) | (vm << 12);
+                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
+                                         __builtin_amdgcn_mbcnt_lo((uint32_t)ball, run_tail));
+                    uint32_t* e = s_runs + (pos % VG_RUNQ) * 3;
+                    e[0] = d0; e[1] = d1; e[2] = d2;
+                }
+                run_tail += (uint32_t)__builtin_popcountll(ball);
             }
         }
-        // ---- phase C: compact the forward k-mers into the ring, four steps at a time so that the
-        // ring (128 entries) is checked for space often enough; a segment that would not fit
-        // (dense hits) hands the rest of the row to the slow path below.
-        int slow_from = 16;
-        if (p.dbg & 2u) continue;
-#pragma unroll
-        for (int seg = 0; seg < 4; ++seg) {
-            if (slow_from != 16) break;
-            const uint32_t seg_total = cnt[4 * seg] + cnt[4 * seg + 1] + cnt[4 * seg + 2] + cnt[4 * seg + 3];
-            if (seg_total == 0) continue;
-            if (__builtin_expect(qtail - qhead + seg_total > QC, 0)) {
-                slow_from = 4 * seg;
-                break;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = 4 * seg + q;
-                if (__builtin_amdgcn_inverse_ballot_w64(ball[j])) {
-                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball[j] >> 32),
-                                         __builtin_amdgcn_mbcnt_lo((uint32_t)ball[j], qtail));
-                    const uint32_t f_hi = funnel(F2, F1, 2 * (15 - j)) & MASK_HI;
-                    s_queue[pos & (QC - 1)] = ((uint64_t)f_hi << 32) | flo[j];
-                }
-                qtail += cnt[j];
-            }
-            if (p.dbg & 1u) { qhead = qtail; continue; }
-            while (qtail - qhead >= 64u) {
-                uint32_t* bump = probe_finish<QC>(p.table, pd, s_queue, qhead, qtail);
-                probe_issue<K, QC>(p.table, s_queue, qhead, 64u, lane, pd);
-                probe_bump(bump);
-                qhead += 64u;
-            }
-        }
-        if (__builtin_expect(slow_from != 16, 0)) {
-            // ---- slow path: flush, then one step at a time
-            probe_bump(probe_finish<QC>(p.table, pd, s_queue, qhead, qtail));
-            while (qtail != qhead) {
-                const uint32_t n = qtail - qhead < 64u ? qtail - qhead : 64u;
-                probe_issue<K, QC>(p.table, s_queue, qhead, n, lane, pd);
-                qhead += n;
-                probe_bump(probe_finish<QC>(p.table, pd, s_queue, qhead, qtail));
-            }
-#pragma unroll 1
-            for (int j = slow_from; j < 16; ++j) {
-                const uint32_t fs = 2 * (15 - j);
-                const uint32_t f_lo = funnel(F1, F0, fs);
-                const uint32_t f_hi = funnel(F2, F1, fs) & MASK_HI;
-                uint64_t bj0 = ball[0];
-#pragma unroll
-                for (int q = 1; q < 16; ++q) bj0 = q == j ? ball[q] : bj0;
-                const bool ps = (bj0 >> lane) & 1ull;
-                const uint64_t bj = __builtin_amdgcn_ballot_w64(ps);
-                if (!bj) continue;
-                if (ps) {
-                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bj >> 32),
-                                         __builtin_amdgcn_mbcnt_lo((uint32_t)bj, qtail));
-                    s_queue[pos & (QC - 1)] = ((uint64_t)f_hi << 32) | f_lo;
-                }
-                qtail += (uint32_t)__builtin_popcountll(bj);
-                while (qtail != qhead) {
-                    const uint32_t n = qtail - qhead < 64u ? qtail - qhead : 64u;
-                    probe_issue<K, QC>(p.table, s_queue, qhead, n, lane, pd);
-                    qhead += n;
-                    probe_bump(probe_finish<QC>(p.table, pd, s_queue, qhead, qtail));
-                }
-            }
-        }
+        if (p.dbg & 1u) { run_head = run_tail; continue; }
+        while (drain_step(false)) {}
     }
-    probe_bump(probe_finish<QC>(p.table, pd, s_queue, qhead, qtail));
-    while (qtail != qhead) {
-        const uint32_t n = qtail - qhead < 64u ? qtail - qhead : 64u;
-        probe_issue<K, QC>(p.table, s_queue, qhead, n, lane, pd);
-        qhead += n;
-        probe_bump(probe_finish<QC>(p.table, pd, s_queue, qhead, qtail));
-    }
+    while (drain_step(true)) {}
 }
 
 // ------------------------------------------------------------------------------------------
@@ -860,23 +824,20 @@ static hipError_t launch_rows_t(const RowParams& p, uint32_t grid, uint32_t bloc
     return hipGetLastError();
 }
 
-#define VG_QCAP_GLOBAL 512u  // ring entries per wave of the global-bitmap variant (dense hits expected)
-
-template <bool LDS_BM, uint32_t QC>
+template <bool LDS_BM>
 static hipError_t launch_count27_t(const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)
 {
-    const size_t lds = (LDS_BM ? (size_t)VG_GRID_LDS_WORDS * 4 : 0) + (size_t)(block / 64) * QC * 8 + 512;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&count27_kernel<LDS_BM, QC>),
+    const size_t lds = (LDS_BM ? (size_t)VG_GRID_LDS_WORDS * 4 : 0) + (size_t)(block / 64) * (VG_RUNQ * 12 + VG_REQ * 8) + 512;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&count27_kernel<LDS_BM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((count27_kernel<LDS_BM, QC>), dim3(grid), dim3(block), lds, st, p);
+    hipLaunchKernelGGL((count27_kernel<LDS_BM>), dim3(grid), dim3(block), lds, st, p);
     return hipGetLastError();
 }
 
 hipError_t launch_count27(bool lds_bitmap, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)
 {
-    return lds_bitmap ? launch_count27_t<true, VG_QCAP>(p, grid, block, st)
-                      : launch_count27_t<false, VG_QCAP_GLOBAL>(p, grid, block, st);
+    return lds_bitmap ? launch_count27_t<true>(p, grid, block, st) : launch_count27_t<false>(p, grid, block, st);
 }
 
 hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)
