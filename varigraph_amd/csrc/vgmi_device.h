@@ -153,8 +153,8 @@ VG_HD uint64_t vg_revcomp(uint64_t x, uint32_t k)
 
 // Grid filter of the fast read kernels (k = 27).  Every 27-mer contains exactly one 16-mer that
 // ENDS at a stream position divisible by 12 (27 - 16 + 1 = 12).  The filter is a blocked Bloom
-// filter (3 bits in one 32-bit word) over every 16-mer found at any of the 12 offsets of any graph
-// k-mer, in both orientations.  A read therefore probes it only at every 12th position -- in the
+// filter (3 bits in one 32-bit word) over every canonical 16-mer found at any of the 12 offsets of any
+// graph k-mer.  A read therefore probes it only at every 12th position -- in the
 // orientation it is read in, no reverse complement, no canonical min -- and a hit makes the 12
 // k-mers containing that 16-mer candidates for the exact table.  Small graphs keep 2^15 words
 // (128 KiB) in LDS; larger graphs use a global bitmap of >= 32 bits per key.
@@ -163,9 +163,29 @@ VG_HD uint64_t vg_revcomp(uint64_t x, uint32_t k)
 #define VG_GRID_LDS_WORDS_LOG2 15u
 #define VG_GRID_LDS_WORDS (1u << VG_GRID_LDS_WORDS_LOG2)
 #define VG_GRID_LDS_MAX_KEYS 65536u
+// reverse complement of a 16-mer (32 bits, first base most significant)
+VG_HD uint32_t vg_revcomp16(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r = __builtin_bitreverse32(x);
+#else
+    uint32_t r = x;
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+    r = ((r >> 2) & 0x33333333u) | ((r & 0x33333333u) << 2);
+    r = ((r >> 4) & 0x0F0F0F0Fu) | ((r & 0x0F0F0F0Fu) << 4);
+    r = ((r >> 8) & 0x00FF00FFu) | ((r & 0x00FF00FFu) << 8);
+    r = (r >> 16) | (r << 16);
+#endif
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);  // bits of each 2-bit field back in order
+    return ~r;
+}
+// The filter is keyed on the CANONICAL 16-mer (min with its reverse complement): a graph k-mer and its
+// reverse complement then share their 12 entries, which halves the fill and cuts false candidates ~6x.
 VG_HD void vg_grid_probe(uint32_t mer16, uint32_t words_log2, uint64_t& word, uint32_t& mask)
 {
-    const uint64_t x = (uint64_t)mer16 * 0x9E3779B97F4A7C15ULL;
+    const uint32_t rc = vg_revcomp16(mer16);
+    const uint32_t cm = mer16 < rc ? mer16 : rc;
+    const uint64_t x = (uint64_t)cm * 0x9E3779B97F4A7C15ULL;
     word = x >> (64 - words_log2);
     const uint32_t y = (uint32_t)(x >> 8);   // bits below the word index of even the largest filter (2^33 words)
     mask = (1u << (y & 31u)) | (1u << ((y >> 5) & 31u)) | (1u << ((y >> 10) & 31u));

@@ -713,14 +713,12 @@ __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t 
     t.slots[s].key_index = (uint32_t)i;
     key_slot[i] = (uint32_t)s;
     atomicOr(&filter_rw[vg_fhash_word(canon) >> t.filter_shift], vg_fhash_bits(canon, t.filter_words_log2));
-    if (grid_rw) {   // k = 27 only: 12 + 12 sixteen-mers of the k-mer and of its reverse complement
-        const uint64_t rcv = vg_revcomp(canon, k);
+    if (grid_rw) {   // k = 27 only: the 12 sixteen-mers of the k-mer (canonicalised inside vg_grid_probe, which
+                     // makes the reverse complement's twelve the same entries)
         for (uint32_t off = 0; off < VG_GRID_STEP; ++off) {
             uint64_t w;
             uint32_t m;
             vg_grid_probe((uint32_t)(canon >> (2 * off)), t.grid_words_log2, w, m);
-            atomicOr(&grid_rw[w], m);
-            vg_grid_probe((uint32_t)(rcv >> (2 * off)), t.grid_words_log2, w, m);
             atomicOr(&grid_rw[w], m);
         }
     }
