@@ -15,8 +15,8 @@ for pm in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ
   rocprofv3 --pmc $pm -d $OUT/pmc_$i -o r1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_pmc_$i.json 2> $OUT/pmc_${i}_err.log
 done
 # calibration of FETCH_SIZE on this kernel's own streaming pattern: same launch with the
-# compaction and the probes switched off (VGMI_DBG=2) reads exactly the read block once
-VGMI_DBG=2 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_cal -o r1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_pmc_cal.json 2> $OUT/pmc_cal_err.log
+# candidate runs dropped (VGMI_DBG=1: no table probes) reads exactly the read block once
+VGMI_DBG=1 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_cal -o r1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_pmc_cal.json 2> $OUT/pmc_cal_err.log
 python3 tools/rocprof_summary.py $OUT > $OUT/summary.txt
 rm -f $OUT/*/*.db $OUT/*/*/*.db 2>/dev/null
 find $OUT -name "*.db" -delete

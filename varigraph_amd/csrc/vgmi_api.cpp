@@ -185,7 +185,7 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
         if (n_keys > VG_GRID_LDS_MAX_KEYS) {
             b = ceil_log2(32 * n_keys) - 5;
             if (b < VG_GRID_LDS_WORDS_LOG2 + 1) b = VG_GRID_LDS_WORDS_LOG2 + 1;
-            if (b > 33) b = 33;
+            if (b > 31) b = 31;   // vg_grid_probe draws the word index from a 32-bit product word
         }
         h.grid_words_log2 = b;
         h.off_grid = align(end);
@@ -260,7 +260,7 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
             // complete 1 KiB rows -> fast kernel.  It covers every k-mer ending at or before its last
             // grid offset (largest position = 11 mod 12 inside those rows); the generic kernel takes
             // the ends after that: the ragged tail row plus at most 11 positions of the last full row.
-            p.row_end = n_bytes >> 10;
+            p.row_end = n_bytes / 768;   // VG_ROW27: count27_kernel walks complete 768-byte rows
             uint64_t emit_from = 0;
             if (p.row_end) {
                 if (c->fast27_lds) { block = 1024; grid = (uint32_t)c->n_cu; }
@@ -271,8 +271,8 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
                     grid = (uint32_t)c->n_cu * (c->wgs_per_cu ? c->wgs_per_cu : 4);
                 }
                 HIPCHK(c, launch_count27(c->fast27_lds, p, grid, block, st));
-                const uint64_t m = p.row_end * 1024 - 1;
-                emit_from = m - ((m - 11) % 12) + 1;
+                // lane L of a row covers the k-mers ending at stream positions 12L - 1 .. 12L + 10
+                emit_from = p.row_end * 768 - 1;
             }
             if (emit_from < n_bytes) {
                 p.emit_from = emit_from;

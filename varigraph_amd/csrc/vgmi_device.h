@@ -185,9 +185,12 @@ VG_HD void vg_grid_probe(uint32_t mer16, uint32_t words_log2, uint64_t& word, ui
 {
     const uint32_t rc = vg_revcomp16(mer16);
     const uint32_t cm = mer16 < rc ? mer16 : rc;
-    const uint64_t x = (uint64_t)cm * 0x9E3779B97F4A7C15ULL;
-    word = x >> (64 - words_log2);
-    const uint32_t y = (uint32_t)(x >> 8);   // bits below the word index of even the largest filter (2^33 words)
+    // one 32 x 32 -> 64 multiply: word index = top bits of the LOW product word (multiplicative hashing; the top of
+    // the full product would be monotonic in cm), bit choices from the low bits of the high word (the product's
+    // well-mixed middle)
+    const uint64_t x = (uint64_t)cm * 0x9E3779B1u;
+    word = (uint32_t)x >> (32 - words_log2);
+    const uint32_t y = (uint32_t)(x >> 32);
     mask = (1u << (y & 31u)) | (1u << ((y >> 5) & 31u)) | (1u << ((y >> 10) & 31u));
 }
 

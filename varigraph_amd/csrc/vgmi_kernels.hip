@@ -366,9 +366,9 @@ struct Pending {
 };
 
 #define VG_Q_KMER_MASK ((1ULL << 54) - 1)
-#define VG_RUNQ 96u       // run ring: entries of 3 dwords {bases[31:0], bases[63:32], bases[75:64] | valid12 << 12};
-                          // a row adds <= 86 runs and <= 4 are left over, so it cannot overflow (LDS: 128 KiB filter +
-                          // 16 waves x (96 x 12 + 64 x 8) B + LUT = 158 208 B of the 160 KiB)
+#define VG_RUNQ 80u       // run ring: entries of 3 dwords {bases[31:0], bases[63:32], bases[75:64] | valid12 << 12};
+                          // a row adds <= 64 runs and <= 4 are left over, so it cannot overflow (LDS: 128 KiB filter +
+                          // 16 waves x (80 x 12 + 64 x 8) B + 4 KiB LUT = 158 720 B of the 160 KiB)
 #define VG_RUN_BATCH 5u   // runs per probe batch (60 k-mers)
 #define VG_REQ 64u        // re-queue ring: 64-bit entries (canonical k-mer | probe distance << 54)
 
@@ -436,6 +436,51 @@ __device__ __forceinline__ void probe_bump(uint32_t* bump)
 
 // LDS_BM: grid filter (2^15 words) staged in LDS (small graphs, one 1024-thread workgroup per CU)
 //         or probed in global memory (large graphs, 256-thread workgroups).
+// Row geometry of the k = 27 kernels: 768-byte rows, 12 bytes (one dwordx3) per lane, so that every lane owns
+// exactly one grid position (VG_GRID_STEP = 12) and every shift below is a compile-time constant.
+#define VG_ROW27 768u
+
+// Base LUT of the k = 27 kernels, at LDS byte offset 0: two sets (A: dwords 0 and 2 of a lane's chunk, B: dword 1)
+// of 4 position tables of 256 u16.  Entry for byte b of a dword = code << 2(3 - b) | invalid << (8 + b) (set A) or
+// invalid << (12 + b) (set B); the OR of a dword's four entries is {4 packed codes, first base most significant} in
+// byte 0 and its 4 invalid bits above.
+#define VG_LUT27_BYTES 4096u
+typedef __attribute__((address_space(3))) const uint16_t lds_u16;
+typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+
+__device__ __forceinline__ void stage_lut27(uint32_t tid, uint32_t nthreads)
+{
+    typedef __attribute__((address_space(3))) uint16_t lds_u16_rw;
+    for (uint32_t i = tid; i < 2048; i += nthreads) {
+        const uint32_t set = i >> 10, b = (i >> 8) & 3u, c = vg_nt4(i & 255u);
+        reinterpret_cast<lds_u16_rw*>((uintptr_t)0)[i] =
+            (uint16_t)(((c & 3u) << (2 * (3 - b))) | ((c >> 2) << ((set ? 12 : 8) + b)));
+    }
+}
+
+// 2 * byte B of w in one SDWA op (the LUT holds u16)
+template <int B>
+__device__ __forceinline__ uint32_t byte_x2(const uint32_t w, const uint32_t one)
+{
+    uint32_t r;
+    if (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(one), "v"(w));
+    if (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(one), "v"(w));
+    if (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(one), "v"(w));
+    if (B == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(one), "v"(w));
+    return r;
+}
+
+template <int SET>
+__device__ __forceinline__ uint32_t encode4(const uint32_t w, const uint32_t one)
+{
+    const uint32_t e0 = *reinterpret_cast<lds_u16*>((uintptr_t)(byte_x2<0>(w, one) + SET * 2048u));
+    const uint32_t e1 = *reinterpret_cast<lds_u16*>((uintptr_t)(byte_x2<1>(w, one) + SET * 2048u + 512u));
+    const uint32_t e2 = *reinterpret_cast<lds_u16*>((uintptr_t)(byte_x2<2>(w, one) + SET * 2048u + 1024u));
+    uint32_t e3 = *reinterpret_cast<lds_u16*>((uintptr_t)(byte_x2<3>(w, one) + SET * 2048u + 1536u));
+    asm("" : "+v"(e3));   // hide the value range: keeps the ORs 32-bit (v_or3_b32) instead of 16-bit ops + re-extension
+    return e0 | e1 | e2 | e3;
+}
+
 template <bool LDS_BM>
 __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams p)
 {
@@ -446,60 +491,70 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
     const uint32_t wave = tid >> 6;
     const uint32_t nwaves = blockDim.x >> 6;
 
-    // LDS carve: [grid filter (LDS_BM, at byte offset 0)][run rings][re-queue rings][LUT]
-    size_t off = LDS_BM ? (size_t)VG_GRID_LDS_WORDS * 4 : 0;
+    // LDS carve: [base LUT, at byte offset 0][grid filter (LDS_BM)][run rings][re-queue rings]
+    size_t off = VG_LUT27_BYTES + (LDS_BM ? (size_t)VG_GRID_LDS_WORDS * 4 : 0);
     uint32_t* s_runs = reinterpret_cast<uint32_t*>(smem + off) + (size_t)wave * VG_RUNQ * 3;
     off += (size_t)nwaves * VG_RUNQ * 12;
     uint64_t* s_req = reinterpret_cast<uint64_t*>(smem + off) + (size_t)wave * VG_REQ;
-    off += (size_t)nwaves * VG_REQ * 8;
-    uint8_t* s_lut = smem + off;
-    stage_lut(s_lut, tid, blockDim.x);
+    stage_lut27(tid, blockDim.x);
     if (LDS_BM) {
         const uint4* src = reinterpret_cast<const uint4*>(p.table.grid);
-        uint4* dst = reinterpret_cast<uint4*>(smem);
+        uint4* dst = reinterpret_cast<uint4*>(smem + VG_LUT27_BYTES);
         for (uint32_t i = tid; i < VG_GRID_LDS_WORDS / 4; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
     const uint32_t* g_grid = p.table.grid;
     const uint32_t gwl = LDS_BM ? VG_GRID_LDS_WORDS_LOG2 : p.table.grid_words_log2;
 
-    // rows [0, row_end) are complete 1 KiB rows, so every load below is an unconditional,
-    // perfectly coalesced dwordx4 (the ragged tail row goes to rows_kernel, see vgmi_api.cpp)
+    // rows [0, row_end) are complete 768-byte rows, so every load below is an unconditional, perfectly
+    // coalesced dwordx3 (the ragged tail goes to rows_kernel, see vgmi_api.cpp)
     const uint64_t total_rows = p.row_end;
     const uint64_t total_waves = (uint64_t)gridDim.x * nwaves;
     const uint64_t rpw = (total_rows + total_waves - 1) / total_waves;
     // the wave index is uniform: keep the row counters in SGPRs
     const uint64_t gw = (uint64_t)blockIdx.x * nwaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
-    const uint64_t r0 = gw * rpw;
-    const uint64_t r1 = r0 + rpw < total_rows ? r0 + rpw : total_rows;
+    const uint64_t r0v = gw * rpw;
+    const uint64_t r1v = r0v + rpw < total_rows ? r0v + rpw : total_rows;
+    const uint64_t r0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r0v >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r0v);
+    const uint64_t r1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r1v >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r1v);
     if (r0 >= r1) return;
-    const uint4* rows = reinterpret_cast<const uint4*>(p.bases) + lane;  // row r, this lane: rows[r * 64]
+    uint32_t one;
+    asm volatile("v_mov_b32 %0, 1" : "=v"(one));   // SDWA takes no inline constant for the shift amount
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+    const uint32_t lane_off = lane * 12u;
+    const uint8_t* const bases = p.bases;
     // the read block streams through once: non-temporal loads keep it from evicting the k-mer
-    // table out of the XCD's L2
-    auto load_row = [rows](uint64_t r) -> uint4 {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rows + r * 64));
-        return make_uint4(v.x, v.y, v.z, v.w);
+    // table out of the XCD's L2.  Address = uniform row base (SGPR pair) + 32-bit lane offset.
+    auto load_row = [lane_off](const uint8_t* rowp) -> u32x3 {
+        return __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4*>(rowp + lane_off));
     };
 
     const uint32_t src1 = (lane + 63u) & 63u, src2 = (lane + 62u) & 63u, src3 = (lane + 61u) & 63u;
     // previous row's words, already rotated by 1 / 2 / 3 lanes (lanes 0..2 take them)
-    uint32_t pr1_be = 0, pr2_be = 0, pr3_be = 0, pr1_inv = 0xFFFFu, pr2_inv = 0xFFFFu, pr3_inv = 0xFFFFu;
+    uint32_t pr1_be = 0, pr2_be = 0, pr3_be = 0, pr1_inv = 0xFFFu, pr2_inv = 0xFFFu, pr3_inv = 0xFFFu;
     // the row before the range is walked first as a warm-up iteration: it only provides the halo
     const uint64_t rs = r0 > 0 ? r0 - 1 : r0;
 
-    // drain bookkeeping: which run / window of a 5-run batch this lane expands
+    // drain bookkeeping: which run / window of a 5-run batch this lane expands.  Ring indices stay
+    // reduced mod the ring size (wave-uniform, SGPR); a lane's slot wraps with one subtract + min.
     const uint32_t my_run = lane / 12u, my_win = lane % 12u;
-    uint32_t run_head = 0, run_tail = 0, req_head = 0, req_tail = 0;
+    uint32_t run_head = 0, run_n = 0, req_head = 0, req_tail = 0;
     Pending pd;
     pd.active = false;
     pd.canon = 0; pd.slot = 0; pd.v = make_uint4(0, 0, 0, 0);
 
+    auto ring_slot = [](uint32_t pos) -> uint32_t {  // pos < 2 * VG_RUNQ
+        const uint32_t w = pos - VG_RUNQ;
+        return w < pos ? w : pos;
+    };
     auto issue_runs = [&](uint32_t n_runs) {
         __builtin_amdgcn_wave_barrier();
         pd.active = false;
         if (my_run < n_runs) {
-            const uint32_t* e = s_runs + ((run_head + my_run) % VG_RUNQ) * 3;
+            const uint32_t* e = s_runs + ring_slot(run_head + my_run) * 3;
             const uint32_t d0 = e[0], d1 = e[1], d2 = e[2];
             if ((d2 >> (12 + my_win)) & 1u) {
                 // k-mer ending at window my_win of the run: bits [2(11 - win), +54) of the 76 run bits
@@ -511,6 +566,8 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
             }
         }
         run_head += n_runs;
+        if (run_head >= VG_RUNQ) run_head -= VG_RUNQ;
+        run_n -= n_runs;
         __builtin_amdgcn_wave_barrier();
     };
     auto issue_requeued = [&](uint32_t n) {
@@ -525,7 +582,7 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
     };
     // one drain step: finish the batch in flight, issue the next one, then bump the finished hits
     auto drain_step = [&](bool flush) -> bool {
-        const uint32_t n_runs = run_tail - run_head, n_req = req_tail - req_head;
+        const uint32_t n_runs = run_n, n_req = req_tail - req_head;
         const bool do_req = n_req >= 32u || (flush && n_runs == 0 && n_req > 0);
         const bool do_runs = !do_req && (n_runs >= VG_RUN_BATCH || (flush && n_runs > 0));
         // every condition here must be wave-uniform: pd.active is per lane
@@ -538,90 +595,85 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
         return true;
     };
 
-    uint4 raw_next = load_row(rs);
-    for (uint64_t r = rs; r < r1; ++r) {
-        const uint4 raw = raw_next;
-        raw_next = load_row(r + 1 < r1 ? r + 1 : r);  // prefetch (the last iteration re-reads its own row)
+    // 32-bit trip count and a scalar row pointer: the loop control stays on the SALU
+    const uint32_t n_it = (uint32_t)(r1 - rs), n_warm = (uint32_t)(r0 - rs);
+    const uint8_t* rowp = bases + rs * VG_ROW27;
+    u32x3 raw_next = load_row(rowp);
+    for (uint32_t it = 0; it < n_it; ++it) {
+        const u32x3 raw = raw_next;
+        const uint8_t* const cur = rowp;
+        if (it + 1 < n_it) rowp += VG_ROW27;
+        raw_next = load_row(rowp);  // prefetch (the last iteration re-reads its own row)
 
-        uint32_t be, inv;
-        encode16(raw, s_lut, be, inv);
+        // own 12 bases: be = 24 bits, first base most significant; inv bit t = base t is not a base
+        const uint32_t g0 = encode4<0>(raw.x, one), g1 = encode4<1>(raw.y, one), g2 = encode4<0>(raw.z, one);
+        const uint32_t be = __builtin_amdgcn_perm(g0, __builtin_amdgcn_perm(g1, g2, 0x0c0c0400u), 0x0c040100u);
+        const uint32_t inv = ((g0 | g1) >> 8) | (g2 & 0xF00u);   // g0: bits 8..11, g1: 12..15, g2: 8..11
         const uint32_t r1_be = __shfl(be, src1), r2_be = __shfl(be, src2), r3_be = __shfl(be, src3);
         const uint32_t r1_inv = __shfl(inv, src1), r2_inv = __shfl(inv, src2), r3_inv = __shfl(inv, src3);
-        // 64-base window, later bases in lower bits: F0 = own chunk, F1..F3 = the three chunks before
-        const uint32_t F0 = be;
-        const uint32_t F1 = lane >= 1 ? r1_be : pr1_be;
-        const uint32_t F2 = lane >= 2 ? r2_be : pr2_be;
-        const uint32_t F3 = lane >= 3 ? r3_be : pr3_be;
+        const uint32_t be1 = lane >= 1 ? r1_be : pr1_be;
+        const uint32_t be2 = lane >= 2 ? r2_be : pr2_be;
+        const uint32_t be3 = lane >= 3 ? r3_be : pr3_be;
         const uint32_t i1 = lane >= 1 ? r1_inv : pr1_inv;
         const uint32_t i2 = lane >= 2 ? r2_inv : pr2_inv;
         const uint32_t i3 = lane >= 3 ? r3_inv : pr3_inv;
         pr1_be = r1_be; pr2_be = r2_be; pr3_be = r3_be; pr1_inv = r1_inv; pr2_inv = r2_inv; pr3_inv = r3_inv;
-        const bool warm = r < r0;
-        if (warm) continue;
+        if (it < n_warm) continue;
 
         {   // empty-read check, see rows_kernel
-            const uint32_t prev_bit = (i1 >> 15) & 1u;
-            const uint32_t adj = inv & ((inv << 1) | prev_bit);
+            const uint32_t adj = inv & ((inv << 1) | (i1 >> 11));
             if (__builtin_expect(__ballot(adj != 0) != 0, 0)) {
                 if (adj) {
-                    const uint64_t base_off = (r << 10) + lane * 16;
-                    for (uint32_t t = 0; t < 16; ++t) {
+                    const uint64_t base_off = (uint64_t)(cur - bases) + lane_off;
+                    for (uint32_t t = 0; t < 12; ++t) {
                         if (!((adj >> t) & 1u)) continue;
                         const uint64_t o = base_off + t;
-                        if (o >= p.n_bytes) continue;
                         if (p.bases[o] == '\n' && (o == 0 || p.bases[o - 1] == '\n')) atomicOr(p.status, 1u);
                     }
                 }
             }
         }
 
-        // invalid-base bits of the 64-base window (bit i = window base i, own chunk = bits 48..63),
-        // smeared forward by 26: bit E of sm set <=> the 27-mer ending at window base E holds a non-base
-        const uint64_t inv64 = ((uint64_t)inv << 48) | ((uint64_t)i1 << 32) | ((uint64_t)i2 << 16) | (uint64_t)i3;
-        uint64_t sm = inv64;
-        sm |= sm << 1; sm |= sm << 2; sm |= sm << 4; sm |= sm << 8; sm |= sm << 11;
+        // 48-base window, base q = 0..47 at bits 2(47 - q) of W2:W1:W0: q = 36..47 own chunk, 0..35 the three
+        // chunks before.  This lane's grid position is g = q 35 (the last base of the previous chunk):
+        //   grid 16-mer  q 20..35                       bits [24, 56)
+        //   run          q  9..46 (k-mers ending at q 35..46, i.e. g .. g + 11)   bits [2, 78)
+        const uint32_t W0 = (be1 << 24) | be;
+        const uint32_t W1 = (be2 << 16) | (be1 >> 8);
+        const uint32_t W2 = (be3 << 8) | (be2 >> 16);
+        // non-base bits.  B bit i = base q 9 + i (i = 0..26, the span of the k-mer ending at g): the k-mer
+        // ending at g + j is spoilt by B iff B >> j != 0, and by the own chunk iff one of own bases 0..j-1 is
+        // a non-base (prefix-OR = x | -x).
+        const uint32_t B = (i3 >> 9) | (i2 << 3) | (i1 << 15);
+        const uint32_t a = (inv << 1) & 0xFFFu;
+        const uint32_t bad_b = B ? (0xFFFFFFFFu >> __builtin_clz(B)) : 0u;
+        const uint32_t vm = ~(a | (0u - a) | bad_b) & 0xFFFu;
+        const bool gv = B < 2048u;   // no non-base in q 20..35
 
-        // grid offsets of this lane: stream position = 11 (mod 12).  1024 % 12 == 16 % 12 == 4, so with
-        // ph = (r + lane) % 3 they are t = 11 (ph 0), t = 7 (ph 1), t = 3 and t = 15 (ph 2).
-        const uint32_t ph = ((uint32_t)(r % 3) + lane % 3) % 3;
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            const uint32_t t = which == 0 ? (ph == 0 ? 11u : (ph == 1 ? 7u : 3u)) : 15u;
-            const bool have = which == 0 || ph == 2;
-            // grid 16-mer: window bases [22 + t, 37 + t]  ->  bits [2(26 - t), +32) of F3:F2:F1:F0
-            const uint32_t gs = 2 * (26 - t);
-            const uint32_t g_hi = gs < 32 ? F1 : F2, g_lo = gs < 32 ? F0 : F1;
-            const uint32_t mer = funnel(g_hi, g_lo, gs & 31u);
-            const bool gv = have && ((uint32_t)(inv64 >> (22 + t)) & 0xFFFFu) == 0;
-            uint64_t gx;
-            uint32_t gm, gw32 = 0;
-            vg_grid_probe(mer, gwl, gx, gm);
-            if (LDS_BM) {
-                typedef __attribute__((address_space(3))) const uint32_t lds_u32;
-                if (gv) gw32 = *reinterpret_cast<lds_u32*>((uintptr_t)((uint32_t)gx << 2));
-            } else {
-                if (gv) gw32 = g_grid[gx];
-            }
-            // validity of the run's 12 windows (ending at window bases 37 + t .. 48 + t)
-            const uint32_t vm = ~(uint32_t)(sm >> (37 + t)) & 0xFFFu;
-            const bool hit = gv && (gw32 & gm) == gm && vm != 0;
-            const uint64_t ball = __builtin_amdgcn_ballot_w64(hit);
-            if (ball) {
-                if (__builtin_amdgcn_inverse_ballot_w64(ball)) {
-                    // run bases: window bases [11 + t, 48 + t] -> bits [2(15 - t), +76) of F3:F2:F1:F0
-                    const uint32_t rsft = 2 * (15 - t);
-                    const uint32_t d0 = funnel(F1, F0, rsft);
-                    const uint32_t d1 = funnel(F2, F1, rsft);
-                    const uint32_t d2 = (funnel(F3, F2, rsft) & 0xFFFu) | (vm << 12);
-                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
-                                         __builtin_amdgcn_mbcnt_lo((uint32_t)ball, run_tail));
-                    uint32_t* e = s_runs + (pos % VG_RUNQ) * 3;
-                    e[0] = d0; e[1] = d1; e[2] = d2;
-                }
-                run_tail += (uint32_t)__builtin_popcountll(ball);
-            }
+        const uint32_t mer = funnel(W1, W0, 24);
+        uint64_t gx;
+        uint32_t gm, gw32 = 0;
+        vg_grid_probe(mer, gwl, gx, gm);
+        if (LDS_BM) {
+            if (gv) gw32 = *reinterpret_cast<lds_u32*>((uintptr_t)(((uint32_t)gx << 2) + VG_LUT27_BYTES));
+        } else {
+            if (gv) gw32 = g_grid[gx];
         }
-        if (p.dbg & 1u) { run_head = run_tail; continue; }
+        const bool hit = gv && (gw32 & gm) == gm && vm != 0;
+        const uint64_t ball = __builtin_amdgcn_ballot_w64(hit);
+        if (ball) {
+            if (__builtin_amdgcn_inverse_ballot_w64(ball)) {
+                const uint32_t d0 = funnel(W1, W0, 2);
+                const uint32_t d1 = funnel(W2, W1, 2);
+                const uint32_t d2 = ((W2 >> 2) & 0xFFFu) | (vm << 12);
+                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)ball, run_head + run_n));
+                uint32_t* e = s_runs + ring_slot(pos) * 3;
+                e[0] = d0; e[1] = d1; e[2] = d2;
+            }
+            run_n += (uint32_t)__builtin_popcountll(ball);
+        }
+        if (p.dbg & 1u) { run_n = 0; continue; }
         while (drain_step(false)) {}
     }
     while (drain_step(true)) {}
@@ -825,7 +877,7 @@ static hipError_t launch_rows_t(const RowParams& p, uint32_t grid, uint32_t bloc
 template <bool LDS_BM>
 static hipError_t launch_count27_t(const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)
 {
-    const size_t lds = (LDS_BM ? (size_t)VG_GRID_LDS_WORDS * 4 : 0) + (size_t)(block / 64) * (VG_RUNQ * 12 + VG_REQ * 8) + 512;
+    const size_t lds = (LDS_BM ? (size_t)VG_GRID_LDS_WORDS * 4 : 0) + (size_t)(block / 64) * (VG_RUNQ * 12 + VG_REQ * 8) + VG_LUT27_BYTES;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&count27_kernel<LDS_BM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
