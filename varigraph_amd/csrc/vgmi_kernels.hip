@@ -340,104 +340,89 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
 // ------------------------------------------------------------------------------------------
 // fast count kernels: k = 27 (every BASELINE.json configuration)
 //
-// Same row walk as rows_kernel (1 KiB rows, 16 bytes per lane, neighbours by ds_bpermute), built
-// around the GRID FILTER (vgmi_device.h):
-//   * a lane looks at its own offsets t whose stream position is 11 mod 12 (one or two per row):
-//     the 16-mer that ends 11 bases earlier sits on the grid; it is tested against the blocked
-//     Bloom filter (LDS for small graphs, global for large ones) -- forward orientation only;
-//   * a hit makes the 12 k-mers ending at t-11 .. t candidates.  They are all substrings of the 38
-//     bases ending at t, which the lane holds (own 16 + 48 halo bases), so the lane queues ONE
-//     entry for the whole RUN: 76 bits of bases + a 12-bit validity mask (windows containing a
-//     non-base are dropped) -- 12x fewer compaction operations than one entry per k-mer, and a
-//     row can never overflow the ring (<= 86 runs per row, 128 slots);
-//   * drain: whenever >= 5 runs are queued, lanes 0..59 expand 5 runs into 60 k-mers (lane ->
-//     run = lane / 12, window = lane % 12), canonicalise (min with the v_bfrev reverse
-//     complement), hash and ISSUE one 16-byte exact-table load each; the previous batch, in flight
-//     since the last drain, is FINISHED: compare, saturating atomicAdd (issued after the new loads
-//     so that no wait ever sees it), and a lane whose slot holds another k-mer re-queues its
-//     k-mer with the probe distance advanced (a dependent load would stall the whole wave);
-//     re-queued k-mers ride in a second small ring and get their own batches.
+// Row walk: 768-byte rows, 12 bytes (one dwordx3) per lane, neighbours by ds_bpermute.  Every lane owns
+// exactly one position of the GRID FILTER (vgmi_device.h; VG_GRID_STEP = 12), so all shifts are constants:
+//   * the 16-mer ending at the last base of the PREVIOUS lane's chunk is canonicalised and tested against the
+//     blocked Bloom filter (LDS for small graphs, global memory for large ones);
+//   * a hit makes the 12 k-mers ending at that base .. 11 bases later candidates.  They are all substrings of
+//     38 bases the lane holds (own 12 + 36 halo), so the lane queues ONE entry for the whole RUN: 76 bits of
+//     bases + a 12-bit validity mask (windows containing a non-base are dropped);
+//   * drain: whenever >= 5 runs are queued, lanes 0..59 expand 5 runs into 60 k-mers (lane -> run = lane / 12,
+//     window = lane % 12), canonicalise (min with the v_bfrev reverse complement), hash and ISSUE one 16-byte
+//     exact-table load each; the batch issued by the previous drain step is FINISHED first: compare, atomic
+//     add for the hits, and a lane whose slot holds another k-mer re-queues its k-mer with the probe distance
+//     advanced (a dependent load would stall the whole wave); re-queued k-mers ride in a second small ring
+//     and get their own batches.
+//
+// Vector memory of the hot loop (row prefetch, table loads, counter atomics) is issued and waited for BY HAND
+// (inline asm + explicit "s_waitcnt vmcnt(n)"): which of them are outstanding depends on wave-uniform run-time
+// state (did the previous row drain?), and the compiler, which has to pick one immediate per program point,
+// can only answer vmcnt(0) -- every row would then wait for the table loads and atomics issued a moment ago.
+// The kernel instead counts, in SGPRs, how many of its own operations were issued after the one it needs and
+// branches to the matching immediate.  Atomics are the returning kind: returning operations complete in issue
+// order, which is what makes the counts exact.  The registers written asynchronously (vm_buf, vm_tv, vm_ret) are
+// operands of every wait, so nothing that reads them can move above it.
 // ------------------------------------------------------------------------------------------
-struct Pending {
-    uint64_t canon;   // canonical k-mer | probe distance << 54
-    uint64_t slot;
-    uint4 v;
-    bool active;
-};
-
 #define VG_Q_KMER_MASK ((1ULL << 54) - 1)
-#define VG_RUNQ 80u       // run ring: entries of 3 dwords {bases[31:0], bases[63:32], bases[75:64] | valid12 << 12};
+#define VG_RUNQ 72u       // run ring: 16-byte entries {bases[31:0], bases[63:32], bases[75:64] | valid12 << 12, -};
                           // a row adds <= 64 runs and <= 4 are left over, so it cannot overflow (LDS: 128 KiB filter +
-                          // 16 waves x (80 x 12 + 64 x 8) B + 4 KiB LUT = 158 720 B of the 160 KiB)
+                          // 16 waves x (72 x 16 + 64 x 8) B + 4 KiB LUT = 161 792 B of the 160 KiB = 163 840 B)
 #define VG_RUN_BATCH 5u   // runs per probe batch (60 k-mers)
 #define VG_REQ 64u        // re-queue ring: 64-bit entries (canonical k-mer | probe distance << 54)
 
-__device__ __forceinline__ void probe_load(const TableView& t, uint64_t kmer, uint64_t dist, Pending& pd)
+// The asynchronously written registers are FIXED physical VGPRs at the top of the 128-register budget both
+// variants run with (occupancy is LDS- resp. workgroup-limited to 4 waves per SIMD): the compiler never learns
+// that a value lives there, so it cannot copy or spill it while the data is still in flight; naming them as
+// clobbers makes it allocate the full budget and keep its own values (about 60 VGPRs) far below.
+// tools/check_hot_vgprs.py verifies on the generated ISA that nothing else touches them.
+//   v[120:122] row prefetch     v123 atomic return (never read)     v[124:127] table slots of the batch in flight
+#define VG_HOT_CLOBBERS "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+
+__device__ __forceinline__ void vm_load_row(const uint8_t* ptr)
 {
-    const uint64_t rc = vg_revcomp(kmer, 27);
-    const uint64_t canon = kmer < rc ? kmer : rc;     // idempotent for re-queued (already canonical) entries
-    pd.canon = canon | (dist << 54);
-    pd.slot = (vg_thash(canon) + dist) & t.cap_mask;
-    pd.v = *reinterpret_cast<const uint4*>(&t.slots[pd.slot]);
+    asm volatile("global_load_dwordx3 v[120:122], %0, off nt ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS);
+}
+__device__ __forceinline__ void vm_load_slot(const VgSlot* ptr)
+{
+    asm volatile("global_load_dwordx4 v[124:127], %0, off ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS);
+}
+__device__ __forceinline__ void vm_atomic_inc(uint32_t* ptr, uint32_t one)
+{
+    asm volatile("global_atomic_add v123, %0, %1, off sc0 ; VGHOT" : : "v"(ptr), "v"(one) : "memory", VG_HOT_CLOBBERS);
+}
+template <int N>
+__device__ __forceinline__ void vm_wait_imm()
+{
+    asm volatile("s_waitcnt vmcnt(%0) ; VGHOT" : : "n"(N) : "memory");
+}
+// n = number of hot operations issued after the one whose result is needed (wave-uniform, SGPR): waits with
+// vmcnt(min(n, 2)) -- an immediate below the exact count is only stricter.  One asm block: the compiler's own
+// lowering of the equivalent if-chain costs ~20 scalar instructions.
+__device__ __forceinline__ void vm_wait(uint32_t n)
+{
+    asm volatile("s_cmp_lt_u32 %0, 2 ; VGHOT\n\t"
+                 "s_cbranch_scc1 1f ; VGHOT\n\t"
+                 "s_waitcnt vmcnt(2) ; VGHOT\n\t"
+                 "s_branch 3f ; VGHOT\n"
+                 "1:\n\t"
+                 "s_cmp_eq_u32 %0, 0 ; VGHOT\n\t"
+                 "s_cbranch_scc1 2f ; VGHOT\n\t"
+                 "s_waitcnt vmcnt(1) ; VGHOT\n\t"
+                 "s_branch 3f ; VGHOT\n"
+                 "2:\n\t"
+                 "s_waitcnt vmcnt(0) ; VGHOT\n"
+                 "3:"
+                 : : "s"(__builtin_amdgcn_readfirstlane((int)n)) : "scc", "memory");
+}
+__device__ __forceinline__ uint4 vm_slot_value()   // after the wait
+{
+    uint4 v;
+    asm volatile("v_mov_b32 %0, v124 ; VGHOT\n\tv_mov_b32 %1, v125 ; VGHOT\n\tv_mov_b32 %2, v126 ; VGHOT\n\tv_mov_b32 %3, v127 ; VGHOT"
+                 : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w));
+    return v;
 }
 
-// Finish the batch issued earlier: returns where the hit's counter lives (nullptr: nothing to add);
-// collisions go to the re-queue ring (or are chased right here when that ring is full).
-__device__ __forceinline__ uint32_t* probe_finish(const TableView& t, Pending& pd, uint64_t* req, uint32_t req_head,
-                                                  uint32_t& req_tail)
-{
-    bool again = false;
-    uint32_t* bump = nullptr;
-    if (pd.active) {
-        const uint64_t c = ((uint64_t)pd.v.y << 32) | pd.v.x;
-        const uint64_t canon = pd.canon & VG_Q_KMER_MASK;
-        if (c == canon) {
-            if (t.counts) bump = &t.counts[pd.v.w];                 // dense counters, clamped at read-out
-            else if (pd.v.z < 255u) bump = &t.slots[pd.slot].count;
-        } else if (c != VG_EMPTY) {
-            again = true;
-        }
-    }
-    const uint64_t ball = __builtin_amdgcn_ballot_w64(again);
-    if (__builtin_expect(ball != 0, 0)) {
-        const uint32_t n = (uint32_t)__builtin_popcountll(ball);
-        const bool fits = req_tail - req_head + n <= VG_REQ && (pd.canon >> 54) < 1023u;
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(again && !fits) == 0, 1)) {
-            if (again) {
-                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
-                                     __builtin_amdgcn_mbcnt_lo((uint32_t)ball, req_tail));
-                req[pos & (VG_REQ - 1)] = pd.canon + (1ULL << 54);
-            }
-            req_tail += n;
-        } else if (again) {
-            const uint64_t canon = pd.canon & VG_Q_KMER_MASK;
-            uint64_t sl = pd.slot;
-            for (;;) {
-                sl = (sl + 1) & t.cap_mask;
-                const uint4 v = *reinterpret_cast<const uint4*>(&t.slots[sl]);
-                const uint64_t c = ((uint64_t)v.y << 32) | v.x;
-                if (c == canon) {
-                    if (t.counts) bump = &t.counts[v.w];
-                    else if (v.z < 255u) bump = &t.slots[sl].count;
-                    break;
-                }
-                if (c == VG_EMPTY) break;
-            }
-        }
-    }
-    pd.active = false;
-    return bump;
-}
-
-__device__ __forceinline__ void probe_bump(uint32_t* bump)
-{
-    if (bump) atomicAdd(bump, 1u);
-}
-
-// LDS_BM: grid filter (2^15 words) staged in LDS (small graphs, one 1024-thread workgroup per CU)
-//         or probed in global memory (large graphs, 256-thread workgroups).
-// Row geometry of the k = 27 kernels: 768-byte rows, 12 bytes (one dwordx3) per lane, so that every lane owns
-// exactly one grid position (VG_GRID_STEP = 12) and every shift below is a compile-time constant.
+// Row geometry of the k = 27 kernels
 #define VG_ROW27 768u
 
 // Base LUT of the k = 27 kernels, at LDS byte offset 0: two sets (A: dwords 0 and 2 of a lane's chunk, B: dword 1)
@@ -458,29 +443,36 @@ __device__ __forceinline__ void stage_lut27(uint32_t tid, uint32_t nthreads)
     }
 }
 
-// 2 * byte B of w in one SDWA op (the LUT holds u16)
-template <int B>
-__device__ __forceinline__ uint32_t byte_x2(const uint32_t w, const uint32_t one)
+struct Addr4 { uint32_t a0, a1, a2, a3; };   // LDS byte offsets of a dword's four LUT entries (before the table offsets)
+
+// 2 * byte b of dword D of the landed row (v120 + D), one SDWA op each (the LUT holds u16)
+#define VG_SDWA_X2(REG, B) "v_lshlrev_b32_sdwa %" #B ", %4, " REG " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #B " ; VGHOT\n\t"
+template <int D>
+__device__ __forceinline__ Addr4 lut_addr4(const uint32_t one)
 {
-    uint32_t r;
-    if (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(one), "v"(w));
-    if (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(one), "v"(w));
-    if (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(one), "v"(w));
-    if (B == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(one), "v"(w));
-    return r;
+    Addr4 a;
+    if (D == 0) asm volatile(VG_SDWA_X2("v120", 0) VG_SDWA_X2("v120", 1) VG_SDWA_X2("v120", 2) VG_SDWA_X2("v120", 3)
+                             : "=&v"(a.a0), "=&v"(a.a1), "=&v"(a.a2), "=&v"(a.a3) : "v"(one));
+    if (D == 1) asm volatile(VG_SDWA_X2("v121", 0) VG_SDWA_X2("v121", 1) VG_SDWA_X2("v121", 2) VG_SDWA_X2("v121", 3)
+                             : "=&v"(a.a0), "=&v"(a.a1), "=&v"(a.a2), "=&v"(a.a3) : "v"(one));
+    if (D == 2) asm volatile(VG_SDWA_X2("v122", 0) VG_SDWA_X2("v122", 1) VG_SDWA_X2("v122", 2) VG_SDWA_X2("v122", 3)
+                             : "=&v"(a.a0), "=&v"(a.a1), "=&v"(a.a2), "=&v"(a.a3) : "v"(one));
+    return a;
 }
 
 template <int SET>
-__device__ __forceinline__ uint32_t encode4(const uint32_t w, const uint32_t one)
+__device__ __forceinline__ uint32_t encode4(const Addr4& a)
 {
-    const uint32_t e0 = *reinterpret_cast<lds_u16*>((uintptr_t)(byte_x2<0>(w, one) + SET * 2048u));
-    const uint32_t e1 = *reinterpret_cast<lds_u16*>((uintptr_t)(byte_x2<1>(w, one) + SET * 2048u + 512u));
-    const uint32_t e2 = *reinterpret_cast<lds_u16*>((uintptr_t)(byte_x2<2>(w, one) + SET * 2048u + 1024u));
-    uint32_t e3 = *reinterpret_cast<lds_u16*>((uintptr_t)(byte_x2<3>(w, one) + SET * 2048u + 1536u));
+    const uint32_t e0 = *reinterpret_cast<lds_u16*>((uintptr_t)(a.a0 + SET * 2048u));
+    const uint32_t e1 = *reinterpret_cast<lds_u16*>((uintptr_t)(a.a1 + SET * 2048u + 512u));
+    const uint32_t e2 = *reinterpret_cast<lds_u16*>((uintptr_t)(a.a2 + SET * 2048u + 1024u));
+    uint32_t e3 = *reinterpret_cast<lds_u16*>((uintptr_t)(a.a3 + SET * 2048u + 1536u));
     asm("" : "+v"(e3));   // hide the value range: keeps the ORs 32-bit (v_or3_b32) instead of 16-bit ops + re-extension
     return e0 | e1 | e2 | e3;
 }
 
+// LDS_BM: grid filter (2^15 words) staged in LDS (small graphs, one 1024-thread workgroup per CU)
+//         or probed in global memory (large graphs, 256-thread workgroups).
 template <bool LDS_BM>
 __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams p)
 {
@@ -491,11 +483,15 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
     const uint32_t wave = tid >> 6;
     const uint32_t nwaves = blockDim.x >> 6;
 
-    // LDS carve: [base LUT, at byte offset 0][grid filter (LDS_BM)][run rings][re-queue rings]
-    size_t off = VG_LUT27_BYTES + (LDS_BM ? (size_t)VG_GRID_LDS_WORDS * 4 : 0);
-    uint32_t* s_runs = reinterpret_cast<uint32_t*>(smem + off) + (size_t)wave * VG_RUNQ * 3;
-    off += (size_t)nwaves * VG_RUNQ * 12;
-    uint64_t* s_req = reinterpret_cast<uint64_t*>(smem + off) + (size_t)wave * VG_REQ;
+    // LDS carve: [base LUT, at byte offset 0][grid filter (LDS_BM)][run rings][re-queue rings]; everything is
+    // addressed by absolute 32-bit LDS offsets (address_space(3)), the rings' bases are wave-uniform
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u32x4 lds_u4_rw;
+    typedef __attribute__((address_space(3))) uint64_t lds_u64_rw;
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    const uint32_t rings0 = VG_LUT27_BYTES + (LDS_BM ? VG_GRID_LDS_WORDS * 4u : 0u);
+    const uint32_t runs_base = rings0 + wave_u * (VG_RUNQ * 16u);
+    const uint32_t req_base = rings0 + nwaves * (VG_RUNQ * 16u) + wave_u * (VG_REQ * 8u);
     stage_lut27(tid, blockDim.x);
     if (LDS_BM) {
         const uint4* src = reinterpret_cast<const uint4*>(p.table.grid);
@@ -505,6 +501,9 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
     __syncthreads();
     const uint32_t* g_grid = p.table.grid;
     const uint32_t gwl = LDS_BM ? VG_GRID_LDS_WORDS_LOG2 : p.table.grid_words_log2;
+    VgSlot* const slots = p.table.slots;
+    uint32_t* const counts = p.table.counts;
+    const uint64_t cap_mask = p.table.cap_mask;
 
     // rows [0, row_end) are complete 768-byte rows, so every load below is an unconditional, perfectly
     // coalesced dwordx3 (the ragged tail goes to rows_kernel, see vgmi_api.cpp)
@@ -512,7 +511,7 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
     const uint64_t total_waves = (uint64_t)gridDim.x * nwaves;
     const uint64_t rpw = (total_rows + total_waves - 1) / total_waves;
     // the wave index is uniform: keep the row counters in SGPRs
-    const uint64_t gw = (uint64_t)blockIdx.x * nwaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    const uint64_t gw = (uint64_t)blockIdx.x * nwaves + wave_u;
     const uint64_t r0v = gw * rpw;
     const uint64_t r1v = r0v + rpw < total_rows ? r0v + rpw : total_rows;
     const uint64_t r0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r0v >> 32)) << 32) |
@@ -522,15 +521,8 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
     if (r0 >= r1) return;
     uint32_t one;
     asm volatile("v_mov_b32 %0, 1" : "=v"(one));   // SDWA takes no inline constant for the shift amount
-    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-    typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
     const uint32_t lane_off = lane * 12u;
     const uint8_t* const bases = p.bases;
-    // the read block streams through once: non-temporal loads keep it from evicting the k-mer
-    // table out of the XCD's L2.  Address = uniform row base (SGPR pair) + 32-bit lane offset.
-    auto load_row = [lane_off](const uint8_t* rowp) -> u32x3 {
-        return __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4*>(rowp + lane_off));
-    };
 
     const uint32_t src1 = (lane + 63u) & 63u, src2 = (lane + 62u) & 63u, src3 = (lane + 61u) & 63u;
     // previous row's words, already rotated by 1 / 2 / 3 lanes (lanes 0..2 take them)
@@ -538,75 +530,131 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
     // the row before the range is walked first as a warm-up iteration: it only provides the halo
     const uint64_t rs = r0 > 0 ? r0 - 1 : r0;
 
-    // drain bookkeeping: which run / window of a 5-run batch this lane expands.  Ring indices stay
-    // reduced mod the ring size (wave-uniform, SGPR); a lane's slot wraps with one subtract + min.
-    const uint32_t my_run = lane / 12u, my_win = lane % 12u;
-    uint32_t run_head = 0, run_n = 0, req_head = 0, req_tail = 0;
-    Pending pd;
-    pd.active = false;
-    pd.canon = 0; pd.slot = 0; pd.v = make_uint4(0, 0, 0, 0);
+    // ---- asynchronous state (see the header comment) ----
+    uint32_t n_after_row = 0;             // hot operations issued after the prefetch of the row buffer
+    uint32_t n_after_slot = 2;            // ... after the table loads of the batch in flight
+    uint64_t b_canon = 0, b_slot = 0;     // per lane: canonical k-mer | probe distance << 54, slot probed
+    bool b_active = false;                // per lane: takes part in the batch in flight (none at the start: the
+                                          // first step "finishes" an empty batch, so the step needs no special case)
 
+    // drain bookkeeping: which run / window of a 5-run batch this lane expands.  Ring state is wave-uniform
+    // (SGPR) and kept reduced mod the ring size; a lane's slot wraps with one subtract + min.
+    const uint32_t my_run = lane / 12u, my_win = lane % 12u;
+    const uint32_t my_sh = 2 * (11 - my_win), my_vbit = 12 + my_win;
+    uint32_t run_head = 0, run_n = 0, req_head = 0, req_n = 0;
     auto ring_slot = [](uint32_t pos) -> uint32_t {  // pos < 2 * VG_RUNQ
         const uint32_t w = pos - VG_RUNQ;
         return w < pos ? w : pos;
     };
-    auto issue_runs = [&](uint32_t n_runs) {
-        __builtin_amdgcn_wave_barrier();
-        pd.active = false;
-        if (my_run < n_runs) {
-            const uint32_t* e = s_runs + ring_slot(run_head + my_run) * 3;
-            const uint32_t d0 = e[0], d1 = e[1], d2 = e[2];
-            if ((d2 >> (12 + my_win)) & 1u) {
-                // k-mer ending at window my_win of the run: bits [2(11 - win), +54) of the 76 run bits
-                const uint32_t sh = 2 * (11 - my_win);
-                const uint32_t lo = funnel(d1, d0, sh);
-                const uint32_t hi = funnel(d2, d1, sh) & MASK_HI;
-                pd.active = true;
-                probe_load(p.table, ((uint64_t)hi << 32) | lo, 0, pd);
+
+    // canonicalise + hash for every lane (cheap), load only for the lanes that take part (>= 1 by construction,
+    // so the load below is always issued and the counters stay exact)
+    auto probe_issue = [&](bool act, uint64_t kmer, uint64_t dist) __attribute__((always_inline)) {
+        const uint64_t rc = vg_revcomp(kmer, 27);
+        const uint64_t canon = kmer < rc ? kmer : rc;   // idempotent for re-queued (already canonical) entries
+        b_canon = canon | (dist << 54);
+        b_slot = (vg_thash(canon) + dist) & cap_mask;
+        b_active = act;
+        if (act) vm_load_slot(&slots[b_slot]);
+        ++n_after_row;
+        n_after_slot = 0;
+    };
+    // one drain step: finish the batch in flight (compare, atomic add for the hits, re-queue the collisions),
+    // then issue the next batch: 32+ re-queued k-mers first, else up to 5 runs
+    auto drain_step = [&]() __attribute__((always_inline)) {
+        vm_wait(n_after_slot);
+        const uint4 tv = vm_slot_value();
+        bool again = false;
+        uint32_t* bump = nullptr;
+        if (b_active) {
+            const uint64_t c = ((uint64_t)tv.y << 32) | tv.x;
+            const uint64_t canon = b_canon & VG_Q_KMER_MASK;
+            if (c == canon) {
+                if (counts) bump = &counts[tv.w];                    // dense counters, clamped at read-out
+                else if (tv.z < 255u) bump = &slots[b_slot].count;
+            } else if (c != VG_EMPTY) {
+                again = true;
             }
         }
-        run_head += n_runs;
-        if (run_head >= VG_RUNQ) run_head -= VG_RUNQ;
-        run_n -= n_runs;
-        __builtin_amdgcn_wave_barrier();
-    };
-    auto issue_requeued = [&](uint32_t n) {
-        __builtin_amdgcn_wave_barrier();
-        pd.active = lane < n;
-        if (pd.active) {
-            const uint64_t e = s_req[(req_head + lane) & (VG_REQ - 1)];
-            probe_load(p.table, e & VG_Q_KMER_MASK, e >> 54, pd);
+        const uint64_t ball = __builtin_amdgcn_ballot_w64(again);
+        if (ball != 0) {
+            const uint32_t n = (uint32_t)__builtin_popcountll(ball);
+            const bool fits = req_n + n <= VG_REQ && (b_canon >> 54) < 1023u;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(again && !fits) == 0, 1)) {
+                if (again) {
+                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
+                                         __builtin_amdgcn_mbcnt_lo((uint32_t)ball, req_head + req_n));
+                    *reinterpret_cast<lds_u64_rw*>((uintptr_t)(req_base + (pos & (VG_REQ - 1)) * 8u)) = b_canon + (1ULL << 54);
+                }
+                req_n += n;
+            } else if (again) {
+                // ring full (or probe distance field exhausted): chase the chain right here.  Ordinary,
+                // compiler-managed loads; its waits are conservative, which is harmless on this rare path
+                const uint64_t canon = b_canon & VG_Q_KMER_MASK;
+                uint64_t sl = b_slot;
+                for (;;) {
+                    sl = (sl + 1) & cap_mask;
+                    const uint4 v = *reinterpret_cast<const uint4*>(&slots[sl]);
+                    const uint64_t c = ((uint64_t)v.y << 32) | v.x;
+                    if (c == canon) {
+                        if (counts) bump = &counts[v.w];
+                        else if (v.z < 255u) bump = &slots[sl].count;
+                        break;
+                    }
+                    if (c == VG_EMPTY) break;
+                }
+            }
         }
-        req_head += n;
+        if (__builtin_amdgcn_ballot_w64(bump != nullptr)) {   // wave-uniform: the atomic is issued iff some lane hit
+            if (bump) vm_atomic_inc(bump, one);
+            ++n_after_row;
+        }
         __builtin_amdgcn_wave_barrier();
-    };
-    // one drain step: finish the batch in flight, issue the next one, then bump the finished hits
-    auto drain_step = [&](bool flush) -> bool {
-        const uint32_t n_runs = run_n, n_req = req_tail - req_head;
-        const bool do_req = n_req >= 32u || (flush && n_runs == 0 && n_req > 0);
-        const bool do_runs = !do_req && (n_runs >= VG_RUN_BATCH || (flush && n_runs > 0));
-        // every condition here must be wave-uniform: pd.active is per lane
-        const bool in_flight = __builtin_amdgcn_ballot_w64(pd.active) != 0;
-        if (!do_req && !do_runs && !(flush && in_flight)) return false;
-        uint32_t* bump = probe_finish(p.table, pd, s_req, req_head, req_tail);
-        if (do_req) issue_requeued(n_req < 64u ? n_req : 64u);
-        else if (do_runs) issue_runs(n_runs < VG_RUN_BATCH ? n_runs : VG_RUN_BATCH);
-        probe_bump(bump);
-        return true;
+        // ring bookkeeping first, branch-free (both rings' counters are updated on both paths: a common tail the
+        // optimiser could sink through a pointer select would push them into scratch memory)
+        const bool do_req = req_n >= 32u || run_n == 0;
+        const uint32_t take_req = do_req ? (req_n < 64u ? req_n : 64u) : 0u;   // may be 0 (final flush)
+        const uint32_t take_run = do_req ? 0u : (run_n < VG_RUN_BATCH ? run_n : VG_RUN_BATCH);
+        const uint32_t rq_head = req_head, rn_head = run_head;
+        req_head += take_req;
+        req_n -= take_req;
+        run_head += take_run;
+        if (run_head >= VG_RUNQ) run_head -= VG_RUNQ;
+        run_n -= take_run;
+        if (do_req) {
+            const bool have = lane < take_req;
+            uint64_t e = 0;
+            if (have) e = *reinterpret_cast<lds_u64_rw*>((uintptr_t)(req_base + ((rq_head + lane) & (VG_REQ - 1)) * 8u));
+            if (take_req) probe_issue(have, e & VG_Q_KMER_MASK, e >> 54);
+            else b_active = false;   // an all-idle batch, no load
+        } else {
+            const bool have = my_run < take_run;
+            u32x4 e = {0u, 0u, 0u, 0u};
+            if (have) e = *reinterpret_cast<lds_u4_rw*>((uintptr_t)(runs_base + ring_slot(rn_head + my_run) * 16u));
+            // k-mer ending at window my_win of the run: bits [2(11 - win), +54) of the 76 run bits
+            const uint32_t lo = funnel(e.y, e.x, my_sh);
+            const uint32_t hi = funnel(e.z, e.y, my_sh) & MASK_HI;
+            probe_issue(have && ((e.z >> my_vbit) & 1u), ((uint64_t)hi << 32) | lo, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
     };
 
     // 32-bit trip count and a scalar row pointer: the loop control stays on the SALU
     const uint32_t n_it = (uint32_t)(r1 - rs), n_warm = (uint32_t)(r0 - rs);
     const uint8_t* rowp = bases + rs * VG_ROW27;
-    u32x3 raw_next = load_row(rowp);
+    vm_load_row(rowp + lane_off);
     for (uint32_t it = 0; it < n_it; ++it) {
-        const u32x3 raw = raw_next;
+        // the row has landed once at most n_after_row younger operations are outstanding
+        vm_wait(n_after_row);
+        const Addr4 a0 = lut_addr4<0>(one), a1 = lut_addr4<1>(one), a2 = lut_addr4<2>(one);
         const uint8_t* const cur = rowp;
         if (it + 1 < n_it) rowp += VG_ROW27;
-        raw_next = load_row(rowp);  // prefetch (the last iteration re-reads its own row)
+        vm_load_row(rowp + lane_off);  // prefetch (the last iteration re-reads its own row)
+        n_after_row = 0;
+        ++n_after_slot;
 
         // own 12 bases: be = 24 bits, first base most significant; inv bit t = base t is not a base
-        const uint32_t g0 = encode4<0>(raw.x, one), g1 = encode4<1>(raw.y, one), g2 = encode4<0>(raw.z, one);
+        const uint32_t g0 = encode4<0>(a0), g1 = encode4<1>(a1), g2 = encode4<0>(a2);
         const uint32_t be = __builtin_amdgcn_perm(g0, __builtin_amdgcn_perm(g1, g2, 0x0c0c0400u), 0x0c040100u);
         const uint32_t inv = ((g0 | g1) >> 8) | (g2 & 0xF00u);   // g0: bits 8..11, g1: 12..15, g2: 8..11
         const uint32_t r1_be = __shfl(be, src1), r2_be = __shfl(be, src2), r3_be = __shfl(be, src3);
@@ -648,35 +696,33 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
         const uint32_t a = (inv << 1) & 0xFFFu;
         const uint32_t bad_b = B ? (0xFFFFFFFFu >> __builtin_clz(B)) : 0u;
         const uint32_t vm = ~(a | (0u - a) | bad_b) & 0xFFFu;
-        const bool gv = B < 2048u;   // no non-base in q 20..35
 
         const uint32_t mer = funnel(W1, W0, 24);
         uint64_t gx;
-        uint32_t gm, gw32 = 0;
+        uint32_t gm, gw32;
         vg_grid_probe(mer, gwl, gx, gm);
-        if (LDS_BM) {
-            if (gv) gw32 = *reinterpret_cast<lds_u32*>((uintptr_t)(((uint32_t)gx << 2) + VG_LUT27_BYTES));
-        } else {
-            if (gv) gw32 = g_grid[gx];
-        }
-        const bool hit = gv && (gw32 & gm) == gm && vm != 0;
+        if (LDS_BM) gw32 = *reinterpret_cast<lds_u32*>((uintptr_t)(((uint32_t)gx << 2) + VG_LUT27_BYTES));
+        else gw32 = g_grid[gx];
+        // B < 2048: no non-base in q 20..35 (the 16-mer itself)
+        const bool hit = B < 2048u && (gw32 & gm) == gm && vm != 0;
         const uint64_t ball = __builtin_amdgcn_ballot_w64(hit);
-        if (ball) {
-            if (__builtin_amdgcn_inverse_ballot_w64(ball)) {
-                const uint32_t d0 = funnel(W1, W0, 2);
-                const uint32_t d1 = funnel(W2, W1, 2);
-                const uint32_t d2 = ((W2 >> 2) & 0xFFFu) | (vm << 12);
-                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
-                                     __builtin_amdgcn_mbcnt_lo((uint32_t)ball, run_head + run_n));
-                uint32_t* e = s_runs + ring_slot(pos) * 3;
-                e[0] = d0; e[1] = d1; e[2] = d2;
-            }
-            run_n += (uint32_t)__builtin_popcountll(ball);
+        if (__builtin_amdgcn_inverse_ballot_w64(ball)) {
+            const uint32_t d0 = funnel(W1, W0, 2);
+            const uint32_t d1 = funnel(W2, W1, 2);
+            const uint32_t d2 = ((W2 >> 2) & 0xFFFu) | (vm << 12);
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
+                                 __builtin_amdgcn_mbcnt_lo((uint32_t)ball, run_head + run_n));
+            *reinterpret_cast<lds_u4_rw*>((uintptr_t)(runs_base + ring_slot(pos) * 16u)) = u32x4{d0, d1, d2, 0u};
         }
+        run_n += (uint32_t)__builtin_popcountll(ball);
         if (p.dbg & 1u) { run_n = 0; continue; }
-        while (drain_step(false)) {}
+        while (run_n >= VG_RUN_BATCH || req_n >= 32u) drain_step();
     }
-    while (drain_step(true)) {}
+    // flush: until the rings are empty and the last step issued nothing (finishing a batch can re-queue)
+    do {
+        drain_step();
+    } while (run_n != 0 || req_n != 0 || __builtin_amdgcn_ballot_w64(b_active) != 0);
+    vm_wait_imm<0>();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -877,7 +923,7 @@ static hipError_t launch_rows_t(const RowParams& p, uint32_t grid, uint32_t bloc
 template <bool LDS_BM>
 static hipError_t launch_count27_t(const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)
 {
-    const size_t lds = (LDS_BM ? (size_t)VG_GRID_LDS_WORDS * 4 : 0) + (size_t)(block / 64) * (VG_RUNQ * 12 + VG_REQ * 8) + VG_LUT27_BYTES;
+    const size_t lds = (LDS_BM ? (size_t)VG_GRID_LDS_WORDS * 4 : 0) + (size_t)(block / 64) * (VG_RUNQ * 16 + VG_REQ * 8) + VG_LUT27_BYTES;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&count27_kernel<LDS_BM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
