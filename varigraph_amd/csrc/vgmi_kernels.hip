@@ -414,6 +414,25 @@ __device__ __forceinline__ void vm_wait(uint32_t n)
                  "3:"
                  : : "s"(__builtin_amdgcn_readfirstlane((int)n)) : "scc", "memory");
 }
+// rare paths: synchronous loads / fire-and-forget atomics, also by hand -- a single compiler-visible memory operation
+// in the loop makes the compiler add its own vmcnt(0) waits in the hot path
+__device__ __forceinline__ uint4 vm_load_slot_sync(const VgSlot* ptr)
+{
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t v;
+    asm volatile("global_load_dwordx4 %0, %1, off ; VGHOT\n\ts_waitcnt vmcnt(0) ; VGHOT" : "=&v"(v) : "v"(ptr) : "memory");
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t vm_load_byte_sync(const uint8_t* ptr)
+{
+    uint32_t v;
+    asm volatile("global_load_ubyte %0, %1, off ; VGHOT\n\ts_waitcnt vmcnt(0) ; VGHOT" : "=&v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void vm_atomic_or_sync(uint32_t* ptr, uint32_t bits)
+{
+    asm volatile("global_atomic_or %0, %1, off ; VGHOT\n\ts_waitcnt vmcnt(0) ; VGHOT" : : "v"(ptr), "v"(bits) : "memory");
+}
 __device__ __forceinline__ uint4 vm_slot_value()   // after the wait
 {
     uint4 v;
@@ -588,13 +607,12 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
                 }
                 req_n += n;
             } else if (again) {
-                // ring full (or probe distance field exhausted): chase the chain right here.  Ordinary,
-                // compiler-managed loads; its waits are conservative, which is harmless on this rare path
+                // ring full (or probe distance field exhausted): chase the chain right here, synchronously
                 const uint64_t canon = b_canon & VG_Q_KMER_MASK;
                 uint64_t sl = b_slot;
                 for (;;) {
                     sl = (sl + 1) & cap_mask;
-                    const uint4 v = *reinterpret_cast<const uint4*>(&slots[sl]);
+                    const uint4 v = vm_load_slot_sync(&slots[sl]);
                     const uint64_t c = ((uint64_t)v.y << 32) | v.x;
                     if (c == canon) {
                         if (counts) bump = &counts[v.w];
@@ -676,7 +694,8 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
                     for (uint32_t t = 0; t < 12; ++t) {
                         if (!((adj >> t) & 1u)) continue;
                         const uint64_t o = base_off + t;
-                        if (p.bases[o] == '\n' && (o == 0 || p.bases[o - 1] == '\n')) atomicOr(p.status, 1u);
+                        if (vm_load_byte_sync(bases + o) == '\n' && (o == 0 || vm_load_byte_sync(bases + o - 1) == '\n'))
+                            vm_atomic_or_sync(p.status, 1u);
                     }
                 }
             }
