@@ -65,7 +65,7 @@ struct vgmi_ctx {
     uint32_t* d_counts = nullptr;   // dense per-key counters of large graphs (per-sample state, not part of the image)
     bool filter_in_lds = false;
     bool fast27 = false;         // k = 27: count27_kernel
-    bool fast27_lds = false;     // ... with the 2^20-bit suffix bitmap resident in LDS
+    bool fast27_lds = false;     // ... with the 128 KiB grid filter resident in LDS
     uint32_t wgs_per_cu = 0;     // VGMI_WGS_PER_CU: tuning override for the global-bitmap variant
     bool force_generic = false;  // VGMI_GENERIC_KERNEL=1: take the generic row kernel (A/B testing)
 
@@ -257,9 +257,9 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
         uint32_t grid, block;
         rows_geometry(c, c->filter_in_lds, grid, block);
         if (c->fast27 && !c->force_generic) {
-            // complete 1 KiB rows -> fast kernel.  It covers every k-mer ending at or before its last
-            // grid offset (largest position = 11 mod 12 inside those rows); the generic kernel takes
-            // the ends after that: the ragged tail row plus at most 11 positions of the last full row.
+            // complete 768-byte rows -> fast kernel.  It covers every k-mer whose run starts at one of its
+            // grid positions; the generic kernel takes the ends after that: the ragged tail plus the last
+            // position of the last full row.
             p.row_end = n_bytes / 768;   // VG_ROW27: count27_kernel walks complete 768-byte rows
             uint64_t emit_from = 0;
             if (p.row_end) {

@@ -9,19 +9,21 @@
 //   K6  masked coverage histogram                  src/varigraph.cpp:253-296
 //
 // Design (DESIGN.md has the full story).  The read block is a '\n'-joined ASCII byte stream.
-// A wavefront walks contiguous 1 KiB rows of it: lane l owns the 16 bytes [16l, 16l+16) of the
-// row (one coalesced dwordx4 per lane), encodes them to 2 bits/base through an LDS-resident
-// copy of seq_nt4_table, and receives the previous 32 bases from lanes l-1 / l-2 (and from the
-// previous row for lanes 0/1) by cross-lane permutes.  From that 48-base window every lane
-// extracts its 16 forward and reverse-complement k-mers with funnel shifts -- no per-read
-// state, no halo recomputation.  For odd k a k-mer can never equal its own reverse complement,
-// so the reference's state machine reduces exactly to "emit iff the last k bases are all
-// valid" (even k takes the sequential kernel below, which restates the machine
-// literally).  The canonical k-mer is tested against a blocked Bloom prefilter held in LDS
-// (when the graph is small enough) so that the ~97 % of read k-mers that are not graph k-mers
-// never leave the CU; survivors are compacted per wavefront into an LDS queue and probed
-// 64 at a time against the exact open-addressing table, whose hits bump 32-bit counters with
-// atomicAdd (skipped once a counter has reached the 255 clamp).
+// A wavefront walks contiguous rows of it; a lane owns a fixed chunk of the row (one coalesced
+// load per lane), encodes it to 2 bits/base through an LDS-resident copy of seq_nt4_table, and
+// receives the bases before its chunk from the lanes before it (previous row for the first
+// lanes) by cross-lane permutes -- no per-read state, no halo recomputation.  For odd k a k-mer
+// can never equal its own reverse complement, so the reference's state machine reduces exactly
+// to "emit iff the last k bases are all valid" (even k takes the sequential
+// kernel below, which restates the machine literally).
+//   rows_kernel     generic odd k: 1 KiB rows, 16 bytes per lane; every canonical k-mer is tested
+//                   against a blocked Bloom prefilter (LDS when the graph is small enough),
+//                   survivors are compacted per wavefront into an LDS queue and probed 64 at a
+//                   time against the exact open-addressing table.
+//   count27_kernel  k = 27 (every BASELINE configuration): 768-byte rows, 12 bytes per lane, ONE
+//                   grid-filter probe per lane and row, candidate RUNS of 12 k-mers, pipelined
+//                   table probes with hand-scheduled vector memory.
+// Hits bump 32-bit counters with atomicAdd (skipped once a counter has reached the 255 clamp).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
