@@ -410,6 +410,36 @@ def test_dense_hits_overflow_path(ctx, k):
     assert (cov == 255).any()
 
 
+def test_saturation_flags_cleared_by_reset(ctx):
+    """Compact table format (k = 27, small graph): a counter that reaches the 255 clamp gets its slot flagged so
+    that later hits skip their atomic.  The flag is per-sample state: after vgmi_counts_reset a shallow sample must
+    count exactly again, and a deep one must saturate exactly again."""
+    k = 27
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genome = acgt[rng.integers(0, 4, size=2000)]
+    keys = np.unique(o.sketch(genome.tobytes(), k))
+
+    def sample(n, seed):
+        r = np.random.default_rng(seed)
+        return [genome[s:s + 150].tobytes() for s in r.integers(0, genome.size - 150, size=n)]
+
+    deep, shallow = sample(20000, 1), sample(300, 2)
+    ctx.table_upload(keys, k)
+    for seqs in (deep, shallow, deep):
+        block = block_from_seqs(seqs)
+        ctx.counts_reset()
+        ctx.reads_submit(block, len(seqs))
+        cov, _, _ = ctx.counts_finish()
+        t = o.Table(keys)
+        t.count_block(block, k)
+        assert np.array_equal(cov, t.counts())
+        if seqs is deep:
+            assert (cov == 255).all()
+        else:
+            assert cov.max() < 255 and cov.sum() > 0
+
+
 # ----------------------------------------------------------------------------- large graphs (global grid bitmap)
 @pytest.mark.parametrize("k", [27, 25])
 def test_large_graph_grid_variant_matches_oracle(k):

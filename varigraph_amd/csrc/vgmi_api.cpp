@@ -31,7 +31,8 @@ struct ImageHeader {  // first 256 bytes of the table image
     uint64_t n_keys;
     uint64_t cap;
     uint64_t off_slots, off_key_slot, off_filter, off_grid, total_bytes;
-    uint32_t grid_words_log2, reserved;
+    uint32_t grid_words_log2;
+    uint32_t slot_bytes;   // 16: VgSlot, 8: compact k-mer words (vgmi_device.h)
     uint8_t pad[256 - 8 - 4 - 4 - 8 - 8 - 40 - 8];
 };
 static_assert(sizeof(ImageHeader) == 256, "image header is 256 bytes");
@@ -62,7 +63,9 @@ struct vgmi_ctx {
     bool has_table = false;
     TableView tv{};
     uint32_t* d_key_slot = nullptr;
-    uint32_t* d_counts = nullptr;   // dense per-key counters of large graphs (per-sample state, not part of the image)
+    uint32_t* d_counts = nullptr;   // counter array (per-sample state, not part of the image): per key (large graphs)
+                                    // or per slot (compact format); nullptr: in-slot counters
+    uint64_t n_counts = 0;
     bool filter_in_lds = false;
     bool fast27 = false;         // k = 27: count27_kernel
     bool fast27_lds = false;     // ... with the 128 KiB grid filter resident in LDS
@@ -162,8 +165,11 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     memcpy(h.magic, "VGMITBL1", 8);
     h.k = k;
     h.n_keys = n_keys;
+    // compact 8-byte slots for the LDS-filter kernel (k = 27, <= 65 536 keys): same bytes, twice the slots
+    const bool compact = k == 27 && n_keys <= VG_GRID_LDS_MAX_KEYS && !getenv("VGMI_WIDE_SLOTS");
+    h.slot_bytes = compact ? 8 : 16;
     uint64_t cap = 64;
-    uint64_t lf_mul = 4;  // load factor <= 0.25: ~88 % of probes end at the first slot
+    uint64_t lf_mul = compact ? 8 : 4;  // load factor <= 0.125 / 0.25: nearly every probe ends at the first slot
     if (const char* e = getenv("VGMI_TABLE_MUL")) lf_mul = (uint64_t)atoi(e) > 1 ? (uint64_t)atoi(e) : 2;
     while (cap < lf_mul * n_keys) cap <<= 1;
     h.cap = cap;
@@ -173,7 +179,7 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     h.filter_words_log2 = ceil_log2(bits) - 5;
     auto align = [](uint64_t x) { return (x + 255) & ~255ULL; };
     h.off_slots = 256;
-    h.off_key_slot = align(h.off_slots + cap * sizeof(VgSlot));
+    h.off_key_slot = align(h.off_slots + cap * h.slot_bytes);
     h.off_filter = align(h.off_key_slot + (n_keys ? n_keys : 1) * 4);
     // grid filter of the k = 27 kernels (vgmi_device.h): 2^15 words in LDS while the graph is small,
     // else >= 32 bits per key in global memory (~2.8 sixteen-mers per key, 3 bits each)
@@ -200,7 +206,9 @@ bool filter_fits_lds(uint32_t words_log2) { return (4ULL << words_log2) + 16 * 1
 int adopt_image(vgmi_ctx* c)
 {
     const ImageHeader& h = c->hdr;
-    c->tv.slots = reinterpret_cast<VgSlot*>(c->d_image + h.off_slots);
+    const bool compact = h.slot_bytes == 8;
+    c->tv.slots = compact ? nullptr : reinterpret_cast<VgSlot*>(c->d_image + h.off_slots);
+    c->tv.slots8 = compact ? reinterpret_cast<unsigned long long*>(c->d_image + h.off_slots) : nullptr;
     c->tv.cap_mask = h.cap - 1;
     c->tv.filter = reinterpret_cast<const uint32_t*>(c->d_image + h.off_filter);
     c->tv.filter_words_log2 = h.filter_words_log2;
@@ -208,14 +216,18 @@ int adopt_image(vgmi_ctx* c)
     c->tv.grid = h.off_grid ? reinterpret_cast<const uint32_t*>(c->d_image + h.off_grid) : nullptr;
     c->tv.grid_words_log2 = h.grid_words_log2;
     c->fast27 = h.k == 27 && h.off_grid;                       // count27_kernel applies
-    c->fast27_lds = c->fast27 && h.grid_words_log2 == VG_GRID_LDS_WORDS_LOG2;  // with the filter in LDS
+    c->fast27_lds = c->fast27 && h.grid_words_log2 == VG_GRID_LDS_WORDS_LOG2 && compact;  // filter in LDS, compact slots
     c->d_key_slot = reinterpret_cast<uint32_t*>(c->d_image + h.off_key_slot);
     c->filter_in_lds = filter_fits_lds(h.filter_words_log2);
     HIPCHK(c, hipMalloc(&c->d_cov, h.n_keys ? h.n_keys : 1));
     c->tv.counts = nullptr;
-    if (h.n_keys > VG_GRID_LDS_MAX_KEYS) {   // large graph: 4 B/key dense counters stay Infinity-Cache resident
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_counts), h.n_keys * 4));
-        HIPCHK(c, hipMemset(c->d_counts, 0, h.n_keys * 4));
+    c->n_counts = 0;
+    if (compact) c->n_counts = h.cap;                                   // per-slot counters
+    else if (h.n_keys > VG_GRID_LDS_MAX_KEYS) c->n_counts = h.n_keys;   // large graph: 4 B/key dense counters stay
+                                                                        // Infinity-Cache resident
+    if (c->n_counts) {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_counts), c->n_counts * 4));
+        HIPCHK(c, hipMemset(c->d_counts, 0, c->n_counts * 4));
         c->tv.counts = c->d_counts;
     }
     c->has_table = true;
@@ -250,6 +262,7 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
     if (n_bytes == 0) return VGMI_OK;
     const uint32_t k = c->hdr.k;
     RowParams p = row_params(c, d_bases, n_bytes, k);
+    if (getenv("VGMI_TRACE")) fprintf(stderr, "[vgmi] launch_count k=%u slots=%p slots8=%p counts=%p cap_mask=%llx filter=%p n_bytes=%zu off=%p n_reads=%zu\n", k, (void*)p.table.slots, (void*)p.table.slots8, (void*)p.table.counts, (unsigned long long)p.table.cap_mask, (const void*)p.table.filter, n_bytes, (const void*)d_read_off, n_reads);
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     if (!e0 || !e1) return fail(c, VGMI_E_HIP, "hipEventCreate failed");
     HIPCHK(c, hipEventRecord(e0, st));
@@ -260,7 +273,7 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
             // complete 768-byte rows -> fast kernel.  It covers every k-mer whose run starts at one of its
             // grid positions; the generic kernel takes the ends after that: the ragged tail plus the last
             // position of the last full row.
-            p.row_end = n_bytes / 768;   // VG_ROW27: count27_kernel walks complete 768-byte rows
+            p.row_end = (n_bytes / 1536) * 2;   // VG_ROW27: count27_kernel walks complete 768-byte rows, two per iteration
             uint64_t emit_from = 0;
             if (p.row_end) {
                 if (c->fast27_lds) { block = 1024; grid = (uint32_t)c->n_cu; }
@@ -443,7 +456,7 @@ int vgmi_table_upload(vgmi_ctx* c, const uint64_t* keys, size_t n_keys, uint32_t
     HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4, c->stream));
     int rc = adopt_image(c);
     if (rc) return rc;
-    HIPCHK(c, launch_table_clear(c->tv.slots, c->hdr.cap, c->stream));
+    HIPCHK(c, launch_table_clear(c->tv, c->stream));
     uint64_t* d_keys = nullptr;
     if (n_keys) {
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_keys), n_keys * 8));
@@ -501,7 +514,7 @@ int vgmi_table_import(vgmi_ctx* c, const void* dev_src, size_t bytes)
     HIPCHK(c, hipMemcpy(c->d_image, dev_src, c->image_bytes, hipMemcpyDeviceToDevice));
     int rc = adopt_image(c);
     if (rc) return rc;
-    HIPCHK(c, launch_counts_reset(c->tv.slots, c->hdr.cap, c->stream));
+    HIPCHK(c, launch_counts_reset(c->tv, c->stream));   // the exporter's per-sample state travels with the image
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->read_base = 0;
     return VGMI_OK;
@@ -559,8 +572,8 @@ int vgmi_counts_reset(vgmi_ctx* c)
     if (rc) return rc;
     rc = collect_timing(c);
     if (rc) return rc;
-    if (c->d_counts) HIPCHK(c, hipMemsetAsync(c->d_counts, 0, c->hdr.n_keys * 4, c->stream));
-    else HIPCHK(c, launch_counts_reset(c->tv.slots, c->hdr.cap, c->stream));
+    if (c->d_counts) HIPCHK(c, hipMemsetAsync(c->d_counts, 0, c->n_counts * 4, c->stream));
+    if (!c->d_counts || c->tv.slots8) HIPCHK(c, launch_counts_reset(c->tv, c->stream));   // in-slot counters / saturation flags
     HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4, c->stream));
     c->read_base = 0;
     c->kernel_ms = 0.f;
@@ -659,7 +672,7 @@ static int finish_common(vgmi_ctx* c, uint8_t* d_cov, uint8_t* d_cov_node, unsig
     for (auto& s : c->stage)
         if (s.busy) HIPCHK(c, hipStreamWaitEvent(c->stream, s.done, 0));
     if (d_hist) HIPCHK(c, hipMemsetAsync(d_hist, 0, 256 * 8, c->stream));
-    HIPCHK(c, launch_cov(c->tv.slots, c->d_key_slot, c->d_counts, c->hdr.n_keys, c->d_flag, d_cov, d_hist, c->stream));
+    HIPCHK(c, launch_cov(c->tv, c->d_key_slot, c->hdr.n_keys, c->d_flag, d_cov, d_hist, c->stream));
     if (d_cov_node && c->n_node_entries)
         HIPCHK(c, launch_node_gather(d_cov, c->d_node_key_index, c->n_node_entries, d_cov_node, c->stream));
     return VGMI_OK;
@@ -713,7 +726,7 @@ static int counts_xfer(vgmi_ctx* c, uint32_t* dev, bool import)
     HIPCHK(c, hipSetDevice(c->device));
     for (auto& s : c->stage)
         if (s.busy) HIPCHK(c, hipStreamWaitEvent(c->stream, s.done, 0));
-    HIPCHK(c, launch_counts_xfer(c->tv.slots, c->d_key_slot, c->d_counts, dev, c->hdr.n_keys, import, c->stream));
+    HIPCHK(c, launch_counts_xfer(c->tv, c->d_key_slot, dev, c->hdr.n_keys, import, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return VGMI_OK;
 }

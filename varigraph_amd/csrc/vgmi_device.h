@@ -21,10 +21,23 @@
 #endif
 
 #define VG_EMPTY 0xFFFFFFFFFFFFFFFFULL
+// The k-mer word of a slot: bits 0..55 canonical k-mer (k <= 28), VG_EMPTY when free, and two flags:
+//   VG_SLOT_CHAIN  some key probed PAST this slot when it was inserted.  A lookup that finds another key here goes
+//                  on only if the flag is set: an absent k-mer stops at the first probe almost always.
+//   VG_SLOT_SAT    (compact format) the slot's counter has reached the 255 clamp: later hits skip their atomic,
+//                  as the reference skips its increment.  Cleared by vgmi_counts_reset.
+// The all-ones pattern cannot be a stored k-mer: its low 2k bits are T^k, whose canonical form is A^k = 0.
+#define VG_SLOT_KMER_MASK ((1ULL << 56) - 1)
+#define VG_SLOT_CHAIN (1ULL << 62)
+#define VG_SLOT_SAT (1ULL << 63)
 
-// One slot of the open-addressing table (16 B, one dwordx4 per probe).
+// Two table formats (chosen at upload, ImageHeader::slot_bytes):
+//   16 B  VgSlot {k-mer word, count, key_index}: one dwordx4 per probe.  In-slot counters for small graphs, dense
+//         per-key counters (TableView::counts[key_index]) for large ones.
+//    8 B  compact: the k-mer word only, counters in a parallel array indexed by slot (TableView::counts[slot]).
+//         k = 27 graphs of <= 65 536 k-mers (the LDS-filter kernel): half the table bytes at twice the slots.
 struct __attribute__((aligned(16))) VgSlot {
-    unsigned long long canon;  // canonical k-mer = hash64^-1(key >> 8), or VG_EMPTY
+    unsigned long long canon;  // k-mer word
     unsigned int count;        // occurrences seen this sample (clamped to 255 on read-out)
     unsigned int key_index;    // index of the key in the uploaded keys[]
 };

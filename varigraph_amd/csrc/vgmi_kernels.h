@@ -11,15 +11,16 @@ namespace vgk {
 enum { K_MODE_COUNT = 0, K_MODE_KEYS = 1, K_MODE_BLOOM = 2 };
 
 struct TableView {
-    VgSlot* slots;              // cap entries
+    VgSlot* slots;              // cap entries (16-byte format) or nullptr
+    unsigned long long* slots8; // cap k-mer words (compact 8-byte format) or nullptr
     uint64_t cap_mask;          // cap - 1 (cap is a power of two)
     const uint32_t* filter;     // blocked-Bloom prefilter, 1 << filter_words_log2 words
     uint32_t filter_words_log2; // >= 2
     uint32_t filter_shift;      // 32 - filter_words_log2
     const uint32_t* grid;       // grid filter (1 << grid_words_log2 words) or nullptr, see vgmi_device.h
     uint32_t grid_words_log2;   // VG_GRID_LDS_WORDS_LOG2 (LDS-resident variant) or larger (global variant)
-    uint32_t* counts;           // large graphs: dense per-key counters (4 B/key, Infinity-Cache sized) instead of the
-                                // in-slot ones; nullptr for small graphs
+    uint32_t* counts;           // 16-byte format: dense per-key counters of large graphs (4 B/key, Infinity-Cache
+                                // sized) or nullptr (in-slot counters); compact format: per-slot counters (cap)
 };
 
 #define VG_BLOOM_MAX_HASH 32
@@ -56,13 +57,13 @@ struct SynthHaps {
 hipError_t launch_count27(bool lds_bitmap, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t launch_seq(int mode, const RowParams& p, const uint64_t* read_off, uint64_t n_reads, hipStream_t st);
-hipError_t launch_table_clear(VgSlot* slots, uint64_t cap, hipStream_t st);
+hipError_t launch_table_clear(const TableView& t, hipStream_t st);
 hipError_t launch_table_insert(const TableView& t, const uint64_t* keys, uint64_t n, uint32_t k, uint32_t* key_slot,
                                uint32_t* filter_rw, uint32_t* grid_rw, uint32_t* status, hipStream_t st);
-hipError_t launch_counts_reset(VgSlot* slots, uint64_t cap, hipStream_t st);
-hipError_t launch_cov(const VgSlot* slots, const uint32_t* key_slot, const uint32_t* counts, uint64_t n, const uint8_t* flag,
+hipError_t launch_counts_reset(const TableView& t, hipStream_t st);
+hipError_t launch_cov(const TableView& t, const uint32_t* key_slot, uint64_t n, const uint8_t* flag,
                       uint8_t* cov, unsigned long long* hist, hipStream_t st);
-hipError_t launch_counts_xfer(VgSlot* slots, const uint32_t* key_slot, uint32_t* dense, uint32_t* ext, uint64_t n, bool import,
+hipError_t launch_counts_xfer(const TableView& t, const uint32_t* key_slot, uint32_t* ext, uint64_t n, bool import,
                               hipStream_t st);
 hipError_t launch_node_gather(const uint8_t* cov, const uint32_t* key_index, uint64_t n, uint8_t* cov_node, hipStream_t st);
 hipError_t launch_bloom_query(const BloomView& b, const uint64_t* keys, uint64_t n, uint8_t* min_out, uint8_t* nz_out,

@@ -81,19 +81,39 @@ __device__ __forceinline__ void bloom_add_key(const BloomView& b, uint64_t key)
     }
 }
 
-// exact-table probe + saturating count of one canonical k-mer
+// counter cell of the key held by slot s (16-byte format: v = the slot; compact format: counts are per slot)
+__device__ __forceinline__ uint32_t* count_cell(const TableView& t, uint64_t s, uint32_t key_index)
+{
+    if (t.slots8) return &t.counts[s];
+    return t.counts ? &t.counts[key_index] : &t.slots[s].count;
+}
+
+// exact-table probe + saturating count of one canonical k-mer (generic kernels; either table format)
 __device__ __forceinline__ void table_count(const TableView& t, uint64_t canon)
 {
     uint64_t s = vg_thash(canon) & t.cap_mask;
+    if (t.slots8) {   // compact format: k-mer words, per-slot counters
+        for (;;) {
+            const uint64_t c = t.slots8[s];
+            if (c == VG_EMPTY) return;
+            if ((c & VG_SLOT_KMER_MASK) == canon) {
+                if (!(c & VG_SLOT_SAT)) atomicAdd(&t.counts[s], 1u);
+                return;
+            }
+            if (!(c & VG_SLOT_CHAIN)) return;
+            s = (s + 1) & t.cap_mask;
+        }
+    }
     for (;;) {
         const uint4 v = *reinterpret_cast<const uint4*>(&t.slots[s]);
         const uint64_t c = ((uint64_t)v.y << 32) | v.x;
-        if (c == canon) {
+        if (c == VG_EMPTY) return;
+        if ((c & VG_SLOT_KMER_MASK) == canon) {
             if (t.counts) atomicAdd(&t.counts[v.w], 1u);
             else if (v.z < 255u) atomicAdd(&t.slots[s].count, 1u);
             return;
         }
-        if (c == VG_EMPTY) return;
+        if (!(c & VG_SLOT_CHAIN)) return;
         s = (s + 1) & t.cap_mask;
     }
 }
@@ -366,9 +386,10 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
 // operands of every wait, so nothing that reads them can move above it.
 // ------------------------------------------------------------------------------------------
 #define VG_Q_KMER_MASK ((1ULL << 54) - 1)
-#define VG_RUNQ 72u       // run ring: 16-byte entries {bases[31:0], bases[63:32], bases[75:64] | valid12 << 12, -};
-                          // a row adds <= 64 runs and <= 4 are left over, so it cannot overflow (LDS: 128 KiB filter +
-                          // 16 waves x (72 x 16 + 64 x 8) B + 4 KiB LUT = 161 792 B of the 160 KiB = 163 840 B)
+#define VG_RUNQ 80u       // run ring: 16-byte entries {bases[31:0], bases[63:32], bases[75:64] | valid12 << 12, -};
+                          // a row adds <= 64 runs, <= 4 are left over and the kernel drains between the two rows of
+                          // a pair when needed, so it cannot overflow (LDS: 128 KiB filter + 16 waves x (80 x 16 +
+                          // 64 x 8) B + 4 KiB LUT = 163 840 B = all of the 160 KiB)
 #define VG_RUN_BATCH 5u   // runs per probe batch (60 k-mers)
 #define VG_REQ 64u        // re-queue ring: 64-bit entries (canonical k-mer | probe distance << 54)
 
@@ -377,16 +398,21 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
 // that a value lives there, so it cannot copy or spill it while the data is still in flight; naming them as
 // clobbers makes it allocate the full budget and keep its own values (about 60 VGPRs) far below.
 // tools/check_hot_vgprs.py verifies on the generated ISA that nothing else touches them.
-//   v[120:122] row prefetch     v123 atomic return (never read)     v[124:127] table slots of the batch in flight
-#define VG_HOT_CLOBBERS "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+//   v[116:118] / v[120:122] row prefetch (first / second row of a pair)     v123 atomic return (never read)
+//   v[124:127] table slots of the batch in flight
+#define VG_HOT_CLOBBERS "v116", "v117", "v118", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
 
+template <int R>   // R = 0: first row of the pair -> v[116:118], 1: second row -> v[120:122]
 __device__ __forceinline__ void vm_load_row(const uint8_t* ptr)
 {
-    asm volatile("global_load_dwordx3 v[120:122], %0, off nt ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS);
+    if (R == 0) asm volatile("global_load_dwordx3 v[116:118], %0, off nt ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS);
+    else asm volatile("global_load_dwordx3 v[120:122], %0, off nt ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS);
 }
-__device__ __forceinline__ void vm_load_slot(const VgSlot* ptr)
+template <bool COMPACT>   // compact table format: the 8-byte k-mer word only
+__device__ __forceinline__ void vm_load_slot(const void* ptr)
 {
-    asm volatile("global_load_dwordx4 v[124:127], %0, off ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS);
+    if (COMPACT) asm volatile("global_load_dwordx2 v[124:125], %0, off ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS);
+    else asm volatile("global_load_dwordx4 v[124:127], %0, off ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS);
 }
 __device__ __forceinline__ void vm_atomic_inc(uint32_t* ptr, uint32_t one)
 {
@@ -418,8 +444,15 @@ __device__ __forceinline__ void vm_wait(uint32_t n)
 }
 // rare paths: synchronous loads / fire-and-forget atomics, also by hand -- a single compiler-visible memory operation
 // in the loop makes the compiler add its own vmcnt(0) waits in the hot path
-__device__ __forceinline__ uint4 vm_load_slot_sync(const VgSlot* ptr)
+template <bool COMPACT>
+__device__ __forceinline__ uint4 vm_load_slot_sync(const void* ptr)
 {
+    if (COMPACT) {
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+        u32x2_t v;
+        asm volatile("global_load_dwordx2 %0, %1, off ; VGHOT\n\ts_waitcnt vmcnt(0) ; VGHOT" : "=&v"(v) : "v"(ptr) : "memory");
+        return make_uint4(v.x, v.y, 0u, 0u);
+    }
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
     u32x4_t v;
     asm volatile("global_load_dwordx4 %0, %1, off ; VGHOT\n\ts_waitcnt vmcnt(0) ; VGHOT" : "=&v"(v) : "v"(ptr) : "memory");
@@ -435,11 +468,19 @@ __device__ __forceinline__ void vm_atomic_or_sync(uint32_t* ptr, uint32_t bits)
 {
     asm volatile("global_atomic_or %0, %1, off ; VGHOT\n\ts_waitcnt vmcnt(0) ; VGHOT" : : "v"(ptr), "v"(bits) : "memory");
 }
+template <bool COMPACT>
 __device__ __forceinline__ uint4 vm_slot_value()   // after the wait
 {
-    uint4 v;
-    asm volatile("v_mov_b32 %0, v124 ; VGHOT\n\tv_mov_b32 %1, v125 ; VGHOT\n\tv_mov_b32 %2, v126 ; VGHOT\n\tv_mov_b32 %3, v127 ; VGHOT"
-                 : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w));
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (COMPACT) asm volatile("v_mov_b32 %0, v124 ; VGHOT\n\tv_mov_b32 %1, v125 ; VGHOT" : "=v"(v.x), "=v"(v.y));
+    else asm volatile("v_mov_b32 %0, v124 ; VGHOT\n\tv_mov_b32 %1, v125 ; VGHOT\n\tv_mov_b32 %2, v126 ; VGHOT\n\tv_mov_b32 %3, v127 ; VGHOT"
+                      : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w));
+    return v;
+}
+__device__ __forceinline__ uint32_t vm_atomic_old()   // return value of the last vm_atomic_inc, after the wait
+{
+    uint32_t v;
+    asm volatile("v_mov_b32 %0, v123 ; VGHOT" : "=v"(v));
     return v;
 }
 
@@ -466,18 +507,20 @@ __device__ __forceinline__ void stage_lut27(uint32_t tid, uint32_t nthreads)
 
 struct Addr4 { uint32_t a0, a1, a2, a3; };   // LDS byte offsets of a dword's four LUT entries (before the table offsets)
 
-// 2 * byte b of dword D of the landed row (v120 + D), one SDWA op each (the LUT holds u16)
+// 2 * byte b of dword D of landed row R (v116 + 4 R + D), one SDWA op each (the LUT holds u16)
 #define VG_SDWA_X2(REG, B) "v_lshlrev_b32_sdwa %" #B ", %4, " REG " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #B " ; VGHOT\n\t"
-template <int D>
+#define VG_SDWA_ROW(REG) asm volatile(VG_SDWA_X2(REG, 0) VG_SDWA_X2(REG, 1) VG_SDWA_X2(REG, 2) VG_SDWA_X2(REG, 3) \
+                                      : "=&v"(a.a0), "=&v"(a.a1), "=&v"(a.a2), "=&v"(a.a3) : "v"(one))
+template <int R, int D>
 __device__ __forceinline__ Addr4 lut_addr4(const uint32_t one)
 {
     Addr4 a;
-    if (D == 0) asm volatile(VG_SDWA_X2("v120", 0) VG_SDWA_X2("v120", 1) VG_SDWA_X2("v120", 2) VG_SDWA_X2("v120", 3)
-                             : "=&v"(a.a0), "=&v"(a.a1), "=&v"(a.a2), "=&v"(a.a3) : "v"(one));
-    if (D == 1) asm volatile(VG_SDWA_X2("v121", 0) VG_SDWA_X2("v121", 1) VG_SDWA_X2("v121", 2) VG_SDWA_X2("v121", 3)
-                             : "=&v"(a.a0), "=&v"(a.a1), "=&v"(a.a2), "=&v"(a.a3) : "v"(one));
-    if (D == 2) asm volatile(VG_SDWA_X2("v122", 0) VG_SDWA_X2("v122", 1) VG_SDWA_X2("v122", 2) VG_SDWA_X2("v122", 3)
-                             : "=&v"(a.a0), "=&v"(a.a1), "=&v"(a.a2), "=&v"(a.a3) : "v"(one));
+    if (R == 0 && D == 0) VG_SDWA_ROW("v116");
+    if (R == 0 && D == 1) VG_SDWA_ROW("v117");
+    if (R == 0 && D == 2) VG_SDWA_ROW("v118");
+    if (R == 1 && D == 0) VG_SDWA_ROW("v120");
+    if (R == 1 && D == 1) VG_SDWA_ROW("v121");
+    if (R == 1 && D == 2) VG_SDWA_ROW("v122");
     return a;
 }
 
@@ -522,19 +565,22 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
     __syncthreads();
     const uint32_t* g_grid = p.table.grid;
     const uint32_t gwl = LDS_BM ? VG_GRID_LDS_WORDS_LOG2 : p.table.grid_words_log2;
-    VgSlot* const slots = p.table.slots;
+    VgSlot* const slots = p.table.slots;                 // 16-byte format (global-filter variant)
+    unsigned long long* const slots8 = p.table.slots8;   // compact format (LDS-filter variant)
     uint32_t* const counts = p.table.counts;
     const uint64_t cap_mask = p.table.cap_mask;
 
-    // rows [0, row_end) are complete 768-byte rows, so every load below is an unconditional, perfectly
-    // coalesced dwordx3 (the ragged tail goes to rows_kernel, see vgmi_api.cpp)
-    const uint64_t total_rows = p.row_end;
+    // rows [0, row_end) are complete 768-byte rows (row_end is even, see vgmi_api.cpp), so every load below is an
+    // unconditional, perfectly coalesced dwordx3 (the ragged tail goes to rows_kernel).  A wave walks a
+    // contiguous range of row PAIRS: two rows per iteration give every wave two independent dependency chains
+    // (LUT reads -> permutes -> filter word), which four waves per SIMD need to keep the VALU fed.
+    const uint64_t total_pairs = p.row_end >> 1;
     const uint64_t total_waves = (uint64_t)gridDim.x * nwaves;
-    const uint64_t rpw = (total_rows + total_waves - 1) / total_waves;
+    const uint64_t ppw = (total_pairs + total_waves - 1) / total_waves;
     // the wave index is uniform: keep the row counters in SGPRs
     const uint64_t gw = (uint64_t)blockIdx.x * nwaves + wave_u;
-    const uint64_t r0v = gw * rpw;
-    const uint64_t r1v = r0v + rpw < total_rows ? r0v + rpw : total_rows;
+    const uint64_t r0v = gw * ppw;
+    const uint64_t r1v = r0v + ppw < total_pairs ? r0v + ppw : total_pairs;
     const uint64_t r0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r0v >> 32)) << 32) |
                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r0v);
     const uint64_t r1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r1v >> 32)) << 32) |
@@ -548,7 +594,7 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
     const uint32_t src1 = (lane + 63u) & 63u, src2 = (lane + 62u) & 63u, src3 = (lane + 61u) & 63u;
     // previous row's words, already rotated by 1 / 2 / 3 lanes (lanes 0..2 take them)
     uint32_t pr1_be = 0, pr2_be = 0, pr3_be = 0, pr1_inv = 0xFFFu, pr2_inv = 0xFFFu, pr3_inv = 0xFFFu;
-    // the row before the range is walked first as a warm-up iteration: it only provides the halo
+    // the pair before the range is walked first as a warm-up iteration: it only provides the halo
     const uint64_t rs = r0 > 0 ? r0 - 1 : r0;
 
     // ---- asynchronous state (see the header comment) ----
@@ -557,6 +603,8 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
     uint64_t b_canon = 0, b_slot = 0;     // per lane: canonical k-mer | probe distance << 54, slot probed
     bool b_active = false;                // per lane: takes part in the batch in flight (none at the start: the
                                           // first step "finishes" an empty batch, so the step needs no special case)
+    uint64_t p_slot = 0;                  // compact format: slot whose counter this lane bumped in the previous step
+    bool p_bumped = false;
 
     // drain bookkeeping: which run / window of a 5-run batch this lane expands.  Ring state is wave-uniform
     // (SGPR) and kept reduced mod the ring size; a lane's slot wraps with one subtract + min.
@@ -576,7 +624,7 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
         b_canon = canon | (dist << 54);
         b_slot = (vg_thash(canon) + dist) & cap_mask;
         b_active = act;
-        if (act) vm_load_slot(&slots[b_slot]);
+        if (act) vm_load_slot<LDS_BM>(LDS_BM ? (const void*)&slots8[b_slot] : (const void*)&slots[b_slot]);
         ++n_after_row;
         n_after_slot = 0;
     };
@@ -584,17 +632,27 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
     // then issue the next batch: 32+ re-queued k-mers first, else up to 5 runs
     auto drain_step = [&]() __attribute__((always_inline)) {
         vm_wait(n_after_slot);
-        const uint4 tv = vm_slot_value();
+        if (LDS_BM) {
+            // the previous step's atomics have returned (they were issued before the loads just waited for): a
+            // counter that has reached the clamp gets its slot flagged, later hits skip their atomic
+            const uint32_t old = vm_atomic_old();
+            const bool sat = p_bumped && old >= 254u;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(sat) != 0, 0)) {
+                if (sat) vm_atomic_or_sync(reinterpret_cast<uint32_t*>(&slots8[p_slot]) + 1, (uint32_t)(VG_SLOT_SAT >> 32));
+            }
+        }
+        const uint4 tv = vm_slot_value<LDS_BM>();
         bool again = false;
         uint32_t* bump = nullptr;
         if (b_active) {
             const uint64_t c = ((uint64_t)tv.y << 32) | tv.x;
             const uint64_t canon = b_canon & VG_Q_KMER_MASK;
-            if (c == canon) {
-                if (counts) bump = &counts[tv.w];                    // dense counters, clamped at read-out
+            if (c != VG_EMPTY && (c & VG_SLOT_KMER_MASK) == canon) {
+                if (LDS_BM) { if (!(c & VG_SLOT_SAT)) bump = &counts[b_slot]; }
+                else if (counts) bump = &counts[tv.w];               // dense counters, clamped at read-out
                 else if (tv.z < 255u) bump = &slots[b_slot].count;
-            } else if (c != VG_EMPTY) {
-                again = true;
+            } else if (c != VG_EMPTY && (c & VG_SLOT_CHAIN)) {
+                again = !(p.dbg & 64u);   // 64: ablation (wrong counts): collisions are dropped instead of re-queued
             }
         }
         const uint64_t ball = __builtin_amdgcn_ballot_w64(again);
@@ -614,17 +672,20 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
                 uint64_t sl = b_slot;
                 for (;;) {
                     sl = (sl + 1) & cap_mask;
-                    const uint4 v = vm_load_slot_sync(&slots[sl]);
+                    const uint4 v = vm_load_slot_sync<LDS_BM>(LDS_BM ? (const void*)&slots8[sl] : (const void*)&slots[sl]);
                     const uint64_t c = ((uint64_t)v.y << 32) | v.x;
-                    if (c == canon) {
-                        if (counts) bump = &counts[v.w];
+                    if (c != VG_EMPTY && (c & VG_SLOT_KMER_MASK) == canon) {
+                        if (LDS_BM) { if (!(c & VG_SLOT_SAT)) { bump = &counts[sl]; b_slot = sl; } }
+                        else if (counts) bump = &counts[v.w];
                         else if (v.z < 255u) bump = &slots[sl].count;
                         break;
                     }
-                    if (c == VG_EMPTY) break;
+                    if (c == VG_EMPTY || !(c & VG_SLOT_CHAIN)) break;
                 }
             }
         }
+        p_bumped = bump != nullptr;
+        p_slot = b_slot;
         if (__builtin_amdgcn_ballot_w64(bump != nullptr)) {   // wave-uniform: the atomic is issued iff some lane hit
             if (bump) vm_atomic_inc(bump, one);
             ++n_after_row;
@@ -654,90 +715,125 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
             // k-mer ending at window my_win of the run: bits [2(11 - win), +54) of the 76 run bits
             const uint32_t lo = funnel(e.y, e.x, my_sh);
             const uint32_t hi = funnel(e.z, e.y, my_sh) & MASK_HI;
-            probe_issue(have && ((e.z >> my_vbit) & 1u), ((uint64_t)hi << 32) | lo, 0);
+            // dbg 32: ablation (wrong counts): one probing lane per run instead of up to 12
+            probe_issue(have && ((e.z >> my_vbit) & 1u) && (!(p.dbg & 32u) || my_win == (__builtin_ctz(e.z >> 12) & 15u)) && (!(p.dbg & 128u) || !(my_win & 1u)), ((uint64_t)hi << 32) | lo, 0);
         }
         __builtin_amdgcn_wave_barrier();
     };
 
-    // 32-bit trip count and a scalar row pointer: the loop control stays on the SALU
-    const uint32_t n_it = (uint32_t)(r1 - rs), n_warm = (uint32_t)(r0 - rs);
-    const uint8_t* rowp = bases + rs * VG_ROW27;
-    vm_load_row(rowp + lane_off);
-    for (uint32_t it = 0; it < n_it; ++it) {
-        // the row has landed once at most n_after_row younger operations are outstanding
-        vm_wait(n_after_row);
-        const Addr4 a0 = lut_addr4<0>(one), a1 = lut_addr4<1>(one), a2 = lut_addr4<2>(one);
-        const uint8_t* const cur = rowp;
-        if (it + 1 < n_it) rowp += VG_ROW27;
-        vm_load_row(rowp + lane_off);  // prefetch (the last iteration re-reads its own row)
-        n_after_row = 0;
-        ++n_after_slot;
-
-        // own 12 bases: be = 24 bits, first base most significant; inv bit t = base t is not a base
-        const uint32_t g0 = encode4<0>(a0), g1 = encode4<1>(a1), g2 = encode4<0>(a2);
-        const uint32_t be = __builtin_amdgcn_perm(g0, __builtin_amdgcn_perm(g1, g2, 0x0c0c0400u), 0x0c040100u);
-        const uint32_t inv = ((g0 | g1) >> 8) | (g2 & 0xF00u);   // g0: bits 8..11, g1: 12..15, g2: 8..11
-        const uint32_t r1_be = __shfl(be, src1), r2_be = __shfl(be, src2), r3_be = __shfl(be, src3);
-        const uint32_t r1_inv = __shfl(inv, src1), r2_inv = __shfl(inv, src2), r3_inv = __shfl(inv, src3);
-        const uint32_t be1 = lane >= 1 ? r1_be : pr1_be;
-        const uint32_t be2 = lane >= 2 ? r2_be : pr2_be;
-        const uint32_t be3 = lane >= 3 ? r3_be : pr3_be;
-        const uint32_t i1 = lane >= 1 ? r1_inv : pr1_inv;
-        const uint32_t i2 = lane >= 2 ? r2_inv : pr2_inv;
-        const uint32_t i3 = lane >= 3 ? r3_inv : pr3_inv;
-        pr1_be = r1_be; pr2_be = r2_be; pr3_be = r3_be; pr1_inv = r1_inv; pr2_inv = r2_inv; pr3_inv = r3_inv;
-        if (it < n_warm) continue;
-
-        {   // empty-read check, see rows_kernel
-            const uint32_t adj = inv & ((inv << 1) | (i1 >> 11));
-            if (__builtin_expect(__ballot(adj != 0) != 0, 0)) {
-                if (adj) {
-                    const uint64_t base_off = (uint64_t)(cur - bases) + lane_off;
-                    for (uint32_t t = 0; t < 12; ++t) {
-                        if (!((adj >> t) & 1u)) continue;
-                        const uint64_t o = base_off + t;
-                        if (vm_load_byte_sync(bases + o) == '\n' && (o == 0 || vm_load_byte_sync(bases + o - 1) == '\n'))
-                            vm_atomic_or_sync(p.status, 1u);
-                    }
-                }
-            }
-        }
-
+    // scan of one row once its words and its neighbours' are known: window, validity, grid probe; returns the
+    // hit predicate and leaves the run entry in d0..d2
+    struct RowScan { uint32_t W0, W1, W2, vm, gm, gw32; bool ok16; };
+    auto scan_probe = [&](uint32_t be, uint32_t inv, uint32_t be1, uint32_t be2, uint32_t be3, uint32_t i1, uint32_t i2,
+                          uint32_t i3) __attribute__((always_inline)) -> RowScan {
+        RowScan r;
         // 48-base window, base q = 0..47 at bits 2(47 - q) of W2:W1:W0: q = 36..47 own chunk, 0..35 the three
         // chunks before.  This lane's grid position is g = q 35 (the last base of the previous chunk):
         //   grid 16-mer  q 20..35                       bits [24, 56)
         //   run          q  9..46 (k-mers ending at q 35..46, i.e. g .. g + 11)   bits [2, 78)
-        const uint32_t W0 = (be1 << 24) | be;
-        const uint32_t W1 = (be2 << 16) | (be1 >> 8);
-        const uint32_t W2 = (be3 << 8) | (be2 >> 16);
+        r.W0 = (be1 << 24) | be;
+        r.W1 = (be2 << 16) | (be1 >> 8);
+        r.W2 = (be3 << 8) | (be2 >> 16);
         // non-base bits.  B bit i = base q 9 + i (i = 0..26, the span of the k-mer ending at g): the k-mer
         // ending at g + j is spoilt by B iff B >> j != 0, and by the own chunk iff one of own bases 0..j-1 is
         // a non-base (prefix-OR = x | -x).
         const uint32_t B = (i3 >> 9) | (i2 << 3) | (i1 << 15);
         const uint32_t a = (inv << 1) & 0xFFFu;
         const uint32_t bad_b = B ? (0xFFFFFFFFu >> __builtin_clz(B)) : 0u;
-        const uint32_t vm = ~(a | (0u - a) | bad_b) & 0xFFFu;
-
-        const uint32_t mer = funnel(W1, W0, 24);
+        r.vm = ~(a | (0u - a) | bad_b) & 0xFFFu;
+        r.ok16 = B < 2048u;   // no non-base in q 20..35 (the 16-mer itself)
+        const uint32_t mer = funnel(r.W1, r.W0, 24);
         uint64_t gx;
-        uint32_t gm, gw32;
-        vg_grid_probe(mer, gwl, gx, gm);
-        if (LDS_BM) gw32 = *reinterpret_cast<lds_u32*>((uintptr_t)(((uint32_t)gx << 2) + VG_LUT27_BYTES));
-        else gw32 = g_grid[gx];
-        // B < 2048: no non-base in q 20..35 (the 16-mer itself)
-        const bool hit = B < 2048u && (gw32 & gm) == gm && vm != 0;
-        const uint64_t ball = __builtin_amdgcn_ballot_w64(hit);
+        vg_grid_probe(mer, gwl, gx, r.gm);
+        if (LDS_BM) r.gw32 = *reinterpret_cast<lds_u32*>((uintptr_t)(((uint32_t)gx << 2) + VG_LUT27_BYTES));
+        else r.gw32 = g_grid[gx];
+        return r;
+    };
+    auto enqueue = [&](const RowScan& r, uint64_t ball, uint32_t tail) __attribute__((always_inline)) {
         if (__builtin_amdgcn_inverse_ballot_w64(ball)) {
-            const uint32_t d0 = funnel(W1, W0, 2);
-            const uint32_t d1 = funnel(W2, W1, 2);
-            const uint32_t d2 = ((W2 >> 2) & 0xFFFu) | (vm << 12);
-            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
-                                 __builtin_amdgcn_mbcnt_lo((uint32_t)ball, run_head + run_n));
+            const uint32_t d0 = funnel(r.W1, r.W0, 2);
+            const uint32_t d1 = funnel(r.W2, r.W1, 2);
+            const uint32_t d2 = ((r.W2 >> 2) & 0xFFFu) | (r.vm << 12);
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, tail));
             *reinterpret_cast<lds_u4_rw*>((uintptr_t)(runs_base + ring_slot(pos) * 16u)) = u32x4{d0, d1, d2, 0u};
         }
-        run_n += (uint32_t)__builtin_popcountll(ball);
-        if (p.dbg & 1u) { run_n = 0; continue; }
-        while (run_n >= VG_RUN_BATCH || req_n >= 32u) drain_step();
+    };
+    auto empty_read_check = [&](uint32_t adj, const uint8_t* row) __attribute__((always_inline)) {
+        // reference: assert(len > 0), src/kmer.cpp:124 -- two adjacent non-bases are necessary; exact test on the bytes
+        if (adj) {
+            const uint64_t base_off = (uint64_t)(row - bases) + lane_off;
+            for (uint32_t t = 0; t < 12; ++t) {
+                if (!((adj >> t) & 1u)) continue;
+                const uint64_t o = base_off + t;
+                if (vm_load_byte_sync(bases + o) == '\n' && (o == 0 || vm_load_byte_sync(bases + o - 1) == '\n'))
+                    vm_atomic_or_sync(p.status, 1u);
+            }
+        }
+    };
+
+    // 32-bit trip count and a scalar row pointer: the loop control stays on the SALU
+    const uint32_t n_it = (uint32_t)(r1 - rs), n_warm = (uint32_t)(r0 - rs);
+    const uint8_t* rowp = bases + rs * (2 * VG_ROW27);
+    vm_load_row<0>(rowp + lane_off);
+    vm_load_row<1>(rowp + VG_ROW27 + lane_off);
+    for (uint32_t it = 0; it < n_it; ++it) {
+        // both rows have landed once at most n_after_row younger operations are outstanding
+        vm_wait(n_after_row);
+        const Addr4 a0 = lut_addr4<0, 0>(one), a1 = lut_addr4<0, 1>(one), a2 = lut_addr4<0, 2>(one);
+        const Addr4 c0 = lut_addr4<1, 0>(one), c1 = lut_addr4<1, 1>(one), c2 = lut_addr4<1, 2>(one);
+        const uint8_t* const cur = rowp;
+        if (it + 1 < n_it) rowp += 2 * VG_ROW27;
+        vm_load_row<0>(rowp + lane_off);            // prefetch (the last iteration re-reads its own pair)
+        vm_load_row<1>(rowp + VG_ROW27 + lane_off);
+        n_after_row = 0;
+        n_after_slot += 2;
+        // first drain point of the iteration (the second one follows the scan): steps half an iteration apart
+        // never wait for table loads that were issued a moment ago
+        if (run_n >= VG_RUN_BATCH || req_n >= 32u) drain_step();
+
+        // own 12 bases of each row: be = 24 bits, first base most significant; inv bit t = base t is not a base
+        const uint32_t g0 = encode4<0>(a0), g1 = encode4<1>(a1), g2 = encode4<0>(a2);
+        const uint32_t h0 = encode4<0>(c0), h1 = encode4<1>(c1), h2 = encode4<0>(c2);
+        const uint32_t beA = __builtin_amdgcn_perm(g0, __builtin_amdgcn_perm(g1, g2, 0x0c0c0400u), 0x0c040100u);
+        const uint32_t invA = ((g0 | g1) >> 8) | (g2 & 0xF00u);   // g0: bits 8..11, g1: 12..15, g2: 8..11
+        const uint32_t beB = __builtin_amdgcn_perm(h0, __builtin_amdgcn_perm(h1, h2, 0x0c0c0400u), 0x0c040100u);
+        const uint32_t invB = ((h0 | h1) >> 8) | (h2 & 0xF00u);
+        const uint32_t a1_be = __shfl(beA, src1), a2_be = __shfl(beA, src2), a3_be = __shfl(beA, src3);
+        const uint32_t a1_inv = __shfl(invA, src1), a2_inv = __shfl(invA, src2), a3_inv = __shfl(invA, src3);
+        const uint32_t b1_be = __shfl(beB, src1), b2_be = __shfl(beB, src2), b3_be = __shfl(beB, src3);
+        const uint32_t b1_inv = __shfl(invB, src1), b2_inv = __shfl(invB, src2), b3_inv = __shfl(invB, src3);
+        // neighbours: lanes l-1..l-3 of the same row; the first lanes take the tail of the row before (row A: second
+        // row of the previous pair, row B: row A -- the permutes wrap, so lanes 0..2 of a*_ hold exactly that tail)
+        const uint32_t beA1 = lane >= 1 ? a1_be : pr1_be, beA2 = lane >= 2 ? a2_be : pr2_be, beA3 = lane >= 3 ? a3_be : pr3_be;
+        const uint32_t iA1 = lane >= 1 ? a1_inv : pr1_inv, iA2 = lane >= 2 ? a2_inv : pr2_inv, iA3 = lane >= 3 ? a3_inv : pr3_inv;
+        const uint32_t beB1 = lane >= 1 ? b1_be : a1_be, beB2 = lane >= 2 ? b2_be : a2_be, beB3 = lane >= 3 ? b3_be : a3_be;
+        const uint32_t iB1 = lane >= 1 ? b1_inv : a1_inv, iB2 = lane >= 2 ? b2_inv : a2_inv, iB3 = lane >= 3 ? b3_inv : a3_inv;
+        pr1_be = b1_be; pr2_be = b2_be; pr3_be = b3_be; pr1_inv = b1_inv; pr2_inv = b2_inv; pr3_inv = b3_inv;
+        if (it < n_warm) continue;
+
+        {   // empty-read check (rare path)
+            const uint32_t adjA = invA & ((invA << 1) | (iA1 >> 11));
+            const uint32_t adjB = invB & ((invB << 1) | (iB1 >> 11));
+            if (__builtin_expect(__ballot((adjA | adjB) != 0) != 0, 0)) {
+                empty_read_check(adjA, cur);
+                empty_read_check(adjB, cur + VG_ROW27);
+            }
+        }
+
+        const RowScan sa = scan_probe(beA, invA, beA1, beA2, beA3, iA1, iA2, iA3);
+        const RowScan sb = scan_probe(beB, invB, beB1, beB2, beB3, iB1, iB2, iB3);
+        const uint64_t ballA = __builtin_amdgcn_ballot_w64(sa.ok16 && (sa.gw32 & sa.gm) == sa.gm && sa.vm != 0);
+        const uint64_t ballB = __builtin_amdgcn_ballot_w64(sb.ok16 && (sb.gw32 & sb.gm) == sb.gm && sb.vm != 0);
+        const uint32_t nA = (uint32_t)__builtin_popcountll(ballA), nB = (uint32_t)__builtin_popcountll(ballB);
+        if (p.dbg & 1u) continue;
+        enqueue(sa, ballA, run_head + run_n);
+        run_n += nA;
+        // the ring holds VG_RUNQ runs: make room for row B's (only rows dense in candidates ever need this)
+        while (run_n + nB > VG_RUNQ) drain_step();
+        enqueue(sb, ballB, run_head + run_n);
+        run_n += nB;
+        if (run_n >= VG_RUN_BATCH || req_n >= 32u) drain_step();
+        while (run_n >= 3 * VG_RUN_BATCH || req_n >= 48u) drain_step();   // dense stretches: keep the rings short
     }
     // flush: until the rings are empty and the last step issued nothing (finishing a batch can re-queue)
     do {
@@ -797,13 +893,12 @@ __global__ __launch_bounds__(256) void seq_kernel(RowParams p, const uint64_t* r
 // ------------------------------------------------------------------------------------------
 // table build (once per graph) and per-sample reset / read-out
 // ------------------------------------------------------------------------------------------
-__global__ void table_clear_kernel(VgSlot* slots, uint64_t cap)
+__global__ void table_clear_kernel(TableView t)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cap) {
-        uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu);
-        *reinterpret_cast<uint4*>(&slots[i]) = v;
-    }
+    if (i > t.cap_mask) return;
+    if (t.slots8) t.slots8[i] = VG_EMPTY;
+    else *reinterpret_cast<uint4*>(&t.slots[i]) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu);
 }
 
 __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t n, uint32_t k,
@@ -820,16 +915,17 @@ __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t 
     const uint64_t canon = vg_hash64_inv(key >> 8, mask);
     uint64_t s = vg_thash(canon) & t.cap_mask;
     for (;;) {
-        unsigned long long* cell = &t.slots[s].canon;
+        unsigned long long* cell = t.slots8 ? &t.slots8[s] : &t.slots[s].canon;
         const unsigned long long prev = atomicCAS(cell, (unsigned long long)VG_EMPTY, (unsigned long long)canon);
         if (prev == VG_EMPTY) break;
-        if (prev == canon) {
+        if ((prev & VG_SLOT_KMER_MASK) == canon) {
             atomicOr(status, 4u);  // duplicate key
             return;
         }
+        atomicOr(cell, (unsigned long long)VG_SLOT_CHAIN);   // this key goes past the slot: lookups must follow
         s = (s + 1) & t.cap_mask;
     }
-    t.slots[s].key_index = (uint32_t)i;
+    if (!t.slots8) t.slots[s].key_index = (uint32_t)i;
     key_slot[i] = (uint32_t)s;
     atomicOr(&filter_rw[vg_fhash_word(canon) >> t.filter_shift], vg_fhash_bits(canon, t.filter_words_log2));
     if (grid_rw) {   // k = 27 only: the 12 sixteen-mers of the k-mer (canonicalised inside vg_grid_probe, which
@@ -843,22 +939,30 @@ __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t 
     }
 }
 
-__global__ void counts_reset_kernel(VgSlot* slots, uint64_t cap)
+// per-sample reset of the table side (the counter arrays are cleared by memset): in-slot counters of the 16-byte
+// format, saturation flags of the compact one
+__global__ void counts_reset_kernel(TableView t)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cap) slots[i].count = 0;
+    if (i > t.cap_mask) return;
+    if (t.slots8) {
+        const unsigned long long c = t.slots8[i];
+        if (c != VG_EMPTY && (c & VG_SLOT_SAT)) t.slots8[i] = c & ~VG_SLOT_SAT;
+    } else {
+        t.slots[i].count = 0;
+    }
 }
 
 // K5 part 1 + K6: cov[i] = min(255, count(key i)); hist[c] += 1 for flagged keys with c != 0
-__global__ void cov_kernel(const VgSlot* slots, const uint32_t* key_slot, const uint32_t* counts, uint64_t n,
-                           const uint8_t* flag, uint8_t* cov, unsigned long long* hist)
+__global__ void cov_kernel(TableView t, const uint32_t* key_slot, uint64_t n, const uint8_t* flag, uint8_t* cov,
+                           unsigned long long* hist)
 {
     __shared__ unsigned int s_hist[256];
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_hist[i] = 0;
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t c32 = counts ? counts[i] : slots[key_slot[i]].count;
+        const uint32_t c32 = *count_cell(t, key_slot[i], (uint32_t)i);
         const uint32_t c = c32 < 255u ? c32 : 255u;
         cov[i] = (uint8_t)c;
         if (hist && c != 0 && flag && flag[i]) atomicAdd(&s_hist[c], 1u);
@@ -870,12 +974,11 @@ __global__ void cov_kernel(const VgSlot* slots, const uint32_t* key_slot, const 
 }
 
 // raw 32-bit counters <-> dense key-ordered array (all-reduce of a read-sharded sample)
-__global__ void counts_xfer_kernel(VgSlot* slots, const uint32_t* key_slot, uint32_t* dense, uint32_t* ext, uint64_t n,
-                                   bool import)
+__global__ void counts_xfer_kernel(TableView t, const uint32_t* key_slot, uint32_t* ext, uint64_t n, bool import)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        uint32_t* cell = dense ? &dense[i] : &slots[key_slot[i]].count;
+        uint32_t* cell = count_cell(t, key_slot[i], (uint32_t)i);
         if (import) *cell = ext[i];
         else ext[i] = *cell;
     }
@@ -983,9 +1086,9 @@ static uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap)
     return (uint32_t)(g < cap ? g : cap);
 }
 
-hipError_t launch_table_clear(VgSlot* slots, uint64_t cap, hipStream_t st)
+hipError_t launch_table_clear(const TableView& t, hipStream_t st)
 {
-    hipLaunchKernelGGL(table_clear_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, slots, cap);
+    hipLaunchKernelGGL(table_clear_kernel, dim3((uint32_t)((t.cap_mask + 256) / 256)), dim3(256), 0, st, t);
     return hipGetLastError();
 }
 
@@ -998,25 +1101,25 @@ hipError_t launch_table_insert(const TableView& t, const uint64_t* keys, uint64_
     return hipGetLastError();
 }
 
-hipError_t launch_counts_reset(VgSlot* slots, uint64_t cap, hipStream_t st)
+hipError_t launch_counts_reset(const TableView& t, hipStream_t st)
 {
-    hipLaunchKernelGGL(counts_reset_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, slots, cap);
+    hipLaunchKernelGGL(counts_reset_kernel, dim3((uint32_t)((t.cap_mask + 256) / 256)), dim3(256), 0, st, t);
     return hipGetLastError();
 }
 
-hipError_t launch_cov(const VgSlot* slots, const uint32_t* key_slot, const uint32_t* counts, uint64_t n, const uint8_t* flag,
-                      uint8_t* cov, unsigned long long* hist, hipStream_t st)
+hipError_t launch_cov(const TableView& t, const uint32_t* key_slot, uint64_t n, const uint8_t* flag, uint8_t* cov,
+                      unsigned long long* hist, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(cov_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, slots, key_slot, counts, n, flag, cov, hist);
+    hipLaunchKernelGGL(cov_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, t, key_slot, n, flag, cov, hist);
     return hipGetLastError();
 }
 
-hipError_t launch_counts_xfer(VgSlot* slots, const uint32_t* key_slot, uint32_t* dense, uint32_t* ext, uint64_t n, bool import,
+hipError_t launch_counts_xfer(const TableView& t, const uint32_t* key_slot, uint32_t* ext, uint64_t n, bool import,
                               hipStream_t st)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(counts_xfer_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, slots, key_slot, dense, ext, n, import);
+    hipLaunchKernelGGL(counts_xfer_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, t, key_slot, ext, n, import);
     return hipGetLastError();
 }
 
