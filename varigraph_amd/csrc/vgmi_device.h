@@ -207,11 +207,13 @@ VG_HD void vg_grid_probe(uint32_t mer16, uint32_t words_log2, uint64_t& word, ui
     mask = (1u << (y & 31u)) | (1u << ((y >> 5) & 31u)) | (1u << ((y >> 10) & 31u));
 }
 
-// slot hash of the exact table (evaluated only for filter passes)
-VG_HD uint64_t vg_thash(uint64_t canon)
+// slot hash of the exact table (evaluated only for filter passes): two 32-bit multiplies and a fold; home slots
+// are 32-bit (tables beyond 2^32 slots stay correct, linear probing just starts in the low part)
+VG_HD uint64_t vg_thash(uint64_t kmer)
 {
-    uint64_t x = canon * 0x9E3779B97F4A7C15ULL;
-    return x ^ (x >> 29);
+    uint32_t h = (uint32_t)kmer * 0x9E3779B1u + (uint32_t)(kmer >> 32) * 0x85EBCA77u;
+    h ^= h >> 15;
+    return h;
 }
 
 #endif
