@@ -591,7 +591,6 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
     const uint32_t lane_off = lane * 12u;
     const uint8_t* const bases = p.bases;
 
-    const uint32_t src1 = (lane + 63u) & 63u, src2 = (lane + 62u) & 63u, src3 = (lane + 61u) & 63u;
     // previous row's words, already rotated by 1 / 2 / 3 lanes (lanes 0..2 take them)
     uint32_t pr1_be = 0, pr2_be = 0, pr3_be = 0, pr1_inv = 0xFFFu, pr2_inv = 0xFFFu, pr3_inv = 0xFFFu;
     // the pair before the range is walked first as a warm-up iteration: it only provides the halo
@@ -798,10 +797,14 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
         const uint32_t invA = ((g0 | g1) >> 8) | (g2 & 0xF00u);   // g0: bits 8..11, g1: 12..15, g2: 8..11
         const uint32_t beB = __builtin_amdgcn_perm(h0, __builtin_amdgcn_perm(h1, h2, 0x0c0c0400u), 0x0c040100u);
         const uint32_t invB = ((h0 | h1) >> 8) | (h2 & 0xF00u);
-        const uint32_t a1_be = __shfl(beA, src1), a2_be = __shfl(beA, src2), a3_be = __shfl(beA, src3);
-        const uint32_t a1_inv = __shfl(invA, src1), a2_inv = __shfl(invA, src2), a3_inv = __shfl(invA, src3);
-        const uint32_t b1_be = __shfl(beB, src1), b2_be = __shfl(beB, src2), b3_be = __shfl(beB, src3);
-        const uint32_t b1_inv = __shfl(invB, src1), b2_inv = __shfl(invB, src2), b3_inv = __shfl(invB, src3);
+        // lane l <- lane l - 1 (wrapping) as a DPP wave rotate: a VALU move instead of an LDS-pipe ds_bpermute (the
+        // LDS pipe carries the 24 LUT reads of the pair and is the busier unit); chained for l - 2 and l - 3
+        auto ror1 = [](uint32_t v) __attribute__((always_inline)) -> uint32_t {
+            return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
+        };
+        const uint32_t a1_be = ror1(beA), a1_inv = ror1(invA), b1_be = ror1(beB), b1_inv = ror1(invB);
+        const uint32_t a2_be = ror1(a1_be), a2_inv = ror1(a1_inv), b2_be = ror1(b1_be), b2_inv = ror1(b1_inv);
+        const uint32_t a3_be = ror1(a2_be), a3_inv = ror1(a2_inv), b3_be = ror1(b2_be), b3_inv = ror1(b2_inv);
         // neighbours: lanes l-1..l-3 of the same row; the first lanes take the tail of the row before (row A: second
         // row of the previous pair, row B: row A -- the permutes wrap, so lanes 0..2 of a*_ hold exactly that tail)
         const uint32_t beA1 = lane >= 1 ? a1_be : pr1_be, beA2 = lane >= 2 ? a2_be : pr2_be, beA3 = lane >= 3 ? a3_be : pr3_be;
