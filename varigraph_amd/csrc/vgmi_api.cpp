@@ -188,14 +188,17 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     uint64_t end = h.off_filter + (4ULL << h.filter_words_log2);
     if (k == 27) {
         uint32_t b = VG_GRID_LDS_WORDS_LOG2;
+        uint64_t entry_bytes = 4;
         if (n_keys > VG_GRID_LDS_MAX_KEYS) {
-            b = ceil_log2(32 * n_keys) - 5;
+            // global variant: 64-bit entries (Bloom word + offset bits), >= 32 bits per key in all
+            b = ceil_log2(32 * n_keys) - 6;
             if (b < VG_GRID_LDS_WORDS_LOG2 + 1) b = VG_GRID_LDS_WORDS_LOG2 + 1;
-            if (b > 31) b = 31;   // vg_grid_probe draws the word index from a 32-bit product word
+            if (b > 31) b = 31;   // vg_grid_probe draws the entry index from a 32-bit product word
+            entry_bytes = 8;
         }
         h.grid_words_log2 = b;
         h.off_grid = align(end);
-        end = h.off_grid + (4ULL << b);
+        end = h.off_grid + (entry_bytes << b);
     }
     h.total_bytes = align(end);
 }
@@ -215,8 +218,10 @@ int adopt_image(vgmi_ctx* c)
     c->tv.filter_shift = 32 - h.filter_words_log2;
     c->tv.grid = h.off_grid ? reinterpret_cast<const uint32_t*>(c->d_image + h.off_grid) : nullptr;
     c->tv.grid_words_log2 = h.grid_words_log2;
-    c->fast27 = h.k == 27 && h.off_grid;                       // count27_kernel applies
-    c->fast27_lds = c->fast27 && h.grid_words_log2 == VG_GRID_LDS_WORDS_LOG2 && compact;  // filter in LDS, compact slots
+    const bool lds_grid = h.grid_words_log2 == VG_GRID_LDS_WORDS_LOG2;
+    c->fast27 = h.k == 27 && h.off_grid && lds_grid == compact;   // count27_kernel applies: LDS filter + compact
+                                                                  // slots, or global (64-bit entry) filter + 16-byte slots
+    c->fast27_lds = c->fast27 && lds_grid;
     c->d_key_slot = reinterpret_cast<uint32_t*>(c->d_image + h.off_key_slot);
     c->filter_in_lds = filter_fits_lds(h.filter_words_log2);
     HIPCHK(c, hipMalloc(&c->d_cov, h.n_keys ? h.n_keys : 1));

@@ -194,10 +194,18 @@ VG_HD uint32_t vg_revcomp16(uint32_t x)
 }
 // The filter is keyed on the CANONICAL 16-mer (min with its reverse complement): a graph k-mer and its
 // reverse complement then share their 12 entries, which halves the fill and cuts false candidates ~6x.
-VG_HD void vg_grid_probe(uint32_t mer16, uint32_t words_log2, uint64_t& word, uint32_t& mask)
+//
+// Global-memory variant (large graphs): entries are 64 bits.  The low word is the blocked Bloom word; the high
+// word holds OFFSET bits: bit (rot + b) mod 32 says "some graph k-mer has this 16-mer at offset b", where the
+// offset is counted from the k-mer's end when the 16-mer is canonical as it stands and from its start otherwise
+// (so a k-mer and its reverse complement set the same bit), and rot is 5 more hash bits.  A candidate run then
+// probes only the windows whose offset bit is set -- about half of the 12 table probes of a true run, and two
+// thirds of a false one, never leave the CU.
+VG_HD void vg_grid_probe(uint32_t mer16, uint32_t words_log2, uint64_t& word, uint32_t& mask, uint32_t& rot, bool& as_is)
 {
     const uint32_t rc = vg_revcomp16(mer16);
-    const uint32_t cm = mer16 < rc ? mer16 : rc;
+    as_is = mer16 <= rc;
+    const uint32_t cm = as_is ? mer16 : rc;
     // one 32 x 32 -> 64 multiply: word index = top bits of the LOW product word (multiplicative hashing; the top of
     // the full product would be monotonic in cm), bit choices from the low bits of the high word (the product's
     // well-mixed middle)
@@ -205,6 +213,13 @@ VG_HD void vg_grid_probe(uint32_t mer16, uint32_t words_log2, uint64_t& word, ui
     word = (uint32_t)x >> (32 - words_log2);
     const uint32_t y = (uint32_t)(x >> 32);
     mask = (1u << (y & 31u)) | (1u << ((y >> 5) & 31u)) | (1u << ((y >> 10) & 31u));
+    rot = (y >> 15) & 31u;
+}
+VG_HD void vg_grid_probe(uint32_t mer16, uint32_t words_log2, uint64_t& word, uint32_t& mask)
+{
+    uint32_t rot;
+    bool as_is;
+    vg_grid_probe(mer16, words_log2, word, mask, rot, as_is);
 }
 
 // slot hash of the exact table (evaluated only for filter passes): two 32-bit multiplies and a fold; home slots

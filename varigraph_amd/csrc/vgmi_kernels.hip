@@ -743,9 +743,19 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
         r.ok16 = B < 2048u;   // no non-base in q 20..35 (the 16-mer itself)
         const uint32_t mer = funnel(r.W1, r.W0, 24);
         uint64_t gx;
-        vg_grid_probe(mer, gwl, gx, r.gm);
-        if (LDS_BM) r.gw32 = *reinterpret_cast<lds_u32*>((uintptr_t)(((uint32_t)gx << 2) + VG_LUT27_BYTES));
-        else r.gw32 = g_grid[gx];
+        if (LDS_BM) {
+            vg_grid_probe(mer, gwl, gx, r.gm);
+            r.gw32 = *reinterpret_cast<lds_u32*>((uintptr_t)(((uint32_t)gx << 2) + VG_LUT27_BYTES));
+        } else {
+            uint32_t rot;
+            bool as_is;
+            vg_grid_probe(mer, gwl, gx, r.gm, rot, as_is);
+            const uint2 g = reinterpret_cast<const uint2*>(g_grid)[gx];
+            r.gw32 = g.x;
+            // offset bits of the 12 windows: window w has the 16-mer w bases before the k-mer's end
+            const uint32_t rr = funnel(g.y, g.y, rot);   // rotate right: bit b -> bit 0 + b
+            r.vm &= as_is ? rr : (__builtin_bitreverse32(rr) >> 20);
+        }
         return r;
     };
     auto enqueue = [&](const RowScan& r, uint64_t ball, uint32_t tail) __attribute__((always_inline)) {
@@ -933,11 +943,22 @@ __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t 
     atomicOr(&filter_rw[vg_fhash_word(canon) >> t.filter_shift], vg_fhash_bits(canon, t.filter_words_log2));
     if (grid_rw) {   // k = 27 only: the 12 sixteen-mers of the k-mer (canonicalised inside vg_grid_probe, which
                      // makes the reverse complement's twelve the same entries)
+        const bool wide = t.grid_words_log2 != VG_GRID_LDS_WORDS_LOG2;   // global variant: 64-bit entries + offset bits
         for (uint32_t off = 0; off < VG_GRID_STEP; ++off) {
             uint64_t w;
-            uint32_t m;
-            vg_grid_probe((uint32_t)(canon >> (2 * off)), t.grid_words_log2, w, m);
-            atomicOr(&grid_rw[w], m);
+            uint32_t m, rot;
+            bool as_is;
+            const uint32_t mer = (uint32_t)(canon >> (2 * off));
+            vg_grid_probe(mer, t.grid_words_log2, w, m, rot, as_is);
+            if (!wide) {
+                atomicOr(&grid_rw[w], m);
+            } else {
+                const uint32_t b = as_is ? off : 11u - off;
+                uint32_t hi = 1u << ((rot + b) & 31u);
+                if (mer == vg_revcomp16(mer)) hi |= 1u << ((rot + 11u - b) & 31u);   // palindromic 16-mer: both readings
+                atomicOr(&grid_rw[2 * w], m);
+                atomicOr(&grid_rw[2 * w + 1], hi);
+            }
         }
     }
 }
