@@ -591,15 +591,19 @@ def test_read_sharded_sample_sums_to_single_gpu_result(name):
         b.close()
 
 
-@pytest.mark.parametrize("table_mul", ["4", "2"])
-def test_every_kmer_counted_once_at_any_alignment(table_mul, monkeypatch):
+@pytest.mark.parametrize("table_mul,wide", [("8", False), ("2", False), ("2", True)])
+def test_every_kmer_counted_once_at_any_alignment(table_mul, wide, monkeypatch):
     """A 400-base sequence whose k-mers are all graph k-mers, placed at assorted stream offsets (row
     boundaries, wave-range boundaries, the last positions before the ragged tail): every k-mer must be
     counted exactly once.  Regression for (a) the flush of a wave that owns a single row while probes
     collide in the table (re-queue path; load factor 0.5 makes collisions frequent) and (b) k-mers
     ending in the last <= 11 positions of the last complete row (no grid offset left in the fast
-    kernel's rows: they belong to the generic tail launch)."""
+    kernel's rows: they belong to the generic tail launch).  Offsets straddle the 768-byte rows and the
+    1536-byte row pairs of the k = 27 kernel; `wide` forces the 16-byte slot format, which a small k = 27 graph
+    only gets through the generic kernel."""
     monkeypatch.setenv("VGMI_TABLE_MUL", table_mul)
+    if wide:
+        monkeypatch.setenv("VGMI_WIDE_SLOTS", "1")
     rng = np.random.default_rng(1)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     S = acgt[rng.integers(0, 4, size=400)].tobytes()
@@ -609,7 +613,8 @@ def test_every_kmer_counted_once_at_any_alignment(table_mul, monkeypatch):
     c = vgmi.Context(0)
     try:
         c.table_upload(uk, 27)
-        for pre in [0, 1, 5, 13, 100, 623, 624, 635, 1000, 1019, 2047, 3000, 5000]:
+        for pre in [0, 1, 5, 13, 100, 340, 366, 367, 368, 379, 623, 624, 635, 760, 767, 1000, 1019, 1130, 1135, 1136,
+                    1147, 1500, 1535, 1536, 2047, 3000, 5000]:
             for post in [0, 3000]:
                 filler = (b"N" * pre + b"\n") if pre else b""
                 tail = (b"N" * post + b"\n") if post else b""

@@ -267,7 +267,6 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
     if (n_bytes == 0) return VGMI_OK;
     const uint32_t k = c->hdr.k;
     RowParams p = row_params(c, d_bases, n_bytes, k);
-    if (getenv("VGMI_TRACE")) fprintf(stderr, "[vgmi] launch_count k=%u slots=%p slots8=%p counts=%p cap_mask=%llx filter=%p n_bytes=%zu off=%p n_reads=%zu\n", k, (void*)p.table.slots, (void*)p.table.slots8, (void*)p.table.counts, (unsigned long long)p.table.cap_mask, (const void*)p.table.filter, n_bytes, (const void*)d_read_off, n_reads);
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     if (!e0 || !e1) return fail(c, VGMI_E_HIP, "hipEventCreate failed");
     HIPCHK(c, hipEventRecord(e0, st));

@@ -40,7 +40,8 @@ struct RowParams {
     uint64_t emit_from;   // rows_kernel<COUNT>: only k-mers ENDING at stream position >= emit_from are counted (the
                           // fast kernel covers the ends up to its last grid offset)
     uint32_t k;
-    uint32_t dbg;         // tuning experiments only (VGMI_DBG): 1 = drop queued k-mers unprobed, 2 = skip compaction
+    uint32_t dbg;         // ablations of count27_kernel only (VGMI_DBG; counts are wrong with any of them): 1 = scan
+                          // only (candidate runs dropped), 32 = one probing lane per run, 64 = collisions dropped
     uint32_t* status;     // bit0 empty read, bit1 bad key, bit2 duplicate key
     TableView table;      // MODE_COUNT
     uint64_t* keys_out;   // MODE_KEYS

@@ -715,7 +715,8 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
             const uint32_t lo = funnel(e.y, e.x, my_sh);
             const uint32_t hi = funnel(e.z, e.y, my_sh) & MASK_HI;
             // dbg 32: ablation (wrong counts): one probing lane per run instead of up to 12
-            probe_issue(have && ((e.z >> my_vbit) & 1u) && (!(p.dbg & 32u) || my_win == (__builtin_ctz(e.z >> 12) & 15u)) && (!(p.dbg & 128u) || !(my_win & 1u)), ((uint64_t)hi << 32) | lo, 0);
+            probe_issue(have && ((e.z >> my_vbit) & 1u) && (!(p.dbg & 32u) || my_win == (__builtin_ctz(e.z >> 12) & 15u)),
+                        ((uint64_t)hi << 32) | lo, 0);
         }
         __builtin_amdgcn_wave_barrier();
     };
