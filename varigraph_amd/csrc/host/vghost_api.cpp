@@ -8,11 +8,16 @@
 
 #include "fastq_kmer_hip.hpp"
 #include "fastx_reader.hpp"
+#include "genotyper.hpp"
 #include "graph_index.hpp"
 #include "make_mbf.hpp"
 
 struct vgh_graph {
     vgh::GraphIndex g;
+};
+struct vgh_genotyper {
+    vgh::Genotyper gt;
+    explicit vgh_genotyper(const vgh::GraphIndex& g) : gt(g) {}
 };
 
 static thread_local std::string g_err;
@@ -172,6 +177,81 @@ int vgh_sample_count(const vgh_graph* h, vgmi_ctx* ctx, const char* const* fastq
         const std::string m = e.what();
         return m.find("empty read") != std::string::npos || m.find("zero-length") != std::string::npos ? VGMI_E_EMPTY_READ
                                                                                                        : VGMI_E_INVALID;
+    }
+}
+
+int vgh_coverage_stats(const uint64_t hist[256], uint64_t read_base, uint64_t genome_size, uint32_t sample_ploidy,
+                       int use_depth, vgh_sample_stats* stats)
+{
+    if (!hist || !stats) return VGMI_E_INVALID;
+    vgh::CoverageStats cs;
+    const bool ok = vgh::coverage_stats(hist, read_base, genome_size, sample_ploidy, use_depth != 0, cs);
+    stats->read_base = read_base;
+    stats->read_depth = cs.read_depth;
+    stats->hap_kmer_coverage = cs.hap_kmer_coverage;
+    stats->max_coverage = cs.max_coverage;
+    stats->hom_coverage = cs.hom_coverage;
+    if (!ok) {
+        g_err = "Failed to retrieve depth information of k-mers from the sequencing data. Please verify your data.";
+        return VGMI_E_STATE;
+    }
+    return VGMI_OK;
+}
+
+void vgh_genotype_config_default(vgh_genotype_config* cfg)
+{
+    if (!cfg) return;
+    const vgh::GenotypeConfig d;
+    cfg->sample_type = "het";
+    cfg->sample_ploidy = d.sample_ploidy;
+    cfg->haploid_num = d.haploid_num;
+    cfg->chr_len_thread = d.chr_len_thread;
+    cfg->transition = "rec";
+    cfg->sv_only = d.sv_only;
+    cfg->threads = d.threads;
+    cfg->min_gq = d.min_gq;
+}
+
+int vgh_genotyper_create(const vgh_graph* g, vgh_genotyper** out)
+{
+    if (!g || !out) return VGMI_E_INVALID;
+    *out = nullptr;
+    try {
+        *out = new vgh_genotyper(g->g);
+        return VGMI_OK;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return VGMI_E_INVALID;
+    }
+}
+
+void vgh_genotyper_free(vgh_genotyper* gt) { delete gt; }
+
+int vgh_genotype(vgh_genotyper* gt, const uint8_t* cov, float hap_kmer_coverage, const char* sample_name,
+                 const vgh_genotype_config* cfg, char** vcf_text_out, size_t* n_bytes_out)
+{
+    if (!gt || !cov || !sample_name || !cfg || !vcf_text_out || !n_bytes_out) return VGMI_E_INVALID;
+    try {
+        vgh::GenotypeConfig c;
+        if (cfg->sample_type) c.sample_type = cfg->sample_type;
+        c.sample_ploidy = cfg->sample_ploidy;
+        c.haploid_num = cfg->haploid_num;
+        c.chr_len_thread = cfg->chr_len_thread;
+        if (cfg->transition) c.transition = cfg->transition;
+        c.sv_only = cfg->sv_only != 0;
+        c.threads = cfg->threads ? cfg->threads : 1;
+        c.min_gq = cfg->min_gq;
+        const std::string text = gt->gt.run(cov, hap_kmer_coverage, sample_name, c);
+        char* buf = static_cast<char*>(malloc(text.size() + 1));
+        if (!buf) return VGMI_E_NOMEM;
+        memcpy(buf, text.data(), text.size());
+        buf[text.size()] = 0;
+        *vcf_text_out = buf;
+        *n_bytes_out = text.size();
+        return VGMI_OK;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return VGMI_E_INVALID;
     }
 }
 

@@ -24,6 +24,12 @@ class SampleStats(C.Structure):
                 ("seconds_total", C.c_double), ("seconds_kernel", C.c_double)]
 
 
+class GenotypeConfig(C.Structure):
+    _fields_ = [("sample_type", C.c_char_p), ("sample_ploidy", C.c_uint32), ("haploid_num", C.c_uint32),
+                ("chr_len_thread", C.c_uint32), ("transition", C.c_char_p), ("sv_only", C.c_int), ("threads", C.c_uint32),
+                ("min_gq", C.c_float)]
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -54,6 +60,13 @@ def lib():
     l.vgh_make_mbf.restype = C.c_int
     l.vgh_make_mbf.argtypes = [vp, C.c_char_p, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64),
                                C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    l.vgh_coverage_stats.restype = C.c_int
+    l.vgh_coverage_stats.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(SampleStats)]
+    l.vgh_genotype_config_default.restype = None; l.vgh_genotype_config_default.argtypes = [C.POINTER(GenotypeConfig)]
+    l.vgh_genotyper_create.restype = C.c_int; l.vgh_genotyper_create.argtypes = [vp, C.POINTER(vp)]
+    l.vgh_genotyper_free.restype = None; l.vgh_genotyper_free.argtypes = [vp]
+    l.vgh_genotype.restype = C.c_int
+    l.vgh_genotype.argtypes = [vp, vp, C.c_float, C.c_char_p, C.POINTER(GenotypeConfig), C.POINTER(vp), C.POINTER(C.c_size_t)]
     _lib = l
     return l
 
@@ -128,6 +141,62 @@ class Graph:
             raise vgmi.VgmiError(rc, self._l.vgh_last_error().decode())
         stats = {f[0]: getattr(st, f[0]) for f in SampleStats._fields_}
         return cov, cov_node, hist, stats
+
+
+def coverage_stats(hist, read_base, genome_size, sample_ploidy=2, use_depth=False):
+    """ReadDepth_ / hapKmerCoverage_ / peaks from a masked coverage histogram (host arithmetic of the reference)."""
+    hist = np.ascontiguousarray(hist, dtype=np.uint64)
+    st = SampleStats()
+    rc = lib().vgh_coverage_stats(hist.ctypes.data_as(C.c_void_p), int(read_base), int(genome_size), sample_ploidy,
+                                  1 if use_depth else 0, C.byref(st))
+    if rc:
+        raise RuntimeError(lib().vgh_last_error().decode())
+    return {f[0]: getattr(st, f[0]) for f in SampleStats._fields_}
+
+
+class Genotyper:
+    """Host HMM of `genotype` (include/vghost.h): keeps the per-node k-mer lists across samples like the reference."""
+
+    def __init__(self, graph):
+        self._l = lib()
+        self._graph = graph   # keeps the C++ graph alive
+        h = C.c_void_p()
+        rc = self._l.vgh_genotyper_create(graph._h, C.byref(h))
+        if rc:
+            raise RuntimeError(self._l.vgh_last_error().decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.vgh_genotyper_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, cov, hap_kmer_coverage, sample_name, sample_type="het", sample_ploidy=2, haploid_num=15,
+            granularity_bp=1000000, transition="rec", sv_only=False, threads=4, min_gq=0.0):
+        """cov: c per key in graph.bin record order.  Returns the VCF text (bytes)."""
+        cov = np.ascontiguousarray(cov, dtype=np.uint8)
+        assert cov.size == self._graph.info["n_keys"]
+        cfg = GenotypeConfig()
+        self._l.vgh_genotype_config_default(C.byref(cfg))
+        st, tr = sample_type.encode(), transition.encode()
+        cfg.sample_type, cfg.transition = st, tr
+        cfg.sample_ploidy, cfg.haploid_num, cfg.chr_len_thread = sample_ploidy, haploid_num, granularity_bp
+        cfg.sv_only, cfg.threads, cfg.min_gq = int(sv_only), threads, min_gq
+        out, n = C.c_void_p(), C.c_size_t()
+        rc = self._l.vgh_genotype(self._h, cov.ctypes.data_as(C.c_void_p), C.c_float(hap_kmer_coverage),
+                                  sample_name.encode(), C.byref(cfg), C.byref(out), C.byref(n))
+        if rc:
+            raise RuntimeError(self._l.vgh_last_error().decode())
+        try:
+            return C.string_at(out, n.value)
+        finally:
+            self._l.vgh_free(out)
 
 
 def load_graph(path):
