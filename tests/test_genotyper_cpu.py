@@ -25,6 +25,11 @@ CASES = [
     ("cohort_sv", "hom", {"sample_type": "hom"}, False),
     ("cohort_sv", "use_depth", {}, True),
     ("cohort_sv", "n5", {"haploid_num": 5}, False),
+    ("cohort_sv", "fre", {"transition": "fre"}, False),
+    ("cohort_sv", "sv", {"sv_only": True}, False),
+    ("cohort_sv", "minsupport", {"min_gq": 30.0}, False),
+    ("cohort_sv", "gran", {"granularity_bp": 20000}, False),
+    ("cohort_snp", "fre_n5", {"transition": "fre", "haploid_num": 5}, False),
     ("cohort_k22", "het", {}, False),
     ("cohort_tetra", "p4_use_depth", {"sample_ploidy": 4}, True),
 ]
@@ -65,10 +70,33 @@ def test_native_hmm_reproduces_reference_vcf(cohort, mode, kw, use_depth, monkey
         gt.close()
     finally:
         g.close()
-    assert got.count(b"\n") > 20
+    assert got.count(b"\n") > 10
     assert _strip_gq(got) == _strip_gq(want)
     # GQ too, where this host's libm agrees with the build container's (it does on the same CPU family)
     if got != want:
         gq = lambda v: [ln.split(b"\t")[9].split(b":")[1] for ln in v.split(b"\n") if ln and not ln.startswith(b"#")]
         diff = [(x, y) for x, y in zip(gq(got), gq(want)) if x != y]
         assert all(abs(float(x) - float(y)) <= 0.11 for x, y in diff), diff[:5]
+
+
+def test_pruned_node_lists_persist_across_samples(monkeypatch):
+    """`-n 5` with two samples in one run: the forward pass prunes every node's k-mer list to the k-mers of the
+    selected haplotypes and the reference never restores it, so sample 1 is genotyped on sample 0's pruned lists.
+    One Genotyper object, two runs, against the reference's two VCFs."""
+    monkeypatch.setenv("VGH_RANDOM_DEVICE_VALUE", "20241022")
+    co = get_cohort("cohort_snp")
+    d = os.path.join(GOLDEN, "cohort_snp")
+    g = host.Graph(os.path.join(d, "graph.bin.gz"))
+    try:
+        a = g.arrays()
+        cov = co.ref_c_in_graph_order()
+        hist = np.bincount(cov[(a["hom_flag"] != 0) & (cov != 0)], minlength=256).astype(np.uint64)
+        st = host.coverage_stats(hist, co.ref_read_base, g.info["genome_size"])
+        gt = host.Genotyper(g)
+        for s in (0, 1):
+            got = gt.run(cov, st["hap_kmer_coverage"], f"sample{s}", haploid_num=5, threads=4)
+            want = open(os.path.join(d, f"expected_two_n5_s{s}.vcf"), "rb").read()
+            assert _strip_gq(got) == _strip_gq(want), s
+        gt.close()
+    finally:
+        g.close()
