@@ -79,3 +79,68 @@ def test_integration_binary_fails_loudly_on_bad_input(tmp_path):
     r = subprocess.run([BIN, "genotype", "--load-graph", str(tmp_path / "nope.bin"), "-s", "nope.cfg"],
                        cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode != 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The native CLI (varigraph_amd/bin/varigraph-mi: own graph.bin reader, device counting, own host HMM and VCF writer;
+# no reference code in the binary).  VGH_RANDOM_DEVICE_VALUE pins the haplotype sampler's seed source the way the
+# deterministic reference build pins std::random_device.
+CLI = os.path.join(ROOT, "varigraph_amd", "bin", "varigraph-mi")
+NATIVE_CASES = CASES + [
+    ("cohort_sv", "fre", ["-m", "fre"]), ("cohort_sv", "sv", ["--sv"]), ("cohort_sv", "minsupport", ["--min-support", "30"]),
+    ("cohort_sv", "gran", ["--granularity", "0.02"]), ("cohort_snp", "fre_n5", ["-m", "fre", "-n", "5"]),
+]
+
+
+@pytest.mark.parametrize("cohort,mode,extra", NATIVE_CASES, ids=[f"{c}-{m}" for c, m, _ in NATIVE_CASES])
+def test_native_cli_vcf_identical_to_reference(cohort, mode, extra, tmp_path):
+    if not os.path.exists(CLI):
+        pytest.skip("varigraph-mi not built (python -m varigraph_amd.build)")
+    d = os.path.join(GOLDEN, cohort)
+    graph = tmp_path / "graph.bin"
+    graph.write_bytes(gzip.open(os.path.join(d, "graph.bin.gz"), "rb").read())
+    fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
+    (tmp_path / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
+    env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+    r = subprocess.run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4", "--gpu", "0",
+                        "--buffer", "8"] + extra, cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = gzip.open(tmp_path / "sample0.varigraph.vcf.gz", "rb").read()
+    # (1) equal to the committed fixture from the build container in everything but GQ
+    want = open(os.path.join(d, f"expected_{mode}.vcf"), "rb").read()
+    assert _strip_gq(got) == _strip_gq(want)
+    # (2) byte-identical to the all-CPU reference on this host, where that binary travelled
+    if os.path.exists(REF):
+        cpu = tmp_path / "cpu"
+        cpu.mkdir()
+        (cpu / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
+        r2 = subprocess.run([REF, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4"] + extra,
+                            cwd=cpu, capture_output=True, text=True)
+        assert r2.returncode == 0, r2.stderr[-2000:]
+        assert got == gzip.open(cpu / "sample0.varigraph.vcf.gz", "rb").read()
+
+
+def test_native_cli_two_samples_and_errors(tmp_path):
+    if not os.path.exists(CLI):
+        pytest.skip("varigraph-mi not built")
+    d = os.path.join(GOLDEN, "cohort_snp")
+    graph = tmp_path / "graph.bin"
+    graph.write_bytes(gzip.open(os.path.join(d, "graph.bin.gz"), "rb").read())
+    fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
+    (tmp_path / "samples.cfg").write_text("".join(f"sample{s} " + " ".join(fq) + "\n" for s in (0, 1)))
+    env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+    r = subprocess.run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4", "-n", "5"], cwd=tmp_path,
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for s in (0, 1):
+        got = gzip.open(tmp_path / f"sample{s}.varigraph.vcf.gz", "rb").read()
+        want = open(os.path.join(d, f"expected_two_n5_s{s}.vcf"), "rb").read()
+        assert _strip_gq(got) == _strip_gq(want)
+    # loud failures: missing graph, missing read file, bad option value
+    assert subprocess.run([CLI, "genotype", "--load-graph", str(tmp_path / "nope.bin"), "-s", "samples.cfg"], cwd=tmp_path,
+                          capture_output=True).returncode != 0
+    (tmp_path / "bad.cfg").write_text("s0 /nonexistent_1.fq.gz\n")
+    assert subprocess.run([CLI, "genotype", "--load-graph", str(graph), "-s", "bad.cfg"], cwd=tmp_path,
+                          capture_output=True).returncode != 0
+    assert subprocess.run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-g", "maybe"], cwd=tmp_path,
+                          capture_output=True).returncode != 0

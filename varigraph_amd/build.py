@@ -67,6 +67,25 @@ def build_host(force=False, verbose=False):
     return HOSTLIB
 
 
+CLI = os.path.join(os.path.dirname(LIB), "bin", "varigraph-mi")
+
+
+def build_cli(force=False, verbose=False):
+    """`varigraph-mi genotype`: the reference's genotype sub-command on this build (csrc/host/main_genotype.cpp)."""
+    src = os.path.join(CSRC, "host", "main_genotype.cpp")
+    if not os.path.exists(src):
+        return None
+    if not force and not _newer(CLI, [src, HOSTLIB, LIB]):
+        return CLI
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    cmd = ["g++", "-O3", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", CLI,
+           "-L", os.path.dirname(LIB), "-lvghost", "-lvgmi", "-Wl,-rpath,$ORIGIN/..", "-lz", "-lpthread"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=ROOT)
+    return CLI
+
+
 def build_oracle(force=False, with_ref=None):
     """Compile the checker. Building it is not using it (only tests/smoke/cpu_baseline call it)."""
     args = ["make", "-s", "-C", ORACLE_DIR, "all"]
@@ -83,6 +102,7 @@ def build_oracle(force=False, with_ref=None):
 def build_all(force=False, verbose=False):
     build_vgmi(force, verbose)
     build_host(force, verbose)
+    build_cli(force, verbose)
     build_oracle(force)
 
 

@@ -1,0 +1,194 @@
+// main_genotype.cpp -- `varigraph-mi genotype`: the reference's `varigraph genotype` sub-command (main.cpp:238-408,
+// src/varigraph.cpp:104-243) on the MI355X build: graph.bin -> device table, FASTQ -> device k-mer counting, host HMM,
+// <sample>.varigraph.vcf.gz in the working directory.  Same options (plus --gpu / --buffer as main.cu:99-100,302-303),
+// same output naming, print-and-exit error behaviour.
+#include <getopt.h>
+#include <zlib.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <filesystem>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "fastq_kmer_hip.hpp"
+#include "genotyper.hpp"
+#include "graph_index.hpp"
+#include "vgmi.h"
+
+namespace {
+
+struct Options {
+    std::string graph = "graph.bin", samples;
+    vgh::GenotypeConfig hmm;
+    bool use_depth = false;
+    int gpu = 0;
+    int buffer_mib = 100;   // main.cu default
+};
+
+void usage(const char* argv0)
+{
+    std::cerr << "Usage: " << argv0 << " genotype --load-graph FILE -s FILE [options]\n"
+              << "Perform genotyping based on k-mer counting (MI355X build).\n\n"
+              << "    --load-graph    FILE   Genome Graph index written by `varigraph construct` [graph.bin]\n"
+              << "    -s, --sample    FILE   samples configuration: sample read1.fq.gz [read2.fq.gz ...] per line\n"
+              << "    -g, --genotype  STR    sample genome status, hom/het [het]\n"
+              << "    --sample-ploidy INT    sample ploidy, 2-8 [2]\n"
+              << "    -n, --number    INT    haploids used for genotyping [15]\n"
+              << "    --granularity   FLOAT  chromosome granularity in Mb [1]\n"
+              << "    -m, --mode      STR    transition probabilities, fre/rec [rec]\n"
+              << "    --sv                   structural variants only\n"
+              << "    --min-support   FLOAT  minimum site quality (GQ) [0]\n"
+              << "    --use-depth            use the sequencing depth as the depth of homozygous k-mers\n"
+              << "    --gpu           INT    device ordinal [0]\n"
+              << "    --buffer        INT    staging buffer in MiB [100]\n"
+              << "    -t, --threads   INT    host threads [10]\n";
+}
+
+[[noreturn]] void die(const std::string& msg)
+{
+    std::cerr << "[varigraph-mi] " << msg << std::endl;
+    std::exit(1);
+}
+
+// Varigraph::parse_sample_config (src/varigraph.cpp:104-146)
+std::vector<std::tuple<std::string, std::vector<std::string>>> parse_samples(const std::string& path)
+{
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) die("'" + path + "': No such file or directory.");
+    std::string all;
+    char buf[1 << 16];
+    int n;
+    while ((n = gzread(f, buf, sizeof buf)) > 0) all.append(buf, n);
+    gzclose(f);
+    std::vector<std::tuple<std::string, std::vector<std::string>>> out;
+    std::istringstream in(all);
+    std::string line;
+    while (std::getline(in, line)) {
+        if (line.empty()) continue;
+        std::istringstream iss(line);
+        std::vector<std::string> tok;
+        for (std::string t; iss >> t;) tok.push_back(t);
+        if (tok.empty()) continue;
+        if (tok.size() <= 1) die("Error: The samples configuration file is missing sequencing file information (" + line + ").");
+        std::vector<std::string> files;
+        for (size_t i = 1; i < tok.size(); i++) {
+            std::error_code ec;
+            if (std::filesystem::exists(tok[i], ec) && std::filesystem::file_size(tok[i], ec) > 0) files.push_back(tok[i]);
+            else die("Error: File '" + tok[i] + "' does not exist or is empty.");
+        }
+        out.emplace_back(tok[0], files);
+    }
+    return out;
+}
+
+int main_genotype(int argc, char** argv)
+{
+    Options o;
+    static const struct option long_options[] = {
+        {"load-graph", required_argument, 0, 1},   {"sample", required_argument, 0, 's'},
+        {"genotype", required_argument, 0, 'g'},   {"sample-ploidy", required_argument, 0, 2},
+        {"number", required_argument, 0, 'n'},     {"granularity", required_argument, 0, 3},
+        {"mode", required_argument, 0, 'm'},       {"sv", no_argument, 0, 4},
+        {"min-support", required_argument, 0, 5},  {"use-depth", no_argument, 0, 6},
+        {"gpu", required_argument, 0, 7},          {"buffer", required_argument, 0, 8},
+        {"threads", required_argument, 0, 't'},    {"help", no_argument, 0, 'h'},
+        {0, 0, 0, 0}};
+    for (;;) {
+        int idx = 0;
+        const int c = getopt_long(argc, argv, "s:g:n:m:t:h", long_options, &idx);
+        if (c == -1) break;
+        switch (c) {
+        case 1: o.graph = optarg; break;
+        case 's': o.samples = optarg; break;
+        case 'g': o.hmm.sample_type = optarg; break;
+        case 2: o.hmm.sample_ploidy = std::max(std::stoi(optarg), 2); break;
+        case 'n': o.hmm.haploid_num = (uint32_t)std::stoull(optarg); break;
+        case 3: o.hmm.chr_len_thread = std::stof(optarg) * 1e6; break;
+        case 'm': o.hmm.transition = optarg; break;
+        case 4: o.hmm.sv_only = true; break;
+        case 5: o.hmm.min_gq = std::stof(optarg); break;
+        case 6: o.use_depth = true; break;
+        case 7: o.gpu = std::stoi(optarg); break;
+        case 8: o.buffer_mib = std::stoi(optarg); break;
+        case 't': o.hmm.threads = std::max(std::stoi(optarg), 1); break;
+        default: usage(argv[0]); return 1;
+        }
+    }
+    if (o.graph.empty()) die("Parameter error: --load-graph. The genome graph file cannot be empty.");
+    if (o.samples.empty()) die("Parameter error: -s. The sample configuration file cannot be empty.");
+    if (o.hmm.sample_type != "hom" && o.hmm.sample_type != "het") die("Parameter error: -g. The provided value must be either 'hom' or 'het'.");
+    if (o.hmm.sample_ploidy == 0 || o.hmm.sample_ploidy > 8) die("Parameter error: --sample-ploidy. The provided value must be between 2 and 8 (inclusive).");
+    if (o.hmm.haploid_num == 0) die("Parameter error: -n. The provided value must be greater than 0.");
+    if (o.hmm.chr_len_thread < 1) die("Parameter error: --granularity. The chromosome granularity must be greater than 1.");
+    if (o.hmm.transition != "fre" && o.hmm.transition != "rec") die("Parameter error: -m. The transition probability type must be either 'fre' or 'rec'.");
+    if (o.buffer_mib < 1) die("Parameter error: --buffer. The buffer size must be at least 1 MiB.");
+
+    const auto t0 = std::chrono::steady_clock::now();
+    auto secs = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+
+    vgmi_ctx* ctx = nullptr;
+    if (vgmi_create(o.gpu, (size_t)o.buffer_mib, &ctx) != VGMI_OK) die(std::string("device ") + std::to_string(o.gpu) + ": " + vgmi_last_error(nullptr));
+    const auto samples = parse_samples(o.samples);
+    std::cerr << "[varigraph-mi] samples: " << samples.size() << ", graph: " << o.graph << std::endl;
+
+    vgh::GraphIndex g;
+    try {
+        g.load(o.graph);
+    } catch (const std::exception& e) {
+        die(e.what());
+    }
+    if (g.upload(ctx) != VGMI_OK) die(vgmi_last_error(ctx));
+    std::cerr << "[varigraph-mi] graph loaded: " << g.keys.size() << " k-mers, k = " << g.k << ", " << g.hap_names.size()
+              << " haplotypes (" << secs() << " s)" << std::endl;
+
+    try {
+        vgh::Genotyper genotyper(g);
+        std::vector<uint8_t> cov(g.keys.size());
+        for (const auto& [name, files] : samples) {   // Varigraph::fastq_genotype (src/varigraph.cpp:148-171)
+            const double ts = secs();
+            vgh::FastqKmerHip fk(ctx, files, g.k, o.hmm.threads);
+            fk.build_fastq_index();
+            uint64_t hist[256];
+            fk.fetch(cov.data(), nullptr, hist);
+            vgh::CoverageStats cs;
+            if (!vgh::coverage_stats(hist, fk.mReadBase, g.genome_size, o.hmm.sample_ploidy, o.use_depth, cs))
+                die("Failed to retrieve depth information of k-mers from the sequencing data. Please verify your data.");
+            const double tc = secs();
+            std::fprintf(stderr, "[varigraph-mi] %s: %.2f Gb sequenced, depth %.2f, haplotype k-mer coverage %.2f; counting %.2f s (kernel %.3f s)\n",
+                         name.c_str(), fk.mReadBase / 1e9, cs.read_depth, cs.hap_kmer_coverage, tc - ts, fk.kernel_seconds());
+            const std::string vcf = genotyper.run(cov.data(), cs.hap_kmer_coverage, name, o.hmm);
+            vgh::Genotyper::write_gz(name + ".varigraph.vcf.gz", vcf);
+            std::fprintf(stderr, "[varigraph-mi] %s: genotyping %.2f s -> %s.varigraph.vcf.gz\n", name.c_str(), secs() - tc, name.c_str());
+        }
+    } catch (const std::exception& e) {
+        die(e.what());
+    }
+    vgmi_destroy(ctx);
+    std::fprintf(stderr, "[varigraph-mi] done in %.2f s\n", secs());
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    if (argc < 2 || std::string(argv[1]) == "-h" || std::string(argv[1]) == "--help") {
+        usage(argv[0]);
+        return 1;
+    }
+    const std::string cmd = argv[1];
+    if (cmd == "genotype") {
+        if (argc < 3) {
+            usage(argv[0]);
+            return 1;
+        }
+        return main_genotype(argc - 1, argv + 1);
+    }
+    std::cerr << "Error: '" << cmd << "' is not a sub-command of this build (genotype).\n";
+    return 1;
+}
