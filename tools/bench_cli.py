@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """CLI-level wall time (SURVEY 8d metric level iii, for information): BASELINE.json config 1
-(1 Mb graph, 100 k pairs 2x150 bp) through `genotype` of (a) the all-CPU reference and (b) the
-integration build whose read counting runs on the MI355X; the two VCFs must be identical."""
+(1 Mb graph, 100 k pairs 2x150 bp) through `genotype` of (a) the all-CPU reference, (b) the
+integration build (reference code, read counting on the MI355X) and (c) the native CLI varigraph-mi (no
+reference code); the VCFs must be identical."""
 import gzip
 import json
 import os
@@ -32,19 +33,26 @@ def main():
         with open(graph, "wb") as f:
             f.write(gzip.open(os.path.join(ROOT, "tests", "golden", "c1", "graph.bin.gz"), "rb").read())
         vcfs = {}
-        for name, exe, extra in (("reference_cpu", "varigraph_det", []), ("integration_hip", "varigraph_hip", ["--gpu", "0"])):
+        exes = (("reference_cpu", os.path.join(ROOT, "oracle", "_ref", "varigraph_det"), []),
+                ("integration_hip", os.path.join(ROOT, "oracle", "_ref", "varigraph_hip"), ["--gpu", "0"]),
+                ("native_cli", os.path.join(ROOT, "varigraph_amd", "bin", "varigraph-mi"), ["--gpu", "0"]))
+        env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+        for name, exe, extra in exes:
+            if not os.path.exists(exe):
+                continue
             d = os.path.join(work, name)
             os.makedirs(d)
             open(os.path.join(d, "samples.cfg"), "w").write("sample0 " + " ".join(fq) + "\n")
             t0 = time.perf_counter()
-            r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", exe), "genotype", "--load-graph", graph, "-s",
-                                "samples.cfg", "-t", "10"] + extra, cwd=d, capture_output=True, text=True)
+            r = subprocess.run([exe, "genotype", "--load-graph", graph, "-s", "samples.cfg", "-t", "10"] + extra, cwd=d,
+                               capture_output=True, text=True, env=env)
             out[name + "_wall_s"] = time.perf_counter() - t0
             if r.returncode != 0:
                 out[name + "_error"] = r.stderr[-300:]
                 continue
             vcfs[name] = gzip.open(os.path.join(d, "sample0.varigraph.vcf.gz"), "rb").read()
-        out["vcf_identical"] = len(vcfs) == 2 and vcfs["reference_cpu"] == vcfs["integration_hip"]
+        out["vcf_identical"] = len(vcfs) >= 2 and all(v == vcfs["reference_cpu"] for v in vcfs.values())
+        out["binaries"] = sorted(vcfs)
         out["vcf_records"] = vcfs.get("reference_cpu", b"").count(b"\n")
     finally:
         shutil.rmtree(work, ignore_errors=True)

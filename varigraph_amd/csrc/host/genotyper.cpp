@@ -614,25 +614,51 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
         }
         return false;
     };
-    // emission score of every genotype of a node (observable_states, :960-1000)
+    // emission score of every genotype of a node (observable_states, :960-1000).  poisson(ave * h, c) and
+    // geometric(p, c) are pure functions of (h, c) within a sample: evaluated once each (the values, and therefore
+    // the products, are the reference's bit for bit)
+    const float ave = r.hap_cov;
+    double score_lo = 256.0f, score_up = -0.1f;
+    poisson_interval(ave, score_lo, score_up);
+    std::vector<long double> pois_tab(256 * 256);
+    std::vector<uint8_t> pois_have(256 * 256, 0);
+    long double geo_tab[256];
+    bool geo_have[256] = {false};
     auto score_combos = [&](std::vector<Combo>& combos) {
-        const float ave = r.hap_cov;
-        double lo = 256.0f, up = -0.1f;
-        poisson_interval(ave, lo, up);
         for (auto& combo : combos) {
             long double& res = combo.observable;
             res = 1.0L;
             for (const auto& st : combo.states) {
                 uint8_t h = st.h, c = st.c, f = st.f;
-                most_likely_depth(h, c, f, ave, up);
-                if (h == 0) res *= geometric(error_param(ave), c);
-                else res *= poisson_pmf(ave * h, c);
+                most_likely_depth(h, c, f, ave, score_up);
+                if (h == 0) {
+                    if (!geo_have[c]) {
+                        geo_tab[c] = geometric(error_param(ave), c);
+                        geo_have[c] = true;
+                    }
+                    res *= geo_tab[c];
+                } else {
+                    const size_t slot = (size_t)h * 256 + c;
+                    if (!pois_have[slot]) {
+                        pois_tab[slot] = poisson_pmf(ave * h, c);
+                        pois_have[slot] = 1;
+                    }
+                    res *= pois_tab[slot];
+                }
             }
         }
     };
     // one step of the forward (alpha) or backward (beta) recursion (:1170-1380)
     auto recursion = [&](const std::vector<HmmScore>& prev, bool use_alpha, long double recomb, long double no_recomb,
                          const std::vector<Combo>& combos) -> std::vector<long double> {
+        // pow(no_recomb, keep) and pow(recomb, change) take ploidy + 1 distinct values each per node
+        const int32_t max_n = (int32_t)cfg.sample_ploidy;
+        std::vector<long double> pow_keep(max_n + 1), pow_change(max_n + 1);
+        if (!(recomb == 0.0L && no_recomb == 0.0L))
+            for (int32_t i = 0; i <= max_n; ++i) {
+                pow_keep[i] = std::pow(no_recomb, i);
+                pow_change[i] = std::pow(recomb, i);
+            }
         std::vector<long double> out;
         long double total = 0.0L;
         for (const auto& combo : combos) {
@@ -654,12 +680,17 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
                         }
                         res += t;
                     } else {
-                        std::vector<uint16_t> common;
-                        std::set_intersection(combo.haps.begin(), combo.haps.end(), p.haps.begin(), p.haps.end(),
-                                              std::back_inserter(common));
-                        const int32_t keep = (int32_t)common.size();
+                        // size of the multiset intersection of two sorted haplotype vectors (std::set_intersection)
+                        int32_t keep = 0;
+                        for (size_t x = 0, y = 0; x < combo.haps.size() && y < p.haps.size();) {
+                            if (combo.haps[x] < p.haps[y]) ++x;
+                            else if (p.haps[y] < combo.haps[x]) ++y;
+                            else { ++keep; ++x; ++y; }
+                        }
                         const int32_t change = hap_num - keep;
-                        res += pv * std::pow(no_recomb, keep) * std::pow(recomb, change) * combo.observable;
+                        const long double pk = keep <= max_n ? pow_keep[keep] : std::pow(no_recomb, keep);
+                        const long double pc = (change >= 0 && change <= max_n) ? pow_change[change] : std::pow(recomb, change);
+                        res += pv * pk * pc * combo.observable;
                     }
                 }
             }
