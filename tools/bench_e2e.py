@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""End-to-end at a chosen scale, everything from files (SURVEY 8d level iii): synthetic reference + cohort VCF +
+30x paired reads of VCF sample 0 -> the UNMODIFIED reference builds graph.bin (`construct`) -> `genotype` by (a) the
+all-CPU reference and (b) the native CLI varigraph-mi (device counting, own HMM) -> VCFs compared byte for byte.
+Needs oracle/_ref/varigraph_det (test infrastructure; it travels to the GPU box as a prebuilt binary)."""
+import argparse, gzip, json, os, shutil, subprocess, sys, tempfile, time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genome", type=int, default=10_000_000)
+    ap.add_argument("--variants", type=int, default=80_000)
+    ap.add_argument("--pairs", type=int, default=1_000_000)
+    ap.add_argument("--threads", type=int, default=10)
+    ap.add_argument("--gz", action="store_true")
+    ap.add_argument("--keep", default="")
+    args = ap.parse_args()
+    from varigraph_amd import synth, vgmi
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "varigraph_det")
+    cli = os.path.join(ROOT, "varigraph_amd", "bin", "varigraph-mi")
+    work = args.keep or tempfile.mkdtemp(prefix="vg_e2e_")
+    os.makedirs(work, exist_ok=True)
+    out = {"genome": args.genome, "variants": args.variants, "pairs": args.pairs, "threads": args.threads, "gz": args.gz}
+    try:
+        t0 = time.perf_counter()
+        ref = synth.make_reference(args.genome)
+        variants, gts = synth.make_cohort(ref, args.variants, n_samples=7, ploidy=2, seed=11)
+        fa, vcf = os.path.join(work, "ref.fa"), os.path.join(work, "in.vcf")
+        synth.write_fasta(fa, "chr1", ref)
+        synth.write_vcf(vcf, "chr1", len(ref), variants, gts, 7, 2)
+        haps = synth.sample_haplotypes(ref, variants, gts, 0, 2)
+        block = vgmi.synth_reads_host(1000, 0, 2 * args.pairs, 150, haps)
+        fq = synth.write_fastq_pair(os.path.join(work, "s"), block, 2 * args.pairs, 150, gz=args.gz)
+        out["synth_s"] = time.perf_counter() - t0
+        graph = os.path.join(work, "graph.bin")
+        t0 = time.perf_counter()
+        r = subprocess.run([ref_bin, "construct", "-r", fa, "-v", vcf, "--save-graph", graph, "-t", "32"], cwd=work,
+                           capture_output=True, text=True)
+        out["reference_construct_s"] = time.perf_counter() - t0
+        if r.returncode != 0:
+            out["error"] = r.stderr[-400:]
+            print(json.dumps(out))
+            return
+        out["graph_bytes"] = os.path.getsize(graph)
+        env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+        vcfs = {}
+        for name, exe, extra in (("reference_cpu", ref_bin, []), ("native_cli", cli, ["--gpu", "0"])):
+            d = os.path.join(work, name)
+            os.makedirs(d, exist_ok=True)
+            open(os.path.join(d, "samples.cfg"), "w").write("sample0 " + " ".join(fq) + "\n")
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "genotype", "--load-graph", graph, "-s", "samples.cfg", "-t", str(args.threads)] + extra,
+                               cwd=d, capture_output=True, text=True, env=env)
+            out[name + "_genotype_s"] = time.perf_counter() - t0
+            if r.returncode != 0:
+                out[name + "_error"] = r.stderr[-400:]
+                continue
+            out[name + "_log_tail"] = [ln for ln in r.stderr.strip().split("\n") if "varigraph-mi]" in ln][-4:]
+            vcfs[name] = gzip.open(os.path.join(d, "sample0.varigraph.vcf.gz"), "rb").read()
+        out["vcf_identical"] = len(vcfs) == 2 and vcfs["reference_cpu"] == vcfs["native_cli"]
+        out["vcf_records"] = vcfs.get("reference_cpu", b"").count(b"\n")
+    finally:
+        if not args.keep:
+            shutil.rmtree(work, ignore_errors=True)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -403,8 +403,13 @@ std::pair<std::string, std::string> Genotyper::flanks(const Chrom& chr, uint32_t
 }
 
 // ---------------------------------------------------------------- hidden states of one node (src/genotype.cpp:640-830)
+// `genotypes` = the window's haplotype combinations (the same for every node of a window), `used` = the haplotypes
+// occurring in them.  The per-haplotype term of a k-mer does not depend on the genotype, so it is evaluated once
+// per (k-mer, haplotype) and summed per genotype.
 std::vector<Genotyper::Combo> Genotyper::hidden_states(Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& top,
-                                                       double lower, double upper, bool filter, const Run& r)
+                                                       const std::vector<std::vector<uint16_t>>& genotypes,
+                                                       const std::vector<uint16_t>& used, double lower, double upper,
+                                                       bool filter, const Run& r)
 {
     Node& node = chr.nodes[node_i];
     const std::vector<uint16_t>& hap_gt = node.gn->hap_gt;
@@ -412,15 +417,16 @@ std::vector<Genotyper::Combo> Genotyper::hidden_states(Chrom& chr, uint32_t node
     auto hap_bit = [&](uint32_t key, uint16_t hap) -> uint8_t { return ((uint8_t)g_.bitvec[(size_t)key * bl + (hap >> 3)] >> (hap & 7)) & 1u; };
     auto last_bit = [&](uint32_t key) -> int { return ((uint8_t)g_.bitvec[(size_t)key * bl + bl - 1] >> 7) & 1; };
 
-    std::vector<Combo> combos;
-    for (auto& haps : haplotype_combinations(top, r.cfg->sample_type, r.cfg->sample_ploidy, (uint16_t)(n_hap_ - 1))) {
-        Combo c;
-        c.haps = std::move(haps);
-        combos.push_back(std::move(c));
+    std::vector<Combo> combos(genotypes.size());
+    for (size_t i = 0; i < genotypes.size(); ++i) {
+        combos[i].haps = genotypes[i];
+        combos[i].states.reserve(node.kmers.size());
     }
 
     std::vector<uint32_t> kept;                   // the node's k-mers that take part (all of them unless `filter`)
+    kept.reserve(node.kmers.size());
     std::map<uint16_t, uint32_t> need_sequence;   // haplotypes with multi-copy, under-covered k-mers: check their sequence
+    std::vector<uint8_t> one(n_hap_, 0);
     for (uint32_t key : node.kmers) {
         const uint8_t c = r.cov[key];
         const uint8_t f = g_.f[key];
@@ -431,17 +437,17 @@ std::vector<Genotyper::Combo> Genotyper::hidden_states(Chrom& chr, uint32_t node
             if (carried == 0) continue;
         }
         kept.push_back(key);
+        const bool in_interval = lb == 1 && c >= lower && c <= upper;
+        for (uint16_t hap : used) {
+            one[hap] = (in_interval && hap_gt[hap] == 0) ? 1 : hap_bit(key, hap);
+            if (one[hap] > 0 && c < lower && f >= 2) need_sequence.emplace(hap, 0);
+        }
+        HiddenState hs;
+        hs.c = c;
+        hs.f = (lb == 1 && f == 1) ? (uint8_t)(f + 1) : f;
         for (Combo& combo : combos) {
-            HiddenState hs;
-            hs.c = c;
-            for (uint16_t hap : combo.haps) {
-                const uint8_t one = (lb == 1 && hap_gt[hap] == 0 && c >= lower && c <= upper) ? 1 : hap_bit(key, hap);
-                hs.h += one;
-                if (one > 0 && c < lower && f >= 2) need_sequence.emplace(hap, 0).first->second++;
-            }
-            uint8_t freq = f;
-            if (lb == 1 && freq == 1) ++freq;
-            hs.f = freq;
+            hs.h = 0;
+            for (uint16_t hap : combo.haps) hs.h += one[hap];
             combo.states.push_back(hs);
         }
     }
@@ -472,10 +478,10 @@ std::vector<Genotyper::Combo> Genotyper::hidden_states(Chrom& chr, uint32_t node
             for (Combo& combo : combos) {
                 uint8_t& h = combo.states[si].h;
                 for (uint16_t hap : combo.haps) {
-                    const uint8_t one = (lb == 1 && hap_gt[hap] == 0 && c >= lower && c <= upper) ? 1 : hap_bit(key, hap);
+                    const uint8_t o1 = (lb == 1 && hap_gt[hap] == 0 && c >= lower && c <= upper) ? 1 : hap_bit(key, hap);
                     auto it = hap_keys.find(hap);
-                    if (it == hap_keys.end() || one == 0) continue;
-                    if (one == 1 && it->second.find(key_hash) == it->second.end()) {
+                    if (it == hap_keys.end() || o1 == 0) continue;
+                    if (o1 == 1 && it->second.find(key_hash) == it->second.end()) {
                         if (h >= 1) h--;
                     }
                 }
@@ -624,10 +630,35 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
     std::vector<uint8_t> pois_have(256 * 256, 0);
     long double geo_tab[256];
     bool geo_have[256] = {false};
-    auto score_combos = [&](std::vector<Combo>& combos) {
-        for (auto& combo : combos) {
-            long double& res = combo.observable;
-            res = 1.0L;
+    // genotypes of this window, the haplotypes they use, and how many haplotypes two genotypes share (the size of
+    // std::set_intersection of the two sorted vectors)
+    const std::vector<std::vector<uint16_t>> genotypes =
+        haplotype_combinations(top, cfg.sample_type, cfg.sample_ploidy, (uint16_t)(n_hap_ - 1));
+    const size_t n_gt = genotypes.size();
+    std::vector<uint16_t> used;
+    for (const auto& gtv : genotypes) used.insert(used.end(), gtv.begin(), gtv.end());
+    std::sort(used.begin(), used.end());
+    used.erase(std::unique(used.begin(), used.end()), used.end());
+    auto shared = [](const std::vector<uint16_t>& a, const std::vector<uint16_t>& b) -> int32_t {
+        int32_t n = 0;
+        for (size_t x = 0, y = 0; x < a.size() && y < b.size();) {
+            if (a[x] < b[y]) ++x;
+            else if (b[y] < a[x]) ++y;
+            else { ++n; ++x; ++y; }
+        }
+        return n;
+    };
+    std::vector<uint8_t> keep_mat(n_gt * n_gt);
+    for (size_t i = 0; i < n_gt; ++i)
+        for (size_t j = 0; j < n_gt; ++j) keep_mat[i * n_gt + j] = (uint8_t)shared(genotypes[i], genotypes[j]);
+
+    // emission score of every genotype of a node; empty when the node has no k-mer left (every genotype is skipped)
+    auto score_combos = [&](const std::vector<Combo>& combos) -> std::vector<long double> {
+        std::vector<long double> obs;
+        if (combos.empty() || combos[0].states.empty()) return obs;
+        obs.reserve(combos.size());
+        for (const auto& combo : combos) {
+            long double res = 1.0L;
             for (const auto& st : combo.states) {
                 uint8_t h = st.h, c = st.c, f = st.f;
                 most_likely_depth(h, c, f, ave, score_up);
@@ -646,33 +677,39 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
                     res *= pois_tab[slot];
                 }
             }
+            obs.push_back(res);
         }
+        return obs;
     };
-    // one step of the forward (alpha) or backward (beta) recursion (:1170-1380)
+    // one step of the forward (alpha) or backward (beta) recursion (:1170-1380); obs[i] = emission of genotype i
     auto recursion = [&](const std::vector<HmmScore>& prev, bool use_alpha, long double recomb, long double no_recomb,
-                         const std::vector<Combo>& combos) -> std::vector<long double> {
+                         const std::vector<long double>& obs) -> std::vector<long double> {
         // pow(no_recomb, keep) and pow(recomb, change) take ploidy + 1 distinct values each per node
         const int32_t max_n = (int32_t)cfg.sample_ploidy;
         std::vector<long double> pow_keep(max_n + 1), pow_change(max_n + 1);
-        if (!(recomb == 0.0L && no_recomb == 0.0L))
+        const bool by_score = recomb == 0.0L && no_recomb == 0.0L;
+        if (!by_score)
             for (int32_t i = 0; i <= max_n; ++i) {
                 pow_keep[i] = std::pow(no_recomb, i);
                 pow_change[i] = std::pow(recomb, i);
             }
+        const bool aligned = prev.size() == n_gt;   // the previous node's entries are this window's genotypes, in order
         std::vector<long double> out;
+        out.reserve(obs.size());
         long double total = 0.0L;
-        for (const auto& combo : combos) {
-            if (combo.haps.empty() || combo.states.empty()) continue;
-            const int32_t hap_num = (int32_t)combo.haps.size();
+        for (size_t gi = 0; gi < obs.size(); ++gi) {
+            const std::vector<uint16_t>& haps = genotypes[gi];
+            const int32_t hap_num = (int32_t)haps.size();
             long double res = 0.0L;
             if (prev.empty()) {
-                res += combo.observable;
+                res += obs[gi];
             } else {
-                for (const auto& p : prev) {
+                for (size_t pi = 0; pi < prev.size(); ++pi) {
+                    const HmmScore& p = prev[pi];
                     const long double pv = use_alpha ? p.a : p.b;
-                    if (recomb == 0.0L && no_recomb == 0.0L) {
-                        long double t = pv * combo.observable;
-                        for (uint16_t hap : combo.haps) {
+                    if (by_score) {
+                        long double t = pv * obs[gi];
+                        for (uint16_t hap : haps) {
                             auto it = hap_score.find(hap);
                             if (it == hap_score.end())
                                 throw std::runtime_error("'" + std::to_string(hap) + "' does not exist in 'hapIdxScoreMap'.");
@@ -680,17 +717,11 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
                         }
                         res += t;
                     } else {
-                        // size of the multiset intersection of two sorted haplotype vectors (std::set_intersection)
-                        int32_t keep = 0;
-                        for (size_t x = 0, y = 0; x < combo.haps.size() && y < p.haps.size();) {
-                            if (combo.haps[x] < p.haps[y]) ++x;
-                            else if (p.haps[y] < combo.haps[x]) ++y;
-                            else { ++keep; ++x; ++y; }
-                        }
+                        const int32_t keep = aligned ? (int32_t)keep_mat[gi * n_gt + pi] : shared(haps, p.haps);
                         const int32_t change = hap_num - keep;
                         const long double pk = keep <= max_n ? pow_keep[keep] : std::pow(no_recomb, keep);
                         const long double pc = (change >= 0 && change <= max_n) ? pow_change[change] : std::pow(recomb, change);
-                        res += pv * pk * pc * combo.observable;
+                        res += pv * pk * pc * obs[gi];
                     }
                 }
             }
@@ -706,7 +737,9 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
         return out;
     };
 
-    // ---- forward
+    // ---- forward.  The emissions are kept for the backward pass: it would recompute exactly the same hidden states
+    // (it runs on the k-mer lists this pass has just pruned, with the same coverage and the same genotypes).
+    std::vector<std::vector<long double>> emissions(last - first);
     std::vector<HmmScore> prev;
     uint32_t prev_start = 0, prev_end = 0;
     for (uint32_t i = first; i < last; ++i) {
@@ -714,18 +747,16 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
         if (skipped(n)) continue;
         const uint32_t n_start = n.start;
         const uint32_t n_end = (uint32_t)(n_start + n.gn->seqs[0].size() - 1);
-        std::vector<Combo> combos = hidden_states(chr, i, top, lower, upper, true, r);
+        const std::vector<Combo> combos = hidden_states(chr, i, top, genotypes, used, lower, upper, true, r);
         long double recomb = 0.0L, no_recomb = 0.0L;
         if (cfg.transition == "rec") std::tie(recomb, no_recomb) = transition_probabilities(n_start - prev_end, (uint16_t)n_hap_);
-        score_combos(combos);
-        const std::vector<long double> alpha = recursion(prev, true, recomb, no_recomb, combos);
+        std::vector<long double>& obs = emissions[i - first];
+        obs = score_combos(combos);
+        const std::vector<long double> alpha = recursion(prev, true, recomb, no_recomb, obs);
         n.hmm.resize(alpha.size());
-        uint32_t j = 0;
-        for (const auto& combo : combos) {
-            if (combo.haps.empty() || combo.states.empty()) continue;
+        for (size_t j = 0; j < alpha.size(); ++j) {
             n.hmm[j].a = alpha[j];
-            n.hmm[j].haps = combo.haps;
-            j++;
+            n.hmm[j].haps = genotypes[j];
         }
         prev_start = n_start;
         prev_end = n_end;
@@ -740,17 +771,11 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
         if (skipped(n)) continue;
         const uint32_t n_start = n.start;
         const uint32_t n_end = (uint32_t)(n_start + n.gn->seqs[0].size() - 1);
-        std::vector<Combo> combos = hidden_states(chr, i, top, lower, upper, false, r);
         long double recomb = 0.0L, no_recomb = 0.0L;
         if (cfg.transition == "rec") std::tie(recomb, no_recomb) = transition_probabilities(prev_start - n_end, (uint16_t)n_hap_);
-        score_combos(combos);
-        const std::vector<long double> beta = recursion(prev, false, recomb, no_recomb, combos);
-        uint32_t j = 0;
-        for (const auto& combo : combos) {
-            if (combo.haps.empty() || combo.states.empty()) continue;
-            n.hmm[j].b = beta[j];
-            j++;
-        }
+        const std::vector<long double> beta = recursion(prev, false, recomb, no_recomb, emissions[i - first]);
+        for (size_t j = 0; j < beta.size(); ++j) n.hmm[j].b = beta[j];
+        std::vector<long double>().swap(emissions[i - first]);
         prev_start = n_start;
         prev_end = n_end;
         prev = n.hmm;

@@ -79,8 +79,9 @@ private:
     struct Run;  // per-call constants
 
     void window(Chrom& chr, uint32_t first, uint32_t last, const Run& r);
-    std::vector<Combo> hidden_states(Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& top, double lower,
-                                     double upper, bool filter, const Run& r);
+    std::vector<Combo> hidden_states(Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& top,
+                                     const std::vector<std::vector<uint16_t>>& genotypes, const std::vector<uint16_t>& used,
+                                     double lower, double upper, bool filter, const Run& r);
     std::pair<std::string, std::string> flanks(const Chrom& chr, uint32_t node_i, uint16_t hap, uint16_t alt_gt,
                                                std::string& alt_seq, uint32_t want) const;
     void posterior(Node& n, const std::vector<uint16_t>& top, const Run& r) const;

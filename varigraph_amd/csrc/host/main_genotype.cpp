@@ -6,6 +6,10 @@
 #include <zlib.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <filesystem>
@@ -146,28 +150,73 @@ int main_genotype(int argc, char** argv)
     std::cerr << "[varigraph-mi] graph loaded: " << g.keys.size() << " k-mers, k = " << g.k << ", " << g.hap_names.size()
               << " haplotypes (" << secs() << " s)" << std::endl;
 
+    // Two stages, in `-s` order: device counting of sample s + 1 overlaps the host HMM of sample s (the HMM keeps
+    // state across samples -- pruned node lists -- so it stays one ordered consumer; Varigraph::fastq_genotype,
+    // src/varigraph.cpp:148-171, runs the two back to back)
+    struct Job {
+        std::string name;
+        std::vector<uint8_t> cov;
+        float hap_cov = 0;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job> queue;
+    bool producer_done = false;
+    std::thread hmm([&] {
+        try {
+            vgh::Genotyper genotyper(g);
+            for (;;) {
+                Job job;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !queue.empty() || producer_done; });
+                    if (queue.empty()) return;
+                    job = std::move(queue.front());
+                    queue.pop_front();
+                }
+                cv.notify_all();
+                const double th = secs();
+                const std::string vcf = genotyper.run(job.cov.data(), job.hap_cov, job.name, o.hmm);
+                vgh::Genotyper::write_gz(job.name + ".varigraph.vcf.gz", vcf);
+                std::fprintf(stderr, "[varigraph-mi] %s: genotyping %.2f s -> %s.varigraph.vcf.gz\n", job.name.c_str(), secs() - th,
+                             job.name.c_str());
+            }
+        } catch (const std::exception& e) {
+            die(e.what());
+        }
+    });
     try {
-        vgh::Genotyper genotyper(g);
-        std::vector<uint8_t> cov(g.keys.size());
-        for (const auto& [name, files] : samples) {   // Varigraph::fastq_genotype (src/varigraph.cpp:148-171)
+        for (const auto& [name, files] : samples) {
             const double ts = secs();
+            Job job;
+            job.name = name;
+            job.cov.resize(g.keys.size());
             vgh::FastqKmerHip fk(ctx, files, g.k, o.hmm.threads);
             fk.build_fastq_index();
             uint64_t hist[256];
-            fk.fetch(cov.data(), nullptr, hist);
+            fk.fetch(job.cov.data(), nullptr, hist);
             vgh::CoverageStats cs;
             if (!vgh::coverage_stats(hist, fk.mReadBase, g.genome_size, o.hmm.sample_ploidy, o.use_depth, cs))
                 die("Failed to retrieve depth information of k-mers from the sequencing data. Please verify your data.");
-            const double tc = secs();
+            job.hap_cov = cs.hap_kmer_coverage;
             std::fprintf(stderr, "[varigraph-mi] %s: %.2f Gb sequenced, depth %.2f, haplotype k-mer coverage %.2f; counting %.2f s (kernel %.3f s)\n",
-                         name.c_str(), fk.mReadBase / 1e9, cs.read_depth, cs.hap_kmer_coverage, tc - ts, fk.kernel_seconds());
-            const std::string vcf = genotyper.run(cov.data(), cs.hap_kmer_coverage, name, o.hmm);
-            vgh::Genotyper::write_gz(name + ".varigraph.vcf.gz", vcf);
-            std::fprintf(stderr, "[varigraph-mi] %s: genotyping %.2f s -> %s.varigraph.vcf.gz\n", name.c_str(), secs() - tc, name.c_str());
+                         name.c_str(), fk.mReadBase / 1e9, cs.read_depth, cs.hap_kmer_coverage, secs() - ts, fk.kernel_seconds());
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return queue.size() < 2; });   // at most two samples' counters waiting
+                queue.push_back(std::move(job));
+            }
+            cv.notify_all();
         }
     } catch (const std::exception& e) {
         die(e.what());
     }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        producer_done = true;
+    }
+    cv.notify_all();
+    hmm.join();
     vgmi_destroy(ctx);
     std::fprintf(stderr, "[varigraph-mi] done in %.2f s\n", secs());
     return 0;
