@@ -3,6 +3,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include <unordered_map>
@@ -17,6 +18,30 @@ namespace {
 // reference uses for its other inputs); graph.bin itself is written uncompressed
 std::vector<uint8_t> slurp(const std::string& path)
 {
+    // plain file (what `construct --save-graph` writes): one bulk read
+    if (FILE* f = fopen(path.c_str(), "rb")) {
+        unsigned char magic[2] = {0, 0};
+        const size_t got = fread(magic, 1, 2, f);
+        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
+            std::vector<uint8_t> buf;
+            if (fseeko(f, 0, SEEK_END) == 0) {
+                const off_t size = ftello(f);
+                if (size >= 0 && fseeko(f, 0, SEEK_SET) == 0) {
+                    buf.resize((size_t)size);
+                    size_t n = 0;
+                    while (n < buf.size()) {
+                        const size_t r = fread(buf.data() + n, 1, buf.size() - n, f);
+                        if (r == 0) break;
+                        n += r;
+                    }
+                    fclose(f);
+                    if (n != buf.size()) throw std::runtime_error("'" + path + "': read error");
+                    return buf;
+                }
+            }
+        }
+        fclose(f);
+    }
     gzFile fp = gzopen(path.c_str(), "rb");
     if (!fp) throw std::runtime_error("'" + path + "': No such file or directory.");
     gzbuffer(fp, 1 << 20);
@@ -40,6 +65,41 @@ std::vector<uint8_t> slurp(const std::string& path)
     buf.resize(n);
     return buf;
 }
+
+// key -> record index of the k-mer table: open addressing, multiplicative hash (the reference's unordered_map is
+// needed only for membership + position here; this is ~5x faster to build and probe at 1e7..1e8 keys)
+struct KeyIndex {
+    std::vector<uint64_t> key;
+    std::vector<uint32_t> idx;
+    uint64_t mask = 0;
+    explicit KeyIndex(const std::vector<uint64_t>& keys)
+    {
+        uint64_t cap = 16;
+        while (cap < 2 * keys.size()) cap <<= 1;
+        mask = cap - 1;
+        key.assign(cap, ~0ULL);
+        idx.assign(cap, 0);
+        for (size_t i = 0; i < keys.size(); ++i) {
+            uint64_t s = slot(keys[i]);
+            while (key[s] != ~0ULL && key[s] != keys[i]) s = (s + 1) & mask;
+            if (key[s] == ~0ULL) {   // the first record of a key wins, like unordered_map::emplace
+                key[s] = keys[i];
+                idx[s] = (uint32_t)i;
+            }
+        }
+    }
+    uint64_t slot(uint64_t k) const { return ((k * 0x9E3779B97F4A7C15ULL) >> 20) & mask; }
+    bool find(uint64_t k, uint32_t& out) const
+    {
+        for (uint64_t s = slot(k);; s = (s + 1) & mask) {
+            if (key[s] == k) {
+                out = idx[s];
+                return true;
+            }
+            if (key[s] == ~0ULL) return false;
+        }
+    }
+};
 
 struct Cursor {
     const uint8_t* p;
@@ -133,6 +193,14 @@ void GraphIndex::load(const std::string& path)
     // k-mer records until EOF: u64 key | u8 c | u8 f | u64 bitLen | i8[bitLen]
     keys.clear(); f.clear(); bitvec.clear();
     bitlen = 0;
+    if ((size_t)(c.end - c.p) >= 26) {   // all records have the same size: reserve once
+        uint64_t bl0;
+        memcpy(&bl0, c.p + 10, 8);
+        const size_t n_rec = (size_t)(c.end - c.p) / (18 + bl0) + 1;
+        keys.reserve(n_rec);
+        f.reserve(n_rec);
+        bitvec.reserve(n_rec * bl0);
+    }
     while (c.p < c.end) {
         const uint64_t key = c.get<uint64_t>();
         (void)c.get<uint8_t>();  // c: per-sample, zero in the index
@@ -157,9 +225,7 @@ void GraphIndex::load(const std::string& path)
 // produces the same permutation.
 void GraphIndex::graph2node()
 {
-    std::unordered_map<uint64_t, uint32_t> index;
-    index.reserve(keys.size() * 2);
-    for (size_t i = 0; i < keys.size(); ++i) index.emplace(keys[i], (uint32_t)i);
+    const KeyIndex index(keys);
 
     chr_names.clear(); node_chr.clear(); node_start.clear(); node_key_index.clear();
     node_off.assign(1, 0);
@@ -171,8 +237,8 @@ void GraphIndex::graph2node()
             std::vector<uint32_t> kept;
             kept.reserve(nd.kmer_hash.size());
             for (uint64_t h : nd.kmer_hash) {
-                auto it = index.find(h);
-                if (it != index.end()) kept.push_back(it->second);
+                uint32_t at;
+                if (index.find(h, at)) kept.push_back(at);
             }
             if (kept.size() > 128) {
                 const uint8_t* fp = f.data();
