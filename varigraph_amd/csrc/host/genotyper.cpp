@@ -537,11 +537,16 @@ void Genotyper::posterior(Node& n, const std::vector<uint16_t>& top, const Run& 
         return s;
     };
 
+    std::vector<std::string> gstr(n.hmm.size());
+    for (size_t i = 0; i < n.hmm.size(); ++i)
+        if (!n.hmm[i].haps.empty()) gstr[i] = genotype_string(n.hmm[i].haps);
+
     std::map<std::string, long double> by_genotype;
-    for (const auto& s : n.hmm) {
+    for (size_t i = 0; i < n.hmm.size(); ++i) {
+        const auto& s = n.hmm[i];
         const long double post = (s.a * s.b) / (long double)denominator;
         if (s.haps.empty()) continue;
-        by_genotype[genotype_string(s.haps)] += post;
+        by_genotype[gstr[i]] += post;
     }
     std::string best_genotype;
     long double best = -1.0;
@@ -553,10 +558,11 @@ void Genotyper::posterior(Node& n, const std::vector<uint16_t>& top, const Run& 
     }
 
     long double max_post = 0.0L;
-    for (const auto& s : n.hmm) {
+    for (size_t i = 0; i < n.hmm.size(); ++i) {
+        const auto& s = n.hmm[i];
         const long double post = (s.a * s.b) / (long double)denominator;
         if (s.haps.empty()) continue;
-        if (genotype_string(s.haps) != best_genotype) continue;
+        if (gstr[i] != best_genotype) continue;
         n.call.probability = best;
         if (max_post < post) {
             max_post = post;
@@ -694,6 +700,19 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
                 pow_change[i] = std::pow(recomb, i);
             }
         const bool aligned = prev.size() == n_gt;   // the previous node's entries are this window's genotypes, in order
+        // (prev * pow(no_recomb, keep)) * pow(recomb, change) does not depend on the genotype being scored: one value
+        // per previous entry and number of shared haplotypes -- the same two roundings, taken out of the inner loop
+        std::vector<long double> step;
+        if (!by_score && aligned) {
+            step.resize(prev.size() * (size_t)(max_n + 1));
+            for (size_t pi = 0; pi < prev.size(); ++pi) {
+                const long double pv = use_alpha ? prev[pi].a : prev[pi].b;
+                for (int32_t keep = 0; keep <= max_n; ++keep) {
+                    const int32_t change = max_n - keep;   // every genotype has `ploidy` haplotypes
+                    step[pi * (size_t)(max_n + 1) + keep] = pv * pow_keep[keep] * pow_change[change];
+                }
+            }
+        }
         std::vector<long double> out;
         out.reserve(obs.size());
         long double total = 0.0L;
@@ -703,6 +722,11 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
             long double res = 0.0L;
             if (prev.empty()) {
                 res += obs[gi];
+            } else if (!by_score && aligned && hap_num == max_n) {
+                const uint8_t* km = &keep_mat[gi * n_gt];
+                const long double o = obs[gi];
+                const size_t stride = (size_t)(max_n + 1);
+                for (size_t pi = 0; pi < prev.size(); ++pi) res += step[pi * stride + km[pi]] * o;
             } else {
                 for (size_t pi = 0; pi < prev.size(); ++pi) {
                     const HmmScore& p = prev[pi];
