@@ -55,7 +55,7 @@ def test_genotype_vcf_identical_to_reference(cohort, mode, extra, tmp_path):
     fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
     (tmp_path / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
     r = subprocess.run([BIN, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4",
-                        "--gpu", "0", "--buffer", "8"] + extra, cwd=tmp_path, capture_output=True, text=True)
+                        "--gpu", "0", "--buffer", "8"] + extra, cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     got = gzip.open(tmp_path / "sample0.varigraph.vcf.gz", "rb").read()
     assert got.count(b"\n") > 20
@@ -64,7 +64,7 @@ def test_genotype_vcf_identical_to_reference(cohort, mode, extra, tmp_path):
     cpu.mkdir()
     (cpu / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
     r2 = subprocess.run([REF, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4"] + extra,
-                        cwd=cpu, capture_output=True, text=True)
+                        cwd=cpu, capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0, r2.stderr[-2000:]
     want_here = gzip.open(cpu / "sample0.varigraph.vcf.gz", "rb").read()
     assert got == want_here
@@ -77,7 +77,7 @@ def test_integration_binary_fails_loudly_on_bad_input(tmp_path):
     if not os.path.exists(BIN):
         pytest.skip("integration binary not built")
     r = subprocess.run([BIN, "genotype", "--load-graph", str(tmp_path / "nope.bin"), "-s", "nope.cfg"],
-                       cwd=tmp_path, capture_output=True, text=True)
+                       cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
 
 
@@ -103,7 +103,7 @@ def test_native_cli_vcf_identical_to_reference(cohort, mode, extra, tmp_path):
     (tmp_path / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
     env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
     r = subprocess.run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4", "--gpu", "0",
-                        "--buffer", "8"] + extra, cwd=tmp_path, capture_output=True, text=True, env=env)
+                        "--buffer", "8"] + extra, cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     got = gzip.open(tmp_path / "sample0.varigraph.vcf.gz", "rb").read()
     # (1) equal to the committed fixture from the build container in everything but GQ
@@ -115,7 +115,7 @@ def test_native_cli_vcf_identical_to_reference(cohort, mode, extra, tmp_path):
         cpu.mkdir()
         (cpu / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
         r2 = subprocess.run([REF, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4"] + extra,
-                            cwd=cpu, capture_output=True, text=True)
+                            cwd=cpu, capture_output=True, text=True, timeout=300)
         assert r2.returncode == 0, r2.stderr[-2000:]
         assert got == gzip.open(cpu / "sample0.varigraph.vcf.gz", "rb").read()
 
@@ -130,7 +130,7 @@ def test_native_cli_two_samples_and_errors(tmp_path):
     (tmp_path / "samples.cfg").write_text("".join(f"sample{s} " + " ".join(fq) + "\n" for s in (0, 1)))
     env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
     r = subprocess.run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4", "-n", "5"], cwd=tmp_path,
-                       capture_output=True, text=True, env=env)
+                       capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     for s in (0, 1):
         got = gzip.open(tmp_path / f"sample{s}.varigraph.vcf.gz", "rb").read()
@@ -138,9 +138,32 @@ def test_native_cli_two_samples_and_errors(tmp_path):
         assert _strip_gq(got) == _strip_gq(want)
     # loud failures: missing graph, missing read file, bad option value
     assert subprocess.run([CLI, "genotype", "--load-graph", str(tmp_path / "nope.bin"), "-s", "samples.cfg"], cwd=tmp_path,
-                          capture_output=True).returncode != 0
+                          capture_output=True, timeout=300).returncode != 0
     (tmp_path / "bad.cfg").write_text("s0 /nonexistent_1.fq.gz\n")
     assert subprocess.run([CLI, "genotype", "--load-graph", str(graph), "-s", "bad.cfg"], cwd=tmp_path,
-                          capture_output=True).returncode != 0
+                          capture_output=True, timeout=300).returncode != 0
     assert subprocess.run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-g", "maybe"], cwd=tmp_path,
-                          capture_output=True).returncode != 0
+                          capture_output=True, timeout=300).returncode != 0
+
+
+def test_native_cli_several_devices_keep_sample_order(tmp_path):
+    """--gpus a,b: samples are counted on several device contexts in parallel (here the same GPU twice) while the
+    HMM consumes them strictly in `-s` order -- its per-node state carries over from sample to sample, so the result
+    must be the one of the sequential run."""
+    if not os.path.exists(CLI):
+        pytest.skip("varigraph-mi not built")
+    d = os.path.join(GOLDEN, "cohort_snp")
+    graph = tmp_path / "graph.bin"
+    graph.write_bytes(gzip.open(os.path.join(d, "graph.bin.gz"), "rb").read())
+    fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
+    (tmp_path / "samples.cfg").write_text("".join(f"sample{s} " + " ".join(fq) + "\n" for s in range(4)))
+    env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+    r = subprocess.run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4", "-n", "5", "--gpus", "0,0"],
+                       cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    body = lambda v: [ln for ln in _strip_gq(v).split(b"\n") if ln and not ln.startswith(b"#")]
+    got = [gzip.open(tmp_path / f"sample{s}.varigraph.vcf.gz", "rb").read() for s in range(4)]
+    for s in (0, 1):
+        want = open(os.path.join(d, f"expected_two_n5_s{s}.vcf"), "rb").read()
+        assert _strip_gq(got[s]) == _strip_gq(want)
+    assert body(got[2]) == body(got[1]) and body(got[3]) == body(got[1])

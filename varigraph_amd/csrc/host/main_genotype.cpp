@@ -5,9 +5,10 @@
 #include <getopt.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
-#include <deque>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <cstdio>
@@ -30,7 +31,8 @@ struct Options {
     std::string graph = "graph.bin", samples;
     vgh::GenotypeConfig hmm;
     bool use_depth = false;
-    int gpu = 0;
+    std::vector<int> gpus = {0};   // --gpu N, or --gpus a,b,c: samples are dealt to the devices, one
+                                   // counting thread and one table replica per device
     int buffer_mib = 100;   // main.cu default
 };
 
@@ -49,6 +51,7 @@ void usage(const char* argv0)
               << "    --min-support   FLOAT  minimum site quality (GQ) [0]\n"
               << "    --use-depth            use the sequencing depth as the depth of homozygous k-mers\n"
               << "    --gpu           INT    device ordinal [0]\n"
+              << "    --gpus          LIST   several devices, e.g. 0,1,2,3: samples are counted on them in parallel\n"
               << "    --buffer        INT    staging buffer in MiB [100]\n"
               << "    -t, --threads   INT    host threads [10]\n";
 }
@@ -100,6 +103,7 @@ int main_genotype(int argc, char** argv)
         {"mode", required_argument, 0, 'm'},       {"sv", no_argument, 0, 4},
         {"min-support", required_argument, 0, 5},  {"use-depth", no_argument, 0, 6},
         {"gpu", required_argument, 0, 7},          {"buffer", required_argument, 0, 8},
+        {"gpus", required_argument, 0, 9},
         {"threads", required_argument, 0, 't'},    {"help", no_argument, 0, 'h'},
         {0, 0, 0, 0}};
     for (;;) {
@@ -117,7 +121,15 @@ int main_genotype(int argc, char** argv)
         case 4: o.hmm.sv_only = true; break;
         case 5: o.hmm.min_gq = std::stof(optarg); break;
         case 6: o.use_depth = true; break;
-        case 7: o.gpu = std::stoi(optarg); break;
+        case 7: o.gpus = {std::stoi(optarg)}; break;
+        case 9: {
+            o.gpus.clear();
+            std::stringstream ss(optarg);
+            for (std::string t; std::getline(ss, t, ',');)
+                if (!t.empty()) o.gpus.push_back(std::stoi(t));
+            if (o.gpus.empty()) die("Parameter error: --gpus. Expected a comma-separated list of device ordinals.");
+            break;
+        }
         case 8: o.buffer_mib = std::stoi(optarg); break;
         case 't': o.hmm.threads = std::max(std::stoi(optarg), 1); break;
         default: usage(argv[0]); return 1;
@@ -135,10 +147,15 @@ int main_genotype(int argc, char** argv)
     const auto t0 = std::chrono::steady_clock::now();
     auto secs = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
 
-    vgmi_ctx* ctx = nullptr;
-    if (vgmi_create(o.gpu, (size_t)o.buffer_mib, &ctx) != VGMI_OK) die(std::string("device ") + std::to_string(o.gpu) + ": " + vgmi_last_error(nullptr));
+    std::vector<vgmi_ctx*> ctxs;
+    for (int dev : o.gpus) {
+        vgmi_ctx* ctx = nullptr;
+        if (vgmi_create(dev, (size_t)o.buffer_mib, &ctx) != VGMI_OK)
+            die(std::string("device ") + std::to_string(dev) + ": " + vgmi_last_error(nullptr));
+        ctxs.push_back(ctx);
+    }
     const auto samples = parse_samples(o.samples);
-    std::cerr << "[varigraph-mi] samples: " << samples.size() << ", graph: " << o.graph << std::endl;
+    std::cerr << "[varigraph-mi] samples: " << samples.size() << ", graph: " << o.graph << ", devices: " << ctxs.size() << std::endl;
 
     vgh::GraphIndex g;
     try {
@@ -146,13 +163,15 @@ int main_genotype(int argc, char** argv)
     } catch (const std::exception& e) {
         die(e.what());
     }
-    if (g.upload(ctx) != VGMI_OK) die(vgmi_last_error(ctx));
+    for (vgmi_ctx* ctx : ctxs)
+        if (g.upload(ctx) != VGMI_OK) die(vgmi_last_error(ctx));
     std::cerr << "[varigraph-mi] graph loaded: " << g.keys.size() << " k-mers, k = " << g.k << ", " << g.hap_names.size()
               << " haplotypes (" << secs() << " s)" << std::endl;
 
-    // Two stages, in `-s` order: device counting of sample s + 1 overlaps the host HMM of sample s (the HMM keeps
-    // state across samples -- pruned node lists -- so it stays one ordered consumer; Varigraph::fastq_genotype,
-    // src/varigraph.cpp:148-171, runs the two back to back)
+    // Two stages.  Counting: one thread per device takes the next sample of the `-s` list (samples are independent
+    // units).  Genotyping: ONE consumer, strictly in `-s` order -- the HMM keeps state across samples (the
+    // pruned node lists), exactly like Varigraph::fastq_genotype (src/varigraph.cpp:148-171), which runs the two
+    // stages back to back; here the counting of later samples overlaps the HMM of earlier ones.
     struct Job {
         std::string name;
         std::vector<uint8_t> cov;
@@ -160,19 +179,22 @@ int main_genotype(int argc, char** argv)
     };
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<Job> queue;
-    bool producer_done = false;
+    std::map<size_t, Job> ready;           // finished counting, keyed by position in the -s list
+    size_t next_to_genotype = 0;
+    std::atomic<size_t> next_to_count{0};
+    const size_t max_ready = 2 * ctxs.size();
+
     std::thread hmm([&] {
         try {
             vgh::Genotyper genotyper(g);
-            for (;;) {
+            for (size_t s = 0; s < samples.size(); ++s) {
                 Job job;
                 {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return !queue.empty() || producer_done; });
-                    if (queue.empty()) return;
-                    job = std::move(queue.front());
-                    queue.pop_front();
+                    cv.wait(lk, [&] { return ready.count(s) != 0; });
+                    job = std::move(ready[s]);
+                    ready.erase(s);
+                    next_to_genotype = s + 1;
                 }
                 cv.notify_all();
                 const double th = secs();
@@ -185,39 +207,48 @@ int main_genotype(int argc, char** argv)
             die(e.what());
         }
     });
-    try {
-        for (const auto& [name, files] : samples) {
-            const double ts = secs();
-            Job job;
-            job.name = name;
-            job.cov.resize(g.keys.size());
-            vgh::FastqKmerHip fk(ctx, files, g.k, o.hmm.threads);
-            fk.build_fastq_index();
-            uint64_t hist[256];
-            fk.fetch(job.cov.data(), nullptr, hist);
-            vgh::CoverageStats cs;
-            if (!vgh::coverage_stats(hist, fk.mReadBase, g.genome_size, o.hmm.sample_ploidy, o.use_depth, cs))
-                die("Failed to retrieve depth information of k-mers from the sequencing data. Please verify your data.");
-            job.hap_cov = cs.hap_kmer_coverage;
-            std::fprintf(stderr, "[varigraph-mi] %s: %.2f Gb sequenced, depth %.2f, haplotype k-mer coverage %.2f; counting %.2f s (kernel %.3f s)\n",
-                         name.c_str(), fk.mReadBase / 1e9, cs.read_depth, cs.hap_kmer_coverage, secs() - ts, fk.kernel_seconds());
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return queue.size() < 2; });   // at most two samples' counters waiting
-                queue.push_back(std::move(job));
+    auto counter = [&](size_t dev_i) {
+        vgmi_ctx* ctx = ctxs[dev_i];
+        try {
+            for (;;) {
+                const size_t s = next_to_count.fetch_add(1);
+                if (s >= samples.size()) return;
+                {   // do not run ahead of the HMM by more than a couple of samples per device (each holds n_keys bytes)
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return s < next_to_genotype + max_ready; });
+                }
+                const auto& [name, files] = samples[s];
+                const double ts = secs();
+                Job job;
+                job.name = name;
+                job.cov.resize(g.keys.size());
+                vgh::FastqKmerHip fk(ctx, files, g.k, o.hmm.threads);
+                fk.build_fastq_index();
+                uint64_t hist[256];
+                fk.fetch(job.cov.data(), nullptr, hist);
+                vgh::CoverageStats cs;
+                if (!vgh::coverage_stats(hist, fk.mReadBase, g.genome_size, o.hmm.sample_ploidy, o.use_depth, cs))
+                    die("Failed to retrieve depth information of k-mers from the sequencing data. Please verify your data.");
+                job.hap_cov = cs.hap_kmer_coverage;
+                std::fprintf(stderr, "[varigraph-mi] %s (device %d): %.2f Gb sequenced, depth %.2f, haplotype k-mer coverage %.2f; counting %.2f s (kernel %.3f s)\n",
+                             name.c_str(), o.gpus[dev_i], fk.mReadBase / 1e9, cs.read_depth, cs.hap_kmer_coverage, secs() - ts,
+                             fk.kernel_seconds());
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    ready.emplace(s, std::move(job));
+                }
+                cv.notify_all();
             }
-            cv.notify_all();
+        } catch (const std::exception& e) {
+            die(e.what());
         }
-    } catch (const std::exception& e) {
-        die(e.what());
-    }
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        producer_done = true;
-    }
-    cv.notify_all();
+    };
+    std::vector<std::thread> counters;
+    for (size_t d = 1; d < ctxs.size(); ++d) counters.emplace_back(counter, d);
+    counter(0);
+    for (auto& t : counters) t.join();
     hmm.join();
-    vgmi_destroy(ctx);
+    for (vgmi_ctx* ctx : ctxs) vgmi_destroy(ctx);
     std::fprintf(stderr, "[varigraph-mi] done in %.2f s\n", secs());
     return 0;
 }
