@@ -10,6 +10,7 @@
 #include <condition_variable>
 #include <map>
 #include <mutex>
+#include <random>
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +21,7 @@
 #include <tuple>
 #include <vector>
 
+#include "constructor.hpp"
 #include "fastq_kmer_hip.hpp"
 #include "genotyper.hpp"
 #include "graph_index.hpp"
@@ -253,6 +255,67 @@ int main_genotype(int argc, char** argv)
     return 0;
 }
 
+// `construct` (main.cpp:21-236, Varigraph::construct src/varigraph.cpp:14-54): same options plus --gpu / --buffer
+int main_construct(int argc, char** argv)
+{
+    vgh::ConstructConfig c;
+    int gpu = 0, buffer_mib = 100;
+    static const struct option long_options[] = {
+        {"reference", required_argument, 0, 'r'}, {"vcf", required_argument, 0, 'v'},
+        {"save-graph", required_argument, 0, 1},  {"vcf-ploidy", required_argument, 0, 2},
+        {"kmer", required_argument, 0, 'k'},      {"fast", no_argument, 0, 3},
+        {"use-unique-kmers", no_argument, 0, 4},  {"gpu", required_argument, 0, 7},
+        {"buffer", required_argument, 0, 8},      {"threads", required_argument, 0, 't'},
+        {"help", no_argument, 0, 'h'},            {0, 0, 0, 0}};
+    for (;;) {
+        int idx = 0;
+        const int o = getopt_long(argc, argv, "r:v:k:t:h", long_options, &idx);
+        if (o == -1) break;
+        switch (o) {
+        case 'r': c.reference = optarg; break;
+        case 'v': c.vcf = optarg; break;
+        case 1: c.out = optarg; break;
+        case 2: c.vcf_ploidy = (uint32_t)std::max(std::stoi(optarg), 1); break;
+        case 'k': c.k = (uint32_t)std::stoul(optarg); break;
+        case 3: c.fast = true; break;
+        case 4: c.use_unique_kmers = true; break;
+        case 7: gpu = std::stoi(optarg); break;
+        case 8: buffer_mib = std::stoi(optarg); break;
+        case 't': break;   // accepted for command-line compatibility
+        default:
+            std::cerr << "Usage: construct -r FASTA -v VCF [--save-graph FILE] [-k INT] [--vcf-ploidy INT] [--fast] "
+                         "[--use-unique-kmers] [--gpu INT] [--buffer INT]\n";
+            return 1;
+        }
+    }
+    if (c.reference.empty()) die("Parameter error: -r. The reference genome file cannot be empty.");
+    if (c.vcf.empty()) die("Parameter error: -v. The VCF file cannot be empty.");
+    if (c.k < 1 || c.k > 28) die("Parameter error: -k. The k-mer length must be in 1..28.");
+    if (const char* e = std::getenv("VGH_RANDOM_DEVICE_VALUE")) {
+        c.random_device_value = (uint32_t)std::strtoul(e, nullptr, 10);
+    } else {
+        std::random_device rd;
+        c.random_device_value = rd();
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    vgmi_ctx* ctx = nullptr;
+    if (vgmi_create(gpu, (size_t)buffer_mib, &ctx) != VGMI_OK) die(std::string("device ") + std::to_string(gpu) + ": " + vgmi_last_error(nullptr));
+    try {
+        const vgh::ConstructStats st = vgh::construct_graph(ctx, c);
+        std::fprintf(stderr,
+                     "[varigraph-mi] construct: genome %.2f Mb, %llu variant nodes, %llu k-mers, %llu haplotypes -> %s\n"
+                     "[varigraph-mi]   Bloom %.1f MB on device in %.2f s, indexing %.2f s (%llu Bloom queries), total %.2f s\n",
+                     st.genome_size / 1e6, (unsigned long long)st.n_variant_nodes, (unsigned long long)st.n_kmers,
+                     (unsigned long long)st.n_haplotypes, c.out.c_str(), st.bloom_bytes / 1e6, st.seconds_bloom, st.seconds_index,
+                     (unsigned long long)st.bloom_queries,
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    } catch (const std::exception& e) {
+        die(e.what());
+    }
+    vgmi_destroy(ctx);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -269,6 +332,13 @@ int main(int argc, char** argv)
         }
         return main_genotype(argc - 1, argv + 1);
     }
-    std::cerr << "Error: '" << cmd << "' is not a sub-command of this build (genotype).\n";
+    if (cmd == "construct") {
+        if (argc < 3) {
+            std::cerr << "Usage: " << argv[0] << " construct -r FASTA -v VCF [--save-graph FILE] [options]\n";
+            return 1;
+        }
+        return main_construct(argc - 1, argv + 1);
+    }
+    std::cerr << "Error: '" << cmd << "' is not a sub-command of this build (construct, genotype).\n";
     return 1;
 }
