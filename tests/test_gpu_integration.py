@@ -167,3 +167,55 @@ def test_native_cli_several_devices_keep_sample_order(tmp_path):
         want = open(os.path.join(d, f"expected_two_n5_s{s}.vcf"), "rb").read()
         assert _strip_gq(got[s]) == _strip_gq(want)
     assert body(got[2]) == body(got[1]) and body(got[3]) == body(got[1])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# `varigraph-mi construct`: the committed graph.bin.gz of every cohort was written by the unmodified reference
+# (deterministic build, std::random_device = 20241022) from the committed in.vcf and the seeded synthetic reference.
+# The native construct (Bloom filter built and queried on the device) must reproduce the file byte for byte.
+@pytest.mark.parametrize("cohort", ["cohort_snp", "cohort_sv", "cohort_k22", "cohort_tetra"])
+def test_native_construct_reproduces_reference_graph(cohort, tmp_path):
+    if not os.path.exists(CLI):
+        pytest.skip("varigraph-mi not built")
+    import json
+    from varigraph_amd import synth
+    d = os.path.join(GOLDEN, cohort)
+    meta = json.load(open(os.path.join(d, "meta.json")))
+    ref = synth.make_reference(meta["ref_len"], seed=meta["ref_seed"])
+    fa = tmp_path / "ref.fa"
+    synth.write_fasta(str(fa), "chr1", ref)
+    env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+    r = subprocess.run([CLI, "construct", "-r", str(fa), "-v", os.path.join(d, "in.vcf"), "--save-graph", "graph.bin", "-k",
+                        str(meta["k"]), "--vcf-ploidy", str(meta["ploidy"]), "--gpu", "0"], cwd=tmp_path, capture_output=True,
+                       text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = (tmp_path / "graph.bin").read_bytes()
+    want = gzip.open(os.path.join(d, "graph.bin.gz"), "rb").read()
+    assert len(got) == len(want)
+    assert got == want
+
+
+def test_native_construct_then_genotype_and_errors(tmp_path):
+    """construct -> genotype with nothing but this repo's binaries, against the reference's VCF; loud failures."""
+    if not os.path.exists(CLI):
+        pytest.skip("varigraph-mi not built")
+    import json
+    from varigraph_amd import synth
+    d = os.path.join(GOLDEN, "cohort_sv")
+    meta = json.load(open(os.path.join(d, "meta.json")))
+    fa = tmp_path / "ref.fa"
+    synth.write_fasta(str(fa), "chr1", synth.make_reference(meta["ref_len"], seed=meta["ref_seed"]))
+    env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+    r = subprocess.run([CLI, "construct", "-r", str(fa), "-v", os.path.join(d, "in.vcf"), "--save-graph", "g.bin"], cwd=tmp_path,
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
+    (tmp_path / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
+    r = subprocess.run([CLI, "genotype", "--load-graph", "g.bin", "-s", "samples.cfg", "-t", "4"], cwd=tmp_path,
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = gzip.open(tmp_path / "sample0.varigraph.vcf.gz", "rb").read()
+    assert _strip_gq(got) == _strip_gq(open(os.path.join(d, "expected_het.vcf"), "rb").read())
+    for bad in (["-r", str(tmp_path / "nope.fa"), "-v", os.path.join(d, "in.vcf")], ["-r", str(fa), "-v", str(tmp_path / "nope.vcf")],
+                ["-r", str(fa), "-v", os.path.join(d, "in.vcf"), "-k", "31"]):
+        assert subprocess.run([CLI, "construct"] + bad, cwd=tmp_path, capture_output=True, timeout=300).returncode != 0
