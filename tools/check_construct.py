@@ -35,7 +35,7 @@ def main():
         common = ["construct", "-r", fa, "-v", vcf, "-k", str(args.k), "--vcf-ploidy", str(args.ploidy)] + extra
         env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
         digests = {}
-        for name, exe, more in (("reference", ref_bin, ["-t", "16"]), ("native", cli, ["--gpu", "0"])):
+        for name, exe, more in (("reference", ref_bin, ["-t", "16"]), ("native", cli, ["--gpu", "0", "-t", "16"])):
             g = os.path.join(work, name + ".bin")
             t0 = time.perf_counter()
             r = subprocess.run([exe] + common + ["--save-graph", g] + more, cwd=work, capture_output=True, text=True, env=env,

@@ -4,15 +4,19 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iterator>
 #include <map>
+#include <mutex>
 #include <numeric>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 
@@ -325,34 +329,118 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
         }
     }
 
-    // ---- index: per variant node and haplotype, the k-mers of allele + flanks with their Bloom count / presence
+    // ---- index: per variant node and haplotype, the k-mers of allele + flanks with their Bloom count / presence.
+    // Chunks of nodes go through three phases: (A, threads) flank sequences and emitted keys per node; one batched
+    // Bloom query on the device; (C, threads) index_run's bookkeeping per node; then ConstructIndex::index's merge into
+    // the table, sequentially and in node order (it fixes the record order of graph.bin).
     const auto t_index = clock::now();
     std::unordered_map<uint64_t, TableEntry> table;   // iteration order = record order of graph.bin
     {
         struct HapWork {   // one (node, haplotype) sequence whose k-mers were emitted
             uint16_t hap, gt;
-            size_t key_begin, key_end;
+            size_t key_begin, key_end;   // into the node's keys, then (after concatenation) into the chunk's
         };
         struct NodeWork {
-            GraphNode* node;
+            uint32_t ni = 0;
+            GraphNode* node = nullptr;
             std::vector<HapWork> haps;
+            std::vector<uint64_t> keys;
+            std::unordered_map<uint64_t, std::vector<int8_t>> kept;
+            std::map<uint64_t, uint8_t> multi;
         };
-        const size_t chunk_keys = (size_t)1 << 25;
+        const uint32_t n_threads = std::max(1u, cfg.threads);
+        auto parallel_for = [&](size_t n, const std::function<void(size_t)>& fn) {
+            std::atomic<size_t> next{0};
+            std::string error;
+            std::mutex emu;
+            auto worker = [&]() {
+                for (;;) {
+                    const size_t i = next.fetch_add(1);
+                    if (i >= n) return;
+                    try {
+                        fn(i);
+                    } catch (const std::exception& e) {
+                        std::lock_guard<std::mutex> lk(emu);
+                        if (error.empty()) error = e.what();
+                        next.store(n);
+                        return;
+                    }
+                }
+            };
+            std::vector<std::thread> pool;
+            for (uint32_t t = 1; t < n_threads && t < n; ++t) pool.emplace_back(worker);
+            worker();
+            for (auto& th : pool) th.join();
+            if (!error.empty()) throw std::runtime_error(error);
+        };
+        const size_t chunk_nodes = 20000;
         for (auto& [chr, nodes] : graph) {
             std::vector<NodeView> view;
             view.reserve(nodes.size());
             for (auto& kv : nodes) view.push_back(NodeView{kv.first, &kv.second});
-            std::vector<NodeWork> work;
-            std::vector<uint64_t> keys;
-            std::vector<uint8_t> cnt, fnd;
-            auto flush = [&]() {
-                if (work.empty()) return;
-                cnt.resize(keys.size());
-                fnd.resize(keys.size());
+            std::vector<uint32_t> variant;
+            for (uint32_t ni = 0; ni < view.size(); ++ni)
+                if (view[ni].gn->hap_gt.size() != 1) variant.push_back(ni);
+            st.n_variant_nodes += variant.size();
+            const std::string& chr_name = chr;
+            for (size_t c0 = 0; c0 < variant.size(); c0 += chunk_nodes) {
+                const size_t c1 = std::min(variant.size(), c0 + chunk_nodes);
+                std::vector<NodeWork> work(c1 - c0);
+                // ---- phase A
+                parallel_for(work.size(), [&](size_t w) {
+                    NodeWork& nw = work[w];
+                    nw.ni = variant[c0 + w];
+                    GraphNode& node = *const_cast<GraphNode*>(view[nw.ni].gn);
+                    nw.node = &node;
+                    uint16_t hap = 0;
+                    for (const uint16_t gt : node.hap_gt) {
+                        if (cfg.fast && hap > 0 && gt == 0) {   // --fast: skip the haplotypes of VCF samples that are all-reference here
+                            const uint16_t group = (hap - 1) / ploidy;
+                            const uint16_t l = group * ploidy + 1, r = (group + 1) * ploidy;
+                            const uint16_t sum = std::accumulate(node.hap_gt.begin() + l, node.hap_gt.begin() + r + 1, 0);
+                            if (sum == 0) {
+                                ++hap;
+                                continue;
+                            }
+                        }
+                        if (gt >= node.seqs.size())
+                            throw std::runtime_error("Error: The node '" + chr_name + "-" + std::to_string(node.start) +
+                                                     "' lacks sequence information for haplotype " + std::to_string(gt) + ".");
+                        std::string seq = node.seqs[gt];
+                        const auto fl = node_flanks(view, nw.ni, hap, gt, seq, cfg.k - 1);
+                        seq = fl.first + seq + fl.second;
+                        if (seq.empty()) throw std::runtime_error("empty allele sequence (the reference aborts on assert(len > 0))");
+                        HapWork hw;
+                        hw.hap = hap;
+                        hw.gt = gt;
+                        hw.key_begin = nw.keys.size();
+                        emitted_keys(seq, cfg.k, nw.keys);
+                        hw.key_end = nw.keys.size();
+                        nw.haps.push_back(hw);
+                        ++hap;
+                    }
+                });
+                // ---- one Bloom batch for the chunk
+                std::vector<uint64_t> keys;
+                size_t total = 0;
+                for (const NodeWork& nw : work) total += nw.keys.size();
+                keys.reserve(total);
+                for (NodeWork& nw : work) {
+                    const size_t base = keys.size();
+                    for (HapWork& hw : nw.haps) {
+                        hw.key_begin += base;
+                        hw.key_end += base;
+                    }
+                    keys.insert(keys.end(), nw.keys.begin(), nw.keys.end());
+                    std::vector<uint64_t>().swap(nw.keys);
+                }
+                std::vector<uint8_t> cnt(keys.size()), fnd(keys.size());
                 if (!keys.empty() && vgmi_bloom_query(ctx, keys.data(), keys.size(), cnt.data(), fnd.data()) != VGMI_OK)
                     throw std::runtime_error(vgmi_last_error(ctx));
                 st.bloom_queries += keys.size();
-                for (NodeWork& nw : work) {   // index_run's bookkeeping, then ConstructIndex::index's merge, in node order
+                // ---- phase C: index_run's bookkeeping per node
+                parallel_for(work.size(), [&](size_t w) {
+                    NodeWork& nw = work[w];
                     GraphNode& node = *nw.node;
                     const size_t bitlen = (node.hap_gt.size() >> 3) + 1;
                     uint8_t min_fre = UINT8_MAX;
@@ -378,19 +466,21 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
                         }
                     }
                     if (min_fre == 0 || cfg.use_unique_kmers) min_fre = 1;
-                    std::unordered_map<uint64_t, std::vector<int8_t>> kept;
-                    std::map<uint64_t, uint8_t> multi;
                     for (auto it = by_key.begin(); it != by_key.end();) {
                         if (it->second.second <= min_fre) {
-                            kept.emplace(it->first, std::move(it->second.first));
-                            if (it->second.second >= 2) multi.emplace(it->first, it->second.second);
+                            nw.kept.emplace(it->first, std::move(it->second.first));
+                            if (it->second.second >= 2) nw.multi.emplace(it->first, it->second.second);
                             it = by_key.erase(it);
                         } else {
                             ++it;
                         }
                     }
-                    if (kept.empty()) continue;
-                    for (auto& [key, bits] : kept) {
+                });
+                // ---- merge, in node order
+                for (NodeWork& nw : work) {
+                    if (nw.kept.empty()) continue;
+                    GraphNode& node = *nw.node;
+                    for (auto& [key, bits] : nw.kept) {
                         node.kmer_hash.push_back(key);
                         auto ins = table.emplace(key, TableEntry{});
                         TableEntry& e = ins.first->second;
@@ -402,52 +492,13 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
                             if (e.f < UINT8_MAX) e.f++;
                         }
                     }
-                    for (const auto& [key, fre] : multi) {
+                    for (const auto& [key, fre] : nw.multi) {
                         auto it = table.find(key);
                         if (it == table.end()) throw std::runtime_error("The k-mer hash '" + std::to_string(key) + "' is not found in the table.");
                         if (it->second.f == 1) it->second.f += fre - 1;
                     }
                 }
-                work.clear();
-                keys.clear();
-            };
-            for (uint32_t ni = 0; ni < view.size(); ++ni) {
-                GraphNode& node = *const_cast<GraphNode*>(view[ni].gn);
-                if (node.hap_gt.size() == 1) continue;
-                st.n_variant_nodes++;
-                NodeWork nw;
-                nw.node = &node;
-                uint16_t hap = 0;
-                for (const uint16_t gt : node.hap_gt) {
-                    if (cfg.fast && hap > 0 && gt == 0) {   // --fast: skip the haplotypes of VCF samples that are all-reference here
-                        const uint16_t group = (hap - 1) / ploidy;
-                        const uint16_t l = group * ploidy + 1, r = (group + 1) * ploidy;
-                        const uint16_t sum = std::accumulate(node.hap_gt.begin() + l, node.hap_gt.begin() + r + 1, 0);
-                        if (sum == 0) {
-                            ++hap;
-                            continue;
-                        }
-                    }
-                    if (gt >= node.seqs.size())
-                        throw std::runtime_error("Error: The node '" + chr + "-" + std::to_string(node.start) +
-                                                 "' lacks sequence information for haplotype " + std::to_string(gt) + ".");
-                    std::string seq = node.seqs[gt];
-                    const auto fl = node_flanks(view, ni, hap, gt, seq, cfg.k - 1);
-                    seq = fl.first + seq + fl.second;
-                    if (seq.empty()) throw std::runtime_error("empty allele sequence (the reference aborts on assert(len > 0))");
-                    HapWork hw;
-                    hw.hap = hap;
-                    hw.gt = gt;
-                    hw.key_begin = keys.size();
-                    emitted_keys(seq, cfg.k, keys);
-                    hw.key_end = keys.size();
-                    nw.haps.push_back(hw);
-                    ++hap;
-                }
-                work.push_back(std::move(nw));
-                if (keys.size() >= chunk_keys) flush();
             }
-            flush();
         }
     }
     st.seconds_index = std::chrono::duration<double>(clock::now() - t_index).count();

@@ -28,6 +28,7 @@ struct ConstructConfig {                  // defaults: include/varigraph.hpp:49-
     uint32_t vcf_ploidy = 2;              // --vcf-ploidy
     bool fast = false;                    // --fast
     bool use_unique_kmers = false;        // --use-unique-kmers
+    uint32_t threads = 10;                // -t: host threads of the indexing phases
     std::vector<uint64_t> bloom_seeds;    // empty: drawn like BloomFilter::_init_seeds from random_device_value
     uint32_t random_device_value = 0;
 };

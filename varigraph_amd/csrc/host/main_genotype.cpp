@@ -281,7 +281,7 @@ int main_construct(int argc, char** argv)
         case 4: c.use_unique_kmers = true; break;
         case 7: gpu = std::stoi(optarg); break;
         case 8: buffer_mib = std::stoi(optarg); break;
-        case 't': break;   // accepted for command-line compatibility
+        case 't': c.threads = (uint32_t)std::max(std::stoi(optarg), 1); break;
         default:
             std::cerr << "Usage: construct -r FASTA -v VCF [--save-graph FILE] [-k INT] [--vcf-ploidy INT] [--fast] "
                          "[--use-unique-kmers] [--gpu INT] [--buffer INT]\n";
