@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """End-to-end at a chosen scale, everything from files (SURVEY 8d level iii): synthetic reference + cohort VCF +
-30x paired reads of VCF sample 0 -> the UNMODIFIED reference builds graph.bin (`construct`) -> `genotype` by (a) the
-all-CPU reference and (b) the native CLI varigraph-mi (device counting, own HMM) -> VCFs compared byte for byte.
+30x paired reads of VCF sample 0 -> `construct` by the UNMODIFIED reference and by varigraph-mi (graph.bin compared byte
+for byte) -> `genotype` by (a) the all-CPU reference and (b) varigraph-mi (device counting, own HMM) -> VCFs compared
+byte for byte.
 Needs oracle/_ref/varigraph_det (test infrastructure; it travels to the GPU box as a prebuilt binary)."""
 import argparse, gzip, json, os, shutil, subprocess, sys, tempfile, time
 
@@ -36,6 +37,7 @@ def main():
         fq = synth.write_fastq_pair(os.path.join(work, "s"), block, 2 * args.pairs, 150, gz=args.gz)
         out["synth_s"] = time.perf_counter() - t0
         graph = os.path.join(work, "graph.bin")
+        env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
         t0 = time.perf_counter()
         r = subprocess.run([ref_bin, "construct", "-r", fa, "-v", vcf, "--save-graph", graph, "-t", "32"], cwd=work,
                            capture_output=True, text=True)
@@ -45,7 +47,16 @@ def main():
             print(json.dumps(out))
             return
         out["graph_bytes"] = os.path.getsize(graph)
-        env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+        graph_native = os.path.join(work, "graph_native.bin")
+        t0 = time.perf_counter()
+        r = subprocess.run([cli, "construct", "-r", fa, "-v", vcf, "--save-graph", graph_native, "-t", "32", "--gpu", "0"], cwd=work,
+                           capture_output=True, text=True, env=env)
+        out["native_construct_s"] = time.perf_counter() - t0
+        if r.returncode != 0:
+            out["native_construct_error"] = r.stderr[-400:]
+        else:
+            out["native_construct_log"] = [ln for ln in r.stderr.strip().split("\n") if "varigraph-mi]" in ln][-2:]
+            out["graph_identical"] = subprocess.run(["cmp", "-s", graph, graph_native]).returncode == 0
         vcfs = {}
         for name, exe, extra in (("reference_cpu", ref_bin, []), ("native_cli", cli, ["--gpu", "0"])):
             d = os.path.join(work, name)
