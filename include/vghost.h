@@ -64,6 +64,10 @@ int vgh_graph_upload(const vgh_graph *g, vgmi_ctx *ctx);
 /* FASTA/Q files -> '\n'-joined read block appended to a caller buffer (for tests of the parser).
  * Returns the number of reads, or <0.  *read_base gets sum(seq.l). */
 int64_t vgh_fastx_read_all(const char *path, char **block_out, size_t *n_bytes_out, uint64_t *read_base);
+/* same with `decode_threads` inflate workers for block-gzip (BGZF) input; source_kind (may be NULL) gets "plain",
+ * "gzip" or "bgzf": how the bytes were decoded (csrc/host/byte_source.hpp) */
+int64_t vgh_fastx_read_all_mt(const char *path, uint32_t decode_threads, char **block_out, size_t *n_bytes_out,
+                              uint64_t *read_base, char source_kind[8]);
 void vgh_free(void *p);
 
 /* construct side: ConstructIndex::build_fasta_index + make_mbf (src/construct_index.cpp:85-139,150-177)

@@ -219,3 +219,43 @@ def test_native_construct_then_genotype_and_errors(tmp_path):
     for bad in (["-r", str(tmp_path / "nope.fa"), "-v", os.path.join(d, "in.vcf")], ["-r", str(fa), "-v", str(tmp_path / "nope.vcf")],
                 ["-r", str(fa), "-v", os.path.join(d, "in.vcf"), "-k", "31"]):
         assert subprocess.run([CLI, "construct"] + bad, cwd=tmp_path, capture_output=True, timeout=300).returncode != 0
+
+
+def test_native_cli_block_gzip_and_plain_inputs(tmp_path):
+    """Ingest row: the same cohort with a bgzip'd VCF / reference for construct and block-gzip, plain and
+    gzip FASTQ for genotype gives the committed graph and one and the same VCF (byte_source.hpp picks the decoder)."""
+    if not os.path.exists(CLI):
+        pytest.skip("varigraph-mi not built")
+    import json
+    from varigraph_amd import synth
+    d = os.path.join(GOLDEN, "cohort_snp")
+    meta = json.load(open(os.path.join(d, "meta.json")))
+    fa = tmp_path / "ref.fa"
+    synth.write_fasta(str(fa), "chr1", synth.make_reference(meta["ref_len"], seed=meta["ref_seed"]))
+    synth.bgzf_compress_file(str(fa), str(tmp_path / "ref.fa.gz"), block=4000)
+    synth.bgzf_compress_file(os.path.join(d, "in.vcf"), str(tmp_path / "in.vcf.gz"), block=3000)
+    env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+    r = subprocess.run([CLI, "construct", "-r", "ref.fa.gz", "-v", "in.vcf.gz", "--save-graph", "g.bin", "-t", "4"], cwd=tmp_path,
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (tmp_path / "g.bin").read_bytes() == gzip.open(os.path.join(d, "graph.bin.gz"), "rb").read()
+    vcfs = {}
+    for kind in ("gz", "plain", "bgzf"):
+        fq = []
+        for i in (1, 2):
+            src = os.path.join(d, f"reads_{i}.fq.gz")
+            if kind == "gz":
+                fq.append(src)
+                continue
+            plain = tmp_path / f"reads_{i}.fq"
+            plain.write_bytes(gzip.open(src, "rb").read())
+            fq.append(str(plain) if kind == "plain" else synth.bgzf_compress_file(str(plain), str(tmp_path / f"reads_{i}.b.fq.gz")))
+        (tmp_path / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
+        r = subprocess.run([CLI, "genotype", "--load-graph", "g.bin", "-s", "samples.cfg", "-t", "6"], cwd=tmp_path,
+                           capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        vcfs[kind] = gzip.open(tmp_path / "sample0.varigraph.vcf.gz", "rb").read()
+    assert vcfs["plain"] == vcfs["gz"] and vcfs["bgzf"] == vcfs["gz"]
+    want = open(os.path.join(d, "expected_het.vcf"), "rb").read() if os.path.exists(os.path.join(d, "expected_het.vcf")) else None
+    if want is not None:
+        assert _strip_gq(vcfs["gz"]) == _strip_gq(want)

@@ -217,3 +217,74 @@ def test_hand_scheduled_registers_untouched_by_compiler():
                        timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("0 scratch accesses") == 2, r.stdout
+
+
+def _bgzf_bytes(data, block=0xff00, level=6, eof_marker=True):
+    """What bgzip writes: gzip members of <= 64 KiB with the 'BC' extra field (SAM spec 4.1)."""
+    import struct
+    import zlib
+    out = []
+    for o in range(0, len(data), block):
+        d = data[o:o + block]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        cd = c.compress(d) + c.flush()
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(cd) + 25) + cd +
+                   struct.pack("<II", zlib.crc32(d), len(d)))
+    if eof_marker:
+        out.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return out
+
+
+def test_byte_sources_deliver_what_gzread_would(tmp_path):
+    """Ingest row: plain / gzip stream / block gzip inputs give the same records; concatenated members are
+    followed, trailing garbage is ignored, a damaged or truncated stream ends the file where gzread would return -1."""
+    rng = np.random.default_rng(7)
+    n = 40000
+    lens = rng.integers(30, 151, size=n)
+    ends = np.cumsum(lens)
+    pool = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(ends[-1]))].tobytes()
+    seqs = [pool[e - l:e] for e, l in zip(ends, lens)]
+    fq = b"".join(b"@r%d x\n%s\n+\n%s\n" % (i, s, b"I" * len(s)) for i, s in enumerate(seqs))
+    want = block_from_seqs(seqs)
+
+    def rd(name, payload, threads=1):
+        p = tmp_path / name
+        p.write_bytes(payload)
+        b, cnt, rb, kind = host.fastx_read_all(str(p), decode_threads=threads, with_kind=True)
+        return bytes(b), cnt, kind
+
+    assert rd("a.fq", fq) == (want.tobytes(), n, "plain")
+    assert rd("a.fq.gz", gzip.compress(fq)) == (want.tobytes(), n, "gzip")
+    # concatenated members, the boundary inside a record; then bytes that are no gzip header
+    cut = len(fq) // 2 + 7
+    two = gzip.compress(fq[:cut]) + gzip.compress(fq[cut:])
+    assert rd("two.fq.gz", two) == (want.tobytes(), n, "gzip")
+    assert rd("junk.fq.gz", two + b"not gzip at all") == (want.tobytes(), n, "gzip")
+    assert rd("junk1.fq.gz", two + b"\x1f") == (want.tobytes(), n, "gzip")
+    # truncated stream: the records before the cut still arrive, nothing after
+    tb, tcnt, _ = rd("trunc.fq.gz", gzip.compress(fq)[: len(gzip.compress(fq)) // 2])
+    assert 0 < tcnt < n and want.tobytes().startswith(tb[: tb.rfind(b"\n", 0, len(tb) - 1) + 1][:1000])
+    # block gzip, 1..8 inflate workers, with and without the EOF marker block
+    blocks = _bgzf_bytes(fq)
+    assert len(blocks) > 100   # several worker tasks
+    for t in (1, 2, 3, 8):
+        assert rd("b.fq.gz", b"".join(blocks), t) == (want.tobytes(), n, "bgzf")
+    assert rd("b2.fq.gz", b"".join(_bgzf_bytes(fq, block=1000, eof_marker=False)), 4) == (want.tobytes(), n, "bgzf")
+    # an ordinary gzip member after some BGZF blocks (cat a.gz b.gz): the stream decoder takes over
+    k = len(blocks) // 2
+    part = sum(0xff00 for _ in range(k))
+    mixed = b"".join(blocks[:k]) + gzip.compress(fq[part:])
+    assert rd("mixed.fq.gz", mixed, 4) == (want.tobytes(), n, "bgzf")
+    # a block with a wrong CRC: everything before it, nothing after it
+    bad = bytearray(blocks[5])
+    bad[-8] ^= 0xFF
+    got, cnt, _ = rd("bad.fq.gz", b"".join(blocks[:5]) + bytes(bad) + b"".join(blocks[6:]), 4)
+    ref_b, ref_cnt, _ = rd("bad_ref.fq", fq[: 5 * 0xff00])
+    # the plain prefix may end in a partial record that kseq still accepts FASTA-style; compare complete records
+    assert cnt in (ref_cnt, ref_cnt - 1) and ref_b.startswith(got[: got.rfind(b"\n", 0, len(got) - 1) + 1])
+    # BGZF file cut in the middle of a block
+    cutb = b"".join(blocks)[: sum(len(b) for b in blocks[:7]) + 100]
+    got, cnt, _ = rd("cutb.fq.gz", cutb, 4)
+    assert 0 < cnt < n and want.tobytes().startswith(got[: got.rfind(b"\n", 0, len(got) - 1) + 1])
+    with pytest.raises(RuntimeError, match="No such file"):
+        host.fastx_read_all(str(tmp_path / "missing.fq.gz"))

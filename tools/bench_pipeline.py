@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sample-level (end-to-end) rate: FASTQ files on disk -> counters on the host, through the C++
-FastqKmerHip pipeline (parser threads -> pinned staging -> HIP), next to the unmodified reference
-on the same files.  SURVEY 8d metric level (ii)."""
+FastqKmerHip pipeline (inflate thread(s) -> parser thread per file -> pinned staging -> HIP) for plain, gzip and
+block-gzip (BGZF) copies of the same reads, next to the unmodified reference on the same files.  SURVEY 8d metric level (ii)."""
 import json
 import os
 import subprocess
@@ -34,15 +34,16 @@ def main():
             with open(p, "rb") as fi, gzip.open(p + ".gz", "wb", compresslevel=4) as fo:
                 shutil.copyfileobj(fi, fo, 1 << 24)
             gz.append(p + ".gz")
+        bgz = [synth.bgzf_compress_file(p, p + ".bgz.gz", level=4) for p in plain]
         g = host.Graph(os.path.join(ROOT, "tests", "golden", "c1", "graph.bin.gz"))
         ctx = vgmi.Context(0, buffer_mib=128)
         g.upload(ctx)
         ref_cov = None
-        for label, files in (("plain", plain), ("gz", gz)):
+        for label, files, threads in (("plain", plain, 2), ("gz", gz, 2), ("bgzf_t4", bgz, 4), ("bgzf_t16", bgz, 16)):
             best = None
             for _ in range(2):
                 t0 = time.perf_counter()
-                cov, _, _, st = g.sample_count(ctx, files, threads=2)
+                cov, _, _, st = g.sample_count(ctx, files, threads=threads)
                 dt = time.perf_counter() - t0
                 best = dt if best is None or dt < best else best
             out[f"hip_{label}_reads_per_s"] = n_reads / best

@@ -1,0 +1,29 @@
+// byte_source.hpp -- the bytes of an input file as zlib's gzopen/gzread would deliver them (what the reference
+// reads through: kseq over gzFile, include/kseq.h:59-72 with src/fastq_kmer.cpp:74-78; GzChunkReader for VCFs), with
+// the inflate work taken off the parsing thread:
+//   plain file            read(2) in 256 KiB chunks (gzopen's transparent mode)
+//   gzip stream           one decode thread per file running zlib's inflate ahead of the parser (concatenated members
+//                         are followed, bytes after the last member that are not a gzip header are ignored -- gz_look)
+//   block gzip (BGZF)     members carrying the 'BC' extra field (bgzip, htslib): the block sizes are in the headers,
+//                         so `decode_threads` workers inflate blocks side by side and the chunks come back in order
+// A damaged stream delivers what decoded before the damage and then ends, like the reference's
+// `while (kseq_read(ks) >= 0)` loop does when gzread returns -1.
+#pragma once
+#include <cstddef>
+#include <memory>
+#include <string>
+
+namespace vgh {
+
+class ByteSource {
+public:
+    virtual ~ByteSource() = default;
+    // next run of bytes (owned by the source, valid until the next call); false at the end of the data
+    virtual bool next_chunk(const unsigned char*& p, size_t& n) = 0;
+    virtual const char* kind() const = 0;   // "plain" | "gzip" | "bgzf"
+
+    // throws std::runtime_error("'<path>': No such file or directory.") like the callers' gzopen checks
+    static std::unique_ptr<ByteSource> open(const std::string& path, unsigned decode_threads = 1);
+};
+
+}  // namespace vgh

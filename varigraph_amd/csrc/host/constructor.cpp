@@ -1,7 +1,6 @@
 // constructor.cpp -- see constructor.hpp
 #include "constructor.hpp"
 
-#include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
@@ -74,36 +73,35 @@ std::vector<std::string> gt_split(const std::string& gt)
     return out;
 }
 
-// line reader over gzopen (plain or gzip), lines without their '\n' (include/GzChunkReader.hpp)
+// lines of a plain / gzip / block-gzip file without their '\n' (include/GzChunkReader.hpp reads through gzopen);
+// cohort VCFs are usually bgzip'd, whose blocks inflate on `decode_threads` workers (byte_source.hpp)
 struct LineReader {
-    gzFile f;
-    std::vector<char> buf;
-    size_t pos = 0, end = 0;
-    explicit LineReader(const std::string& path) : f(gzopen(path.c_str(), "rb")), buf(1 << 20)
-    {
-        if (!f) throw std::runtime_error("'" + path + "': No such file or directory.");
-    }
-    ~LineReader() { gzclose(f); }
+    std::unique_ptr<ByteSource> src;
+    const unsigned char* cur = nullptr;
+    const unsigned char* end = nullptr;
+    bool eof = false;
+    LineReader(const std::string& path, unsigned decode_threads) : src(ByteSource::open(path, decode_threads)) {}
     bool next(std::string& line)
     {
         line.clear();
         for (;;) {
-            if (pos == end) {
-                if (gzeof(f)) return !line.empty();
-                const int n = gzread(f, buf.data(), (unsigned)buf.size());
-                if (n <= 0) return !line.empty();
-                pos = 0;
-                end = (size_t)n;
+            if (cur == end) {
+                size_t n = 0;
+                if (eof || !src->next_chunk(cur, n) || n == 0) {
+                    eof = true;
+                    cur = end = nullptr;
+                    return !line.empty();
+                }
+                end = cur + n;
             }
-            const char* b = buf.data() + pos;
-            const char* nl = static_cast<const char*>(memchr(b, '\n', end - pos));
+            const unsigned char* nl = static_cast<const unsigned char*>(memchr(cur, '\n', (size_t)(end - cur)));
             if (nl) {
-                line.append(b, nl - b);
-                pos += (size_t)(nl - b) + 1;
+                line.append(reinterpret_cast<const char*>(cur), (size_t)(nl - cur));
+                cur = nl + 1;
                 return true;
             }
-            line.append(b, end - pos);
-            pos = end;
+            line.append(reinterpret_cast<const char*>(cur), (size_t)(end - cur));
+            cur = end;
         }
     }
 };
@@ -204,7 +202,7 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
     {
         uint32_t prev_start = 0, prev_end = 0;
         std::string prev_chr;
-        LineReader lr(cfg.vcf);
+        LineReader lr(cfg.vcf, std::max(2u, cfg.threads));
         std::string line;
         auto ref_only_node = [&](const std::string& chr, uint32_t start, const std::string& seq) {
             GraphNode& n = graph[chr][start];

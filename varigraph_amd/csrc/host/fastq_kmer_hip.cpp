@@ -30,7 +30,7 @@ struct Channel {  // parser threads -> submitting thread
     std::string error;
 };
 
-void parse_file(const std::string& path, Channel& ch, size_t block_bytes)
+void parse_file(const std::string& path, Channel& ch, size_t block_bytes, unsigned decode_threads)
 {
     auto grab = [&]() {
         std::unique_lock<std::mutex> lk(ch.mu);
@@ -48,7 +48,7 @@ void parse_file(const std::string& path, Channel& ch, size_t block_bytes)
         ch.cv_full.notify_one();
     };
     try {
-        FastxReader rd(path);
+        FastxReader rd(path, decode_threads);
         std::unique_ptr<Block> cur = grab();
         while (rd.next() >= 0) {  // stops at EOF (-1) and at the first truncated record (-2)
             const std::string& s = rd.seq();
@@ -99,6 +99,8 @@ void FastqKmerHip::build_fastq_index()
 
     Channel ch;
     const size_t n_par = std::min<size_t>(threads_, files_.size());
+    // block-gzip inputs: the threads not parsing inflate blocks (byte_source.hpp); at least 2 per file
+    const unsigned decode_threads = std::max<unsigned>(2u, (unsigned)(threads_ / n_par));
     for (size_t i = 0; i < 2 * n_par + 1; ++i) {
         auto b = std::make_unique<Block>();
         b->bytes.reserve(block_bytes_ + 1024);
@@ -109,7 +111,7 @@ void FastqKmerHip::build_fastq_index()
     auto start_more = [&]() {  // called with ch.mu held
         while (ch.producers < n_par && next_file < files_.size()) {
             ch.producers++;
-            workers.emplace_back(parse_file, files_[next_file++], std::ref(ch), block_bytes_);
+            workers.emplace_back(parse_file, files_[next_file++], std::ref(ch), block_bytes_, decode_threads);
         }
     };
     std::string err;

@@ -5,51 +5,39 @@
 
 namespace vgh {
 
-static const int kBufSize = 1 << 18;
+FastxReader::FastxReader(const std::string& path, unsigned decode_threads) : src_(ByteSource::open(path, decode_threads)) {}
 
-FastxReader::FastxReader(const std::string& path)
-{
-    fp_ = gzopen(path.c_str(), "rb");
-    if (!fp_) throw std::runtime_error("'" + path + "': No such file or directory.");
-    gzbuffer(fp_, 1 << 20);
-    buf_ = new unsigned char[kBufSize];
-}
+FastxReader::~FastxReader() = default;
 
-FastxReader::~FastxReader()
+bool FastxReader::refill()
 {
-    if (fp_) gzclose(fp_);
-    delete[] buf_;
+    if (eof_) return false;
+    size_t n = 0;
+    if (!src_->next_chunk(cur_, n) || n == 0) {
+        eof_ = true;
+        cur_ = end_ = nullptr;
+        return false;
+    }
+    end_ = cur_ + n;
+    return true;
 }
 
 int FastxReader::getc()
 {
-    if (begin_ >= end_) {
-        if (eof_) return -1;
-        begin_ = 0;
-        end_ = gzread(fp_, buf_, kBufSize);
-        if (end_ < kBufSize) eof_ = true;
-        if (end_ <= 0) { end_ = 0; return -1; }
-    }
-    return buf_[begin_++];
+    if (cur_ >= end_ && !refill()) return -1;
+    return *cur_++;
 }
 
 bool FastxReader::get_line(std::string& s, bool append)
 {
     if (!append) s.clear();
-    if (begin_ >= end_ && eof_) return false;
+    if (cur_ >= end_ && !refill()) return false;
     for (;;) {
-        if (begin_ >= end_) {
-            if (eof_) break;
-            begin_ = 0;
-            end_ = gzread(fp_, buf_, kBufSize);
-            if (end_ < kBufSize) eof_ = true;
-            if (end_ <= 0) { end_ = 0; break; }
-        }
-        const unsigned char* nl = static_cast<const unsigned char*>(memchr(buf_ + begin_, '\n', (size_t)(end_ - begin_)));
-        const int i = nl ? (int)(nl - buf_) : end_;
-        s.append(reinterpret_cast<const char*>(buf_ + begin_), (size_t)(i - begin_));
-        begin_ = i + 1;
-        if (nl) break;
+        const unsigned char* nl = static_cast<const unsigned char*>(memchr(cur_, '\n', (size_t)(end_ - cur_)));
+        const unsigned char* stop = nl ? nl : end_;
+        s.append(reinterpret_cast<const char*>(cur_), (size_t)(stop - cur_));
+        cur_ = nl ? nl + 1 : end_;
+        if (nl || !refill()) break;
     }
     if (s.size() > 1 && s.back() == '\r') s.pop_back();  // kseq.h: KS_SEP_LINE strips one trailing '\r'
     return true;

@@ -7,18 +7,20 @@
 //   * FASTQ: the rest of the '+' line is skipped, quality lines are appended until they are at
 //     least as long as the sequence; a length mismatch or a missing quality is a truncated record
 //     (-2) and the reference's `while (kseq_read(ks) >= 0)` loop stops reading the file there
-//   * the file is opened with gzopen, so plain and gzip inputs both work
+//   * the bytes come from a ByteSource (plain, gzip or block-gzip input, as gzopen would deliver them) whose
+//     inflate runs on its own thread(s), `decode_threads` of them for block gzip
 #pragma once
-#include <zlib.h>
-
 #include <cstdint>
+#include <memory>
 #include <string>
+
+#include "byte_source.hpp"
 
 namespace vgh {
 
 class FastxReader {
 public:
-    explicit FastxReader(const std::string& path);  // throws std::runtime_error if it cannot open
+    explicit FastxReader(const std::string& path, unsigned decode_threads = 1);  // throws std::runtime_error if it cannot open
     ~FastxReader();
     FastxReader(const FastxReader&) = delete;
     FastxReader& operator=(const FastxReader&) = delete;
@@ -27,15 +29,18 @@ public:
     long next();
     const std::string& seq() const { return seq_; }
     const std::string& name() const { return name_; }  // up to the first whitespace of the header line
+    const char* source_kind() const { return src_->kind(); }
 
 private:
     int getc();
     // append up to (not including) the next '\n' to s; returns false at EOF with nothing read
     bool get_line(std::string& s, bool append);
 
-    gzFile fp_;
-    unsigned char* buf_;
-    int begin_ = 0, end_ = 0;
+    bool refill();   // false at the end of the data
+
+    std::unique_ptr<ByteSource> src_;
+    const unsigned char* cur_ = nullptr;
+    const unsigned char* end_ = nullptr;
     bool eof_ = false;
     int last_char_ = 0;
     std::string seq_, qual_, name_;

@@ -86,11 +86,16 @@ int vgh_graph_upload(const vgh_graph* h, vgmi_ctx* ctx)
     return rc;
 }
 
-int64_t vgh_fastx_read_all(const char* path, char** block_out, size_t* n_bytes_out, uint64_t* read_base)
+int64_t vgh_fastx_read_all_mt(const char* path, uint32_t decode_threads, char** block_out, size_t* n_bytes_out,
+                              uint64_t* read_base, char source_kind[8])
 {
     if (!path || !block_out || !n_bytes_out) return VGMI_E_INVALID;
     try {
-        vgh::FastxReader rd(path);
+        vgh::FastxReader rd(path, decode_threads ? decode_threads : 1);
+        if (source_kind) {
+            strncpy(source_kind, rd.source_kind(), 7);
+            source_kind[7] = 0;
+        }
         std::string block;
         int64_t n = 0;
         uint64_t rb = 0;
@@ -112,6 +117,11 @@ int64_t vgh_fastx_read_all(const char* path, char** block_out, size_t* n_bytes_o
         g_err = e.what();
         return VGMI_E_INVALID;
     }
+}
+
+int64_t vgh_fastx_read_all(const char* path, char** block_out, size_t* n_bytes_out, uint64_t* read_base)
+{
+    return vgh_fastx_read_all_mt(path, 1, block_out, n_bytes_out, read_base, nullptr);
 }
 
 void vgh_free(void* p) { free(p); }

@@ -51,6 +51,9 @@ def lib():
     l.vgh_graph_upload.restype = C.c_int; l.vgh_graph_upload.argtypes = [vp, vp]
     l.vgh_fastx_read_all.restype = C.c_int64
     l.vgh_fastx_read_all.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]
+    l.vgh_fastx_read_all_mt.restype = C.c_int64
+    l.vgh_fastx_read_all_mt.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64),
+                                        C.c_char_p]
     l.vgh_free.restype = None; l.vgh_free.argtypes = [vp]
     l.vgh_sample_count.restype = C.c_int
     l.vgh_sample_count.argtypes = [vp, vp, C.POINTER(C.c_char_p), C.c_size_t, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp,
@@ -208,17 +211,21 @@ def load_graph(path):
         g.close()
 
 
-def fastx_read_all(path):
-    """All records of a FASTA/Q(.gz) file as a '\\n'-joined block (kseq_read semantics)."""
+def fastx_read_all(path, decode_threads=1, with_kind=False):
+    """All records of a FASTA/Q(.gz) file as a '\\n'-joined block (kseq_read semantics).  with_kind: also how the
+    bytes were decoded ("plain" | "gzip" | "bgzf", csrc/host/byte_source.hpp)."""
     l = lib()
     p, n, rb = C.c_void_p(), C.c_size_t(), C.c_uint64()
-    cnt = l.vgh_fastx_read_all(os.fsencode(path), C.byref(p), C.byref(n), C.byref(rb))
+    kind = C.create_string_buffer(8)
+    cnt = l.vgh_fastx_read_all_mt(os.fsencode(path), decode_threads, C.byref(p), C.byref(n), C.byref(rb), kind)
     if cnt < 0:
         raise RuntimeError(l.vgh_last_error().decode())
     try:
         block = _arr(p.value, n.value, np.uint8)
     finally:
         l.vgh_free(p)
+    if with_kind:
+        return block, int(cnt), rb.value, kind.value.decode()
     return block, int(cnt), rb.value
 
 

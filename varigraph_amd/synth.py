@@ -158,3 +158,21 @@ def snp_kmer_keys(ref, positions, alts, k=27):
             canon = np.minimum(fwd, rc)
             out.append((hash64_np(canon, k) << np.uint64(8)) | np.uint64(k))
     return np.unique(np.concatenate(out))
+
+
+def bgzf_compress_file(src, dst, level=4, block=0xff00):
+    """Block-gzip (BGZF, what bgzip / htslib write: SAM spec 4.1) copy of `src`: gzip members of <= 64 KiB whose
+    extra field 'BC' carries the member size, closed by the empty EOF block."""
+    import struct
+    import zlib
+    with open(src, "rb") as fi, open(dst, "wb") as fo:
+        while True:
+            d = fi.read(block)
+            if not d:
+                break
+            c = zlib.compressobj(level, zlib.DEFLATED, -15)
+            cd = c.compress(d) + c.flush()
+            fo.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(cd) + 25) + cd +
+                     struct.pack("<II", zlib.crc32(d), len(d)))
+        fo.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return dst
