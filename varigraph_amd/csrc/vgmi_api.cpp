@@ -33,7 +33,8 @@ struct ImageHeader {  // first 256 bytes of the table image
     uint64_t off_slots, off_key_slot, off_filter, off_grid, total_bytes;
     uint32_t grid_words_log2;
     uint32_t slot_bytes;   // 16: VgSlot, 8: compact k-mer words (vgmi_device.h)
-    uint8_t pad[256 - 8 - 4 - 4 - 8 - 8 - 40 - 8];
+    uint32_t home_bucket_log2;   // 0: vg_thash home slots, else minimiser buckets (vg_thash_local)
+    uint8_t pad[256 - 8 - 4 - 4 - 8 - 8 - 40 - 8 - 4];
 };
 static_assert(sizeof(ImageHeader) == 256, "image header is 256 bytes");
 
@@ -173,6 +174,14 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     if (const char* e = getenv("VGMI_TABLE_MUL")) lf_mul = (uint64_t)atoi(e) > 1 ? (uint64_t)atoi(e) : 2;
     while (cap < lf_mul * n_keys) cap <<= 1;
     h.cap = cap;
+    // tables that live in HBM (k = 27, global grid filter): home slots in minimiser buckets of 32 slots (512 bytes), so
+    // the k-mers of neighbouring read positions probe the same few lines (vg_thash_local; VGMI_LOCALITY=0 switches
+    // it off, another value sets the bucket size)
+    h.home_bucket_log2 = 0;
+    if (k == 27 && !compact && n_keys > VG_GRID_LDS_MAX_KEYS) {
+        h.home_bucket_log2 = 5;
+        if (const char* e = getenv("VGMI_LOCALITY")) h.home_bucket_log2 = (uint32_t)atoi(e) < 16 ? (uint32_t)atoi(e) : 5;
+    }
     // prefilter: >= 16 bits per key, power of two, at least 128 bits
     uint64_t bits = 128;
     while (bits < 16 * n_keys) bits <<= 1;
@@ -213,6 +222,7 @@ int adopt_image(vgmi_ctx* c)
     c->tv.slots = compact ? nullptr : reinterpret_cast<VgSlot*>(c->d_image + h.off_slots);
     c->tv.slots8 = compact ? reinterpret_cast<unsigned long long*>(c->d_image + h.off_slots) : nullptr;
     c->tv.cap_mask = h.cap - 1;
+    c->tv.home_bucket_log2 = h.home_bucket_log2;
     c->tv.filter = reinterpret_cast<const uint32_t*>(c->d_image + h.off_filter);
     c->tv.filter_words_log2 = h.filter_words_log2;
     c->tv.filter_shift = 32 - h.filter_words_log2;
@@ -228,8 +238,9 @@ int adopt_image(vgmi_ctx* c)
     c->tv.counts = nullptr;
     c->n_counts = 0;
     if (compact) c->n_counts = h.cap;                                   // per-slot counters
-    else if (h.n_keys > VG_GRID_LDS_MAX_KEYS) c->n_counts = h.n_keys;   // large graph: 4 B/key dense counters stay
-                                                                        // Infinity-Cache resident
+    else if (h.n_keys > VG_GRID_LDS_MAX_KEYS && (h.home_bucket_log2 == 0 || getenv("VGMI_DENSE_COUNTS")))
+        c->n_counts = h.n_keys;   // randomly placed slots: 4 B/key dense counters stay Infinity-Cache resident
+    // (minimiser buckets: the counter lives in the slot, the atomic hits the line its probe has just fetched)
     if (c->n_counts) {
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_counts), c->n_counts * 4));
         HIPCHK(c, hipMemset(c->d_counts, 0, c->n_counts * 4));

@@ -231,4 +231,25 @@ VG_HD uint64_t vg_thash(uint64_t kmer)
     return h;
 }
 
+// locality variant of the home slot (k = 27, tables that live in HBM): the bucket is drawn from the k-mer's MINIMISER
+// -- the smallest hash among its twelve canonical 16-mers -- so the k-mers of consecutive read positions, which share
+// their minimiser for ~6 positions on average, have their home slots inside the same 1 << bucket_log2 slots (one or
+// two 128-byte lines) instead of twelve random sectors.  The position inside the bucket comes from the whole k-mer.
+// `rc` is the reverse complement of `canon` (window off of one is the reverse complement of window 11 - off of the
+// other, so the twelve canonical 16-mers need no per-window reversal).
+VG_HD uint64_t vg_thash_local(uint64_t canon, uint64_t rc, uint32_t bucket_log2)
+{
+    uint32_t best = 0xFFFFFFFFu;
+    for (uint32_t off = 0; off < 12; ++off) {
+        const uint32_t m = (uint32_t)(canon >> (2 * off)), r = (uint32_t)(rc >> (2 * (11 - off)));
+        uint32_t h = (m < r ? m : r) * 0x9E3779B1u;
+        h ^= h >> 15;
+        best = h < best ? h : best;
+    }
+    uint32_t b = best * 0x85EBCA77u;
+    b ^= b >> 13;
+    const uint32_t sub = (uint32_t)canon * 0x9E3779B1u + (uint32_t)(canon >> 32) * 0x85EBCA77u;
+    return ((uint64_t)b << bucket_log2) | (sub >> (32 - bucket_log2));
+}
+
 #endif

@@ -14,6 +14,7 @@ struct TableView {
     VgSlot* slots;              // cap entries (16-byte format) or nullptr
     unsigned long long* slots8; // cap k-mer words (compact 8-byte format) or nullptr
     uint64_t cap_mask;          // cap - 1 (cap is a power of two)
+    uint32_t home_bucket_log2;  // 0: home slot = vg_thash; else minimiser buckets of 1 << this slots (vg_thash_local)
     const uint32_t* filter;     // blocked-Bloom prefilter, 1 << filter_words_log2 words
     uint32_t filter_words_log2; // >= 2
     uint32_t filter_shift;      // 32 - filter_words_log2

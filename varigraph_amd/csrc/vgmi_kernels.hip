@@ -89,9 +89,15 @@ __device__ __forceinline__ uint32_t* count_cell(const TableView& t, uint64_t s, 
 }
 
 // exact-table probe + saturating count of one canonical k-mer (generic kernels; either table format)
+__device__ __forceinline__ uint64_t table_home(const TableView& t, uint64_t canon)
+{
+    if (t.home_bucket_log2) return vg_thash_local(canon, vg_revcomp(canon, 27), t.home_bucket_log2) & t.cap_mask;
+    return vg_thash(canon) & t.cap_mask;
+}
+
 __device__ __forceinline__ void table_count(const TableView& t, uint64_t canon)
 {
-    uint64_t s = vg_thash(canon) & t.cap_mask;
+    uint64_t s = table_home(t, canon);
     if (t.slots8) {   // compact format: k-mer words, per-slot counters
         for (;;) {
             const uint64_t c = t.slots8[s];
@@ -569,6 +575,7 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
     unsigned long long* const slots8 = p.table.slots8;   // compact format (LDS-filter variant)
     uint32_t* const counts = p.table.counts;
     const uint64_t cap_mask = p.table.cap_mask;
+    const uint32_t hb_log2 = p.table.home_bucket_log2;
 
     // rows [0, row_end) are complete 768-byte rows (row_end is even, see vgmi_api.cpp), so every load below is an
     // unconditional, perfectly coalesced dwordx3 (the ragged tail goes to rows_kernel).  A wave walks a
@@ -621,7 +628,8 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
         const uint64_t rc = vg_revcomp(kmer, 27);
         const uint64_t canon = kmer < rc ? kmer : rc;   // idempotent for re-queued (already canonical) entries
         b_canon = canon | (dist << 54);
-        b_slot = (vg_thash(canon) + dist) & cap_mask;
+        const uint64_t home = (!LDS_BM && hb_log2) ? vg_thash_local(canon, canon == kmer ? rc : kmer, hb_log2) : vg_thash(canon);
+        b_slot = (home + dist) & cap_mask;
         b_active = act;
         if (act) vm_load_slot<LDS_BM>(LDS_BM ? (const void*)&slots8[b_slot] : (const void*)&slots[b_slot]);
         ++n_after_row;
@@ -927,7 +935,7 @@ __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t 
         return;
     }
     const uint64_t canon = vg_hash64_inv(key >> 8, mask);
-    uint64_t s = vg_thash(canon) & t.cap_mask;
+    uint64_t s = table_home(t, canon);
     for (;;) {
         unsigned long long* cell = t.slots8 ? &t.slots8[s] : &t.slots[s].canon;
         const unsigned long long prev = atomicCAS(cell, (unsigned long long)VG_EMPTY, (unsigned long long)canon);
