@@ -69,6 +69,8 @@ int64_t vgh_fastx_read_all(const char *path, char **block_out, size_t *n_bytes_o
 int64_t vgh_fastx_read_all_mt(const char *path, uint32_t decode_threads, char **block_out, size_t *n_bytes_out,
                               uint64_t *read_base, char source_kind[8]);
 void vgh_free(void *p);
+/* CRC-32 (gzip polynomial) of the ingest decoder, csrc/host/fast_inflate.hpp (for tests) */
+uint32_t vgh_crc32(uint32_t crc, const void *data, size_t n);
 
 /* construct side: ConstructIndex::build_fasta_index + make_mbf (src/construct_index.cpp:85-139,150-177)
  * with the Bloom filter on the device.  seeds == NULL: the seeds BloomFilter::_init_seeds

@@ -261,6 +261,39 @@ def test_byte_sources_deliver_what_gzread_would(tmp_path):
     assert rd("two.fq.gz", two) == (want.tobytes(), n, "gzip")
     assert rd("junk.fq.gz", two + b"not gzip at all") == (want.tobytes(), n, "gzip")
     assert rd("junk1.fq.gz", two + b"\x1f") == (want.tobytes(), n, "gzip")
+    # every block type and header field the decoder (csrc/host/fast_inflate.cpp) has to handle: stored, fixed and dynamic
+    # Huffman blocks, literal-only and run-length streams, sync/full flush points, FEXTRA/FNAME/FCOMMENT/FHCRC
+    import struct
+    import zlib
+
+    def member(d, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, flush_every=0, fields=False):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+        if flush_every:
+            body = b"".join(c.compress(d[i:i + flush_every]) + c.flush(zlib.Z_SYNC_FLUSH if (i // flush_every) % 3 else zlib.Z_FULL_FLUSH)
+                            for i in range(0, len(d), flush_every)) + c.flush()
+        else:
+            body = c.compress(d) + c.flush()
+        h = b"\x1f\x8b\x08" + bytes([0x1E if fields else 0]) + b"\0\0\0\0\0\xff"
+        if fields:
+            h += struct.pack("<H", 7) + b"ab\x03\x00xyz" + b"reads.fq\0" + b"a comment\0"
+            h += struct.pack("<H", zlib.crc32(h) & 0xFFFF)
+        return h + body + struct.pack("<II", zlib.crc32(d), len(d) & 0xFFFFFFFF)
+
+    part = fq[: len(fq) // 8]
+    part = part[: part.rfind(b"\n@r") + 1]
+    (tmp_path / "part.fq").write_bytes(part)
+    ref_part = bytes(host.fastx_read_all(str(tmp_path / "part.fq"))[0])
+    for name, payload in (("l0", member(part, 0)), ("l1", member(part, 1)), ("l9", member(part, 9)),
+                          ("fixed", member(part, 6, zlib.Z_FIXED)), ("huff", member(part, 6, zlib.Z_HUFFMAN_ONLY)),
+                          ("rle", member(part, 6, zlib.Z_RLE)), ("flush", member(part, 6, flush_every=777)),
+                          ("fields", member(part, 6, fields=True)),
+                          ("chain", member(part[:5000], 0) + member(b"") + member(part[5000:], 9, fields=True))):
+        got, _, kind = rd(name + ".fq.gz", payload)
+        assert kind == "gzip" and got == ref_part, name
+    # a flipped bit in the trailer CRC: all data arrives (the reference's gzread also hands it over before it fails)
+    bad_crc = bytearray(member(part, 6))
+    bad_crc[-6] ^= 0x40
+    assert rd("badcrc.fq.gz", bytes(bad_crc))[0] == ref_part
     # truncated stream: the records before the cut still arrive, nothing after
     tb, tcnt, _ = rd("trunc.fq.gz", gzip.compress(fq)[: len(gzip.compress(fq)) // 2])
     assert 0 < tcnt < n and want.tobytes().startswith(tb[: tb.rfind(b"\n", 0, len(tb) - 1) + 1][:1000])

@@ -5,6 +5,7 @@
 #include <zlib.h>
 
 #include <condition_variable>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <deque>
@@ -12,6 +13,8 @@
 #include <stdexcept>
 #include <thread>
 #include <vector>
+
+#include "fast_inflate.hpp"
 
 namespace vgh {
 
@@ -65,9 +68,13 @@ private:
     size_t back_pos_ = 0;
 };
 
+constexpr size_t kHistory = 32768;       // room in front of a chunk's payload for the decoder's window (fast_inflate.hpp)
+constexpr size_t kSlack = 512;
+
 struct Chunk {
-    std::vector<unsigned char> data;
-    size_t n = 0;
+    std::vector<unsigned char> data;     // kHistory + payload capacity + kSlack
+    size_t n = 0;                        // payload bytes
+    unsigned char* payload() { return data.data() + kHistory; }
 };
 
 // filled chunks in order from one producer to the consumer, empty ones back
@@ -77,7 +84,7 @@ public:
     {
         for (size_t i = 0; i < n_chunks; ++i) {
             auto c = std::make_unique<Chunk>();
-            c->data.resize(bytes);
+            c->data.resize(kHistory + bytes + kSlack);
             free_.push_back(std::move(c));
         }
     }
@@ -134,8 +141,8 @@ private:
 };
 
 // zlib inflate over (concatenated) gzip members from the current position of `in` into `pipe`; returns when the
-// data ends (cleanly or not) or the pipe is cancelled
-void inflate_members(FileIn& in, Pipe& pipe)
+// data ends (cleanly or not) or the pipe is cancelled.  Kept as the cross-check of the decoder below (VGH_ZLIB_INFLATE=1).
+void inflate_members_zlib(FileIn& in, Pipe& pipe)
 {
     z_stream zs;
     std::memset(&zs, 0, sizeof zs);
@@ -152,11 +159,11 @@ void inflate_members(FileIn& in, Pipe& pipe)
         if (!cur) {
             cur = pipe.get_free();
             if (!cur) break;
-            zs.next_out = cur->data.data();
-            zs.avail_out = (uInt)cur->data.size();
+            zs.next_out = cur->payload();
+            zs.avail_out = (uInt)kChunk;
         }
         const int ret = inflate(&zs, Z_NO_FLUSH);
-        cur->n = cur->data.size() - zs.avail_out;
+        cur->n = kChunk - zs.avail_out;
         if (ret == Z_STREAM_END) {
             // another member?  (gz_look: fewer than two bytes left, or no gzip magic = trailing garbage, ignored)
             if (zs.avail_in < 2) {
@@ -183,6 +190,29 @@ void inflate_members(FileIn& in, Pipe& pipe)
         else pipe.recycle(std::move(cur));
     }
     inflateEnd(&zs);
+}
+
+// the same through this repo's decoder (fast_inflate.hpp): about twice zlib's rate
+void inflate_members(FileIn& in, Pipe& pipe)
+{
+    static const bool use_zlib = [] {
+        const char* e = getenv("VGH_ZLIB_INFLATE");
+        return e && e[0] == '1';
+    }();
+    if (use_zlib) return inflate_members_zlib(in, pipe);
+    std::unique_ptr<Chunk> cur;
+    GunzipIO io;
+    io.read = [&](unsigned char* dst, size_t n) { return in.read(dst, n); };
+    io.next_buffer = [&](size_t, size_t) -> unsigned char* {
+        cur = pipe.get_free();
+        return cur ? cur->payload() : nullptr;
+    };
+    io.commit = [&](size_t n) {
+        cur->n = n;
+        pipe.put_full(std::move(cur));
+    };
+    fast_gunzip(io, kChunk);
+    if (cur) pipe.recycle(std::move(cur));
 }
 
 class PlainSource final : public ByteSource {
@@ -220,7 +250,7 @@ public:
         if (held_) pipe_.recycle(std::move(held_));
         held_ = pipe_.take();
         if (!held_) return false;
-        p = held_->data.data();
+        p = held_->payload();
         n = held_->n;
         return true;
     }
@@ -421,7 +451,7 @@ private:
             if (!c) break;
             auto t = fresh_task();
             if (!t) { pipe.cancel(); break; }
-            t->out.assign(c->data.begin(), c->data.begin() + (long)c->n);
+            t->out.assign(c->payload(), c->payload() + c->n);
             t->out_n = c->n;
             pipe.recycle(std::move(c));
             dispatch(std::move(t), true);
@@ -456,7 +486,7 @@ private:
                 zs.avail_out = b.out_len;
                 const int ret = inflate(&zs, Z_FINISH);
                 if (ret != Z_STREAM_END || zs.avail_out != 0 ||
-                    (uint32_t)crc32(crc32(0L, Z_NULL, 0), t->out.data() + b.out_off, b.out_len) != b.crc) {
+                    crc32_fast(0, t->out.data() + b.out_off, b.out_len) != b.crc) {
                     failed = true;
                     break;
                 }

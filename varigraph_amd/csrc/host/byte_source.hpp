@@ -2,8 +2,9 @@
 // reads through: kseq over gzFile, include/kseq.h:59-72 with src/fastq_kmer.cpp:74-78; GzChunkReader for VCFs), with
 // the inflate work taken off the parsing thread:
 //   plain file            read(2) in 256 KiB chunks (gzopen's transparent mode)
-//   gzip stream           one decode thread per file running zlib's inflate ahead of the parser (concatenated members
-//                         are followed, bytes after the last member that are not a gzip header are ignored -- gz_look)
+//   gzip stream           one decode thread per file running this repo's inflate (fast_inflate.hpp, about twice zlib's
+//                         rate) ahead of the parser; concatenated members are followed, bytes after the last member
+//                         that are not a gzip header are ignored (gz_look)
 //   block gzip (BGZF)     members carrying the 'BC' extra field (bgzip, htslib): the block sizes are in the headers,
 //                         so `decode_threads` workers inflate blocks side by side and the chunks come back in order
 // A damaged stream delivers what decoded before the damage and then ends, like the reference's

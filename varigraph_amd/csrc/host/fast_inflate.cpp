@@ -352,7 +352,8 @@ private:
         if (!nb) return false;
         std::memcpy(nb - h, hist_.data() + kHist - h, h);
         hist_valid_ = h;
-        obase_ = out_ = crc_from_ = nb;
+        obase_ = out_ = nb;
+        crc_from_ = nb;
         oend_ = nb + cap_;
         win_start_ = nb - member_h;
         return true;

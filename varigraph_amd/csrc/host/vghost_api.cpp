@@ -7,6 +7,7 @@
 #include <string>
 
 #include "fastq_kmer_hip.hpp"
+#include "fast_inflate.hpp"
 #include "fastx_reader.hpp"
 #include "genotyper.hpp"
 #include "graph_index.hpp"
@@ -125,6 +126,8 @@ int64_t vgh_fastx_read_all(const char* path, char** block_out, size_t* n_bytes_o
 }
 
 void vgh_free(void* p) { free(p); }
+
+uint32_t vgh_crc32(uint32_t crc, const void* data, size_t n) { return vgh::crc32_fast(crc, static_cast<const unsigned char*>(data), n); }
 
 int vgh_bloom_reference_seeds(uint32_t random_device_value, uint32_t n_hash, uint64_t* seeds_out)
 {
