@@ -43,6 +43,20 @@ bool FastxReader::get_line(std::string& s, bool append)
     return true;
 }
 
+// drops the rest of the current line; false if the data ends before a '\n'
+bool FastxReader::skip_line()
+{
+    for (;;) {
+        if (cur_ >= end_ && !refill()) return false;
+        const unsigned char* nl = static_cast<const unsigned char*>(memchr(cur_, '\n', (size_t)(end_ - cur_)));
+        if (nl) {
+            cur_ = nl + 1;
+            return true;
+        }
+        cur_ = end_;
+    }
+}
+
 long FastxReader::next()
 {
     int c;
@@ -57,18 +71,21 @@ long FastxReader::next()
     {
         bool any = false;
         name_.clear();
-        for (;;) {
-            c = getc();
-            if (c == -1) break;
+        c = -1;
+        for (;;) {   // whole runs of name characters at a time
+            if (cur_ >= end_ && !refill()) break;
             any = true;
-            if (c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r') break;
-            name_.push_back((char)c);
+            const unsigned char* p = cur_;
+            while (p < end_ && !(*p == ' ' || (*p >= '\t' && *p <= '\r'))) ++p;   // isspace: ' ', \t \n \v \f \r
+            name_.append(reinterpret_cast<const char*>(cur_), (size_t)(p - cur_));
+            cur_ = p;
+            if (p < end_) {
+                c = *cur_++;
+                break;
+            }
         }
         if (!any) return -1;  // EOF right after the header character
-        if (c != '\n' && c != -1) {
-            std::string comment;
-            get_line(comment, false);
-        }
+        if (c != '\n' && c != -1) skip_line();
     }
     while ((c = getc()) != -1 && c != '>' && c != '+' && c != '@') {
         if (c == '\n') continue;
@@ -77,8 +94,7 @@ long FastxReader::next()
     }
     if (c == '>' || c == '@') last_char_ = c;
     if (c != '+') return (long)seq_.size();  // FASTA
-    while ((c = getc()) != -1 && c != '\n') {}
-    if (c == -1) return -2;
+    if (!skip_line()) return -2;   // rest of the '+' line
     while (get_line(qual_, true) && qual_.size() < seq_.size()) {}
     last_char_ = 0;
     if (seq_.size() != qual_.size()) return -2;

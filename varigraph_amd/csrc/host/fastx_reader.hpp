@@ -37,6 +37,7 @@ private:
     bool get_line(std::string& s, bool append);
 
     bool refill();   // false at the end of the data
+    bool skip_line();
 
     std::unique_ptr<ByteSource> src_;
     const unsigned char* cur_ = nullptr;
