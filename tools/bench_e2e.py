@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--threads", type=int, default=10)
     ap.add_argument("--gz", action="store_true")
     ap.add_argument("--keep", default="")
+    ap.add_argument("--native-only", action="store_true", help="skip the reference runs (no comparison)")
     args = ap.parse_args()
     from varigraph_amd import synth, vgmi
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "varigraph_det")
@@ -38,15 +39,16 @@ def main():
         out["synth_s"] = time.perf_counter() - t0
         graph = os.path.join(work, "graph.bin")
         env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
-        t0 = time.perf_counter()
-        r = subprocess.run([ref_bin, "construct", "-r", fa, "-v", vcf, "--save-graph", graph, "-t", "32"], cwd=work,
-                           capture_output=True, text=True)
-        out["reference_construct_s"] = time.perf_counter() - t0
-        if r.returncode != 0:
-            out["error"] = r.stderr[-400:]
-            print(json.dumps(out))
-            return
-        out["graph_bytes"] = os.path.getsize(graph)
+        if not args.native_only:
+            t0 = time.perf_counter()
+            r = subprocess.run([ref_bin, "construct", "-r", fa, "-v", vcf, "--save-graph", graph, "-t", "32"], cwd=work,
+                               capture_output=True, text=True)
+            out["reference_construct_s"] = time.perf_counter() - t0
+            if r.returncode != 0:
+                out["error"] = r.stderr[-400:]
+                print(json.dumps(out))
+                return
+            out["graph_bytes"] = os.path.getsize(graph)
         graph_native = os.path.join(work, "graph_native.bin")
         t0 = time.perf_counter()
         r = subprocess.run([cli, "construct", "-r", fa, "-v", vcf, "--save-graph", graph_native, "-t", "32", "--gpu", "0"], cwd=work,
@@ -56,9 +58,14 @@ def main():
             out["native_construct_error"] = r.stderr[-400:]
         else:
             out["native_construct_log"] = [ln for ln in r.stderr.strip().split("\n") if "varigraph-mi]" in ln][-2:]
-            out["graph_identical"] = subprocess.run(["cmp", "-s", graph, graph_native]).returncode == 0
+            if args.native_only:
+                graph = graph_native
+            else:
+                out["graph_identical"] = subprocess.run(["cmp", "-s", graph, graph_native]).returncode == 0
         vcfs = {}
         for name, exe, extra in (("reference_cpu", ref_bin, []), ("native_cli", cli, ["--gpu", "0"])):
+            if args.native_only and name == "reference_cpu":
+                continue
             d = os.path.join(work, name)
             os.makedirs(d, exist_ok=True)
             open(os.path.join(d, "samples.cfg"), "w").write("sample0 " + " ".join(fq) + "\n")
@@ -71,8 +78,9 @@ def main():
                 continue
             out[name + "_log_tail"] = [ln for ln in r.stderr.strip().split("\n") if "varigraph-mi]" in ln][-4:]
             vcfs[name] = gzip.open(os.path.join(d, "sample0.varigraph.vcf.gz"), "rb").read()
-        out["vcf_identical"] = len(vcfs) == 2 and vcfs["reference_cpu"] == vcfs["native_cli"]
-        out["vcf_records"] = vcfs.get("reference_cpu", b"").count(b"\n")
+        if not args.native_only:
+            out["vcf_identical"] = len(vcfs) == 2 and vcfs["reference_cpu"] == vcfs["native_cli"]
+        out["vcf_records"] = vcfs.get("native_cli", b"").count(b"\n")
     finally:
         if not args.keep:
             shutil.rmtree(work, ignore_errors=True)

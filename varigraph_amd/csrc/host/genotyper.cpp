@@ -7,8 +7,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <iomanip>
 #include <iterator>
 #include <map>
@@ -287,10 +289,10 @@ std::pair<std::string, std::string> Genotyper::flanks(const Chrom& chr, uint32_t
 // `genotypes` = the window's haplotype combinations (the same for every node of a window), `used` = the haplotypes
 // occurring in them.  The per-haplotype term of a k-mer does not depend on the genotype, so it is evaluated once
 // per (k-mer, haplotype) and summed per genotype.
-std::vector<Genotyper::Combo> Genotyper::hidden_states(Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& top,
-                                                       const std::vector<std::vector<uint16_t>>& genotypes,
-                                                       const std::vector<uint16_t>& used, double lower, double upper,
-                                                       bool filter, const Run& r)
+Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& top,
+                                               const std::vector<std::vector<uint16_t>>& genotypes,
+                                               const std::vector<uint16_t>& used, double lower, double upper,
+                                               bool filter, const Run& r, NodeStates&& recycled)
 {
     Node& node = chr.nodes[node_i];
     const std::vector<uint16_t>& hap_gt = node.gn->hap_gt;
@@ -298,11 +300,25 @@ std::vector<Genotyper::Combo> Genotyper::hidden_states(Chrom& chr, uint32_t node
     auto hap_bit = [&](uint32_t key, uint16_t hap) -> uint8_t { return ((uint8_t)g_.bitvec[(size_t)key * bl + (hap >> 3)] >> (hap & 7)) & 1u; };
     auto last_bit = [&](uint32_t key) -> int { return ((uint8_t)g_.bitvec[(size_t)key * bl + bl - 1] >> 7) & 1; };
 
-    std::vector<Combo> combos(genotypes.size());
-    for (size_t i = 0; i < genotypes.size(); ++i) {
-        combos[i].haps = genotypes[i];
-        combos[i].states.reserve(node.kmers.size());
+    const size_t n_gt = genotypes.size();
+    NodeStates ns = std::move(recycled);   // the previous node's buffers
+    ns.n_genotypes = n_gt;
+    ns.c.clear();
+    ns.f.clear();
+    ns.h.clear();
+    ns.c.reserve(node.kmers.size());
+    ns.f.reserve(node.kmers.size());
+    ns.h.resize(node.kmers.size() * n_gt);
+    // the window's genotypes as one flat list (read once per k-mer)
+    std::vector<uint16_t> flat;
+    std::vector<uint32_t> flat_off(n_gt + 1, 0);
+    for (size_t gi = 0; gi < n_gt; ++gi) {
+        flat.insert(flat.end(), genotypes[gi].begin(), genotypes[gi].end());
+        flat_off[gi + 1] = (uint32_t)flat.size();
     }
+    bool pairs = true;
+    for (size_t gi = 0; gi < n_gt; ++gi) pairs = pairs && genotypes[gi].size() == 2;
+    size_t n_kept = 0;
 
     std::vector<uint32_t> kept;                   // the node's k-mers that take part (all of them unless `filter`)
     kept.reserve(node.kmers.size());
@@ -323,15 +339,21 @@ std::vector<Genotyper::Combo> Genotyper::hidden_states(Chrom& chr, uint32_t node
             one[hap] = (in_interval && hap_gt[hap] == 0) ? 1 : hap_bit(key, hap);
             if (one[hap] > 0 && c < lower && f >= 2) need_sequence.emplace(hap, 0);
         }
-        HiddenState hs;
-        hs.c = c;
-        hs.f = (lb == 1 && f == 1) ? (uint8_t)(f + 1) : f;
-        for (Combo& combo : combos) {
-            hs.h = 0;
-            for (uint16_t hap : combo.haps) hs.h += one[hap];
-            combo.states.push_back(hs);
+        ns.c.push_back(c);
+        ns.f.push_back((lb == 1 && f == 1) ? (uint8_t)(f + 1) : f);
+        uint8_t* hrow = &ns.h[n_kept * n_gt];
+        if (pairs) {
+            for (size_t gi = 0; gi < n_gt; ++gi) hrow[gi] = (uint8_t)(one[flat[2 * gi]] + one[flat[2 * gi + 1]]);
+        } else {
+            for (size_t gi = 0; gi < n_gt; ++gi) {
+                uint8_t h = 0;
+                for (uint32_t t = flat_off[gi]; t < flat_off[gi + 1]; ++t) h += one[flat[t]];
+                hrow[gi] = h;
+            }
         }
+        ++n_kept;
     }
+    ns.h.resize(n_kept * n_gt);
 
     if (!need_sequence.empty()) {
         std::unordered_map<uint16_t, std::unordered_set<uint64_t>> hap_keys;
@@ -356,9 +378,9 @@ std::vector<Genotyper::Combo> Genotyper::hidden_states(Chrom& chr, uint32_t node
             }
             const int lb = last_bit(key);
             const uint64_t key_hash = g_.keys[key];
-            for (Combo& combo : combos) {
-                uint8_t& h = combo.states[si].h;
-                for (uint16_t hap : combo.haps) {
+            for (size_t gi = 0; gi < n_gt; ++gi) {
+                uint8_t& h = ns.h[(size_t)si * n_gt + gi];
+                for (uint16_t hap : genotypes[gi]) {
                     const uint8_t o1 = (lb == 1 && hap_gt[hap] == 0 && c >= lower && c <= upper) ? 1 : hap_bit(key, hap);
                     auto it = hap_keys.find(hap);
                     if (it == hap_keys.end() || o1 == 0) continue;
@@ -371,7 +393,7 @@ std::vector<Genotyper::Combo> Genotyper::hidden_states(Chrom& chr, uint32_t node
         }
     }
     if (filter) node.kmers = kept;
-    return combos;
+    return ns;
 }
 
 // ---------------------------------------------------------------- posterior of one node (src/genotype.cpp:1387-1522)
@@ -385,20 +407,14 @@ void Genotyper::posterior(Node& n, const std::vector<uint16_t>& top, const Run& 
     }
     const auto& hap_gt = n.gn->hap_gt;
 
-    std::unordered_map<uint16_t, std::pair<uint64_t, uint64_t>> per_hap;   // haplotype -> (#k-mers, sum of coverage)
+    // selected haplotype -> (#k-mers it carries, sum of their coverage); any other haplotype reads as (0, 0)
+    std::vector<uint64_t> hap_num(n_hap_, 0), hap_sum(n_hap_, 0);
     for (uint32_t key : n.kmers) {
+        const uint8_t c = r.cov[key];
         for (uint16_t hap : top) {
-            const bool carried = ((uint8_t)g_.bitvec[(size_t)key * bl + (hap >> 3)] >> (hap & 7)) & 1u;
-            auto it = per_hap.find(hap);
-            if (carried) {
-                if (it == per_hap.end()) {
-                    per_hap[hap] = {1, r.cov[key]};
-                } else {
-                    ++it->second.first;
-                    it->second.second += r.cov[key];
-                }
-            } else if (it == per_hap.end()) {
-                per_hap[hap] = {0, 0};
+            if (((uint8_t)g_.bitvec[(size_t)key * bl + (hap >> 3)] >> (hap & 7)) & 1u) {
+                ++hap_num[hap];
+                hap_sum[hap] += c;
             }
         }
     }
@@ -406,35 +422,58 @@ void Genotyper::posterior(Node& n, const std::vector<uint16_t>& top, const Run& 
     long double denominator = 0.0L;
     for (const auto& s : n.hmm) denominator += s.a * s.b;
 
-    auto genotype_string = [&](const std::vector<uint16_t>& haps) -> std::string {
-        std::vector<std::string> gts;
-        for (uint16_t hap : haps) gts.push_back(std::to_string(hap_gt[hap]));
-        std::sort(gts.begin(), gts.end());
-        std::string s;
-        for (size_t i = 0; i < gts.size(); ++i) {
-            s += gts[i];
-            if (i + 1 != gts.size()) s += "/";
-        }
-        return s;
+    // The reference sums the posteriors per genotype STRING (alleles as decimal strings, sorted as strings, joined by
+    // '/') in a std::map and takes the first maximum in key order.  Few distinct strings occur per node: every entry
+    // gets the index of its string, the sums run in entry order exactly as the map's do, and the strings themselves
+    // are only built once each.
+    struct Distinct { std::string text; long double sum = 0.0L; };
+    std::vector<Distinct> distinct;
+    std::vector<int32_t> gid(n.hmm.size(), -1);
+    uint16_t max_allele = 0;
+    for (uint16_t a : hap_gt) max_allele = a > max_allele ? a : max_allele;
+    std::vector<std::string> allele_text((size_t)max_allele + 1);   // decimal string per allele number, filled on demand
+    std::vector<std::vector<uint16_t>> distinct_alleles;  // sorted (as strings) allele tuple of every distinct string
+    std::vector<uint16_t> tuple;
+    auto text_of = [&](uint16_t a) -> const std::string& {
+        if (allele_text[a].empty()) allele_text[a] = std::to_string(a);
+        return allele_text[a];
     };
-
-    std::vector<std::string> gstr(n.hmm.size());
-    for (size_t i = 0; i < n.hmm.size(); ++i)
-        if (!n.hmm[i].haps.empty()) gstr[i] = genotype_string(n.hmm[i].haps);
-
-    std::map<std::string, long double> by_genotype;
+    for (size_t i = 0; i < n.hmm.size(); ++i) {
+        if (!n.hmm[i].haps || n.hmm[i].haps->empty()) continue;
+        const auto& haps = *n.hmm[i].haps;
+        tuple.clear();
+        for (uint16_t hap : haps) tuple.push_back(hap_gt[hap]);
+        std::sort(tuple.begin(), tuple.end(), [&](uint16_t x, uint16_t y) { return text_of(x) < text_of(y); });
+        int32_t id = -1;
+        for (size_t d = 0; d < distinct_alleles.size(); ++d)
+            if (distinct_alleles[d] == tuple) { id = (int32_t)d; break; }
+        if (id < 0) {
+            id = (int32_t)distinct.size();
+            distinct_alleles.push_back(tuple);
+            Distinct e;
+            for (size_t t = 0; t < tuple.size(); ++t) {
+                e.text += text_of(tuple[t]);
+                if (t + 1 != tuple.size()) e.text += "/";
+            }
+            distinct.push_back(std::move(e));
+        }
+        gid[i] = id;
+    }
     for (size_t i = 0; i < n.hmm.size(); ++i) {
         const auto& s = n.hmm[i];
         const long double post = (s.a * s.b) / (long double)denominator;
-        if (s.haps.empty()) continue;
-        by_genotype[gstr[i]] += post;
+        if (gid[i] < 0) continue;
+        distinct[(size_t)gid[i]].sum += post;
     }
-    std::string best_genotype;
+    std::vector<size_t> order(distinct.size());
+    for (size_t d = 0; d < order.size(); ++d) order[d] = d;
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return distinct[x].text < distinct[y].text; });
+    int32_t best_id = -1;
     long double best = -1.0;
-    for (const auto& e : by_genotype) {
-        if (e.second > best) {
-            best = e.second;
-            best_genotype = e.first;
+    for (size_t d : order) {
+        if (distinct[d].sum > best) {
+            best = distinct[d].sum;
+            best_id = (int32_t)d;
         }
     }
 
@@ -442,18 +481,17 @@ void Genotyper::posterior(Node& n, const std::vector<uint16_t>& top, const Run& 
     for (size_t i = 0; i < n.hmm.size(); ++i) {
         const auto& s = n.hmm[i];
         const long double post = (s.a * s.b) / (long double)denominator;
-        if (s.haps.empty()) continue;
-        if (gstr[i] != best_genotype) continue;
+        if (gid[i] < 0 || gid[i] != best_id) continue;
         n.call.probability = best;
         if (max_post < post) {
             max_post = post;
-            n.call.haps = s.haps;
+            n.call.haps = *s.haps;
             n.call.kmer_num.clear();
             n.call.kmer_ave_cov.clear();
             for (uint16_t hap : n.call.haps) {
-                const auto& info = per_hap[hap];
-                const uint64_t num = info.first;
-                const float ave = (num != 0) ? static_cast<float>(info.second) / (float)num : 0.0;
+                const uint64_t num = hap < n_hap_ ? hap_num[hap] : 0;
+                const uint64_t sum = hap < n_hap_ ? hap_sum[hap] : 0;
+                const float ave = (num != 0) ? static_cast<float>(sum) / (float)num : 0.0;
                 n.call.kmer_num.push_back(num);
                 n.call.kmer_ave_cov.push_back(ave);
             }
@@ -535,36 +573,73 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
         }
         return n;
     };
+    bool all_full = true;   // every genotype has `ploidy` haplotypes
+    for (const auto& gtv : genotypes) all_full = all_full && gtv.size() == (size_t)cfg.sample_ploidy;
     std::vector<uint8_t> keep_mat(n_gt * n_gt);
     for (size_t i = 0; i < n_gt; ++i)
         for (size_t j = 0; j < n_gt; ++j) keep_mat[i * n_gt + j] = (uint8_t)shared(genotypes[i], genotypes[j]);
 
-    // emission score of every genotype of a node; empty when the node has no k-mer left (every genotype is skipped)
-    auto score_combos = [&](const std::vector<Combo>& combos) -> std::vector<long double> {
+    // emission score of every genotype of a node; empty when the node has no k-mer left (every genotype is skipped).
+    // Every genotype's score is the product of its k-mers' terms in k-mer order (observable_states); walking the
+    // k-mers in the outer loop keeps that order per genotype and turns one long dependent multiply chain per
+    // genotype into n_genotypes independent ones.  A k-mer's term depends on the genotype only through h.
+    std::vector<long double> term_buf;
+    std::vector<uint8_t> term_have;
+    auto score_states = [&](const NodeStates& ns) -> std::vector<long double> {
         std::vector<long double> obs;
-        if (combos.empty() || combos[0].states.empty()) return obs;
-        obs.reserve(combos.size());
-        for (const auto& combo : combos) {
-            long double res = 1.0L;
-            for (const auto& st : combo.states) {
-                uint8_t h = st.h, c = st.c, f = st.f;
-                most_likely_depth(h, c, f, ave, score_up);
+        const size_t nk = ns.c.size(), ng = ns.n_genotypes;
+        if (ng == 0 || nk == 0) return obs;
+        uint8_t max_h = 0;
+        for (uint8_t h : ns.h) max_h = h > max_h ? h : max_h;
+        const size_t hs = (size_t)max_h + 1;
+        // the term of k-mer j under h copies, for the (j, h) that occur
+        term_buf.resize(nk * hs);
+        term_have.assign(nk * hs, 0);
+        for (size_t j = 0; j < nk; ++j) {
+            const uint8_t* hj = &ns.h[j * ng];
+            for (size_t gi = 0; gi < ng; ++gi) {
+                const uint8_t h = hj[gi];
+                if (term_have[j * hs + h]) continue;
+                term_have[j * hs + h] = 1;
+                uint8_t c = ns.c[j];
+                most_likely_depth(h, c, ns.f[j], ave, score_up);
                 if (h == 0) {
                     if (!geo_have[c]) {
                         geo_tab[c] = geometric(error_param(ave), c);
                         geo_have[c] = true;
                     }
-                    res *= geo_tab[c];
+                    term_buf[j * hs + h] = geo_tab[c];
                 } else {
                     const size_t slot = (size_t)h * 256 + c;
                     if (!pois_have[slot]) {
                         pois_tab[slot] = poisson_pmf(ave * h, c);
                         pois_have[slot] = 1;
                     }
-                    res *= pois_tab[slot];
+                    term_buf[j * hs + h] = pois_tab[slot];
                 }
             }
-            obs.push_back(res);
+        }
+        obs.resize(ng);
+        size_t gi = 0;
+        for (; gi + 4 <= ng; gi += 4) {   // four products in x87 registers, each in k-mer order
+            long double r0 = 1.0L, r1 = 1.0L, r2 = 1.0L, r3 = 1.0L;
+            const uint8_t* hj = &ns.h[gi];
+            const long double* t = term_buf.data();
+            for (size_t j = 0; j < nk; ++j, hj += ng, t += hs) {
+                r0 *= t[hj[0]];
+                r1 *= t[hj[1]];
+                r2 *= t[hj[2]];
+                r3 *= t[hj[3]];
+            }
+            obs[gi] = r0;
+            obs[gi + 1] = r1;
+            obs[gi + 2] = r2;
+            obs[gi + 3] = r3;
+        }
+        for (; gi < ng; ++gi) {
+            long double res = 1.0L;
+            for (size_t j = 0; j < nk; ++j) res *= term_buf[j * hs + ns.h[j * ng + gi]];
+            obs[gi] = res;
         }
         return obs;
     };
@@ -597,7 +672,36 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
         std::vector<long double> out;
         out.reserve(obs.size());
         long double total = 0.0L;
-        for (size_t gi = 0; gi < obs.size(); ++gi) {
+        size_t gi0 = 0;
+        if (!prev.empty() && !by_score && aligned && all_full) {
+            // four genotypes at a time: each sum still adds its terms in the order of the previous entries, but four
+            // independent x87 add chains are in flight instead of one
+            const size_t stride = (size_t)(max_n + 1);
+            for (; gi0 + 4 <= obs.size(); gi0 += 4) {
+                const uint8_t* k0 = &keep_mat[gi0 * n_gt];
+                const uint8_t* k1 = k0 + n_gt;
+                const uint8_t* k2 = k1 + n_gt;
+                const uint8_t* k3 = k2 + n_gt;
+                const long double o0 = obs[gi0], o1 = obs[gi0 + 1], o2 = obs[gi0 + 2], o3 = obs[gi0 + 3];
+                long double r0 = 0.0L, r1 = 0.0L, r2 = 0.0L, r3 = 0.0L;
+                const long double* sp = step.data();
+                for (size_t pi = 0; pi < prev.size(); ++pi, sp += stride) {
+                    r0 += sp[k0[pi]] * o0;
+                    r1 += sp[k1[pi]] * o1;
+                    r2 += sp[k2[pi]] * o2;
+                    r3 += sp[k3[pi]] * o3;
+                }
+                out.push_back(r0);
+                total += r0;
+                out.push_back(r1);
+                total += r1;
+                out.push_back(r2);
+                total += r2;
+                out.push_back(r3);
+                total += r3;
+            }
+        }
+        for (size_t gi = gi0; gi < obs.size(); ++gi) {
             const std::vector<uint16_t>& haps = genotypes[gi];
             const int32_t hap_num = (int32_t)haps.size();
             long double res = 0.0L;
@@ -622,7 +726,7 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
                         }
                         res += t;
                     } else {
-                        const int32_t keep = aligned ? (int32_t)keep_mat[gi * n_gt + pi] : shared(haps, p.haps);
+                        const int32_t keep = aligned ? (int32_t)keep_mat[gi * n_gt + pi] : shared(haps, *p.haps);
                         const int32_t change = hap_num - keep;
                         const long double pk = keep <= max_n ? pow_keep[keep] : std::pow(no_recomb, keep);
                         const long double pc = (change >= 0 && change <= max_n) ? pow_change[change] : std::pow(recomb, change);
@@ -645,30 +749,32 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
     // ---- forward.  The emissions are kept for the backward pass: it would recompute exactly the same hidden states
     // (it runs on the k-mer lists this pass has just pruned, with the same coverage and the same genotypes).
     std::vector<std::vector<long double>> emissions(last - first);
-    std::vector<HmmScore> prev;
+    const std::vector<HmmScore> no_prev;
+    const std::vector<HmmScore>* prev = &no_prev;   // the entries of the node scored before this one
     uint32_t prev_start = 0, prev_end = 0;
+    NodeStates states;
     for (uint32_t i = first; i < last; ++i) {
         Node& n = chr.nodes[i];
         if (skipped(n)) continue;
         const uint32_t n_start = n.start;
         const uint32_t n_end = (uint32_t)(n_start + n.gn->seqs[0].size() - 1);
-        const std::vector<Combo> combos = hidden_states(chr, i, top, genotypes, used, lower, upper, true, r);
+        states = hidden_states(chr, i, top, genotypes, used, lower, upper, true, r, std::move(states));
         long double recomb = 0.0L, no_recomb = 0.0L;
         if (cfg.transition == "rec") std::tie(recomb, no_recomb) = transition_probabilities(n_start - prev_end, (uint16_t)n_hap_);
         std::vector<long double>& obs = emissions[i - first];
-        obs = score_combos(combos);
-        const std::vector<long double> alpha = recursion(prev, true, recomb, no_recomb, obs);
+        obs = score_states(states);
+        const std::vector<long double> alpha = recursion(*prev, true, recomb, no_recomb, obs);
         n.hmm.resize(alpha.size());
         for (size_t j = 0; j < alpha.size(); ++j) {
             n.hmm[j].a = alpha[j];
-            n.hmm[j].haps = genotypes[j];
+            n.hmm[j].haps = &genotypes[j];
         }
         prev_start = n_start;
         prev_end = n_end;
-        prev = n.hmm;
+        prev = &n.hmm;
     }
     // ---- backward
-    std::vector<HmmScore>().swap(prev);
+    prev = &no_prev;
     prev_start = 0;
     prev_end = 0;
     for (uint32_t i = last; i-- > first;) {
@@ -678,12 +784,12 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
         const uint32_t n_end = (uint32_t)(n_start + n.gn->seqs[0].size() - 1);
         long double recomb = 0.0L, no_recomb = 0.0L;
         if (cfg.transition == "rec") std::tie(recomb, no_recomb) = transition_probabilities(prev_start - n_end, (uint16_t)n_hap_);
-        const std::vector<long double> beta = recursion(prev, false, recomb, no_recomb, emissions[i - first]);
+        const std::vector<long double> beta = recursion(*prev, false, recomb, no_recomb, emissions[i - first]);
         for (size_t j = 0; j < beta.size(); ++j) n.hmm[j].b = beta[j];
         std::vector<long double>().swap(emissions[i - first]);
         prev_start = n_start;
         prev_end = n_end;
-        prev = n.hmm;
+        prev = &n.hmm;
     }
     (void)prev_end;
     // ---- posterior
@@ -698,6 +804,7 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
 std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const std::string& sample_name,
                            const GenotypeConfig& cfg)
 {
+    const auto t_begin = std::chrono::steady_clock::now();
     Run r;
     r.cov = cov;
     r.hap_cov = hap_kmer_coverage;
@@ -753,6 +860,8 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
     worker();
     for (auto& th : pool) th.join();
     if (failed.load()) throw std::runtime_error(error);
+    const auto t_hmm = std::chrono::steady_clock::now();
+    last_hmm_seconds = std::chrono::duration<double>(t_hmm - t_begin).count();
 
     // ---- VCF (src/genotype.cpp:1579-1696): sites in vcf_info order, only those with a non-reference call
     std::ostringstream oss;
@@ -795,6 +904,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
     // text that is: no leading newline, exactly one trailing
     std::string text = strip_newlines(oss.str());
     if (!text.empty()) text += "\n";
+    last_text_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_hmm).count();
     return text;
 }
 

@@ -43,13 +43,15 @@ public:
     std::string run(const uint8_t* cov, float hap_kmer_coverage, const std::string& sample_name,
                     const GenotypeConfig& cfg);
 
+    double last_hmm_seconds = 0, last_text_seconds = 0;   // of the last run(): windows on the pool / VCF text
+
     // gzip `text` the way SAVE does (one gzwrite per call) into `path`
     static void write_gz(const std::string& path, const std::string& text);
 
 private:
     struct HmmScore {
         long double a = 0, b = 0;
-        std::vector<uint16_t> haps;
+        const std::vector<uint16_t>* haps = nullptr;   // the window's genotype this entry scores (alive during window())
     };
     struct SiteCall {
         long double probability = 0;
@@ -70,18 +72,18 @@ private:
         uint32_t len = 0;
         std::vector<Node> nodes;       // every node (ref-only spacers included), start ascending
     };
-    struct HiddenState { uint8_t h = 0, c = 0, f = 0; };
-    struct Combo {
-        std::vector<uint16_t> haps;
-        std::vector<HiddenState> states;
-        long double observable = 0.0L;
+    // hidden states of one node, k-mer major: k-mer j of the node (after pruning) has coverage c[j], multiplicity
+    // f[j] and, under genotype g of the window, h[j * n_genotypes + g] copies
+    struct NodeStates {
+        std::vector<uint8_t> c, f, h;
+        size_t n_genotypes = 0;
     };
     struct Run;  // per-call constants
 
     void window(Chrom& chr, uint32_t first, uint32_t last, const Run& r);
-    std::vector<Combo> hidden_states(Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& top,
-                                     const std::vector<std::vector<uint16_t>>& genotypes, const std::vector<uint16_t>& used,
-                                     double lower, double upper, bool filter, const Run& r);
+    NodeStates hidden_states(Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& top,
+                             const std::vector<std::vector<uint16_t>>& genotypes, const std::vector<uint16_t>& used,
+                             double lower, double upper, bool filter, const Run& r, NodeStates&& recycled);
     std::pair<std::string, std::string> flanks(const Chrom& chr, uint32_t node_i, uint16_t hap, uint16_t alt_gt,
                                                std::string& alt_seq, uint32_t want) const;
     void posterior(Node& n, const std::vector<uint16_t>& top, const Run& r) const;

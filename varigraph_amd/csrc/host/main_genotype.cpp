@@ -201,8 +201,10 @@ int main_genotype(int argc, char** argv)
                 cv.notify_all();
                 const double th = secs();
                 const std::string vcf = genotyper.run(job.cov.data(), job.hap_cov, job.name, o.hmm);
+                const double tz = secs();
                 vgh::Genotyper::write_gz(job.name + ".varigraph.vcf.gz", vcf);
-                std::fprintf(stderr, "[varigraph-mi] %s: genotyping %.2f s -> %s.varigraph.vcf.gz\n", job.name.c_str(), secs() - th,
+                std::fprintf(stderr, "[varigraph-mi] %s: genotyping %.2f s (HMM %.2f, VCF text %.2f, gzip %.2f) -> %s.varigraph.vcf.gz\n",
+                             job.name.c_str(), secs() - th, genotyper.last_hmm_seconds, genotyper.last_text_seconds, secs() - tz,
                              job.name.c_str());
             }
         } catch (const std::exception& e) {
