@@ -674,22 +674,21 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
         long double total = 0.0L;
         size_t gi0 = 0;
         if (!prev.empty() && !by_score && aligned && all_full) {
-            // four genotypes at a time: each sum still adds its terms in the order of the previous entries, but four
-            // independent x87 add chains are in flight instead of one
+            // three genotypes at a time: each sum still adds its terms in the order of the previous entries, but three
+            // independent x87 add chains are in flight instead of one (three accumulators and their three emission
+            // factors fill the register stack; a fourth chain would spill the factors to 80-bit memory operands)
             const size_t stride = (size_t)(max_n + 1);
-            for (; gi0 + 4 <= obs.size(); gi0 += 4) {
+            for (; gi0 + 3 <= obs.size(); gi0 += 3) {
                 const uint8_t* k0 = &keep_mat[gi0 * n_gt];
                 const uint8_t* k1 = k0 + n_gt;
                 const uint8_t* k2 = k1 + n_gt;
-                const uint8_t* k3 = k2 + n_gt;
-                const long double o0 = obs[gi0], o1 = obs[gi0 + 1], o2 = obs[gi0 + 2], o3 = obs[gi0 + 3];
-                long double r0 = 0.0L, r1 = 0.0L, r2 = 0.0L, r3 = 0.0L;
+                const long double o0 = obs[gi0], o1 = obs[gi0 + 1], o2 = obs[gi0 + 2];
+                long double r0 = 0.0L, r1 = 0.0L, r2 = 0.0L;
                 const long double* sp = step.data();
                 for (size_t pi = 0; pi < prev.size(); ++pi, sp += stride) {
                     r0 += sp[k0[pi]] * o0;
                     r1 += sp[k1[pi]] * o1;
                     r2 += sp[k2[pi]] * o2;
-                    r3 += sp[k3[pi]] * o3;
                 }
                 out.push_back(r0);
                 total += r0;
@@ -697,8 +696,6 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
                 total += r1;
                 out.push_back(r2);
                 total += r2;
-                out.push_back(r3);
-                total += r3;
             }
         }
         for (size_t gi = gi0; gi < obs.size(); ++gi) {
