@@ -860,43 +860,63 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
     const auto t_hmm = std::chrono::steady_clock::now();
     last_hmm_seconds = std::chrono::duration<double>(t_hmm - t_begin).count();
 
-    // ---- VCF (src/genotype.cpp:1579-1696): sites in vcf_info order, only those with a non-reference call
-    std::ostringstream oss;
-    oss << std::fixed << std::setprecision(1);
-    oss << g_.vcf_head + "\t" + sample_name + "\n";
-    std::map<std::string, const Chrom*> by_name;
-    for (const auto& c : chroms_) by_name[c.name] = &c;
-    for (const auto& [chr_name, sites] : g_.vcf_info) {
-        auto ci = by_name.find(chr_name);
-        if (ci == by_name.end()) continue;
-        const Chrom& chr = *ci->second;
-        for (const auto& [start, fields] : sites) {
-            auto ni = std::lower_bound(chr.nodes.begin(), chr.nodes.end(), start,
-                                       [](const Node& n, uint32_t s) { return n.start < s; });
-            if (ni == chr.nodes.end() || ni->start != start) continue;
-            const SiteCall& call = ni->call;
-            if (call.haps.empty()) continue;
-            std::vector<std::string> gt;
-            for (uint16_t hap : call.haps) gt.push_back(std::to_string(ni->gn->hap_gt[hap]));
-            if (std::all_of(gt.begin(), gt.end(), [](const std::string& c) { return c == "0" || c == "."; })) continue;
-            for (size_t i = 0; i < 9; i++) {
-                if (i == 0) oss << fields[i];
-                else if (i == 6) oss << "\tPASS";
-                else if (i < 8) oss << "\t" << fields[i];
-                else oss << "\t" << "GT:GQ:GPP:NAK:CAK:UK";
+    // ---- VCF (src/genotype.cpp:1579-1696): sites in vcf_info order, only those with a non-reference call.  The
+    // reference walks mVcfInfoMap (chromosome, then position) and looks every site up in the graph; the windows are the
+    // same nodes in the same order, so every task writes the lines of its own nodes and the pieces are joined in task
+    // order (chromosomes of the graph that the VCF lacks have thrown in window() already).
+    std::vector<std::string> pieces(tasks.size());
+    std::atomic<size_t> next_text{0};
+    auto text_worker = [&]() {
+        std::ostringstream oss;
+        oss << std::fixed << std::setprecision(1);
+        for (;;) {
+            const size_t t = next_text.fetch_add(1);
+            if (t >= tasks.size()) return;
+            const Chrom& chr = *tasks[t].chr;
+            auto vc = g_.vcf_info.find(chr.name);
+            if (vc == g_.vcf_info.end()) continue;
+            const auto& sites = vc->second;
+            oss.str(std::string());
+            for (uint32_t ni = tasks[t].first; ni < tasks[t].last; ++ni) {
+                const Node& node = chr.nodes[ni];
+                const SiteCall& call = node.call;
+                if (call.haps.empty()) continue;
+                auto site = sites.find(node.start);
+                if (site == sites.end()) continue;
+                const auto& fields = site->second;
+                std::vector<std::string> gt;
+                for (uint16_t hap : call.haps) gt.push_back(std::to_string(node.gn->hap_gt[hap]));
+                if (std::all_of(gt.begin(), gt.end(), [](const std::string& c) { return c == "0" || c == "."; })) continue;
+                for (size_t i = 0; i < 9; i++) {
+                    if (i == 0) oss << fields[i];
+                    else if (i == 6) oss << "\tPASS";
+                    else if (i < 8) oss << "\t" << fields[i];
+                    else oss << "\t" << "GT:GQ:GPP:NAK:CAK:UK";
+                }
+                const float gq = phred_scaled(call.probability);
+                if (gq < cfg.min_gq) std::fill(gt.begin(), gt.end(), ".");
+                oss << "\t";
+                for (size_t i = 0; i < gt.size(); ++i) oss << (i ? "/" : "") << gt[i];
+                oss << ":" << gq << ":" << call.probability << ":" << join_numbers(call.kmer_num, ",") << ":";
+                for (size_t i = 0; i < call.kmer_ave_cov.size(); i++) {
+                    if (i) oss << ",";
+                    oss << call.kmer_ave_cov[i];
+                }
+                oss << ":" << +call.unique_kmers << "\n";
             }
-            const float gq = phred_scaled(call.probability);
-            if (gq < cfg.min_gq) std::fill(gt.begin(), gt.end(), ".");
-            oss << "\t";
-            for (size_t i = 0; i < gt.size(); ++i) oss << (i ? "/" : "") << gt[i];
-            oss << ":" << gq << ":" << call.probability << ":" << join_numbers(call.kmer_num, ",") << ":";
-            for (size_t i = 0; i < call.kmer_ave_cov.size(); i++) {
-                if (i) oss << ",";
-                oss << call.kmer_ave_cov[i];
-            }
-            oss << ":" << +call.unique_kmers << "\n";
+            pieces[t] = oss.str();
         }
+    };
+    {
+        std::vector<std::thread> tpool;
+        for (uint32_t t = 1; t < n_threads; ++t) tpool.emplace_back(text_worker);
+        text_worker();
+        for (auto& th : tpool) th.join();
     }
+    // the graph's chromosomes are a std::map like mVcfInfoMap: the tasks are already in the reference's output order
+    std::ostringstream oss;
+    oss << g_.vcf_head + "\t" + sample_name + "\n";
+    for (const auto& piece : pieces) oss << piece;
     // SAVE::save strips the newlines around each 10 MB chunk and adds one back (src/save.cpp:16-24); on the whole
     // text that is: no leading newline, exactly one trailing
     std::string text = strip_newlines(oss.str());
@@ -905,12 +925,59 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
     return text;
 }
 
-void Genotyper::write_gz(const std::string& path, const std::string& text)
+// SAVE writes the text through gzwrite (src/save.cpp:11-30); the bytes of a .gz depend on the zlib build anyway, what
+// has to be identical is the content.  Here the text goes out as block gzip (BGZF: gzip members of <= 64 KiB with the
+// 'BC' extra field, the form bgzip / tabix expect for VCFs) and the blocks are deflated by `threads` workers.
+void Genotyper::write_gz(const std::string& path, const std::string& text, unsigned threads)
 {
-    gzFile f = gzopen(path.c_str(), "wb");
+    FILE* f = fopen(path.c_str(), "wb");
     if (!f) throw std::runtime_error("'" + path + "': No such file or directory or possibly reached the maximum open file limit.");
-    if (!text.empty()) gzwrite(f, text.data(), (unsigned)text.size());
-    gzclose(f);
+    constexpr size_t kBlock = 0xff00;
+    const size_t n_blocks = (text.size() + kBlock - 1) / kBlock;
+    std::vector<std::string> out(n_blocks);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> failed{false};
+    auto worker = [&]() {
+        std::vector<unsigned char> buf(compressBound(kBlock) + 64);
+        for (;;) {
+            const size_t b = next.fetch_add(1);
+            if (b >= n_blocks) return;
+            const size_t off = b * kBlock, len = std::min(kBlock, text.size() - off);
+            z_stream zs;
+            std::memset(&zs, 0, sizeof zs);
+            if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { failed = true; return; }
+            zs.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(text.data() + off));
+            zs.avail_in = (uInt)len;
+            zs.next_out = buf.data();
+            zs.avail_out = (uInt)buf.size();
+            const int rc = deflate(&zs, Z_FINISH);
+            const size_t clen = buf.size() - zs.avail_out;
+            deflateEnd(&zs);
+            if (rc != Z_STREAM_END || clen + 26 > 65536) { failed = true; return; }
+            const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef*>(text.data() + off), (uInt)len);
+            const uint16_t bsize = (uint16_t)(clen + 25);
+            std::string& o = out[b];
+            o.reserve(clen + 26);
+            static const unsigned char head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+            o.append(reinterpret_cast<const char*>(head), 16);
+            o.push_back((char)(bsize & 0xFF));
+            o.push_back((char)(bsize >> 8));
+            o.append(reinterpret_cast<const char*>(buf.data()), clen);
+            for (uint32_t v : {crc, (uint32_t)len})
+                for (int sh = 0; sh < 32; sh += 8) o.push_back((char)((v >> sh) & 0xFF));
+        }
+    };
+    const unsigned n_threads = (unsigned)std::max<size_t>(1, std::min<size_t>(threads ? threads : 1, n_blocks));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
+    bool ok = !failed.load();
+    for (size_t b = 0; ok && b < n_blocks; ++b) ok = fwrite(out[b].data(), 1, out[b].size(), f) == out[b].size();
+    static const unsigned char eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    ok = ok && fwrite(eof_block, 1, sizeof eof_block, f) == sizeof eof_block;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) throw std::runtime_error("'" + path + "': write error");
 }
 
 }  // namespace vgh

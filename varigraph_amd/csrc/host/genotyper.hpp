@@ -45,8 +45,8 @@ public:
 
     double last_hmm_seconds = 0, last_text_seconds = 0;   // of the last run(): windows on the pool / VCF text
 
-    // gzip `text` the way SAVE does (one gzwrite per call) into `path`
-    static void write_gz(const std::string& path, const std::string& text);
+    // `text` into `path` as block gzip (same content as SAVE's gzwrite), deflated by `threads` workers
+    static void write_gz(const std::string& path, const std::string& text, unsigned threads = 1);
 
 private:
     struct HmmScore {

@@ -1,6 +1,16 @@
 #include "graph_index.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <thread>
+#include <memory>
 #include <zlib.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstdio>
@@ -14,89 +24,140 @@ namespace vgh {
 
 namespace {
 
-// whole file into memory through zlib (transparent for plain files, like the gzopen the
-// reference uses for its other inputs); graph.bin itself is written uncompressed
-std::vector<uint8_t> slurp(const std::string& path)
+// the bytes of the file: plain files (what `construct --save-graph` writes) are mapped, gzip'd ones inflated through
+// zlib (transparent like the gzopen the reference uses for its other inputs)
+struct Bytes {
+    const uint8_t* data = nullptr;
+    size_t size = 0;
+    void* map = nullptr;
+    std::vector<uint8_t> own;
+    Bytes() = default;
+    Bytes(const Bytes&) = delete;
+    Bytes& operator=(const Bytes&) = delete;
+    ~Bytes() { if (map) munmap(map, size); }
+};
+
+void slurp(const std::string& path, Bytes& out)
 {
-    // plain file (what `construct --save-graph` writes): one bulk read
-    if (FILE* f = fopen(path.c_str(), "rb")) {
-        unsigned char magic[2] = {0, 0};
-        const size_t got = fread(magic, 1, 2, f);
-        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
-            std::vector<uint8_t> buf;
-            if (fseeko(f, 0, SEEK_END) == 0) {
-                const off_t size = ftello(f);
-                if (size >= 0 && fseeko(f, 0, SEEK_SET) == 0) {
-                    buf.resize((size_t)size);
-                    size_t n = 0;
-                    while (n < buf.size()) {
-                        const size_t r = fread(buf.data() + n, 1, buf.size() - n, f);
-                        if (r == 0) break;
-                        n += r;
-                    }
-                    fclose(f);
-                    if (n != buf.size()) throw std::runtime_error("'" + path + "': read error");
-                    return buf;
-                }
-            }
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("'" + path + "': No such file or directory.");
+    unsigned char magic[2] = {0, 0};
+    const ssize_t got = ::pread(fd, magic, 2, 0);
+    struct stat st;
+    if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+        if (m != MAP_FAILED) {
+            ::close(fd);
+            (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+            out.map = m;
+            out.data = static_cast<const uint8_t*>(m);
+            out.size = (size_t)st.st_size;
+            return;
         }
-        fclose(f);
     }
+    ::close(fd);
     gzFile fp = gzopen(path.c_str(), "rb");
     if (!fp) throw std::runtime_error("'" + path + "': No such file or directory.");
     gzbuffer(fp, 1 << 20);
-    std::vector<uint8_t> buf;
-    size_t cap = 1 << 22;
-    buf.resize(cap);
+    std::vector<uint8_t>& buf = out.own;
+    buf.resize(1 << 22);
     size_t n = 0;
     for (;;) {
         if (n == buf.size()) buf.resize(buf.size() * 2);
         size_t want = buf.size() - n;
         if (want > (1u << 30)) want = 1u << 30;
-        int got = gzread(fp, buf.data() + n, (unsigned)want);
-        if (got < 0) {
+        int r = gzread(fp, buf.data() + n, (unsigned)want);
+        if (r < 0) {
             gzclose(fp);
             throw std::runtime_error("'" + path + "': read error");
         }
-        if (got == 0) break;
-        n += (size_t)got;
+        if (r == 0) break;
+        n += (size_t)r;
     }
     gzclose(fp);
     buf.resize(n);
-    return buf;
+    out.data = buf.data();
+    out.size = n;
+}
+
+template <typename F>
+void parallel_chunks(size_t n, unsigned threads, F&& body)   // body(begin, end, thread)
+{
+    if (threads <= 1 || n < 4096) {
+        body((size_t)0, n, 0u);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t per = (n + threads - 1) / threads;
+    for (unsigned t = 0; t < threads; ++t) {
+        const size_t b = std::min(n, (size_t)t * per), e = std::min(n, b + per);
+        if (b == e) break;
+        pool.emplace_back([&body, b, e, t] { body(b, e, t); });
+    }
+    for (auto& th : pool) th.join();
 }
 
 // key -> record index of the k-mer table: open addressing, multiplicative hash (the reference's unordered_map is
 // needed only for membership + position here; this is ~5x faster to build and probe at 1e7..1e8 keys)
 struct KeyIndex {
-    std::vector<uint64_t> key;
-    std::vector<uint32_t> idx;
+    // zero pages straight from the kernel are the empty table.  A cell is tag << 32 | ~index (0 = empty): 32 hash bits
+    // select the candidates, the record's key decides; 8 bytes per cell and a load factor of 1/3..2/3 keep the table --
+    // whose pages are touched in random order -- small
+    const uint64_t* keys = nullptr;
+    uint64_t* cell = nullptr;
+    size_t bytes = 0;
     uint64_t mask = 0;
-    explicit KeyIndex(const std::vector<uint64_t>& keys)
+    KeyIndex(const KeyIndex&) = delete;
+    KeyIndex& operator=(const KeyIndex&) = delete;
+    ~KeyIndex() { if (cell) munmap(cell, bytes); }
+    KeyIndex(const std::vector<uint64_t>& key_vec, unsigned threads) : keys(key_vec.data())
     {
         uint64_t cap = 16;
-        while (cap < 2 * keys.size()) cap <<= 1;
+        while (2 * cap < 3 * key_vec.size()) cap <<= 1;
         mask = cap - 1;
-        key.assign(cap, ~0ULL);
-        idx.assign(cap, 0);
-        for (size_t i = 0; i < keys.size(); ++i) {
-            uint64_t s = slot(keys[i]);
-            while (key[s] != ~0ULL && key[s] != keys[i]) s = (s + 1) & mask;
-            if (key[s] == ~0ULL) {   // the first record of a key wins, like unordered_map::emplace
-                key[s] = keys[i];
-                idx[s] = (uint32_t)i;
+        bytes = cap * sizeof(uint64_t);
+        void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) throw std::runtime_error("graph index: out of memory");
+        cell = static_cast<uint64_t*>(m);
+        uint64_t* cp = cell;
+        // cells are claimed with a compare-and-swap, so the threads fill the table side by side; the FIRST record of a
+        // key wins like unordered_map::emplace (smallest index = largest ~index, whatever the arrival order)
+        parallel_chunks(key_vec.size(), threads, [&](size_t b, size_t e, unsigned) {
+            for (size_t i = b; i < e; ++i) {
+                const uint64_t k = keys[i];
+                const uint64_t h = hash(k);
+                const uint64_t mine = (h & 0xFFFFFFFF00000000ULL) | (uint32_t) ~(uint32_t)i;
+                uint64_t s = (h >> 8) & mask;
+                for (;;) {
+                    uint64_t cur = __atomic_load_n(&cp[s], __ATOMIC_RELAXED);
+                    if (cur == 0 && __atomic_compare_exchange_n(&cp[s], &cur, mine, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+                    if ((cur >> 32) == (mine >> 32) && keys[(uint32_t) ~(uint32_t)cur] == k) {   // the same key again
+                        while (mine > cur && !__atomic_compare_exchange_n(&cp[s], &cur, mine, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+                        break;
+                    }
+                    s = (s + 1) & mask;
+                }
             }
-        }
+        });
     }
-    uint64_t slot(uint64_t k) const { return ((k * 0x9E3779B97F4A7C15ULL) >> 20) & mask; }
+    static uint64_t hash(uint64_t k)
+    {
+        k *= 0x9E3779B97F4A7C15ULL;
+        return (k ^ (k >> 29)) | (1ULL << 63);   // tag never 0: an occupied cell is never 0
+    }
     bool find(uint64_t k, uint32_t& out) const
     {
-        for (uint64_t s = slot(k);; s = (s + 1) & mask) {
-            if (key[s] == k) {
-                out = idx[s];
-                return true;
+        const uint64_t h = hash(k);
+        for (uint64_t s = (h >> 8) & mask;; s = (s + 1) & mask) {
+            const uint64_t cur = cell[s];
+            if (cur == 0) return false;
+            if ((cur >> 32) == (h >> 32)) {
+                const uint32_t i = ~(uint32_t)cur;
+                if (keys[i] == k) {
+                    out = i;
+                    return true;
+                }
             }
-            if (key[s] == ~0ULL) return false;
         }
     }
 };
@@ -133,8 +194,17 @@ struct Cursor {
 
 void GraphIndex::load(const std::string& path)
 {
-    std::vector<uint8_t> buf = slurp(path);
-    Cursor c{buf.data(), buf.data() + buf.size()};
+    const bool timing = getenv("VGH_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    auto lap = [&](const char* what) {
+        if (timing) std::fprintf(stderr, "[graph_index] %-22s %.3f s\n", what, now() - t0);
+        t0 = now();
+    };
+    Bytes buf;
+    slurp(path, buf);
+    lap("file read");
+    Cursor c{buf.data, buf.data + buf.size};
 
     graph_base_num = c.get<uint64_t>();
     k = c.get<uint32_t>();
@@ -160,6 +230,7 @@ void GraphIndex::load(const std::string& path)
         }
     }
 
+    lap("VCF lines");
     hap_num = c.get<uint16_t>();
     for (uint16_t i = 0; i < hap_num; ++i) {
         const uint16_t idx = c.get<uint16_t>();
@@ -188,6 +259,7 @@ void GraphIndex::load(const std::string& path)
         }
     }
 
+    lap("nodes");
     (void)c.get<uint64_t>();  // ReadBase (always 0 in a graph index)
 
     // k-mer records until EOF: u64 key | u8 c | u8 f | u64 bitLen | i8[bitLen]
@@ -214,8 +286,11 @@ void GraphIndex::load(const std::string& path)
         bitvec.resize(o + bl);
         c.bytes(bitvec.data() + o, bl);
     }
+    lap("k-mer records");
     graph2node();
+    lap("graph2node");
     compute_hom_flags();
+    lap("hom flags");
 }
 
 // src/construct_index.cpp:710-751 + :1572-1603: per variant node, resolve kmerHashVec against the
@@ -225,31 +300,55 @@ void GraphIndex::load(const std::string& path)
 // produces the same permutation.
 void GraphIndex::graph2node()
 {
-    const KeyIndex index(keys);
+    const bool timing = getenv("VGH_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    auto lap = [&](const char* what) {
+        if (timing) std::fprintf(stderr, "[graph_index]   %-20s %.3f s\n", what, now() - t0);
+        t0 = now();
+    };
+    const KeyIndex index(keys, threads);
+    lap("key index");
 
     chr_names.clear(); node_chr.clear(); node_start.clear(); node_key_index.clear();
     node_off.assign(1, 0);
+    // variant nodes in mGraphMap order, resolved side by side, appended in order
+    std::vector<const GraphNode*> vnodes;
     for (const auto& [chr, nodes] : graph) {
         const uint32_t chr_id = (uint32_t)chr_names.size();
         chr_names.push_back(chr);
         for (const auto& [start, nd] : nodes) {
             if (nd.hap_gt.size() == 1) continue;
-            std::vector<uint32_t> kept;
+            node_chr.push_back(chr_id);
+            node_start.push_back(start);
+            vnodes.push_back(&nd);
+        }
+    }
+    std::vector<std::vector<uint32_t>> kept_all(vnodes.size());
+    const uint8_t* fp = f.data();
+    parallel_chunks(vnodes.size(), threads, [&](size_t b, size_t e, unsigned) {
+        for (size_t v = b; v < e; ++v) {
+            const GraphNode& nd = *vnodes[v];
+            std::vector<uint32_t>& kept = kept_all[v];
             kept.reserve(nd.kmer_hash.size());
             for (uint64_t h : nd.kmer_hash) {
                 uint32_t at;
                 if (index.find(h, at)) kept.push_back(at);
             }
             if (kept.size() > 128) {
-                const uint8_t* fp = f.data();
-                std::sort(kept.begin(), kept.end(), [fp](uint32_t a, uint32_t b) { return fp[a] < fp[b]; });
+                std::sort(kept.begin(), kept.end(), [fp](uint32_t a, uint32_t b2) { return fp[a] < fp[b2]; });
                 kept.resize(128);
             }
-            node_chr.push_back(chr_id);
-            node_start.push_back(start);
-            node_key_index.insert(node_key_index.end(), kept.begin(), kept.end());
-            node_off.push_back(node_key_index.size());
         }
+    });
+    lap("node lookups");
+    size_t total = 0;
+    for (const auto& kept : kept_all) total += kept.size();
+    node_key_index.reserve(total);
+    node_off.reserve(vnodes.size() + 1);
+    for (const auto& kept : kept_all) {
+        node_key_index.insert(node_key_index.end(), kept.begin(), kept.end());
+        node_off.push_back(node_key_index.size());
     }
 }
 
@@ -258,20 +357,22 @@ void GraphIndex::graph2node()
 void GraphIndex::compute_hom_flags()
 {
     hom_flag.assign(keys.size(), 0);
-    for (size_t r = 0; r < keys.size(); ++r) {
-        if (f[r] > 1) continue;
-        const int8_t* bv = bitvec.data() + r * bitlen;
-        uint32_t index = 0, sample_count = 0;
-        for (uint32_t i = 1; i < hap_num; ++i) {
-            index++;
-            if ((bv[i >> 3] >> (i & 7)) & 1) sample_count++;
-            if (index == vcf_ploidy) {
-                index = 0;
-                if (sample_count == vcf_ploidy) { hom_flag[r] = 1; break; }
-                sample_count = 0;
+    parallel_chunks(keys.size(), threads, [&](size_t rb, size_t re, unsigned) {
+        for (size_t r = rb; r < re; ++r) {
+            if (f[r] > 1) continue;
+            const int8_t* bv = bitvec.data() + r * bitlen;
+            uint32_t index = 0, sample_count = 0;
+            for (uint32_t i = 1; i < hap_num; ++i) {
+                index++;
+                if ((bv[i >> 3] >> (i & 7)) & 1) sample_count++;
+                if (index == vcf_ploidy) {
+                    index = 0;
+                    if (sample_count == vcf_ploidy) { hom_flag[r] = 1; break; }
+                    sample_count = 0;
+                }
             }
         }
-    }
+    });
 }
 
 int GraphIndex::upload(vgmi_ctx* ctx) const

@@ -49,6 +49,8 @@ struct GraphIndex {
     std::vector<uint64_t> node_off;
     std::vector<uint32_t> node_key_index;
 
+    unsigned threads = 1;   // host threads of load(): key index build and node resolution (graph2node)
+
     // throws std::runtime_error
     void load(const std::string& path);
     void graph2node();

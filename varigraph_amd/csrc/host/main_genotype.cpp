@@ -149,22 +149,32 @@ int main_genotype(int argc, char** argv)
     const auto t0 = std::chrono::steady_clock::now();
     auto secs = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
 
+    const auto samples = parse_samples(o.samples);   // exits on a bad list before anything touches the device
+    std::cerr << "[varigraph-mi] samples: " << samples.size() << ", graph: " << o.graph << ", devices: " << o.gpus.size() << std::endl;
+    // the device contexts come up (HIP runtime start, staging buffers) while the graph is read
     std::vector<vgmi_ctx*> ctxs;
-    for (int dev : o.gpus) {
-        vgmi_ctx* ctx = nullptr;
-        if (vgmi_create(dev, (size_t)o.buffer_mib, &ctx) != VGMI_OK)
-            die(std::string("device ") + std::to_string(dev) + ": " + vgmi_last_error(nullptr));
-        ctxs.push_back(ctx);
-    }
-    const auto samples = parse_samples(o.samples);
-    std::cerr << "[varigraph-mi] samples: " << samples.size() << ", graph: " << o.graph << ", devices: " << ctxs.size() << std::endl;
-
+    std::string ctx_error;
+    std::thread bring_up([&] {
+        for (int dev : o.gpus) {
+            vgmi_ctx* ctx = nullptr;
+            if (vgmi_create(dev, (size_t)o.buffer_mib, &ctx) != VGMI_OK) {
+                ctx_error = std::string("device ") + std::to_string(dev) + ": " + vgmi_last_error(nullptr);
+                return;
+            }
+            ctxs.push_back(ctx);
+        }
+    });
     vgh::GraphIndex g;
+    std::string load_error;
     try {
+        g.threads = std::max(1u, o.hmm.threads);
         g.load(o.graph);
     } catch (const std::exception& e) {
-        die(e.what());
+        load_error = e.what();
     }
+    bring_up.join();
+    if (!ctx_error.empty()) die(ctx_error);
+    if (!load_error.empty()) die(load_error);
     for (vgmi_ctx* ctx : ctxs)
         if (g.upload(ctx) != VGMI_OK) die(vgmi_last_error(ctx));
     std::cerr << "[varigraph-mi] graph loaded: " << g.keys.size() << " k-mers, k = " << g.k << ", " << g.hap_names.size()
@@ -202,7 +212,7 @@ int main_genotype(int argc, char** argv)
                 const double th = secs();
                 const std::string vcf = genotyper.run(job.cov.data(), job.hap_cov, job.name, o.hmm);
                 const double tz = secs();
-                vgh::Genotyper::write_gz(job.name + ".varigraph.vcf.gz", vcf);
+                vgh::Genotyper::write_gz(job.name + ".varigraph.vcf.gz", vcf, o.hmm.threads);
                 std::fprintf(stderr, "[varigraph-mi] %s: genotyping %.2f s (HMM %.2f, VCF text %.2f, gzip %.2f) -> %s.varigraph.vcf.gz\n",
                              job.name.c_str(), secs() - th, genotyper.last_hmm_seconds, genotyper.last_text_seconds, secs() - tz,
                              job.name.c_str());
