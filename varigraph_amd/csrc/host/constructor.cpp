@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <functional>
@@ -151,6 +152,12 @@ void put(std::ofstream& o, const T& v)
 ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
 {
     using clock = std::chrono::steady_clock;
+    const bool timing = getenv("VGH_TIMING") != nullptr;
+    auto t_lap = clock::now();
+    auto lap = [&](const char* what) {
+        if (timing) std::fprintf(stderr, "[construct] %-18s %.3f s\n", what, std::chrono::duration<double>(clock::now() - t_lap).count());
+        t_lap = clock::now();
+    };
     ConstructStats st;
     if (cfg.k < 1 || cfg.k > 28) throw std::runtime_error("k must be in 1..28");
     const uint32_t ploidy = cfg.vcf_ploidy;
@@ -171,6 +178,7 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
     }
     st.genome_size = genome_size;
 
+    lap("reference FASTA");
     // ---- make_mbf on the device
     const auto t_bloom = clock::now();
     {
@@ -191,6 +199,7 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
     }
     st.seconds_bloom = std::chrono::duration<double>(clock::now() - t_bloom).count();
 
+    lap("Bloom build");
     // ---- construct: VCF -> nodes
     std::map<std::string, std::map<uint32_t, GraphNode>> graph;
     std::map<std::string, std::map<uint32_t, std::vector<std::string>>> vcf_info;
@@ -327,6 +336,7 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
         }
     }
 
+    lap("VCF -> nodes");
     // ---- index: per variant node and haplotype, the k-mers of allele + flanks with their Bloom count / presence.
     // Chunks of nodes go through three phases: (A, threads) flank sequences and emitted keys per node; one batched
     // Bloom query on the device; (C, threads) index_run's bookkeeping per node; then ConstructIndex::index's merge into
@@ -501,6 +511,7 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
     }
     st.seconds_index = std::chrono::duration<double>(clock::now() - t_index).count();
 
+    lap("index");
     // ---- save_index (byte layout: SURVEY.md Appendix A)
     {
         std::ofstream o(cfg.out, std::ios::binary);
@@ -562,6 +573,7 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
         o.close();
         if (!o) throw std::runtime_error("'" + cfg.out + "': write error");
     }
+    lap("save");
     st.graph_base_num = graph_base_num;
     st.n_kmers = table.size();
     st.n_haplotypes = hap_map.size();
