@@ -2,6 +2,9 @@
 #include "constructor.hpp"
 
 
+#include <fcntl.h>
+#include <unistd.h>
+#include <memory>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -141,10 +144,57 @@ void emitted_keys(const std::string& s, uint32_t k, std::vector<uint64_t>& out)
     }
 }
 
+// graph.bin goes out through one 64 MiB buffer and write(2): the file is 1e8 fields of 1..8 bytes
+class OutFile {
+public:
+    explicit OutFile(const std::string& path) : fd_(::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644)), buf_(64u << 20)
+    {
+        if (fd_ < 0) throw std::runtime_error("'" + path + "': No such file or directory.");
+    }
+    ~OutFile() { if (fd_ >= 0) ::close(fd_); }
+    void write(const void* p, size_t n)
+    {
+        if (n > buf_.size() - used_) {
+            flush();
+            if (n > buf_.size()) { raw(p, n); return; }
+        }
+        std::memcpy(buf_.data() + used_, p, n);
+        used_ += n;
+    }
+    bool close()
+    {
+        flush();
+        const bool ok = ::close(fd_) == 0 && ok_;
+        fd_ = -1;
+        return ok;
+    }
+
+private:
+    void raw(const void* p, size_t n)
+    {
+        const char* c = static_cast<const char*>(p);
+        while (n) {
+            const ssize_t w = ::write(fd_, c, n);
+            if (w <= 0) { ok_ = false; return; }
+            c += w;
+            n -= (size_t)w;
+        }
+    }
+    void flush()
+    {
+        raw(buf_.data(), used_);
+        used_ = 0;
+    }
+    int fd_;
+    std::vector<char> buf_;
+    size_t used_ = 0;
+    bool ok_ = true;
+};
+
 template <typename T>
-void put(std::ofstream& o, const T& v)
+void put(OutFile& o, const T& v)
 {
-    o.write(reinterpret_cast<const char*>(&v), sizeof(T));
+    o.write(&v, sizeof(T));
 }
 
 }  // namespace
@@ -163,7 +213,16 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
     const uint32_t ploidy = cfg.vcf_ploidy;
 
     // ---- build_fasta_index: the first record of a name provides the sequence, every record counts for the size
-    std::unordered_map<std::string, std::string> fasta_seq;
+    // the big containers live in one block that the CLI leaves to process exit (ConstructConfig::release_memory)
+    struct Heavy {
+        std::unordered_map<std::string, std::string> fasta_seq;
+        std::map<std::string, std::map<uint32_t, GraphNode>> graph;
+        std::map<std::string, std::map<uint32_t, std::vector<std::string>>> vcf_info;
+        std::unordered_map<uint64_t, TableEntry> table;   // iteration order = record order of graph.bin
+    };
+    Heavy* heavy = new Heavy;
+    std::unique_ptr<Heavy> heavy_owner(cfg.release_memory ? heavy : nullptr);
+    std::unordered_map<std::string, std::string>& fasta_seq = heavy->fasta_seq;
     std::unordered_map<std::string, uint32_t> fasta_len;
     uint64_t genome_size = 0;
     {
@@ -201,8 +260,8 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
 
     lap("Bloom build");
     // ---- construct: VCF -> nodes
-    std::map<std::string, std::map<uint32_t, GraphNode>> graph;
-    std::map<std::string, std::map<uint32_t, std::vector<std::string>>> vcf_info;
+    std::map<std::string, std::map<uint32_t, GraphNode>>& graph = heavy->graph;
+    std::map<std::string, std::map<uint32_t, std::vector<std::string>>>& vcf_info = heavy->vcf_info;
     std::map<uint16_t, std::string> hap_map;
     hap_map[0] = "reference";
     uint16_t hap_num = 0;
@@ -342,7 +401,7 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
     // Bloom query on the device; (C, threads) index_run's bookkeeping per node; then ConstructIndex::index's merge into
     // the table, sequentially and in node order (it fixes the record order of graph.bin).
     const auto t_index = clock::now();
-    std::unordered_map<uint64_t, TableEntry> table;   // iteration order = record order of graph.bin
+    std::unordered_map<uint64_t, TableEntry>& table = heavy->table;
     {
         struct HapWork {   // one (node, haplotype) sequence whose k-mers were emitted
             uint16_t hap, gt;
@@ -514,19 +573,16 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
     lap("index");
     // ---- save_index (byte layout: SURVEY.md Appendix A)
     {
-        std::ofstream o(cfg.out, std::ios::binary);
-        if (!o.is_open()) throw std::runtime_error("'" + cfg.out + "': No such file or directory.");
-        std::vector<char> iobuf(8 << 20);
-        o.rdbuf()->pubsetbuf(iobuf.data(), (std::streamsize)iobuf.size());
+        OutFile o(cfg.out);
         put<uint64_t>(o, graph_base_num);
         put<uint32_t>(o, cfg.k);
         put<uint32_t>(o, ploidy);
         put<uint32_t>(o, (uint32_t)vcf_head.length());
-        o.write(vcf_head.data(), (std::streamsize)vcf_head.length());
+        o.write(vcf_head.data(), (size_t)vcf_head.length());
         put<uint32_t>(o, (uint32_t)vcf_info.size());
         for (const auto& [chr, sites] : vcf_info) {
             put<uint32_t>(o, (uint32_t)chr.length());
-            o.write(chr.data(), (std::streamsize)chr.length());
+            o.write(chr.data(), (size_t)chr.length());
             put<uint32_t>(o, fasta_len.at(chr));
             put<uint32_t>(o, (uint32_t)sites.size());
             for (const auto& [start, fields] : sites) {
@@ -534,7 +590,7 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
                 put<uint32_t>(o, (uint32_t)fields.size());
                 for (const auto& f : fields) {
                     put<uint32_t>(o, (uint32_t)f.length());
-                    o.write(f.data(), (std::streamsize)f.length());
+                    o.write(f.data(), (size_t)f.length());
                 }
             }
         }
@@ -542,24 +598,24 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
         for (const auto& [idx, name] : hap_map) {
             put<uint16_t>(o, idx);
             put<uint32_t>(o, (uint32_t)name.length());
-            o.write(name.data(), (std::streamsize)name.length());
+            o.write(name.data(), (size_t)name.length());
         }
         put<uint32_t>(o, (uint32_t)graph.size());
         for (const auto& [chr, nodes] : graph) {
             put<uint32_t>(o, (uint32_t)chr.length());
-            o.write(chr.data(), (std::streamsize)chr.length());
+            o.write(chr.data(), (size_t)chr.length());
             put<uint32_t>(o, (uint32_t)nodes.size());
             for (const auto& [start, n] : nodes) {
                 put<uint32_t>(o, start);
                 put<uint32_t>(o, (uint32_t)n.seqs.size());
                 for (const auto& s : n.seqs) {
                     put<uint32_t>(o, (uint32_t)s.length());
-                    o.write(s.data(), (std::streamsize)s.length());
+                    o.write(s.data(), (size_t)s.length());
                 }
                 put<uint32_t>(o, (uint32_t)n.hap_gt.size());
-                o.write(reinterpret_cast<const char*>(n.hap_gt.data()), (std::streamsize)(sizeof(uint16_t) * n.hap_gt.size()));
+                o.write(reinterpret_cast<const char*>(n.hap_gt.data()), (size_t)(sizeof(uint16_t) * n.hap_gt.size()));
                 put<uint32_t>(o, (uint32_t)n.kmer_hash.size());
-                o.write(reinterpret_cast<const char*>(n.kmer_hash.data()), (std::streamsize)(sizeof(uint64_t) * n.kmer_hash.size()));
+                o.write(reinterpret_cast<const char*>(n.kmer_hash.data()), (size_t)(sizeof(uint64_t) * n.kmer_hash.size()));
             }
         }
         put<uint64_t>(o, (uint64_t)0);   // ReadBase
@@ -568,10 +624,9 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
             put<uint8_t>(o, e.c);
             put<uint8_t>(o, e.f);
             put<uint64_t>(o, (uint64_t)e.bits.size());
-            o.write(reinterpret_cast<const char*>(e.bits.data()), (std::streamsize)e.bits.size());
+            o.write(reinterpret_cast<const char*>(e.bits.data()), (size_t)e.bits.size());
         }
-        o.close();
-        if (!o) throw std::runtime_error("'" + cfg.out + "': write error");
+        if (!o.close()) throw std::runtime_error("'" + cfg.out + "': write error");
     }
     lap("save");
     st.graph_base_num = graph_base_num;

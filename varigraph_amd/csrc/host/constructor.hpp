@@ -31,6 +31,8 @@ struct ConstructConfig {                  // defaults: include/varigraph.hpp:49-
     uint32_t threads = 10;                // -t: host threads of the indexing phases
     std::vector<uint64_t> bloom_seeds;    // empty: drawn like BloomFilter::_init_seeds from random_device_value
     uint32_t random_device_value = 0;
+    bool release_memory = true;           // false: the graph containers are left to process exit (the CLI: freeing 1e8 small
+                                          // allocations costs seconds and nothing follows)
 };
 
 struct ConstructStats {

@@ -313,6 +313,7 @@ int main_construct(int argc, char** argv)
     vgmi_ctx* ctx = nullptr;
     if (vgmi_create(gpu, (size_t)buffer_mib, &ctx) != VGMI_OK) die(std::string("device ") + std::to_string(gpu) + ": " + vgmi_last_error(nullptr));
     try {
+        c.release_memory = false;   // the process ends right after
         const vgh::ConstructStats st = vgh::construct_graph(ctx, c);
         std::fprintf(stderr,
                      "[varigraph-mi] construct: genome %.2f Mb, %llu variant nodes, %llu k-mers, %llu haplotypes -> %s\n"
