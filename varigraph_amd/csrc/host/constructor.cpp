@@ -441,6 +441,8 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
             if (!error.empty()) throw std::runtime_error(error);
         };
         const size_t chunk_nodes = 20000;
+        double t_a = 0, t_q = 0, t_c = 0, t_m = 0;
+        auto since = [](clock::time_point t) { return std::chrono::duration<double>(clock::now() - t).count(); };
         for (auto& [chr, nodes] : graph) {
             std::vector<NodeView> view;
             view.reserve(nodes.size());
@@ -454,6 +456,7 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
                 const size_t c1 = std::min(variant.size(), c0 + chunk_nodes);
                 std::vector<NodeWork> work(c1 - c0);
                 // ---- phase A
+                auto t_ph = clock::now();
                 parallel_for(work.size(), [&](size_t w) {
                     NodeWork& nw = work[w];
                     nw.ni = variant[c0 + w];
@@ -492,6 +495,8 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
                 size_t total = 0;
                 for (const NodeWork& nw : work) total += nw.keys.size();
                 keys.reserve(total);
+                t_a += since(t_ph);
+                t_ph = clock::now();
                 for (NodeWork& nw : work) {
                     const size_t base = keys.size();
                     for (HapWork& hw : nw.haps) {
@@ -505,6 +510,8 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
                 if (!keys.empty() && vgmi_bloom_query(ctx, keys.data(), keys.size(), cnt.data(), fnd.data()) != VGMI_OK)
                     throw std::runtime_error(vgmi_last_error(ctx));
                 st.bloom_queries += keys.size();
+                t_q += since(t_ph);
+                t_ph = clock::now();
                 // ---- phase C: index_run's bookkeeping per node
                 parallel_for(work.size(), [&](size_t w) {
                     NodeWork& nw = work[w];
@@ -543,6 +550,8 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
                         }
                     }
                 });
+                t_c += since(t_ph);
+                t_ph = clock::now();
                 // ---- merge, in node order
                 for (NodeWork& nw : work) {
                     if (nw.kept.empty()) continue;
@@ -565,8 +574,11 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
                         if (it->second.f == 1) it->second.f += fre - 1;
                     }
                 }
+                t_m += since(t_ph);
             }
         }
+        if (timing)
+            std::fprintf(stderr, "[construct]   flanks+keys %.3f s, Bloom batch %.3f s, per-node bookkeeping %.3f s, merge %.3f s\n", t_a, t_q, t_c, t_m);
     }
     st.seconds_index = std::chrono::duration<double>(clock::now() - t_index).count();
 
