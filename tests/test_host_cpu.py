@@ -321,3 +321,15 @@ def test_byte_sources_deliver_what_gzread_would(tmp_path):
     assert 0 < cnt < n and want.tobytes().startswith(got[: got.rfind(b"\n", 0, len(got) - 1) + 1])
     with pytest.raises(RuntimeError, match="No such file"):
         host.fastx_read_all(str(tmp_path / "missing.fq.gz"))
+
+
+def test_stl_order_map_iterates_like_unordered_map(tmp_path):
+    """csrc/host/stl_order_map.hpp fixes graph.bin's k-mer record order: it must iterate exactly like libstdc++'s
+    std::unordered_map<uint64_t, ...> after the same inserts (tests/native/order_map_check.cpp)."""
+    import subprocess
+    exe = str(tmp_path / "order_map_check")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "varigraph_amd", "csrc", "host"),
+                        os.path.join(ROOT, "tests", "native", "order_map_check.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "order identical" in r.stdout, r.stdout[-2000:]

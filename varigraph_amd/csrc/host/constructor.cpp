@@ -28,6 +28,7 @@
 #include "graph_index.hpp"
 #include "make_mbf.hpp"
 #include "node_flanks.hpp"
+#include "stl_order_map.hpp"
 #include "vgmi.h"
 
 namespace vgh {
@@ -110,10 +111,8 @@ struct LineReader {
     }
 };
 
-struct TableEntry {   // kmerCovFreBitVec (include/construct_index.hpp:45-72)
-    uint8_t c = 0, f = 0;
-    std::vector<int8_t> bits;
-};
+// k-mer table record (kmerCovFreBitVec, include/construct_index.hpp:45-72) as the payload of a StlOrderMap node:
+// byte 0 = c, byte 1 = f, then the haplotype bitmap
 
 struct NodeView {
     uint32_t start;
@@ -218,7 +217,7 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
         std::unordered_map<std::string, std::string> fasta_seq;
         std::map<std::string, std::map<uint32_t, GraphNode>> graph;
         std::map<std::string, std::map<uint32_t, std::vector<std::string>>> vcf_info;
-        std::unordered_map<uint64_t, TableEntry> table;   // iteration order = record order of graph.bin
+        std::unique_ptr<StlOrderMap> table;   // iteration order = record order of graph.bin (stl_order_map.hpp)
     };
     Heavy* heavy = new Heavy;
     std::unique_ptr<Heavy> heavy_owner(cfg.release_memory ? heavy : nullptr);
@@ -401,7 +400,8 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
     // Bloom query on the device; (C, threads) index_run's bookkeeping per node; then ConstructIndex::index's merge into
     // the table, sequentially and in node order (it fixes the record order of graph.bin).
     const auto t_index = clock::now();
-    std::unordered_map<uint64_t, TableEntry>& table = heavy->table;
+    std::unique_ptr<StlOrderMap>& table = heavy->table;
+    size_t table_bitlen = 0;
     {
         struct HapWork {   // one (node, haplotype) sequence whose k-mers were emitted
             uint16_t hap, gt;
@@ -412,7 +412,9 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
             GraphNode* node = nullptr;
             std::vector<HapWork> haps;
             std::vector<uint64_t> keys;
-            std::unordered_map<uint64_t, std::vector<int8_t>> kept;
+            std::unordered_map<uint64_t, std::vector<int8_t>> kept;   // phase C only: its iteration order is the node's k-mer order
+            std::vector<uint64_t> kept_keys;                          // ... flattened by the same thread
+            std::vector<int8_t> kept_bits;                            // kept_keys.size() * bitlen
             std::map<uint64_t, uint8_t> multi;
         };
         const uint32_t n_threads = std::max(1u, cfg.threads);
@@ -549,29 +551,58 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
                             ++it;
                         }
                     }
+                    // the sequential merge below reads flat arrays; the map is taken apart by the thread that built it
+                    nw.kept_keys.reserve(nw.kept.size());
+                    nw.kept_bits.reserve(nw.kept.size() * bitlen);
+                    for (const auto& [key, bits] : nw.kept) {
+                        nw.kept_keys.push_back(key);
+                        nw.kept_bits.insert(nw.kept_bits.end(), bits.begin(), bits.end());
+                    }
+                    std::unordered_map<uint64_t, std::vector<int8_t>>().swap(nw.kept);
                 });
                 t_c += since(t_ph);
                 t_ph = clock::now();
                 // ---- merge, in node order
-                for (NodeWork& nw : work) {
-                    if (nw.kept.empty()) continue;
+                // the chunk's insert sequence first (node order, each node's k-mers in its own map's order: both reach the
+                // file), then the inserts with the bucket and chain head of the keys ahead already on their way
+                struct Pending { uint64_t key; const int8_t* bits; };
+                std::vector<Pending> seq;
+                std::vector<size_t> node_end(work.size());
+                for (size_t w = 0; w < work.size(); ++w) {
+                    NodeWork& nw = work[w];
                     GraphNode& node = *nw.node;
-                    for (auto& [key, bits] : nw.kept) {
-                        node.kmer_hash.push_back(key);
-                        auto ins = table.emplace(key, TableEntry{});
-                        TableEntry& e = ins.first->second;
+                    if (!nw.kept_keys.empty()) {
+                        const size_t bl = nw.kept_bits.size() / nw.kept_keys.size();
+                        if (!table) {
+                            table_bitlen = bl;
+                            table = std::make_unique<StlOrderMap>(2 + table_bitlen);
+                        }
+                        if (bl != table_bitlen) throw std::runtime_error("haplotype bitmaps of different lengths");
+                        node.kmer_hash.insert(node.kmer_hash.end(), nw.kept_keys.begin(), nw.kept_keys.end());
+                        for (size_t j = 0; j < nw.kept_keys.size(); ++j) seq.push_back(Pending{nw.kept_keys[j], nw.kept_bits.data() + j * bl});
+                    }
+                    node_end[w] = seq.size();
+                }
+                size_t i = 0;
+                for (size_t w = 0; w < work.size(); ++w) {
+                    for (; i < node_end[w]; ++i) {
+                        if (i + 12 < seq.size()) table->prefetch(seq[i + 12].key);
+                        const int8_t* bits = seq[i].bits;
+                        const auto ins = table->emplace(seq[i].key);
+                        uint8_t* e = table->payload(ins.first);
                         if (ins.second) {
-                            e.bits = std::move(bits);
-                            e.f++;
+                            std::memcpy(e + 2, bits, table_bitlen);
+                            e[1]++;
                         } else {
-                            for (size_t i = 0; i < bits.size(); i++) e.bits[i] |= bits[i];
-                            if (e.f < UINT8_MAX) e.f++;
+                            for (size_t b = 0; b < table_bitlen; b++) e[2 + b] |= (uint8_t)bits[b];
+                            if (e[1] < UINT8_MAX) e[1]++;
                         }
                     }
-                    for (const auto& [key, fre] : nw.multi) {
-                        auto it = table.find(key);
-                        if (it == table.end()) throw std::runtime_error("The k-mer hash '" + std::to_string(key) + "' is not found in the table.");
-                        if (it->second.f == 1) it->second.f += fre - 1;
+                    for (const auto& [key, fre] : work[w].multi) {   // after the node's own inserts, before the next node's
+                        const uint32_t id = table ? table->find(key) : StlOrderMap::kNil;
+                        if (id == StlOrderMap::kNil) throw std::runtime_error("The k-mer hash '" + std::to_string(key) + "' is not found in the table.");
+                        uint8_t* e = table->payload(id);
+                        if (e[1] == 1) e[1] += fre - 1;
                     }
                 }
                 t_m += since(t_ph);
@@ -631,18 +662,25 @@ ConstructStats construct_graph(vgmi_ctx* ctx, const ConstructConfig& cfg)
             }
         }
         put<uint64_t>(o, (uint64_t)0);   // ReadBase
-        for (const auto& [key, e] : table) {
-            put<uint64_t>(o, key);
-            put<uint8_t>(o, e.c);
-            put<uint8_t>(o, e.f);
-            put<uint64_t>(o, (uint64_t)e.bits.size());
-            o.write(reinterpret_cast<const char*>(e.bits.data()), (size_t)e.bits.size());
+        if (table) {
+            const uint64_t bl = table_bitlen;
+            const std::vector<uint32_t> order = table->order();
+            for (size_t i = 0; i < order.size(); ++i) {
+                if (i + 16 < order.size()) table->prefetch_record(order[i + 16]);
+                const uint32_t id = order[i];
+                const uint8_t* e = table->payload(id);
+                put<uint64_t>(o, table->key(id));
+                put<uint8_t>(o, e[0]);
+                put<uint8_t>(o, e[1]);
+                put<uint64_t>(o, bl);
+                o.write(e + 2, bl);
+            }
         }
         if (!o.close()) throw std::runtime_error("'" + cfg.out + "': write error");
     }
     lap("save");
     st.graph_base_num = graph_base_num;
-    st.n_kmers = table.size();
+    st.n_kmers = table ? table->size() : 0;
     st.n_haplotypes = hap_map.size();
     return st;
 }
