@@ -630,3 +630,47 @@ def test_every_kmer_counted_once_at_any_alignment(table_mul, wide, monkeypatch):
                 assert np.array_equal(cov, want), (pre, post, int((cov != want).sum()))
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("k", [4, 12, 22, 28])
+def test_bloom_even_k_segmented_matches_sequential_oracle(ctx, k):
+    """Even k: emission depends on history (palindromic k-mers do not advance l, a non-base resets l but not the
+    registers, src/kmer.cpp:134,145).  The device splits a chromosome into 1 KiB segments and rebuilds the state by
+    look-back (bloom_even_kernel); the oracle runs the reference's sequential loop.  The sequence is built to hurt:
+    N runs that end exactly on / just before / just after segment borders, runs longer than a segment, single Ns every
+    few bases (stale register bits), long palindromic stretches (ACGT..., AT..., poly-A/T), lower case and other bytes."""
+    rng = np.random.default_rng(100 + k)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def rand(n):
+        return acgt[rng.integers(0, 4, size=n)]
+
+    def lit(b, n=1):
+        return np.tile(np.frombuffer(b, dtype=np.uint8), n)
+
+    parts = [rand(5), lit(b"N"), rand(k - 1), lit(b"N"), rand(k), lit(b"N"), rand(3 * k)]
+    parts += [lit(b"ACGT", 700), rand(50), lit(b"AT", 900), lit(b"N"), lit(b"AT", 40), rand(7), lit(b"A", 1500), lit(b"T", 1500)]
+    for border_shift in (-2, -1, 0, 1, 2):   # an N run ending around a multiple of 1024
+        cur = sum(p.size for p in parts)
+        pad = (-cur) % 1024 + 1024 + border_shift - 9
+        parts += [rand(pad), lit(b"N", 9), rand(k // 2), lit(b"n"), rand(2 * k + 3)]
+    parts += [rand(300), lit(b"N", 3000), rand(k - 1), lit(b"N", 1100), rand(4000)]
+    sprinkled = rand(6000)
+    sprinkled[rng.choice(6000, size=900, replace=False)] = ord("N")
+    parts += [sprinkled, np.frombuffer(b"acgtRYKM-*", dtype=np.uint8), rand(2500)]
+    for _ in range(30):   # exact reverse-complement palindromes of length k dropped into random sequence
+        h = rand(k // 2)
+        comp = np.array([{65: 84, 67: 71, 71: 67, 84: 65}[x] for x in h[::-1]], dtype=np.uint8)
+        parts += [rand(int(rng.integers(1, 3 * k))), h, comp]
+    parts += [rand(20000)]
+    seq = np.concatenate(parts)
+    n = max(1, seq.size - k + 1)
+    m, nh = vgmi.bloom_params(n, 0.01)
+    seeds = rng.integers(1, 1 << 63, size=nh).astype(np.uint64)
+    ctx.bloom_create(m, nh, seeds)
+    ctx.bloom_add_seq(seq, k)
+    got = ctx.bloom_fetch()
+    want = np.zeros(m, dtype=np.uint8)
+    o.bloom_add_seq(want, seeds, seq, k)
+    assert want.sum() > 0
+    assert np.array_equal(got, want)

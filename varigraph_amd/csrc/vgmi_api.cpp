@@ -857,14 +857,9 @@ int vgmi_bloom_add_seq_device(vgmi_ctx* c, const char* dev_bases, uint64_t len, 
         rows_geometry(c, false, grid, block);
         HIPCHK(c, launch_rows(K_MODE_BLOOM, false, p, grid, block, c->stream));
     } else {
-        uint64_t off[2] = {0, len};
-        uint64_t* d_off = nullptr;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_off), 16));
-        hipError_t e = hipMemcpy(d_off, off, 16, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = launch_seq(K_MODE_BLOOM, p, d_off, 1, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        (void)hipFree(d_off);
-        HIPCHK(c, e);
+        // even k: the sequential state machine, one lane per 1 KiB segment with its state rebuilt by look-back
+        HIPCHK(c, launch_bloom_even(p, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return VGMI_OK;
 }

@@ -913,6 +913,83 @@ __global__ __launch_bounds__(256) void seq_kernel(RowParams p, const uint64_t* r
 }
 
 // ------------------------------------------------------------------------------------------
+// even k over ONE long sequence (K3 on a chromosome): the state machine above, one lane per segment.
+// The emitter's state at a position is (fwd, rc, l): the registers hold the last k VALID bases (a non-base only
+// resets l, src/kmer.cpp:145; zeros before the sequence's first bases), and only min(l, k) matters.  A lane rebuilds
+// it exactly from a look-back window in front of its segment: it steps back over `want` valid bases (or to the start
+// of the sequence) and replays from there with zero registers.  After k valid bases the registers are exact; l is
+// exact from the first non-base after that point on, and otherwise at least the count of non-palindromic positions
+// replayed with exact registers -- which settles min(l, k) once that count reaches k.  If neither happens (more than
+// k palindromic positions in a row: not a real sequence) the window is doubled.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bloom_even_kernel(RowParams p, uint64_t seg_len)
+{
+    const uint64_t seg = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t s = seg * seg_len;
+    if (s >= p.n_bytes) return;
+    const uint64_t e = s + seg_len < p.n_bytes ? s + seg_len : p.n_bytes;
+    const uint32_t K = p.k;
+    const uint64_t mask = (1ULL << (2 * K)) - 1, shift1 = 2 * (uint64_t)(K - 1);
+    // nothing to emit in a segment without bases (long runs of N): no look-back either
+    {
+        bool any = false;
+        for (uint64_t i = s; i < e && !any; ++i) any = vg_nt4(p.bases[i]) < 4;
+        if (!any) return;
+    }
+    uint64_t fwd = 0, rc = 0;
+    uint32_t l = 0;
+    for (uint64_t want = 3ull * K;; want *= 2) {
+        // window start: `want` valid bases back, or the start of the sequence
+        uint64_t b = s;
+        uint64_t got = 0;
+        while (b > 0 && got < want) {
+            --b;
+            if (vg_nt4(p.bases[b]) < 4) ++got;
+        }
+        fwd = 0;
+        rc = 0;
+        l = 0;
+        const bool from_start = b == 0;
+        uint64_t valid = 0, exact_nonpal = 0;
+        bool l_exact = from_start;   // replay from the sequence start is the reference's own run
+        for (uint64_t i = b; i < s; ++i) {
+            const uint32_t c = vg_nt4(p.bases[i]);
+            if (c < 4) {
+                fwd = (fwd << 2 | c) & mask;
+                rc = (rc >> 2) | (uint64_t)(3u ^ c) << shift1;
+                ++valid;
+                if (fwd != rc) {
+                    if (l < K) ++l;
+                    if (from_start || valid > K) ++exact_nonpal;
+                }
+            } else {
+                l = 0;
+                if (from_start || valid >= K) l_exact = true;   // registers exact here: l is exact from now on
+                exact_nonpal = 0;
+            }
+        }
+        if (l_exact) break;
+        if (exact_nonpal >= K) {   // the true l is at least this: saturated
+            l = K;
+            break;
+        }
+    }
+    for (uint64_t i = s; i < e; ++i) {
+        const uint32_t c = vg_nt4(p.bases[i]);
+        if (c < 4) {
+            fwd = (fwd << 2 | c) & mask;
+            rc = (rc >> 2) | (uint64_t)(3u ^ c) << shift1;
+            if (fwd != rc) {
+                if (l < K) ++l;
+                if (l >= K) bloom_add_key(p.bloom, vg_hash64(fwd < rc ? fwd : rc, mask) << 8 | K);
+            }
+        } else {
+            l = 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // table build (once per graph) and per-sample reset / read-out
 // ------------------------------------------------------------------------------------------
 __global__ void table_clear_kernel(TableView t)
@@ -1109,6 +1186,15 @@ hipError_t launch_seq(int mode, const RowParams& p, const uint64_t* read_off, ui
     if (mode == MODE_COUNT) hipLaunchKernelGGL((seq_kernel<MODE_COUNT>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
     else if (mode == MODE_KEYS) hipLaunchKernelGGL((seq_kernel<MODE_KEYS>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
     else hipLaunchKernelGGL((seq_kernel<MODE_BLOOM>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
+    return hipGetLastError();
+}
+
+hipError_t launch_bloom_even(const RowParams& p, hipStream_t st)
+{
+    const uint64_t seg_len = 1024;
+    const uint64_t n_seg = (p.n_bytes + seg_len - 1) / seg_len;
+    if (n_seg == 0) return hipSuccess;
+    hipLaunchKernelGGL(bloom_even_kernel, dim3((uint32_t)((n_seg + 255) / 256)), dim3(256), 0, st, p, seg_len);
     return hipGetLastError();
 }
 
