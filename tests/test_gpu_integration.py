@@ -169,6 +169,26 @@ def test_native_cli_several_devices_keep_sample_order(tmp_path):
     assert body(got[2]) == body(got[1]) and body(got[3]) == body(got[1])
 
 
+def test_native_cli_independent_samples_run_side_by_side(tmp_path):
+    """-n >= #haplotypes: nothing can be pruned from a node's k-mer list, the samples are independent, and --gpus a,b,c
+    runs one genotyping consumer per device context.  Every sample must come out as the single-sample run does."""
+    if not os.path.exists(CLI):
+        pytest.skip("varigraph-mi not built")
+    d = os.path.join(GOLDEN, "cohort_snp")
+    graph = tmp_path / "graph.bin"
+    graph.write_bytes(gzip.open(os.path.join(d, "graph.bin.gz"), "rb").read())
+    fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
+    (tmp_path / "samples.cfg").write_text("".join(f"sample{s} " + " ".join(fq) + "\n" for s in range(5)))
+    env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+    r = subprocess.run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "3", "--gpus", "0,0,0"],
+                       cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = open(os.path.join(d, "expected_het.vcf"), "rb").read()
+    for s in range(5):
+        got = gzip.open(tmp_path / f"sample{s}.varigraph.vcf.gz", "rb").read()
+        assert _strip_gq(got).replace(b"sample%d" % s, b"sample0") == _strip_gq(want).replace(b"sample0", b"sample0"), s
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # `varigraph-mi construct`: the committed graph.bin.gz of every cohort was written by the unmodified reference
 # (deterministic build, std::random_device = 20241022) from the committed in.vcf and the seeded synthetic reference.

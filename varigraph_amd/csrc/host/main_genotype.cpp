@@ -194,19 +194,36 @@ int main_genotype(int argc, char** argv)
     std::map<size_t, Job> ready;           // finished counting, keyed by position in the -s list
     size_t next_to_genotype = 0;
     std::atomic<size_t> next_to_count{0};
-    const size_t max_ready = 2 * ctxs.size();
+    const size_t max_ready = 2 * ctxs.size();   // samples counted but not yet taken by a genotyping consumer
 
-    std::thread hmm([&] {
+    // The HMM prunes a node's k-mer list to the k-mers some selected haplotype carries and the pruned list stays for
+    // the next sample (genotype.cpp:815-818), so samples must be genotyped in order by one consumer -- unless nothing
+    // can be pruned: every haplotype is selected (-n >= #haplotypes) and every k-mer is carried by one.  Then the
+    // samples are independent and one consumer per device runs them side by side, each on its own Genotyper.
+    bool independent = g.hap_names.size() <= o.hmm.haploid_num;
+    if (independent && ctxs.size() > 1) {
+        const size_t bl = g.bitlen, n_hap = g.hap_names.size();
+        for (size_t r = 0; r < g.keys.size() && independent; ++r) {
+            bool any = false;
+            for (size_t h = 0; h < n_hap && !any; ++h) any = ((uint8_t)g.bitvec[r * bl + (h >> 3)] >> (h & 7)) & 1u;
+            independent = any;
+        }
+    }
+    const size_t n_consumers = independent ? std::max<size_t>(1, std::min(ctxs.size(), samples.size())) : 1;
+    std::atomic<size_t> next_hmm{0};
+    auto consumer = [&] {
         try {
             vgh::Genotyper genotyper(g);
-            for (size_t s = 0; s < samples.size(); ++s) {
+            for (;;) {
+                const size_t s = next_hmm.fetch_add(1);
+                if (s >= samples.size()) return;
                 Job job;
                 {
                     std::unique_lock<std::mutex> lk(mu);
                     cv.wait(lk, [&] { return ready.count(s) != 0; });
                     job = std::move(ready[s]);
                     ready.erase(s);
-                    next_to_genotype = s + 1;
+                    next_to_genotype = std::max(next_to_genotype, s + 1);
                 }
                 cv.notify_all();
                 const double th = secs();
@@ -220,7 +237,9 @@ int main_genotype(int argc, char** argv)
         } catch (const std::exception& e) {
             die(e.what());
         }
-    });
+    };
+    std::vector<std::thread> hmm_threads;
+    for (size_t c = 0; c < n_consumers; ++c) hmm_threads.emplace_back(consumer);
     auto counter = [&](size_t dev_i) {
         vgmi_ctx* ctx = ctxs[dev_i];
         try {
@@ -261,7 +280,7 @@ int main_genotype(int argc, char** argv)
     for (size_t d = 1; d < ctxs.size(); ++d) counters.emplace_back(counter, d);
     counter(0);
     for (auto& t : counters) t.join();
-    hmm.join();
+    for (auto& t : hmm_threads) t.join();
     for (vgmi_ctx* ctx : ctxs) vgmi_destroy(ctx);
     std::fprintf(stderr, "[varigraph-mi] done in %.2f s\n", secs());
     return 0;
