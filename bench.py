@@ -52,6 +52,15 @@ def cohort_haplotypes():
     return synth.sample_haplotypes(ref, variants, gts, 0, meta["ploidy"])
 
 
+def cpu_quota():
+    """CPUs this process may use at once according to its cgroup (cpu.max), or None without a quota."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if quota == "max" else round(int(quota) / int(period), 2)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(haps, n_reads, cores):
     """Reference CPU path (oracle/_ref/ref_harness = the unmodified reference's
     FastqKmer::build_fastq_index) on a bounded sample of the same workload, on this box's host
@@ -84,7 +93,7 @@ def cpu_baseline(haps, n_reads, cores):
             if sweep:
                 best = max(sweep, key=sweep.get)
                 return {"value": sweep[best], "unit": "reads/s", "cores": best, "kind": "reference",
-                        "host_logical_cpus": cores,
+                        "host_logical_cpus": cores, "cgroup_cpu_quota": cpu_quota(),
                         "sweep_reads_per_s_by_threads": {str(k): round(v) for k, v in sorted(sweep.items())},
                         "sample": f"{n_reads} reads (plain FASTQ, 2 files) of the same workload through the unmodified "
                                   f"reference FastqKmer::build_fastq_index (oracle/_ref), best of the -t sweep"}

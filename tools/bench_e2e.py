@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--gz", action="store_true")
     ap.add_argument("--keep", default="")
     ap.add_argument("--native-only", action="store_true", help="skip the reference runs (no comparison)")
+    ap.add_argument("--samples", type=int, default=1, help="the same reads as N samples (native-only runs)")
+    ap.add_argument("--gpus", default="0", help="device list of the native run, e.g. 0,0,0,0")
     args = ap.parse_args()
     from varigraph_amd import synth, vgmi
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "varigraph_det")
@@ -63,12 +65,13 @@ def main():
             else:
                 out["graph_identical"] = subprocess.run(["cmp", "-s", graph, graph_native]).returncode == 0
         vcfs = {}
-        for name, exe, extra in (("reference_cpu", ref_bin, []), ("native_cli", cli, ["--gpu", "0"])):
+        for name, exe, extra in (("reference_cpu", ref_bin, []), ("native_cli", cli, ["--gpus", args.gpus])):
             if args.native_only and name == "reference_cpu":
                 continue
             d = os.path.join(work, name)
             os.makedirs(d, exist_ok=True)
-            open(os.path.join(d, "samples.cfg"), "w").write("sample0 " + " ".join(fq) + "\n")
+            n_samples = args.samples if name == "native_cli" else 1
+            open(os.path.join(d, "samples.cfg"), "w").write("".join(f"sample{i} " + " ".join(fq) + "\n" for i in range(n_samples)))
             t0 = time.perf_counter()
             r = subprocess.run([exe, "genotype", "--load-graph", graph, "-s", "samples.cfg", "-t", str(args.threads)] + extra,
                                cwd=d, capture_output=True, text=True, env=env)
