@@ -316,14 +316,11 @@ private:
         bitbuf_ = 0;
         bitcnt_ = 0;
     }
-    // room for n more bytes of compressed look-ahead in front of the bit reader (block headers)
+    // a block header (dynamic code lengths: < 400 bytes) must not run into the end of the buffer: compact + read more.
+    // Bytes already inside bitbuf_ stay valid, in_ only moves together with its data.
     void top_up()
     {
-        if ((size_t)(in_end_ - in_) < 2048 && !file_eof_) {
-            const uint32_t keep = bitcnt_;   // bytes already inside bitbuf_ stay valid: in_ only moves with its data
-            fill_input();
-            (void)keep;
-        }
+        if ((size_t)(in_end_ - in_) < 2048 && !file_eof_) fill_input();
     }
 
     // ---- output ----
