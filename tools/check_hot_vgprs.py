@@ -13,7 +13,7 @@ def main():
         text = open(out).read()
     bad = 0
     found = 0
-    for m in re.finditer(r"^(_ZN3vgk14count27_kernelILb[01]EEEvNS_9RowParamsE):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN3vgk14count27_kernelILb[01]ELb[01]EEEvNS_9RowParamsE):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
         found += 1
         name, body = m.group(1), m.group(2)
         top = 0
@@ -28,7 +28,7 @@ def main():
         print(f"{name}: {n_hot} hand-written instructions, compiler's highest VGPR v{top}, {n_scratch} scratch accesses")
         if top >= 120 or n_hot == 0 or n_scratch:
             bad += 1
-    if found != 2 or bad:
+    if found != 3 or bad:
         print("FAILED")
         return 1
     print("OK")

@@ -167,10 +167,11 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     h.k = k;
     h.n_keys = n_keys;
     // compact 8-byte slots for the LDS-filter kernel (k = 27, <= 65 536 keys): same bytes, twice the slots
-    const bool compact = k == 27 && n_keys <= VG_GRID_LDS_MAX_KEYS && !getenv("VGMI_WIDE_SLOTS");
+    const bool small = n_keys <= VG_GRID_LDS_MAX_KEYS;
+    const bool compact = k == 27 && !getenv("VGMI_WIDE_SLOTS") && (small || getenv("VGMI_COMPACT_LARGE"));
     h.slot_bytes = compact ? 8 : 16;
     uint64_t cap = 64;
-    uint64_t lf_mul = compact ? 8 : 4;  // load factor <= 0.125 / 0.25: nearly every probe ends at the first slot
+    uint64_t lf_mul = (compact && small) ? 8 : 4;  // load factor <= 0.125 / 0.25: nearly every probe ends at the first slot
     if (const char* e = getenv("VGMI_TABLE_MUL")) lf_mul = (uint64_t)atoi(e) > 1 ? (uint64_t)atoi(e) : 2;
     while (cap < lf_mul * n_keys) cap <<= 1;
     h.cap = cap;
@@ -178,7 +179,7 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     // the k-mers of neighbouring read positions probe the same few lines (vg_thash_local; VGMI_LOCALITY=0 switches
     // it off, another value sets the bucket size)
     h.home_bucket_log2 = 0;
-    if (k == 27 && !compact && n_keys > VG_GRID_LDS_MAX_KEYS) {
+    if (k == 27 && n_keys > VG_GRID_LDS_MAX_KEYS) {
         h.home_bucket_log2 = 5;
         if (const char* e = getenv("VGMI_LOCALITY")) h.home_bucket_log2 = (uint32_t)atoi(e) < 16 ? (uint32_t)atoi(e) : 5;
     }
@@ -229,7 +230,7 @@ int adopt_image(vgmi_ctx* c)
     c->tv.grid = h.off_grid ? reinterpret_cast<const uint32_t*>(c->d_image + h.off_grid) : nullptr;
     c->tv.grid_words_log2 = h.grid_words_log2;
     const bool lds_grid = h.grid_words_log2 == VG_GRID_LDS_WORDS_LOG2;
-    c->fast27 = h.k == 27 && h.off_grid && lds_grid == compact;   // count27_kernel applies: LDS filter + compact
+    c->fast27 = h.k == 27 && h.off_grid && (!lds_grid || compact);   // count27_kernel applies: LDS filter + compact
                                                                   // slots, or global (64-bit entry) filter + 16-byte slots
     c->fast27_lds = c->fast27 && lds_grid;
     c->d_key_slot = reinterpret_cast<uint32_t*>(c->d_image + h.off_key_slot);

@@ -543,7 +543,7 @@ __device__ __forceinline__ uint32_t encode4(const Addr4& a)
 
 // LDS_BM: grid filter (2^15 words) staged in LDS (small graphs, one 1024-thread workgroup per CU)
 //         or probed in global memory (large graphs, 256-thread workgroups).
-template <bool LDS_BM>
+template <bool LDS_BM, bool COMPACT>
 __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams p)
 {
     constexpr uint32_t MASK_HI = (1u << (2 * 27 - 32)) - 1;  // 54-bit k-mer: low word full, 22 bits high
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
         const uint64_t home = (!LDS_BM && hb_log2) ? vg_thash_local(canon, canon == kmer ? rc : kmer, hb_log2) : vg_thash(canon);
         b_slot = (home + dist) & cap_mask;
         b_active = act;
-        if (act) vm_load_slot<LDS_BM>(LDS_BM ? (const void*)&slots8[b_slot] : (const void*)&slots[b_slot]);
+        if (act) vm_load_slot<COMPACT>(COMPACT ? (const void*)&slots8[b_slot] : (const void*)&slots[b_slot]);
         ++n_after_row;
         n_after_slot = 0;
     };
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
     // then issue the next batch: 32+ re-queued k-mers first, else up to 5 runs
     auto drain_step = [&]() __attribute__((always_inline)) {
         vm_wait(n_after_slot);
-        if (LDS_BM) {
+        if (COMPACT) {
             // the previous step's atomics have returned (they were issued before the loads just waited for): a
             // counter that has reached the clamp gets its slot flagged, later hits skip their atomic
             const uint32_t old = vm_atomic_old();
@@ -648,14 +648,14 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
                 if (sat) vm_atomic_or_sync(reinterpret_cast<uint32_t*>(&slots8[p_slot]) + 1, (uint32_t)(VG_SLOT_SAT >> 32));
             }
         }
-        const uint4 tv = vm_slot_value<LDS_BM>();
+        const uint4 tv = vm_slot_value<COMPACT>();
         bool again = false;
         uint32_t* bump = nullptr;
         if (b_active) {
             const uint64_t c = ((uint64_t)tv.y << 32) | tv.x;
             const uint64_t canon = b_canon & VG_Q_KMER_MASK;
             if (c != VG_EMPTY && (c & VG_SLOT_KMER_MASK) == canon) {
-                if (LDS_BM) { if (!(c & VG_SLOT_SAT)) bump = &counts[b_slot]; }
+                if (COMPACT) { if (!(c & VG_SLOT_SAT)) bump = &counts[b_slot]; }
                 else if (counts) bump = &counts[tv.w];               // dense counters, clamped at read-out
                 else if (tv.z < 255u) bump = &slots[b_slot].count;
             } else if (c != VG_EMPTY && (c & VG_SLOT_CHAIN)) {
@@ -679,10 +679,10 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
                 uint64_t sl = b_slot;
                 for (;;) {
                     sl = (sl + 1) & cap_mask;
-                    const uint4 v = vm_load_slot_sync<LDS_BM>(LDS_BM ? (const void*)&slots8[sl] : (const void*)&slots[sl]);
+                    const uint4 v = vm_load_slot_sync<COMPACT>(COMPACT ? (const void*)&slots8[sl] : (const void*)&slots[sl]);
                     const uint64_t c = ((uint64_t)v.y << 32) | v.x;
                     if (c != VG_EMPTY && (c & VG_SLOT_KMER_MASK) == canon) {
-                        if (LDS_BM) { if (!(c & VG_SLOT_SAT)) { bump = &counts[sl]; b_slot = sl; } }
+                        if (COMPACT) { if (!(c & VG_SLOT_SAT)) { bump = &counts[sl]; b_slot = sl; } }
                         else if (counts) bump = &counts[v.w];
                         else if (v.z < 255u) bump = &slots[sl].count;
                         break;
@@ -1154,20 +1154,21 @@ static hipError_t launch_rows_t(const RowParams& p, uint32_t grid, uint32_t bloc
     return hipGetLastError();
 }
 
-template <bool LDS_BM>
+template <bool LDS_BM, bool COMPACT>
 static hipError_t launch_count27_t(const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)
 {
     const size_t lds = (LDS_BM ? (size_t)VG_GRID_LDS_WORDS * 4 : 0) + (size_t)(block / 64) * (VG_RUNQ * 16 + VG_REQ * 8) + VG_LUT27_BYTES;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&count27_kernel<LDS_BM>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&count27_kernel<LDS_BM, COMPACT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((count27_kernel<LDS_BM>), dim3(grid), dim3(block), lds, st, p);
+    hipLaunchKernelGGL((count27_kernel<LDS_BM, COMPACT>), dim3(grid), dim3(block), lds, st, p);
     return hipGetLastError();
 }
 
 hipError_t launch_count27(bool lds_bitmap, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)
 {
-    return lds_bitmap ? launch_count27_t<true>(p, grid, block, st) : launch_count27_t<false>(p, grid, block, st);
+    if (lds_bitmap) return launch_count27_t<true, true>(p, grid, block, st);
+    return p.table.slots8 ? launch_count27_t<false, true>(p, grid, block, st) : launch_count27_t<false, false>(p, grid, block, st);
 }
 
 hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)
