@@ -442,13 +442,15 @@ def test_saturation_flags_cleared_by_reset(ctx):
 
 # ----------------------------------------------------------------------------- large graphs (global grid bitmap)
 @pytest.mark.parametrize("k,placement", [(27, None), (25, None), (27, {"VGMI_LOCALITY": "0"}), (27, {"VGMI_LOCALITY": "3"}),
-                                         (27, {"VGMI_DENSE_COUNTS": "1"})],
-                         ids=["k27", "k25", "k27-random-homes", "k27-buckets-of-8", "k27-dense-counters"])
+                                         (27, {"VGMI_WIDE_SLOTS": "1"}), (27, {"VGMI_WIDE_SLOTS": "1", "VGMI_DENSE_COUNTS": "1"}),
+                                         (27, {"VGMI_WIDE_SLOTS": "1", "VGMI_LOCALITY": "0"})],
+                         ids=["k27", "k25", "k27-random-homes", "k27-buckets-of-8", "k27-16-byte-slots",
+                              "k27-16-byte-slots-dense-counters", "k27-16-byte-slots-random-homes"])
 def test_large_graph_grid_variant_matches_oracle(k, placement, monkeypatch):
     """> 65 536 keys: k = 27 takes count27_kernel<global grid bitmap> (+ generic tail row), k = 25 the
     generic rows_kernel with the global blocked-Bloom prefilter.  Dense SNPs (1 per 60 bp) give ~35 %
-    hit rate: exercises ring pressure, re-queued collision probes and unsaturated counters.  The k = 27 table puts
-    home slots in minimiser buckets with in-slot counters by default; the other placements stay covered."""
+    hit rate: exercises ring pressure, re-queued collision probes and unsaturated counters.  The k = 27 table has
+    8-byte slots in minimiser buckets with per-slot counters by default; the other formats and placements stay covered."""
     import torch
     for name, val in (placement or {}).items():
         monkeypatch.setenv(name, val)

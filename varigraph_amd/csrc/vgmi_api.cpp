@@ -166,12 +166,13 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     memcpy(h.magic, "VGMITBL1", 8);
     h.k = k;
     h.n_keys = n_keys;
-    // compact 8-byte slots for the LDS-filter kernel (k = 27, <= 65 536 keys): same bytes, twice the slots
+    // k = 27: compact 8-byte slots (a minimiser bucket of 32 is two 128-byte lines, its counters one); small graphs
+    // spend the same bytes on twice the slots
     const bool small = n_keys <= VG_GRID_LDS_MAX_KEYS;
-    const bool compact = k == 27 && !getenv("VGMI_WIDE_SLOTS") && (small || getenv("VGMI_COMPACT_LARGE"));
+    const bool compact = k == 27 && !getenv("VGMI_WIDE_SLOTS");   // 8-byte k-mer words + per-slot counters
     h.slot_bytes = compact ? 8 : 16;
     uint64_t cap = 64;
-    uint64_t lf_mul = (compact && small) ? 8 : 4;  // load factor <= 0.125 / 0.25: nearly every probe ends at the first slot
+    uint64_t lf_mul = compact ? 8 : 4;   // load factor <= 0.125 / 0.25: nearly every probe ends at the first slot
     if (const char* e = getenv("VGMI_TABLE_MUL")) lf_mul = (uint64_t)atoi(e) > 1 ? (uint64_t)atoi(e) : 2;
     while (cap < lf_mul * n_keys) cap <<= 1;
     h.cap = cap;
