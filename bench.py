@@ -259,7 +259,7 @@ def main():
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": b_stream * n_reads,
-                         "kernel": "vgk::count27_kernel<true>", "kernel_ms": avg_kernel_s * 1e3,
+                         "kernel": "vgk::count27_kernel<true, true>", "kernel_ms": avg_kernel_s * 1e3,
                          "bytes_per_read": b_stream,
                          "note": "C2's 0.43 MB table is on-chip, so the compulsory HBM traffic is the ASCII "
                                  "read stream only (SURVEY 8d B_stream); the kernel is instruction-issue bound "
