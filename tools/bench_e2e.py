@@ -21,6 +21,10 @@ def main():
     ap.add_argument("--native-only", action="store_true", help="skip the reference runs (no comparison)")
     ap.add_argument("--samples", type=int, default=1, help="the same reads as N samples (native-only runs)")
     ap.add_argument("--gpus", default="0", help="device list of the native run, e.g. 0,0,0,0")
+    ap.add_argument("--ploidy", type=int, default=2, help="ploidy of the VCF samples and of the sequenced sample")
+    ap.add_argument("--vcf-samples", type=int, default=7)
+    ap.add_argument("--indel", type=float, default=0.0)
+    ap.add_argument("--sv", type=float, default=0.0)
     args = ap.parse_args()
     from varigraph_amd import synth, vgmi
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "varigraph_det")
@@ -31,11 +35,12 @@ def main():
     try:
         t0 = time.perf_counter()
         ref = synth.make_reference(args.genome)
-        variants, gts = synth.make_cohort(ref, args.variants, n_samples=7, ploidy=2, seed=11)
+        variants, gts = synth.make_cohort(ref, args.variants, n_samples=args.vcf_samples, ploidy=args.ploidy, seed=11,
+                                          indel_frac=args.indel, sv_frac=args.sv)
         fa, vcf = os.path.join(work, "ref.fa"), os.path.join(work, "in.vcf")
         synth.write_fasta(fa, "chr1", ref)
-        synth.write_vcf(vcf, "chr1", len(ref), variants, gts, 7, 2)
-        haps = synth.sample_haplotypes(ref, variants, gts, 0, 2)
+        synth.write_vcf(vcf, "chr1", len(ref), variants, gts, args.vcf_samples, args.ploidy)
+        haps = synth.sample_haplotypes(ref, variants, gts, 0, args.ploidy)
         block = vgmi.synth_reads_host(1000, 0, 2 * args.pairs, 150, haps)
         fq = synth.write_fastq_pair(os.path.join(work, "s"), block, 2 * args.pairs, 150, gz=args.gz)
         out["synth_s"] = time.perf_counter() - t0
@@ -43,7 +48,7 @@ def main():
         env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
         if not args.native_only:
             t0 = time.perf_counter()
-            r = subprocess.run([ref_bin, "construct", "-r", fa, "-v", vcf, "--save-graph", graph, "-t", "32"], cwd=work,
+            r = subprocess.run([ref_bin, "construct", "-r", fa, "-v", vcf, "--save-graph", graph, "-t", "32", "--vcf-ploidy", str(args.ploidy)], cwd=work,
                                capture_output=True, text=True)
             out["reference_construct_s"] = time.perf_counter() - t0
             if r.returncode != 0:
@@ -53,7 +58,7 @@ def main():
             out["graph_bytes"] = os.path.getsize(graph)
         graph_native = os.path.join(work, "graph_native.bin")
         t0 = time.perf_counter()
-        r = subprocess.run([cli, "construct", "-r", fa, "-v", vcf, "--save-graph", graph_native, "-t", "32", "--gpu", "0"], cwd=work,
+        r = subprocess.run([cli, "construct", "-r", fa, "-v", vcf, "--save-graph", graph_native, "-t", "32", "--gpu", "0", "--vcf-ploidy", str(args.ploidy)], cwd=work,
                            capture_output=True, text=True, env=env)
         out["native_construct_s"] = time.perf_counter() - t0
         if r.returncode != 0:
@@ -73,7 +78,8 @@ def main():
             n_samples = args.samples if name == "native_cli" else 1
             open(os.path.join(d, "samples.cfg"), "w").write("".join(f"sample{i} " + " ".join(fq) + "\n" for i in range(n_samples)))
             t0 = time.perf_counter()
-            r = subprocess.run([exe, "genotype", "--load-graph", graph, "-s", "samples.cfg", "-t", str(args.threads)] + extra,
+            r = subprocess.run([exe, "genotype", "--load-graph", graph, "-s", "samples.cfg", "-t", str(args.threads)] + extra +
+                               (["--sample-ploidy", str(args.ploidy), "--use-depth"] if args.ploidy != 2 else []),
                                cwd=d, capture_output=True, text=True, env=env)
             out[name + "_genotype_s"] = time.perf_counter() - t0
             if r.returncode != 0:
