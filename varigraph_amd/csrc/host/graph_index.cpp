@@ -124,6 +124,7 @@ struct KeyIndex {
         // key wins like unordered_map::emplace (smallest index = largest ~index, whatever the arrival order)
         parallel_chunks(key_vec.size(), threads, [&](size_t b, size_t e, unsigned) {
             for (size_t i = b; i < e; ++i) {
+                if (i + 12 < e) __builtin_prefetch(&cp[(hash(keys[i + 12]) >> 8) & mask], 1);
                 const uint64_t k = keys[i];
                 const uint64_t h = hash(k);
                 const uint64_t mine = (h & 0xFFFFFFFF00000000ULL) | (uint32_t) ~(uint32_t)i;
@@ -145,6 +146,7 @@ struct KeyIndex {
         k *= 0x9E3779B97F4A7C15ULL;
         return (k ^ (k >> 29)) | (1ULL << 63);   // tag never 0: an occupied cell is never 0
     }
+    void prefetch(uint64_t k) const { __builtin_prefetch(&cell[(hash(k) >> 8) & mask]); }
     bool find(uint64_t k, uint32_t& out) const
     {
         const uint64_t h = hash(k);
@@ -331,9 +333,11 @@ void GraphIndex::graph2node()
             const GraphNode& nd = *vnodes[v];
             std::vector<uint32_t>& kept = kept_all[v];
             kept.reserve(nd.kmer_hash.size());
-            for (uint64_t h : nd.kmer_hash) {
+            const size_t nk = nd.kmer_hash.size();
+            for (size_t j = 0; j < nk; ++j) {
+                if (j + 8 < nk) index.prefetch(nd.kmer_hash[j + 8]);
                 uint32_t at;
-                if (index.find(h, at)) kept.push_back(at);
+                if (index.find(nd.kmer_hash[j], at)) kept.push_back(at);
             }
             if (kept.size() > 128) {
                 std::sort(kept.begin(), kept.end(), [fp](uint32_t a, uint32_t b2) { return fp[a] < fp[b2]; });
