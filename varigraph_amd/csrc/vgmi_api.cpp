@@ -175,6 +175,7 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     uint64_t lf_mul = compact ? 8 : 4;   // load factor <= 0.125 / 0.25: nearly every probe ends at the first slot
     if (const char* e = getenv("VGMI_TABLE_MUL")) lf_mul = (uint64_t)atoi(e) > 1 ? (uint64_t)atoi(e) : 2;
     while (cap < lf_mul * n_keys) cap <<= 1;
+    while (cap > (1ULL << 32) && cap / 2 >= 2 * n_keys) cap >>= 1;   // slot numbers are 32-bit (key_slot)
     h.cap = cap;
     // tables that live in HBM (k = 27, global grid filter): home slots in minimiser buckets of 32 slots (512 bytes), so
     // the k-mers of neighbouring read positions probe the same few lines (vg_thash_local; VGMI_LOCALITY=0 switches
