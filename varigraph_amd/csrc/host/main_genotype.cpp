@@ -283,7 +283,9 @@ int main_genotype(int argc, char** argv)
     for (auto& t : hmm_threads) t.join();
     for (vgmi_ctx* ctx : ctxs) vgmi_destroy(ctx);
     std::fprintf(stderr, "[varigraph-mi] done in %.2f s\n", secs());
-    return 0;
+    // every output file is closed and the devices are released: skip taking the graph (1e7s of small allocations) apart
+    std::fflush(nullptr);
+    std::_Exit(0);
 }
 
 // `construct` (main.cpp:21-236, Varigraph::construct src/varigraph.cpp:14-54): same options plus --gpu / --buffer
@@ -345,7 +347,8 @@ int main_construct(int argc, char** argv)
         die(e.what());
     }
     vgmi_destroy(ctx);
-    return 0;
+    std::fflush(nullptr);
+    std::_Exit(0);   // graph.bin is closed; the containers were left alone on purpose (release_memory = false)
 }
 
 }  // namespace
