@@ -271,9 +271,10 @@ def test_native_cli_block_gzip_and_plain_inputs(tmp_path):
             plain.write_bytes(gzip.open(src, "rb").read())
             fq.append(str(plain) if kind == "plain" else synth.bgzf_compress_file(str(plain), str(tmp_path / f"reads_{i}.b.fq.gz")))
         (tmp_path / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
-        r = subprocess.run([CLI, "genotype", "--load-graph", "g.bin", "-s", "samples.cfg", "-t", "6"], cwd=tmp_path,
-                           capture_output=True, text=True, env=env, timeout=300)
+        r = subprocess.run([CLI, "genotype", "--load-graph", "g.bin", "-s", "samples.cfg", "-t", "6"] + (["-D"] if kind == "plain" else []),
+                           cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
+        assert ("[graph_index]" in r.stderr) == (kind == "plain")   # -D / --debug: single-threaded, phase times
         vcfs[kind] = gzip.open(tmp_path / "sample0.varigraph.vcf.gz", "rb").read()
     assert vcfs["plain"] == vcfs["gz"] and vcfs["bgzf"] == vcfs["gz"]
     want = open(os.path.join(d, "expected_het.vcf"), "rb").read() if os.path.exists(os.path.join(d, "expected_het.vcf")) else None

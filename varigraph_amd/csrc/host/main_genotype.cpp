@@ -55,6 +55,7 @@ void usage(const char* argv0)
               << "    --gpu           INT    device ordinal [0]\n"
               << "    --gpus          LIST   several devices, e.g. 0,1,2,3: samples are counted on them in parallel\n"
               << "    --buffer        INT    staging buffer in MiB [100]\n"
+              << "    -D, --debug            single host thread, phase times on stderr\n"
               << "    -t, --threads   INT    host threads [10]\n";
 }
 
@@ -98,6 +99,7 @@ std::vector<std::tuple<std::string, std::vector<std::string>>> parse_samples(con
 int main_genotype(int argc, char** argv)
 {
     Options o;
+    bool debug = false;
     static const struct option long_options[] = {
         {"load-graph", required_argument, 0, 1},   {"sample", required_argument, 0, 's'},
         {"genotype", required_argument, 0, 'g'},   {"sample-ploidy", required_argument, 0, 2},
@@ -105,12 +107,12 @@ int main_genotype(int argc, char** argv)
         {"mode", required_argument, 0, 'm'},       {"sv", no_argument, 0, 4},
         {"min-support", required_argument, 0, 5},  {"use-depth", no_argument, 0, 6},
         {"gpu", required_argument, 0, 7},          {"buffer", required_argument, 0, 8},
-        {"gpus", required_argument, 0, 9},
+        {"gpus", required_argument, 0, 9},         {"debug", no_argument, 0, 'D'},
         {"threads", required_argument, 0, 't'},    {"help", no_argument, 0, 'h'},
         {0, 0, 0, 0}};
     for (;;) {
         int idx = 0;
-        const int c = getopt_long(argc, argv, "s:g:n:m:t:h", long_options, &idx);
+        const int c = getopt_long(argc, argv, "s:g:n:m:t:Dh", long_options, &idx);
         if (c == -1) break;
         switch (c) {
         case 1: o.graph = optarg; break;
@@ -134,8 +136,13 @@ int main_genotype(int argc, char** argv)
         }
         case 8: o.buffer_mib = std::stoi(optarg); break;
         case 't': o.hmm.threads = std::max(std::stoi(optarg), 1); break;
+        case 'D': debug = true; break;
         default: usage(argv[0]); return 1;
         }
+    }
+    if (debug) {   // main.cpp:317, genotype.cpp:63-65: debug runs single-threaded; here it also prints the phase times
+        o.hmm.threads = 1;
+        setenv("VGH_TIMING", "1", 1);
     }
     if (o.graph.empty()) die("Parameter error: --load-graph. The genome graph file cannot be empty.");
     if (o.samples.empty()) die("Parameter error: -s. The sample configuration file cannot be empty.");
@@ -293,16 +300,17 @@ int main_construct(int argc, char** argv)
 {
     vgh::ConstructConfig c;
     int gpu = 0, buffer_mib = 100;
+    bool debug = false;
     static const struct option long_options[] = {
         {"reference", required_argument, 0, 'r'}, {"vcf", required_argument, 0, 'v'},
         {"save-graph", required_argument, 0, 1},  {"vcf-ploidy", required_argument, 0, 2},
         {"kmer", required_argument, 0, 'k'},      {"fast", no_argument, 0, 3},
         {"use-unique-kmers", no_argument, 0, 4},  {"gpu", required_argument, 0, 7},
         {"buffer", required_argument, 0, 8},      {"threads", required_argument, 0, 't'},
-        {"help", no_argument, 0, 'h'},            {0, 0, 0, 0}};
+        {"debug", no_argument, 0, 'D'},           {"help", no_argument, 0, 'h'},            {0, 0, 0, 0}};
     for (;;) {
         int idx = 0;
-        const int o = getopt_long(argc, argv, "r:v:k:t:h", long_options, &idx);
+        const int o = getopt_long(argc, argv, "r:v:k:t:Dh", long_options, &idx);
         if (o == -1) break;
         switch (o) {
         case 'r': c.reference = optarg; break;
@@ -315,6 +323,7 @@ int main_construct(int argc, char** argv)
         case 7: gpu = std::stoi(optarg); break;
         case 8: buffer_mib = std::stoi(optarg); break;
         case 't': c.threads = (uint32_t)std::max(std::stoi(optarg), 1); break;
+        case 'D': debug = true; break;   // main.cpp:141, construct_index.cpp:33-35
         default:
             std::cerr << "Usage: construct -r FASTA -v VCF [--save-graph FILE] [-k INT] [--vcf-ploidy INT] [--fast] "
                          "[--use-unique-kmers] [--gpu INT] [--buffer INT]\n";
@@ -334,6 +343,10 @@ int main_construct(int argc, char** argv)
     vgmi_ctx* ctx = nullptr;
     if (vgmi_create(gpu, (size_t)buffer_mib, &ctx) != VGMI_OK) die(std::string("device ") + std::to_string(gpu) + ": " + vgmi_last_error(nullptr));
     try {
+        if (debug) {
+            c.threads = 1;
+            setenv("VGH_TIMING", "1", 1);
+        }
         c.release_memory = false;   // the process ends right after
         const vgh::ConstructStats st = vgh::construct_graph(ctx, c);
         std::fprintf(stderr,
