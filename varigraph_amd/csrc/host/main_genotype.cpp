@@ -299,7 +299,7 @@ int main_genotype(int argc, char** argv)
 int main_construct(int argc, char** argv)
 {
     vgh::ConstructConfig c;
-    int gpu = 0, buffer_mib = 100;
+    int gpu = 0, buffer_mib = 100, vcf_ploidy = (int)c.vcf_ploidy, kmer = (int)c.k;
     bool debug = false;
     static const struct option long_options[] = {
         {"reference", required_argument, 0, 'r'}, {"vcf", required_argument, 0, 'v'},
@@ -316,8 +316,8 @@ int main_construct(int argc, char** argv)
         case 'r': c.reference = optarg; break;
         case 'v': c.vcf = optarg; break;
         case 1: c.out = optarg; break;
-        case 2: c.vcf_ploidy = (uint32_t)std::max(std::stoi(optarg), 1); break;
-        case 'k': c.k = (uint32_t)std::stoul(optarg); break;
+        case 2: vcf_ploidy = std::stoi(optarg); break;
+        case 'k': kmer = std::stoi(optarg); break;
         case 3: c.fast = true; break;
         case 4: c.use_unique_kmers = true; break;
         case 7: gpu = std::stoi(optarg); break;
@@ -332,7 +332,12 @@ int main_construct(int argc, char** argv)
     }
     if (c.reference.empty()) die("Parameter error: -r. The reference genome file cannot be empty.");
     if (c.vcf.empty()) die("Parameter error: -v. The VCF file cannot be empty.");
-    if (c.k < 1 || c.k > 28) die("Parameter error: -k. The k-mer length must be in 1..28.");
+    if (c.out.empty()) die("Parameter error: --save-graph. The Genome Graph file cannot be empty.");
+    // main.cpp:181-191
+    if (vcf_ploidy <= 0 || vcf_ploidy > 8) die("Parameter error: --vcf-ploidy. The provided value must be between 2 and 8 (inclusive).");
+    if (kmer <= 0 || kmer > 28) die("Parameter error: -k. The provided value must be between 1 and 28 (inclusive).");
+    c.vcf_ploidy = (uint32_t)vcf_ploidy;
+    c.k = (uint32_t)kmer;
     if (const char* e = std::getenv("VGH_RANDOM_DEVICE_VALUE")) {
         c.random_device_value = (uint32_t)std::strtoul(e, nullptr, 10);
     } else {
