@@ -149,7 +149,11 @@ int main_genotype(int argc, char** argv)
     if (o.hmm.sample_type != "hom" && o.hmm.sample_type != "het") die("Parameter error: -g. The provided value must be either 'hom' or 'het'.");
     if (o.hmm.sample_ploidy == 0 || o.hmm.sample_ploidy > 8) die("Parameter error: --sample-ploidy. The provided value must be between 2 and 8 (inclusive).");
     if (o.hmm.haploid_num == 0) die("Parameter error: -n. The provided value must be greater than 0.");
+    if (o.hmm.haploid_num < 10)   // main.cpp:367-369
+        std::cerr << "[varigraph-mi] Parameter warning: -n. The number of haploids for genotyping is relatively low, which may affect the accuracy of genotyping.\n";
     if (o.hmm.chr_len_thread < 1) die("Parameter error: --granularity. The chromosome granularity must be greater than 1.");
+    if (o.hmm.chr_len_thread < 1000)   // main.cpp:375-377
+        std::cerr << "[varigraph-mi] Parameter warning: --granularity. The chromosome granularity is less than 1000bp (" << o.hmm.chr_len_thread << " bp).\n";
     if (o.hmm.transition != "fre" && o.hmm.transition != "rec") die("Parameter error: -m. The transition probability type must be either 'fre' or 'rec'.");
     if (o.buffer_mib < 1) die("Parameter error: --buffer. The buffer size must be at least 1 MiB.");
 
