@@ -79,7 +79,9 @@ public:
     std::vector<uint32_t> order() const
     {
         std::vector<uint32_t> list;   // the list the next bucket array is rehashed from
-        std::vector<uint32_t> seq, bkt, count, start, grouped;
+        struct Bucket { uint32_t count, start; };   // one cache line touch per record in either pass
+        std::vector<uint32_t> seq, bkt, grouped;
+        std::vector<Bucket> buckets;
         for (size_t e = 0; e < epochs_.size(); ++e) {
             const size_t from = epochs_[e].first_id;
             const size_t to = e + 1 < epochs_.size() ? epochs_[e + 1].first_id : keys_.size();
@@ -89,27 +91,26 @@ public:
             for (size_t id = from; id < to; ++id) seq.push_back((uint32_t)id);
             const size_t m = seq.size();
             bkt.resize(m);
-            for (size_t i = 0; i < m; ++i) bkt[i] = (uint32_t)(keys_[seq[i]] % n_bkt);
+            buckets.assign(n_bkt, Bucket{0, kNil});
             // stable grouping by bucket, buckets in order of first appearance ...
-            count.assign(n_bkt, 0);
             for (size_t i = 0; i < m; ++i) {
-                if (i + 16 < m) __builtin_prefetch(&count[bkt[i + 16]], 1);
-                count[bkt[i]]++;
+                if (i + 24 < m) __builtin_prefetch(&keys_[seq[i + 24]]);
+                bkt[i] = (uint32_t)(keys_[seq[i]] % n_bkt);
             }
-            start.assign(n_bkt, kNil);
+            for (size_t i = 0; i < m; ++i) {
+                if (i + 16 < m) __builtin_prefetch(&buckets[bkt[i + 16]], 1);
+                buckets[bkt[i]].count++;
+            }
             grouped.resize(m);
             uint32_t running = 0;
             for (size_t i = 0; i < m; ++i) {
-                if (i + 16 < m) {
-                    __builtin_prefetch(&start[bkt[i + 16]], 1);
-                    __builtin_prefetch(&count[bkt[i + 16]]);
+                if (i + 16 < m) __builtin_prefetch(&buckets[bkt[i + 16]], 1);
+                Bucket& b = buckets[bkt[i]];
+                if (b.start == kNil) {
+                    b.start = running;
+                    running += b.count;
                 }
-                const uint32_t b = bkt[i];
-                if (start[b] == kNil) {
-                    start[b] = running;
-                    running += count[b];
-                }
-                grouped[start[b]++] = seq[i];
+                grouped[b.start++] = seq[i];
             }
             // ... and the list is that sequence backwards
             list.resize(m);
