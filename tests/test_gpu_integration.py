@@ -17,6 +17,16 @@ import pytest
 
 from conftest import GOLDEN, ROOT
 
+
+def _run(cmd, **kw):
+    """subprocess.run that turns a timeout into a failure naming the binary and showing what it had printed so far."""
+    try:
+        return subprocess.run(cmd, **kw)
+    except subprocess.TimeoutExpired as e:
+        err = e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
+        raise AssertionError(f"TIMEOUT after {e.timeout} s: {' '.join(map(str, cmd[:3]))} ...\nstderr so far:\n{err[-3000:]}") from None
+
+
 pytestmark = pytest.mark.gpu
 
 BIN = os.path.join(ROOT, "oracle", "_ref", "varigraph_hip")
@@ -54,7 +64,7 @@ def test_genotype_vcf_identical_to_reference(cohort, mode, extra, tmp_path):
     graph.write_bytes(gzip.open(os.path.join(d, "graph.bin.gz"), "rb").read())
     fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
     (tmp_path / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
-    r = subprocess.run([BIN, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4",
+    r = _run([BIN, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4",
                         "--gpu", "0", "--buffer", "8"] + extra, cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     got = gzip.open(tmp_path / "sample0.varigraph.vcf.gz", "rb").read()
@@ -63,7 +73,7 @@ def test_genotype_vcf_identical_to_reference(cohort, mode, extra, tmp_path):
     cpu = tmp_path / "cpu"
     cpu.mkdir()
     (cpu / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
-    r2 = subprocess.run([REF, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4"] + extra,
+    r2 = _run([REF, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4"] + extra,
                         cwd=cpu, capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0, r2.stderr[-2000:]
     want_here = gzip.open(cpu / "sample0.varigraph.vcf.gz", "rb").read()
@@ -76,7 +86,7 @@ def test_genotype_vcf_identical_to_reference(cohort, mode, extra, tmp_path):
 def test_integration_binary_fails_loudly_on_bad_input(tmp_path):
     if not os.path.exists(BIN):
         pytest.skip("integration binary not built")
-    r = subprocess.run([BIN, "genotype", "--load-graph", str(tmp_path / "nope.bin"), "-s", "nope.cfg"],
+    r = _run([BIN, "genotype", "--load-graph", str(tmp_path / "nope.bin"), "-s", "nope.cfg"],
                        cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
 
@@ -102,7 +112,7 @@ def test_native_cli_vcf_identical_to_reference(cohort, mode, extra, tmp_path):
     fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
     (tmp_path / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
     env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
-    r = subprocess.run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4", "--gpu", "0",
+    r = _run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4", "--gpu", "0",
                         "--buffer", "8"] + extra, cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     got = gzip.open(tmp_path / "sample0.varigraph.vcf.gz", "rb").read()
@@ -114,7 +124,7 @@ def test_native_cli_vcf_identical_to_reference(cohort, mode, extra, tmp_path):
         cpu = tmp_path / "cpu"
         cpu.mkdir()
         (cpu / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
-        r2 = subprocess.run([REF, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4"] + extra,
+        r2 = _run([REF, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4"] + extra,
                             cwd=cpu, capture_output=True, text=True, timeout=300)
         assert r2.returncode == 0, r2.stderr[-2000:]
         assert got == gzip.open(cpu / "sample0.varigraph.vcf.gz", "rb").read()
@@ -129,7 +139,7 @@ def test_native_cli_two_samples_and_errors(tmp_path):
     fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
     (tmp_path / "samples.cfg").write_text("".join(f"sample{s} " + " ".join(fq) + "\n" for s in (0, 1)))
     env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
-    r = subprocess.run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4", "-n", "5"], cwd=tmp_path,
+    r = _run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4", "-n", "5"], cwd=tmp_path,
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     for s in (0, 1):
@@ -137,12 +147,12 @@ def test_native_cli_two_samples_and_errors(tmp_path):
         want = open(os.path.join(d, f"expected_two_n5_s{s}.vcf"), "rb").read()
         assert _strip_gq(got) == _strip_gq(want)
     # loud failures: missing graph, missing read file, bad option value
-    assert subprocess.run([CLI, "genotype", "--load-graph", str(tmp_path / "nope.bin"), "-s", "samples.cfg"], cwd=tmp_path,
+    assert _run([CLI, "genotype", "--load-graph", str(tmp_path / "nope.bin"), "-s", "samples.cfg"], cwd=tmp_path,
                           capture_output=True, timeout=300).returncode != 0
     (tmp_path / "bad.cfg").write_text("s0 /nonexistent_1.fq.gz\n")
-    assert subprocess.run([CLI, "genotype", "--load-graph", str(graph), "-s", "bad.cfg"], cwd=tmp_path,
+    assert _run([CLI, "genotype", "--load-graph", str(graph), "-s", "bad.cfg"], cwd=tmp_path,
                           capture_output=True, timeout=300).returncode != 0
-    assert subprocess.run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-g", "maybe"], cwd=tmp_path,
+    assert _run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-g", "maybe"], cwd=tmp_path,
                           capture_output=True, timeout=300).returncode != 0
 
 
@@ -158,7 +168,7 @@ def test_native_cli_several_devices_keep_sample_order(tmp_path):
     fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
     (tmp_path / "samples.cfg").write_text("".join(f"sample{s} " + " ".join(fq) + "\n" for s in range(4)))
     env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
-    r = subprocess.run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4", "-n", "5", "--gpus", "0,0"],
+    r = _run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4", "-n", "5", "--gpus", "0,0"],
                        cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     body = lambda v: [ln for ln in _strip_gq(v).split(b"\n") if ln and not ln.startswith(b"#")]
@@ -180,7 +190,7 @@ def test_native_cli_independent_samples_run_side_by_side(tmp_path):
     fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
     (tmp_path / "samples.cfg").write_text("".join(f"sample{s} " + " ".join(fq) + "\n" for s in range(5)))
     env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
-    r = subprocess.run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "3", "--gpus", "0,0,0"],
+    r = _run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "3", "--gpus", "0,0,0"],
                        cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     want = open(os.path.join(d, "expected_het.vcf"), "rb").read()
@@ -205,7 +215,7 @@ def test_native_construct_reproduces_reference_graph(cohort, tmp_path):
     fa = tmp_path / "ref.fa"
     synth.write_fasta(str(fa), "chr1", ref)
     env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
-    r = subprocess.run([CLI, "construct", "-r", str(fa), "-v", os.path.join(d, "in.vcf"), "--save-graph", "graph.bin", "-k",
+    r = _run([CLI, "construct", "-r", str(fa), "-v", os.path.join(d, "in.vcf"), "--save-graph", "graph.bin", "-k",
                         str(meta["k"]), "--vcf-ploidy", str(meta["ploidy"]), "--gpu", "0"], cwd=tmp_path, capture_output=True,
                        text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -226,19 +236,19 @@ def test_native_construct_then_genotype_and_errors(tmp_path):
     fa = tmp_path / "ref.fa"
     synth.write_fasta(str(fa), "chr1", synth.make_reference(meta["ref_len"], seed=meta["ref_seed"]))
     env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
-    r = subprocess.run([CLI, "construct", "-r", str(fa), "-v", os.path.join(d, "in.vcf"), "--save-graph", "g.bin"], cwd=tmp_path,
+    r = _run([CLI, "construct", "-r", str(fa), "-v", os.path.join(d, "in.vcf"), "--save-graph", "g.bin"], cwd=tmp_path,
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
     (tmp_path / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
-    r = subprocess.run([CLI, "genotype", "--load-graph", "g.bin", "-s", "samples.cfg", "-t", "4"], cwd=tmp_path,
+    r = _run([CLI, "genotype", "--load-graph", "g.bin", "-s", "samples.cfg", "-t", "4"], cwd=tmp_path,
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     got = gzip.open(tmp_path / "sample0.varigraph.vcf.gz", "rb").read()
     assert _strip_gq(got) == _strip_gq(open(os.path.join(d, "expected_het.vcf"), "rb").read())
     for bad in (["-r", str(tmp_path / "nope.fa"), "-v", os.path.join(d, "in.vcf")], ["-r", str(fa), "-v", str(tmp_path / "nope.vcf")],
                 ["-r", str(fa), "-v", os.path.join(d, "in.vcf"), "-k", "31"]):
-        assert subprocess.run([CLI, "construct"] + bad, cwd=tmp_path, capture_output=True, timeout=300).returncode != 0
+        assert _run([CLI, "construct"] + bad, cwd=tmp_path, capture_output=True, timeout=300).returncode != 0
 
 
 def test_native_cli_block_gzip_and_plain_inputs(tmp_path):
@@ -255,7 +265,7 @@ def test_native_cli_block_gzip_and_plain_inputs(tmp_path):
     synth.bgzf_compress_file(str(fa), str(tmp_path / "ref.fa.gz"), block=4000)
     synth.bgzf_compress_file(os.path.join(d, "in.vcf"), str(tmp_path / "in.vcf.gz"), block=3000)
     env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
-    r = subprocess.run([CLI, "construct", "-r", "ref.fa.gz", "-v", "in.vcf.gz", "--save-graph", "g.bin", "-t", "4"], cwd=tmp_path,
+    r = _run([CLI, "construct", "-r", "ref.fa.gz", "-v", "in.vcf.gz", "--save-graph", "g.bin", "-t", "4"], cwd=tmp_path,
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert (tmp_path / "g.bin").read_bytes() == gzip.open(os.path.join(d, "graph.bin.gz"), "rb").read()
@@ -271,7 +281,7 @@ def test_native_cli_block_gzip_and_plain_inputs(tmp_path):
             plain.write_bytes(gzip.open(src, "rb").read())
             fq.append(str(plain) if kind == "plain" else synth.bgzf_compress_file(str(plain), str(tmp_path / f"reads_{i}.b.fq.gz")))
         (tmp_path / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
-        r = subprocess.run([CLI, "genotype", "--load-graph", "g.bin", "-s", "samples.cfg", "-t", "6"] + (["-D"] if kind == "plain" else []),
+        r = _run([CLI, "genotype", "--load-graph", "g.bin", "-s", "samples.cfg", "-t", "6"] + (["-D"] if kind == "plain" else []),
                            cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         assert ("[graph_index]" in r.stderr) == (kind == "plain")   # -D / --debug: single-threaded, phase times
