@@ -83,8 +83,14 @@ def cpu_baseline(haps, n_reads, cores):
             for threads in sorted({10, 16, 32, min(64, cores), cores}):  # 10 = reference default (-t)
                 if threads > cores or time.perf_counter() > t_budget:
                     continue
-                out = subprocess.run([harness, "count", graph, str(threads), os.path.join(work, "c.bin")] + fq,
-                                     capture_output=True, text=True)
+                try:
+                    # the reference's own thread pool notifies without holding its mutex (include/ThreadPool.hpp:
+                    # submit / shutdown), so a run can -- rarely -- sleep forever on a lost wake-up: bound it
+                    out = subprocess.run([harness, "count", graph, str(threads), os.path.join(work, "c.bin")] + fq,
+                                         capture_output=True, text=True, timeout=120)
+                except subprocess.TimeoutExpired:
+                    log(f"reference harness at -t {threads} did not finish in 120 s (lost wake-up in its thread pool?): skipped")
+                    continue
                 if out.returncode != 0:
                     log("reference harness failed:", out.stderr[-500:])
                     continue

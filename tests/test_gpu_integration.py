@@ -19,12 +19,25 @@ from conftest import GOLDEN, ROOT
 
 
 def _run(cmd, **kw):
-    """subprocess.run that turns a timeout into a failure naming the binary and showing what it had printed so far."""
-    try:
-        return subprocess.run(cmd, **kw)
-    except subprocess.TimeoutExpired as e:
-        err = e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
-        raise AssertionError(f"TIMEOUT after {e.timeout} s: {' '.join(map(str, cmd[:3]))} ...\nstderr so far:\n{err[-3000:]}") from None
+    """subprocess.run with two additions.  (1) A timeout becomes a failure naming the binary and showing what it had
+    printed.  (2) Binaries that contain the reference's code (oracle/_ref: the all-CPU reference and the adapter build)
+    are retried: the reference's thread pool notifies its workers without holding the mutex they wait under
+    (include/ThreadPool.hpp: submit() / shutdown()), so a run can, rarely, sleep forever on a lost wake-up -- seen twice
+    in ~30 runs of this file on the 256-thread measurement host.  The native CLI does not use that pool and gets no
+    retry."""
+    has_reference_code = os.sep + os.path.join("oracle", "_ref") + os.sep in str(cmd[0])
+    attempts = 4 if has_reference_code else 1
+    if has_reference_code and "timeout" in kw:
+        kw = dict(kw, timeout=min(kw["timeout"], 90))
+    for attempt in range(attempts):
+        try:
+            return subprocess.run(cmd, **kw)
+        except subprocess.TimeoutExpired as e:
+            err = e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
+            if attempt + 1 < attempts:
+                print(f"[retry] {cmd[0]} did not finish in {e.timeout} s (attempt {attempt + 1}); stderr tail: {err[-300:]}")
+                continue
+            raise AssertionError(f"TIMEOUT after {e.timeout} s: {' '.join(map(str, cmd[:3]))} ...\nstderr so far:\n{err[-3000:]}") from None
 
 
 pytestmark = pytest.mark.gpu
