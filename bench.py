@@ -52,6 +52,16 @@ def cohort_haplotypes():
     return synth.sample_haplotypes(ref, variants, gts, 0, meta["ploidy"])
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_quota():
     """CPUs this process may use at once according to its cgroup (cpu.max), or None without a quota."""
     try:
@@ -96,10 +106,24 @@ def cpu_baseline(haps, n_reads, cores):
                     continue
                 vals = dict(ln.split(" ", 1) for ln in out.stdout.splitlines() if " " in ln)
                 sweep[threads] = n_reads / float(vals["build_fastq_index_s"])
+            t1 = None
+            if sweep and time.perf_counter() < t_budget:
+                # -t 1 on the first tenth of the sample (the single-thread rate is ~1e5 reads/s)
+                n1 = (n_reads // 10) // 2 * 2
+                fq1 = synth.write_fastq_pair(os.path.join(work, "s1"), block[: n1 * (READ_LEN + 1)], n1, READ_LEN, gz=False)
+                try:
+                    out = subprocess.run([harness, "count", graph, "1", os.path.join(work, "c1.bin")] + fq1,
+                                         capture_output=True, text=True, timeout=120)
+                    if out.returncode == 0:
+                        vals = dict(ln.split(" ", 1) for ln in out.stdout.splitlines() if " " in ln)
+                        t1 = round(n1 / float(vals["build_fastq_index_s"]))
+                except subprocess.TimeoutExpired:
+                    pass
             if sweep:
                 best = max(sweep, key=sweep.get)
                 return {"value": sweep[best], "unit": "reads/s", "cores": best, "kind": "reference",
-                        "host_logical_cpus": cores, "cgroup_cpu_quota": cpu_quota(),
+                        "host_logical_cpus": cores, "cgroup_cpu_quota": cpu_quota(), "cpu_model": cpu_model(),
+                        "reads_per_s_at_t1": t1,
                         "sweep_reads_per_s_by_threads": {str(k): round(v) for k, v in sorted(sweep.items())},
                         "sample": f"{n_reads} reads (plain FASTQ, 2 files) of the same workload through the unmodified "
                                   f"reference FastqKmer::build_fastq_index (oracle/_ref), best of the -t sweep"}
