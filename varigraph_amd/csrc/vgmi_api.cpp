@@ -204,6 +204,7 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
         if (n_keys > VG_GRID_LDS_MAX_KEYS) {
             // global variant: 64-bit entries (Bloom word + offset bits), >= 32 bits per key in all
             b = ceil_log2(32 * n_keys) - 6;
+            if (const char* e = getenv("VGMI_GRID_SHIFT")) b = (uint32_t)((int)b + atoi(e));   // A/B: grid filter size
             if (b < VG_GRID_LDS_WORDS_LOG2 + 1) b = VG_GRID_LDS_WORDS_LOG2 + 1;
             if (b > 31) b = 31;   // vg_grid_probe draws the entry index from a 32-bit product word
             entry_bytes = 8;
