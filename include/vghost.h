@@ -123,6 +123,9 @@ void vgh_genotyper_free(vgh_genotyper *gt);
  * <sample>.varigraph.vcf.gz. */
 int vgh_genotype(vgh_genotyper *gt, const uint8_t *cov, float hap_kmer_coverage, const char *sample_name,
                  const vgh_genotype_config *cfg, char **vcf_text_out, size_t *n_bytes_out);
+/* <sample>.varigraph.vcf.gz as `varigraph-mi genotype` writes it: block gzip (BGZF) of `text`, deflated by `threads`
+ * workers; the decompressed bytes are what the reference's SAVE::save writes (src/save.cpp:11-30) */
+int vgh_write_vcf_gz(const char *path, const char *text, size_t n_bytes, uint32_t threads);
 
 #ifdef __cplusplus
 }

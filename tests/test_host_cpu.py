@@ -333,3 +333,31 @@ def test_stl_order_map_iterates_like_unordered_map(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "order identical" in r.stdout, r.stdout[-2000:]
+
+
+def test_vcf_writer_emits_block_gzip_independent_of_thread_count(tmp_path):
+    """The CLI's output writer: valid BGZF (every member carries its size in the 'BC' field, EOF marker at the end), the
+    content is the text, and the bytes do not depend on how many workers deflated the blocks."""
+    import struct
+    rng = np.random.default_rng(9)
+    lines = [b"chr1\t%d\t.\tA\tC\t.\tPASS\t.\tGT:GQ:GPP:NAK:CAK:UK\t0/1:%d.0:0.99:%d,%d:5.5,4.2:%d\n" % (i * 37, rng.integers(0, 99), rng.integers(1, 60),
+             rng.integers(1, 60), rng.integers(0, 50)) for i in range(60000)]
+    for text in (b"".join(lines), b"", b"x", b"".join(lines)[:0xff00], b"".join(lines)[:0xff01]):
+        outs = []
+        for threads in (1, 3, 8):
+            p = tmp_path / f"o{threads}.vcf.gz"
+            host.write_vcf_gz(str(p), text, threads)
+            outs.append(p.read_bytes())
+        assert outs[0] == outs[1] == outs[2]
+        assert gzip.decompress(outs[0]) == text
+        # walk the members through their BSIZE fields
+        raw, o, total = outs[0], 0, 0
+        while o < len(raw):
+            assert raw[o:o + 4] == b"\x1f\x8b\x08\x04" and raw[o + 12:o + 16] == b"BC\x02\x00"
+            bsize = struct.unpack("<H", raw[o + 16:o + 18])[0] + 1
+            isize = struct.unpack("<I", raw[o + bsize - 4:o + bsize])[0]
+            assert isize <= 0xff00
+            total += isize
+            o += bsize
+        assert o == len(raw) and total == len(text)
+        assert raw.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))

@@ -125,6 +125,18 @@ int64_t vgh_fastx_read_all(const char* path, char** block_out, size_t* n_bytes_o
     return vgh_fastx_read_all_mt(path, 1, block_out, n_bytes_out, read_base, nullptr);
 }
 
+int vgh_write_vcf_gz(const char* path, const char* text, size_t n_bytes, uint32_t threads)
+{
+    if (!path || (!text && n_bytes)) return VGMI_E_INVALID;
+    try {
+        vgh::Genotyper::write_gz(path, std::string(text ? text : "", n_bytes), threads);
+        return VGMI_OK;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return VGMI_E_INVALID;
+    }
+}
+
 void vgh_free(void* p) { free(p); }
 
 uint32_t vgh_crc32(uint32_t crc, const void* data, size_t n) { return vgh::crc32_fast(crc, static_cast<const unsigned char*>(data), n); }

@@ -211,6 +211,15 @@ def load_graph(path):
         g.close()
 
 
+def write_vcf_gz(path, text, threads=1):
+    """`text` (bytes) as block gzip, the way `varigraph-mi genotype` writes <sample>.varigraph.vcf.gz."""
+    l = lib()
+    l.vgh_write_vcf_gz.restype = C.c_int
+    l.vgh_write_vcf_gz.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_uint32]
+    if l.vgh_write_vcf_gz(os.fsencode(path), text, len(text), threads):
+        raise RuntimeError(l.vgh_last_error().decode())
+
+
 def fastx_read_all(path, decode_threads=1, with_kind=False):
     """All records of a FASTA/Q(.gz) file as a '\\n'-joined block (kseq_read semantics).  with_kind: also how the
     bytes were decoded ("plain" | "gzip" | "bgzf", csrc/host/byte_source.hpp)."""
