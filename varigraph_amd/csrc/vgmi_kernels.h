@@ -42,7 +42,8 @@ struct RowParams {
                           // fast kernel covers the ends up to its last grid offset)
     uint32_t k;
     uint32_t dbg;         // ablations of count27_kernel only (VGMI_DBG; counts are wrong with any of them): 1 = scan
-                          // only (candidate runs dropped), 32 = one probing lane per run, 64 = collisions dropped
+                          // only (candidate runs dropped), 32 = one probing lane per run, 64 = collisions dropped; 128 = K3 without the per-wave
+                          // privatisation (same filter, A/B only)
     uint32_t* status;     // bit0 empty read, bit1 bad key, bit2 duplicate key
     TableView table;      // MODE_COUNT
     uint64_t* keys_out;   // MODE_KEYS

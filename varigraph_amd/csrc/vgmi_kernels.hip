@@ -81,6 +81,57 @@ __device__ __forceinline__ void bloom_add_key(const BloomView& b, uint64_t key)
     }
 }
 
+// n occurrences of one key at once: filter[pos] = min(255, filter[pos] + n) per hash (n increments of the reference)
+__device__ __forceinline__ void bloom_add_key_n(const BloomView& b, uint64_t key, uint32_t n)
+{
+    for (uint32_t i = 0; i < b.n_hash; ++i) {
+        const uint64_t pos = mod_u64(vg_murmur_sum(key, b.seeds[i]), b.m, b.magic);
+        uint32_t* w = reinterpret_cast<uint32_t*>(b.filter + (pos & ~3ULL));
+        const uint32_t sh = (uint32_t)(pos & 3) * 8;
+        uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+            const uint32_t v = (old >> sh) & 0xFFu;
+            if (v == 0xFFu) break;
+            const uint32_t nv = v + n > 255u ? 255u : v + n;
+            const uint32_t prev = atomicCAS(w, old, (old & ~(0xFFu << sh)) | (nv << sh));
+            if (prev == old) break;
+            old = prev;
+        }
+    }
+}
+
+// Per-wavefront privatisation of the Bloom update (K3): the k-mers the 64 lanes present in one step go through a
+// 128-cell table in LDS first, so a key that several lanes hold -- tandem repeats, homopolymers, satellites put the same
+// k-mer at many of a wave's 1 024 consecutive positions -- reaches the filter once, with its multiplicity, instead of
+// as up to 64 compare-and-swap loops fighting over the same seven bytes.
+#define VG_BPRIV_CELLS 128u
+__device__ __forceinline__ void bloom_add_wave(const BloomView& b, unsigned long long* cell_key, uint32_t* cell_cnt, bool active,
+                                               uint64_t key)
+{
+    uint32_t slot = 0;
+    bool owner = false;
+    if (active) {
+        slot = (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> 57);
+        for (;;) {
+            const unsigned long long old = atomicCAS(&cell_key[slot], ~0ULL, (unsigned long long)key);
+            if (old == ~0ULL) { owner = true; break; }
+            if (old == key) break;
+            slot = (slot + 1) & (VG_BPRIV_CELLS - 1);
+        }
+        atomicAdd(&cell_cnt[slot], 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (owner) {
+        const uint32_t n = cell_cnt[slot];
+        cell_cnt[slot] = 0;
+        cell_key[slot] = ~0ULL;
+        bloom_add_key_n(b, key, n);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // counter cell of the key held by slot s (16-byte format: v = the slot; compact format: counts are per slot)
 __device__ __forceinline__ uint32_t* count_cell(const TableView& t, uint64_t s, uint32_t key_index)
 {
@@ -212,6 +263,15 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
     if (FLDS) off += (size_t)4 << p.table.filter_words_log2;
     uint64_t* s_queue = reinterpret_cast<uint64_t*>(smem + off) + (size_t)wave * VG_QCAP;
     if (MODE == MODE_COUNT) off += (size_t)nwaves * VG_QCAP * 8;
+    unsigned long long* s_bkey = reinterpret_cast<unsigned long long*>(smem + off) + (size_t)wave * VG_BPRIV_CELLS;
+    if (MODE == MODE_BLOOM) off += (size_t)nwaves * VG_BPRIV_CELLS * 8;
+    uint32_t* s_bcnt = reinterpret_cast<uint32_t*>(smem + off) + (size_t)wave * VG_BPRIV_CELLS;
+    if (MODE == MODE_BLOOM) off += (size_t)nwaves * VG_BPRIV_CELLS * 4;
+    if (MODE == MODE_BLOOM)
+        for (uint32_t i = lane; i < VG_BPRIV_CELLS; i += 64) {
+            s_bkey[i] = ~0ULL;
+            s_bcnt[i] = 0;
+        }
     uint8_t* s_lut = smem + off;
     stage_lut(s_lut, tid, blockDim.x);
     if (FLDS) {
@@ -332,7 +392,11 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
                 if (pos < p.n_bytes) p.keys_out[pos] = valid ? (vg_hash64(canon, mask) << 8 | K) : ~0ULL;
             } else if (MODE == MODE_BLOOM) {
                 const uint64_t pos = (r << 10) + lane * 16 + j;
-                if (valid && pos < p.n_bytes) bloom_add_key(p.bloom, vg_hash64(canon, mask) << 8 | K);
+                if (p.dbg & 128u) {   // A/B: every lane updates the filter itself
+                    if (valid && pos < p.n_bytes) bloom_add_key(p.bloom, vg_hash64(canon, mask) << 8 | K);
+                } else {
+                    bloom_add_wave(p.bloom, s_bkey, s_bcnt, valid && pos < p.n_bytes, vg_hash64(canon, mask) << 8 | K);
+                }
             } else {
                 const bool emit = valid && (r << 10) + lane * 16 + j >= p.emit_from;
                 bool pass;
@@ -924,6 +988,16 @@ __global__ __launch_bounds__(256) void seq_kernel(RowParams p, const uint64_t* r
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bloom_even_kernel(RowParams p, uint64_t seg_len)
 {
+    __shared__ unsigned long long s_bkey[4 * VG_BPRIV_CELLS];
+    __shared__ uint32_t s_bcnt[4 * VG_BPRIV_CELLS];
+    unsigned long long* const cell_key = s_bkey + (threadIdx.x >> 6) * VG_BPRIV_CELLS;
+    uint32_t* const cell_cnt = s_bcnt + (threadIdx.x >> 6) * VG_BPRIV_CELLS;
+    for (uint32_t i = threadIdx.x & 63u; i < VG_BPRIV_CELLS; i += 64) {
+        cell_key[i] = ~0ULL;
+        cell_cnt[i] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     const uint64_t seg = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t s = seg * seg_len;
     if (s >= p.n_bytes) return;
@@ -974,18 +1048,29 @@ __global__ __launch_bounds__(256) void bloom_even_kernel(RowParams p, uint64_t s
             break;
         }
     }
-    for (uint64_t i = s; i < e; ++i) {
-        const uint32_t c = vg_nt4(p.bases[i]);
-        if (c < 4) {
-            fwd = (fwd << 2 | c) & mask;
-            rc = (rc >> 2) | (uint64_t)(3u ^ c) << shift1;
-            if (fwd != rc) {
-                if (l < K) ++l;
-                if (l >= K) bloom_add_key(p.bloom, vg_hash64(fwd < rc ? fwd : rc, mask) << 8 | K);
+    // the lanes of a wave walk their segments in step, so the keys of one step go through the per-wave table like in
+    // the odd-k kernel (neighbouring segments of a low-complexity region emit the same k-mer)
+    for (uint64_t t = 0; t < seg_len; ++t) {
+        const uint64_t i = s + t;
+        bool emit = false;
+        uint64_t key = 0;
+        if (i < e) {
+            const uint32_t c = vg_nt4(p.bases[i]);
+            if (c < 4) {
+                fwd = (fwd << 2 | c) & mask;
+                rc = (rc >> 2) | (uint64_t)(3u ^ c) << shift1;
+                if (fwd != rc) {
+                    if (l < K) ++l;
+                    if (l >= K) {
+                        emit = true;
+                        key = vg_hash64(fwd < rc ? fwd : rc, mask) << 8 | K;
+                    }
+                }
+            } else {
+                l = 0;
             }
-        } else {
-            l = 0;
         }
+        bloom_add_wave(p.bloom, cell_key, cell_cnt, emit, key);
     }
 }
 
@@ -1140,6 +1225,7 @@ static size_t rows_lds_bytes(int mode, bool flds, uint32_t filter_words_log2, ui
     size_t b = 512;
     if (flds) b += (size_t)4 << filter_words_log2;
     if (mode == MODE_COUNT) b += (size_t)(block / 64) * VG_QCAP * 8;
+    if (mode == MODE_BLOOM) b += (size_t)(block / 64) * VG_BPRIV_CELLS * 12;
     return b;
 }
 
