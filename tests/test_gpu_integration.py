@@ -28,7 +28,7 @@ def _run(cmd, **kw):
     has_reference_code = os.sep + os.path.join("oracle", "_ref") + os.sep in str(cmd[0])
     attempts = 4 if has_reference_code else 1
     if has_reference_code and "timeout" in kw:
-        kw = dict(kw, timeout=min(kw["timeout"], 90))
+        kw = dict(kw, timeout=min(kw["timeout"], 45))   # the fixtures take a second or two
     for attempt in range(attempts):
         try:
             return subprocess.run(cmd, **kw)
