@@ -187,7 +187,7 @@ struct Cursor {
     void bytes(void* dst, size_t n)
     {
         if ((size_t)(end - p) < n) throw std::runtime_error("graph index truncated");
-        memcpy(dst, p, n);
+        if (n) memcpy(dst, p, n);   // an empty list's data() may be null
         p += n;
     }
 };
