@@ -153,6 +153,7 @@ public:
     ~OutFile() { if (fd_ >= 0) ::close(fd_); }
     void write(const void* p, size_t n)
     {
+        if (n == 0) return;   // empty strings / lists: their data() may be null
         if (n > buf_.size() - used_) {
             flush();
             if (n > buf_.size()) { raw(p, n); return; }
