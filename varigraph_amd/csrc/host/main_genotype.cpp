@@ -62,7 +62,8 @@ void usage(const char* argv0)
 [[noreturn]] void die(const std::string& msg)
 {
     std::cerr << "[varigraph-mi] " << msg << std::endl;
-    std::exit(1);
+    std::fflush(nullptr);
+    std::_Exit(1);   // other threads (parsers, device streams) may be mid-flight: no static destructors under them
 }
 
 // Varigraph::parse_sample_config (src/varigraph.cpp:104-146)
