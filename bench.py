@@ -12,6 +12,14 @@ Workload at N=1 (BASELINE.json configs[1], "C2"): the 1 Mb / 1 k SNP / 15-haplot
 1000+rank) after ONE RCCL broadcast of the table image from rank 0: weak scaling, no data-path
 collective.
 
+Next to the C2 numbers the same line carries a `c3` block (BASELINE.json configs[2] / [3]): the chr20-class graph
+(60 Mb reference, 500 k SNPs, 2.56e7 k-mers: the table lives in HBM) with 2.4e7 device-generated reads per rank, its
+own kernel time, measured hits per read and HBM roofline (B_read = 150 + 992 + 2 hits), and a `verify`
+block: an UNSATURATED prefix of each workload compared counter by counter with the oracle outside the timed region.
+
+`python bench.py --gpus N` without a launcher starts its own N ranks (one process per GPU, RCCL); under
+`torch.distributed.run` it uses the ranks it is given.
+
 Prints one JSON line (rank 0).
 """
 import argparse
@@ -154,11 +162,29 @@ def measured_traffic(n_reads):
     return t["bytes_per_launch"], t
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU, BEFORE anything in
+    this process touches the GPU (the parent never does), and leave with the worst exit code."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200, help="timed sample passes (C2: 6 ms each)")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=100_000_000, help="reads per sample (2 per pair)")
     ap.add_argument("--cpu-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -168,7 +194,13 @@ def main():
     ap.add_argument("--shard-reads", action="store_true",
                     help="strong scaling: ONE sample of --reads reads sharded over the ranks, raw counters summed "
                          "with one RCCL all-reduce per step (default: one sample per rank, weak scaling)")
+    ap.add_argument("--no-c3", action="store_true", help="skip the chr20-class (table in HBM) leg")
+    ap.add_argument("--c3-reads", type=int, default=24_000_000)
+    ap.add_argument("--c3-steps", type=int, default=20)
+    ap.add_argument("--verify-reads", type=int, default=2_000_000, help="unsaturated prefix checked against the oracle")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
 
     import torch
     from varigraph_amd import build, vgmi
@@ -197,12 +229,77 @@ def main():
 
     from varigraph_amd import dist as vdist
     ctx = vgmi.Context(local, buffer_mib=256)
-    # ---- graph index: parsed on rank 0, table image broadcast once over xGMI (RCCL)
+    shard = args.shard_reads and world > 1
+
+    def fence():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def broadcast_table(ctx):
+        """ONE broadcast of the read-only table image from the rank that built it (RCCL over xGMI)."""
+        if not dist:
+            return None
+        fence()
+        t0 = time.perf_counter()
+        nbytes = vdist.broadcast_table_image(ctx, dist, rank, comm_dev, ctx_device=ctx_dev)
+        fence()
+        return {"bytes": nbytes, "seconds": time.perf_counter() - t0, "backend": "rccl" if args.backend == "nccl" else "gloo"}
+
+    def generate(haps, seed, first_read, n_reads):
+        cat = np.concatenate(haps)
+        hap_off = np.concatenate([[0], np.cumsum([len(h) for h in haps])]).astype(np.uint64)
+        d_cat = torch.from_numpy(cat).cuda()
+        d_block = torch.empty(n_reads * (READ_LEN + 1), dtype=torch.uint8, device="cuda")
+        chunk = 8_000_000
+        for first in range(0, n_reads, chunk):
+            n = min(chunk, n_reads - first)
+            ctx.synth_reads_device(seed, first_read + first, n, READ_LEN, d_cat, hap_off, d_block[first * (READ_LEN + 1):])
+        del d_cat
+        return d_block
+
+    def timed(step, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        for _ in range(warmup):
+            step()
+        ctx.count_kernel_ms()
+        fence()
+        kernel_ms, launches = 0.0, 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+            ms, n = ctx.count_kernel_ms()   # HIP events on the stream the count kernel runs on
+            kernel_ms += ms
+            launches += n
+        fence()
+        elapsed = time.perf_counter() - t0
+        if dist:
+            elapsed = vdist.max_over_ranks(elapsed, dist, comm_dev)
+        return elapsed, kernel_ms / max(launches, 1)
+
+    def verify(keys, d_block, n_check):
+        """An unsaturated prefix of the sample, counter by counter against the oracle (the checker; outside every
+        timed region).  A kernel that merely touches every key often enough cannot pass this."""
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        n_check = min(n_check, d_block.numel() // (READ_LEN + 1))
+        ctx.counts_reset()
+        ctx.reads_submit_device(d_block, n_check * (READ_LEN + 1), n_check)
+        got, _, _ = ctx.counts_finish()
+        t = oracle_lib.Table(keys)
+        t.count_block(d_block[: n_check * (READ_LEN + 1)].cpu().numpy(), K)
+        want = t.counts()
+        ok = bool(np.array_equal(got, want))
+        return {"reads": n_check, "oracle_match": ok, "cov_sum": int(got.astype(np.int64).sum()),
+                "keys_nonzero": int((got != 0).sum()), "keys_saturated": int((got == 255).sum()),
+                "distinct_counter_values": int(np.unique(got).size)}
+
+    # ================= C2: the 1 Mb graph (table on-chip), BASELINE.json configs[1] =================
     g = load_graph() if rank == 0 else None
     if rank == 0:
         ctx.table_upload(g["keys"], g["k"])
+    bcast_c2 = broadcast_table(ctx)
     if dist:
-        vdist.broadcast_table_image(ctx, dist, rank, comm_dev, ctx_device=ctx_dev)
         # node CSR + flags: small host-side graph data every rank needs for the gather
         arrs = {k: g[k] for k in ("node_off", "node_key_index", "hom_flag")} if rank == 0 else None
         arrs = vdist.broadcast_arrays(arrs, dist, rank, comm_dev)
@@ -213,22 +310,11 @@ def main():
     ctx.flags_upload(hom_flag)
     info = ctx.table_info()
 
-    # ---- this rank's sample, generated in HBM
     haps = cohort_haplotypes()
-    cat = np.concatenate(haps)
-    hap_off = np.concatenate([[0], np.cumsum([len(h) for h in haps])]).astype(np.uint64)
-    d_cat = torch.from_numpy(cat).cuda()
-    shard = args.shard_reads and world > 1
     n_reads = args.reads // world if shard else args.reads
     first_read = rank * n_reads if shard else 0
-    sample_seed = 1000 if shard else 1000 + rank
+    d_block = generate(haps, 1000 if shard else 1000 + rank, first_read, n_reads)
     n_bytes = n_reads * (READ_LEN + 1)
-    d_block = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")
-    chunk = 8_000_000
-    for first in range(0, n_reads, chunk):
-        n = min(chunk, n_reads - first)
-        ctx.synth_reads_device(sample_seed, first_read + first, n, READ_LEN, d_cat, hap_off,
-                               d_block[first * (READ_LEN + 1):])
     d_cov = torch.empty(max(info["n_keys"], 1), dtype=torch.uint8, device="cuda")
     d_cov_node = torch.empty(max(int(node_off[-1]), 1), dtype=torch.uint8, device="cuda")
     d_hist = torch.empty(256, dtype=torch.int64, device="cuda")
@@ -240,51 +326,86 @@ def main():
             vdist.allreduce_counts(ctx, dist, comm_dev, ctx_device=ctx_dev)
         ctx.counts_finish_device(d_cov, d_cov_node, d_hist)
 
-    def fence():
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    kernel_ms = 0.0
-    launches = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        ms, n = ctx.count_kernel_ms()   # per step: HIP events on the context stream around the count kernel
-        kernel_ms += ms
-        launches += n
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        elapsed = vdist.max_over_ranks(elapsed, dist, comm_dev)
-
-    # sanity: the sample must have produced coverage
+    elapsed, kernel_ms = timed(step, args.steps, args.warmup)
     cov_sum = int(d_cov.to(torch.int64).sum().item())
     hist = d_hist.cpu().numpy()
+    # hits per read on an unsaturated stretch (the counters clamp at 255): measured, for B_probe
+    ver_c2 = verify(g["keys"], d_block, args.verify_reads) if rank == 0 and args.verify_reads else None
+    del d_block
+    torch.cuda.empty_cache()
+
+    # ================= C3 / C4: the chr20-class graph (table in HBM), BASELINE.json configs[2], [3] =================
+    c3 = None
+    if not args.no_c3 and not shard:
+        from varigraph_amd import synth
+        t_g = time.perf_counter()
+        keys3, haps3 = synth.snp_graph(60_000_000, 500_000)   # every rank needs the haplotypes for its sample; the
+        t_g = time.perf_counter() - t_g                        # table itself is built on rank 0 only
+        if rank == 0:
+            ctx.table_upload(keys3, K)
+        bcast_c3 = broadcast_table(ctx)
+        info3 = ctx.table_info()
+        n3 = args.c3_reads
+        d_block3 = generate(haps3, 99 + rank, 0, n3)
+        d_cov3 = torch.empty(info3["n_keys"], dtype=torch.uint8, device="cuda")
+
+        def step3():
+            ctx.counts_reset()
+            ctx.reads_submit_device(d_block3, n3 * (READ_LEN + 1), n3)
+            ctx.counts_finish_device(d_cov3, None, None)
+
+        el3, kms3 = timed(step3, args.c3_steps, 1)
+        cov3 = d_cov3.cpu().numpy()
+        if rank == 0:
+            # hits per read, measured: the clamped counters of the full sample (30x: nothing near 255) summed
+            hits3 = float(cov3.astype(np.int64).sum()) / n3
+            b_read3 = READ_LEN + (READ_LEN - K + 1) * 8 + 2 * hits3 + info3["n_keys"] / n3
+            ach3 = b_read3 * n3 / (kms3 * 1e-3) / 1e9
+            tr3 = None
+            p3 = os.path.join(ROOT, "profiles", "hbm_traffic_c3.json")
+            if os.path.exists(p3):
+                tj = json.load(open(p3))
+                if tj.get("reads_per_launch") == n3:
+                    tr3 = tj["bytes_per_launch"]
+            c3 = {"workload": f"C3: chr20-class synthetic SNP graph (60 Mb, 500 k SNPs, {info3['n_keys']} k-mers), "
+                              f"{n3 // 2} read pairs 2x150 bp per sample, one sample per GPU",
+                  "value": world * n3 * args.c3_steps / el3, "unit": "reads/s", "steps": args.c3_steps,
+                  "ms_per_step": el3 / args.c3_steps * 1e3, "graph_kmers": info3["n_keys"], "table_slots": info3["n_slots"],
+                  "graph_build_s": t_g, "table_broadcast": bcast_c3,
+                  "hits_per_read": hits3, "keys_saturated": int((cov3 == 255).sum()),
+                  "roofline": {"bound": "hbm", "achieved": ach3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach3 / HBM_PEAK_GBS, "traffic": tr3,
+                               "algorithmic_bytes_per_launch": b_read3 * n3, "bytes_per_read": b_read3,
+                               "kernel": "vgk::count27_kernel<false, true>", "kernel_ms": kms3,
+                               "note": "SURVEY 8d: B_read = 150 (bases) + 124 x 8 (one key compare per k-mer) + 2 x hits "
+                                       "+ amortised read-out; hits measured from this run's counters"},
+                  "verify": verify(keys3, d_block3, args.verify_reads) if args.verify_reads else None}
+        del d_block3, d_cov3
 
     if rank == 0:
         total_reads = world * n_reads * args.steps
         value = total_reads / elapsed
-        avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
+        avg_kernel_s = kernel_ms / 1e3
         n_node = int(node_off[-1])
         b_stream = READ_LEN + (info["n_keys"] + n_node) / n_reads   # bases + amortised read-out
-        hits_per_read = 3.3
-        b_probe = (READ_LEN - K + 1) * 8 + 2 * hits_per_read
+        # hits per read for B_probe: measured on the unsaturated verification prefix (the full sample clamps)
+        hits_per_read = ver_c2["cov_sum"] / ver_c2["reads"] if ver_c2 and not ver_c2["keys_saturated"] else None
+        b_probe = (READ_LEN - K + 1) * 8 + 2 * (hits_per_read if hits_per_read is not None else 0.0)
         ach = b_stream * n_reads / avg_kernel_s / 1e9
         ach_probe = (b_stream + b_probe) * n_reads / avg_kernel_s / 1e9
         traffic, traffic_src = measured_traffic(n_reads)
         out = {
             "metric": "150 bp reads/sec genotyped (k=27)",
-            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "reads/s", "n_gpus": world, "world_size": dist.get_world_size() if dist else 1,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if shard else "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "C2: 1 Mb ref + 1 k SNP graph (15 haplotypes, 53 734 k-mers), "
-                                   f"{n_reads // 2} read pairs 2x150 bp per sample, k=27, one sample per GPU",
+                                   f"{n_reads // 2} read pairs 2x150 bp per sample, k=27, one sample per GPU"
+                                   + ("" if c3 is None else "; c3 block: chr20-class graph (60 Mb, 500 k SNPs), 12 M pairs per sample"),
                        "reads_per_sample": n_reads, "graph_kmers": info["n_keys"], "table_slots": info["n_slots"],
                        "prefilter_bits": info["filter_bits"], "parallelism": (f"one sample, reads sharded x{world} + all-reduce" if shard else f"sample-per-gpu x{world}")},
+            "table_broadcast": bcast_c2,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
@@ -294,12 +415,16 @@ def main():
                          "note": "C2's 0.43 MB table is on-chip, so the compulsory HBM traffic is the ASCII "
                                  "read stream only (SURVEY 8d B_stream); the kernel is instruction-issue bound "
                                  "(VALU + LDS, see DESIGN.md section 6 for the accounting)"},
-            "roofline_probe_inclusive": {"achieved": ach_probe, "frac": ach_probe / HBM_PEAK_GBS, "unit": "GB/s",
-                                         "bytes_per_read": b_stream + b_probe,
-                                         "note": "SURVEY 8d B_stream+B_probe figure comparable with the "
-                                                 "large-table configs; probes are served on-chip here"},
+            "probe_inclusive_rate": {"achieved": ach_probe, "unit": "GB/s", "bytes_per_read": b_stream + b_probe,
+                                     "hits_per_read_measured": hits_per_read,
+                                     "note": "SURVEY 8d B_stream+B_probe bytes over the same kernel time, for comparison "
+                                             "with the c3 block only: the probes are served on-chip here, so this is NOT "
+                                             "an HBM fraction"},
             "check": {"cov_sum": cov_sum, "hist_nonzero_bins": int((hist > 0).sum())},
+            "verify": ver_c2,
         }
+        if c3 is not None:
+            out["c3"] = c3
         if world == 1 and not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
             out["cpu_baseline"] = cpu_baseline(haps, args.cpu_reads, cores)

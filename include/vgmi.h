@@ -66,6 +66,10 @@ int vgmi_table_upload(vgmi_ctx *ctx, const uint64_t *host_keys, size_t n_keys, u
 int vgmi_table_image_bytes(vgmi_ctx *ctx, size_t *bytes);
 int vgmi_table_export(vgmi_ctx *ctx, void *dev_dst, size_t bytes);
 int vgmi_table_import(vgmi_ctx *ctx, const void *dev_src, size_t bytes);
+/* Same hand-over inside ONE process that drives several devices (`varigraph-mi genotype --gpus a,b,...`): dst adopts a
+ * copy of src's table image through one device-to-device transfer (xGMI peer copy between different devices); the table
+ * is built once per run, not once per device. */
+int vgmi_table_clone(vgmi_ctx *dst, vgmi_ctx *src);
 int vgmi_table_info(vgmi_ctx *ctx, size_t *n_keys, uint32_t *k, size_t *n_slots, size_t *filter_bits);
 
 /* Per-node k-mer lists in CSR form.
@@ -153,6 +157,10 @@ int vgmi_synth_reads_device(vgmi_ctx *ctx, uint64_t seed, uint64_t first_read, u
 int vgmi_synth_reads_host(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
                           const char *hap_cat, const uint64_t *hap_off, uint32_t n_hap, char *out);
 int vgmi_synth_reference_host(uint64_t seed, uint64_t len, char *out);
+/* keys (hash64(canonical) << 8 | k) of the 2k k-mers covering each SNP site, reference allele then alternative:
+ * keys_out[(2 * site + allele) * k + w]; neighbouring sites stay on the reference (large-table workloads) */
+int vgmi_synth_snp_keys_host(const char *ref, uint64_t ref_len, const uint64_t *pos, const char *alts,
+                             uint64_t n_sites, uint32_t k, uint64_t *keys_out);
 
 #ifdef __cplusplus
 }

@@ -184,6 +184,7 @@ def test_native_cli_several_devices_keep_sample_order(tmp_path):
     r = _run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4", "-n", "5", "--gpus", "0,0"],
                        cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
+    assert "table: 1 build on device 0, 1 device-to-device image copies" in r.stderr   # built once, copied, never re-uploaded
     body = lambda v: [ln for ln in _strip_gq(v).split(b"\n") if ln and not ln.startswith(b"#")]
     got = [gzip.open(tmp_path / f"sample{s}.varigraph.vcf.gz", "rb").read() for s in range(4)]
     for s in (0, 1):
@@ -206,6 +207,7 @@ def test_native_cli_independent_samples_run_side_by_side(tmp_path):
     r = _run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "3", "--gpus", "0,0,0"],
                        cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
+    assert "table: 1 build on device 0, 2 device-to-device image copies" in r.stderr
     want = open(os.path.join(d, "expected_het.vcf"), "rb").read()
     for s in range(5):
         got = gzip.open(tmp_path / f"sample{s}.varigraph.vcf.gz", "rb").read()

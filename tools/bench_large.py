@@ -24,14 +24,7 @@ def main():
     import torch
     from varigraph_amd import synth, vgmi
     t0 = time.time()
-    ref = synth.make_reference(args.genome, seed=777)
-    rng = np.random.default_rng(5)
-    pos = np.sort(rng.choice(np.arange(100, args.genome - 100), size=args.variants, replace=False))
-    alt_code = (synth._CODE[ref[pos]] + rng.integers(1, 4, size=args.variants)) % 4
-    alts = synth._ACGT[alt_code]
-    keys = synth.snp_kmer_keys(ref, pos, alts)
-    hap1 = ref.copy()
-    hap1[pos] = alts
+    keys, (ref, hap1) = synth.snp_graph(args.genome, args.variants)
     print(f"graph: {len(keys)} keys built in {time.time() - t0:.1f}s", file=sys.stderr)
     ctx = vgmi.Context(0, buffer_mib=64)
     ctx.table_upload(keys, 27)

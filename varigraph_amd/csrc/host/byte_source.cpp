@@ -4,7 +4,9 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <cerrno>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstdint>
 #include <cstring>
@@ -28,7 +30,7 @@ constexpr size_t kTaskOut = 2u << 20;    // BGZF: decoded bytes per worker task 
 // file descriptor with a push-back area (the bytes looked at to tell the formats apart)
 class FileIn {
 public:
-    explicit FileIn(const std::string& path) : fd_(::open(path.c_str(), O_RDONLY))
+    explicit FileIn(const std::string& path) : path_(path), fd_(::open(path.c_str(), O_RDONLY))
     {
         if (fd_ < 0) throw std::runtime_error("'" + path + "': No such file or directory.");
 #ifdef POSIX_FADV_SEQUENTIAL
@@ -49,7 +51,13 @@ public:
         }
         while (got < n) {
             const ssize_t r = ::read(fd_, dst + got, n - got);
-            if (r <= 0) break;   // an I/O error ends the data like gzread's -1 ends the reference's loop
+            if (r < 0 && errno == EINTR) continue;
+            if (r < 0) {   // an I/O error ends the data like gzread's -1 ends the reference's loop -- but not silently
+                std::fprintf(stderr, "[varigraph-mi] warning: '%s': read error (%s); the data ends here\n", path_.c_str(),
+                             std::strerror(errno));
+                break;
+            }
+            if (r == 0) break;
             got += (size_t)r;
         }
         return got;
@@ -62,7 +70,10 @@ public:
         back_pos_ = 0;
     }
 
+    const std::string& path() const { return path_; }
+
 private:
+    std::string path_;
     int fd_;
     std::vector<unsigned char> back_;
     size_t back_pos_ = 0;
@@ -211,7 +222,11 @@ void inflate_members(FileIn& in, Pipe& pipe)
         cur->n = n;
         pipe.put_full(std::move(cur));
     };
-    fast_gunzip(io, kChunk);
+    const GunzipEnd end = fast_gunzip(io, kChunk);
+    // the reference's gzread loop ends the same way at a damaged or short stream; the decoder here knows why
+    if (end == GunzipEnd::Corrupt || end == GunzipEnd::Truncated)
+        std::fprintf(stderr, "[varigraph-mi] warning: '%s': gzip stream %s; only what decoded cleanly is used\n", in.path().c_str(),
+                     end == GunzipEnd::Corrupt ? "is damaged (bad block, CRC-32 or length)" : "ends inside a member");
     if (cur) pipe.recycle(std::move(cur));
 }
 
@@ -337,6 +352,8 @@ public:
             order_.pop_front();
             cv_room_.notify_one();
             if (held_->failed) {   // nothing after the damage is delivered
+                std::fprintf(stderr, "[varigraph-mi] warning: '%s': a block-gzip member does not inflate; the data ends in front of it\n",
+                             in_->path().c_str());
                 ended_ = true;
                 cancel_ = true;
                 cv_work_.notify_all();

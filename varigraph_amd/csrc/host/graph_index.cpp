@@ -184,6 +184,11 @@ struct Cursor {
         p += n;
         return s;
     }
+    // a count read from the file must be backed by that many bytes BEFORE anything is sized by it
+    void need(size_t n) const
+    {
+        if ((size_t)(end - p) < n) throw std::runtime_error("graph index corrupt: a list is longer than the file");
+    }
     void bytes(void* dst, size_t n)
     {
         if ((size_t)(end - p) < n) throw std::runtime_error("graph index truncated");
@@ -248,12 +253,15 @@ void GraphIndex::load(const std::string& path)
             GraphNode nd;
             nd.start = c.get<uint32_t>();
             const uint32_t n_seq = c.get<uint32_t>();
+            c.need((size_t)n_seq * 4);   // every sequence carries at least its length field
             nd.seqs.reserve(n_seq);
             for (uint32_t q = 0; q < n_seq; ++q) nd.seqs.push_back(c.str());
             const uint32_t n_gt = c.get<uint32_t>();
+            c.need(sizeof(uint16_t) * (size_t)n_gt);
             nd.hap_gt.resize(n_gt);
             c.bytes(nd.hap_gt.data(), sizeof(uint16_t) * n_gt);
             const uint32_t n_km = c.get<uint32_t>();
+            c.need(sizeof(uint64_t) * (size_t)n_km);
             nd.kmer_hash.resize(n_km);
             c.bytes(nd.kmer_hash.data(), sizeof(uint64_t) * n_km);
             const uint32_t st = nd.start;
@@ -270,6 +278,9 @@ void GraphIndex::load(const std::string& path)
     if ((size_t)(c.end - c.p) >= 26) {   // all records have the same size: reserve once
         uint64_t bl0;
         memcpy(&bl0, c.p + 10, 8);
+        // bitLen = floor(#haplotypes / 8) + 1 in every record (construct_index.cpp:1206-1215): the bitmap readers
+        // (hom flags, HMM) index it by haplotype number
+        if (bl0 != (uint64_t)(hap_num >> 3) + 1) throw std::runtime_error("graph index corrupt: k-mer bitmap length does not match the haplotype count");
         const size_t n_rec = (size_t)(c.end - c.p) / (18 + bl0) + 1;
         keys.reserve(n_rec);
         f.reserve(n_rec);
@@ -280,7 +291,10 @@ void GraphIndex::load(const std::string& path)
         (void)c.get<uint8_t>();  // c: per-sample, zero in the index
         const uint8_t fv = c.get<uint8_t>();
         const uint64_t bl = c.get<uint64_t>();
-        if (keys.empty()) bitlen = bl;
+        if (keys.empty()) {
+            if (bl != (uint64_t)(hap_num >> 3) + 1) throw std::runtime_error("graph index corrupt: k-mer bitmap length does not match the haplotype count");
+            bitlen = bl;
+        }
         if (bl != bitlen) throw std::runtime_error("graph index: k-mer records with different bitmap lengths");
         keys.push_back(key);
         f.push_back(fv);
@@ -383,7 +397,13 @@ int GraphIndex::upload(vgmi_ctx* ctx) const
 {
     int rc = vgmi_table_upload(ctx, keys.data(), keys.size(), k);
     if (rc) return rc;
-    rc = vgmi_nodes_upload(ctx, node_off.data(), node_key_index.data(), node_off.size() - 1);
+    return upload_nodes(ctx);
+}
+
+// the per-node lists and the hom flags alone, for a context that received its table image from another device
+int GraphIndex::upload_nodes(vgmi_ctx* ctx) const
+{
+    int rc = vgmi_nodes_upload(ctx, node_off.data(), node_key_index.data(), node_off.size() - 1);
     if (rc) return rc;
     return vgmi_flags_upload(ctx, hom_flag.data());
 }

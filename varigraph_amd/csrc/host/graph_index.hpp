@@ -56,6 +56,7 @@ struct GraphIndex {
     void graph2node();
     void compute_hom_flags();
     int upload(vgmi_ctx* ctx) const;
+    int upload_nodes(vgmi_ctx* ctx) const;
 };
 
 }  // namespace vgh

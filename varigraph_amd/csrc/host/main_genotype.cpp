@@ -66,6 +66,37 @@ void usage(const char* argv0)
     std::_Exit(1);   // other threads (parsers, device streams) may be mid-flight: no static destructors under them
 }
 
+// option values: the reference hands optarg to std::stoi / stof / stoull bare (main.cpp:127-144,294-320), so a
+// non-numeric value ends it in std::terminate; here it is a parameter error like the range checks
+int opt_int(const char* name, const char* v)
+{
+    try {
+        size_t used = 0;
+        const int r = std::stoi(v, &used);
+        if (used == 0) throw std::invalid_argument(v);
+        return r;
+    } catch (const std::exception&) {
+        die(std::string("Parameter error: ") + name + ". '" + v + "' is not an integer.");
+    }
+}
+unsigned long long opt_u64(const char* name, const char* v)
+{
+    try {
+        if (v[0] == '-') throw std::invalid_argument(v);
+        return std::stoull(v);
+    } catch (const std::exception&) {
+        die(std::string("Parameter error: ") + name + ". '" + v + "' is not a non-negative integer.");
+    }
+}
+float opt_float(const char* name, const char* v)
+{
+    try {
+        return std::stof(v);
+    } catch (const std::exception&) {
+        die(std::string("Parameter error: ") + name + ". '" + v + "' is not a number.");
+    }
+}
+
 // Varigraph::parse_sample_config (src/varigraph.cpp:104-146)
 std::vector<std::tuple<std::string, std::vector<std::string>>> parse_samples(const std::string& path)
 {
@@ -119,24 +150,24 @@ int main_genotype(int argc, char** argv)
         case 1: o.graph = optarg; break;
         case 's': o.samples = optarg; break;
         case 'g': o.hmm.sample_type = optarg; break;
-        case 2: o.hmm.sample_ploidy = std::max(std::stoi(optarg), 2); break;
-        case 'n': o.hmm.haploid_num = (uint32_t)std::stoull(optarg); break;
-        case 3: o.hmm.chr_len_thread = std::stof(optarg) * 1e6; break;
+        case 2: o.hmm.sample_ploidy = std::max(opt_int("--sample-ploidy", optarg), 2); break;
+        case 'n': o.hmm.haploid_num = (uint32_t)opt_u64("-n", optarg); break;
+        case 3: o.hmm.chr_len_thread = opt_float("--granularity", optarg) * 1e6; break;
         case 'm': o.hmm.transition = optarg; break;
         case 4: o.hmm.sv_only = true; break;
-        case 5: o.hmm.min_gq = std::stof(optarg); break;
+        case 5: o.hmm.min_gq = opt_float("--min-support", optarg); break;
         case 6: o.use_depth = true; break;
-        case 7: o.gpus = {std::stoi(optarg)}; break;
+        case 7: o.gpus = {opt_int("--gpu", optarg)}; break;
         case 9: {
             o.gpus.clear();
             std::stringstream ss(optarg);
             for (std::string t; std::getline(ss, t, ',');)
-                if (!t.empty()) o.gpus.push_back(std::stoi(t));
+                if (!t.empty()) o.gpus.push_back(opt_int("--gpus", t.c_str()));
             if (o.gpus.empty()) die("Parameter error: --gpus. Expected a comma-separated list of device ordinals.");
             break;
         }
-        case 8: o.buffer_mib = std::stoi(optarg); break;
-        case 't': o.hmm.threads = std::max(std::stoi(optarg), 1); break;
+        case 8: o.buffer_mib = opt_int("--buffer", optarg); break;
+        case 't': o.hmm.threads = std::max(opt_int("-t", optarg), 1); break;
         case 'D': debug = true; break;
         default: usage(argv[0]); return 1;
         }
@@ -187,8 +218,27 @@ int main_genotype(int argc, char** argv)
     bring_up.join();
     if (!ctx_error.empty()) die(ctx_error);
     if (!load_error.empty()) die(load_error);
-    for (vgmi_ctx* ctx : ctxs)
-        if (g.upload(ctx) != VGMI_OK) die(vgmi_last_error(ctx));
+    // ONE table build (first device), then the image goes device to device in a doubling tree (round r: the 2^r devices
+    // that hold it feed the next 2^r over xGMI), never through the host again; node lists and flags are small host uploads
+    if (g.upload(ctxs[0]) != VGMI_OK) die(vgmi_last_error(ctxs[0]));
+    const double t_built = secs();
+    size_t image_bytes = 0;
+    (void)vgmi_table_image_bytes(ctxs[0], &image_bytes);
+    for (size_t have = 1; have < ctxs.size(); have *= 2) {
+        std::vector<std::thread> copies;
+        std::vector<std::string> errs(ctxs.size());
+        for (size_t i = 0; i < have && have + i < ctxs.size(); ++i)
+            copies.emplace_back([&, i] {
+                vgmi_ctx* dst = ctxs[have + i];
+                if (vgmi_table_clone(dst, ctxs[i]) != VGMI_OK || g.upload_nodes(dst) != VGMI_OK) errs[have + i] = vgmi_last_error(dst);
+            });
+        for (auto& t : copies) t.join();
+        for (const auto& e : errs)
+            if (!e.empty()) die(e);
+    }
+    if (ctxs.size() > 1)
+        std::fprintf(stderr, "[varigraph-mi] table: 1 build on device %d, %zu device-to-device image copies of %.1f MB (%.3f s)\n", o.gpus[0],
+                     ctxs.size() - 1, image_bytes / 1e6, secs() - t_built);
     std::cerr << "[varigraph-mi] graph loaded: " << g.keys.size() << " k-mers, k = " << g.k << ", " << g.hap_names.size()
               << " haplotypes (" << secs() << " s)" << std::endl;
 
@@ -222,6 +272,11 @@ int main_genotype(int argc, char** argv)
         }
     }
     const size_t n_consumers = independent ? std::max<size_t>(1, std::min(ctxs.size(), samples.size())) : 1;
+    // -t is the budget of the whole run: counting threads (inflate workers) and HMM consumers that run side by side
+    // share it instead of each taking all of it
+    const unsigned count_threads = std::max<unsigned>(1, o.hmm.threads / (unsigned)std::max<size_t>(1, std::min(ctxs.size(), samples.size())));
+    vgh::GenotypeConfig hmm_cfg = o.hmm;
+    hmm_cfg.threads = std::max<unsigned>(1, o.hmm.threads / (unsigned)n_consumers);
     std::atomic<size_t> next_hmm{0};
     auto consumer = [&] {
         try {
@@ -239,9 +294,9 @@ int main_genotype(int argc, char** argv)
                 }
                 cv.notify_all();
                 const double th = secs();
-                const std::string vcf = genotyper.run(job.cov.data(), job.hap_cov, job.name, o.hmm);
+                const std::string vcf = genotyper.run(job.cov.data(), job.hap_cov, job.name, hmm_cfg);
                 const double tz = secs();
-                vgh::Genotyper::write_gz(job.name + ".varigraph.vcf.gz", vcf, o.hmm.threads);
+                vgh::Genotyper::write_gz(job.name + ".varigraph.vcf.gz", vcf, hmm_cfg.threads);
                 std::fprintf(stderr, "[varigraph-mi] %s: genotyping %.2f s (HMM %.2f, VCF text %.2f, gzip %.2f) -> %s.varigraph.vcf.gz\n",
                              job.name.c_str(), secs() - th, genotyper.last_hmm_seconds, genotyper.last_text_seconds, secs() - tz,
                              job.name.c_str());
@@ -267,7 +322,7 @@ int main_genotype(int argc, char** argv)
                 Job job;
                 job.name = name;
                 job.cov.resize(g.keys.size());
-                vgh::FastqKmerHip fk(ctx, files, g.k, o.hmm.threads);
+                vgh::FastqKmerHip fk(ctx, files, g.k, count_threads);
                 fk.build_fastq_index();
                 uint64_t hist[256];
                 fk.fetch(job.cov.data(), nullptr, hist);
@@ -321,13 +376,13 @@ int main_construct(int argc, char** argv)
         case 'r': c.reference = optarg; break;
         case 'v': c.vcf = optarg; break;
         case 1: c.out = optarg; break;
-        case 2: vcf_ploidy = std::stoi(optarg); break;
-        case 'k': kmer = std::stoi(optarg); break;
+        case 2: vcf_ploidy = opt_int("--vcf-ploidy", optarg); break;
+        case 'k': kmer = opt_int("-k", optarg); break;
         case 3: c.fast = true; break;
         case 4: c.use_unique_kmers = true; break;
-        case 7: gpu = std::stoi(optarg); break;
-        case 8: buffer_mib = std::stoi(optarg); break;
-        case 't': c.threads = (uint32_t)std::max(std::stoi(optarg), 1); break;
+        case 7: gpu = opt_int("--gpu", optarg); break;
+        case 8: buffer_mib = opt_int("--buffer", optarg); break;
+        case 't': c.threads = (uint32_t)std::max(opt_int("-t", optarg), 1); break;
         case 'D': debug = true; break;   // main.cpp:141, construct_index.cpp:33-35
         default:
             std::cerr << "Usage: construct -r FASTA -v VCF [--save-graph FILE] [-k INT] [--vcf-ploidy INT] [--fast] "

@@ -46,6 +46,7 @@ struct Stage {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;  // last kernel that used this stage
     bool busy = false;
+    bool after_reset = false;   // the next launch on this stage's stream must wait for the per-sample reset (main stream)
 };
 
 }  // namespace
@@ -85,6 +86,7 @@ struct vgmi_ctx {
 
     // per-sample state
     uint64_t read_base = 0;
+    hipEvent_t reset_done = nullptr;   // recorded on the main stream behind the per-sample reset
     Stage stage[2];
     int next_stage = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;  // (start, stop) of count launches
@@ -425,6 +427,7 @@ int vgmi_create(int device, size_t buffer_mib, vgmi_ctx** out)
     if ((e = hipMalloc(&c->d_status, 4)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(c->d_status, 0, 4)) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipMalloc(&c->d_hist, 256 * 8)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipEventCreateWithFlags(&c->reset_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     *out = c;
     return VGMI_OK;
 }
@@ -448,6 +451,7 @@ void vgmi_destroy(vgmi_ctx* c)
     if (c->bv.filter) (void)hipFree(c->bv.filter);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_hist) (void)hipFree(c->d_hist);
+    if (c->reset_done) (void)hipEventDestroy(c->reset_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -539,6 +543,38 @@ int vgmi_table_import(vgmi_ctx* c, const void* dev_src, size_t bytes)
     return VGMI_OK;
 }
 
+int vgmi_table_clone(vgmi_ctx* dst, vgmi_ctx* src)
+{
+    if (!dst || !src || dst == src) return VGMI_E_INVALID;
+    if (!src->has_table) return fail(dst, VGMI_E_STATE, "the source context has no table");
+    HIPCHK(dst, hipSetDevice(src->device));
+    HIPCHK(dst, hipStreamSynchronize(src->stream));
+    HIPCHK(dst, hipSetDevice(dst->device));
+    HIPCHK(dst, hipStreamSynchronize(dst->stream));
+    free_table(dst);
+    dst->hdr = src->hdr;
+    dst->image_bytes = src->image_bytes;
+    HIPCHK(dst, hipMalloc(reinterpret_cast<void**>(&dst->d_image), dst->image_bytes));
+    if (dst->device == src->device) {
+        HIPCHK(dst, hipMemcpy(dst->d_image, src->d_image, dst->image_bytes, hipMemcpyDeviceToDevice));
+    } else {
+        // one device-to-device transfer over xGMI (peer access when the link allows it, the runtime stages otherwise)
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dst->device, src->device) == hipSuccess && can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(src->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIPCHK(dst, e);
+            (void)hipGetLastError();
+        }
+        HIPCHK(dst, hipMemcpyPeer(dst->d_image, dst->device, src->d_image, src->device, dst->image_bytes));
+    }
+    int rc = adopt_image(dst);
+    if (rc) return rc;
+    HIPCHK(dst, launch_counts_reset(dst->tv, dst->stream));   // the source's per-sample state travels with the image
+    HIPCHK(dst, hipStreamSynchronize(dst->stream));
+    dst->read_base = 0;
+    return VGMI_OK;
+}
+
 int vgmi_table_info(vgmi_ctx* c, size_t* n_keys, uint32_t* k, size_t* n_slots, size_t* filter_bits)
 {
     if (!c) return VGMI_E_INVALID;
@@ -594,6 +630,9 @@ int vgmi_counts_reset(vgmi_ctx* c)
     if (c->d_counts) HIPCHK(c, hipMemsetAsync(c->d_counts, 0, c->n_counts * 4, c->stream));
     if (!c->d_counts || c->tv.slots8) HIPCHK(c, launch_counts_reset(c->tv, c->stream));   // in-slot counters / saturation flags
     HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4, c->stream));
+    // host blocks are counted on the stages' own (non-blocking) streams: their next launch waits for this reset
+    HIPCHK(c, hipEventRecord(c->reset_done, c->stream));
+    for (auto& s : c->stage) s.after_reset = true;
     c->read_base = 0;
     c->kernel_ms = 0.f;
     c->launches = 0;
@@ -653,6 +692,7 @@ int vgmi_reads_submit(vgmi_ctx* c, const char* bases, size_t n_bytes, const uint
         int rc = ensure_stage(c, s);
         if (rc) return rc;
         if (s.busy) { HIPCHK(c, hipEventSynchronize(s.done)); s.busy = false; }
+        if (s.after_reset) { HIPCHK(c, hipStreamWaitEvent(s.stream, c->reset_done, 0)); s.after_reset = false; }
         memcpy(s.h, bases + pos, len);
         HIPCHK(c, hipMemcpyAsync(s.d, s.h, len, hipMemcpyHostToDevice, s.stream));
         const uint64_t* d_off = nullptr;
@@ -968,6 +1008,29 @@ int vgmi_synth_reads_host(uint64_t seed, uint64_t first_read, uint64_t n_reads, 
         char* o = out + r * (read_len + 1);
         for (uint32_t j = 0; j < read_len; ++j) o[j] = vgs_read_base(seed, first_read + r, j, read_len, hp, hl, n_hap);
         o[read_len] = '\n';
+    }
+    return VGMI_OK;
+}
+
+int vgmi_synth_snp_keys_host(const char* ref, uint64_t ref_len, const uint64_t* pos, const char* alts, uint64_t n_sites,
+                             uint32_t k, uint64_t* keys_out)
+{
+    if (!ref || !pos || !alts || !keys_out || k < 1 || k > 28) return VGMI_E_INVALID;
+    const uint64_t mask = k == 32 ? ~0ULL : (1ULL << (2 * k)) - 1;
+    for (uint64_t i = 0; i < n_sites; ++i) {
+        const uint64_t p = pos[i];
+        if (p < k - 1 || p + k > ref_len) return VGMI_E_INVALID;
+        for (uint32_t allele = 0; allele < 2; ++allele) {
+            uint64_t fwd = 0, rc = 0;
+            uint64_t* out = keys_out + (2 * i + allele) * k;
+            for (uint64_t q = p - (k - 1); q <= p + (k - 1); ++q) {
+                const uint32_t c = vg_nt4((unsigned char)(allele && q == p ? alts[i] : ref[q]));
+                if (c > 3) return VGMI_E_INVALID;
+                fwd = (fwd << 2 | c) & mask;
+                rc = (rc >> 2) | (uint64_t)(3u ^ c) << (2 * (k - 1));
+                if (q >= p) out[q - p] = vg_hash64(fwd < rc ? fwd : rc, mask) << 8 | k;
+            }
+        }
     }
     return VGMI_OK;
 }

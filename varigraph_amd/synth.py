@@ -160,6 +160,21 @@ def snp_kmer_keys(ref, positions, alts, k=27):
     return np.unique(np.concatenate(out))
 
 
+def snp_graph(genome, n_variants, ref_seed=777, var_seed=5, k=27):
+    """Large-table workloads (BASELINE configs 3-5 class) without running `construct`: an iid reference, uniformly
+    placed SNPs, the key set of every k-mer covering a site on either allele, and the two haplotypes of the sequenced
+    (all-het) sample.  Returns (keys, [ref, alt_haplotype])."""
+    ref = make_reference(genome, seed=ref_seed)
+    rng = np.random.default_rng(var_seed)
+    pos = np.sort(rng.choice(np.arange(100, genome - 100), size=n_variants, replace=False))
+    alt_code = (_CODE[ref[pos]] + rng.integers(1, 4, size=n_variants)) % 4
+    alts = _ACGT[alt_code]
+    keys = np.unique(vgmi.synth_snp_keys(ref, pos, alts, k))   # == snp_kmer_keys(ref, pos, alts, k), natively
+    hap1 = ref.copy()
+    hap1[pos] = alts
+    return keys, [ref, hap1]
+
+
 def bgzf_compress_file(src, dst, level=4, block=0xff00):
     """Block-gzip (BGZF, what bgzip / htslib write: SAM spec 4.1) copy of `src`: gzip members of <= 64 KiB whose
     extra field 'BC' carries the member size, closed by the empty EOF block."""

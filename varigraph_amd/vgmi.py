@@ -40,6 +40,7 @@ def load_library():
         "vgmi_table_image_bytes": (i32, [vp, C.POINTER(sz)]),
         "vgmi_table_export": (i32, [vp, vp, sz]),
         "vgmi_table_import": (i32, [vp, vp, sz]),
+        "vgmi_table_clone": (i32, [vp, vp]),
         "vgmi_table_info": (i32, [vp, C.POINTER(sz), C.POINTER(u32), C.POINTER(sz), C.POINTER(sz)]),
         "vgmi_nodes_upload": (i32, [vp, vp, vp, sz]),
         "vgmi_flags_upload": (i32, [vp, vp]),
@@ -63,6 +64,7 @@ def load_library():
         "vgmi_synth_reads_device": (i32, [vp, u64, u64, u64, u32, vp, vp, u32, vp]),
         "vgmi_synth_reads_host": (i32, [u64, u64, u64, u32, vp, vp, u32, vp]),
         "vgmi_synth_reference_host": (i32, [u64, u64, vp]),
+        "vgmi_synth_snp_keys_host": (i32, [vp, u64, vp, vp, u64, u32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
@@ -109,6 +111,18 @@ def synth_reference(seed, length):
     rc = lib().vgmi_synth_reference_host(seed, length, _ptr(out))
     if rc:
         raise VgmiError(rc, "synth_reference")
+    return out
+
+
+def synth_snp_keys(ref, pos, alts, k=27):
+    """Unsorted, possibly repeated keys of the k-mers covering SNP sites (see include/vgmi.h)."""
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    pos = np.ascontiguousarray(pos, dtype=np.uint64)
+    alts = np.ascontiguousarray(alts, dtype=np.uint8)
+    out = np.empty(2 * k * pos.size, dtype=np.uint64)
+    rc = lib().vgmi_synth_snp_keys_host(_ptr(ref), ref.size, _ptr(pos), _ptr(alts), pos.size, k, _ptr(out))
+    if rc:
+        raise VgmiError(rc, "synth_snp_keys")
     return out
 
 
@@ -173,6 +187,12 @@ class Context:
 
     def table_import(self, dev_tensor):
         self._chk(self._l.vgmi_table_import(self._h, _ptr(dev_tensor), dev_tensor.numel()))
+        self.n_keys = self.table_info()["n_keys"]
+        self.n_node_entries = 0
+
+    def table_clone_from(self, src):
+        """Adopt a device-to-device copy of `src`'s table image (one process, several contexts / devices)."""
+        self._chk(self._l.vgmi_table_clone(self._h, src._h))
         self.n_keys = self.table_info()["n_keys"]
         self.n_node_entries = 0
 
