@@ -58,7 +58,7 @@ def test_c3_full_size_prefix_equals_oracle_and_properties(chr20):
     assert want.sum() > 10 * pre          # the dense graph: ~20 hits per read
     # (3) monotone in the input, (4) 30x coverage touches nearly every k-mer of the sequenced haplotypes
     assert (full >= part).all()
-    assert (full != 0).mean() > 0.95
+    assert (full != 0).mean() > 0.85      # (keys that pair an allele with a neighbouring site's other allele are not on the sample)
     assert int(full.max()) < 255 or (full == 255).sum() < 100
 
 
