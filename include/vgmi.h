@@ -119,6 +119,28 @@ int vgmi_counts_import_device(vgmi_ctx *ctx, const uint32_t *dev_counts /* n_key
  * the last reset, and the number of launches; for roofline accounting. */
 int vgmi_count_kernel_ms(vgmi_ctx *ctx, float *ms, uint64_t *launches);
 
+/* ---- device-side FASTQ parsing -----------------------------------------------------------------
+ * replaces: kseq_read + the per-record sequence copy of FastqKmer::fastq_file_open (include/kseq.h:192-232,
+ *           src/fastq_kmer.cpp:97-105) for REGULAR four-line FASTQ records; the host only moves file text (plain, or
+ *           what it inflated) into pinned buffers.  One stream per input file; streams of one context may be driven
+ *           from different host threads side by side (everything else of a context stays single-threaded).
+ *   open     after vgmi_counts_reset, odd k
+ *   acquire  the next pinned staging buffer (waits until the device has taken the previous contents)
+ *   commit   n_bytes of file text, continuing where the previous commit ended: copied, parsed and counted
+ *            asynchronously
+ *   close    waits; n_records / n_bases (= the records' contribution to mReadBase, also added to vgmi_read_base) /
+ *            consumed_bytes = how much of the committed text the device took.  stopped == 0: the text ended inside a
+ *            record (or cleanly): the unconsumed tail (< 1 MiB) is returned in tail_out for the host reader.
+ *            stopped != 0: record number n_records is not a regular four-line record (FASTA, wrapped lines, length
+ *            mismatch, empty sequence, '\r' / NUL bytes ...): the host reader must take the stream over at byte
+ *            consumed_bytes -- a record boundary, where a fresh kseq state is exactly the reference's state. */
+typedef struct vgmi_fastq vgmi_fastq;
+int vgmi_fastq_open(vgmi_ctx *ctx, vgmi_fastq **out);
+int vgmi_fastq_acquire(vgmi_fastq *fq, char **host_buf, size_t *capacity);
+int vgmi_fastq_commit(vgmi_fastq *fq, size_t n_bytes);
+int vgmi_fastq_close(vgmi_fastq *fq, uint64_t *n_records, uint64_t *n_bases, uint64_t *consumed_bytes, int *stopped,
+                     char *tail_out, size_t tail_cap, size_t *tail_len);
+
 /* K1 alone: the key every position of a read block emits, for emitter parity tests.
  * keys_out[i] = key of the k-mer ENDING at byte i, or UINT64_MAX when the reference emits nothing
  * there (kmerBit::kmer_sketch_* loop, src/kmer.cpp:126-146).  Host buffers. */

@@ -1,0 +1,183 @@
+"""Device-side FASTQ parsing (vgmi_fastq_*, csrc/vgmi_fastq.hip) against the host reader -- the literal restatement of
+kseq_read (include/kseq.h:192-232 as used by src/fastq_kmer.cpp:97-105) that test_host_cpu.py pins -- and the oracle.
+
+Every file below goes through FastqKmerHip twice, device parser and VGH_HOST_PARSE=1: counters, mReadBase and read count
+must be identical, also when tiny staging buffers (VGMI_FASTQ_CHUNK_KB) put every kind of record across a chunk boundary,
+and when the file is not regular four-line FASTQ at all (the device parser must hand over at the right byte)."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as o
+from conftest import get_cohort
+from varigraph_amd import host, synth, vgmi
+
+pytestmark = pytest.mark.gpu
+
+
+def _reads(n, seed, lo=30, hi=160):
+    rng = np.random.default_rng(seed)
+    cohort = get_cohort("cohort_snp")
+    hap = cohort.haplotypes()[1]
+    out = []
+    for _ in range(n):
+        ln = int(rng.integers(lo, hi))
+        s = int(rng.integers(0, len(hap) - ln))
+        r = bytearray(hap[s:s + ln].tobytes())
+        if rng.random() < 0.1:
+            r[int(rng.integers(0, ln))] = ord("N")
+        if rng.random() < 0.05:
+            r = bytearray(bytes(r).lower())
+        out.append(bytes(r))
+    return out
+
+
+def _fastq(reads, qual_char=b"I", names=None, trailing_newline=True, line_end=b"\n"):
+    parts = []
+    for i, r in enumerate(reads):
+        nm = names[i] if names else b"r%d extra comment" % i
+        q = qual_char * len(r) if len(qual_char) == 1 else (qual_char * len(r))[:len(r)]
+        parts.append(b"@" + nm + line_end + r + line_end + b"+" + line_end + q + line_end)
+    t = b"".join(parts)
+    return t if trailing_newline else t[:-len(line_end)]
+
+
+def _cases():
+    rd = _reads(400, 1)
+    c = {}
+    c["regular"] = _fastq(rd)
+    c["no_trailing_newline"] = _fastq(rd, trailing_newline=False)
+    c["quality_starts_with_at_plus_gt"] = _fastq(rd, qual_char=b"@+>I")
+    c["names_with_at_and_tabs"] = _fastq(rd, names=[b"@@r%d\t@x +y" % i for i in range(len(rd))])
+    c["crlf"] = _fastq(rd, line_end=b"\r\n")
+    c["one_crlf_line_in_the_middle"] = _fastq(rd[:200]) + _fastq(rd[200:201], line_end=b"\r\n") + _fastq(rd[201:])
+    wrapped = b"".join(b"@w%d\n" % i + r[:40] + b"\n" + r[40:] + b"\n+\n" + b"I" * 40 + b"\n" + b"I" * (len(r) - 40) + b"\n"
+                       for i, r in enumerate(rd[:50]) if len(r) > 80)
+    c["wrapped_lines_after_regular_ones"] = _fastq(rd[:100]) + wrapped + _fastq(rd[100:])
+    c["fasta"] = b"".join(b">s%d\n" % i + r + b"\n" for i, r in enumerate(rd))
+    c["fasta_after_fastq"] = _fastq(rd[:150]) + b"".join(b">s%d\n" % i + r + b"\n" for i, r in enumerate(rd[150:]))
+    c["blank_lines_between_records"] = _fastq(rd[:100]) + b"\n\n" + _fastq(rd[100:200]) + b"\n" + _fastq(rd[200:])
+    c["quality_too_short_stops_the_file"] = _fastq(rd[:120]) + b"@bad\n" + rd[120] + b"\n+\nIII\n" + _fastq(rd[121:])
+    c["quality_too_long_stops_the_file"] = _fastq(rd[:120]) + b"@bad\n" + rd[120] + b"\n+\n" + b"I" * (len(rd[120]) + 3) + b"\n" + _fastq(rd[121:])
+    c["truncated_inside_last_quality"] = _fastq(rd)[:-20]
+    c["truncated_inside_last_sequence"] = _fastq(rd[:399]) + b"@last\n" + rd[399][:17]
+    c["junk_before_first_record"] = b"# made by hand\n\n" + _fastq(rd)
+    c["nul_byte_in_a_sequence"] = _fastq(rd[:77]) + b"@n\nACGTACGTACGTACGTACGTACGTACGTACGT\0ACGTACGTACGTACGTACGTACGTACGTACGTACGT\n+\n" + b"I" * 69 + b"\n" + _fastq(rd[77:])
+    c["sequence_line_starting_with_gt"] = _fastq(rd[:30]) + b"@x\n>CGTACGT\n+\nIIIIIIII\n" + _fastq(rd[30:])
+    c["single_record"] = _fastq(rd[:1])
+    c["only_a_header"] = b"@lonely"
+    return c
+
+
+@pytest.fixture(scope="module")
+def graph_ctx():
+    cohort = get_cohort("cohort_snp")
+    g = host.Graph(os.path.join(cohort.dir, "graph.bin.gz"))
+    ctx = vgmi.Context(0, buffer_mib=16)
+    g.upload(ctx)
+    yield g, ctx, cohort
+    ctx.close()
+    g.close()
+
+
+def _count(g, ctx, paths, host_parse, chunk_kb=None):
+    old = {k: os.environ.get(k) for k in ("VGH_HOST_PARSE", "VGMI_FASTQ_CHUNK_KB")}
+    os.environ["VGH_HOST_PARSE"] = "1" if host_parse else "0"
+    if chunk_kb:
+        os.environ["VGMI_FASTQ_CHUNK_KB"] = str(chunk_kb)
+    else:
+        os.environ.pop("VGMI_FASTQ_CHUNK_KB", None)
+    try:
+        cov, _node, _hist, st = g.sample_count(ctx, paths, threads=4, require_depth=False)
+        return {"cov": cov, "read_base": st["read_base"], "n_reads": st["n_reads"]}
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("name", sorted(_cases()))
+def test_device_parser_equals_host_reader(name, graph_ctx, tmp_path):
+    g, ctx, cohort = graph_ctx
+    text = _cases()[name]
+    p = tmp_path / "x.fq"
+    p.write_bytes(text)
+    try:
+        want = _count(g, ctx, [str(p)], host_parse=True)
+    except vgmi.VgmiError as e:   # the reference aborts on this input (empty sequence): so must the device path, with the same message
+        for chunk_kb in (None, 4):
+            with pytest.raises(vgmi.VgmiError) as e2:
+                _count(g, ctx, [str(p)], host_parse=False, chunk_kb=chunk_kb)
+            assert str(e2.value) == str(e)
+        return
+    # the host reader itself against the oracle on the same block
+    block, _n, rb = host.fastx_read_all(str(p))
+    t = o.Table(cohort.graph.keys)
+    if len(block):
+        t.count_block(block, cohort.k)
+    assert np.array_equal(want["cov"], t.counts())
+    assert want["read_base"] == rb
+    for chunk_kb in (None, 4, 5, 64):
+        got = _count(g, ctx, [str(p)], host_parse=False, chunk_kb=chunk_kb)
+        assert np.array_equal(got["cov"], want["cov"]), (name, chunk_kb)
+        assert got["read_base"] == want["read_base"], (name, chunk_kb)
+        assert got["n_reads"] == want["n_reads"], (name, chunk_kb)
+
+
+def test_device_parser_reports_where_it_stopped(graph_ctx):
+    """The stream-level contract of vgmi_fastq_close: records and bases taken, the byte the host reader resumes at."""
+    g, ctx, cohort = graph_ctx
+    rd = _reads(50, 3)
+    reg = _fastq(rd)
+    ctx.counts_reset()
+    r = ctx.fastq_text(reg, piece=1000)
+    assert (r["n_records"], r["n_bases"], r["consumed"], r["stopped"], r["tail"]) == (50, sum(map(len, rd)), len(reg), False, b"")
+    ctx.counts_reset()
+    r = ctx.fastq_text(reg[:-1], piece=777)          # unterminated last line: that record is the host reader's
+    last = len(_fastq(rd[:49]))
+    assert (r["n_records"], r["consumed"], r["stopped"]) == (49, last, False) and r["tail"] == reg[last:-1]
+    bad = _fastq(rd[:20]) + b">fasta\nACGT\n" + _fastq(rd[20:])
+    ctx.counts_reset()
+    r = ctx.fastq_text(bad, piece=4096)
+    assert (r["n_records"], r["consumed"], r["stopped"], r["tail"]) == (20, len(_fastq(rd[:20])), True, b"")
+    ctx.counts_reset()
+    ctx.counts_finish()
+
+
+def test_empty_sequence_is_an_error_on_both_paths(graph_ctx, tmp_path):
+    g, ctx, _ = graph_ctx
+    p = tmp_path / "e.fq"
+    p.write_bytes(_fastq(_reads(10, 5)) + b"@e\n\n+\n\n" + _fastq(_reads(10, 6)))
+    for hp in (True, False):
+        with pytest.raises(Exception, match="empty read"):
+            _count(g, ctx, [str(p)], host_parse=hp)
+
+
+@pytest.mark.parametrize("kind", ["plain", "gzip", "bgzf"])
+def test_cohort_files_device_parser_all_containers(kind, graph_ctx, tmp_path):
+    """The committed cohort FASTQs (gzip), re-packed as plain / gzip / block gzip: reference-dumped counters."""
+    g, ctx, cohort = graph_ctx
+    paths = []
+    for m in (1, 2):
+        raw = gzip.open(os.path.join(cohort.dir, f"reads_{m}.fq.gz"), "rb").read()
+        if kind == "plain":
+            p = tmp_path / f"r{m}.fq"
+            p.write_bytes(raw)
+        elif kind == "gzip":
+            p = tmp_path / f"r{m}.fq.gz"
+            with gzip.open(p, "wb", compresslevel=3) as f:
+                f.write(raw)
+        else:
+            q = tmp_path / f"r{m}.fq"
+            q.write_bytes(raw)
+            p = tmp_path / f"r{m}.fq.bgz"
+            synth.bgzf_compress_file(str(q), str(p))
+        paths.append(str(p))
+    for chunk_kb in (None, 16):
+        got = _count(g, ctx, paths, host_parse=False, chunk_kb=chunk_kb)
+        assert np.array_equal(got["cov"], cohort.ref_c_in_graph_order())
+        assert got["read_base"] == cohort.ref_read_base

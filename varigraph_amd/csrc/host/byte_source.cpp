@@ -547,4 +547,51 @@ std::unique_ptr<ByteSource> ByteSource::open(const std::string& path, unsigned d
     return std::make_unique<GzipSource>(std::move(in));
 }
 
+namespace {
+class MemorySource final : public ByteSource {
+public:
+    MemorySource(const void* d, size_t n) : p_(static_cast<const unsigned char*>(d)), n_(n) {}
+    bool next_chunk(const unsigned char*& p, size_t& n) override
+    {
+        if (!n_) return false;
+        p = p_;
+        n = n_;
+        n_ = 0;
+        return true;
+    }
+    const char* kind() const override { return "memory"; }
+
+private:
+    const unsigned char* p_;
+    size_t n_;
+};
+
+class SkipSource final : public ByteSource {
+public:
+    SkipSource(std::unique_ptr<ByteSource> in, uint64_t n) : in_(std::move(in)), left_(n) {}
+    bool next_chunk(const unsigned char*& p, size_t& n) override
+    {
+        for (;;) {
+            if (!in_->next_chunk(p, n)) return false;
+            if (left_ >= n) { left_ -= n; continue; }
+            p += left_;
+            n -= (size_t)left_;
+            left_ = 0;
+            if (n) return true;
+        }
+    }
+    const char* kind() const override { return in_->kind(); }
+
+private:
+    std::unique_ptr<ByteSource> in_;
+    uint64_t left_;
+};
+}  // namespace
+
+std::unique_ptr<ByteSource> ByteSource::from_memory(const void* data, size_t n) { return std::make_unique<MemorySource>(data, n); }
+std::unique_ptr<ByteSource> ByteSource::skip(std::unique_ptr<ByteSource> inner, uint64_t n)
+{
+    return n ? std::make_unique<SkipSource>(std::move(inner), n) : std::move(inner);
+}
+
 }  // namespace vgh

@@ -11,6 +11,7 @@
 // `while (kseq_read(ks) >= 0)` loop does when gzread returns -1.
 #pragma once
 #include <cstddef>
+#include <cstdint>
 #include <memory>
 #include <string>
 
@@ -25,6 +26,10 @@ public:
 
     // throws std::runtime_error("'<path>': No such file or directory.") like the callers' gzopen checks
     static std::unique_ptr<ByteSource> open(const std::string& path, unsigned decode_threads = 1);
+    // a run of bytes already in memory (not owned; must outlive the source)
+    static std::unique_ptr<ByteSource> from_memory(const void* data, size_t n);
+    // `inner` without its first `n` bytes (the device-side FASTQ parser hands a stream over at a byte offset)
+    static std::unique_ptr<ByteSource> skip(std::unique_ptr<ByteSource> inner, uint64_t n);
 };
 
 }  // namespace vgh

@@ -1,6 +1,12 @@
 #include "fastq_kmer_hip.hpp"
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -79,6 +85,139 @@ void parse_file(const std::string& path, Channel& ch, size_t block_bytes, unsign
     ch.cv_full.notify_all();
 }
 
+// ---- device-side parsing (vgmi_fastq_*): the host moves file text, the device finds the records ----------------------
+
+// records of `rd` (from a record boundary on) through the host reader into read blocks and vgmi_reads_submit; the
+// context's host-block path is single-threaded, hence the mutex shared by the files of one sample
+void host_leg(vgmi_ctx* ctx, FastxReader& rd, const std::string& path, size_t block_bytes, std::mutex& submit_mu, uint64_t& n_reads,
+              uint64_t& read_base)
+{
+    std::vector<char> block;
+    block.reserve(block_bytes + 1024);
+    size_t in_block = 0;
+    auto flush = [&]() {
+        if (!in_block) return;
+        std::lock_guard<std::mutex> lk(submit_mu);
+        if (vgmi_reads_submit(ctx, block.data(), block.size(), nullptr, in_block) != VGMI_OK) throw std::runtime_error(vgmi_last_error(ctx));
+        block.clear();
+        in_block = 0;
+    };
+    while (rd.next() >= 0) {
+        const std::string& s = rd.seq();
+        const size_t len = strnlen(s.data(), s.size());   // src/fastq_kmer.cpp:101 vs :105, see parse_file
+        if (len == 0) throw std::runtime_error("'" + path + "': empty read sequence (the reference aborts on assert(len > 0), kmer.cpp:124)");
+        if (block.size() + len + 1 > block_bytes && in_block) flush();
+        block.insert(block.end(), s.data(), s.data() + len);
+        block.push_back('\n');
+        ++in_block;
+        ++n_reads;
+        read_base += s.size();
+    }
+    flush();
+}
+
+// plain file: `threads` readers fill one pinned buffer side by side (a single read(2) stream moves 3-6 GB/s, the link
+// to the device ten times that)
+size_t fill_plain(int fd, uint64_t offset, uint64_t file_size, char* buf, size_t cap, unsigned threads)
+{
+    const size_t want = (size_t)std::min<uint64_t>(cap, file_size - offset);
+    if (want == 0) return 0;
+    const unsigned n_thr = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, want >> 22));   // >= 4 MiB per reader
+    std::atomic<bool> bad{false};
+    auto part = [&](unsigned t) {
+        size_t b = want / n_thr * t, e = t + 1 == n_thr ? want : want / n_thr * (t + 1);
+        while (b < e) {
+            const ssize_t r = ::pread(fd, buf + b, e - b, (off_t)(offset + b));
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) { bad = true; return; }
+            b += (size_t)r;
+        }
+    };
+    std::vector<std::thread> ts;
+    for (unsigned t = 1; t < n_thr; ++t) ts.emplace_back(part, t);
+    part(0);
+    for (auto& t : ts) t.join();
+    if (bad) throw std::runtime_error("read error");
+    return want;
+}
+
+struct DeviceFileResult {
+    uint64_t n_reads = 0, read_base = 0;
+};
+
+DeviceFileResult device_file(vgmi_ctx* ctx, const std::string& path, size_t block_bytes, unsigned threads, std::mutex& submit_mu)
+{
+    DeviceFileResult res;
+    // plain or compressed?  (gzopen's transparent mode: anything that does not start with the gzip magic is plain)
+    int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("'" + path + "': No such file or directory.");
+    unsigned char magic[2] = {0, 0};
+    const ssize_t got = ::pread(fd, magic, 2, 0);
+    const bool plain = !(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { ::close(fd); throw std::runtime_error("'" + path + "': cannot stat"); }
+    const uint64_t file_size = (uint64_t)sb.st_size;
+    struct FdGuard { int fd; ~FdGuard() { if (fd >= 0) ::close(fd); } } guard{fd};
+
+    vgmi_fastq* fq = nullptr;
+    if (vgmi_fastq_open(ctx, &fq) != VGMI_OK) throw std::runtime_error(vgmi_last_error(ctx));
+    uint64_t n_rec = 0, n_bases = 0, consumed = 0;
+    int stopped = 0;
+    std::vector<char> tail(1u << 20);
+    size_t tail_len = 0;
+    bool closed = false;
+    auto close_stream = [&]() {
+        closed = true;
+        if (vgmi_fastq_close(fq, &n_rec, &n_bases, &consumed, &stopped, tail.data(), tail.size(), &tail_len) != VGMI_OK)
+            throw std::runtime_error(vgmi_last_error(ctx));
+    };
+    try {
+        std::unique_ptr<ByteSource> src;
+        if (!plain) src = ByteSource::open(path, threads);
+        uint64_t offset = 0;
+        const unsigned char* left_p = nullptr;   // rest of a decoded chunk that did not fit the previous buffer
+        size_t left_n = 0;
+        for (;;) {
+            char* buf = nullptr;
+            size_t cap = 0;
+            if (vgmi_fastq_acquire(fq, &buf, &cap) != VGMI_OK) throw std::runtime_error(vgmi_last_error(ctx));
+            size_t n = 0;
+            if (plain) {
+                n = fill_plain(fd, offset, file_size, buf, cap, threads);
+                offset += n;
+            } else {
+                for (;;) {
+                    if (!left_n && !src->next_chunk(left_p, left_n)) break;
+                    const size_t take = std::min(left_n, cap - n);
+                    memcpy(buf + n, left_p, take);
+                    n += take;
+                    left_p += take;
+                    left_n -= take;
+                    if (n == cap) break;
+                }
+            }
+            if (vgmi_fastq_commit(fq, n) != VGMI_OK) throw std::runtime_error(vgmi_last_error(ctx));
+            if (n < cap) break;   // end of the data
+        }
+        close_stream();
+    } catch (...) {
+        if (!closed) (void)vgmi_fastq_close(fq, nullptr, nullptr, nullptr, nullptr, tail.data(), tail.size(), &tail_len);
+        throw;
+    }
+    res.n_reads = n_rec;
+    res.read_base = n_bases;
+    // what the device did not take: the text after the last complete record (an unterminated last line, or nothing), or
+    // -- once it met a record that is not a regular four-line one -- the rest of the stream from that record on
+    if (stopped) {
+        FastxReader rd(ByteSource::skip(ByteSource::open(path, threads), consumed));
+        host_leg(ctx, rd, path, block_bytes, submit_mu, res.n_reads, res.read_base);
+    } else if (tail_len) {
+        FastxReader rd(ByteSource::from_memory(tail.data(), tail_len));
+        host_leg(ctx, rd, path, block_bytes, submit_mu, res.n_reads, res.read_base);
+    }
+    return res;
+}
+
 }  // namespace
 
 FastqKmerHip::FastqKmerHip(vgmi_ctx* ctx, const std::vector<std::string>& fastqFileNameVec, uint32_t kmerLen,
@@ -96,6 +235,40 @@ void FastqKmerHip::build_fastq_index()
     if (vgmi_counts_reset(ctx_) != VGMI_OK) throw std::runtime_error(vgmi_last_error(ctx_));
     mReadBase = 0;
     mReadNum = 0;
+
+    const char* force_host = std::getenv("VGH_HOST_PARSE");
+    if ((k_ & 1) && !(force_host && force_host[0] == '1')) {
+        // device-side record parsing: one worker per file (two at a time: the files of a pair), each moving file text
+        // through its own pinned buffers and HIP stream
+        const size_t n_par = std::min<size_t>(std::min<size_t>(threads_, 2), files_.size());
+        const unsigned io_threads = std::max<unsigned>(1u, (unsigned)(threads_ / n_par));
+        std::mutex submit_mu, res_mu;
+        std::atomic<size_t> next{0};
+        std::string err;
+        auto worker = [&]() {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= files_.size()) return;
+                try {
+                    const DeviceFileResult r = device_file(ctx_, files_[i], block_bytes_, io_threads, submit_mu);
+                    std::lock_guard<std::mutex> lk(res_mu);
+                    mReadBase += r.read_base;
+                    mReadNum += r.n_reads;
+                } catch (const std::exception& e) {
+                    std::lock_guard<std::mutex> lk(res_mu);
+                    if (err.empty()) err = e.what();
+                    next = files_.size();
+                    return;
+                }
+            }
+        };
+        std::vector<std::thread> ws;
+        for (size_t t = 1; t < n_par; ++t) ws.emplace_back(worker);
+        worker();
+        for (auto& t : ws) t.join();
+        if (!err.empty()) throw std::runtime_error(err);
+        return;
+    }
 
     Channel ch;
     const size_t n_par = std::min<size_t>(threads_, files_.size());

@@ -7,6 +7,8 @@ namespace vgh {
 
 FastxReader::FastxReader(const std::string& path, unsigned decode_threads) : src_(ByteSource::open(path, decode_threads)) {}
 
+FastxReader::FastxReader(std::unique_ptr<ByteSource> src) : src_(std::move(src)) {}
+
 FastxReader::~FastxReader() = default;
 
 bool FastxReader::refill()

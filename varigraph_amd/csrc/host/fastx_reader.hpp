@@ -21,6 +21,7 @@ namespace vgh {
 class FastxReader {
 public:
     explicit FastxReader(const std::string& path, unsigned decode_threads = 1);  // throws std::runtime_error if it cannot open
+    explicit FastxReader(std::unique_ptr<ByteSource> src);   // any byte stream, read from a record boundary on
     ~FastxReader();
     FastxReader(const FastxReader&) = delete;
     FastxReader& operator=(const FastxReader&) = delete;

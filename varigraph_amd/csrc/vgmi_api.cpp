@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -34,7 +35,8 @@ struct ImageHeader {  // first 256 bytes of the table image
     uint32_t grid_words_log2;
     uint32_t slot_bytes;   // 16: VgSlot, 8: compact k-mer words (vgmi_device.h)
     uint32_t home_bucket_log2;   // 0: vg_thash home slots, else minimiser buckets (vg_thash_local)
-    uint8_t pad[256 - 8 - 4 - 4 - 8 - 8 - 40 - 8 - 4];
+    uint32_t home_by_offset;     // place inside the bucket = minimiser offset (vgmi_device.h)
+    uint8_t pad[256 - 8 - 4 - 4 - 8 - 8 - 40 - 8 - 4 - 4];
 };
 static_assert(sizeof(ImageHeader) == 256, "image header is 256 bytes");
 
@@ -85,6 +87,8 @@ struct vgmi_ctx {
     uint32_t* d_status = nullptr;
 
     // per-sample state
+    std::mutex mu;                 // event list / counters below when several FASTQ streams submit from their own threads
+    int open_fastq = 0;
     uint64_t read_base = 0;
     hipEvent_t reset_done = nullptr;   // recorded on the main stream behind the per-sample reset
     Stage stage[2];
@@ -186,6 +190,10 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     if (k == 27 && n_keys > VG_GRID_LDS_MAX_KEYS) {
         h.home_bucket_log2 = 5;
         if (const char* e = getenv("VGMI_LOCALITY")) h.home_bucket_log2 = (uint32_t)atoi(e) < 16 ? (uint32_t)atoi(e) : 5;
+        // A/B knob (off: measured -5 % on the dense chr20-class graph, +4 % on the 1.2 Gb one -- more k-mers share a
+        // (minimiser, offset) pair than a hashed place inside the bucket makes collide)
+        h.home_by_offset = 0;
+        if (const char* e = getenv("VGMI_SLOT_ORDER")) h.home_by_offset = atoi(e) != 0 && h.home_bucket_log2 >= 5;
     }
     // prefilter: >= 16 bits per key, power of two, at least 128 bits
     uint64_t bits = 128;
@@ -229,6 +237,7 @@ int adopt_image(vgmi_ctx* c)
     c->tv.slots8 = compact ? reinterpret_cast<unsigned long long*>(c->d_image + h.off_slots) : nullptr;
     c->tv.cap_mask = h.cap - 1;
     c->tv.home_bucket_log2 = h.home_bucket_log2;
+    c->tv.home_by_offset = h.home_by_offset;
     c->tv.filter = reinterpret_cast<const uint32_t*>(c->d_image + h.off_filter);
     c->tv.filter_words_log2 = h.filter_words_log2;
     c->tv.filter_shift = 32 - h.filter_words_log2;
@@ -278,16 +287,38 @@ void rows_geometry(vgmi_ctx* c, bool flds, uint32_t& grid, uint32_t& block)
     else      { block = 256;  grid = (uint32_t)c->n_cu * 8; }
 }
 
+// n_bytes_dev != nullptr: the block's length lives in device memory (device-side FASTQ parser); n_bytes is then only an
+// upper bound and the kernels derive their geometry themselves (odd k only)
 int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_t* d_read_off, size_t n_reads,
-                 hipStream_t st)
+                 hipStream_t st, const unsigned long long* n_bytes_dev = nullptr)
 {
     if (n_bytes == 0) return VGMI_OK;
     const uint32_t k = c->hdr.k;
     RowParams p = row_params(c, d_bases, n_bytes, k);
-    hipEvent_t e0 = get_event(c), e1 = get_event(c);
+    p.n_bytes_dev = n_bytes_dev;
+    hipEvent_t e0, e1;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        e0 = get_event(c);
+        e1 = get_event(c);
+    }
     if (!e0 || !e1) return fail(c, VGMI_E_HIP, "hipEventCreate failed");
     HIPCHK(c, hipEventRecord(e0, st));
-    if (k & 1) {
+    if (n_bytes_dev) {
+        if (!(k & 1)) return fail(c, VGMI_E_INVALID, "device-side block length: odd k only");
+        uint32_t grid, block;
+        rows_geometry(c, c->filter_in_lds, grid, block);
+        if (c->fast27 && !c->force_generic) {
+            uint32_t g27, b27;
+            if (c->fast27_lds) { b27 = 1024; g27 = (uint32_t)c->n_cu; }
+            else { b27 = 256; g27 = (uint32_t)c->n_cu * (c->wgs_per_cu ? c->wgs_per_cu : 4); }
+            HIPCHK(c, launch_count27(c->fast27_lds, p, g27, b27, st));
+            p.tail27 = 1;
+            HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, 1, block, st));
+        } else {
+            HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, grid, block, st));
+        }
+    } else if (k & 1) {
         uint32_t grid, block;
         rows_geometry(c, c->filter_in_lds, grid, block);
         if (c->fast27 && !c->force_generic) {
@@ -322,6 +353,7 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
         HIPCHK(c, launch_seq(K_MODE_COUNT, p, d_read_off, n_reads, st));
     }
     HIPCHK(c, hipEventRecord(e1, st));
+    std::lock_guard<std::mutex> lk(c->mu);
     c->timed.emplace_back(e0, e1);
     c->launches++;
     return VGMI_OK;
@@ -622,6 +654,7 @@ int vgmi_counts_reset(vgmi_ctx* c)
 {
     if (!c) return VGMI_E_INVALID;
     if (!c->has_table) return fail(c, VGMI_E_STATE, "no table");
+    if (c->open_fastq) return fail(c, VGMI_E_STATE, "close the FASTQ streams first");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = sync_stages(c);
     if (rc) return rc;
@@ -650,6 +683,7 @@ int vgmi_reads_submit_device(vgmi_ctx* c, const char* dev_bases, size_t n_bytes,
     HIPCHK(c, hipSetDevice(c->device));
     int rc = launch_count(c, dev_bases, n_bytes, dev_read_off, n_reads, c->stream);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
     c->read_base += n_bytes - n_reads;
     return VGMI_OK;
 }
@@ -714,6 +748,7 @@ int vgmi_reads_submit(vgmi_ctx* c, const char* bases, size_t n_bytes, const uint
         pos += len;
         read_i += piece_reads;
     }
+    std::lock_guard<std::mutex> lk(c->mu);
     c->read_base += n_bytes - n_reads;
     return VGMI_OK;
 }
@@ -743,6 +778,7 @@ int vgmi_counts_finish(vgmi_ctx* c, uint8_t* cov_out, uint8_t* cov_node_out, uin
     if (!c->has_table) return fail(c, VGMI_E_STATE, "no table");
     if (cov_node_out && !c->d_node_key_index) return fail(c, VGMI_E_STATE, "no nodes uploaded");
     if (hist_out && !c->d_flag) return fail(c, VGMI_E_STATE, "no flags uploaded");
+    if (c->open_fastq) return fail(c, VGMI_E_STATE, "close the FASTQ streams first");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = finish_common(c, c->d_cov, cov_node_out ? c->d_cov_node : nullptr, hist_out ? c->d_hist : nullptr);
     if (rc) return rc;
@@ -805,6 +841,169 @@ int vgmi_count_kernel_ms(vgmi_ctx* c, float* ms, uint64_t* launches)
     if (ms) *ms = c->kernel_ms;
     if (launches) *launches = c->launches;
     return VGMI_OK;
+}
+
+/* ---------------------------------------------------------------- device-side FASTQ parsing */
+
+struct vgmi_fastq {
+    vgmi_ctx* c = nullptr;
+    hipStream_t stream = nullptr;
+    char* h_stage[2] = {nullptr, nullptr};      // pinned
+    hipEvent_t h_done[2] = {nullptr, nullptr};  // the H2D copy out of that staging buffer has finished
+    bool h_busy[2] = {false, false};
+    uint8_t* d_raw[2] = {nullptr, nullptr};
+    uint8_t* d_packed = nullptr;
+    uint32_t *d_tile = nullptr, *d_nlpos = nullptr, *d_rec = nullptr, *d_off = nullptr, *d_bsum = nullptr;
+    FqState* d_state = nullptr;
+    size_t cap = 0;
+    uint32_t cap_lines = 0, tail_max = 0;
+    int next = 0, acquired = -1;
+};
+
+namespace {
+void fastq_free(vgmi_fastq* f)
+{
+    if (!f) return;
+    for (int i = 0; i < 2; ++i) {
+        if (f->h_stage[i]) (void)hipHostFree(f->h_stage[i]);
+        if (f->h_done[i]) (void)hipEventDestroy(f->h_done[i]);
+        if (f->d_raw[i]) (void)hipFree(f->d_raw[i]);
+    }
+    for (void* p : {(void*)f->d_packed, (void*)f->d_tile, (void*)f->d_nlpos, (void*)f->d_rec, (void*)f->d_off, (void*)f->d_bsum,
+                    (void*)f->d_state})
+        if (p) (void)hipFree(p);
+    if (f->stream) (void)hipStreamDestroy(f->stream);
+    delete f;
+}
+}  // namespace
+
+int vgmi_fastq_open(vgmi_ctx* c, vgmi_fastq** out)
+{
+    if (!c || !out) return VGMI_E_INVALID;
+    *out = nullptr;
+    if (!c->has_table) return fail(c, VGMI_E_STATE, "no table");
+    if (!(c->hdr.k & 1)) return fail(c, VGMI_E_STATE, "the device-side FASTQ parser serves odd k (even k: host reader + vgmi_reads_submit)");
+    HIPCHK(c, hipSetDevice(c->device));
+    vgmi_fastq* f = new (std::nothrow) vgmi_fastq();
+    if (!f) return fail(c, VGMI_E_NOMEM, "out of host memory");
+    f->c = c;
+    f->cap = c->buffer_bytes < (16u << 20) ? (16u << 20) : (c->buffer_bytes > (1u << 30) ? (1u << 30) : c->buffer_bytes);
+    if (const char* e = getenv("VGMI_FASTQ_CHUNK_KB"))   // tests: small chunks put every kind of record across a boundary
+        if (atoi(e) >= 4) f->cap = (size_t)atoi(e) << 10;
+    f->tail_max = 1u << 20;                          // an incomplete record carried between chunks: up to 1 MiB
+    f->cap_lines = (uint32_t)((f->cap + f->tail_max) / 6);
+    const size_t raw_bytes = f->tail_max + f->cap + 256;
+    const uint32_t n_tiles = (uint32_t)((raw_bytes + 4095) / 4096) + 1;
+    const uint32_t cap_rec = f->cap_lines / 4 + 1;
+    hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipHostMalloc(reinterpret_cast<void**>(&f->h_stage[i]), f->cap, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&f->h_done[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_raw[i]), raw_bytes);
+    }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_packed), f->cap + f->tail_max + 256);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_tile), (size_t)n_tiles * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_nlpos), (size_t)f->cap_lines * 4 + 64);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_rec), (size_t)cap_rec * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_off), (size_t)cap_rec * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_bsum), (size_t)(cap_rec / 1024 + 2) * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_state), sizeof(FqState));
+    if (e == hipSuccess) e = launch_fastq_init(f->d_state, f->tail_max, f->stream);
+    // the per-sample reset runs on the context's main stream: this stream starts behind it
+    if (e == hipSuccess) e = hipStreamWaitEvent(f->stream, c->reset_done, 0);
+    if (e != hipSuccess) {
+        fastq_free(f);
+        HIPCHK(c, e);
+    }
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->open_fastq++;
+    }
+    *out = f;
+    return VGMI_OK;
+}
+
+int vgmi_fastq_acquire(vgmi_fastq* f, char** host_buf, size_t* capacity)
+{
+    if (!f || !host_buf || !capacity) return VGMI_E_INVALID;
+    vgmi_ctx* c = f->c;
+    if (f->acquired >= 0) return fail(c, VGMI_E_STATE, "commit the buffer acquired before");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int i = f->next;
+    if (f->h_busy[i]) {
+        HIPCHK(c, hipEventSynchronize(f->h_done[i]));
+        f->h_busy[i] = false;
+    }
+    f->acquired = i;
+    *host_buf = f->h_stage[i];
+    *capacity = f->cap;
+    return VGMI_OK;
+}
+
+int vgmi_fastq_commit(vgmi_fastq* f, size_t n_bytes)
+{
+    if (!f) return VGMI_E_INVALID;
+    vgmi_ctx* c = f->c;
+    if (f->acquired < 0) return fail(c, VGMI_E_STATE, "no buffer acquired");
+    if (n_bytes > f->cap) return fail(c, VGMI_E_INVALID, "more bytes than the buffer holds");
+    const int i = f->acquired;
+    f->acquired = -1;
+    if (n_bytes == 0) return VGMI_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(f->d_raw[i] + f->tail_max, f->h_stage[i], n_bytes, hipMemcpyHostToDevice, f->stream));
+    HIPCHK(c, hipEventRecord(f->h_done[i], f->stream));
+    f->h_busy[i] = true;
+    FqBuffers b{};
+    b.raw = f->d_raw[i];
+    b.raw_next = f->d_raw[i ^ 1];
+    b.packed = f->d_packed;
+    b.tile = f->d_tile;
+    b.nlpos = f->d_nlpos;
+    b.rec_bytes = f->d_rec;
+    b.out_off = f->d_off;
+    b.block_sum = f->d_bsum;
+    b.state = f->d_state;
+    b.cap_lines = f->cap_lines;
+    b.tail_max = f->tail_max;
+    HIPCHK(c, launch_fastq_chunk(b, (uint32_t)n_bytes, f->stream));
+    // the read block's length is on the device: the count kernels fetch it (upper bound here: tail + chunk)
+    int rc = launch_count(c, reinterpret_cast<const char*>(f->d_packed), f->tail_max + n_bytes, nullptr, 0, f->stream,
+                          &f->d_state->packed_bytes);
+    if (rc) return rc;
+    f->next = i ^ 1;
+    return VGMI_OK;
+}
+
+int vgmi_fastq_close(vgmi_fastq* f, uint64_t* n_records, uint64_t* n_bases, uint64_t* consumed_bytes, int* stopped,
+                     char* tail_out, size_t tail_cap, size_t* tail_len)
+{
+    if (!f) return VGMI_E_INVALID;
+    vgmi_ctx* c = f->c;
+    int rc = VGMI_OK;
+    FqState st{};
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess) e = hipStreamSynchronize(f->stream);
+    if (e == hipSuccess) e = hipMemcpy(&st, f->d_state, sizeof st, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) {
+        if (n_records) *n_records = st.n_records;
+        if (n_bases) *n_bases = st.n_bases;
+        if (consumed_bytes) *consumed_bytes = st.consumed;
+        if (stopped) *stopped = (int)st.stopped;
+        if (tail_len) *tail_len = st.stopped ? 0 : st.tail_len;
+        if (!st.stopped && st.tail_len) {
+            if (!tail_out || tail_cap < st.tail_len) rc = fail(c, VGMI_E_INVALID, "tail buffer too small (1 MiB suffices)");
+            // the carry kernel left the tail in front of the landing area of the buffer the next chunk would have used
+            else e = hipMemcpy(tail_out, f->d_raw[f->next] + f->tail_max - st.tail_len, st.tail_len, hipMemcpyDeviceToHost);
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->open_fastq--;
+        if (e == hipSuccess) c->read_base += st.n_bases;
+    }
+    fastq_free(f);
+    if (e != hipSuccess) HIPCHK(c, e);
+    return rc;
 }
 
 /* ---------------------------------------------------------------- K1 trace */

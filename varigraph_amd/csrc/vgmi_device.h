@@ -237,18 +237,27 @@ VG_HD uint64_t vg_thash(uint64_t kmer)
 // two 128-byte lines) instead of twelve random sectors.  The position inside the bucket comes from the whole k-mer.
 // `rc` is the reverse complement of `canon` (window off of one is the reverse complement of window 11 - off of the
 // other, so the twelve canonical 16-mers need no per-window reversal).
-VG_HD uint64_t vg_thash_local(uint64_t canon, uint64_t rc, uint32_t bucket_log2)
+// With `by_offset` the place inside the bucket is not hashed either: it is 2 * o + one hash bit, o = how far the minimiser
+// sits from the k-mer's end, counted in the minimiser's OWN canonical orientation (so it does not depend on which strand
+// of the k-mer is the canonical one).  Along a read the k-mers that share a minimiser occurrence have o = e, e + 1, ...
+// (or 11 - e, 10 - e, ...): their slots -- and their per-slot counters -- are neighbours, a candidate run's probes read
+// one or two lines and its counter updates leave as one or two atomic requests (tools/ubench_mem2: the memory system
+// charges per request, the lanes of a request are free).
+VG_HD uint64_t vg_thash_local(uint64_t canon, uint64_t rc, uint32_t bucket_log2, bool by_offset = false)
 {
-    uint32_t best = 0xFFFFFFFFu;
+    uint32_t best = 0xFFFFFFFFu, best_o = 0;
     for (uint32_t off = 0; off < 12; ++off) {
         const uint32_t m = (uint32_t)(canon >> (2 * off)), r = (uint32_t)(rc >> (2 * (11 - off)));
         uint32_t h = (m < r ? m : r) * 0x9E3779B1u;
         h ^= h >> 15;
+        const uint32_t o = m <= r ? off : 11u - off;
+        best_o = h < best ? o : best_o;
         best = h < best ? h : best;
     }
     uint32_t b = best * 0x85EBCA77u;
     b ^= b >> 13;
     const uint32_t sub = (uint32_t)canon * 0x9E3779B1u + (uint32_t)(canon >> 32) * 0x85EBCA77u;
+    if (by_offset && bucket_log2 >= 5) return ((uint64_t)b << bucket_log2) | ((2u * best_o + (sub >> 31)) & ((1u << bucket_log2) - 1u));
     return ((uint64_t)b << bucket_log2) | (sub >> (32 - bucket_log2));
 }
 

@@ -15,6 +15,7 @@ struct TableView {
     unsigned long long* slots8; // cap k-mer words (compact 8-byte format) or nullptr
     uint64_t cap_mask;          // cap - 1 (cap is a power of two)
     uint32_t home_bucket_log2;  // 0: home slot = vg_thash; else minimiser buckets of 1 << this slots (vg_thash_local)
+    uint32_t home_by_offset;    // place inside the bucket from the minimiser's offset (neighbouring k-mers -> neighbouring slots)
     const uint32_t* filter;     // blocked-Bloom prefilter, 1 << filter_words_log2 words
     uint32_t filter_words_log2; // >= 2
     uint32_t filter_shift;      // 32 - filter_words_log2
@@ -45,6 +46,10 @@ struct RowParams {
                           // only (candidate runs dropped), 32 = one probing lane per run, 64 = collisions dropped; 128 = K3 without the per-wave
                           // privatisation (same filter, A/B only)
     uint32_t* status;     // bit0 empty read, bit1 bad key, bit2 duplicate key
+    const unsigned long long* n_bytes_dev;   // count kernels: when set, the block's length is read from device memory (the
+                          // device-side FASTQ parser knows it, the host does not) and n_bytes / row_end / row_begin /
+                          // emit_from are derived from it in the kernel; tail27 tells rows_kernel it runs behind count27_kernel
+    uint32_t tail27;
     TableView table;      // MODE_COUNT
     uint64_t* keys_out;   // MODE_KEYS
     BloomView bloom;      // MODE_BLOOM
@@ -56,6 +61,33 @@ struct SynthHaps {
     uint64_t off[VG_SYNTH_MAX_HAPS];
     uint64_t len[VG_SYNTH_MAX_HAPS];
 };
+
+// device-side FASTQ parsing (vgmi_fastq.hip)
+struct FqState {                       // device-resident, one per open stream
+    unsigned long long n_records;      // accepted since the stream was opened
+    unsigned long long n_bases;        // their sequence bytes (mReadBase)
+    unsigned long long consumed;       // file text bytes taken by the device: the host reader resumes here
+    unsigned long long packed_bytes;   // read block of the chunk just parsed (the count kernels' n_bytes)
+    uint32_t stopped;                  // sticky: the device parser has handed the rest of the stream to the host reader
+    uint32_t tail_len;                 // bytes of an incomplete record carried into the next chunk
+    uint32_t start;                    // where this chunk's text begins in the raw buffer (tail_max - previous tail_len)
+    uint32_t consumed_end;             // end of the last accepted record of this chunk
+    uint32_t n_lines, n_good, first_bad, dirty;   // per chunk
+};
+struct FqBuffers {
+    const uint8_t* raw;                // tail_max bytes of carry area + the chunk
+    uint8_t* raw_next;                 // the other raw buffer (receives the tail)
+    uint8_t* packed;                   // '\n'-joined sequences
+    uint32_t* tile;                    // newline count / base per 4 KiB tile
+    uint32_t* nlpos;                   // cap_lines newline positions
+    uint32_t* rec_bytes;               // per record: sequence length + 1
+    uint32_t* out_off;                 // per record: offset in the packed block
+    uint32_t* block_sum;               // scan scratch
+    FqState* state;
+    uint32_t cap_lines, tail_max;
+};
+hipError_t launch_fastq_init(FqState* st, uint32_t tail_max, hipStream_t s);
+hipError_t launch_fastq_chunk(const FqBuffers& b, uint32_t n_new, hipStream_t s);
 
 hipError_t launch_count27(bool lds_bitmap, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);

@@ -142,7 +142,7 @@ __device__ __forceinline__ uint32_t* count_cell(const TableView& t, uint64_t s, 
 // exact-table probe + saturating count of one canonical k-mer (generic kernels; either table format)
 __device__ __forceinline__ uint64_t table_home(const TableView& t, uint64_t canon)
 {
-    if (t.home_bucket_log2) return vg_thash_local(canon, vg_revcomp(canon, 27), t.home_bucket_log2) & t.cap_mask;
+    if (t.home_bucket_log2) return vg_thash_local(canon, vg_revcomp(canon, 27), t.home_bucket_log2, t.home_by_offset != 0) & t.cap_mask;
     return vg_thash(canon) & t.cap_mask;
 }
 
@@ -282,14 +282,26 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
     }
     __syncthreads();
 
+    // ---- block length: host value, or (device-side FASTQ parser) read from device memory together with what follows from it
+    uint64_t n_bytes = p.n_bytes, row_begin = p.row_begin, emit_from = p.emit_from;
+    if (p.n_bytes_dev) {
+        n_bytes = *p.n_bytes_dev;
+        emit_from = 0;
+        if (p.tail27) {   // behind count27_kernel: the ends it does not cover (see launch_count in vgmi_api.cpp)
+            const uint64_t row_end27 = (n_bytes / 1536) * 2;
+            emit_from = row_end27 ? row_end27 * 768 - 1 : 0;
+        }
+        row_begin = emit_from >> 10;
+        if (emit_from >= n_bytes) return;
+    }
     // ---- this wave's contiguous row range within [row_begin, total_rows)
-    const uint64_t total_rows = (p.n_bytes + 1023) >> 10;
-    if (p.row_begin >= total_rows) return;
-    const uint64_t span = total_rows - p.row_begin;
+    const uint64_t total_rows = (n_bytes + 1023) >> 10;
+    if (row_begin >= total_rows) return;
+    const uint64_t span = total_rows - row_begin;
     const uint64_t total_waves = (uint64_t)gridDim.x * nwaves;
     const uint64_t rpw = (span + total_waves - 1) / total_waves;
     const uint64_t gw = (uint64_t)blockIdx.x * nwaves + wave;
-    uint64_t r0 = p.row_begin + gw * rpw;
+    uint64_t r0 = row_begin + gw * rpw;
     uint64_t r1 = r0 + rpw < total_rows ? r0 + rpw : total_rows;
     if (r0 >= r1) return;
 
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
     // carry from the row before r0 (values already rotated by 1 and 2 lanes)
     uint32_t pr1_be = 0, pr2_be = 0, pr1_rc = ~0u, pr2_rc = ~0u, pr1_inv = 0xFFFFu, pr2_inv = 0xFFFFu;
     if (r0 > 0) {
-        const uint4 raw = load_chunk(p.bases, p.n_bytes, ((r0 - 1) << 10) + lane * 16);
+        const uint4 raw = load_chunk(p.bases, n_bytes, ((r0 - 1) << 10) + lane * 16);
         uint32_t be, inv;
         encode16(raw, s_lut, be, inv);
         const uint32_t rcw = rc_word(be);
@@ -313,10 +325,10 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
 
     uint32_t qhead = 0, qtail = 0;  // wave-uniform ring indices (MODE_COUNT)
 
-    uint4 raw_next = load_chunk(p.bases, p.n_bytes, (r0 << 10) + lane * 16);
+    uint4 raw_next = load_chunk(p.bases, n_bytes, (r0 << 10) + lane * 16);
     for (uint64_t r = r0; r < r1; ++r) {
         const uint4 raw = raw_next;
-        if (r + 1 < r1) raw_next = load_chunk(p.bases, p.n_bytes, ((r + 1) << 10) + lane * 16);
+        if (r + 1 < r1) raw_next = load_chunk(p.bases, n_bytes, ((r + 1) << 10) + lane * 16);
 
         uint32_t be, inv;
         encode16(raw, s_lut, be, inv);
@@ -356,7 +368,7 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
                     for (uint32_t t = 0; t < 16; ++t) {
                         if (!((adj >> t) & 1u)) continue;
                         const uint64_t o = base_off + t;
-                        if (o >= p.n_bytes) continue;
+                        if (o >= n_bytes) continue;
                         if (p.bases[o] == '\n' && (o == 0 || p.bases[o - 1] == '\n')) atomicOr(p.status, 1u);
                     }
                 }
@@ -389,16 +401,16 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
 
             if (MODE == MODE_KEYS) {
                 const uint64_t pos = (r << 10) + lane * 16 + j;
-                if (pos < p.n_bytes) p.keys_out[pos] = valid ? (vg_hash64(canon, mask) << 8 | K) : ~0ULL;
+                if (pos < n_bytes) p.keys_out[pos] = valid ? (vg_hash64(canon, mask) << 8 | K) : ~0ULL;
             } else if (MODE == MODE_BLOOM) {
                 const uint64_t pos = (r << 10) + lane * 16 + j;
                 if (p.dbg & 128u) {   // A/B: every lane updates the filter itself
-                    if (valid && pos < p.n_bytes) bloom_add_key(p.bloom, vg_hash64(canon, mask) << 8 | K);
+                    if (valid && pos < n_bytes) bloom_add_key(p.bloom, vg_hash64(canon, mask) << 8 | K);
                 } else {
-                    bloom_add_wave(p.bloom, s_bkey, s_bcnt, valid && pos < p.n_bytes, vg_hash64(canon, mask) << 8 | K);
+                    bloom_add_wave(p.bloom, s_bkey, s_bcnt, valid && pos < n_bytes, vg_hash64(canon, mask) << 8 | K);
                 }
             } else {
-                const bool emit = valid && (r << 10) + lane * 16 + j >= p.emit_from;
+                const bool emit = valid && (r << 10) + lane * 16 + j >= emit_from;
                 bool pass;
                 if (FLDS) {
                     const uint32_t h = vg_fhash_word(canon);
@@ -640,12 +652,13 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
     uint32_t* const counts = p.table.counts;
     const uint64_t cap_mask = p.table.cap_mask;
     const uint32_t hb_log2 = p.table.home_bucket_log2;
+    const bool hb_off = p.table.home_by_offset != 0;
 
     // rows [0, row_end) are complete 768-byte rows (row_end is even, see vgmi_api.cpp), so every load below is an
     // unconditional, perfectly coalesced dwordx3 (the ragged tail goes to rows_kernel).  A wave walks a
     // contiguous range of row PAIRS: two rows per iteration give every wave two independent dependency chains
     // (LUT reads -> permutes -> filter word), which four waves per SIMD need to keep the VALU fed.
-    const uint64_t total_pairs = p.row_end >> 1;
+    const uint64_t total_pairs = p.n_bytes_dev ? *p.n_bytes_dev / (2 * VG_ROW27) : p.row_end >> 1;   // device-side block length: vgmi_fastq.hip
     const uint64_t total_waves = (uint64_t)gridDim.x * nwaves;
     const uint64_t ppw = (total_pairs + total_waves - 1) / total_waves;
     // the wave index is uniform: keep the row counters in SGPRs
@@ -692,7 +705,7 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
         const uint64_t rc = vg_revcomp(kmer, 27);
         const uint64_t canon = kmer < rc ? kmer : rc;   // idempotent for re-queued (already canonical) entries
         b_canon = canon | (dist << 54);
-        const uint64_t home = (!LDS_BM && hb_log2) ? vg_thash_local(canon, canon == kmer ? rc : kmer, hb_log2) : vg_thash(canon);
+        const uint64_t home = (!LDS_BM && hb_log2) ? vg_thash_local(canon, canon == kmer ? rc : kmer, hb_log2, hb_off) : vg_thash(canon);
         b_slot = (home + dist) & cap_mask;
         b_active = act;
         if (act) vm_load_slot<COMPACT>(COMPACT ? (const void*)&slots8[b_slot] : (const void*)&slots[b_slot]);

@@ -130,8 +130,10 @@ class Graph:
         ctx.n_keys = self.info["n_keys"]
         ctx.n_node_entries = self.info["n_node_entries"]
 
-    def sample_count(self, ctx, fastq_paths, threads=4, sample_ploidy=2, use_depth=False):
-        """FastqKmerHip::build_fastq_index + coverage statistics for one sample."""
+    def sample_count(self, ctx, fastq_paths, threads=4, sample_ploidy=2, use_depth=False, require_depth=True):
+        """FastqKmerHip::build_fastq_index + coverage statistics for one sample.  require_depth=False: a sample too thin
+        for the coverage peak (the reference exits with "Failed to retrieve depth information") still returns its
+        counters."""
         i = self.info
         cov = np.empty(i["n_keys"], dtype=np.uint8)
         cov_node = np.empty(i["n_node_entries"], dtype=np.uint8)
@@ -140,7 +142,7 @@ class Graph:
         arr = (C.c_char_p * len(fastq_paths))(*[os.fsencode(p) for p in fastq_paths])
         rc = self._l.vgh_sample_count(self._h, ctx._h, arr, len(fastq_paths), threads, sample_ploidy, int(use_depth),
                                       vgmi._ptr(cov), vgmi._ptr(cov_node), vgmi._ptr(hist), C.byref(st))
-        if rc:
+        if rc and (require_depth or b"Failed to retrieve depth" not in self._l.vgh_last_error()):
             raise vgmi.VgmiError(rc, self._l.vgh_last_error().decode())
         stats = {f[0]: getattr(st, f[0]) for f in SampleStats._fields_}
         return cov, cov_node, hist, stats

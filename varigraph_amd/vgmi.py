@@ -53,6 +53,10 @@ def load_library():
         "vgmi_count_kernel_ms": (i32, [vp, C.POINTER(C.c_float), C.POINTER(u64)]),
         "vgmi_counts_export_device": (i32, [vp, vp]),
         "vgmi_counts_import_device": (i32, [vp, vp]),
+        "vgmi_fastq_open": (i32, [vp, C.POINTER(vp)]),
+        "vgmi_fastq_acquire": (i32, [vp, C.POINTER(vp), C.POINTER(sz)]),
+        "vgmi_fastq_commit": (i32, [vp, sz]),
+        "vgmi_fastq_close": (i32, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(i32), vp, sz, C.POINTER(sz)]),
         "vgmi_sketch_keys": (i32, [vp, vp, sz, vp, sz, u32, vp]),
         "vgmi_bloom_params": (i32, [u64, C.c_double, C.POINTER(u64), C.POINTER(u32)]),
         "vgmi_bloom_create": (i32, [vp, u64, u32, vp]),
@@ -250,6 +254,31 @@ class Context:
         ms, n = C.c_float(), C.c_uint64()
         self._chk(self._l.vgmi_count_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def fastq_text(self, text, piece=None):
+        """Device-side FASTQ parser over one stream of file text (bytes), committed in pieces of `piece` bytes (default:
+        whole staging buffers).  Returns dict(n_records, n_bases, consumed, stopped, tail)."""
+        fq = C.c_void_p()
+        self._chk(self._l.vgmi_fastq_open(self._h, C.byref(fq)))
+        mv = memoryview(text)
+        pos = 0
+        try:
+            while True:
+                buf, cap = C.c_void_p(), C.c_size_t()
+                self._chk(self._l.vgmi_fastq_acquire(fq, C.byref(buf), C.byref(cap)))
+                n = min(cap.value if piece is None else min(piece, cap.value), len(mv) - pos)
+                C.memmove(buf, bytes(mv[pos:pos + n]), n)
+                self._chk(self._l.vgmi_fastq_commit(fq, n))
+                pos += n
+                if pos >= len(mv):
+                    break
+        finally:
+            nr, nb, cons, st, tl = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int(), C.c_size_t()
+            tail = C.create_string_buffer(1 << 20)
+            rc = self._l.vgmi_fastq_close(fq, C.byref(nr), C.byref(nb), C.byref(cons), C.byref(st), tail, 1 << 20, C.byref(tl))
+        self._chk(rc)
+        return {"n_records": nr.value, "n_bases": nb.value, "consumed": cons.value, "stopped": bool(st.value),
+                "tail": tail.raw[:tl.value]}
 
     def sketch_keys(self, block, n_reads, k, read_off=None):
         block = np.ascontiguousarray(block, dtype=np.uint8)
