@@ -95,7 +95,7 @@ def cpu_baseline(haps, n_reads, cores):
             graph = os.path.join(work, "graph.bin")
             with open(graph, "wb") as f:
                 f.write(gzip.open(graph_gz, "rb").read())
-            fq = synth.write_fastq_pair(os.path.join(work, "s"), block, n_reads, READ_LEN, gz=False)
+            fq = synth.write_fastq_pair_fast(os.path.join(work, "s"), block, n_reads, READ_LEN)
             sweep = {}
             t_budget = time.perf_counter() + 40.0
             for threads in sorted({10, 16, 32, min(64, cores), cores}):  # 10 = reference default (-t)
@@ -118,7 +118,7 @@ def cpu_baseline(haps, n_reads, cores):
             if sweep and time.perf_counter() < t_budget:
                 # -t 1 on the first tenth of the sample (the single-thread rate is ~1e5 reads/s)
                 n1 = (n_reads // 10) // 2 * 2
-                fq1 = synth.write_fastq_pair(os.path.join(work, "s1"), block[: n1 * (READ_LEN + 1)], n1, READ_LEN, gz=False)
+                fq1 = synth.write_fastq_pair_fast(os.path.join(work, "s1"), block[: n1 * (READ_LEN + 1)], n1, READ_LEN)
                 try:
                     out = subprocess.run([harness, "count", graph, "1", os.path.join(work, "c1.bin")] + fq1,
                                          capture_output=True, text=True, timeout=120)
@@ -148,6 +148,83 @@ def cpu_baseline(haps, n_reads, cores):
     finally:
         import shutil
         shutil.rmtree(work, ignore_errors=True)
+
+
+def sample_level(ctx, haps, cpu_ref, n_plain=8_000_000, n_packed=1_000_000):
+    """SURVEY 8d level (ii): FASTQ FILES -> counters, through the product's FastqKmerHip (csrc/host): plain, gzip and
+    block-gzip copies of one sample of the C2 workload, with the records found on the device (vgmi_fastq_*) and, for
+    comparison, by the host parser; plus the PCIe-inclusive rate of the host-block entry point vgmi_reads_submit."""
+    import gzip
+    import shutil
+    from varigraph_amd import host, synth, vgmi
+    out = {}
+    work = tempfile.mkdtemp(prefix="vg_sample_")
+    try:
+        g = host.Graph(os.path.join(ROOT, "tests", "golden", "c1", "graph.bin.gz"))
+        g.upload(ctx)
+        threads = int(min(16, max(2, (cpu_quota() or os.cpu_count() or 2))))
+        block = vgmi.synth_reads_host(1000, 0, n_plain, READ_LEN, haps)
+        plain = synth.write_fastq_pair_fast(os.path.join(work, "p"), block, n_plain, READ_LEN)
+        small = synth.write_fastq_pair_fast(os.path.join(work, "c"), block[: n_packed * (READ_LEN + 1)], n_packed, READ_LEN)
+        gz, bgz = [], []
+        for p in small:
+            with open(p, "rb") as fi, gzip.open(p + ".gz", "wb", compresslevel=4) as fo:
+                shutil.copyfileobj(fi, fo, 1 << 24)
+            gz.append(p + ".gz")
+            bgz.append(synth.bgzf_compress_file(p, p + ".bgz.gz", level=4))
+        out["bytes_per_read_plain"] = sum(os.path.getsize(p) for p in plain) / n_plain
+        out["host_threads"] = threads
+
+        def rate(files, n, host_parse):
+            os.environ["VGH_HOST_PARSE"] = "1" if host_parse else "0"
+            best, cov = None, None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                cov, _, _, st = g.sample_count(ctx, files, threads=threads, require_depth=False)
+                dt = time.perf_counter() - t0
+                best = dt if best is None or dt < best else best
+            return n / best, cov
+
+        r_plain, cov_ref = rate(plain, n_plain, False)
+        out["plain_reads_per_s"] = r_plain
+        out["plain_text_gb_per_s"] = r_plain * out["bytes_per_read_plain"] / 1e9
+        out["plain_host_parser_reads_per_s"], cov_h = rate(plain, n_plain, True)
+        out["gzip_reads_per_s"], _ = rate(gz, n_packed, False)
+        out["bgzf_reads_per_s"], _ = rate(bgz, n_packed, False)
+        out["counters_identical_device_vs_host_parser"] = bool(np.array_equal(cov_ref, cov_h))
+        os.environ.pop("VGH_HOST_PARSE", None)
+        # PCIe-inclusive: the packed read block handed over from host memory (vgmi_reads_submit: pinned staging + H2D)
+        best = None
+        for _ in range(3):
+            ctx.counts_reset()
+            t0 = time.perf_counter()
+            ctx.reads_submit(block, n_plain)
+            ctx.counts_finish()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        out["reads_submit_from_host_memory_reads_per_s"] = n_plain / best
+        if cpu_ref and cpu_ref.get("kind") == "reference":
+            out["reference_plain_reads_per_s"] = cpu_ref["value"]
+            out["plain_vs_reference"] = r_plain / cpu_ref["value"]
+        harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+        if os.path.exists(harness):   # the unmodified reference on the gzip files, -t 10 (its default)
+            graph = os.path.join(work, "graph.bin")
+            with open(graph, "wb") as f:
+                f.write(gzip.open(os.path.join(ROOT, "tests", "golden", "c1", "graph.bin.gz"), "rb").read())
+            try:
+                r = subprocess.run([harness, "count", graph, "10", os.path.join(work, "c.bin")] + gz, capture_output=True, text=True,
+                                   timeout=120)
+                vals = dict(ln.split(" ", 1) for ln in r.stdout.splitlines() if " " in ln)
+                out["reference_gzip_reads_per_s"] = n_packed / float(vals["build_fastq_index_s"])
+                out["gzip_vs_reference"] = out["gzip_reads_per_s"] / out["reference_gzip_reads_per_s"]
+            except (subprocess.TimeoutExpired, KeyError, ValueError):
+                pass
+        out["sample"] = (f"{n_plain} reads (2 plain FASTQ files, {out['bytes_per_read_plain']:.0f} B/read) / {n_packed} reads "
+                         f"(gzip and block-gzip level 4), page-cache resident, best of 3; files -> counters on the host")
+        g.close()
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return out
 
 
 def measured_traffic(n_reads):
@@ -197,7 +274,8 @@ def main():
     ap.add_argument("--no-c3", action="store_true", help="skip the chr20-class (table in HBM) leg")
     ap.add_argument("--c3-reads", type=int, default=24_000_000)
     ap.add_argument("--c3-steps", type=int, default=20)
-    ap.add_argument("--verify-reads", type=int, default=2_000_000, help="unsaturated prefix checked against the oracle")
+    ap.add_argument("--verify-reads", type=int, default=1_000_000, help="unsaturated prefix checked against the oracle")
+    ap.add_argument("--no-sample-level", action="store_true", help="skip the FASTQ-files-to-counters leg")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
@@ -428,6 +506,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
             out["cpu_baseline"] = cpu_baseline(haps, args.cpu_reads, cores)
+        if world == 1 and not args.no_sample_level:
+            out["sample_level"] = sample_level(ctx, haps, out.get("cpu_baseline"))
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist:

@@ -82,7 +82,7 @@ def test_bench_starts_its_own_ranks():
     env = dict(os.environ, VGMI_BENCH_DEVICE="0")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--reads", "4000000",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--reads", "4000000", "--no-sample-level",
                         "--steps", "3", "--warmup", "1", "--no-c3", "--verify-reads", "200000"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]

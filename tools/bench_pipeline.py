@@ -39,18 +39,22 @@ def main():
         ctx = vgmi.Context(0, buffer_mib=128)
         g.upload(ctx)
         ref_cov = None
-        for label, files, threads in (("plain", plain, 2), ("gz", gz, 2), ("bgzf_t4", bgz, 4), ("bgzf_t16", bgz, 16)):
-            best = None
-            for _ in range(2):
-                t0 = time.perf_counter()
-                cov, _, _, st = g.sample_count(ctx, files, threads=threads)
-                dt = time.perf_counter() - t0
-                best = dt if best is None or dt < best else best
-            out[f"hip_{label}_reads_per_s"] = n_reads / best
-            out[f"hip_{label}_kernel_s"] = st["seconds_kernel"]
-            if ref_cov is None:
-                ref_cov = cov
-            assert np.array_equal(cov, ref_cov)
+        for parse in ("device", "host"):   # device: vgmi_fastq_* (records found on the GPU); host: parser thread per file
+            os.environ["VGH_HOST_PARSE"] = "1" if parse == "host" else "0"
+            for label, files, threads in (("plain_t2", plain, 2), ("plain_t8", plain, 8), ("plain_t16", plain, 16), ("gz_t2", gz, 2),
+                                          ("bgzf_t4", bgz, 4), ("bgzf_t16", bgz, 16)):
+                best = None
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    cov, _, _, st = g.sample_count(ctx, files, threads=threads, require_depth=False)
+                    dt = time.perf_counter() - t0
+                    best = dt if best is None or dt < best else best
+                out[f"{parse}_parse_{label}_reads_per_s"] = n_reads / best
+                out[f"{parse}_parse_{label}_kernel_s"] = st["seconds_kernel"]
+                if ref_cov is None:
+                    ref_cov = cov
+                assert np.array_equal(cov, ref_cov)
+        out["plain_bytes_per_read"] = sum(os.path.getsize(p) for p in plain) / n_reads
         harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
         if os.path.exists(harness):
             graph = os.path.join(work, "graph.bin")

@@ -89,6 +89,7 @@ struct vgmi_ctx {
     // per-sample state
     std::mutex mu;                 // event list / counters below when several FASTQ streams submit from their own threads
     int open_fastq = 0;
+    std::vector<struct vgmi_fastq*> fastq_pool;   // closed streams keep their pinned and device buffers for the next file
     uint64_t read_base = 0;
     hipEvent_t reset_done = nullptr;   // recorded on the main stream behind the per-sample reset
     Stage stage[2];
@@ -105,6 +106,8 @@ struct vgmi_ctx {
 };
 
 namespace {
+
+void fastq_free(vgmi_fastq* f);
 
 int fail(vgmi_ctx* c, int code, const std::string& msg)
 {
@@ -478,6 +481,8 @@ void vgmi_destroy(vgmi_ctx* c)
         if (s.stream) (void)hipStreamDestroy(s.stream);
         if (s.done) (void)hipEventDestroy(s.done);
     }
+    for (vgmi_fastq* f : c->fastq_pool) fastq_free(f);
+    c->fastq_pool.clear();
     for (auto& pr : c->timed) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto& e : c->event_pool) (void)hipEventDestroy(e);
     if (c->bv.filter) (void)hipFree(c->bv.filter);
@@ -884,12 +889,39 @@ int vgmi_fastq_open(vgmi_ctx* c, vgmi_fastq** out)
     if (!c->has_table) return fail(c, VGMI_E_STATE, "no table");
     if (!(c->hdr.k & 1)) return fail(c, VGMI_E_STATE, "the device-side FASTQ parser serves odd k (even k: host reader + vgmi_reads_submit)");
     HIPCHK(c, hipSetDevice(c->device));
+    size_t want_cap = c->buffer_bytes < (16u << 20) ? (16u << 20) : (c->buffer_bytes > (1u << 30) ? (1u << 30) : c->buffer_bytes);
+    if (const char* e = getenv("VGMI_FASTQ_CHUNK_KB"))   // tests: small chunks put every kind of record across a boundary
+        if (atoi(e) >= 4) want_cap = (size_t)atoi(e) << 10;
+    {   // a closed stream of the same geometry: its buffers are reused (pinned allocations cost more than a small file)
+        vgmi_fastq* r = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            for (size_t i = 0; i < c->fastq_pool.size() && !r; ++i)
+                if (c->fastq_pool[i]->cap == want_cap) {
+                    r = c->fastq_pool[i];
+                    c->fastq_pool.erase(c->fastq_pool.begin() + (long)i);
+                }
+        }
+        if (r) {
+            r->next = 0;
+            r->acquired = -1;
+            r->h_busy[0] = r->h_busy[1] = false;
+            hipError_t e = launch_fastq_init(r->d_state, r->tail_max, r->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(r->stream, c->reset_done, 0);
+            if (e != hipSuccess) {
+                fastq_free(r);
+                HIPCHK(c, e);
+            }
+            std::lock_guard<std::mutex> lk(c->mu);
+            c->open_fastq++;
+            *out = r;
+            return VGMI_OK;
+        }
+    }
     vgmi_fastq* f = new (std::nothrow) vgmi_fastq();
     if (!f) return fail(c, VGMI_E_NOMEM, "out of host memory");
     f->c = c;
-    f->cap = c->buffer_bytes < (16u << 20) ? (16u << 20) : (c->buffer_bytes > (1u << 30) ? (1u << 30) : c->buffer_bytes);
-    if (const char* e = getenv("VGMI_FASTQ_CHUNK_KB"))   // tests: small chunks put every kind of record across a boundary
-        if (atoi(e) >= 4) f->cap = (size_t)atoi(e) << 10;
+    f->cap = want_cap;
     f->tail_max = 1u << 20;                          // an incomplete record carried between chunks: up to 1 MiB
     f->cap_lines = (uint32_t)((f->cap + f->tail_max) / 6);
     const size_t raw_bytes = f->tail_max + f->cap + 256;
@@ -996,12 +1028,17 @@ int vgmi_fastq_close(vgmi_fastq* f, uint64_t* n_records, uint64_t* n_bases, uint
             else e = hipMemcpy(tail_out, f->d_raw[f->next] + f->tail_max - st.tail_len, st.tail_len, hipMemcpyDeviceToHost);
         }
     }
+    bool keep = false;
     {
         std::lock_guard<std::mutex> lk(c->mu);
         c->open_fastq--;
         if (e == hipSuccess) c->read_base += st.n_bases;
+        if (e == hipSuccess && c->fastq_pool.size() < 4) {
+            c->fastq_pool.push_back(f);
+            keep = true;
+        }
     }
-    fastq_free(f);
+    if (!keep) fastq_free(f);
     if (e != hipSuccess) HIPCHK(c, e);
     return rc;
 }
