@@ -138,6 +138,18 @@ typedef struct vgmi_fastq vgmi_fastq;
 int vgmi_fastq_open(vgmi_ctx *ctx, vgmi_fastq **out);
 int vgmi_fastq_acquire(vgmi_fastq *fq, char **host_buf, size_t *capacity);
 int vgmi_fastq_commit(vgmi_fastq *fq, size_t n_bytes);
+/* Block-gzip (BGZF: bgzip, htslib) input: the staging buffer holds COMPRESSED file bytes, continuing where the previous
+ * commit's `taken` ended.  The host walks the member headers; every whole member whose text fits the chunk is inflated
+ * on the device (one wavefront per member, CRC-32 and ISIZE checked) into the text the FASTQ kernels parse.
+ *   taken     compressed bytes consumed (whole members); the caller puts the rest in front of the next buffer
+ *   n_text    text bytes these members inflate to
+ *   not_bgzf  the bytes at `taken` are not a block-gzip member (plain gzip member, damage): the device path ends there
+ * replaces: gzread's inflate under kseq (include/kseq.h:59-72, src/fastq_kmer.cpp:74-78). */
+int vgmi_fastq_commit_bgzf(vgmi_fastq *fq, size_t n_bytes, size_t *taken, size_t *n_text, int *not_bgzf);
+/* After the last commit (waits): failed != 0 if a member did not inflate to its ISIZE / CRC-32; good_compressed_bytes =
+ * compressed bytes in front of the first such member (all committed bytes if none failed): the text of those bytes went
+ * through the parser, the host decoder takes the file over at that offset. */
+int vgmi_fastq_bgzf_status(vgmi_fastq *fq, int *failed, uint64_t *good_compressed_bytes, uint32_t *reason);
 int vgmi_fastq_close(vgmi_fastq *fq, uint64_t *n_records, uint64_t *n_bases, uint64_t *consumed_bytes, int *stopped,
                      char *tail_out, size_t tail_cap, size_t *tail_len);
 

@@ -181,3 +181,112 @@ def test_cohort_files_device_parser_all_containers(kind, graph_ctx, tmp_path):
         got = _count(g, ctx, paths, host_parse=False, chunk_kb=chunk_kb)
         assert np.array_equal(got["cov"], cohort.ref_c_in_graph_order())
         assert got["read_base"] == cohort.ref_read_base
+
+
+# ---- block gzip inflated on the device (csrc/vgmi_inflate.hip) -----------------------------------------------------
+def _bgzf(tmp_path, name, text, level, block=0xff00):
+    src = tmp_path / (name + ".fq")
+    src.write_bytes(text)
+    dst = tmp_path / (name + ".fq.gz")
+    synth.bgzf_compress_file(str(src), str(dst), level=level, block=block)
+    return dst
+
+
+def _count_env(g, ctx, paths, env, chunk_kb=None):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return _count(g, ctx, paths, host_parse=env.get("VGH_HOST_PARSE") == "1", chunk_kb=chunk_kb)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("level,block", [(0, 0xff00), (1, 0xff00), (6, 0xff00), (9, 0xff00), (4, 3000), (6, 70)])
+def test_bgzf_inflated_on_the_device(level, block, graph_ctx, tmp_path):
+    """Stored, fixed and dynamic DEFLATE blocks, full-size and tiny members: counters equal the all-host path
+    (inflate workers + host parser) and the oracle; mixed qualities make the streams literal/match mixed."""
+    g, ctx, cohort = graph_ctx
+    rd = _reads(3000 if block > 100 else 60, 21 + level)
+    rng = np.random.default_rng(level)
+    quals = [bytes(rng.integers(33, 74, size=len(r), dtype=np.uint8)) for r in rd]
+    text = b"".join(b"@q%d\n" % i + r + b"\n+\n" + q + b"\n" for i, (r, q) in enumerate(zip(rd, quals)))
+    p = _bgzf(tmp_path, "a", text, level, block)
+    want = _count_env(g, ctx, [str(p)], {"VGH_HOST_PARSE": "1"})
+    t = o.Table(cohort.graph.keys)
+    t.count_block(np.frombuffer(b"".join(r + b"\n" for r in rd), dtype=np.uint8), cohort.k)
+    assert np.array_equal(want["cov"], t.counts())
+    for chunk_kb in (None, 200, 96):
+        got = _count_env(g, ctx, [str(p)], {"VGH_HOST_PARSE": "0"}, chunk_kb=chunk_kb)
+        assert np.array_equal(got["cov"], want["cov"]) and got["read_base"] == want["read_base"] and got["n_reads"] == want["n_reads"]
+    host_inflate = _count_env(g, ctx, [str(p)], {"VGH_HOST_PARSE": "0", "VGH_HOST_INFLATE": "1"})
+    assert np.array_equal(host_inflate["cov"], want["cov"])
+
+
+@pytest.mark.parametrize("damage", ["flip_in_third_member", "truncated_mid_member", "gzip_member_after_bgzf", "crc_field", "no_eof_marker"])
+def test_bgzf_damage_and_mixtures_equal_the_host_decoder(damage, graph_ctx, tmp_path):
+    """What the device cannot vouch for goes to the host decoder at the right byte: same counters as the all-host path
+    (which delivers what decoded cleanly before the damage, like the reference's gzread loop)."""
+    g, ctx, cohort = graph_ctx
+    rd = _reads(2500, 77)
+    text = _fastq(rd)
+    p = _bgzf(tmp_path, "d", text, 5)
+    raw = bytearray(p.read_bytes())
+    # member boundaries
+    offs, pos = [], 0
+    while pos < len(raw):
+        offs.append(pos)
+        pos += (raw[pos + 16] | raw[pos + 17] << 8) + 1
+    assert len(offs) >= 5
+    if damage == "flip_in_third_member":
+        raw[offs[2] + 200] ^= 0x5A
+    elif damage == "truncated_mid_member":
+        raw = raw[: offs[3] + 1000]
+    elif damage == "gzip_member_after_bgzf":
+        raw = raw[: offs[3]] + gzip.compress(text[-30000:], 6)
+    elif damage == "crc_field":
+        raw[offs[2] - 8] ^= 1
+    elif damage == "no_eof_marker":
+        raw = raw[: offs[-1]]
+    q = tmp_path / "dmg.fq.gz"
+    q.write_bytes(bytes(raw))
+    want = _count_env(g, ctx, [str(q)], {"VGH_HOST_PARSE": "1"})
+    for chunk_kb in (None, 160):
+        got = _count_env(g, ctx, [str(q)], {"VGH_HOST_PARSE": "0"}, chunk_kb=chunk_kb)
+        assert np.array_equal(got["cov"], want["cov"]), damage
+        assert got["read_base"] == want["read_base"] and got["n_reads"] == want["n_reads"], damage
+    assert want["n_reads"] > 0
+
+
+def test_bgzf_stream_contract(graph_ctx, tmp_path):
+    """vgmi_fastq_commit_bgzf / _bgzf_status directly: a clean file is inflated and parsed entirely on the device (nothing
+    left for the host decoder); a damaged member is named by its compressed offset and nothing behind it is parsed."""
+    g, ctx, cohort = graph_ctx
+    rd = _reads(2000, 5)
+    text = _fastq(rd)
+    p = _bgzf(tmp_path, "c", text, 6)
+    comp = p.read_bytes()
+    for piece in (None, 150_000):
+        ctx.counts_reset()
+        r = ctx.fastq_bgzf(comp, piece=piece)
+        assert not r["inflate_failed"] and not r["stopped"]
+        assert r["taken"] == r["good_compressed_bytes"] == len(comp)
+        assert (r["n_records"], r["n_bases"], r["consumed"], r["tail"]) == (2000, sum(map(len, rd)), len(text), b"")
+        got, _, _ = ctx.counts_finish()
+        t = o.Table(cohort.graph.keys)
+        t.count_block(np.frombuffer(b"".join(x + b"\n" for x in rd), dtype=np.uint8), cohort.k)
+        assert np.array_equal(got, t.counts())
+    offs, pos = [], 0
+    while pos < len(comp):
+        offs.append(pos)
+        pos += (comp[pos + 16] | comp[pos + 17] << 8) + 1
+    bad = bytearray(comp)
+    bad[offs[3] + 300] ^= 0xFF
+    ctx.counts_reset()
+    r = ctx.fastq_bgzf(bytes(bad))
+    assert r["inflate_failed"] and r["good_compressed_bytes"] == offs[3] and r["reason"] in (1, 2, 3, 4, 5)
+    assert r["consumed"] + len(r["tail"]) == 3 * 0xff00      # the text of the three members in front of it, no more
+    ctx.counts_finish()

@@ -30,9 +30,10 @@ constexpr size_t kTaskOut = 2u << 20;    // BGZF: decoded bytes per worker task 
 // file descriptor with a push-back area (the bytes looked at to tell the formats apart)
 class FileIn {
 public:
-    explicit FileIn(const std::string& path) : path_(path), fd_(::open(path.c_str(), O_RDONLY))
+    explicit FileIn(const std::string& path, uint64_t offset = 0) : path_(path), fd_(::open(path.c_str(), O_RDONLY))
     {
         if (fd_ < 0) throw std::runtime_error("'" + path + "': No such file or directory.");
+        if (offset && ::lseek(fd_, (off_t)offset, SEEK_SET) < 0) throw std::runtime_error("'" + path + "': cannot seek.");
 #ifdef POSIX_FADV_SEQUENTIAL
         (void)posix_fadvise(fd_, 0, 0, POSIX_FADV_SEQUENTIAL);
 #endif
@@ -535,9 +536,11 @@ private:
 
 }  // namespace
 
-std::unique_ptr<ByteSource> ByteSource::open(const std::string& path, unsigned decode_threads)
+std::unique_ptr<ByteSource> ByteSource::open(const std::string& path, unsigned decode_threads) { return open_at(path, 0, decode_threads); }
+
+std::unique_ptr<ByteSource> ByteSource::open_at(const std::string& path, uint64_t offset, unsigned decode_threads)
 {
-    auto in = std::make_unique<FileIn>(path);
+    auto in = std::make_unique<FileIn>(path, offset);
     // enough of the first member to see a BGZF extra field (bgzip writes XLEN = 6)
     unsigned char head[64];
     const size_t n = in->read(head, sizeof head);
@@ -587,6 +590,30 @@ private:
     uint64_t left_;
 };
 }  // namespace
+
+namespace {
+class ConcatSource final : public ByteSource {
+public:
+    ConcatSource(std::unique_ptr<ByteSource> a, std::unique_ptr<ByteSource> b) : a_(std::move(a)), b_(std::move(b)) {}
+    bool next_chunk(const unsigned char*& p, size_t& n) override
+    {
+        if (a_) {
+            if (a_->next_chunk(p, n)) return true;
+            a_.reset();
+        }
+        return b_->next_chunk(p, n);
+    }
+    const char* kind() const override { return b_->kind(); }
+
+private:
+    std::unique_ptr<ByteSource> a_, b_;
+};
+}  // namespace
+
+std::unique_ptr<ByteSource> ByteSource::concat(std::unique_ptr<ByteSource> a, std::unique_ptr<ByteSource> b)
+{
+    return std::make_unique<ConcatSource>(std::move(a), std::move(b));
+}
 
 std::unique_ptr<ByteSource> ByteSource::from_memory(const void* data, size_t n) { return std::make_unique<MemorySource>(data, n); }
 std::unique_ptr<ByteSource> ByteSource::skip(std::unique_ptr<ByteSource> inner, uint64_t n)

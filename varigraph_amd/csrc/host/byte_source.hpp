@@ -26,6 +26,10 @@ public:
 
     // throws std::runtime_error("'<path>': No such file or directory.") like the callers' gzopen checks
     static std::unique_ptr<ByteSource> open(const std::string& path, unsigned decode_threads = 1);
+    // the same from a byte offset of the file on (a member boundary of a compressed file)
+    static std::unique_ptr<ByteSource> open_at(const std::string& path, uint64_t offset, unsigned decode_threads = 1);
+    // `a` to its end, then `b`
+    static std::unique_ptr<ByteSource> concat(std::unique_ptr<ByteSource> a, std::unique_ptr<ByteSource> b);
     // a run of bytes already in memory (not owned; must outlive the source)
     static std::unique_ptr<ByteSource> from_memory(const void* data, size_t n);
     // `inner` without its first `n` bytes (the device-side FASTQ parser hands a stream over at a byte offset)

@@ -159,6 +159,15 @@ DeviceFileResult device_file(vgmi_ctx* ctx, const std::string& path, size_t bloc
     const uint64_t file_size = (uint64_t)sb.st_size;
     struct FdGuard { int fd; ~FdGuard() { if (fd >= 0) ::close(fd); } } guard{fd};
 
+    // block gzip?  (the first member carries the 'BC' extra subfield: bgzip, htslib)
+    bool bgzf = false;
+    if (!plain) {
+        unsigned char h[18] = {0};
+        if (::pread(fd, h, 18, 0) == 18 && h[2] == 8 && h[3] == 4 && (h[10] | h[11] << 8) >= 6 && h[12] == 'B' && h[13] == 'C') bgzf = true;
+        const char* off = std::getenv("VGH_HOST_INFLATE");   // A/B: block gzip through the host's inflate workers
+        if (off && off[0] == '1') bgzf = false;
+    }
+
     vgmi_fastq* fq = nullptr;
     if (vgmi_fastq_open(ctx, &fq) != VGMI_OK) throw std::runtime_error(vgmi_last_error(ctx));
     uint64_t n_rec = 0, n_bases = 0, consumed = 0;
@@ -166,17 +175,23 @@ DeviceFileResult device_file(vgmi_ctx* ctx, const std::string& path, size_t bloc
     std::vector<char> tail(1u << 20);
     size_t tail_len = 0;
     bool closed = false;
+    int inflate_failed = 0;
+    uint64_t comp_taken = 0;          // block gzip: compressed bytes handed to the device as whole members
+    uint64_t comp_good = 0;           // ... of which the device vouches for (everything unless a member failed)
     auto close_stream = [&]() {
+        if (bgzf && vgmi_fastq_bgzf_status(fq, &inflate_failed, &comp_good, nullptr) != VGMI_OK) throw std::runtime_error(vgmi_last_error(ctx));
         closed = true;
         if (vgmi_fastq_close(fq, &n_rec, &n_bases, &consumed, &stopped, tail.data(), tail.size(), &tail_len) != VGMI_OK)
             throw std::runtime_error(vgmi_last_error(ctx));
     };
     try {
         std::unique_ptr<ByteSource> src;
-        if (!plain) src = ByteSource::open(path, threads);
+        if (!plain && !bgzf) src = ByteSource::open(path, threads);
         uint64_t offset = 0;
         const unsigned char* left_p = nullptr;   // rest of a decoded chunk that did not fit the previous buffer
         size_t left_n = 0;
+        std::vector<char> carry;                 // block gzip: the bytes behind the last whole member of the previous buffer
+        double ratio = 5.0;                      // text bytes per compressed byte, tracked
         for (;;) {
             char* buf = nullptr;
             size_t cap = 0;
@@ -185,6 +200,26 @@ DeviceFileResult device_file(vgmi_ctx* ctx, const std::string& path, size_t bloc
             if (plain) {
                 n = fill_plain(fd, offset, file_size, buf, cap, threads);
                 offset += n;
+                if (vgmi_fastq_commit(fq, n) != VGMI_OK) throw std::runtime_error(vgmi_last_error(ctx));
+                if (n < cap) break;   // end of the data
+            } else if (bgzf) {
+                // compressed bytes whose text fills about nine tenths of a chunk
+                size_t want = (size_t)std::min<double>((double)cap, 0.9 * (double)cap / ratio);
+                want = std::max<size_t>(want, std::min<size_t>(cap, carry.size() + (256u << 10)));
+                memcpy(buf, carry.data(), carry.size());
+                n = carry.size();
+                const size_t got = fill_plain(fd, offset, file_size, buf + n, want - n, threads);
+                offset += got;
+                n += got;
+                size_t taken = 0, n_text = 0;
+                int not_bgzf = 0;
+                if (vgmi_fastq_commit_bgzf(fq, n, &taken, &n_text, &not_bgzf) != VGMI_OK) throw std::runtime_error(vgmi_last_error(ctx));
+                comp_taken += taken;
+                carry.assign(buf + taken, buf + n);
+                if (taken && n_text) ratio = std::max(1.0, (double)n_text / (double)taken);
+                if (not_bgzf) break;                                  // the host decoder goes on at comp_taken
+                if (offset >= file_size && (taken == 0 || carry.empty())) break;   // end of the file (a cut-off member stays for the host)
+                if (taken == 0 && want >= cap) break;                 // cannot happen with 64 KiB members; never spin
             } else {
                 for (;;) {
                     if (!left_n && !src->next_chunk(left_p, left_n)) break;
@@ -195,9 +230,9 @@ DeviceFileResult device_file(vgmi_ctx* ctx, const std::string& path, size_t bloc
                     left_n -= take;
                     if (n == cap) break;
                 }
+                if (vgmi_fastq_commit(fq, n) != VGMI_OK) throw std::runtime_error(vgmi_last_error(ctx));
+                if (n < cap) break;   // end of the data
             }
-            if (vgmi_fastq_commit(fq, n) != VGMI_OK) throw std::runtime_error(vgmi_last_error(ctx));
-            if (n < cap) break;   // end of the data
         }
         close_stream();
     } catch (...) {
@@ -207,9 +242,14 @@ DeviceFileResult device_file(vgmi_ctx* ctx, const std::string& path, size_t bloc
     res.n_reads = n_rec;
     res.read_base = n_bases;
     // what the device did not take: the text after the last complete record (an unterminated last line, or nothing), or
-    // -- once it met a record that is not a regular four-line one -- the rest of the stream from that record on
+    // -- once it met a record that is not a regular four-line one -- the rest of the stream from that record on; for
+    // block gzip also the file from the first member the device did not take or could not vouch for
     if (stopped) {
         FastxReader rd(ByteSource::skip(ByteSource::open(path, threads), consumed));
+        host_leg(ctx, rd, path, block_bytes, submit_mu, res.n_reads, res.read_base);
+    } else if (bgzf && (inflate_failed ? comp_good : comp_taken) < file_size) {
+        const uint64_t at = inflate_failed ? comp_good : comp_taken;
+        FastxReader rd(ByteSource::concat(ByteSource::from_memory(tail.data(), tail_len), ByteSource::open_at(path, at, threads)));
         host_leg(ctx, rd, path, block_bytes, submit_mu, res.n_reads, res.read_base);
     } else if (tail_len) {
         FastxReader rd(ByteSource::from_memory(tail.data(), tail_len));

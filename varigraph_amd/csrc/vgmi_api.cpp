@@ -177,7 +177,6 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     h.n_keys = n_keys;
     // k = 27: compact 8-byte slots (a minimiser bucket of 32 is two 128-byte lines, its counters one); small graphs
     // spend the same bytes on twice the slots
-    const bool small = n_keys <= VG_GRID_LDS_MAX_KEYS;
     const bool compact = k == 27 && !getenv("VGMI_WIDE_SLOTS");   // 8-byte k-mer words + per-slot counters
     h.slot_bytes = compact ? 8 : 16;
     uint64_t cap = 64;
@@ -863,6 +862,16 @@ struct vgmi_fastq {
     size_t cap = 0;
     uint32_t cap_lines = 0, tail_max = 0;
     int next = 0, acquired = -1;
+    // block-gzip input inflated on the device (allocated by the first vgmi_fastq_commit_bgzf)
+    uint8_t* d_comp = nullptr;
+    BgzfMember* d_members = nullptr;
+    BgzfMember* h_members[2] = {nullptr, nullptr};   // pinned
+    uint32_t* d_status = nullptr;
+    uint32_t* d_crc = nullptr;
+    BgzfVerdict* d_verdict = nullptr;
+    uint32_t max_members = 0;
+    std::vector<uint32_t> batch_members;             // members per committed batch
+    std::vector<uint64_t> member_size;               // compressed size of every member committed, in stream order
 };
 
 namespace {
@@ -875,8 +884,10 @@ void fastq_free(vgmi_fastq* f)
         if (f->d_raw[i]) (void)hipFree(f->d_raw[i]);
     }
     for (void* p : {(void*)f->d_packed, (void*)f->d_tile, (void*)f->d_nlpos, (void*)f->d_rec, (void*)f->d_off, (void*)f->d_bsum,
-                    (void*)f->d_state})
+                    (void*)f->d_state, (void*)f->d_comp, (void*)f->d_members, (void*)f->d_status, (void*)f->d_crc, (void*)f->d_verdict})
         if (p) (void)hipFree(p);
+    for (int i = 0; i < 2; ++i)
+        if (f->h_members[i]) (void)hipHostFree(f->h_members[i]);
     if (f->stream) (void)hipStreamDestroy(f->stream);
     delete f;
 }
@@ -906,6 +917,9 @@ int vgmi_fastq_open(vgmi_ctx* c, vgmi_fastq** out)
             r->next = 0;
             r->acquired = -1;
             r->h_busy[0] = r->h_busy[1] = false;
+            r->batch_members.clear();
+            r->member_size.clear();
+            if (r->d_verdict) (void)hipMemsetAsync(r->d_verdict, 0xFF, 12, r->stream), (void)hipMemsetAsync(&r->d_verdict->good_bytes, 0, 8, r->stream);
             hipError_t e = launch_fastq_init(r->d_state, r->tail_max, r->stream);
             if (e == hipSuccess) e = hipStreamWaitEvent(r->stream, c->reset_done, 0);
             if (e != hipSuccess) {
@@ -1003,6 +1017,150 @@ int vgmi_fastq_commit(vgmi_fastq* f, size_t n_bytes)
                           &f->d_state->packed_bytes);
     if (rc) return rc;
     f->next = i ^ 1;
+    return VGMI_OK;
+}
+
+namespace {
+// one BGZF member header at p (n bytes available): total size, DEFLATE range, trailer.  0 = not (yet) a whole member,
+// -1 = not a block-gzip member at all (SAM spec 4.1: gzip member with FEXTRA and a 'BC' subfield of 2 bytes)
+int bgzf_member(const unsigned char* p, size_t n, uint32_t& total, uint32_t& d_off, uint32_t& d_len, uint32_t& crc, uint32_t& isize)
+{
+    if (n < 18) return 0;
+    if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || p[3] != 4) return -1;   // FLG: FEXTRA and nothing else, as bgzip writes
+    const uint32_t xlen = p[10] | (uint32_t)p[11] << 8;
+    if (n < 12 + (size_t)xlen) return xlen > 4096 ? -1 : 0;
+    uint32_t bsize = 0;
+    bool found = false;
+    for (uint32_t q = 0; q + 4 <= xlen;) {
+        const unsigned char* sf = p + 12 + q;
+        const uint32_t slen = sf[2] | (uint32_t)sf[3] << 8;
+        if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && q + 6 <= xlen) {
+            bsize = sf[4] | (uint32_t)sf[5] << 8;
+            found = true;
+        }
+        q += 4 + slen;
+    }
+    if (!found) return -1;
+    total = bsize + 1;
+    if (total < 12 + xlen + 8) return -1;
+    if (n < total) return 0;
+    d_off = 12 + xlen;
+    d_len = total - d_off - 8;
+    memcpy(&crc, p + total - 8, 4);
+    memcpy(&isize, p + total - 4, 4);
+    if (isize > 65536) return -1;
+    return 1;
+}
+}  // namespace
+
+int vgmi_fastq_commit_bgzf(vgmi_fastq* f, size_t n_bytes, size_t* taken, size_t* n_text, int* not_bgzf)
+{
+    if (!f || !taken) return VGMI_E_INVALID;
+    vgmi_ctx* c = f->c;
+    *taken = 0;
+    if (n_text) *n_text = 0;
+    if (not_bgzf) *not_bgzf = 0;
+    if (f->acquired < 0) return fail(c, VGMI_E_STATE, "no buffer acquired");
+    if (n_bytes > f->cap) return fail(c, VGMI_E_INVALID, "more bytes than the buffer holds");
+    const int i = f->acquired;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!f->d_comp) {
+        f->max_members = (uint32_t)(f->cap / 4096) + 1024;     // bgzip members compress 64 KiB each; tiny ones are rare
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_comp), f->cap + 64);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_members), (size_t)f->max_members * sizeof(BgzfMember));
+        for (int b = 0; b < 2 && e == hipSuccess; ++b)
+            e = hipHostMalloc(reinterpret_cast<void**>(&f->h_members[b]), (size_t)f->max_members * sizeof(BgzfMember), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_status), (size_t)f->max_members * 4);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_crc), 1024);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_verdict), sizeof(BgzfVerdict));
+        if (e == hipSuccess) {
+            uint32_t tab[256];
+            for (uint32_t n = 0; n < 256; ++n) {
+                uint32_t v = n;
+                for (int k = 0; k < 8; ++k) v = (v & 1u) ? 0xEDB88320u ^ (v >> 1) : v >> 1;
+                tab[n] = v;
+            }
+            e = hipMemcpy(f->d_crc, tab, sizeof tab, hipMemcpyHostToDevice);
+        }
+        if (e == hipSuccess) {
+            const BgzfVerdict v{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
+            e = hipMemcpy(f->d_verdict, &v, sizeof v, hipMemcpyHostToDevice);
+        }
+        HIPCHK(c, e);
+    }
+    // walk the member headers of the staged bytes: whole members whose text fits one chunk
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(f->h_stage[i]);
+    BgzfMember* tab = f->h_members[i];
+    uint32_t n_mem = 0, text = 0;
+    size_t pos = 0;
+    int stop = 0;
+    while (pos < n_bytes && n_mem < f->max_members) {
+        uint32_t total, d_off, d_len, crc, isize;
+        const int r = bgzf_member(p + pos, n_bytes - pos, total, d_off, d_len, crc, isize);
+        if (r <= 0) { stop = r; break; }
+        if ((size_t)text + isize > f->cap) break;
+        tab[n_mem] = BgzfMember{(uint32_t)(pos + d_off), d_len, text, isize, crc, 0u};
+        f->member_size.push_back(total);
+        ++n_mem;
+        text += isize;
+        pos += total;
+    }
+    if (stop < 0 && not_bgzf) *not_bgzf = 1;
+    f->acquired = -1;
+    *taken = pos;
+    if (n_text) *n_text = text;
+    if (n_mem == 0) return VGMI_OK;   // nothing whole yet (or not block gzip): the staging buffer stays with the caller
+    f->batch_members.push_back(n_mem);
+    HIPCHK(c, hipMemcpyAsync(f->d_comp, f->h_stage[i], pos, hipMemcpyHostToDevice, f->stream));
+    HIPCHK(c, hipMemcpyAsync(f->d_members, tab, (size_t)n_mem * sizeof(BgzfMember), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(c, hipEventRecord(f->h_done[i], f->stream));
+    f->h_busy[i] = true;
+    HIPCHK(c, launch_bgzf_inflate(f->d_comp, f->d_members, n_mem, f->d_raw[i] + f->tail_max, f->d_status, f->d_crc, f->d_verdict, f->stream));
+    FqBuffers b{};
+    b.raw = f->d_raw[i];
+    b.raw_next = f->d_raw[i ^ 1];
+    b.packed = f->d_packed;
+    b.tile = f->d_tile;
+    b.nlpos = f->d_nlpos;
+    b.rec_bytes = f->d_rec;
+    b.out_off = f->d_off;
+    b.block_sum = f->d_bsum;
+    b.state = f->d_state;
+    b.cap_lines = f->cap_lines;
+    b.tail_max = f->tail_max;
+    if (text) {
+        HIPCHK(c, launch_fastq_chunk(b, text, f->stream, &f->d_verdict->good_bytes));
+        int rc = launch_count(c, reinterpret_cast<const char*>(f->d_packed), f->tail_max + (size_t)text, nullptr, 0, f->stream,
+                              &f->d_state->packed_bytes);
+        if (rc) return rc;
+    }
+    f->next = i ^ 1;
+    return VGMI_OK;
+}
+
+int vgmi_fastq_bgzf_status(vgmi_fastq* f, int* failed, uint64_t* good_compressed_bytes, uint32_t* reason)
+{
+    if (!f || !failed) return VGMI_E_INVALID;
+    vgmi_ctx* c = f->c;
+    *failed = 0;
+    if (good_compressed_bytes) *good_compressed_bytes = 0;
+    if (!f->d_verdict) return VGMI_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(f->stream));
+    BgzfVerdict v;
+    HIPCHK(c, hipMemcpy(&v, f->d_verdict, sizeof v, hipMemcpyDeviceToHost));
+    uint64_t bytes = 0;
+    size_t mi = 0;
+    if (v.first_bad_batch == 0xFFFFFFFFu) {
+        for (uint64_t sz : f->member_size) bytes += sz;
+    } else {
+        *failed = 1;
+        if (reason) *reason = v.reason;
+        for (uint32_t b = 0; b < v.first_bad_batch && b < f->batch_members.size(); ++b)
+            for (uint32_t k = 0; k < f->batch_members[b]; ++k) bytes += f->member_size[mi++];
+        for (uint32_t k = 0; k < v.first_bad_member && mi < f->member_size.size(); ++k) bytes += f->member_size[mi++];
+    }
+    if (good_compressed_bytes) *good_compressed_bytes = bytes;
     return VGMI_OK;
 }
 

@@ -257,7 +257,12 @@ VG_HD uint64_t vg_thash_local(uint64_t canon, uint64_t rc, uint32_t bucket_log2,
     uint32_t b = best * 0x85EBCA77u;
     b ^= b >> 13;
     const uint32_t sub = (uint32_t)canon * 0x9E3779B1u + (uint32_t)(canon >> 32) * 0x85EBCA77u;
-    if (by_offset && bucket_log2 >= 5) return ((uint64_t)b << bucket_log2) | ((2u * best_o + (sub >> 31)) & ((1u << bucket_log2) - 1u));
+    // 16 offset places per bucket (12 used), each 1 << (bucket_log2 - 4) slots wide: the k-mers that share minimiser AND
+    // offset (the alleles of one site, combinations with a neighbouring site) spread over them by hash
+    if (by_offset && bucket_log2 >= 5) {
+        const uint32_t w = bucket_log2 - 4;
+        return ((uint64_t)b << bucket_log2) | (best_o << w) | (sub >> (32 - w));
+    }
     return ((uint64_t)b << bucket_log2) | (sub >> (32 - bucket_log2));
 }
 

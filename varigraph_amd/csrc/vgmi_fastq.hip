@@ -94,9 +94,21 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* sh, ui
 }
 
 // K1: newlines per tile; '\r' / NUL bytes anywhere in the chunk make it dirty
-__global__ __launch_bounds__(256) void fq_count_kernel(const uint8_t* raw, FqState* st, uint32_t end, uint32_t* tile_nl)
+// chunk end: host value, or cut on the device (block-gzip batch with a member that did not inflate)
+__device__ __forceinline__ uint32_t fq_end(uint32_t tail_max, uint32_t n_new, const uint32_t* n_new_dev)
+{
+    if (n_new_dev) {
+        const uint32_t d = *n_new_dev;
+        n_new = d < n_new ? d : n_new;
+    }
+    return tail_max + n_new;
+}
+
+__global__ __launch_bounds__(256) void fq_count_kernel(const uint8_t* raw, FqState* st, uint32_t tail_max, uint32_t n_new,
+                                                       const uint32_t* n_new_dev, uint32_t* tile_nl)
 {
     __shared__ uint32_t sh[4];
+    const uint32_t end = fq_end(tail_max, n_new, n_new_dev);
     const uint32_t start = st->start, off = blockIdx.x * FQ_TILE + threadIdx.x * 16u;
     uint32_t n = 0, bad = 0;
     if (!st->stopped && off < end && off + 16 > start) {
@@ -129,10 +141,12 @@ __global__ __launch_bounds__(1024) void fq_scan_small_kernel(uint32_t* v, uint32
 }
 
 // K3: positions of the newlines, in order
-__global__ __launch_bounds__(256) void fq_nlpos_kernel(const uint8_t* raw, FqState* st, uint32_t end, const uint32_t* tile_base,
-                                                       uint32_t* nlpos, uint32_t cap_lines)
+__global__ __launch_bounds__(256) void fq_nlpos_kernel(const uint8_t* raw, FqState* st, uint32_t tail_max, uint32_t n_new,
+                                                       const uint32_t* n_new_dev, const uint32_t* tile_base, uint32_t* nlpos,
+                                                       uint32_t cap_lines)
 {
     __shared__ uint32_t sh[4];
+    const uint32_t end = fq_end(tail_max, n_new, n_new_dev);
     if (st->stopped || st->dirty || st->n_lines > cap_lines) return;
     const uint32_t start = st->start, off = blockIdx.x * FQ_TILE + threadIdx.x * 16u;
     uint32_t m = 0;
@@ -182,10 +196,11 @@ __global__ __launch_bounds__(1024) void fq_scan_blocks_kernel(const uint32_t* v,
 }
 
 // K7: chunk bookkeeping (one thread) -- runs BEFORE the copy so that fq_pack only touches accepted records
-__global__ void fq_finish_kernel(FqState* st, const uint32_t* nlpos, const uint32_t* rec_bytes, const uint32_t* out_off, uint32_t end,
-                                 uint32_t cap_lines, uint32_t tail_max)
+__global__ void fq_finish_kernel(FqState* st, const uint32_t* nlpos, const uint32_t* rec_bytes, const uint32_t* out_off, uint32_t n_new,
+                                 const uint32_t* n_new_dev, uint32_t cap_lines, uint32_t tail_max)
 {
     if (threadIdx.x || blockIdx.x) return;
+    const uint32_t end = fq_end(tail_max, n_new, n_new_dev);
     uint32_t good = 0, consumed_end = st->start, packed = 0;
     if (!st->stopped) {
         if (st->dirty || st->n_lines > cap_lines) {
@@ -257,20 +272,20 @@ hipError_t launch_fastq_init(FqState* st, uint32_t tail_max, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_fastq_chunk(const FqBuffers& b, uint32_t n_new, hipStream_t s)
+hipError_t launch_fastq_chunk(const FqBuffers& b, uint32_t n_new, hipStream_t s, const uint32_t* n_new_dev)
 {
     const uint32_t end = b.tail_max + n_new;
     const uint32_t n_tiles = (end + FQ_TILE - 1) / FQ_TILE;
     const uint32_t cap_rec = b.cap_lines / 4;
     const uint32_t n_rblk = (cap_rec + 1023u) / 1024u;
-    hipLaunchKernelGGL(fq_count_kernel, dim3(n_tiles), dim3(256), 0, s, b.raw, b.state, end, b.tile);
+    hipLaunchKernelGGL(fq_count_kernel, dim3(n_tiles), dim3(256), 0, s, b.raw, b.state, b.tail_max, n_new, n_new_dev, b.tile);
     hipLaunchKernelGGL(fq_scan_small_kernel, dim3(1), dim3(1024), 0, s, b.tile, n_tiles, &b.state->n_lines);
-    hipLaunchKernelGGL(fq_nlpos_kernel, dim3(n_tiles), dim3(256), 0, s, b.raw, b.state, end, b.tile, b.nlpos, b.cap_lines);
+    hipLaunchKernelGGL(fq_nlpos_kernel, dim3(n_tiles), dim3(256), 0, s, b.raw, b.state, b.tail_max, n_new, n_new_dev, b.tile, b.nlpos, b.cap_lines);
     hipLaunchKernelGGL(fq_records_kernel, dim3((cap_rec + 255u) / 256u), dim3(256), 0, s, b.raw, b.state, b.nlpos, b.rec_bytes, b.cap_lines);
     hipLaunchKernelGGL(fq_scan_blocks_kernel, dim3(n_rblk), dim3(1024), 0, s, b.rec_bytes, b.state, b.block_sum, b.out_off, 0, b.cap_lines);
     hipLaunchKernelGGL(fq_scan_small_kernel, dim3(1), dim3(1024), 0, s, b.block_sum, n_rblk, (uint32_t*)nullptr);
     hipLaunchKernelGGL(fq_scan_blocks_kernel, dim3(n_rblk), dim3(1024), 0, s, b.rec_bytes, b.state, b.block_sum, b.out_off, 1, b.cap_lines);
-    hipLaunchKernelGGL(fq_finish_kernel, dim3(1), dim3(1), 0, s, b.state, b.nlpos, b.rec_bytes, b.out_off, end, b.cap_lines, b.tail_max);
+    hipLaunchKernelGGL(fq_finish_kernel, dim3(1), dim3(1), 0, s, b.state, b.nlpos, b.rec_bytes, b.out_off, n_new, n_new_dev, b.cap_lines, b.tail_max);
     hipLaunchKernelGGL(fq_pack_kernel, dim3(2048), dim3(256), 0, s, b.raw, b.state, b.nlpos, b.out_off, b.packed);
     hipLaunchKernelGGL(fq_carry_kernel, dim3(1), dim3(256), 0, s, b.raw, b.raw_next, b.state, b.tail_max);
     return hipGetLastError();

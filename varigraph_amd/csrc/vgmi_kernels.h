@@ -87,7 +87,23 @@ struct FqBuffers {
     uint32_t cap_lines, tail_max;
 };
 hipError_t launch_fastq_init(FqState* st, uint32_t tail_max, hipStream_t s);
-hipError_t launch_fastq_chunk(const FqBuffers& b, uint32_t n_new, hipStream_t s);
+// n_new_dev (may be null): the chunk is cut to min(n_new, *n_new_dev) bytes on the device (text in front of a block-gzip
+// member that did not inflate)
+hipError_t launch_fastq_chunk(const FqBuffers& b, uint32_t n_new, hipStream_t s, const uint32_t* n_new_dev = nullptr);
+
+// block-gzip members inflated on the device (vgmi_inflate.hip)
+struct BgzfMember {
+    uint32_t c_off, c_len;   // DEFLATE bytes of the member inside the compressed batch
+    uint32_t u_off, u_len;   // where its text goes inside the chunk, ISIZE
+    uint32_t crc, pad;       // CRC-32 from the trailer
+};
+struct BgzfVerdict {         // device-resident, per stream
+    uint32_t first_bad_batch, first_bad_member, reason;   // 0xFFFFFFFF while every member has inflated and checked
+    uint32_t good_bytes;     // of the batch just inflated: text in front of the first bad member
+    uint32_t batches;
+};
+hipError_t launch_bgzf_inflate(const uint8_t* comp, const BgzfMember* members, uint32_t n_members, uint8_t* out_base, uint32_t* status,
+                               const uint32_t* crc_table, BgzfVerdict* verdict, hipStream_t s);
 
 hipError_t launch_count27(bool lds_bitmap, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);

@@ -56,6 +56,8 @@ def load_library():
         "vgmi_fastq_open": (i32, [vp, C.POINTER(vp)]),
         "vgmi_fastq_acquire": (i32, [vp, C.POINTER(vp), C.POINTER(sz)]),
         "vgmi_fastq_commit": (i32, [vp, sz]),
+        "vgmi_fastq_commit_bgzf": (i32, [vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(i32)]),
+        "vgmi_fastq_bgzf_status": (i32, [vp, C.POINTER(i32), C.POINTER(u64), C.POINTER(u32)]),
         "vgmi_fastq_close": (i32, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(i32), vp, sz, C.POINTER(sz)]),
         "vgmi_sketch_keys": (i32, [vp, vp, sz, vp, sz, u32, vp]),
         "vgmi_bloom_params": (i32, [u64, C.c_double, C.POINTER(u64), C.POINTER(u32)]),
@@ -279,6 +281,39 @@ class Context:
         self._chk(rc)
         return {"n_records": nr.value, "n_bases": nb.value, "consumed": cons.value, "stopped": bool(st.value),
                 "tail": tail.raw[:tl.value]}
+
+    def fastq_bgzf(self, comp, piece=None):
+        """Block-gzip bytes through the device inflate + parser.  Returns the dict of fastq_text plus inflate_failed,
+        good_compressed_bytes, taken (compressed bytes handed over as whole members)."""
+        fq = C.c_void_p()
+        self._chk(self._l.vgmi_fastq_open(self._h, C.byref(fq)))
+        comp = bytes(comp)
+        pos, carry, total_taken = 0, b"", 0
+        failed, good, reason = C.c_int(), C.c_uint64(), C.c_uint32()
+        try:
+            while True:
+                buf, cap = C.c_void_p(), C.c_size_t()
+                self._chk(self._l.vgmi_fastq_acquire(fq, C.byref(buf), C.byref(cap)))
+                room = (cap.value if piece is None else min(piece, cap.value)) - len(carry)
+                new = comp[pos:pos + max(room, 0)]
+                pos += len(new)
+                data = carry + new
+                C.memmove(buf, data, len(data))
+                taken, n_text, nb = C.c_size_t(), C.c_size_t(), C.c_int()
+                self._chk(self._l.vgmi_fastq_commit_bgzf(fq, len(data), C.byref(taken), C.byref(n_text), C.byref(nb)))
+                total_taken += taken.value
+                carry = data[taken.value:]
+                if nb.value or (pos >= len(comp) and (taken.value == 0 or not carry)):
+                    break
+            self._chk(self._l.vgmi_fastq_bgzf_status(fq, C.byref(failed), C.byref(good), C.byref(reason)))
+        finally:
+            nr, nbs, cons, st, tl = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int(), C.c_size_t()
+            tail = C.create_string_buffer(1 << 20)
+            rc = self._l.vgmi_fastq_close(fq, C.byref(nr), C.byref(nbs), C.byref(cons), C.byref(st), tail, 1 << 20, C.byref(tl))
+        self._chk(rc)
+        return {"n_records": nr.value, "n_bases": nbs.value, "consumed": cons.value, "stopped": bool(st.value),
+                "tail": tail.raw[:tl.value], "inflate_failed": bool(failed.value), "good_compressed_bytes": good.value,
+                "reason": reason.value, "taken": total_taken}
 
     def sketch_keys(self, block, n_reads, k, read_off=None):
         block = np.ascontiguousarray(block, dtype=np.uint8)
