@@ -24,18 +24,25 @@ namespace vgk {
 #define INF_LIT_BITS 10u
 #define INF_DIST_BITS 8u
 #define INF_MAXBITS 15
+#define INF_RING 2048u
 
 struct InfTables {                 // per wavefront, in LDS
+    uint32_t multi[1u << INF_LIT_BITS];   // up to three LITERALS decoded from the same index: bytes 0..2 | count << 24 | bits << 26
     uint16_t lit[1u << INF_LIT_BITS];     // entry: symbol << 4 | code length (0 = code longer than INF_LIT_BITS or unused)
     uint16_t dist[1u << INF_DIST_BITS];
     uint8_t len[320];              // code lengths: 0..287 literal/length, 288..319 distance
     uint16_t sorted[320];          // symbols ordered by code (canonical decoding of the long codes)
     uint16_t count[2][INF_MAXBITS + 1];
     uint16_t offs[2][INF_MAXBITS + 1];
-    uint32_t crc_part[64];
+    uint8_t ring[INF_RING];        // the last INF_RING output bytes: LZ77 sources come from here, not from global memory --
+                                   // a global read-back would wait (vmcnt) for every store still in flight
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return (uint64_t)uni((uint32_t)(v >> 32)) << 32 | uni((uint32_t)v); }
+// a load every lane issues at the same address, its value handed to the scalar side
+__device__ __forceinline__ uint64_t ld64u(const uint64_t* p) { return uni64(*p); }
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t code, uint32_t len) { return __builtin_bitreverse32(code) >> (32 - len); }
 
@@ -101,16 +108,36 @@ __device__ bool inf_build(InfTables& t, uint32_t which, uint32_t first, uint32_t
     return true;
 }
 
+// Sequence lines are runs of literals with 2-3 bit codes: one lookup yields as many literals as the index holds whole
+// codes of (at most three).  Built from the single-symbol table: entry i = the literals coded by the low bits of i.
+__device__ void inf_build_multi(InfTables& t, uint32_t lane)
+{
+    for (uint32_t i = lane; i < (1u << INF_LIT_BITS); i += 64) {
+        uint32_t pos = 0, n = 0, bytes = 0;
+        while (n < 3) {
+            const uint32_t e = t.lit[i >> pos];          // the bits above the index are unknown: only codes that fit count
+            const uint32_t l = e & 15u, sym = e >> 4;
+            if (!l || l > INF_LIT_BITS - pos || sym >= 256) break;
+            bytes |= sym << (8 * n);
+            ++n;
+            pos += l;
+        }
+        t.multi[i] = bytes | n << 24 | pos << 26;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // a code longer than the fast table: canonical decoding bit by bit (RFC 1951 3.2.2; rare by construction)
 __device__ __forceinline__ int32_t inf_slow(const InfTables& t, uint32_t which, uint64_t bitbuf, uint32_t& len_out)
 {
     uint32_t code = 0, first = 0, index = 0;
     for (uint32_t l = 1; l <= INF_MAXBITS; ++l) {
         code |= (uint32_t)(bitbuf >> (l - 1)) & 1u;
-        const uint32_t cnt = t.count[which][l];
+        const uint32_t cnt = uni(t.count[which][l]);
         if (code < first + cnt) {
             len_out = l;
-            return t.sorted[which * 288 + index + (code - first)];
+            return (int32_t)uni(t.sorted[which * 288 + index + (code - first)]);
         }
         index += cnt;
         first = (first + cnt) << 1;
@@ -119,10 +146,6 @@ __device__ __forceinline__ int32_t inf_slow(const InfTables& t, uint32_t which, 
     return -1;
 }
 
-__device__ __constant__ uint16_t inf_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__device__ __constant__ uint8_t inf_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__device__ __constant__ uint16_t inf_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__device__ __constant__ uint8_t inf_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __device__ __constant__ uint8_t inf_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // ---- CRC-32 (gzip polynomial, reflected) ---------------------------------------------------------------------------
@@ -150,8 +173,9 @@ __device__ __forceinline__ uint32_t gf2_x8n(uint32_t n)
 
 // One member per wavefront.  status[m]: 0 = good, else the reason (1 code lengths, 2 bad symbol / distance, 3 output or
 // input overrun, 4 length != ISIZE, 5 CRC-32, 6 stored-block header, 7 reserved block type).
-__global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* comp, const BgzfMember* members, uint32_t n_members, uint8_t* out_base,
-                                                           uint32_t* status, const uint32_t* crc_table)
+__global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const BgzfMember* __restrict__ members, uint32_t n_members,
+                                                           uint8_t* __restrict__ out_base, uint32_t* __restrict__ status,
+                                                           const uint32_t* __restrict__ crc_table)
 {
     __shared__ InfTables tabs[4];
     __shared__ uint32_t s_crc[256];
@@ -162,29 +186,42 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* comp, 
     const uint32_t m = blockIdx.x * 4u + wave_in_block;
     if (m >= n_members) return;
     InfTables& t = tabs[wave_in_block];
-    const BgzfMember mem = members[m];
-    const uint8_t* in = comp + mem.c_off;
-    const uint32_t in_len = mem.c_len;       // deflate bytes (header and trailer stripped by the host walk)
-    uint8_t* out = out_base + mem.u_off;
-    const uint32_t out_len = mem.u_len;      // ISIZE
+    const uint8_t* in = comp + uni(members[m].c_off);
+    const uint32_t in_len = uni(members[m].c_len);       // deflate bytes (header and trailer stripped by the host walk)
+    uint8_t* out = out_base + uni(members[m].u_off);
+    const uint32_t out_len = uni(members[m].u_len);      // ISIZE
+    const uint32_t want_crc = uni(members[m].crc);
 
     // ---- wave-uniform decoder state ----
     uint64_t bitbuf = 0;
     uint32_t bitcnt = 0, ip = 0, op = 0, err = 0;
-    // the input is padded by the host (>= 8 readable bytes behind every member); bytes past in_len are never consumed
-    // unless the stream is damaged, which the position check below reports
+    // Input window: three aligned 8-byte words (cur holds the byte at in + ip), fetched with scalar loads two words ahead
+    // of use, so a refill never waits for memory.  The host pads every batch (>= 32 readable bytes behind the last member);
+    // bytes past in_len are only consumed by a damaged stream, which the position check reports.
+    const uint64_t* win = reinterpret_cast<const uint64_t*>((uint64_t)in & ~7ULL);
+    uint64_t cur = ld64u(win), n1 = ld64u(win + 1), n2 = ld64u(win + 2);
     auto refill = [&]() {
-        // 8 bytes at any alignment, assembled from two aligned 8-byte loads (all lanes the same address: one request)
-        const uint64_t a = (uint64_t)(in + ip);
-        const uint64_t* p8 = reinterpret_cast<const uint64_t*>(a & ~7ULL);
-        const uint32_t sh = (uint32_t)(a & 7u) * 8u;
-        const uint64_t lo = p8[0], hi = p8[1];
-        uint64_t w = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
-        w = ((uint64_t)uni((uint32_t)(w >> 32)) << 32) | uni((uint32_t)w);
+        const uint32_t sh = (uint32_t)((uint64_t)(in + ip) & 7u) * 8u;
+        const uint64_t w = sh ? (cur >> sh) | (n1 << (64 - sh)) : cur;
         bitbuf |= w << bitcnt;
         const uint32_t adv = (63u - bitcnt) >> 3;
+        const uint32_t before = (uint32_t)((uint64_t)(in + ip) >> 3);
         ip += adv;
         bitcnt += adv * 8u;
+        if ((uint32_t)((uint64_t)(in + ip) >> 3) != before) {   // at most one word further (adv <= 7)
+            ++win;
+            cur = n1;
+            n1 = n2;
+            n2 = ld64u(win + 2);
+        }
+    };
+    auto need = [&](uint32_t n) { if (bitcnt < n) refill(); };
+    // after a jump of the input position (stored block)
+    auto reload = [&]() {
+        win = reinterpret_cast<const uint64_t*>((uint64_t)(in + ip) & ~7ULL);
+        cur = ld64u(win);
+        n1 = ld64u(win + 1);
+        n2 = ld64u(win + 2);
     };
     auto take = [&](uint32_t n) -> uint32_t {
         const uint32_t v = (uint32_t)bitbuf & ((1u << n) - 1u);
@@ -206,11 +243,18 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* comp, 
             // the bytes still in the bit buffer come first
             const uint32_t src = ip - (bitcnt >> 3);
             if (src + len > in_len || op + len > out_len) { err = 3; break; }
-            for (uint32_t i = lane; i < len; i += 64) out[op + i] = in[src + i];
+            for (uint32_t i = lane; i < len; i += 64) {
+                const uint8_t b = in[src + i];
+                out[op + i] = b;
+                t.ring[(op + i) & (INF_RING - 1u)] = b;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
             op += len;
             ip = src + len;
             bitbuf = 0;
             bitcnt = 0;
+            reload();
             continue;
         }
         if (type == 3) { err = 7; break; }
@@ -220,6 +264,7 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* comp, 
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (!inf_build(t, 0, 0, 288, lane) || !inf_build(t, 1, 288, 30, lane)) { err = 1; break; }
+            inf_build_multi(t, lane);
         } else {                    // dynamic codes: the code lengths are themselves Huffman coded
             const uint32_t hlit = take(5) + 257, hdist = take(5) + 1, hclen = take(4) + 4;
             if (hlit > 286 || hdist > 30) { err = 1; break; }
@@ -231,14 +276,14 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* comp, 
             for (uint32_t i = 0; i < hclen; ++i) {
                 if (bitcnt < 3) refill();
                 const uint32_t v = take(3);
-                if (lane == 0) t.len[288 + inf_clen_order[i]] = (uint8_t)v;
+                if (lane == 0) t.len[288 + uni(inf_clen_order[i])] = (uint8_t)v;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (!inf_build(t, 1, 288, 19, lane)) { err = 1; break; }
             // the hlit + hdist lengths, written to a staging area first (the code-length code occupies len[288..306])
             uint32_t idx = 0, prev = 0;
-            uint8_t* const stage = reinterpret_cast<uint8_t*>(t.crc_part);   // 256 bytes; continued in sorted[] (unused until the next build)
+            uint8_t* const stage = reinterpret_cast<uint8_t*>(t.multi);      // rebuilt below; 256 bytes, continued in sorted[] (unused until the next build)
             uint8_t* const stage2 = reinterpret_cast<uint8_t*>(t.sorted);
             auto put = [&](uint32_t i, uint32_t v) {
                 if (lane == 0) {
@@ -291,12 +336,28 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* comp, 
             for (uint32_t q = 0; q < 5; ++q) t.len[lane + 64 * q] = mine[q];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (t.len[256] == 0) { err = 1; break; }    // no end-of-block code
+            if (uni(t.len[256]) == 0) { err = 1; break; }    // no end-of-block code
             if (!inf_build(t, 0, 0, 288, lane) || !inf_build(t, 1, 288, 30, lane)) { err = 1; break; }
+            inf_build_multi(t, lane);
         }
         // ---- symbols of this block ----
         for (;;) {
-            refill();
+            need(32);     // a literal/length code (<= 15 bits) and its extra bits (<= 5)
+            {   // literals first: up to three per lookup, one byte per lane
+                const uint32_t mm = uni(t.multi[(uint32_t)bitbuf & ((1u << INF_LIT_BITS) - 1u)]);
+                const uint32_t n = (mm >> 24) & 3u;
+                if (n) {
+                    if (op + n > out_len) { err = 3; break; }
+                    if (lane < n) {
+                        const uint8_t b = (uint8_t)(mm >> (8 * lane));
+                        out[op + lane] = b;
+                        t.ring[(op + lane) & (INF_RING - 1u)] = b;
+                    }
+                    op += n;
+                    take(mm >> 26);
+                    continue;
+                }
+            }
             uint32_t e = uni(t.lit[(uint32_t)bitbuf & ((1u << INF_LIT_BITS) - 1u)]);
             uint32_t l = e & 15u;
             int32_t sym = (int32_t)(e >> 4);
@@ -309,15 +370,25 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* comp, 
             take(l);
             if (sym < 256) {
                 if (op >= out_len) { err = 3; break; }
-                if (lane == 0) out[op] = (uint8_t)sym;
+                if (lane == 0) {
+                    out[op] = (uint8_t)sym;
+                    t.ring[op & (INF_RING - 1u)] = (uint8_t)sym;
+                }
                 ++op;
                 continue;
             }
             if (sym == 256) break;
             sym -= 257;
             if (sym >= 29) { err = 2; break; }
-            const uint32_t len = inf_len_base[sym] + take(inf_len_extra[sym]);
-            refill();
+            // length codes 257..285 (RFC 1951 3.2.5) in closed form: no table fetch on the serial path
+            uint32_t len;
+            if (sym < 8) len = 3 + (uint32_t)sym;
+            else if (sym == 28) len = 258;
+            else {
+                const uint32_t e = ((uint32_t)sym >> 2) - 1;
+                len = ((4u + ((uint32_t)sym & 3u)) << e) + 3u + take(e);
+            }
+            need(32);     // a distance code (<= 15 bits) and its extra bits (<= 13)
             uint32_t de = uni(t.dist[(uint32_t)bitbuf & ((1u << INF_DIST_BITS) - 1u)]);
             uint32_t dl = de & 15u;
             int32_t dsym = (int32_t)(de >> 4);
@@ -329,16 +400,38 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* comp, 
             }
             take(dl);
             if (dsym >= 30) { err = 2; break; }
-            const uint32_t dist = inf_dist_base[dsym] + take(inf_dist_extra[dsym]);
+            uint32_t dist;
+            if (dsym < 4) dist = 1 + (uint32_t)dsym;
+            else {
+                const uint32_t e = ((uint32_t)dsym >> 1) - 1;
+                dist = ((2u + ((uint32_t)dsym & 1u)) << e) + 1u + take(e);
+            }
             if (dist > op) { err = 2; break; }
             if (op + len > out_len) { err = 3; break; }
-            // the literals written by lane 0 and earlier copies must be visible to every lane's loads
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const uint8_t* const src = out + op - dist;
-            for (uint32_t i = lane; i < len; i += 64) out[op + i] = src[dist >= len ? i : i % dist];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            if (dist <= INF_RING - 258u) {
+                // sources from the LDS ring (the LDS pipe is in order per wavefront: earlier ring writes of any lane are seen)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t i = lane; i < len; i += 64) {
+                    const uint8_t b = t.ring[(op - dist + (dist >= len ? i : i % dist)) & (INF_RING - 1u)];
+                    out[op + i] = b;
+                    t.ring[(op + i) & (INF_RING - 1u)] = b;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                // far match: read the output back; every earlier store of the wave must have landed
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint8_t* const src = out + op - dist;
+                for (uint32_t i = lane; i < len; i += 64) {
+                    const uint8_t b = src[dist >= len ? i : i % dist];
+                    out[op + i] = b;
+                    t.ring[(op + i) & (INF_RING - 1u)] = b;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
             op += len;
         }
         if (ip - (bitcnt >> 3) > in_len) err = 3;   // the block ran past the member's deflate bytes
@@ -353,19 +446,19 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* comp, 
         const uint32_t e = b + slice < out_len ? b + slice : out_len;
         uint32_t c = 0xFFFFFFFFu;
         for (uint32_t i = b; i < e; ++i) c = s_crc[(c ^ out[i]) & 0xFFu] ^ (c >> 8);
-        t.crc_part[lane] = ~c;
+        t.multi[lane] = ~c;      // (the decode tables are no longer needed)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
             const uint32_t x_full = gf2_x8n(slice);
-            uint32_t crc = t.crc_part[0];
+            uint32_t crc = t.multi[0];
             for (uint32_t i = 1; i < 64; ++i) {
                 const uint32_t bi = i * slice;
                 if (bi >= out_len) break;
                 const uint32_t li = bi + slice <= out_len ? slice : out_len - bi;
-                crc = gf2_mul(li == slice ? x_full : gf2_x8n(li), crc) ^ t.crc_part[i];
+                crc = gf2_mul(li == slice ? x_full : gf2_x8n(li), crc) ^ t.multi[i];
             }
-            if (crc != mem.crc) err = 5;
+            if (crc != want_crc) err = 5;
         }
         err = uni(err);
     }
