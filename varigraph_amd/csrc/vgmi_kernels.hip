@@ -947,10 +947,31 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
 // k, where palindromic k-mers and stale registers make emission history-dependent
 // (src/kmer.cpp:134 `continue` before ++l; :145 only l is reset).
 // ------------------------------------------------------------------------------------------
+#define VG_SEQ_LDS 16384u   // bytes of read text a wavefront stages (64 reads of up to ~250 bases)
 template <int MODE>
 __global__ __launch_bounds__(256) void seq_kernel(RowParams p, const uint64_t* read_off, uint64_t n_reads)
 {
+    // The 64 reads of a wavefront are one contiguous stretch of the block: it is copied into LDS with coalesced 16-byte
+    // loads and every lane walks ITS read there (a lane per read straight from global memory touches 64 different
+    // lines per step and thrashes the 32 KiB L1).  Stretches longer than the staging area are read in place.
+    __shared__ __attribute__((aligned(16))) uint8_t s_text[4][VG_SEQ_LDS];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t r_first = r - lane;
+    bool staged = false;
+    uint64_t stage_base = 0;
+    if (r_first < n_reads) {
+        const uint64_t r_last = r_first + 64 < n_reads ? r_first + 64 : n_reads;
+        const uint64_t b = read_off[r_first] & ~15ULL, e = read_off[r_last];
+        if (e - b <= VG_SEQ_LDS && e <= ((p.n_bytes + 15) & ~15ULL)) {
+            for (uint64_t o = b + lane * 16u; o < e; o += 1024)
+                *reinterpret_cast<uint4*>(&s_text[wave][o - b]) = load_chunk(p.bases, p.n_bytes, o);
+            staged = true;
+            stage_base = b;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if (r >= n_reads) return;
     const uint64_t s = read_off[r];
     const uint64_t e = read_off[r + 1] - (MODE == MODE_BLOOM ? 0 : 1);  // reads end with '\n'; a Bloom sequence does not
@@ -963,7 +984,7 @@ __global__ __launch_bounds__(256) void seq_kernel(RowParams p, const uint64_t* r
     uint64_t fwd = 0, rc = 0;
     uint32_t l = 0;
     for (uint64_t i = s; i < e; ++i) {
-        const uint32_t c = vg_nt4(p.bases[i]);
+        const uint32_t c = vg_nt4(staged ? s_text[wave][i - stage_base] : p.bases[i]);
         uint64_t out = ~0ULL;
         if (c < 4) {
             fwd = (fwd << 2 | c) & mask;
