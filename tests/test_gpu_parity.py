@@ -440,6 +440,43 @@ def test_saturation_flags_cleared_by_reset(ctx):
             assert cov.max() < 255 and cov.sum() > 0
 
 
+def test_saturation_flags_do_not_travel_with_the_table_image(ctx):
+    """The slot array is part of the table image: an image exported (or cloned) after a deep sample carries that sample's
+    saturation flags, which the importer has no list of -- its first reset must sweep them away, or hits on those
+    k-mers would skip their atomics for good."""
+    import torch
+    k = 27
+    rng = np.random.default_rng(78)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genome = acgt[rng.integers(0, 4, size=2000)]
+    keys = np.unique(o.sketch(genome.tobytes(), k))
+    r = np.random.default_rng(3)
+    deep = block_from_seqs([genome[s:s + 150].tobytes() for s in r.integers(0, genome.size - 150, size=20000)])
+    shallow = block_from_seqs([genome[s:s + 150].tobytes() for s in r.integers(0, genome.size - 150, size=300)])
+    ctx.table_upload(keys, k)
+    ctx.counts_reset()
+    ctx.reads_submit(deep, 20000)
+    cov, _, _ = ctx.counts_finish()
+    assert (cov == 255).mean() > 0.9
+    img = torch.empty(ctx.table_image_bytes(), dtype=torch.uint8, device="cuda")
+    ctx.table_export(img)
+    t = o.Table(keys)
+    t.count_block(shallow, k)
+    for how in ("import", "clone"):
+        other = vgmi.Context(0, buffer_mib=16)
+        try:
+            if how == "import":
+                other.table_import(img)
+            else:
+                other.table_clone_from(ctx)
+            other.counts_reset()
+            other.reads_submit(shallow, 300)
+            got, _, _ = other.counts_finish()
+        finally:
+            other.close()
+        assert np.array_equal(got, t.counts()), how
+
+
 # ----------------------------------------------------------------------------- large graphs (global grid bitmap)
 @pytest.mark.parametrize("k,placement", [(27, None), (25, None), (27, {"VGMI_LOCALITY": "0"}), (27, {"VGMI_LOCALITY": "3"}),
                                          (27, {"VGMI_WIDE_SLOTS": "1"}), (27, {"VGMI_WIDE_SLOTS": "1", "VGMI_DENSE_COUNTS": "1"}),

@@ -550,6 +550,16 @@ __device__ __forceinline__ void vm_atomic_or_sync(uint32_t* ptr, uint32_t bits)
 {
     asm volatile("global_atomic_or %0, %1, off ; VGHOT\n\ts_waitcnt vmcnt(0) ; VGHOT" : : "v"(ptr), "v"(bits) : "memory");
 }
+__device__ __forceinline__ uint32_t vm_atomic_add_ret_sync(uint32_t* ptr, uint32_t v)
+{
+    uint32_t old;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0 ; VGHOT\n\ts_waitcnt vmcnt(0) ; VGHOT" : "=&v"(old) : "v"(ptr), "v"(v) : "memory");
+    return old;
+}
+__device__ __forceinline__ void vm_store64_sync(unsigned long long* ptr, unsigned long long v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off ; VGHOT\n\ts_waitcnt vmcnt(0) ; VGHOT" : : "v"(ptr), "v"(v) : "memory");
+}
 template <bool COMPACT>
 __device__ __forceinline__ uint4 vm_slot_value()   // after the wait
 {
@@ -722,7 +732,12 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
             const uint32_t old = vm_atomic_old();
             const bool sat = p_bumped && old >= 254u;
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(sat) != 0, 0)) {
-                if (sat) vm_atomic_or_sync(reinterpret_cast<uint32_t*>(&slots8[p_slot]) + 1, (uint32_t)(VG_SLOT_SAT >> 32));
+                if (sat) {
+                    vm_atomic_or_sync(reinterpret_cast<uint32_t*>(&slots8[p_slot]) + 1, (uint32_t)(VG_SLOT_SAT >> 32));
+                    // remembered for the per-sample reset (duplicates are harmless; an overflowing list makes it sweep)
+                    const uint32_t at = vm_atomic_add_ret_sync(p.table.sat_n, 1u);
+                    if (at < p.table.sat_cap) vm_store64_sync(&p.table.sat_list[at], (unsigned long long)p_slot);
+                }
             }
         }
         const uint4 tv = vm_slot_value<COMPACT>();
@@ -1172,13 +1187,23 @@ __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t 
 // format, saturation flags of the compact one
 __global__ void counts_reset_kernel(TableView t)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > t.cap_mask) return;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t.slots8) {
-        const unsigned long long c = t.slots8[i];
-        if (c != VG_EMPTY && (c & VG_SLOT_SAT)) t.slots8[i] = c & ~VG_SLOT_SAT;
+        const uint32_t n = t.sat_n ? *t.sat_n : 0xFFFFFFFFu;
+        if (n <= t.sat_cap) {      // the flags set this sample are all on the list
+            for (uint64_t i = tid; i < n; i += stride) {
+                const uint64_t s = t.sat_list[i];
+                t.slots8[s] &= ~VG_SLOT_SAT;
+            }
+            return;
+        }
+        for (uint64_t i = tid; i <= t.cap_mask; i += stride) {
+            const unsigned long long c = t.slots8[i];
+            if (c != VG_EMPTY && (c & VG_SLOT_SAT)) t.slots8[i] = c & ~VG_SLOT_SAT;
+        }
     } else {
-        t.slots[i].count = 0;
+        for (uint64_t i = tid; i <= t.cap_mask; i += stride) t.slots[i].count = 0;
     }
 }
 
@@ -1343,7 +1368,7 @@ hipError_t launch_table_insert(const TableView& t, const uint64_t* keys, uint64_
 
 hipError_t launch_counts_reset(const TableView& t, hipStream_t st)
 {
-    hipLaunchKernelGGL(counts_reset_kernel, dim3((uint32_t)((t.cap_mask + 256) / 256)), dim3(256), 0, st, t);
+    hipLaunchKernelGGL(counts_reset_kernel, dim3(grid_for(t.cap_mask + 1, 256, 4096)), dim3(256), 0, st, t);
     return hipGetLastError();
 }
 
