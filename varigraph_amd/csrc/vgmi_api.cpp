@@ -67,8 +67,8 @@ struct vgmi_ctx {
     bool has_table = false;
     TableView tv{};
     uint32_t* d_key_slot = nullptr;
-    unsigned long long* d_sat_list = nullptr;   // compact format: slots flagged saturated this sample (reset clears those)
-    uint32_t* d_sat_n = nullptr;
+    uint8_t* d_sat_dirty = nullptr;   // compact format: 2048-slot regions holding a saturation flag (the reset sweeps those)
+    uint64_t n_sat_regions = 0;
     uint32_t* d_counts = nullptr;   // counter array (per-sample state, not part of the image): per key (large graphs)
                                     // or per slot (compact format); nullptr: in-slot counters
     uint64_t n_counts = 0;
@@ -159,10 +159,8 @@ void free_table(vgmi_ctx* c)
     c->d_flag = nullptr;
     if (c->d_counts) (void)hipFree(c->d_counts);
     c->d_counts = nullptr;
-    if (c->d_sat_list) (void)hipFree(c->d_sat_list);
-    if (c->d_sat_n) (void)hipFree(c->d_sat_n);
-    c->d_sat_list = nullptr;
-    c->d_sat_n = nullptr;
+    if (c->d_sat_dirty) (void)hipFree(c->d_sat_dirty);
+    c->d_sat_dirty = nullptr;
 }
 
 void free_nodes(vgmi_ctx* c)
@@ -269,18 +267,12 @@ int adopt_image(vgmi_ctx* c)
         HIPCHK(c, hipMemset(c->d_counts, 0, c->n_counts * 4));
         c->tv.counts = c->d_counts;
     }
-    c->tv.sat_list = nullptr;
-    c->tv.sat_n = nullptr;
-    c->tv.sat_cap = 0;
+    c->tv.sat_dirty = nullptr;
     if (compact) {
-        const uint32_t cap = 1u << 20;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_sat_list), (size_t)cap * 8));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_sat_n), 4));
-        const uint32_t unknown = 0x80000000u;        // flags of unknown origin (an imported image): the first reset sweeps
-        HIPCHK(c, hipMemcpy(c->d_sat_n, &unknown, 4, hipMemcpyHostToDevice));
-        c->tv.sat_list = c->d_sat_list;
-        c->tv.sat_n = c->d_sat_n;
-        c->tv.sat_cap = cap;
+        c->n_sat_regions = ((h.cap - 1) >> 11) + 1;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_sat_dirty), c->n_sat_regions));
+        HIPCHK(c, hipMemset(c->d_sat_dirty, 1, c->n_sat_regions));   // flags of unknown origin (an imported image): the first reset sweeps everything
+        c->tv.sat_dirty = c->d_sat_dirty;
     }
     c->has_table = true;
     free_nodes(c);
@@ -593,7 +585,6 @@ int vgmi_table_import(vgmi_ctx* c, const void* dev_src, size_t bytes)
     int rc = adopt_image(c);
     if (rc) return rc;
     HIPCHK(c, launch_counts_reset(c->tv, c->stream));   // the exporter's per-sample state travels with the image
-    if (c->d_sat_n) HIPCHK(c, hipMemsetAsync(c->d_sat_n, 0, 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->read_base = 0;
     return VGMI_OK;
@@ -626,7 +617,6 @@ int vgmi_table_clone(vgmi_ctx* dst, vgmi_ctx* src)
     int rc = adopt_image(dst);
     if (rc) return rc;
     HIPCHK(dst, launch_counts_reset(dst->tv, dst->stream));   // the source's per-sample state travels with the image
-    if (dst->d_sat_n) HIPCHK(dst, hipMemsetAsync(dst->d_sat_n, 0, 4, dst->stream));
     HIPCHK(dst, hipStreamSynchronize(dst->stream));
     dst->read_base = 0;
     return VGMI_OK;
@@ -687,7 +677,6 @@ int vgmi_counts_reset(vgmi_ctx* c)
     if (rc) return rc;
     if (c->d_counts) HIPCHK(c, hipMemsetAsync(c->d_counts, 0, c->n_counts * 4, c->stream));
     if (!c->d_counts || c->tv.slots8) HIPCHK(c, launch_counts_reset(c->tv, c->stream));   // in-slot counters / saturation flags
-    if (c->d_sat_n) HIPCHK(c, hipMemsetAsync(c->d_sat_n, 0, 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4, c->stream));
     // host blocks are counted on the stages' own (non-blocking) streams: their next launch waits for this reset
     HIPCHK(c, hipEventRecord(c->reset_done, c->stream));

@@ -21,9 +21,8 @@ struct TableView {
     uint32_t filter_shift;      // 32 - filter_words_log2
     const uint32_t* grid;       // grid filter (1 << grid_words_log2 words) or nullptr, see vgmi_device.h
     uint32_t grid_words_log2;   // VG_GRID_LDS_WORDS_LOG2 (LDS-resident variant) or larger (global variant)
-    unsigned long long* sat_list;   // compact format: slots whose saturation flag was set this sample (the per-sample reset
-    uint32_t* sat_n;                // clears exactly those instead of sweeping the slot array; the list overflowing
-    uint32_t sat_cap;               // -- sat_n > sat_cap -- falls back to the sweep)
+    uint8_t* sat_dirty;         // compact format: one byte per 2048-slot region, set when a slot of the region gets its
+                                // saturation flag; the per-sample reset sweeps only those regions
     uint32_t* counts;           // 16-byte format: dense per-key counters of large graphs (4 B/key, Infinity-Cache
                                 // sized) or nullptr (in-slot counters); compact format: per-slot counters (cap)
 };

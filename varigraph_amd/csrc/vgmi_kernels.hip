@@ -468,6 +468,7 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
 // operands of every wait, so nothing that reads them can move above it.
 // ------------------------------------------------------------------------------------------
 #define VG_Q_KMER_MASK ((1ULL << 54) - 1)
+#define VG_SAT_REGION_LOG2 11u   // TableView::sat_dirty granularity
 #define VG_RUNQ 80u       // run ring: 16-byte entries {bases[31:0], bases[63:32], bases[75:64] | valid12 << 12, -};
                           // a row adds <= 64 runs, <= 4 are left over and the kernel drains between the two rows of
                           // a pair when needed, so it cannot overflow (LDS: 128 KiB filter + 16 waves x (80 x 16 +
@@ -550,15 +551,9 @@ __device__ __forceinline__ void vm_atomic_or_sync(uint32_t* ptr, uint32_t bits)
 {
     asm volatile("global_atomic_or %0, %1, off ; VGHOT\n\ts_waitcnt vmcnt(0) ; VGHOT" : : "v"(ptr), "v"(bits) : "memory");
 }
-__device__ __forceinline__ uint32_t vm_atomic_add_ret_sync(uint32_t* ptr, uint32_t v)
+__device__ __forceinline__ void vm_store_byte_sync(uint8_t* ptr, uint32_t v)
 {
-    uint32_t old;
-    asm volatile("global_atomic_add %0, %1, %2, off sc0 ; VGHOT\n\ts_waitcnt vmcnt(0) ; VGHOT" : "=&v"(old) : "v"(ptr), "v"(v) : "memory");
-    return old;
-}
-__device__ __forceinline__ void vm_store64_sync(unsigned long long* ptr, unsigned long long v)
-{
-    asm volatile("global_store_dwordx2 %0, %1, off ; VGHOT\n\ts_waitcnt vmcnt(0) ; VGHOT" : : "v"(ptr), "v"(v) : "memory");
+    asm volatile("global_store_byte %0, %1, off ; VGHOT\n\ts_waitcnt vmcnt(0) ; VGHOT" : : "v"(ptr), "v"(v) : "memory");
 }
 template <bool COMPACT>
 __device__ __forceinline__ uint4 vm_slot_value()   // after the wait
@@ -730,13 +725,15 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
             // the previous step's atomics have returned (they were issued before the loads just waited for): a
             // counter that has reached the clamp gets its slot flagged, later hits skip their atomic
             const uint32_t old = vm_atomic_old();
-            const bool sat = p_bumped && old >= 254u;
+            // exactly one increment takes a counter from 254 to 255: that lane flags the slot and puts it on the reset
+            // list (every lane that sees an older value >= 254 doing so would serialise thousands of same-address
+            // atomics on the list counter at deep coverage)
+            const bool sat = p_bumped && old == 254u;
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(sat) != 0, 0)) {
                 if (sat) {
                     vm_atomic_or_sync(reinterpret_cast<uint32_t*>(&slots8[p_slot]) + 1, (uint32_t)(VG_SLOT_SAT >> 32));
-                    // remembered for the per-sample reset (duplicates are harmless; an overflowing list makes it sweep)
-                    const uint32_t at = vm_atomic_add_ret_sync(p.table.sat_n, 1u);
-                    if (at < p.table.sat_cap) vm_store64_sync(&p.table.sat_list[at], (unsigned long long)p_slot);
+                    // the slot's region is marked for the per-sample reset (a plain store of 1: no contention)
+                    vm_store_byte_sync(p.table.sat_dirty + (p_slot >> VG_SAT_REGION_LOG2), 1u);
                 }
             }
         }
@@ -1185,25 +1182,26 @@ __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t 
 
 // per-sample reset of the table side (the counter arrays are cleared by memset): in-slot counters of the 16-byte
 // format, saturation flags of the compact one
-__global__ void counts_reset_kernel(TableView t)
+__global__ __launch_bounds__(256) void counts_reset_kernel(TableView t)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t.slots8) {
-        const uint32_t n = t.sat_n ? *t.sat_n : 0xFFFFFFFFu;
-        if (n <= t.sat_cap) {      // the flags set this sample are all on the list
-            for (uint64_t i = tid; i < n; i += stride) {
-                const uint64_t s = t.sat_list[i];
-                t.slots8[s] &= ~VG_SLOT_SAT;
+        // saturation flags: only the 2048-slot regions a flag was set in this sample (all of them for an image of unknown
+        // history: the dirty bytes are then preset)
+        const uint64_t n_regions = (t.cap_mask >> VG_SAT_REGION_LOG2) + 1;
+        for (uint64_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+            if (!t.sat_dirty[r]) continue;
+            const uint64_t b = r << VG_SAT_REGION_LOG2;
+            const uint64_t e = b + (1ULL << VG_SAT_REGION_LOG2) <= t.cap_mask + 1 ? b + (1ULL << VG_SAT_REGION_LOG2) : t.cap_mask + 1;
+            for (uint64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+                const unsigned long long c = t.slots8[i];
+                if (c != VG_EMPTY && (c & VG_SLOT_SAT)) t.slots8[i] = c & ~VG_SLOT_SAT;
             }
-            return;
-        }
-        for (uint64_t i = tid; i <= t.cap_mask; i += stride) {
-            const unsigned long long c = t.slots8[i];
-            if (c != VG_EMPTY && (c & VG_SLOT_SAT)) t.slots8[i] = c & ~VG_SLOT_SAT;
+            __syncthreads();
+            if (threadIdx.x == 0) t.sat_dirty[r] = 0;
         }
     } else {
-        for (uint64_t i = tid; i <= t.cap_mask; i += stride) t.slots[i].count = 0;
+        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= t.cap_mask; i += stride) t.slots[i].count = 0;
     }
 }
 
