@@ -67,6 +67,10 @@ struct vgmi_ctx {
     bool has_table = false;
     TableView tv{};
     uint32_t* d_key_slot = nullptr;
+    uint64_t xt_bytes_since_clamp = 0;
+    unsigned long long* d_xt_lines = nullptr;   // table keyed by the grid 16-mer (vgmi_xtable.hip), VGMI_XTABLE=1
+    uint32_t* d_xt_counts = nullptr;
+    uint32_t* d_xt_id = nullptr;                // key index -> counter id (path order), nullptr: identity
     uint8_t* d_sat_dirty = nullptr;   // compact format: 2048-slot regions holding a saturation flag (the reset sweeps those)
     uint64_t n_sat_regions = 0;
     uint32_t* d_counts = nullptr;   // counter array (per-sample state, not part of the image): per key (large graphs)
@@ -161,6 +165,13 @@ void free_table(vgmi_ctx* c)
     c->d_counts = nullptr;
     if (c->d_sat_dirty) (void)hipFree(c->d_sat_dirty);
     c->d_sat_dirty = nullptr;
+    if (c->d_xt_lines) (void)hipFree(c->d_xt_lines);
+    if (c->d_xt_counts) (void)hipFree(c->d_xt_counts);
+    if (c->d_xt_id) (void)hipFree(c->d_xt_id);
+    c->d_xt_lines = nullptr;
+    c->d_xt_counts = nullptr;
+    c->d_xt_id = nullptr;
+    c->tv.xt = XTableView{};
 }
 
 void free_nodes(vgmi_ctx* c)
@@ -279,6 +290,83 @@ int adopt_image(vgmi_ctx* c)
     return VGMI_OK;
 }
 
+// the table keyed by the grid 16-mer, built from the compact image (k-mers = slots8[key_slot[i]]): after an upload, an
+// import and a clone alike
+int build_xtable(vgmi_ctx* c)
+{
+    const char* e = getenv("VGMI_XTABLE");
+    const ImageHeader& h = c->hdr;
+    if (!(e && e[0] == '1') || h.k != 27 || h.slot_bytes != 8 || h.n_keys <= VG_GRID_LDS_MAX_KEYS) return VGMI_OK;
+    XTableView x{};
+    x.lines_log2 = ceil_log2((h.n_keys * 12 + 4) / 5);          // lines of 16 slots at <= 31 % load
+    if (x.lines_log2 < 20) x.lines_log2 = 20;
+    if (x.lines_log2 > 31) return fail(c, VGMI_E_INVALID, "too many keys for the grid-16-mer table");
+    x.id_shift = 26 + (32 - x.lines_log2);
+    if (h.n_keys >= (1ULL << (64 - x.id_shift)) - 1) return fail(c, VGMI_E_INVALID, "too many keys for the grid-16-mer table");
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xt_lines), (size_t)128 << x.lines_log2));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xt_counts), h.n_keys * 4));
+    HIPCHK(c, hipMemsetAsync(c->d_xt_counts, 0, h.n_keys * 4, c->stream));
+    x.lines = c->d_xt_lines;
+    x.counts = c->d_xt_counts;
+    HIPCHK(c, launch_xtable_build(x, c->tv.slots8, c->d_key_slot, nullptr, h.n_keys, c->d_status, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint32_t st = 0;
+    HIPCHK(c, hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
+    if (st & 8u) return fail(c, VGMI_E_HIP, "grid-16-mer table overflow");
+    // counter ids in path order (xtable_number_*; any numbering is correct, VGMI_XTABLE_ORDER=0 keeps the key index)
+    const char* ord = getenv("VGMI_XTABLE_ORDER");
+    if (!(ord && ord[0] == '0')) {
+        const uint64_t n = h.n_keys;
+        uint32_t *link = nullptr, *link2 = nullptr, *mark = nullptr;
+        unsigned long long* cursor = nullptr;
+        hipError_t he = hipMalloc(reinterpret_cast<void**>(&link), n * 8);
+        if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&link2), n * 8);
+        if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&mark), n * 4);
+        if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&cursor), 8);
+        if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&c->d_xt_id), n * 4);
+        if (he == hipSuccess) he = hipMemsetAsync(c->d_xt_id, 0xFF, n * 4, c->stream);
+        if (he == hipSuccess) he = hipMemsetAsync(mark, 0, n * 4, c->stream);
+        if (he == hipSuccess) he = hipMemsetAsync(cursor, 0, 8, c->stream);
+        if (he == hipSuccess) he = launch_xtable_number(x, c->tv.slots8, c->d_key_slot, n, link, link2, c->d_xt_id, cursor, mark, c->d_status, c->stream);
+        unsigned long long used = 0;
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he == hipSuccess) he = hipMemcpy(&used, cursor, 8, hipMemcpyDeviceToHost);
+        if (he == hipSuccess) he = hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost);
+        for (void* q : {(void*)link, (void*)link2, (void*)mark, (void*)cursor})
+            if (q) (void)hipFree(q);
+        HIPCHK(c, he);
+        if ((st & 16u) || used != n) {      // not a permutation (cannot happen; the identity numbering is always right)
+            (void)hipFree(c->d_xt_id);
+            c->d_xt_id = nullptr;
+            HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4, c->stream));
+        } else {
+            HIPCHK(c, launch_xtable_build(x, c->tv.slots8, c->d_key_slot, c->d_xt_id, n, c->d_status, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
+            if (st & 8u) return fail(c, VGMI_E_HIP, "grid-16-mer table overflow");
+        }
+    }
+    c->tv.xt = x;
+    return VGMI_OK;
+}
+
+// grid-16-mer table: counters are bumped without a return value; before any could wrap (2^32 hits need > 2^31 submitted
+// bytes), counters far above the read-out clamp are pulled back
+int xt_clamp_if_due(vgmi_ctx* c, size_t n_bytes, hipStream_t st)
+{
+    bool due = false;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->xt_bytes_since_clamp += n_bytes;
+        if (c->xt_bytes_since_clamp >= (1ULL << 31)) {
+            c->xt_bytes_since_clamp = 0;
+            due = true;
+        }
+    }
+    if (due) HIPCHK(c, launch_xclamp(c->tv.xt, c->hdr.n_keys, st));
+    return VGMI_OK;
+}
+
 RowParams row_params(vgmi_ctx* c, const char* d_bases, size_t n_bytes, uint32_t k)
 {
     RowParams p{};
@@ -321,7 +409,13 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
         if (!(k & 1)) return fail(c, VGMI_E_INVALID, "device-side block length: odd k only");
         uint32_t grid, block;
         rows_geometry(c, c->filter_in_lds, grid, block);
-        if (c->fast27 && !c->force_generic) {
+        if (c->tv.xt.lines && !c->force_generic) {
+            int rcx = xt_clamp_if_due(c, n_bytes, st);
+            if (rcx) return rcx;
+            HIPCHK(c, launch_count27x(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
+            p.tail27 = 2;
+            HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, 1, block, st));
+        } else if (c->fast27 && !c->force_generic) {
             uint32_t g27, b27;
             if (c->fast27_lds) { b27 = 1024; g27 = (uint32_t)c->n_cu; }
             else { b27 = 256; g27 = (uint32_t)c->n_cu * (c->wgs_per_cu ? c->wgs_per_cu : 4); }
@@ -334,7 +428,22 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
     } else if (k & 1) {
         uint32_t grid, block;
         rows_geometry(c, c->filter_in_lds, grid, block);
-        if (c->fast27 && !c->force_generic) {
+        if (c->tv.xt.lines && !c->force_generic) {
+            // grid-16-mer table: complete 768-byte rows -> count27x_kernel, the ends behind them -> the generic kernel
+            const uint64_t rows = n_bytes / 768;
+            uint64_t emit_from = 0;
+            int rcx = xt_clamp_if_due(c, n_bytes, st);
+            if (rcx) return rcx;
+            if (rows) {
+                HIPCHK(c, launch_count27x(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
+                emit_from = rows * 768 - 1;
+            }
+            if (emit_from < n_bytes) {
+                p.emit_from = emit_from;
+                p.row_begin = emit_from >> 10;
+                HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, 1, block, st));
+            }
+        } else if (c->fast27 && !c->force_generic) {
             // complete 768-byte rows -> fast kernel.  It covers every k-mer whose run starts at one of its
             // grid positions; the generic kernel takes the ends after that: the ragged tail plus the last
             // position of the last full row.
@@ -541,6 +650,8 @@ int vgmi_table_upload(vgmi_ctx* c, const uint64_t* keys, size_t n_keys, uint32_t
     HIPCHK(c, e);
     rc = check_status(c);
     if (rc) { free_table(c); return rc; }
+    rc = build_xtable(c);
+    if (rc) { free_table(c); return rc; }
     c->read_base = 0;
     return VGMI_OK;
 }
@@ -586,6 +697,8 @@ int vgmi_table_import(vgmi_ctx* c, const void* dev_src, size_t bytes)
     if (rc) return rc;
     HIPCHK(c, launch_counts_reset(c->tv, c->stream));   // the exporter's per-sample state travels with the image
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = build_xtable(c);
+    if (rc) return rc;
     c->read_base = 0;
     return VGMI_OK;
 }
@@ -618,6 +731,8 @@ int vgmi_table_clone(vgmi_ctx* dst, vgmi_ctx* src)
     if (rc) return rc;
     HIPCHK(dst, launch_counts_reset(dst->tv, dst->stream));   // the source's per-sample state travels with the image
     HIPCHK(dst, hipStreamSynchronize(dst->stream));
+    rc = build_xtable(dst);
+    if (rc) return rc;
     dst->read_base = 0;
     return VGMI_OK;
 }
@@ -675,6 +790,7 @@ int vgmi_counts_reset(vgmi_ctx* c)
     if (rc) return rc;
     rc = collect_timing(c);
     if (rc) return rc;
+    if (c->tv.xt.lines) HIPCHK(c, hipMemsetAsync(c->d_xt_counts, 0, c->hdr.n_keys * 4, c->stream));
     if (c->d_counts) HIPCHK(c, hipMemsetAsync(c->d_counts, 0, c->n_counts * 4, c->stream));
     if (!c->d_counts || c->tv.slots8) HIPCHK(c, launch_counts_reset(c->tv, c->stream));   // in-slot counters / saturation flags
     HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4, c->stream));
@@ -781,7 +897,8 @@ static int finish_common(vgmi_ctx* c, uint8_t* d_cov, uint8_t* d_cov_node, unsig
     for (auto& s : c->stage)
         if (s.busy) HIPCHK(c, hipStreamWaitEvent(c->stream, s.done, 0));
     if (d_hist) HIPCHK(c, hipMemsetAsync(d_hist, 0, 256 * 8, c->stream));
-    HIPCHK(c, launch_cov(c->tv, c->d_key_slot, c->hdr.n_keys, c->d_flag, d_cov, d_hist, c->stream));
+    if (c->tv.xt.lines) HIPCHK(c, launch_xcov(c->tv.xt, c->d_xt_id, c->hdr.n_keys, c->d_flag, d_cov, d_hist, c->stream));
+    else HIPCHK(c, launch_cov(c->tv, c->d_key_slot, c->hdr.n_keys, c->d_flag, d_cov, d_hist, c->stream));
     if (d_cov_node && c->n_node_entries)
         HIPCHK(c, launch_node_gather(d_cov, c->d_node_key_index, c->n_node_entries, d_cov_node, c->stream));
     return VGMI_OK;
@@ -836,7 +953,8 @@ static int counts_xfer(vgmi_ctx* c, uint32_t* dev, bool import)
     HIPCHK(c, hipSetDevice(c->device));
     for (auto& s : c->stage)
         if (s.busy) HIPCHK(c, hipStreamWaitEvent(c->stream, s.done, 0));
-    HIPCHK(c, launch_counts_xfer(c->tv, c->d_key_slot, dev, c->hdr.n_keys, import, c->stream));
+    if (c->tv.xt.lines) HIPCHK(c, launch_xcounts_xfer(c->tv.xt, c->d_xt_id, dev, c->hdr.n_keys, import, c->stream));
+    else HIPCHK(c, launch_counts_xfer(c->tv, c->d_key_slot, dev, c->hdr.n_keys, import, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return VGMI_OK;
 }

@@ -10,6 +10,14 @@ namespace vgk {
 
 enum { K_MODE_COUNT = 0, K_MODE_KEYS = 1, K_MODE_BLOOM = 2 };
 
+// table keyed by the read's grid 16-mer (vgmi_xtable.hip): lines of 16 entries, dense counters by id
+struct XTableView {
+    unsigned long long* lines;   // 16 << lines_log2 entries, or nullptr: not in use
+    uint32_t lines_log2;
+    uint32_t id_shift;           // 26 + (32 - lines_log2): entry = j' | f << 4 | tag << 26 | id << id_shift
+    uint32_t* counts;            // n_keys
+};
+
 struct TableView {
     VgSlot* slots;              // cap entries (16-byte format) or nullptr
     unsigned long long* slots8; // cap k-mer words (compact 8-byte format) or nullptr
@@ -23,6 +31,7 @@ struct TableView {
     uint32_t grid_words_log2;   // VG_GRID_LDS_WORDS_LOG2 (LDS-resident variant) or larger (global variant)
     uint8_t* sat_dirty;         // compact format: one byte per 2048-slot region, set when a slot of the region gets its
                                 // saturation flag; the per-sample reset sweeps only those regions
+    XTableView xt;              // when xt.lines is set, every count kernel looks k-mers up there and counts in xt.counts
     uint32_t* counts;           // 16-byte format: dense per-key counters of large graphs (4 B/key, Infinity-Cache
                                 // sized) or nullptr (in-slot counters); compact format: per-slot counters (cap)
 };
@@ -107,6 +116,16 @@ struct BgzfVerdict {         // device-resident, per stream
 hipError_t launch_bgzf_inflate(const uint8_t* comp, const BgzfMember* members, uint32_t n_members, uint8_t* out_base, uint32_t* status,
                                const uint32_t* crc_table, BgzfVerdict* verdict, hipStream_t s);
 
+hipError_t launch_xtable_build(const XTableView& t, const unsigned long long* slots8, const uint32_t* key_slot, const uint32_t* id_of_key,
+                               uint64_t n_keys, uint32_t* status, hipStream_t st);
+hipError_t launch_xtable_number(const XTableView& t, const unsigned long long* slots8, const uint32_t* key_slot, uint64_t n, uint32_t* link,
+                                uint32_t* link2, uint32_t* id_of_key, unsigned long long* cursor, uint32_t* mark, uint32_t* status,
+                                hipStream_t st);
+hipError_t launch_count27x(const RowParams& p, const XTableView& t, uint32_t grid, hipStream_t st);
+hipError_t launch_xclamp(const XTableView& t, uint64_t n, hipStream_t st);
+hipError_t launch_xcov(const XTableView& t, const uint32_t* id_of_key, uint64_t n, const uint8_t* flag, uint8_t* cov, unsigned long long* hist,
+                       hipStream_t st);
+hipError_t launch_xcounts_xfer(const XTableView& t, const uint32_t* id_of_key, uint32_t* ext, uint64_t n, bool import, hipStream_t st);
 hipError_t launch_count27(bool lds_bitmap, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t launch_bloom_even(const RowParams& p, hipStream_t st);   // even k, one long sequence (K3)

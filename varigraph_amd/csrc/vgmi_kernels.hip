@@ -30,6 +30,7 @@
 #include "vg_synth.h"
 #include "vgmi_device.h"
 #include "vgmi_kernels.h"
+#include "vgmi_xtable.h"
 
 namespace vgk {
 
@@ -148,6 +149,10 @@ __device__ __forceinline__ uint64_t table_home(const TableView& t, uint64_t cano
 
 __device__ __forceinline__ void table_count(const TableView& t, uint64_t canon)
 {
+    if (t.xt.lines) {   // grid-16-mer table: the k-mer's own first 16-mer (offset 0) is as good as any of the twelve
+        xt_count(t.xt, canon, 0);
+        return;
+    }
     uint64_t s = table_home(t, canon);
     if (t.slots8) {   // compact format: k-mer words, per-slot counters
         for (;;) {
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
         n_bytes = *p.n_bytes_dev;
         emit_from = 0;
         if (p.tail27) {   // behind count27_kernel: the ends it does not cover (see launch_count in vgmi_api.cpp)
-            const uint64_t row_end27 = (n_bytes / 1536) * 2;
+            const uint64_t row_end27 = p.tail27 == 2 ? n_bytes / 768 : (n_bytes / 1536) * 2;   // 2: count27x_kernel (single rows)
             emit_from = row_end27 ? row_end27 * 768 - 1 : 0;
         }
         row_begin = emit_from >> 10;
