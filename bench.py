@@ -454,7 +454,8 @@ def main():
                   "roofline": {"bound": "hbm", "achieved": ach3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach3 / HBM_PEAK_GBS, "traffic": tr3,
                                "algorithmic_bytes_per_launch": b_read3 * n3, "bytes_per_read": b_read3,
-                               "kernel": "vgk::count27_kernel<false, true>", "kernel_ms": kms3,
+                               "kernel": ("vgk::count27_kernel<false, true>" if os.environ.get("VGMI_XTABLE") == "0" else "vgk::count27x_kernel"),
+                               "kernel_ms": kms3,
                                "note": "SURVEY 8d: B_read = 150 (bases) + 124 x 8 (one key compare per k-mer) + 2 x hits "
                                        "+ amortised read-out; hits measured from this run's counters"},
                   "verify": verify(keys3, d_block3, args.verify_reads) if args.verify_reads else None}

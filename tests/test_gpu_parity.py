@@ -478,15 +478,18 @@ def test_saturation_flags_do_not_travel_with_the_table_image(ctx):
 
 
 # ----------------------------------------------------------------------------- large graphs (global grid bitmap)
-@pytest.mark.parametrize("k,placement", [(27, None), (25, None), (27, {"VGMI_LOCALITY": "0"}), (27, {"VGMI_LOCALITY": "3"}),
+@pytest.mark.parametrize("k,placement", [(27, None), (25, None), (27, {"VGMI_XTABLE": "0"}), (27, {"VGMI_XTABLE": "0", "VGMI_LOCALITY": "0"}),
+                                         (27, {"VGMI_XTABLE": "0", "VGMI_LOCALITY": "3"}),
                                          (27, {"VGMI_WIDE_SLOTS": "1"}), (27, {"VGMI_WIDE_SLOTS": "1", "VGMI_DENSE_COUNTS": "1"}),
                                          (27, {"VGMI_WIDE_SLOTS": "1", "VGMI_LOCALITY": "0"}),
-                                         (27, {"VGMI_SLOT_ORDER": "1", "VGMI_LOCALITY": "6"}), (27, {"VGMI_XTABLE": "1"})],
-                         ids=["k27", "k25", "k27-random-homes", "k27-buckets-of-8", "k27-16-byte-slots",
+                                         (27, {"VGMI_XTABLE": "0", "VGMI_SLOT_ORDER": "1", "VGMI_LOCALITY": "6"}),
+                                         (27, {"VGMI_XTABLE_ORDER": "0"}), (27, {"VGMI_XTABLE_SHIFT": "-1"})],
+                         ids=["k27", "k25", "k27-minimiser-buckets", "k27-random-homes", "k27-buckets-of-8", "k27-16-byte-slots",
                               "k27-16-byte-slots-dense-counters", "k27-16-byte-slots-random-homes", "k27-slots-by-minimiser-offset",
-                              "k27-grid-16-mer-table"])
+                              "k27-grid-table-ids-by-key-index", "k27-grid-table-crowded"])
 def test_large_graph_grid_variant_matches_oracle(k, placement, monkeypatch):
-    """> 65 536 keys: k = 27 takes count27_kernel<global grid bitmap> (+ generic tail row), k = 25 the
+    """> 65 536 keys: k = 27 takes count27x_kernel over the grid-16-mer table (default; path-ordered counter ids) or, with
+    VGMI_XTABLE=0, count27_kernel<global grid bitmap> over the minimiser-bucket table (+ generic tail row either way), k = 25 the
     generic rows_kernel with the global blocked-Bloom prefilter.  Dense SNPs (1 per 60 bp) give ~35 %
     hit rate: exercises ring pressure, re-queued collision probes and unsaturated counters.  The k = 27 table has
     8-byte slots in minimiser buckets with per-slot counters by default; the other formats and placements stay covered."""

@@ -114,6 +114,8 @@ struct vgmi_ctx {
 namespace {
 
 void fastq_free(vgmi_fastq* f);
+struct ImageHeader;
+bool xtable_wanted(const ImageHeader& h);
 
 int fail(vgmi_ctx* c, int code, const std::string& msg)
 {
@@ -269,7 +271,7 @@ int adopt_image(vgmi_ctx* c)
     HIPCHK(c, hipMalloc(&c->d_cov, h.n_keys ? h.n_keys : 1));
     c->tv.counts = nullptr;
     c->n_counts = 0;
-    if (compact) c->n_counts = h.cap;                                   // per-slot counters
+    if (compact && !xtable_wanted(h)) c->n_counts = h.cap;              // per-slot counters (the grid-16-mer table has its own, per key)
     else if (h.n_keys > VG_GRID_LDS_MAX_KEYS && (h.home_bucket_log2 == 0 || getenv("VGMI_DENSE_COUNTS")))
         c->n_counts = h.n_keys;   // randomly placed slots: 4 B/key dense counters stay Infinity-Cache resident
     // (minimiser buckets: the counter lives in the slot, the atomic hits the line its probe has just fetched)
@@ -292,13 +294,22 @@ int adopt_image(vgmi_ctx* c)
 
 // the table keyed by the grid 16-mer, built from the compact image (k-mers = slots8[key_slot[i]]): after an upload, an
 // import and a clone alike
-int build_xtable(vgmi_ctx* c)
+// k = 27 graphs that live in HBM count through the grid-16-mer table (VGMI_XTABLE=0: the minimiser-bucket table and
+// count27_kernel<false, *> of round 1, kept as the A/B reference)
+bool xtable_wanted(const ImageHeader& h)
 {
     const char* e = getenv("VGMI_XTABLE");
+    return !(e && e[0] == '0') && h.k == 27 && h.slot_bytes == 8 && h.n_keys > VG_GRID_LDS_MAX_KEYS;
+}
+
+int build_xtable(vgmi_ctx* c)
+{
     const ImageHeader& h = c->hdr;
-    if (!(e && e[0] == '1') || h.k != 27 || h.slot_bytes != 8 || h.n_keys <= VG_GRID_LDS_MAX_KEYS) return VGMI_OK;
+    if (!xtable_wanted(h)) return VGMI_OK;
     XTableView x{};
     x.lines_log2 = ceil_log2((h.n_keys * 12 + 4) / 5);          // lines of 16 slots at <= 31 % load
+    if (x.lines_log2 > 29) x.lines_log2 = 29;                   // 64 GiB of lines unless asked for more (WGS class: 37 % load)
+    if (const char* sh = getenv("VGMI_XTABLE_SHIFT")) x.lines_log2 = (uint32_t)((int)x.lines_log2 + atoi(sh));   // A/B: table size
     if (x.lines_log2 < 20) x.lines_log2 = 20;
     if (x.lines_log2 > 31) return fail(c, VGMI_E_INVALID, "too many keys for the grid-16-mer table");
     x.id_shift = 26 + (32 - x.lines_log2);
@@ -792,7 +803,7 @@ int vgmi_counts_reset(vgmi_ctx* c)
     if (rc) return rc;
     if (c->tv.xt.lines) HIPCHK(c, hipMemsetAsync(c->d_xt_counts, 0, c->hdr.n_keys * 4, c->stream));
     if (c->d_counts) HIPCHK(c, hipMemsetAsync(c->d_counts, 0, c->n_counts * 4, c->stream));
-    if (!c->d_counts || c->tv.slots8) HIPCHK(c, launch_counts_reset(c->tv, c->stream));   // in-slot counters / saturation flags
+    if (!c->tv.xt.lines && (!c->d_counts || c->tv.slots8)) HIPCHK(c, launch_counts_reset(c->tv, c->stream));   // in-slot counters / saturation flags
     HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4, c->stream));
     // host blocks are counted on the stages' own (non-blocking) streams: their next launch waits for this reset
     HIPCHK(c, hipEventRecord(c->reset_done, c->stream));
