@@ -21,7 +21,7 @@ def main():
         if m:
             sect = "cal" if "pmc_cal" in m.group(1) else "main"
             continue
-        m = re.match(r"\s*\d+\s+[\d.]+\s+([\d.]+)\s+(FETCH_SIZE|WRITE_SIZE)\s+(.*count27_kernel\S*)", ln)
+        m = re.match(r"\s*\d+\s+[\d.]+\s+([\d.]+)\s+(FETCH_SIZE|WRITE_SIZE)\s+(.*count27x?_kernel\S*)", ln)
         if m and sect:
             vals[(sect, m.group(2))] = float(m.group(1))
             kernel = m.group(3).split("(")[0].replace("void ", "").strip()

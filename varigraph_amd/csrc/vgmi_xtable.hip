@@ -225,19 +225,57 @@ __global__ __launch_bounds__(256) void count27x_kernel(RowParams p, XTableView x
     };
     auto ror1 = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xF, 0xF, false); };
 
+    // A drain step ISSUES the first-slot loads of up to 5 runs x 12 windows and FINISHES the batch the previous step
+    // issued (compare, spill slots, atomic): the loads of a batch have a whole step to arrive (the kernel is bound by
+    // memory round trips, not instructions).  finish-only when nothing is queued.
+    const uint64_t key_mask = (1ULL << xt.id_shift) - 1, line_mask = (1ULL << xt.lines_log2) - 1;
+    uint64_t p_line = 0, p_want = 0;
+    unsigned long long p_e = XT_EMPTY;
+    bool p_act = false;
     auto drain = [&]() {
+        // ---- issue
         const uint32_t take = run_n < 5u ? run_n : 5u;
         const bool have = my_run < take;
-        uint4 e = make_uint4(0, 0, 0, 0);
-        if (have) e = runs[ring(run_head + my_run)];
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (have) q = runs[ring(run_head + my_run)];
         run_head = ring(run_head + take);
         run_n -= take;
-        if (have && ((e.z >> (12 + my_win)) & 1u)) {
-            const uint32_t sh = 2 * (11 - my_win);
-            const uint32_t lo = __builtin_amdgcn_alignbit(e.y, e.x, sh);
-            const uint32_t hi = __builtin_amdgcn_alignbit(e.z, e.y, sh) & MASK_HI;
-            xt_count(xt, (uint64_t)hi << 32 | lo, my_win);
+        const bool act = have && ((q.z >> (12 + my_win)) & 1u);
+        const uint32_t sh = 2 * (11 - my_win);
+        const uint32_t lo = __builtin_amdgcn_alignbit(q.y, q.x, sh);
+        const uint32_t hi = __builtin_amdgcn_alignbit(q.z, q.y, sh) & MASK_HI;
+        uint64_t line, want;
+        xt_key(xt, (uint64_t)hi << 32 | lo, my_win, line, want);
+        unsigned long long e = XT_EMPTY;
+        if (act) e = xt.lines[(line << 4) + ((uint32_t)want & 15u)];
+        // ---- finish the previous batch
+        if (p_act && p_e != XT_EMPTY) {
+            unsigned long long hit = ((p_e ^ p_want) & key_mask) == 0 ? p_e : XT_EMPTY;
+            uint64_t ln = p_line;
+            while (hit == XT_EMPTY) {          // slot j' holds another k-mer: the spill slots, then the next line
+                const unsigned long long* L = xt.lines + (ln << 4);
+                const ulonglong2 s01 = *reinterpret_cast<const ulonglong2*>(L + 12);
+                const ulonglong2 s23 = *reinterpret_cast<const ulonglong2*>(L + 14);
+                const unsigned long long sp[4] = {s01.x, s01.y, s23.x, s23.y};
+                bool full = true;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (sp[k] == XT_EMPTY) full = false;
+                    else if (((sp[k] ^ p_want) & key_mask) == 0) hit = sp[k];
+                }
+                if (hit != XT_EMPTY || !full) break;
+                ln = (ln + 1) & line_mask;
+                const unsigned long long nx = xt.lines[(ln << 4) + ((uint32_t)p_want & 15u)];
+                if (nx == XT_EMPTY) break;
+                if (((nx ^ p_want) & key_mask) == 0) hit = nx;
+            }
+            if (hit != XT_EMPTY)
+                __hip_atomic_fetch_add(xt.counts + (hit >> xt.id_shift), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        p_act = act;
+        p_e = e;
+        p_want = want;
+        p_line = line;
     };
 
     // halo: the row in front of the range
@@ -306,6 +344,7 @@ __global__ __launch_bounds__(256) void count27x_kernel(RowParams p, XTableView x
         __builtin_amdgcn_wave_barrier();
     }
     while (run_n) drain();
+    drain();     // finishes the last batch (issues nothing)
 }
 
 // K5 part 1 + K6 over dense counters: cov[i] = min(255, counts[id(i)]); hist[c] += 1 for flagged keys with c != 0
