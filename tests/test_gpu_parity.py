@@ -483,7 +483,7 @@ def test_saturation_flags_do_not_travel_with_the_table_image(ctx):
                                          (27, {"VGMI_WIDE_SLOTS": "1"}), (27, {"VGMI_WIDE_SLOTS": "1", "VGMI_DENSE_COUNTS": "1"}),
                                          (27, {"VGMI_WIDE_SLOTS": "1", "VGMI_LOCALITY": "0"}),
                                          (27, {"VGMI_XTABLE": "0", "VGMI_SLOT_ORDER": "1", "VGMI_LOCALITY": "6"}),
-                                         (27, {"VGMI_XTABLE_ORDER": "0"}), (27, {"VGMI_XTABLE_SHIFT": "-1"})],
+                                         (27, {"VGMI_XTABLE_ORDER": "0"}), (27, {"VGMI_XTABLE_LOAD": "60"})],
                          ids=["k27", "k25", "k27-minimiser-buckets", "k27-random-homes", "k27-buckets-of-8", "k27-16-byte-slots",
                               "k27-16-byte-slots-dense-counters", "k27-16-byte-slots-random-homes", "k27-slots-by-minimiser-offset",
                               "k27-grid-table-ids-by-key-index", "k27-grid-table-crowded"])

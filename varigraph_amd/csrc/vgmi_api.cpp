@@ -307,14 +307,20 @@ int build_xtable(vgmi_ctx* c)
     const ImageHeader& h = c->hdr;
     if (!xtable_wanted(h)) return VGMI_OK;
     XTableView x{};
-    x.lines_log2 = ceil_log2((h.n_keys * 12 + 4) / 5);          // lines of 16 slots at <= 31 % load
-    if (x.lines_log2 > 29) x.lines_log2 = 29;                   // 64 GiB of lines unless asked for more (WGS class: 37 % load)
-    if (const char* sh = getenv("VGMI_XTABLE_SHIFT")) x.lines_log2 = (uint32_t)((int)x.lines_log2 + atoi(sh));   // A/B: table size
-    if (x.lines_log2 < 20) x.lines_log2 = 20;
-    if (x.lines_log2 > 31) return fail(c, VGMI_E_INVALID, "too many keys for the grid-16-mer table");
-    x.id_shift = 26 + (32 - x.lines_log2);
+    // lines of 16 slots at 25 % load (measured, chr20 / WGS class: 31 % 11.4 / 45.9 ms, 25 % 10.1 / 43.4, 20 % 9.9 / 41.8;
+    // VGMI_XTABLE_LOAD=percent for A/B); never more than half of the free device memory
+    double load = 0.25;
+    if (const char* e = getenv("VGMI_XTABLE_LOAD")) load = atoi(e) >= 5 && atoi(e) <= 90 ? atoi(e) / 100.0 : load;
+    uint64_t n_lines = (uint64_t)((double)h.n_keys * 12.0 / (16.0 * load)) + 1;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && n_lines * 128 > free_b / 2) n_lines = free_b / 2 / 128;
+    if (n_lines < (1u << 20)) n_lines = 1u << 20;
+    if (n_lines >= (1ULL << 31) || n_lines * 16 < h.n_keys * 13) return fail(c, VGMI_E_NOMEM, "not enough device memory for the grid-16-mer table");
+    x.n_lines = (uint32_t)n_lines;
+    x.tag_bits = ceil_log2(((1ULL << 32) + n_lines - 1) / n_lines + 1);
+    x.id_shift = 26 + x.tag_bits;
     if (h.n_keys >= (1ULL << (64 - x.id_shift)) - 1) return fail(c, VGMI_E_INVALID, "too many keys for the grid-16-mer table");
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xt_lines), (size_t)128 << x.lines_log2));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xt_lines), (size_t)128 * n_lines));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xt_counts), h.n_keys * 4));
     HIPCHK(c, hipMemsetAsync(c->d_xt_counts, 0, h.n_keys * 4, c->stream));
     x.lines = c->d_xt_lines;

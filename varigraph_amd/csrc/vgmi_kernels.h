@@ -12,9 +12,10 @@ enum { K_MODE_COUNT = 0, K_MODE_KEYS = 1, K_MODE_BLOOM = 2 };
 
 // table keyed by the read's grid 16-mer (vgmi_xtable.hip): lines of 16 entries, dense counters by id
 struct XTableView {
-    unsigned long long* lines;   // 16 << lines_log2 entries, or nullptr: not in use
-    uint32_t lines_log2;
-    uint32_t id_shift;           // 26 + (32 - lines_log2): entry = j' | f << 4 | tag << 26 | id << id_shift
+    unsigned long long* lines;   // 16 * n_lines entries, or nullptr: not in use
+    uint32_t n_lines;            // any number (not a power of two): line = (h(X) * n_lines) >> 32
+    uint32_t tag_bits;           // low bits of h(X) kept in the entry: 2^tag_bits >= the h-values one line covers, so (line, tag) is X
+    uint32_t id_shift;           // 26 + tag_bits: entry = j' | f << 4 | tag << 26 | id << id_shift
     uint32_t* counts;            // n_keys
 };
 

@@ -36,8 +36,8 @@ __device__ __forceinline__ void xt_key(const XTableView& t, uint64_t kmer, uint3
         j = 11u - w;
     }
     const uint32_t h = xt_hash(as_is ? x : rc);
-    line = h >> (32 - t.lines_log2);
-    const uint32_t tag = t.lines_log2 == 32 ? 0u : (h & ((1u << (32 - t.lines_log2)) - 1u));
+    line = ((uint64_t)h * t.n_lines) >> 32;          // the h-values of one line are consecutive: their low tag_bits differ
+    const uint32_t tag = h & ((1u << t.tag_bits) - 1u);
     want = (uint64_t)j | (uint64_t)f << 4 | (uint64_t)tag << 26;
 }
 
@@ -46,7 +46,6 @@ __device__ __forceinline__ void xt_count(const XTableView& t, uint64_t kmer, uin
     uint64_t line, want;
     xt_key(t, kmer, w, line, want);
     const uint64_t key_mask = (1ULL << t.id_shift) - 1;
-    const uint64_t line_mask = (1ULL << t.lines_log2) - 1;
     const uint32_t j = (uint32_t)want & 15u;
     for (;;) {
         const unsigned long long* L = t.lines + (line << 4);
@@ -71,7 +70,7 @@ __device__ __forceinline__ void xt_count(const XTableView& t, uint64_t kmer, uin
             return;
         }
         if (!full) return;
-        line = (line + 1) & line_mask;
+        line = line + 1 == t.n_lines ? 0 : line + 1;
     }
 }
 
@@ -81,7 +80,6 @@ __device__ __forceinline__ uint32_t xt_find(const XTableView& t, uint64_t kmer)
     uint64_t line, want;
     xt_key(t, kmer, 0, line, want);
     const uint64_t key_mask = (1ULL << t.id_shift) - 1;
-    const uint64_t line_mask = (1ULL << t.lines_log2) - 1;
     const uint32_t j = (uint32_t)want & 15u;
     for (;;) {
         const unsigned long long* L = t.lines + (line << 4);
@@ -95,7 +93,7 @@ __device__ __forceinline__ uint32_t xt_find(const XTableView& t, uint64_t kmer)
             else if (((s ^ want) & key_mask) == 0) return (uint32_t)(s >> t.id_shift);
         }
         if (!full) return 0xFFFFFFFFu;
-        line = (line + 1) & line_mask;
+        line = line + 1 == t.n_lines ? 0 : line + 1;
     }
 }
 

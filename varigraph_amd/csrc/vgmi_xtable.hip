@@ -7,10 +7,10 @@
 // DESIGN.md section 6.2): 37.8 requests per read, of which 13.6 are table lines -- the twelve candidate k-mers of a run
 // hash to two or three minimiser buckets of two lines each -- and 10.5 are atomic requests on per-slot counters
 // scattered the same way.  Here every graph k-mer is stored under EACH of its twelve canonical 16-mers:
-//     line   = top bits of h(X), h a bijection of the 32-bit canonical 16-mer X (so line + tag identify X exactly)
+//     line   = (h(X) * n_lines) >> 32, h a bijection of the 32-bit canonical 16-mer X (so line + tag identify X exactly)
 //     entry  = { j' : 4   offset of X from the k-mer's end, counted in X's canonical orientation
 //                f  : 22  the 11 bases of the k-mer outside X, in that orientation
-//                tag: 32 - lines_log2 bits of h(X)
+//                tag: the low bits of h(X) that tell the 16-mers of one line apart
 //                id : the k-mer's counter id }                                  8 bytes, 16 per 128-byte line
 //     slot   = j' (0..11); a second k-mer with the same (line, j') -- the other allele, another X of the line -- takes one of
 //              the spill slots 12..15, then the next line (a lookup goes on to the next line only when all four spill
@@ -34,7 +34,7 @@ namespace vgk {
 // ---- build ----------------------------------------------------------------------------------------------------------
 __global__ void xtable_clear_kernel(XTableView t)
 {
-    const uint64_t n = 16ULL << t.lines_log2;
+    const uint64_t n = 16ULL * t.n_lines;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) t.lines[i] = XT_EMPTY;
 }
@@ -51,7 +51,6 @@ __global__ void xtable_insert_kernel(XTableView t, const unsigned long long* slo
     uint64_t line, want;
     xt_key(t, kmer, w, line, want);
     const uint64_t id = id_of_key ? id_of_key[i] : i;
-    const uint64_t line_mask = (1ULL << t.lines_log2) - 1;
     auto insert = [&](uint64_t ln, uint64_t wnt) {
         const unsigned long long e = wnt | id << t.id_shift;
         const uint32_t j = (uint32_t)wnt & 15u;
@@ -60,7 +59,7 @@ __global__ void xtable_insert_kernel(XTableView t, const unsigned long long* slo
             if (atomicCAS(&L[j], XT_EMPTY, e) == XT_EMPTY) return;
             for (uint32_t s = 12; s < 16; ++s)
                 if (atomicCAS(&L[s], XT_EMPTY, e) == XT_EMPTY) return;
-            ln = (ln + 1) & line_mask;
+            ln = ln + 1 == t.n_lines ? 0 : ln + 1;
         }
         atomicOr(status, 8u);    // cannot happen at the load the host sizes the table for
     };
@@ -228,7 +227,7 @@ __global__ __launch_bounds__(256) void count27x_kernel(RowParams p, XTableView x
     // A drain step ISSUES the first-slot loads of up to 5 runs x 12 windows and FINISHES the batch the previous step
     // issued (compare, spill slots, atomic): the loads of a batch have a whole step to arrive (the kernel is bound by
     // memory round trips, not instructions).  finish-only when nothing is queued.
-    const uint64_t key_mask = (1ULL << xt.id_shift) - 1, line_mask = (1ULL << xt.lines_log2) - 1;
+    const uint64_t key_mask = (1ULL << xt.id_shift) - 1;
     uint64_t p_line = 0, p_want = 0;
     unsigned long long p_e = XT_EMPTY;
     bool p_act = false;
@@ -264,7 +263,7 @@ __global__ __launch_bounds__(256) void count27x_kernel(RowParams p, XTableView x
                     else if (((sp[k] ^ p_want) & key_mask) == 0) hit = sp[k];
                 }
                 if (hit != XT_EMPTY || !full) break;
-                ln = (ln + 1) & line_mask;
+                ln = ln + 1 == xt.n_lines ? 0 : ln + 1;
                 const unsigned long long nx = xt.lines[(ln << 4) + ((uint32_t)p_want & 15u)];
                 if (nx == XT_EMPTY) break;
                 if (((nx ^ p_want) & key_mask) == 0) hit = nx;
