@@ -68,9 +68,6 @@ struct vgmi_ctx {
     TableView tv{};
     uint32_t* d_key_slot = nullptr;
     uint64_t xt_bytes_since_clamp = 0;
-    void* d_xp_lines = nullptr;                 // scratch of the partitioned variant (VGMI_XPART=1): run records binned by filter slice
-    uint32_t* d_xp_n = nullptr;
-    size_t xp_lines_bytes = 0;
     unsigned long long* d_xt_lines = nullptr;   // table keyed by the grid 16-mer (vgmi_xtable.hip), VGMI_XTABLE=1
     uint32_t* d_xt_counts = nullptr;
     uint32_t* d_xt_id = nullptr;                // key index -> counter id (path order), nullptr: identity
@@ -173,11 +170,6 @@ void free_table(vgmi_ctx* c)
     if (c->d_xt_lines) (void)hipFree(c->d_xt_lines);
     if (c->d_xt_counts) (void)hipFree(c->d_xt_counts);
     if (c->d_xt_id) (void)hipFree(c->d_xt_id);
-    if (c->d_xp_lines) (void)hipFree(c->d_xp_lines);
-    if (c->d_xp_n) (void)hipFree(c->d_xp_n);
-    c->d_xp_lines = nullptr;
-    c->d_xp_n = nullptr;
-    c->xp_lines_bytes = 0;
     c->d_xt_lines = nullptr;
     c->d_xt_counts = nullptr;
     c->d_xt_id = nullptr;
@@ -392,32 +384,6 @@ int xt_clamp_if_due(vgmi_ctx* c, size_t n_bytes, hipStream_t st)
     return VGMI_OK;
 }
 
-// grid-16-mer table, complete rows of a block: one kernel, or -- main stream only, VGMI_XPART=1 -- scan + probe with the grid
-// probes partitioned by filter slice (vgmi_xtable.hip)
-int launch_x_rows(vgmi_ctx* c, const RowParams& p, size_t n_bytes, hipStream_t st)
-{
-    const char* e = getenv("VGMI_XPART");
-    if (!(e && e[0] == '1') || st != c->stream) {
-        HIPCHK(c, launch_count27x(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
-        return VGMI_OK;
-    }
-    const uint32_t scan_blocks = (uint32_t)c->n_cu * 2, n_streams = scan_blocks * 4 * 64;
-    const uint64_t records = n_bytes / 12 + 64;
-    const uint32_t cap_lines = (uint32_t)(records / n_streams / 8 * 13 / 10) + 16;
-    const size_t need = (size_t)n_streams * cap_lines * 128;
-    if (need > c->xp_lines_bytes) {
-        HIPCHK(c, hipStreamSynchronize(st));
-        if (c->d_xp_lines) (void)hipFree(c->d_xp_lines);
-        c->d_xp_lines = nullptr;
-        c->xp_lines_bytes = 0;
-        HIPCHK(c, hipMalloc(&c->d_xp_lines, need));
-        c->xp_lines_bytes = need;
-    }
-    if (!c->d_xp_n) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xp_n), (size_t)n_streams * 4));
-    HIPCHK(c, launch_count27x_partitioned(p, c->tv.xt, c->d_xp_lines, c->d_xp_n, scan_blocks, cap_lines, (uint32_t)c->n_cu * 8, st));
-    return VGMI_OK;
-}
-
 RowParams row_params(vgmi_ctx* c, const char* d_bases, size_t n_bytes, uint32_t k)
 {
     RowParams p{};
@@ -463,8 +429,7 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
         if (c->tv.xt.lines && !c->force_generic) {
             int rcx = xt_clamp_if_due(c, n_bytes, st);
             if (rcx) return rcx;
-            rcx = launch_x_rows(c, p, n_bytes, st);
-            if (rcx) return rcx;
+            HIPCHK(c, launch_count27x(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
             p.tail27 = 2;
             HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, 1, block, st));
         } else if (c->fast27 && !c->force_generic) {
@@ -487,8 +452,7 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
             int rcx = xt_clamp_if_due(c, n_bytes, st);
             if (rcx) return rcx;
             if (rows) {
-                rcx = launch_x_rows(c, p, n_bytes, st);
-                if (rcx) return rcx;
+                HIPCHK(c, launch_count27x(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
                 emit_from = rows * 768 - 1;
             }
             if (emit_from < n_bytes) {

@@ -123,8 +123,6 @@ hipError_t launch_xtable_number(const XTableView& t, const unsigned long long* s
                                 uint32_t* link2, uint32_t* id_of_key, unsigned long long* cursor, uint32_t* mark, uint32_t* status,
                                 hipStream_t st);
 hipError_t launch_count27x(const RowParams& p, const XTableView& t, uint32_t grid, hipStream_t st);
-hipError_t launch_count27x_partitioned(const RowParams& p, const XTableView& t, void* scratch_lines, uint32_t* scratch_n, uint32_t scan_blocks,
-                                       uint32_t cap_lines, uint32_t probe_blocks, hipStream_t st);
 hipError_t launch_xclamp(const XTableView& t, uint64_t n, hipStream_t st);
 hipError_t launch_xcov(const XTableView& t, const uint32_t* id_of_key, uint64_t n, const uint8_t* flag, uint8_t* cov, unsigned long long* hist,
                        hipStream_t st);

@@ -181,96 +181,57 @@ hipError_t launch_xtable_number(const XTableView& t, const unsigned long long* s
 }
 
 // ---- counting ---------------------------------------------------------------------------------------------------------
-// Front end shared by the kernels below: a wavefront walks complete 768-byte rows, a lane owns 12 bytes and one grid
-// position per row (count27_kernel::scan_probe, vgmi_kernels.hip, has the derivation of every constant).
-struct XRow {
-    uint32_t d0, d1, d2;    // the run: 76 bits of bases (q 9..46) | 12-bit window mask << 12 in d2
-    uint32_t mer;           // the grid 16-mer (q 20..35)
-    uint32_t vm;            // windows whose 27 bases are all bases
-    bool ok;                // the 16-mer itself has no non-base and some window is valid
-};
+typedef __attribute__((address_space(3))) const uint16_t xlds_u16;
 
-struct XWalk {
-    const uint16_t* lut;
-    uint32_t lane;
-    uint32_t pr1_be = 0, pr2_be = 0, pr3_be = 0, pr1_inv = 0xFFFu, pr2_inv = 0xFFFu, pr3_inv = 0xFFFu;
-
-    __device__ __forceinline__ uint32_t enc4(uint32_t w, uint32_t set) const
-    {
-        return (uint32_t)lut[set * 1024u + (w & 0xFFu)] | lut[set * 1024u + 256u + ((w >> 8) & 0xFFu)] |
-               lut[set * 1024u + 512u + ((w >> 16) & 0xFFu)] | lut[set * 1024u + 768u + (w >> 24)];
-    }
-    static __device__ __forceinline__ uint32_t ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xF, 0xF, false); }
-
-    // one row's 12 bytes of this lane -> its run; `inv_out` / `i1_out` feed the empty-read check
-    __device__ __forceinline__ XRow step(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t& inv_out, uint32_t& i1_out)
-    {
-        const uint32_t g0 = enc4(w0, 0), g1 = enc4(w1, 1), g2 = enc4(w2, 0);
-        const uint32_t be = (g0 & 0xFFu) << 16 | (g1 & 0xFFu) << 8 | (g2 & 0xFFu);
-        const uint32_t inv = ((g0 | g1) >> 8) | (g2 & 0xF00u);       // g0: bits 8..11 -> 0..3, g1: 12..15 -> 4..7, g2: 8..11
-        const uint32_t a1_be = ror1(be), a1_inv = ror1(inv);
-        const uint32_t a2_be = ror1(a1_be), a2_inv = ror1(a1_inv);
-        const uint32_t a3_be = ror1(a2_be), a3_inv = ror1(a2_inv);
-        const uint32_t be1 = lane >= 1 ? a1_be : pr1_be, be2 = lane >= 2 ? a2_be : pr2_be, be3 = lane >= 3 ? a3_be : pr3_be;
-        const uint32_t i1 = lane >= 1 ? a1_inv : pr1_inv, i2 = lane >= 2 ? a2_inv : pr2_inv, i3 = lane >= 3 ? a3_inv : pr3_inv;
-        pr1_be = a1_be; pr2_be = a2_be; pr3_be = a3_be; pr1_inv = a1_inv; pr2_inv = a2_inv; pr3_inv = a3_inv;
-        const uint32_t W0 = (be1 << 24) | be, W1 = (be2 << 16) | (be1 >> 8), W2 = (be3 << 8) | (be2 >> 16);
-        const uint32_t B = (i3 >> 9) | (i2 << 3) | (i1 << 15);
-        const uint32_t a = (inv << 1) & 0xFFFu;
-        const uint32_t bad_b = B ? (0xFFFFFFFFu >> __builtin_clz(B)) : 0u;
-        XRow r;
-        r.vm = ~(a | (0u - a) | bad_b) & 0xFFFu;
-        r.ok = B < 2048u && r.vm != 0;
-        r.mer = __builtin_amdgcn_alignbit(W1, W0, 24);
-        r.d0 = __builtin_amdgcn_alignbit(W1, W0, 2);
-        r.d1 = __builtin_amdgcn_alignbit(W2, W1, 2);
-        r.d2 = (W2 >> 2) & 0xFFFu;
-        inv_out = inv;
-        i1_out = i1;
-        return r;
-    }
-};
-
-__device__ __forceinline__ void x_stage_lut(uint16_t* s_lut)
+__global__ __launch_bounds__(256) void count27x_kernel(RowParams p, XTableView xt)
 {
-    for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) {
+    constexpr uint32_t MASK_HI = (1u << (2 * 27 - 32)) - 1;
+    __shared__ __attribute__((aligned(16))) uint16_t s_lut[2048];     // position LUT of count27_kernel (stage_lut27 layout)
+    __shared__ __attribute__((aligned(16))) uint4 s_runs[4][XT_RUNQ];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    for (uint32_t i = tid; i < 2048; i += blockDim.x) {
         const uint32_t set = i >> 10, b = (i >> 8) & 3u, c = vg_nt4(i & 255u);
         s_lut[i] = (uint16_t)(((c & 3u) << (2 * (3 - b))) | ((c >> 2) << ((set ? 12 : 8) + b)));
     }
     __syncthreads();
-}
+    uint4* const runs = s_runs[wave];
 
-__device__ __forceinline__ void x_empty_read_check(const RowParams& p, uint64_t r, uint32_t lane, uint32_t inv, uint32_t i1)
-{
-    // reference: assert(len > 0), src/kmer.cpp:124 -- two adjacent non-bases are necessary; exact test on the bytes
-    const uint32_t adj = inv & ((inv << 1) | (i1 >> 11));
-    if (__builtin_expect(__ballot(adj != 0) != 0, 0) && adj) {
-        const uint64_t base_off = r * 768 + lane * 12u;
-        for (uint32_t t = 0; t < 12; ++t) {
-            if (!((adj >> t) & 1u)) continue;
-            const uint64_t o = base_off + t;
-            if (p.bases[o] == '\n' && (o == 0 || p.bases[o - 1] == '\n')) atomicOr(p.status, 1u);
-        }
-    }
-}
+    const uint64_t n_bytes = p.n_bytes_dev ? *p.n_bytes_dev : p.n_bytes;
+    const uint64_t total_rows = n_bytes / 768;            // complete rows; the ragged tail goes to rows_kernel (launch_count)
+    const uint64_t total_waves = (uint64_t)gridDim.x * 4;
+    const uint64_t rpw = (total_rows + total_waves - 1) / total_waves;
+    const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t r0 = gw * rpw;
+    const uint64_t r1 = r0 + rpw < total_rows ? r0 + rpw : total_rows;
+    if (r0 >= r1) return;
 
-// Back end shared by the kernels below: candidate runs queue in an LDS ring; a drain step ISSUES the first-slot loads of
-// up to 5 runs x 12 windows and FINISHES the batch the previous step issued (compare, spill slots, atomic).
-struct XDrain {
-    XTableView xt;
-    uint4* runs;
-    uint32_t lane, my_run, my_win;
+    const uint32_t* const grid = p.table.grid;
+    const uint32_t gwl = p.table.grid_words_log2;
+    const uint32_t my_run = lane / 12u, my_win = lane % 12u;
     uint32_t run_head = 0, run_n = 0;
+    auto ring = [](uint32_t pos) -> uint32_t { return pos >= XT_RUNQ ? pos - XT_RUNQ : pos; };
+
+    // 12 ASCII bytes -> 24 bits of bases (first base most significant) + 12 non-base flags
+    auto encode12 = [&](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t& be, uint32_t& inv) {
+        auto enc4 = [&](uint32_t w, uint32_t set) -> uint32_t {
+            return (uint32_t)s_lut[set * 1024u + (w & 0xFFu)] | s_lut[set * 1024u + 256u + ((w >> 8) & 0xFFu)] |
+                   s_lut[set * 1024u + 512u + ((w >> 16) & 0xFFu)] | s_lut[set * 1024u + 768u + (w >> 24)];
+        };
+        const uint32_t g0 = enc4(w0, 0), g1 = enc4(w1, 1), g2 = enc4(w2, 0);
+        be = (g0 & 0xFFu) << 16 | (g1 & 0xFFu) << 8 | (g2 & 0xFFu);
+        inv = ((g0 | g1) >> 8) | (g2 & 0xF00u);       // g0: bits 8..11 -> 0..3, g1: 12..15 -> 4..7, g2: 8..11
+    };
+    auto ror1 = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xF, 0xF, false); };
+
+    // A drain step ISSUES the first-slot loads of up to 5 runs x 12 windows and FINISHES the batch the previous step
+    // issued (compare, spill slots, atomic): the loads of a batch have a whole step to arrive (the kernel is bound by
+    // memory round trips, not instructions).  finish-only when nothing is queued.
+    const uint64_t key_mask = (1ULL << xt.id_shift) - 1;
     uint64_t p_line = 0, p_want = 0;
     unsigned long long p_e = XT_EMPTY;
     bool p_act = false;
-
-    static __device__ __forceinline__ uint32_t ring(uint32_t pos) { return pos >= XT_RUNQ ? pos - XT_RUNQ : pos; }
-
-    __device__ __forceinline__ void step()
-    {
-        constexpr uint32_t MASK_HI = (1u << (2 * 27 - 32)) - 1;
-        const uint64_t key_mask = (1ULL << xt.id_shift) - 1;
+    auto drain = [&]() {
         // ---- issue
         const uint32_t take = run_n < 5u ? run_n : 5u;
         const bool have = my_run < take;
@@ -314,63 +275,12 @@ struct XDrain {
         p_e = e;
         p_want = want;
         p_line = line;
-    }
+    };
 
-    // the runs of the lanes in `ball` (this lane's: d0, d1, d2 | vm << 12) go on the ring
-    __device__ __forceinline__ void push(bool cand, uint32_t d0, uint32_t d1, uint32_t d2vm)
-    {
-        const uint64_t ball = __ballot(cand);
-        const uint32_t n = (uint32_t)__builtin_popcountll(ball);
-        while (run_n + n > XT_RUNQ) step();
-        if (cand) {
-            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
-            runs[ring(run_head + run_n + pos)] = make_uint4(d0, d1, d2vm, 0u);
-        }
-        run_n += n;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    __device__ __forceinline__ void flush()
-    {
-        while (run_n) step();
-        step();     // finishes the last batch (issues nothing)
-    }
-};
-
-// filter word of a grid 16-mer: which windows of the run are candidates (0: none)
-__device__ __forceinline__ uint32_t x_filter(const uint2 g, uint32_t gm, uint32_t rot, bool as_is, uint32_t vm)
-{
-    const uint32_t rr = __builtin_amdgcn_alignbit(g.y, g.y, rot);
-    vm &= as_is ? rr : (__builtin_bitreverse32(rr) >> 20);
-    return (g.x & gm) == gm ? vm : 0u;
-}
-
-// One kernel does it all (the default): rows -> filter probe in HBM -> table.
-__global__ __launch_bounds__(256) void count27x_kernel(RowParams p, XTableView xt)
-{
-    __shared__ __attribute__((aligned(16))) uint16_t s_lut[2048];     // position LUT of count27_kernel (stage_lut27 layout)
-    __shared__ __attribute__((aligned(16))) uint4 s_runs[4][XT_RUNQ];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    x_stage_lut(s_lut);
-
-    const uint64_t n_bytes = p.n_bytes_dev ? *p.n_bytes_dev : p.n_bytes;
-    const uint64_t total_rows = n_bytes / 768;            // complete rows; the ragged tail goes to rows_kernel (launch_count)
-    const uint64_t total_waves = (uint64_t)gridDim.x * 4;
-    const uint64_t rpw = (total_rows + total_waves - 1) / total_waves;
-    const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave;
-    const uint64_t r0 = gw * rpw;
-    const uint64_t r1 = r0 + rpw < total_rows ? r0 + rpw : total_rows;
-    if (r0 >= r1) return;
-
-    const uint32_t* const grid = p.table.grid;
-    const uint32_t gwl = p.table.grid_words_log2;
-    XWalk walk{s_lut, lane};
-    XDrain dr{xt, s_runs[wave], lane, lane / 12u, lane % 12u};
-
+    // halo: the row in front of the range
+    uint32_t pr1_be = 0, pr2_be = 0, pr3_be = 0, pr1_inv = 0xFFFu, pr2_inv = 0xFFFu, pr3_inv = 0xFFFu;
     const uint8_t* const bases = p.bases;
-    const uint64_t rs = r0 > 0 ? r0 - 1 : r0;      // the row in front of the range: halo only
+    const uint64_t rs = r0 > 0 ? r0 - 1 : r0;
     auto load_row = [&](uint64_t r, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(bases + r * 768 + lane * 12u);
         w0 = __builtin_nontemporal_load(src);
@@ -381,183 +291,59 @@ __global__ __launch_bounds__(256) void count27x_kernel(RowParams p, XTableView x
     load_row(rs, n0, n1, n2);
     for (uint64_t r = rs; r < r1; ++r) {
         const uint32_t w0 = n0, w1 = n1, w2 = n2;
+        uint32_t be, inv;
+        encode12(w0, w1, w2, be, inv);
+        const uint32_t a1_be = ror1(be), a1_inv = ror1(inv);
+        const uint32_t a2_be = ror1(a1_be), a2_inv = ror1(a1_inv);
+        const uint32_t a3_be = ror1(a2_be), a3_inv = ror1(a2_inv);
+        const uint32_t be1 = lane >= 1 ? a1_be : pr1_be, be2 = lane >= 2 ? a2_be : pr2_be, be3 = lane >= 3 ? a3_be : pr3_be;
+        const uint32_t i1 = lane >= 1 ? a1_inv : pr1_inv, i2 = lane >= 2 ? a2_inv : pr2_inv, i3 = lane >= 3 ? a3_inv : pr3_inv;
+        pr1_be = a1_be; pr2_be = a2_be; pr3_be = a3_be; pr1_inv = a1_inv; pr2_inv = a2_inv; pr3_inv = a3_inv;
         if (r + 1 < r1) load_row(r + 1, n0, n1, n2);     // the next row is in flight while this one is worked on
-        uint32_t inv, i1;
-        const XRow x = walk.step(w0, w1, w2, inv, i1);
-        if (r < r0) continue;
-        x_empty_read_check(p, r, lane, inv, i1);
+        if (r < r0) continue;      // warm-up row: halo only
+
+        {   // empty-read check (reference: assert(len > 0), src/kmer.cpp:124): two adjacent non-bases are necessary
+            const uint32_t adj = inv & ((inv << 1) | (i1 >> 11));
+            if (__builtin_expect(__ballot(adj != 0) != 0, 0) && adj) {
+                const uint64_t base_off = r * 768 + lane * 12u;
+                for (uint32_t t = 0; t < 12; ++t) {
+                    if (!((adj >> t) & 1u)) continue;
+                    const uint64_t o = base_off + t;
+                    if (bases[o] == '\n' && (o == 0 || bases[o - 1] == '\n')) atomicOr(p.status, 1u);
+                }
+            }
+        }
+        // 48-base window (see count27_kernel::scan_probe): q 36..47 own chunk, 0..35 the three chunks before
+        const uint32_t W0 = (be1 << 24) | be, W1 = (be2 << 16) | (be1 >> 8), W2 = (be3 << 8) | (be2 >> 16);
+        const uint32_t B = (i3 >> 9) | (i2 << 3) | (i1 << 15);
+        const uint32_t a = (inv << 1) & 0xFFFu;
+        const uint32_t bad_b = B ? (0xFFFFFFFFu >> __builtin_clz(B)) : 0u;
+        uint32_t vm = ~(a | (0u - a) | bad_b) & 0xFFFu;
+        const bool ok16 = B < 2048u;
+        const uint32_t mer = __builtin_amdgcn_alignbit(W1, W0, 24);
         uint64_t gx;
         uint32_t gm, rot;
         bool as_is;
-        vg_grid_probe(x.mer, gwl, gx, gm, rot, as_is);
+        vg_grid_probe(mer, gwl, gx, gm, rot, as_is);
         const uint2 g = reinterpret_cast<const uint2*>(grid)[gx];     // issued here ...
-        while (dr.run_n >= 5u) dr.step();                               // ... and in flight while the queued runs are looked up
-        const uint32_t vm = x.ok ? x_filter(g, gm, rot, as_is, x.vm) : 0u;
-        dr.push(vm != 0, x.d0, x.d1, x.d2 | vm << 12);
-    }
-    dr.flush();
-}
-
-// ---- the same in two kernels, grid probes partitioned by filter slice (VGMI_XPART=1) ---------------------------------------
-// The 12.6 filter words per read are what is left of the request count, and they are L2 misses only
-// because the filter (128 MiB at chr20 class) is 32 x an XCD's L2.  xscan_kernel does the front end and bins every run
-// by the top bits of its filter index into XP_PARTS streams per wavefront (16-byte records, eight to a 128-byte line, whole
-// lines written); xprobe_kernel takes one partition at a time, all workgroups of an XCD the same one, so that the slice
-// of the filter it touches (1/64) stays in that XCD's L2 (tools/ubench_mem3: 75-140 G probes/s next to a stream, against
-// 51 G/s from HBM), and feeds the same table.  A stream that is full hands its records to the one-kernel path inline.
-#define XP_PARTS 64u
-#define XP_LOG2 6u
-
-struct XPartView {
-    uint4* lines;            // [n_scan_waves][XP_PARTS][cap_lines] lines of 8 records {d0, d1, d2 | vm << 12, mer}
-    uint32_t* n_lines;       // [n_scan_waves][XP_PARTS]
-    uint32_t n_scan_waves, cap_lines;
-};
-
-__global__ __launch_bounds__(256) void xscan_kernel(RowParams p, XTableView xt, XPartView pv)
-{
-    __shared__ __attribute__((aligned(16))) uint16_t s_lut[2048];
-    __shared__ __attribute__((aligned(16))) uint4 s_bins[4][XP_PARTS][8];
-    __shared__ uint32_t s_cnt[4][XP_PARTS];
-    __shared__ __attribute__((aligned(16))) uint4 s_runs[4][XT_RUNQ];      // inline path of an overflowing stream
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    x_stage_lut(s_lut);
-    s_cnt[wave][lane] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-    __builtin_amdgcn_wave_barrier();
-    const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave;      // == stream owner index, < pv.n_scan_waves
-    uint4* const my_lines = pv.lines + (gw * XP_PARTS + lane) * (uint64_t)pv.cap_lines * 8;   // lane = the bin this lane owns
-    uint32_t my_n = 0;
-
-    const uint64_t n_bytes = p.n_bytes_dev ? *p.n_bytes_dev : p.n_bytes;
-    const uint64_t total_rows = n_bytes / 768;
-    const uint64_t total_waves = (uint64_t)gridDim.x * 4;
-    const uint64_t rpw = (total_rows + total_waves - 1) / total_waves;
-    const uint64_t r0 = gw * rpw;
-    const uint64_t r1 = r0 + rpw < total_rows ? r0 + rpw : total_rows;
-
-    const uint32_t* const grid = p.table.grid;
-    const uint32_t gwl = p.table.grid_words_log2;
-    XWalk walk{s_lut, lane};
-    XDrain dr{xt, s_runs[wave], lane, lane / 12u, lane % 12u};
-    uint4 (*bins)[8] = s_bins[wave];
-    uint32_t* cnt = s_cnt[wave];
-
-    // bin owner: a full bin leaves as one 128-byte line; a full stream hands the eight runs to the one-kernel path
-    auto flush_bins = [&](uint32_t min_fill) {
-        const uint32_t c = cnt[lane];
-        const bool full = c >= min_fill && c > 0;
-        if (!__ballot(full)) return;
-        uint4 rec[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) rec[k] = bins[lane][k];
-        const uint32_t have = c < 8u ? c : 8u;
-        const bool to_stream = full && my_n < pv.cap_lines;
-        if (to_stream) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) my_lines[(uint64_t)my_n * 8 + k] = (uint32_t)k < have ? rec[k] : make_uint4(0, 0, 0, 0);
-            ++my_n;
+        while (run_n >= 5u) drain();                                    // ... and in flight while the queued runs are looked up
+        const uint32_t rr = __builtin_amdgcn_alignbit(g.y, g.y, rot);
+        vm &= as_is ? rr : (__builtin_bitreverse32(rr) >> 20);
+        const bool cand = ok16 && (g.x & gm) == gm && vm != 0;
+        const uint64_t ball = __ballot(cand);
+        const uint32_t n = (uint32_t)__builtin_popcountll(ball);
+        while (run_n + n > XT_RUNQ) drain();
+        if (cand) {
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
+            runs[ring(run_head + run_n + pos)] =
+                make_uint4(__builtin_amdgcn_alignbit(W1, W0, 2), __builtin_amdgcn_alignbit(W2, W1, 2), ((W2 >> 2) & 0xFFFu) | (vm << 12), 0u);
         }
-        if (full) cnt[lane] = 0;
-        // overflowing streams (rare: an adversarial block whose grid 16-mers all hash to one slice): filter + table right here
-        if (__builtin_expect(__ballot(full && !to_stream) != 0, 0)) {
-            for (uint32_t k = 0; k < 8; ++k) {
-                const bool mine = full && !to_stream && k < have;
-                uint32_t vm = 0;
-                if (mine) {
-                    uint64_t gx;
-                    uint32_t gm, rot;
-                    bool as_is;
-                    vg_grid_probe(rec[k].w, gwl, gx, gm, rot, as_is);
-                    vm = x_filter(reinterpret_cast<const uint2*>(grid)[gx], gm, rot, as_is, rec[k].z >> 12);
-                }
-                dr.push(vm != 0, rec[k].x, rec[k].y, (rec[k].z & 0xFFFu) | vm << 12);
-            }
-        }
+        run_n += n;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
-    };
-
-    if (r0 < r1) {
-        const uint8_t* const bases = p.bases;
-        const uint64_t rs = r0 > 0 ? r0 - 1 : r0;
-        auto load_row = [&](uint64_t r, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(bases + r * 768 + lane * 12u);
-            w0 = __builtin_nontemporal_load(src);
-            w1 = __builtin_nontemporal_load(src + 1);
-            w2 = __builtin_nontemporal_load(src + 2);
-        };
-        uint32_t n0, n1, n2;
-        load_row(rs, n0, n1, n2);
-        for (uint64_t r = rs; r < r1; ++r) {
-            const uint32_t w0 = n0, w1 = n1, w2 = n2;
-            if (r + 1 < r1) load_row(r + 1, n0, n1, n2);
-            uint32_t inv, i1;
-            const XRow x = walk.step(w0, w1, w2, inv, i1);
-            if (r < r0) continue;
-            x_empty_read_check(p, r, lane, inv, i1);
-            uint64_t gx;
-            uint32_t gm, rot;
-            bool as_is;
-            vg_grid_probe(x.mer, gwl, gx, gm, rot, as_is);
-            const uint32_t part = (uint32_t)(gx >> (gwl - XP_LOG2));
-            const uint4 rec = make_uint4(x.d0, x.d1, x.d2 | x.vm << 12, x.mer);
-            bool pending = x.ok;
-            while (__ballot(pending)) {
-                if (pending) {
-                    const uint32_t pos = atomicAdd(&cnt[part], 1u);
-                    if (pos < 8u) {
-                        bins[part][pos] = rec;
-                        pending = false;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-                __builtin_amdgcn_wave_barrier();
-                flush_bins(8);
-            }
-        }
     }
-    flush_bins(1);          // what is left, padded with empty records
-    dr.flush();
-    pv.n_lines[gw * XP_PARTS + lane] = my_n;
-}
-
-// workgroup b takes the partitions p with p % 8 == b % 8 (workgroup b runs on XCD b % 8: observed, used for speed only),
-// in ascending order, and inside a partition the scan wavefronts' streams round-robin among the XCD's wavefronts
-__global__ __launch_bounds__(256) void xprobe_kernel(RowParams p, XTableView xt, XPartView pv)
-{
-    __shared__ __attribute__((aligned(16))) uint4 s_runs[4][XT_RUNQ];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t xcd = blockIdx.x & 7u;
-    const uint32_t w_in_xcd = (blockIdx.x >> 3) * 4 + wave, n_in_xcd = (gridDim.x >> 3) * 4;
-    const uint32_t* const grid = p.table.grid;
-    const uint32_t gwl = p.table.grid_words_log2;
-    XDrain dr{xt, s_runs[wave], lane, lane / 12u, lane % 12u};
-    for (uint32_t part = xcd; part < XP_PARTS; part += 8) {
-        for (uint32_t sw = w_in_xcd; sw < pv.n_scan_waves; sw += n_in_xcd) {
-            const uint32_t nl = pv.n_lines[sw * XP_PARTS + part];
-            const uint4* const src = pv.lines + ((uint64_t)sw * XP_PARTS + part) * pv.cap_lines * 8;
-            // 8 lines (64 records, 1 KiB) per step
-            for (uint32_t l0 = 0; l0 < nl; l0 += 8) {
-                const uint32_t idx = l0 * 8 + lane;
-                uint4 rec = make_uint4(0, 0, 0, 0);
-                if (idx < nl * 8) rec = src[idx];
-                const uint32_t vm0 = rec.z >> 12;
-                uint64_t gx;
-                uint32_t gm, rot;
-                bool as_is;
-                vg_grid_probe(rec.w, gwl, gx, gm, rot, as_is);
-                uint2 g = make_uint2(0, 0);
-                if (vm0) g = reinterpret_cast<const uint2*>(grid)[gx];      // the partition's slice of the filter: L2-resident
-                while (dr.run_n >= 5u) dr.step();
-                const uint32_t vm = vm0 ? x_filter(g, gm, rot, as_is, vm0) : 0u;
-                dr.push(vm != 0, rec.x, rec.y, (rec.z & 0xFFFu) | vm << 12);
-            }
-        }
-    }
-    dr.flush();
+    while (run_n) drain();
+    drain();     // finishes the last batch (issues nothing)
 }
 
 // K5 part 1 + K6 over dense counters: cov[i] = min(255, counts[id(i)]); hist[c] += 1 for flagged keys with c != 0
@@ -621,16 +407,6 @@ hipError_t launch_xtable_build(const XTableView& t, const unsigned long long* sl
 hipError_t launch_count27x(const RowParams& p, const XTableView& t, uint32_t grid, hipStream_t st)
 {
     hipLaunchKernelGGL(count27x_kernel, dim3(grid), dim3(256), 0, st, p, t);
-    return hipGetLastError();
-}
-
-// partitioned variant: scratch = n_scan_waves * 64 * cap_lines lines of 128 bytes + n_scan_waves * 64 counters
-hipError_t launch_count27x_partitioned(const RowParams& p, const XTableView& t, void* scratch_lines, uint32_t* scratch_n, uint32_t scan_blocks,
-                                       uint32_t cap_lines, uint32_t probe_blocks, hipStream_t st)
-{
-    XPartView pv{reinterpret_cast<uint4*>(scratch_lines), scratch_n, scan_blocks * 4, cap_lines};
-    hipLaunchKernelGGL(xscan_kernel, dim3(scan_blocks), dim3(256), 0, st, p, t, pv);
-    hipLaunchKernelGGL(xprobe_kernel, dim3(probe_blocks), dim3(256), 0, st, p, t, pv);
     return hipGetLastError();
 }
 
