@@ -41,8 +41,11 @@ struct InfTables {                 // per wavefront, in LDS
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 __device__ __forceinline__ uint64_t uni64(uint64_t v) { return (uint64_t)uni((uint32_t)(v >> 32)) << 32 | uni((uint32_t)v); }
-// a load every lane issues at the same address, its value handed to the scalar side
-__device__ __forceinline__ uint64_t ld64u(const uint64_t* p) { return uni64(*p); }
+// The compressed input is read with SCALAR loads (constant address space, wave-uniform address): they count on lgkmcnt,
+// so a refill never waits behind the byte stores of the output (a vector load's vmcnt(0) drained every store in flight:
+// one memory round trip per 8 input bytes, most of the kernel's time in its first version)
+typedef __attribute__((address_space(4))) const uint64_t inf_cu64;
+__device__ __forceinline__ uint64_t ld64u(const uint64_t* p) { return *reinterpret_cast<inf_cu64*>((uintptr_t)p); }
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t code, uint32_t len) { return __builtin_bitreverse32(code) >> (32 - len); }
 
