@@ -71,6 +71,10 @@ int vgmi_table_import(vgmi_ctx *ctx, const void *dev_src, size_t bytes);
  * is built once per run, not once per device. */
 int vgmi_table_clone(vgmi_ctx *dst, vgmi_ctx *src);
 int vgmi_table_info(vgmi_ctx *ctx, size_t *n_keys, uint32_t *k, size_t *n_slots, size_t *filter_bits);
+/* The k = 27 table of large graphs is keyed by the read's grid 16-mer: its number of 128-byte lines (0: not in
+ * use) and how many (k-mer, 16-mer) pairs found no room near their home line and are served by the exact overflow table
+ * (16-mers of repeats). Diagnostic only; no reference counterpart. */
+int vgmi_xtable_info(vgmi_ctx *ctx, size_t *n_lines, size_t *overflow_pairs);
 
 /* Per-node k-mer lists in CSR form.
  * replaces: nodeSrt::GraphKmerHashHapStrMapIterVec built by ConstructIndex::graph2node

@@ -535,6 +535,46 @@ def test_large_graph_grid_variant_matches_oracle(k, placement, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("crowded", [False, True], ids=["default-load", "crowded"])
+def test_repeat_rich_graph_matches_oracle(crowded, monkeypatch):
+    """A reference made of thousands of diverged copies of one 400-bp element: every 16-mer of the element sits in hundreds
+    of different graph k-mers, far more than the home line of the grid-16-mer table and the lines behind it hold.  Those
+    k-mers must be served by the exact overflow table, and nothing may be matched by (offset, flank, tag) alone."""
+    if crowded:
+        monkeypatch.setenv("VGMI_XTABLE_LOAD", "60")
+    from varigraph_amd import synth
+    rng = np.random.default_rng(99)
+    unit = synth.make_reference(400, seed=31)
+    copies = 6000
+    ref = np.tile(unit, copies)
+    mut = rng.random(ref.size) < 0.02                       # 2 % divergence between copies
+    ref[mut] = synth._ACGT[(synth._CODE[ref[mut]] + rng.integers(1, 4, size=int(mut.sum()))) % 4]
+    G = ref.size
+    V = 60_000
+    pos = np.sort(rng.choice(np.arange(100, G - 100), size=V, replace=False))
+    alts = synth._ACGT[(synth._CODE[ref[pos]] + rng.integers(1, 4, size=V)) % 4]
+    keys = np.unique(vgmi.synth_snp_keys(ref, pos, alts, 27))
+    assert keys.size > 300_000
+    hap1 = ref.copy()
+    hap1[pos] = alts
+    n_reads = 120_000
+    block = vgmi.synth_reads_host(11, 0, n_reads, 150, [ref, hap1])
+    c = vgmi.Context(0, buffer_mib=16)
+    try:
+        c.table_upload(keys, 27)
+        x = c.xtable_info()
+        assert x["n_lines"] > 0 and x["overflow_pairs"] > 1000, x
+        c.counts_reset()
+        c.reads_submit(block, n_reads)
+        cov, _, _ = c.counts_finish()
+        t = o.Table(keys)
+        t.count_block(block, 27)
+        assert np.array_equal(cov, t.counts())
+        assert int(cov.astype(np.int64).sum()) > 1_000_000
+    finally:
+        c.close()
+
+
 def test_make_mbf_matches_reference_whole_genome_bloom(ctx, tmp_path):
     """vgh_make_mbf (FASTA -> device Bloom, seeds as the reference draws them for the det build's
     random_device value) == the reference's build_fasta_index + make_mbf, byte for byte (sha256)."""

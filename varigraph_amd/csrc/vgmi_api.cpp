@@ -71,6 +71,8 @@ struct vgmi_ctx {
     unsigned long long* d_xt_lines = nullptr;   // table keyed by the grid 16-mer (vgmi_xtable.hip), VGMI_XTABLE=1
     uint32_t* d_xt_counts = nullptr;
     uint32_t* d_xt_id = nullptr;                // key index -> counter id (path order), nullptr: identity
+    ulonglong2* d_xt_over = nullptr;            // exact table of the k-mers that overflowed their lines (repeats), or nullptr
+    uint64_t xt_over_keys = 0;                  // pairs (key, 16-mer) that overflowed in the last build
     uint8_t* d_sat_dirty = nullptr;   // compact format: 2048-slot regions holding a saturation flag (the reset sweeps those)
     uint64_t n_sat_regions = 0;
     uint32_t* d_counts = nullptr;   // counter array (per-sample state, not part of the image): per key (large graphs)
@@ -170,6 +172,9 @@ void free_table(vgmi_ctx* c)
     if (c->d_xt_lines) (void)hipFree(c->d_xt_lines);
     if (c->d_xt_counts) (void)hipFree(c->d_xt_counts);
     if (c->d_xt_id) (void)hipFree(c->d_xt_id);
+    if (c->d_xt_over) (void)hipFree(c->d_xt_over);
+    c->d_xt_over = nullptr;
+    c->xt_over_keys = 0;
     c->d_xt_lines = nullptr;
     c->d_xt_counts = nullptr;
     c->d_xt_id = nullptr;
@@ -302,6 +307,54 @@ bool xtable_wanted(const ImageHeader& h)
     return !(e && e[0] == '0') && h.k == 27 && h.slot_bytes == 8 && h.n_keys > VG_GRID_LDS_MAX_KEYS;
 }
 
+// lines + overflow table of one numbering of the keys (id_of_key, or the key index).  The (key, 16-mer) pairs that find no
+// room within XT_HOPS lines of home are collected on a list (one pass that only counts when the list is too short, then
+// again with a list that fits), and their keys go into the exact overflow table.
+static int xtable_fill(vgmi_ctx* c, XTableView& x, const uint32_t* id_of_key)
+{
+    const uint64_t n = c->hdr.n_keys;
+    unsigned long long* d_n = nullptr;
+    uint32_t* d_list = nullptr;
+    uint64_t cap = 1u << 16;
+    hipError_t he = hipMalloc(reinterpret_cast<void**>(&d_n), 8);
+    unsigned long long n_over = 0;
+    for (int pass = 0; he == hipSuccess && pass < 2; ++pass) {
+        he = hipMalloc(reinterpret_cast<void**>(&d_list), cap * 4);
+        if (he == hipSuccess) he = hipMemsetAsync(d_n, 0, 8, c->stream);
+        if (he == hipSuccess) he = launch_xtable_build(x, c->tv.slots8, c->d_key_slot, id_of_key, n, d_list, (uint32_t)cap, d_n, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he == hipSuccess) he = hipMemcpy(&n_over, d_n, 8, hipMemcpyDeviceToHost);
+        if (he != hipSuccess || n_over <= cap) break;
+        // which pairs overflow depends on the order the threads arrive in: leave room
+        (void)hipFree(d_list);
+        d_list = nullptr;
+        cap = n_over + n_over / 4 + 1024;
+        if (cap >= (1ULL << 32)) {
+            (void)hipFree(d_n);
+            return fail(c, VGMI_E_NOMEM, "grid-16-mer table: too many k-mers of repeats");
+        }
+    }
+    if (he == hipSuccess && n_over > cap) he = hipErrorOutOfMemory;
+    if (c->d_xt_over) (void)hipFree(c->d_xt_over);
+    c->d_xt_over = nullptr;
+    x.over = nullptr;
+    x.over_mask = 0;
+    c->xt_over_keys = n_over;
+    if (he == hipSuccess && n_over) {
+        uint64_t slots = 1024;
+        while (slots < 2 * n_over) slots <<= 1;
+        he = hipMalloc(reinterpret_cast<void**>(&c->d_xt_over), slots * 16);
+        if (he == hipSuccess) he = launch_xtable_over(c->d_xt_over, (uint32_t)(slots - 1), c->tv.slots8, c->d_key_slot, id_of_key, d_list, n_over, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        x.over = c->d_xt_over;
+        x.over_mask = (uint32_t)(slots - 1);
+    }
+    if (d_list) (void)hipFree(d_list);
+    if (d_n) (void)hipFree(d_n);
+    HIPCHK(c, he);
+    return VGMI_OK;
+}
+
 int build_xtable(vgmi_ctx* c)
 {
     const ImageHeader& h = c->hdr;
@@ -317,25 +370,25 @@ int build_xtable(vgmi_ctx* c)
     if (n_lines < (1u << 20)) n_lines = 1u << 20;
     if (n_lines >= (1ULL << 31) || n_lines * 16 < h.n_keys * 13) return fail(c, VGMI_E_NOMEM, "not enough device memory for the grid-16-mer table");
     x.n_lines = (uint32_t)n_lines;
-    x.tag_bits = ceil_log2(((1ULL << 32) + n_lines - 1) / n_lines + 1);
+    // an entry found in line P has its home in P - XT_HOPS .. P: at most (XT_HOPS + 1) * ceil(2^32 / n_lines) + 1 consecutive
+    // h-values, told apart by their low tag_bits
+    x.tag_bits = ceil_log2((XT_HOPS + 1) * (((1ULL << 32) + n_lines - 1) / n_lines) + 1);
     x.id_shift = 26 + x.tag_bits;
     if (h.n_keys >= (1ULL << (64 - x.id_shift)) - 1) return fail(c, VGMI_E_INVALID, "too many keys for the grid-16-mer table");
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xt_lines), (size_t)128 * n_lines));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xt_lines), (size_t)128 * (n_lines + XT_HOPS)));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xt_counts), h.n_keys * 4));
     HIPCHK(c, hipMemsetAsync(c->d_xt_counts, 0, h.n_keys * 4, c->stream));
     x.lines = c->d_xt_lines;
     x.counts = c->d_xt_counts;
-    HIPCHK(c, launch_xtable_build(x, c->tv.slots8, c->d_key_slot, nullptr, h.n_keys, c->d_status, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    uint32_t st = 0;
-    HIPCHK(c, hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
-    if (st & 8u) return fail(c, VGMI_E_HIP, "grid-16-mer table overflow");
+    int rc = xtable_fill(c, x, nullptr);
+    if (rc != VGMI_OK) return rc;
     // counter ids in path order (xtable_number_*; any numbering is correct, VGMI_XTABLE_ORDER=0 keeps the key index)
     const char* ord = getenv("VGMI_XTABLE_ORDER");
     if (!(ord && ord[0] == '0')) {
         const uint64_t n = h.n_keys;
         uint32_t *link = nullptr, *link2 = nullptr, *mark = nullptr;
         unsigned long long* cursor = nullptr;
+        uint32_t st = 0;
         hipError_t he = hipMalloc(reinterpret_cast<void**>(&link), n * 8);
         if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&link2), n * 8);
         if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&mark), n * 4);
@@ -357,10 +410,8 @@ int build_xtable(vgmi_ctx* c)
             c->d_xt_id = nullptr;
             HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4, c->stream));
         } else {
-            HIPCHK(c, launch_xtable_build(x, c->tv.slots8, c->d_key_slot, c->d_xt_id, n, c->d_status, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            HIPCHK(c, hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
-            if (st & 8u) return fail(c, VGMI_E_HIP, "grid-16-mer table overflow");
+            rc = xtable_fill(c, x, c->d_xt_id);
+            if (rc != VGMI_OK) return rc;
         }
     }
     c->tv.xt = x;
@@ -751,6 +802,14 @@ int vgmi_table_clone(vgmi_ctx* dst, vgmi_ctx* src)
     rc = build_xtable(dst);
     if (rc) return rc;
     dst->read_base = 0;
+    return VGMI_OK;
+}
+
+int vgmi_xtable_info(vgmi_ctx* c, size_t* n_lines, size_t* overflow_pairs)
+{
+    if (!c) return VGMI_E_INVALID;
+    if (n_lines) *n_lines = c->tv.xt.lines ? c->tv.xt.n_lines : 0;
+    if (overflow_pairs) *overflow_pairs = c->tv.xt.lines ? c->xt_over_keys : 0;
     return VGMI_OK;
 }
 

@@ -11,12 +11,17 @@ namespace vgk {
 enum { K_MODE_COUNT = 0, K_MODE_KEYS = 1, K_MODE_BLOOM = 2 };
 
 // table keyed by the read's grid 16-mer (vgmi_xtable.hip): lines of 16 entries, dense counters by id
+#define XT_HOPS 3u          // a k-mer sits in its home line or one of the XT_HOPS lines behind it (the table ends in XT_HOPS lines of slack)
 struct XTableView {
-    unsigned long long* lines;   // 16 * n_lines entries, or nullptr: not in use
-    uint32_t n_lines;            // any number (not a power of two): line = (h(X) * n_lines) >> 32
-    uint32_t tag_bits;           // low bits of h(X) kept in the entry: 2^tag_bits >= the h-values one line covers, so (line, tag) is X
+    unsigned long long* lines;   // 16 * (n_lines + XT_HOPS) entries, or nullptr: not in use
+    uint32_t n_lines;            // home lines, any number (not a power of two): line = (h(X) * n_lines) >> 32
+    uint32_t tag_bits;           // low bits of h(X) kept in the entry: 2^tag_bits >= the h-values XT_HOPS + 1 consecutive lines
+                                 // cover, so an entry's (line it was found in, tag) is X
     uint32_t id_shift;           // 26 + tag_bits: entry = j' | f << 4 | tag << 26 | id << id_shift
     uint32_t* counts;            // n_keys
+    const ulonglong2* over;      // {canonical k-mer | XT_EMPTY, id} of the k-mers some 16-mer of which found no room
+                                 // (repeats), or nullptr: none
+    uint32_t over_mask;          // its capacity - 1 (a power of two)
 };
 
 struct TableView {
@@ -118,7 +123,9 @@ hipError_t launch_bgzf_inflate(const uint8_t* comp, const BgzfMember* members, u
                                const uint32_t* crc_table, BgzfVerdict* verdict, hipStream_t s);
 
 hipError_t launch_xtable_build(const XTableView& t, const unsigned long long* slots8, const uint32_t* key_slot, const uint32_t* id_of_key,
-                               uint64_t n_keys, uint32_t* status, hipStream_t st);
+                               uint64_t n_keys, uint32_t* over_list, uint32_t over_cap, unsigned long long* over_n, hipStream_t st);
+hipError_t launch_xtable_over(ulonglong2* over, uint32_t over_mask, const unsigned long long* slots8, const uint32_t* key_slot,
+                              const uint32_t* id_of_key, const uint32_t* over_list, uint64_t n_over, hipStream_t st);
 hipError_t launch_xtable_number(const XTableView& t, const unsigned long long* slots8, const uint32_t* key_slot, uint64_t n, uint32_t* link,
                                 uint32_t* link2, uint32_t* id_of_key, unsigned long long* cursor, uint32_t* mark, uint32_t* status,
                                 hipStream_t st);

@@ -13,8 +13,10 @@
 //                tag: the low bits of h(X) that tell the 16-mers of one line apart
 //                id : the k-mer's counter id }                                  8 bytes, 16 per 128-byte line
 //     slot   = j' (0..11); a second k-mer with the same (line, j') -- the other allele, another X of the line -- takes one of
-//              the spill slots 12..15, then the next line (a lookup goes on to the next line only when all four spill
-//              slots are taken).
+//              the spill slots 12..15, then slot j' / the spill slots of the next line, XT_HOPS lines at most (a lookup goes
+//              on to the next line only when all four spill slots are taken; tag covers the h-values of XT_HOPS + 1
+//              consecutive lines, so a match there is still exact).  16-mers of repeats, with more k-mers than that, send
+//              the k-mer to a small exact overflow table keyed by the k-mer itself.
 // A read position's grid 16-mer is one of those twelve for every k-mer that contains it, so a candidate run's twelve
 // lookups are ONE line (plus its spill slots) by construction, whatever strand the read is on: (tag, j', f) of a window
 // and of its reverse complement are the same triple.  Counters are dense by id; with ids numbered along the graph's
@@ -34,14 +36,17 @@ namespace vgk {
 // ---- build ----------------------------------------------------------------------------------------------------------
 __global__ void xtable_clear_kernel(XTableView t)
 {
-    const uint64_t n = 16ULL * t.n_lines;
+    const uint64_t n = 16ULL * ((uint64_t)t.n_lines + XT_HOPS);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) t.lines[i] = XT_EMPTY;
 }
 
-// one thread per (key, offset): canonical k-mers come from the compact table image (slots8[key_slot[i]])
+// one thread per (key, offset): canonical k-mers come from the compact table image (slots8[key_slot[i]]).  A pair that finds
+// its home line and the XT_HOPS lines behind it full (slot j' and the four spill slots of each) puts the key's index on
+// over_list: those keys go into the exact overflow table (xtable_over_kernel).  Slots never empty again, so a lookup that
+// follows the same rule sees the same full lines and ends in that table too.
 __global__ void xtable_insert_kernel(XTableView t, const unsigned long long* slots8, const uint32_t* key_slot, const uint32_t* id_of_key,
-                                     uint64_t n_keys, uint32_t* status)
+                                     uint64_t n_keys, uint32_t* over_list, uint32_t over_cap, unsigned long long* over_n)
 {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_keys * 12) return;
@@ -51,26 +56,52 @@ __global__ void xtable_insert_kernel(XTableView t, const unsigned long long* slo
     uint64_t line, want;
     xt_key(t, kmer, w, line, want);
     const uint64_t id = id_of_key ? id_of_key[i] : i;
-    auto insert = [&](uint64_t ln, uint64_t wnt) {
-        const unsigned long long e = wnt | id << t.id_shift;
+    auto insert = [&](uint64_t wnt) {
+        const unsigned long long e = (wnt & ((1ULL << t.id_shift) - 1)) | id << t.id_shift;
         const uint32_t j = (uint32_t)wnt & 15u;
-        for (uint32_t hop = 0; hop < 4096; ++hop) {
-            unsigned long long* L = t.lines + (ln << 4);
+        for (uint32_t hop = 0; hop <= XT_HOPS; ++hop) {
+            unsigned long long* L = t.lines + ((line + hop) << 4);
             if (atomicCAS(&L[j], XT_EMPTY, e) == XT_EMPTY) return;
             for (uint32_t s = 12; s < 16; ++s)
                 if (atomicCAS(&L[s], XT_EMPTY, e) == XT_EMPTY) return;
-            ln = ln + 1 == t.n_lines ? 0 : ln + 1;
         }
-        atomicOr(status, 8u);    // cannot happen at the load the host sizes the table for
+        const unsigned long long pos = atomicAdd(over_n, 1ULL);
+        if (pos < over_cap) over_list[pos] = (uint32_t)i;
     };
-    insert(line, want);
+    insert(want);
     // a 16-mer that is its own reverse complement reads the same on both strands, but the offset and the flank do not:
     // the other strand's window finds the k-mer under the mirrored pair
     const uint32_t x = (uint32_t)(kmer >> (2 * w));
     if (x == vg_revcomp16(x)) {
         const uint32_t j = (uint32_t)want & 15u, f = (uint32_t)(want >> 4) & 0x3FFFFFu;
-        const uint64_t mirrored = (want & ~0x3FFFFFFULL) | (uint64_t)(11u - j) | (uint64_t)((uint32_t)vg_revcomp(f, 11)) << 4;
-        insert(line, mirrored);
+        insert((want & ~0x3FFFFFFULL) | (uint64_t)(11u - j) | (uint64_t)((uint32_t)vg_revcomp(f, 11)) << 4);
+    }
+}
+
+// the overflow table: open addressing on the canonical k-mer, one entry per key however many of its pairs overflowed
+__global__ void xtable_over_clear_kernel(ulonglong2* over, uint32_t over_mask)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= over_mask) over[i] = make_ulonglong2(XT_EMPTY, 0ULL);
+}
+
+__global__ void xtable_over_kernel(ulonglong2* over, uint32_t over_mask, const unsigned long long* slots8, const uint32_t* key_slot,
+                                   const uint32_t* id_of_key, const uint32_t* over_list, uint64_t n_over)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_over) return;
+    const uint32_t i = over_list[g];
+    const unsigned long long kmer = slots8[key_slot[i]] & ((1ULL << 54) - 1);
+    uint32_t s = xt_over_hash(kmer) & over_mask;
+    for (;;) {
+        unsigned long long* cell = reinterpret_cast<unsigned long long*>(&over[s]);
+        const unsigned long long was = atomicCAS(cell, XT_EMPTY, kmer);
+        if (was == XT_EMPTY) {
+            cell[1] = id_of_key ? id_of_key[i] : i;
+            return;
+        }
+        if (was == kmer) return;      // another pair of the same key
+        s = (s + 1) & over_mask;
     }
 }
 
@@ -183,7 +214,7 @@ hipError_t launch_xtable_number(const XTableView& t, const unsigned long long* s
 // ---- counting ---------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) const uint16_t xlds_u16;
 
-__global__ __launch_bounds__(256) void count27x_kernel(RowParams p, XTableView xt)
+__global__ __launch_bounds__(256, 8) void count27x_kernel(RowParams p, XTableView xt)
 {
     constexpr uint32_t MASK_HI = (1u << (2 * 27 - 32)) - 1;
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[2048];     // position LUT of count27_kernel (stage_lut27 layout)
@@ -249,27 +280,13 @@ __global__ __launch_bounds__(256) void count27x_kernel(RowParams p, XTableView x
         if (act) e = xt.lines[(line << 4) + ((uint32_t)want & 15u)];
         // ---- finish the previous batch
         if (p_act && p_e != XT_EMPTY) {
-            unsigned long long hit = ((p_e ^ p_want) & key_mask) == 0 ? p_e : XT_EMPTY;
-            uint64_t ln = p_line;
-            while (hit == XT_EMPTY) {          // slot j' holds another k-mer: the spill slots, then the next line
-                const unsigned long long* L = xt.lines + (ln << 4);
-                const ulonglong2 s01 = *reinterpret_cast<const ulonglong2*>(L + 12);
-                const ulonglong2 s23 = *reinterpret_cast<const ulonglong2*>(L + 14);
-                const unsigned long long sp[4] = {s01.x, s01.y, s23.x, s23.y};
-                bool full = true;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (sp[k] == XT_EMPTY) full = false;
-                    else if (((sp[k] ^ p_want) & key_mask) == 0) hit = sp[k];
-                }
-                if (hit != XT_EMPTY || !full) break;
-                ln = ln + 1 == xt.n_lines ? 0 : ln + 1;
-                const unsigned long long nx = xt.lines[(ln << 4) + ((uint32_t)p_want & 15u)];
-                if (nx == XT_EMPTY) break;
-                if (((nx ^ p_want) & key_mask) == 0) hit = nx;
+            uint32_t id;
+            if (((p_e ^ p_want) & key_mask) == 0) id = (uint32_t)(p_e >> xt.id_shift);
+            else {          // slot j' holds another k-mer: spill slots, the lines behind, the overflow table
+                const unsigned long long r = xt_lookup_rest(xt, p_line, p_want, id);
+                if (r != XT_EMPTY) id = (uint32_t)(r >> xt.id_shift);
             }
-            if (hit != XT_EMPTY)
-                __hip_atomic_fetch_add(xt.counts + (hit >> xt.id_shift), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (id != 0xFFFFFFFFu) __hip_atomic_fetch_add(xt.counts + id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         p_act = act;
         p_e = e;
@@ -282,7 +299,11 @@ __global__ __launch_bounds__(256) void count27x_kernel(RowParams p, XTableView x
     const uint8_t* const bases = p.bases;
     const uint64_t rs = r0 > 0 ? r0 - 1 : r0;
     auto load_row = [&](uint64_t r, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(bases + r * 768 + lane * 12u);
+        // wave-uniform row base in scalar registers + a 32-bit lane offset: no 64-bit address held in vector registers
+        const uint64_t ro = r * 768;
+        const uint64_t rb = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ro) |
+                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ro >> 32)) << 32;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(bases + rb + lane * 12u);
         w0 = __builtin_nontemporal_load(src);
         w1 = __builtin_nontemporal_load(src + 1);
         w2 = __builtin_nontemporal_load(src + 2);
@@ -394,13 +415,24 @@ hipError_t launch_xclamp(const XTableView& t, uint64_t n, hipStream_t st)
 }
 
 hipError_t launch_xtable_build(const XTableView& t, const unsigned long long* slots8, const uint32_t* key_slot, const uint32_t* id_of_key,
-                               uint64_t n_keys, uint32_t* status, hipStream_t st)
+                               uint64_t n_keys, uint32_t* over_list, uint32_t over_cap, unsigned long long* over_n, hipStream_t st)
 {
     hipLaunchKernelGGL(xtable_clear_kernel, dim3(4096), dim3(256), 0, st, t);
     if (n_keys) {
         const uint64_t n = n_keys * 12;
-        hipLaunchKernelGGL(xtable_insert_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, t, slots8, key_slot, id_of_key, n_keys, status);
+        hipLaunchKernelGGL(xtable_insert_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, t, slots8, key_slot, id_of_key, n_keys,
+                           over_list, over_cap, over_n);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_xtable_over(ulonglong2* over, uint32_t over_mask, const unsigned long long* slots8, const uint32_t* key_slot,
+                              const uint32_t* id_of_key, const uint32_t* over_list, uint64_t n_over, hipStream_t st)
+{
+    hipLaunchKernelGGL(xtable_over_clear_kernel, dim3((over_mask + 256) / 256), dim3(256), 0, st, over, over_mask);
+    if (n_over)
+        hipLaunchKernelGGL(xtable_over_kernel, dim3((uint32_t)((n_over + 255) / 256)), dim3(256), 0, st, over, over_mask, slots8, key_slot, id_of_key,
+                           over_list, n_over);
     return hipGetLastError();
 }
 

@@ -42,6 +42,7 @@ def load_library():
         "vgmi_table_import": (i32, [vp, vp, sz]),
         "vgmi_table_clone": (i32, [vp, vp]),
         "vgmi_table_info": (i32, [vp, C.POINTER(sz), C.POINTER(u32), C.POINTER(sz), C.POINTER(sz)]),
+        "vgmi_xtable_info": (i32, [vp, C.POINTER(sz), C.POINTER(sz)]),
         "vgmi_nodes_upload": (i32, [vp, vp, vp, sz]),
         "vgmi_flags_upload": (i32, [vp, vp]),
         "vgmi_counts_reset": (i32, [vp]),
@@ -206,6 +207,11 @@ class Context:
         n, k, s, f = C.c_size_t(), C.c_uint32(), C.c_size_t(), C.c_size_t()
         self._chk(self._l.vgmi_table_info(self._h, C.byref(n), C.byref(k), C.byref(s), C.byref(f)))
         return {"n_keys": n.value, "k": k.value, "n_slots": s.value, "filter_bits": f.value}
+
+    def xtable_info(self):
+        n, o = C.c_size_t(), C.c_size_t()
+        self._chk(self._l.vgmi_xtable_info(self._h, C.byref(n), C.byref(o)))
+        return {"n_lines": n.value, "overflow_pairs": o.value}
 
     def nodes_upload(self, node_off, key_index):
         node_off = np.ascontiguousarray(node_off, dtype=np.uint64)
