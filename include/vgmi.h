@@ -142,6 +142,9 @@ typedef struct vgmi_fastq vgmi_fastq;
 int vgmi_fastq_open(vgmi_ctx *ctx, vgmi_fastq **out);
 int vgmi_fastq_acquire(vgmi_fastq *fq, char **host_buf, size_t *capacity);
 int vgmi_fastq_commit(vgmi_fastq *fq, size_t n_bytes);
+/* Text one block-gzip commit may inflate to (>= the staging capacity: the device side is sized to keep every wavefront
+ * busy with a member, whatever the staging buffers are). */
+int vgmi_fastq_text_capacity(vgmi_fastq *fq, size_t *text_bytes);
 /* Block-gzip (BGZF: bgzip, htslib) input: the staging buffer holds COMPRESSED file bytes, continuing where the previous
  * commit's `taken` ended.  The host walks the member headers; every whole member whose text fits the chunk is inflated
  * on the device (one wavefront per member, CRC-32 and ISIZE checked) into the text the FASTQ kernels parse.

@@ -192,6 +192,8 @@ DeviceFileResult device_file(vgmi_ctx* ctx, const std::string& path, size_t bloc
         size_t left_n = 0;
         std::vector<char> carry;                 // block gzip: the bytes behind the last whole member of the previous buffer
         double ratio = 5.0;                      // text bytes per compressed byte, tracked
+        size_t text_cap = 0;
+        if (bgzf && vgmi_fastq_text_capacity(fq, &text_cap) != VGMI_OK) throw std::runtime_error(vgmi_last_error(ctx));
         for (;;) {
             char* buf = nullptr;
             size_t cap = 0;
@@ -204,7 +206,7 @@ DeviceFileResult device_file(vgmi_ctx* ctx, const std::string& path, size_t bloc
                 if (n < cap) break;   // end of the data
             } else if (bgzf) {
                 // compressed bytes whose text fills about nine tenths of a chunk
-                size_t want = (size_t)std::min<double>((double)cap, 0.9 * (double)cap / ratio);
+                size_t want = (size_t)std::min<double>((double)cap, 0.9 * (double)text_cap / ratio);
                 want = std::max<size_t>(want, std::min<size_t>(cap, carry.size() + (256u << 10)));
                 memcpy(buf, carry.data(), carry.size());
                 n = carry.size();

@@ -1064,7 +1064,8 @@ struct vgmi_fastq {
     uint8_t* d_packed = nullptr;
     uint32_t *d_tile = nullptr, *d_nlpos = nullptr, *d_rec = nullptr, *d_off = nullptr, *d_bsum = nullptr;
     FqState* d_state = nullptr;
-    size_t cap = 0;
+    size_t cap = 0;          // pinned staging buffers (the context's --buffer size)
+    size_t text_cap = 0;     // text per chunk on the device: >= cap
     uint32_t cap_lines = 0, tail_max = 0;
     int next = 0, acquired = -1;
     // block-gzip input inflated on the device (allocated by the first vgmi_fastq_commit_bgzf)
@@ -1106,8 +1107,12 @@ int vgmi_fastq_open(vgmi_ctx* c, vgmi_fastq** out)
     if (!(c->hdr.k & 1)) return fail(c, VGMI_E_STATE, "the device-side FASTQ parser serves odd k (even k: host reader + vgmi_reads_submit)");
     HIPCHK(c, hipSetDevice(c->device));
     size_t want_cap = c->buffer_bytes < (16u << 20) ? (16u << 20) : (c->buffer_bytes > (1u << 30) ? (1u << 30) : c->buffer_bytes);
+    // Text per chunk on the device.  Block-gzip input inflates one member (64 KiB of text) per wavefront: a chunk below
+    // 256 MiB leaves wavefront slots empty (measured: 6.4e7 reads/s with 100 MiB chunks, 9.9e7 with 256 MiB), so the
+    // device side is sized for that whatever the staging buffers are; plain text arrives in staging-buffer pieces.
+    size_t want_text = want_cap < ((size_t)256 << 20) ? ((size_t)256 << 20) : want_cap;
     if (const char* e = getenv("VGMI_FASTQ_CHUNK_KB"))   // tests: small chunks put every kind of record across a boundary
-        if (atoi(e) >= 4) want_cap = (size_t)atoi(e) << 10;
+        if (atoi(e) >= 4) want_text = want_cap = (size_t)atoi(e) << 10;
     {   // a closed stream of the same geometry: its buffers are reused (pinned allocations cost more than a small file)
         vgmi_fastq* r = nullptr;
         {
@@ -1141,9 +1146,10 @@ int vgmi_fastq_open(vgmi_ctx* c, vgmi_fastq** out)
     if (!f) return fail(c, VGMI_E_NOMEM, "out of host memory");
     f->c = c;
     f->cap = want_cap;
+    f->text_cap = want_text;
     f->tail_max = 1u << 20;                          // an incomplete record carried between chunks: up to 1 MiB
-    f->cap_lines = (uint32_t)((f->cap + f->tail_max) / 6);
-    const size_t raw_bytes = f->tail_max + f->cap + 256;
+    f->cap_lines = (uint32_t)((f->text_cap + f->tail_max) / 6);
+    const size_t raw_bytes = f->tail_max + f->text_cap + 256;
     const uint32_t n_tiles = (uint32_t)((raw_bytes + 4095) / 4096) + 1;
     const uint32_t cap_rec = f->cap_lines / 4 + 1;
     hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
@@ -1152,7 +1158,7 @@ int vgmi_fastq_open(vgmi_ctx* c, vgmi_fastq** out)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&f->h_done[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_raw[i]), raw_bytes);
     }
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_packed), f->cap + f->tail_max + 256);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_packed), f->text_cap + f->tail_max + 256);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_tile), (size_t)n_tiles * 4);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_nlpos), (size_t)f->cap_lines * 4 + 64);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_rec), (size_t)cap_rec * 4);
@@ -1188,6 +1194,13 @@ int vgmi_fastq_acquire(vgmi_fastq* f, char** host_buf, size_t* capacity)
     f->acquired = i;
     *host_buf = f->h_stage[i];
     *capacity = f->cap;
+    return VGMI_OK;
+}
+
+int vgmi_fastq_text_capacity(vgmi_fastq* f, size_t* text_bytes)
+{
+    if (!f || !text_bytes) return VGMI_E_INVALID;
+    *text_bytes = f->text_cap;
     return VGMI_OK;
 }
 
@@ -1270,7 +1283,7 @@ int vgmi_fastq_commit_bgzf(vgmi_fastq* f, size_t n_bytes, size_t* taken, size_t*
     const int i = f->acquired;
     HIPCHK(c, hipSetDevice(c->device));
     if (!f->d_comp) {
-        f->max_members = (uint32_t)(f->cap / 4096) + 1024;     // bgzip members compress 64 KiB each; tiny ones are rare
+        f->max_members = (uint32_t)(f->text_cap / 4096) + 1024;     // bgzip members compress 64 KiB each; tiny ones are rare
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_comp), f->cap + 64);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_members), (size_t)f->max_members * sizeof(BgzfMember));
         for (int b = 0; b < 2 && e == hipSuccess; ++b)
@@ -1303,7 +1316,7 @@ int vgmi_fastq_commit_bgzf(vgmi_fastq* f, size_t n_bytes, size_t* taken, size_t*
         uint32_t total, d_off, d_len, crc, isize;
         const int r = bgzf_member(p + pos, n_bytes - pos, total, d_off, d_len, crc, isize);
         if (r <= 0) { stop = r; break; }
-        if ((size_t)text + isize > f->cap) break;
+        if ((size_t)text + isize > f->text_cap) break;
         tab[n_mem] = BgzfMember{(uint32_t)(pos + d_off), d_len, text, isize, crc, 0u};
         f->member_size.push_back(total);
         ++n_mem;

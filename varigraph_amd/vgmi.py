@@ -56,6 +56,7 @@ def load_library():
         "vgmi_counts_import_device": (i32, [vp, vp]),
         "vgmi_fastq_open": (i32, [vp, C.POINTER(vp)]),
         "vgmi_fastq_acquire": (i32, [vp, C.POINTER(vp), C.POINTER(sz)]),
+        "vgmi_fastq_text_capacity": (i32, [vp, C.POINTER(sz)]),
         "vgmi_fastq_commit": (i32, [vp, sz]),
         "vgmi_fastq_commit_bgzf": (i32, [vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(i32)]),
         "vgmi_fastq_bgzf_status": (i32, [vp, C.POINTER(i32), C.POINTER(u64), C.POINTER(u32)]),
