@@ -18,7 +18,7 @@ def driver(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("bs") / "byte_source_check")
     cmd = ["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17", "-I", HOST,
            os.path.join(ROOT, "tests", "native", "byte_source_check.cpp"), os.path.join(HOST, "byte_source.cpp"),
-           os.path.join(HOST, "fast_inflate.cpp"), os.path.join(HOST, "fastx_reader.cpp"), "-lz", "-lpthread", "-o", exe]
+           os.path.join(HOST, "fast_inflate.cpp"), os.path.join(HOST, "par_gunzip.cpp"), os.path.join(HOST, "fastx_reader.cpp"), "-lz", "-lpthread", "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         pytest.skip("sanitizer build unavailable: " + r.stderr[-300:])

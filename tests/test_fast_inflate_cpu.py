@@ -35,7 +35,9 @@ def driver(tmp_path_factory):
     return exe
 
 
-def test_fast_inflate_matches_zlib_on_every_stream_shape(driver, tmp_path):
+def make_streams():
+    """name -> gzip bytes: every block type, header field, flush pattern, concatenated members, trailing garbage, truncation at many
+    offsets and random bit flips"""
     rnd = random.Random(5)
     rng = np.random.default_rng(3)
     seqs = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.choice(5, p=[.2499, .2499, .2499, .2499, .0004], size=(3000, 150))]
@@ -77,6 +79,11 @@ def test_fast_inflate_matches_zlib_on_every_stream_shape(driver, tmp_path):
         b = bytearray(base)
         b[off] ^= 0x55
         files[name] = bytes(b)
+    return files
+
+
+def test_fast_inflate_matches_zlib_on_every_stream_shape(driver, tmp_path):
+    files = make_streams()
     paths = []
     for name, payload in files.items():
         p = tmp_path / (name + ".gz")

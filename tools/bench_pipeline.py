@@ -42,7 +42,7 @@ def main():
         for parse in ("device", "host"):   # device: vgmi_fastq_* (records found on the GPU); host: parser thread per file
             os.environ["VGH_HOST_PARSE"] = "1" if parse == "host" else "0"
             for label, files, threads in (("plain_t2", plain, 2), ("plain_t8", plain, 8), ("plain_t16", plain, 16), ("gz_t2", gz, 2),
-                                          ("bgzf_t4", bgz, 4), ("bgzf_t16", bgz, 16)):
+                                          ("gz_t8", gz, 8), ("gz_t16", gz, 16), ("bgzf_t4", bgz, 4), ("bgzf_t16", bgz, 16)):
                 best = None
                 for _ in range(3):
                     t0 = time.perf_counter()

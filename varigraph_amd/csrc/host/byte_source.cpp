@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "fast_inflate.hpp"
+#include "par_gunzip.hpp"
 
 namespace vgh {
 
@@ -547,6 +548,13 @@ std::unique_ptr<ByteSource> ByteSource::open_at(const std::string& path, uint64_
     in->unread(head, n);
     if (n < 2 || head[0] != 0x1f || head[1] != 0x8b) return std::make_unique<PlainSource>(std::move(in));
     if (parse_bgzf_extra(head, n).is_bgzf) return std::make_unique<BgzfSource>(std::move(in), decode_threads);
+    // an ordinary gzip file read from its start with threads to spare: several of them decode it (par_gunzip.hpp);
+    // VGH_PAR_GUNZIP=0 keeps the one-thread decoder
+    if (offset == 0 && decode_threads >= 2) {
+        const char* e = getenv("VGH_PAR_GUNZIP");
+        if (!(e && e[0] == '0'))
+            if (auto par = open_parallel_gunzip(path, decode_threads)) return par;
+    }
     return std::make_unique<GzipSource>(std::move(in));
 }
 
