@@ -28,7 +28,7 @@ constexpr size_t kWin = 32768;           // DEFLATE window; also the number of p
 constexpr size_t kSlack = 320;           // a match (258) plus the overshoot of its wide copies, in symbols
 constexpr size_t kRoom = 1u << 16;       // free symbols asked for before a stretch of decoding
 constexpr uint64_t kNoBit = ~0ULL;
-constexpr size_t kMaxRun = (size_t)1 << 30;   // symbols per run (spans are sized for about 12 MiB of text)
+constexpr size_t kMaxRun = (size_t)1 << 30;   // symbols per run (spans are sized for about 6 MiB of text)
 constexpr size_t kPad = 4096;            // readable zero bytes behind the end of the mapped file
 
 // ---- the file, mapped, with kPad zero bytes behind its end (the bit reader loads eight bytes at a time) ----------------
@@ -444,6 +444,22 @@ RunEnd decode_blocks(const Mapped& m, Run<T>& r, uint64_t stop_bit, uint32_t max
 
 // First bit position in [from, to) where a dynamic-code block (not the last of its member) starts whose header describes
 // three complete codes and which, with the two blocks behind it, decodes.  The run then holds those blocks.
+struct Kraft9 {            // sum of 128 >> l over three 3-bit code lengths (l = 0: unused)
+    uint16_t v[512];
+    Kraft9()
+    {
+        for (uint32_t i = 0; i < 512; ++i) {
+            uint32_t s = 0;
+            for (uint32_t k = 0; k < 3; ++k) {
+                const uint32_t l = (i >> (3 * k)) & 7u;
+                if (l) s += 128u >> l;
+            }
+            v[i] = (uint16_t)s;
+        }
+    }
+};
+const Kraft9 kraft9;
+
 uint64_t find_start(const Mapped& m, uint64_t from, uint64_t to, Run<uint16_t>& r, Tables& tb, RunEnd& trial)
 {
     trial = RunEnd::Bad;
@@ -459,11 +475,10 @@ uint64_t find_start(const Mapped& m, uint64_t from, uint64_t to, Run<uint16_t>& 
         uint64_t w2;
         std::memcpy(&w2, m.data + ((p + 17) >> 3), 8);
         w2 >>= ((p + 17) & 7);   // 57 bits = 19 code lengths of 3 bits
+        // Kraft sum of the code-length code, three lengths per table look-up
+        w2 &= (1ULL << (3 * hclen)) - 1;
         uint32_t sum = 0;
-        for (uint32_t i = 0; i < hclen; ++i) {
-            const uint32_t l = (uint32_t)(w2 >> (3 * i)) & 7u;
-            if (l) sum += 128u >> l;
-        }
+        for (uint32_t c = 0; c < 7; ++c) sum += kraft9.v[(w2 >> (9 * c)) & 511u];
         if (sum != 128u) continue;
         r.n = kWin;
         r.floor = 0;
@@ -908,8 +923,9 @@ std::unique_ptr<ByteSource> open_parallel_gunzip(const std::string& path, unsign
     if (!m || m->size < 18 || m->data[0] != 0x1f || m->data[1] != 0x8b) return nullptr;
     size_t span = span_bytes;
     if (!span) {
-        // compressed bytes that hold about 12 MiB of text, from the ratio of the first blocks: 2 MiB for FASTQ at gzip -6,
-        // far less for text that inflates a thousandfold (a span's symbols are held in memory)
+        // compressed bytes that hold about 6 MiB of text (measured best: 3.5-7 MiB per span), from the ratio of the first
+        // blocks: 1 MiB for FASTQ at gzip -6, far less for text that inflates a thousandfold (a span's symbols are held
+        // in memory)
         span = (size_t)2 << 20;
         size_t after = 0;
         if (member_header(*m, 0, after) == Hdr::Ok) {
@@ -921,8 +937,8 @@ std::unique_ptr<ByteSource> open_parallel_gunzip(const std::string& path, unsign
                 (void)decode_blocks<false>(*m, probe, probe.bit + ((uint64_t)256 << 13), 64, tb);
                 const double in_bytes = (double)(probe.bit / 8 - after);
                 if (in_bytes >= 1024 && probe.out() > 0) {
-                    const double want = 12.0 * 1048576.0 * in_bytes / (double)probe.out();
-                    span = want > 4194304.0 ? (size_t)4 << 20 : (want < 65536.0 ? (size_t)65536 : (size_t)want);
+                    const double want = 6.0 * 1048576.0 * in_bytes / (double)probe.out();
+                    span = want > 2097152.0 ? (size_t)2 << 20 : (want < 65536.0 ? (size_t)65536 : (size_t)want);
                 }
             }
         }
