@@ -3,9 +3,11 @@
 // the VCF prints GPP with one decimal and GQ from log10(1 - p).
 #include "genotyper.hpp"
 
+#include <immintrin.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -255,6 +257,7 @@ struct Genotyper::Run {
 Genotyper::Genotyper(const GraphIndex& g) : g_(g)
 {
     n_hap_ = (uint32_t)g.hap_names.size();
+    for (const auto& kv : g.hap_names) hap_ids_.push_back(kv.first);
     // variant nodes in mGraphMap order carry the graph2node k-mer lists (CSR over key indices)
     size_t v = 0;
     for (const auto& [chr, nodes] : g.graph) {
@@ -289,10 +292,28 @@ std::pair<std::string, std::string> Genotyper::flanks(const Chrom& chr, uint32_t
 // `genotypes` = the window's haplotype combinations (the same for every node of a window), `used` = the haplotypes
 // occurring in them.  The per-haplotype term of a k-mer does not depend on the genotype, so it is evaluated once
 // per (k-mer, haplotype) and summed per genotype.
+namespace {
+// h[g] = one16[pos_a[g]] + one16[pos_b[g]] for 16 genotypes per step (the copy count of every genotype of a window for one
+// k-mer: the same byte sums as the scalar loop)
+__attribute__((target("ssse3"))) void hrow_pairs_ssse3(const uint8_t* one16, const uint8_t* pos_a, const uint8_t* pos_b, uint8_t* out, size_t n16)
+{
+    const __m128i tab = _mm_loadu_si128(reinterpret_cast<const __m128i*>(one16));
+    for (size_t g = 0; g < n16; g += 16) {
+        const __m128i a = _mm_shuffle_epi8(tab, _mm_loadu_si128(reinterpret_cast<const __m128i*>(pos_a + g)));
+        const __m128i b = _mm_shuffle_epi8(tab, _mm_loadu_si128(reinterpret_cast<const __m128i*>(pos_b + g)));
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(out + g), _mm_add_epi8(a, b));
+    }
+}
+const bool g_have_ssse3 = [] {
+    __builtin_cpu_init();
+    return __builtin_cpu_supports("ssse3") != 0;
+}();
+}  // namespace
+
 Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& top,
                                                const std::vector<std::vector<uint16_t>>& genotypes,
-                                               const std::vector<uint16_t>& used, double lower, double upper,
-                                               bool filter, const Run& r, NodeStates&& recycled)
+                                               const std::vector<uint16_t>& used, const GenotypeList& gl, double lower,
+                                               double upper, bool filter, const Run& r, NodeStates&& recycled)
 {
     Node& node = chr.nodes[node_i];
     const std::vector<uint16_t>& hap_gt = node.gn->hap_gt;
@@ -309,21 +330,18 @@ Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, cons
     ns.c.reserve(node.kmers.size());
     ns.f.reserve(node.kmers.size());
     ns.h.resize(node.kmers.size() * n_gt);
-    // the window's genotypes as one flat list (read once per k-mer)
-    std::vector<uint16_t> flat;
-    std::vector<uint32_t> flat_off(n_gt + 1, 0);
-    for (size_t gi = 0; gi < n_gt; ++gi) {
-        flat.insert(flat.end(), genotypes[gi].begin(), genotypes[gi].end());
-        flat_off[gi + 1] = (uint32_t)flat.size();
-    }
-    bool pairs = true;
-    for (size_t gi = 0; gi < n_gt; ++gi) pairs = pairs && genotypes[gi].size() == 2;
+    const std::vector<uint16_t>& flat = gl.flat;
+    const std::vector<uint32_t>& flat_off = gl.off;
+    const bool pairs = gl.pairs;
+    const bool shuffle = pairs && !gl.pos_a.empty() && g_have_ssse3;
     size_t n_kept = 0;
 
-    std::vector<uint32_t> kept;                   // the node's k-mers that take part (all of them unless `filter`)
+    std::vector<uint32_t>& kept = ns.kept;        // the node's k-mers that take part (all of them unless `filter`)
+    kept.clear();
     kept.reserve(node.kmers.size());
     std::map<uint16_t, uint32_t> need_sequence;   // haplotypes with multi-copy, under-covered k-mers: check their sequence
-    std::vector<uint8_t> one(n_hap_, 0);
+    std::vector<uint8_t>& one = ns.one;
+    one.assign(n_hap_, 0);
     for (uint32_t key : node.kmers) {
         const uint8_t c = r.cov[key];
         const uint8_t f = g_.f[key];
@@ -343,7 +361,14 @@ Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, cons
         ns.f.push_back((lb == 1 && f == 1) ? (uint8_t)(f + 1) : f);
         uint8_t* hrow = &ns.h[n_kept * n_gt];
         if (pairs) {
-            for (size_t gi = 0; gi < n_gt; ++gi) hrow[gi] = (uint8_t)(one[flat[2 * gi]] + one[flat[2 * gi + 1]]);
+            size_t gi = 0;
+            if (shuffle) {
+                uint8_t one16[16] = {0};
+                for (size_t p = 0; p < used.size(); ++p) one16[p] = one[used[p]];
+                gi = n_gt & ~(size_t)15;
+                hrow_pairs_ssse3(one16, gl.pos_a.data(), gl.pos_b.data(), hrow, gi);
+            }
+            for (; gi < n_gt; ++gi) hrow[gi] = (uint8_t)(one[flat[2 * gi]] + one[flat[2 * gi + 1]]);
         } else {
             for (size_t gi = 0; gi < n_gt; ++gi) {
                 uint8_t h = 0;
@@ -438,9 +463,21 @@ void Genotyper::posterior(Node& n, const std::vector<uint16_t>& top, const Run& 
         if (allele_text[a].empty()) allele_text[a] = std::to_string(a);
         return allele_text[a];
     };
+    // the string of an entry depends on its alleles only: pairs of small allele numbers (the usual case) remember theirs
+    const size_t na = (size_t)max_allele + 1;
+    std::vector<int32_t> pair_id;
+    if (na <= 64) pair_id.assign(na * na, -2);
     for (size_t i = 0; i < n.hmm.size(); ++i) {
         if (!n.hmm[i].haps || n.hmm[i].haps->empty()) continue;
         const auto& haps = *n.hmm[i].haps;
+        int32_t* memo = nullptr;
+        if (haps.size() == 2 && !pair_id.empty()) {
+            memo = &pair_id[(size_t)hap_gt[haps[0]] * na + hap_gt[haps[1]]];
+            if (*memo != -2) {
+                gid[i] = *memo;
+                continue;
+            }
+        }
         tuple.clear();
         for (uint16_t hap : haps) tuple.push_back(hap_gt[hap]);
         std::sort(tuple.begin(), tuple.end(), [&](uint16_t x, uint16_t y) { return text_of(x) < text_of(y); });
@@ -458,12 +495,15 @@ void Genotyper::posterior(Node& n, const std::vector<uint16_t>& top, const Run& 
             distinct.push_back(std::move(e));
         }
         gid[i] = id;
+        if (memo) *memo = id;
     }
+    // (a * b) / denominator of every entry: the same expression in both passes of the reference, evaluated once
+    std::vector<long double> post(n.hmm.size());
     for (size_t i = 0; i < n.hmm.size(); ++i) {
         const auto& s = n.hmm[i];
-        const long double post = (s.a * s.b) / (long double)denominator;
+        post[i] = (s.a * s.b) / (long double)denominator;
         if (gid[i] < 0) continue;
-        distinct[(size_t)gid[i]].sum += post;
+        distinct[(size_t)gid[i]].sum += post[i];
     }
     std::vector<size_t> order(distinct.size());
     for (size_t d = 0; d < order.size(); ++d) order[d] = d;
@@ -477,29 +517,59 @@ void Genotyper::posterior(Node& n, const std::vector<uint16_t>& top, const Run& 
         }
     }
 
+    // the entry with the largest posterior among those of the winning string (the first one on ties) makes the call
     long double max_post = 0.0L;
+    size_t winner = n.hmm.size();
     for (size_t i = 0; i < n.hmm.size(); ++i) {
-        const auto& s = n.hmm[i];
-        const long double post = (s.a * s.b) / (long double)denominator;
         if (gid[i] < 0 || gid[i] != best_id) continue;
         n.call.probability = best;
-        if (max_post < post) {
-            max_post = post;
-            n.call.haps = *s.haps;
-            n.call.kmer_num.clear();
-            n.call.kmer_ave_cov.clear();
-            for (uint16_t hap : n.call.haps) {
-                const uint64_t num = hap < n_hap_ ? hap_num[hap] : 0;
-                const uint64_t sum = hap < n_hap_ ? hap_sum[hap] : 0;
-                const float ave = (num != 0) ? static_cast<float>(sum) / (float)num : 0.0;
-                n.call.kmer_num.push_back(num);
-                n.call.kmer_ave_cov.push_back(ave);
-            }
-            n.call.unique_kmers = unique_kmers;
+        if (max_post < post[i]) {
+            max_post = post[i];
+            winner = i;
         }
+    }
+    if (winner != n.hmm.size()) {
+        n.call.haps = *n.hmm[winner].haps;
+        n.call.kmer_num.clear();
+        n.call.kmer_ave_cov.clear();
+        for (uint16_t hap : n.call.haps) {
+            const uint64_t num = hap < n_hap_ ? hap_num[hap] : 0;
+            const uint64_t sum = hap < n_hap_ ? hap_sum[hap] : 0;
+            const float ave = (num != 0) ? static_cast<float>(sum) / (float)num : 0.0;
+            n.call.kmer_num.push_back(num);
+            n.call.kmer_ave_cov.push_back(ave);
+        }
+        n.call.unique_kmers = unique_kmers;
     }
     std::vector<HmmScore>().swap(n.hmm);
 }
+
+// The per-key arrays (coverage, multiplicity, haplotype bits) are indexed by key number, i.e. at random: a node's keys are
+// asked for one node ahead of their use
+void Genotyper::prefetch_keys(const Node& n, const Run& r) const
+{
+    const uint64_t bl = g_.bitlen;
+    for (uint32_t key : n.kmers) {
+        __builtin_prefetch(&r.cov[key]);
+        __builtin_prefetch(&g_.f[key]);
+        __builtin_prefetch(&g_.bitvec[(size_t)key * bl]);
+    }
+}
+
+// phase times summed over the pool's threads (VGH_TIMING): where the windows spend their time
+namespace {
+struct HmmPhases {
+    std::atomic<long long> select{0}, states{0}, emit{0}, fwd{0}, bwd{0}, post{0};
+};
+HmmPhases g_phase;
+const bool g_phase_on = getenv("VGH_TIMING") != nullptr;
+struct PhaseTimer {
+    std::atomic<long long>& acc;
+    std::chrono::steady_clock::time_point t0;
+    explicit PhaseTimer(std::atomic<long long>& a) : acc(a) { if (g_phase_on) t0 = std::chrono::steady_clock::now(); }
+    ~PhaseTimer() { if (g_phase_on) acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
 
 // ---------------------------------------------------------------- one window: selection, forward, backward, posterior
 void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
@@ -510,6 +580,7 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
     if (first >= chr.nodes.size()) return;
 
     // ---- haplotype selection (src/genotype.cpp:500-610)
+    std::unique_ptr<PhaseTimer> t_select(new PhaseTimer(g_phase.select));
     std::vector<uint16_t> top;
     if (n_hap_ <= r.haploid_num)
         for (const auto& kv : g_.hap_names) top.push_back(kv.first);
@@ -517,20 +588,21 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
     const uint64_t bl = g_.bitlen;
     for (uint32_t i = first; i < last; ++i) {
         const Node& n = chr.nodes[i];
+        if (i + 1 < last) prefetch_keys(chr.nodes[i + 1], r);
         if (n.gn->hap_gt.size() == 1) continue;
         for (uint32_t key : n.kmers) {
             const uint8_t c = r.cov[key];
             if (c <= 1 || g_.f[key] > 1) continue;
-            for (const auto& kv : g_.hap_names) {
-                const uint16_t hap = kv.first;
-                if (((uint8_t)g_.bitvec[(size_t)key * bl + (hap >> 3)] >> (hap & 7)) & 1u) support[hap] += c;
-            }
+            const uint8_t* bits = reinterpret_cast<const uint8_t*>(g_.bitvec.data()) + (size_t)key * bl;
+            for (const uint16_t hap : hap_ids_)
+                if ((bits[hap >> 3] >> (hap & 7)) & 1u) support[hap] += c;
         }
     }
     HaplotypeSampler sampler(support, (int)r.haploid_num);
     if (top.empty()) top = sampler.top;
     std::sort(top.begin(), top.end());
     const std::unordered_map<uint16_t, double>& hap_score = sampler.score;
+    t_select.reset();
 
     double lower = 256.0f, upper = -0.1f;
     poisson_interval(r.hap_cov, lower, upper);
@@ -573,6 +645,23 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
         }
         return n;
     };
+    GenotypeList glist;
+    glist.off.assign(n_gt + 1, 0);
+    for (size_t gi = 0; gi < n_gt; ++gi) {
+        glist.flat.insert(glist.flat.end(), genotypes[gi].begin(), genotypes[gi].end());
+        glist.off[gi + 1] = (uint32_t)glist.flat.size();
+        glist.pairs = glist.pairs && genotypes[gi].size() == 2;
+    }
+    if (glist.pairs && used.size() <= 16) {
+        std::unordered_map<uint16_t, uint8_t> where;
+        for (size_t p = 0; p < used.size(); ++p) where[used[p]] = (uint8_t)p;
+        glist.pos_a.resize(n_gt);
+        glist.pos_b.resize(n_gt);
+        for (size_t gi = 0; gi < n_gt; ++gi) {
+            glist.pos_a[gi] = where[glist.flat[2 * gi]];
+            glist.pos_b[gi] = where[glist.flat[2 * gi + 1]];
+        }
+    }
     bool all_full = true;   // every genotype has `ploidy` haplotypes
     for (const auto& gtv : genotypes) all_full = all_full && gtv.size() == (size_t)cfg.sample_ploidy;
     std::vector<uint8_t> keep_mat(n_gt * n_gt);
@@ -594,13 +683,18 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
         const size_t hs = (size_t)max_h + 1;
         // the term of k-mer j under h copies, for the (j, h) that occur
         term_buf.resize(nk * hs);
+        // which copy numbers occur for k-mer j: one pass over its row (a term is only evaluated for those, as the
+        // reference evaluates it)
         term_have.assign(nk * hs, 0);
         for (size_t j = 0; j < nk; ++j) {
             const uint8_t* hj = &ns.h[j * ng];
-            for (size_t gi = 0; gi < ng; ++gi) {
-                const uint8_t h = hj[gi];
-                if (term_have[j * hs + h]) continue;
-                term_have[j * hs + h] = 1;
+            uint8_t* have = &term_have[j * hs];
+            for (size_t gi = 0; gi < ng; ++gi) have[hj[gi]] = 1;
+        }
+        for (size_t j = 0; j < nk; ++j) {
+            for (size_t hh = 0; hh < hs; ++hh) {
+                if (!term_have[j * hs + hh]) continue;
+                const uint8_t h = (uint8_t)hh;
                 uint8_t c = ns.c[j];
                 most_likely_depth(h, c, ns.f[j], ave, score_up);
                 if (h == 0) {
@@ -755,12 +849,21 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
         if (skipped(n)) continue;
         const uint32_t n_start = n.start;
         const uint32_t n_end = (uint32_t)(n_start + n.gn->seqs[0].size() - 1);
-        states = hidden_states(chr, i, top, genotypes, used, lower, upper, true, r, std::move(states));
+        if (i + 1 < last) prefetch_keys(chr.nodes[i + 1], r);
+        {
+            PhaseTimer t(g_phase.states);
+            states = hidden_states(chr, i, top, genotypes, used, glist, lower, upper, true, r, std::move(states));
+        }
         long double recomb = 0.0L, no_recomb = 0.0L;
         if (cfg.transition == "rec") std::tie(recomb, no_recomb) = transition_probabilities(n_start - prev_end, (uint16_t)n_hap_);
         std::vector<long double>& obs = emissions[i - first];
-        obs = score_states(states);
+        {
+            PhaseTimer t(g_phase.emit);
+            obs = score_states(states);
+        }
+        std::unique_ptr<PhaseTimer> t_fwd(new PhaseTimer(g_phase.fwd));
         const std::vector<long double> alpha = recursion(*prev, true, recomb, no_recomb, obs);
+        t_fwd.reset();
         n.hmm.resize(alpha.size());
         for (size_t j = 0; j < alpha.size(); ++j) {
             n.hmm[j].a = alpha[j];
@@ -770,30 +873,38 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
         prev_end = n_end;
         prev = &n.hmm;
     }
-    // ---- backward
+    // ---- backward, and the posterior of a node as soon as the node in front of it has used its beta (its alpha / beta
+    // entries are still in the cache then; the posterior of one node does not depend on any other's)
     prev = &no_prev;
     prev_start = 0;
     prev_end = 0;
+    Node* due = nullptr;
     for (uint32_t i = last; i-- > first;) {
         Node& n = chr.nodes[i];
         if (skipped(n)) continue;
+        prefetch_keys(n, r);
         const uint32_t n_start = n.start;
         const uint32_t n_end = (uint32_t)(n_start + n.gn->seqs[0].size() - 1);
         long double recomb = 0.0L, no_recomb = 0.0L;
         if (cfg.transition == "rec") std::tie(recomb, no_recomb) = transition_probabilities(prev_start - n_end, (uint16_t)n_hap_);
+        std::unique_ptr<PhaseTimer> t_bwd(new PhaseTimer(g_phase.bwd));
         const std::vector<long double> beta = recursion(*prev, false, recomb, no_recomb, emissions[i - first]);
+        t_bwd.reset();
         for (size_t j = 0; j < beta.size(); ++j) n.hmm[j].b = beta[j];
         std::vector<long double>().swap(emissions[i - first]);
+        if (due) {
+            PhaseTimer t(g_phase.post);
+            posterior(*due, top, r);
+        }
+        due = &n;
         prev_start = n_start;
         prev_end = n_end;
         prev = &n.hmm;
     }
     (void)prev_end;
-    // ---- posterior
-    for (uint32_t i = first; i < last; ++i) {
-        Node& n = chr.nodes[i];
-        if (skipped(n)) continue;
-        posterior(n, top, r);
+    if (due) {
+        PhaseTimer t(g_phase.post);
+        posterior(*due, top, r);
     }
 }
 
@@ -859,6 +970,11 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
     if (failed.load()) throw std::runtime_error(error);
     const auto t_hmm = std::chrono::steady_clock::now();
     last_hmm_seconds = std::chrono::duration<double>(t_hmm - t_begin).count();
+    if (g_phase_on) {
+        std::fprintf(stderr, "[varigraph-mi] HMM thread-seconds: selection %.2f, hidden states %.2f, emissions %.2f, forward %.2f, backward %.2f, posterior %.2f (wall %.2f on %u threads)\n",
+                     g_phase.select.exchange(0) * 1e-9, g_phase.states.exchange(0) * 1e-9, g_phase.emit.exchange(0) * 1e-9, g_phase.fwd.exchange(0) * 1e-9,
+                     g_phase.bwd.exchange(0) * 1e-9, g_phase.post.exchange(0) * 1e-9, last_hmm_seconds, n_threads);
+    }
 
     // ---- VCF (src/genotype.cpp:1579-1696): sites in vcf_info order, only those with a non-reference call.  The
     // reference walks mVcfInfoMap (chromosome, then position) and looks every site up in the graph; the windows are the

@@ -77,20 +77,32 @@ private:
     struct NodeStates {
         std::vector<uint8_t> c, f, h;
         size_t n_genotypes = 0;
+        std::vector<uint32_t> kept;   // scratch reused from node to node
+        std::vector<uint8_t> one;
+    };
+    // the window's genotypes as one flat list (the same for every node of the window)
+    struct GenotypeList {
+        std::vector<uint16_t> flat;
+        std::vector<uint32_t> off;
+        bool pairs = true;            // every genotype has two haplotypes
+        // pairs over at most 16 haplotypes: position (in `used`) of each genotype's two haplotypes, for a byte shuffle
+        std::vector<uint8_t> pos_a, pos_b;
     };
     struct Run;  // per-call constants
 
     void window(Chrom& chr, uint32_t first, uint32_t last, const Run& r);
     NodeStates hidden_states(Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& top,
                              const std::vector<std::vector<uint16_t>>& genotypes, const std::vector<uint16_t>& used,
-                             double lower, double upper, bool filter, const Run& r, NodeStates&& recycled);
+                             const GenotypeList& gl, double lower, double upper, bool filter, const Run& r, NodeStates&& recycled);
     std::pair<std::string, std::string> flanks(const Chrom& chr, uint32_t node_i, uint16_t hap, uint16_t alt_gt,
                                                std::string& alt_seq, uint32_t want) const;
     void posterior(Node& n, const std::vector<uint16_t>& top, const Run& r) const;
+    void prefetch_keys(const Node& n, const Run& r) const;
 
     const GraphIndex& g_;
     std::vector<Chrom> chroms_;   // mGraphMap order
     uint32_t n_hap_ = 0;
+    std::vector<uint16_t> hap_ids_;   // the keys of g_.hap_names in their order
 };
 
 }  // namespace vgh
