@@ -150,7 +150,7 @@ def cpu_baseline(haps, n_reads, cores):
         shutil.rmtree(work, ignore_errors=True)
 
 
-def sample_level(ctx, haps, cpu_ref, n_plain=8_000_000, n_packed=1_000_000):
+def sample_level(ctx, haps, cpu_ref, n_plain=8_000_000, n_packed=4_000_000):
     """SURVEY 8d level (ii): FASTQ FILES -> counters, through the product's FastqKmerHip (csrc/host): plain, gzip and
     block-gzip copies of one sample of the C2 workload, with the records found on the device (vgmi_fastq_*) and, for
     comparison, by the host parser; plus the PCIe-inclusive rate of the host-block entry point vgmi_reads_submit."""
@@ -166,12 +166,16 @@ def sample_level(ctx, haps, cpu_ref, n_plain=8_000_000, n_packed=1_000_000):
         block = vgmi.synth_reads_host(1000, 0, n_plain, READ_LEN, haps)
         plain = synth.write_fastq_pair_fast(os.path.join(work, "p"), block, n_plain, READ_LEN)
         small = synth.write_fastq_pair_fast(os.path.join(work, "c"), block[: n_packed * (READ_LEN + 1)], n_packed, READ_LEN)
-        gz, bgz = [], []
-        for p in small:
+        def to_gzip(p):
             with open(p, "rb") as fi, gzip.open(p + ".gz", "wb", compresslevel=4) as fo:
                 shutil.copyfileobj(fi, fo, 1 << 24)
-            gz.append(p + ".gz")
-            bgz.append(synth.bgzf_compress_file(p, p + ".bgz.gz", level=4))
+            return p + ".gz"
+
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(4) as pool:   # zlib releases the interpreter lock: the four files are written side by side
+            gz_f = [pool.submit(to_gzip, p) for p in small]
+            bgz_f = [pool.submit(synth.bgzf_compress_file, p, p + ".bgz.gz", 4) for p in small]
+            gz, bgz = [f.result() for f in gz_f], [f.result() for f in bgz_f]
         out["bytes_per_read_plain"] = sum(os.path.getsize(p) for p in plain) / n_plain
         out["host_threads"] = threads
 
