@@ -36,6 +36,7 @@ struct InfTables {                 // per wavefront, in LDS
     uint16_t offs[2][INF_MAXBITS + 1];
     uint8_t ring[INF_RING];        // the last INF_RING output bytes: LZ77 sources come from here, not from global memory --
                                    // a global read-back would wait (vmcnt) for every store still in flight
+    uint8_t pad[64];               // where the lanes that have no byte of a literal run write theirs
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -46,6 +47,8 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) { return (uint64_t)uni((ui
 // one memory round trip per 8 input bytes, most of the kernel's time in its first version)
 typedef __attribute__((address_space(4))) const uint64_t inf_cu64;
 __device__ __forceinline__ uint64_t ld64u(const uint64_t* p) { return *reinterpret_cast<inf_cu64*>((uintptr_t)p); }
+typedef __attribute__((address_space(4))) const uint32_t inf_cu32;
+__device__ __forceinline__ uint32_t ld32u(const uint32_t* p) { return *reinterpret_cast<inf_cu32*>((uintptr_t)p); }
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t code, uint32_t len) { return __builtin_bitreverse32(code) >> (32 - len); }
 
@@ -194,38 +197,50 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __rest
     uint8_t* out = out_base + uni(members[m].u_off);
     const uint32_t out_len = uni(members[m].u_len);      // ISIZE
     const uint32_t want_crc = uni(members[m].crc);
+    // table indices are formed on the vector side (a mask the compiler cannot see through): the scalar unit is the busy one
+    uint32_t vmask_lit, vmask_dist;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vmask_lit) : "s"((1u << INF_LIT_BITS) - 1u));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vmask_dist) : "s"((1u << INF_DIST_BITS) - 1u));
+    // stores at offsets >= ISIZE are dropped by the hardware
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)out_len, 0x00020000);
 
     // ---- wave-uniform decoder state ----
     uint64_t bitbuf = 0;
     uint32_t bitcnt = 0, ip = 0, op = 0, err = 0;
-    // Input window: three aligned 8-byte words (cur holds the byte at in + ip), fetched with scalar loads two words ahead
-    // of use, so a refill never waits for memory.  The host pads every batch (>= 32 readable bytes behind the last member);
-    // bytes past in_len are only consumed by a damaged stream, which the position check reports.
-    const uint64_t* win = reinterpret_cast<const uint64_t*>((uint64_t)in & ~7ULL);
-    uint64_t cur = ld64u(win), n1 = ld64u(win + 1), n2 = ld64u(win + 2);
-    auto refill = [&]() {
-        const uint32_t sh = (uint32_t)((uint64_t)(in + ip) & 7u) * 8u;
-        const uint64_t w = sh ? (cur >> sh) | (n1 << (64 - sh)) : cur;
-        bitbuf |= w << bitcnt;
-        const uint32_t adv = (63u - bitcnt) >> 3;
-        const uint32_t before = (uint32_t)((uint64_t)(in + ip) >> 3);
-        ip += adv;
-        bitcnt += adv * 8u;
-        if ((uint32_t)((uint64_t)(in + ip) >> 3) != before) {   // at most one word further (adv <= 7)
-            ++win;
-            cur = n1;
-            n1 = n2;
-            n2 = ld64u(win + 2);
+    // Input: aligned 32-bit words appended whole to the 64-bit bit buffer whenever it holds 32 bits or fewer, fetched with
+    // scalar loads three words ahead of use, so a refill never waits for memory (and costs eight scalar instructions: the
+    // scalar unit is what this kernel is short of).  ip = input bytes appended so far.  The host pads every batch (>= 32
+    // readable bytes behind the last member); bytes past in_len are only consumed by a damaged stream, which the
+    // position check reports.
+    const uint32_t* wq;
+    uint32_t wa, wb, wc;
+    auto reload = [&]() {          // (re)start at input byte ip: the bit buffer is empty
+        const uint32_t lead = (uint32_t)((uint64_t)(in + ip) & 3u);
+        wq = reinterpret_cast<const uint32_t*>((uint64_t)(in + ip) & ~3ULL);
+        wa = ld32u(wq);
+        wb = ld32u(wq + 1);
+        wc = ld32u(wq + 2);
+        bitbuf = (uint64_t)(wa >> (8u * lead));
+        bitcnt = 32u - 8u * lead;
+        ip += 4u - lead;
+        wa = wb;
+        wb = wc;
+        wc = ld32u(wq + 3);
+        ++wq;
+    };
+    reload();
+    auto refill = [&]() {          // leaves at least 33 bits
+        if (bitcnt <= 32u) {
+            bitbuf |= (uint64_t)wa << bitcnt;
+            bitcnt += 32u;
+            ip += 4u;
+            wa = wb;
+            wb = wc;
+            wc = ld32u(wq + 3);
+            ++wq;
         }
     };
     auto need = [&](uint32_t n) { if (bitcnt < n) refill(); };
-    // after a jump of the input position (stored block)
-    auto reload = [&]() {
-        win = reinterpret_cast<const uint64_t*>((uint64_t)(in + ip) & ~7ULL);
-        cur = ld64u(win);
-        n1 = ld64u(win + 1);
-        n2 = ld64u(win + 2);
-    };
     auto take = [&](uint32_t n) -> uint32_t {
         const uint32_t v = (uint32_t)bitbuf & ((1u << n) - 1u);
         bitbuf >>= n;
@@ -296,7 +311,7 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __rest
             };
             while (idx < hlit + hdist && !err) {
                 refill();
-                uint32_t e = uni(t.dist[(uint32_t)bitbuf & ((1u << INF_DIST_BITS) - 1u)]);
+                uint32_t e = uni(t.dist[(uint32_t)bitbuf & vmask_dist]);
                 uint32_t l = e & 15u, sym = e >> 4;
                 if (!l) { err = 1; break; }     // code-length codes are at most 7 bits: always in the fast table
                 take(l);
@@ -345,23 +360,26 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __rest
         }
         // ---- symbols of this block ----
         for (;;) {
-            need(32);     // a literal/length code (<= 15 bits) and its extra bits (<= 5)
-            {   // literals first: up to three per lookup, one byte per lane
-                const uint32_t mm = uni(t.multi[(uint32_t)bitbuf & ((1u << INF_LIT_BITS) - 1u)]);
+            // Runs of literals first: up to three per look-up, one byte per lane.  The kernel is bound by SCALAR issue
+            // (11.5 SALU + 3 branches per output byte, one scalar instruction per SIMD and four cycles: four members per
+            // SIMD take 58 cycles per byte), so this loop keeps the scalar unit out of what the vector side can do: no exec
+            // mask games (lanes without a byte store to an offset the buffer descriptor drops, and write their LDS byte
+            // to a pad), no bounds branch (the descriptor ends at ISIZE; the position is checked once per run).
+            for (;;) {
+                need(32);     // a literal/length code (<= 15 bits) and its extra bits (<= 5)
+                const uint32_t mm = uni(t.multi[(uint32_t)bitbuf & vmask_lit]);
                 const uint32_t n = (mm >> 24) & 3u;
-                if (n) {
-                    if (op + n > out_len) { err = 3; break; }
-                    if (lane < n) {
-                        const uint8_t b = (uint8_t)(mm >> (8 * lane));
-                        out[op + lane] = b;
-                        t.ring[(op + lane) & (INF_RING - 1u)] = b;
-                    }
-                    op += n;
-                    take(mm >> 26);
-                    continue;
-                }
+                if (!n) break;
+                const bool mine = lane < n;
+                const uint8_t b = (uint8_t)(mm >> (8u * (lane & 3u)));
+                __builtin_amdgcn_raw_buffer_store_b8(b, orsrc, mine ? op + lane : 0xFFFFFFFFu, 0, 0);
+                uint8_t* const cell = mine ? &t.ring[(op + lane) & (INF_RING - 1u)] : &t.pad[lane];
+                *cell = b;
+                op += n;
+                take(mm >> 26);
             }
-            uint32_t e = uni(t.lit[(uint32_t)bitbuf & ((1u << INF_LIT_BITS) - 1u)]);
+            if (op > out_len) { err = 3; break; }
+            uint32_t e = uni(t.lit[(uint32_t)bitbuf & vmask_lit]);
             uint32_t l = e & 15u;
             int32_t sym = (int32_t)(e >> 4);
             if (!l) {
@@ -392,7 +410,7 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __rest
                 len = ((4u + ((uint32_t)sym & 3u)) << e) + 3u + take(e);
             }
             need(32);     // a distance code (<= 15 bits) and its extra bits (<= 13)
-            uint32_t de = uni(t.dist[(uint32_t)bitbuf & ((1u << INF_DIST_BITS) - 1u)]);
+            uint32_t de = uni(t.dist[(uint32_t)bitbuf & vmask_dist]);
             uint32_t dl = de & 15u;
             int32_t dsym = (int32_t)(de >> 4);
             if (!dl) {
