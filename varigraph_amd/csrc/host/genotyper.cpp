@@ -249,6 +249,9 @@ std::string strip_newlines(const std::string& s)   // strip(str, '\n') of src/st
 
 struct Genotyper::Run {
     const uint8_t* cov;
+    // coverage | multiplicity << 8 | haplotype bits << 16 of every key in one word (one cache line per k-mer instead of
+    // three: the arrays are indexed at random), when the bits fit; else nullptr
+    const uint64_t* packed = nullptr;
     float hap_cov;
     const GenotypeConfig* cfg;
     uint32_t haploid_num;   // min(-n, #haplotypes)
@@ -292,6 +295,21 @@ std::pair<std::string, std::string> Genotyper::flanks(const Chrom& chr, uint32_t
 // `genotypes` = the window's haplotype combinations (the same for every node of a window), `used` = the haplotypes
 // occurring in them.  The per-haplotype term of a k-mer does not depend on the genotype, so it is evaluated once
 // per (k-mer, haplotype) and summed per genotype.
+// phase times summed over the pool's threads (VGH_TIMING): where the windows spend their time
+namespace {
+struct HmmPhases {
+    std::atomic<long long> select{0}, states{0}, emit{0}, fwd{0}, bwd{0}, post{0};
+};
+HmmPhases g_phase;
+const bool g_phase_on = getenv("VGH_TIMING") != nullptr;
+struct PhaseTimer {
+    std::atomic<long long>& acc;
+    std::chrono::steady_clock::time_point t0;
+    explicit PhaseTimer(std::atomic<long long>& a) : acc(a) { if (g_phase_on) t0 = std::chrono::steady_clock::now(); }
+    ~PhaseTimer() { if (g_phase_on) acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
+
 namespace {
 // h[g] = one16[pos_a[g]] + one16[pos_b[g]] for 16 genotypes per step (the copy count of every genotype of a window for one
 // k-mer: the same byte sums as the scalar loop)
@@ -313,7 +331,7 @@ const bool g_have_ssse3 = [] {
 Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& top,
                                                const std::vector<std::vector<uint16_t>>& genotypes,
                                                const std::vector<uint16_t>& used, const GenotypeList& gl, double lower,
-                                               double upper, bool filter, const Run& r, NodeStates&& recycled)
+                                               double upper, bool filter, const Run& r, NodeStates&& recycled, const Node* ahead)
 {
     Node& node = chr.nodes[node_i];
     const std::vector<uint16_t>& hap_gt = node.gn->hap_gt;
@@ -342,7 +360,72 @@ Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, cons
     std::map<uint16_t, uint32_t> need_sequence;   // haplotypes with multi-copy, under-covered k-mers: check their sequence
     std::vector<uint8_t>& one = ns.one;
     one.assign(n_hap_, 0);
+    // the per-key arrays are indexed at random: the keys of the node ahead are asked for one per k-mer of this node (all at
+    // once they would overrun the core's miss buffers and most of the requests would be dropped)
+    const uint32_t* pf = ahead ? ahead->kmers.data() : nullptr;
+    const uint32_t* const pf_end = ahead ? pf + ahead->kmers.size() : nullptr;
+    auto prefetch_one = [&]() {
+        if (pf != pf_end) {
+            const uint32_t k2 = *pf++;
+            if (r.packed) {
+                __builtin_prefetch(&r.packed[k2]);
+                return;
+            }
+            __builtin_prefetch(&r.cov[k2]);
+            __builtin_prefetch(&g_.f[k2]);
+            __builtin_prefetch(&g_.bitvec[(size_t)k2 * bl]);
+        }
+    };
+    // Fast path (haplotype bits of a k-mer fit one 64-bit word, genotypes are pairs over <= 16 haplotypes): the word is
+    // read once per k-mer and every test is a mask or a shift of it
+    const bool fast = shuffle && r.packed != nullptr;
+    ns.cls.clear();
+    ns.rep.clear();
+    // haplotypes (positions in `used`) that carried the same k-mers so far: a partition refined k-mer by k-mer
+    uint16_t part[16];
+    uint32_t n_part = 1;
+    part[0] = (uint16_t)((1u << used.size()) - 1u);
+    uint64_t top_mask = 0;
+    uint8_t gt0[16] = {0};      // haplotype used[p] carries the reference allele at this node
+    if (fast) {
+        for (uint16_t hap : top) top_mask |= 1ULL << hap;
+        for (size_t p = 0; p < used.size(); ++p) gt0[p] = hap_gt[used[p]] == 0;
+    }
     for (uint32_t key : node.kmers) {
+        prefetch_one();
+        uint8_t* hrow = &ns.h[n_kept * n_gt];
+        if (fast) {
+            const uint64_t w = r.packed[key];
+            const uint8_t c = (uint8_t)w, f = (uint8_t)(w >> 8);
+            const uint64_t bits = w >> 16;
+            const int lb = (int)((bits >> (8 * bl - 1)) & 1u);
+            if (filter && (bits & top_mask) == 0) continue;
+            kept.push_back(key);
+            const bool in_interval = lb == 1 && c >= lower && c <= upper;
+            uint8_t one16[16] = {0};
+            uint32_t carried_mask = 0;
+            for (size_t p = 0; p < used.size(); ++p) {
+                one16[p] = (in_interval && gt0[p]) ? 1 : (uint8_t)((bits >> used[p]) & 1u);
+                carried_mask |= (uint32_t)one16[p] << p;
+            }
+            for (uint32_t q = 0, nq = n_part; q < nq; ++q) {
+                const uint16_t in = (uint16_t)(part[q] & carried_mask);
+                if (in && in != part[q]) {
+                    part[n_part++] = (uint16_t)(part[q] & ~carried_mask);
+                    part[q] = in;
+                }
+            }
+            if (c < lower && f >= 2)
+                for (size_t p = 0; p < used.size(); ++p)
+                    if (one16[p]) need_sequence.emplace(used[p], 0);
+            ns.c.push_back(c);
+            ns.f.push_back((lb == 1 && f == 1) ? (uint8_t)(f + 1) : f);
+            const size_t g16 = n_gt & ~(size_t)15;
+            hrow_pairs_ssse3(one16, gl.pos_a.data(), gl.pos_b.data(), hrow, g16);
+            for (size_t gi = g16; gi < n_gt; ++gi) hrow[gi] = (uint8_t)(one16[gl.pos_a[gi]] + one16[gl.pos_b[gi]]);
+            ++n_kept;
+            continue;
+        }
         const uint8_t c = r.cov[key];
         const uint8_t f = g_.f[key];
         const int lb = last_bit(key);
@@ -359,16 +442,8 @@ Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, cons
         }
         ns.c.push_back(c);
         ns.f.push_back((lb == 1 && f == 1) ? (uint8_t)(f + 1) : f);
-        uint8_t* hrow = &ns.h[n_kept * n_gt];
         if (pairs) {
-            size_t gi = 0;
-            if (shuffle) {
-                uint8_t one16[16] = {0};
-                for (size_t p = 0; p < used.size(); ++p) one16[p] = one[used[p]];
-                gi = n_gt & ~(size_t)15;
-                hrow_pairs_ssse3(one16, gl.pos_a.data(), gl.pos_b.data(), hrow, gi);
-            }
-            for (; gi < n_gt; ++gi) hrow[gi] = (uint8_t)(one[flat[2 * gi]] + one[flat[2 * gi + 1]]);
+            for (size_t gi = 0; gi < n_gt; ++gi) hrow[gi] = (uint8_t)(one[flat[2 * gi]] + one[flat[2 * gi + 1]]);
         } else {
             for (size_t gi = 0; gi < n_gt; ++gi) {
                 uint8_t h = 0;
@@ -379,7 +454,26 @@ Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, cons
         ++n_kept;
     }
     ns.h.resize(n_kept * n_gt);
+    while (pf != pf_end) prefetch_one();
 
+    if (fast && need_sequence.empty() && n_kept) {
+        uint8_t group[16] = {0};
+        for (uint32_t q = 0; q < n_part; ++q)
+            for (size_t p = 0; p < used.size(); ++p)
+                if ((part[q] >> p) & 1u) group[p] = (uint8_t)q;
+        int16_t id_of[256];
+        std::memset(id_of, 0xFF, sizeof id_of);
+        ns.cls.resize(n_gt);
+        for (size_t gi = 0; gi < n_gt; ++gi) {
+            const uint8_t a = group[gl.pos_a[gi]], b = group[gl.pos_b[gi]];
+            int16_t& id = id_of[a < b ? a * 16 + b : b * 16 + a];
+            if (id < 0) {
+                id = (int16_t)ns.rep.size();
+                ns.rep.push_back((uint16_t)gi);
+            }
+            ns.cls[gi] = (uint16_t)id;
+        }
+    }
     if (!need_sequence.empty()) {
         std::unordered_map<uint16_t, std::unordered_set<uint64_t>> hap_keys;
         for (const auto& [hap, unused] : need_sequence) {
@@ -435,6 +529,18 @@ void Genotyper::posterior(Node& n, const std::vector<uint16_t>& top, const Run& 
     // selected haplotype -> (#k-mers it carries, sum of their coverage); any other haplotype reads as (0, 0)
     std::vector<uint64_t> hap_num(n_hap_, 0), hap_sum(n_hap_, 0);
     for (uint32_t key : n.kmers) {
+        if (r.packed) {
+            const uint64_t w = r.packed[key];
+            const uint8_t c = (uint8_t)w;
+            const uint64_t bits = w >> 16;
+            for (uint16_t hap : top) {
+                if ((bits >> hap) & 1u) {
+                    ++hap_num[hap];
+                    hap_sum[hap] += c;
+                }
+            }
+            continue;
+        }
         const uint8_t c = r.cov[key];
         for (uint16_t hap : top) {
             if (((uint8_t)g_.bitvec[(size_t)key * bl + (hap >> 3)] >> (hap & 7)) & 1u) {
@@ -548,6 +654,10 @@ void Genotyper::posterior(Node& n, const std::vector<uint16_t>& top, const Run& 
 // asked for one node ahead of their use
 void Genotyper::prefetch_keys(const Node& n, const Run& r) const
 {
+    if (r.packed) {
+        for (uint32_t key : n.kmers) __builtin_prefetch(&r.packed[key]);
+        return;
+    }
     const uint64_t bl = g_.bitlen;
     for (uint32_t key : n.kmers) {
         __builtin_prefetch(&r.cov[key]);
@@ -556,20 +666,6 @@ void Genotyper::prefetch_keys(const Node& n, const Run& r) const
     }
 }
 
-// phase times summed over the pool's threads (VGH_TIMING): where the windows spend their time
-namespace {
-struct HmmPhases {
-    std::atomic<long long> select{0}, states{0}, emit{0}, fwd{0}, bwd{0}, post{0};
-};
-HmmPhases g_phase;
-const bool g_phase_on = getenv("VGH_TIMING") != nullptr;
-struct PhaseTimer {
-    std::atomic<long long>& acc;
-    std::chrono::steady_clock::time_point t0;
-    explicit PhaseTimer(std::atomic<long long>& a) : acc(a) { if (g_phase_on) t0 = std::chrono::steady_clock::now(); }
-    ~PhaseTimer() { if (g_phase_on) acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
-};
-}  // namespace
 
 // ---------------------------------------------------------------- one window: selection, forward, backward, posterior
 void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
@@ -588,8 +684,23 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
     const uint64_t bl = g_.bitlen;
     for (uint32_t i = first; i < last; ++i) {
         const Node& n = chr.nodes[i];
-        if (i + 1 < last) prefetch_keys(chr.nodes[i + 1], r);
         if (n.gn->hap_gt.size() == 1) continue;
+        {
+            uint32_t nx = i + 1;
+            while (nx < last && chr.nodes[nx].gn->hap_gt.size() == 1) ++nx;
+            if (nx < last) prefetch_keys(chr.nodes[nx], r);
+        }
+        if (r.packed) {
+            for (uint32_t key : n.kmers) {
+                const uint64_t w = r.packed[key];
+                const uint8_t c = (uint8_t)w;
+                if (c <= 1 || (uint8_t)(w >> 8) > 1) continue;
+                const uint64_t bits = w >> 16;
+                for (const uint16_t hap : hap_ids_)
+                    if ((bits >> hap) & 1u) support[hap] += c;
+            }
+            continue;
+        }
         for (uint32_t key : n.kmers) {
             const uint8_t c = r.cov[key];
             if (c <= 1 || g_.f[key] > 1) continue;
@@ -672,7 +783,7 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
     // Every genotype's score is the product of its k-mers' terms in k-mer order (observable_states); walking the
     // k-mers in the outer loop keeps that order per genotype and turns one long dependent multiply chain per
     // genotype into n_genotypes independent ones.  A k-mer's term depends on the genotype only through h.
-    std::vector<long double> term_buf;
+    std::vector<long double> term_buf, class_prod;
     std::vector<uint8_t> term_have;
     auto score_states = [&](const NodeStates& ns) -> std::vector<long double> {
         std::vector<long double> obs;
@@ -714,6 +825,38 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
             }
         }
         obs.resize(ng);
+        if (!ns.rep.empty()) {
+            // one product per class of genotypes with the same column of h (the same factors in the same order give the
+            // same bits), four classes in x87 registers at a time
+            const size_t nc = ns.rep.size();
+            std::vector<long double>& prod = class_prod;
+            prod.resize(nc);
+            size_t ci = 0;
+            for (; ci + 4 <= nc; ci += 4) {
+                const size_t g0 = ns.rep[ci], g1 = ns.rep[ci + 1], g2 = ns.rep[ci + 2], g3 = ns.rep[ci + 3];
+                long double r0 = 1.0L, r1 = 1.0L, r2 = 1.0L, r3 = 1.0L;
+                const uint8_t* hj = ns.h.data();
+                const long double* t = term_buf.data();
+                for (size_t j = 0; j < nk; ++j, hj += ng, t += hs) {
+                    r0 *= t[hj[g0]];
+                    r1 *= t[hj[g1]];
+                    r2 *= t[hj[g2]];
+                    r3 *= t[hj[g3]];
+                }
+                prod[ci] = r0;
+                prod[ci + 1] = r1;
+                prod[ci + 2] = r2;
+                prod[ci + 3] = r3;
+            }
+            for (; ci < nc; ++ci) {
+                long double res = 1.0L;
+                const size_t g = ns.rep[ci];
+                for (size_t j = 0; j < nk; ++j) res *= term_buf[j * hs + ns.h[j * ng + g]];
+                prod[ci] = res;
+            }
+            for (size_t g = 0; g < ng; ++g) obs[g] = prod[ns.cls[g]];
+            return obs;
+        }
         size_t gi = 0;
         for (; gi + 4 <= ng; gi += 4) {   // four products in x87 registers, each in k-mer order
             long double r0 = 1.0L, r1 = 1.0L, r2 = 1.0L, r3 = 1.0L;
@@ -849,10 +992,12 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
         if (skipped(n)) continue;
         const uint32_t n_start = n.start;
         const uint32_t n_end = (uint32_t)(n_start + n.gn->seqs[0].size() - 1);
-        if (i + 1 < last) prefetch_keys(chr.nodes[i + 1], r);
         {
             PhaseTimer t(g_phase.states);
-            states = hidden_states(chr, i, top, genotypes, used, glist, lower, upper, true, r, std::move(states));
+            uint32_t nx = i + 1;        // the node that is worked on next (nodes with one allele are passed over)
+            while (nx < last && skipped(chr.nodes[nx])) ++nx;
+            states = hidden_states(chr, i, top, genotypes, used, glist, lower, upper, true, r, std::move(states),
+                                   nx < last ? &chr.nodes[nx] : nullptr);
         }
         long double recomb = 0.0L, no_recomb = 0.0L;
         if (cfg.transition == "rec") std::tie(recomb, no_recomb) = transition_probabilities(n_start - prev_end, (uint16_t)n_hap_);
@@ -918,6 +1063,23 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
     r.hap_cov = hap_kmer_coverage;
     r.cfg = &cfg;
     r.haploid_num = std::min(cfg.haploid_num, n_hap_);
+    if (g_.bitlen <= 6) {
+        const size_t n_keys = g_.f.size(), bl = g_.bitlen;
+        packed_.resize(n_keys);
+        const uint32_t nt = std::max(1u, cfg.threads);
+        std::vector<std::thread> fill;
+        auto part = [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; ++i) {
+                uint64_t bits = 0;
+                std::memcpy(&bits, &g_.bitvec[i * bl], bl);
+                packed_[i] = (uint64_t)cov[i] | (uint64_t)(uint8_t)g_.f[i] << 8 | bits << 16;
+            }
+        };
+        for (uint32_t t = 1; t < nt; ++t) fill.emplace_back(part, n_keys * t / nt, n_keys * (t + 1) / nt);
+        part(0, n_keys / nt);
+        for (auto& th : fill) th.join();
+        r.packed = packed_.data();
+    }
 
     for (auto& c : chroms_)
         for (auto& n : c.nodes) {

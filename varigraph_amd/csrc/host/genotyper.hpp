@@ -79,6 +79,9 @@ private:
         size_t n_genotypes = 0;
         std::vector<uint32_t> kept;   // scratch reused from node to node
         std::vector<uint8_t> one;
+        // Genotypes whose haplotypes carry the same k-mers of this node have the same column of h, hence the same
+        // emission score: cls[g] = class of genotype g, rep[c] = its first member (both empty: every genotype for itself)
+        std::vector<uint16_t> cls, rep;
     };
     // the window's genotypes as one flat list (the same for every node of the window)
     struct GenotypeList {
@@ -93,7 +96,8 @@ private:
     void window(Chrom& chr, uint32_t first, uint32_t last, const Run& r);
     NodeStates hidden_states(Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& top,
                              const std::vector<std::vector<uint16_t>>& genotypes, const std::vector<uint16_t>& used,
-                             const GenotypeList& gl, double lower, double upper, bool filter, const Run& r, NodeStates&& recycled);
+                             const GenotypeList& gl, double lower, double upper, bool filter, const Run& r, NodeStates&& recycled,
+                             const Node* ahead);
     std::pair<std::string, std::string> flanks(const Chrom& chr, uint32_t node_i, uint16_t hap, uint16_t alt_gt,
                                                std::string& alt_seq, uint32_t want) const;
     void posterior(Node& n, const std::vector<uint16_t>& top, const Run& r) const;
@@ -103,6 +107,7 @@ private:
     std::vector<Chrom> chroms_;   // mGraphMap order
     uint32_t n_hap_ = 0;
     std::vector<uint16_t> hap_ids_;   // the keys of g_.hap_names in their order
+    std::vector<uint64_t> packed_;    // per key: coverage | multiplicity << 8 | haplotype bits << 16 (this sample)
 };
 
 }  // namespace vgh
