@@ -9,10 +9,12 @@
 #include <zlib.h>
 
 #include <chrono>
+#include <exception>
 #include <cstdio>
 #include <cstdlib>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -219,90 +221,185 @@ void GraphIndex::load(const std::string& path)
     if (k < 1 || k > 28) throw std::runtime_error("graph index: bad k-mer length");
     vcf_head = c.str();
 
-    const uint32_t n_info = c.get<uint32_t>();
-    for (uint32_t i = 0; i < n_info; ++i) {
-        std::string chr = c.str();
-        const uint32_t len = c.get<uint32_t>();
-        chr_len[chr] = len;
-        genome_size += len;  // construct_index.cpp:959-960
-        auto& sites = vcf_info[chr];
-        const uint32_t n_sites = c.get<uint32_t>();
-        for (uint32_t j = 0; j < n_sites; ++j) {
-            const uint32_t start = c.get<uint32_t>();
-            const uint32_t n_fields = c.get<uint32_t>();
-            std::vector<std::string> fields;
-            fields.reserve(n_fields);
-            for (uint32_t q = 0; q < n_fields; ++q) fields.push_back(c.str());
-            sites[start] = std::move(fields);
+    // The three sections -- VCF lines, nodes, k-mer records -- are independent; a first pass over the length fields finds
+    // where the second and the third begin, then the sections are read side by side (the first two on a thread of their
+    // own each, the fixed-size k-mer records by the rest).
+    auto skip_str = [](Cursor& w) {
+        const uint32_t n = w.get<uint32_t>();
+        w.need(n);
+        w.p += n;
+    };
+    Cursor c_vcf = c;
+    {
+        const uint32_t n_info = c.get<uint32_t>();
+        for (uint32_t i = 0; i < n_info; ++i) {
+            skip_str(c);
+            (void)c.get<uint32_t>();
+            const uint32_t n_sites = c.get<uint32_t>();
+            for (uint32_t j = 0; j < n_sites; ++j) {
+                (void)c.get<uint32_t>();
+                const uint32_t n_fields = c.get<uint32_t>();
+                for (uint32_t q = 0; q < n_fields; ++q) skip_str(c);
+            }
         }
     }
-
-    lap("VCF lines");
-    hap_num = c.get<uint16_t>();
-    for (uint16_t i = 0; i < hap_num; ++i) {
-        const uint16_t idx = c.get<uint16_t>();
-        hap_names.emplace(idx, c.str());
-    }
-
-    const uint32_t n_chr = c.get<uint32_t>();
-    for (uint32_t i = 0; i < n_chr; ++i) {
-        std::string chr = c.str();
-        auto& nodes = graph[chr];
-        const uint32_t n_nodes = c.get<uint32_t>();
-        for (uint32_t j = 0; j < n_nodes; ++j) {
-            GraphNode nd;
-            nd.start = c.get<uint32_t>();
-            const uint32_t n_seq = c.get<uint32_t>();
-            c.need((size_t)n_seq * 4);   // every sequence carries at least its length field
-            nd.seqs.reserve(n_seq);
-            for (uint32_t q = 0; q < n_seq; ++q) nd.seqs.push_back(c.str());
-            const uint32_t n_gt = c.get<uint32_t>();
-            c.need(sizeof(uint16_t) * (size_t)n_gt);
-            nd.hap_gt.resize(n_gt);
-            c.bytes(nd.hap_gt.data(), sizeof(uint16_t) * n_gt);
-            const uint32_t n_km = c.get<uint32_t>();
-            c.need(sizeof(uint64_t) * (size_t)n_km);
-            nd.kmer_hash.resize(n_km);
-            c.bytes(nd.kmer_hash.data(), sizeof(uint64_t) * n_km);
-            const uint32_t st = nd.start;
-            nodes[st] = std::move(nd);
+    Cursor c_nodes = c;
+    {
+        const uint16_t n_hap = c.get<uint16_t>();
+        hap_num = n_hap;          // the k-mer records are checked against it while the names are still being read
+        for (uint16_t i = 0; i < n_hap; ++i) {
+            (void)c.get<uint16_t>();
+            skip_str(c);
+        }
+        const uint32_t n_chr = c.get<uint32_t>();
+        for (uint32_t i = 0; i < n_chr; ++i) {
+            skip_str(c);
+            const uint32_t n_nodes = c.get<uint32_t>();
+            for (uint32_t j = 0; j < n_nodes; ++j) {
+                (void)c.get<uint32_t>();
+                const uint32_t n_seq = c.get<uint32_t>();
+                c.need((size_t)n_seq * 4);
+                for (uint32_t q = 0; q < n_seq; ++q) skip_str(c);
+                const uint32_t n_gt = c.get<uint32_t>();
+                c.need(sizeof(uint16_t) * (size_t)n_gt);
+                c.p += sizeof(uint16_t) * (size_t)n_gt;
+                const uint32_t n_km = c.get<uint32_t>();
+                c.need(sizeof(uint64_t) * (size_t)n_km);
+                c.p += sizeof(uint64_t) * (size_t)n_km;
+            }
         }
     }
+    lap("section offsets");
+    std::exception_ptr err_vcf, err_nodes;
+    auto read_vcf = [&]() {
+        try {
+            Cursor c = c_vcf;
+            const uint32_t n_info = c.get<uint32_t>();
+            for (uint32_t i = 0; i < n_info; ++i) {
+                std::string chr = c.str();
+                const uint32_t len = c.get<uint32_t>();
+                chr_len[chr] = len;
+                genome_size += len;  // construct_index.cpp:959-960
+                auto& sites = vcf_info[chr];
+                const uint32_t n_sites = c.get<uint32_t>();
+                for (uint32_t j = 0; j < n_sites; ++j) {
+                    const uint32_t start = c.get<uint32_t>();
+                    const uint32_t n_fields = c.get<uint32_t>();
+                    std::vector<std::string> fields;
+                    fields.reserve(n_fields);
+                    for (uint32_t q = 0; q < n_fields; ++q) fields.push_back(c.str());
+                    sites[start] = std::move(fields);
+                }
+            }
 
-    lap("nodes");
+        } catch (...) {
+            err_vcf = std::current_exception();
+        }
+    };
+    auto read_nodes = [&]() {
+        try {
+            Cursor c = c_nodes;
+            const uint16_t n_names = c.get<uint16_t>();
+            for (uint16_t i = 0; i < n_names; ++i) {
+                const uint16_t idx = c.get<uint16_t>();
+                hap_names.emplace(idx, c.str());
+            }
+
+            const uint32_t n_chr = c.get<uint32_t>();
+            for (uint32_t i = 0; i < n_chr; ++i) {
+                std::string chr = c.str();
+                auto& nodes = graph[chr];
+                const uint32_t n_nodes = c.get<uint32_t>();
+                for (uint32_t j = 0; j < n_nodes; ++j) {
+                    GraphNode nd;
+                    nd.start = c.get<uint32_t>();
+                    const uint32_t n_seq = c.get<uint32_t>();
+                    c.need((size_t)n_seq * 4);   // every sequence carries at least its length field
+                    nd.seqs.reserve(n_seq);
+                    for (uint32_t q = 0; q < n_seq; ++q) nd.seqs.push_back(c.str());
+                    const uint32_t n_gt = c.get<uint32_t>();
+                    c.need(sizeof(uint16_t) * (size_t)n_gt);
+                    nd.hap_gt.resize(n_gt);
+                    c.bytes(nd.hap_gt.data(), sizeof(uint16_t) * n_gt);
+                    const uint32_t n_km = c.get<uint32_t>();
+                    c.need(sizeof(uint64_t) * (size_t)n_km);
+                    nd.kmer_hash.resize(n_km);
+                    c.bytes(nd.kmer_hash.data(), sizeof(uint64_t) * n_km);
+                    const uint32_t st = nd.start;
+                    nodes[st] = std::move(nd);
+                }
+            }
+
+        } catch (...) {
+            err_nodes = std::current_exception();
+        }
+    };
+    std::thread th_vcf, th_nodes;
+    if (threads >= 3) {
+        th_vcf = std::thread(read_vcf);
+        th_nodes = std::thread(read_nodes);
+    } else {
+        read_vcf();
+        read_nodes();
+    }
+    struct Joiner {
+        std::thread &a, &b;
+        ~Joiner() { if (a.joinable()) a.join(); if (b.joinable()) b.join(); }
+    } joiner{th_vcf, th_nodes};
     (void)c.get<uint64_t>();  // ReadBase (always 0 in a graph index)
 
-    // k-mer records until EOF: u64 key | u8 c | u8 f | u64 bitLen | i8[bitLen]
+    // k-mer records until EOF: u64 key | u8 c | u8 f | u64 bitLen | i8[bitLen].  bitLen = floor(#haplotypes / 8) + 1 in every
+    // record (construct_index.cpp:1206-1215; the bitmap readers -- hom flags, HMM -- index it by haplotype number), so the
+    // records have one size and the threads take a stretch of them each; every record's bitLen is still checked.
     keys.clear(); f.clear(); bitvec.clear();
     bitlen = 0;
-    if ((size_t)(c.end - c.p) >= 26) {   // all records have the same size: reserve once
+    if (c.p < c.end) {
+        const size_t left = (size_t)(c.end - c.p);
+        if (left < 18) throw std::runtime_error("graph index truncated");
         uint64_t bl0;
         memcpy(&bl0, c.p + 10, 8);
-        // bitLen = floor(#haplotypes / 8) + 1 in every record (construct_index.cpp:1206-1215): the bitmap readers
-        // (hom flags, HMM) index it by haplotype number
         if (bl0 != (uint64_t)(hap_num >> 3) + 1) throw std::runtime_error("graph index corrupt: k-mer bitmap length does not match the haplotype count");
-        const size_t n_rec = (size_t)(c.end - c.p) / (18 + bl0) + 1;
-        keys.reserve(n_rec);
-        f.reserve(n_rec);
-        bitvec.reserve(n_rec * bl0);
-    }
-    while (c.p < c.end) {
-        const uint64_t key = c.get<uint64_t>();
-        (void)c.get<uint8_t>();  // c: per-sample, zero in the index
-        const uint8_t fv = c.get<uint8_t>();
-        const uint64_t bl = c.get<uint64_t>();
-        if (keys.empty()) {
-            if (bl != (uint64_t)(hap_num >> 3) + 1) throw std::runtime_error("graph index corrupt: k-mer bitmap length does not match the haplotype count");
-            bitlen = bl;
+        bitlen = bl0;
+        const size_t rec = 18 + (size_t)bl0;
+        if (left % rec != 0) {
+            // a short last record, or records of another size somewhere: the serial walk names the reason
+            Cursor w = c;
+            while (w.p < w.end) {
+                (void)w.get<uint64_t>();
+                (void)w.get<uint8_t>();
+                (void)w.get<uint8_t>();
+                const uint64_t bl = w.get<uint64_t>();
+                if (bl != bitlen) throw std::runtime_error("graph index: k-mer records with different bitmap lengths");
+                w.need((size_t)bl);
+                w.p += bl;
+            }
         }
-        if (bl != bitlen) throw std::runtime_error("graph index: k-mer records with different bitmap lengths");
-        keys.push_back(key);
-        f.push_back(fv);
-        const size_t o = bitvec.size();
-        bitvec.resize(o + bl);
-        c.bytes(bitvec.data() + o, bl);
+        const size_t n_rec = left / rec;
+        keys.resize(n_rec);
+        f.resize(n_rec);
+        bitvec.resize(n_rec * bl0);
+        const uint8_t* const base = c.p;
+        std::atomic<bool> mixed{false};
+        parallel_chunks(n_rec, threads >= 3 ? threads - 2 : threads, [&](size_t rb, size_t re, unsigned) {
+            for (size_t i = rb; i < re; ++i) {
+                const uint8_t* r = base + i * rec;
+                uint64_t bl;
+                memcpy(&keys[i], r, 8);              // key; r[8] = c: per-sample, zero in the index
+                f[i] = r[9];
+                memcpy(&bl, r + 10, 8);
+                if (bl != bl0) mixed = true;
+                memcpy(bitvec.data() + i * bl0, r + 18, bl0);
+            }
+        });
+        if (mixed) throw std::runtime_error("graph index: k-mer records with different bitmap lengths");
+        c.p = c.end;
     }
     lap("k-mer records");
+    if (th_vcf.joinable()) th_vcf.join();
+    if (th_nodes.joinable()) th_nodes.join();
+    if (err_vcf) std::rethrow_exception(err_vcf);
+    if (err_nodes) std::rethrow_exception(err_nodes);
+    lap("VCF lines, nodes");
     graph2node();
     lap("graph2node");
     compute_hom_flags();
