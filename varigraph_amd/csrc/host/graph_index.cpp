@@ -395,6 +395,7 @@ void GraphIndex::load(const std::string& path)
         c.p = c.end;
     }
     lap("k-mer records");
+    if (on_keys) on_keys();
     if (th_vcf.joinable()) th_vcf.join();
     if (th_nodes.joinable()) th_nodes.join();
     if (err_vcf) std::rethrow_exception(err_vcf);

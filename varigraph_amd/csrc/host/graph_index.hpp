@@ -9,6 +9,7 @@
 // contiguous arrays that can be handed to vgmi_table_upload / vgmi_nodes_upload as they are.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -55,6 +56,9 @@ struct GraphIndex {
     void load(const std::string& path);
     void graph2node();
     void compute_hom_flags();
+    // called by load() from its own thread as soon as keys / k are complete (the node lists and flags are not yet): lets the
+    // caller start the device's table build while graph2node still runs on the host
+    std::function<void()> on_keys;
     int upload(vgmi_ctx* ctx) const;
     int upload_nodes(vgmi_ctx* ctx) const;
 };

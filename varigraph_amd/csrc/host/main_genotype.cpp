@@ -197,6 +197,19 @@ int main_genotype(int argc, char** argv)
     // the device contexts come up (HIP runtime start, staging buffers) while the graph is read
     std::vector<vgmi_ctx*> ctxs;
     std::string ctx_error;
+    // ... and the first device builds its table as soon as the k-mer records are read, while the host still resolves the
+    // node lists (graph2node)
+    vgh::GraphIndex g;
+    std::mutex keys_mu;
+    std::condition_variable keys_cv;
+    int keys_state = 0;   // 1: keys complete, -1: the load failed before that
+    g.on_keys = [&] {
+        {
+            std::lock_guard<std::mutex> lk(keys_mu);
+            keys_state = 1;
+        }
+        keys_cv.notify_all();
+    };
     std::thread bring_up([&] {
         for (int dev : o.gpus) {
             vgmi_ctx* ctx = nullptr;
@@ -206,8 +219,13 @@ int main_genotype(int argc, char** argv)
             }
             ctxs.push_back(ctx);
         }
+        std::unique_lock<std::mutex> lk(keys_mu);
+        keys_cv.wait(lk, [&] { return keys_state != 0; });
+        if (keys_state < 0) return;
+        lk.unlock();
+        // ONE table build (first device)
+        if (vgmi_table_upload(ctxs[0], g.keys.data(), g.keys.size(), g.k) != VGMI_OK) ctx_error = vgmi_last_error(ctxs[0]);
     });
-    vgh::GraphIndex g;
     std::string load_error;
     try {
         g.threads = std::max(1u, o.hmm.threads);
@@ -215,12 +233,17 @@ int main_genotype(int argc, char** argv)
     } catch (const std::exception& e) {
         load_error = e.what();
     }
+    {
+        std::lock_guard<std::mutex> lk(keys_mu);
+        if (keys_state == 0) keys_state = -1;
+    }
+    keys_cv.notify_all();
     bring_up.join();
-    if (!ctx_error.empty()) die(ctx_error);
     if (!load_error.empty()) die(load_error);
-    // ONE table build (first device), then the image goes device to device in a doubling tree (round r: the 2^r devices
-    // that hold it feed the next 2^r over xGMI), never through the host again; node lists and flags are small host uploads
-    if (g.upload(ctxs[0]) != VGMI_OK) die(vgmi_last_error(ctxs[0]));
+    if (!ctx_error.empty()) die(ctx_error);
+    // the image then goes device to device in a doubling tree (round r: the 2^r devices that hold it feed the next 2^r over
+    // xGMI), never through the host again; node lists and flags are small host uploads
+    if (g.upload_nodes(ctxs[0]) != VGMI_OK) die(vgmi_last_error(ctxs[0]));
     const double t_built = secs();
     size_t image_bytes = 0;
     (void)vgmi_table_image_bytes(ctxs[0], &image_bytes);
