@@ -26,6 +26,7 @@
 #include <unordered_set>
 
 #include "../vgmi_device.h"
+#include "mem_advice.hpp"
 #include "node_flanks.hpp"
 
 namespace vgh {
@@ -1065,6 +1066,10 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
     r.haploid_num = std::min(cfg.haploid_num, n_hap_);
     if (g_.bitlen <= 6) {
         const size_t n_keys = g_.f.size(), bl = g_.bitlen;
+        if (packed_.capacity() < n_keys) {
+            packed_.reserve(n_keys);
+            advise_huge_pages(packed_.data(), n_keys * sizeof(uint64_t));
+        }
         packed_.resize(n_keys);
         const uint32_t nt = std::max(1u, cfg.threads);
         std::vector<std::thread> fill;

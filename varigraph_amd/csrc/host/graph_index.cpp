@@ -1,5 +1,7 @@
 #include "graph_index.hpp"
 
+#include "mem_advice.hpp"
+
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -120,6 +122,9 @@ struct KeyIndex {
         bytes = cap * sizeof(uint64_t);
         void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (m == MAP_FAILED) throw std::runtime_error("graph index: out of memory");
+#ifdef MADV_HUGEPAGE
+        (void)madvise(m, bytes, MADV_HUGEPAGE);   // touched at random: 2 MiB pages spare most of the TLB misses and page faults
+#endif
         cell = static_cast<uint64_t*>(m);
         uint64_t* cp = cell;
         // cells are claimed with a compare-and-swap, so the threads fill the table side by side; the FIRST record of a
@@ -149,6 +154,12 @@ struct KeyIndex {
         return (k ^ (k >> 29)) | (1ULL << 63);   // tag never 0: an occupied cell is never 0
     }
     void prefetch(uint64_t k) const { __builtin_prefetch(&cell[(hash(k) >> 8) & mask]); }
+    // second stage, for a key whose cell was asked for a while ago: the record its first candidate points at
+    void prefetch_record(uint64_t k) const
+    {
+        const uint64_t h = hash(k), cur = cell[(h >> 8) & mask];
+        if (cur != 0 && (cur >> 32) == (h >> 32)) __builtin_prefetch(&keys[(uint32_t) ~(uint32_t)cur]);
+    }
     bool find(uint64_t k, uint32_t& out) const
     {
         const uint64_t h = hash(k);
@@ -375,6 +386,12 @@ void GraphIndex::load(const std::string& path)
             }
         }
         const size_t n_rec = left / rec;
+        keys.reserve(n_rec);
+        f.reserve(n_rec);
+        bitvec.reserve(n_rec * bl0);
+        advise_huge_pages(keys.data(), n_rec * sizeof(uint64_t));   // before the first touch
+        advise_huge_pages(f.data(), n_rec);
+        advise_huge_pages(bitvec.data(), n_rec * bl0);
         keys.resize(n_rec);
         f.resize(n_rec);
         bitvec.resize(n_rec * bl0);
@@ -446,8 +463,10 @@ void GraphIndex::graph2node()
             std::vector<uint32_t>& kept = kept_all[v];
             kept.reserve(nd.kmer_hash.size());
             const size_t nk = nd.kmer_hash.size();
+            for (size_t j = 0; j < nk && j < 16; ++j) index.prefetch(nd.kmer_hash[j]);
             for (size_t j = 0; j < nk; ++j) {
-                if (j + 8 < nk) index.prefetch(nd.kmer_hash[j + 8]);
+                if (j + 16 < nk) index.prefetch(nd.kmer_hash[j + 16]);
+                if (j + 8 < nk) index.prefetch_record(nd.kmer_hash[j + 8]);
                 uint32_t at;
                 if (index.find(nd.kmer_hash[j], at)) kept.push_back(at);
             }
