@@ -290,3 +290,45 @@ def test_bgzf_stream_contract(graph_ctx, tmp_path):
     assert r["inflate_failed"] and r["good_compressed_bytes"] == offs[3] and r["reason"] in (1, 2, 3, 4, 5)
     assert r["consumed"] + len(r["tail"]) == 3 * 0xff00      # the text of the three members in front of it, no more
     ctx.counts_finish()
+
+
+@pytest.mark.parametrize("damage", ["clean", "truncated", "flipped_bit", "two_members_and_garbage"])
+def test_gzip_files_through_several_inflate_threads(damage, graph_ctx, tmp_path, monkeypatch):
+    """An ordinary gzip FASTQ file read with threads to spare is inflated by several of them (par_gunzip.cpp: small spans here,
+    so that the file has dozens of seams).  Counters, read count and base count must be those of the one-thread decoder --
+    also where a damaged stream ends -- on the device-parser path and on the host-parser path."""
+    import gzip
+    g, ctx, cohort = graph_ctx
+    rng = np.random.default_rng(5)
+    haps = cohort.haplotypes()
+    reads = []
+    for i in range(30_000):
+        h = haps[i % len(haps)]
+        p = int(rng.integers(0, h.size - 150))
+        reads.append(h[p:p + 150].tobytes())
+    text = b"".join(b"@A00:1:%d 1:N:0\n%s\n+\n%s\n" % (i, r, b"F" * 150) for i, r in enumerate(reads))
+    if damage == "two_members_and_garbage":
+        comp = gzip.compress(text[:4_000_000], 4) + gzip.compress(text[4_000_000:], 6) + b"\0garbage behind the last member"
+    else:
+        comp = gzip.compress(text, 4)
+    if damage == "truncated":
+        comp = comp[:len(comp) * 2 // 3]
+    elif damage == "flipped_bit":
+        b = bytearray(comp)
+        b[len(b) // 2] ^= 0x10
+        comp = bytes(b)
+    path = tmp_path / ("reads_%s.fq.gz" % damage)
+    path.write_bytes(comp)
+    monkeypatch.setenv("VGH_PARGZ_SPAN_KB", "64")
+    got = {}
+    for par in ("0", "1"):
+        monkeypatch.setenv("VGH_PAR_GUNZIP", par)
+        for host_parse in (False, True):
+            got[(par, host_parse)] = _count(g, ctx, [str(path)], host_parse)
+    ref = got[("0", True)]
+    assert ref["n_reads"] > 5_000 and int(ref["cov"].astype(np.int64).sum()) > 0
+    if damage == "clean":
+        assert ref["n_reads"] == 30_000
+    for key, r in got.items():
+        assert r["n_reads"] == ref["n_reads"] and r["read_base"] == ref["read_base"], key
+        assert np.array_equal(r["cov"], ref["cov"]), key
