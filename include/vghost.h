@@ -61,6 +61,15 @@ const char *vgh_graph_chr_name(const vgh_graph *g, uint32_t chr);
 /* table + node CSR + flags -> device context */
 int vgh_graph_upload(const vgh_graph *g, vgmi_ctx *ctx);
 
+/* The reference's per-sample dump of the k-mer table (FastqKmer::save_index / load_index, src/fastq_kmer.cpp:200-298; public but
+ * never called by its CLI): u64 ReadBase, then every record of the graph's k-mer table as
+ * u64 key | u8 c | u8 f | u64 bitLen | i8[bitLen] -- graph.bin's last section with the sample's coverage in c -- in the
+ * iteration order of the reference's unordered_map after load_index (derived, csrc/host/stl_order_map.hpp).
+ * save writes exactly the bytes the reference writes for the same counters; load accepts the records in any order (the
+ * reference loads them into a map) and fails on a key the graph does not hold. cov: n_keys bytes in key order. */
+int vgh_reads_index_save(const vgh_graph *g, const uint8_t *cov, uint64_t read_base, const char *path);
+int vgh_reads_index_load(const vgh_graph *g, const char *path, uint8_t *cov, uint64_t *read_base);
+
 /* FASTA/Q files -> '\n'-joined read block appended to a caller buffer (for tests of the parser).
  * Returns the number of reads, or <0.  *read_base gets sum(seq.l). */
 int64_t vgh_fastx_read_all(const char *path, char **block_out, size_t *n_bytes_out, uint64_t *read_base);

@@ -182,6 +182,10 @@ int vgmi_bloom_add_seq(vgmi_ctx *ctx, const char *host_bases, uint64_t len, uint
 int vgmi_bloom_add_seq_device(vgmi_ctx *ctx, const char *dev_bases, uint64_t len, uint32_t k);
 int vgmi_bloom_fetch(vgmi_ctx *ctx, uint8_t *host_filter_out /* m bytes */);
 int vgmi_bloom_load(vgmi_ctx *ctx, const uint8_t *host_filter /* m bytes */);
+/* BloomFilter::save / load (src/counting_bloom_filter.cpp:126-190; public, not called by the reference's CLI): the file is
+ * u64 size | u32 numHashes | numHashes x u64 seed | size counter bytes. load_file creates the filter from the file. */
+int vgmi_bloom_save_file(vgmi_ctx *ctx, const char *path);
+int vgmi_bloom_load_file(vgmi_ctx *ctx, const char *path);
 /* batch BloomFilter::count (min over hashes) and ::find (all non-zero); outputs may be NULL */
 int vgmi_bloom_query(vgmi_ctx *ctx, const uint64_t *host_keys, size_t n, uint8_t *host_min_out,
                      uint8_t *host_all_nonzero_out);

@@ -185,6 +185,7 @@ static int cmd_count(int argc, char** argv, bool sample) {
     fk.build_fastq_index();
     auto t3 = chrono::steady_clock::now();
     dump_counts(out, fk.mReadBase, ci);
+    if (const char* idx = getenv("VG_SAVE_READS_INDEX")) fk.save_index(idx);   // FastqKmer's own dump (src/fastq_kmer.cpp:200-238)
 
     auto sec = [](auto a, auto b) { return chrono::duration<double>(b - a).count(); };
     printf("load_s %.6f\ngraph2node_s %.6f\nbuild_fastq_index_s %.6f\nread_base %llu\nn_keys %zu\nk %u\nthreads %u\n",

@@ -591,6 +591,18 @@ def test_make_mbf_matches_reference_whole_genome_bloom(ctx, tmp_path):
         assert (gs, m, nh) == (c["genome_size"], c["m"], c["n_hash"])
         filt = ctx.bloom_fetch()
         assert hashlib.sha256(filt.tobytes()).hexdigest() == c["sha256"]
+        # BloomFilter::save's file: size, number of hashes, the 64-bit seeds, the counters -- and back through load_file
+        path = str(tmp_path / ("mbf_%d.bin" % c["k"]))
+        ctx.bloom_save_file(path)
+        data = open(path, "rb").read()
+        head = c["m"].to_bytes(8, "little") + c["n_hash"].to_bytes(4, "little") + b"".join(int(x, 16).to_bytes(8, "little") for x in c["seeds"])
+        assert data[:len(head)] == head and data[len(head):] == filt.tobytes()
+        other = vgmi.Context(0, buffer_mib=16)
+        try:
+            other.bloom_load_file(path)
+            assert np.array_equal(other.bloom_fetch(), filt)
+        finally:
+            other.close()
 
 
 def test_full_size_c2_properties(ctx):

@@ -361,3 +361,34 @@ def test_vcf_writer_emits_block_gzip_independent_of_thread_count(tmp_path):
             o += bsize
         assert o == len(raw) and total == len(text)
         assert raw.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+
+
+@pytest.mark.parametrize("name", ["cohort_snp", "cohort_sv"])
+def test_reads_index_dump_is_the_reference_file(name, tmp_path):
+    """vgh_reads_index_save writes the bytes FastqKmer::save_index writes for the same counters (sha256 of the reference's own
+    file, tests/golden/make_reads_index_golden.py); vgh_reads_index_load reads them back, also with the records reversed (the
+    reference loads them into a map), and refuses a k-mer the graph does not hold."""
+    import hashlib
+    import json
+    from conftest import get_cohort
+    cohort = get_cohort(name)
+    want = json.load(open(os.path.join(os.path.dirname(cohort.dir), "reads_index.json")))[name]
+    g = host.Graph(os.path.join(cohort.dir, "graph.bin.gz"))
+    try:
+        cov = cohort.ref_c_in_graph_order()
+        path = str(tmp_path / "reads.idx")
+        g.reads_index_save(path, cov, want["read_base"])
+        data = open(path, "rb").read()
+        assert len(data) == want["bytes"] and hashlib.sha256(data).hexdigest() == want["sha256"]
+        back, rb = g.reads_index_load(path)
+        assert rb == want["read_base"] and np.array_equal(back, cov)
+        rec = (len(data) - 8) // cov.size
+        records = [data[8 + i * rec:8 + (i + 1) * rec] for i in range(cov.size)]
+        open(path, "wb").write(data[:8] + b"".join(reversed(records)))
+        back, rb = g.reads_index_load(path)
+        assert np.array_equal(back, cov)
+        open(path, "wb").write(data[:8] + b"\x01" * 8 + records[0][8:])
+        with pytest.raises(RuntimeError, match="not in the graph"):
+            g.reads_index_load(path)
+    finally:
+        g.close()

@@ -1,6 +1,7 @@
 #include "graph_index.hpp"
 
 #include "mem_advice.hpp"
+#include "stl_order_map.hpp"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -508,6 +509,67 @@ void GraphIndex::compute_hom_flags()
             }
         }
     });
+}
+
+void GraphIndex::save_reads_index(const std::string& path, const uint8_t* cov, uint64_t read_base) const
+{
+    FILE* fp = std::fopen(path.c_str(), "wb");
+    if (!fp) throw std::runtime_error("'" + path + "': No such file or directory.");
+    const size_t rec = 18 + (size_t)bitlen, n = keys.size();
+    // The reference writes its unordered_map in iteration order, and that map was filled by load_index with operator[] in
+    // graph.bin's record order (src/construct_index.cpp:1067-1100): the order libstdc++ gives that insert sequence
+    StlOrderMap seq(0);
+    for (size_t i = 0; i < n; ++i) seq.emplace(keys[i]);
+    const std::vector<uint32_t> order = seq.order();
+    std::vector<uint8_t> buf;
+    buf.reserve((size_t)1 << 22);
+    bool ok = std::fwrite(&read_base, 8, 1, fp) == 1;
+    const uint64_t bl = bitlen;
+    for (size_t at = 0; at < n && ok; ++at) {
+        const size_t i = order[at];
+        const size_t o = buf.size();
+        buf.resize(o + rec);
+        uint8_t* r = buf.data() + o;
+        memcpy(r, &keys[i], 8);
+        r[8] = cov[i];
+        r[9] = f[i];
+        memcpy(r + 10, &bl, 8);
+        memcpy(r + 18, bitvec.data() + i * bitlen, bitlen);
+        if (buf.size() + rec > buf.capacity() || at + 1 == n) {
+            ok = std::fwrite(buf.data(), 1, buf.size(), fp) == buf.size();
+            buf.clear();
+        }
+    }
+    if (std::fclose(fp) != 0) ok = false;
+    if (!ok) throw std::runtime_error("'" + path + "': write error.");
+}
+
+void GraphIndex::load_reads_index(const std::string& path, uint8_t* cov, uint64_t& read_base) const
+{
+    Bytes in;
+    slurp(path, in);
+    Cursor c{in.data, in.data + in.size};
+    read_base = c.get<uint64_t>();
+    std::memset(cov, 0, keys.size());
+    std::unique_ptr<KeyIndex> index;      // only for a file whose records are not in this graph's order
+    size_t i = 0;
+    while (c.p < c.end) {
+        const uint64_t key = c.get<uint64_t>();
+        const uint8_t cv = c.get<uint8_t>();
+        (void)c.get<uint8_t>();           // f: the graph's own
+        const uint64_t bl = c.get<uint64_t>();
+        c.need(bl);
+        c.p += bl;
+        if (i < keys.size() && keys[i] == key) {
+            cov[i++] = cv;
+            continue;
+        }
+        if (!index) index.reset(new KeyIndex(keys, threads));
+        uint32_t at;
+        if (!index->find(key, at)) throw std::runtime_error("'" + path + "': a k-mer that is not in the graph");
+        cov[at] = cv;
+        ++i;
+    }
 }
 
 int GraphIndex::upload(vgmi_ctx* ctx) const

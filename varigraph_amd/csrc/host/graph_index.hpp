@@ -59,6 +59,9 @@ struct GraphIndex {
     // called by load() from its own thread as soon as keys / k are complete (the node lists and flags are not yet): lets the
     // caller start the device's table build while graph2node still runs on the host
     std::function<void()> on_keys;
+    // FastqKmer::save_index / load_index (src/fastq_kmer.cpp:200-298): ReadBase + the k-mer records with the sample's coverage
+    void save_reads_index(const std::string& path, const uint8_t* cov, uint64_t read_base) const;
+    void load_reads_index(const std::string& path, uint8_t* cov, uint64_t& read_base) const;
     int upload(vgmi_ctx* ctx) const;
     int upload_nodes(vgmi_ctx* ctx) const;
 };

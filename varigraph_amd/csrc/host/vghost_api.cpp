@@ -49,6 +49,30 @@ int vgh_graph_load(const char* path, vgh_graph** out)
 
 void vgh_graph_free(vgh_graph* g) { delete g; }
 
+int vgh_reads_index_save(const vgh_graph* h, const uint8_t* cov, uint64_t read_base, const char* path)
+{
+    if (!h || !cov || !path) return VGMI_E_INVALID;
+    try {
+        h->g.save_reads_index(path, cov, read_base);
+        return VGMI_OK;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return VGMI_E_INVALID;
+    }
+}
+
+int vgh_reads_index_load(const vgh_graph* h, const char* path, uint8_t* cov, uint64_t* read_base)
+{
+    if (!h || !cov || !path || !read_base) return VGMI_E_INVALID;
+    try {
+        h->g.load_reads_index(path, cov, *read_base);
+        return VGMI_OK;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return VGMI_E_INVALID;
+    }
+}
+
 int vgh_graph_get_info(const vgh_graph* h, vgh_graph_info* info)
 {
     if (!h || !info) return VGMI_E_INVALID;

@@ -110,6 +110,7 @@ struct vgmi_ctx {
     // bloom
     bool has_bloom = false;
     BloomView bv{};
+    uint64_t bloom_seeds64[VG_BLOOM_MAX_HASH] = {0};   // as handed in (the file format keeps all 64 bits)
     size_t bloom_alloc = 0;
 };
 
@@ -1495,6 +1496,7 @@ int vgmi_bloom_create(vgmi_ctx* c, uint64_t m, uint32_t n_hash, const uint64_t* 
     c->bv.magic = UINT64_MAX / m;
     c->bv.n_hash = n_hash;
     for (uint32_t i = 0; i < n_hash; ++i) c->bv.seeds[i] = (uint32_t)seeds[i];  // `unsigned int seed`
+    for (uint32_t i = 0; i < n_hash; ++i) c->bloom_seeds64[i] = seeds[i];
     c->has_bloom = true;
     return VGMI_OK;
 }
@@ -1539,6 +1541,49 @@ int vgmi_bloom_add_seq(vgmi_ctx* c, const char* bases, uint64_t len, uint32_t k)
     if (rc) return rc;
     HIPCHK(c, e);
     return VGMI_OK;
+}
+
+// BloomFilter::save / load (src/counting_bloom_filter.cpp:126-190): u64 size | u32 numHashes | numHashes x u64 seed | size bytes
+int vgmi_bloom_save_file(vgmi_ctx* c, const char* path)
+{
+    if (!c || !path) return VGMI_E_INVALID;
+    if (!c->has_bloom) return fail(c, VGMI_E_STATE, "no Bloom filter");
+    std::vector<uint8_t> filt(c->bv.m);
+    int rc = vgmi_bloom_fetch(c, filt.data());
+    if (rc != VGMI_OK) return rc;
+    FILE* fp = fopen(path, "wb");
+    if (!fp) return fail(c, VGMI_E_INVALID, std::string("'") + path + "': No such file or directory.");
+    const uint64_t m = c->bv.m;
+    const uint32_t nh = c->bv.n_hash;
+    bool ok = fwrite(&m, 8, 1, fp) == 1 && fwrite(&nh, 4, 1, fp) == 1 && fwrite(c->bloom_seeds64, 8, nh, fp) == nh &&
+              fwrite(filt.data(), 1, filt.size(), fp) == filt.size();
+    if (fclose(fp) != 0) ok = false;
+    return ok ? VGMI_OK : fail(c, VGMI_E_INVALID, std::string("'") + path + "': write error.");
+}
+
+int vgmi_bloom_load_file(vgmi_ctx* c, const char* path)
+{
+    if (!c || !path) return VGMI_E_INVALID;
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return fail(c, VGMI_E_INVALID, std::string("'") + path + "': No such file or directory.");
+    uint64_t m = 0, seeds[VG_BLOOM_MAX_HASH];
+    uint32_t nh = 0;
+    bool ok = fread(&m, 8, 1, fp) == 1 && fread(&nh, 4, 1, fp) == 1 && nh >= 1 && nh <= VG_BLOOM_MAX_HASH && m > 0 &&
+              fread(seeds, 8, nh, fp) == nh;
+    std::vector<uint8_t> filt;
+    if (ok) {
+        const long at = ftell(fp);
+        ok = at >= 0 && fseek(fp, 0, SEEK_END) == 0 && (uint64_t)(ftell(fp) - at) == m && fseek(fp, at, SEEK_SET) == 0;   // sized by the file, not by its header
+        if (ok) {
+            filt.resize(m);
+            ok = fread(filt.data(), 1, filt.size(), fp) == filt.size();
+        }
+    }
+    fclose(fp);
+    if (!ok) return fail(c, VGMI_E_INVALID, std::string("'") + path + "': not a counting Bloom filter file.");
+    int rc = vgmi_bloom_create(c, m, nh, seeds);
+    if (rc != VGMI_OK) return rc;
+    return vgmi_bloom_load(c, filt.data());
 }
 
 int vgmi_bloom_fetch(vgmi_ctx* c, uint8_t* out)

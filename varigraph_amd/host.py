@@ -130,6 +130,22 @@ class Graph:
         ctx.n_keys = self.info["n_keys"]
         ctx.n_node_entries = self.info["n_node_entries"]
 
+    def reads_index_save(self, path, cov, read_base):
+        """FastqKmer::save_index: the reference's per-sample dump of the k-mer table."""
+        cov = np.ascontiguousarray(cov, dtype=np.uint8)
+        assert cov.size == self.info["n_keys"]
+        self._l.vgh_reads_index_save.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p]
+        if self._l.vgh_reads_index_save(self._h, vgmi._ptr(cov), int(read_base), os.fsencode(path)):
+            raise RuntimeError(self._l.vgh_last_error().decode())
+
+    def reads_index_load(self, path):
+        cov = np.empty(self.info["n_keys"], dtype=np.uint8)
+        rb = C.c_uint64()
+        self._l.vgh_reads_index_load.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_uint64)]
+        if self._l.vgh_reads_index_load(self._h, os.fsencode(path), vgmi._ptr(cov), C.byref(rb)):
+            raise RuntimeError(self._l.vgh_last_error().decode())
+        return cov, rb.value
+
     def sample_count(self, ctx, fastq_paths, threads=4, sample_ploidy=2, use_depth=False, require_depth=True):
         """FastqKmerHip::build_fastq_index + coverage statistics for one sample.  require_depth=False: a sample too thin
         for the coverage peak (the reference exits with "Failed to retrieve depth information") still returns its

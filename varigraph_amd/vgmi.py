@@ -67,6 +67,8 @@ def load_library():
         "vgmi_bloom_add_seq": (i32, [vp, vp, u64, u32]),
         "vgmi_bloom_add_seq_device": (i32, [vp, vp, u64, u32]),
         "vgmi_bloom_fetch": (i32, [vp, vp]),
+        "vgmi_bloom_save_file": (i32, [vp, C.c_char_p]),
+        "vgmi_bloom_load_file": (i32, [vp, C.c_char_p]),
         "vgmi_bloom_load": (i32, [vp, vp]),
         "vgmi_bloom_query": (i32, [vp, vp, sz, vp, vp]),
         "vgmi_synth_reads_device": (i32, [vp, u64, u64, u64, u32, vp, vp, u32, vp]),
@@ -343,6 +345,13 @@ class Context:
 
     def bloom_add_seq_device(self, dev_seq, length, k):
         self._chk(self._l.vgmi_bloom_add_seq_device(self._h, _ptr(dev_seq), length, k))
+
+    def bloom_save_file(self, path):
+        self._chk(self._l.vgmi_bloom_save_file(self._h, os.fsencode(path)))
+
+    def bloom_load_file(self, path):
+        self._chk(self._l.vgmi_bloom_load_file(self._h, os.fsencode(path)))
+        self._bloom_m = os.path.getsize(path) - 12 - 8 * int.from_bytes(open(path, 'rb').read(12)[8:12], 'little')
 
     def bloom_fetch(self):
         out = np.empty(self._bloom_m, dtype=np.uint8)
