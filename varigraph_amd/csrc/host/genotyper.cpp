@@ -790,8 +790,16 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
         std::vector<long double> obs;
         const size_t nk = ns.c.size(), ng = ns.n_genotypes;
         if (ng == 0 || nk == 0) return obs;
+        // with classes of equivalent genotypes (hidden_states) every column of h equals its class's first member's:
+        // those columns alone say which copy numbers occur
+        const bool by_class = !ns.rep.empty();
         uint8_t max_h = 0;
-        for (uint8_t h : ns.h) max_h = h > max_h ? h : max_h;
+        if (by_class) {
+            for (size_t j = 0; j < nk; ++j)
+                for (uint16_t g : ns.rep) max_h = std::max(max_h, ns.h[j * ng + g]);
+        } else {
+            for (uint8_t h : ns.h) max_h = h > max_h ? h : max_h;
+        }
         const size_t hs = (size_t)max_h + 1;
         // the term of k-mer j under h copies, for the (j, h) that occur
         term_buf.resize(nk * hs);
@@ -801,7 +809,11 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
         for (size_t j = 0; j < nk; ++j) {
             const uint8_t* hj = &ns.h[j * ng];
             uint8_t* have = &term_have[j * hs];
-            for (size_t gi = 0; gi < ng; ++gi) have[hj[gi]] = 1;
+            if (by_class) {
+                for (uint16_t g : ns.rep) have[hj[g]] = 1;
+            } else {
+                for (size_t gi = 0; gi < ng; ++gi) have[hj[gi]] = 1;
+            }
         }
         for (size_t j = 0; j < nk; ++j) {
             for (size_t hh = 0; hh < hs; ++hh) {
