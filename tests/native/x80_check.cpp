@@ -1,0 +1,115 @@
+// csrc/vg_x80.h (extended precision in integer arithmetic, non-negative operands) against the x87 unit: products, sums and
+// quotients of random and edge operands -- normal numbers over the whole exponent range, results that underflow gradually,
+// denormal operands, zeros, significands of all ones / single bits / short patterns.  Prints "<n> cases, <k> mismatches".
+// Test infrastructure (tests/test_x80_cpu.py).
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+
+#include "vg_x80.h"
+
+static long double to_ld(VgX80 v)
+{
+    unsigned char b[16];
+    x80_store(b, v);
+    long double x;
+    memcpy(&x, b, sizeof x);
+    return x;
+}
+
+static VgX80 from_ld(long double x)
+{
+    unsigned char b[16] = {0};
+    memcpy(b, &x, 10);
+    return x80_load(b);
+}
+
+static bool same(VgX80 a, VgX80 b) { return a.m == b.m && a.e == b.e; }
+
+int main(int argc, char** argv)
+{
+    const long n = argc > 1 ? atol(argv[1]) : 3000000;
+    std::mt19937_64 rng(12345);
+    auto significand = [&]() -> uint64_t {
+        switch (rng() % 8) {
+            case 0: return ~0ULL;
+            case 1: return 1ULL << 63;
+            case 2: return (1ULL << 63) | 1u;
+            case 3: return (1ULL << 63) | (rng() & 0xFFFF);
+            case 4: return ~(rng() & 0xFFFF);
+            case 5: return (1ULL << 63) | (1ULL << (rng() % 63));
+            default: return rng() | (1ULL << 63);
+        }
+    };
+    auto value = [&]() -> VgX80 {
+        VgX80 v;
+        const unsigned kind = (unsigned)(rng() % 16);
+        if (kind == 0) {
+            v.m = 0;
+            v.e = 0;
+        } else if (kind == 1) {                       // denormal
+            v.e = 0;
+            v.m = significand() >> (1 + rng() % 63);
+            if (v.m == 0) v.m = 1;
+        } else if (kind < 5) {                        // close to the underflow boundary
+            v.e = 1 + (uint32_t)(rng() % 140);
+            v.m = significand();
+        } else if (kind < 8) {                        // products of these land around the boundary
+            v.e = 8100 + (uint32_t)(rng() % 300);
+            v.m = significand();
+        } else if (kind < 12) {                       // probabilities
+            v.e = VG_X80_BIAS - (uint32_t)(rng() % 200);
+            v.m = significand();
+        } else {                                      // anything below 2^8
+            v.e = 1 + (uint32_t)(rng() % (VG_X80_BIAS + 8));
+            v.m = significand();
+        }
+        return v;
+    };
+    long bad = 0, cases = 0;
+    for (long i = 0; i < n; ++i) {
+        const VgX80 a = value(), b = value();
+        volatile long double x = to_ld(a), y = to_ld(b);
+        {
+            volatile long double p = x * y;
+            if (!same(from_ld(p), x80_mul(a, b))) {
+                if (bad++ < 10) printf("mul %016llx:%u * %016llx:%u\n", (unsigned long long)a.m, a.e, (unsigned long long)b.m, b.e);
+            }
+            ++cases;
+        }
+        {
+            volatile long double s = x + y;
+            if (!same(from_ld(s), x80_add(a, b))) {
+                if (bad++ < 10) printf("add %016llx:%u + %016llx:%u\n", (unsigned long long)a.m, a.e, (unsigned long long)b.m, b.e);
+            }
+            ++cases;
+        }
+        if (b.m != 0 && (int)a.e - (int)b.e < 16000) {     // no overflow in the quotient
+            volatile long double q = x / y;
+            if (!same(from_ld(q), x80_div(a, b))) {
+                if (bad++ < 10) printf("div %016llx:%u / %016llx:%u\n", (unsigned long long)a.m, a.e, (unsigned long long)b.m, b.e);
+            }
+            ++cases;
+        }
+    }
+    // chains as the recursion builds them: r += s * o over 120 terms
+    for (long i = 0; i < n / 200; ++i) {
+        VgX80 r = {0, 0};
+        volatile long double rr = 0.0L;
+        const VgX80 o = value();
+        volatile long double oo = to_ld(o);
+        for (int t = 0; t < 120; ++t) {
+            const VgX80 s = value();
+            volatile long double ss = to_ld(s);
+            if ((int)s.e + (int)o.e > 2 * VG_X80_BIAS - 100) continue;
+            r = x80_add(r, x80_mul(s, o));
+            rr = rr + ss * oo;
+        }
+        if (!same(from_ld(rr), r)) ++bad;
+        ++cases;
+    }
+    printf("%ld cases, %ld mismatches\n", cases, bad);
+    return bad != 0;
+}
