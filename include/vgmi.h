@@ -190,6 +190,21 @@ int vgmi_bloom_load_file(vgmi_ctx *ctx, const char *path);
 int vgmi_bloom_query(vgmi_ctx *ctx, const uint64_t *host_keys, size_t n, uint8_t *host_min_out,
                      uint8_t *host_all_nonzero_out);
 
+/* ---- forward / backward recursion of the genotyping HMM in the reference's `long double` arithmetic -------------------
+ * replaces (inner loops of): GenotypeNameSpace::forward / backward (src/genotype.cpp:1170-1380) for windows whose genotypes
+ * all have `ploidy` haplotypes and whose transition is "rec".  A chain is one window walked in one direction; per step the
+ * host supplies the node's row of emission scores, the two tables of powers (libm stays on the host: no_recomb^0..ploidy,
+ * then recomb^0..ploidy) and whether the chain (re)starts there (the first node, or the node behind one without k-mers).
+ * Every value is an x86-64 `long double` in its 16-byte memory form; out[step * n_gt + g] is the normalised score the
+ * reference stores in HMMScore::a (forward chains) or ::b (backward chains), bit for bit (csrc/vg_x80.h). All pointers host. */
+typedef struct vgmi_hmm_chain {
+    uint64_t first_step, n_steps;
+    uint32_t keep_index, pad;
+} vgmi_hmm_chain;
+int vgmi_hmm_recursion(vgmi_ctx *ctx, uint32_t n_gt, uint32_t ploidy, const uint8_t *keep, uint32_t n_windows,
+                       const void *obs, uint64_t n_rows, const uint32_t *row, const uint8_t *restart, const void *pow,
+                       uint64_t n_steps, const void *uniform, const vgmi_hmm_chain *chains, uint32_t n_chains, void *out);
+
 /* ---- bench / test tooling (not part of the reference seam) -------------------------------
  * Seeded synthetic reads (varigraph_amd/csrc/vg_synth.h) written straight into device memory:
  * reads [first_read, first_read+n_reads) of the stream `seed`, each `read_len` bases + '\n'.

@@ -34,7 +34,7 @@ def _hipcc():
 
 
 def build_vgmi(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, f) for f in ("vgmi_kernels.hip", "vgmi_xtable.hip", "vgmi_fastq.hip", "vgmi_inflate.hip", "vgmi_api.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("vgmi_kernels.hip", "vgmi_xtable.hip", "vgmi_fastq.hip", "vgmi_inflate.hip", "vgmi_hmm.hip", "vgmi_api.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("vgmi_kernels.h", "vgmi_device.h", "vgmi_xtable.h", "vg_synth.h")] + [
         os.path.join(ROOT, "include", "vgmi.h")]
     if not force and not _newer(LIB, deps):

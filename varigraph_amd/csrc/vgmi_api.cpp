@@ -1543,6 +1543,58 @@ int vgmi_bloom_add_seq(vgmi_ctx* c, const char* bases, uint64_t len, uint32_t k)
     return VGMI_OK;
 }
 
+int vgmi_hmm_recursion(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, uint32_t n_windows, const void* obs,
+                       uint64_t n_rows, const uint32_t* row, const uint8_t* restart, const void* pow, uint64_t n_steps,
+                       const void* uniform, const vgmi_hmm_chain* chains, uint32_t n_chains, void* out)
+{
+    if (!c || !keep || !obs || !row || !restart || !pow || !uniform || !chains || !out) return VGMI_E_INVALID;
+    if (n_gt < 1 || n_gt > 128 || ploidy < 1 || ploidy > 4) return fail(c, VGMI_E_INVALID, "HMM recursion: 1..128 genotypes of 1..4 haplotypes");
+    for (uint32_t i = 0; i < n_chains; ++i)
+        if (chains[i].keep_index >= n_windows || chains[i].first_step + chains[i].n_steps > n_steps)
+            return fail(c, VGMI_E_INVALID, "HMM recursion: a chain points outside its arrays");
+    for (uint64_t s = 0; s < n_steps; ++s)
+        if (row[s] >= n_rows) return fail(c, VGMI_E_INVALID, "HMM recursion: a step points outside the emission rows");
+    if (n_steps == 0 || n_chains == 0) return VGMI_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t stride = ploidy + 1;
+    const size_t b_keep = (size_t)n_windows * n_gt * n_gt, b_obs = (size_t)n_rows * n_gt * 16, b_row = (size_t)n_steps * 4,
+                 b_pow = (size_t)n_steps * 2 * stride * 16, b_ch = (size_t)n_chains * sizeof(vgmi_hmm_chain), b_out = (size_t)n_steps * n_gt * 16;
+    static_assert(sizeof(vgmi_hmm_chain) == sizeof(HmmChain), "chain layout");
+    uint8_t* d = nullptr;
+    const size_t o_keep = 0, o_obs = (o_keep + b_keep + 255) & ~(size_t)255, o_row = (o_obs + b_obs + 255) & ~(size_t)255,
+                 o_rs = (o_row + b_row + 255) & ~(size_t)255, o_pow = (o_rs + n_steps + 255) & ~(size_t)255,
+                 o_uni = (o_pow + b_pow + 255) & ~(size_t)255, o_ch = o_uni + 256, o_out = (o_ch + b_ch + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), o_out + b_out);
+    if (e != hipSuccess) return fail(c, VGMI_E_NOMEM, "HMM recursion: not enough device memory");
+    hipStream_t st = c->stream;
+    e = hipMemcpyAsync(d + o_keep, keep, b_keep, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_obs, obs, b_obs, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_row, row, b_row, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_rs, restart, n_steps, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_pow, pow, b_pow, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_uni, uniform, 16, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_ch, chains, b_ch, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        HmmParams P{};
+        P.n_gt = n_gt;
+        P.ploidy = ploidy;
+        P.keep = d + o_keep;
+        P.obs = d + o_obs;
+        P.row = reinterpret_cast<const uint32_t*>(d + o_row);
+        P.restart = d + o_rs;
+        P.pow = d + o_pow;
+        P.uniform = d + o_uni;
+        P.chains = reinterpret_cast<const HmmChain*>(d + o_ch);
+        P.out = d + o_out;
+        e = launch_hmm_recursion(P, n_chains, st);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d + o_out, b_out, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    HIPCHK(c, e);
+    return VGMI_OK;
+}
+
 // BloomFilter::save / load (src/counting_bloom_filter.cpp:126-190): u64 size | u32 numHashes | numHashes x u64 seed | size bytes
 int vgmi_bloom_save_file(vgmi_ctx* c, const char* path)
 {

@@ -1,0 +1,98 @@
+// vgmi_hmm.hip -- the forward / backward recursion of the genotyping HMM on the device, in the reference's arithmetic.
+//
+// replaces (inner loops of): GenotypeNameSpace::forward / backward (src/genotype.cpp:1170-1380): for every genotype g of the
+// window,  r_g = sum over the previous node's entries p, IN THEIR ORDER, of  ((prev_p * no_recomb^keep) * recomb^change) * obs_g,
+// keep = haplotypes g and p share, change = ploidy - keep;  then  total = sum of r_g in genotype order,  out_g = r_g / total
+// (1 / n when total is zero).  The first node of a chain has  r_g = obs_g.  All of it is `long double` on the host; here it is
+// vg_x80.h: the x87 unit's results bit for bit (one rounding per operation, gradual underflow), in integer instructions.
+//
+// One workgroup per chain (a window in one direction), one lane per genotype (<= 128).  The chain is serial node by node and
+// term by term -- that is the reference's order of additions -- so the parallelism is genotypes x chains: 120 lanes x 2 x
+// the windows of a sample.  The libm values (exp, pow) stay on the host and arrive as tables per step.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vg_x80.h"
+#include "vgmi_kernels.h"
+
+namespace vgk {
+
+__global__ __launch_bounds__(128) void hmm_recursion_kernel(HmmParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t hmm_smem[];
+    const uint32_t n = P.n_gt, stride = P.ploidy + 1, g = threadIdx.x;
+    const bool active = g < n;
+    uint8_t* const s_keep = hmm_smem;                                              // n * n
+    uint64_t* const s_step_m = reinterpret_cast<uint64_t*>(hmm_smem + ((n * n + 15u) & ~15u));   // 128 * stride
+    uint32_t* const s_step_e = reinterpret_cast<uint32_t*>(s_step_m + 128u * stride);
+    uint64_t* const s_r_m = reinterpret_cast<uint64_t*>(s_step_e + 128u * stride);      // 512 * stride bytes on: 8-byte aligned
+    uint32_t* const s_r_e = reinterpret_cast<uint32_t*>(s_r_m + 128);
+
+    const HmmChain ch = P.chains[blockIdx.x];
+    const uint8_t* keep_g = P.keep + (size_t)ch.keep_index * n * n;
+    for (uint32_t i = g; i < n * n; i += blockDim.x) s_keep[i] = keep_g[i];
+    __syncthreads();
+    const uint8_t* const my_keep = s_keep + (size_t)g * n;
+    const VgX80 uniform = x80_load(P.uniform);
+
+    VgX80 prev = {0, 0};
+    for (uint64_t s = ch.first_step; s < ch.first_step + ch.n_steps; ++s) {
+        const bool restart = P.restart[s] != 0;
+        VgX80 o = {0, 0};
+        if (active) o = x80_load(P.obs + ((size_t)P.row[s] * n + g) * 16);
+        if (!restart) {
+            // (prev * no_recomb^keep) * recomb^change for this lane's previous entry and every keep
+            const uint8_t* pw = P.pow + s * (size_t)(2 * stride) * 16;
+            for (uint32_t k = 0; k < stride; ++k) {
+                const VgX80 pk = x80_load(pw + (size_t)k * 16), pc = x80_load(pw + (size_t)(stride + (P.ploidy - k)) * 16);
+                const VgX80 st = x80_mul(x80_mul(prev, pk), pc);
+                s_step_m[g * stride + k] = st.m;
+                s_step_e[g * stride + k] = st.e;
+            }
+        }
+        __syncthreads();
+        VgX80 r = {0, 0};
+        if (active) {
+            if (restart) {
+                r = o;
+            } else {
+                for (uint32_t p = 0; p < n; ++p) {
+                    const uint32_t at = p * stride + my_keep[p];
+                    VgX80 st;
+                    st.m = s_step_m[at];
+                    st.e = s_step_e[at];
+                    r = x80_add(r, x80_mul(st, o));
+                }
+            }
+        }
+        s_r_m[g] = r.m;
+        s_r_e[g] = r.e;
+        __syncthreads();
+        VgX80 total = {0, 0};
+        for (uint32_t p = 0; p < n; ++p) {
+            VgX80 t;
+            t.m = s_r_m[p];
+            t.e = s_r_e[p];
+            total = x80_add(total, t);
+        }
+        const VgX80 out = total.m != 0 ? x80_div(r, total) : uniform;
+        prev = out;
+        if (active) x80_store(P.out + (s * n + g) * 16, out);
+        __syncthreads();
+    }
+}
+
+size_t hmm_lds_bytes(uint32_t n_gt, uint32_t ploidy)
+{
+    const uint32_t stride = ploidy + 1;
+    return (((size_t)n_gt * n_gt + 15u) & ~(size_t)15u) + (size_t)128 * stride * 12 + (size_t)128 * 12 + 64;
+}
+
+hipError_t launch_hmm_recursion(const HmmParams& P, uint32_t n_chains, hipStream_t st)
+{
+    if (n_chains == 0) return hipSuccess;
+    hipLaunchKernelGGL(hmm_recursion_kernel, dim3(n_chains), dim3(128), hmm_lds_bytes(P.n_gt, P.ploidy), st, P);
+    return hipGetLastError();
+}
+
+}  // namespace vgk

@@ -122,6 +122,26 @@ struct BgzfVerdict {         // device-resident, per stream
 hipError_t launch_bgzf_inflate(const uint8_t* comp, const BgzfMember* members, uint32_t n_members, uint8_t* out_base, uint32_t* status,
                                const uint32_t* crc_table, BgzfVerdict* verdict, hipStream_t s);
 
+// ---- HMM recursion (vgmi_hmm.hip) ----
+struct HmmChain {
+    uint64_t first_step, n_steps;   // its steps in the step arrays, in the order they are taken
+    uint32_t keep_index;            // which keep matrix (one per window)
+    uint32_t pad;
+};
+struct HmmParams {
+    uint32_t n_gt, ploidy;          // genotypes per window (<= 128), haplotypes per genotype (<= 4)
+    const uint8_t* keep;            // per window: n_gt x n_gt, haplotypes shared by genotype g (row) and previous entry p
+    const uint8_t* obs;             // per node: n_gt emission scores, 16 bytes each (x86-64 long double)
+    const uint32_t* row;            // per step: the node's row in obs
+    const uint8_t* restart;         // per step: the chain begins (again) here: r = obs
+    const uint8_t* pow;             // per step: no_recomb^0..ploidy, then recomb^0..ploidy, 16 bytes each
+    const uint8_t* uniform;         // 1 / n_gt as the host computes it
+    const HmmChain* chains;
+    uint8_t* out;                   // per step: n_gt normalised scores
+};
+hipError_t launch_hmm_recursion(const HmmParams& P, uint32_t n_chains, hipStream_t st);
+size_t hmm_lds_bytes(uint32_t n_gt, uint32_t ploidy);
+
 hipError_t launch_xtable_build(const XTableView& t, const unsigned long long* slots8, const uint32_t* key_slot, const uint32_t* id_of_key,
                                uint64_t n_keys, uint32_t* over_list, uint32_t over_cap, unsigned long long* over_n, hipStream_t st);
 hipError_t launch_xtable_over(ulonglong2* over, uint32_t over_mask, const unsigned long long* slots8, const uint32_t* key_slot,

@@ -66,6 +66,7 @@ def load_library():
         "vgmi_bloom_create": (i32, [vp, u64, u32, vp]),
         "vgmi_bloom_add_seq": (i32, [vp, vp, u64, u32]),
         "vgmi_bloom_add_seq_device": (i32, [vp, vp, u64, u32]),
+        "vgmi_hmm_recursion": (i32, [vp, u32, u32, vp, u32, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp, u32, vp]),
         "vgmi_bloom_fetch": (i32, [vp, vp]),
         "vgmi_bloom_save_file": (i32, [vp, C.c_char_p]),
         "vgmi_bloom_load_file": (i32, [vp, C.c_char_p]),
@@ -345,6 +346,26 @@ class Context:
 
     def bloom_add_seq_device(self, dev_seq, length, k):
         self._chk(self._l.vgmi_bloom_add_seq_device(self._h, _ptr(dev_seq), length, k))
+
+    def hmm_recursion(self, keep, obs, row, restart, pow_tables, uniform, chains, ploidy):
+        """Forward / backward recursion of the HMM on the device (vgmi_hmm_recursion).  keep: (windows, n_gt, n_gt) uint8;
+        obs: (rows, n_gt) longdouble; row, restart: per step; pow_tables: (steps, 2, ploidy + 1) longdouble; uniform:
+        longdouble scalar; chains: list of (first_step, n_steps, keep_index).  Returns (steps, n_gt) longdouble."""
+        keep = np.ascontiguousarray(keep, dtype=np.uint8)
+        obs = np.ascontiguousarray(obs, dtype=np.longdouble)
+        row = np.ascontiguousarray(row, dtype=np.uint32)
+        restart = np.ascontiguousarray(restart, dtype=np.uint8)
+        pow_tables = np.ascontiguousarray(pow_tables, dtype=np.longdouble)
+        uni = np.ascontiguousarray([uniform], dtype=np.longdouble)
+        n_gt = obs.shape[1]
+        ch = np.zeros((len(chains), 3), dtype=np.uint64)
+        for i, (f, n, k) in enumerate(chains):
+            ch[i] = (f, n, k)       # keep_index | pad << 32 in the third word (little endian)
+        out = np.zeros((row.size, n_gt), dtype=np.longdouble)
+        assert obs.itemsize == 16 and pow_tables.shape == (row.size, 2, ploidy + 1)
+        self._chk(self._l.vgmi_hmm_recursion(self._h, n_gt, ploidy, _ptr(keep), keep.shape[0], _ptr(obs), obs.shape[0], _ptr(row),
+                                              _ptr(restart), _ptr(pow_tables), row.size, _ptr(uni), _ptr(ch), len(chains), _ptr(out)))
+        return out
 
     def bloom_save_file(self, path):
         self._chk(self._l.vgmi_bloom_save_file(self._h, os.fsencode(path)))
