@@ -56,11 +56,21 @@ __global__ __launch_bounds__(128) void hmm_recursion_kernel(HmmParams P)
             if (restart) {
                 r = o;
             } else {
+                // the table entry of term p + 1 and the keep byte of term p + 2 are fetched while term p is computed: the
+                // chain r -> r is the only dependency the loop has to wait for (one wavefront per SIMD: nothing else hides LDS)
+                uint32_t at = my_keep[0];
+                VgX80 nx;
+                nx.m = s_step_m[at];
+                nx.e = s_step_e[at];
+                uint32_t k2 = n > 1 ? my_keep[1] : 0;
                 for (uint32_t p = 0; p < n; ++p) {
-                    const uint32_t at = p * stride + my_keep[p];
-                    VgX80 st;
-                    st.m = s_step_m[at];
-                    st.e = s_step_e[at];
+                    const VgX80 st = nx;
+                    if (p + 1 < n) {
+                        at = (p + 1) * stride + k2;
+                        nx.m = s_step_m[at];
+                        nx.e = s_step_e[at];
+                        k2 = my_keep[p + 2 < n ? p + 2 : p + 1];
+                    }
                     r = x80_add(r, x80_mul(st, o));
                 }
             }
@@ -69,10 +79,15 @@ __global__ __launch_bounds__(128) void hmm_recursion_kernel(HmmParams P)
         s_r_e[g] = r.e;
         __syncthreads();
         VgX80 total = {0, 0};
+        VgX80 tn;
+        tn.m = s_r_m[0];
+        tn.e = s_r_e[0];
         for (uint32_t p = 0; p < n; ++p) {
-            VgX80 t;
-            t.m = s_r_m[p];
-            t.e = s_r_e[p];
+            const VgX80 t = tn;
+            if (p + 1 < n) {
+                tn.m = s_r_m[p + 1];
+                tn.e = s_r_e[p + 1];
+            }
             total = x80_add(total, t);
         }
         const VgX80 out = total.m != 0 ? x80_div(r, total) : uniform;
