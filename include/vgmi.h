@@ -204,6 +204,16 @@ typedef struct vgmi_hmm_chain {
 int vgmi_hmm_recursion(vgmi_ctx *ctx, uint32_t n_gt, uint32_t ploidy, const uint8_t *keep, uint32_t n_windows,
                        const void *obs, uint64_t n_rows, const uint32_t *row, const uint8_t *restart, const void *pow,
                        uint64_t n_steps, const void *uniform, const vgmi_hmm_chain *chains, uint32_t n_chains, void *out);
+/* The same recursion followed by the posterior of every node (src/genotype.cpp:1387-1522) while alpha and beta are still
+ * on the device: per row (node) the host gives the genotype STRING of every entry (gid: the reference keys a std::map by
+ * the alleles as decimal strings, sorted as strings) and the strings in string order (order, 0xFF behind the last), and the
+ * steps that hold the row's alpha and beta.  Back come the winning string's probability (16-byte long double) and the entry
+ * that makes the call (winner; 0xFFFFFFFF: none, as when every posterior is NaN or zero on the host).  alpha_beta_or_null as
+ * `out` above when the caller wants them too. */
+int vgmi_hmm_calls(vgmi_ctx *ctx, uint32_t n_gt, uint32_t ploidy, const uint8_t *keep, uint32_t n_windows, const void *obs,
+                   uint64_t n_rows, const uint32_t *row, const uint8_t *restart, const void *pow, uint64_t n_steps,
+                   const void *uniform, const vgmi_hmm_chain *chains, uint32_t n_chains, const uint8_t *gid, const uint8_t *order,
+                   const uint64_t *fwd_step, const uint64_t *bwd_step, void *prob, uint32_t *winner, void *alpha_beta_or_null);
 
 /* ---- bench / test tooling (not part of the reference seam) -------------------------------
  * Seeded synthetic reads (varigraph_amd/csrc/vg_synth.h) written straight into device memory:

@@ -258,6 +258,27 @@ struct Genotyper::Run {
     uint32_t haploid_num;   // min(-n, #haplotypes)
 };
 
+// A window prepared for the device recursion: its genotypes, the emission scores of its nodes and the tables of powers of
+// both directions; window_finish() turns the device's alpha / beta into the nodes' calls.
+struct Genotyper::WindowWork {
+    Chrom* chr = nullptr;
+    bool on_device = false;
+    std::vector<uint16_t> top;
+    std::vector<std::vector<uint16_t>> genotypes;
+    std::vector<uint8_t> keep_mat;
+    size_t n_gt = 0;
+    uint32_t ploidy = 0;
+    std::vector<uint32_t> nodes;                  // nodes with emission scores, in position order
+    // where this window's rows and steps go in the run's arrays (room for every node the HMM works on; the tail stays unused)
+    size_t row0 = 0, step0 = 0, room = 0;
+    long double* obs = nullptr;                   // row0 on: nodes.size() x n_gt emission scores
+    long double* pw = nullptr;                    // step0 on: per step no_recomb^0..ploidy, recomb^0..ploidy
+    uint32_t* row = nullptr;                      // step0 on: forward chain (the nodes in order), then backward chain (from the last)
+    uint8_t* restart = nullptr;
+    uint8_t *gid = nullptr, *order = nullptr;     // row0 on: per node the genotype string of every entry / the strings in string order
+    uint64_t *fwd_step = nullptr, *bwd_step = nullptr;   // row0 on: the steps that hold the node's alpha / beta
+};
+
 Genotyper::Genotyper(const GraphIndex& g) : g_(g)
 {
     n_hap_ = (uint32_t)g.hap_names.size();
@@ -669,7 +690,7 @@ void Genotyper::prefetch_keys(const Node& n, const Run& r) const
 
 
 // ---------------------------------------------------------------- one window: selection, forward, backward, posterior
-void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
+void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, WindowWork* work)
 {
     const GenotypeConfig& cfg = *r.cfg;
     auto vcf_chr = g_.vcf_info.find(chr.name);
@@ -995,6 +1016,74 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
 
     // ---- forward.  The emissions are kept for the backward pass: it would recompute exactly the same hidden states
     // (it runs on the k-mer lists this pass has just pruned, with the same coverage and the same genotypes).
+    // Device recursion: this pass fills hidden states, emission scores and the libm tables of every node; the recursion
+    // itself and the posterior follow in window_finish() (the pruning of a node's k-mer list depends on the window's
+    // haplotypes, not on alpha, so nothing here waits for the recursion)
+    const bool to_device = work != nullptr && work->obs != nullptr && n_gt == work->n_gt && cfg.transition == "rec" && all_full && n_gt <= 128 &&
+                           cfg.sample_ploidy >= 1 && cfg.sample_ploidy <= 4;
+    if (to_device) {
+        const uint32_t stride = cfg.sample_ploidy + 1;
+        struct Seen { uint32_t start, end; int32_t at; };   // every node the HMM works on; at: its place in work->nodes or -1
+        std::vector<Seen> seen;
+        NodeStates st;
+        for (uint32_t i = first; i < last; ++i) {
+            Node& n = chr.nodes[i];
+            if (skipped(n)) continue;
+            const uint32_t n_start = n.start;
+            const uint32_t n_end = (uint32_t)(n_start + n.gn->seqs[0].size() - 1);
+            {
+                PhaseTimer t(g_phase.states);
+                uint32_t nx = i + 1;
+                while (nx < last && skipped(chr.nodes[nx])) ++nx;
+                st = hidden_states(chr, i, top, genotypes, used, glist, lower, upper, true, r, std::move(st), nx < last ? &chr.nodes[nx] : nullptr);
+            }
+            std::vector<long double> obs;
+            {
+                PhaseTimer t(g_phase.emit);
+                obs = score_states(st);
+            }
+            if (obs.empty()) {
+                seen.push_back(Seen{n_start, n_end, -1});
+                continue;
+            }
+            seen.push_back(Seen{n_start, n_end, (int32_t)work->nodes.size()});
+            if (work->nodes.size() >= work->room || obs.size() != n_gt) throw std::runtime_error("internal: device HMM window larger than announced");
+            std::memcpy(work->obs + work->nodes.size() * n_gt, obs.data(), n_gt * sizeof(long double));
+            genotype_strings(n, genotypes, work->gid + work->nodes.size() * n_gt, work->order + work->nodes.size() * n_gt);
+            work->nodes.push_back(i);
+        }
+        const size_t m = work->nodes.size();
+        auto powers = [&](long double* dst, uint32_t distance) {
+            long double recomb, no_recomb;
+            std::tie(recomb, no_recomb) = transition_probabilities(distance, (uint16_t)n_hap_);
+            for (uint32_t k = 0; k < stride; ++k) {
+                dst[k] = std::pow(no_recomb, (int32_t)k);
+                dst[stride + k] = std::pow(recomb, (int32_t)k);
+            }
+        };
+        for (size_t q = 0; q < seen.size(); ++q) {
+            if (seen[q].at < 0) continue;
+            const size_t j = (size_t)seen[q].at, fs = j, bs = m + (m - 1 - j);     // its forward and its backward step
+            // forward: the node in front (prev_end = 0 in front of the first); the chain restarts behind a node without scores
+            powers(work->pw + fs * 2 * stride, seen[q].start - (q ? seen[q - 1].end : 0u));
+            work->restart[fs] = (q == 0 || seen[q - 1].at < 0) ? 1 : 0;
+            work->row[fs] = (uint32_t)(work->row0 + j);
+            // backward: the node behind (prev_start = 0 behind the last)
+            powers(work->pw + bs * 2 * stride, (q + 1 < seen.size() ? seen[q + 1].start : 0u) - seen[q].end);
+            work->restart[bs] = (q + 1 == seen.size() || seen[q + 1].at < 0) ? 1 : 0;
+            work->row[bs] = (uint32_t)(work->row0 + j);
+            work->fwd_step[j] = work->step0 + fs;
+            work->bwd_step[j] = work->step0 + bs;
+        }
+        work->chr = &chr;
+        work->on_device = true;
+        work->n_gt = n_gt;
+        work->ploidy = cfg.sample_ploidy;
+        work->top = top;
+        work->keep_mat = keep_mat;
+        work->genotypes = genotypes;
+        return;
+    }
     std::vector<std::vector<long double>> emissions(last - first);
     const std::vector<HmmScore> no_prev;
     const std::vector<HmmScore>* prev = &no_prev;   // the entries of the node scored before this one
@@ -1066,6 +1155,97 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r)
     }
 }
 
+// The genotype STRING of every entry of a node (posterior(): alleles as decimal strings, sorted as strings, joined by '/'),
+// as small numbers in order of first appearance, and those numbers in string order (0xFF behind the last): what the
+// device's posterior groups and ranks by.
+void Genotyper::genotype_strings(const Node& n, const std::vector<std::vector<uint16_t>>& genotypes, uint8_t* gid, uint8_t* order) const
+{
+    const auto& hap_gt = n.gn->hap_gt;
+    uint16_t max_allele = 0;
+    for (uint16_t a : hap_gt) max_allele = a > max_allele ? a : max_allele;
+    std::vector<std::string> allele_text((size_t)max_allele + 1);
+    auto text_of = [&](uint16_t a) -> const std::string& {
+        if (allele_text[a].empty()) allele_text[a] = std::to_string(a);
+        return allele_text[a];
+    };
+    std::vector<std::string> texts;
+    std::vector<std::vector<uint16_t>> tuples;
+    const size_t na = (size_t)max_allele + 1;
+    std::vector<int32_t> pair_id;
+    if (na <= 64) pair_id.assign(na * na, -2);
+    std::vector<uint16_t> tuple;
+    for (size_t i = 0; i < genotypes.size(); ++i) {
+        const auto& haps = genotypes[i];
+        int32_t* memo = nullptr;
+        if (haps.size() == 2 && !pair_id.empty()) {
+            memo = &pair_id[(size_t)hap_gt[haps[0]] * na + hap_gt[haps[1]]];
+            if (*memo != -2) {
+                gid[i] = (uint8_t)*memo;
+                continue;
+            }
+        }
+        tuple.clear();
+        for (uint16_t hap : haps) tuple.push_back(hap_gt[hap]);
+        std::sort(tuple.begin(), tuple.end(), [&](uint16_t x, uint16_t y) { return text_of(x) < text_of(y); });
+        int32_t id = -1;
+        for (size_t d = 0; d < tuples.size(); ++d)
+            if (tuples[d] == tuple) { id = (int32_t)d; break; }
+        if (id < 0) {
+            id = (int32_t)tuples.size();
+            tuples.push_back(tuple);
+            std::string t;
+            for (size_t q = 0; q < tuple.size(); ++q) {
+                t += text_of(tuple[q]);
+                if (q + 1 != tuple.size()) t += "/";
+            }
+            texts.push_back(std::move(t));
+        }
+        gid[i] = (uint8_t)id;
+        if (memo) *memo = id;
+    }
+    std::vector<size_t> by_text(texts.size());
+    for (size_t d = 0; d < by_text.size(); ++d) by_text[d] = d;
+    std::sort(by_text.begin(), by_text.end(), [&](size_t x, size_t y) { return texts[x] < texts[y]; });
+    for (size_t q = 0; q < genotypes.size(); ++q) order[q] = q < by_text.size() ? (uint8_t)by_text[q] : 0xFF;
+}
+
+// the device's verdict on the nodes of a window prepared by window(): probability of the winning genotype string and the
+// entry that makes the call, per node; the rest of the call (k-mer counts of its haplotypes) as posterior() fills it
+void Genotyper::window_finish(WindowWork& w, const long double* prob, const uint32_t* winner, const Run& r)
+{
+    const uint64_t bl = g_.bitlen;
+    std::vector<uint64_t> hap_num(n_hap_), hap_sum(n_hap_);
+    for (size_t j = 0; j < w.nodes.size(); ++j) {
+        if (winner[j] >= w.n_gt) continue;            // no entry with a positive posterior: no call
+        PhaseTimer t(g_phase.post);
+        Node& n = w.chr->nodes[w.nodes[j]];
+        uint8_t unique_kmers = 0;
+        std::fill(hap_num.begin(), hap_num.end(), 0);
+        std::fill(hap_sum.begin(), hap_sum.end(), 0);
+        for (uint32_t key : n.kmers) {
+            if (g_.f[key] <= 1 && unique_kmers < UINT8_MAX) unique_kmers++;
+            const uint8_t c = r.cov[key];
+            for (uint16_t hap : w.top)
+                if (((uint8_t)g_.bitvec[(size_t)key * bl + (hap >> 3)] >> (hap & 7)) & 1u) {
+                    ++hap_num[hap];
+                    hap_sum[hap] += c;
+                }
+        }
+        n.call.probability = prob[j];
+        n.call.haps = w.genotypes[winner[j]];
+        n.call.kmer_num.clear();
+        n.call.kmer_ave_cov.clear();
+        for (uint16_t hap : n.call.haps) {
+            const uint64_t num = hap < n_hap_ ? hap_num[hap] : 0;
+            const uint64_t sum = hap < n_hap_ ? hap_sum[hap] : 0;
+            const float ave = (num != 0) ? static_cast<float>(sum) / (float)num : 0.0;
+            n.call.kmer_num.push_back(num);
+            n.call.kmer_ave_cov.push_back(ave);
+        }
+        n.call.unique_kmers = unique_kmers;
+    }
+}
+
 // ---------------------------------------------------------------- driver + VCF text
 std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const std::string& sample_name,
                            const GenotypeConfig& cfg)
@@ -1126,6 +1306,60 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
             tasks.push_back({&chr, first, end});
         }
     }
+    // With a device context (set_device; VGH_HMM_DEVICE=0 keeps the host): recursion and posterior of the eligible windows on the
+    // device (window(), window_finish()).
+    // The windows write their emission scores and step tables straight into the run's arrays: room for every node with more
+    // than one allele is set aside per window (a node without k-mers leaves its row unused).
+    const bool use_device = dev_ != nullptr && [] { const char* e = getenv("VGH_HMM_DEVICE"); return !(e && e[0] == '0'); }() &&
+                            cfg.transition == "rec" && cfg.sample_ploidy >= 1 && cfg.sample_ploidy <= 4;
+    std::vector<WindowWork> works(use_device ? tasks.size() : 0);
+    size_t dev_n_gt = 0, total_room = 0;
+    const uint32_t dev_stride = cfg.sample_ploidy + 1;
+    struct Raw {
+        void* p = nullptr;
+        ~Raw() { std::free(p); }
+    } raw_obs, raw_pw, raw_row, raw_restart, raw_gid, raw_order, raw_fs, raw_bs, raw_prob, raw_win;
+    if (use_device) {
+        std::vector<uint16_t> some(std::min<size_t>(r.haploid_num, n_hap_));
+        for (size_t i = 0; i < some.size(); ++i) some[i] = (uint16_t)i;
+        dev_n_gt = haplotype_combinations(some, cfg.sample_type, cfg.sample_ploidy, (uint16_t)(n_hap_ - 1)).size();
+        for (size_t t = 0; t < tasks.size(); ++t) {
+            size_t room = 0;
+            for (uint32_t i = tasks[t].first; i < tasks[t].last; ++i) room += tasks[t].chr->nodes[i].gn->hap_gt.size() > 1;
+            works[t].room = room;
+            works[t].row0 = total_room;
+            works[t].step0 = 2 * total_room;
+            total_room += room;
+        }
+        // (the emission scores of all windows are held at once: beyond 6 GiB the host runs the recursion as before)
+        if (dev_n_gt >= 1 && dev_n_gt <= 128 && total_room && total_room * dev_n_gt * sizeof(long double) <= ((size_t)6 << 30)) {
+            raw_obs.p = std::malloc(total_room * dev_n_gt * sizeof(long double));
+            raw_pw.p = std::malloc(2 * total_room * 2 * dev_stride * sizeof(long double));
+            raw_row.p = std::calloc(2 * total_room, sizeof(uint32_t));
+            raw_restart.p = std::calloc(2 * total_room, 1);
+            raw_gid.p = std::calloc(total_room * dev_n_gt, 1);
+            raw_order.p = std::calloc(total_room * dev_n_gt, 1);
+            raw_fs.p = std::calloc(total_room, sizeof(uint64_t));
+            raw_bs.p = std::calloc(total_room, sizeof(uint64_t));
+            raw_prob.p = std::malloc(total_room * sizeof(long double));
+            raw_win.p = std::malloc(total_room * sizeof(uint32_t));
+            if (!raw_obs.p || !raw_pw.p || !raw_row.p || !raw_restart.p || !raw_gid.p || !raw_order.p || !raw_fs.p || !raw_bs.p || !raw_prob.p || !raw_win.p)
+                throw std::runtime_error("out of memory (HMM tables)");
+            advise_huge_pages(raw_obs.p, total_room * dev_n_gt * sizeof(long double));       // gigabytes, first touched here and by the copies
+            for (size_t t = 0; t < tasks.size(); ++t) {
+                works[t].n_gt = dev_n_gt;      // a window whose genotype list has another length takes the host path
+                works[t].obs = static_cast<long double*>(raw_obs.p) + works[t].row0 * dev_n_gt;
+                works[t].pw = static_cast<long double*>(raw_pw.p) + works[t].step0 * 2 * dev_stride;
+                works[t].row = static_cast<uint32_t*>(raw_row.p) + works[t].step0;
+                works[t].restart = static_cast<uint8_t*>(raw_restart.p) + works[t].step0;
+                works[t].gid = static_cast<uint8_t*>(raw_gid.p) + works[t].row0 * dev_n_gt;
+                works[t].order = static_cast<uint8_t*>(raw_order.p) + works[t].row0 * dev_n_gt;
+                works[t].fwd_step = static_cast<uint64_t*>(raw_fs.p) + works[t].row0;
+                works[t].bwd_step = static_cast<uint64_t*>(raw_bs.p) + works[t].row0;
+            }
+        }
+    }
+    const bool device_ready = raw_obs.p != nullptr;
     std::atomic<size_t> next{0};
     std::string error;
     std::atomic<bool> failed{false};
@@ -1134,7 +1368,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
             const size_t t = next.fetch_add(1);
             if (t >= tasks.size() || failed.load()) return;
             try {
-                window(*tasks[t].chr, tasks[t].first, tasks[t].last, r);
+                window(*tasks[t].chr, tasks[t].first, tasks[t].last, r, device_ready ? &works[t] : nullptr);
             } catch (const std::exception& e) {
                 if (!failed.exchange(true)) error = e.what();
                 return;
@@ -1147,12 +1381,61 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
     worker();
     for (auto& th : pool) th.join();
     if (failed.load()) throw std::runtime_error(error);
+    last_device_seconds = 0;
+    if (device_ready) {
+        // ---- the recursion of every prepared window in ONE device call (a chain per window and direction), then the calls
+        std::vector<size_t> dw;
+        for (size_t t = 0; t < works.size(); ++t)
+            if (works[t].on_device && !works[t].nodes.empty()) dw.push_back(t);
+        if (!dw.empty()) {
+            const size_t n = dev_n_gt;
+            std::vector<uint8_t> keep(dw.size() * n * n);
+            std::vector<vgmi_hmm_chain> chains;
+            for (size_t wi = 0; wi < dw.size(); ++wi) {
+                const WindowWork& w = works[dw[wi]];
+                if (w.n_gt != n || w.ploidy != cfg.sample_ploidy) throw std::runtime_error("internal: a window with another genotype list");
+                std::memcpy(&keep[wi * n * n], w.keep_mat.data(), n * n);
+                const uint64_t m = w.nodes.size();
+                chains.push_back(vgmi_hmm_chain{w.step0, m, (uint32_t)wi, 0});
+                chains.push_back(vgmi_hmm_chain{w.step0 + m, m, (uint32_t)wi, 0});
+            }
+            const long double uniform = 1.0L / (long double)n;
+            const auto td0 = std::chrono::steady_clock::now();
+            if (vgmi_hmm_calls(dev_, (uint32_t)n, cfg.sample_ploidy, keep.data(), (uint32_t)dw.size(), raw_obs.p, total_room,
+                               static_cast<const uint32_t*>(raw_row.p), static_cast<const uint8_t*>(raw_restart.p), raw_pw.p, 2 * total_room, &uniform,
+                               chains.data(), (uint32_t)chains.size(), static_cast<const uint8_t*>(raw_gid.p), static_cast<const uint8_t*>(raw_order.p),
+                               static_cast<const uint64_t*>(raw_fs.p), static_cast<const uint64_t*>(raw_bs.p), raw_prob.p,
+                               static_cast<uint32_t*>(raw_win.p), nullptr) != VGMI_OK)
+                throw std::runtime_error(std::string("device HMM recursion: ") + vgmi_last_error(dev_));
+            last_device_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - td0).count();
+        }
+        std::atomic<size_t> next_w{0};
+        auto finisher = [&]() {
+            for (;;) {
+                const size_t q = next_w.fetch_add(1);
+                if (q >= dw.size() || failed.load()) return;
+                try {
+                    WindowWork& w = works[dw[q]];
+                    window_finish(w, static_cast<const long double*>(raw_prob.p) + w.row0, static_cast<const uint32_t*>(raw_win.p) + w.row0, r);
+                } catch (const std::exception& e) {
+                    if (!failed.exchange(true)) error = e.what();
+                    return;
+                }
+            }
+        };
+        std::vector<std::thread> pool2;
+        for (uint32_t t = 1; t < n_threads; ++t) pool2.emplace_back(finisher);
+        finisher();
+        for (auto& th : pool2) th.join();
+        if (failed.load()) throw std::runtime_error(error);
+    }
     const auto t_hmm = std::chrono::steady_clock::now();
     last_hmm_seconds = std::chrono::duration<double>(t_hmm - t_begin).count();
     if (g_phase_on) {
         std::fprintf(stderr, "[varigraph-mi] HMM thread-seconds: selection %.2f, hidden states %.2f, emissions %.2f, forward %.2f, backward %.2f, posterior %.2f (wall %.2f on %u threads)\n",
                      g_phase.select.exchange(0) * 1e-9, g_phase.states.exchange(0) * 1e-9, g_phase.emit.exchange(0) * 1e-9, g_phase.fwd.exchange(0) * 1e-9,
                      g_phase.bwd.exchange(0) * 1e-9, g_phase.post.exchange(0) * 1e-9, last_hmm_seconds, n_threads);
+        if (last_device_seconds > 0) std::fprintf(stderr, "[varigraph-mi] HMM recursion on the device: %.2f s\n", last_device_seconds);
     }
 
     // ---- VCF (src/genotype.cpp:1579-1696): sites in vcf_info order, only those with a non-reference call.  The

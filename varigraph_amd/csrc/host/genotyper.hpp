@@ -15,6 +15,7 @@
 // graph index.  Like the reference, the forward pass prunes a node's k-mer list to the k-mers carried by a selected
 // haplotype and the pruned list persists across samples (ConstructIndex::reset does not restore it).
 #pragma once
+#include "vgmi.h"
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -44,6 +45,11 @@ public:
                     const GenotypeConfig& cfg);
 
     double last_hmm_seconds = 0, last_text_seconds = 0;   // of the last run(): windows on the pool / VCF text
+    double last_device_seconds = 0;                       // ... of which the device recursion (0: the host ran it)
+
+    // The forward / backward recursion of eligible windows (transition "rec", every genotype with `ploidy` haplotypes, at most
+    // 128 genotypes) runs on this context's device (vgmi_hmm_recursion: the reference's arithmetic bit for bit); nullptr: host.
+    void set_device(vgmi_ctx* ctx) { dev_ = ctx; }
 
     // `text` into `path` as block gzip (same content as SAVE's gzwrite), deflated by `threads` workers
     static void write_gz(const std::string& path, const std::string& text, unsigned threads = 1);
@@ -93,7 +99,10 @@ private:
     };
     struct Run;  // per-call constants
 
-    void window(Chrom& chr, uint32_t first, uint32_t last, const Run& r);
+    struct WindowWork;   // what a window hands to the device recursion and gets back (genotyper.cpp)
+    void window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, WindowWork* work = nullptr);
+    void window_finish(WindowWork& w, const long double* prob, const uint32_t* winner, const Run& r);
+    void genotype_strings(const Node& n, const std::vector<std::vector<uint16_t>>& genotypes, uint8_t* gid, uint8_t* order) const;
     NodeStates hidden_states(Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& top,
                              const std::vector<std::vector<uint16_t>>& genotypes, const std::vector<uint16_t>& used,
                              const GenotypeList& gl, double lower, double upper, bool filter, const Run& r, NodeStates&& recycled,
@@ -105,6 +114,7 @@ private:
 
     const GraphIndex& g_;
     std::vector<Chrom> chroms_;   // mGraphMap order
+    vgmi_ctx* dev_ = nullptr;
     uint32_t n_hap_ = 0;
     std::vector<uint16_t> hap_ids_;   // the keys of g_.hap_names in their order
     std::vector<uint64_t> packed_;    // per key: coverage | multiplicity << 8 | haplotype bits << 16 (this sample)

@@ -301,9 +301,24 @@ int main_genotype(int argc, char** argv)
     vgh::GenotypeConfig hmm_cfg = o.hmm;
     hmm_cfg.threads = std::max<unsigned>(1, o.hmm.threads / (unsigned)n_consumers);
     std::atomic<size_t> next_hmm{0};
+    std::atomic<unsigned> consumer_no{0};
     auto consumer = [&] {
         try {
             vgh::Genotyper genotyper(g);
+            // the HMM's recursion and posterior run on the device, through a context of their own (its stream and buffers are
+            // not the counting's); VGH_HMM_DEVICE=0 keeps them on the host
+            struct OwnCtx {
+                vgmi_ctx* c = nullptr;
+                ~OwnCtx() { if (c) vgmi_destroy(c); }
+            } own;
+            {
+                const char* e = getenv("VGH_HMM_DEVICE");
+                if (!(e && e[0] == '0')) {
+                    const int dev = o.gpus[consumer_no.fetch_add(1) % o.gpus.size()];
+                    if (vgmi_create(dev, 16, &own.c) != VGMI_OK) die(std::string("device ") + std::to_string(dev) + ": " + vgmi_last_error(nullptr));
+                    genotyper.set_device(own.c);
+                }
+            }
             for (;;) {
                 const size_t s = next_hmm.fetch_add(1);
                 if (s >= samples.size()) return;

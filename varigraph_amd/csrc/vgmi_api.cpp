@@ -1543,28 +1543,37 @@ int vgmi_bloom_add_seq(vgmi_ctx* c, const char* bases, uint64_t len, uint32_t k)
     return VGMI_OK;
 }
 
-int vgmi_hmm_recursion(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, uint32_t n_windows, const void* obs,
-                       uint64_t n_rows, const uint32_t* row, const uint8_t* restart, const void* pow, uint64_t n_steps,
-                       const void* uniform, const vgmi_hmm_chain* chains, uint32_t n_chains, void* out)
+namespace {
+// recursion (+ posterior when gid is given) in one pass over device buffers: alpha / beta leave the device only if `out` asks
+int hmm_run(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, uint32_t n_windows, const void* obs, uint64_t n_rows,
+            const uint32_t* row, const uint8_t* restart, const void* pow, uint64_t n_steps, const void* uniform, const vgmi_hmm_chain* chains,
+            uint32_t n_chains, void* out, const uint8_t* gid, const uint8_t* order, const uint64_t* fwd_step, const uint64_t* bwd_step,
+            void* prob, uint32_t* winner)
 {
-    if (!c || !keep || !obs || !row || !restart || !pow || !uniform || !chains || !out) return VGMI_E_INVALID;
+    if (!c || !keep || !obs || !row || !restart || !pow || !uniform || !chains) return VGMI_E_INVALID;
     if (n_gt < 1 || n_gt > 128 || ploidy < 1 || ploidy > 4) return fail(c, VGMI_E_INVALID, "HMM recursion: 1..128 genotypes of 1..4 haplotypes");
     for (uint32_t i = 0; i < n_chains; ++i)
         if (chains[i].keep_index >= n_windows || chains[i].first_step + chains[i].n_steps > n_steps)
             return fail(c, VGMI_E_INVALID, "HMM recursion: a chain points outside its arrays");
     for (uint64_t s = 0; s < n_steps; ++s)
         if (row[s] >= n_rows) return fail(c, VGMI_E_INVALID, "HMM recursion: a step points outside the emission rows");
+    if (gid)
+        for (uint64_t i = 0; i < n_rows; ++i)
+            if (fwd_step[i] >= n_steps || bwd_step[i] >= n_steps) return fail(c, VGMI_E_INVALID, "HMM posterior: a row points outside the steps");
     if (n_steps == 0 || n_chains == 0) return VGMI_OK;
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t stride = ploidy + 1;
     const size_t b_keep = (size_t)n_windows * n_gt * n_gt, b_obs = (size_t)n_rows * n_gt * 16, b_row = (size_t)n_steps * 4,
-                 b_pow = (size_t)n_steps * 2 * stride * 16, b_ch = (size_t)n_chains * sizeof(vgmi_hmm_chain), b_out = (size_t)n_steps * n_gt * 16;
+                 b_pow = (size_t)n_steps * 2 * stride * 16, b_ch = (size_t)n_chains * sizeof(vgmi_hmm_chain), b_out = (size_t)n_steps * n_gt * 16,
+                 b_gid = gid ? (size_t)n_rows * n_gt : 0, b_fs = gid ? (size_t)n_rows * 8 : 0, b_prob = gid ? (size_t)n_rows * 16 : 0,
+                 b_win = gid ? (size_t)n_rows * 4 : 0;
     static_assert(sizeof(vgmi_hmm_chain) == sizeof(HmmChain), "chain layout");
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_keep = 0, o_obs = up(o_keep + b_keep), o_row = up(o_obs + b_obs), o_rs = up(o_row + b_row), o_pow = up(o_rs + n_steps),
+                 o_uni = up(o_pow + b_pow), o_ch = o_uni + 256, o_out = up(o_ch + b_ch), o_gid = up(o_out + b_out), o_ord = up(o_gid + b_gid),
+                 o_fs = up(o_ord + b_gid), o_bs = up(o_fs + b_fs), o_prob = up(o_bs + b_fs), o_win = up(o_prob + b_prob), total = up(o_win + b_win);
     uint8_t* d = nullptr;
-    const size_t o_keep = 0, o_obs = (o_keep + b_keep + 255) & ~(size_t)255, o_row = (o_obs + b_obs + 255) & ~(size_t)255,
-                 o_rs = (o_row + b_row + 255) & ~(size_t)255, o_pow = (o_rs + n_steps + 255) & ~(size_t)255,
-                 o_uni = (o_pow + b_pow + 255) & ~(size_t)255, o_ch = o_uni + 256, o_out = (o_ch + b_ch + 255) & ~(size_t)255;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), o_out + b_out);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), total);
     if (e != hipSuccess) return fail(c, VGMI_E_NOMEM, "HMM recursion: not enough device memory");
     hipStream_t st = c->stream;
     e = hipMemcpyAsync(d + o_keep, keep, b_keep, hipMemcpyHostToDevice, st);
@@ -1574,6 +1583,10 @@ int vgmi_hmm_recursion(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_pow, pow, b_pow, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_uni, uniform, 16, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_ch, chains, b_ch, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && gid) e = hipMemcpyAsync(d + o_gid, gid, b_gid, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && gid) e = hipMemcpyAsync(d + o_ord, order, b_gid, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && gid) e = hipMemcpyAsync(d + o_fs, fwd_step, b_fs, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && gid) e = hipMemcpyAsync(d + o_bs, bwd_step, b_fs, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         HmmParams P{};
         P.n_gt = n_gt;
@@ -1588,11 +1601,45 @@ int vgmi_hmm_recursion(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_
         P.out = d + o_out;
         e = launch_hmm_recursion(P, n_chains, st);
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(out, d + o_out, b_out, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && gid) {
+        HmmPostParams Q{};
+        Q.n_gt = n_gt;
+        Q.ab = d + o_out;
+        Q.fwd_step = reinterpret_cast<const uint64_t*>(d + o_fs);
+        Q.bwd_step = reinterpret_cast<const uint64_t*>(d + o_bs);
+        Q.gid = d + o_gid;
+        Q.order = d + o_ord;
+        Q.prob = d + o_prob;
+        Q.winner = reinterpret_cast<uint32_t*>(d + o_win);
+        e = launch_hmm_posterior(Q, n_rows, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(prob, d + o_prob, b_prob, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(winner, d + o_win, b_win, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess && out) e = hipMemcpyAsync(out, d + o_out, b_out, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(d);
     HIPCHK(c, e);
     return VGMI_OK;
+}
+}  // namespace
+
+int vgmi_hmm_recursion(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, uint32_t n_windows, const void* obs,
+                       uint64_t n_rows, const uint32_t* row, const uint8_t* restart, const void* pow, uint64_t n_steps,
+                       const void* uniform, const vgmi_hmm_chain* chains, uint32_t n_chains, void* out)
+{
+    if (!out) return VGMI_E_INVALID;
+    return hmm_run(c, n_gt, ploidy, keep, n_windows, obs, n_rows, row, restart, pow, n_steps, uniform, chains, n_chains, out, nullptr, nullptr,
+                   nullptr, nullptr, nullptr, nullptr);
+}
+
+int vgmi_hmm_calls(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, uint32_t n_windows, const void* obs, uint64_t n_rows,
+                   const uint32_t* row, const uint8_t* restart, const void* pow, uint64_t n_steps, const void* uniform,
+                   const vgmi_hmm_chain* chains, uint32_t n_chains, const uint8_t* gid, const uint8_t* order, const uint64_t* fwd_step,
+                   const uint64_t* bwd_step, void* prob, uint32_t* winner, void* alpha_beta_or_null)
+{
+    if (!gid || !order || !fwd_step || !bwd_step || !prob || !winner) return VGMI_E_INVALID;
+    return hmm_run(c, n_gt, ploidy, keep, n_windows, obs, n_rows, row, restart, pow, n_steps, uniform, chains, n_chains, alpha_beta_or_null, gid,
+                   order, fwd_step, bwd_step, prob, winner);
 }
 
 // BloomFilter::save / load (src/counting_bloom_filter.cpp:126-190): u64 size | u32 numHashes | numHashes x u64 seed | size bytes

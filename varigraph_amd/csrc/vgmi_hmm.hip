@@ -97,6 +97,97 @@ __global__ __launch_bounds__(128) void hmm_recursion_kernel(HmmParams P)
     }
 }
 
+// ---- posterior of a node (src/genotype.cpp:1387-1522) from the alpha / beta rows the recursion left on the device --------
+//   denominator = sum of a_g * b_g in entry order;  post_g = (a_g * b_g) / denominator;  per genotype STRING (gid, made by the
+//   host: alleles as decimal strings, sorted as strings) the sum of its entries' posts in entry order;  the first maximum in
+//   string order (order[]) wins, its sum is the call's probability;  the call's genotype is the first entry of that string
+//   with the largest post.  A zero denominator makes every post NaN on the host, which no comparison accepts: no call.
+__device__ __forceinline__ bool x80_gt(VgX80 a, VgX80 b) { return a.e > b.e || (a.e == b.e && a.m > b.m); }
+
+__global__ __launch_bounds__(128) void hmm_posterior_kernel(HmmPostParams P)
+{
+    __shared__ uint64_t s_m[128];
+    __shared__ uint32_t s_e[128];
+    __shared__ uint64_t s_sum_m[128];
+    __shared__ uint32_t s_sum_e[128];
+    __shared__ uint8_t s_gid[128];
+    const uint32_t n = P.n_gt, g = threadIdx.x;
+    const uint64_t rowi = blockIdx.x;
+    const bool active = g < n;
+    VgX80 p = {0, 0};
+    if (active) {
+        const VgX80 a = x80_load(P.ab + (P.fwd_step[rowi] * n + g) * 16), b = x80_load(P.ab + (P.bwd_step[rowi] * n + g) * 16);
+        p = x80_mul(a, b);
+        s_gid[g] = P.gid[rowi * n + g];
+    }
+    s_m[g] = p.m;
+    s_e[g] = p.e;
+    __syncthreads();
+    VgX80 den = {0, 0};
+    for (uint32_t q = 0; q < n; ++q) {
+        VgX80 t;
+        t.m = s_m[q];
+        t.e = s_e[q];
+        den = x80_add(den, t);
+    }
+    if (den.m == 0) {
+        if (g == 0) P.winner[rowi] = 0xFFFFFFFFu;
+        return;
+    }
+    __syncthreads();
+    const VgX80 post = x80_div(p, den);
+    s_m[g] = post.m;
+    s_e[g] = post.e;
+    __syncthreads();
+    // lane k sums string k's entries in entry order
+    VgX80 sum = {0, 0};
+    for (uint32_t q = 0; q < n; ++q)
+        if (s_gid[q] == g) {
+            VgX80 t;
+            t.m = s_m[q];
+            t.e = s_e[q];
+            sum = x80_add(sum, t);
+        }
+    s_sum_m[g] = sum.m;
+    s_sum_e[g] = sum.e;
+    __syncthreads();
+    if (g == 0) {
+        const uint8_t* ord = P.order + rowi * n;
+        VgX80 best = {0, 0};
+        uint32_t best_id = 0xFFFFFFFFu;
+        for (uint32_t k = 0; k < n && ord[k] != 0xFF; ++k) {
+            VgX80 sk;
+            sk.m = s_sum_m[ord[k]];
+            sk.e = s_sum_e[ord[k]];
+            if (best_id == 0xFFFFFFFFu || x80_gt(sk, best)) {     // the host starts from -1: the first string always enters
+                best = sk;
+                best_id = ord[k];
+            }
+        }
+        VgX80 max_post = {0, 0};
+        uint32_t win = 0xFFFFFFFFu;
+        for (uint32_t q = 0; q < n; ++q) {
+            if (s_gid[q] != best_id) continue;
+            VgX80 t;
+            t.m = s_m[q];
+            t.e = s_e[q];
+            if (x80_gt(t, max_post)) {
+                max_post = t;
+                win = q;
+            }
+        }
+        x80_store(P.prob + rowi * 16, best);
+        P.winner[rowi] = best_id == 0xFFFFFFFFu ? 0xFFFFFFFEu : win;   // 0xFFFFFFFE: no string at all
+    }
+}
+
+hipError_t launch_hmm_posterior(const HmmPostParams& P, uint64_t n_rows, hipStream_t st)
+{
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(hmm_posterior_kernel, dim3((uint32_t)n_rows), dim3(128), 0, st, P);
+    return hipGetLastError();
+}
+
 size_t hmm_lds_bytes(uint32_t n_gt, uint32_t ploidy)
 {
     const uint32_t stride = ploidy + 1;

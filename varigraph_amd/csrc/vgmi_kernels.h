@@ -140,6 +140,17 @@ struct HmmParams {
     uint8_t* out;                   // per step: n_gt normalised scores
 };
 hipError_t launch_hmm_recursion(const HmmParams& P, uint32_t n_chains, hipStream_t st);
+struct HmmPostParams {
+    uint32_t n_gt;
+    const uint8_t* ab;              // the recursion's output: per step n_gt scores
+    const uint64_t* fwd_step;       // per row: the step that holds its alpha / its beta
+    const uint64_t* bwd_step;
+    const uint8_t* gid;             // per row: genotype string of every entry
+    const uint8_t* order;           // per row: the strings in string order, 0xFF behind the last
+    uint8_t* prob;                  // per row: the winning string's probability (16 bytes)
+    uint32_t* winner;               // per row: the entry that makes the call; 0xFFFFFFFF: none
+};
+hipError_t launch_hmm_posterior(const HmmPostParams& P, uint64_t n_rows, hipStream_t st);
 size_t hmm_lds_bytes(uint32_t n_gt, uint32_t ploidy);
 
 hipError_t launch_xtable_build(const XTableView& t, const unsigned long long* slots8, const uint32_t* key_slot, const uint32_t* id_of_key,
