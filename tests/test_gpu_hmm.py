@@ -90,3 +90,76 @@ def test_recursion_equals_x87(ploidy, n_hap):
         g = got[first:first + count]
         assert np.array_equal(g, want), (ploidy, w, int(np.argmax((g != want).any(axis=1))))
     assert (got > 0).any() and (got == 0).any()
+
+
+def test_posterior_on_the_device_equals_x87():
+    """vgmi_hmm_calls: per node the sum of a * b, the posteriors, their sums per genotype string in entry order, the first
+    maximum in string order and the first entry of that string with the largest posterior -- as posterior() of the host
+    (src/genotype.cpp:1387-1522) computes them in long double."""
+    rng = np.random.default_rng(77)
+    ploidy, n_hap = 2, 12
+    genotypes = list(itertools.combinations_with_replacement(range(n_hap), ploidy))
+    n = len(genotypes)
+    keep = np.zeros((1, n, n), dtype=np.uint8)
+    for i, a in enumerate(genotypes):
+        for j, b in enumerate(genotypes):
+            keep[0, i, j] = len(set(a) & set(b)) if a[0] != a[1] or b[0] != b[1] else (2 if a == b else (1 if a[0] in b else 0))
+    n_rows = 30
+    expo = rng.choice([0, -10, -200, -3000, -4900], size=(n_rows, n), p=[.2, .3, .3, .15, .05])
+    obs = (rng.random((n_rows, n)).astype(LD) + LD(0.01)) * np.power(LD(10), expo.astype(LD))
+    obs[11] = 0
+    row = list(range(n_rows)) + list(range(n_rows))[::-1]
+    restart = [1] + [0] * (n_rows - 1) + [1] + [0] * (n_rows - 1)
+    pows = np.zeros((2 * n_rows, 2, ploidy + 1), dtype=LD)
+    for s in range(2 * n_rows):
+        d = LD(rng.integers(1, 20_000))
+        recomb = (LD(1) - np.exp(-d / LD(24))) * (LD(1) / LD(24))
+        no_recomb = np.exp(-d / LD(24)) + recomb
+        pows[s, 0] = [no_recomb ** LD(k) for k in range(ploidy + 1)]
+        pows[s, 1] = [recomb ** LD(k) for k in range(ploidy + 1)]
+    chains = [(0, n_rows, 0), (n_rows, n_rows, 0)]
+    # genotype strings: a few alleles per node, ids by first appearance, order by text
+    gid = np.zeros((n_rows, n), dtype=np.uint8)
+    order = np.full((n_rows, n), 0xFF, dtype=np.uint8)
+    for r in range(n_rows):
+        alleles = rng.integers(0, 12 if r % 5 == 0 else 3, size=n_hap)
+        texts = {}
+        for g, (a, b) in enumerate(genotypes):
+            t = "/".join(sorted([str(alleles[a]), str(alleles[b])]))
+            gid[r, g] = texts.setdefault(t, len(texts))
+        ranked = sorted(texts, key=lambda t: t)
+        order[r, :len(ranked)] = [texts[t] for t in ranked]
+    fwd = np.arange(n_rows, dtype=np.uint64)
+    bwd = np.array([n_rows + (n_rows - 1 - j) for j in range(n_rows)], dtype=np.uint64)
+    uniform = LD(1) / LD(n)
+    ctx = vgmi.Context(0, buffer_mib=16)
+    try:
+        prob, winner, ab = ctx.hmm_calls(keep, obs, row, restart, pows, uniform, chains, ploidy, gid, order, fwd, bwd)
+    finally:
+        ctx.close()
+    n_called = 0
+    for r in range(n_rows):
+        a, b = ab[fwd[r]], ab[bwd[r]]
+        den = LD(0)
+        for g in range(n):
+            den = den + a[g] * b[g]
+        if den == 0:
+            assert winner[r] == 0xFFFFFFFF
+            continue
+        post = (a * b) / den
+        sums = {}
+        for g in range(n):
+            sums[gid[r, g]] = sums.get(gid[r, g], LD(0)) + post[g]
+        best, best_id = LD(-1), None
+        for k in order[r]:
+            if k == 0xFF:
+                break
+            if sums[k] > best:
+                best, best_id = sums[k], k
+        mx, win = LD(0), 0xFFFFFFFF
+        for g in range(n):
+            if gid[r, g] == best_id and mx < post[g]:
+                mx, win = post[g], g
+        assert winner[r] == win and prob[r] == best, r
+        n_called += win != 0xFFFFFFFF
+    assert n_called > 20

@@ -67,6 +67,7 @@ def load_library():
         "vgmi_bloom_add_seq": (i32, [vp, vp, u64, u32]),
         "vgmi_bloom_add_seq_device": (i32, [vp, vp, u64, u32]),
         "vgmi_hmm_recursion": (i32, [vp, u32, u32, vp, u32, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp, u32, vp]),
+        "vgmi_hmm_calls": (i32, [vp, u32, u32, vp, u32, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]),
         "vgmi_bloom_fetch": (i32, [vp, vp]),
         "vgmi_bloom_save_file": (i32, [vp, C.c_char_p]),
         "vgmi_bloom_load_file": (i32, [vp, C.c_char_p]),
@@ -366,6 +367,30 @@ class Context:
         self._chk(self._l.vgmi_hmm_recursion(self._h, n_gt, ploidy, _ptr(keep), keep.shape[0], _ptr(obs), obs.shape[0], _ptr(row),
                                               _ptr(restart), _ptr(pow_tables), row.size, _ptr(uni), _ptr(ch), len(chains), _ptr(out)))
         return out
+
+    def hmm_calls(self, keep, obs, row, restart, pow_tables, uniform, chains, ploidy, gid, order, fwd_step, bwd_step):
+        """hmm_recursion followed by the posterior on the device (vgmi_hmm_calls): returns (prob, winner, alpha_beta)."""
+        keep = np.ascontiguousarray(keep, dtype=np.uint8)
+        obs = np.ascontiguousarray(obs, dtype=np.longdouble)
+        row = np.ascontiguousarray(row, dtype=np.uint32)
+        restart = np.ascontiguousarray(restart, dtype=np.uint8)
+        pow_tables = np.ascontiguousarray(pow_tables, dtype=np.longdouble)
+        uni = np.ascontiguousarray([uniform], dtype=np.longdouble)
+        gid = np.ascontiguousarray(gid, dtype=np.uint8)
+        order = np.ascontiguousarray(order, dtype=np.uint8)
+        fwd_step = np.ascontiguousarray(fwd_step, dtype=np.uint64)
+        bwd_step = np.ascontiguousarray(bwd_step, dtype=np.uint64)
+        n_gt = obs.shape[1]
+        ch = np.zeros((len(chains), 3), dtype=np.uint64)
+        for i, (f, n, k) in enumerate(chains):
+            ch[i] = (f, n, k)
+        ab = np.zeros((row.size, n_gt), dtype=np.longdouble)
+        prob = np.zeros(obs.shape[0], dtype=np.longdouble)
+        winner = np.zeros(obs.shape[0], dtype=np.uint32)
+        self._chk(self._l.vgmi_hmm_calls(self._h, n_gt, ploidy, _ptr(keep), keep.shape[0], _ptr(obs), obs.shape[0], _ptr(row), _ptr(restart),
+                                          _ptr(pow_tables), row.size, _ptr(uni), _ptr(ch), len(chains), _ptr(gid), _ptr(order), _ptr(fwd_step),
+                                          _ptr(bwd_step), _ptr(prob), _ptr(winner), _ptr(ab)))
+        return prob, winner, ab
 
     def bloom_save_file(self, path):
         self._chk(self._l.vgmi_bloom_save_file(self._h, os.fsencode(path)))
