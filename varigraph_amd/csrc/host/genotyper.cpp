@@ -1222,7 +1222,20 @@ void Genotyper::window_finish(WindowWork& w, const long double* prob, const uint
         uint8_t unique_kmers = 0;
         std::fill(hap_num.begin(), hap_num.end(), 0);
         std::fill(hap_sum.begin(), hap_sum.end(), 0);
+        if (j + 1 < w.nodes.size()) prefetch_keys(w.chr->nodes[w.nodes[j + 1]], r);
         for (uint32_t key : n.kmers) {
+            if (r.packed) {
+                const uint64_t word = r.packed[key];
+                if ((uint8_t)(word >> 8) <= 1 && unique_kmers < UINT8_MAX) unique_kmers++;
+                const uint8_t c = (uint8_t)word;
+                const uint64_t bits = word >> 16;
+                for (uint16_t hap : w.top)
+                    if ((bits >> hap) & 1u) {
+                        ++hap_num[hap];
+                        hap_sum[hap] += c;
+                    }
+                continue;
+            }
             if (g_.f[key] <= 1 && unique_kmers < UINT8_MAX) unique_kmers++;
             const uint8_t c = r.cov[key];
             for (uint16_t hap : w.top)
