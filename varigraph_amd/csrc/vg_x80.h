@@ -226,6 +226,180 @@ VG_X80_HD VgX80 x80_div(VgX80 a, VgX80 b)    // b != 0
     return x80_round_pack(q, lo, e, false);
 }
 
+// ---- the same arithmetic on values held NORMALISED ----------------------------------------------------------------------
+// A chain of operations (the recursion: a hundred products and sums per lane and node) keeps its values as  m with bit 63 set,
+// e the exponent field that significand would have -- below 1 for a denormal, whose low 1 - e bits are then zero -- so that the
+// common case (a normal result, e >= 1) is one rounding at 64 bits with no shifts by variable denormal distances; a result
+// that is not normal goes through x80_round_pack above.  n80_from / n80_to convert from and to the stored form, exactly.
+struct VgN80 {
+    uint64_t m;   // 0 for zero, else bit 63 set
+    int32_t e;
+};
+
+VG_X80_HD VgN80 n80_from(VgX80 v)
+{
+    VgN80 r = {0, 0};
+    if (v.m != 0) x80_normal(v, r.m, r.e);
+    return r;
+}
+
+VG_X80_HD VgX80 n80_to(VgN80 v)
+{
+    VgX80 r = {0, 0};
+    if (v.m != 0) {
+        if (v.e >= 1) {
+            r.m = v.m;
+            r.e = (uint32_t)v.e;
+        } else {
+            r.m = v.m >> (uint32_t)(1 - v.e);     // the bits that leave are zero
+        }
+    }
+    return r;
+}
+
+// (hi:lo), bit 127 set and of weight 2^(e - BIAS); bit 0 of lo may stand for any non-zero bits below it (it is never the guard)
+VG_X80_HD VgN80 n80_round(uint64_t hi, uint64_t lo, int32_t e)
+{
+    VgN80 r;
+    if (e >= 1) {
+        const uint64_t inc = (lo | (hi & 1u)) > (1ULL << 63) ? 1u : 0u;     // guard and (sticky or odd)
+        r.m = hi + inc;
+        r.e = e;
+        if (r.m < inc) {        // 2^64: one binade up
+            r.m = 1ULL << 63;
+            ++r.e;
+        }
+    } else {
+        r = n80_from(x80_round_pack(hi, lo, e, false));
+    }
+    return r;
+}
+
+VG_X80_HD VgN80 n80_mul(VgN80 a, VgN80 b)
+{
+    if (a.m == 0 || b.m == 0) {
+        VgN80 z = {0, 0};
+        return z;
+    }
+    uint64_t hi, lo;
+    x80_mul64(a.m, b.m, hi, lo);    // in [2^126, 2^128)
+    int32_t e = a.e + b.e - VG_X80_BIAS + 1;
+    if (!(hi >> 63)) {
+        hi = (hi << 1) | (lo >> 63);
+        lo <<= 1;
+        --e;
+    }
+    return n80_round(hi, lo, e);
+}
+
+VG_X80_HD VgN80 n80_add(VgN80 a, VgN80 b)
+{
+    if (a.m == 0) return b;
+    if (b.m == 0) return a;
+    if (a.e < b.e) {
+        const VgN80 t = a;
+        a = b;
+        b = t;
+    }
+    const uint32_t d = (uint32_t)(a.e - b.e);
+    // b's significand shifted right by d into 128 bits; beyond the guard bit only "something is there" matters
+    uint64_t bh, bl;
+    if (d < 64) {
+        bh = b.m >> d;
+        bl = (b.m << 1) << (63 - d);
+    } else {
+        bh = 0;
+        bl = d == 64 ? b.m : 1u;
+    }
+    uint64_t hi = a.m + bh, lo = bl;
+    int32_t e = a.e;
+    if (hi < bh) {              // carry: bit 127 is the carry
+        lo = (lo >> 1) | (lo & 1u) | (hi << 63);
+        hi = (hi >> 1) | (1ULL << 63);
+        ++e;
+    }
+    return n80_round(hi, lo, e);
+}
+
+VG_X80_HD VgN80 n80_div(VgN80 a, VgN80 b)    // b != 0
+{
+    if (a.m == 0) {
+        VgN80 z = {0, 0};
+        return z;
+    }
+    uint64_t nh, nl;
+    int32_t e = a.e - b.e + VG_X80_BIAS;
+    if (a.m >= b.m) {
+        nh = a.m >> 1;
+        nl = a.m << 63;
+    } else {
+        nh = a.m;
+        nl = 0;
+        --e;
+    }
+    uint64_t q = 0, r = nh;
+    for (int i = 63; i >= 0; --i) {
+        const bool top = (r >> 63) != 0;
+        r = (r << 1) | ((nl >> i) & 1u);
+        if (top || r >= b.m) {
+            r -= b.m;
+            q |= 1ULL << i;
+        }
+    }
+    const bool guard = (r >> 63) != 0 || (r << 1) >= b.m;
+    const uint64_t r2 = (r << 1) - (guard ? b.m : 0);
+    return n80_round(q, ((uint64_t)guard << 63) | (r2 != 0 ? 1u : 0u), e);
+}
+
+// r + s * o  (the product rounded, then the sum rounded) -- the recursion's term.  Written without branches for the case
+// that is all but universal there (the product and the sum are normal numbers): selects instead of per-lane jumps, which on
+// the device cost more than the arithmetic they skip.  Anything else takes the two functions above.
+VG_X80_HD VgN80 n80_muladd(VgN80 r, VgN80 s, VgN80 o)
+{
+    const uint64_t half = 1ULL << 63;
+    const bool t_zero = s.m == 0 || o.m == 0;
+    uint64_t hi, lo;
+    x80_mul64(s.m, o.m, hi, lo);
+    const bool up = (hi >> 63) != 0;                 // product of the significands in [2^127, 2^128)
+    int32_t te = s.e + o.e - VG_X80_BIAS + (up ? 1 : 0);
+    const uint64_t hi1 = (hi << 1) | (lo >> 63), lo1 = lo << 1;
+    hi = up ? hi : hi1;
+    lo = up ? lo : lo1;
+    uint64_t inc = (lo | (hi & 1u)) > half ? 1u : 0u;
+    uint64_t tm = hi + inc;
+    const bool over = tm < inc;
+    tm = over ? half : tm;
+    te += over ? 1 : 0;
+    bool slow = !t_zero && te < 1;
+
+    const bool r_zero = r.m == 0;
+    const bool r_big = r.e >= te;
+    const uint64_t am = r_big ? r.m : tm, bm = r_big ? tm : r.m;
+    int32_t e = r_big ? r.e : te;
+    const uint32_t d = (uint32_t)(r_big ? r.e - te : te - r.e);
+    const bool near = d < 64;
+    const uint64_t bh = near ? bm >> (d & 63u) : 0u;
+    lo = near ? (bm << 1) << ((63u - d) & 63u) : (d == 64 ? bm : 1u);
+    hi = am + bh;
+    const bool carry = hi < bh;
+    const uint64_t lo2 = (lo >> 1) | (lo & 1u) | (hi << 63), hi2 = (hi >> 1) | half;
+    lo = carry ? lo2 : lo;
+    hi = carry ? hi2 : hi;
+    e += carry ? 1 : 0;
+    inc = (lo | (hi & 1u)) > half ? 1u : 0u;
+    uint64_t m = hi + inc;
+    const bool over2 = m < inc;
+    m = over2 ? half : m;
+    e += over2 ? 1 : 0;
+    slow = slow || (!t_zero && !r_zero && e < 1);
+
+    VgN80 out;
+    out.m = t_zero ? r.m : (r_zero ? tm : m);
+    out.e = t_zero ? r.e : (r_zero ? te : e);
+    if (slow) out = n80_add(r, n80_mul(s, o));
+    return out;
+}
+
 VG_X80_HD bool x80_is_zero(VgX80 v) { return v.m == 0; }
 
 #endif

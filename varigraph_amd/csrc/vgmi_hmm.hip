@@ -24,9 +24,9 @@ __global__ __launch_bounds__(128) void hmm_recursion_kernel(HmmParams P)
     const bool active = g < n;
     uint8_t* const s_keep = hmm_smem;                                              // n * n
     uint64_t* const s_step_m = reinterpret_cast<uint64_t*>(hmm_smem + ((n * n + 15u) & ~15u));   // 128 * stride
-    uint32_t* const s_step_e = reinterpret_cast<uint32_t*>(s_step_m + 128u * stride);
+    int32_t* const s_step_e = reinterpret_cast<int32_t*>(s_step_m + 128u * stride);
     uint64_t* const s_r_m = reinterpret_cast<uint64_t*>(s_step_e + 128u * stride);      // 512 * stride bytes on: 8-byte aligned
-    uint32_t* const s_r_e = reinterpret_cast<uint32_t*>(s_r_m + 128);
+    int32_t* const s_r_e = reinterpret_cast<int32_t*>(s_r_m + 128);
 
     const HmmChain ch = P.chains[blockIdx.x];
     const uint8_t* keep_g = P.keep + (size_t)ch.keep_index * n * n;
@@ -35,23 +35,26 @@ __global__ __launch_bounds__(128) void hmm_recursion_kernel(HmmParams P)
     const uint8_t* const my_keep = s_keep + (size_t)g * n;
     const VgX80 uniform = x80_load(P.uniform);
 
-    VgX80 prev = {0, 0};
+    // values stay normalised (vg_x80.h: VgN80) from the load of a score to the store of a row: the hundred products and sums
+    // of a node then take the one-rounding path, and only a result that is not a normal number takes the general one
+    VgN80 prev = {0, 0};
     for (uint64_t s = ch.first_step; s < ch.first_step + ch.n_steps; ++s) {
         const bool restart = P.restart[s] != 0;
-        VgX80 o = {0, 0};
-        if (active) o = x80_load(P.obs + ((size_t)P.row[s] * n + g) * 16);
+        VgN80 o = {0, 0};
+        if (active) o = n80_from(x80_load(P.obs + ((size_t)P.row[s] * n + g) * 16));
         if (!restart) {
             // (prev * no_recomb^keep) * recomb^change for this lane's previous entry and every keep
             const uint8_t* pw = P.pow + s * (size_t)(2 * stride) * 16;
             for (uint32_t k = 0; k < stride; ++k) {
-                const VgX80 pk = x80_load(pw + (size_t)k * 16), pc = x80_load(pw + (size_t)(stride + (P.ploidy - k)) * 16);
-                const VgX80 st = x80_mul(x80_mul(prev, pk), pc);
+                const VgN80 pk = n80_from(x80_load(pw + (size_t)k * 16)),
+                            pc = n80_from(x80_load(pw + (size_t)(stride + (P.ploidy - k)) * 16));
+                const VgN80 st = n80_mul(n80_mul(prev, pk), pc);
                 s_step_m[g * stride + k] = st.m;
                 s_step_e[g * stride + k] = st.e;
             }
         }
         __syncthreads();
-        VgX80 r = {0, 0};
+        VgN80 r = {0, 0};
         if (active) {
             if (restart) {
                 r = o;
@@ -59,39 +62,44 @@ __global__ __launch_bounds__(128) void hmm_recursion_kernel(HmmParams P)
                 // the table entry of term p + 1 and the keep byte of term p + 2 are fetched while term p is computed: the
                 // chain r -> r is the only dependency the loop has to wait for (one wavefront per SIMD: nothing else hides LDS)
                 uint32_t at = my_keep[0];
-                VgX80 nx;
+                VgN80 nx;
                 nx.m = s_step_m[at];
                 nx.e = s_step_e[at];
                 uint32_t k2 = n > 1 ? my_keep[1] : 0;
                 for (uint32_t p = 0; p < n; ++p) {
-                    const VgX80 st = nx;
+                    const VgN80 st = nx;
                     if (p + 1 < n) {
                         at = (p + 1) * stride + k2;
                         nx.m = s_step_m[at];
                         nx.e = s_step_e[at];
                         k2 = my_keep[p + 2 < n ? p + 2 : p + 1];
                     }
-                    r = x80_add(r, x80_mul(st, o));
+                    r = n80_muladd(r, st, o);
                 }
             }
         }
         s_r_m[g] = r.m;
         s_r_e[g] = r.e;
         __syncthreads();
-        VgX80 total = {0, 0};
-        VgX80 tn;
+        VgN80 total = {0, 0};
+        VgN80 tn;
         tn.m = s_r_m[0];
         tn.e = s_r_e[0];
         for (uint32_t p = 0; p < n; ++p) {
-            const VgX80 t = tn;
+            const VgN80 t = tn;
             if (p + 1 < n) {
                 tn.m = s_r_m[p + 1];
                 tn.e = s_r_e[p + 1];
             }
-            total = x80_add(total, t);
+            total = n80_add(total, t);
         }
-        const VgX80 out = total.m != 0 ? x80_div(r, total) : uniform;
-        prev = out;
+        VgX80 out = uniform;
+        if (total.m != 0) {
+            prev = n80_div(r, total);
+            out = n80_to(prev);
+        } else {
+            prev = n80_from(uniform);
+        }
         if (active) x80_store(P.out + (s * n + g) * 16, out);
         __syncthreads();
     }
