@@ -71,7 +71,9 @@ int main(int argc, char** argv)
     };
     long bad = 0, cases = 0;
     for (long i = 0; i < n; ++i) {
-        const VgX80 a = value(), b = value();
+        const VgX80 a = value();
+        VgX80 b = value();
+        if (rng() % 3 == 0 && a.e > 80 && b.e) b.e = a.e - 70 + (uint32_t)(rng() % 140);   // every alignment distance of a sum
         volatile long double x = to_ld(a), y = to_ld(b);
         {
             volatile long double p = x * y;
@@ -82,7 +84,8 @@ int main(int argc, char** argv)
         }
         {
             volatile long double s = x + y;
-            if (!same(from_ld(s), x80_add(a, b)) || !same(from_ld(s), n80_to(n80_add(n80_from(a), n80_from(b))))) {
+            if (!same(from_ld(s), x80_add(a, b)) || !same(from_ld(s), n80_to(n80_add(n80_from(a), n80_from(b)))) ||
+                !same(from_ld(s), n80_to(n80_sum(n80_from(a), n80_from(b))))) {
                 if (bad++ < 10) printf("add %016llx:%u + %016llx:%u\n", (unsigned long long)a.m, a.e, (unsigned long long)b.m, b.e);
             }
             ++cases;

@@ -85,7 +85,7 @@ def main():
             if r.returncode != 0:
                 out[name + "_error"] = r.stderr[-400:]
                 continue
-            out[name + "_log_tail"] = [ln for ln in r.stderr.strip().split("\n") if "varigraph-mi]" in ln or "graph_index]" in ln][-14:]
+            out[name + "_log_tail"] = [ln for ln in r.stderr.strip().split("\n") if "varigraph-mi]" in ln or "graph_index]" in ln or "[vgmi]" in ln][-16:]
             vcfs[name] = gzip.open(os.path.join(d, "sample0.varigraph.vcf.gz"), "rb").read()
         if not args.native_only:
             out["vcf_identical"] = len(vcfs) == 2 and vcfs["reference_cpu"] == vcfs["native_cli"]

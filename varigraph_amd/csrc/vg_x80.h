@@ -400,6 +400,36 @@ VG_X80_HD VgN80 n80_muladd(VgN80 r, VgN80 s, VgN80 o)
     return out;
 }
 
+// a + b in the same style (the recursion's sum over a node's entries, which runs on the scalar unit: no jumps there either)
+VG_X80_HD VgN80 n80_sum(VgN80 a, VgN80 b)
+{
+    const uint64_t half = 1ULL << 63;
+    const bool a_zero = a.m == 0, b_zero = b.m == 0;
+    const bool a_big = a.e >= b.e;
+    const uint64_t am = a_big ? a.m : b.m, bm = a_big ? b.m : a.m;
+    int32_t e = a_big ? a.e : b.e;
+    const uint32_t d = (uint32_t)(a_big ? a.e - b.e : b.e - a.e);
+    const bool near = d < 64;
+    const uint64_t bh = near ? bm >> (d & 63u) : 0u;
+    uint64_t lo = near ? (bm << 1) << ((63u - d) & 63u) : (d == 64 ? bm : 1u);
+    uint64_t hi = am + bh;
+    const bool carry = hi < bh;
+    const uint64_t lo2 = (lo >> 1) | (lo & 1u) | (hi << 63), hi2 = (hi >> 1) | half;
+    lo = carry ? lo2 : lo;
+    hi = carry ? hi2 : hi;
+    e += carry ? 1 : 0;
+    const uint64_t inc = (lo | (hi & 1u)) > half ? 1u : 0u;
+    uint64_t m = hi + inc;
+    const bool over = m < inc;
+    m = over ? half : m;
+    e += over ? 1 : 0;
+    VgN80 out;
+    out.m = a_zero ? b.m : (b_zero ? a.m : m);
+    out.e = a_zero ? b.e : (b_zero ? a.e : e);
+    if (!a_zero && !b_zero && e < 1) out = n80_add(a, b);
+    return out;
+}
+
 VG_X80_HD bool x80_is_zero(VgX80 v) { return v.m == 0; }
 
 #endif

@@ -1576,6 +1576,12 @@ int hmm_run(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, ui
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), total);
     if (e != hipSuccess) return fail(c, VGMI_E_NOMEM, "HMM recursion: not enough device memory");
     hipStream_t st = c->stream;
+    // VGMI_HMM_TIMING=1: upload / recursion / posterior + download, milliseconds on stderr (diagnostics)
+    const bool timing = getenv("VGMI_HMM_TIMING") != nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (timing)
+        for (auto& x : ev) (void)hipEventCreate(&x);
+    if (timing) (void)hipEventRecord(ev[0], st);
     e = hipMemcpyAsync(d + o_keep, keep, b_keep, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_obs, obs, b_obs, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_row, row, b_row, hipMemcpyHostToDevice, st);
@@ -1599,7 +1605,9 @@ int hmm_run(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, ui
         P.uniform = d + o_uni;
         P.chains = reinterpret_cast<const HmmChain*>(d + o_ch);
         P.out = d + o_out;
+        if (timing) (void)hipEventRecord(ev[1], st);
         e = launch_hmm_recursion(P, n_chains, st);
+        if (timing) (void)hipEventRecord(ev[2], st);
     }
     if (e == hipSuccess && gid) {
         HmmPostParams Q{};
@@ -1616,7 +1624,19 @@ int hmm_run(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, ui
         if (e == hipSuccess) e = hipMemcpyAsync(winner, d + o_win, b_win, hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess && out) e = hipMemcpyAsync(out, d + o_out, b_out, hipMemcpyDeviceToHost, st);
+    if (timing) (void)hipEventRecord(ev[3], st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (timing) {
+        float a = 0, b = 0, g = 0;
+        if (e == hipSuccess) {
+            (void)hipEventElapsedTime(&a, ev[0], ev[1]);
+            (void)hipEventElapsedTime(&b, ev[1], ev[2]);
+            (void)hipEventElapsedTime(&g, ev[2], ev[3]);
+        }
+        fprintf(stderr, "[vgmi] HMM on the device: %u chains, %llu steps, upload %.1f ms (%.0f MB), recursion %.1f ms, posterior + download %.1f ms\n",
+                n_chains, (unsigned long long)n_steps, a, (double)(b_keep + b_obs + b_row + b_pow + 2 * b_gid + 2 * b_fs) / 1e6, b, g);
+        for (auto& x : ev) (void)hipEventDestroy(x);
+    }
     (void)hipFree(d);
     HIPCHK(c, e);
     return VGMI_OK;

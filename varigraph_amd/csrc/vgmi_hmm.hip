@@ -11,16 +11,28 @@
 // the windows of a sample.  The libm values (exp, pow) stay on the host and arrive as tables per step.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "vg_x80.h"
 #include "vgmi_kernels.h"
 
 namespace vgk {
 
+// what a step reads from memory, fetched one step ahead of its use (a chain is latency from end to end: a load that is
+// waited for is time nothing else fills)
+template <uint32_t STRIDE>
+struct HmmStepIn {
+    VgX80 keep_pow[STRIDE], change_pow[STRIDE];     // no_recomb^k, recomb^(ploidy - k)
+    VgX80 obs;
+    uint32_t restart;
+};
+
+template <uint32_t STRIDE>
 __global__ __launch_bounds__(128) void hmm_recursion_kernel(HmmParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t hmm_smem[];
-    const uint32_t n = P.n_gt, stride = P.ploidy + 1, g = threadIdx.x;
+    constexpr uint32_t stride = STRIDE;
+    const uint32_t n = P.n_gt, g = threadIdx.x;
     const bool active = g < n;
     uint8_t* const s_keep = hmm_smem;                                              // n * n
     uint64_t* const s_step_m = reinterpret_cast<uint64_t*>(hmm_smem + ((n * n + 15u) & ~15u));   // 128 * stride
@@ -34,21 +46,42 @@ __global__ __launch_bounds__(128) void hmm_recursion_kernel(HmmParams P)
     __syncthreads();
     const uint8_t* const my_keep = s_keep + (size_t)g * n;
     const VgX80 uniform = x80_load(P.uniform);
+    if (ch.n_steps == 0) return;
+
+    // a zero the compiler cannot see through: the per-step loads go through the vector memory path, whose counter the
+    // waits on LDS do not share (a scalar load in flight would make every LDS wait a wait for memory)
+    uint32_t lane_zero = 0;
+    asm volatile("" : "+v"(lane_zero));
+    auto fetch = [&](uint64_t s, uint32_t row_s, HmmStepIn<STRIDE>& in) {
+        const uint8_t* pw = P.pow + s * (size_t)(2 * stride) * 16 + lane_zero;
+        for (uint32_t k = 0; k < stride; ++k) {
+            in.keep_pow[k] = x80_load(pw + (size_t)k * 16);
+            in.change_pow[k] = x80_load(pw + (size_t)(stride + (stride - 1 - k)) * 16);
+        }
+        in.obs = x80_load(P.obs + ((size_t)row_s * n + (active ? g : 0u)) * 16);
+        in.restart = P.restart[s + lane_zero];
+    };
+    const uint64_t s_end = ch.first_step + ch.n_steps;
+    HmmStepIn<STRIDE> cur;
+    fetch(ch.first_step, P.row[ch.first_step], cur);
+    uint32_t row_next = ch.n_steps > 1 ? P.row[ch.first_step + 1] : 0u;
 
     // values stay normalised (vg_x80.h: VgN80) from the load of a score to the store of a row: the hundred products and sums
     // of a node then take the one-rounding path, and only a result that is not a normal number takes the general one
     VgN80 prev = {0, 0};
-    for (uint64_t s = ch.first_step; s < ch.first_step + ch.n_steps; ++s) {
-        const bool restart = P.restart[s] != 0;
+    for (uint64_t s = ch.first_step; s < s_end; ++s) {
+        HmmStepIn<STRIDE> nx = cur;
+        uint32_t row_after = 0;
+        if (s + 1 < s_end) fetch(s + 1, row_next, nx);
+        if (s + 2 < s_end) row_after = P.row[s + 2 + lane_zero];
+
+        const bool restart = __builtin_amdgcn_readfirstlane(cur.restart) != 0;
         VgN80 o = {0, 0};
-        if (active) o = n80_from(x80_load(P.obs + ((size_t)P.row[s] * n + g) * 16));
+        if (active) o = n80_from(cur.obs);
         if (!restart) {
             // (prev * no_recomb^keep) * recomb^change for this lane's previous entry and every keep
-            const uint8_t* pw = P.pow + s * (size_t)(2 * stride) * 16;
             for (uint32_t k = 0; k < stride; ++k) {
-                const VgN80 pk = n80_from(x80_load(pw + (size_t)k * 16)),
-                            pc = n80_from(x80_load(pw + (size_t)(stride + (P.ploidy - k)) * 16));
-                const VgN80 st = n80_mul(n80_mul(prev, pk), pc);
+                const VgN80 st = n80_mul(n80_mul(prev, n80_from(cur.keep_pow[k])), n80_from(cur.change_pow[k]));
                 s_step_m[g * stride + k] = st.m;
                 s_step_e[g * stride + k] = st.e;
             }
@@ -56,24 +89,29 @@ __global__ __launch_bounds__(128) void hmm_recursion_kernel(HmmParams P)
         __syncthreads();
         VgN80 r = {0, 0};
         if (active) {
-            if (restart) {
+            if (restart || (P.dbg & 2u)) {
                 r = o;
             } else {
                 // the table entry of term p + 1 and the keep byte of term p + 2 are fetched while term p is computed: the
                 // chain r -> r is the only dependency the loop has to wait for (one wavefront per SIMD: nothing else hides LDS)
                 uint32_t at = my_keep[0];
-                VgN80 nx;
-                nx.m = s_step_m[at];
-                nx.e = s_step_e[at];
+                VgN80 nxt;
+                nxt.m = s_step_m[at];
+                nxt.e = s_step_e[at];
                 uint32_t k2 = n > 1 ? my_keep[1] : 0;
                 for (uint32_t p = 0; p < n; ++p) {
-                    const VgN80 st = nx;
+                    const VgN80 st = nxt;
                     if (p + 1 < n) {
                         at = (p + 1) * stride + k2;
-                        nx.m = s_step_m[at];
-                        nx.e = s_step_e[at];
+                        nxt.m = s_step_m[at];
+                        nxt.e = s_step_e[at];
                         k2 = my_keep[p + 2 < n ? p + 2 : p + 1];
                     }
+                    // a term more than 64 binades below the sum so far leaves it as it is (its exponent is at most the
+                    // operands' sum + 2); when that holds for every genotype of the wavefront -- past the entries that carry
+                    // the previous node's weight it mostly does -- the term is not computed
+                    const bool nothing = st.m == 0 || o.m == 0 || (r.m != 0 && r.e - (st.e + o.e - VG_X80_BIAS + 2) > 64);
+                    if (__builtin_amdgcn_ballot_w64(!nothing) == 0 && !(P.dbg & 8u)) continue;
                     r = n80_muladd(r, st, o);
                 }
             }
@@ -83,25 +121,32 @@ __global__ __launch_bounds__(128) void hmm_recursion_kernel(HmmParams P)
         __syncthreads();
         VgN80 total = {0, 0};
         VgN80 tn;
-        tn.m = s_r_m[0];
-        tn.e = s_r_e[0];
-        for (uint32_t p = 0; p < n; ++p) {
+        // every lane adds the same values in the same order; the addresses carry lane_zero so that this runs on the vector
+        // unit, branch-free (as scalar code it is a jump per case and twice the time)
+        tn.m = s_r_m[lane_zero];
+        tn.e = s_r_e[lane_zero];
+        for (uint32_t p = 0; p < ((P.dbg & 1u) ? 1u : n); ++p) {
             const VgN80 t = tn;
             if (p + 1 < n) {
-                tn.m = s_r_m[p + 1];
-                tn.e = s_r_e[p + 1];
+                tn.m = s_r_m[p + 1 + lane_zero];
+                tn.e = s_r_e[p + 1 + lane_zero];
             }
-            total = n80_add(total, t);
+            // an entry more than 64 binades below the running sum (or zero) leaves it as it is: every lane sees the same two
+            // values, so the jump is taken by the whole wavefront (most entries of an informative node are that small)
+            if (t.m == 0 || (total.m != 0 && total.e - t.e > 64)) continue;
+            total = n80_sum(total, t);
         }
         VgX80 out = uniform;
         if (total.m != 0) {
-            prev = n80_div(r, total);
+            prev = (P.dbg & 4u) ? r : n80_div(r, total);
             out = n80_to(prev);
         } else {
             prev = n80_from(uniform);
         }
         if (active) x80_store(P.out + (s * n + g) * 16, out);
         __syncthreads();
+        cur = nx;
+        row_next = row_after;
     }
 }
 
@@ -205,7 +250,17 @@ size_t hmm_lds_bytes(uint32_t n_gt, uint32_t ploidy)
 hipError_t launch_hmm_recursion(const HmmParams& P, uint32_t n_chains, hipStream_t st)
 {
     if (n_chains == 0) return hipSuccess;
-    hipLaunchKernelGGL(hmm_recursion_kernel, dim3(n_chains), dim3(128), hmm_lds_bytes(P.n_gt, P.ploidy), st, P);
+    const size_t lds = hmm_lds_bytes(P.n_gt, P.ploidy);
+    HmmParams Q = P;
+    const char* dbg = getenv("VGMI_DBG");
+    Q.dbg = dbg ? (uint32_t)atoi(dbg) : 0u;
+    switch (P.ploidy) {
+        case 1: hipLaunchKernelGGL(hmm_recursion_kernel<2>, dim3(n_chains), dim3(128), lds, st, Q); break;
+        case 2: hipLaunchKernelGGL(hmm_recursion_kernel<3>, dim3(n_chains), dim3(128), lds, st, Q); break;
+        case 3: hipLaunchKernelGGL(hmm_recursion_kernel<4>, dim3(n_chains), dim3(128), lds, st, Q); break;
+        case 4: hipLaunchKernelGGL(hmm_recursion_kernel<5>, dim3(n_chains), dim3(128), lds, st, Q); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

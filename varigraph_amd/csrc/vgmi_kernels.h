@@ -138,6 +138,7 @@ struct HmmParams {
     const uint8_t* uniform;         // 1 / n_gt as the host computes it
     const HmmChain* chains;
     uint8_t* out;                   // per step: n_gt normalised scores
+    uint32_t dbg;                   // VGMI_DBG ablations (wrong results): 1 no sum over entries, 2 no terms, 4 no division; 8 no skipped terms (right results)
 };
 hipError_t launch_hmm_recursion(const HmmParams& P, uint32_t n_chains, hipStream_t st);
 struct HmmPostParams {
