@@ -214,6 +214,17 @@ int vgmi_hmm_calls(vgmi_ctx *ctx, uint32_t n_gt, uint32_t ploidy, const uint8_t 
                    uint64_t n_rows, const uint32_t *row, const uint8_t *restart, const void *pow, uint64_t n_steps,
                    const void *uniform, const vgmi_hmm_chain *chains, uint32_t n_chains, const uint8_t *gid, const uint8_t *order,
                    const uint64_t *fwd_step, const uint64_t *bwd_step, void *prob, uint32_t *winner, void *alpha_beta_or_null);
+/* The same on a PART of a run's arrays: every array is the whole run's, indexed by global row / step (row[], fwd_step[],
+ * bwd_step[] and the chains hold global numbers); the call reads rows [row_lo, row_hi) and steps [step_lo, step_hi) and writes
+ * those rows of prob / winner.  keep holds the matrices of this part's chains (keep_index counts from 0 here).  Each call
+ * works on a stream and device buffers of its own: parts may be computed at the same time from several threads on one
+ * context -- the windows of a sample become ready one after the other, and a chain is serial from end to end, so the host
+ * prepares the next part while the device runs the last (varigraph_amd/csrc/host/genotyper.cpp). */
+int vgmi_hmm_calls_part(vgmi_ctx *ctx, uint32_t n_gt, uint32_t ploidy, const uint8_t *keep, uint32_t n_windows, const void *obs,
+                        uint64_t row_lo, uint64_t row_hi, const uint32_t *row, const uint8_t *restart, const void *pow,
+                        uint64_t step_lo, uint64_t step_hi, const void *uniform, const vgmi_hmm_chain *chains, uint32_t n_chains,
+                        const uint8_t *gid, const uint8_t *order, const uint64_t *fwd_step, const uint64_t *bwd_step, void *prob,
+                        uint32_t *winner);
 
 /* ---- bench / test tooling (not part of the reference seam) -------------------------------
  * Seeded synthetic reads (varigraph_amd/csrc/vg_synth.h) written straight into device memory:

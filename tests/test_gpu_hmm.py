@@ -163,3 +163,73 @@ def test_posterior_on_the_device_equals_x87():
         assert winner[r] == win and prob[r] == best, r
         n_called += win != 0xFFFFFFFF
     assert n_called > 20
+
+
+def test_parts_side_by_side_equal_the_whole_call():
+    """vgmi_hmm_calls_part on three parts of a run's arrays, from three threads at once on one context, fills prob / winner
+    exactly as vgmi_hmm_calls on the whole arrays does (global row / step numbers, rows a window leaves unused included)."""
+    import threading
+    rng = np.random.default_rng(5)
+    ploidy, n_hap = 2, 15
+    genotypes = list(itertools.combinations_with_replacement(range(n_hap), ploidy))
+    n = len(genotypes)
+    n_windows, room = 6, 25
+    keep = rng.integers(0, ploidy + 1, size=(n_windows, n, n), dtype=np.uint8)
+    n_rows = n_windows * room
+    expo = rng.choice([0, -10, -200, -3000, -4900], size=(n_rows, n), p=[.2, .3, .3, .15, .05])
+    obs = (rng.random((n_rows, n)).astype(LD) + LD(0.01)) * np.power(LD(10), expo.astype(LD))
+    row = np.zeros(2 * n_rows, dtype=np.uint32)
+    restart = np.zeros(2 * n_rows, dtype=np.uint8)
+    fwd = np.zeros(n_rows, dtype=np.uint64)
+    bwd = np.zeros(n_rows, dtype=np.uint64)
+    chains = []
+    for w in range(n_windows):
+        row0, step0, used = w * room, 2 * w * room, room - (w % 3)          # some windows leave rows unused
+        row[step0:step0 + 2 * room] = row0
+        fwd[row0:row0 + room] = step0
+        bwd[row0:row0 + room] = step0
+        row[step0:step0 + used] = np.arange(row0, row0 + used)
+        row[step0 + used:step0 + 2 * used] = np.arange(row0, row0 + used)[::-1]
+        restart[step0] = restart[step0 + used] = 1
+        fwd[row0:row0 + used] = step0 + np.arange(used)
+        bwd[row0:row0 + used] = step0 + used + (used - 1 - np.arange(used))
+        chains.append((step0, used, w))
+        chains.append((step0 + used, used, w))
+    pows = np.zeros((2 * n_rows, 2, ploidy + 1), dtype=LD)
+    for s in range(2 * n_rows):
+        d = LD(rng.integers(1, 20_000))
+        recomb = (LD(1) - np.exp(-d / LD(24))) * (LD(1) / LD(24))
+        no_recomb = np.exp(-d / LD(24)) + recomb
+        pows[s, 0] = [no_recomb ** LD(k) for k in range(ploidy + 1)]
+        pows[s, 1] = [recomb ** LD(k) for k in range(ploidy + 1)]
+    gid = rng.integers(0, 4, size=(n_rows, n), dtype=np.uint8)
+    order = np.full((n_rows, n), 0xFF, dtype=np.uint8)
+    order[:, :4] = [2, 0, 3, 1]
+    uniform = LD(1) / LD(n)
+    ctx = vgmi.Context(0, buffer_mib=16)
+    try:
+        prob, winner, _ = ctx.hmm_calls(keep, obs, row, restart, pows, uniform, chains, ploidy, gid, order, fwd, bwd)
+        prob2 = np.full(n_rows, LD(-1), dtype=LD)
+        winner2 = np.full(n_rows, 12345, dtype=np.uint32)
+        errors = []
+
+        def part(w0, w1):
+            try:
+                ch = [(f, c, k - w0) for f, c, k in chains if w0 <= k < w1]
+                ctx.hmm_calls_part(np.ascontiguousarray(keep[w0:w1]), obs, row, restart, pows, uniform, ch, ploidy, gid, order, fwd, bwd,
+                                   (w0 * room, w1 * room), (2 * w0 * room, 2 * w1 * room), prob2, winner2)
+            except Exception as e:      # noqa: BLE001 -- reported below
+                errors.append(e)
+        threads = [threading.Thread(target=part, args=a) for a in ((0, 2), (2, 3), (3, 6))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        ctx.close()
+    assert not errors, errors
+    used = np.zeros(n_rows, dtype=bool)
+    for w in range(n_windows):
+        used[w * room:w * room + room - (w % 3)] = True
+    assert np.array_equal(winner[used], winner2[used]) and np.array_equal(prob[used], prob2[used])
+    assert (winner[used] != 0xFFFFFFFF).sum() > 100

@@ -12,10 +12,13 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <iomanip>
 #include <iterator>
 #include <map>
+#include <mutex>
 #include <queue>
 #include <random>
 #include <set>
@@ -1369,79 +1372,125 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                 works[t].order = static_cast<uint8_t*>(raw_order.p) + works[t].row0 * dev_n_gt;
                 works[t].fwd_step = static_cast<uint64_t*>(raw_fs.p) + works[t].row0;
                 works[t].bwd_step = static_cast<uint64_t*>(raw_bs.p) + works[t].row0;
+                // rows and steps a window leaves unused (nodes without k-mers) still point into its own part of the arrays
+                std::fill(works[t].row, works[t].row + 2 * works[t].room, (uint32_t)works[t].row0);
+                std::fill(works[t].fwd_step, works[t].fwd_step + works[t].room, (uint64_t)works[t].step0);
+                std::fill(works[t].bwd_step, works[t].bwd_step + works[t].room, (uint64_t)works[t].step0);
             }
         }
     }
     const bool device_ready = raw_obs.p != nullptr;
+    const uint32_t n_threads = std::max(1u, std::min<uint32_t>(cfg.threads, (uint32_t)tasks.size()));
+    // ---- three kinds of work on one pool: a window is prepared (window()), the recursion and posterior of a PART of the
+    // windows run on the device (one call per part, on a thread of its own that mostly waits), the calls of a part's windows
+    // are written back (window_finish()).  A chain is serial from its first node to its last, so the device takes as long
+    // for ten windows as for all of them: the parts go to the device as soon as their windows are prepared, side by side
+    // (vgmi_hmm_calls_part: own stream and buffers per call), while the pool prepares the next and finishes the last.
+    // At most four parts, over all the samples genotyped at the same time (set_device): a process has four hardware queues by
+    // default and a stream beyond them shares one, waiting behind the other stream's kernel for its whole length.
+    const size_t max_parts = std::min<size_t>(4, dev_parts_);
+    const size_t part_windows = std::max<size_t>(n_threads, (tasks.size() + max_parts - 1) / max_parts);
+    const size_t n_parts = device_ready ? (tasks.size() + part_windows - 1) / part_windows : 0;
+    std::vector<std::atomic<size_t>> part_done(n_parts);
+    for (auto& d : part_done) d.store(0);
+    std::vector<std::thread> part_threads(n_parts);
+    std::mutex q_mu;
+    std::condition_variable q_cv;
+    std::deque<size_t> finish_q;          // windows whose calls are back from the device
+    size_t parts_open = n_parts;          // under q_mu
     std::atomic<size_t> next{0};
     std::string error;
     std::atomic<bool> failed{false};
+    std::atomic<int64_t> dev_first{INT64_MAX}, dev_last{0};
+    auto fail_with = [&](const char* what) {
+        if (!failed.exchange(true)) error = what;
+        std::lock_guard<std::mutex> lock(q_mu);
+        q_cv.notify_all();
+    };
+    auto since_begin = [&]() { return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count(); };
+    auto run_part = [&](size_t part) {
+        try {
+            const size_t t0 = part * part_windows, t1 = std::min(tasks.size(), t0 + part_windows);
+            std::vector<size_t> dw;
+            for (size_t t = t0; t < t1; ++t)
+                if (works[t].on_device && !works[t].nodes.empty()) dw.push_back(t);
+            if (!dw.empty() && !failed.load()) {
+                const size_t n = dev_n_gt;
+                std::vector<uint8_t> keep(dw.size() * n * n);
+                std::vector<vgmi_hmm_chain> chains;
+                for (size_t wi = 0; wi < dw.size(); ++wi) {
+                    const WindowWork& w = works[dw[wi]];
+                    if (w.n_gt != n || w.ploidy != cfg.sample_ploidy) throw std::runtime_error("internal: a window with another genotype list");
+                    std::memcpy(&keep[wi * n * n], w.keep_mat.data(), n * n);
+                    const uint64_t m = w.nodes.size();
+                    chains.push_back(vgmi_hmm_chain{w.step0, m, (uint32_t)wi, 0});
+                    chains.push_back(vgmi_hmm_chain{w.step0 + m, m, (uint32_t)wi, 0});
+                }
+                const uint64_t row_lo = works[t0].row0, row_hi = works[t1 - 1].row0 + works[t1 - 1].room;
+                const long double uniform = 1.0L / (long double)n;
+                const int64_t ta = since_begin();
+                if (vgmi_hmm_calls_part(dev_, (uint32_t)n, cfg.sample_ploidy, keep.data(), (uint32_t)dw.size(), raw_obs.p, row_lo, row_hi,
+                                        static_cast<const uint32_t*>(raw_row.p), static_cast<const uint8_t*>(raw_restart.p), raw_pw.p, 2 * row_lo,
+                                        2 * row_hi, &uniform, chains.data(), (uint32_t)chains.size(), static_cast<const uint8_t*>(raw_gid.p),
+                                        static_cast<const uint8_t*>(raw_order.p), static_cast<const uint64_t*>(raw_fs.p),
+                                        static_cast<const uint64_t*>(raw_bs.p), raw_prob.p, static_cast<uint32_t*>(raw_win.p)) != VGMI_OK)
+                    throw std::runtime_error(std::string("device HMM recursion: ") + vgmi_last_error(dev_));
+                const int64_t tb = since_begin();
+                if (g_phase_on)
+                    std::fprintf(stderr, "[varigraph-mi] HMM part %zu (windows %zu-%zu): on the device from %.3f to %.3f s\n", part, t0, t1 - 1, ta * 1e-9, tb * 1e-9);
+                for (int64_t v = dev_first.load(); ta < v && !dev_first.compare_exchange_weak(v, ta);) {}
+                for (int64_t v = dev_last.load(); tb > v && !dev_last.compare_exchange_weak(v, tb);) {}
+            }
+            std::lock_guard<std::mutex> lock(q_mu);
+            for (size_t t : dw) finish_q.push_back(t);
+            --parts_open;
+            q_cv.notify_all();
+        } catch (const std::exception& e) {
+            fail_with(e.what());
+        }
+    };
     auto worker = [&]() {
         for (;;) {
             const size_t t = next.fetch_add(1);
-            if (t >= tasks.size() || failed.load()) return;
+            if (t >= tasks.size() || failed.load()) break;
             try {
                 window(*tasks[t].chr, tasks[t].first, tasks[t].last, r, device_ready ? &works[t] : nullptr);
+                if (device_ready) {
+                    const size_t part = t / part_windows;
+                    const size_t in_part = std::min(tasks.size(), (part + 1) * part_windows) - part * part_windows;
+                    if (part_done[part].fetch_add(1) + 1 == in_part) part_threads[part] = std::thread(run_part, part);
+                }
             } catch (const std::exception& e) {
-                if (!failed.exchange(true)) error = e.what();
+                fail_with(e.what());
+                return;
+            }
+        }
+        for (;;) {      // nothing left to prepare: the calls that are back
+            size_t t;
+            {
+                std::unique_lock<std::mutex> lock(q_mu);
+                q_cv.wait(lock, [&] { return !finish_q.empty() || parts_open == 0 || failed.load(); });
+                if (failed.load() || finish_q.empty()) return;
+                t = finish_q.front();
+                finish_q.pop_front();
+            }
+            try {
+                WindowWork& w = works[t];
+                window_finish(w, static_cast<const long double*>(raw_prob.p) + w.row0, static_cast<const uint32_t*>(raw_win.p) + w.row0, r);
+            } catch (const std::exception& e) {
+                fail_with(e.what());
                 return;
             }
         }
     };
-    const uint32_t n_threads = std::max(1u, std::min<uint32_t>(cfg.threads, (uint32_t)tasks.size()));
     std::vector<std::thread> pool;
     for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(worker);
     worker();
     for (auto& th : pool) th.join();
+    for (auto& th : part_threads)
+        if (th.joinable()) th.join();
     if (failed.load()) throw std::runtime_error(error);
-    last_device_seconds = 0;
-    if (device_ready) {
-        // ---- the recursion of every prepared window in ONE device call (a chain per window and direction), then the calls
-        std::vector<size_t> dw;
-        for (size_t t = 0; t < works.size(); ++t)
-            if (works[t].on_device && !works[t].nodes.empty()) dw.push_back(t);
-        if (!dw.empty()) {
-            const size_t n = dev_n_gt;
-            std::vector<uint8_t> keep(dw.size() * n * n);
-            std::vector<vgmi_hmm_chain> chains;
-            for (size_t wi = 0; wi < dw.size(); ++wi) {
-                const WindowWork& w = works[dw[wi]];
-                if (w.n_gt != n || w.ploidy != cfg.sample_ploidy) throw std::runtime_error("internal: a window with another genotype list");
-                std::memcpy(&keep[wi * n * n], w.keep_mat.data(), n * n);
-                const uint64_t m = w.nodes.size();
-                chains.push_back(vgmi_hmm_chain{w.step0, m, (uint32_t)wi, 0});
-                chains.push_back(vgmi_hmm_chain{w.step0 + m, m, (uint32_t)wi, 0});
-            }
-            const long double uniform = 1.0L / (long double)n;
-            const auto td0 = std::chrono::steady_clock::now();
-            if (vgmi_hmm_calls(dev_, (uint32_t)n, cfg.sample_ploidy, keep.data(), (uint32_t)dw.size(), raw_obs.p, total_room,
-                               static_cast<const uint32_t*>(raw_row.p), static_cast<const uint8_t*>(raw_restart.p), raw_pw.p, 2 * total_room, &uniform,
-                               chains.data(), (uint32_t)chains.size(), static_cast<const uint8_t*>(raw_gid.p), static_cast<const uint8_t*>(raw_order.p),
-                               static_cast<const uint64_t*>(raw_fs.p), static_cast<const uint64_t*>(raw_bs.p), raw_prob.p,
-                               static_cast<uint32_t*>(raw_win.p), nullptr) != VGMI_OK)
-                throw std::runtime_error(std::string("device HMM recursion: ") + vgmi_last_error(dev_));
-            last_device_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - td0).count();
-        }
-        std::atomic<size_t> next_w{0};
-        auto finisher = [&]() {
-            for (;;) {
-                const size_t q = next_w.fetch_add(1);
-                if (q >= dw.size() || failed.load()) return;
-                try {
-                    WindowWork& w = works[dw[q]];
-                    window_finish(w, static_cast<const long double*>(raw_prob.p) + w.row0, static_cast<const uint32_t*>(raw_win.p) + w.row0, r);
-                } catch (const std::exception& e) {
-                    if (!failed.exchange(true)) error = e.what();
-                    return;
-                }
-            }
-        };
-        std::vector<std::thread> pool2;
-        for (uint32_t t = 1; t < n_threads; ++t) pool2.emplace_back(finisher);
-        finisher();
-        for (auto& th : pool2) th.join();
-        if (failed.load()) throw std::runtime_error(error);
-    }
+    last_device_seconds = dev_last.load() > 0 ? (double)(dev_last.load() - dev_first.load()) * 1e-9 : 0;
     const auto t_hmm = std::chrono::steady_clock::now();
     last_hmm_seconds = std::chrono::duration<double>(t_hmm - t_begin).count();
     if (g_phase_on) {

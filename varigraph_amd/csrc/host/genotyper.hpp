@@ -49,7 +49,9 @@ public:
 
     // The forward / backward recursion of eligible windows (transition "rec", every genotype with `ploidy` haplotypes, at most
     // 128 genotypes) runs on this context's device (vgmi_hmm_recursion: the reference's arithmetic bit for bit); nullptr: host.
-    void set_device(vgmi_ctx* ctx) { dev_ = ctx; }
+    // max_parts: into how many device calls side by side a sample's windows may go (the process's four hardware queues,
+    // shared by the consumers that genotype at the same time)
+    void set_device(vgmi_ctx* ctx, unsigned max_parts = 4) { dev_ = ctx; dev_parts_ = max_parts ? max_parts : 1; }
 
     // `text` into `path` as block gzip (same content as SAVE's gzwrite), deflated by `threads` workers
     static void write_gz(const std::string& path, const std::string& text, unsigned threads = 1);
@@ -115,6 +117,7 @@ private:
     const GraphIndex& g_;
     std::vector<Chrom> chroms_;   // mGraphMap order
     vgmi_ctx* dev_ = nullptr;
+    unsigned dev_parts_ = 4;
     uint32_t n_hap_ = 0;
     std::vector<uint16_t> hap_ids_;   // the keys of g_.hap_names in their order
     std::vector<uint64_t> packed_;    // per key: coverage | multiplicity << 8 | haplotype bits << 16 (this sample)

@@ -316,7 +316,9 @@ int main_genotype(int argc, char** argv)
                 if (!(e && e[0] == '0')) {
                     const int dev = o.gpus[consumer_no.fetch_add(1) % o.gpus.size()];
                     if (vgmi_create(dev, 16, &own.c) != VGMI_OK) die(std::string("device ") + std::to_string(dev) + ": " + vgmi_last_error(nullptr));
-                    genotyper.set_device(own.c);
+                    size_t on_dev = 0;      // consumers whose HMM calls go to this device
+                    for (size_t k = 0; k < n_consumers; ++k) on_dev += o.gpus[k % o.gpus.size()] == dev;
+                    genotyper.set_device(own.c, (unsigned)std::max<size_t>(1, 4 / std::max<size_t>(1, on_dev)));
                 }
             }
             for (;;) {

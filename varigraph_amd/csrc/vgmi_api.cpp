@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -59,6 +60,10 @@ struct vgmi_ctx {
     size_t buffer_bytes = 0;
     std::string err;
     hipStream_t stream = nullptr;  // main stream: table build, device submits, finish
+    // working memory of the HMM calls, kept between them: hipFree waits for every stream of the device, so a part that
+    // finished would wait for the parts still running (vgmi_hmm_calls_part); a sample reuses the last sample's blocks
+    std::mutex hmm_mu;
+    std::vector<std::pair<uint8_t*, size_t>> hmm_blocks;   // not in use
 
     // table image (one allocation) and views into it
     uint8_t* d_image = nullptr;
@@ -122,6 +127,8 @@ bool xtable_wanted(const ImageHeader& h);
 
 int fail(vgmi_ctx* c, int code, const std::string& msg)
 {
+    static std::mutex mu;       // vgmi_hmm_calls_part may fail on several threads of one context
+    std::lock_guard<std::mutex> lock(mu);
     if (c) c->err = msg; else g_create_error = msg;
     return code;
 }
@@ -677,6 +684,7 @@ void vgmi_destroy(vgmi_ctx* c)
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_hist) (void)hipFree(c->d_hist);
     if (c->reset_done) (void)hipEventDestroy(c->reset_done);
+    for (auto& b : c->hmm_blocks) (void)hipFree(b.first);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1544,67 +1552,115 @@ int vgmi_bloom_add_seq(vgmi_ctx* c, const char* bases, uint64_t len, uint32_t k)
 }
 
 namespace {
-// recursion (+ posterior when gid is given) in one pass over device buffers: alpha / beta leave the device only if `out` asks
-int hmm_run(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, uint32_t n_windows, const void* obs, uint64_t n_rows,
-            const uint32_t* row, const uint8_t* restart, const void* pow, uint64_t n_steps, const void* uniform, const vgmi_hmm_chain* chains,
-            uint32_t n_chains, void* out, const uint8_t* gid, const uint8_t* order, const uint64_t* fwd_step, const uint64_t* bwd_step,
-            void* prob, uint32_t* winner)
+// recursion (+ posterior when gid is given) in one pass over device buffers: alpha / beta leave the device only if `out` asks.
+// Every array is indexed by GLOBAL row / step; this call reads and writes rows [row_lo, row_hi) and steps [step_lo, step_hi) only
+// (device buffers of that size, the kernels' pointers moved back by the range's start).  It works on a stream of its own and
+// touches nothing of the context but its device and error text: calls on parts of the same arrays may run side by side.
+int hmm_run(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, uint32_t n_windows, const void* obs, uint64_t row_lo,
+            uint64_t row_hi, const uint32_t* row, const uint8_t* restart, const void* pow, uint64_t step_lo, uint64_t step_hi,
+            const void* uniform, const vgmi_hmm_chain* chains, uint32_t n_chains, void* out, const uint8_t* gid, const uint8_t* order,
+            const uint64_t* fwd_step, const uint64_t* bwd_step, void* prob, uint32_t* winner)
 {
     if (!c || !keep || !obs || !row || !restart || !pow || !uniform || !chains) return VGMI_E_INVALID;
     if (n_gt < 1 || n_gt > 128 || ploidy < 1 || ploidy > 4) return fail(c, VGMI_E_INVALID, "HMM recursion: 1..128 genotypes of 1..4 haplotypes");
+    if (row_lo > row_hi || step_lo > step_hi) return fail(c, VGMI_E_INVALID, "HMM recursion: an empty-handed range");
+    const uint64_t n_rows = row_hi - row_lo, n_steps = step_hi - step_lo;
     for (uint32_t i = 0; i < n_chains; ++i)
-        if (chains[i].keep_index >= n_windows || chains[i].first_step + chains[i].n_steps > n_steps)
+        if (chains[i].keep_index >= n_windows || chains[i].first_step < step_lo || chains[i].first_step + chains[i].n_steps > step_hi)
             return fail(c, VGMI_E_INVALID, "HMM recursion: a chain points outside its arrays");
-    for (uint64_t s = 0; s < n_steps; ++s)
-        if (row[s] >= n_rows) return fail(c, VGMI_E_INVALID, "HMM recursion: a step points outside the emission rows");
+    for (uint64_t s = step_lo; s < step_hi; ++s)
+        if (row[s] < row_lo || row[s] >= row_hi) return fail(c, VGMI_E_INVALID, "HMM recursion: a step points outside the emission rows");
     if (gid)
-        for (uint64_t i = 0; i < n_rows; ++i)
-            if (fwd_step[i] >= n_steps || bwd_step[i] >= n_steps) return fail(c, VGMI_E_INVALID, "HMM posterior: a row points outside the steps");
+        for (uint64_t i = row_lo; i < row_hi; ++i)
+            if (fwd_step[i] < step_lo || fwd_step[i] >= step_hi || bwd_step[i] < step_lo || bwd_step[i] >= step_hi)
+                return fail(c, VGMI_E_INVALID, "HMM posterior: a row points outside the steps");
     if (n_steps == 0 || n_chains == 0) return VGMI_OK;
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t stride = ploidy + 1;
-    const size_t b_keep = (size_t)n_windows * n_gt * n_gt, b_obs = (size_t)n_rows * n_gt * 16, b_row = (size_t)n_steps * 4,
-                 b_pow = (size_t)n_steps * 2 * stride * 16, b_ch = (size_t)n_chains * sizeof(vgmi_hmm_chain), b_out = (size_t)n_steps * n_gt * 16,
-                 b_gid = gid ? (size_t)n_rows * n_gt : 0, b_fs = gid ? (size_t)n_rows * 8 : 0, b_prob = gid ? (size_t)n_rows * 16 : 0,
-                 b_win = gid ? (size_t)n_rows * 4 : 0;
+    const size_t b_keep = (size_t)n_windows * n_gt * n_gt, w_obs = (size_t)n_gt * 16, b_obs = (size_t)n_rows * w_obs, b_row = (size_t)n_steps * 4,
+                 w_pow = (size_t)2 * stride * 16, b_pow = (size_t)n_steps * w_pow, b_ch = (size_t)n_chains * sizeof(vgmi_hmm_chain),
+                 b_out = (size_t)n_steps * w_obs, b_gid = gid ? (size_t)n_rows * n_gt : 0, b_fs = gid ? (size_t)n_rows * 8 : 0,
+                 b_prob = gid ? (size_t)n_rows * 16 : 0, b_win = gid ? (size_t)n_rows * 4 : 0;
     static_assert(sizeof(vgmi_hmm_chain) == sizeof(HmmChain), "chain layout");
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_keep = 0, o_obs = up(o_keep + b_keep), o_row = up(o_obs + b_obs), o_rs = up(o_row + b_row), o_pow = up(o_rs + n_steps),
                  o_uni = up(o_pow + b_pow), o_ch = o_uni + 256, o_out = up(o_ch + b_ch), o_gid = up(o_out + b_out), o_ord = up(o_gid + b_gid),
                  o_fs = up(o_ord + b_gid), o_bs = up(o_fs + b_fs), o_prob = up(o_bs + b_fs), o_win = up(o_prob + b_prob), total = up(o_win + b_win);
+    const auto h0 = std::chrono::steady_clock::now();
     uint8_t* d = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), total);
-    if (e != hipSuccess) return fail(c, VGMI_E_NOMEM, "HMM recursion: not enough device memory");
-    hipStream_t st = c->stream;
+    size_t d_bytes = 0;
+    {
+        // the smallest kept block that is large enough, else a new one (the kept ones that are too small make room first)
+        std::lock_guard<std::mutex> lock(c->hmm_mu);
+        size_t best = SIZE_MAX;
+        for (size_t i = 0; i < c->hmm_blocks.size(); ++i)
+            if (c->hmm_blocks[i].second >= total && (best == SIZE_MAX || c->hmm_blocks[i].second < c->hmm_blocks[best].second)) best = i;
+        if (best != SIZE_MAX) {
+            d = c->hmm_blocks[best].first;
+            d_bytes = c->hmm_blocks[best].second;
+            c->hmm_blocks.erase(c->hmm_blocks.begin() + (ptrdiff_t)best);
+        }
+    }
+    hipError_t e = hipSuccess;
+    if (!d) {
+        d_bytes = total;
+        e = hipMalloc(reinterpret_cast<void**>(&d), total);
+        if (e != hipSuccess) {
+            std::vector<std::pair<uint8_t*, size_t>> drop;
+            {
+                std::lock_guard<std::mutex> lock(c->hmm_mu);
+                drop.swap(c->hmm_blocks);
+            }
+            for (auto& b : drop) (void)hipFree(b.first);
+            e = hipMalloc(reinterpret_cast<void**>(&d), total);
+        }
+        if (e != hipSuccess) return fail(c, VGMI_E_NOMEM, "HMM recursion: not enough device memory");
+    }
+    auto keep_block = [&]() {
+        std::lock_guard<std::mutex> lock(c->hmm_mu);
+        c->hmm_blocks.emplace_back(d, d_bytes);
+    };
+    const auto h1 = std::chrono::steady_clock::now();
+    hipStream_t st = nullptr;
+    e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        keep_block();
+        HIPCHK(c, e);
+    }
     // VGMI_HMM_TIMING=1: upload / recursion / posterior + download, milliseconds on stderr (diagnostics)
     const bool timing = getenv("VGMI_HMM_TIMING") != nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     if (timing)
         for (auto& x : ev) (void)hipEventCreate(&x);
     if (timing) (void)hipEventRecord(ev[0], st);
+    const uint8_t* h_obs = static_cast<const uint8_t*>(obs) + row_lo * w_obs;
+    const uint8_t* h_pow = static_cast<const uint8_t*>(pow) + step_lo * w_pow;
     e = hipMemcpyAsync(d + o_keep, keep, b_keep, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d + o_obs, obs, b_obs, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d + o_row, row, b_row, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d + o_rs, restart, n_steps, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d + o_pow, pow, b_pow, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_obs, h_obs, b_obs, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_row, row + step_lo, b_row, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_rs, restart + step_lo, n_steps, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_pow, h_pow, b_pow, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_uni, uniform, 16, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_ch, chains, b_ch, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && gid) e = hipMemcpyAsync(d + o_gid, gid, b_gid, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && gid) e = hipMemcpyAsync(d + o_ord, order, b_gid, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && gid) e = hipMemcpyAsync(d + o_fs, fwd_step, b_fs, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && gid) e = hipMemcpyAsync(d + o_bs, bwd_step, b_fs, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && gid) e = hipMemcpyAsync(d + o_gid, gid + row_lo * n_gt, b_gid, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && gid) e = hipMemcpyAsync(d + o_ord, order + row_lo * n_gt, b_gid, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && gid) e = hipMemcpyAsync(d + o_fs, fwd_step + row_lo, b_fs, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && gid) e = hipMemcpyAsync(d + o_bs, bwd_step + row_lo, b_fs, hipMemcpyHostToDevice, st);
+    const auto h2 = std::chrono::steady_clock::now();
+    // where global row / step 0 would lie (the kernels only touch the range)
+    auto back = [](uint8_t* p, size_t bytes) { return reinterpret_cast<uint8_t*>(reinterpret_cast<uintptr_t>(p) - bytes); };
     if (e == hipSuccess) {
         HmmParams P{};
         P.n_gt = n_gt;
         P.ploidy = ploidy;
         P.keep = d + o_keep;
-        P.obs = d + o_obs;
-        P.row = reinterpret_cast<const uint32_t*>(d + o_row);
-        P.restart = d + o_rs;
-        P.pow = d + o_pow;
+        P.obs = back(d + o_obs, row_lo * w_obs);
+        P.row = reinterpret_cast<const uint32_t*>(back(d + o_row, step_lo * 4));
+        P.restart = back(d + o_rs, step_lo);
+        P.pow = back(d + o_pow, step_lo * w_pow);
         P.uniform = d + o_uni;
         P.chains = reinterpret_cast<const HmmChain*>(d + o_ch);
-        P.out = d + o_out;
+        P.out = back(d + o_out, step_lo * w_obs);
         if (timing) (void)hipEventRecord(ev[1], st);
         e = launch_hmm_recursion(P, n_chains, st);
         if (timing) (void)hipEventRecord(ev[2], st);
@@ -1612,18 +1668,19 @@ int hmm_run(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, ui
     if (e == hipSuccess && gid) {
         HmmPostParams Q{};
         Q.n_gt = n_gt;
-        Q.ab = d + o_out;
-        Q.fwd_step = reinterpret_cast<const uint64_t*>(d + o_fs);
-        Q.bwd_step = reinterpret_cast<const uint64_t*>(d + o_bs);
-        Q.gid = d + o_gid;
-        Q.order = d + o_ord;
-        Q.prob = d + o_prob;
-        Q.winner = reinterpret_cast<uint32_t*>(d + o_win);
+        Q.row0 = row_lo;
+        Q.ab = back(d + o_out, step_lo * w_obs);
+        Q.fwd_step = reinterpret_cast<const uint64_t*>(back(d + o_fs, row_lo * 8));
+        Q.bwd_step = reinterpret_cast<const uint64_t*>(back(d + o_bs, row_lo * 8));
+        Q.gid = back(d + o_gid, row_lo * n_gt);
+        Q.order = back(d + o_ord, row_lo * n_gt);
+        Q.prob = back(d + o_prob, row_lo * 16);
+        Q.winner = reinterpret_cast<uint32_t*>(back(d + o_win, row_lo * 4));
         e = launch_hmm_posterior(Q, n_rows, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(prob, d + o_prob, b_prob, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(winner, d + o_win, b_win, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(static_cast<uint8_t*>(prob) + row_lo * 16, d + o_prob, b_prob, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(winner + row_lo, d + o_win, b_win, hipMemcpyDeviceToHost, st);
     }
-    if (e == hipSuccess && out) e = hipMemcpyAsync(out, d + o_out, b_out, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && out) e = hipMemcpyAsync(static_cast<uint8_t*>(out) + step_lo * w_obs, d + o_out, b_out, hipMemcpyDeviceToHost, st);
     if (timing) (void)hipEventRecord(ev[3], st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (timing) {
@@ -1633,11 +1690,15 @@ int hmm_run(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, ui
             (void)hipEventElapsedTime(&b, ev[1], ev[2]);
             (void)hipEventElapsedTime(&g, ev[2], ev[3]);
         }
-        fprintf(stderr, "[vgmi] HMM on the device: %u chains, %llu steps, upload %.1f ms (%.0f MB), recursion %.1f ms, posterior + download %.1f ms\n",
-                n_chains, (unsigned long long)n_steps, a, (double)(b_keep + b_obs + b_row + b_pow + 2 * b_gid + 2 * b_fs) / 1e6, b, g);
+        auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
+        fprintf(stderr, "[vgmi] HMM on the device: %u chains, %llu steps, upload %.1f ms (%.0f MB), recursion %.1f ms, posterior + download %.1f ms; "
+                        "host: memory %.1f ms, copies issued in %.1f ms, whole call %.1f ms\n",
+                n_chains, (unsigned long long)n_steps, a, (double)(b_keep + b_obs + b_row + b_pow + 2 * b_gid + 2 * b_fs) / 1e6, b, g, ms(h0, h1),
+                ms(h1, h2), ms(h0, std::chrono::steady_clock::now()));
         for (auto& x : ev) (void)hipEventDestroy(x);
     }
-    (void)hipFree(d);
+    (void)hipStreamDestroy(st);
+    keep_block();
     HIPCHK(c, e);
     return VGMI_OK;
 }
@@ -1648,8 +1709,8 @@ int vgmi_hmm_recursion(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_
                        const void* uniform, const vgmi_hmm_chain* chains, uint32_t n_chains, void* out)
 {
     if (!out) return VGMI_E_INVALID;
-    return hmm_run(c, n_gt, ploidy, keep, n_windows, obs, n_rows, row, restart, pow, n_steps, uniform, chains, n_chains, out, nullptr, nullptr,
-                   nullptr, nullptr, nullptr, nullptr);
+    return hmm_run(c, n_gt, ploidy, keep, n_windows, obs, 0, n_rows, row, restart, pow, 0, n_steps, uniform, chains, n_chains, out, nullptr,
+                   nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 int vgmi_hmm_calls(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, uint32_t n_windows, const void* obs, uint64_t n_rows,
@@ -1658,8 +1719,18 @@ int vgmi_hmm_calls(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* k
                    const uint64_t* bwd_step, void* prob, uint32_t* winner, void* alpha_beta_or_null)
 {
     if (!gid || !order || !fwd_step || !bwd_step || !prob || !winner) return VGMI_E_INVALID;
-    return hmm_run(c, n_gt, ploidy, keep, n_windows, obs, n_rows, row, restart, pow, n_steps, uniform, chains, n_chains, alpha_beta_or_null, gid,
-                   order, fwd_step, bwd_step, prob, winner);
+    return hmm_run(c, n_gt, ploidy, keep, n_windows, obs, 0, n_rows, row, restart, pow, 0, n_steps, uniform, chains, n_chains, alpha_beta_or_null,
+                   gid, order, fwd_step, bwd_step, prob, winner);
+}
+
+int vgmi_hmm_calls_part(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, uint32_t n_windows, const void* obs, uint64_t row_lo,
+                        uint64_t row_hi, const uint32_t* row, const uint8_t* restart, const void* pow, uint64_t step_lo, uint64_t step_hi,
+                        const void* uniform, const vgmi_hmm_chain* chains, uint32_t n_chains, const uint8_t* gid, const uint8_t* order,
+                        const uint64_t* fwd_step, const uint64_t* bwd_step, void* prob, uint32_t* winner)
+{
+    if (!gid || !order || !fwd_step || !bwd_step || !prob || !winner) return VGMI_E_INVALID;
+    return hmm_run(c, n_gt, ploidy, keep, n_windows, obs, row_lo, row_hi, row, restart, pow, step_lo, step_hi, uniform, chains, n_chains, nullptr,
+                   gid, order, fwd_step, bwd_step, prob, winner);
 }
 
 // BloomFilter::save / load (src/counting_bloom_filter.cpp:126-190): u64 size | u32 numHashes | numHashes x u64 seed | size bytes

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(128) void hmm_posterior_kernel(HmmPostParams P)
     __shared__ uint32_t s_sum_e[128];
     __shared__ uint8_t s_gid[128];
     const uint32_t n = P.n_gt, g = threadIdx.x;
-    const uint64_t rowi = blockIdx.x;
+    const uint64_t rowi = P.row0 + blockIdx.x;
     const bool active = g < n;
     VgX80 p = {0, 0};
     if (active) {

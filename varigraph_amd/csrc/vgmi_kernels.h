@@ -143,6 +143,7 @@ struct HmmParams {
 hipError_t launch_hmm_recursion(const HmmParams& P, uint32_t n_chains, hipStream_t st);
 struct HmmPostParams {
     uint32_t n_gt;
+    uint64_t row0;                  // the launch's first row (workgroup b takes row0 + b)
     const uint8_t* ab;              // the recursion's output: per step n_gt scores
     const uint64_t* fwd_step;       // per row: the step that holds its alpha / its beta
     const uint64_t* bwd_step;

@@ -68,6 +68,8 @@ def load_library():
         "vgmi_bloom_add_seq_device": (i32, [vp, vp, u64, u32]),
         "vgmi_hmm_recursion": (i32, [vp, u32, u32, vp, u32, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp, u32, vp]),
         "vgmi_hmm_calls": (i32, [vp, u32, u32, vp, u32, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]),
+        "vgmi_hmm_calls_part": (i32, [vp, u32, u32, vp, u32, vp, C.c_uint64, C.c_uint64, vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp, u32,
+                                      vp, vp, vp, vp, vp, vp]),
         "vgmi_bloom_fetch": (i32, [vp, vp]),
         "vgmi_bloom_save_file": (i32, [vp, C.c_char_p]),
         "vgmi_bloom_load_file": (i32, [vp, C.c_char_p]),
@@ -391,6 +393,24 @@ class Context:
                                           _ptr(pow_tables), row.size, _ptr(uni), _ptr(ch), len(chains), _ptr(gid), _ptr(order), _ptr(fwd_step),
                                           _ptr(bwd_step), _ptr(prob), _ptr(winner), _ptr(ab)))
         return prob, winner, ab
+
+    def hmm_calls_part(self, keep, obs, row, restart, pow_tables, uniform, chains, ploidy, gid, order, fwd_step, bwd_step, rows, steps,
+                       prob, winner):
+        """vgmi_hmm_calls_part: the arrays are the whole run's (global rows / steps), the call works on rows [rows[0], rows[1]) and
+        steps [steps[0], steps[1]) and fills those rows of prob / winner (numpy arrays of the whole run); keep holds the
+        matrices of this part's chains only.  Calls on different parts may run at the same time."""
+        n_gt = obs.shape[1]
+        uni = np.ascontiguousarray([uniform], dtype=np.longdouble)
+        ch = np.zeros((len(chains), 3), dtype=np.uint64)
+        for i, (f, n, k) in enumerate(chains):
+            ch[i] = (f, n, k)
+        for a, t in ((keep, np.uint8), (obs, np.longdouble), (row, np.uint32), (restart, np.uint8), (pow_tables, np.longdouble),
+                     (gid, np.uint8), (order, np.uint8), (fwd_step, np.uint64), (bwd_step, np.uint64), (prob, np.longdouble),
+                     (winner, np.uint32)):
+            assert a.dtype == t and a.flags.c_contiguous
+        self._chk(self._l.vgmi_hmm_calls_part(self._h, n_gt, ploidy, _ptr(keep), keep.shape[0], _ptr(obs), rows[0], rows[1], _ptr(row),
+                                               _ptr(restart), _ptr(pow_tables), steps[0], steps[1], _ptr(uni), _ptr(ch), len(chains), _ptr(gid),
+                                               _ptr(order), _ptr(fwd_step), _ptr(bwd_step), _ptr(prob), _ptr(winner)))
 
     def bloom_save_file(self, path):
         self._chk(self._l.vgmi_bloom_save_file(self._h, os.fsencode(path)))
