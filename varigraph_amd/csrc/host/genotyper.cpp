@@ -282,29 +282,44 @@ struct Genotyper::WindowWork {
     uint64_t *fwd_step = nullptr, *bwd_step = nullptr;   // row0 on: the steps that hold the node's alpha / beta
 };
 
-Genotyper::Genotyper(const GraphIndex& g) : g_(g)
+Genotyper::Genotyper(const GraphIndex& g, unsigned threads) : g_(g)
 {
     n_hap_ = (uint32_t)g.hap_names.size();
     for (const auto& kv : g.hap_names) hap_ids_.push_back(kv.first);
-    // variant nodes in mGraphMap order carry the graph2node k-mer lists (CSR over key indices)
+    // variant nodes in mGraphMap order carry the graph2node k-mer lists (CSR over key indices).  The maps are walked once for
+    // the nodes' places; the half million small k-mer lists are then copied by `threads` workers.
+    struct Place { uint32_t start; const GraphNode* gn; size_t v; };
     size_t v = 0;
     for (const auto& [chr, nodes] : g.graph) {
         Chrom c;
         c.name = chr;
         auto it = g.chr_len.find(chr);
         c.len = it == g.chr_len.end() ? 0 : it->second;
-        c.nodes.reserve(nodes.size());
+        std::vector<Place> places;
+        places.reserve(nodes.size());
         for (const auto& [start, gn] : nodes) {
-            Node n;
-            n.start = start;
-            n.gn = &gn;
+            size_t mine = SIZE_MAX;
             if (gn.hap_gt.size() != 1) {
                 if (v + 1 >= g.node_off.size()) throw std::runtime_error("graph index: node list shorter than the graph");
-                n.kmers.assign(g.node_key_index.begin() + g.node_off[v], g.node_key_index.begin() + g.node_off[v + 1]);
-                ++v;
+                mine = v++;
             }
-            c.nodes.push_back(std::move(n));
+            places.push_back({start, &gn, mine});
         }
+        c.nodes.resize(places.size());
+        auto fill = [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                Node& n = c.nodes[i];
+                n.start = places[i].start;
+                n.gn = places[i].gn;
+                if (places[i].v != SIZE_MAX)
+                    n.kmers.assign(g.node_key_index.begin() + g.node_off[places[i].v], g.node_key_index.begin() + g.node_off[places[i].v + 1]);
+            }
+        };
+        const size_t nt = std::max<size_t>(1, std::min<size_t>(threads, places.size() / 4096 + 1));
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nt; ++t) pool.emplace_back(fill, places.size() * t / nt, places.size() * (t + 1) / nt);
+        fill(0, places.size() / nt);
+        for (auto& th : pool) th.join();
         chroms_.push_back(std::move(c));
     }
 }

@@ -37,7 +37,7 @@ struct GenotypeConfig {           // defaults: include/varigraph.hpp:49-68
 
 class Genotyper {
 public:
-    explicit Genotyper(const GraphIndex& g);
+    explicit Genotyper(const GraphIndex& g, unsigned threads = 1);   // threads: workers that copy the nodes' k-mer lists
 
     // cov: c of every key in graph.bin record order (g.keys).  Returns the decompressed content of
     // <sample>.varigraph.vcf.gz.  Throws std::runtime_error where the reference prints and exits.

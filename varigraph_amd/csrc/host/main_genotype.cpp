@@ -304,7 +304,9 @@ int main_genotype(int argc, char** argv)
     std::atomic<unsigned> consumer_no{0};
     auto consumer = [&] {
         try {
-            vgh::Genotyper genotyper(g);
+            const double tc0 = secs();
+            vgh::Genotyper genotyper(g, hmm_cfg.threads);
+            const double tc1 = secs();
             // the HMM's recursion and posterior run on the device, through a context of their own (its stream and buffers are
             // not the counting's); VGH_HMM_DEVICE=0 keeps them on the host
             struct OwnCtx {
@@ -321,6 +323,8 @@ int main_genotype(int argc, char** argv)
                     genotyper.set_device(own.c, (unsigned)std::max<size_t>(1, 4 / std::max<size_t>(1, on_dev)));
                 }
             }
+            if (getenv("VGH_TIMING"))
+                std::fprintf(stderr, "[varigraph-mi] consumer: genotyper set up from %.2f to %.2f s, device context by %.2f s\n", tc0, tc1, secs());
             for (;;) {
                 const size_t s = next_hmm.fetch_add(1);
                 if (s >= samples.size()) return;
@@ -388,7 +392,9 @@ int main_genotype(int argc, char** argv)
     counter(0);
     for (auto& t : counters) t.join();
     for (auto& t : hmm_threads) t.join();
+    const double t_joined = secs();
     for (vgmi_ctx* ctx : ctxs) vgmi_destroy(ctx);
+    if (getenv("VGH_TIMING")) std::fprintf(stderr, "[varigraph-mi] last sample written at %.2f s, devices released by %.2f s\n", t_joined, secs());
     std::fprintf(stderr, "[varigraph-mi] done in %.2f s\n", secs());
     // every output file is closed and the devices are released: skip taking the graph (1e7s of small allocations) apart
     std::fflush(nullptr);
