@@ -305,3 +305,29 @@ def test_native_cli_block_gzip_and_plain_inputs(tmp_path):
     want = open(os.path.join(d, "expected_het.vcf"), "rb").read() if os.path.exists(os.path.join(d, "expected_het.vcf")) else None
     if want is not None:
         assert _strip_gq(vcfs["gz"]) == _strip_gq(want)
+
+
+def test_native_cli_hmm_on_the_device_in_parts_equals_the_host_hmm(tmp_path):
+    """The same sample with the HMM's recursion and posterior on the device (the default: the windows go to the device in
+    parts as they are prepared -- twenty windows of 5 kb here, four parts) and on the host (VGH_HMM_DEVICE=0): identical VCF bytes, and
+    the log shows which one ran."""
+    if not os.path.exists(CLI):
+        pytest.skip("varigraph-mi not built")
+    d = os.path.join(GOLDEN, "cohort_sv")
+    graph = tmp_path / "graph.bin"
+    graph.write_bytes(gzip.open(os.path.join(d, "graph.bin.gz"), "rb").read())
+    fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
+    out = {}
+    for name, knob in (("device", {}), ("host", {"VGH_HMM_DEVICE": "0"})):
+        w = tmp_path / name
+        w.mkdir()
+        (w / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
+        env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022", VGH_TIMING="1", **knob)
+        r = _run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4", "--gpu", "0", "--granularity", "0.005"],
+                 cwd=w, capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[name] = (gzip.open(w / "sample0.varigraph.vcf.gz", "rb").read(), r.stderr)
+    assert out["device"][0] == out["host"][0] and out["device"][0].count(b"\n") > 50
+    parts = [ln for ln in out["device"][1].split("\n") if "HMM part" in ln]
+    assert len(parts) == 4, out["device"][1][-1500:]
+    assert "HMM part" not in out["host"][1]
