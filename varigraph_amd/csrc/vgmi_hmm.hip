@@ -250,10 +250,30 @@ size_t hmm_lds_bytes(uint32_t n_gt, uint32_t ploidy)
 hipError_t launch_hmm_recursion(const HmmParams& P, uint32_t n_chains, hipStream_t st)
 {
     if (n_chains == 0) return hipSuccess;
-    const size_t lds = hmm_lds_bytes(P.n_gt, P.ploidy);
+    size_t lds = hmm_lds_bytes(P.n_gt, P.ploidy);
+    // A small launch asks for more than half a CU's LDS: its workgroups then have a CU each.  The parts of a sample are
+    // launches of a few dozen chains on streams of their own; the dispatcher starts each at the same CUs, and chains that
+    // share a SIMD wait for each other's instructions (measured: 450 instead of 400 ms for the later parts).
+    const size_t alone = 84 * 1024;
+    const bool spread = n_chains <= 64 && lds < alone;
+    if (spread) lds = alone;
     HmmParams Q = P;
     const char* dbg = getenv("VGMI_DBG");
     Q.dbg = dbg ? (uint32_t)atoi(dbg) : 0u;
+    if (spread) {
+        hipError_t e = hipSuccess;
+        switch (P.ploidy) {
+            case 1: e = hipFuncSetAttribute(reinterpret_cast<const void*>(hmm_recursion_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
+            case 2: e = hipFuncSetAttribute(reinterpret_cast<const void*>(hmm_recursion_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
+            case 3: e = hipFuncSetAttribute(reinterpret_cast<const void*>(hmm_recursion_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
+            case 4: e = hipFuncSetAttribute(reinterpret_cast<const void*>(hmm_recursion_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
+            default: break;
+        }
+        if (e != hipSuccess) {      // not granted: the plain launch
+            (void)hipGetLastError();
+            lds = hmm_lds_bytes(P.n_gt, P.ploidy);
+        }
+    }
     switch (P.ploidy) {
         case 1: hipLaunchKernelGGL(hmm_recursion_kernel<2>, dim3(n_chains), dim3(128), lds, st, Q); break;
         case 2: hipLaunchKernelGGL(hmm_recursion_kernel<3>, dim3(n_chains), dim3(128), lds, st, Q); break;
