@@ -36,8 +36,10 @@ def _host_chain(keep, obs_rows, restart, pows, uniform, ploidy):
     return out
 
 
-@pytest.mark.parametrize("ploidy,n_hap", [(2, 15), (2, 5), (1, 9), (3, 6), (4, 5)])
-def test_recursion_equals_x87(ploidy, n_hap):
+@pytest.mark.parametrize("ploidy,n_hap,waves", [(2, 15, 4), (2, 15, 2), (2, 5, 4), (1, 9, 2), (3, 6, 4), (4, 5, 2)])
+def test_recursion_equals_x87(ploidy, n_hap, waves, monkeypatch):
+    """waves: the kernel with four wavefronts per chain (what a launch of few chains gets) or two (a launch of many)."""
+    monkeypatch.setenv("VGMI_HMM_WAVES", str(waves))
     assert np.finfo(LD).nmant == 63, "numpy.longdouble is not the x87 format here"
     rng = np.random.default_rng(ploidy * 100 + n_hap)
     genotypes = list(itertools.combinations_with_replacement(range(n_hap), ploidy))[:128]

@@ -27,13 +27,17 @@ struct HmmStepIn {
     uint32_t restart;
 };
 
-template <uint32_t STRIDE>
-__global__ __launch_bounds__(128) void hmm_recursion_kernel(HmmParams P)
+// WAVES wavefronts share the genotypes evenly (2: a throughput launch; 4: a launch of few chains that has a CU per workgroup
+// anyway -- the fewer genotypes a wavefront holds, the more often all of them agree that a term is negligible, and the idle
+// SIMDs cost nothing: 392 instead of 405 ms on a chr20-scale sample; 8, two per SIMD, 455 ms)
+template <uint32_t STRIDE, uint32_t WAVES>
+__global__ __launch_bounds__(64 * WAVES) void hmm_recursion_kernel(HmmParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t hmm_smem[];
     constexpr uint32_t stride = STRIDE;
-    const uint32_t n = P.n_gt, g = threadIdx.x;
-    const bool active = g < n;
+    const uint32_t n = P.n_gt, per_wave = (n + WAVES - 1) / WAVES, lane = threadIdx.x & 63u;
+    const bool active = lane < per_wave && (threadIdx.x >> 6) * per_wave + lane < n;
+    const uint32_t g = active ? (threadIdx.x >> 6) * per_wave + lane : 0u;      // an idle lane reads genotype 0's inputs and writes nothing
     uint8_t* const s_keep = hmm_smem;                                              // n * n
     uint64_t* const s_step_m = reinterpret_cast<uint64_t*>(hmm_smem + ((n * n + 15u) & ~15u));   // 128 * stride
     int32_t* const s_step_e = reinterpret_cast<int32_t*>(s_step_m + 128u * stride);
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(128) void hmm_recursion_kernel(HmmParams P)
 
     const HmmChain ch = P.chains[blockIdx.x];
     const uint8_t* keep_g = P.keep + (size_t)ch.keep_index * n * n;
-    for (uint32_t i = g; i < n * n; i += blockDim.x) s_keep[i] = keep_g[i];
+    for (uint32_t i = threadIdx.x; i < n * n; i += blockDim.x) s_keep[i] = keep_g[i];
     __syncthreads();
     const uint8_t* const my_keep = s_keep + (size_t)g * n;
     const VgX80 uniform = x80_load(P.uniform);
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(128) void hmm_recursion_kernel(HmmParams P)
             in.keep_pow[k] = x80_load(pw + (size_t)k * 16);
             in.change_pow[k] = x80_load(pw + (size_t)(stride + (stride - 1 - k)) * 16);
         }
-        in.obs = x80_load(P.obs + ((size_t)row_s * n + (active ? g : 0u)) * 16);
+        in.obs = x80_load(P.obs + ((size_t)row_s * n + g) * 16);
         in.restart = P.restart[s + lane_zero];
     };
     const uint64_t s_end = ch.first_step + ch.n_steps;
@@ -82,8 +86,10 @@ __global__ __launch_bounds__(128) void hmm_recursion_kernel(HmmParams P)
             // (prev * no_recomb^keep) * recomb^change for this lane's previous entry and every keep
             for (uint32_t k = 0; k < stride; ++k) {
                 const VgN80 st = n80_mul(n80_mul(prev, n80_from(cur.keep_pow[k])), n80_from(cur.change_pow[k]));
-                s_step_m[g * stride + k] = st.m;
-                s_step_e[g * stride + k] = st.e;
+                if (active) {
+                    s_step_m[g * stride + k] = st.m;
+                    s_step_e[g * stride + k] = st.e;
+                }
             }
         }
         __syncthreads();
@@ -116,8 +122,10 @@ __global__ __launch_bounds__(128) void hmm_recursion_kernel(HmmParams P)
                 }
             }
         }
-        s_r_m[g] = r.m;
-        s_r_e[g] = r.e;
+        if (active) {
+            s_r_m[g] = r.m;
+            s_r_e[g] = r.e;
+        }
         __syncthreads();
         VgN80 total = {0, 0};
         VgN80 tn;
@@ -247,41 +255,51 @@ size_t hmm_lds_bytes(uint32_t n_gt, uint32_t ploidy)
     return (((size_t)n_gt * n_gt + 15u) & ~(size_t)15u) + (size_t)128 * stride * 12 + (size_t)128 * 12 + 64;
 }
 
+namespace {
+template <uint32_t STRIDE, uint32_t WAVES>
+hipError_t launch_recursion_as(const HmmParams& Q, uint32_t n_chains, size_t lds, size_t plain_lds, hipStream_t st)
+{
+    if (lds > plain_lds &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(hmm_recursion_kernel<STRIDE, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+        (void)hipGetLastError();    // not granted: the plain launch
+        lds = plain_lds;
+    }
+    hipLaunchKernelGGL((hmm_recursion_kernel<STRIDE, WAVES>), dim3(n_chains), dim3(64 * WAVES), lds, st, Q);
+    return hipGetLastError();
+}
+template <uint32_t STRIDE>
+hipError_t launch_recursion_waves(uint32_t waves, const HmmParams& Q, uint32_t n_chains, size_t lds, size_t plain_lds, hipStream_t st)
+{
+    switch (waves) {
+        case 4: return launch_recursion_as<STRIDE, 4>(Q, n_chains, lds, plain_lds, st);
+        default: return launch_recursion_as<STRIDE, 2>(Q, n_chains, lds, plain_lds, st);
+    }
+}
+}  // namespace
+
 hipError_t launch_hmm_recursion(const HmmParams& P, uint32_t n_chains, hipStream_t st)
 {
     if (n_chains == 0) return hipSuccess;
-    size_t lds = hmm_lds_bytes(P.n_gt, P.ploidy);
+    const size_t plain_lds = hmm_lds_bytes(P.n_gt, P.ploidy);
     // A small launch asks for more than half a CU's LDS: its workgroups then have a CU each.  The parts of a sample are
     // launches of a few dozen chains on streams of their own; the dispatcher starts each at the same CUs, and chains that
     // share a SIMD wait for each other's instructions (measured: 450 instead of 400 ms for the later parts).
     const size_t alone = 84 * 1024;
-    const bool spread = n_chains <= 64 && lds < alone;
-    if (spread) lds = alone;
+    const bool spread = n_chains <= 64 && plain_lds < alone;
+    const size_t lds = spread ? alone : plain_lds;
+    uint32_t waves = spread ? 4u : 2u;
+    if (const char* w = getenv("VGMI_HMM_WAVES")) waves = atoi(w) == 4 ? 4u : 2u;     // A/B
     HmmParams Q = P;
     const char* dbg = getenv("VGMI_DBG");
     Q.dbg = dbg ? (uint32_t)atoi(dbg) : 0u;
-    if (spread) {
-        hipError_t e = hipSuccess;
-        switch (P.ploidy) {
-            case 1: e = hipFuncSetAttribute(reinterpret_cast<const void*>(hmm_recursion_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
-            case 2: e = hipFuncSetAttribute(reinterpret_cast<const void*>(hmm_recursion_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
-            case 3: e = hipFuncSetAttribute(reinterpret_cast<const void*>(hmm_recursion_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
-            case 4: e = hipFuncSetAttribute(reinterpret_cast<const void*>(hmm_recursion_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
-            default: break;
-        }
-        if (e != hipSuccess) {      // not granted: the plain launch
-            (void)hipGetLastError();
-            lds = hmm_lds_bytes(P.n_gt, P.ploidy);
-        }
-    }
     switch (P.ploidy) {
-        case 1: hipLaunchKernelGGL(hmm_recursion_kernel<2>, dim3(n_chains), dim3(128), lds, st, Q); break;
-        case 2: hipLaunchKernelGGL(hmm_recursion_kernel<3>, dim3(n_chains), dim3(128), lds, st, Q); break;
-        case 3: hipLaunchKernelGGL(hmm_recursion_kernel<4>, dim3(n_chains), dim3(128), lds, st, Q); break;
-        case 4: hipLaunchKernelGGL(hmm_recursion_kernel<5>, dim3(n_chains), dim3(128), lds, st, Q); break;
+        case 1: return launch_recursion_waves<2>(waves, Q, n_chains, lds, plain_lds, st);
+        case 2: return launch_recursion_waves<3>(waves, Q, n_chains, lds, plain_lds, st);
+        case 3: return launch_recursion_waves<4>(waves, Q, n_chains, lds, plain_lds, st);
+        case 4: return launch_recursion_waves<5>(waves, Q, n_chains, lds, plain_lds, st);
         default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 }  // namespace vgk
