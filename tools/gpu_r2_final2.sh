@@ -6,7 +6,7 @@ timeout 900 python tools/bench_chunk.py 8000000 64,100,256 > $OUT/bench_chunk.js
 VGH_TIMING=1 timeout 2000 python tools/bench_e2e.py --native-only --genome 60000000 --variants 500000 --pairs 6000000 --threads 10 > $OUT/e2e_chr20_native.json 2> $OUT/e2e.err
 VGH_TIMING=1 timeout 2000 python tools/bench_e2e.py --native-only --genome 60000000 --variants 500000 --pairs 6000000 --threads 10 --gz > $OUT/e2e_chr20_native_gz.json 2>> $OUT/e2e.err
 timeout 900 python tools/bench_hmm.py 1000 > $OUT/bench_hmm.json 2>> $OUT/e2e.err
-for cfgs in "10 0" "10 0,0" "16 0,0" "16 0,0,0,0"; do set -- $cfgs; timeout 1500 python tools/bench_e2e.py --native-only --genome 60000000 --variants 500000 --pairs 6000000 --threads $1 --samples 8 --gpus $2 >> $OUT/e2e_chr20_8samples.jsonl 2>> $OUT/e2e.err; done
+for cfgs in "10 0" "16 0" "16 0,0,0,0"; do set -- $cfgs; timeout 1500 python tools/bench_e2e.py --native-only --genome 60000000 --variants 500000 --pairs 6000000 --threads $1 --samples 8 --gpus $2 >> $OUT/e2e_chr20_8samples.jsonl 2>> $OUT/e2e.err; done
 VGH_HMM_DEVICE=0 timeout 1500 python tools/bench_e2e.py --native-only --genome 60000000 --variants 500000 --pairs 6000000 --threads 16 --samples 8 --gpus 0,0,0,0 >> $OUT/e2e_chr20_8samples.jsonl 2>> $OUT/e2e.err
 cat $OUT/bench_chunk.jsonl; cat $OUT/bench_hmm.json; python3 -c "
 import json

@@ -284,9 +284,14 @@ int main_genotype(int argc, char** argv)
     // The HMM prunes a node's k-mer list to the k-mers some selected haplotype carries and the pruned list stays for
     // the next sample (genotype.cpp:815-818), so samples must be genotyped in order by one consumer -- unless nothing
     // can be pruned: every haplotype is selected (-n >= #haplotypes) and every k-mer is carried by one.  Then the
-    // samples are independent and one consumer per device runs them side by side, each on its own Genotyper.
+    // samples are independent and the consumers (one per device, two on a single one) run them side by side, each on its own
+    // Genotyper.
+    // With the HMM's recursion on the device a consumer's threads idle while its chains run (a chain is latency, §4.8 of
+    // DESIGN.md): two consumers share one device's worth of samples, each with half the threads.
+    const bool device_hmm = [] { const char* e = getenv("VGH_HMM_DEVICE"); return !(e && e[0] == '0'); }();
+    const size_t want_consumers = std::max<size_t>(1, std::min(samples.size(), std::max<size_t>(ctxs.size(), device_hmm ? 2 : 1)));
     bool independent = g.hap_names.size() <= o.hmm.haploid_num;
-    if (independent && ctxs.size() > 1) {
+    if (independent && want_consumers > 1) {
         const size_t bl = g.bitlen, n_hap = g.hap_names.size();
         for (size_t r = 0; r < g.keys.size() && independent; ++r) {
             bool any = false;
@@ -294,7 +299,7 @@ int main_genotype(int argc, char** argv)
             independent = any;
         }
     }
-    const size_t n_consumers = independent ? std::max<size_t>(1, std::min(ctxs.size(), samples.size())) : 1;
+    const size_t n_consumers = independent ? want_consumers : 1;
     // -t is the budget of the whole run: counting threads (inflate workers) and HMM consumers that run side by side
     // share it instead of each taking all of it
     const unsigned count_threads = std::max<unsigned>(1, o.hmm.threads / (unsigned)std::max<size_t>(1, std::min(ctxs.size(), samples.size())));
