@@ -266,9 +266,10 @@ int main_genotype(int argc, char** argv)
               << " haplotypes (" << secs() << " s)" << std::endl;
 
     // Two stages.  Counting: one thread per device takes the next sample of the `-s` list (samples are independent
-    // units).  Genotyping: ONE consumer, strictly in `-s` order -- the HMM keeps state across samples (the
+    // units).  Genotyping: one consumer, strictly in `-s` order, when the HMM keeps state across samples (the
     // pruned node lists), exactly like Varigraph::fastq_genotype (src/varigraph.cpp:148-171), which runs the two
-    // stages back to back; here the counting of later samples overlaps the HMM of earlier ones.
+    // stages back to back -- several consumers when it does not (below); either way the counting of later samples
+    // overlaps the HMM of earlier ones.
     struct Job {
         std::string name;
         std::vector<uint8_t> cov;
