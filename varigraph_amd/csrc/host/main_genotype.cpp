@@ -290,7 +290,10 @@ int main_genotype(int argc, char** argv)
     // With the HMM's recursion on the device a consumer's threads idle while its chains run (a chain is latency, §4.8 of
     // DESIGN.md): two consumers share one device's worth of samples, each with half the threads.
     const bool device_hmm = [] { const char* e = getenv("VGH_HMM_DEVICE"); return !(e && e[0] == '0'); }();
-    const size_t want_consumers = std::max<size_t>(1, std::min(samples.size(), std::max<size_t>(ctxs.size(), device_hmm ? 2 : 1)));
+    // (a consumer holds the nodes' k-mer lists and a packed word per k-mer of its own: 12 bytes per k-mer -- not doubled for a
+    // graph of more than 2^29 k-mers)
+    const bool second_consumer = device_hmm && g.keys.size() < ((size_t)1 << 29);
+    const size_t want_consumers = std::max<size_t>(1, std::min(samples.size(), std::max<size_t>(ctxs.size(), second_consumer ? 2 : 1)));
     bool independent = g.hap_names.size() <= o.hmm.haploid_num;
     if (independent && want_consumers > 1) {
         const size_t bl = g.bitlen, n_hap = g.hap_names.size();
