@@ -1396,6 +1396,53 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
     }
     const bool device_ready = raw_obs.p != nullptr;
     const uint32_t n_threads = std::max(1u, std::min<uint32_t>(cfg.threads, (uint32_t)tasks.size()));
+    // ---- VCF (src/genotype.cpp:1579-1696): sites in vcf_info order, only those with a non-reference call.  The
+    // reference walks mVcfInfoMap (chromosome, then position) and looks every site up in the graph; the windows are the
+    // same nodes in the same order, so every task writes the lines of its own nodes and the pieces are joined in task
+    // order (chromosomes of the graph that the VCF lacks have thrown in window() already).  A window's lines are written
+    // as soon as its calls are known -- for most windows while the last chains are still on the device.
+    std::vector<std::string> pieces(tasks.size());
+    std::vector<uint8_t> piece_done(tasks.size(), 0);
+    auto make_piece = [&](size_t t) {
+        piece_done[t] = 1;
+        std::ostringstream oss;
+        oss << std::fixed << std::setprecision(1);
+        {
+            const Chrom& chr = *tasks[t].chr;
+            auto vc = g_.vcf_info.find(chr.name);
+            if (vc == g_.vcf_info.end()) return;
+            const auto& sites = vc->second;
+            oss.str(std::string());
+            for (uint32_t ni = tasks[t].first; ni < tasks[t].last; ++ni) {
+                const Node& node = chr.nodes[ni];
+                const SiteCall& call = node.call;
+                if (call.haps.empty()) continue;
+                auto site = sites.find(node.start);
+                if (site == sites.end()) continue;
+                const auto& fields = site->second;
+                std::vector<std::string> gt;
+                for (uint16_t hap : call.haps) gt.push_back(std::to_string(node.gn->hap_gt[hap]));
+                if (std::all_of(gt.begin(), gt.end(), [](const std::string& c) { return c == "0" || c == "."; })) continue;
+                for (size_t i = 0; i < 9; i++) {
+                    if (i == 0) oss << fields[i];
+                    else if (i == 6) oss << "\tPASS";
+                    else if (i < 8) oss << "\t" << fields[i];
+                    else oss << "\t" << "GT:GQ:GPP:NAK:CAK:UK";
+                }
+                const float gq = phred_scaled(call.probability);
+                if (gq < cfg.min_gq) std::fill(gt.begin(), gt.end(), ".");
+                oss << "\t";
+                for (size_t i = 0; i < gt.size(); ++i) oss << (i ? "/" : "") << gt[i];
+                oss << ":" << gq << ":" << call.probability << ":" << join_numbers(call.kmer_num, ",") << ":";
+                for (size_t i = 0; i < call.kmer_ave_cov.size(); i++) {
+                    if (i) oss << ",";
+                    oss << call.kmer_ave_cov[i];
+                }
+                oss << ":" << +call.unique_kmers << "\n";
+            }
+            pieces[t] = oss.str();
+        }
+    };
     // ---- three kinds of work on one pool: a window is prepared (window()), the recursion and posterior of a PART of the
     // windows run on the device (one call per part, on a thread of its own that mostly waits), the calls of a part's windows
     // are written back (window_finish()).  A chain is serial from its first node to its last, so the device takes as long
@@ -1492,6 +1539,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
             try {
                 WindowWork& w = works[t];
                 window_finish(w, static_cast<const long double*>(raw_prob.p) + w.row0, static_cast<const uint32_t*>(raw_win.p) + w.row0, r);
+                make_piece(t);
             } catch (const std::exception& e) {
                 fail_with(e.what());
                 return;
@@ -1515,54 +1563,16 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
         if (last_device_seconds > 0) std::fprintf(stderr, "[varigraph-mi] HMM recursion on the device: %.2f s\n", last_device_seconds);
     }
 
-    // ---- VCF (src/genotype.cpp:1579-1696): sites in vcf_info order, only those with a non-reference call.  The
-    // reference walks mVcfInfoMap (chromosome, then position) and looks every site up in the graph; the windows are the
-    // same nodes in the same order, so every task writes the lines of its own nodes and the pieces are joined in task
-    // order (chromosomes of the graph that the VCF lacks have thrown in window() already).
-    std::vector<std::string> pieces(tasks.size());
-    std::atomic<size_t> next_text{0};
-    auto text_worker = [&]() {
-        std::ostringstream oss;
-        oss << std::fixed << std::setprecision(1);
-        for (;;) {
-            const size_t t = next_text.fetch_add(1);
-            if (t >= tasks.size()) return;
-            const Chrom& chr = *tasks[t].chr;
-            auto vc = g_.vcf_info.find(chr.name);
-            if (vc == g_.vcf_info.end()) continue;
-            const auto& sites = vc->second;
-            oss.str(std::string());
-            for (uint32_t ni = tasks[t].first; ni < tasks[t].last; ++ni) {
-                const Node& node = chr.nodes[ni];
-                const SiteCall& call = node.call;
-                if (call.haps.empty()) continue;
-                auto site = sites.find(node.start);
-                if (site == sites.end()) continue;
-                const auto& fields = site->second;
-                std::vector<std::string> gt;
-                for (uint16_t hap : call.haps) gt.push_back(std::to_string(node.gn->hap_gt[hap]));
-                if (std::all_of(gt.begin(), gt.end(), [](const std::string& c) { return c == "0" || c == "."; })) continue;
-                for (size_t i = 0; i < 9; i++) {
-                    if (i == 0) oss << fields[i];
-                    else if (i == 6) oss << "\tPASS";
-                    else if (i < 8) oss << "\t" << fields[i];
-                    else oss << "\t" << "GT:GQ:GPP:NAK:CAK:UK";
-                }
-                const float gq = phred_scaled(call.probability);
-                if (gq < cfg.min_gq) std::fill(gt.begin(), gt.end(), ".");
-                oss << "\t";
-                for (size_t i = 0; i < gt.size(); ++i) oss << (i ? "/" : "") << gt[i];
-                oss << ":" << gq << ":" << call.probability << ":" << join_numbers(call.kmer_num, ",") << ":";
-                for (size_t i = 0; i < call.kmer_ave_cov.size(); i++) {
-                    if (i) oss << ",";
-                    oss << call.kmer_ave_cov[i];
-                }
-                oss << ":" << +call.unique_kmers << "\n";
-            }
-            pieces[t] = oss.str();
-        }
-    };
+    // ---- the pieces that are not written yet (windows without a device call), then the whole text
     {
+        std::atomic<size_t> next_text{0};
+        auto text_worker = [&]() {
+            for (;;) {
+                const size_t t = next_text.fetch_add(1);
+                if (t >= tasks.size()) return;
+                if (!piece_done[t]) make_piece(t);
+            }
+        };
         std::vector<std::thread> tpool;
         for (uint32_t t = 1; t < n_threads; ++t) tpool.emplace_back(text_worker);
         text_worker();
