@@ -318,7 +318,7 @@ def test_native_cli_hmm_on_the_device_in_parts_equals_the_host_hmm(tmp_path):
     graph.write_bytes(gzip.open(os.path.join(d, "graph.bin.gz"), "rb").read())
     fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
     out = {}
-    for name, knob in (("device", {}), ("host", {"VGH_HMM_DEVICE": "0"})):
+    for name, knob in (("device", {}), ("host", {"VGH_HMM_DEVICE": "0"}), ("bound", {"VGH_HMM_DEVICE_GIB": "0"})):
         w = tmp_path / name
         w.mkdir()
         (w / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
@@ -331,3 +331,5 @@ def test_native_cli_hmm_on_the_device_in_parts_equals_the_host_hmm(tmp_path):
     parts = [ln for ln in out["device"][1].split("\n") if "HMM part" in ln]
     assert len(parts) == 4, out["device"][1][-1500:]
     assert "HMM part" not in out["host"][1]
+    # a sample whose scores exceed the bound stays on the host
+    assert out["bound"][0] == out["host"][0] and "HMM part" not in out["bound"][1]

@@ -1362,8 +1362,12 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
             works[t].step0 = 2 * total_room;
             total_room += room;
         }
-        // (the emission scores of all windows are held at once: beyond 6 GiB the host runs the recursion as before)
-        if (dev_n_gt >= 1 && dev_n_gt <= 128 && total_room && total_room * dev_n_gt * sizeof(long double) <= ((size_t)6 << 30)) {
+        // (the emission scores of all windows are held at once, on the host and -- with alpha and beta, three times that -- on
+        // the device: beyond 16 GiB, a genome's worth of sites at 120 genotypes, the host runs the recursion as before;
+        // VGH_HMM_DEVICE_GIB moves the bound)
+        size_t score_gib = 16;
+        if (const char* e = getenv("VGH_HMM_DEVICE_GIB")) score_gib = (size_t)std::max(0L, atol(e));
+        if (dev_n_gt >= 1 && dev_n_gt <= 128 && total_room && total_room * dev_n_gt * sizeof(long double) <= (score_gib << 30)) {
             raw_obs.p = std::malloc(total_room * dev_n_gt * sizeof(long double));
             raw_pw.p = std::malloc(2 * total_room * 2 * dev_stride * sizeof(long double));
             raw_row.p = std::calloc(2 * total_room, sizeof(uint32_t));
