@@ -11,6 +11,9 @@
 //   x80_add   the smaller operand aligned into 128 bits with a sticky bit, one rounding
 //   x80_div   128 / 64 restoring division of the significands, guard and sticky from the remainder, one rounding
 //
+//   n80_*     the same three on values kept normalised (VgN80) along a chain of operations, n80_muladd / n80_sum the
+//             branch-free forms the device recursion runs (vgmi_hmm.hip); the general functions remain their fallback
+//
 // tests/native/x80_check.cpp holds each against the x87 unit on tens of millions of random and edge operands.
 #ifndef VG_X80_H
 #define VG_X80_H
