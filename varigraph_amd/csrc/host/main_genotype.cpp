@@ -293,7 +293,9 @@ int main_genotype(int argc, char** argv)
     // (a consumer holds the nodes' k-mer lists and a packed word per k-mer of its own: 12 bytes per k-mer -- not doubled for a
     // graph of more than 2^29 k-mers)
     const bool second_consumer = device_hmm && g.keys.size() < ((size_t)1 << 29);
-    const size_t want_consumers = std::max<size_t>(1, std::min(samples.size(), std::max<size_t>(ctxs.size(), second_consumer ? 2 : 1)));
+    size_t per_run = std::max<size_t>(ctxs.size(), second_consumer ? 2 : 1);
+    if (const char* e = getenv("VGH_HMM_CONSUMERS")) per_run = (size_t)std::max(1L, atol(e));      // A/B
+    const size_t want_consumers = std::max<size_t>(1, std::min(samples.size(), per_run));
     bool independent = g.hap_names.size() <= o.hmm.haploid_num;
     if (independent && want_consumers > 1) {
         const size_t bl = g.bitlen, n_hap = g.hap_names.size();
