@@ -226,7 +226,8 @@ def test_bgzf_inflated_on_the_device(level, block, graph_ctx, tmp_path):
     assert np.array_equal(host_inflate["cov"], want["cov"])
 
 
-@pytest.mark.parametrize("damage", ["flip_in_third_member", "truncated_mid_member", "gzip_member_after_bgzf", "crc_field", "no_eof_marker"])
+@pytest.mark.parametrize("damage", ["flip_in_third_member", "truncated_mid_member", "gzip_member_after_bgzf", "crc_field", "no_eof_marker",
+                                    "fastq_text_behind_last_member", "short_garbage_behind_last_member"])
 def test_bgzf_damage_and_mixtures_equal_the_host_decoder(damage, graph_ctx, tmp_path):
     """What the device cannot vouch for goes to the host decoder at the right byte: same counters as the all-host path
     (which delivers what decoded cleanly before the damage, like the reference's gzread loop)."""
@@ -251,6 +252,12 @@ def test_bgzf_damage_and_mixtures_equal_the_host_decoder(damage, graph_ctx, tmp_
         raw[offs[2] - 8] ^= 1
     elif damage == "no_eof_marker":
         raw = raw[: offs[-1]]
+    elif damage == "fastq_text_behind_last_member":
+        # bytes behind the last member that are no gzip header: gzread (and the host block-gzip source) ignore them; handed
+        # to a parser as text they would be a read (ByteSource::open_at went transparent at an offset)
+        raw = raw + b"\n@x\n" + rd[0][:60] + b"\n+\n" + b"I" * 60 + b"\n"
+    elif damage == "short_garbage_behind_last_member":
+        raw = raw + b"@x\nACGT\n+\nII"
     q = tmp_path / "dmg.fq.gz"
     q.write_bytes(bytes(raw))
     want = _count_env(g, ctx, [str(q)], {"VGH_HOST_PARSE": "1"})

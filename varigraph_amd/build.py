@@ -35,12 +35,15 @@ def _hipcc():
 
 def build_vgmi(force=False, verbose=False):
     srcs = [os.path.join(CSRC, f) for f in ("vgmi_kernels.hip", "vgmi_xtable.hip", "vgmi_fastq.hip", "vgmi_inflate.hip", "vgmi_hmm.hip", "vgmi_api.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("vgmi_kernels.h", "vgmi_device.h", "vgmi_xtable.h", "vg_synth.h")] + [
+    # every header and source of csrc/ (vg_x80.h defines the HMM kernels' arithmetic: editing it must rebuild the library)
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp"))) + [
         os.path.join(ROOT, "include", "vgmi.h")]
     if not force and not _newer(LIB, deps):
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
            "-Wno-unused-function", *srcs, "-o", LIB]
+    if os.environ.get("VGMI_ABLATION") == "1":   # profiling builds only: the VGMI_DBG ablations (wrong results on purpose)
+        cmd.insert(1, "-DVGMI_ABLATION")
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=ROOT)

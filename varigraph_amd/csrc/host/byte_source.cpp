@@ -546,7 +546,14 @@ std::unique_ptr<ByteSource> ByteSource::open_at(const std::string& path, uint64_
     unsigned char head[64];
     const size_t n = in->read(head, sizeof head);
     in->unread(head, n);
-    if (n < 2 || head[0] != 0x1f || head[1] != 0x8b) return std::make_unique<PlainSource>(std::move(in));
+    if (n < 2 || head[0] != 0x1f || head[1] != 0x8b) {
+        // Transparent (plain text) mode exists at the START of a file only.  At an offset the caller continues a compressed
+        // stream (the device took the block-gzip members in front): bytes there that are no gzip header are trailing
+        // garbage, which gzread -- and BgzfSource / GzipSource above a whole file -- ignore.  Delivering them as text would
+        // turn garbage holding '@' or '>' into reads.
+        if (offset > 0) return from_memory(nullptr, 0);
+        return std::make_unique<PlainSource>(std::move(in));
+    }
     if (parse_bgzf_extra(head, n).is_bgzf) return std::make_unique<BgzfSource>(std::move(in), decode_threads);
     // an ordinary gzip file read from its start with threads to spare: several of them decode it (par_gunzip.hpp);
     // VGH_PAR_GUNZIP=0 keeps the one-thread decoder

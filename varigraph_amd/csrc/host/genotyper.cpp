@@ -708,7 +708,7 @@ void Genotyper::prefetch_keys(const Node& n, const Run& r) const
 
 
 // ---------------------------------------------------------------- one window: selection, forward, backward, posterior
-void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, WindowWork* work)
+void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, WindowWork* work, const std::vector<uint16_t>* forced_top)
 {
     const GenotypeConfig& cfg = *r.cfg;
     auto vcf_chr = g_.vcf_info.find(chr.name);
@@ -751,6 +751,7 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, 
     }
     HaplotypeSampler sampler(support, (int)r.haploid_num);
     if (top.empty()) top = sampler.top;
+    if (forced_top) top = *forced_top;
     std::sort(top.begin(), top.end());
     const std::unordered_map<uint16_t, double>& hap_score = sampler.score;
     t_select.reset();
@@ -1367,7 +1368,17 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
         // VGH_HMM_DEVICE_GIB moves the bound)
         size_t score_gib = 16;
         if (const char* e = getenv("VGH_HMM_DEVICE_GIB")) score_gib = (size_t)std::max(0L, atol(e));
-        if (dev_n_gt >= 1 && dev_n_gt <= 128 && total_room && total_room * dev_n_gt * sizeof(long double) <= (score_gib << 30)) {
+        // ... and what the device has free right now: a part holds its scores, alpha and beta (3 x its scores) until its calls are
+        // back, all parts of a sample may be in flight at once, and 4 / dev_parts_ samples share the device (set_device)
+        bool fits_device = true;
+        {
+            size_t free_b = 0, total_b = 0;
+            const size_t need = 3 * total_room * dev_n_gt * sizeof(long double) * ((4 + dev_parts_ - 1) / dev_parts_) + (size_t(1) << 30);
+            if (vgmi_device_memory(dev_, &free_b, &total_b) == VGMI_OK) fits_device = need <= free_b - free_b / 10;
+            if (!fits_device && g_phase_on)
+                std::fprintf(stderr, "[varigraph-mi] HMM on the host: %.1f GiB of device memory wanted, %.1f free\n", need / 1073741824.0, free_b / 1073741824.0);
+        }
+        if (fits_device && dev_n_gt >= 1 && dev_n_gt <= 128 && total_room && total_room * dev_n_gt * sizeof(long double) <= (score_gib << 30)) {
             raw_obs.p = std::malloc(total_room * dev_n_gt * sizeof(long double));
             raw_pw.p = std::malloc(2 * total_room * 2 * dev_stride * sizeof(long double));
             raw_row.p = std::calloc(2 * total_room, sizeof(uint32_t));
@@ -1495,11 +1506,23 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                 const uint64_t row_lo = works[t0].row0, row_hi = works[t1 - 1].row0 + works[t1 - 1].room;
                 const long double uniform = 1.0L / (long double)n;
                 const int64_t ta = since_begin();
-                if (vgmi_hmm_calls_part(dev_, (uint32_t)n, cfg.sample_ploidy, keep.data(), (uint32_t)dw.size(), raw_obs.p, row_lo, row_hi,
+                const int rc = vgmi_hmm_calls_part(dev_, (uint32_t)n, cfg.sample_ploidy, keep.data(), (uint32_t)dw.size(), raw_obs.p, row_lo, row_hi,
                                         static_cast<const uint32_t*>(raw_row.p), static_cast<const uint8_t*>(raw_restart.p), raw_pw.p, 2 * row_lo,
                                         2 * row_hi, &uniform, chains.data(), (uint32_t)chains.size(), static_cast<const uint8_t*>(raw_gid.p),
                                         static_cast<const uint8_t*>(raw_order.p), static_cast<const uint64_t*>(raw_fs.p),
-                                        static_cast<const uint64_t*>(raw_bs.p), raw_prob.p, static_cast<uint32_t*>(raw_win.p)) != VGMI_OK)
+                                        static_cast<const uint64_t*>(raw_bs.p), raw_prob.p, static_cast<uint32_t*>(raw_win.p));
+                if (rc == VGMI_E_NOMEM || (rc == VGMI_OK && getenv("VGH_HMM_FAKE_NOMEM") && part % 2 == 1)) {
+                    // the device had no room for this part after all (other samples' parts, the table, the read buffers): the
+                    // host runs these windows' recursion instead, with the haplotypes the first pass drew -- the sample is
+                    // not lost, only slower
+                    if (g_phase_on) std::fprintf(stderr, "[varigraph-mi] HMM part %zu: no device memory, %zu windows back on the host\n", part, dw.size());
+                    for (size_t t : dw) {
+                        WindowWork& w = works[t];
+                        w.on_device = false;
+                        window(*tasks[t].chr, tasks[t].first, tasks[t].last, r, nullptr, &w.top);
+                    }
+                    dw.clear();
+                } else if (rc != VGMI_OK)
                     throw std::runtime_error(std::string("device HMM recursion: ") + vgmi_last_error(dev_));
                 const int64_t tb = since_begin();
                 if (g_phase_on)

@@ -102,7 +102,10 @@ private:
     struct Run;  // per-call constants
 
     struct WindowWork;   // what a window hands to the device recursion and gets back (genotyper.cpp)
-    void window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, WindowWork* work = nullptr);
+    // forced_top: the window's selected haplotypes as an earlier pass over the same window drew them (the host takes a window
+    // back from the device path: same haplotypes, same pruned k-mer lists, nothing is drawn again)
+    void window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, WindowWork* work = nullptr,
+                const std::vector<uint16_t>* forced_top = nullptr);
     void window_finish(WindowWork& w, const long double* prob, const uint32_t* winner, const Run& r);
     void genotype_strings(const Node& n, const std::vector<std::vector<uint16_t>>& genotypes, uint8_t* gid, uint8_t* order) const;
     NodeStates hidden_states(Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& top,

@@ -443,6 +443,26 @@ int xt_clamp_if_due(vgmi_ctx* c, size_t n_bytes, hipStream_t st)
     return VGMI_OK;
 }
 
+}  // namespace
+
+// the ablation knob: honoured by -DVGMI_ABLATION builds only; anywhere else a set VGMI_DBG is reported once and ignored
+uint32_t vgmi_dbg_env()
+{
+    static const uint32_t v = [] {
+        const char* d = getenv("VGMI_DBG");
+        const uint32_t x = d ? (uint32_t)atoi(d) : 0u;
+#ifdef VGMI_ABLATION
+        if (x) fprintf(stderr, "[vgmi] WARNING: VGMI_DBG=%u in an ablation build: counters and genotypes are WRONG on purpose\n", x);
+        return x;
+#else
+        if (x) fprintf(stderr, "[vgmi] VGMI_DBG=%u ignored: this library was built without -DVGMI_ABLATION\n", x);
+        return 0u;
+#endif
+    }();
+    return v;
+}
+
+namespace {
 RowParams row_params(vgmi_ctx* c, const char* d_bases, size_t n_bytes, uint32_t k)
 {
     RowParams p{};
@@ -452,7 +472,7 @@ RowParams row_params(vgmi_ctx* c, const char* d_bases, size_t n_bytes, uint32_t 
     p.status = c->d_status;
     p.table = c->tv;
     p.keys_out = nullptr;
-    if (const char* d = getenv("VGMI_DBG")) p.dbg = (uint32_t)atoi(d);
+    p.dbg = vgmi_dbg_env();
     p.bloom = c->bv;
     return p;
 }
@@ -1293,7 +1313,12 @@ int vgmi_fastq_commit_bgzf(vgmi_fastq* f, size_t n_bytes, size_t* taken, size_t*
     HIPCHK(c, hipSetDevice(c->device));
     if (!f->d_comp) {
         f->max_members = (uint32_t)(f->text_cap / 4096) + 1024;     // bgzip members compress 64 KiB each; tiny ones are rare
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_comp), f->cap + 64);
+        // 512 KiB of zeroed slack behind the staged bytes: inside one damaged DEFLATE block the decoder can run up to
+        // ~390 KB past its member before the per-block bound stops it (65 536 symbols x 48 bits); those reads must stay
+        // inside the allocation (and see zeros) whatever the last member of a full batch contains
+        constexpr size_t kCompSlack = 512u << 10;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_comp), f->cap + kCompSlack);
+        if (e == hipSuccess) e = hipMemsetAsync(f->d_comp + f->cap, 0, kCompSlack, f->stream);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_members), (size_t)f->max_members * sizeof(BgzfMember));
         for (int b = 0; b < 2 && e == hipSuccess; ++b)
             e = hipHostMalloc(reinterpret_cast<void**>(&f->h_members[b]), (size_t)f->max_members * sizeof(BgzfMember), hipHostMallocDefault);
@@ -1703,6 +1728,17 @@ int hmm_run(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, ui
     return VGMI_OK;
 }
 }  // namespace
+
+int vgmi_device_memory(vgmi_ctx* c, size_t* free_bytes, size_t* total_bytes)
+{
+    if (!c) return VGMI_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    HIPCHK(c, hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return VGMI_OK;
+}
 
 int vgmi_hmm_recursion(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, uint32_t n_windows, const void* obs,
                        uint64_t n_rows, const uint32_t* row, const uint8_t* restart, const void* pow, uint64_t n_steps,

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64 * WAVES) void hmm_recursion_kernel(HmmParams P)
         __syncthreads();
         VgN80 r = {0, 0};
         if (active) {
-            if (restart || (P.dbg & 2u)) {
+            if (restart || (VG_DBG(P.dbg) & 2u)) {
                 r = o;
             } else {
                 // the table entry of term p + 1 and the keep byte of term p + 2 are fetched while term p is computed: the
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64 * WAVES) void hmm_recursion_kernel(HmmParams P)
                     // operands' sum + 2); when that holds for every genotype of the wavefront -- past the entries that carry
                     // the previous node's weight it mostly does -- the term is not computed
                     const bool nothing = st.m == 0 || o.m == 0 || (r.m != 0 && r.e - (st.e + o.e - VG_X80_BIAS + 2) > 64);
-                    if (__builtin_amdgcn_ballot_w64(!nothing) == 0 && !(P.dbg & 8u)) continue;
+                    if (__builtin_amdgcn_ballot_w64(!nothing) == 0 && !(VG_DBG(P.dbg) & 8u)) continue;
                     r = n80_muladd(r, st, o);
                 }
             }
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * WAVES) void hmm_recursion_kernel(HmmParams P)
         // unit, branch-free (as scalar code it is a jump per case and twice the time)
         tn.m = s_r_m[lane_zero];
         tn.e = s_r_e[lane_zero];
-        for (uint32_t p = 0; p < ((P.dbg & 1u) ? 1u : n); ++p) {
+        for (uint32_t p = 0; p < ((VG_DBG(P.dbg) & 1u) ? 1u : n); ++p) {
             const VgN80 t = tn;
             if (p + 1 < n) {
                 tn.m = s_r_m[p + 1 + lane_zero];
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64 * WAVES) void hmm_recursion_kernel(HmmParams P)
         }
         VgX80 out = uniform;
         if (total.m != 0) {
-            prev = (P.dbg & 4u) ? r : n80_div(r, total);
+            prev = (VG_DBG(P.dbg) & 4u) ? r : n80_div(r, total);
             out = n80_to(prev);
         } else {
             prev = n80_from(uniform);
@@ -291,8 +291,7 @@ hipError_t launch_hmm_recursion(const HmmParams& P, uint32_t n_chains, hipStream
     uint32_t waves = spread ? 4u : 2u;
     if (const char* w = getenv("VGMI_HMM_WAVES")) waves = atoi(w) == 4 ? 4u : 2u;     // A/B
     HmmParams Q = P;
-    const char* dbg = getenv("VGMI_DBG");
-    Q.dbg = dbg ? (uint32_t)atoi(dbg) : 0u;
+    Q.dbg = vgmi_dbg_env();
     switch (P.ploidy) {
         case 1: return launch_recursion_waves<2>(waves, Q, n_chains, lds, plain_lds, st);
         case 2: return launch_recursion_waves<3>(waves, Q, n_chains, lds, plain_lds, st);

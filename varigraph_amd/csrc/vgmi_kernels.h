@@ -6,6 +6,16 @@
 
 #include "vgmi_device.h"
 
+// VGMI_DBG ablations change the arithmetic (wrong counters / genotypes): they exist only in a library built with
+// -DVGMI_ABLATION (VGMI_ABLATION=1 python -m varigraph_amd.build --force; tools/pmc_quick.sh does).  A product build reads no
+// debug knob at all, and vgmi_dbg_env() says so loudly if the variable is set.
+#ifdef VGMI_ABLATION
+#define VG_DBG(x) (x)
+#else
+#define VG_DBG(x) 0u
+#endif
+uint32_t vgmi_dbg_env();
+
 namespace vgk {
 
 enum { K_MODE_COUNT = 0, K_MODE_KEYS = 1, K_MODE_BLOOM = 2 };

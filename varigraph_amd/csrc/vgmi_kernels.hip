@@ -409,7 +409,7 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
                 if (pos < n_bytes) p.keys_out[pos] = valid ? (vg_hash64(canon, mask) << 8 | K) : ~0ULL;
             } else if (MODE == MODE_BLOOM) {
                 const uint64_t pos = (r << 10) + lane * 16 + j;
-                if (p.dbg & 128u) {   // A/B: every lane updates the filter itself
+                if (VG_DBG(p.dbg) & 128u) {   // A/B: every lane updates the filter itself
                     if (valid && pos < n_bytes) bloom_add_key(p.bloom, vg_hash64(canon, mask) << 8 | K);
                 } else {
                     bloom_add_wave(p.bloom, s_bkey, s_bcnt, valid && pos < n_bytes, vg_hash64(canon, mask) << 8 | K);
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
                 else if (counts) bump = &counts[tv.w];               // dense counters, clamped at read-out
                 else if (tv.z < 255u) bump = &slots[b_slot].count;
             } else if (c != VG_EMPTY && (c & VG_SLOT_CHAIN)) {
-                again = !(p.dbg & 64u);   // 64: ablation (wrong counts): collisions are dropped instead of re-queued
+                again = !(VG_DBG(p.dbg) & 64u);   // 64: ablation (wrong counts): collisions are dropped instead of re-queued
             }
         }
         const uint64_t ball = __builtin_amdgcn_ballot_w64(again);
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
             const uint32_t lo = funnel(e.y, e.x, my_sh);
             const uint32_t hi = funnel(e.z, e.y, my_sh) & MASK_HI;
             // dbg 32: ablation (wrong counts): one probing lane per run instead of up to 12
-            probe_issue(have && ((e.z >> my_vbit) & 1u) && (!(p.dbg & 32u) || my_win == (__builtin_ctz(e.z >> 12) & 15u)),
+            probe_issue(have && ((e.z >> my_vbit) & 1u) && (!(VG_DBG(p.dbg) & 32u) || my_win == (__builtin_ctz(e.z >> 12) & 15u)),
                         ((uint64_t)hi << 32) | lo, 0);
         }
         __builtin_amdgcn_wave_barrier();
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
         const uint64_t ballA = __builtin_amdgcn_ballot_w64(sa.ok16 && (sa.gw32 & sa.gm) == sa.gm && sa.vm != 0);
         const uint64_t ballB = __builtin_amdgcn_ballot_w64(sb.ok16 && (sb.gw32 & sb.gm) == sb.gm && sb.vm != 0);
         const uint32_t nA = (uint32_t)__builtin_popcountll(ballA), nB = (uint32_t)__builtin_popcountll(ballB);
-        if (p.dbg & 1u) continue;
+        if (VG_DBG(p.dbg) & 1u) continue;
         enqueue(sa, ballA, run_head + run_n);
         run_n += nA;
         // the ring holds VG_RUNQ runs: make room for row B's (only rows dense in candidates ever need this)

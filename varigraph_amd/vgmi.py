@@ -36,6 +36,7 @@ def load_library():
         "vgmi_destroy": (None, [vp]),
         "vgmi_last_error": (C.c_char_p, [vp]),
         "vgmi_stream": (vp, [vp]),
+        "vgmi_device_memory": (i32, [vp, C.POINTER(sz), C.POINTER(sz)]),
         "vgmi_table_upload": (i32, [vp, vp, sz, u32]),
         "vgmi_table_image_bytes": (i32, [vp, C.POINTER(sz)]),
         "vgmi_table_export": (i32, [vp, vp, sz]),
