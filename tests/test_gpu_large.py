@@ -141,3 +141,72 @@ def test_wgs_class_table_geometry_small_read_set():
     np.add.at(want, order[pos[hit]], 1)
     assert np.array_equal(got, np.minimum(want, 255).astype(np.uint8))
     assert np.array_equal(twice, np.minimum(2 * want, 255).astype(np.uint8))
+
+
+def _oracle_counts_by_search(sorted_keys, block, n_reads):
+    """Expected counters without a CPU hash table over 2.7e8 keys: the oracle's emitted keys of every read (vgo_sketch, the
+    reference's state machine), looked up by binary search in the sorted key list.  Returns (index array, count array)."""
+    rows = block.reshape(n_reads, L + 1)
+    emitted = np.concatenate([o.sketch(rows[i, :L].tobytes(), 27) for i in range(n_reads)])
+    pos = np.searchsorted(sorted_keys, emitted)
+    pos[pos == sorted_keys.size] = 0
+    hit = sorted_keys[pos] == emitted
+    idx, cnt = np.unique(pos[hit], return_counts=True)
+    return idx, cnt
+
+
+def test_c5_wgs_class_single_gpu_slice():
+    """BASELINE config 5's single-GPU slice at its stated size: the whole-genome class graph (3 Gb reference, 5 M SNPs,
+    2.67e8 graph k-mers) resident in HBM -- compact image, grid-16-mer table at 25 % load (~1e2 GB) -- NEXT TO
+    the construct-side Bloom filter of a 3 Gb genome (28.8 GB), 2e7 reads generated on the device.  Checked: a prefix
+    counter by counter against the oracle's emitted keys, whole == ragged split, monotone, nothing spilled past the table."""
+    import torch
+    keys, haps = synth.snp_graph(3_000_000_000, 5_000_000)
+    assert keys.size > 2.6e8 and np.all(keys[1:] > keys[:-1])     # np.unique: sorted, so binary search needs no argsort
+    ctx = vgmi.Context(0, buffer_mib=64)
+    try:
+        m, nh = vgmi.bloom_params(3_000_000_000, 0.01)
+        assert m > 28_000_000_000
+        ctx.bloom_create(m, nh, np.arange(1, nh + 1, dtype=np.uint64))      # resident for the whole test
+        ctx.table_upload(keys, 27)
+        info, xinfo = ctx.table_info(), ctx.xtable_info()
+        assert info["n_keys"] == keys.size and info["n_slots"] >= 1 << 31
+        assert xinfo["n_lines"] * 128 > 50e9      # the default table of this class, not the fallback for a short device
+        free_b, total_b = ctx.device_memory()
+        assert total_b - free_b > 130e9           # table + Bloom really are resident together
+        n_reads = 20_000_000
+        off = np.array([0, haps[0].size, haps[0].size + haps[1].size], dtype=np.uint64)
+        d_cat = torch.empty(int(off[-1]), dtype=torch.uint8, device="cuda")
+        d_cat[: haps[0].size] = torch.from_numpy(haps[0]).cuda()
+        d_cat[haps[0].size:] = torch.from_numpy(haps[1]).cuda()
+        del haps
+        d_block = torch.empty(n_reads * (L + 1), dtype=torch.uint8, device="cuda")
+        for first in range(0, n_reads, 10_000_000):
+            ctx.synth_reads_device(4711, first, 10_000_000, L, d_cat, off, d_block[first * (L + 1):])
+        del d_cat
+        ctx.counts_reset()
+        ctx.reads_submit_device(d_block, d_block.numel(), n_reads)
+        full, _, _ = ctx.counts_finish()
+        ms_full, _ = ctx.count_kernel_ms()
+        assert ctx.read_base() == n_reads * L
+        cuts = [0, 16 * 70_001, 16 * 600_000, 16 * 600_001, n_reads]
+        ctx.counts_reset()
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ctx.reads_submit_device(d_block[a * (L + 1):], (b - a) * (L + 1), b - a)
+        split, _, _ = ctx.counts_finish()
+        assert np.array_equal(full, split)
+        pre = 150_000
+        ctx.counts_reset()
+        ctx.reads_submit_device(d_block, pre * (L + 1), pre)
+        part, _, _ = ctx.counts_finish()
+        idx, cnt = _oracle_counts_by_search(keys, d_block[: pre * (L + 1)].cpu().numpy(), pre)
+        want = np.zeros(keys.size, dtype=np.uint8)
+        want[idx] = np.minimum(cnt, 255).astype(np.uint8)
+        assert np.array_equal(part, want)
+        assert int(cnt.sum()) > 4 * pre           # ~4.7 hits per read on this graph
+        assert (full >= part).all()
+        assert 4.0 < full.astype(np.int64).sum() / n_reads < 6.0
+        print(f"C5 slice: {n_reads} reads in {ms_full:.1f} ms of count kernel, {xinfo['n_lines'] * 128 / 1e9:.0f} GB table, "
+              f"{xinfo['overflow_pairs']} overflow pairs")
+    finally:
+        ctx.close()

@@ -1581,6 +1581,9 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
         if (th.joinable()) th.join();
     if (failed.load()) throw std::runtime_error(error);
     last_device_seconds = dev_last.load() > 0 ? (double)(dev_last.load() - dev_first.load()) * 1e-9 : 0;
+    last_windows = tasks.size();
+    last_device_windows = 0;
+    for (const auto& w : works) last_device_windows += w.on_device && !w.nodes.empty();
     const auto t_hmm = std::chrono::steady_clock::now();
     last_hmm_seconds = std::chrono::duration<double>(t_hmm - t_begin).count();
     if (g_phase_on) {

@@ -46,6 +46,7 @@ public:
 
     double last_hmm_seconds = 0, last_text_seconds = 0;   // of the last run(): windows on the pool / VCF text
     double last_device_seconds = 0;                       // ... of which the device recursion (0: the host ran it)
+    size_t last_windows = 0, last_device_windows = 0;     // windows of the last run() / those whose recursion and posterior ran on the device
 
     // The forward / backward recursion of eligible windows (transition "rec", every genotype with `ploidy` haplotypes, at most
     // 128 genotypes) runs on this context's device (vgmi_hmm_recursion: the reference's arithmetic bit for bit); nullptr: host.

@@ -352,9 +352,9 @@ int main_genotype(int argc, char** argv)
                 const std::string vcf = genotyper.run(job.cov.data(), job.hap_cov, job.name, hmm_cfg);
                 const double tz = secs();
                 vgh::Genotyper::write_gz(job.name + ".varigraph.vcf.gz", vcf, hmm_cfg.threads);
-                std::fprintf(stderr, "[varigraph-mi] %s: genotyping %.2f s (HMM %.2f, VCF text %.2f, gzip %.2f) -> %s.varigraph.vcf.gz\n",
-                             job.name.c_str(), secs() - th, genotyper.last_hmm_seconds, genotyper.last_text_seconds, secs() - tz,
-                             job.name.c_str());
+                std::fprintf(stderr, "[varigraph-mi] %s: genotyping %.2f s (HMM %.2f with %zu of %zu windows on the device, VCF text %.2f, gzip %.2f) -> %s.varigraph.vcf.gz\n",
+                             job.name.c_str(), secs() - th, genotyper.last_hmm_seconds, genotyper.last_device_windows, genotyper.last_windows,
+                             genotyper.last_text_seconds, secs() - tz, job.name.c_str());
             }
         } catch (const std::exception& e) {
             die(e.what());

@@ -191,7 +191,7 @@ def snp_kmer_keys(ref, positions, alts, k=27):
     return np.unique(np.concatenate(out))
 
 
-def snp_graph(genome, n_variants, ref_seed=777, var_seed=5, k=27):
+def snp_graph(genome, n_variants, ref_seed=777, var_seed=5, k=27, want_keys=True):
     """Large-table workloads (BASELINE configs 3-5 class) without running `construct`: an iid reference, uniformly
     placed SNPs, the key set of every k-mer covering a site on either allele, and the two haplotypes of the sequenced
     (all-het) sample.  Returns (keys, [ref, alt_haplotype])."""
@@ -200,7 +200,9 @@ def snp_graph(genome, n_variants, ref_seed=777, var_seed=5, k=27):
     pos = np.sort(rng.choice(np.arange(100, genome - 100), size=n_variants, replace=False))
     alt_code = (_CODE[ref[pos]] + rng.integers(1, 4, size=n_variants)) % 4
     alts = _ACGT[alt_code]
-    keys = np.unique(vgmi.synth_snp_keys(ref, pos, alts, k))   # == snp_kmer_keys(ref, pos, alts, k), natively
+    # == snp_kmer_keys(ref, pos, alts, k), natively; want_keys=False: a rank that receives the table image by broadcast
+    # needs the haplotypes only
+    keys = np.unique(vgmi.synth_snp_keys(ref, pos, alts, k)) if want_keys else None
     hap1 = ref.copy()
     hap1[pos] = alts
     return keys, [ref, hap1]

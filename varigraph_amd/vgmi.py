@@ -211,6 +211,11 @@ class Context:
         self.n_keys = self.table_info()["n_keys"]
         self.n_node_entries = 0
 
+    def device_memory(self):
+        f, t = C.c_size_t(), C.c_size_t()
+        self._chk(self._l.vgmi_device_memory(self._h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
     def table_info(self):
         n, k, s, f = C.c_size_t(), C.c_uint32(), C.c_size_t(), C.c_size_t()
         self._chk(self._l.vgmi_table_info(self._h, C.byref(n), C.byref(k), C.byref(s), C.byref(f)))
