@@ -198,6 +198,7 @@ int vgmi_bloom_query(vgmi_ctx *ctx, const uint64_t *host_keys, size_t n, uint8_t
  * all have `ploidy` haplotypes and whose transition is "rec".  A chain is one window walked in one direction; per step the
  * host supplies the node's row of emission scores, the two tables of powers (libm stays on the host: no_recomb^0..ploidy,
  * then recomb^0..ploidy) and whether the chain (re)starts there (the first node, or the node behind one without k-mers).
+ * At most 2048 genotypes; beyond 128 the keep matrices must be symmetric (they are by construction: what two genotypes share).
  * Every value is an x86-64 `long double` in its 16-byte memory form; out[step * n_gt + g] is the normalised score the
  * reference stores in HMMScore::a (forward chains) or ::b (backward chains), bit for bit (csrc/vg_x80.h). All pointers host. */
 typedef struct vgmi_hmm_chain {

@@ -205,3 +205,26 @@ def test_c4_eight_samples_over_the_gpus_present_equal_single_sample_reference_ru
         print(f"C4: 8 samples over --gpus {gpus}: varigraph-mi {t_nat:.1f} s, 8 reference runs {t_ref:.0f} s")
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def test_more_than_128_genotypes_run_on_the_device_vcf_identical(tmp_path_factory):
+    """`-n 20` over a panel of 21 haplotypes: 210 genotypes per window -- beyond one lane per genotype.  The recursion and the
+    posterior still run on the device (hmm_recursion_big_kernel) and the VCF is the reference's byte for byte."""
+    _need_binaries()
+    work = str(tmp_path_factory.mktemp("n20"))
+    try:
+        ref, variants, gts, graph = _dataset(work, 3_000_000, 12_000, vcf_samples=10, ploidy=2)
+        haps = synth.sample_haplotypes(ref, variants, gts, 0, 2)
+        fq = _write_fastq(os.path.join(work, "s"), haps, 300_000, seed=77)
+        cfg = "sample0 " + " ".join(fq) + "\n"
+        t_nat, log = _native_genotype(os.path.join(work, "native"), graph, cfg, ["-n", "20", "--gpu", "0"])
+        t_ref = _reference_genotype(os.path.join(work, "cpu"), graph, cfg, ["-n", "20"], timeout=600)
+        got, want = _vcf(os.path.join(work, "native"), "sample0"), _vcf(os.path.join(work, "cpu"), "sample0")
+        assert got == want and got.count(b"\n") > 8_000
+        line = [ln for ln in log.split("\n") if "windows on the device" in ln]
+        assert line, log[-1500:]
+        n_dev, n_all = [int(x) for x in line[0].split("with ")[1].split(" windows")[0].split(" of ")]
+        assert n_dev == n_all and n_all >= 3, line[0]
+        print(f"-n 20 (210 genotypes): varigraph-mi {t_nat:.1f} s, reference {t_ref:.0f} s")
+    finally:
+        shutil.rmtree(work, ignore_errors=True)

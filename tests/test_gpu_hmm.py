@@ -235,3 +235,101 @@ def test_parts_side_by_side_equal_the_whole_call():
         used[w * room:w * room + room - (w % 3)] = True
     assert np.array_equal(winner[used], winner2[used]) and np.array_equal(prob[used], prob2[used])
     assert (winner[used] != 0xFFFFFFFF).sum() > 100
+
+
+def _keep_matrix(genotypes, n_hap, perm=None):
+    """Haplotypes two genotypes share (multiset intersection, std::set_intersection of the sorted vectors) for all pairs."""
+    m = np.zeros((len(genotypes), n_hap), dtype=np.int16)
+    for i, g in enumerate(genotypes):
+        for h in g:
+            m[i, h] += 1
+    if perm is not None:
+        m = m[perm]
+    return np.minimum(m[:, None, :], m[None, :, :]).sum(axis=2).astype(np.uint8)
+
+
+@pytest.mark.parametrize("ploidy,n_hap,n_want", [(2, 16, 136), (2, 20, 210), (4, 10, 715), (4, 13, 1820), (1, 300, 300), (3, 14, 560)])
+def test_recursion_and_posterior_beyond_128_genotypes_equal_x87(ploidy, n_hap, n_want):
+    """More genotypes than lanes of the one-lane-per-genotype kernel: `-n 16` and up on a diploid sample (n (n + 1) / 2 pairs),
+    and any list the C ABI is handed -- multisets of four out of ten and thirteen haplotypes here.  hmm_recursion_big_kernel
+    (several genotypes per lane, keep matrix read by rows from global memory) and hmm_posterior_big_kernel against the same
+    computations in numpy.longdouble, bit for bit."""
+    assert np.finfo(LD).nmant == 63
+    rng = np.random.default_rng(ploidy * 1000 + n_hap)
+    genotypes = list(itertools.combinations_with_replacement(range(n_hap), ploidy))
+    n = len(genotypes)
+    assert n == n_want
+    n_windows = 2
+    keep = np.stack([_keep_matrix(genotypes, n_hap, rng.permutation(n)) for _ in range(n_windows)])
+    assert np.array_equal(keep[0], keep[0].T)
+    n_rows = 10 if n > 1000 else 16
+    expo = rng.choice([0, -20, -300, -2000, -4800, -4940, -4960], size=(n_rows, n), p=[.15, .2, .25, .2, .1, .05, .05])
+    obs = (rng.random((n_rows, n)).astype(LD) + LD(0.01)) * np.power(LD(10), expo.astype(LD))
+    obs[rng.random((n_rows, n)) < 0.02] = 0
+    obs[3] = 0
+    # window w: rows [w * half, (w + 1) * half) forward, then backward
+    half = n_rows // n_windows
+    steps_row, steps_restart, pows, chains = [], [], [], []
+    fwd = np.zeros(n_rows, dtype=np.uint64)
+    bwd = np.zeros(n_rows, dtype=np.uint64)
+    for w in range(n_windows):
+        for direction in (1, -1):
+            rows = list(range(w * half, (w + 1) * half))[::direction]
+            first = len(steps_row)
+            for i, r in enumerate(rows):
+                (fwd if direction == 1 else bwd)[r] = len(steps_row)
+                steps_row.append(r)
+                steps_restart.append(1 if i == 0 or (i % 4 == 3 and w == 1) else 0)
+                d = LD(rng.integers(1, 50_000))
+                recomb = (LD(1) - np.exp(-d / LD(30))) * (LD(1) / LD(30))
+                no_recomb = np.exp(-d / LD(30)) + recomb
+                pows.append([[no_recomb ** LD(k) for k in range(ploidy + 1)], [recomb ** LD(k) for k in range(ploidy + 1)]])
+            chains.append((first, len(rows), w))
+    pows = np.array(pows, dtype=LD)
+    uniform = LD(1) / LD(n)
+    gid = rng.integers(0, 7, size=(n_rows, n), dtype=np.uint8)
+    order = np.full((n_rows, n), 0xFF, dtype=np.uint8)
+    order[:, :7] = [4, 0, 6, 2, 1, 5, 3]
+    ctx = vgmi.Context(0, buffer_mib=16)
+    try:
+        prob, winner, ab = ctx.hmm_calls(keep, obs, steps_row, steps_restart, pows, uniform, chains, ploidy, gid, order, fwd, bwd)
+        # a keep matrix that is not symmetric is refused beyond 128 genotypes (the kernel reads it by rows)
+        bad = keep.copy()
+        bad[0, 1, 0] ^= 1
+        with pytest.raises(Exception):
+            ctx.hmm_recursion(bad, obs, steps_row, steps_restart, pows, uniform, chains, ploidy)
+    finally:
+        ctx.close()
+    for first, count, w in chains:
+        want = _host_chain(keep[w], [obs[r] for r in steps_row[first:first + count]], steps_restart[first:first + count],
+                           pows[first:first + count], uniform, ploidy)
+        g = ab[first:first + count]
+        assert np.array_equal(g, want), (ploidy, n, w, int(np.argmax((g != want).any(axis=1))))
+    assert (ab > 0).any() and (ab == 0).any()
+    n_called = 0
+    for r in range(n_rows):
+        a, b = ab[fwd[r]], ab[bwd[r]]
+        den = LD(0)
+        p_ = a * b
+        for g in range(n):
+            den = den + p_[g]
+        if den == 0:
+            assert winner[r] == 0xFFFFFFFF
+            continue
+        post = p_ / den
+        sums = {}
+        for g in range(n):
+            sums[gid[r, g]] = sums.get(gid[r, g], LD(0)) + post[g]
+        best, best_id = LD(-1), None
+        for k in order[r]:
+            if k == 0xFF:
+                break
+            if sums[k] > best:
+                best, best_id = sums[k], k
+        mx, win = LD(0), 0xFFFFFFFF
+        for g in range(n):
+            if gid[r, g] == best_id and mx < post[g]:
+                mx, win = post[g], g
+        assert winner[r] == win and prob[r] == best, r
+        n_called += win != 0xFFFFFFFF
+    assert n_called >= n_rows // 2

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Verify on the generated gfx950 ISA that the fixed VGPRs the k=27 kernels use for in-flight vector-memory data
-(v120..v127, see vgmi_kernels.hip) are touched only by the hand-written (VGHOT-tagged) instructions, and that the
+(v116..v127, see vgmi_kernels.hip) are touched only by the hand-written (VGHOT-tagged) instructions, and that the
 compiler's own allocation stays below them.  Usage: check_hot_vgprs.py [path/to/vgmi_kernels.hip]"""
 import os, re, subprocess, sys, tempfile
 
@@ -13,7 +13,7 @@ def main():
         text = open(out).read()
     bad = 0
     found = 0
-    for m in re.finditer(r"^(_ZN3vgk14count27_kernelILb[01]ELb[01]EEEvNS_9RowParamsE):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN3vgk14count27_kernelILb[01]ELb[01]EEEvNS_9RowParamsE|_ZN3vgk15count27s_kernelENS_9RowParamsE):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
         found += 1
         name, body = m.group(1), m.group(2)
         top = 0
@@ -26,9 +26,9 @@ def main():
         n_hot = body.count("VGHOT")
         n_scratch = len(re.findall(r"\bscratch_(load|store)", body))   # stack traffic would also break the vmcnt bookkeeping
         print(f"{name}: {n_hot} hand-written instructions, compiler's highest VGPR v{top}, {n_scratch} scratch accesses")
-        if top >= 120 or n_hot == 0 or n_scratch:
+        if top >= 116 or n_hot == 0 or n_scratch:     # v116.. are the hand-managed registers of every variant
             bad += 1
-    if found != 3 or bad:
+    if found != 4 or bad:
         print("FAILED")
         return 1
     print("OK")

@@ -1038,8 +1038,8 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, 
     // Device recursion: this pass fills hidden states, emission scores and the libm tables of every node; the recursion
     // itself and the posterior follow in window_finish() (the pruning of a node's k-mer list depends on the window's
     // haplotypes, not on alpha, so nothing here waits for the recursion)
-    const bool to_device = work != nullptr && work->obs != nullptr && n_gt == work->n_gt && cfg.transition == "rec" && all_full && n_gt <= 128 &&
-                           cfg.sample_ploidy >= 1 && cfg.sample_ploidy <= 4;
+    const bool to_device = work != nullptr && work->obs != nullptr && n_gt == work->n_gt && cfg.transition == "rec" && all_full && n_gt <= 2048 &&
+                           cfg.sample_ploidy >= 1 && cfg.sample_ploidy <= 4;    // 2048: VGMI_HMM_MAX_GT (csrc/vgmi_kernels.h)
     if (to_device) {
         const uint32_t stride = cfg.sample_ploidy + 1;
         struct Seen { uint32_t start, end; int32_t at; };   // every node the HMM works on; at: its place in work->nodes or -1
@@ -1068,7 +1068,14 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, 
             seen.push_back(Seen{n_start, n_end, (int32_t)work->nodes.size()});
             if (work->nodes.size() >= work->room || obs.size() != n_gt) throw std::runtime_error("internal: device HMM window larger than announced");
             std::memcpy(work->obs + work->nodes.size() * n_gt, obs.data(), n_gt * sizeof(long double));
-            genotype_strings(n, genotypes, work->gid + work->nodes.size() * n_gt, work->order + work->nodes.size() * n_gt);
+            if (!genotype_strings(n, genotypes, work->gid + work->nodes.size() * n_gt, work->order + work->nodes.size() * n_gt)) {
+                // more distinct genotype strings at this node than the device's byte-sized ids hold (> 255: dozens of alleles
+                // under hundreds of genotypes): the host takes the window, with the haplotypes already drawn
+                work->nodes.clear();
+                work->on_device = false;
+                window(chr, first, last, r, nullptr, &top);
+                return;
+            }
             work->nodes.push_back(i);
         }
         const size_t m = work->nodes.size();
@@ -1177,7 +1184,7 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, 
 // The genotype STRING of every entry of a node (posterior(): alleles as decimal strings, sorted as strings, joined by '/'),
 // as small numbers in order of first appearance, and those numbers in string order (0xFF behind the last): what the
 // device's posterior groups and ranks by.
-void Genotyper::genotype_strings(const Node& n, const std::vector<std::vector<uint16_t>>& genotypes, uint8_t* gid, uint8_t* order) const
+bool Genotyper::genotype_strings(const Node& n, const std::vector<std::vector<uint16_t>>& genotypes, uint8_t* gid, uint8_t* order) const
 {
     const auto& hap_gt = n.gn->hap_gt;
     uint16_t max_allele = 0;
@@ -1211,6 +1218,7 @@ void Genotyper::genotype_strings(const Node& n, const std::vector<std::vector<ui
             if (tuples[d] == tuple) { id = (int32_t)d; break; }
         if (id < 0) {
             id = (int32_t)tuples.size();
+            if (id >= 255) return false;      // 0xFF ends the order list
             tuples.push_back(tuple);
             std::string t;
             for (size_t q = 0; q < tuple.size(); ++q) {
@@ -1226,6 +1234,7 @@ void Genotyper::genotype_strings(const Node& n, const std::vector<std::vector<ui
     for (size_t d = 0; d < by_text.size(); ++d) by_text[d] = d;
     std::sort(by_text.begin(), by_text.end(), [&](size_t x, size_t y) { return texts[x] < texts[y]; });
     for (size_t q = 0; q < genotypes.size(); ++q) order[q] = q < by_text.size() ? (uint8_t)by_text[q] : 0xFF;
+    return true;
 }
 
 // the device's verdict on the nodes of a window prepared by window(): probability of the winning genotype string and the
@@ -1378,7 +1387,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
             if (!fits_device && g_phase_on)
                 std::fprintf(stderr, "[varigraph-mi] HMM on the host: %.1f GiB of device memory wanted, %.1f free\n", need / 1073741824.0, free_b / 1073741824.0);
         }
-        if (fits_device && dev_n_gt >= 1 && dev_n_gt <= 128 && total_room && total_room * dev_n_gt * sizeof(long double) <= (score_gib << 30)) {
+        if (fits_device && dev_n_gt >= 1 && dev_n_gt <= 2048 && total_room && total_room * dev_n_gt * sizeof(long double) <= (score_gib << 30)) {
             raw_obs.p = std::malloc(total_room * dev_n_gt * sizeof(long double));
             raw_pw.p = std::malloc(2 * total_room * 2 * dev_stride * sizeof(long double));
             raw_row.p = std::calloc(2 * total_room, sizeof(uint32_t));

@@ -49,7 +49,7 @@ public:
     size_t last_windows = 0, last_device_windows = 0;     // windows of the last run() / those whose recursion and posterior ran on the device
 
     // The forward / backward recursion of eligible windows (transition "rec", every genotype with `ploidy` haplotypes, at most
-    // 128 genotypes) runs on this context's device (vgmi_hmm_recursion: the reference's arithmetic bit for bit); nullptr: host.
+    // 2048 genotypes) runs on this context's device (vgmi_hmm_recursion: the reference's arithmetic bit for bit); nullptr: host.
     // max_parts: into how many device calls side by side a sample's windows may go (the process's four hardware queues,
     // shared by the consumers that genotype at the same time)
     void set_device(vgmi_ctx* ctx, unsigned max_parts = 4) { dev_ = ctx; dev_parts_ = max_parts ? max_parts : 1; }
@@ -108,7 +108,8 @@ private:
     void window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, WindowWork* work = nullptr,
                 const std::vector<uint16_t>* forced_top = nullptr);
     void window_finish(WindowWork& w, const long double* prob, const uint32_t* winner, const Run& r);
-    void genotype_strings(const Node& n, const std::vector<std::vector<uint16_t>>& genotypes, uint8_t* gid, uint8_t* order) const;
+    // false: more than 255 distinct genotype strings at this node (the device's ids are bytes)
+    bool genotype_strings(const Node& n, const std::vector<std::vector<uint16_t>>& genotypes, uint8_t* gid, uint8_t* order) const;
     NodeStates hidden_states(Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& top,
                              const std::vector<std::vector<uint16_t>>& genotypes, const std::vector<uint16_t>& used,
                              const GenotypeList& gl, double lower, double upper, bool filter, const Run& r, NodeStates&& recycled,

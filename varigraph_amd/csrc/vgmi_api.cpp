@@ -37,7 +37,8 @@ struct ImageHeader {  // first 256 bytes of the table image
     uint32_t slot_bytes;   // 16: VgSlot, 8: compact k-mer words (vgmi_device.h)
     uint32_t home_bucket_log2;   // 0: vg_thash home slots, else minimiser buckets (vg_thash_local)
     uint32_t home_by_offset;     // place inside the bucket = minimiser offset (vgmi_device.h)
-    uint8_t pad[256 - 8 - 4 - 4 - 8 - 8 - 40 - 8 - 4 - 4];
+    uint32_t grid_mer;           // 16: grid filter over 16-mers (step 12); 12: over 12-mers (step 16; small graphs, count27s_kernel)
+    uint8_t pad[256 - 8 - 4 - 4 - 8 - 8 - 40 - 8 - 4 - 4 - 4];
 };
 static_assert(sizeof(ImageHeader) == 256, "image header is 256 bytes");
 
@@ -86,6 +87,7 @@ struct vgmi_ctx {
     bool filter_in_lds = false;
     bool fast27 = false;         // k = 27: count27_kernel
     bool fast27_lds = false;     // ... with the 128 KiB grid filter resident in LDS
+    bool fast27_small = false;   // ... over 12-mers: count27s_kernel (the default for graphs of <= 65 536 k-mers)
     uint32_t wgs_per_cu = 0;     // VGMI_WGS_PER_CU: tuning override for the global-bitmap variant
     bool force_generic = false;  // VGMI_GENERIC_KERNEL=1: take the generic row kernel (A/B testing)
 
@@ -252,6 +254,13 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
             entry_bytes = 8;
         }
         h.grid_words_log2 = b;
+        // small graphs (LDS-resident filter): 12-mer grid, 16 bytes per lane (count27s_kernel); VGMI_GRID12=0 keeps the
+        // 16-mer grid and count27_kernel<true, true> of rounds 1-2 as the A/B reference
+        h.grid_mer = 16;
+        if (b == VG_GRID_LDS_WORDS_LOG2 && compact) {
+            const char* e = getenv("VGMI_GRID12");
+            if (!(e && e[0] == '0')) h.grid_mer = 12;
+        }
         h.off_grid = align(end);
         end = h.off_grid + (entry_bytes << b);
     }
@@ -279,6 +288,7 @@ int adopt_image(vgmi_ctx* c)
     c->fast27 = h.k == 27 && h.off_grid && (!lds_grid || compact);   // count27_kernel applies: LDS filter + compact
                                                                   // slots, or global (64-bit entry) filter + 16-byte slots
     c->fast27_lds = c->fast27 && lds_grid;
+    c->fast27_small = c->fast27_lds && h.grid_mer == 12;   // count27s_kernel
     c->d_key_slot = reinterpret_cast<uint32_t*>(c->d_image + h.off_key_slot);
     c->filter_in_lds = filter_fits_lds(h.filter_words_log2);
     HIPCHK(c, hipMalloc(&c->d_cov, h.n_keys ? h.n_keys : 1));
@@ -511,6 +521,10 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
             HIPCHK(c, launch_count27x(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
             p.tail27 = 2;
             HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, 1, block, st));
+        } else if (c->fast27_small && !c->force_generic) {
+            HIPCHK(c, launch_count27s(p, (uint32_t)c->n_cu, st));
+            p.tail27 = 3;
+            HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, 1, block, st));
         } else if (c->fast27 && !c->force_generic) {
             uint32_t g27, b27;
             if (c->fast27_lds) { b27 = 1024; g27 = (uint32_t)c->n_cu; }
@@ -533,6 +547,21 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
             if (rows) {
                 HIPCHK(c, launch_count27x(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
                 emit_from = rows * 768 - 1;
+            }
+            if (emit_from < n_bytes) {
+                p.emit_from = emit_from;
+                p.row_begin = emit_from >> 10;
+                HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, 1, block, st));
+            }
+        } else if (c->fast27_small && !c->force_generic) {
+            // complete pairs of 1 024-byte rows -> count27s_kernel: lane L of a row covers the k-mers ending at stream positions
+            // 16 L - 1 .. 16 L + 14 of the row; the generic kernel takes the ends behind the last pair, from the last position of
+            // the last full row on
+            p.row_end = (n_bytes / 2048) * 2;
+            uint64_t emit_from = 0;
+            if (p.row_end) {
+                HIPCHK(c, launch_count27s(p, (uint32_t)c->n_cu, st));
+                emit_from = p.row_end * 1024 - 1;
             }
             if (emit_from < n_bytes) {
                 p.emit_from = emit_from;
@@ -739,7 +768,7 @@ int vgmi_table_upload(vgmi_ctx* c, const uint64_t* keys, size_t n_keys, uint32_t
         HIPCHK(c, hipMemcpyAsync(d_keys, keys, n_keys * 8, hipMemcpyHostToDevice, c->stream));
         hipError_t e = launch_table_insert(c->tv, d_keys, n_keys, k, c->d_key_slot,
                                            const_cast<uint32_t*>(c->tv.filter), const_cast<uint32_t*>(c->tv.grid),
-                                           c->d_status, c->stream);
+                                           c->hdr.grid_mer == 12, c->d_status, c->stream);
         if (e != hipSuccess) { (void)hipFree(d_keys); HIPCHK(c, e); }
     }
     hipError_t e = hipStreamSynchronize(c->stream);
@@ -1587,7 +1616,14 @@ int hmm_run(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, ui
             const uint64_t* fwd_step, const uint64_t* bwd_step, void* prob, uint32_t* winner)
 {
     if (!c || !keep || !obs || !row || !restart || !pow || !uniform || !chains) return VGMI_E_INVALID;
-    if (n_gt < 1 || n_gt > 128 || ploidy < 1 || ploidy > 4) return fail(c, VGMI_E_INVALID, "HMM recursion: 1..128 genotypes of 1..4 haplotypes");
+    if (n_gt < 1 || n_gt > VGMI_HMM_MAX_GT || ploidy < 1 || ploidy > 4) return fail(c, VGMI_E_INVALID, "HMM recursion: 1..2048 genotypes of 1..4 haplotypes");
+    if (n_gt > 128)     // the many-genotype kernel reads keep[p][g] for keep[g][p]: what two genotypes share is symmetric
+        for (uint32_t w = 0; w < n_windows; ++w) {
+            const uint8_t* m = keep + (size_t)w * n_gt * n_gt;
+            for (uint32_t i = 0; i < n_gt; ++i)
+                for (uint32_t j = i + 1; j < n_gt; ++j)
+                    if (m[(size_t)i * n_gt + j] != m[(size_t)j * n_gt + i]) return fail(c, VGMI_E_INVALID, "HMM recursion: keep matrix not symmetric");
+        }
     if (row_lo > row_hi || step_lo > step_hi) return fail(c, VGMI_E_INVALID, "HMM recursion: an empty-handed range");
     const uint64_t n_rows = row_hi - row_lo, n_steps = step_hi - step_lo;
     for (uint32_t i = 0; i < n_chains; ++i)

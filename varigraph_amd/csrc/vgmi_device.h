@@ -222,11 +222,35 @@ VG_HD void vg_grid_probe(uint32_t mer16, uint32_t words_log2, uint64_t& word, ui
     vg_grid_probe(mer16, words_log2, word, mask, rot, as_is);
 }
 
-// slot hash of the exact table (evaluated only for filter passes): two 32-bit multiplies and a fold; home slots
-// are 32-bit (tables beyond 2^32 slots stay correct, linear probing just starts in the low part)
+// Small graphs (<= VG_GRID_LDS_MAX_KEYS k-mers: the filter lives in LDS, the table in L2) take a coarser grid: every 27-mer
+// contains exactly one 12-mer that ends at a stream position = 15 (mod 16) (27 - 12 + 1 = 16), so a lane of count27s_kernel
+// owns 16 bytes (one dwordx4) and one grid position per row, and the per-position work -- neighbour exchange, validity,
+// canonical form, hash, filter word, enqueue -- is paid once per 16 bases instead of once per 12.  A 12-mer is specific
+// enough only while the key set is small: 6.5e4 k-mers put <= ~7e4 of the 1.7e7 possible 12-mers into the filter (a random
+// position matches by chance 0.4 % of the time, next to ~1 % Bloom false positives); a chr20-class graph would make every
+// position a candidate, which is why large graphs keep the 16-mer grid.  Same blocked Bloom form: 3 bits in one of 2^15
+// 32-bit words, keyed on the canonical 12-mer; both products are 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate).
+#define VG_GRID12_STEP 16u
+#define VG_GRID12_MER 12u
+VG_HD uint32_t vg_revcomp12(uint32_t x)
+{
+    return vg_revcomp16(x) >> 8;     // the 12-mer sits in the low 24 bits: its complement-reverse lands in the top 24
+}
+VG_HD void vg_grid12_probe(uint32_t mer12, uint32_t& word, uint32_t& mask)
+{
+    const uint32_t rc = vg_revcomp12(mer12);
+    const uint32_t cm = mer12 < rc ? mer12 : rc;
+    const uint32_t h1 = vg_mul24(cm, 0x9E3779u), h2 = vg_mul24(cm, 0x85EBCBu);
+    word = h1 >> (32 - VG_GRID_LDS_WORDS_LOG2);
+    mask = (1u << (h2 >> 27)) | (1u << ((h2 >> 22) & 31u)) | (1u << ((h2 >> 17) & 31u));
+}
+
+// slot hash of the exact table (evaluated only for filter passes): three 24-bit multiplies (full rate on CDNA; the 32-bit
+// v_mul_lo_u32 is quarter rate) and a fold; home slots are 32-bit (tables beyond 2^32 slots stay correct, linear probing
+// just starts in the low part)
 VG_HD uint64_t vg_thash(uint64_t kmer)
 {
-    uint32_t h = (uint32_t)kmer * 0x9E3779B1u + (uint32_t)(kmer >> 32) * 0x85EBCA77u;
+    uint32_t h = vg_mul24((uint32_t)kmer, 0x9E3779u) + vg_mul24((uint32_t)(kmer >> 24), 0x85EBCBu) + vg_mul24((uint32_t)(kmer >> 48), 0xC2B2AFu);
     h ^= h >> 15;
     return h;
 }

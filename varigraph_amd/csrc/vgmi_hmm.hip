@@ -242,9 +242,215 @@ __global__ __launch_bounds__(128) void hmm_posterior_kernel(HmmPostParams P)
     }
 }
 
+// ---- more than 128 genotypes per window (`-n` > 15 on a diploid sample: n (n + 1) / 2 pairs; any list the C ABI is given) -------
+// The same recursion, the same order of additions: 256 lanes per chain, lane t holds genotypes t, t + 256, ... (GPL of them, in
+// registers), the step table of ALL previous entries lives in LDS (12 bytes x n x (ploidy + 1)), and the keep matrix -- n x n
+// bytes, too large for LDS from 363 genotypes on -- is read from global memory ROW p for term p: keep is symmetric (what two
+// genotypes share does not depend on who asks), so keep[p][g] = keep[g][p] and the 256 lanes read consecutive bytes; the
+// matrix of a window is L2-resident (n = 2 048: 4 MiB).  Time per node is n x GPL dependent terms per lane: the reference's
+// O(n^2) per node, 256 genotypes at a time.
+template <uint32_t STRIDE, uint32_t GPL>
+__global__ __launch_bounds__(256) void hmm_recursion_big_kernel(HmmParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t hmm_smem[];
+    constexpr uint32_t stride = STRIDE, T = 256;
+    const uint32_t n = P.n_gt, tid = threadIdx.x;
+    uint64_t* const s_step_m = reinterpret_cast<uint64_t*>(hmm_smem);                 // n * stride
+    uint64_t* const s_r_m = s_step_m + (size_t)n * stride;                             // n
+    int32_t* const s_step_e = reinterpret_cast<int32_t*>(s_r_m + n);                   // n * stride
+    int32_t* const s_r_e = s_step_e + (size_t)n * stride;                              // n
+    const HmmChain ch = P.chains[blockIdx.x];
+    const uint8_t* const keep_g = P.keep + (size_t)ch.keep_index * n * n;
+    const VgX80 uniform = x80_load(P.uniform);
+    if (ch.n_steps == 0) return;
+    uint32_t lane_zero = 0;
+    asm volatile("" : "+v"(lane_zero));
+    bool act[GPL];
+    uint32_t gi[GPL];
+#pragma unroll
+    for (uint32_t j = 0; j < GPL; ++j) {
+        act[j] = tid + j * T < n;
+        gi[j] = act[j] ? tid + j * T : 0u;     // an idle slot reads genotype 0's inputs and writes nothing
+    }
+    VgN80 prev[GPL];
+#pragma unroll
+    for (uint32_t j = 0; j < GPL; ++j) prev[j] = VgN80{0, 0};
+    const uint64_t s_end = ch.first_step + ch.n_steps;
+    for (uint64_t s = ch.first_step; s < s_end; ++s) {
+        const uint32_t row_s = P.row[s];
+        const bool restart = P.restart[s] != 0;
+        const uint8_t* pw = P.pow + s * (size_t)(2 * stride) * 16;
+        VgN80 o[GPL], r[GPL];
+#pragma unroll
+        for (uint32_t j = 0; j < GPL; ++j) {
+            o[j] = VgN80{0, 0};
+            if (act[j]) o[j] = n80_from(x80_load(P.obs + ((size_t)row_s * n + gi[j]) * 16));
+            r[j] = VgN80{0, 0};
+        }
+        if (!restart) {
+            for (uint32_t k = 0; k < stride; ++k) {
+                const VgN80 kp = n80_from(x80_load(pw + (size_t)k * 16 + lane_zero));
+                const VgN80 cp = n80_from(x80_load(pw + (size_t)(stride + (stride - 1 - k)) * 16 + lane_zero));
+#pragma unroll
+                for (uint32_t j = 0; j < GPL; ++j) {
+                    const VgN80 st = n80_mul(n80_mul(prev[j], kp), cp);
+                    if (act[j]) {
+                        s_step_m[(size_t)gi[j] * stride + k] = st.m;
+                        s_step_e[(size_t)gi[j] * stride + k] = st.e;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (restart) {
+#pragma unroll
+            for (uint32_t j = 0; j < GPL; ++j) r[j] = o[j];
+        } else {
+            uint8_t kb[GPL], kb_next[GPL];
+#pragma unroll
+            for (uint32_t j = 0; j < GPL; ++j) kb_next[j] = keep_g[gi[j]];
+            for (uint32_t p = 0; p < n; ++p) {
+#pragma unroll
+                for (uint32_t j = 0; j < GPL; ++j) kb[j] = kb_next[j];
+                if (p + 1 < n) {
+#pragma unroll
+                    for (uint32_t j = 0; j < GPL; ++j) kb_next[j] = keep_g[(size_t)(p + 1) * n + gi[j]];
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < GPL; ++j) {
+                    VgN80 st;
+                    st.m = s_step_m[(size_t)p * stride + kb[j]];
+                    st.e = s_step_e[(size_t)p * stride + kb[j]];
+                    // a term more than 64 binades below the sum so far leaves it as it is (vgmi_hmm.hip, the small kernel)
+                    const bool nothing = !act[j] || st.m == 0 || o[j].m == 0 || (r[j].m != 0 && r[j].e - (st.e + o[j].e - VG_X80_BIAS + 2) > 64);
+                    if (__builtin_amdgcn_ballot_w64(!nothing) == 0) continue;
+                    r[j] = n80_muladd(r[j], st, o[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < GPL; ++j)
+            if (act[j]) {
+                s_r_m[gi[j]] = r[j].m;
+                s_r_e[gi[j]] = r[j].e;
+            }
+        __syncthreads();
+        VgN80 total = {0, 0};
+        for (uint32_t p = 0; p < n; ++p) {
+            VgN80 t;
+            t.m = s_r_m[p + lane_zero];
+            t.e = s_r_e[p + lane_zero];
+            if (t.m == 0 || (total.m != 0 && total.e - t.e > 64)) continue;
+            total = n80_sum(total, t);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < GPL; ++j) {
+            VgX80 out = uniform;
+            if (total.m != 0) {
+                prev[j] = n80_div(r[j], total);
+                out = n80_to(prev[j]);
+            } else {
+                prev[j] = n80_from(uniform);
+            }
+            if (act[j]) x80_store(P.out + (s * n + gi[j]) * 16, out);
+        }
+        __syncthreads();
+    }
+}
+
+// the posterior for any number of genotypes: 256 lanes, lane t takes entries t, t + 256, ...; at most 255 distinct genotype
+// strings per node (gid is a byte; the host keeps a node with more on its own path)
+__global__ __launch_bounds__(256) void hmm_posterior_big_kernel(HmmPostParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t post_smem[];
+    const uint32_t n = P.n_gt, tid = threadIdx.x;
+    uint64_t* const s_m = reinterpret_cast<uint64_t*>(post_smem);       // n
+    uint64_t* const s_sum_m = s_m + n;                                  // 256
+    uint32_t* const s_e = reinterpret_cast<uint32_t*>(s_sum_m + 256);   // n
+    uint32_t* const s_sum_e = s_e + n;                                  // 256
+    uint8_t* const s_gid = reinterpret_cast<uint8_t*>(s_sum_e + 256);   // n
+    const uint64_t rowi = P.row0 + blockIdx.x;
+    const uint64_t fs = P.fwd_step[rowi], bs = P.bwd_step[rowi];
+    for (uint32_t g = tid; g < n; g += 256) {
+        const VgX80 a = x80_load(P.ab + (fs * n + g) * 16), b = x80_load(P.ab + (bs * n + g) * 16);
+        const VgX80 p = x80_mul(a, b);
+        s_m[g] = p.m;
+        s_e[g] = p.e;
+        s_gid[g] = P.gid[rowi * n + g];
+    }
+    __syncthreads();
+    VgX80 den = {0, 0};
+    for (uint32_t q = 0; q < n; ++q) {
+        VgX80 t;
+        t.m = s_m[q];
+        t.e = s_e[q];
+        den = x80_add(den, t);
+    }
+    if (den.m == 0) {
+        if (tid == 0) P.winner[rowi] = 0xFFFFFFFFu;
+        return;
+    }
+    __syncthreads();
+    for (uint32_t g = tid; g < n; g += 256) {
+        VgX80 p;
+        p.m = s_m[g];
+        p.e = s_e[g];
+        const VgX80 post = x80_div(p, den);
+        s_m[g] = post.m;
+        s_e[g] = post.e;
+    }
+    __syncthreads();
+    VgX80 sum = {0, 0};      // lane k sums string k's entries in entry order
+    for (uint32_t q = 0; q < n; ++q)
+        if (s_gid[q] == tid) {
+            VgX80 t;
+            t.m = s_m[q];
+            t.e = s_e[q];
+            sum = x80_add(sum, t);
+        }
+    s_sum_m[tid] = sum.m;
+    s_sum_e[tid] = sum.e;
+    __syncthreads();
+    if (tid == 0) {
+        const uint8_t* ord = P.order + rowi * n;
+        VgX80 best = {0, 0};
+        uint32_t best_id = 0xFFFFFFFFu;
+        for (uint32_t k = 0; k < n && ord[k] != 0xFF; ++k) {
+            VgX80 sk;
+            sk.m = s_sum_m[ord[k]];
+            sk.e = s_sum_e[ord[k]];
+            if (best_id == 0xFFFFFFFFu || x80_gt(sk, best)) {
+                best = sk;
+                best_id = ord[k];
+            }
+        }
+        VgX80 max_post = {0, 0};
+        uint32_t win = 0xFFFFFFFFu;
+        for (uint32_t q = 0; q < n; ++q) {
+            if (s_gid[q] != best_id) continue;
+            VgX80 t;
+            t.m = s_m[q];
+            t.e = s_e[q];
+            if (x80_gt(t, max_post)) {
+                max_post = t;
+                win = q;
+            }
+        }
+        x80_store(P.prob + rowi * 16, best);
+        P.winner[rowi] = best_id == 0xFFFFFFFFu ? 0xFFFFFFFEu : win;
+    }
+}
+
 hipError_t launch_hmm_posterior(const HmmPostParams& P, uint64_t n_rows, hipStream_t st)
 {
     if (n_rows == 0) return hipSuccess;
+    if (P.n_gt > 128) {
+        const size_t lds = (size_t)P.n_gt * 13 + 256 * 12 + 64;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hmm_posterior_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(hmm_posterior_big_kernel, dim3((uint32_t)n_rows), dim3(256), lds, st, P);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(hmm_posterior_kernel, dim3((uint32_t)n_rows), dim3(128), 0, st, P);
     return hipGetLastError();
 }
@@ -278,9 +484,40 @@ hipError_t launch_recursion_waves(uint32_t waves, const HmmParams& Q, uint32_t n
 }
 }  // namespace
 
+namespace {
+template <uint32_t STRIDE, uint32_t GPL>
+hipError_t launch_recursion_big_as(const HmmParams& Q, uint32_t n_chains, hipStream_t st)
+{
+    const size_t lds = (size_t)Q.n_gt * (STRIDE + 1) * 12 + 64;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hmm_recursion_big_kernel<STRIDE, GPL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((hmm_recursion_big_kernel<STRIDE, GPL>), dim3(n_chains), dim3(256), lds, st, Q);
+    return hipGetLastError();
+}
+template <uint32_t STRIDE>
+hipError_t launch_recursion_big(const HmmParams& Q, uint32_t n_chains, hipStream_t st)
+{
+    if (Q.n_gt <= 512) return launch_recursion_big_as<STRIDE, 2>(Q, n_chains, st);
+    if (Q.n_gt <= 1024) return launch_recursion_big_as<STRIDE, 4>(Q, n_chains, st);
+    return launch_recursion_big_as<STRIDE, 8>(Q, n_chains, st);
+}
+}  // namespace
+
 hipError_t launch_hmm_recursion(const HmmParams& P, uint32_t n_chains, hipStream_t st)
 {
     if (n_chains == 0) return hipSuccess;
+    if (P.n_gt > 128) {
+        if (P.n_gt > VGMI_HMM_MAX_GT) return hipErrorInvalidValue;
+        HmmParams Q = P;
+        Q.dbg = 0;
+        switch (P.ploidy) {
+            case 1: return launch_recursion_big<2>(Q, n_chains, st);
+            case 2: return launch_recursion_big<3>(Q, n_chains, st);
+            case 3: return launch_recursion_big<4>(Q, n_chains, st);
+            case 4: return launch_recursion_big<5>(Q, n_chains, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
     const size_t plain_lds = hmm_lds_bytes(P.n_gt, P.ploidy);
     // A small launch asks for more than half a CU's LDS: its workgroups then have a CU each.  The parts of a sample are
     // launches of a few dozen chains on streams of their own; the dispatcher starts each at the same CUs, and chains that

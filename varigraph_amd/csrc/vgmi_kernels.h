@@ -76,7 +76,7 @@ struct RowParams {
     const unsigned long long* n_bytes_dev;   // count kernels: when set, the block's length is read from device memory (the
                           // device-side FASTQ parser knows it, the host does not) and n_bytes / row_end / row_begin /
                           // emit_from are derived from it in the kernel; tail27 tells rows_kernel it runs behind count27_kernel
-    uint32_t tail27;
+    uint32_t tail27;      // 1 behind count27_kernel, 2 behind count27x_kernel, 3 behind count27s_kernel
     TableView table;      // MODE_COUNT
     uint64_t* keys_out;   // MODE_KEYS
     BloomView bloom;      // MODE_BLOOM
@@ -138,8 +138,9 @@ struct HmmChain {
     uint32_t keep_index;            // which keep matrix (one per window)
     uint32_t pad;
 };
+#define VGMI_HMM_MAX_GT 2048u        // genotypes per window the device takes (12 x n x (ploidy + 2) bytes of LDS: 147 KB at the bound)
 struct HmmParams {
-    uint32_t n_gt, ploidy;          // genotypes per window (<= 128), haplotypes per genotype (<= 4)
+    uint32_t n_gt, ploidy;          // genotypes per window (<= VGMI_HMM_MAX_GT; <= 128: one lane per genotype, keep matrix in LDS), haplotypes per genotype (<= 4)
     const uint8_t* keep;            // per window: n_gt x n_gt, haplotypes shared by genotype g (row) and previous entry p
     const uint8_t* obs;             // per node: n_gt emission scores, 16 bytes each (x86-64 long double)
     const uint32_t* row;            // per step: the node's row in obs
@@ -178,12 +179,13 @@ hipError_t launch_xcov(const XTableView& t, const uint32_t* id_of_key, uint64_t 
                        hipStream_t st);
 hipError_t launch_xcounts_xfer(const XTableView& t, const uint32_t* id_of_key, uint32_t* ext, uint64_t n, bool import, hipStream_t st);
 hipError_t launch_count27(bool lds_bitmap, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
+hipError_t launch_count27s(const RowParams& p, uint32_t grid, hipStream_t st);   // small graphs: 12-mer grid, 1 024-byte rows
 hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t launch_bloom_even(const RowParams& p, hipStream_t st);   // even k, one long sequence (K3)
 hipError_t launch_seq(int mode, const RowParams& p, const uint64_t* read_off, uint64_t n_reads, hipStream_t st);
 hipError_t launch_table_clear(const TableView& t, hipStream_t st);
 hipError_t launch_table_insert(const TableView& t, const uint64_t* keys, uint64_t n, uint32_t k, uint32_t* key_slot,
-                               uint32_t* filter_rw, uint32_t* grid_rw, uint32_t* status, hipStream_t st);
+                               uint32_t* filter_rw, uint32_t* grid_rw, bool grid12, uint32_t* status, hipStream_t st);
 hipError_t launch_counts_reset(const TableView& t, hipStream_t st);
 hipError_t launch_cov(const TableView& t, const uint32_t* key_slot, uint64_t n, const uint8_t* flag,
                       uint8_t* cov, unsigned long long* hist, hipStream_t st);

@@ -293,8 +293,10 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
         n_bytes = *p.n_bytes_dev;
         emit_from = 0;
         if (p.tail27) {   // behind count27_kernel: the ends it does not cover (see launch_count in vgmi_api.cpp)
-            const uint64_t row_end27 = p.tail27 == 2 ? n_bytes / 768 : (n_bytes / 1536) * 2;   // 2: count27x_kernel (single rows)
-            emit_from = row_end27 ? row_end27 * 768 - 1 : 0;
+            // 1: count27_kernel (pairs of 768-byte rows), 2: count27x_kernel (single rows), 3: count27s_kernel (pairs of 1 024-byte rows)
+            const uint64_t row_bytes = p.tail27 == 3 ? 1024u : 768u;
+            const uint64_t row_end27 = p.tail27 == 2 ? n_bytes / 768 : (n_bytes / (2 * row_bytes)) * 2;
+            emit_from = row_end27 ? row_end27 * row_bytes - 1 : 0;
         }
         row_begin = emit_from >> 10;
         if (emit_from >= n_bytes) return;
@@ -489,6 +491,7 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
 //   v[116:118] / v[120:122] row prefetch (first / second row of a pair)     v123 atomic return (never read)
 //   v[124:127] table slots of the batch in flight
 #define VG_HOT_CLOBBERS "v116", "v117", "v118", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+#define VG_HOT_CLOBBERS_S "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
 
 template <int R>   // R = 0: first row of the pair -> v[116:118], 1: second row -> v[120:122]
 __device__ __forceinline__ void vm_load_row(const uint8_t* ptr)
@@ -496,6 +499,34 @@ __device__ __forceinline__ void vm_load_row(const uint8_t* ptr)
     if (R == 0) asm volatile("global_load_dwordx3 v[116:118], %0, off nt ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS);
     else asm volatile("global_load_dwordx3 v[120:122], %0, off nt ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS);
 }
+// count27s_kernel: 16 bytes per lane, v[116:119] first / v[120:123] second row of a pair; table word v[124:125], atomic return v126
+template <int R>
+__device__ __forceinline__ void vms_load_row(const uint8_t* ptr)
+{
+    if (R == 0) asm volatile("global_load_dwordx4 v[116:119], %0, off nt ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS_S);
+    else asm volatile("global_load_dwordx4 v[120:123], %0, off nt ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS_S);
+}
+__device__ __forceinline__ void vms_load_slot(const void* ptr)
+{
+    asm volatile("global_load_dwordx2 v[124:125], %0, off ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS_S);
+}
+__device__ __forceinline__ void vms_atomic_inc(uint32_t* ptr, uint32_t one)
+{
+    asm volatile("global_atomic_add v126, %0, %1, off sc0 ; VGHOT" : : "v"(ptr), "v"(one) : "memory", VG_HOT_CLOBBERS_S);
+}
+__device__ __forceinline__ uint2 vms_slot_value()   // after the wait
+{
+    uint2 v;
+    asm volatile("v_mov_b32 %0, v124 ; VGHOT\n\tv_mov_b32 %1, v125 ; VGHOT" : "=v"(v.x), "=v"(v.y));
+    return v;
+}
+__device__ __forceinline__ uint32_t vms_atomic_old()   // return value of the last vms_atomic_inc, after the wait
+{
+    uint32_t v;
+    asm volatile("v_mov_b32 %0, v126 ; VGHOT" : "=v"(v));
+    return v;
+}
+
 template <bool COMPACT>   // compact table format: the 8-byte k-mer word only
 __device__ __forceinline__ void vm_load_slot(const void* ptr)
 {
@@ -613,6 +644,21 @@ __device__ __forceinline__ Addr4 lut_addr4(const uint32_t one)
     if (R == 1 && D == 0) VG_SDWA_ROW("v120");
     if (R == 1 && D == 1) VG_SDWA_ROW("v121");
     if (R == 1 && D == 2) VG_SDWA_ROW("v122");
+    return a;
+}
+
+template <int R, int D>   // count27s_kernel: dword D (0..3) of landed row R (v116 + 4 R + D)
+__device__ __forceinline__ Addr4 luts_addr4(const uint32_t one)
+{
+    Addr4 a;
+    if (R == 0 && D == 0) VG_SDWA_ROW("v116");
+    if (R == 0 && D == 1) VG_SDWA_ROW("v117");
+    if (R == 0 && D == 2) VG_SDWA_ROW("v118");
+    if (R == 0 && D == 3) VG_SDWA_ROW("v119");
+    if (R == 1 && D == 0) VG_SDWA_ROW("v120");
+    if (R == 1 && D == 1) VG_SDWA_ROW("v121");
+    if (R == 1 && D == 2) VG_SDWA_ROW("v122");
+    if (R == 1 && D == 3) VG_SDWA_ROW("v123");
     return a;
 }
 
@@ -959,6 +1005,293 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
 }
 
 // ------------------------------------------------------------------------------------------
+// count27s_kernel: k = 27, graphs of <= 65 536 k-mers (BASELINE config 2, the bench) -- round 3.
+//
+// The same pipeline as count27_kernel<true, true> on a coarser grid (vgmi_device.h, VG_GRID12_*): 1 024-byte rows, 16 bytes
+// (one dwordx4) per lane, ONE grid 12-mer per lane and row, candidate runs of 16 k-mers, four runs (64 lanes) per probe
+// batch.  What is paid per grid position -- two neighbour exchanges instead of three, validity, canonical form, hash, filter
+// word, ballot, enqueue -- is paid once per 16 bases instead of once per 12, the drain's lanes are all busy (4 x 16 = 64
+// instead of 5 x 12 = 60), and no 32-bit multiply (quarter rate) is left in the loop.  The vector memory is scheduled by
+// hand exactly as there (see the header of count27_kernel); fixed registers: v[116:119] / v[120:123] the two rows of a
+// pair, v[124:125] the table word in flight, v126 the atomic's return value.
+//
+// A lane's 48-base window, base q = 0..47 at bits 2(47 - q) of W2:W1:W0: q 32..47 own chunk (W0), q 16..31 lane - 1 (W1),
+// q 0..15 lane - 2 (W2).  Grid position g = q 31 (the last base of the previous lane's chunk):
+//   grid 12-mer  q 20..31 = the low 24 bits of W1
+//   run          q  5..46 (k-mers ending at q 31..46, i.e. g .. g + 15) = bits [2, 86)
+// ------------------------------------------------------------------------------------------
+#define VG_ROW27S 1024u
+#define VG_RUN_BATCH_S 4u
+
+__global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
+{
+    constexpr uint32_t MASK_HI = (1u << (2 * 27 - 32)) - 1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint32_t nwaves = blockDim.x >> 6;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u32x4 lds_u4_rw;
+    typedef __attribute__((address_space(3))) uint64_t lds_u64_rw;
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    const uint32_t rings0 = VG_LUT27_BYTES + VG_GRID_LDS_WORDS * 4u;
+    const uint32_t runs_base = rings0 + wave_u * (VG_RUNQ * 16u);
+    const uint32_t req_base = rings0 + nwaves * (VG_RUNQ * 16u) + wave_u * (VG_REQ * 8u);
+    stage_lut27(tid, blockDim.x);
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(p.table.grid);
+        uint4* dst = reinterpret_cast<uint4*>(smem + VG_LUT27_BYTES);
+        for (uint32_t i = tid; i < VG_GRID_LDS_WORDS / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    unsigned long long* const slots8 = p.table.slots8;
+    uint32_t* const counts = p.table.counts;
+    const uint64_t cap_mask = p.table.cap_mask;
+
+    // rows [0, row_end) are complete 1 024-byte rows, row_end even: a wave walks a contiguous range of row PAIRS
+    const uint64_t total_pairs = p.n_bytes_dev ? *p.n_bytes_dev / (2 * VG_ROW27S) : p.row_end >> 1;
+    const uint64_t total_waves = (uint64_t)gridDim.x * nwaves;
+    const uint64_t ppw = (total_pairs + total_waves - 1) / total_waves;
+    const uint64_t gw = (uint64_t)blockIdx.x * nwaves + wave_u;
+    const uint64_t r0v = gw * ppw;
+    const uint64_t r1v = r0v + ppw < total_pairs ? r0v + ppw : total_pairs;
+    const uint64_t r0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r0v >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r0v);
+    const uint64_t r1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r1v >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r1v);
+    if (r0 >= r1) return;
+    uint32_t one;
+    asm volatile("v_mov_b32 %0, 1" : "=v"(one));
+    const uint32_t lane_off = lane * 16u;
+    const uint8_t* const bases = p.bases;
+
+    // previous row's words, already rotated by 1 / 2 lanes (lanes 0 and 1 take them); nothing lies in front of the block
+    uint32_t pr1_be = 0, pr2_be = 0, pr1_inv = 0xFFFFu, pr2_inv = 0xFFFFu;
+    const uint64_t rs = r0 > 0 ? r0 - 1 : r0;   // the pair before the range is walked first: it only provides the halo
+
+    uint32_t n_after_row = 0, n_after_slot = 2;
+    uint64_t b_canon = 0, b_slot = 0;
+    bool b_active = false;
+    uint64_t p_slot = 0;
+    bool p_bumped = false;
+
+    const uint32_t my_run = lane >> 4, my_win = lane & 15u;
+    const uint32_t my_sh = 2 * (15 - my_win);
+    uint32_t run_head = 0, run_n = 0, req_head = 0, req_n = 0;
+    auto ring_slot = [](uint32_t pos) -> uint32_t {  // pos < 2 * VG_RUNQ
+        const uint32_t w = pos - VG_RUNQ;
+        return w < pos ? w : pos;
+    };
+
+    auto probe_issue = [&](bool act, uint64_t kmer, uint64_t dist) __attribute__((always_inline)) {
+        const uint64_t rc = vg_revcomp(kmer, 27);
+        const uint64_t canon = kmer < rc ? kmer : rc;   // idempotent for re-queued (already canonical) entries
+        b_canon = canon | (dist << 54);
+        b_slot = (vg_thash(canon) + dist) & cap_mask;
+        b_active = act;
+        if (act) vms_load_slot(&slots8[b_slot]);
+        ++n_after_row;
+        n_after_slot = 0;
+    };
+    auto drain_step = [&]() __attribute__((always_inline)) {
+        vm_wait(n_after_slot);
+        {
+            // the previous step's atomics have returned (issued before the loads just waited for): the one increment that
+            // takes a counter from 254 to 255 flags the slot (later hits skip their atomic, as the reference skips its
+            // increment) and marks its region for the per-sample reset
+            const uint32_t old = vms_atomic_old();
+            const bool sat = p_bumped && old == 254u;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(sat) != 0, 0)) {
+                if (sat) {
+                    vm_atomic_or_sync(reinterpret_cast<uint32_t*>(&slots8[p_slot]) + 1, (uint32_t)(VG_SLOT_SAT >> 32));
+                    vm_store_byte_sync(p.table.sat_dirty + (p_slot >> VG_SAT_REGION_LOG2), 1u);
+                }
+            }
+        }
+        const uint2 tv = vms_slot_value();
+        bool again = false;
+        uint32_t* bump = nullptr;
+        if (b_active) {
+            const uint64_t c = ((uint64_t)tv.y << 32) | tv.x;
+            const uint64_t canon = b_canon & VG_Q_KMER_MASK;
+            if (c != VG_EMPTY && (c & VG_SLOT_KMER_MASK) == canon) {
+                if (!(c & VG_SLOT_SAT)) bump = &counts[b_slot];
+            } else if (c != VG_EMPTY && (c & VG_SLOT_CHAIN)) {
+                again = !(VG_DBG(p.dbg) & 64u);
+            }
+        }
+        const uint64_t ball = __builtin_amdgcn_ballot_w64(again);
+        if (ball != 0) {
+            const uint32_t n = (uint32_t)__builtin_popcountll(ball);
+            const bool fits = req_n + n <= VG_REQ && (b_canon >> 54) < 1023u;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(again && !fits) == 0, 1)) {
+                if (again) {
+                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
+                                         __builtin_amdgcn_mbcnt_lo((uint32_t)ball, req_head + req_n));
+                    *reinterpret_cast<lds_u64_rw*>((uintptr_t)(req_base + (pos & (VG_REQ - 1)) * 8u)) = b_canon + (1ULL << 54);
+                }
+                req_n += n;
+            } else if (again) {
+                // ring full (or probe distance field exhausted): chase the chain right here, synchronously
+                const uint64_t canon = b_canon & VG_Q_KMER_MASK;
+                uint64_t sl = b_slot;
+                for (;;) {
+                    sl = (sl + 1) & cap_mask;
+                    const uint4 v = vm_load_slot_sync<true>(&slots8[sl]);
+                    const uint64_t c = ((uint64_t)v.y << 32) | v.x;
+                    if (c != VG_EMPTY && (c & VG_SLOT_KMER_MASK) == canon) {
+                        if (!(c & VG_SLOT_SAT)) { bump = &counts[sl]; b_slot = sl; }
+                        break;
+                    }
+                    if (c == VG_EMPTY || !(c & VG_SLOT_CHAIN)) break;
+                }
+            }
+        }
+        p_bumped = bump != nullptr;
+        p_slot = b_slot;
+        if (__builtin_amdgcn_ballot_w64(bump != nullptr)) {   // wave-uniform: the atomic is issued iff some lane hit
+            if (bump) vms_atomic_inc(bump, one);
+            ++n_after_row;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const bool do_req = req_n >= 32u || run_n == 0;
+        const uint32_t take_req = do_req ? (req_n < 64u ? req_n : 64u) : 0u;   // may be 0 (final flush)
+        const uint32_t take_run = do_req ? 0u : (run_n < VG_RUN_BATCH_S ? run_n : VG_RUN_BATCH_S);
+        const uint32_t rq_head = req_head, rn_head = run_head;
+        req_head += take_req;
+        req_n -= take_req;
+        run_head += take_run;
+        if (run_head >= VG_RUNQ) run_head -= VG_RUNQ;
+        run_n -= take_run;
+        if (do_req) {
+            const bool have = lane < take_req;
+            uint64_t e = 0;
+            if (have) e = *reinterpret_cast<lds_u64_rw*>((uintptr_t)(req_base + ((rq_head + lane) & (VG_REQ - 1)) * 8u));
+            if (take_req) probe_issue(have, e & VG_Q_KMER_MASK, e >> 54);
+            else b_active = false;   // an all-idle batch, no load
+        } else {
+            const bool have = my_run < take_run;
+            u32x4 e = {0u, 0u, 0u, 0u};
+            if (have) e = *reinterpret_cast<lds_u4_rw*>((uintptr_t)(runs_base + ring_slot(rn_head + my_run) * 16u));
+            // k-mer ending at window my_win of the run: bits [2(15 - win), +54) of the 84 run bits
+            const uint32_t lo = funnel(e.y, e.x, my_sh);
+            const uint32_t hi = funnel(e.z, e.y, my_sh) & MASK_HI;
+            probe_issue(have && ((e.w >> my_win) & 1u) && (!(VG_DBG(p.dbg) & 32u) || my_win == (__builtin_ctz(e.w) & 15u)),
+                        ((uint64_t)hi << 32) | lo, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // scan of one row once its words and its neighbours' are known: validity of the 16 windows, grid probe
+    struct RowScan { uint32_t W0, W1, W2, vm, gm, gw32; };
+    auto scan_probe = [&](uint32_t be, uint32_t inv, uint32_t be1, uint32_t be2, uint32_t i1, uint32_t i2) __attribute__((always_inline)) -> RowScan {
+        RowScan r;
+        r.W0 = be;
+        r.W1 = be1;
+        r.W2 = be2;
+        // non-base bits.  B bit i = base q 5 + i (i = 0..26, the span of the k-mer ending at g): the k-mer ending at g + j is
+        // spoilt by B iff B >> j != 0, and by the own chunk iff one of own bases 0..j-1 is a non-base (x | -x = every bit
+        // from the lowest set one up).  A non-base inside the 12-mer itself (B bits 15..26) spoils all 16 windows: vm = 0.
+        const uint32_t B = (i2 >> 5) | (i1 << 11);
+        const uint32_t a = (inv << 1) & 0xFFFFu;
+        const uint32_t bad_b = B ? (0xFFFFFFFFu >> __builtin_clz(B)) : 0u;
+        r.vm = ~(a | (0u - a) | bad_b) & 0xFFFFu;
+        uint32_t gx;
+        vg_grid12_probe(be1 & 0xFFFFFFu, gx, r.gm);
+        r.gw32 = *reinterpret_cast<lds_u32*>((uintptr_t)((gx << 2) + VG_LUT27_BYTES));
+        return r;
+    };
+    auto enqueue = [&](const RowScan& r, uint64_t ball, uint32_t tail) __attribute__((always_inline)) {
+        if (__builtin_amdgcn_inverse_ballot_w64(ball)) {
+            const uint32_t d0 = funnel(r.W1, r.W0, 2);
+            const uint32_t d1 = funnel(r.W2, r.W1, 2);
+            const uint32_t d2 = r.W2 >> 2;
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, tail));
+            *reinterpret_cast<lds_u4_rw*>((uintptr_t)(runs_base + ring_slot(pos) * 16u)) = u32x4{d0, d1, d2, r.vm};
+        }
+    };
+    auto empty_read_check = [&](uint32_t adj, const uint8_t* row) __attribute__((always_inline)) {
+        // reference: assert(len > 0), src/kmer.cpp:124 -- two adjacent non-bases are necessary; exact test on the bytes
+        if (adj) {
+            const uint64_t base_off = (uint64_t)(row - bases) + lane_off;
+            for (uint32_t t = 0; t < 16; ++t) {
+                if (!((adj >> t) & 1u)) continue;
+                const uint64_t o = base_off + t;
+                if (vm_load_byte_sync(bases + o) == '\n' && (o == 0 || vm_load_byte_sync(bases + o - 1) == '\n'))
+                    vm_atomic_or_sync(p.status, 1u);
+            }
+        }
+    };
+
+    const uint32_t n_it = (uint32_t)(r1 - rs), n_warm = (uint32_t)(r0 - rs);
+    const uint8_t* rowp = bases + rs * (2 * VG_ROW27S);
+    vms_load_row<0>(rowp + lane_off);
+    vms_load_row<1>(rowp + VG_ROW27S + lane_off);
+    for (uint32_t it = 0; it < n_it; ++it) {
+        vm_wait(n_after_row);   // both rows have landed once at most n_after_row younger operations are outstanding
+        const Addr4 a0 = luts_addr4<0, 0>(one), a1 = luts_addr4<0, 1>(one), a2 = luts_addr4<0, 2>(one), a3 = luts_addr4<0, 3>(one);
+        const Addr4 c0 = luts_addr4<1, 0>(one), c1 = luts_addr4<1, 1>(one), c2 = luts_addr4<1, 2>(one), c3 = luts_addr4<1, 3>(one);
+        const uint8_t* const cur = rowp;
+        if (it + 1 < n_it) rowp += 2 * VG_ROW27S;
+        vms_load_row<0>(rowp + lane_off);            // prefetch (the last iteration re-reads its own pair)
+        vms_load_row<1>(rowp + VG_ROW27S + lane_off);
+        n_after_row = 0;
+        n_after_slot += 2;
+        if (run_n >= VG_RUN_BATCH_S || req_n >= 32u) drain_step();
+
+        // own 16 bases of each row: be = 32 bits, first base most significant; inv bit t = base t is not a base.
+        // LUT sets (stage_lut27): A puts a dword's four non-base flags at bits 8..11, B at bits 12..15
+        const uint32_t g0 = encode4<0>(a0), g1 = encode4<1>(a1), g2 = encode4<0>(a2), g3 = encode4<1>(a3);
+        const uint32_t h0 = encode4<0>(c0), h1 = encode4<1>(c1), h2 = encode4<0>(c2), h3 = encode4<1>(c3);
+        const uint32_t beA = __builtin_amdgcn_perm(__builtin_amdgcn_perm(g0, g1, 0x0c0c0400u), __builtin_amdgcn_perm(g2, g3, 0x0c0c0400u), 0x05040100u);
+        const uint32_t invA = (((g0 | g1) >> 8) & 0xFFu) | ((g2 | g3) & 0xFF00u);
+        const uint32_t beB = __builtin_amdgcn_perm(__builtin_amdgcn_perm(h0, h1, 0x0c0c0400u), __builtin_amdgcn_perm(h2, h3, 0x0c0c0400u), 0x05040100u);
+        const uint32_t invB = (((h0 | h1) >> 8) & 0xFFu) | ((h2 | h3) & 0xFF00u);
+        auto ror1 = [](uint32_t v) __attribute__((always_inline)) -> uint32_t {
+            return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
+        };
+        const uint32_t a1_be = ror1(beA), a1_inv = ror1(invA), b1_be = ror1(beB), b1_inv = ror1(invB);
+        const uint32_t a2_be = ror1(a1_be), a2_inv = ror1(a1_inv), b2_be = ror1(b1_be), b2_inv = ror1(b1_inv);
+        // neighbours: lanes l-1, l-2 of the same row; the first lanes take the tail of the row before (row A: second row of
+        // the previous pair, row B: row A -- the rotates wrap, so lanes 0, 1 of a*_ hold exactly that tail)
+        const uint32_t beA1 = lane >= 1 ? a1_be : pr1_be, beA2 = lane >= 2 ? a2_be : pr2_be;
+        const uint32_t iA1 = lane >= 1 ? a1_inv : pr1_inv, iA2 = lane >= 2 ? a2_inv : pr2_inv;
+        const uint32_t beB1 = lane >= 1 ? b1_be : a1_be, beB2 = lane >= 2 ? b2_be : a2_be;
+        const uint32_t iB1 = lane >= 1 ? b1_inv : a1_inv, iB2 = lane >= 2 ? b2_inv : a2_inv;
+        pr1_be = b1_be; pr2_be = b2_be; pr1_inv = b1_inv; pr2_inv = b2_inv;
+        if (it < n_warm) continue;
+
+        {   // empty-read check (rare path)
+            const uint32_t adjA = invA & ((invA << 1) | (iA1 >> 15));
+            const uint32_t adjB = invB & ((invB << 1) | (iB1 >> 15));
+            if (__builtin_expect(__ballot(((adjA | adjB) & 0xFFFFu) != 0) != 0, 0)) {
+                empty_read_check(adjA & 0xFFFFu, cur);
+                empty_read_check(adjB & 0xFFFFu, cur + VG_ROW27S);
+            }
+        }
+
+        const RowScan sa = scan_probe(beA, invA, beA1, beA2, iA1, iA2);
+        const RowScan sb = scan_probe(beB, invB, beB1, beB2, iB1, iB2);
+        const uint64_t ballA = __builtin_amdgcn_ballot_w64((sa.gw32 & sa.gm) == sa.gm && sa.vm != 0);
+        const uint64_t ballB = __builtin_amdgcn_ballot_w64((sb.gw32 & sb.gm) == sb.gm && sb.vm != 0);
+        const uint32_t nA = (uint32_t)__builtin_popcountll(ballA), nB = (uint32_t)__builtin_popcountll(ballB);
+        if (VG_DBG(p.dbg) & 1u) continue;
+        enqueue(sa, ballA, run_head + run_n);
+        run_n += nA;
+        while (run_n + nB > VG_RUNQ) drain_step();   // make room for row B's runs (only rows dense in candidates need this)
+        enqueue(sb, ballB, run_head + run_n);
+        run_n += nB;
+        if (run_n >= VG_RUN_BATCH_S || req_n >= 32u) drain_step();
+        while (run_n >= 3 * VG_RUN_BATCH_S || req_n >= 48u) drain_step();   // dense stretches: keep the rings short
+    }
+    do {   // flush: until the rings are empty and the last step issued nothing (finishing a batch can re-queue)
+        drain_step();
+    } while (run_n != 0 || req_n != 0 || __builtin_amdgcn_ballot_w64(b_active) != 0);
+    vm_wait_imm<0>();
+}
+
+// ------------------------------------------------------------------------------------------
 // sequential kernel: literal restatement of the reference state machine, any k in 1..28.
 // One lane per read (read r = bytes [off[r], off[r+1]-1), followed by its '\n'); used for even
 // k, where palindromic k-mers and stale registers make emission history-dependent
@@ -1137,7 +1470,7 @@ __global__ void table_clear_kernel(TableView t)
 }
 
 __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t n, uint32_t k,
-                                    uint32_t* key_slot, uint32_t* filter_rw, uint32_t* grid_rw, uint32_t* status)
+                                    uint32_t* key_slot, uint32_t* filter_rw, uint32_t* grid_rw, bool grid12, uint32_t* status)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1163,7 +1496,13 @@ __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t 
     if (!t.slots8) t.slots[s].key_index = (uint32_t)i;
     key_slot[i] = (uint32_t)s;
     atomicOr(&filter_rw[vg_fhash_word(canon) >> t.filter_shift], vg_fhash_bits(canon, t.filter_words_log2));
-    if (grid_rw) {   // k = 27 only: the 12 sixteen-mers of the k-mer (canonicalised inside vg_grid_probe, which
+    if (grid_rw && grid12) {   // small graphs: the 16 twelve-mers of the k-mer (vgmi_device.h, VG_GRID12_*)
+        for (uint32_t off = 0; off < VG_GRID12_STEP; ++off) {
+            uint32_t w, m;
+            vg_grid12_probe((uint32_t)(canon >> (2 * off)) & 0xFFFFFFu, w, m);
+            atomicOr(&grid_rw[w], m);
+        }
+    } else if (grid_rw) {   // k = 27 only: the 12 sixteen-mers of the k-mer (canonicalised inside vg_grid_probe, which
                      // makes the reverse complement's twelve the same entries)
         const bool wide = t.grid_words_log2 != VG_GRID_LDS_WORDS_LOG2;   // global variant: 64-bit entries + offset bits
         for (uint32_t off = 0; off < VG_GRID_STEP; ++off) {
@@ -1313,6 +1652,15 @@ static hipError_t launch_count27_t(const RowParams& p, uint32_t grid, uint32_t b
     return hipGetLastError();
 }
 
+hipError_t launch_count27s(const RowParams& p, uint32_t grid, hipStream_t st)
+{
+    const size_t lds = (size_t)VG_GRID_LDS_WORDS * 4 + (size_t)16 * (VG_RUNQ * 16 + VG_REQ * 8) + VG_LUT27_BYTES;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&count27s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(count27s_kernel, dim3(grid), dim3(1024), lds, st, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_count27(bool lds_bitmap, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st)
 {
     if (lds_bitmap) return launch_count27_t<true, true>(p, grid, block, st);
@@ -1361,11 +1709,11 @@ hipError_t launch_table_clear(const TableView& t, hipStream_t st)
 }
 
 hipError_t launch_table_insert(const TableView& t, const uint64_t* keys, uint64_t n, uint32_t k, uint32_t* key_slot,
-                               uint32_t* filter_rw, uint32_t* grid_rw, uint32_t* status, hipStream_t st)
+                               uint32_t* filter_rw, uint32_t* grid_rw, bool grid12, uint32_t* status, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(table_insert_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, t, keys, n, k, key_slot,
-                       filter_rw, grid_rw, status);
+                       filter_rw, grid_rw, grid12, status);
     return hipGetLastError();
 }
 
