@@ -216,8 +216,8 @@ def test_hand_scheduled_registers_untouched_by_compiler():
     r = subprocess.run(["python3", os.path.join(ROOT, "tools", "check_hot_vgprs.py")], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    # count27s_kernel (12-mer grid), count27_kernel: LDS filter + compact, global filter + compact / 16-byte slots
-    assert r.stdout.count("0 scratch accesses") == 4, r.stdout
+    # count27s_kernel (12-mer grid: path table / hash table), count27_kernel: LDS filter + compact, global filter + compact / 16-byte slots
+    assert r.stdout.count("0 scratch accesses") == 5, r.stdout
 
 
 def _bgzf_bytes(data, block=0xff00, level=6, eof_marker=True):

@@ -13,7 +13,7 @@ def main():
         text = open(out).read()
     bad = 0
     found = 0
-    for m in re.finditer(r"^(_ZN3vgk14count27_kernelILb[01]ELb[01]EEEvNS_9RowParamsE|_ZN3vgk15count27s_kernelENS_9RowParamsE):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN3vgk14count27_kernelILb[01]ELb[01]EEEvNS_9RowParamsE|_ZN3vgk15count27s_kernelILb[01]EEEvNS_9RowParamsE):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
         found += 1
         name, body = m.group(1), m.group(2)
         top = 0
@@ -26,9 +26,10 @@ def main():
         n_hot = body.count("VGHOT")
         n_scratch = len(re.findall(r"\bscratch_(load|store)", body))   # stack traffic would also break the vmcnt bookkeeping
         print(f"{name}: {n_hot} hand-written instructions, compiler's highest VGPR v{top}, {n_scratch} scratch accesses")
-        if top >= 116 or n_hot == 0 or n_scratch:     # v116.. are the hand-managed registers of every variant
+        limit = 100 if "count27s_kernelILb1" in name else 116     # the path-table variant also hand-manages v100..v112
+        if top >= limit or n_hot == 0 or n_scratch:
             bad += 1
-    if found != 4 or bad:
+    if found != 5 or bad:
         print("FAILED")
         return 1
     print("OK")

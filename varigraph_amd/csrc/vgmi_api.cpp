@@ -78,6 +78,8 @@ struct vgmi_ctx {
     uint32_t* d_xt_counts = nullptr;
     uint32_t* d_xt_id = nullptr;                // key index -> counter id (path order), nullptr: identity
     ulonglong2* d_xt_over = nullptr;            // exact table of the k-mers that overflowed their lines (repeats), or nullptr
+    unsigned long long* d_pt_index = nullptr;   // path table of small graphs (vgmi_ptable.hip): 12-mer -> places in d_pt_P
+    ulonglong2* d_pt_P = nullptr;               // the k-mers along their unitigs, both orientations
     uint64_t xt_over_keys = 0;                  // pairs (key, 16-mer) that overflowed in the last build
     uint8_t* d_sat_dirty = nullptr;   // compact format: 2048-slot regions holding a saturation flag (the reset sweeps those)
     uint64_t n_sat_regions = 0;
@@ -185,6 +187,11 @@ void free_table(vgmi_ctx* c)
     if (c->d_xt_over) (void)hipFree(c->d_xt_over);
     c->d_xt_over = nullptr;
     c->xt_over_keys = 0;
+    if (c->d_pt_index) (void)hipFree(c->d_pt_index);
+    if (c->d_pt_P) (void)hipFree(c->d_pt_P);
+    c->d_pt_index = nullptr;
+    c->d_pt_P = nullptr;
+    c->tv.pt = PathView{};
     c->d_xt_lines = nullptr;
     c->d_xt_counts = nullptr;
     c->d_xt_id = nullptr;
@@ -433,6 +440,51 @@ int build_xtable(vgmi_ctx* c)
         }
     }
     c->tv.xt = x;
+    return VGMI_OK;
+}
+
+// the path table of small graphs, derived from the compact image like the grid-16-mer table of large ones (after an upload,
+// an import and a clone alike); VGMI_PTABLE=0 keeps count27s_kernel on the hash table alone (A/B)
+int build_ptable(vgmi_ctx* c)
+{
+    const ImageHeader& h = c->hdr;
+    c->tv.pt = PathView{};
+    if (!c->fast27_small || h.n_keys == 0) return VGMI_OK;
+    if (const char* e = getenv("VGMI_PTABLE"))
+        if (e[0] == '0') return VGMI_OK;
+    const uint64_t n = h.n_keys;
+    const uint32_t bucket_log2 = 17;      // 2 MiB of index for <= 65 536 k-mers (~7e4 distinct canonical 12-mers: a third bucket entry is wanted in ~2 % of the buckets)
+    uint32_t *key_of_slot = nullptr, *link = nullptr, *link2 = nullptr, *pos = nullptr, *mark = nullptr;
+    unsigned long long* cursor = nullptr;
+    hipError_t he = hipMalloc(reinterpret_cast<void**>(&key_of_slot), h.cap * 4);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&link), n * 8);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&link2), n * 8);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&pos), n * 4);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&mark), n * 4);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&cursor), 8);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&c->d_pt_P), 2 * n * sizeof(ulonglong2));
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&c->d_pt_index), (size_t)16 << bucket_log2);
+    if (he == hipSuccess) he = hipMemsetAsync(c->d_pt_index, 0, (size_t)16 << bucket_log2, c->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(pos, 0xFF, n * 4, c->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(mark, 0, n * 4, c->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(cursor, 0, 8, c->stream);
+    if (he == hipSuccess) he = launch_ptable_order(c->tv, c->d_key_slot, n, key_of_slot, link, link2, pos, cursor, mark, c->d_status, c->stream);
+    unsigned long long used = 0;
+    uint32_t st = 0;
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    if (he == hipSuccess) he = hipMemcpy(&used, cursor, 8, hipMemcpyDeviceToHost);
+    if (he == hipSuccess) he = hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost);
+    const bool ordered = !(st & 16u) && used == n;      // else (cannot happen): chains of one, in key order -- any layout is correct
+    if (he == hipSuccess && (st & 16u)) he = hipMemsetAsync(c->d_status, 0, 4, c->stream);
+    if (he == hipSuccess) he = launch_ptable_fill(c->tv, c->d_key_slot, ordered ? pos : nullptr, n, c->d_pt_P, c->d_pt_index, bucket_log2, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    for (void* q : {(void*)key_of_slot, (void*)link, (void*)link2, (void*)pos, (void*)mark, (void*)cursor})
+        if (q) (void)hipFree(q);
+    HIPCHK(c, he);
+    c->tv.pt.index = c->d_pt_index;
+    c->tv.pt.P = c->d_pt_P;
+    c->tv.pt.bucket_log2 = bucket_log2;
+    c->tv.pt.n2 = (uint32_t)(2 * n);
     return VGMI_OK;
 }
 
@@ -778,6 +830,8 @@ int vgmi_table_upload(vgmi_ctx* c, const uint64_t* keys, size_t n_keys, uint32_t
     if (rc) { free_table(c); return rc; }
     rc = build_xtable(c);
     if (rc) { free_table(c); return rc; }
+    rc = build_ptable(c);
+    if (rc) { free_table(c); return rc; }
     c->read_base = 0;
     return VGMI_OK;
 }
@@ -825,6 +879,8 @@ int vgmi_table_import(vgmi_ctx* c, const void* dev_src, size_t bytes)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     rc = build_xtable(c);
     if (rc) return rc;
+    rc = build_ptable(c);
+    if (rc) return rc;
     c->read_base = 0;
     return VGMI_OK;
 }
@@ -858,6 +914,8 @@ int vgmi_table_clone(vgmi_ctx* dst, vgmi_ctx* src)
     HIPCHK(dst, launch_counts_reset(dst->tv, dst->stream));   // the source's per-sample state travels with the image
     HIPCHK(dst, hipStreamSynchronize(dst->stream));
     rc = build_xtable(dst);
+    if (rc) return rc;
+    rc = build_ptable(dst);
     if (rc) return rc;
     dst->read_base = 0;
     return VGMI_OK;
@@ -927,6 +985,7 @@ int vgmi_counts_reset(vgmi_ctx* c)
     if (c->tv.xt.lines) HIPCHK(c, hipMemsetAsync(c->d_xt_counts, 0, c->hdr.n_keys * 4, c->stream));
     if (c->d_counts) HIPCHK(c, hipMemsetAsync(c->d_counts, 0, c->n_counts * 4, c->stream));
     if (!c->tv.xt.lines && (!c->d_counts || c->tv.slots8)) HIPCHK(c, launch_counts_reset(c->tv, c->stream));   // in-slot counters / saturation flags
+    if (c->tv.pt.P) HIPCHK(c, launch_ptable_reset(c->tv.pt.P, c->tv.pt.n2, c->stream));                         // ... and their copies in the path table
     HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4, c->stream));
     // host blocks are counted on the stages' own (non-blocking) streams: their next launch waits for this reset
     HIPCHK(c, hipEventRecord(c->reset_done, c->stream));

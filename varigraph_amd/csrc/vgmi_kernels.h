@@ -34,6 +34,14 @@ struct XTableView {
     uint32_t over_mask;          // its capacity - 1 (a power of two)
 };
 
+// path table of small graphs (vgmi_ptable.hip): what count27s_kernel looks candidate runs up in
+struct PathView {
+    const unsigned long long* index;   // 2 << bucket_log2 entries, or nullptr: not in use
+    ulonglong2* P;                     // n2 entries {k-mer word | saturation flag, table slot}; P[n2 - 1 - i] = reverse complement of P[i]
+    uint32_t bucket_log2;
+    uint32_t n2;
+};
+
 struct TableView {
     VgSlot* slots;              // cap entries (16-byte format) or nullptr
     unsigned long long* slots8; // cap k-mer words (compact 8-byte format) or nullptr
@@ -48,6 +56,7 @@ struct TableView {
     uint8_t* sat_dirty;         // compact format: one byte per 2048-slot region, set when a slot of the region gets its
                                 // saturation flag; the per-sample reset sweeps only those regions
     XTableView xt;              // when xt.lines is set, every count kernel looks k-mers up there and counts in xt.counts
+    PathView pt;                // small graphs: count27s_kernel's run lookups (counters stay per slot)
     uint32_t* counts;           // 16-byte format: dense per-key counters of large graphs (4 B/key, Infinity-Cache
                                 // sized) or nullptr (in-slot counters); compact format: per-slot counters (cap)
 };
@@ -180,6 +189,11 @@ hipError_t launch_xcov(const XTableView& t, const uint32_t* id_of_key, uint64_t 
 hipError_t launch_xcounts_xfer(const XTableView& t, const uint32_t* id_of_key, uint32_t* ext, uint64_t n, bool import, hipStream_t st);
 hipError_t launch_count27(bool lds_bitmap, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t launch_count27s(const RowParams& p, uint32_t grid, hipStream_t st);   // small graphs: 12-mer grid, 1 024-byte rows
+hipError_t launch_ptable_order(const TableView& t, const uint32_t* key_slot, uint64_t n, uint32_t* key_of_slot, uint32_t* link, uint32_t* link2,
+                               uint32_t* pos_of_key, unsigned long long* cursor, uint32_t* mark, uint32_t* status, hipStream_t st);
+hipError_t launch_ptable_fill(const TableView& t, const uint32_t* key_slot, const uint32_t* pos_of_key, uint64_t n, ulonglong2* P,
+                              unsigned long long* index, uint32_t bucket_log2, hipStream_t st);
+hipError_t launch_ptable_reset(ulonglong2* P, uint64_t n2, hipStream_t st);
 hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t launch_bloom_even(const RowParams& p, hipStream_t st);   // even k, one long sequence (K3)
 hipError_t launch_seq(int mode, const RowParams& p, const uint64_t* read_off, uint64_t n_reads, hipStream_t st);

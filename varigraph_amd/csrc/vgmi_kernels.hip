@@ -527,6 +527,83 @@ __device__ __forceinline__ uint32_t vms_atomic_old()   // return value of the la
     return v;
 }
 
+// path-table drain of count27s_kernel<true>: index pair v[108:111], candidate entries v[100:103] / v[104:107], atomic return v112
+#define VG_HOT_CLOBBERS_P "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", VG_HOT_CLOBBERS_S
+__device__ __forceinline__ void vmp_load_index(const void* ptr)
+{
+    asm volatile("global_load_dwordx4 v[108:111], %0, off ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS_P);
+}
+template <int C>
+__device__ __forceinline__ void vmp_load_cand(const void* ptr)
+{
+    if (C == 0) asm volatile("global_load_dwordx4 v[100:103], %0, off ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS_P);
+    else asm volatile("global_load_dwordx4 v[104:107], %0, off ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS_P);
+}
+template <int C>
+__device__ __forceinline__ void vmp_atomic_inc(uint32_t* ptr, uint32_t one)
+{
+    if (C == 0) asm volatile("global_atomic_add v112, %0, %1, off sc0 ; VGHOT" : : "v"(ptr), "v"(one) : "memory", VG_HOT_CLOBBERS_P);
+    else asm volatile("global_atomic_add v113, %0, %1, off sc0 ; VGHOT" : : "v"(ptr), "v"(one) : "memory", VG_HOT_CLOBBERS_P);
+}
+__device__ __forceinline__ uint4 vmp_index_value()
+{
+    uint4 v;
+    asm volatile("v_mov_b32 %0, v108 ; VGHOT\n\tv_mov_b32 %1, v109 ; VGHOT\n\tv_mov_b32 %2, v110 ; VGHOT\n\tv_mov_b32 %3, v111 ; VGHOT"
+                 : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w));
+    return v;
+}
+template <int C>
+__device__ __forceinline__ uint3 vmp_cand_value()     // {k-mer word lo, hi, slot}
+{
+    uint3 v;
+    if (C == 0) asm volatile("v_mov_b32 %0, v100 ; VGHOT\n\tv_mov_b32 %1, v101 ; VGHOT\n\tv_mov_b32 %2, v102 ; VGHOT" : "=v"(v.x), "=v"(v.y), "=v"(v.z));
+    else asm volatile("v_mov_b32 %0, v104 ; VGHOT\n\tv_mov_b32 %1, v105 ; VGHOT\n\tv_mov_b32 %2, v106 ; VGHOT" : "=v"(v.x), "=v"(v.y), "=v"(v.z));
+    return v;
+}
+template <int C>
+__device__ __forceinline__ uint32_t vmp_atomic_old()
+{
+    uint32_t v;
+    if (C == 0) asm volatile("v_mov_b32 %0, v112 ; VGHOT" : "=v"(v));
+    else asm volatile("v_mov_b32 %0, v113 ; VGHOT" : "=v"(v));
+    return v;
+}
+// rare path: a returning atomic waited for on the spot
+__device__ __forceinline__ uint32_t vm_atomic_inc_sync(uint32_t* ptr, uint32_t one)
+{
+    uint32_t old;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0 ; VGHOT\n\ts_waitcnt vmcnt(0) ; VGHOT" : "=&v"(old) : "v"(ptr), "v"(one) : "memory");
+    return old;
+}
+// n = hot operations issued after the one whose result is needed: waits with vmcnt(min(n, 4)) (a drain step of the path-table
+// variant puts up to four operations in flight)
+__device__ __forceinline__ void vm_wait4(uint32_t n)
+{
+    asm volatile("s_cmp_lt_u32 %0, 4 ; VGHOT\n\t"
+                 "s_cbranch_scc1 1f ; VGHOT\n\t"
+                 "s_waitcnt vmcnt(4) ; VGHOT\n\t"
+                 "s_branch 9f ; VGHOT\n"
+                 "1:\n\t"
+                 "s_cmp_lt_u32 %0, 2 ; VGHOT\n\t"
+                 "s_cbranch_scc1 2f ; VGHOT\n\t"
+                 "s_cmp_eq_u32 %0, 2 ; VGHOT\n\t"
+                 "s_cbranch_scc1 3f ; VGHOT\n\t"
+                 "s_waitcnt vmcnt(3) ; VGHOT\n\t"
+                 "s_branch 9f ; VGHOT\n"
+                 "3:\n\t"
+                 "s_waitcnt vmcnt(2) ; VGHOT\n\t"
+                 "s_branch 9f ; VGHOT\n"
+                 "2:\n\t"
+                 "s_cmp_eq_u32 %0, 0 ; VGHOT\n\t"
+                 "s_cbranch_scc1 4f ; VGHOT\n\t"
+                 "s_waitcnt vmcnt(1) ; VGHOT\n\t"
+                 "s_branch 9f ; VGHOT\n"
+                 "4:\n\t"
+                 "s_waitcnt vmcnt(0) ; VGHOT\n"
+                 "9:"
+                 : : "s"(__builtin_amdgcn_readfirstlane((int)n)) : "scc", "memory");
+}
+
 template <bool COMPACT>   // compact table format: the 8-byte k-mer word only
 __device__ __forceinline__ void vm_load_slot(const void* ptr)
 {
@@ -1023,6 +1100,7 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
 #define VG_ROW27S 1024u
 #define VG_RUN_BATCH_S 4u
 
+template <bool PT>   // PT: candidate runs are looked up in the path table (vgmi_ptable.hip); else k-mer by k-mer in the hash table
 __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
 {
     constexpr uint32_t MASK_HI = (1u << (2 * 27 - 32)) - 1;
@@ -1094,7 +1172,194 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
         ++n_after_row;
         n_after_slot = 0;
     };
-    auto drain_step = [&]() __attribute__((always_inline)) {
+    // ================= path-table drain (PT), two levels =================
+    // Level 1, once per <= 64 queued runs, ONE LANE PER RUN: the run's 12-mer is looked up in the index (exact compare), a run
+    // that is not there is dropped (the filter's false positives end here), and every place the index lists becomes one
+    // RESOLVED entry {run bits, validity bits, base}: the k-mer of window w is P[base - 16 + w] if it is a graph k-mer at all.
+    // A read that carries the 12-mer reversed needs no turning round: P holds every chain in both orientations, mirrored
+    // (P[n2 - 1 - i] is the reverse complement of P[i]), so its windows are the consecutive entries from n2 - place on.
+    // The index load is issued when the runs are popped and used an iteration later.
+    // Level 2, per <= 4 resolved entries, one lane per WINDOW: one 16-byte load of P[base - 16 + w] -- 16 consecutive entries
+    // per entry -- then, a step later, the compare on the whole k-mer and the atomic unless the entry is flagged saturated.
+    // What is paid per run is paid by one lane; the 64-lane steps do only what differs from window to window.
+    constexpr uint32_t RQ = 64, ZQ = 48;
+    const uint32_t rq_base = rings0 + wave_u * (VG_RUNQ * 16u + VG_REQ * 8u), zq_base = rq_base + RQ * 16u;
+    const ulonglong2* const ptP = p.table.pt.P;
+    const unsigned long long* const pt_index = p.table.pt.index;
+    const uint32_t pt_n2 = p.table.pt.n2, pt_bshift = 32u - p.table.pt.bucket_log2;
+    uint32_t z_head = 0, z_n = 0;                         // resolved-entry ring (wave-uniform)
+    uint32_t n_after_z = 4, n_after_idx = 4;              // hot operations issued after the last one of a level-2 step / after the index load
+    u32x4 l1_run = {0u, 0u, 0u, 0u};                      // level 1: the run this lane resolves
+    bool l1_pending = false;                              // wave-uniform
+    uint32_t l1_n = 0;
+    const uint32_t vm_shift = my_win < 12u ? 20u + my_win : 16u + my_win;
+    auto hot = [&](uint32_t k) __attribute__((always_inline)) {
+        n_after_row += k;
+        n_after_z += k;
+        n_after_idx += k;
+    };
+    auto slow_count = [&](uint32_t klo, uint32_t khi) __attribute__((always_inline)) {
+        // a run whose 12-mer has more places than the index holds: this window through the hash table, on the spot (rare)
+        const uint64_t kmer = (uint64_t)khi << 32 | klo, rc = vg_revcomp(kmer, 27);
+        const uint64_t canon = kmer < rc ? kmer : rc;
+        uint64_t sl = vg_thash(canon) & cap_mask;
+        for (;;) {
+            const uint4 v = vm_load_slot_sync<true>(&slots8[sl]);
+            const uint64_t c = ((uint64_t)v.y << 32) | v.x;
+            if (c == VG_EMPTY) break;
+            if ((c & VG_SLOT_KMER_MASK) == canon) {
+                if (!(c & VG_SLOT_SAT) && vm_atomic_inc_sync(&counts[sl], one) == 254u) {
+                    vm_atomic_or_sync(reinterpret_cast<uint32_t*>(&slots8[sl]) + 1, (uint32_t)(VG_SLOT_SAT >> 32));
+                    vm_store_byte_sync(p.table.sat_dirty + (sl >> VG_SAT_REGION_LOG2), 1u);
+                }
+                break;
+            }
+            if (!(c & VG_SLOT_CHAIN)) break;
+            sl = (sl + 1) & cap_mask;
+        }
+    };
+    // one level-2 step: TWO batches of <= 4 resolved entries (A: candidate registers v[100:103], B: v[104:107]).  The loads and
+    // atomics a step issues are waited for at the top of the next one; with eight entries per step the steps are an iteration
+    // apart, which is what an L2 round trip under this load needs (a four-entry step every half iteration stalled on it).
+    struct Half { uint32_t lo, hi, idx, q_slot, q_idx; bool h, q_bumped; };
+    Half hA = {0, 0, 0, 0, 0, false, false}, hB = {0, 0, 0, 0, 0, false, false};
+    auto sat_flag = [&](const Half& H, uint32_t old) __attribute__((always_inline)) {
+        // the one increment that took a counter from 254 to 255 flags its k-mer: in the hash table (the generic kernels and the
+        // slow path look there) and in both of its path-table entries
+        const bool sat = H.q_bumped && old == 254u;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(sat) != 0, 0)) {
+            if (sat) {
+                vm_atomic_or_sync(reinterpret_cast<uint32_t*>(&slots8[H.q_slot]) + 1, (uint32_t)(VG_SLOT_SAT >> 32));
+                vm_store_byte_sync(p.table.sat_dirty + (H.q_slot >> VG_SAT_REGION_LOG2), 1u);
+                vm_atomic_or_sync(reinterpret_cast<uint32_t*>(const_cast<ulonglong2*>(&ptP[H.q_idx])) + 1, (uint32_t)(VG_SLOT_SAT >> 32));
+                vm_atomic_or_sync(reinterpret_cast<uint32_t*>(const_cast<ulonglong2*>(&ptP[pt_n2 - 1u - H.q_idx])) + 1, (uint32_t)(VG_SLOT_SAT >> 32));
+            }
+        }
+    };
+    auto step2 = [&]() __attribute__((always_inline)) {
+        vm_wait4(n_after_z);
+        sat_flag(hA, vmp_atomic_old<0>());
+        sat_flag(hB, vmp_atomic_old<1>());
+        // ---- finish: the entries of P have landed
+        {
+            const uint3 ca = vmp_cand_value<0>(), cb = vmp_cand_value<1>();
+            const bool hit_a = hA.h && ca.x == hA.lo && (ca.y & MASK_HI) == hA.hi && !(ca.y >> 31);
+            const bool hit_b = hB.h && cb.x == hB.lo && (cb.y & MASK_HI) == hB.hi && !(cb.y >> 31);
+            hA.q_slot = ca.z;
+            hA.q_idx = hA.idx;
+            hA.q_bumped = hit_a;
+            hB.q_slot = cb.z;
+            hB.q_idx = hB.idx;
+            hB.q_bumped = hit_b;
+            if (__builtin_amdgcn_ballot_w64(hit_a)) {   // wave-uniform: the atomic is issued iff some lane hit
+                if (hit_a) vmp_atomic_inc<0>(&counts[ca.z], one);
+                hot(1);
+            }
+            if (__builtin_amdgcn_ballot_w64(hit_b)) {
+                if (hit_b) vmp_atomic_inc<1>(&counts[cb.z], one);
+                hot(1);
+            }
+        }
+        // ---- issue: up to 2 x 4 resolved entries x 16 windows
+        {
+            const uint32_t take = z_n < 8u ? z_n : 8u;
+            const bool have_a = my_run < take, have_b = my_run + 4u < take;
+            u32x4 ea = {0u, 0u, 0u, 0u}, eb = {0u, 0u, 0u, 0u};
+            uint32_t zs = z_head + my_run;
+            zs = zs >= ZQ ? zs - ZQ : zs;
+            uint32_t zt = zs + 4u;
+            zt = zt >= ZQ ? zt - ZQ : zt;
+            if (have_a) ea = *reinterpret_cast<lds_u4_rw*>((uintptr_t)(zq_base + zs * 16u));
+            if (have_b) eb = *reinterpret_cast<lds_u4_rw*>((uintptr_t)(zq_base + zt * 16u));
+            z_head += take;
+            if (z_head >= ZQ) z_head -= ZQ;
+            z_n -= take;
+            // entry: run bits [0, 84) in x, y, z[0:20); validity bits 0..11 in z[20:32), 12..15 in w[28:32); w[0:19) base; w[19] slow
+            hA.lo = funnel(ea.y, ea.x, my_sh);
+            hA.hi = funnel(ea.z, ea.y, my_sh) & MASK_HI;
+            hB.lo = funnel(eb.y, eb.x, my_sh);
+            hB.hi = funnel(eb.z, eb.y, my_sh) & MASK_HI;
+            const bool off = (VG_DBG(p.dbg) & 512u) != 0;
+            const bool valid_a = have_a && (((my_win < 12u ? ea.z : ea.w) >> vm_shift) & 1u) != 0 && !off;
+            const bool valid_b = have_b && (((my_win < 12u ? eb.z : eb.w) >> vm_shift) & 1u) != 0 && !off;
+            const bool slow_a = valid_a && ((ea.w >> 19) & 1u) != 0, slow_b = valid_b && ((eb.w >> 19) & 1u) != 0;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow_a || slow_b) != 0, 0)) {
+                if (slow_a) slow_count(hA.lo, hA.hi);
+                if (slow_b) slow_count(hB.lo, hB.hi);
+            }
+            hA.idx = (ea.w & 0x7FFFFu) - 16u + my_win;
+            hB.idx = (eb.w & 0x7FFFFu) - 16u + my_win;
+            hA.h = valid_a && !slow_a && hA.idx < pt_n2;
+            hB.h = valid_b && !slow_b && hB.idx < pt_n2;
+            if (__builtin_amdgcn_ballot_w64(hA.h)) {
+                if (hA.h) vmp_load_cand<0>(&ptP[hA.idx]);
+                hot(1);
+            }
+            if (__builtin_amdgcn_ballot_w64(hB.h)) {
+                if (hB.h) vmp_load_cand<1>(&ptP[hB.idx]);
+                hot(1);
+            }
+        }
+        n_after_z = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
+    // level 1, first half: every lane takes one queued run and asks for its index bucket
+    auto resolve_issue = [&]() __attribute__((always_inline)) {
+        l1_n = run_n < 64u ? run_n : 64u;
+        if (lane < l1_n) {
+            l1_run = *reinterpret_cast<lds_u4_rw*>((uintptr_t)(rq_base + ((run_head + lane) & (RQ - 1u)) * 16u));
+            vmp_load_index(pt_index + ((uint64_t)(vg_mul24(l1_run.w & 0xFFFFFFu, 0x9E3779u) >> pt_bshift) << 1));
+        }
+        run_head = (run_head + l1_n) & (RQ - 1u);
+        run_n -= l1_n;
+        hot(1);
+        n_after_idx = 0;
+        l1_pending = true;
+        __builtin_amdgcn_wave_barrier();
+    };
+    // level 1, second half: the buckets have landed; the resolved entries go into their ring (level-2 steps make room)
+    auto resolve_finish = [&]() __attribute__((always_inline)) {
+        vm_wait4(n_after_idx);
+        const uint4 ix = vmp_index_value();
+        const uint32_t cx = l1_run.w & 0xFFFFFFu;
+        const bool act = lane < l1_n;
+        const bool as_is = ((l1_run.w >> 24) & 1u) != 0;
+        const bool m0 = ((ix.x ^ cx) & 0xFFFFFFu) == 0 && (((ix.x >> 24) | (ix.y << 8)) & 0x7FFFFu) != 0;
+        const bool m1 = ((ix.z ^ cx) & 0xFFFFFFu) == 0 && (((ix.z >> 24) | (ix.w << 8)) & 0x7FFFFu) != 0;
+        const uint32_t wl = m0 ? ix.x : ix.z, wh = m0 ? ix.y : ix.w;
+        const uint32_t pa = ((wl >> 24) | (wh << 8)) & 0x7FFFFu, pb = (wh >> 11) & 0x7FFFFu;
+        const bool found = m0 || m1;
+        // more places than the entry holds, or a 12-mer that found no entry in its bucket: the hash table decides, window by window
+        const bool slow = act && (found ? pb == 0x7FFFFu : ((ix.y >> 30) & 1u) != 0) && !(VG_DBG(p.dbg) & 1024u);
+        const bool ok = act && found && pb != 0x7FFFFu && !(VG_DBG(p.dbg) & 1024u);
+        // window w of the run is P[place - 16 + w] when the read carries the 12-mer as the index has it, P[n2 - place + w] otherwise
+        const uint32_t base_a = as_is ? pa : pt_n2 + 16u - pa, base_b = as_is ? pb : pt_n2 + 16u - pb;
+        const uint32_t wz = l1_run.w & 0xF0000000u;
+        // three kinds of entry (first place, second place, hash-table fallback), each pushed in two halves of the wavefront so that
+        // a round never needs more room than the ring has; ONE copy of the code (a level-2 step sits inside)
+#pragma unroll 1
+        for (uint32_t round = 0; round < 6u; ++round) {
+            const uint32_t kind = round >> 1;
+            const bool pred = kind == 0u ? ok : kind == 1u ? (ok && pb != 0) : slow;
+            const uint32_t w_word = wz | (kind == 0u ? base_a : kind == 1u ? base_b : (1u << 19));
+            const bool mine = pred && (lane >> 5) == (round & 1u);
+            const uint64_t ball = __builtin_amdgcn_ballot_w64(mine);
+            if (ball == 0) continue;
+            const uint32_t n = (uint32_t)__builtin_popcountll(ball);
+            while (z_n + n > ZQ) step2();
+            if (mine) {
+                uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, z_head + z_n));
+                pos = pos >= ZQ ? pos - ZQ : pos;
+                pos = pos >= ZQ ? pos - ZQ : pos;
+                *reinterpret_cast<lds_u4_rw*>((uintptr_t)(zq_base + pos * 16u)) = u32x4{l1_run.x, l1_run.y, l1_run.z, w_word};
+            }
+            z_n += n;
+            __builtin_amdgcn_wave_barrier();
+        }
+        l1_pending = false;
+    };
+
+    auto drain_hash = [&]() __attribute__((always_inline)) {
         vm_wait(n_after_slot);
         {
             // the previous step's atomics have returned (issued before the loads just waited for): the one increment that
@@ -1183,8 +1448,15 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
         __builtin_amdgcn_wave_barrier();
     };
 
+    auto drain_step = [&]() __attribute__((always_inline)) { drain_hash(); };
+    // path table: the run ring is emptied by level 1 in one go (after the round before it has been finished)
+    auto make_room = [&]() __attribute__((always_inline)) {
+        if (l1_pending) resolve_finish();
+        resolve_issue();
+    };
+
     // scan of one row once its words and its neighbours' are known: validity of the 16 windows, grid probe
-    struct RowScan { uint32_t W0, W1, W2, vm, gm, gw32; };
+    struct RowScan { uint32_t W0, W1, W2, vm, gm, gw32, cm; };   // cm: canonical 12-mer | (the read carries it as it stands) << 24
     auto scan_probe = [&](uint32_t be, uint32_t inv, uint32_t be1, uint32_t be2, uint32_t i1, uint32_t i2) __attribute__((always_inline)) -> RowScan {
         RowScan r;
         r.W0 = be;
@@ -1197,9 +1469,13 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
         const uint32_t a = (inv << 1) & 0xFFFFu;
         const uint32_t bad_b = B ? (0xFFFFFFFFu >> __builtin_clz(B)) : 0u;
         r.vm = ~(a | (0u - a) | bad_b) & 0xFFFFu;
-        uint32_t gx;
-        vg_grid12_probe(be1 & 0xFFFFFFu, gx, r.gm);
-        r.gw32 = *reinterpret_cast<lds_u32*>((uintptr_t)((gx << 2) + VG_LUT27_BYTES));
+        // vg_grid12_probe (vgmi_device.h), with the canonical form kept for the run's entry
+        const uint32_t mer = be1 & 0xFFFFFFu, rcm = vg_revcomp12(mer);
+        const uint32_t cm = mer < rcm ? mer : rcm;
+        r.cm = cm | (mer <= rcm ? 1u << 24 : 0u);
+        const uint32_t h1 = vg_mul24(cm, 0x9E3779u), h2 = vg_mul24(cm, 0x85EBCBu);
+        r.gm = (1u << (h2 >> 27)) | (1u << ((h2 >> 22) & 31u)) | (1u << ((h2 >> 17) & 31u));
+        r.gw32 = *reinterpret_cast<lds_u32*>((uintptr_t)(((h1 >> (32 - VG_GRID_LDS_WORDS_LOG2)) << 2) + VG_LUT27_BYTES));
         return r;
     };
     auto enqueue = [&](const RowScan& r, uint64_t ball, uint32_t tail) __attribute__((always_inline)) {
@@ -1208,7 +1484,11 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
             const uint32_t d1 = funnel(r.W2, r.W1, 2);
             const uint32_t d2 = r.W2 >> 2;
             const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, tail));
-            *reinterpret_cast<lds_u4_rw*>((uintptr_t)(runs_base + ring_slot(pos) * 16u)) = u32x4{d0, d1, d2, r.vm};
+            if (PT)   // run bits [0, 84) | validity bits 0..11 in z[20:32), 12..15 in w[28:32) | canonical 12-mer and its orientation in w[0:25)
+                *reinterpret_cast<lds_u4_rw*>((uintptr_t)(rq_base + (pos & (RQ - 1u)) * 16u)) =
+                    u32x4{d0, d1, (d2 & 0xFFFFFu) | (r.vm << 20), r.cm | ((r.vm >> 12) << 28)};
+            else
+                *reinterpret_cast<lds_u4_rw*>((uintptr_t)(runs_base + ring_slot(pos) * 16u)) = u32x4{d0, d1, d2, r.vm};
         }
     };
     auto empty_read_check = [&](uint32_t adj, const uint8_t* row) __attribute__((always_inline)) {
@@ -1229,7 +1509,9 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
     vms_load_row<0>(rowp + lane_off);
     vms_load_row<1>(rowp + VG_ROW27S + lane_off);
     for (uint32_t it = 0; it < n_it; ++it) {
-        vm_wait(n_after_row);   // both rows have landed once at most n_after_row younger operations are outstanding
+        // both rows have landed once at most n_after_row younger operations are outstanding
+        if (PT) vm_wait4(n_after_row);
+        else vm_wait(n_after_row);
         const Addr4 a0 = luts_addr4<0, 0>(one), a1 = luts_addr4<0, 1>(one), a2 = luts_addr4<0, 2>(one), a3 = luts_addr4<0, 3>(one);
         const Addr4 c0 = luts_addr4<1, 0>(one), c1 = luts_addr4<1, 1>(one), c2 = luts_addr4<1, 2>(one), c3 = luts_addr4<1, 3>(one);
         const uint8_t* const cur = rowp;
@@ -1238,7 +1520,11 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
         vms_load_row<1>(rowp + VG_ROW27S + lane_off);
         n_after_row = 0;
         n_after_slot += 2;
-        if (run_n >= VG_RUN_BATCH_S || req_n >= 32u) drain_step();
+        if (PT) {
+            n_after_z += 2;
+            n_after_idx += 2;
+            if (z_n >= 8u) step2();
+        } else if (run_n >= VG_RUN_BATCH_S || req_n >= 32u) drain_step();
 
         // own 16 bases of each row: be = 32 bits, first base most significant; inv bit t = base t is not a base.
         // LUT sets (stage_lut27): A puts a dword's four non-base flags at bits 8..11, B at bits 12..15
@@ -1249,7 +1535,7 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
         const uint32_t beB = __builtin_amdgcn_perm(__builtin_amdgcn_perm(h0, h1, 0x0c0c0400u), __builtin_amdgcn_perm(h2, h3, 0x0c0c0400u), 0x05040100u);
         const uint32_t invB = (((h0 | h1) >> 8) & 0xFFu) | ((h2 | h3) & 0xFF00u);
         auto ror1 = [](uint32_t v) __attribute__((always_inline)) -> uint32_t {
-            return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
+            return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x13C /* wave_ror:1: every lane has a source, no "old" value to set up */, 0xF, 0xF, false);
         };
         const uint32_t a1_be = ror1(beA), a1_inv = ror1(invA), b1_be = ror1(beB), b1_inv = ror1(invB);
         const uint32_t a2_be = ror1(a1_be), a2_inv = ror1(a1_inv), b2_be = ror1(b1_be), b2_inv = ror1(b1_inv);
@@ -1277,6 +1563,20 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
         const uint64_t ballB = __builtin_amdgcn_ballot_w64((sb.gw32 & sb.gm) == sb.gm && sb.vm != 0);
         const uint32_t nA = (uint32_t)__builtin_popcountll(ballA), nB = (uint32_t)__builtin_popcountll(ballB);
         if (VG_DBG(p.dbg) & 1u) continue;
+        if (PT) {
+            if (run_n + nA > RQ) make_room();
+            enqueue(sa, ballA, run_head + run_n);
+            run_n += nA;
+            if (run_n + nB > RQ) make_room();
+            enqueue(sb, ballB, run_head + run_n);
+            run_n += nB;
+            // level 1: ask at the end of one iteration, use at the end of the next (the bucket loads have a whole iteration)
+            if (l1_pending) resolve_finish();
+            else if (run_n >= 40u) resolve_issue();
+            if (z_n >= 8u) step2();
+            while (z_n >= 32u) step2();           // dense stretches: keep the ring short
+            continue;
+        }
         enqueue(sa, ballA, run_head + run_n);
         run_n += nA;
         while (run_n + nB > VG_RUNQ) drain_step();   // make room for row B's runs (only rows dense in candidates need this)
@@ -1285,9 +1585,19 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
         if (run_n >= VG_RUN_BATCH_S || req_n >= 32u) drain_step();
         while (run_n >= 3 * VG_RUN_BATCH_S || req_n >= 48u) drain_step();   // dense stretches: keep the rings short
     }
-    do {   // flush: until the rings are empty and the last step issued nothing (finishing a batch can re-queue)
-        drain_step();
-    } while (run_n != 0 || req_n != 0 || __builtin_amdgcn_ballot_w64(b_active) != 0);
+    if (PT) {   // flush: both levels until nothing is queued or in flight
+        while (run_n != 0 || l1_pending) {
+            if (l1_pending) resolve_finish();
+            if (run_n != 0) resolve_issue();
+        }
+        do {
+            step2();
+        } while (z_n != 0 || __builtin_amdgcn_ballot_w64(hA.h || hB.h || hA.q_bumped || hB.q_bumped) != 0);
+    } else {
+        do {   // flush: until the rings are empty and the last step issued nothing (finishing a batch can re-queue)
+            drain_step();
+        } while (run_n != 0 || req_n != 0 || __builtin_amdgcn_ballot_w64(b_active) != 0);
+    }
     vm_wait_imm<0>();
 }
 
@@ -1655,9 +1965,11 @@ static hipError_t launch_count27_t(const RowParams& p, uint32_t grid, uint32_t b
 hipError_t launch_count27s(const RowParams& p, uint32_t grid, hipStream_t st)
 {
     const size_t lds = (size_t)VG_GRID_LDS_WORDS * 4 + (size_t)16 * (VG_RUNQ * 16 + VG_REQ * 8) + VG_LUT27_BYTES;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&count27s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const void* fn = p.table.pt.index ? reinterpret_cast<const void*>(&count27s_kernel<true>) : reinterpret_cast<const void*>(&count27s_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(count27s_kernel, dim3(grid), dim3(1024), lds, st, p);
+    if (p.table.pt.index) hipLaunchKernelGGL(count27s_kernel<true>, dim3(grid), dim3(1024), lds, st, p);
+    else hipLaunchKernelGGL(count27s_kernel<false>, dim3(grid), dim3(1024), lds, st, p);
     return hipGetLastError();
 }
 
