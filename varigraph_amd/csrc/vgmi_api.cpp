@@ -78,8 +78,10 @@ struct vgmi_ctx {
     uint32_t* d_xt_counts = nullptr;
     uint32_t* d_xt_id = nullptr;                // key index -> counter id (path order), nullptr: identity
     ulonglong2* d_xt_over = nullptr;            // exact table of the k-mers that overflowed their lines (repeats), or nullptr
-    unsigned long long* d_pt_index = nullptr;   // path table of small graphs (vgmi_ptable.hip): 12-mer -> places in d_pt_P
-    ulonglong2* d_pt_P = nullptr;               // the k-mers along their unitigs, both orientations
+    unsigned long long* d_pt_index = nullptr;   // path table of small graphs (build_ptable): 12-mer -> places in the unitig sequence
+    uint32_t *d_pt_S = nullptr, *d_pt_VB = nullptr, *d_pt_SB = nullptr, *d_pt_SLOT = nullptr;   // sequence, k-mer starts, saturation bits, slots
+    size_t pt_sb_bytes = 0;
+    uint64_t pt_slow_cx = 0, pt_bucket_ovf = 0;  // 12-mers with more than two places / buckets with a third 12-mer (those runs take the hash table)
     uint64_t xt_over_keys = 0;                  // pairs (key, 16-mer) that overflowed in the last build
     uint8_t* d_sat_dirty = nullptr;   // compact format: 2048-slot regions holding a saturation flag (the reset sweeps those)
     uint64_t n_sat_regions = 0;
@@ -187,10 +189,10 @@ void free_table(vgmi_ctx* c)
     if (c->d_xt_over) (void)hipFree(c->d_xt_over);
     c->d_xt_over = nullptr;
     c->xt_over_keys = 0;
-    if (c->d_pt_index) (void)hipFree(c->d_pt_index);
-    if (c->d_pt_P) (void)hipFree(c->d_pt_P);
+    for (void* q : {(void*)c->d_pt_index, (void*)c->d_pt_S, (void*)c->d_pt_VB, (void*)c->d_pt_SB, (void*)c->d_pt_SLOT})
+        if (q) (void)hipFree(q);
     c->d_pt_index = nullptr;
-    c->d_pt_P = nullptr;
+    c->d_pt_S = c->d_pt_VB = c->d_pt_SB = c->d_pt_SLOT = nullptr;
     c->tv.pt = PathView{};
     c->d_xt_lines = nullptr;
     c->d_xt_counts = nullptr;
@@ -444,7 +446,8 @@ int build_xtable(vgmi_ctx* c)
 }
 
 // the path table of small graphs, derived from the compact image like the grid-16-mer table of large ones (after an upload,
-// an import and a clone alike); VGMI_PTABLE=0 keeps count27s_kernel on the hash table alone (A/B)
+// an import and a clone alike); VGMI_PTABLE=0 keeps count27s_kernel on the hash table alone (A/B).  The device orders the
+// k-mers along their unitigs (vgmi_ptable.hip); the layout of the sequence and the index is host work over <= 65 536 k-mers.
 int build_ptable(vgmi_ctx* c)
 {
     const ImageHeader& h = c->hdr;
@@ -453,18 +456,20 @@ int build_ptable(vgmi_ctx* c)
     if (const char* e = getenv("VGMI_PTABLE"))
         if (e[0] == '0') return VGMI_OK;
     const uint64_t n = h.n_keys;
-    const uint32_t bucket_log2 = 17;      // 2 MiB of index for <= 65 536 k-mers (~7e4 distinct canonical 12-mers: a third bucket entry is wanted in ~2 % of the buckets)
+    // 8 MiB of index for a 6.5e4-k-mer graph (~7e4 distinct canonical 12-mers: a third 12-mer is wanted in ~0.3 % of the buckets; at
+    // half the size it was 1 %, and every run of such a 12-mer took the hash table: 1.8 ms of 6.0 per 1e8 reads, measured)
+    uint32_t bucket_log2 = 13;
+    while (bucket_log2 < 18 && (1ull << bucket_log2) < 4 * n) ++bucket_log2;      // >= 4 buckets per k-mer
     uint32_t *key_of_slot = nullptr, *link = nullptr, *link2 = nullptr, *pos = nullptr, *mark = nullptr;
     unsigned long long* cursor = nullptr;
+    ulonglong2* d_P = nullptr;
     hipError_t he = hipMalloc(reinterpret_cast<void**>(&key_of_slot), h.cap * 4);
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&link), n * 8);
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&link2), n * 8);
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&pos), n * 4);
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&mark), n * 4);
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&cursor), 8);
-    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&c->d_pt_P), 2 * n * sizeof(ulonglong2));
-    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&c->d_pt_index), (size_t)16 << bucket_log2);
-    if (he == hipSuccess) he = hipMemsetAsync(c->d_pt_index, 0, (size_t)16 << bucket_log2, c->stream);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&d_P), 2 * n * sizeof(ulonglong2));
     if (he == hipSuccess) he = hipMemsetAsync(pos, 0xFF, n * 4, c->stream);
     if (he == hipSuccess) he = hipMemsetAsync(mark, 0, n * 4, c->stream);
     if (he == hipSuccess) he = hipMemsetAsync(cursor, 0, 8, c->stream);
@@ -476,15 +481,122 @@ int build_ptable(vgmi_ctx* c)
     if (he == hipSuccess) he = hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost);
     const bool ordered = !(st & 16u) && used == n;      // else (cannot happen): chains of one, in key order -- any layout is correct
     if (he == hipSuccess && (st & 16u)) he = hipMemsetAsync(c->d_status, 0, 4, c->stream);
-    if (he == hipSuccess) he = launch_ptable_fill(c->tv, c->d_key_slot, ordered ? pos : nullptr, n, c->d_pt_P, c->d_pt_index, bucket_log2, c->stream);
+    if (he == hipSuccess) he = launch_ptable_fill(c->tv, c->d_key_slot, ordered ? pos : nullptr, n, d_P, c->stream);
+    std::vector<ulonglong2> P(2 * n);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-    for (void* q : {(void*)key_of_slot, (void*)link, (void*)link2, (void*)pos, (void*)mark, (void*)cursor})
+    if (he == hipSuccess) he = hipMemcpy(P.data(), d_P, 2 * n * sizeof(ulonglong2), hipMemcpyDeviceToHost);
+    for (void* q : {(void*)key_of_slot, (void*)link, (void*)link2, (void*)pos, (void*)mark, (void*)cursor, (void*)d_P})
         if (q) (void)hipFree(q);
     HIPCHK(c, he);
+
+    // ---- layout (host).  P[0, n): the k-mers chain after chain, each in the orientation its chain is walked in; P[2n - 1 - i] is
+    // the reverse complement of P[i].  A chain of L k-mers is L + 26 bases; the chains follow each other without a gap, the
+    // second half of S is the reverse complement of the first, 32 bases of padding at either end.
+    const uint64_t M54 = (1ULL << 54) - 1;
+    std::vector<uint32_t> kpos(n);
+    uint64_t chains = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t a = i ? (uint64_t)P[i - 1].x & M54 : 0, b = (uint64_t)P[i].x & M54;
+        if (i == 0 || (b >> 2) != (a & (M54 >> 2))) ++chains;
+        kpos[i] = (uint32_t)(i + 26 * (chains - 1));
+    }
+    const uint64_t Th = n + 26 * chains, T = 2 * Th, Tp = T + 64;
+    if (Tp + 64 >= (1u << 19) - 1) return VGMI_OK;      // places are 19-bit fields: a graph of very many very short chains keeps the hash table
+    std::vector<uint8_t> base(Tp, 0), vb(Tp, 0);
+    std::vector<uint32_t> slot(Tp, 0), chain_end(Tp, 0);       // chain_end[start of a chain's span] = its end (first half, unpadded)
+    {
+        uint64_t span_start = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint64_t km = (uint64_t)P[i].x & M54;
+            for (uint32_t t = 0; t < 27; ++t) base[32 + kpos[i] + t] = (uint8_t)((km >> (2 * (26 - t))) & 3u);
+            vb[32 + kpos[i]] = 1;
+            slot[32 + kpos[i]] = (uint32_t)P[i].y;
+            vb[32 + T - 27 - kpos[i]] = 1;
+            slot[32 + T - 27 - kpos[i]] = (uint32_t)P[i].y;
+            const bool last_of_chain = i + 1 == n || kpos[i + 1] != kpos[i] + 1;
+            if (last_of_chain) {
+                chain_end[span_start] = (uint32_t)(kpos[i] + 27);
+                span_start = kpos[i] + 27;
+            }
+        }
+        for (uint64_t j = 0; j < Th; ++j) base[32 + T - 1 - j] = (uint8_t)(3u - base[32 + j]);
+        for (uint64_t j = 0; j < 32; ++j) base[Tp - 1 - j] = (uint8_t)(3u - base[j]);     // the pads mirror each other too (zeros / threes)
+    }
+    const size_t s_words = (size_t)(Tp + 15) / 16 + 8, b_words = (size_t)(Tp + 31) / 32 + 4;
+    std::vector<uint32_t> S(s_words, 0), VB(b_words, 0);
+    for (uint64_t j = 0; j < Tp; ++j) {
+        S[j >> 4] |= (uint32_t)base[j] << (2 * (15 - (j & 15)));
+        if (vb[j]) VB[j >> 5] |= 1u << (j & 31);
+    }
+    // index: every occurrence of a 12-mer inside a chain's span that reads as its canonical form lists the place of the run's
+    // first base (15 bases in front of it); the occurrence on the other strand is listed from the mirrored half
+    // bucket = two 16-byte entries.  Entry: word 0 = 12-mer | place 0 << 24 | place 1 << 43 | (first entry only) "a 12-mer found no
+    // entry here" << 62; word 1 = place 2 | place 3 << 19 | "more than four places" << 38.  Place 0 = 0: the entry is free.
+    std::vector<unsigned long long> index((size_t)4 << bucket_log2, 0ULL);
+    uint64_t slow_cx = 0, bucket_ovf = 0;
+    auto add = [&](uint32_t x, uint32_t place) {
+        unsigned long long* B = &index[(size_t)(vg_mul24(x, 0x9E3779u) >> (32 - bucket_log2)) << 2];
+        for (int e = 0; e < 2; ++e) {
+            unsigned long long& lo = B[2 * e];
+            unsigned long long& hi = B[2 * e + 1];
+            const uint32_t q0 = (uint32_t)(lo >> 24) & 0x7FFFFu, q1 = (uint32_t)(lo >> 43) & 0x7FFFFu;
+            const uint32_t q2 = (uint32_t)hi & 0x7FFFFu, q3 = (uint32_t)(hi >> 19) & 0x7FFFFu;
+            if (q0 == 0) {
+                lo = (lo & (1ULL << 62)) | x | (unsigned long long)place << 24;
+                return;
+            }
+            if (((uint32_t)lo & 0xFFFFFFu) != x) continue;
+            if (q1 == 0) lo |= (unsigned long long)place << 43;
+            else if (q2 == 0) hi |= place;
+            else if (q3 == 0) hi |= (unsigned long long)place << 19;
+            else if (!(hi >> 38 & 1)) {
+                hi |= 1ULL << 38;              // a fifth place: runs with this 12-mer take the hash table
+                ++slow_cx;
+            }
+            return;
+        }
+        if (!(B[0] >> 62 & 1)) ++bucket_ovf;
+        B[0] |= 1ULL << 62;                    // a third 12-mer in this bucket: lookups that miss here take the hash table
+    };
+    for (uint64_t s0 = 0; s0 < Th;) {
+        const uint64_t e0 = chain_end[s0];
+        for (int halfno = 0; halfno < 2; ++halfno) {
+            const uint64_t lo = halfno ? T - e0 : s0, hi = halfno ? T - s0 : e0;      // the chain's span in this half (unpadded)
+            uint32_t x = 0;
+            for (uint64_t b = lo; b < hi; ++b) {
+                x = ((x << 2) | base[32 + b]) & 0xFFFFFFu;
+                if (b + 1 < lo + 12) continue;
+                const uint64_t first = b + 1 - 12;                       // the 12-mer is bases first .. first + 11
+                if (x <= vg_revcomp12(x)) add(x, (uint32_t)(32 + first - 15));
+            }
+        }
+        s0 = e0;
+    }
+    c->pt_slow_cx = slow_cx;
+    c->pt_bucket_ovf = bucket_ovf;
+    he = hipMalloc(reinterpret_cast<void**>(&c->d_pt_index), index.size() * 8);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&c->d_pt_S), S.size() * 4);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&c->d_pt_VB), VB.size() * 4);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&c->d_pt_SB), VB.size() * 4);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&c->d_pt_SLOT), (size_t)(Tp + 64) * 4);
+    if (he == hipSuccess) he = hipMemcpy(c->d_pt_index, index.data(), index.size() * 8, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemcpy(c->d_pt_S, S.data(), S.size() * 4, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemcpy(c->d_pt_VB, VB.data(), VB.size() * 4, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemset(c->d_pt_SB, 0, VB.size() * 4);
+    if (he == hipSuccess) he = hipMemset(c->d_pt_SLOT, 0, (size_t)(Tp + 64) * 4);
+    if (he == hipSuccess) he = hipMemcpy(c->d_pt_SLOT, slot.data(), (size_t)Tp * 4, hipMemcpyHostToDevice);
+    HIPCHK(c, he);
+    c->pt_sb_bytes = VB.size() * 4;
+    if (getenv("VGMI_VERBOSE"))
+        fprintf(stderr, "[vgmi] path table: %llu k-mers in %llu chains, %llu bases, %llu 12-mers with a fifth place, %llu buckets with a third 12-mer\n",
+                (unsigned long long)n, (unsigned long long)chains, (unsigned long long)Tp, (unsigned long long)slow_cx, (unsigned long long)bucket_ovf);
     c->tv.pt.index = c->d_pt_index;
-    c->tv.pt.P = c->d_pt_P;
+    c->tv.pt.S = c->d_pt_S;
+    c->tv.pt.VB = c->d_pt_VB;
+    c->tv.pt.SB = c->d_pt_SB;
+    c->tv.pt.SLOT = c->d_pt_SLOT;
     c->tv.pt.bucket_log2 = bucket_log2;
-    c->tv.pt.n2 = (uint32_t)(2 * n);
+    c->tv.pt.Tp = (uint32_t)Tp;
     return VGMI_OK;
 }
 
@@ -985,7 +1097,7 @@ int vgmi_counts_reset(vgmi_ctx* c)
     if (c->tv.xt.lines) HIPCHK(c, hipMemsetAsync(c->d_xt_counts, 0, c->hdr.n_keys * 4, c->stream));
     if (c->d_counts) HIPCHK(c, hipMemsetAsync(c->d_counts, 0, c->n_counts * 4, c->stream));
     if (!c->tv.xt.lines && (!c->d_counts || c->tv.slots8)) HIPCHK(c, launch_counts_reset(c->tv, c->stream));   // in-slot counters / saturation flags
-    if (c->tv.pt.P) HIPCHK(c, launch_ptable_reset(c->tv.pt.P, c->tv.pt.n2, c->stream));                         // ... and their copies in the path table
+    if (c->tv.pt.SB) HIPCHK(c, hipMemsetAsync(c->d_pt_SB, 0, c->pt_sb_bytes, c->stream));                       // ... and their copies in the path table
     HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4, c->stream));
     // host blocks are counted on the stages' own (non-blocking) streams: their next launch waits for this reset
     HIPCHK(c, hipEventRecord(c->reset_done, c->stream));

@@ -34,12 +34,15 @@ struct XTableView {
     uint32_t over_mask;          // its capacity - 1 (a power of two)
 };
 
-// path table of small graphs (vgmi_ptable.hip): what count27s_kernel looks candidate runs up in
+// path table of small graphs (vgmi_ptable.hip, build_ptable in vgmi_api.cpp): what count27s_kernel<true> checks candidate runs against
 struct PathView {
-    const unsigned long long* index;   // 2 << bucket_log2 entries, or nullptr: not in use
-    ulonglong2* P;                     // n2 entries {k-mer word | saturation flag, table slot}; P[n2 - 1 - i] = reverse complement of P[i]
+    const unsigned long long* index;   // 2 << bucket_log2 entries {12-mer : 24, place a : 19, place b : 19}, or nullptr: not in use
+    const uint32_t* S;                 // the graph's unitigs, both orientations, 2 bits per base, 16 bases per word (first base most significant)
+    const uint32_t* VB;                // bit per base position: a graph k-mer starts here
+    uint32_t* SB;                      // bit per base position: ... and its counter has reached the clamp (per sample)
+    const uint32_t* SLOT;              // per base position: the hash-table slot of the k-mer that starts here
     uint32_t bucket_log2;
-    uint32_t n2;
+    uint32_t Tp;                       // bases in S, pads included: S[Tp - 1 - j] is the complement of S[j]
 };
 
 struct TableView {
@@ -191,9 +194,7 @@ hipError_t launch_count27(bool lds_bitmap, const RowParams& p, uint32_t grid, ui
 hipError_t launch_count27s(const RowParams& p, uint32_t grid, hipStream_t st);   // small graphs: 12-mer grid, 1 024-byte rows
 hipError_t launch_ptable_order(const TableView& t, const uint32_t* key_slot, uint64_t n, uint32_t* key_of_slot, uint32_t* link, uint32_t* link2,
                                uint32_t* pos_of_key, unsigned long long* cursor, uint32_t* mark, uint32_t* status, hipStream_t st);
-hipError_t launch_ptable_fill(const TableView& t, const uint32_t* key_slot, const uint32_t* pos_of_key, uint64_t n, ulonglong2* P,
-                              unsigned long long* index, uint32_t bucket_log2, hipStream_t st);
-hipError_t launch_ptable_reset(ulonglong2* P, uint64_t n2, hipStream_t st);
+hipError_t launch_ptable_fill(const TableView& t, const uint32_t* key_slot, const uint32_t* pos_of_key, uint64_t n, ulonglong2* P, hipStream_t st);
 hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t launch_bloom_even(const RowParams& p, hipStream_t st);   // even k, one long sequence (K3)
 hipError_t launch_seq(int mode, const RowParams& p, const uint64_t* read_off, uint64_t n_reads, hipStream_t st);

@@ -527,45 +527,74 @@ __device__ __forceinline__ uint32_t vms_atomic_old()   // return value of the la
     return v;
 }
 
-// path-table drain of count27s_kernel<true>: index pair v[108:111], candidate entries v[100:103] / v[104:107], atomic return v112
-#define VG_HOT_CLOBBERS_P "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", VG_HOT_CLOBBERS_S
-__device__ __forceinline__ void vmp_load_index(const void* ptr)
+// path-table drain of count27s_kernel<true>: the index bucket's two entries v[108:111], v[112:115]; per place (0..3) 16 bytes of
+// sequence v[92 + 4 c : 95 + 4 c], the words with the k-mer-start bits v[76 + 4 c : 77 + 4 c] and with the saturation bits v[78 + 4 c : 79 + 4 c]
+#define VG_HOT_CLOBBERS_P "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", \
+                          "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", \
+                          "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", VG_HOT_CLOBBERS_S
+__device__ __forceinline__ void vmp_load_index(const void* ptr)     // 32 bytes: both entries of the bucket
 {
-    asm volatile("global_load_dwordx4 v[108:111], %0, off ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS_P);
+    asm volatile("global_load_dwordx4 v[108:111], %0, off ; VGHOT\n\tglobal_load_dwordx4 v[112:115], %0, off offset:16 ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS_P);
 }
-template <int C>
-__device__ __forceinline__ void vmp_load_cand(const void* ptr)
+#define VG_SEQ_ASM(C, SQ, VBR, SBR) \
+    if (c == C) asm volatile("global_load_dwordx4 " SQ ", %0, off ; VGHOT\n\tglobal_load_dwordx2 " VBR ", %1, off ; VGHOT\n\tglobal_load_dwordx2 " SBR ", %2, off ; VGHOT" \
+                             : : "v"(sq), "v"(vb), "v"(sb) : VG_HOT_CLOBBERS_P)
+template <int c>
+__device__ __forceinline__ void vmp_load_place(const void* sq, const void* vb, const void* sb)     // three loads
 {
-    if (C == 0) asm volatile("global_load_dwordx4 v[100:103], %0, off ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS_P);
-    else asm volatile("global_load_dwordx4 v[104:107], %0, off ; VGHOT" : : "v"(ptr) : VG_HOT_CLOBBERS_P);
+    VG_SEQ_ASM(0, "v[92:95]", "v[76:77]", "v[78:79]");
+    VG_SEQ_ASM(1, "v[96:99]", "v[80:81]", "v[82:83]");
+    VG_SEQ_ASM(2, "v[100:103]", "v[84:85]", "v[86:87]");
+    VG_SEQ_ASM(3, "v[104:107]", "v[88:89]", "v[90:91]");
 }
-template <int C>
-__device__ __forceinline__ void vmp_atomic_inc(uint32_t* ptr, uint32_t one)
-{
-    if (C == 0) asm volatile("global_atomic_add v112, %0, %1, off sc0 ; VGHOT" : : "v"(ptr), "v"(one) : "memory", VG_HOT_CLOBBERS_P);
-    else asm volatile("global_atomic_add v113, %0, %1, off sc0 ; VGHOT" : : "v"(ptr), "v"(one) : "memory", VG_HOT_CLOBBERS_P);
-}
+#define VG_MOV4(A, B, C, D) asm volatile("v_mov_b32 %0, " A " ; VGHOT\n\tv_mov_b32 %1, " B " ; VGHOT\n\tv_mov_b32 %2, " C " ; VGHOT\n\tv_mov_b32 %3, " D " ; VGHOT" \
+                                         : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w))
+template <int e>
 __device__ __forceinline__ uint4 vmp_index_value()
 {
     uint4 v;
-    asm volatile("v_mov_b32 %0, v108 ; VGHOT\n\tv_mov_b32 %1, v109 ; VGHOT\n\tv_mov_b32 %2, v110 ; VGHOT\n\tv_mov_b32 %3, v111 ; VGHOT"
-                 : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w));
+    if (e == 0) VG_MOV4("v108", "v109", "v110", "v111");
+    else VG_MOV4("v112", "v113", "v114", "v115");
     return v;
 }
-template <int C>
-__device__ __forceinline__ uint3 vmp_cand_value()     // {k-mer word lo, hi, slot}
+template <int c>
+__device__ __forceinline__ uint4 vmp_seq_value()
 {
-    uint3 v;
-    if (C == 0) asm volatile("v_mov_b32 %0, v100 ; VGHOT\n\tv_mov_b32 %1, v101 ; VGHOT\n\tv_mov_b32 %2, v102 ; VGHOT" : "=v"(v.x), "=v"(v.y), "=v"(v.z));
-    else asm volatile("v_mov_b32 %0, v104 ; VGHOT\n\tv_mov_b32 %1, v105 ; VGHOT\n\tv_mov_b32 %2, v106 ; VGHOT" : "=v"(v.x), "=v"(v.y), "=v"(v.z));
+    uint4 v;
+    if (c == 0) VG_MOV4("v92", "v93", "v94", "v95");
+    if (c == 1) VG_MOV4("v96", "v97", "v98", "v99");
+    if (c == 2) VG_MOV4("v100", "v101", "v102", "v103");
+    if (c == 3) VG_MOV4("v104", "v105", "v106", "v107");
     return v;
 }
-template <int C>
-__device__ __forceinline__ uint32_t vmp_atomic_old()
+template <int c>
+__device__ __forceinline__ uint4 vmp_bits_value()     // {start bits lo, hi, saturation bits lo, hi}
+{
+    uint4 v;
+    if (c == 0) VG_MOV4("v76", "v77", "v78", "v79");
+    if (c == 1) VG_MOV4("v80", "v81", "v82", "v83");
+    if (c == 2) VG_MOV4("v84", "v85", "v86", "v87");
+    if (c == 3) VG_MOV4("v88", "v89", "v90", "v91");
+    return v;
+}
+// rare path of the path-table drain: four independent dword loads / four returning atomic increments, one wait for all
+__device__ __forceinline__ void vm_load_dword4_sync(const uint32_t* p0, const uint32_t* p1, const uint32_t* p2, const uint32_t* p3, uint32_t (&v)[4])
+{
+    asm volatile("global_load_dword %0, %4, off ; VGHOT\n\tglobal_load_dword %1, %5, off ; VGHOT\n\tglobal_load_dword %2, %6, off ; VGHOT\n\t"
+                 "global_load_dword %3, %7, off ; VGHOT\n\ts_waitcnt vmcnt(0) ; VGHOT"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+}
+__device__ __forceinline__ void vm_atomic_add4_sync(uint32_t* p0, uint32_t* p1, uint32_t* p2, uint32_t* p3, const uint32_t (&add)[4], uint32_t (&old)[4])
+{
+    asm volatile("global_atomic_add %0, %4, %8, off sc0 ; VGHOT\n\tglobal_atomic_add %1, %5, %9, off sc0 ; VGHOT\n\t"
+                 "global_atomic_add %2, %6, %10, off sc0 ; VGHOT\n\tglobal_atomic_add %3, %7, %11, off sc0 ; VGHOT\n\ts_waitcnt vmcnt(0) ; VGHOT"
+                 : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3])
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(add[0]), "v"(add[1]), "v"(add[2]), "v"(add[3]) : "memory");
+}
+__device__ __forceinline__ uint32_t vm_load_dword_sync(const uint32_t* ptr)
 {
     uint32_t v;
-    if (C == 0) asm volatile("v_mov_b32 %0, v112 ; VGHOT" : "=v"(v));
-    else asm volatile("v_mov_b32 %0, v113 ; VGHOT" : "=v"(v));
+    asm volatile("global_load_dword %0, %1, off ; VGHOT\n\ts_waitcnt vmcnt(0) ; VGHOT" : "=&v"(v) : "v"(ptr) : "memory");
     return v;
 }
 // rare path: a returning atomic waited for on the spot
@@ -1172,34 +1201,38 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
         ++n_after_row;
         n_after_slot = 0;
     };
-    // ================= path-table drain (PT), two levels =================
-    // Level 1, once per <= 64 queued runs, ONE LANE PER RUN: the run's 12-mer is looked up in the index (exact compare), a run
-    // that is not there is dropped (the filter's false positives end here), and every place the index lists becomes one
-    // RESOLVED entry {run bits, validity bits, base}: the k-mer of window w is P[base - 16 + w] if it is a graph k-mer at all.
-    // A read that carries the 12-mer reversed needs no turning round: P holds every chain in both orientations, mirrored
-    // (P[n2 - 1 - i] is the reverse complement of P[i]), so its windows are the consecutive entries from n2 - place on.
-    // The index load is issued when the runs are popped and used an iteration later.
-    // Level 2, per <= 4 resolved entries, one lane per WINDOW: one 16-byte load of P[base - 16 + w] -- 16 consecutive entries
-    // per entry -- then, a step later, the compare on the whole k-mer and the atomic unless the entry is flagged saturated.
-    // What is paid per run is paid by one lane; the 64-lane steps do only what differs from window to window.
-    constexpr uint32_t RQ = 64, ZQ = 48;
-    const uint32_t rq_base = rings0 + wave_u * (VG_RUNQ * 16u + VG_REQ * 8u), zq_base = rq_base + RQ * 16u;
-    const ulonglong2* const ptP = p.table.pt.P;
+    // ================= path-table drain (PT): one lane per run =================
+    // Once per <= 64 queued runs, every lane takes ONE run through three phases, an iteration of the row loop apart (each
+    // phase's loads have that long to arrive):
+    //   1  the run leaves the ring, its index bucket is asked for
+    //   2  exact compare on the 12-mer: a run that is not in the index is dropped (the filter's false positives end here);
+    //      for each of its (up to two) places: 16 bytes of the unitig sequence S, the words that hold the 16 k-mer-start
+    //      bits and the 16 saturation bits.  A read that carries the 12-mer reversed needs no turning round: S holds every
+    //      unitig in both orientations, mirrored, so its run is compared at Tp - 42 - place
+    //   3  run XOR sequence: the first mismatch on either side of the 12-mer bounds the windows that equal the unitig's k-mers
+    //      (two find-first-bit instructions give all 16 answers); AND the start bits AND the run's own validity bits = the hits.
+    //      Hits whose saturation bit is set are done (the steady state of a deep sample); the others fetch their slot and bump
+    //      its counter, bit by bit.
+    constexpr uint32_t RQ = 64;
+    const uint32_t rq_base = rings0 + wave_u * (VG_RUNQ * 16u + VG_REQ * 8u);
     const unsigned long long* const pt_index = p.table.pt.index;
-    const uint32_t pt_n2 = p.table.pt.n2, pt_bshift = 32u - p.table.pt.bucket_log2;
-    uint32_t z_head = 0, z_n = 0;                         // resolved-entry ring (wave-uniform)
-    uint32_t n_after_z = 4, n_after_idx = 4;              // hot operations issued after the last one of a level-2 step / after the index load
-    u32x4 l1_run = {0u, 0u, 0u, 0u};                      // level 1: the run this lane resolves
-    bool l1_pending = false;                              // wave-uniform
-    uint32_t l1_n = 0;
-    const uint32_t vm_shift = my_win < 12u ? 20u + my_win : 16u + my_win;
+    const uint32_t* const ptS = p.table.pt.S;
+    const uint32_t* const ptVB = p.table.pt.VB;
+    uint32_t* const ptSB = p.table.pt.SB;
+    const uint32_t* const ptSLOT = p.table.pt.SLOT;
+    const uint32_t pt_Tp = p.table.pt.Tp, pt_bshift = 32u - p.table.pt.bucket_log2;
+    uint32_t n_after_idx = 8, n_after_seq = 8;            // hot operations issued after the index load / after the last load of phase 2
+    u32x4 l1_run = {0u, 0u, 0u, 0u};                      // the run this lane works on
+    uint32_t l1_n = 0, l1_phase = 0;                      // wave-uniform: runs in the round, 0 idle / 1 bucket in flight / 2 sequence in flight
+    uint32_t pl[4] = {0u, 0u, 0u, 0u};                    // places (0: none)
+    bool l1_slow = false;
     auto hot = [&](uint32_t k) __attribute__((always_inline)) {
         n_after_row += k;
-        n_after_z += k;
         n_after_idx += k;
+        n_after_seq += k;
     };
     auto slow_count = [&](uint32_t klo, uint32_t khi) __attribute__((always_inline)) {
-        // a run whose 12-mer has more places than the index holds: this window through the hash table, on the spot (rare)
+        // a window of a run whose 12-mer the index does not cover: through the hash table, on the spot (rare)
         const uint64_t kmer = (uint64_t)khi << 32 | klo, rc = vg_revcomp(kmer, 27);
         const uint64_t canon = kmer < rc ? kmer : rc;
         uint64_t sl = vg_thash(canon) & cap_mask;
@@ -1218,145 +1251,157 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
             sl = (sl + 1) & cap_mask;
         }
     };
-    // one level-2 step: TWO batches of <= 4 resolved entries (A: candidate registers v[100:103], B: v[104:107]).  The loads and
-    // atomics a step issues are waited for at the top of the next one; with eight entries per step the steps are an iteration
-    // apart, which is what an L2 round trip under this load needs (a four-entry step every half iteration stalled on it).
-    struct Half { uint32_t lo, hi, idx, q_slot, q_idx; bool h, q_bumped; };
-    Half hA = {0, 0, 0, 0, 0, false, false}, hB = {0, 0, 0, 0, 0, false, false};
-    auto sat_flag = [&](const Half& H, uint32_t old) __attribute__((always_inline)) {
-        // the one increment that took a counter from 254 to 255 flags its k-mer: in the hash table (the generic kernels and the
-        // slow path look there) and in both of its path-table entries
-        const bool sat = H.q_bumped && old == 254u;
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(sat) != 0, 0)) {
-            if (sat) {
-                vm_atomic_or_sync(reinterpret_cast<uint32_t*>(&slots8[H.q_slot]) + 1, (uint32_t)(VG_SLOT_SAT >> 32));
-                vm_store_byte_sync(p.table.sat_dirty + (H.q_slot >> VG_SAT_REGION_LOG2), 1u);
-                vm_atomic_or_sync(reinterpret_cast<uint32_t*>(const_cast<ulonglong2*>(&ptP[H.q_idx])) + 1, (uint32_t)(VG_SLOT_SAT >> 32));
-                vm_atomic_or_sync(reinterpret_cast<uint32_t*>(const_cast<ulonglong2*>(&ptP[pt_n2 - 1u - H.q_idx])) + 1, (uint32_t)(VG_SLOT_SAT >> 32));
-            }
-        }
-    };
-    auto step2 = [&]() __attribute__((always_inline)) {
-        vm_wait4(n_after_z);
-        sat_flag(hA, vmp_atomic_old<0>());
-        sat_flag(hB, vmp_atomic_old<1>());
-        // ---- finish: the entries of P have landed
-        {
-            const uint3 ca = vmp_cand_value<0>(), cb = vmp_cand_value<1>();
-            const bool hit_a = hA.h && ca.x == hA.lo && (ca.y & MASK_HI) == hA.hi && !(ca.y >> 31);
-            const bool hit_b = hB.h && cb.x == hB.lo && (cb.y & MASK_HI) == hB.hi && !(cb.y >> 31);
-            hA.q_slot = ca.z;
-            hA.q_idx = hA.idx;
-            hA.q_bumped = hit_a;
-            hB.q_slot = cb.z;
-            hB.q_idx = hB.idx;
-            hB.q_bumped = hit_b;
-            if (__builtin_amdgcn_ballot_w64(hit_a)) {   // wave-uniform: the atomic is issued iff some lane hit
-                if (hit_a) vmp_atomic_inc<0>(&counts[ca.z], one);
-                hot(1);
-            }
-            if (__builtin_amdgcn_ballot_w64(hit_b)) {
-                if (hit_b) vmp_atomic_inc<1>(&counts[cb.z], one);
-                hot(1);
-            }
-        }
-        // ---- issue: up to 2 x 4 resolved entries x 16 windows
-        {
-            const uint32_t take = z_n < 8u ? z_n : 8u;
-            const bool have_a = my_run < take, have_b = my_run + 4u < take;
-            u32x4 ea = {0u, 0u, 0u, 0u}, eb = {0u, 0u, 0u, 0u};
-            uint32_t zs = z_head + my_run;
-            zs = zs >= ZQ ? zs - ZQ : zs;
-            uint32_t zt = zs + 4u;
-            zt = zt >= ZQ ? zt - ZQ : zt;
-            if (have_a) ea = *reinterpret_cast<lds_u4_rw*>((uintptr_t)(zq_base + zs * 16u));
-            if (have_b) eb = *reinterpret_cast<lds_u4_rw*>((uintptr_t)(zq_base + zt * 16u));
-            z_head += take;
-            if (z_head >= ZQ) z_head -= ZQ;
-            z_n -= take;
-            // entry: run bits [0, 84) in x, y, z[0:20); validity bits 0..11 in z[20:32), 12..15 in w[28:32); w[0:19) base; w[19] slow
-            hA.lo = funnel(ea.y, ea.x, my_sh);
-            hA.hi = funnel(ea.z, ea.y, my_sh) & MASK_HI;
-            hB.lo = funnel(eb.y, eb.x, my_sh);
-            hB.hi = funnel(eb.z, eb.y, my_sh) & MASK_HI;
-            const bool off = (VG_DBG(p.dbg) & 512u) != 0;
-            const bool valid_a = have_a && (((my_win < 12u ? ea.z : ea.w) >> vm_shift) & 1u) != 0 && !off;
-            const bool valid_b = have_b && (((my_win < 12u ? eb.z : eb.w) >> vm_shift) & 1u) != 0 && !off;
-            const bool slow_a = valid_a && ((ea.w >> 19) & 1u) != 0, slow_b = valid_b && ((eb.w >> 19) & 1u) != 0;
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow_a || slow_b) != 0, 0)) {
-                if (slow_a) slow_count(hA.lo, hA.hi);
-                if (slow_b) slow_count(hB.lo, hB.hi);
-            }
-            hA.idx = (ea.w & 0x7FFFFu) - 16u + my_win;
-            hB.idx = (eb.w & 0x7FFFFu) - 16u + my_win;
-            hA.h = valid_a && !slow_a && hA.idx < pt_n2;
-            hB.h = valid_b && !slow_b && hB.idx < pt_n2;
-            if (__builtin_amdgcn_ballot_w64(hA.h)) {
-                if (hA.h) vmp_load_cand<0>(&ptP[hA.idx]);
-                hot(1);
-            }
-            if (__builtin_amdgcn_ballot_w64(hB.h)) {
-                if (hB.h) vmp_load_cand<1>(&ptP[hB.idx]);
-                hot(1);
-            }
-        }
-        n_after_z = 0;
-        __builtin_amdgcn_wave_barrier();
-    };
-    // level 1, first half: every lane takes one queued run and asks for its index bucket
+    // phase 1
     auto resolve_issue = [&]() __attribute__((always_inline)) {
         l1_n = run_n < 64u ? run_n : 64u;
-        if (lane < l1_n) {
+        if (lane < l1_n && !(VG_DBG(p.dbg) & 2048u)) {      // 2048: ablation (wrong counts): the runs are popped and forgotten
             l1_run = *reinterpret_cast<lds_u4_rw*>((uintptr_t)(rq_base + ((run_head + lane) & (RQ - 1u)) * 16u));
-            vmp_load_index(pt_index + ((uint64_t)(vg_mul24(l1_run.w & 0xFFFFFFu, 0x9E3779u) >> pt_bshift) << 1));
+            vmp_load_index(pt_index + ((uint64_t)(vg_mul24(l1_run.w & 0xFFFFFFu, 0x9E3779u) >> pt_bshift) << 2));
         }
         run_head = (run_head + l1_n) & (RQ - 1u);
         run_n -= l1_n;
-        hot(1);
+        hot(2);
         n_after_idx = 0;
-        l1_pending = true;
+        l1_phase = 1;
         __builtin_amdgcn_wave_barrier();
     };
-    // level 1, second half: the buckets have landed; the resolved entries go into their ring (level-2 steps make room)
-    auto resolve_finish = [&]() __attribute__((always_inline)) {
+    // phase 2
+    auto resolve_places = [&]() __attribute__((always_inline)) {
         vm_wait4(n_after_idx);
-        const uint4 ix = vmp_index_value();
+        const uint4 e0 = vmp_index_value<0>(), e1 = vmp_index_value<1>();
         const uint32_t cx = l1_run.w & 0xFFFFFFu;
-        const bool act = lane < l1_n;
+        const bool act = lane < l1_n && !(VG_DBG(p.dbg) & (1024u | 2048u));
         const bool as_is = ((l1_run.w >> 24) & 1u) != 0;
-        const bool m0 = ((ix.x ^ cx) & 0xFFFFFFu) == 0 && (((ix.x >> 24) | (ix.y << 8)) & 0x7FFFFu) != 0;
-        const bool m1 = ((ix.z ^ cx) & 0xFFFFFFu) == 0 && (((ix.z >> 24) | (ix.w << 8)) & 0x7FFFFu) != 0;
-        const uint32_t wl = m0 ? ix.x : ix.z, wh = m0 ? ix.y : ix.w;
-        const uint32_t pa = ((wl >> 24) | (wh << 8)) & 0x7FFFFu, pb = (wh >> 11) & 0x7FFFFu;
+        // entry: x[0:24) the 12-mer, places 0 and 1 in x[24:32) : y[0:11) and y[11:30), y[30] "some 12-mer found no entry in this
+        // bucket" (first entry only); places 2 and 3 in z[0:19) and z[19:32) : w[0:6), w[6] "more than four places"
+        const bool m0 = ((e0.x ^ cx) & 0xFFFFFFu) == 0 && (((e0.x >> 24) | (e0.y << 8)) & 0x7FFFFu) != 0;
+        const bool m1 = ((e1.x ^ cx) & 0xFFFFFFu) == 0 && (((e1.x >> 24) | (e1.y << 8)) & 0x7FFFFu) != 0;
+        const uint4 e = m0 ? e0 : e1;
         const bool found = m0 || m1;
+        const uint32_t q0 = ((e.x >> 24) | (e.y << 8)) & 0x7FFFFu, q1 = (e.y >> 11) & 0x7FFFFu;
+        const uint32_t q2 = e.z & 0x7FFFFu, q3 = ((e.z >> 19) | (e.w << 13)) & 0x7FFFFu;
+        const bool more = ((e.w >> 6) & 1u) != 0;
         // more places than the entry holds, or a 12-mer that found no entry in its bucket: the hash table decides, window by window
-        const bool slow = act && (found ? pb == 0x7FFFFu : ((ix.y >> 30) & 1u) != 0) && !(VG_DBG(p.dbg) & 1024u);
-        const bool ok = act && found && pb != 0x7FFFFu && !(VG_DBG(p.dbg) & 1024u);
-        // window w of the run is P[place - 16 + w] when the read carries the 12-mer as the index has it, P[n2 - place + w] otherwise
-        const uint32_t base_a = as_is ? pa : pt_n2 + 16u - pa, base_b = as_is ? pb : pt_n2 + 16u - pb;
-        const uint32_t wz = l1_run.w & 0xF0000000u;
-        // three kinds of entry (first place, second place, hash-table fallback), each pushed in two halves of the wavefront so that
-        // a round never needs more room than the ring has; ONE copy of the code (a level-2 step sits inside)
-#pragma unroll 1
-        for (uint32_t round = 0; round < 6u; ++round) {
-            const uint32_t kind = round >> 1;
-            const bool pred = kind == 0u ? ok : kind == 1u ? (ok && pb != 0) : slow;
-            const uint32_t w_word = wz | (kind == 0u ? base_a : kind == 1u ? base_b : (1u << 19));
-            const bool mine = pred && (lane >> 5) == (round & 1u);
-            const uint64_t ball = __builtin_amdgcn_ballot_w64(mine);
-            if (ball == 0) continue;
-            const uint32_t n = (uint32_t)__builtin_popcountll(ball);
-            while (z_n + n > ZQ) step2();
-            if (mine) {
-                uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, z_head + z_n));
-                pos = pos >= ZQ ? pos - ZQ : pos;
-                pos = pos >= ZQ ? pos - ZQ : pos;
-                *reinterpret_cast<lds_u4_rw*>((uintptr_t)(zq_base + pos * 16u)) = u32x4{l1_run.x, l1_run.y, l1_run.z, w_word};
-            }
-            z_n += n;
-            __builtin_amdgcn_wave_barrier();
+        l1_slow = act && (found ? more : ((e0.y >> 30) & 1u) != 0);
+        const bool ok = act && found && !more;
+        const uint32_t flip = pt_Tp - 42u;
+        pl[0] = ok ? (as_is ? q0 : flip - q0) : 0u;
+        pl[1] = ok && q1 != 0 ? (as_is ? q1 : flip - q1) : 0u;
+        pl[2] = ok && q2 != 0 ? (as_is ? q2 : flip - q2) : 0u;
+        pl[3] = ok && q3 != 0 ? (as_is ? q3 : flip - q3) : 0u;
+        if (__builtin_amdgcn_ballot_w64(pl[0] != 0)) {
+            if (pl[0] != 0) vmp_load_place<0>(ptS + (pl[0] >> 4), ptVB + (pl[0] >> 5), ptSB + (pl[0] >> 5));
+            hot(3);
         }
-        l1_pending = false;
+        if (__builtin_amdgcn_ballot_w64(pl[1] != 0)) {
+            if (pl[1] != 0) vmp_load_place<1>(ptS + (pl[1] >> 4), ptVB + (pl[1] >> 5), ptSB + (pl[1] >> 5));
+            hot(3);
+        }
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(pl[2] != 0) != 0, 0)) {     // neighbouring sites: a third and a fourth allele combination
+            if (pl[2] != 0) vmp_load_place<2>(ptS + (pl[2] >> 4), ptVB + (pl[2] >> 5), ptSB + (pl[2] >> 5));
+            hot(3);
+            if (__builtin_amdgcn_ballot_w64(pl[3] != 0)) {
+                if (pl[3] != 0) vmp_load_place<3>(ptS + (pl[3] >> 4), ptVB + (pl[3] >> 5), ptSB + (pl[3] >> 5));
+                hot(3);
+            }
+        }
+        n_after_seq = 0;
+        l1_phase = 2;
+    };
+    // phase 3, per place: the windows of the run that equal the k-mers starting at place .. place + 15, less the saturated ones
+    auto windows_at = [&](uint32_t place, const uint4 sq, const uint4 bits, uint32_t vm16, uint32_t& hits) __attribute__((always_inline)) -> uint32_t {
+        // the 42 bases from `place` on, aligned like the run's 84 bits: the 128-bit big-endian stream sq.x : y : z : w shifted
+        // right by 44 - 2 (place mod 16)
+        const uint32_t sh = 44u - 2u * (place & 15u);
+        const bool far = sh >= 32u;
+        const uint32_t x0 = funnel(far ? sq.y : sq.z, far ? sq.z : sq.w, sh & 31u);
+        const uint32_t x1 = funnel(far ? sq.x : sq.y, far ? sq.y : sq.z, sh & 31u);
+        const uint32_t x2 = funnel(far ? 0u : sq.x, far ? sq.x : sq.y, sh & 31u);
+        const uint32_t d0 = x0 ^ l1_run.x, d1 = x1 ^ l1_run.y, d2 = (x2 ^ l1_run.z) & 0xFFFFFu;
+        // bases r27 .. r41 (behind the 12-mer) are bits [0, 30): the mismatch nearest to the 12-mer (highest bit) ends the windows
+        const uint32_t tr = (d0 | (d0 >> 1)) & 0x15555555u;
+        const uint32_t mask_r = tr ? (1u << (15u - ((31u - (uint32_t)__builtin_clz(tr)) >> 1))) - 1u : 0xFFFFu;
+        // bases r0 .. r14 (in front of it) are bits [54, 84): the mismatch nearest to the 12-mer (lowest bit) starts them
+        const uint32_t fl = funnel(d2, d1, 22) & 0x3FFFFFFFu;
+        const uint32_t tl = (fl | (fl >> 1)) & 0x15555555u;
+        const uint32_t mask_l = tl ? ~((1u << (15u - ((uint32_t)__builtin_ctz(tl) >> 1))) - 1u) & 0xFFFFu : 0xFFFFu;
+        const uint32_t starts = funnel(bits.y, bits.x, place & 31u) & 0xFFFFu;
+        const uint32_t sats = funnel(bits.w, bits.z, place & 31u) & 0xFFFFu;
+        hits = mask_l & mask_r & starts & vm16;
+        return hits & ~sats;
+    };
+    auto bump_all = [&](uint32_t todo, uint32_t place) __attribute__((always_inline)) {
+        // the unsaturated hits of this lane's run, up to four windows per round (every lane with a hit left takes part): their
+        // slots in one round trip, their counters in a second.  A lane with fewer hits left pads the round by adding 0 to the
+        // counter of its first window (its own address: a shared dummy would serialise every padded lane of the device).
+#pragma unroll 1
+        while (__builtin_amdgcn_ballot_w64(todo != 0) != 0) {
+            if (todo != 0) {
+                uint32_t pos[4], sl[4], old[4];
+                bool live[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    live[q] = todo != 0;
+                    pos[q] = place + (live[q] ? (uint32_t)__builtin_ctz(todo) : 0u);
+                    todo &= todo - 1u;      // 0 stays 0
+                }
+                vm_load_dword4_sync(ptSLOT + pos[0], ptSLOT + pos[1], ptSLOT + pos[2], ptSLOT + pos[3], sl);
+                const uint32_t add[4] = {1u, live[1] ? 1u : 0u, live[2] ? 1u : 0u, live[3] ? 1u : 0u};
+                vm_atomic_add4_sync(&counts[sl[0]], &counts[live[1] ? sl[1] : sl[0]], &counts[live[2] ? sl[2] : sl[0]], &counts[live[3] ? sl[3] : sl[0]], add, old);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (live[q] && old[q] == 254u) {
+                        // this increment took the counter to the clamp: flag the k-mer in the hash table (the generic kernels
+                        // and the slow path look there) and at both of its places in the path table
+                        vm_atomic_or_sync(reinterpret_cast<uint32_t*>(&slots8[sl[q]]) + 1, (uint32_t)(VG_SLOT_SAT >> 32));
+                        vm_store_byte_sync(p.table.sat_dirty + (sl[q] >> VG_SAT_REGION_LOG2), 1u);
+                        const uint32_t mir = pt_Tp - 27u - pos[q];
+                        vm_atomic_or_sync(ptSB + (pos[q] >> 5), 1u << (pos[q] & 31u));
+                        vm_atomic_or_sync(ptSB + (mir >> 5), 1u << (mir & 31u));
+                    }
+                }
+            }
+        }
+    };
+    auto resolve_compare = [&]() __attribute__((always_inline)) {
+        vm_wait4(n_after_seq);
+        const uint32_t vm16 = (l1_run.z >> 20) | ((l1_run.w >> 28) << 12);
+        uint32_t hits = 0, todo[4] = {0u, 0u, 0u, 0u};
+        if (pl[0] != 0) todo[0] = windows_at(pl[0], vmp_seq_value<0>(), vmp_bits_value<0>(), vm16, hits);
+        if (pl[1] != 0) todo[1] = windows_at(pl[1], vmp_seq_value<1>(), vmp_bits_value<1>(), vm16, hits);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(pl[2] != 0) != 0, 0)) {
+            if (pl[2] != 0) todo[2] = windows_at(pl[2], vmp_seq_value<2>(), vmp_bits_value<2>(), vm16, hits);
+            if (pl[3] != 0) todo[3] = windows_at(pl[3], vmp_seq_value<3>(), vmp_bits_value<3>(), vm16, hits);
+        }
+        if (VG_DBG(p.dbg) & 512u) todo[0] = todo[1] = todo[2] = todo[3] = 0;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64((todo[0] | todo[1] | todo[2] | todo[3]) != 0) != 0, 0)) {
+            bump_all(todo[0], pl[0]);
+            bump_all(todo[1], pl[1]);
+            if (__builtin_amdgcn_ballot_w64((todo[2] | todo[3]) != 0) != 0) {
+                bump_all(todo[2], pl[2]);
+                bump_all(todo[3], pl[3]);
+            }
+        }
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(l1_slow && !(VG_DBG(p.dbg) & 4096u)) != 0, 0)) {     // 4096: ablation: no slow path
+            // runs the index does not cover, one after the other, their 16 windows side by side on lanes 0..15
+            uint64_t left = __builtin_amdgcn_ballot_w64(l1_slow);
+            while (left) {
+                const uint32_t src = (uint32_t)__builtin_ctzll(left);
+                left &= left - 1;
+                const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)l1_run.x, (int)src), ry = (uint32_t)__builtin_amdgcn_readlane((int)l1_run.y, (int)src);
+                const uint32_t rz = (uint32_t)__builtin_amdgcn_readlane((int)l1_run.z, (int)src), rw = (uint32_t)__builtin_amdgcn_readlane((int)l1_run.w, (int)src);
+                const uint32_t v16 = (rz >> 20) | ((rw >> 28) << 12);
+                if (lane < 16u && ((v16 >> lane) & 1u)) {
+                    const uint32_t sh2 = 2u * (15u - lane);
+                    slow_count(funnel(ry, rx, sh2), funnel(rz, ry, sh2) & MASK_HI);
+                }
+            }
+        }
+        l1_phase = 0;
+    };
+    auto l1_advance = [&]() __attribute__((always_inline)) {
+        if (l1_phase == 2) resolve_compare();
+        else if (l1_phase == 1) resolve_places();
     };
 
     auto drain_hash = [&]() __attribute__((always_inline)) {
@@ -1451,7 +1496,7 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
     auto drain_step = [&]() __attribute__((always_inline)) { drain_hash(); };
     // path table: the run ring is emptied by level 1 in one go (after the round before it has been finished)
     auto make_room = [&]() __attribute__((always_inline)) {
-        if (l1_pending) resolve_finish();
+        while (l1_phase != 0) l1_advance();
         resolve_issue();
     };
 
@@ -1521,9 +1566,8 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
         n_after_row = 0;
         n_after_slot += 2;
         if (PT) {
-            n_after_z += 2;
             n_after_idx += 2;
-            if (z_n >= 8u) step2();
+            n_after_seq += 2;
         } else if (run_n >= VG_RUN_BATCH_S || req_n >= 32u) drain_step();
 
         // own 16 bases of each row: be = 32 bits, first base most significant; inv bit t = base t is not a base.
@@ -1570,11 +1614,9 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
             if (run_n + nB > RQ) make_room();
             enqueue(sb, ballB, run_head + run_n);
             run_n += nB;
-            // level 1: ask at the end of one iteration, use at the end of the next (the bucket loads have a whole iteration)
-            if (l1_pending) resolve_finish();
-            else if (run_n >= 40u) resolve_issue();
-            if (z_n >= 8u) step2();
-            while (z_n >= 32u) step2();           // dense stretches: keep the ring short
+            // one phase per iteration: every phase's loads have a whole iteration to arrive
+            l1_advance();
+            if (l1_phase == 0 && run_n >= 24u) resolve_issue();
             continue;
         }
         enqueue(sa, ballA, run_head + run_n);
@@ -1585,14 +1627,11 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
         if (run_n >= VG_RUN_BATCH_S || req_n >= 32u) drain_step();
         while (run_n >= 3 * VG_RUN_BATCH_S || req_n >= 48u) drain_step();   // dense stretches: keep the rings short
     }
-    if (PT) {   // flush: both levels until nothing is queued or in flight
-        while (run_n != 0 || l1_pending) {
-            if (l1_pending) resolve_finish();
+    if (PT) {   // flush: until nothing is queued or in flight
+        while (run_n != 0 || l1_phase != 0) {
+            while (l1_phase != 0) l1_advance();
             if (run_n != 0) resolve_issue();
         }
-        do {
-            step2();
-        } while (z_n != 0 || __builtin_amdgcn_ballot_w64(hA.h || hB.h || hA.q_bumped || hB.q_bumped) != 0);
     } else {
         do {   // flush: until the rings are empty and the last step issued nothing (finishing a batch can re-queue)
             drain_step();

@@ -5,23 +5,19 @@
 // src/fastq_kmer.cpp:128-139 (saturating count).
 //
 // Why.  A candidate run is 16 consecutive k-mers of a read (the windows around one grid 12-mer X, vgmi_device.h).  Looked up
-// one by one in the exact hash table they are 16 random 8-byte probes; 5.4e7 runs per 1e8-read sample make 8.6e8 probes,
-// which is all an XCD's L2 delivers in 3.3 ms (tools/ubench_mem: 263 G random requests/s below 4 MiB) -- measured: the scan
-// alone takes 2.7 ms of the kernel's 6.0 (VGMI_DBG=1).  But the 16 k-mers are not random: they are CONSECUTIVE k-mers of a
-// haplotype path, and so are the graph's k-mers they may equal.  So:
-//     P      the graph's k-mers laid out along their unitigs (chains of k-mers that follow each other uniquely in the key set:
-//            the 27 k-mers across one allele of a SNP are one chain), each chain once in every orientation: entry i + 1 is entry
-//            i shifted by one base.  16 bytes per entry: {k-mer word | saturation flag, table slot}.  2 n entries, P[2n - 1 - i]
-//            is the reverse complement of P[i].
-//     index  canonical 12-mer cx -> up to two places p0 in P such that "the k-mer that has cx w bases before its end" is
-//            P[p0 + w] (for every w at which such a k-mer exists); the two alleles of a site give two places.  2^17 buckets of
-//            two 8-byte entries {cx : 24, p0a : 19, p0b : 19}, exact compare on cx.
-// A run costs one 16-byte index load (one request for its 16 lanes) and one or two loads of 16 CONSECUTIVE entries of P (one or
-// two lines each): 3-5 requests instead of 16, all of them in 0.9 MiB + 2 MiB that stay L2-resident.  The compare is on the
-// whole k-mer, so a hit is exact; every (12-mer, k-mer) incidence of the graph is in the index unless it is marked as
-// overflowed (a third place for one 12-mer: neighbouring sites, repeats; a third 12-mer in one bucket) -- runs that meet a
-// mark take the exact hash table as before.  Counters stay per table slot, so read-out, the generic kernels (ragged tails,
-// k != 27) and the image format do not change; the path table is derived from the image after upload / import / clone.
+// one by one in the exact hash table they are 16 probes with 16 canonical forms and 16 hashes, on 16 lanes -- and every lane
+// of a drain step pays the step's whole instruction stream: the drain cost more than the scan (6.0 ms per 1e8 reads, 2.7 of them
+// scan; measured with the lookups compiled out).  But the 16 k-mers are not independent: they are CONSECUTIVE k-mers of a
+// haplotype path, and so are the graph's k-mers they may equal.  So the graph's k-mers are laid out along their unitigs
+// (chains of k-mers that follow each other uniquely in the key set: the 27 k-mers across one allele of a SNP are one chain of
+// 53 bases) as a SEQUENCE, S, once per orientation, and an index maps a canonical 12-mer to the (up to two: two alleles)
+// places of S where it occurs.  ONE LANE then checks a whole run: it fetches the 42 bases of S around the place, XORs them
+// with the run's 42 bases, and the first mismatch on either side of the 12-mer bounds the windows that are graph k-mers --
+// all 16 answers from two find-first-bit instructions, exact because the compare is on every base.  Per position of S a bit
+// says whether a graph k-mer starts there (VB), another whether its counter is saturated (SB, per sample), and SLOT holds its
+// hash-table slot: counters stay per table slot, so read-out, the generic kernels (ragged tails, k != 27) and the image format
+// do not change.  This file orders the k-mers (device kernels, as vgmi_xtable.hip numbers counters along paths);
+// build_ptable (vgmi_api.cpp) lays S, VB, SLOT and the index out on the host -- at most 65 536 k-mers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -151,44 +147,6 @@ __global__ void pt_fill_kernel(TableView t, const uint32_t* key_slot, const uint
     P[2 * n - 1 - pos] = make_ulonglong2(as_is ? R : K, slot);
 }
 
-// index entry: cx | (p0a + 1 biased place, 0: the entry is empty) << 24 | (p0b, 0: none, PT_OVF: more than two places) << 43;
-// bit 62 of a bucket's FIRST entry: some 12-mer of this bucket found no entry (lookups that miss then take the hash table)
-#define PT_P0_MASK 0x7FFFFu
-#define PT_OVF 0x7FFFFu
-#define PT_BUCKET_OVF (1ULL << 62)
-#define PT_BIAS 16u
-
-__global__ void pt_index_kernel(const ulonglong2* P, uint64_t n2, unsigned long long* index, uint32_t bucket_log2)
-{
-    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n2 * 16) return;
-    const uint64_t idx = g >> 4;
-    const uint32_t o = (uint32_t)g & 15u;                     // X = bases o .. o + 11 of the k-mer
-    const uint64_t kmer = P[idx].x & PT_MASK54;
-    const uint32_t x = (uint32_t)(kmer >> (2 * (15 - o))) & 0xFFFFFFu;
-    if (x > vg_revcomp12(x)) return;                          // this incidence is listed from the other orientation's entry
-    const uint32_t w = 15u - o;                               // X lies w bases before the k-mer's end
-    const uint64_t p0 = idx + PT_BIAS - w;                    // >= 1: P[p0 - PT_BIAS + w] is this k-mer
-    unsigned long long* B = index + ((uint64_t)(vg_mul24(x, 0x9E3779u) >> (32 - bucket_log2)) << 1);
-    for (int e = 0; e < 2; ++e) {
-        for (;;) {
-            const unsigned long long raw = *reinterpret_cast<volatile unsigned long long*>(&B[e]);
-            const unsigned long long flag = raw & PT_BUCKET_OVF, cur = raw & ~PT_BUCKET_OVF;
-            const uint32_t pa = (uint32_t)(cur >> 24) & PT_P0_MASK;
-            if (pa == 0) {                                     // empty: claim it
-                if (atomicCAS(&B[e], raw, (unsigned long long)x | p0 << 24 | flag) == raw) return;
-                continue;                                      // somebody else wrote here first: look again
-            }
-            if (((uint32_t)cur & 0xFFFFFFu) != x) break;       // another 12-mer lives here: next entry
-            const uint32_t pb = (uint32_t)(cur >> 43) & PT_P0_MASK;
-            if (pa == p0 || pb == p0 || pb == PT_OVF) return;  // listed (the same place from a neighbouring k-mer), or given up on
-            const unsigned long long want = (cur & ~((unsigned long long)PT_P0_MASK << 43)) | (unsigned long long)(pb == 0 ? p0 : PT_OVF) << 43 | flag;
-            if (atomicCAS(&B[e], raw, want) == raw) return;
-        }
-    }
-    atomicOr(&B[0], PT_BUCKET_OVF);                            // both entries belong to other 12-mers
-}
-
 hipError_t launch_ptable_order(const TableView& t, const uint32_t* key_slot, uint64_t n, uint32_t* key_of_slot, uint32_t* link, uint32_t* link2,
                                uint32_t* pos_of_key, unsigned long long* cursor, uint32_t* mark, uint32_t* status, hipStream_t st)
 {
@@ -203,27 +161,10 @@ hipError_t launch_ptable_order(const TableView& t, const uint32_t* key_slot, uin
     return hipGetLastError();
 }
 
-hipError_t launch_ptable_fill(const TableView& t, const uint32_t* key_slot, const uint32_t* pos_of_key, uint64_t n, ulonglong2* P,
-                              unsigned long long* index, uint32_t bucket_log2, hipStream_t st)
+hipError_t launch_ptable_fill(const TableView& t, const uint32_t* key_slot, const uint32_t* pos_of_key, uint64_t n, ulonglong2* P, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(pt_fill_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, t, key_slot, pos_of_key, n, P);
-    const uint64_t m = 2 * n * 16;
-    hipLaunchKernelGGL(pt_index_kernel, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, st, P, 2 * n, index, bucket_log2);
-    return hipGetLastError();
-}
-
-// per-sample reset: the saturation flags of P
-__global__ void pt_reset_kernel(ulonglong2* P, uint64_t n2)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n2) P[i].x &= ~VG_SLOT_SAT;
-}
-
-hipError_t launch_ptable_reset(ulonglong2* P, uint64_t n2, hipStream_t st)
-{
-    if (n2 == 0) return hipSuccess;
-    hipLaunchKernelGGL(pt_reset_kernel, dim3((uint32_t)((n2 + 255) / 256)), dim3(256), 0, st, P, n2);
     return hipGetLastError();
 }
 
