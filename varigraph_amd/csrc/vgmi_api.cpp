@@ -456,10 +456,12 @@ int build_ptable(vgmi_ctx* c)
     if (const char* e = getenv("VGMI_PTABLE"))
         if (e[0] == '0') return VGMI_OK;
     const uint64_t n = h.n_keys;
-    // 8 MiB of index for a 6.5e4-k-mer graph (~7e4 distinct canonical 12-mers: a third 12-mer is wanted in ~0.3 % of the buckets; at
-    // half the size it was 1 %, and every run of such a 12-mer took the hash table: 1.8 ms of 6.0 per 1e8 reads, measured)
+    // >= 8 buckets of 32 bytes per k-mer (16 MiB for a 6.5e4-k-mer graph with its ~7e4 distinct canonical 12-mers): a third 12-mer is
+    // wanted in ~0.03 % of the buckets.  Every run of such a 12-mer takes the hash table, window by window: with 2^17 buckets (1 %)
+    // that was 1.8 ms of 6.0 per 1e8 reads, with 2^18 (0.4 %) 0.56 of 5.0 (VGMI_DBG=4096 ablation); only the buckets of 12-mers
+    // that occur are ever read twice, so the size costs address space, not cache.
     uint32_t bucket_log2 = 13;
-    while (bucket_log2 < 18 && (1ull << bucket_log2) < 4 * n) ++bucket_log2;      // >= 4 buckets per k-mer
+    while (bucket_log2 < 19 && (1ull << bucket_log2) < 8 * n) ++bucket_log2;
     uint32_t *key_of_slot = nullptr, *link = nullptr, *link2 = nullptr, *pos = nullptr, *mark = nullptr;
     unsigned long long* cursor = nullptr;
     ulonglong2* d_P = nullptr;
@@ -535,7 +537,7 @@ int build_ptable(vgmi_ctx* c)
     std::vector<unsigned long long> index((size_t)4 << bucket_log2, 0ULL);
     uint64_t slow_cx = 0, bucket_ovf = 0;
     auto add = [&](uint32_t x, uint32_t place) {
-        unsigned long long* B = &index[(size_t)(vg_mul24(x, 0x9E3779u) >> (32 - bucket_log2)) << 2];
+        unsigned long long* B = &index[(size_t)(vg_idx_hash(x) >> (32 - bucket_log2)) << 2];
         for (int e = 0; e < 2; ++e) {
             unsigned long long& lo = B[2 * e];
             unsigned long long& hi = B[2 * e + 1];

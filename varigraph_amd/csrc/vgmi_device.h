@@ -245,6 +245,17 @@ VG_HD void vg_grid12_probe(uint32_t mer12, uint32_t& word, uint32_t& mask)
     mask = (1u << (h2 >> 27)) | (1u << ((h2 >> 22) & 31u)) | (1u << ((h2 >> 17) & 31u));
 }
 
+// bucket hash of the path table's 12-mer index (build_ptable, count27s_kernel: once per run, not per position -- two 32-bit multiplies
+// are affordable here, and the plain multiplicative hash left three times the expected number of overfull buckets)
+VG_HD uint32_t vg_idx_hash(uint32_t cx)
+{
+    uint32_t h = cx * 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    h ^= h >> 13;
+    return h;
+}
+
 // slot hash of the exact table (evaluated only for filter passes): three 24-bit multiplies (full rate on CDNA; the 32-bit
 // v_mul_lo_u32 is quarter rate) and a fold; home slots are 32-bit (tables beyond 2^32 slots stay correct, linear probing
 // just starts in the low part)

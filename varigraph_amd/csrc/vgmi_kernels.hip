@@ -1256,7 +1256,7 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
         l1_n = run_n < 64u ? run_n : 64u;
         if (lane < l1_n && !(VG_DBG(p.dbg) & 2048u)) {      // 2048: ablation (wrong counts): the runs are popped and forgotten
             l1_run = *reinterpret_cast<lds_u4_rw*>((uintptr_t)(rq_base + ((run_head + lane) & (RQ - 1u)) * 16u));
-            vmp_load_index(pt_index + ((uint64_t)(vg_mul24(l1_run.w & 0xFFFFFFu, 0x9E3779u) >> pt_bshift) << 2));
+            vmp_load_index(pt_index + ((uint64_t)(vg_idx_hash(l1_run.w & 0xFFFFFFu) >> pt_bshift) << 2));
         }
         run_head = (run_head + l1_n) & (RQ - 1u);
         run_n -= l1_n;
