@@ -252,9 +252,11 @@ std::string strip_newlines(const std::string& s)   // strip(str, '\n') of src/st
 }  // namespace
 
 struct Genotyper::Run {
-    const uint8_t* cov;
-    // coverage | multiplicity << 8 | haplotype bits << 16 of every key in one word (one cache line per k-mer instead of
-    // three: the arrays are indexed at random), when the bits fit; else nullptr
+    // Everything per sample is in NODE ORDER: entry j belongs to place j of the graph2node lists (GraphIndex::node_key_index[j] is
+    // its key) -- the order the device's per-node gather (K5, vgmi_counts_finish's cov_node) delivers and the order the windows
+    // walk, so a node's k-mers are neighbours in memory instead of gathers over the key arrays.
+    const uint8_t* cov;      // cov_node
+    // coverage | multiplicity << 8 | haplotype bits << 16 of every entry in one word, when the bits fit; else nullptr
     const uint64_t* packed = nullptr;
     float hap_cov;
     const GenotypeConfig* cfg;
@@ -311,8 +313,10 @@ Genotyper::Genotyper(const GraphIndex& g, unsigned threads) : g_(g)
                 Node& n = c.nodes[i];
                 n.start = places[i].start;
                 n.gn = places[i].gn;
-                if (places[i].v != SIZE_MAX)
-                    n.kmers.assign(g.node_key_index.begin() + g.node_off[places[i].v], g.node_key_index.begin() + g.node_off[places[i].v + 1]);
+                if (places[i].v != SIZE_MAX) {      // places of the node's k-mers in the node-ordered arrays (not key indices)
+                    n.kmers.resize(g.node_off[places[i].v + 1] - g.node_off[places[i].v]);
+                    std::iota(n.kmers.begin(), n.kmers.end(), (uint32_t)g.node_off[places[i].v]);
+                }
             }
         };
         const size_t nt = std::max<size_t>(1, std::min<size_t>(threads, places.size() / 4096 + 1));
@@ -376,6 +380,7 @@ Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, cons
     Node& node = chr.nodes[node_i];
     const std::vector<uint16_t>& hap_gt = node.gn->hap_gt;
     const uint64_t bl = g_.bitlen;
+    const uint32_t* const key_of = g_.node_key_index.data();      // place in the node-ordered arrays -> key
     auto hap_bit = [&](uint32_t key, uint16_t hap) -> uint8_t { return ((uint8_t)g_.bitvec[(size_t)key * bl + (hap >> 3)] >> (hap & 7)) & 1u; };
     auto last_bit = [&](uint32_t key) -> int { return ((uint8_t)g_.bitvec[(size_t)key * bl + bl - 1] >> 7) & 1; };
 
@@ -412,8 +417,8 @@ Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, cons
                 return;
             }
             __builtin_prefetch(&r.cov[k2]);
-            __builtin_prefetch(&g_.f[k2]);
-            __builtin_prefetch(&g_.bitvec[(size_t)k2 * bl]);
+            __builtin_prefetch(&g_.f[key_of[k2]]);
+            __builtin_prefetch(&g_.bitvec[(size_t)key_of[k2] * bl]);
         }
     };
     // Fast path (haplotype bits of a k-mer fit one 64-bit word, genotypes are pairs over <= 16 haplotypes): the word is
@@ -431,16 +436,16 @@ Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, cons
         for (uint16_t hap : top) top_mask |= 1ULL << hap;
         for (size_t p = 0; p < used.size(); ++p) gt0[p] = hap_gt[used[p]] == 0;
     }
-    for (uint32_t key : node.kmers) {
+    for (uint32_t pos : node.kmers) {
         prefetch_one();
         uint8_t* hrow = &ns.h[n_kept * n_gt];
         if (fast) {
-            const uint64_t w = r.packed[key];
+            const uint64_t w = r.packed[pos];
             const uint8_t c = (uint8_t)w, f = (uint8_t)(w >> 8);
             const uint64_t bits = w >> 16;
             const int lb = (int)((bits >> (8 * bl - 1)) & 1u);
             if (filter && (bits & top_mask) == 0) continue;
-            kept.push_back(key);
+            kept.push_back(pos);
             const bool in_interval = lb == 1 && c >= lower && c <= upper;
             uint8_t one16[16] = {0};
             uint32_t carried_mask = 0;
@@ -466,7 +471,8 @@ Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, cons
             ++n_kept;
             continue;
         }
-        const uint8_t c = r.cov[key];
+        const uint32_t key = key_of[pos];
+        const uint8_t c = r.cov[pos];
         const uint8_t f = g_.f[key];
         const int lb = last_bit(key);
         if (filter) {
@@ -474,7 +480,7 @@ Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, cons
             for (uint16_t hap : top) carried += hap_bit(key, hap);
             if (carried == 0) continue;
         }
-        kept.push_back(key);
+        kept.push_back(pos);
         const bool in_interval = lb == 1 && c >= lower && c <= upper;
         for (uint16_t hap : used) {
             one[hap] = (in_interval && hap_gt[hap] == 0) ? 1 : hap_bit(key, hap);
@@ -528,8 +534,9 @@ Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, cons
             hap_keys[hap] = sequence_keys(seq, g_.k);
         }
         uint32_t si = 0;
-        for (uint32_t key : kept) {
-            const uint8_t c = r.cov[key];
+        for (uint32_t pos : kept) {
+            const uint32_t key = key_of[pos];
+            const uint8_t c = r.cov[pos];
             const uint8_t f = g_.f[key];
             if (c > lower || f <= 1) {
                 si++;
@@ -559,18 +566,19 @@ Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, cons
 void Genotyper::posterior(Node& n, const std::vector<uint16_t>& top, const Run& r) const
 {
     const uint64_t bl = g_.bitlen;
+    const uint32_t* const key_of = g_.node_key_index.data();
     uint8_t unique_kmers = 0;
-    for (uint32_t key : n.kmers) {
-        if (g_.f[key] > 1) continue;
+    for (uint32_t pos : n.kmers) {
+        if (g_.f[key_of[pos]] > 1) continue;
         if (unique_kmers < UINT8_MAX) unique_kmers++;
     }
     const auto& hap_gt = n.gn->hap_gt;
 
     // selected haplotype -> (#k-mers it carries, sum of their coverage); any other haplotype reads as (0, 0)
     std::vector<uint64_t> hap_num(n_hap_, 0), hap_sum(n_hap_, 0);
-    for (uint32_t key : n.kmers) {
+    for (uint32_t pos : n.kmers) {
         if (r.packed) {
-            const uint64_t w = r.packed[key];
+            const uint64_t w = r.packed[pos];
             const uint8_t c = (uint8_t)w;
             const uint64_t bits = w >> 16;
             for (uint16_t hap : top) {
@@ -581,7 +589,8 @@ void Genotyper::posterior(Node& n, const std::vector<uint16_t>& top, const Run& 
             }
             continue;
         }
-        const uint8_t c = r.cov[key];
+        const uint8_t c = r.cov[pos];
+        const uint32_t key = key_of[pos];
         for (uint16_t hap : top) {
             if (((uint8_t)g_.bitvec[(size_t)key * bl + (hap >> 3)] >> (hap & 7)) & 1u) {
                 ++hap_num[hap];
@@ -694,13 +703,15 @@ void Genotyper::posterior(Node& n, const std::vector<uint16_t>& top, const Run& 
 // asked for one node ahead of their use
 void Genotyper::prefetch_keys(const Node& n, const Run& r) const
 {
-    if (r.packed) {
-        for (uint32_t key : n.kmers) __builtin_prefetch(&r.packed[key]);
+    if (n.kmers.empty()) return;
+    if (r.packed) {      // a node's entries are neighbours (unless an earlier sample pruned the list): one line per 8
+        for (size_t j = 0; j < n.kmers.size(); j += 8) __builtin_prefetch(&r.packed[n.kmers[j]]);
         return;
     }
     const uint64_t bl = g_.bitlen;
-    for (uint32_t key : n.kmers) {
-        __builtin_prefetch(&r.cov[key]);
+    __builtin_prefetch(&r.cov[n.kmers[0]]);
+    for (uint32_t pos : n.kmers) {
+        const uint32_t key = g_.node_key_index[pos];
         __builtin_prefetch(&g_.f[key]);
         __builtin_prefetch(&g_.bitvec[(size_t)key * bl]);
     }
@@ -731,8 +742,8 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, 
             if (nx < last) prefetch_keys(chr.nodes[nx], r);
         }
         if (r.packed) {
-            for (uint32_t key : n.kmers) {
-                const uint64_t w = r.packed[key];
+            for (uint32_t pos : n.kmers) {
+                const uint64_t w = r.packed[pos];
                 const uint8_t c = (uint8_t)w;
                 if (c <= 1 || (uint8_t)(w >> 8) > 1) continue;
                 const uint64_t bits = w >> 16;
@@ -741,8 +752,9 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, 
             }
             continue;
         }
-        for (uint32_t key : n.kmers) {
-            const uint8_t c = r.cov[key];
+        for (uint32_t pos : n.kmers) {
+            const uint32_t key = g_.node_key_index[pos];
+            const uint8_t c = r.cov[pos];
             if (c <= 1 || g_.f[key] > 1) continue;
             const uint8_t* bits = reinterpret_cast<const uint8_t*>(g_.bitvec.data()) + (size_t)key * bl;
             for (const uint16_t hap : hap_ids_)
@@ -1251,9 +1263,9 @@ void Genotyper::window_finish(WindowWork& w, const long double* prob, const uint
         std::fill(hap_num.begin(), hap_num.end(), 0);
         std::fill(hap_sum.begin(), hap_sum.end(), 0);
         if (j + 1 < w.nodes.size()) prefetch_keys(w.chr->nodes[w.nodes[j + 1]], r);
-        for (uint32_t key : n.kmers) {
+        for (uint32_t pos : n.kmers) {
             if (r.packed) {
-                const uint64_t word = r.packed[key];
+                const uint64_t word = r.packed[pos];
                 if ((uint8_t)(word >> 8) <= 1 && unique_kmers < UINT8_MAX) unique_kmers++;
                 const uint8_t c = (uint8_t)word;
                 const uint64_t bits = word >> 16;
@@ -1264,8 +1276,9 @@ void Genotyper::window_finish(WindowWork& w, const long double* prob, const uint
                     }
                 continue;
             }
+            const uint32_t key = g_.node_key_index[pos];
             if (g_.f[key] <= 1 && unique_kmers < UINT8_MAX) unique_kmers++;
-            const uint8_t c = r.cov[key];
+            const uint8_t c = r.cov[pos];
             for (uint16_t hap : w.top)
                 if (((uint8_t)g_.bitvec[(size_t)key * bl + (hap >> 3)] >> (hap & 7)) & 1u) {
                     ++hap_num[hap];
@@ -1289,32 +1302,47 @@ void Genotyper::window_finish(WindowWork& w, const long double* prob, const uint
 
 // ---------------------------------------------------------------- driver + VCF text
 std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const std::string& sample_name,
-                           const GenotypeConfig& cfg)
+                           const GenotypeConfig& cfg, const uint8_t* cov_node)
 {
     const auto t_begin = std::chrono::steady_clock::now();
+    const size_t n_entries = g_.node_key_index.size();
+    std::vector<uint8_t> gathered;
+    if (!cov_node) {      // a caller with per-key counters only (tests, the C API): the per-node gather on the host
+        gathered.resize(n_entries);
+        for (size_t j = 0; j < n_entries; ++j) gathered[j] = cov[g_.node_key_index[j]];
+        cov_node = gathered.data();
+    }
     Run r;
-    r.cov = cov;
+    r.cov = cov_node;
     r.hap_cov = hap_kmer_coverage;
     r.cfg = &cfg;
     r.haploid_num = std::min(cfg.haploid_num, n_hap_);
     if (g_.bitlen <= 6) {
-        const size_t n_keys = g_.f.size(), bl = g_.bitlen;
-        if (packed_.capacity() < n_keys) {
-            packed_.reserve(n_keys);
-            advise_huge_pages(packed_.data(), n_keys * sizeof(uint64_t));
+        // one word per entry of the node lists: multiplicity and haplotype bits are the graph's (filled once, a gather over the
+        // key arrays), the low byte is this sample's coverage -- a sequential pass over the device's cov_node
+        const size_t bl = g_.bitlen;
+        const bool first = packed_.size() != n_entries;
+        if (first) {
+            packed_.reserve(n_entries);
+            advise_huge_pages(packed_.data(), n_entries * sizeof(uint64_t));
+            packed_.resize(n_entries);
         }
-        packed_.resize(n_keys);
         const uint32_t nt = std::max(1u, cfg.threads);
         std::vector<std::thread> fill;
         auto part = [&](size_t a, size_t b) {
-            for (size_t i = a; i < b; ++i) {
-                uint64_t bits = 0;
-                std::memcpy(&bits, &g_.bitvec[i * bl], bl);
-                packed_[i] = (uint64_t)cov[i] | (uint64_t)(uint8_t)g_.f[i] << 8 | bits << 16;
+            if (first) {
+                for (size_t j = a; j < b; ++j) {
+                    const size_t key = g_.node_key_index[j];
+                    uint64_t bits = 0;
+                    std::memcpy(&bits, &g_.bitvec[key * bl], bl);
+                    packed_[j] = (uint64_t)cov_node[j] | (uint64_t)(uint8_t)g_.f[key] << 8 | bits << 16;
+                }
+            } else {
+                for (size_t j = a; j < b; ++j) packed_[j] = (packed_[j] & ~(uint64_t)0xFF) | cov_node[j];
             }
         };
-        for (uint32_t t = 1; t < nt; ++t) fill.emplace_back(part, n_keys * t / nt, n_keys * (t + 1) / nt);
-        part(0, n_keys / nt);
+        for (uint32_t t = 1; t < nt; ++t) fill.emplace_back(part, n_entries * t / nt, n_entries * (t + 1) / nt);
+        part(0, n_entries / nt);
         for (auto& th : fill) th.join();
         r.packed = packed_.data();
     }

@@ -39,10 +39,12 @@ class Genotyper {
 public:
     explicit Genotyper(const GraphIndex& g, unsigned threads = 1);   // threads: workers that copy the nodes' k-mer lists
 
-    // cov: c of every key in graph.bin record order (g.keys).  Returns the decompressed content of
+    // cov: c of every key in graph.bin record order (g.keys); cov_node: the same counters gathered in node order (entry j = key
+    // g.node_key_index[j]: vgmi_counts_finish's cov_node, the device's per-node depth lookup of src/genotype.cpp:546,660,1405-1408) --
+    // when given, cov is not read at all; when nullptr, the gather is done here.  Returns the decompressed content of
     // <sample>.varigraph.vcf.gz.  Throws std::runtime_error where the reference prints and exits.
     std::string run(const uint8_t* cov, float hap_kmer_coverage, const std::string& sample_name,
-                    const GenotypeConfig& cfg);
+                    const GenotypeConfig& cfg, const uint8_t* cov_node = nullptr);
 
     double last_hmm_seconds = 0, last_text_seconds = 0;   // of the last run(): windows on the pool / VCF text
     double last_device_seconds = 0;                       // ... of which the device recursion (0: the host ran it)
@@ -72,7 +74,7 @@ private:
     struct Node {
         uint32_t start = 0;
         const GraphNode* gn = nullptr;
-        std::vector<uint32_t> kmers;   // key indices; pruned by the forward pass, persists across samples
+        std::vector<uint32_t> kmers;   // places in the node-ordered arrays (GraphIndex::node_key_index); pruned by the forward pass, persists across samples
         std::vector<HmmScore> hmm;     // per sample
         SiteCall call;                 // per sample
     };
@@ -125,7 +127,7 @@ private:
     unsigned dev_parts_ = 4;
     uint32_t n_hap_ = 0;
     std::vector<uint16_t> hap_ids_;   // the keys of g_.hap_names in their order
-    std::vector<uint64_t> packed_;    // per key: coverage | multiplicity << 8 | haplotype bits << 16 (this sample)
+    std::vector<uint64_t> packed_;    // per node-list entry: coverage (this sample) | multiplicity << 8 | haplotype bits << 16
 };
 
 }  // namespace vgh

@@ -272,7 +272,7 @@ int main_genotype(int argc, char** argv)
     // overlaps the HMM of earlier ones.
     struct Job {
         std::string name;
-        std::vector<uint8_t> cov;
+        std::vector<uint8_t> cov_node;     // the sample's counters gathered per node on the device (K5): what the HMM's windows walk
         float hap_cov = 0;
     };
     std::mutex mu;
@@ -349,7 +349,7 @@ int main_genotype(int argc, char** argv)
                 }
                 cv.notify_all();
                 const double th = secs();
-                const std::string vcf = genotyper.run(job.cov.data(), job.hap_cov, job.name, hmm_cfg);
+                const std::string vcf = genotyper.run(nullptr, job.hap_cov, job.name, hmm_cfg, job.cov_node.data());
                 const double tz = secs();
                 vgh::Genotyper::write_gz(job.name + ".varigraph.vcf.gz", vcf, hmm_cfg.threads);
                 std::fprintf(stderr, "[varigraph-mi] %s: genotyping %.2f s (HMM %.2f with %zu of %zu windows on the device, VCF text %.2f, gzip %.2f) -> %s.varigraph.vcf.gz\n",
@@ -376,11 +376,13 @@ int main_genotype(int argc, char** argv)
                 const double ts = secs();
                 Job job;
                 job.name = name;
-                job.cov.resize(g.keys.size());
+                job.cov_node.resize(g.node_key_index.size());
                 vgh::FastqKmerHip fk(ctx, files, g.k, count_threads);
                 fk.build_fastq_index();
                 uint64_t hist[256];
-                fk.fetch(job.cov.data(), nullptr, hist);
+                // the per-node depth lookup (src/genotype.cpp:546,660,1405-1408) and the masked histogram (src/varigraph.cpp:253-296)
+                // happen on the device: node-ordered counters and 256 bins come back, the per-key array is not fetched
+                fk.fetch(nullptr, job.cov_node.data(), hist);
                 vgh::CoverageStats cs;
                 if (!vgh::coverage_stats(hist, fk.mReadBase, g.genome_size, o.hmm.sample_ploidy, o.use_depth, cs))
                     die("Failed to retrieve depth information of k-mers from the sequencing data. Please verify your data.");
