@@ -279,6 +279,7 @@ def main():
     ap.add_argument("--c3-reads", type=int, default=24_000_000)
     ap.add_argument("--c3-steps", type=int, default=20)
     ap.add_argument("--no-c5", action="store_true", help="skip the whole-genome-class (3 Gb, 5 M SNPs) leg")
+    ap.add_argument("--no-bloom", action="store_true", help="skip the construct-side Bloom leg")
     ap.add_argument("--c5-reads", type=int, default=100_000_000)
     ap.add_argument("--c5-steps", type=int, default=10)
     ap.add_argument("--verify-reads", type=int, default=1_000_000, help="unsaturated prefix checked against the oracle")
@@ -551,6 +552,46 @@ def main():
         del d_block5, d_cov5
         torch.cuda.empty_cache()
 
+    # ================= construct side: K3 counting-Bloom update and K4 query (15 B per reference k-mer) =================
+    bloom = None
+    if rank == 0 and world == 1 and not args.no_bloom:
+        G = 60_000_000                                   # the chr20-class reference of config 3 / 4
+        m_b, nh_b = vgmi.bloom_params(G - K + 1, 0.01)
+        gen = torch.Generator(device="cuda").manual_seed(7)
+        seq = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")[torch.randint(0, 4, (G,), generator=gen, device="cuda")]
+        seeds_b = np.arange(1, nh_b + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        best_add = None
+        for _ in range(4):
+            ctx.bloom_create(m_b, nh_b, seeds_b)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.bloom_add_seq_device(seq, G, K)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best_add = dt if best_add is None or dt < best_add else best_add
+        qk = (np.random.default_rng(3).integers(0, 1 << 54, size=10_000_000, dtype=np.uint64) << np.uint64(8)) | np.uint64(K)
+        t0 = time.perf_counter()
+        mn, nz = ctx.bloom_query(qk)                     # host keys in, host answers out (PCIe-inclusive, as construct calls it)
+        t_q = time.perf_counter() - t0
+        n_km = G - K + 1
+        tb = None
+        pb = os.path.join(ROOT, "profiles", "r3_bloom_traffic.json")
+        if os.path.exists(pb):
+            tb = json.load(open(pb))
+        bloom = {"workload": f"K3: every k-mer of a {G // 1_000_000} Mb random reference (resident in HBM) into BloomFilter(n = G - k + 1, p = 0.01): "
+                             f"{m_b / 1e6:.0f} MB of saturating byte counters, {nh_b} MurmurHash3 positions per k-mer; K4: 1e7 random keys queried",
+                 "add_kmers_per_s": n_km / best_add, "add_seconds": best_add,
+                 "filter_updates_per_s": nh_b * n_km / best_add,
+                 "roofline": {"bound": "hbm", "achieved": 15.0 * n_km / best_add / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": 15.0 * n_km / best_add / 1e9 / HBM_PEAK_GBS, "traffic": tb.get("bytes_per_launch") if tb else None,
+                              "bytes_per_kmer": 15.0, "kernel": "vgk::rows_kernel<2, false>",
+                              "note": "SURVEY 8d accounting: 1 base + 7 byte read-modify-writes per k-mer.  The kernel is bound by random "
+                                      "32-bit compare-and-swaps on a filter far larger than the caches (one 64-byte sector per "
+                                      "byte counter), not by bytes: see DESIGN.md section 6"},
+                 "query_keys_per_s_pcie_inclusive": qk.size / t_q, "query_hits": int(nz.sum())}
+        del seq
+        torch.cuda.empty_cache()
+
     if rank == 0:
         total_reads = world * n_reads * args.steps
         value = total_reads / elapsed
@@ -599,6 +640,8 @@ def main():
             out["c3"] = c3
         if c5 is not None:
             out["c5"] = c5
+        if bloom is not None:
+            out["bloom"] = bloom
         if world == 1 and not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
             out["cpu_baseline"] = cpu_baseline(haps, args.cpu_reads, cores)

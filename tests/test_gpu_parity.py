@@ -770,3 +770,101 @@ def test_bloom_even_k_segmented_matches_sequential_oracle(ctx, k):
     o.bloom_add_seq(want, seeds, seq, k)
     assert want.sum() > 0
     assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Small graphs (<= 65 536 k-mers): count27s_kernel and the path table (vgmi_ptable.hip).  The golden cohorts above run through
+# the default (12-mer grid + path table) in every test of this file; these add the shapes the path table has rare paths for and
+# keep the two A/B variants (hash-table drain, round 2's 16-mer kernel) in the matrix.
+def _small_graph(kind, rng):
+    from varigraph_amd import synth
+    if kind == "repeats":
+        # 120 diverged copies of one 300-bp element: every 12-mer of the element has dozens of places (> 4: the run goes to the
+        # hash table window by window) and the index buckets of neighbouring 12-mers fill up
+        unit = synth.make_reference(300, seed=5)
+        ref = np.tile(unit, 120)
+        mut = rng.random(ref.size) < 0.03
+        ref[mut] = synth._ACGT[(synth._CODE[ref[mut]] + rng.integers(1, 4, size=int(mut.sum()))) % 4]
+        n_var = 900
+    elif kind == "dense-sites":
+        # a SNP every ~12 bp: every k-mer spans two or three sites, chains are short, 12-mers have three and four places
+        ref = synth.make_reference(20_000, seed=6)
+        n_var = 1100
+    else:   # "plain": one SNP per kilobase (the C2 shape)
+        ref = synth.make_reference(400_000, seed=7)
+        n_var = 400
+    pos = np.sort(rng.choice(np.arange(100, ref.size - 100), size=n_var, replace=False))
+    alts = synth._ACGT[(synth._CODE[ref[pos]] + rng.integers(1, 4, size=n_var)) % 4]
+    keys = np.unique(vgmi.synth_snp_keys(ref, pos, alts, 27))
+    hap1 = ref.copy()
+    hap1[pos] = alts
+    return keys, [ref, hap1]
+
+
+@pytest.mark.parametrize("kind", ["plain", "repeats", "dense-sites"])
+@pytest.mark.parametrize("variant", [{}, {"VGMI_PTABLE": "0"}, {"VGMI_GRID12": "0"}], ids=["path-table", "hash-drain", "grid16-round2"])
+def test_small_graph_variants_match_oracle(kind, variant, monkeypatch):
+    for k_, v_ in variant.items():
+        monkeypatch.setenv(k_, v_)
+    rng = np.random.default_rng({"plain": 1, "repeats": 2, "dense-sites": 3}[kind])
+    keys, haps = _small_graph(kind, rng)
+    assert 1000 < keys.size <= 65536, keys.size
+    n_reads = 60_000
+    block = vgmi.synth_reads_host(23, 0, n_reads, 150, haps)
+    # reads with non-bases and lower case on top (validity masks, both strands come from the generator already)
+    b2 = block.copy()
+    idx = rng.choice(b2.size, size=3000, replace=False)
+    idx = idx[b2[idx] != 10]
+    b2[idx[:1500]] = ord("N")
+    b2[idx[1500:]] |= 0x20
+    c = vgmi.Context(0, buffer_mib=16)
+    try:
+        c.table_upload(keys, 27)
+        t = o.Table(keys)
+        for blk in (block, b2):
+            c.counts_reset()
+            # ragged pieces: the fast kernel takes whole pairs of rows, the generic kernel the ends
+            cuts = [0, 16 * 1000, 16 * 1000 + 16 * 37, n_reads]
+            for a, e in zip(cuts[:-1], cuts[1:]):
+                c.reads_submit(blk[a * 151:e * 151], e - a)
+            cov, _, _ = c.counts_finish()
+            t.reset()
+            t.count_block(blk, 27)
+            assert np.array_equal(cov, t.counts()), (kind, variant)
+        assert int(cov.astype(np.int64).sum()) > 50_000
+    finally:
+        c.close()
+
+
+def test_small_graph_saturation_through_the_path_table():
+    """Deep coverage of a tiny graph: every counter passes 254 -> 255 under contention from all wavefronts, the saturation
+    bits of both places and the hash table's flag are set by exactly that increment, later hits skip their atomic, and a reset
+    clears all of it (a shallow sample afterwards counts from zero)."""
+    rng = np.random.default_rng(3)
+    keys, haps = _small_graph("dense-sites", rng)
+    n_reads = 3_000_000                        # 20 kb x 2 haplotypes: ~11 000 x
+    c = vgmi.Context(0, buffer_mib=64)
+    try:
+        import torch
+        c.table_upload(keys, 27)
+        off = np.array([0, haps[0].size, haps[0].size + haps[1].size], dtype=np.uint64)
+        d_cat = torch.from_numpy(np.concatenate(haps)).cuda()
+        d_block = torch.empty(n_reads * 151, dtype=torch.uint8, device="cuda")
+        c.synth_reads_device(77, 0, n_reads, 150, d_cat, off, d_block)
+        c.counts_reset()
+        c.reads_submit_device(d_block, d_block.numel(), n_reads)
+        deep, _, _ = c.counts_finish()
+        pre = 40_000
+        small = d_block[: pre * 151].cpu().numpy()
+        t = o.Table(keys)
+        t.count_block(d_block.cpu().numpy(), 27)
+        assert np.array_equal(deep, t.counts())
+        assert (deep == 255).mean() > 0.9
+        c.counts_reset()
+        c.reads_submit(small, pre)
+        shallow, _, _ = c.counts_finish()
+        t.reset()
+        t.count_block(small, 27)
+        assert np.array_equal(shallow, t.counts()) and shallow.max() < 255
+    finally:
+        c.close()

@@ -12,6 +12,7 @@ def main():
     ap.add_argument("--genome", type=int, default=60_000_000)
     ap.add_argument("--k", type=int, default=27)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--query", type=int, default=0, help="also time K4 (BloomFilter::count / ::find) on this many random keys")
     args = ap.parse_args()
     import torch
     from varigraph_amd import vgmi
@@ -40,8 +41,15 @@ def main():
         res.append(time.perf_counter() - t)
     best = min(res[1:])
     n_kmers = G - k + 1
-    print(json.dumps({"genome": G, "k": k, "bloom_bytes": m, "n_hash": nh, "seconds": best, "kmers_per_s": n_kmers / best,
-                      "accounting_GBps": 15.0 * n_kmers / best / 1e9, "filter_updates_per_s": nh * n_kmers / best}))
+    out = {"genome": G, "k": k, "bloom_bytes": m, "n_hash": nh, "seconds": best, "kmers_per_s": n_kmers / best,
+           "accounting_GBps": 15.0 * n_kmers / best / 1e9, "filter_updates_per_s": nh * n_kmers / best}
+    if args.query:
+        qk = (np.random.default_rng(3).integers(0, 1 << (2 * k), size=args.query, dtype=np.uint64) << np.uint64(8)) | np.uint64(k)
+        t = time.perf_counter()
+        mn, nz = ctx.bloom_query(qk)
+        out["query_keys_per_s_pcie_inclusive"] = args.query / (time.perf_counter() - t)
+        out["query_all_nonzero"] = int(nz.sum())
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -3,9 +3,9 @@
 
 MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE come from their own --pmc passes, in KiB.  FETCH_SIZE tallies
 64 B per 128 B request on wide coalesced streams; the factor is measured on this kernel's own row loads (the
-calibration pass: same launch with the candidate runs dropped, VGMI_DBG=1, which reads exactly the read block plus the
-filter staging) and applied to the streaming part only.  The remainder -- scattered 16 B table probes that miss the XCD
-L2 -- and WRITE_SIZE are taken raw."""
+calibration pass: same launch with the candidate runs dropped, VGMI_DBG=1 in an ablation build, which reads exactly the read
+block plus the filter staging) and applied to the streaming part only.  The remainder -- index buckets, unitig sequence and
+bit words (round 3; table probes before) that miss the XCD L2 -- and WRITE_SIZE are taken raw."""
 import json, re, sys, os
 
 def main():
@@ -21,13 +21,12 @@ def main():
         if m:
             sect = "cal" if "pmc_cal" in m.group(1) else "main"
             continue
-        m = re.match(r"\s*\d+\s+[\d.]+\s+([\d.]+)\s+(FETCH_SIZE|WRITE_SIZE)\s+(.*count27x?_kernel\S*)", ln)
+        m = re.match(r"\s*\d+\s+[\d.]+\s+([\d.]+)\s+(FETCH_SIZE|WRITE_SIZE)\s+(.*count27[xs]?_kernel\S*)", ln)
         if m and sect:
             vals[(sect, m.group(2))] = float(m.group(1))
             kernel = m.group(3).split("(")[0].replace("void ", "").strip()
     fetch, cal, write = vals[("main", "FETCH_SIZE")], vals[("cal", "FETCH_SIZE")], vals[("main", "WRITE_SIZE")]
-    rows = n_reads * (read_len + 1) // 768
-    stream = rows * 768 + 256 * (128 << 10)    # complete rows + one 128 KiB filter staging per workgroup (256 CUs)
+    stream = n_reads * (read_len + 1) + 256 * (128 << 10)    # the read block once + one 128 KiB filter staging per workgroup (256 CUs)
     factor = stream / (cal * 1024)
     probe = (fetch - cal) * 1024
     wr = write * 1024
