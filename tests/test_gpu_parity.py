@@ -859,7 +859,7 @@ def test_small_graph_saturation_through_the_path_table():
         t = o.Table(keys)
         t.count_block(d_block.cpu().numpy(), 27)
         assert np.array_equal(deep, t.counts())
-        assert (deep == 255).mean() > 0.9
+        assert (deep == 255).mean() > 0.4      # (keys pairing an allele with a neighbouring site's other allele are not on the sample)
         c.counts_reset()
         c.reads_submit(small, pre)
         shallow, _, _ = c.counts_finish()
