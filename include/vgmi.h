@@ -230,6 +230,37 @@ int vgmi_hmm_calls_part(vgmi_ctx *ctx, uint32_t n_gt, uint32_t ploidy, const uin
                         const uint8_t *gid, const uint8_t *order, const uint64_t *fwd_step, const uint64_t *bwd_step, void *prob,
                         uint32_t *winner);
 
+/* ---- emission scores of the HMM's nodes on the device ---------------------------------------------------------------------
+ * replaces: GenotypeNameSpace::hidden_states + observable_states (src/genotype.cpp:640-830, 960-1000, most_likely_depth :1118-1145)
+ * for a DIPLOID sample whose windows all use the same genotype list -- every haplotype of the graph is selected (-n >= haplotypes),
+ * so no k-mer list is pruned and nothing is drawn per window.  Everything is in NODE ORDER (entry j = place j of the graph2node
+ * lists, the order of vgmi_counts_finish's cov_node):
+ *   entries_upload   once per graph: per entry  multiplicity << 8 | haplotype bits << 16  (f and BitVec of its k-mer)
+ *   sample_upload    per sample: the coverage of every entry (cov_node) 
+ *   emissions        per group of windows ("part"): per row (node) its entries [entry_begin, +entry_count), the bit mask of the
+ *                    genotypes' haplotypes that carry the reference allele there (gt0, bit p = used[p]); genotype g is the pair
+ *                    (used[pos_a[g]], used[pos_b[g]]); tables = the sample's 256 geometric terms then 256 Poisson terms for one
+ *                    and for two copies (16-byte long doubles; libm stays on the host).  Back come, per row, the number of k-mers
+ *                    that took part (0: the node has no score) and flags (bit 0: a haplotype's sequence has to be checked --
+ *                    the host must score this node itself and hand the row in with part_set_row; bit 1: a k-mer no selected
+ *                    haplotype carries -- the caller's guarantee does not hold, do not use the part).  The scores stay on the
+ *                    device inside the part.
+ *   part_calls       vgmi_hmm_calls on the part's rows (row / step numbers count from 0 inside the part)
+ * A context may hold several parts; calls on different parts may run side by side (own streams). */
+typedef struct vgmi_hmm_part vgmi_hmm_part;
+int vgmi_hmm_entries_upload(vgmi_ctx *ctx, const uint64_t *host_entries, size_t n_entries);
+int vgmi_hmm_sample_upload(vgmi_ctx *ctx, const uint8_t *host_cov_node, size_t n_entries);
+int vgmi_hmm_emissions(vgmi_ctx *ctx, uint32_t n_gt, uint32_t n_used, const uint8_t *used, const uint8_t *pos_a, const uint8_t *pos_b,
+                       uint64_t top_mask, uint32_t bit_len, float ave, double lower, double upper, const void *tables,
+                       uint64_t n_rows, const uint64_t *entry_begin, const uint32_t *entry_count, const uint16_t *gt0,
+                       uint32_t *n_kept_out, uint8_t *flags_out, vgmi_hmm_part **out);
+int vgmi_hmm_part_set_row(vgmi_hmm_part *part, uint64_t row, const void *obs_row);
+int vgmi_hmm_part_calls(vgmi_hmm_part *part, uint32_t ploidy, const uint8_t *keep, uint32_t n_windows, const uint32_t *row,
+                        const uint8_t *restart, const void *pow, uint64_t n_steps, const void *uniform, const vgmi_hmm_chain *chains,
+                        uint32_t n_chains, const uint8_t *gid, const uint8_t *order, const uint64_t *fwd_step, const uint64_t *bwd_step,
+                        void *prob, uint32_t *winner);
+void vgmi_hmm_part_free(vgmi_hmm_part *part);
+
 /* ---- bench / test tooling (not part of the reference seam) -------------------------------
  * Seeded synthetic reads (varigraph_amd/csrc/vg_synth.h) written straight into device memory:
  * reads [first_read, first_read+n_reads) of the stream `seed`, each `read_len` bases + '\n'.

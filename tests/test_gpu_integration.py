@@ -327,7 +327,7 @@ def test_native_cli_hmm_on_the_device_in_parts_equals_the_host_hmm(tmp_path):
     fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
     out = {}
     for name, knob in (("device", {}), ("host", {"VGH_HMM_DEVICE": "0"}), ("bound", {"VGH_HMM_DEVICE_GIB": "0"}),
-                       ("nomem", {"VGH_HMM_FAKE_NOMEM": "1"})):
+                       ("nomem", {"VGH_HMM_FAKE_NOMEM": "1", "VGH_HMM_EMIT_DEVICE": "0"}), ("host_emissions", {"VGH_HMM_EMIT_DEVICE": "0"})):
         w = tmp_path / name
         w.mkdir()
         (w / "samples.cfg").write_text("sample0 " + " ".join(fq) + "\n")
@@ -343,5 +343,8 @@ def test_native_cli_hmm_on_the_device_in_parts_equals_the_host_hmm(tmp_path):
     # parts the device has no memory for (here: every second part, after the fact) go back to the host with the haplotypes
     # already drawn: same bytes
     assert out["nomem"][0] == out["host"][0] and "back on the host" in out["nomem"][1]
+    # emission scores prepared by the host (round 2's path) and on the device (the default for this panel: all 15 haplotypes selected)
+    assert out["host_emissions"][0] == out["host"][0] and "emissions on the device" not in out["host_emissions"][1]
+    assert "emissions on the device" in out["device"][1]
     # a sample whose scores exceed the bound stays on the host
     assert out["bound"][0] == out["host"][0] and "HMM part" not in out["bound"][1]

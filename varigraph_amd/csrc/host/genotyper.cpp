@@ -558,7 +558,10 @@ Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, cons
             si++;
         }
     }
-    if (filter) node.kmers = kept;
+    if (filter) {
+        if (kept.size() != node.kmers.size()) lists_whole_.store(false, std::memory_order_relaxed);     // the device's emission path needs whole lists
+        node.kmers = kept;
+    }
     return ns;
 }
 
@@ -1383,6 +1386,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                             cfg.transition == "rec" && cfg.sample_ploidy >= 1 && cfg.sample_ploidy <= 4;
     std::vector<WindowWork> works(use_device ? tasks.size() : 0);
     size_t dev_n_gt = 0, total_room = 0;
+    bool dev_emit = false;
     const uint32_t dev_stride = cfg.sample_ploidy + 1;
     struct Raw {
         void* p = nullptr;
@@ -1415,7 +1419,11 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
             if (!fits_device && g_phase_on)
                 std::fprintf(stderr, "[varigraph-mi] HMM on the host: %.1f GiB of device memory wanted, %.1f free\n", need / 1073741824.0, free_b / 1073741824.0);
         }
-        if (fits_device && dev_n_gt >= 1 && dev_n_gt <= 2048 && total_room && total_room * dev_n_gt * sizeof(long double) <= (score_gib << 30)) {
+        const bool device_ok = fits_device && dev_n_gt >= 1 && dev_n_gt <= 2048 && total_room && total_room * dev_n_gt * sizeof(long double) <= (score_gib << 30);
+        // the emission scores can be computed on the device as well (below): a diploid sample, every haplotype selected, whole lists
+        dev_emit = device_ok && !emit_device_off_ && r.packed != nullptr && cfg.sample_ploidy == 2 && n_hap_ <= r.haploid_num && n_hap_ <= 16 &&
+                   dev_n_gt <= 128 && lists_whole_.load() && [] { const char* e = getenv("VGH_HMM_EMIT_DEVICE"); return !(e && e[0] == '0'); }();
+        if (device_ok && !dev_emit) {
             raw_obs.p = std::malloc(total_room * dev_n_gt * sizeof(long double));
             raw_pw.p = std::malloc(2 * total_room * 2 * dev_stride * sizeof(long double));
             raw_row.p = std::calloc(2 * total_room, sizeof(uint32_t));
@@ -1610,6 +1618,258 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
             }
         }
     };
+    // ---- emission scores on the device too (vgmi_hmm_emissions): a diploid sample over a graph all of whose haplotypes are selected
+    // (-n >= haplotypes: one genotype list for every window, no k-mer list is ever pruned).  Per part of the windows: the host lists
+    // the nodes' entry ranges, the device scores them from the node-ordered coverage it was handed, the host scores the few nodes
+    // whose haplotype sequences must be consulted, builds the step tables (libm) and the genotype strings, the device runs recursion
+    // and posterior on the scores where they lie.  VGH_HMM_EMIT_DEVICE=0: the host prepares the scores as before.
+    bool emitted_on_device = false;
+    std::atomic<size_t> emit_windows_done{0};
+    if (dev_emit) {
+        const double tb0 = since_begin() * 1e-9;
+        const float ave = r.hap_cov;
+        double lower = 256.0f, upper = -0.1f;
+        poisson_interval(ave, lower, upper);
+        // one genotype list for the whole sample
+        std::vector<uint16_t> top;
+        for (const auto& kv : g_.hap_names) top.push_back(kv.first);
+        std::sort(top.begin(), top.end());
+        const std::vector<std::vector<uint16_t>> genotypes = haplotype_combinations(top, cfg.sample_type, cfg.sample_ploidy, (uint16_t)(n_hap_ - 1));
+        const size_t n_gt = genotypes.size();
+        std::vector<uint16_t> used;
+        for (const auto& gtv : genotypes) used.insert(used.end(), gtv.begin(), gtv.end());
+        std::sort(used.begin(), used.end());
+        used.erase(std::unique(used.begin(), used.end()), used.end());
+        bool pairs = true;
+        for (const auto& gtv : genotypes) pairs = pairs && gtv.size() == 2;
+        if (pairs && n_gt >= 1 && n_gt <= 128 && used.size() <= 16) {
+            GenotypeList glist;
+            glist.off.assign(n_gt + 1, 0);
+            std::vector<uint8_t> where(n_hap_ + 1, 0), used8(used.size());
+            for (size_t p2 = 0; p2 < used.size(); ++p2) {
+                where[used[p2]] = (uint8_t)p2;
+                used8[p2] = (uint8_t)used[p2];
+            }
+            glist.pos_a.resize(n_gt);
+            glist.pos_b.resize(n_gt);
+            for (size_t gi = 0; gi < n_gt; ++gi) {
+                glist.flat.insert(glist.flat.end(), genotypes[gi].begin(), genotypes[gi].end());
+                glist.off[gi + 1] = (uint32_t)glist.flat.size();
+                glist.pos_a[gi] = where[genotypes[gi][0]];
+                glist.pos_b[gi] = where[genotypes[gi][1]];
+            }
+            auto shared2 = [](const std::vector<uint16_t>& a, const std::vector<uint16_t>& b) -> uint8_t {
+                uint8_t n2 = 0;
+                for (size_t x = 0, y = 0; x < a.size() && y < b.size();) {
+                    if (a[x] < b[y]) ++x;
+                    else if (b[y] < a[x]) ++y;
+                    else { ++n2; ++x; ++y; }
+                }
+                return n2;
+            };
+            std::vector<uint8_t> keep_mat(n_gt * n_gt);
+            for (size_t i = 0; i < n_gt; ++i)
+                for (size_t j = 0; j < n_gt; ++j) keep_mat[i * n_gt + j] = shared2(genotypes[i], genotypes[j]);
+            uint64_t top_mask = 0;
+            for (uint16_t hap : top) top_mask |= 1ULL << hap;
+            // the sample's libm values: geometric(error_param(ave), c) for h = 0, poisson(ave * h, c) for h = 1, 2
+            std::vector<long double> tab(768);
+            for (int c2 = 0; c2 < 256; ++c2) {
+                tab[c2] = geometric(error_param(ave), (uint8_t)c2);
+                for (uint8_t h = 1; h <= 2; ++h) tab[(size_t)h * 256 + c2] = poisson_pmf(ave * h, (uint8_t)c2);
+            }
+            if (!entries_uploaded_) {
+                if (vgmi_hmm_entries_upload(dev_, packed_.data(), packed_.size()) != VGMI_OK) throw std::runtime_error(std::string("device HMM emissions: ") + vgmi_last_error(dev_));
+                entries_uploaded_ = true;
+            }
+            if (vgmi_hmm_sample_upload(dev_, cov_node, n_entries) != VGMI_OK) throw std::runtime_error(std::string("device HMM emissions: ") + vgmi_last_error(dev_));
+            const uint32_t stride = cfg.sample_ploidy + 1;
+            const size_t max_parts_e = std::min<size_t>(4, dev_parts_);
+            const size_t per_part = std::max<size_t>(1, (tasks.size() + max_parts_e - 1) / max_parts_e);
+            const size_t n_parts_e = (tasks.size() + per_part - 1) / per_part;
+            std::atomic<bool> broken{false};
+            std::mutex err_mu;
+            std::string err_text;
+            auto part_fn = [&](size_t part) {
+                try {
+                    const size_t t0 = part * per_part, t1 = std::min(tasks.size(), t0 + per_part);
+                    // rows: every node the HMM works on, window after window
+                    std::vector<uint64_t> e_begin;
+                    std::vector<uint32_t> e_count, row_node;
+                    std::vector<uint16_t> gt0;
+                    std::vector<size_t> win_row0(t1 - t0 + 1, 0);
+                    for (size_t t = t0; t < t1; ++t) {
+                        Chrom& chr = *tasks[t].chr;
+                        auto vcf_chr = g_.vcf_info.find(chr.name);
+                        if (vcf_chr == g_.vcf_info.end()) throw std::runtime_error("'" + chr.name + "' does not exist in the VCF file.");
+                        for (uint32_t i = tasks[t].first; i < tasks[t].last; ++i) {
+                            const Node& n = chr.nodes[i];
+                            if (n.gn->hap_gt.size() <= 1) continue;
+                            if (cfg.sv_only) {
+                                auto site = vcf_chr->second.find(n.start);
+                                if (site == vcf_chr->second.end())
+                                    throw std::runtime_error("'" + chr.name + ":" + std::to_string(n.start) + "' does not exist in the VCF file.");
+                                if (site->second[3].size() < 50 && site->second[4].size() < 50) continue;
+                            }
+                            if (!n.kmers.empty() && (size_t)(n.kmers.back() - n.kmers.front()) + 1 != n.kmers.size()) {
+                                broken = true;      // a pruned list after all: the host path
+                                return;
+                            }
+                            e_begin.push_back(n.kmers.empty() ? 0 : n.kmers.front());
+                            e_count.push_back((uint32_t)n.kmers.size());
+                            uint16_t m = 0;
+                            for (size_t p2 = 0; p2 < used.size(); ++p2) m |= (uint16_t)((n.gn->hap_gt[used[p2]] == 0) << p2);
+                            gt0.push_back(m);
+                            row_node.push_back(i);
+                        }
+                        win_row0[t - t0 + 1] = e_begin.size();
+                    }
+                    const size_t n_rows = e_begin.size();
+                    std::vector<uint32_t> n_kept(n_rows ? n_rows : 1);
+                    std::vector<uint8_t> flags(n_rows ? n_rows : 1);
+                    struct PartHandle {
+                        vgmi_hmm_part* p = nullptr;
+                        ~PartHandle() { vgmi_hmm_part_free(p); }
+                    } ph;
+                    const int64_t ta = since_begin();
+                    if (vgmi_hmm_emissions(dev_, (uint32_t)n_gt, (uint32_t)used.size(), used8.data(), glist.pos_a.data(), glist.pos_b.data(), top_mask,
+                                           (uint32_t)g_.bitlen, ave, lower, upper, tab.data(), n_rows, e_begin.data(), e_count.data(), gt0.data(), n_kept.data(),
+                                           flags.data(), &ph.p) != VGMI_OK)
+                        throw std::runtime_error(std::string("device HMM emissions: ") + vgmi_last_error(dev_));
+                    for (size_t rr = 0; rr < n_rows; ++rr)
+                        if (flags[rr] & 2u) {
+                            broken = true;          // a k-mer no haplotype carries: the host path prunes it
+                            return;
+                        }
+                    // step tables, genotype strings and the nodes the host must score itself
+                    std::vector<long double> pw(2 * n_rows * 2 * stride);
+                    std::vector<uint32_t> row(2 * n_rows, 0);
+                    std::vector<uint8_t> restart(2 * n_rows, 0), gid(n_rows * n_gt, 0), order(n_rows * n_gt, 0);
+                    std::vector<uint64_t> fwd(n_rows, 0), bwd(n_rows, 0);
+                    std::vector<vgmi_hmm_chain> chains;
+                    std::vector<std::vector<uint32_t>> win_nodes(t1 - t0), win_rows(t1 - t0);
+                    size_t step_next = 0;
+                    for (size_t t = t0; t < t1; ++t) {
+                        Chrom& chr = *tasks[t].chr;
+                        const size_t ra = win_row0[t - t0], rb = win_row0[t - t0 + 1];
+                        struct Seen { uint32_t start, end; int64_t row; };
+                        std::vector<Seen> seen;
+                        seen.reserve(rb - ra);
+                        size_t m = 0;
+                        for (size_t rr = ra; rr < rb; ++rr) {
+                            Node& n = chr.nodes[row_node[rr]];
+                            const uint32_t n_start = n.start, n_end = (uint32_t)(n_start + n.gn->seqs[0].size() - 1);
+                            if (flags[rr] & 1u) {
+                                // a multi-copy, under-covered, carried k-mer: the reference consults the haplotype's sequence (:760-800)
+                                PhaseTimer tt(g_phase.states);
+                                NodeStates st = hidden_states(chr, row_node[rr], top, genotypes, used, glist, lower, upper, true, r, NodeStates(), nullptr);
+                                std::vector<long double> obs(n_gt);
+                                const size_t nk = st.c.size();
+                                for (size_t gi = 0; gi < n_gt; ++gi) {
+                                    long double res = 1.0L;
+                                    for (size_t j = 0; j < nk; ++j) {
+                                        const uint8_t h = st.h[j * n_gt + gi];
+                                        uint8_t c2 = st.c[j];
+                                        most_likely_depth(h, c2, st.f[j], ave, upper);
+                                        res *= tab[(size_t)h * 256 + c2];
+                                    }
+                                    obs[gi] = res;
+                                }
+                                n_kept[rr] = (uint32_t)nk;
+                                if (nk && vgmi_hmm_part_set_row(ph.p, rr, obs.data()) != VGMI_OK)
+                                    throw std::runtime_error(std::string("device HMM emissions: ") + vgmi_last_error(dev_));
+                            }
+                            if (n_kept[rr] == 0) {
+                                seen.push_back(Seen{n_start, n_end, -1});
+                                continue;
+                            }
+                            seen.push_back(Seen{n_start, n_end, (int64_t)rr});
+                            (void)genotype_strings(n, genotypes, gid.data() + rr * n_gt, order.data() + rr * n_gt);     // <= 128 strings: always fits
+                            win_nodes[t - t0].push_back(row_node[rr]);
+                            win_rows[t - t0].push_back((uint32_t)rr);
+                            ++m;
+                        }
+                        if (m == 0) continue;
+                        const size_t step0 = step_next;
+                        step_next += 2 * m;
+                        auto powers = [&](long double* dst, uint32_t distance) {
+                            long double recomb, no_recomb;
+                            std::tie(recomb, no_recomb) = transition_probabilities(distance, (uint16_t)n_hap_);
+                            for (uint32_t k = 0; k < stride; ++k) {
+                                dst[k] = std::pow(no_recomb, (int32_t)k);
+                                dst[stride + k] = std::pow(recomb, (int32_t)k);
+                            }
+                        };
+                        size_t j = 0;
+                        for (size_t q = 0; q < seen.size(); ++q) {
+                            if (seen[q].row < 0) continue;
+                            const size_t fs = step0 + j, bs = step0 + m + (m - 1 - j);
+                            powers(pw.data() + fs * 2 * stride, seen[q].start - (q ? seen[q - 1].end : 0u));
+                            restart[fs] = (q == 0 || seen[q - 1].row < 0) ? 1 : 0;
+                            row[fs] = (uint32_t)seen[q].row;
+                            powers(pw.data() + bs * 2 * stride, (q + 1 < seen.size() ? seen[q + 1].start : 0u) - seen[q].end);
+                            restart[bs] = (q + 1 == seen.size() || seen[q + 1].row < 0) ? 1 : 0;
+                            row[bs] = (uint32_t)seen[q].row;
+                            fwd[seen[q].row] = fs;
+                            bwd[seen[q].row] = bs;
+                            ++j;
+                        }
+                        chains.push_back(vgmi_hmm_chain{step0, m, 0, 0});
+                        chains.push_back(vgmi_hmm_chain{step0 + m, m, 0, 0});
+                    }
+                    std::vector<long double> prob(n_rows ? n_rows : 1);
+                    std::vector<uint32_t> winner(n_rows ? n_rows : 1, 0xFFFFFFFFu);
+                    if (step_next) {
+                        const long double uniform = 1.0L / (long double)n_gt;
+                        if (vgmi_hmm_part_calls(ph.p, cfg.sample_ploidy, keep_mat.data(), 1, row.data(), restart.data(), pw.data(), step_next, &uniform,
+                                                chains.data(), (uint32_t)chains.size(), gid.data(), order.data(), fwd.data(), bwd.data(), prob.data(),
+                                                winner.data()) != VGMI_OK)
+                            throw std::runtime_error(std::string("device HMM recursion: ") + vgmi_last_error(dev_));
+                    }
+                    const int64_t tbb = since_begin();
+                    if (g_phase_on)
+                        std::fprintf(stderr, "[varigraph-mi] HMM part %zu (windows %zu-%zu): emissions, recursion and posterior on the device from %.3f to %.3f s\n",
+                                     part, t0, t1 - 1, ta * 1e-9, tbb * 1e-9);
+                    for (int64_t v = dev_first.load(); ta < v && !dev_first.compare_exchange_weak(v, ta);) {}
+                    for (int64_t v = dev_last.load(); tbb > v && !dev_last.compare_exchange_weak(v, tbb);) {}
+                    // the calls
+                    for (size_t t = t0; t < t1; ++t) {
+                        WindowWork w;
+                        w.chr = tasks[t].chr;
+                        w.n_gt = n_gt;
+                        w.genotypes = genotypes;
+                        w.top = top;
+                        w.nodes = win_nodes[t - t0];
+                        std::vector<long double> pr(w.nodes.size());
+                        std::vector<uint32_t> wi(w.nodes.size());
+                        for (size_t q = 0; q < w.nodes.size(); ++q) {
+                            pr[q] = prob[win_rows[t - t0][q]];
+                            wi[q] = winner[win_rows[t - t0][q]];
+                        }
+                        window_finish(w, pr.data(), wi.data(), r);
+                        make_piece(t);
+                        emit_windows_done += !w.nodes.empty();
+                    }
+                } catch (const std::exception& e) {
+                    std::lock_guard<std::mutex> lock(err_mu);
+                    if (err_text.empty()) err_text = e.what();
+                }
+            };
+            std::vector<std::thread> pthreads;
+            for (size_t p2 = 1; p2 < n_parts_e; ++p2) pthreads.emplace_back(part_fn, p2);
+            if (n_parts_e) part_fn(0);
+            for (auto& th : pthreads) th.join();
+            if (!err_text.empty()) throw std::runtime_error(err_text);
+            if (broken.load()) {
+                // a list was pruned after all (or would be): this graph takes the host's preparation from now on
+                emit_device_off_ = true;
+                return run(cov, hap_kmer_coverage, sample_name, cfg, cov_node);
+            }
+            emitted_on_device = true;
+            if (g_phase_on) std::fprintf(stderr, "[varigraph-mi] HMM emissions on the device: %zu parts, %.2f s\n", n_parts_e, since_begin() * 1e-9 - tb0);
+        }
+    }
+    if (!emitted_on_device) {
     std::vector<std::thread> pool;
     for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(worker);
     worker();
@@ -1617,9 +1877,10 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
     for (auto& th : part_threads)
         if (th.joinable()) th.join();
     if (failed.load()) throw std::runtime_error(error);
+    }
     last_device_seconds = dev_last.load() > 0 ? (double)(dev_last.load() - dev_first.load()) * 1e-9 : 0;
     last_windows = tasks.size();
-    last_device_windows = 0;
+    last_device_windows = emitted_on_device ? emit_windows_done.load() : 0;
     for (const auto& w : works) last_device_windows += w.on_device && !w.nodes.empty();
     const auto t_hmm = std::chrono::steady_clock::now();
     last_hmm_seconds = std::chrono::duration<double>(t_hmm - t_begin).count();

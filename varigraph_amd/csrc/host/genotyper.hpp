@@ -16,6 +16,7 @@
 // haplotype and the pruned list persists across samples (ConstructIndex::reset does not restore it).
 #pragma once
 #include "vgmi.h"
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -127,6 +128,9 @@ private:
     unsigned dev_parts_ = 4;
     uint32_t n_hap_ = 0;
     std::vector<uint16_t> hap_ids_;   // the keys of g_.hap_names in their order
+    std::atomic<bool> lists_whole_{true};   // no node's k-mer list has been pruned (the device's emission path needs whole, contiguous lists)
+    bool entries_uploaded_ = false;         // the graph's per-entry multiplicity and haplotype bits are on dev_
+    bool emit_device_off_ = false;          // the device's emission path turned out not to apply to this graph
     std::vector<uint64_t> packed_;    // per node-list entry: coverage (this sample) | multiplicity << 8 | haplotype bits << 16
 };
 

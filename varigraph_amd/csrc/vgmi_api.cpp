@@ -63,6 +63,9 @@ struct vgmi_ctx {
     hipStream_t stream = nullptr;  // main stream: table build, device submits, finish
     // working memory of the HMM calls, kept between them: hipFree waits for every stream of the device, so a part that
     // finished would wait for the parts still running (vgmi_hmm_calls_part); a sample reuses the last sample's blocks
+    unsigned long long* d_hmm_entries = nullptr;     // vgmi_hmm_entries_upload: per node-list entry f << 8 | haplotype bits << 16
+    uint8_t* d_hmm_cov = nullptr;                    // vgmi_hmm_sample_upload: this sample's coverage per entry
+    size_t hmm_n_entries = 0;
     std::mutex hmm_mu;
     std::vector<std::pair<uint8_t*, size_t>> hmm_blocks;   // not in use
 
@@ -900,6 +903,8 @@ void vgmi_destroy(vgmi_ctx* c)
     if (c->d_hist) (void)hipFree(c->d_hist);
     if (c->reset_done) (void)hipEventDestroy(c->reset_done);
     for (auto& b : c->hmm_blocks) (void)hipFree(b.first);
+    if (c->d_hmm_entries) (void)hipFree(c->d_hmm_entries);
+    if (c->d_hmm_cov) (void)hipFree(c->d_hmm_cov);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1786,9 +1791,10 @@ namespace {
 int hmm_run(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, uint32_t n_windows, const void* obs, uint64_t row_lo,
             uint64_t row_hi, const uint32_t* row, const uint8_t* restart, const void* pow, uint64_t step_lo, uint64_t step_hi,
             const void* uniform, const vgmi_hmm_chain* chains, uint32_t n_chains, void* out, const uint8_t* gid, const uint8_t* order,
-            const uint64_t* fwd_step, const uint64_t* bwd_step, void* prob, uint32_t* winner)
+            const uint64_t* fwd_step, const uint64_t* bwd_step, void* prob, uint32_t* winner, const uint8_t* dev_obs = nullptr)
 {
-    if (!c || !keep || !obs || !row || !restart || !pow || !uniform || !chains) return VGMI_E_INVALID;
+    // dev_obs: the emission rows [row_lo, row_hi) are already on the device (vgmi_hmm_emissions); obs is then not read
+    if (!c || !keep || (!obs && !dev_obs) || !row || !restart || !pow || !uniform || !chains) return VGMI_E_INVALID;
     if (n_gt < 1 || n_gt > VGMI_HMM_MAX_GT || ploidy < 1 || ploidy > 4) return fail(c, VGMI_E_INVALID, "HMM recursion: 1..2048 genotypes of 1..4 haplotypes");
     if (n_gt > 128)     // the many-genotype kernel reads keep[p][g] for keep[g][p]: what two genotypes share is symmetric
         for (uint32_t w = 0; w < n_windows; ++w) {
@@ -1811,7 +1817,7 @@ int hmm_run(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, ui
     if (n_steps == 0 || n_chains == 0) return VGMI_OK;
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t stride = ploidy + 1;
-    const size_t b_keep = (size_t)n_windows * n_gt * n_gt, w_obs = (size_t)n_gt * 16, b_obs = (size_t)n_rows * w_obs, b_row = (size_t)n_steps * 4,
+    const size_t b_keep = (size_t)n_windows * n_gt * n_gt, w_obs = (size_t)n_gt * 16, b_obs = dev_obs ? 0 : (size_t)n_rows * w_obs, b_row = (size_t)n_steps * 4,
                  w_pow = (size_t)2 * stride * 16, b_pow = (size_t)n_steps * w_pow, b_ch = (size_t)n_chains * sizeof(vgmi_hmm_chain),
                  b_out = (size_t)n_steps * w_obs, b_gid = gid ? (size_t)n_rows * n_gt : 0, b_fs = gid ? (size_t)n_rows * 8 : 0,
                  b_prob = gid ? (size_t)n_rows * 16 : 0, b_win = gid ? (size_t)n_rows * 4 : 0;
@@ -1867,10 +1873,10 @@ int hmm_run(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, ui
     if (timing)
         for (auto& x : ev) (void)hipEventCreate(&x);
     if (timing) (void)hipEventRecord(ev[0], st);
-    const uint8_t* h_obs = static_cast<const uint8_t*>(obs) + row_lo * w_obs;
+    const uint8_t* h_obs = dev_obs ? nullptr : static_cast<const uint8_t*>(obs) + row_lo * w_obs;
     const uint8_t* h_pow = static_cast<const uint8_t*>(pow) + step_lo * w_pow;
     e = hipMemcpyAsync(d + o_keep, keep, b_keep, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d + o_obs, h_obs, b_obs, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && !dev_obs) e = hipMemcpyAsync(d + o_obs, h_obs, b_obs, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_row, row + step_lo, b_row, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_rs, restart + step_lo, n_steps, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_pow, h_pow, b_pow, hipMemcpyHostToDevice, st);
@@ -1888,7 +1894,7 @@ int hmm_run(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, ui
         P.n_gt = n_gt;
         P.ploidy = ploidy;
         P.keep = d + o_keep;
-        P.obs = back(d + o_obs, row_lo * w_obs);
+        P.obs = dev_obs ? back(const_cast<uint8_t*>(dev_obs), row_lo * w_obs) : back(d + o_obs, row_lo * w_obs);
         P.row = reinterpret_cast<const uint32_t*>(back(d + o_row, step_lo * 4));
         P.restart = back(d + o_rs, step_lo);
         P.pow = back(d + o_pow, step_lo * w_pow);
@@ -1937,6 +1943,138 @@ int hmm_run(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, ui
     return VGMI_OK;
 }
 }  // namespace
+
+struct vgmi_hmm_part {
+    vgmi_ctx* c = nullptr;
+    uint8_t* d_obs = nullptr;
+    uint64_t n_rows = 0;
+    uint32_t n_gt = 0;
+};
+
+int vgmi_hmm_entries_upload(vgmi_ctx* c, const uint64_t* entries, size_t n)
+{
+    if (!c || (n && !entries)) return VGMI_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->d_hmm_entries) (void)hipFree(c->d_hmm_entries);
+    if (c->d_hmm_cov) (void)hipFree(c->d_hmm_cov);
+    c->d_hmm_entries = nullptr;
+    c->d_hmm_cov = nullptr;
+    c->hmm_n_entries = n;
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_hmm_entries), (n ? n : 1) * 8) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_hmm_cov), n ? n : 1) != hipSuccess)
+        return fail(c, VGMI_E_NOMEM, "HMM emissions: not enough device memory for the node-list entries");
+    if (n) HIPCHK(c, hipMemcpy(c->d_hmm_entries, entries, n * 8, hipMemcpyHostToDevice));
+    return VGMI_OK;
+}
+
+int vgmi_hmm_sample_upload(vgmi_ctx* c, const uint8_t* cov_node, size_t n)
+{
+    if (!c || (n && !cov_node)) return VGMI_E_INVALID;
+    if (!c->d_hmm_cov || n != c->hmm_n_entries) return fail(c, VGMI_E_STATE, "HMM emissions: upload the entries first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n) HIPCHK(c, hipMemcpy(c->d_hmm_cov, cov_node, n, hipMemcpyHostToDevice));
+    return VGMI_OK;
+}
+
+int vgmi_hmm_emissions(vgmi_ctx* c, uint32_t n_gt, uint32_t n_used, const uint8_t* used, const uint8_t* pos_a, const uint8_t* pos_b,
+                       uint64_t top_mask, uint32_t bit_len, float ave, double lower, double upper, const void* tables, uint64_t n_rows,
+                       const uint64_t* entry_begin, const uint32_t* entry_count, const uint16_t* gt0, uint32_t* n_kept_out,
+                       uint8_t* flags_out, vgmi_hmm_part** out)
+{
+    if (!c || !used || !pos_a || !pos_b || !tables || !entry_begin || !entry_count || !gt0 || !n_kept_out || !flags_out || !out) return VGMI_E_INVALID;
+    if (n_gt < 1 || n_gt > 128 || n_used < 1 || n_used > 16 || bit_len < 1 || bit_len > 6) return fail(c, VGMI_E_INVALID, "HMM emissions: 1..128 pairs over 1..16 haplotypes, 1..6 bytes of haplotype bits");
+    if (!c->d_hmm_entries) return fail(c, VGMI_E_STATE, "HMM emissions: upload the entries first");
+    for (uint64_t r = 0; r < n_rows; ++r)
+        if (entry_begin[r] + entry_count[r] > c->hmm_n_entries) return fail(c, VGMI_E_INVALID, "HMM emissions: a row points outside the entries");
+    for (uint32_t g = 0; g < n_gt; ++g)
+        if (pos_a[g] >= n_used || pos_b[g] >= n_used) return fail(c, VGMI_E_INVALID, "HMM emissions: a genotype names a haplotype outside the list");
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    auto* part = new vgmi_hmm_part;
+    part->c = c;
+    part->n_rows = n_rows;
+    part->n_gt = n_gt;
+    const size_t b_obs = (size_t)(n_rows ? n_rows : 1) * n_gt * 16;
+    uint8_t* d_small = nullptr;     // entry_begin | entry_count | gt0 | tables | n_kept | flags
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_eb = 0, o_ec = up(o_eb + n_rows * 8), o_g0 = up(o_ec + n_rows * 4), o_tab = up(o_g0 + n_rows * 2), o_nk = up(o_tab + 768 * 16),
+                 o_fl = up(o_nk + n_rows * 4), total = up(o_fl + n_rows) + 256;
+    hipStream_t st = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&part->d_obs), b_obs);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_small), total);
+    if (e != hipSuccess) {
+        if (part->d_obs) (void)hipFree(part->d_obs);
+        delete part;
+        return fail(c, VGMI_E_NOMEM, "HMM emissions: not enough device memory");
+    }
+    e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_small + o_eb, entry_begin, n_rows * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_small + o_ec, entry_count, n_rows * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_small + o_g0, gt0, n_rows * 2, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_small + o_tab, tables, 768 * 16, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        HmmEmitParams P{};
+        P.packed = c->d_hmm_entries;
+        P.cov = c->d_hmm_cov;
+        P.entry_begin = reinterpret_cast<const uint64_t*>(d_small + o_eb);
+        P.entry_count = reinterpret_cast<const uint32_t*>(d_small + o_ec);
+        P.gt0 = reinterpret_cast<const uint16_t*>(d_small + o_g0);
+        P.row_lo = 0;
+        P.n_gt = n_gt;
+        P.n_used = n_used;
+        P.bl8 = 8 * bit_len;
+        memcpy(P.used, used, n_used);
+        memcpy(P.pos_a, pos_a, n_gt);
+        memcpy(P.pos_b, pos_b, n_gt);
+        P.top_mask = top_mask;
+        P.ave = ave;
+        P.lower = lower;
+        P.upper = upper;
+        P.tables = d_small + o_tab;
+        P.obs = part->d_obs;
+        P.n_kept = reinterpret_cast<uint32_t*>(d_small + o_nk);
+        P.flags = d_small + o_fl;
+        e = launch_hmm_emissions(P, n_rows, st);
+    }
+    if (e == hipSuccess && n_rows) e = hipMemcpyAsync(n_kept_out, d_small + o_nk, n_rows * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && n_rows) e = hipMemcpyAsync(flags_out, d_small + o_fl, n_rows, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (st) (void)hipStreamDestroy(st);
+    (void)hipFree(d_small);
+    if (e != hipSuccess) {
+        (void)hipFree(part->d_obs);
+        delete part;
+        HIPCHK(c, e);
+    }
+    *out = part;
+    return VGMI_OK;
+}
+
+int vgmi_hmm_part_set_row(vgmi_hmm_part* part, uint64_t row, const void* obs_row)
+{
+    if (!part || !obs_row || row >= part->n_rows) return VGMI_E_INVALID;
+    vgmi_ctx* c = part->c;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(part->d_obs + row * part->n_gt * 16, obs_row, (size_t)part->n_gt * 16, hipMemcpyHostToDevice));
+    return VGMI_OK;
+}
+
+int vgmi_hmm_part_calls(vgmi_hmm_part* part, uint32_t ploidy, const uint8_t* keep, uint32_t n_windows, const uint32_t* row, const uint8_t* restart,
+                        const void* pow, uint64_t n_steps, const void* uniform, const vgmi_hmm_chain* chains, uint32_t n_chains, const uint8_t* gid,
+                        const uint8_t* order, const uint64_t* fwd_step, const uint64_t* bwd_step, void* prob, uint32_t* winner)
+{
+    if (!part || !gid || !order || !fwd_step || !bwd_step || !prob || !winner) return VGMI_E_INVALID;
+    return hmm_run(part->c, part->n_gt, ploidy, keep, n_windows, nullptr, 0, part->n_rows, row, restart, pow, 0, n_steps, uniform, chains, n_chains,
+                   nullptr, gid, order, fwd_step, bwd_step, prob, winner, part->d_obs);
+}
+
+void vgmi_hmm_part_free(vgmi_hmm_part* part)
+{
+    if (!part) return;
+    (void)hipSetDevice(part->c->device);
+    if (part->d_obs) (void)hipFree(part->d_obs);
+    delete part;
+}
 
 int vgmi_device_memory(vgmi_ctx* c, size_t* free_bytes, size_t* total_bytes)
 {

@@ -441,6 +441,84 @@ __global__ __launch_bounds__(256) void hmm_posterior_big_kernel(HmmPostParams P)
     }
 }
 
+// ---- emission scores of a node: hidden states (src/genotype.cpp:640-830) and observable states (:960-1000) --------------------
+// One workgroup of 128 lanes per node, lane g = genotype g = a PAIR of haplotypes (used[pos_a[g]], used[pos_b[g]]).  Per k-mer of
+// the node, in list order: coverage c, multiplicity f and the haplotype bits decide, the same for every lane, which of the
+// <= 16 haplotypes count as carrying the k-mer; the lane's copy number h is the sum over its two; (h, c, f) go through
+// most_likely_depth (:1118-1145, float and double arithmetic as the host's SSE code does it) and select the term -- geometric for
+// h = 0, Poisson(ave * h) otherwise, libm values tabulated by the host per sample -- and the lane multiplies it onto its product
+// in the reference's long double (vg_x80.h).  A k-mer that is under-covered, multi-copy and carried makes the reference check
+// the haplotype's SEQUENCE (:760-800): such a node is flagged and scored by the host.  Every k-mer list must be whole (no
+// selected-haplotype pruning: all haplotypes are selected), which the caller guarantees and bit 1 of the flags verifies.
+__device__ __forceinline__ uint32_t hmm_most_likely_depth(uint32_t h, uint32_t c, uint32_t f, float ave, double upper)
+{
+    if (f == 1u) return c;
+    if (h > 0u && (float)c > ave * (float)h) return (uint32_t)(int32_t)(ave * (float)h) & 0xFFu;
+    if (h == 0u && (float)c > ave) return ((double)f > (double)((float)c) / upper) ? 0u : (uint32_t)(int32_t)((float)c / (float)f) & 0xFFu;
+    if (h == 0u) return (uint32_t)(int32_t)((float)c / (float)f) & 0xFFu;
+    return c;
+}
+
+__global__ __launch_bounds__(128) void hmm_emissions_kernel(HmmEmitParams P)
+{
+    __shared__ uint64_t s_tm[768];
+    __shared__ int32_t s_te[768];
+    const uint32_t g = threadIdx.x;
+    for (uint32_t i = g; i < 768u; i += 128u) {
+        const VgN80 t = n80_from(x80_load(P.tables + (size_t)i * 16));
+        s_tm[i] = t.m;
+        s_te[i] = t.e;
+    }
+    __syncthreads();
+    const uint64_t rowi = P.row_lo + blockIdx.x;
+    const uint64_t e0 = P.entry_begin[rowi];
+    const uint32_t cnt = P.entry_count[rowi], gt0 = P.gt0[rowi];
+    const bool active = g < P.n_gt;
+    const uint32_t pa = P.pos_a[active ? g : 0u], pb = P.pos_b[active ? g : 0u];
+    VgN80 prod;
+    prod.m = 1ULL << 63;      // 1.0L
+    prod.e = VG_X80_BIAS;
+    uint32_t kept = 0, flag = 0;
+    for (uint32_t j = 0; j < cnt; ++j) {
+        const unsigned long long w = P.packed[e0 + j];
+        const uint32_t c = P.cov[e0 + j], f = (uint32_t)(w >> 8) & 0xFFu;
+        const unsigned long long bits = w >> 16;
+        const uint32_t lb = (uint32_t)(bits >> (P.bl8 - 1u)) & 1u;
+        if ((bits & P.top_mask) == 0) {      // the host would drop it from the list: this path does not prune
+            flag |= 2u;
+            continue;
+        }
+        ++kept;
+        const bool in_interval = lb == 1u && (double)c >= P.lower && (double)c <= P.upper;
+        uint32_t om = 0;
+        for (uint32_t p = 0; p < P.n_used; ++p) {
+            const uint32_t one = (in_interval && ((gt0 >> p) & 1u)) ? 1u : (uint32_t)(bits >> P.used[p]) & 1u;
+            om |= one << p;
+        }
+        if ((double)c < P.lower && f >= 2u && om != 0) flag |= 1u;
+        const uint32_t fj = (lb == 1u && f == 1u) ? 2u : f;
+        const uint32_t h = ((om >> pa) & 1u) + ((om >> pb) & 1u);
+        const uint32_t cc = hmm_most_likely_depth(h, c, fj, P.ave, P.upper);
+        const uint32_t ti = h * 256u + cc;
+        VgN80 t;
+        t.m = s_tm[ti];
+        t.e = s_te[ti];
+        prod = n80_mul(prod, t);
+    }
+    if (active) x80_store(P.obs + (rowi * P.n_gt + g) * 16, n80_to(prod));
+    if (g == 0) {
+        P.n_kept[rowi] = kept;
+        P.flags[rowi] = (uint8_t)flag;
+    }
+}
+
+hipError_t launch_hmm_emissions(const HmmEmitParams& P, uint64_t n_rows, hipStream_t st)
+{
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(hmm_emissions_kernel, dim3((uint32_t)n_rows), dim3(128), 0, st, P);
+    return hipGetLastError();
+}
+
 hipError_t launch_hmm_posterior(const HmmPostParams& P, uint64_t n_rows, hipStream_t st)
 {
     if (n_rows == 0) return hipSuccess;

@@ -176,6 +176,26 @@ struct HmmPostParams {
     uint32_t* winner;               // per row: the entry that makes the call; 0xFFFFFFFF: none
 };
 hipError_t launch_hmm_posterior(const HmmPostParams& P, uint64_t n_rows, hipStream_t st);
+// emission scores of a window's nodes on the device (hidden states + observable states of src/genotype.cpp:640-830, 960-1000) for the
+// case every k-mer list is whole and every genotype is a pair of haplotypes (vgmi_hmm_emissions in vgmi.h)
+struct HmmEmitParams {
+    const unsigned long long* packed;   // per node-list entry: multiplicity << 8 | haplotype bits << 16 (the low byte is not used)
+    const uint8_t* cov;                 // per node-list entry: this sample's coverage
+    const uint64_t* entry_begin;        // per row: its node's entries
+    const uint32_t* entry_count;
+    const uint16_t* gt0;                // per row: bit p = haplotype used[p] carries the reference allele at this node
+    uint64_t row_lo;                    // the launch's first row (workgroup b takes row_lo + b)
+    uint32_t n_gt, n_used, bl8;         // genotypes (<= 128), haplotypes in them (<= 16), bit length of a k-mer's haplotype bits (8 * bitlen)
+    uint8_t used[16], pos_a[128], pos_b[128];
+    unsigned long long top_mask;
+    float ave;
+    double lower, upper;
+    const uint8_t* tables;              // 256 geometric terms (h = 0), then 256 Poisson terms per h = 1, 2: 16-byte long doubles
+    uint8_t* obs;                       // out, per row: n_gt scores
+    uint32_t* n_kept;                   // out, per row: k-mers that took part
+    uint8_t* flags;                     // out, per row: bit 0 the host must score this node (a haplotype's sequence has to be checked), bit 1 a k-mer no selected haplotype carries
+};
+hipError_t launch_hmm_emissions(const HmmEmitParams& P, uint64_t n_rows, hipStream_t st);
 size_t hmm_lds_bytes(uint32_t n_gt, uint32_t ploidy);
 
 hipError_t launch_xtable_build(const XTableView& t, const unsigned long long* slots8, const uint32_t* key_slot, const uint32_t* id_of_key,
