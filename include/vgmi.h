@@ -242,7 +242,7 @@ int vgmi_hmm_calls_part(vgmi_ctx *ctx, uint32_t n_gt, uint32_t ploidy, const uin
  *                    (used[pos_a[g]], used[pos_b[g]]); tables = the sample's 256 geometric terms then 256 Poisson terms for one
  *                    and for two copies (16-byte long doubles; libm stays on the host).  Back come, per row, the number of k-mers
  *                    that took part (0: the node has no score) and flags (bit 0: a haplotype's sequence has to be checked --
- *                    the host must score this node itself and hand the row in with part_set_row; bit 1: a k-mer no selected
+ *                    the host must score this node itself and hand its row in with part_set_rows; bit 1: a k-mer no selected
  *                    haplotype carries -- the caller's guarantee does not hold, do not use the part).  The scores stay on the
  *                    device inside the part.
  *   part_calls       vgmi_hmm_calls on the part's rows (row / step numbers count from 0 inside the part)
@@ -254,7 +254,7 @@ int vgmi_hmm_emissions(vgmi_ctx *ctx, uint32_t n_gt, uint32_t n_used, const uint
                        uint64_t top_mask, uint32_t bit_len, float ave, double lower, double upper, const void *tables,
                        uint64_t n_rows, const uint64_t *entry_begin, const uint32_t *entry_count, const uint16_t *gt0,
                        uint32_t *n_kept_out, uint8_t *flags_out, vgmi_hmm_part **out);
-int vgmi_hmm_part_set_row(vgmi_hmm_part *part, uint64_t row, const void *obs_row);
+int vgmi_hmm_part_set_rows(vgmi_hmm_part *part, uint64_t n, const uint64_t *rows, const void *obs_rows /* n x n_gt long doubles */);
 int vgmi_hmm_part_calls(vgmi_hmm_part *part, uint32_t ploidy, const uint8_t *keep, uint32_t n_windows, const uint32_t *row,
                         const uint8_t *restart, const void *pow, uint64_t n_steps, const void *uniform, const vgmi_hmm_chain *chains,
                         uint32_t n_chains, const uint8_t *gid, const uint8_t *order, const uint64_t *fwd_step, const uint64_t *bwd_step,

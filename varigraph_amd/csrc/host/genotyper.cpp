@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <iomanip>
 #include <iterator>
 #include <map>
@@ -721,6 +722,137 @@ void Genotyper::prefetch_keys(const Node& n, const Run& r) const
 }
 
 
+// ---------------------------------------------------------------- emission scores of one node (observable_states, :960-1000)
+// Scratch and the sample's memoised libm values, one per thread that scores nodes.
+struct Genotyper::ScoreCtx {
+    float ave = 0;
+    double score_up = 0;
+    std::vector<long double> pois_tab = std::vector<long double>(256 * 256);
+    std::vector<uint8_t> pois_have = std::vector<uint8_t>(256 * 256, 0);
+    long double geo_tab[256];
+    bool geo_have[256] = {false};
+    std::vector<long double> term_buf, class_prod;
+    std::vector<uint8_t> term_have;
+};
+
+std::vector<long double> Genotyper::score_states(const NodeStates& ns, ScoreCtx& sc) const
+{
+    const float ave = sc.ave;
+    const double score_up = sc.score_up;
+    std::vector<long double>& pois_tab = sc.pois_tab;
+    std::vector<uint8_t>& pois_have = sc.pois_have;
+    long double* const geo_tab = sc.geo_tab;
+    bool* const geo_have = sc.geo_have;
+    std::vector<long double>& term_buf = sc.term_buf;
+    std::vector<long double>& class_prod = sc.class_prod;
+    std::vector<uint8_t>& term_have = sc.term_have;
+    std::vector<long double> obs;
+    const size_t nk = ns.c.size(), ng = ns.n_genotypes;
+    if (ng == 0 || nk == 0) return obs;
+    // with classes of equivalent genotypes (hidden_states) every column of h equals its class's first member's:
+    // those columns alone say which copy numbers occur
+    const bool by_class = !ns.rep.empty();
+    uint8_t max_h = 0;
+    if (by_class) {
+        for (size_t j = 0; j < nk; ++j)
+            for (uint16_t g : ns.rep) max_h = std::max(max_h, ns.h[j * ng + g]);
+    } else {
+        for (uint8_t h : ns.h) max_h = h > max_h ? h : max_h;
+    }
+    const size_t hs = (size_t)max_h + 1;
+    // the term of k-mer j under h copies, for the (j, h) that occur
+    term_buf.resize(nk * hs);
+    // which copy numbers occur for k-mer j: one pass over its row (a term is only evaluated for those, as the
+    // reference evaluates it)
+    term_have.assign(nk * hs, 0);
+    for (size_t j = 0; j < nk; ++j) {
+        const uint8_t* hj = &ns.h[j * ng];
+        uint8_t* have = &term_have[j * hs];
+        if (by_class) {
+            for (uint16_t g : ns.rep) have[hj[g]] = 1;
+        } else {
+            for (size_t gi = 0; gi < ng; ++gi) have[hj[gi]] = 1;
+        }
+    }
+    for (size_t j = 0; j < nk; ++j) {
+        for (size_t hh = 0; hh < hs; ++hh) {
+            if (!term_have[j * hs + hh]) continue;
+            const uint8_t h = (uint8_t)hh;
+            uint8_t c = ns.c[j];
+            most_likely_depth(h, c, ns.f[j], ave, score_up);
+            if (h == 0) {
+                if (!geo_have[c]) {
+                    geo_tab[c] = geometric(error_param(ave), c);
+                    geo_have[c] = true;
+                }
+                term_buf[j * hs + h] = geo_tab[c];
+            } else {
+                const size_t slot = (size_t)h * 256 + c;
+                if (!pois_have[slot]) {
+                    pois_tab[slot] = poisson_pmf(ave * h, c);
+                    pois_have[slot] = 1;
+                }
+                term_buf[j * hs + h] = pois_tab[slot];
+            }
+        }
+    }
+    obs.resize(ng);
+    if (!ns.rep.empty()) {
+        // one product per class of genotypes with the same column of h (the same factors in the same order give the
+        // same bits), four classes in x87 registers at a time
+        const size_t nc = ns.rep.size();
+        std::vector<long double>& prod = class_prod;
+        prod.resize(nc);
+        size_t ci = 0;
+        for (; ci + 4 <= nc; ci += 4) {
+            const size_t g0 = ns.rep[ci], g1 = ns.rep[ci + 1], g2 = ns.rep[ci + 2], g3 = ns.rep[ci + 3];
+            long double r0 = 1.0L, r1 = 1.0L, r2 = 1.0L, r3 = 1.0L;
+            const uint8_t* hj = ns.h.data();
+            const long double* t = term_buf.data();
+            for (size_t j = 0; j < nk; ++j, hj += ng, t += hs) {
+                r0 *= t[hj[g0]];
+                r1 *= t[hj[g1]];
+                r2 *= t[hj[g2]];
+                r3 *= t[hj[g3]];
+            }
+            prod[ci] = r0;
+            prod[ci + 1] = r1;
+            prod[ci + 2] = r2;
+            prod[ci + 3] = r3;
+        }
+        for (; ci < nc; ++ci) {
+            long double res = 1.0L;
+            const size_t g = ns.rep[ci];
+            for (size_t j = 0; j < nk; ++j) res *= term_buf[j * hs + ns.h[j * ng + g]];
+            prod[ci] = res;
+        }
+        for (size_t g = 0; g < ng; ++g) obs[g] = prod[ns.cls[g]];
+        return obs;
+    }
+    size_t gi = 0;
+    for (; gi + 4 <= ng; gi += 4) {   // four products in x87 registers, each in k-mer order
+        long double r0 = 1.0L, r1 = 1.0L, r2 = 1.0L, r3 = 1.0L;
+        const uint8_t* hj = &ns.h[gi];
+        const long double* t = term_buf.data();
+        for (size_t j = 0; j < nk; ++j, hj += ng, t += hs) {
+            r0 *= t[hj[0]];
+            r1 *= t[hj[1]];
+            r2 *= t[hj[2]];
+            r3 *= t[hj[3]];
+        }
+        obs[gi] = r0;
+        obs[gi + 1] = r1;
+        obs[gi + 2] = r2;
+        obs[gi + 3] = r3;
+    }
+    for (; gi < ng; ++gi) {
+        long double res = 1.0L;
+        for (size_t j = 0; j < nk; ++j) res *= term_buf[j * hs + ns.h[j * ng + gi]];
+        obs[gi] = res;
+    }
+    return obs;
+}
+
 // ---------------------------------------------------------------- one window: selection, forward, backward, posterior
 void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, WindowWork* work, const std::vector<uint16_t>* forced_top)
 {
@@ -790,10 +922,6 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, 
     const float ave = r.hap_cov;
     double score_lo = 256.0f, score_up = -0.1f;
     poisson_interval(ave, score_lo, score_up);
-    std::vector<long double> pois_tab(256 * 256);
-    std::vector<uint8_t> pois_have(256 * 256, 0);
-    long double geo_tab[256];
-    bool geo_have[256] = {false};
     // genotypes of this window, the haplotypes they use, and how many haplotypes two genotypes share (the size of
     // std::set_intersection of the two sorted vectors)
     const std::vector<std::vector<uint16_t>> genotypes =
@@ -839,115 +967,10 @@ void Genotyper::window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, 
     // Every genotype's score is the product of its k-mers' terms in k-mer order (observable_states); walking the
     // k-mers in the outer loop keeps that order per genotype and turns one long dependent multiply chain per
     // genotype into n_genotypes independent ones.  A k-mer's term depends on the genotype only through h.
-    std::vector<long double> term_buf, class_prod;
-    std::vector<uint8_t> term_have;
-    auto score_states = [&](const NodeStates& ns) -> std::vector<long double> {
-        std::vector<long double> obs;
-        const size_t nk = ns.c.size(), ng = ns.n_genotypes;
-        if (ng == 0 || nk == 0) return obs;
-        // with classes of equivalent genotypes (hidden_states) every column of h equals its class's first member's:
-        // those columns alone say which copy numbers occur
-        const bool by_class = !ns.rep.empty();
-        uint8_t max_h = 0;
-        if (by_class) {
-            for (size_t j = 0; j < nk; ++j)
-                for (uint16_t g : ns.rep) max_h = std::max(max_h, ns.h[j * ng + g]);
-        } else {
-            for (uint8_t h : ns.h) max_h = h > max_h ? h : max_h;
-        }
-        const size_t hs = (size_t)max_h + 1;
-        // the term of k-mer j under h copies, for the (j, h) that occur
-        term_buf.resize(nk * hs);
-        // which copy numbers occur for k-mer j: one pass over its row (a term is only evaluated for those, as the
-        // reference evaluates it)
-        term_have.assign(nk * hs, 0);
-        for (size_t j = 0; j < nk; ++j) {
-            const uint8_t* hj = &ns.h[j * ng];
-            uint8_t* have = &term_have[j * hs];
-            if (by_class) {
-                for (uint16_t g : ns.rep) have[hj[g]] = 1;
-            } else {
-                for (size_t gi = 0; gi < ng; ++gi) have[hj[gi]] = 1;
-            }
-        }
-        for (size_t j = 0; j < nk; ++j) {
-            for (size_t hh = 0; hh < hs; ++hh) {
-                if (!term_have[j * hs + hh]) continue;
-                const uint8_t h = (uint8_t)hh;
-                uint8_t c = ns.c[j];
-                most_likely_depth(h, c, ns.f[j], ave, score_up);
-                if (h == 0) {
-                    if (!geo_have[c]) {
-                        geo_tab[c] = geometric(error_param(ave), c);
-                        geo_have[c] = true;
-                    }
-                    term_buf[j * hs + h] = geo_tab[c];
-                } else {
-                    const size_t slot = (size_t)h * 256 + c;
-                    if (!pois_have[slot]) {
-                        pois_tab[slot] = poisson_pmf(ave * h, c);
-                        pois_have[slot] = 1;
-                    }
-                    term_buf[j * hs + h] = pois_tab[slot];
-                }
-            }
-        }
-        obs.resize(ng);
-        if (!ns.rep.empty()) {
-            // one product per class of genotypes with the same column of h (the same factors in the same order give the
-            // same bits), four classes in x87 registers at a time
-            const size_t nc = ns.rep.size();
-            std::vector<long double>& prod = class_prod;
-            prod.resize(nc);
-            size_t ci = 0;
-            for (; ci + 4 <= nc; ci += 4) {
-                const size_t g0 = ns.rep[ci], g1 = ns.rep[ci + 1], g2 = ns.rep[ci + 2], g3 = ns.rep[ci + 3];
-                long double r0 = 1.0L, r1 = 1.0L, r2 = 1.0L, r3 = 1.0L;
-                const uint8_t* hj = ns.h.data();
-                const long double* t = term_buf.data();
-                for (size_t j = 0; j < nk; ++j, hj += ng, t += hs) {
-                    r0 *= t[hj[g0]];
-                    r1 *= t[hj[g1]];
-                    r2 *= t[hj[g2]];
-                    r3 *= t[hj[g3]];
-                }
-                prod[ci] = r0;
-                prod[ci + 1] = r1;
-                prod[ci + 2] = r2;
-                prod[ci + 3] = r3;
-            }
-            for (; ci < nc; ++ci) {
-                long double res = 1.0L;
-                const size_t g = ns.rep[ci];
-                for (size_t j = 0; j < nk; ++j) res *= term_buf[j * hs + ns.h[j * ng + g]];
-                prod[ci] = res;
-            }
-            for (size_t g = 0; g < ng; ++g) obs[g] = prod[ns.cls[g]];
-            return obs;
-        }
-        size_t gi = 0;
-        for (; gi + 4 <= ng; gi += 4) {   // four products in x87 registers, each in k-mer order
-            long double r0 = 1.0L, r1 = 1.0L, r2 = 1.0L, r3 = 1.0L;
-            const uint8_t* hj = &ns.h[gi];
-            const long double* t = term_buf.data();
-            for (size_t j = 0; j < nk; ++j, hj += ng, t += hs) {
-                r0 *= t[hj[0]];
-                r1 *= t[hj[1]];
-                r2 *= t[hj[2]];
-                r3 *= t[hj[3]];
-            }
-            obs[gi] = r0;
-            obs[gi + 1] = r1;
-            obs[gi + 2] = r2;
-            obs[gi + 3] = r3;
-        }
-        for (; gi < ng; ++gi) {
-            long double res = 1.0L;
-            for (size_t j = 0; j < nk; ++j) res *= term_buf[j * hs + ns.h[j * ng + gi]];
-            obs[gi] = res;
-        }
-        return obs;
-    };
+    ScoreCtx sctx;
+    sctx.ave = ave;
+    sctx.score_up = score_up;
+    auto score_states = [&](const NodeStates& ns) -> std::vector<long double> { return this->score_states(ns, sctx); };
     // one step of the forward (alpha) or backward (beta) recursion (:1170-1380); obs[i] = emission of genotype i
     auto recursion = [&](const std::vector<HmmScore>& prev, bool use_alpha, long double recomb, long double no_recomb,
                          const std::vector<long double>& obs) -> std::vector<long double> {
@@ -1257,14 +1280,16 @@ bool Genotyper::genotype_strings(const Node& n, const std::vector<std::vector<ui
 void Genotyper::window_finish(WindowWork& w, const long double* prob, const uint32_t* winner, const Run& r)
 {
     const uint64_t bl = g_.bitlen;
-    std::vector<uint64_t> hap_num(n_hap_), hap_sum(n_hap_);
     for (size_t j = 0; j < w.nodes.size(); ++j) {
         if (winner[j] >= w.n_gt) continue;            // no entry with a positive posterior: no call
         PhaseTimer t(g_phase.post);
         Node& n = w.chr->nodes[w.nodes[j]];
+        // k-mer count and coverage sum of the CALLED haplotypes only (posterior() tallies every selected haplotype and then reads
+        // the called ones: the same numbers for a seventh of the work at 15 haplotypes)
+        const std::vector<uint16_t>& called = w.genotypes[winner[j]];
+        uint64_t num[8] = {0}, sum[8] = {0};
+        const size_t nc = std::min<size_t>(called.size(), 8);
         uint8_t unique_kmers = 0;
-        std::fill(hap_num.begin(), hap_num.end(), 0);
-        std::fill(hap_sum.begin(), hap_sum.end(), 0);
         if (j + 1 < w.nodes.size()) prefetch_keys(w.chr->nodes[w.nodes[j + 1]], r);
         for (uint32_t pos : n.kmers) {
             if (r.packed) {
@@ -1272,31 +1297,30 @@ void Genotyper::window_finish(WindowWork& w, const long double* prob, const uint
                 if ((uint8_t)(word >> 8) <= 1 && unique_kmers < UINT8_MAX) unique_kmers++;
                 const uint8_t c = (uint8_t)word;
                 const uint64_t bits = word >> 16;
-                for (uint16_t hap : w.top)
-                    if ((bits >> hap) & 1u) {
-                        ++hap_num[hap];
-                        hap_sum[hap] += c;
+                for (size_t q = 0; q < nc; ++q)
+                    if (called[q] < n_hap_ && ((bits >> called[q]) & 1u)) {
+                        ++num[q];
+                        sum[q] += c;
                     }
                 continue;
             }
             const uint32_t key = g_.node_key_index[pos];
             if (g_.f[key] <= 1 && unique_kmers < UINT8_MAX) unique_kmers++;
             const uint8_t c = r.cov[pos];
-            for (uint16_t hap : w.top)
-                if (((uint8_t)g_.bitvec[(size_t)key * bl + (hap >> 3)] >> (hap & 7)) & 1u) {
-                    ++hap_num[hap];
-                    hap_sum[hap] += c;
+            for (size_t q = 0; q < nc; ++q)
+                if (called[q] < n_hap_ && (((uint8_t)g_.bitvec[(size_t)key * bl + (called[q] >> 3)] >> (called[q] & 7)) & 1u)) {
+                    ++num[q];
+                    sum[q] += c;
                 }
         }
         n.call.probability = prob[j];
-        n.call.haps = w.genotypes[winner[j]];
+        n.call.haps = called;
         n.call.kmer_num.clear();
         n.call.kmer_ave_cov.clear();
-        for (uint16_t hap : n.call.haps) {
-            const uint64_t num = hap < n_hap_ ? hap_num[hap] : 0;
-            const uint64_t sum = hap < n_hap_ ? hap_sum[hap] : 0;
-            const float ave = (num != 0) ? static_cast<float>(sum) / (float)num : 0.0;
-            n.call.kmer_num.push_back(num);
+        for (size_t q = 0; q < called.size(); ++q) {
+            const uint64_t nq = q < nc ? num[q] : 0, sq = q < nc ? sum[q] : 0;
+            const float ave = (nq != 0) ? static_cast<float>(sq) / (float)nq : 0.0;
+            n.call.kmer_num.push_back(nq);
             n.call.kmer_ave_cov.push_back(ave);
         }
         n.call.unique_kmers = unique_kmers;
@@ -1741,57 +1765,101 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                             broken = true;          // a k-mer no haplotype carries: the host path prunes it
                             return;
                         }
-                    // step tables, genotype strings and the nodes the host must score itself
-                    std::vector<long double> pw(2 * n_rows * 2 * stride);
-                    std::vector<uint32_t> row(2 * n_rows, 0);
-                    std::vector<uint8_t> restart(2 * n_rows, 0), gid(n_rows * n_gt, 0), order(n_rows * n_gt, 0);
-                    std::vector<uint64_t> fwd(n_rows, 0), bwd(n_rows, 0);
-                    std::vector<vgmi_hmm_chain> chains;
-                    std::vector<std::vector<uint32_t>> win_nodes(t1 - t0), win_rows(t1 - t0);
-                    size_t step_next = 0;
-                    for (size_t t = t0; t < t1; ++t) {
-                        Chrom& chr = *tasks[t].chr;
-                        const size_t ra = win_row0[t - t0], rb = win_row0[t - t0 + 1];
-                        struct Seen { uint32_t start, end; int64_t row; };
-                        std::vector<Seen> seen;
-                        seen.reserve(rb - ra);
-                        size_t m = 0;
-                        for (size_t rr = ra; rr < rb; ++rr) {
+                    // The part's windows on `helpers` threads, three passes.  A: the nodes the host must score itself (their scores are
+                    // handed in as one block), the genotype strings, which nodes have a score at all.  B: the step tables (libm) at the
+                    // places A's counts give them.  Then recursion and posterior on the device.  C: the calls and the VCF lines.
+                    const size_t nw = t1 - t0;
+                    const size_t helpers = std::max<size_t>(1, std::min<size_t>(nw, n_threads / n_parts_e));
+                    auto over_windows = [&](const std::function<void(size_t)>& fn) {
+                        std::atomic<size_t> nextw{0};
+                        std::string herr;
+                        std::mutex hmu;
+                        auto body = [&]() {
+                            for (;;) {
+                                const size_t wi = nextw.fetch_add(1);
+                                if (wi >= nw) return;
+                                try {
+                                    fn(wi);
+                                } catch (const std::exception& e) {
+                                    std::lock_guard<std::mutex> lock(hmu);
+                                    if (herr.empty()) herr = e.what();
+                                }
+                            }
+                        };
+                        std::vector<std::thread> hs;
+                        for (size_t h2 = 1; h2 < helpers; ++h2) hs.emplace_back(body);
+                        body();
+                        for (auto& th : hs) th.join();
+                        if (!herr.empty()) throw std::runtime_error(herr);
+                    };
+                    struct Seen { uint32_t start, end; int64_t row; };
+                    std::vector<std::vector<Seen>> seen(nw);
+                    std::vector<std::vector<uint32_t>> win_nodes(nw), win_rows(nw);
+                    std::vector<std::vector<uint64_t>> host_rows(nw);
+                    std::vector<std::vector<long double>> host_obs(nw);
+                    std::vector<uint8_t> gid(n_rows * n_gt, 0), order(n_rows * n_gt, 0);
+                    over_windows([&](size_t wi) {
+                        Chrom& chr = *tasks[t0 + wi].chr;
+                        ScoreCtx sctx;
+                        sctx.ave = ave;
+                        sctx.score_up = upper;
+                        NodeStates st;
+                        for (size_t rr = win_row0[wi]; rr < win_row0[wi + 1]; ++rr) {
                             Node& n = chr.nodes[row_node[rr]];
                             const uint32_t n_start = n.start, n_end = (uint32_t)(n_start + n.gn->seqs[0].size() - 1);
                             if (flags[rr] & 1u) {
                                 // a multi-copy, under-covered, carried k-mer: the reference consults the haplotype's sequence (:760-800)
-                                PhaseTimer tt(g_phase.states);
-                                NodeStates st = hidden_states(chr, row_node[rr], top, genotypes, used, glist, lower, upper, true, r, NodeStates(), nullptr);
-                                std::vector<long double> obs(n_gt);
-                                const size_t nk = st.c.size();
-                                for (size_t gi = 0; gi < n_gt; ++gi) {
-                                    long double res = 1.0L;
-                                    for (size_t j = 0; j < nk; ++j) {
-                                        const uint8_t h = st.h[j * n_gt + gi];
-                                        uint8_t c2 = st.c[j];
-                                        most_likely_depth(h, c2, st.f[j], ave, upper);
-                                        res *= tab[(size_t)h * 256 + c2];
-                                    }
-                                    obs[gi] = res;
+                                {
+                                    PhaseTimer tt(g_phase.states);
+                                    st = hidden_states(chr, row_node[rr], top, genotypes, used, glist, lower, upper, true, r, std::move(st), nullptr);
                                 }
-                                n_kept[rr] = (uint32_t)nk;
-                                if (nk && vgmi_hmm_part_set_row(ph.p, rr, obs.data()) != VGMI_OK)
-                                    throw std::runtime_error(std::string("device HMM emissions: ") + vgmi_last_error(dev_));
+                                PhaseTimer tt(g_phase.emit);
+                                const std::vector<long double> obs = score_states(st, sctx);
+                                n_kept[rr] = (uint32_t)(obs.empty() ? 0 : st.c.size());
+                                if (!obs.empty()) {
+                                    host_rows[wi].push_back(rr);
+                                    host_obs[wi].insert(host_obs[wi].end(), obs.begin(), obs.end());
+                                }
                             }
                             if (n_kept[rr] == 0) {
-                                seen.push_back(Seen{n_start, n_end, -1});
+                                seen[wi].push_back(Seen{n_start, n_end, -1});
                                 continue;
                             }
-                            seen.push_back(Seen{n_start, n_end, (int64_t)rr});
+                            seen[wi].push_back(Seen{n_start, n_end, (int64_t)rr});
                             (void)genotype_strings(n, genotypes, gid.data() + rr * n_gt, order.data() + rr * n_gt);     // <= 128 strings: always fits
-                            win_nodes[t - t0].push_back(row_node[rr]);
-                            win_rows[t - t0].push_back((uint32_t)rr);
-                            ++m;
+                            win_nodes[wi].push_back(row_node[rr]);
+                            win_rows[wi].push_back((uint32_t)rr);
                         }
-                        if (m == 0) continue;
-                        const size_t step0 = step_next;
-                        step_next += 2 * m;
+                    });
+                    {
+                        std::vector<uint64_t> all_rows;
+                        std::vector<long double> all_obs;
+                        for (size_t wi = 0; wi < nw; ++wi) {
+                            all_rows.insert(all_rows.end(), host_rows[wi].begin(), host_rows[wi].end());
+                            all_obs.insert(all_obs.end(), host_obs[wi].begin(), host_obs[wi].end());
+                            std::vector<long double>().swap(host_obs[wi]);
+                        }
+                        if (!all_rows.empty() && vgmi_hmm_part_set_rows(ph.p, all_rows.size(), all_rows.data(), all_obs.data()) != VGMI_OK)
+                            throw std::runtime_error(std::string("device HMM emissions: ") + vgmi_last_error(dev_));
+                    }
+                    std::vector<size_t> win_step0(nw + 1, 0);
+                    for (size_t wi = 0; wi < nw; ++wi) win_step0[wi + 1] = win_step0[wi] + 2 * win_rows[wi].size();
+                    const size_t n_steps = win_step0[nw];
+                    std::vector<long double> pw((n_steps ? n_steps : 1) * 2 * stride);
+                    std::vector<uint32_t> row(n_steps ? n_steps : 1, 0);
+                    std::vector<uint8_t> restart(n_steps ? n_steps : 1, 0);
+                    std::vector<uint64_t> fwd(n_rows ? n_rows : 1, 0), bwd(n_rows ? n_rows : 1, 0);
+                    std::vector<vgmi_hmm_chain> chains;
+                    for (size_t wi = 0; wi < nw; ++wi) {
+                        const size_t m = win_rows[wi].size();
+                        if (!m) continue;
+                        chains.push_back(vgmi_hmm_chain{win_step0[wi], m, 0, 0});
+                        chains.push_back(vgmi_hmm_chain{win_step0[wi] + m, m, 0, 0});
+                    }
+                    over_windows([&](size_t wi) {
+                        const size_t m = win_rows[wi].size();
+                        if (!m) return;
+                        const size_t step0 = win_step0[wi];
                         auto powers = [&](long double* dst, uint32_t distance) {
                             long double recomb, no_recomb;
                             std::tie(recomb, no_recomb) = transition_probabilities(distance, (uint16_t)n_hap_);
@@ -1800,56 +1868,54 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                                 dst[stride + k] = std::pow(recomb, (int32_t)k);
                             }
                         };
+                        const std::vector<Seen>& sn = seen[wi];
                         size_t j = 0;
-                        for (size_t q = 0; q < seen.size(); ++q) {
-                            if (seen[q].row < 0) continue;
+                        for (size_t q = 0; q < sn.size(); ++q) {
+                            if (sn[q].row < 0) continue;
                             const size_t fs = step0 + j, bs = step0 + m + (m - 1 - j);
-                            powers(pw.data() + fs * 2 * stride, seen[q].start - (q ? seen[q - 1].end : 0u));
-                            restart[fs] = (q == 0 || seen[q - 1].row < 0) ? 1 : 0;
-                            row[fs] = (uint32_t)seen[q].row;
-                            powers(pw.data() + bs * 2 * stride, (q + 1 < seen.size() ? seen[q + 1].start : 0u) - seen[q].end);
-                            restart[bs] = (q + 1 == seen.size() || seen[q + 1].row < 0) ? 1 : 0;
-                            row[bs] = (uint32_t)seen[q].row;
-                            fwd[seen[q].row] = fs;
-                            bwd[seen[q].row] = bs;
+                            powers(pw.data() + fs * 2 * stride, sn[q].start - (q ? sn[q - 1].end : 0u));
+                            restart[fs] = (q == 0 || sn[q - 1].row < 0) ? 1 : 0;
+                            row[fs] = (uint32_t)sn[q].row;
+                            powers(pw.data() + bs * 2 * stride, (q + 1 < sn.size() ? sn[q + 1].start : 0u) - sn[q].end);
+                            restart[bs] = (q + 1 == sn.size() || sn[q + 1].row < 0) ? 1 : 0;
+                            row[bs] = (uint32_t)sn[q].row;
+                            fwd[sn[q].row] = fs;
+                            bwd[sn[q].row] = bs;
                             ++j;
                         }
-                        chains.push_back(vgmi_hmm_chain{step0, m, 0, 0});
-                        chains.push_back(vgmi_hmm_chain{step0 + m, m, 0, 0});
-                    }
+                    });
                     std::vector<long double> prob(n_rows ? n_rows : 1);
                     std::vector<uint32_t> winner(n_rows ? n_rows : 1, 0xFFFFFFFFu);
-                    if (step_next) {
+                    if (n_steps) {
                         const long double uniform = 1.0L / (long double)n_gt;
-                        if (vgmi_hmm_part_calls(ph.p, cfg.sample_ploidy, keep_mat.data(), 1, row.data(), restart.data(), pw.data(), step_next, &uniform,
+                        if (vgmi_hmm_part_calls(ph.p, cfg.sample_ploidy, keep_mat.data(), 1, row.data(), restart.data(), pw.data(), n_steps, &uniform,
                                                 chains.data(), (uint32_t)chains.size(), gid.data(), order.data(), fwd.data(), bwd.data(), prob.data(),
                                                 winner.data()) != VGMI_OK)
                             throw std::runtime_error(std::string("device HMM recursion: ") + vgmi_last_error(dev_));
                     }
                     const int64_t tbb = since_begin();
                     if (g_phase_on)
-                        std::fprintf(stderr, "[varigraph-mi] HMM part %zu (windows %zu-%zu): emissions, recursion and posterior on the device from %.3f to %.3f s\n",
-                                     part, t0, t1 - 1, ta * 1e-9, tbb * 1e-9);
+                        std::fprintf(stderr, "[varigraph-mi] HMM part %zu (windows %zu-%zu): emissions, recursion and posterior on the device from %.3f to %.3f s (%zu of %zu nodes scored by the host)\n",
+                                     part, t0, t1 - 1, ta * 1e-9, tbb * 1e-9, [&] { size_t c2 = 0; for (auto& v : host_rows) c2 += v.size(); return c2; }(), n_rows);
                     for (int64_t v = dev_first.load(); ta < v && !dev_first.compare_exchange_weak(v, ta);) {}
                     for (int64_t v = dev_last.load(); tbb > v && !dev_last.compare_exchange_weak(v, tbb);) {}
-                    // the calls
-                    for (size_t t = t0; t < t1; ++t) {
+                    over_windows([&](size_t wi) {
                         WindowWork w;
-                        w.chr = tasks[t].chr;
+                        w.chr = tasks[t0 + wi].chr;
                         w.n_gt = n_gt;
                         w.genotypes = genotypes;
                         w.top = top;
-                        w.nodes = win_nodes[t - t0];
+                        w.nodes = win_nodes[wi];
                         std::vector<long double> pr(w.nodes.size());
-                        std::vector<uint32_t> wi(w.nodes.size());
+                        std::vector<uint32_t> wn(w.nodes.size());
                         for (size_t q = 0; q < w.nodes.size(); ++q) {
-                            pr[q] = prob[win_rows[t - t0][q]];
-                            wi[q] = winner[win_rows[t - t0][q]];
+                            pr[q] = prob[win_rows[wi][q]];
+                            wn[q] = winner[win_rows[wi][q]];
                         }
-                        window_finish(w, pr.data(), wi.data(), r);
-                        make_piece(t);
+                        window_finish(w, pr.data(), wn.data(), r);
+                        make_piece(t0 + wi);
                         emit_windows_done += !w.nodes.empty();
-                    }
+                    });
                 } catch (const std::exception& e) {
                     std::lock_guard<std::mutex> lock(err_mu);
                     if (err_text.empty()) err_text = e.what();

@@ -106,6 +106,8 @@ private:
     struct Run;  // per-call constants
 
     struct WindowWork;   // what a window hands to the device recursion and gets back (genotyper.cpp)
+    struct ScoreCtx;     // per-thread scratch and memoised libm values of score_states
+    std::vector<long double> score_states(const NodeStates& ns, ScoreCtx& sc) const;
     // forced_top: the window's selected haplotypes as an earlier pass over the same window drew them (the host takes a window
     // back from the device path: same haplotypes, same pruned k-mer lists, nothing is drawn again)
     void window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, WindowWork* work = nullptr,

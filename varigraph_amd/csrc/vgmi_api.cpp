@@ -1784,6 +1784,44 @@ int vgmi_bloom_add_seq(vgmi_ctx* c, const char* bases, uint64_t len, uint32_t k)
 }
 
 namespace {
+// Device working memory of the HMM calls is kept in the context between calls: hipFree waits for every stream of the device --
+// other parts', other samples' chains -- so nothing is freed while samples are genotyped.
+uint8_t* hmm_block_take(vgmi_ctx* c, size_t bytes, size_t& got)
+{
+    {
+        std::lock_guard<std::mutex> lock(c->hmm_mu);
+        size_t best = SIZE_MAX;
+        for (size_t i = 0; i < c->hmm_blocks.size(); ++i)
+            if (c->hmm_blocks[i].second >= bytes && (best == SIZE_MAX || c->hmm_blocks[i].second < c->hmm_blocks[best].second)) best = i;
+        if (best != SIZE_MAX) {
+            uint8_t* d = c->hmm_blocks[best].first;
+            got = c->hmm_blocks[best].second;
+            c->hmm_blocks.erase(c->hmm_blocks.begin() + (ptrdiff_t)best);
+            return d;
+        }
+    }
+    uint8_t* d = nullptr;
+    got = bytes;
+    if (hipMalloc(reinterpret_cast<void**>(&d), bytes) == hipSuccess) return d;
+    (void)hipGetLastError();
+    std::vector<std::pair<uint8_t*, size_t>> drop;     // the kept ones that are too small make room
+    {
+        std::lock_guard<std::mutex> lock(c->hmm_mu);
+        drop.swap(c->hmm_blocks);
+    }
+    for (auto& b : drop) (void)hipFree(b.first);
+    if (hipMalloc(reinterpret_cast<void**>(&d), bytes) == hipSuccess) return d;
+    (void)hipGetLastError();
+    return nullptr;
+}
+
+void hmm_block_give(vgmi_ctx* c, uint8_t* d, size_t bytes)
+{
+    if (!d) return;
+    std::lock_guard<std::mutex> lock(c->hmm_mu);
+    c->hmm_blocks.emplace_back(d, bytes);
+}
+
 // recursion (+ posterior when gid is given) in one pass over device buffers: alpha / beta leave the device only if `out` asks.
 // Every array is indexed by GLOBAL row / step; this call reads and writes rows [row_lo, row_hi) and steps [step_lo, step_hi) only
 // (device buffers of that size, the kernels' pointers moved back by the range's start).  It works on a stream of its own and
@@ -1947,6 +1985,7 @@ int hmm_run(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, ui
 struct vgmi_hmm_part {
     vgmi_ctx* c = nullptr;
     uint8_t* d_obs = nullptr;
+    size_t obs_bytes = 0;      // of the block d_obs came as
     uint64_t n_rows = 0;
     uint32_t n_gt = 0;
 };
@@ -2000,13 +2039,16 @@ int vgmi_hmm_emissions(vgmi_ctx* c, uint32_t n_gt, uint32_t n_used, const uint8_
     const size_t o_eb = 0, o_ec = up(o_eb + n_rows * 8), o_g0 = up(o_ec + n_rows * 4), o_tab = up(o_g0 + n_rows * 2), o_nk = up(o_tab + 768 * 16),
                  o_fl = up(o_nk + n_rows * 4), total = up(o_fl + n_rows) + 256;
     hipStream_t st = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&part->d_obs), b_obs);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_small), total);
-    if (e != hipSuccess) {
-        if (part->d_obs) (void)hipFree(part->d_obs);
+    size_t small_bytes = 0;
+    part->d_obs = hmm_block_take(c, b_obs, part->obs_bytes);
+    d_small = hmm_block_take(c, total, small_bytes);
+    if (!part->d_obs || !d_small) {
+        hmm_block_give(c, part->d_obs, part->obs_bytes);
+        hmm_block_give(c, d_small, small_bytes);
         delete part;
         return fail(c, VGMI_E_NOMEM, "HMM emissions: not enough device memory");
     }
+    hipError_t e = hipSuccess;
     e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMemcpyAsync(d_small + o_eb, entry_begin, n_rows * 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_small + o_ec, entry_count, n_rows * 4, hipMemcpyHostToDevice, st);
@@ -2040,9 +2082,9 @@ int vgmi_hmm_emissions(vgmi_ctx* c, uint32_t n_gt, uint32_t n_used, const uint8_
     if (e == hipSuccess && n_rows) e = hipMemcpyAsync(flags_out, d_small + o_fl, n_rows, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (st) (void)hipStreamDestroy(st);
-    (void)hipFree(d_small);
+    hmm_block_give(c, d_small, small_bytes);
     if (e != hipSuccess) {
-        (void)hipFree(part->d_obs);
+        hmm_block_give(c, part->d_obs, part->obs_bytes);
         delete part;
         HIPCHK(c, e);
     }
@@ -2050,12 +2092,27 @@ int vgmi_hmm_emissions(vgmi_ctx* c, uint32_t n_gt, uint32_t n_used, const uint8_
     return VGMI_OK;
 }
 
-int vgmi_hmm_part_set_row(vgmi_hmm_part* part, uint64_t row, const void* obs_row)
+int vgmi_hmm_part_set_rows(vgmi_hmm_part* part, uint64_t n, const uint64_t* rows, const void* obs_rows)
 {
-    if (!part || !obs_row || row >= part->n_rows) return VGMI_E_INVALID;
+    if (!part || (n && (!rows || !obs_rows))) return VGMI_E_INVALID;
     vgmi_ctx* c = part->c;
+    for (uint64_t i = 0; i < n; ++i)
+        if (rows[i] >= part->n_rows) return fail(c, VGMI_E_INVALID, "HMM emissions: a row outside the part");
+    if (n == 0) return VGMI_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy(part->d_obs + row * part->n_gt * 16, obs_row, (size_t)part->n_gt * 16, hipMemcpyHostToDevice));
+    const size_t b_obs = (size_t)n * part->n_gt * 16, o_rows = (b_obs + 255) & ~(size_t)255;
+    size_t d_bytes = 0;
+    uint8_t* d = hmm_block_take(c, o_rows + n * 8, d_bytes);
+    if (!d) return fail(c, VGMI_E_NOMEM, "HMM emissions: not enough device memory");
+    hipStream_t st = nullptr;      // a stream of its own: other parts' work on this device is not waited for
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemcpyAsync(d, obs_rows, b_obs, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_rows, rows, n * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = launch_hmm_scatter_rows(part->d_obs, reinterpret_cast<const uint64_t*>(d + o_rows), d, part->n_gt, n, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (st) (void)hipStreamDestroy(st);
+    hmm_block_give(c, d, d_bytes);
+    HIPCHK(c, e);
     return VGMI_OK;
 }
 
@@ -2071,8 +2128,7 @@ int vgmi_hmm_part_calls(vgmi_hmm_part* part, uint32_t ploidy, const uint8_t* kee
 void vgmi_hmm_part_free(vgmi_hmm_part* part)
 {
     if (!part) return;
-    (void)hipSetDevice(part->c->device);
-    if (part->d_obs) (void)hipFree(part->d_obs);
+    hmm_block_give(part->c, part->d_obs, part->obs_bytes);      // kept for the next part / sample (hipFree would wait for every stream)
     delete part;
 }
 

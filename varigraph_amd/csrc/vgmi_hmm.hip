@@ -512,6 +512,21 @@ __global__ __launch_bounds__(128) void hmm_emissions_kernel(HmmEmitParams P)
     }
 }
 
+// rows the host scored itself, handed in as one block: row[i] of the part <- src[i]
+__global__ __launch_bounds__(128) void hmm_scatter_rows_kernel(uint8_t* obs, const uint64_t* rows, const uint8_t* src, uint32_t n_gt)
+{
+    const uint32_t g = threadIdx.x;
+    if (g < n_gt)
+        *reinterpret_cast<uint4*>(obs + (rows[blockIdx.x] * n_gt + g) * 16) = *reinterpret_cast<const uint4*>(src + ((size_t)blockIdx.x * n_gt + g) * 16);
+}
+
+hipError_t launch_hmm_scatter_rows(uint8_t* obs, const uint64_t* rows, const uint8_t* src, uint32_t n_gt, uint64_t n, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(hmm_scatter_rows_kernel, dim3((uint32_t)n), dim3(128), 0, st, obs, rows, src, n_gt);
+    return hipGetLastError();
+}
+
 hipError_t launch_hmm_emissions(const HmmEmitParams& P, uint64_t n_rows, hipStream_t st)
 {
     if (n_rows == 0) return hipSuccess;

@@ -196,6 +196,7 @@ struct HmmEmitParams {
     uint8_t* flags;                     // out, per row: bit 0 the host must score this node (a haplotype's sequence has to be checked), bit 1 a k-mer no selected haplotype carries
 };
 hipError_t launch_hmm_emissions(const HmmEmitParams& P, uint64_t n_rows, hipStream_t st);
+hipError_t launch_hmm_scatter_rows(uint8_t* obs, const uint64_t* rows, const uint8_t* src, uint32_t n_gt, uint64_t n, hipStream_t st);
 size_t hmm_lds_bytes(uint32_t n_gt, uint32_t ploidy);
 
 hipError_t launch_xtable_build(const XTableView& t, const unsigned long long* slots8, const uint32_t* key_slot, const uint32_t* id_of_key,

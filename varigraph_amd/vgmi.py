@@ -75,7 +75,7 @@ def load_library():
         "vgmi_hmm_sample_upload": (i32, [vp, vp, sz]),
         "vgmi_hmm_emissions": (i32, [vp, u32, u32, vp, vp, vp, C.c_uint64, u32, C.c_float, C.c_double, C.c_double, vp, C.c_uint64, vp, vp, vp, vp, vp,
                                       C.POINTER(vp)]),
-        "vgmi_hmm_part_set_row": (i32, [vp, C.c_uint64, vp]),
+        "vgmi_hmm_part_set_rows": (i32, [vp, C.c_uint64, vp, vp]),
         "vgmi_hmm_part_calls": (i32, [vp, u32, vp, u32, vp, vp, vp, C.c_uint64, vp, vp, u32, vp, vp, vp, vp, vp, vp]),
         "vgmi_hmm_part_free": (None, [vp]),
         "vgmi_bloom_fetch": (i32, [vp, vp]),
