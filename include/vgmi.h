@@ -259,6 +259,8 @@ int vgmi_hmm_part_calls(vgmi_hmm_part *part, uint32_t ploidy, const uint8_t *kee
                         const uint8_t *restart, const void *pow, uint64_t n_steps, const void *uniform, const vgmi_hmm_chain *chains,
                         uint32_t n_chains, const uint8_t *gid, const uint8_t *order, const uint64_t *fwd_step, const uint64_t *bwd_step,
                         void *prob, uint32_t *winner);
+/* the part's emission rows back on the host (n_rows x n_gt long doubles): tests and diagnostics */
+int vgmi_hmm_part_fetch(vgmi_hmm_part *part, void *obs_out);
 void vgmi_hmm_part_free(vgmi_hmm_part *part);
 
 /* ---- bench / test tooling (not part of the reference seam) -------------------------------

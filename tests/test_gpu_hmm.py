@@ -333,3 +333,79 @@ def test_recursion_and_posterior_beyond_128_genotypes_equal_x87(ploidy, n_hap, n
         assert winner[r] == win and prob[r] == best, r
         n_called += win != 0xFFFFFFFF
     assert n_called >= n_rows // 2
+
+
+def test_emission_scores_on_the_device_equal_the_host_arithmetic():
+    """vgmi_hmm_emissions (hmm_emissions_kernel): hidden states and observable states of a node (src/genotype.cpp:640-830, 960-1000,
+    most_likely_depth :1118-1145) against the same computation spelled out here -- float32 / float64 steps as the host's SSE
+    code takes them, the product in numpy.longdouble (x87) in k-mer order -- on random node lists: coverage 0..255, multiplicity
+    1..4, reference-allele flags, k-mers inside and outside the Poisson interval, terms down to 1e-300 so that products run through
+    the denormal range; plus the per-row counts and the two flags."""
+    assert np.finfo(LD).nmant == 63
+    rng = np.random.default_rng(2027)
+    n_hap, bit_len = 15, 2
+    used = np.arange(n_hap, dtype=np.uint8)
+    pairs = list(itertools.combinations_with_replacement(range(n_hap), 2))
+    pos_a = np.array([a for a, _ in pairs], dtype=np.uint8)
+    pos_b = np.array([b for _, b in pairs], dtype=np.uint8)
+    n_gt = len(pairs)
+    top_mask = (1 << n_hap) - 1
+    ave = np.float32(23.5)
+    lower, upper = float(ave) - 1.96 * float(np.sqrt(np.float64(ave))), float(ave) + 1.96 * float(np.sqrt(np.float64(ave)))
+    expo = rng.integers(-300, 1, size=768)
+    tables = (rng.random(768).astype(LD) + LD(0.05)) * np.power(LD(10), expo.astype(LD))
+    n_rows = 300
+    counts = rng.integers(0, 70, size=n_rows)
+    counts[5] = 0
+    entry_begin = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
+    n_entries = int(counts.sum())
+    f = rng.choice([1, 1, 1, 2, 3, 4], size=n_entries).astype(np.uint64)
+    bits = rng.integers(1, 1 << n_hap, size=n_entries).astype(np.uint64)         # some haplotype carries every k-mer
+    lb = rng.integers(0, 2, size=n_entries).astype(np.uint64)
+    bits |= lb << np.uint64(8 * bit_len - 1)
+    cov = rng.choice([0, 1, 5, 14, 15, 20, 23, 24, 30, 33, 34, 60, 255], size=n_entries).astype(np.uint8)
+    entries = (f << np.uint64(8)) | (bits << np.uint64(16))
+    gt0 = rng.integers(0, 1 << n_hap, size=n_rows).astype(np.uint16)
+    ctx = vgmi.Context(0, buffer_mib=16)
+    try:
+        obs, n_kept, flags = ctx.hmm_emissions(entries, cov, used, pos_a, pos_b, top_mask, bit_len, ave, lower, upper, tables, entry_begin, counts, gt0)
+        # an entry no selected haplotype carries must be reported (the caller's guarantee is checked, not assumed)
+        e2 = entries.copy()
+        e2[int(entry_begin[7])] &= np.uint64(0xFFFF) | (np.uint64(1) << np.uint64(16 + 8 * bit_len - 1))
+        _, _, flags2 = ctx.hmm_emissions(e2, cov, used, pos_a, pos_b, top_mask, bit_len, ave, lower, upper, tables, entry_begin, counts, gt0)
+    finally:
+        ctx.close()
+    assert flags2[7] & 2 and not (flags & 2).any()
+
+    def mld(h, c, ff):
+        if ff == 1:
+            return c
+        cf = np.float32(c)
+        if h > 0 and cf > ave * np.float32(h):
+            return int(ave * np.float32(h)) & 0xFF
+        if h == 0 and cf > ave:
+            return 0 if float(ff) > float(cf) / upper else int(cf / np.float32(ff)) & 0xFF
+        if h == 0:
+            return int(cf / np.float32(ff)) & 0xFF
+        return c
+    n_flagged = 0
+    for r in range(n_rows):
+        prod = np.ones(n_gt, dtype=LD)
+        flag = 0
+        for j in range(int(entry_begin[r]), int(entry_begin[r]) + int(counts[r])):
+            c, ff, b = int(cov[j]), int(f[j]), int(bits[j])
+            l = (b >> (8 * bit_len - 1)) & 1
+            in_interval = l == 1 and lower <= c <= upper
+            one = [1 if (in_interval and (int(gt0[r]) >> p) & 1) else (b >> p) & 1 for p in range(n_hap)]
+            if c < lower and ff >= 2 and any(one):
+                flag |= 1
+            fj = 2 if (l == 1 and ff == 1) else ff
+            term = {}
+            for h in (0, 1, 2):
+                term[h] = tables[h * 256 + mld(h, c, fj)]
+            hs = np.array([one[a] + one[b2] for a, b2 in pairs])
+            prod = prod * np.where(hs == 0, term[0], np.where(hs == 1, term[1], term[2]))
+        assert n_kept[r] == counts[r] and flags[r] == flag, r
+        assert np.array_equal(obs[r], prod), (r, int(np.argmax(obs[r] != prod)))
+        n_flagged += flag
+    assert 20 < n_flagged < n_rows and (obs == 0).any() and (obs > 0).any()

@@ -2125,6 +2125,15 @@ int vgmi_hmm_part_calls(vgmi_hmm_part* part, uint32_t ploidy, const uint8_t* kee
                    nullptr, gid, order, fwd_step, bwd_step, prob, winner, part->d_obs);
 }
 
+int vgmi_hmm_part_fetch(vgmi_hmm_part* part, void* obs_out)
+{
+    if (!part || !obs_out) return VGMI_E_INVALID;
+    vgmi_ctx* c = part->c;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (part->n_rows) HIPCHK(c, hipMemcpy(obs_out, part->d_obs, (size_t)part->n_rows * part->n_gt * 16, hipMemcpyDeviceToHost));
+    return VGMI_OK;
+}
+
 void vgmi_hmm_part_free(vgmi_hmm_part* part)
 {
     if (!part) return;

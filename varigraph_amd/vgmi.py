@@ -77,6 +77,7 @@ def load_library():
                                       C.POINTER(vp)]),
         "vgmi_hmm_part_set_rows": (i32, [vp, C.c_uint64, vp, vp]),
         "vgmi_hmm_part_calls": (i32, [vp, u32, vp, u32, vp, vp, vp, C.c_uint64, vp, vp, u32, vp, vp, vp, vp, vp, vp]),
+        "vgmi_hmm_part_fetch": (i32, [vp, vp]),
         "vgmi_hmm_part_free": (None, [vp]),
         "vgmi_bloom_fetch": (i32, [vp, vp]),
         "vgmi_bloom_save_file": (i32, [vp, C.c_char_p]),
@@ -406,6 +407,34 @@ class Context:
                                           _ptr(pow_tables), row.size, _ptr(uni), _ptr(ch), len(chains), _ptr(gid), _ptr(order), _ptr(fwd_step),
                                           _ptr(bwd_step), _ptr(prob), _ptr(winner), _ptr(ab)))
         return prob, winner, ab
+
+    def hmm_emissions(self, entries, cov_node, used, pos_a, pos_b, top_mask, bit_len, ave, lower, upper, tables, entry_begin, entry_count, gt0):
+        """vgmi_hmm_entries_upload + _sample_upload + _emissions + _part_fetch: returns (obs (rows, n_gt) longdouble, n_kept, flags)."""
+        entries = np.ascontiguousarray(entries, dtype=np.uint64)
+        cov_node = np.ascontiguousarray(cov_node, dtype=np.uint8)
+        used = np.ascontiguousarray(used, dtype=np.uint8)
+        pos_a = np.ascontiguousarray(pos_a, dtype=np.uint8)
+        pos_b = np.ascontiguousarray(pos_b, dtype=np.uint8)
+        tables = np.ascontiguousarray(tables, dtype=np.longdouble)
+        entry_begin = np.ascontiguousarray(entry_begin, dtype=np.uint64)
+        entry_count = np.ascontiguousarray(entry_count, dtype=np.uint32)
+        gt0 = np.ascontiguousarray(gt0, dtype=np.uint16)
+        assert tables.size == 768
+        n_rows, n_gt = entry_begin.size, pos_a.size
+        self._chk(self._l.vgmi_hmm_entries_upload(self._h, _ptr(entries), entries.size))
+        self._chk(self._l.vgmi_hmm_sample_upload(self._h, _ptr(cov_node), cov_node.size))
+        n_kept = np.zeros(max(n_rows, 1), dtype=np.uint32)
+        flags = np.zeros(max(n_rows, 1), dtype=np.uint8)
+        part = C.c_void_p()
+        self._chk(self._l.vgmi_hmm_emissions(self._h, n_gt, used.size, _ptr(used), _ptr(pos_a), _ptr(pos_b), int(top_mask), bit_len, float(ave), float(lower),
+                                              float(upper), _ptr(tables), n_rows, _ptr(entry_begin), _ptr(entry_count), _ptr(gt0), _ptr(n_kept), _ptr(flags),
+                                              C.byref(part)))
+        try:
+            obs = np.zeros((n_rows, n_gt), dtype=np.longdouble)
+            self._chk(self._l.vgmi_hmm_part_fetch(part, _ptr(obs)))
+        finally:
+            self._l.vgmi_hmm_part_free(part)
+        return obs, n_kept[:n_rows], flags[:n_rows]
 
     def hmm_calls_part(self, keep, obs, row, restart, pow_tables, uniform, chains, ploidy, gid, order, fwd_step, bwd_step, rows, steps,
                        prob, winner):
