@@ -1804,6 +1804,9 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                         sctx.ave = ave;
                         sctx.score_up = upper;
                         NodeStates st;
+                        // the genotype strings of a node with two alleles depend on which haplotypes carry the reference allele only:
+                        // one evaluation per distinct mask (the strings themselves as genotype_strings builds them)
+                        std::unordered_map<uint32_t, uint32_t> gs_memo;      // mask -> a row that holds the pattern
                         for (size_t rr = win_row0[wi]; rr < win_row0[wi + 1]; ++rr) {
                             Node& n = chr.nodes[row_node[rr]];
                             const uint32_t n_start = n.start, n_end = (uint32_t)(n_start + n.gn->seqs[0].size() - 1);
@@ -1826,7 +1829,18 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                                 continue;
                             }
                             seen[wi].push_back(Seen{n_start, n_end, (int64_t)rr});
-                            (void)genotype_strings(n, genotypes, gid.data() + rr * n_gt, order.data() + rr * n_gt);     // <= 128 strings: always fits
+                            {
+                                bool biallelic = true;
+                                for (uint16_t hap : used) biallelic = biallelic && n.gn->hap_gt[hap] <= 1;
+                                auto it = biallelic ? gs_memo.find(gt0[rr]) : gs_memo.end();
+                                if (it != gs_memo.end()) {
+                                    std::memcpy(gid.data() + rr * n_gt, gid.data() + (size_t)it->second * n_gt, n_gt);
+                                    std::memcpy(order.data() + rr * n_gt, order.data() + (size_t)it->second * n_gt, n_gt);
+                                } else {
+                                    (void)genotype_strings(n, genotypes, gid.data() + rr * n_gt, order.data() + rr * n_gt);     // <= 128 strings: always fits
+                                    if (biallelic) gs_memo.emplace(gt0[rr], (uint32_t)rr);
+                                }
+                            }
                             win_nodes[wi].push_back(row_node[rr]);
                             win_rows[wi].push_back((uint32_t)rr);
                         }
@@ -1860,12 +1874,25 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                         const size_t m = win_rows[wi].size();
                         if (!m) return;
                         const size_t step0 = win_step0[wi];
+                        // the tables of powers are a function of the distance alone: neighbouring nodes are tens to hundreds of bases
+                        // apart, so a window's few thousand steps share a few hundred distinct tables (same libm calls, each made once)
+                        constexpr uint32_t kMemo = 4096;
+                        std::vector<long double> memo((size_t)kMemo * 2 * stride);
+                        std::vector<uint8_t> memo_have(kMemo, 0);
                         auto powers = [&](long double* dst, uint32_t distance) {
+                            if (distance < kMemo && memo_have[distance]) {
+                                std::memcpy(dst, &memo[(size_t)distance * 2 * stride], 2 * stride * sizeof(long double));
+                                return;
+                            }
                             long double recomb, no_recomb;
                             std::tie(recomb, no_recomb) = transition_probabilities(distance, (uint16_t)n_hap_);
                             for (uint32_t k = 0; k < stride; ++k) {
                                 dst[k] = std::pow(no_recomb, (int32_t)k);
                                 dst[stride + k] = std::pow(recomb, (int32_t)k);
+                            }
+                            if (distance < kMemo) {
+                                std::memcpy(&memo[(size_t)distance * 2 * stride], dst, 2 * stride * sizeof(long double));
+                                memo_have[distance] = 1;
                             }
                         };
                         const std::vector<Seen>& sn = seen[wi];
