@@ -652,6 +652,12 @@ RowParams row_params(vgmi_ctx* c, const char* d_bases, size_t n_bytes, uint32_t 
     p.table = c->tv;
     p.keys_out = nullptr;
     p.dbg = vgmi_dbg_env();
+    static const uint32_t l1_min = [] {
+        const char* e = getenv("VGMI_L1_MIN");
+        const int v = e ? atoi(e) : 60;      // measured (C2, kernel ms per 1e8 reads): 8 4.93, 16 4.67, 24 4.44, 32 4.35, 40 4.29, 48 4.23, 56 4.23
+        return (uint32_t)(v < 1 ? 1 : v > 64 ? 64 : v);
+    }();
+    p.l1_min = l1_min;
     p.bloom = c->bv;
     return p;
 }

@@ -89,6 +89,7 @@ struct RowParams {
                           // device-side FASTQ parser knows it, the host does not) and n_bytes / row_end / row_begin /
                           // emit_from are derived from it in the kernel; tail27 tells rows_kernel it runs behind count27_kernel
     uint32_t tail27;      // 1 behind count27_kernel, 2 behind count27x_kernel, 3 behind count27s_kernel
+    uint32_t l1_min;      // count27s_kernel<true>: queued runs that start a round of the path-table look-up (VGMI_L1_MIN; default 60, at most 64: one lane per run)
     TableView table;      // MODE_COUNT
     uint64_t* keys_out;   // MODE_KEYS
     BloomView bloom;      // MODE_BLOOM

@@ -1213,14 +1213,16 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
     //      (two find-first-bit instructions give all 16 answers); AND the start bits AND the run's own validity bits = the hits.
     //      Hits whose saturation bit is set are done (the steady state of a deep sample); the others fetch their slot and bump
     //      its counter, bit by bit.
-    constexpr uint32_t RQ = 64;
+    constexpr uint32_t RQ = 112;      // run ring: all of the wavefront's 1 792 bytes (a round takes up to 64 runs, rows keep adding)
     const uint32_t rq_base = rings0 + wave_u * (VG_RUNQ * 16u + VG_REQ * 8u);
+    auto rq_wrap = [](uint32_t pos) -> uint32_t { return pos >= RQ ? pos - RQ : pos; };      // pos < 2 * RQ
     const unsigned long long* const pt_index = p.table.pt.index;
     const uint32_t* const ptS = p.table.pt.S;
     const uint32_t* const ptVB = p.table.pt.VB;
     uint32_t* const ptSB = p.table.pt.SB;
     const uint32_t* const ptSLOT = p.table.pt.SLOT;
     const uint32_t pt_Tp = p.table.pt.Tp, pt_bshift = 32u - p.table.pt.bucket_log2;
+    const uint32_t l1_min = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.l1_min);
     uint32_t n_after_idx = 8, n_after_seq = 8;            // hot operations issued after the index load / after the last load of phase 2
     u32x4 l1_run = {0u, 0u, 0u, 0u};                      // the run this lane works on
     uint32_t l1_n = 0, l1_phase = 0;                      // wave-uniform: runs in the round, 0 idle / 1 bucket in flight / 2 sequence in flight
@@ -1255,10 +1257,10 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
     auto resolve_issue = [&]() __attribute__((always_inline)) {
         l1_n = run_n < 64u ? run_n : 64u;
         if (lane < l1_n && !(VG_DBG(p.dbg) & 2048u)) {      // 2048: ablation (wrong counts): the runs are popped and forgotten
-            l1_run = *reinterpret_cast<lds_u4_rw*>((uintptr_t)(rq_base + ((run_head + lane) & (RQ - 1u)) * 16u));
+            l1_run = *reinterpret_cast<lds_u4_rw*>((uintptr_t)(rq_base + rq_wrap(run_head + lane) * 16u));
             vmp_load_index(pt_index + ((uint64_t)(vg_idx_hash(l1_run.w & 0xFFFFFFu) >> pt_bshift) << 2));
         }
-        run_head = (run_head + l1_n) & (RQ - 1u);
+        run_head = rq_wrap(run_head + l1_n);
         run_n -= l1_n;
         hot(2);
         n_after_idx = 0;
@@ -1530,7 +1532,7 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
             const uint32_t d2 = r.W2 >> 2;
             const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, tail));
             if (PT)   // run bits [0, 84) | validity bits 0..11 in z[20:32), 12..15 in w[28:32) | canonical 12-mer and its orientation in w[0:25)
-                *reinterpret_cast<lds_u4_rw*>((uintptr_t)(rq_base + (pos & (RQ - 1u)) * 16u)) =
+                *reinterpret_cast<lds_u4_rw*>((uintptr_t)(rq_base + rq_wrap(pos) * 16u)) =
                     u32x4{d0, d1, (d2 & 0xFFFFFu) | (r.vm << 20), r.cm | ((r.vm >> 12) << 28)};
             else
                 *reinterpret_cast<lds_u4_rw*>((uintptr_t)(runs_base + ring_slot(pos) * 16u)) = u32x4{d0, d1, d2, r.vm};
@@ -1616,7 +1618,7 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
             run_n += nB;
             // one phase per iteration: every phase's loads have a whole iteration to arrive
             l1_advance();
-            if (l1_phase == 0 && run_n >= 24u) resolve_issue();
+            if (l1_phase == 0 && run_n >= l1_min) resolve_issue();
             continue;
         }
         enqueue(sa, ballA, run_head + run_n);
