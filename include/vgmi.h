@@ -74,6 +74,12 @@ int vgmi_table_import(vgmi_ctx *ctx, const void *dev_src, size_t bytes);
  * is built once per run, not once per device. */
 int vgmi_table_clone(vgmi_ctx *dst, vgmi_ctx *src);
 int vgmi_table_info(vgmi_ctx *ctx, size_t *n_keys, uint32_t *k, size_t *n_slots, size_t *filter_bits);
+/* Batched exact lookup, the table's `find`: index_out[i] = the index keys[i] has in the uploaded key array, 0xFFFFFFFF when
+ * the table does not hold it.  Replaces the per-node loop of Varigraph graph2node (src/construct_index.cpp:710-751:
+ * mGraphKmerHashHapStrMap.find(kmerHash) for every k-mer of every variant node) with one call over the concatenated node
+ * lists.  Host pointers.  Reads the table only and works on a stream of its own: may be called while another thread
+ * streams reads into the same context. */
+int vgmi_table_lookup(vgmi_ctx *ctx, const uint64_t *host_keys, size_t n, uint32_t *index_out);
 /* The k = 27 table of large graphs is keyed by the read's grid 16-mer: its number of 128-byte lines (0: not in
  * use) and how many (k-mer, 16-mer) pairs found no room near their home line and are served by the exact overflow table
  * (16-mers of repeats). Diagnostic only; no reference counterpart. */

@@ -836,6 +836,110 @@ def test_small_graph_variants_match_oracle(kind, variant, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("variant", [("small", {}), ("large", {}), ("large", {"VGMI_WIDE_SLOTS": "1", "VGMI_XTABLE": "0"}), ("k25", {})],
+                         ids=["small-graph", "large-graph", "large-graph-16-byte-slots", "k25"])
+def test_table_lookup_returns_the_index_of_every_key(variant, monkeypatch):
+    """vgmi_table_lookup == graph2node's find (src/construct_index.cpp:710-751): keys of the set map to their index in the uploaded
+    array, whatever order they are asked in; k-mers the graph does not hold, keys of another k and malformed keys map to 0xFFFFFFFF.
+    The counters are not touched (a sample counted before the lookups reads out the same after them)."""
+    from varigraph_amd import synth
+    size, env = variant
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    rng = np.random.default_rng(21)
+    k = 25 if size == "k25" else 27
+    if size == "small":
+        keys, haps = _small_graph("plain", rng)
+    else:
+        G, V = 2_000_000, 30_000
+        ref = synth.make_reference(G, seed=99)
+        pos = np.sort(rng.choice(np.arange(100, G - 100), size=V, replace=False))
+        alts = synth._ACGT[(synth._CODE[ref[pos]] + rng.integers(1, 4, size=V)) % 4]
+        keys = np.unique(synth.snp_kmer_keys(ref, pos, alts, k=k))
+        hap1 = ref.copy()
+        hap1[pos] = alts
+        haps = [ref, hap1]
+        assert keys.size > 65_536
+    keys = keys[rng.permutation(keys.size)]             # the uploaded order is the index
+    absent = np.unique(o.sketch(synth._ACGT[rng.integers(0, 4, size=20_000)].tobytes(), k))
+    absent = absent[~np.isin(absent, keys)]
+    assert absent.size > 10_000
+    other_k = (keys[:100] & ~np.uint64(0xFF)) | np.uint64(k - 2)
+    too_wide = keys[:100] | (np.uint64(1) << np.uint64(8 + 2 * k))
+    asked = np.concatenate([keys, absent, other_k, too_wide, keys[:1000]])
+    want = np.concatenate([np.arange(keys.size, dtype=np.uint32), np.full(absent.size + 200, 0xFFFFFFFF, dtype=np.uint32),
+                           np.arange(1000, dtype=np.uint32)])
+    order = rng.permutation(asked.size)
+    c = vgmi.Context(0, buffer_mib=16)
+    try:
+        c.table_upload(keys, k)
+        block = vgmi.synth_reads_host(3, 0, 20_000, 150, haps)
+        c.counts_reset()
+        c.reads_submit(block, 20_000)
+        got = c.table_lookup(asked[order])
+        assert np.array_equal(got, want[order]), int((got != want[order]).sum())
+        assert c.table_lookup(np.empty(0, dtype=np.uint64)).size == 0
+        cov, _, _ = c.counts_finish()
+        t = o.Table(keys)
+        t.count_block(block, k)
+        assert np.array_equal(cov, t.counts())
+    finally:
+        c.close()
+
+
+def _low_complexity_sequence(rng):
+    """What a unitig layout can trip over: homopolymers (a k-mer that follows itself), short tandem repeats (k-mers on cycles:
+    no chain end to start a walk from), an inverted repeat (12-mers that are their own reverse complement across the centre,
+    k-mers next to their own reverse complement), 12-mers with more than four places, and one element in both orientations."""
+    from varigraph_amd import synth
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+
+    def rc(a):
+        return np.array([comp[int(x)] for x in a[::-1]], dtype=np.uint8)
+
+    def lit(s, times=1):
+        return np.frombuffer((s * times).encode(), dtype=np.uint8).copy()
+
+    r = lambda n, seed: synth._ACGT[rng.integers(0, 4, size=n)]     # (make_reference's seeds are offsets into one stream)
+    x = r(70, 11)
+    unit30, unit13, elem = r(30, 12), r(13, 13), r(200, 14)
+    twelve = r(12, 15)
+    spread = np.concatenate([np.concatenate([r(45, 100 + i), twelve]) for i in range(7)])     # one 12-mer at seven places
+    parts = [r(1500, 16), lit("A", 100), r(80, 17), lit("AC", 60), r(80, 18), lit("ACG", 40), r(80, 19), lit("T", 64),
+             r(80, 20), x, rc(x), r(80, 21), np.tile(unit30, 8), r(80, 22), np.tile(unit13, 10), r(80, 23), spread,
+             r(80, 24), elem, r(300, 25), rc(elem), r(1500, 26)]
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("variant", [{}, {"VGMI_PTABLE": "0"}], ids=["path-table", "hash-drain"])
+def test_small_graph_low_complexity_keys_match_oracle(variant, monkeypatch):
+    for k_, v_ in variant.items():
+        monkeypatch.setenv(k_, v_)
+    rng = np.random.default_rng(9)
+    seq = _low_complexity_sequence(rng)
+    keys = np.unique(o.sketch(seq, 27))
+    assert 3000 < keys.size <= 65536, keys.size
+    from varigraph_amd import synth
+    other = seq.copy()                          # reads of a diverged copy leave and re-enter the chains everywhere
+    mut = rng.random(other.size) < 0.02
+    other[mut] = synth._ACGT[(synth._CODE[other[mut]] + rng.integers(1, 4, size=int(mut.sum()))) % 4]
+    n_reads = 40_000
+    block = vgmi.synth_reads_host(31, 0, n_reads, 150, [seq, other])
+    c = vgmi.Context(0, buffer_mib=16)
+    try:
+        c.table_upload(keys, 27)
+        c.counts_reset()
+        c.reads_submit(block, n_reads)
+        cov, _, _ = c.counts_finish()
+        t = o.Table(keys)
+        t.count_block(block, 27)
+        want = t.counts()
+        assert np.array_equal(cov, want), (variant, int((cov != want).sum()))
+        assert (cov == 255).any() and (cov < 255).any() and int(cov.astype(np.int64).sum()) > 500_000
+    finally:
+        c.close()
+
+
 def test_small_graph_saturation_through_the_path_table():
     """Deep coverage of a tiny graph: every counter passes 254 -> 255 under contention from all wavefronts, the saturation
     bits of both places and the hash table's flag are set by exactly that increment, later hits skip their atomic, and a reset

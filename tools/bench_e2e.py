@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--vcf-samples", type=int, default=7)
     ap.add_argument("--indel", type=float, default=0.0)
     ap.add_argument("--sv", type=float, default=0.0)
+    ap.add_argument("--matrix", default="", help="after the ordinary runs: the native genotype again per configuration on the same files, "
+                    "';'-separated lists of 't=<threads>' / 'samples=<n>' / NAME=value (environment); times and the VCF's md5 per run")
+    ap.add_argument("--repeat", type=int, default=1, help="runs per --matrix configuration (all reported)")
     args = ap.parse_args()
     from varigraph_amd import synth, vgmi
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "varigraph_det")
@@ -85,11 +88,46 @@ def main():
             if r.returncode != 0:
                 out[name + "_error"] = r.stderr[-400:]
                 continue
-            out[name + "_log_tail"] = [ln for ln in r.stderr.strip().split("\n") if "varigraph-mi]" in ln or "graph_index]" in ln or "[vgmi]" in ln][-16:]
+            out[name + "_log_tail"] = [ln for ln in r.stderr.strip().split("\n") if "varigraph-mi]" in ln or "graph_index]" in ln or "[vgmi]" in ln][-160:]
             vcfs[name] = gzip.open(os.path.join(d, "sample0.varigraph.vcf.gz"), "rb").read()
         if not args.native_only:
             out["vcf_identical"] = len(vcfs) == 2 and vcfs["reference_cpu"] == vcfs["native_cli"]
         out["vcf_records"] = vcfs.get("native_cli", b"").count(b"\n")
+        if args.matrix:
+            import hashlib
+            out["matrix"] = []
+            for cfg in [c for c in args.matrix.split(";") if c.strip()]:
+                env2, threads, n_samples = dict(env), args.threads, args.samples
+                for item in cfg.split(","):
+                    name, _, val = item.strip().partition("=")
+                    if name == "t":
+                        threads = int(val)
+                    elif name == "samples":
+                        n_samples = int(val)
+                    elif name:
+                        env2[name] = val
+                d = os.path.join(work, "matrix")
+                shutil.rmtree(d, ignore_errors=True)
+                os.makedirs(d)
+                open(os.path.join(d, "samples.cfg"), "w").write("".join(f"sample{i} " + " ".join(fq) + "\n" for i in range(n_samples)))
+                for _ in range(args.repeat):
+                    t0 = time.perf_counter()
+                    r = subprocess.run([cli, "genotype", "--load-graph", graph, "-s", "samples.cfg", "-t", str(threads), "--gpus", args.gpus] +
+                                       (["--sample-ploidy", str(args.ploidy), "--use-depth"] if args.ploidy != 2 else []),
+                                       cwd=d, capture_output=True, text=True, env=env2)
+                    dt = time.perf_counter() - t0
+                    row = {"config": cfg, "threads": threads, "samples": n_samples, "genotype_s": dt, "rc": r.returncode}
+                    if r.returncode == 0:
+                        lines = [ln for ln in r.stderr.strip().split("\n") if "varigraph-mi]" in ln or "graph_index]" in ln]
+                        row["done_in"] = next((ln.split("done in")[1].strip() for ln in reversed(lines) if "done in" in ln), None)
+                        row["loaded"] = next((ln[ln.rfind("(") + 1:ln.rfind(")")] for ln in lines if "graph loaded" in ln), None)
+                        row["vcf_md5"] = sorted({hashlib.md5(gzip.open(os.path.join(d, f"sample{i}.varigraph.vcf.gz"), "rb").read().replace(
+                            f"sample{i}".encode(), b"S")).hexdigest() for i in range(n_samples)})
+                        row["same_as_first_run"] = hashlib.md5(vcfs.get("native_cli", b"").replace(b"sample0", b"S")).hexdigest() in row["vcf_md5"] and len(row["vcf_md5"]) == 1
+                        row["log"] = [ln for ln in lines if "thread-seconds" not in ln][-90:]
+                    else:
+                        row["error"] = r.stderr[-300:]
+                    out["matrix"].append(row)
     finally:
         if not args.keep:
             shutil.rmtree(work, ignore_errors=True)

@@ -8,7 +8,7 @@ from varigraph_amd import vgmi
 LD = np.longdouble
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-    n_windows, n, ploidy = 60, 120, 2
+    n_windows, n, ploidy = (int(sys.argv[2]) if len(sys.argv) > 2 else 60), 120, 2
     rng = np.random.default_rng(1)
     keep = rng.integers(0, 3, size=(n_windows, n, n), dtype=np.uint8)
     n_rows = n_windows * steps

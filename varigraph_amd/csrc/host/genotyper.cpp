@@ -19,6 +19,7 @@
 #include <iomanip>
 #include <iterator>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <queue>
 #include <random>
@@ -34,6 +35,35 @@
 #include "node_flanks.hpp"
 
 namespace vgh {
+
+namespace {
+std::mutex g_cpu_mu;
+std::condition_variable g_cpu_cv;
+unsigned g_cpu_limit = 0, g_cpu_used = 0;
+}  // namespace
+
+void CpuBudget::set(unsigned tokens)
+{
+    std::lock_guard<std::mutex> lk(g_cpu_mu);
+    g_cpu_limit = tokens;
+    g_cpu_cv.notify_all();
+}
+
+CpuBudget::Hold::Hold()
+{
+    std::unique_lock<std::mutex> lk(g_cpu_mu);
+    g_cpu_cv.wait(lk, [] { return g_cpu_limit == 0 || g_cpu_used < g_cpu_limit; });
+    ++g_cpu_used;
+}
+
+CpuBudget::Hold::~Hold()
+{
+    {
+        std::lock_guard<std::mutex> lk(g_cpu_mu);
+        --g_cpu_used;
+    }
+    g_cpu_cv.notify_one();
+}
 
 namespace {
 
@@ -293,23 +323,32 @@ Genotyper::Genotyper(const GraphIndex& g, unsigned threads) : g_(g)
     // the nodes' places; the half million small k-mer lists are then copied by `threads` workers.
     struct Place { uint32_t start; const GraphNode* gn; size_t v; };
     size_t v = 0;
-    for (const auto& [chr, nodes] : g.graph) {
+    const auto t_ctor = std::chrono::steady_clock::now();
+    double s_walk = 0, s_alloc = 0, s_fill = 0;
+    auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
+    for (const auto& [chr, nodes] : g.graph_seq) {
+        auto t_a = std::chrono::steady_clock::now();
         Chrom c;
         c.name = chr;
         auto it = g.chr_len.find(chr);
         c.len = it == g.chr_len.end() ? 0 : it->second;
         std::vector<Place> places;
         places.reserve(nodes.size());
-        for (const auto& [start, gn] : nodes) {
+        for (const GraphNode* gn : nodes) {
             size_t mine = SIZE_MAX;
-            if (gn.hap_gt.size() != 1) {
+            if (gn->hap_gt.size() != 1) {
                 if (v + 1 >= g.node_off.size()) throw std::runtime_error("graph index: node list shorter than the graph");
                 mine = v++;
             }
-            places.push_back({start, &gn, mine});
+            places.push_back({gn->start, gn, mine});
         }
+        s_walk += since(t_a);
+        t_a = std::chrono::steady_clock::now();
         c.nodes.resize(places.size());
+        s_alloc += since(t_a);
+        t_a = std::chrono::steady_clock::now();
         auto fill = [&](size_t lo, size_t hi) {
+            CpuBudget::Hold cpu;
             for (size_t i = lo; i < hi; ++i) {
                 Node& n = c.nodes[i];
                 n.start = places[i].start;
@@ -325,8 +364,11 @@ Genotyper::Genotyper(const GraphIndex& g, unsigned threads) : g_(g)
         for (size_t t = 1; t < nt; ++t) pool.emplace_back(fill, places.size() * t / nt, places.size() * (t + 1) / nt);
         fill(0, places.size() / nt);
         for (auto& th : pool) th.join();
+        s_fill += since(t_a);
         chroms_.push_back(std::move(c));
     }
+    if (getenv("VGH_TIMING"))
+        std::fprintf(stderr, "[varigraph-mi] genotyper set-up %.3f s: nodes walked %.3f, allocated %.3f, k-mer lists %.3f\n", since(t_ctor), s_walk, s_alloc, s_fill);
 }
 
 // flanking sequence of a haplotype around a node: node_flanks.hpp (shared with `construct`)
@@ -1357,6 +1399,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
         const uint32_t nt = std::max(1u, cfg.threads);
         std::vector<std::thread> fill;
         auto part = [&](size_t a, size_t b) {
+            CpuBudget::Hold cpu;
             if (first) {
                 for (size_t j = a; j < b; ++j) {
                     const size_t key = g_.node_key_index[j];
@@ -1586,6 +1629,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                     // not lost, only slower
                     if (g_phase_on) std::fprintf(stderr, "[varigraph-mi] HMM part %zu: no device memory, %zu windows back on the host\n", part, dw.size());
                     for (size_t t : dw) {
+                        CpuBudget::Hold cpu;
                         WindowWork& w = works[t];
                         w.on_device = false;
                         window(*tasks[t].chr, tasks[t].first, tasks[t].last, r, nullptr, &w.top);
@@ -1612,7 +1656,10 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
             const size_t t = next.fetch_add(1);
             if (t >= tasks.size() || failed.load()) break;
             try {
-                window(*tasks[t].chr, tasks[t].first, tasks[t].last, r, device_ready ? &works[t] : nullptr);
+                {
+                    CpuBudget::Hold cpu;
+                    window(*tasks[t].chr, tasks[t].first, tasks[t].last, r, device_ready ? &works[t] : nullptr);
+                }
                 if (device_ready) {
                     const size_t part = t / part_windows;
                     const size_t in_part = std::min(tasks.size(), (part + 1) * part_windows) - part * part_windows;
@@ -1633,6 +1680,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                 finish_q.pop_front();
             }
             try {
+                CpuBudget::Hold cpu;
                 WindowWork& w = works[t];
                 window_finish(w, static_cast<const long double*>(raw_prob.p) + w.row0, static_cast<const uint32_t*>(raw_win.p) + w.row0, r);
                 make_piece(t);
@@ -1718,6 +1766,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                 try {
                     const size_t t0 = part * per_part, t1 = std::min(tasks.size(), t0 + per_part);
                     // rows: every node the HMM works on, window after window
+                    auto cpu = std::make_unique<CpuBudget::Hold>();
                     std::vector<uint64_t> e_begin;
                     std::vector<uint32_t> e_count, row_node;
                     std::vector<uint16_t> gt0;
@@ -1755,11 +1804,14 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                         vgmi_hmm_part* p = nullptr;
                         ~PartHandle() { vgmi_hmm_part_free(p); }
                     } ph;
+                    cpu.reset();
                     const int64_t ta = since_begin();
+                    int64_t t_emit = 0, t_a = 0, t_rows = 0, t_b = 0, t_calls = 0;
                     if (vgmi_hmm_emissions(dev_, (uint32_t)n_gt, (uint32_t)used.size(), used8.data(), glist.pos_a.data(), glist.pos_b.data(), top_mask,
                                            (uint32_t)g_.bitlen, ave, lower, upper, tab.data(), n_rows, e_begin.data(), e_count.data(), gt0.data(), n_kept.data(),
                                            flags.data(), &ph.p) != VGMI_OK)
                         throw std::runtime_error(std::string("device HMM emissions: ") + vgmi_last_error(dev_));
+                    t_emit = since_begin();
                     for (size_t rr = 0; rr < n_rows; ++rr)
                         if (flags[rr] & 2u) {
                             broken = true;          // a k-mer no haplotype carries: the host path prunes it
@@ -1779,6 +1831,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                                 const size_t wi = nextw.fetch_add(1);
                                 if (wi >= nw) return;
                                 try {
+                                    CpuBudget::Hold cpu;
                                     fn(wi);
                                 } catch (const std::exception& e) {
                                     std::lock_guard<std::mutex> lock(hmu);
@@ -1845,6 +1898,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                             win_rows[wi].push_back((uint32_t)rr);
                         }
                     });
+                    t_a = since_begin();
                     {
                         std::vector<uint64_t> all_rows;
                         std::vector<long double> all_obs;
@@ -1856,6 +1910,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                         if (!all_rows.empty() && vgmi_hmm_part_set_rows(ph.p, all_rows.size(), all_rows.data(), all_obs.data()) != VGMI_OK)
                             throw std::runtime_error(std::string("device HMM emissions: ") + vgmi_last_error(dev_));
                     }
+                    t_rows = since_begin();
                     std::vector<size_t> win_step0(nw + 1, 0);
                     for (size_t wi = 0; wi < nw; ++wi) win_step0[wi + 1] = win_step0[wi] + 2 * win_rows[wi].size();
                     const size_t n_steps = win_step0[nw];
@@ -1911,6 +1966,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                             ++j;
                         }
                     });
+                    t_b = since_begin();
                     std::vector<long double> prob(n_rows ? n_rows : 1);
                     std::vector<uint32_t> winner(n_rows ? n_rows : 1, 0xFFFFFFFFu);
                     if (n_steps) {
@@ -1921,9 +1977,12 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                             throw std::runtime_error(std::string("device HMM recursion: ") + vgmi_last_error(dev_));
                     }
                     const int64_t tbb = since_begin();
+                    t_calls = tbb;
                     if (g_phase_on)
-                        std::fprintf(stderr, "[varigraph-mi] HMM part %zu (windows %zu-%zu): emissions, recursion and posterior on the device from %.3f to %.3f s (%zu of %zu nodes scored by the host)\n",
-                                     part, t0, t1 - 1, ta * 1e-9, tbb * 1e-9, [&] { size_t c2 = 0; for (auto& v : host_rows) c2 += v.size(); return c2; }(), n_rows);
+                        std::fprintf(stderr, "[varigraph-mi] HMM part %zu (windows %zu-%zu): emissions, recursion and posterior on the device from %.3f to %.3f s (%zu of %zu nodes scored by the host): "
+                                     "emission kernel %.3f, host-scored nodes + strings %.3f, rows handed in %.3f, step tables %.3f, recursion + posterior %.3f\n",
+                                     part, t0, t1 - 1, ta * 1e-9, tbb * 1e-9, [&] { size_t c2 = 0; for (auto& v : host_rows) c2 += v.size(); return c2; }(), n_rows,
+                                     (t_emit - ta) * 1e-9, (t_a - t_emit) * 1e-9, (t_rows - t_a) * 1e-9, (t_b - t_rows) * 1e-9, (t_calls - t_b) * 1e-9);
                     for (int64_t v = dev_first.load(); ta < v && !dev_first.compare_exchange_weak(v, ta);) {}
                     for (int64_t v = dev_last.load(); tbb > v && !dev_last.compare_exchange_weak(v, tbb);) {}
                     over_windows([&](size_t wi) {
@@ -1991,7 +2050,10 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
             for (;;) {
                 const size_t t = next_text.fetch_add(1);
                 if (t >= tasks.size()) return;
-                if (!piece_done[t]) make_piece(t);
+                if (!piece_done[t]) {
+                    CpuBudget::Hold cpu;
+                    make_piece(t);
+                }
             }
         };
         std::vector<std::thread> tpool;
@@ -2000,6 +2062,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
         for (auto& th : tpool) th.join();
     }
     // the graph's chromosomes are a std::map like mVcfInfoMap: the tasks are already in the reference's output order
+    CpuBudget::Hold cpu;
     std::ostringstream oss;
     oss << g_.vcf_head + "\t" + sample_name + "\n";
     for (const auto& piece : pieces) oss << piece;
@@ -2028,6 +2091,7 @@ void Genotyper::write_gz(const std::string& path, const std::string& text, unsig
         for (;;) {
             const size_t b = next.fetch_add(1);
             if (b >= n_blocks) return;
+            CpuBudget::Hold cpu;
             const size_t off = b * kBlock, len = std::min(kBlock, text.size() - off);
             z_stream zs;
             std::memset(&zs, 0, sizeof zs);

@@ -36,6 +36,21 @@ struct GenotypeConfig {           // defaults: include/varigraph.hpp:49-68
     float min_gq = 0.0f;                  // --min-support
 };
 
+// The threads of a run share ONE budget of running compute threads (`-t`): several Genotypers work side by side (one per
+// sample in flight), each with helper threads of its own, and a helper takes a token for the length of a work item -- a window, a
+// block of text -- not while it waits for the device.  A Genotyper that works alone then has every thread of the run, instead of
+// an n-th of them for the whole sample.  set(0) (the default): no limit.  Never hold a token while waiting for other threads.
+class CpuBudget {
+public:
+    static void set(unsigned tokens);
+    struct Hold {
+        Hold();
+        ~Hold();
+        Hold(const Hold&) = delete;
+        Hold& operator=(const Hold&) = delete;
+    };
+};
+
 class Genotyper {
 public:
     explicit Genotyper(const GraphIndex& g, unsigned threads = 1);   // threads: workers that copy the nodes' k-mer lists

@@ -8,6 +8,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <thread>
+#include <iterator>
 #include <memory>
 #include <zlib.h>
 
@@ -300,7 +301,8 @@ void GraphIndex::load(const std::string& path)
                     std::vector<std::string> fields;
                     fields.reserve(n_fields);
                     for (uint32_t q = 0; q < n_fields; ++q) fields.push_back(c.str());
-                    sites[start] = std::move(fields);
+                    if (sites.empty() || std::prev(sites.end())->first < start) sites.emplace_hint(sites.end(), start, std::move(fields));
+                    else sites[start] = std::move(fields);
                 }
             }
 
@@ -308,6 +310,8 @@ void GraphIndex::load(const std::string& path)
             err_vcf = std::current_exception();
         }
     };
+    bool seq_in_order = true;
+    graph_seq.clear();
     auto read_nodes = [&]() {
         try {
             Cursor c = c_nodes;
@@ -321,7 +325,9 @@ void GraphIndex::load(const std::string& path)
             for (uint32_t i = 0; i < n_chr; ++i) {
                 std::string chr = c.str();
                 auto& nodes = graph[chr];
+                auto& seq = graph_seq[chr];
                 const uint32_t n_nodes = c.get<uint32_t>();
+                seq.reserve(seq.size() + n_nodes);
                 for (uint32_t j = 0; j < n_nodes; ++j) {
                     GraphNode nd;
                     nd.start = c.get<uint32_t>();
@@ -338,7 +344,13 @@ void GraphIndex::load(const std::string& path)
                     nd.kmer_hash.resize(n_km);
                     c.bytes(nd.kmer_hash.data(), sizeof(uint64_t) * n_km);
                     const uint32_t st = nd.start;
-                    nodes[st] = std::move(nd);
+                    // the writer walks its map: starts ascend, and a node goes behind the last one without a search of the tree
+                    if (nodes.empty() || std::prev(nodes.end())->first < st) {
+                        seq.push_back(&nodes.emplace_hint(nodes.end(), st, std::move(nd))->second);
+                    } else {
+                        nodes[st] = std::move(nd);
+                        seq_in_order = false;
+                    }
                 }
             }
 
@@ -418,6 +430,7 @@ void GraphIndex::load(const std::string& path)
     if (th_nodes.joinable()) th_nodes.join();
     if (err_vcf) std::rethrow_exception(err_vcf);
     if (err_nodes) std::rethrow_exception(err_nodes);
+    if (!seq_in_order) index_nodes();
     lap("VCF lines, nodes");
     graph2node();
     lap("graph2node");
@@ -430,6 +443,16 @@ void GraphIndex::load(const std::string& path)
 // keep the first 128.  The sort runs on a vector with the same length, initial order and
 // comparison outcomes as the reference's vector of map iterators, so libstdc++'s introsort
 // produces the same permutation.
+void GraphIndex::index_nodes()
+{
+    graph_seq.clear();
+    for (const auto& [chr, nodes] : graph) {
+        auto& seq = graph_seq[chr];
+        seq.reserve(nodes.size());
+        for (const auto& [start, nd] : nodes) seq.push_back(&nd);
+    }
+}
+
 void GraphIndex::graph2node()
 {
     const bool timing = getenv("VGH_TIMING") != nullptr;
@@ -439,25 +462,78 @@ void GraphIndex::graph2node()
         if (timing) std::fprintf(stderr, "[graph_index]   %-20s %.3f s\n", what, now() - t0);
         t0 = now();
     };
-    const KeyIndex index(keys, threads);
-    lap("key index");
-
     chr_names.clear(); node_chr.clear(); node_start.clear(); node_key_index.clear();
     node_off.assign(1, 0);
     // variant nodes in mGraphMap order, resolved side by side, appended in order
     std::vector<const GraphNode*> vnodes;
-    for (const auto& [chr, nodes] : graph) {
+    {
+        size_t have = 0, want = 0;
+        for (const auto& kv : graph_seq) have += kv.second.size();
+        for (const auto& kv : graph) want += kv.second.size();
+        if (have != want || graph_seq.size() != graph.size()) index_nodes();     // a graph that was not read by load()
+    }
+    for (const auto& [chr, seq] : graph_seq) {
         const uint32_t chr_id = (uint32_t)chr_names.size();
         chr_names.push_back(chr);
-        for (const auto& [start, nd] : nodes) {
-            if (nd.hap_gt.size() == 1) continue;
+        for (const GraphNode* nd : seq) {
+            if (nd->hap_gt.size() == 1) continue;
             node_chr.push_back(chr_id);
-            node_start.push_back(start);
-            vnodes.push_back(&nd);
+            node_start.push_back(nd->start);
+            vnodes.push_back(nd);
         }
     }
     std::vector<std::vector<uint32_t>> kept_all(vnodes.size());
     const uint8_t* fp = f.data();
+    if (batched_find) {
+        // every node's k-mers in one array, one batched lookup (the device holds the table already), the answers written per node
+        std::vector<uint64_t> q_off(vnodes.size() + 1, 0);
+        for (size_t v = 0; v < vnodes.size(); ++v) q_off[v + 1] = q_off[v] + vnodes[v]->kmer_hash.size();
+        const size_t total_q = q_off.back();
+        std::unique_ptr<uint64_t[]> flat(new uint64_t[total_q ? total_q : 1]);        // (no zero fill: every word is written below)
+        std::unique_ptr<uint32_t[]> found(new uint32_t[total_q ? total_q : 1]);
+        parallel_chunks(vnodes.size(), threads, [&](size_t b, size_t e, unsigned) {
+            for (size_t v = b; v < e; ++v)
+                if (!vnodes[v]->kmer_hash.empty())
+                    std::memcpy(&flat[q_off[v]], vnodes[v]->kmer_hash.data(), vnodes[v]->kmer_hash.size() * 8);
+        });
+        lap("node k-mers listed");
+        if (batched_find(flat.get(), total_q, found.get())) {
+            lap("batched lookup");
+            node_off.assign(vnodes.size() + 1, 0);
+            parallel_chunks(vnodes.size(), threads, [&](size_t b, size_t e, unsigned) {
+                for (size_t v = b; v < e; ++v) {
+                    size_t n_kept = 0;
+                    for (size_t j = q_off[v]; j < q_off[v + 1]; ++j) n_kept += found[j] != 0xFFFFFFFFu;
+                    node_off[v + 1] = std::min<size_t>(n_kept, 128);
+                }
+            });
+            for (size_t v = 0; v < vnodes.size(); ++v) node_off[v + 1] += node_off[v];
+            node_key_index.resize(node_off.back());
+            parallel_chunks(vnodes.size(), threads, [&](size_t b, size_t e, unsigned) {
+                std::vector<uint32_t> kept;
+                for (size_t v = b; v < e; ++v) {
+                    uint32_t* dst = node_key_index.data() + node_off[v];
+                    size_t n_kept = 0;
+                    for (size_t j = q_off[v]; j < q_off[v + 1]; ++j) n_kept += found[j] != 0xFFFFFFFFu;
+                    if (n_kept <= 128) {
+                        for (size_t j = q_off[v]; j < q_off[v + 1]; ++j)
+                            if (found[j] != 0xFFFFFFFFu) *dst++ = found[j];
+                        continue;
+                    }
+                    kept.clear();
+                    for (size_t j = q_off[v]; j < q_off[v + 1]; ++j)
+                        if (found[j] != 0xFFFFFFFFu) kept.push_back(found[j]);
+                    std::sort(kept.begin(), kept.end(), [fp](uint32_t a, uint32_t b2) { return fp[a] < fp[b2]; });
+                    std::memcpy(dst, kept.data(), 128 * 4);
+                }
+            });
+            lap("node lists written");
+            return;
+        }
+    }
+    {
+    const KeyIndex index(keys, threads);
+    lap("key index");
     parallel_chunks(vnodes.size(), threads, [&](size_t b, size_t e, unsigned) {
         for (size_t v = b; v < e; ++v) {
             const GraphNode& nd = *vnodes[v];
@@ -477,15 +553,16 @@ void GraphIndex::graph2node()
             }
         }
     });
-    lap("node lookups");
-    size_t total = 0;
-    for (const auto& kept : kept_all) total += kept.size();
-    node_key_index.reserve(total);
-    node_off.reserve(vnodes.size() + 1);
-    for (const auto& kept : kept_all) {
-        node_key_index.insert(node_key_index.end(), kept.begin(), kept.end());
-        node_off.push_back(node_key_index.size());
     }
+    lap("node lookups");
+    node_off.resize(vnodes.size() + 1);
+    for (size_t v = 0; v < vnodes.size(); ++v) node_off[v + 1] = node_off[v] + kept_all[v].size();
+    node_key_index.resize(node_off.back());
+    parallel_chunks(vnodes.size(), threads, [&](size_t b, size_t e, unsigned) {
+        for (size_t v = b; v < e; ++v)
+            if (!kept_all[v].empty()) std::memcpy(&node_key_index[node_off[v]], kept_all[v].data(), kept_all[v].size() * 4);
+    });
+    lap("node lists joined");
 }
 
 // src/varigraph.cpp:263-287 without the per-sample `c == 0` test: f <= 1 and, for some VCF sample,

@@ -35,6 +35,10 @@ struct GraphIndex {
     uint16_t hap_num = 0;
     std::map<uint16_t, std::string> hap_names;                                     // mHapMap
     std::map<std::string, std::map<uint32_t, GraphNode>> graph;                    // mGraphMap
+    // the nodes of every chromosome in map order (what a walk over mGraphMap[chr] visits), as an array: graph2node and every
+    // Genotyper read the million nodes through it instead of chasing the tree again.  load() fills it as it reads the file
+    std::map<std::string, std::vector<const GraphNode*>> graph_seq;
+    void index_nodes();                                                            // rebuilds graph_seq from graph
 
     // k-mer table, file record order
     std::vector<uint64_t> keys;
@@ -59,6 +63,9 @@ struct GraphIndex {
     // called by load() from its own thread as soon as keys / k are complete (the node lists and flags are not yet): lets the
     // caller start the device's table build while graph2node still runs on the host
     std::function<void()> on_keys;
+    // graph2node's lookups as ONE batch (the device's table: vgmi_table_lookup): index_out[i] = index of keys[i] in `keys`, 0xFFFFFFFF when
+    // absent; returns false when it cannot serve (then, and when unset, the host's own index does the lookups)
+    std::function<bool(const uint64_t* keys, size_t n, uint32_t* index_out)> batched_find;
     // FastqKmer::save_index / load_index (src/fastq_kmer.cpp:200-298): ReadBase + the k-mer records with the sample's coverage
     void save_reads_index(const std::string& path, const uint8_t* cov, uint64_t read_base) const;
     void load_reads_index(const std::string& path, uint8_t* cov, uint64_t& read_base) const;

@@ -203,6 +203,7 @@ int main_genotype(int argc, char** argv)
     std::mutex keys_mu;
     std::condition_variable keys_cv;
     int keys_state = 0;   // 1: keys complete, -1: the load failed before that
+    int table_state = 0;  // 1: the first device holds the table, -1: it never will
     g.on_keys = [&] {
         {
             std::lock_guard<std::mutex> lk(keys_mu);
@@ -210,7 +211,22 @@ int main_genotype(int argc, char** argv)
         }
         keys_cv.notify_all();
     };
+    // graph2node's lookups (every k-mer of every variant node against the key set) go to that table as one batch
+    g.batched_find = [&](const uint64_t* keys, size_t n, uint32_t* index_out) {
+        if (const char* e = getenv("VGH_DEVICE_GRAPH2NODE"))
+            if (e[0] == '0') return false;
+        {
+            std::unique_lock<std::mutex> lk(keys_mu);
+            keys_cv.wait(lk, [&] { return table_state != 0; });
+            if (table_state < 0) return false;
+        }
+        return vgmi_table_lookup(ctxs[0], keys, n, index_out) == VGMI_OK;
+    };
     std::thread bring_up([&] {
+        struct TableFlag {      // whatever way this thread ends, a waiting graph2node hears of it
+            std::mutex& mu; std::condition_variable& cv; int& state;
+            ~TableFlag() { { std::lock_guard<std::mutex> lk(mu); if (state == 0) state = -1; } cv.notify_all(); }
+        } table_flag{keys_mu, keys_cv, table_state};
         for (int dev : o.gpus) {
             vgmi_ctx* ctx = nullptr;
             if (vgmi_create(dev, (size_t)o.buffer_mib, &ctx) != VGMI_OK) {
@@ -224,7 +240,15 @@ int main_genotype(int argc, char** argv)
         if (keys_state < 0) return;
         lk.unlock();
         // ONE table build (first device)
-        if (vgmi_table_upload(ctxs[0], g.keys.data(), g.keys.size(), g.k) != VGMI_OK) ctx_error = vgmi_last_error(ctxs[0]);
+        if (vgmi_table_upload(ctxs[0], g.keys.data(), g.keys.size(), g.k) != VGMI_OK) {
+            ctx_error = vgmi_last_error(ctxs[0]);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk2(keys_mu);
+            table_state = 1;
+        }
+        keys_cv.notify_all();
     });
     std::string load_error;
     try {
@@ -310,7 +334,11 @@ int main_genotype(int argc, char** argv)
     // share it instead of each taking all of it
     const unsigned count_threads = std::max<unsigned>(1, o.hmm.threads / (unsigned)std::max<size_t>(1, std::min(ctxs.size(), samples.size())));
     vgh::GenotypeConfig hmm_cfg = o.hmm;
-    hmm_cfg.threads = std::max<unsigned>(1, o.hmm.threads / (unsigned)n_consumers);
+    // ... the consumers through one budget of running threads (vgh::CpuBudget): a consumer whose neighbours wait for the device has
+    // all of -t for its own preparation, calls and text; VGH_CPU_BUDGET=0: a fixed share each (rounds 2-3)
+    const bool shared_budget = n_consumers > 1 && [] { const char* e = getenv("VGH_CPU_BUDGET"); return !(e && e[0] == '0'); }();
+    if (shared_budget) vgh::CpuBudget::set(std::max<unsigned>(1, o.hmm.threads));
+    else hmm_cfg.threads = std::max<unsigned>(1, o.hmm.threads / (unsigned)n_consumers);
     std::atomic<size_t> next_hmm{0};
     std::atomic<unsigned> consumer_no{0};
     auto consumer = [&] {
@@ -362,6 +390,29 @@ int main_genotype(int argc, char** argv)
     };
     std::vector<std::thread> hmm_threads;
     for (size_t c = 0; c < n_consumers; ++c) hmm_threads.emplace_back(consumer);
+    // the read-out of a counted sample: the per-node depth lookup (src/genotype.cpp:546,660,1405-1408) and the masked histogram
+    // (src/varigraph.cpp:253-296) happen on the device: node-ordered counters and 256 bins come back, the per-key array is not fetched
+    auto counted = [&](size_t s, vgh::FastqKmerHip& fk, size_t dev_i, double ts) {
+        const std::string& name = std::get<0>(samples[s]);
+        Job job;
+        job.name = name;
+        job.cov_node.resize(g.node_key_index.size());
+        uint64_t hist[256];
+        const double tf = secs();
+        fk.fetch(nullptr, job.cov_node.data(), hist);
+        const double fetch_s = secs() - tf;
+        vgh::CoverageStats cs;
+        if (!vgh::coverage_stats(hist, fk.mReadBase, g.genome_size, o.hmm.sample_ploidy, o.use_depth, cs))
+            die("Failed to retrieve depth information of k-mers from the sequencing data. Please verify your data.");
+        job.hap_cov = cs.hap_kmer_coverage;
+        std::fprintf(stderr, "[varigraph-mi] %s (device %d): %.2f Gb sequenced, depth %.2f, haplotype k-mer coverage %.2f; counting %.2f s (kernel %.3f s, read-out %.3f s)\n",
+                     name.c_str(), o.gpus[dev_i], fk.mReadBase / 1e9, cs.read_depth, cs.hap_kmer_coverage, secs() - ts, fk.kernel_seconds(), fetch_s);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            ready.emplace(s, std::move(job));
+        }
+        cv.notify_all();
+    };
     auto counter = [&](size_t dev_i) {
         vgmi_ctx* ctx = ctxs[dev_i];
         try {
@@ -374,27 +425,9 @@ int main_genotype(int argc, char** argv)
                 }
                 const auto& [name, files] = samples[s];
                 const double ts = secs();
-                Job job;
-                job.name = name;
-                job.cov_node.resize(g.node_key_index.size());
                 vgh::FastqKmerHip fk(ctx, files, g.k, count_threads);
                 fk.build_fastq_index();
-                uint64_t hist[256];
-                // the per-node depth lookup (src/genotype.cpp:546,660,1405-1408) and the masked histogram (src/varigraph.cpp:253-296)
-                // happen on the device: node-ordered counters and 256 bins come back, the per-key array is not fetched
-                fk.fetch(nullptr, job.cov_node.data(), hist);
-                vgh::CoverageStats cs;
-                if (!vgh::coverage_stats(hist, fk.mReadBase, g.genome_size, o.hmm.sample_ploidy, o.use_depth, cs))
-                    die("Failed to retrieve depth information of k-mers from the sequencing data. Please verify your data.");
-                job.hap_cov = cs.hap_kmer_coverage;
-                std::fprintf(stderr, "[varigraph-mi] %s (device %d): %.2f Gb sequenced, depth %.2f, haplotype k-mer coverage %.2f; counting %.2f s (kernel %.3f s)\n",
-                             name.c_str(), o.gpus[dev_i], fk.mReadBase / 1e9, cs.read_depth, cs.hap_kmer_coverage, secs() - ts,
-                             fk.kernel_seconds());
-                {
-                    std::lock_guard<std::mutex> lk(mu);
-                    ready.emplace(s, std::move(job));
-                }
-                cv.notify_all();
+                counted(s, fk, dev_i, ts);
             }
         } catch (const std::exception& e) {
             die(e.what());

@@ -961,6 +961,64 @@ int vgmi_table_upload(vgmi_ctx* c, const uint64_t* keys, size_t n_keys, uint32_t
     return VGMI_OK;
 }
 
+// Batched exact lookup: index_out[i] = the index keys[i] has in the uploaded key array, 0xFFFFFFFF when the table does not hold it
+// (a key of another k included).  Works on a stream and buffers of its own and only reads the table, so it may run while another
+// thread counts reads on the same context.
+int vgmi_table_lookup(vgmi_ctx* c, const uint64_t* keys, size_t n, uint32_t* index_out)
+{
+    if (!c || (n && (!keys || !index_out))) return VGMI_E_INVALID;
+    if (!c->has_table) return fail(c, VGMI_E_STATE, "no table");
+    if (n == 0) return VGMI_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const TableView tv = c->tv;
+    const uint64_t cap = c->hdr.cap, n_keys = c->hdr.n_keys;
+    const size_t chunk = std::min<size_t>(n, (size_t)1 << 25);      // 256 MiB of keys per round, two rounds in flight
+    hipStream_t st = nullptr;
+    uint32_t* key_of_slot = nullptr;
+    uint64_t* d_keys[2] = {nullptr, nullptr};
+    uint32_t* d_out[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipError_t he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (he == hipSuccess && tv.slots8) {
+        he = hipMalloc(reinterpret_cast<void**>(&key_of_slot), cap * 4);
+        if (he == hipSuccess) he = hipMemsetAsync(key_of_slot, 0xFF, cap * 4, st);
+        if (he == hipSuccess) he = launch_table_key_of_slot(c->d_key_slot, n_keys, key_of_slot, st);
+    }
+    for (int b = 0; b < 2 && he == hipSuccess; ++b) {
+        he = hipMalloc(reinterpret_cast<void**>(&d_keys[b]), chunk * 8);
+        if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&d_out[b]), chunk * 4);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&done[b], hipEventDisableTiming);
+    }
+    size_t at[2] = {0, 0}, len[2] = {0, 0};
+    auto collect = [&](int b) {
+        if (he != hipSuccess || !len[b]) return;
+        he = hipEventSynchronize(done[b]);
+        len[b] = 0;
+    };
+    int b = 0;
+    for (size_t off = 0; off < n && he == hipSuccess; off += chunk, b ^= 1) {
+        collect(b);
+        if (he != hipSuccess) break;
+        at[b] = off;
+        len[b] = std::min(chunk, n - off);
+        he = hipMemcpyAsync(d_keys[b], keys + off, len[b] * 8, hipMemcpyHostToDevice, st);
+        if (he == hipSuccess) he = launch_table_lookup(tv, d_keys[b], len[b], c->hdr.k, key_of_slot, d_out[b], st);
+        if (he == hipSuccess) he = hipMemcpyAsync(index_out + off, d_out[b], len[b] * 4, hipMemcpyDeviceToHost, st);
+        if (he == hipSuccess) he = hipEventRecord(done[b], st);
+    }
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    for (int q = 0; q < 2; ++q) {
+        if (d_keys[q]) (void)hipFree(d_keys[q]);
+        if (d_out[q]) (void)hipFree(d_out[q]);
+        if (done[q]) (void)hipEventDestroy(done[q]);
+    }
+    if (key_of_slot) (void)hipFree(key_of_slot);
+    if (st) (void)hipStreamDestroy(st);
+    (void)at;
+    HIPCHK(c, he);
+    return VGMI_OK;
+}
+
 int vgmi_table_image_bytes(vgmi_ctx* c, size_t* bytes)
 {
     if (!c || !bytes) return VGMI_E_INVALID;

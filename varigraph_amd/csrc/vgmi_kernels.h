@@ -223,6 +223,9 @@ hipError_t launch_seq(int mode, const RowParams& p, const uint64_t* read_off, ui
 hipError_t launch_table_clear(const TableView& t, hipStream_t st);
 hipError_t launch_table_insert(const TableView& t, const uint64_t* keys, uint64_t n, uint32_t k, uint32_t* key_slot,
                                uint32_t* filter_rw, uint32_t* grid_rw, bool grid12, uint32_t* status, hipStream_t st);
+hipError_t launch_table_key_of_slot(const uint32_t* key_slot, uint64_t n, uint32_t* key_of_slot, hipStream_t st);
+hipError_t launch_table_lookup(const TableView& t, const uint64_t* keys, uint64_t n, uint32_t k, const uint32_t* key_of_slot, uint32_t* out,
+                               hipStream_t st);
 hipError_t launch_counts_reset(const TableView& t, hipStream_t st);
 hipError_t launch_cov(const TableView& t, const uint32_t* key_slot, uint64_t n, const uint8_t* flag,
                       uint8_t* cov, unsigned long long* hist, hipStream_t st);

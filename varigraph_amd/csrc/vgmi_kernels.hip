@@ -1875,6 +1875,38 @@ __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t 
     }
 }
 
+// key -> its index in the uploaded key array (graph2node's mGraphKmerHashHapStrMap.find, src/construct_index.cpp:710-751), batched:
+// the compact format keeps key_slot (index -> slot) only, so the caller hands in the inverse (slot -> index) for the call
+__global__ void table_key_of_slot_kernel(const uint32_t* key_slot, uint64_t n, uint32_t* key_of_slot)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) key_of_slot[key_slot[i]] = (uint32_t)i;
+}
+
+__global__ void table_lookup_kernel(TableView t, const uint64_t* keys, uint64_t n, uint32_t k, const uint32_t* key_of_slot, uint32_t* out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = keys[i];
+    const uint64_t mask = (1ULL << (2 * k)) - 1;
+    uint32_t found = 0xFFFFFFFFu;
+    if ((key & 0xFFu) == k && (key >> 8) <= mask) {
+        const uint64_t canon = vg_hash64_inv(key >> 8, mask);
+        uint64_t s = table_home(t, canon);
+        for (;;) {
+            const uint64_t c = t.slots8 ? t.slots8[s] : t.slots[s].canon;
+            if (c == VG_EMPTY) break;
+            if ((c & VG_SLOT_KMER_MASK) == canon) {
+                found = t.slots8 ? key_of_slot[s] : t.slots[s].key_index;
+                break;
+            }
+            if (!(c & VG_SLOT_CHAIN)) break;
+            s = (s + 1) & t.cap_mask;
+        }
+    }
+    out[i] = found;
+}
+
 // per-sample reset of the table side (the counter arrays are cleared by memset): in-slot counters of the 16-byte
 // format, saturation flags of the compact one
 __global__ __launch_bounds__(256) void counts_reset_kernel(TableView t)
@@ -2067,6 +2099,21 @@ hipError_t launch_table_insert(const TableView& t, const uint64_t* keys, uint64_
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(table_insert_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, t, keys, n, k, key_slot,
                        filter_rw, grid_rw, grid12, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_table_key_of_slot(const uint32_t* key_slot, uint64_t n, uint32_t* key_of_slot, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(table_key_of_slot_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, key_slot, n, key_of_slot);
+    return hipGetLastError();
+}
+
+hipError_t launch_table_lookup(const TableView& t, const uint64_t* keys, uint64_t n, uint32_t k, const uint32_t* key_of_slot, uint32_t* out,
+                               hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(table_lookup_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, t, keys, n, k, key_of_slot, out);
     return hipGetLastError();
 }
 

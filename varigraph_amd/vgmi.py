@@ -44,6 +44,7 @@ def load_library():
         "vgmi_table_clone": (i32, [vp, vp]),
         "vgmi_table_info": (i32, [vp, C.POINTER(sz), C.POINTER(u32), C.POINTER(sz), C.POINTER(sz)]),
         "vgmi_xtable_info": (i32, [vp, C.POINTER(sz), C.POINTER(sz)]),
+        "vgmi_table_lookup": (i32, [vp, vp, sz, vp]),
         "vgmi_nodes_upload": (i32, [vp, vp, vp, sz]),
         "vgmi_flags_upload": (i32, [vp, vp]),
         "vgmi_counts_reset": (i32, [vp]),
@@ -228,6 +229,13 @@ class Context:
         n, k, s, f = C.c_size_t(), C.c_uint32(), C.c_size_t(), C.c_size_t()
         self._chk(self._l.vgmi_table_info(self._h, C.byref(n), C.byref(k), C.byref(s), C.byref(f)))
         return {"n_keys": n.value, "k": k.value, "n_slots": s.value, "filter_bits": f.value}
+
+    def table_lookup(self, keys):
+        """Index of every key in the uploaded key array, 0xFFFFFFFF where the table does not hold it (graph2node's find, batched)."""
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.empty(keys.size, dtype=np.uint32)
+        self._chk(self._l.vgmi_table_lookup(self._h, _ptr(keys) if keys.size else None, keys.size, _ptr(out) if keys.size else None))
+        return out
 
     def xtable_info(self):
         n, o = C.c_size_t(), C.c_size_t()
