@@ -324,6 +324,7 @@ Genotyper::Genotyper(const GraphIndex& g, unsigned threads) : g_(g)
     struct Place { uint32_t start; const GraphNode* gn; size_t v; };
     size_t v = 0;
     const auto t_ctor = std::chrono::steady_clock::now();
+    kmer_pool_.reset(new uint32_t[g.node_off.empty() || g.node_off.back() == 0 ? 1 : g.node_off.back()]);
     double s_walk = 0, s_alloc = 0, s_fill = 0;
     auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
     for (const auto& [chr, nodes] : g.graph_seq) {
@@ -354,8 +355,9 @@ Genotyper::Genotyper(const GraphIndex& g, unsigned threads) : g_(g)
                 n.start = places[i].start;
                 n.gn = places[i].gn;
                 if (places[i].v != SIZE_MAX) {      // places of the node's k-mers in the node-ordered arrays (not key indices)
-                    n.kmers.resize(g.node_off[places[i].v + 1] - g.node_off[places[i].v]);
-                    std::iota(n.kmers.begin(), n.kmers.end(), (uint32_t)g.node_off[places[i].v]);
+                    n.kmers.p = kmer_pool_.get() + g.node_off[places[i].v];
+                    n.kmers.n = (uint32_t)(g.node_off[places[i].v + 1] - g.node_off[places[i].v]);
+                    std::iota(n.kmers.p, n.kmers.p + n.kmers.n, (uint32_t)g.node_off[places[i].v]);
                 }
             }
         };
@@ -603,7 +605,7 @@ Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, cons
     }
     if (filter) {
         if (kept.size() != node.kmers.size()) lists_whole_.store(false, std::memory_order_relaxed);     // the device's emission path needs whole lists
-        node.kmers = kept;
+        node.kmers.keep(kept);
     }
     return ns;
 }

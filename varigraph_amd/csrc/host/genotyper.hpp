@@ -16,8 +16,10 @@
 // haplotype and the pruned list persists across samples (ConstructIndex::reset does not restore it).
 #pragma once
 #include "vgmi.h"
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -87,10 +89,29 @@ private:
         std::vector<float> kmer_ave_cov;
         uint8_t unique_kmers = 0;
     };
+    // a node's k-mer list: a stretch of the Genotyper's one pool of places (half a million small vectors cost a fifth of a second
+    // to allocate, per Genotyper); it only ever shrinks (the forward pass prunes it)
+    struct KmerList {
+        uint32_t* p = nullptr;
+        uint32_t n = 0;
+        size_t size() const { return n; }
+        bool empty() const { return n == 0; }
+        const uint32_t* data() const { return p; }
+        const uint32_t* begin() const { return p; }
+        const uint32_t* end() const { return p + n; }
+        uint32_t operator[](size_t i) const { return p[i]; }
+        uint32_t front() const { return p[0]; }
+        uint32_t back() const { return p[n - 1]; }
+        void keep(const std::vector<uint32_t>& subset)      // subset.size() <= size()
+        {
+            std::copy(subset.begin(), subset.end(), p);
+            n = (uint32_t)subset.size();
+        }
+    };
     struct Node {
         uint32_t start = 0;
         const GraphNode* gn = nullptr;
-        std::vector<uint32_t> kmers;   // places in the node-ordered arrays (GraphIndex::node_key_index); pruned by the forward pass, persists across samples
+        KmerList kmers;                // places in the node-ordered arrays (GraphIndex::node_key_index); pruned by the forward pass, persists across samples
         std::vector<HmmScore> hmm;     // per sample
         SiteCall call;                 // per sample
     };
@@ -141,6 +162,7 @@ private:
 
     const GraphIndex& g_;
     std::vector<Chrom> chroms_;   // mGraphMap order
+    std::unique_ptr<uint32_t[]> kmer_pool_;   // what the nodes' KmerLists point into: place j of the node-ordered arrays at [j]
     vgmi_ctx* dev_ = nullptr;
     unsigned dev_parts_ = 4;
     uint32_t n_hap_ = 0;

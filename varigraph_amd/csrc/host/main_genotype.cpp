@@ -317,7 +317,12 @@ int main_genotype(int argc, char** argv)
     // (a consumer holds the nodes' k-mer lists and a packed word per k-mer of its own: 12 bytes per k-mer -- not doubled for a
     // graph of more than 2^29 k-mers)
     const bool second_consumer = device_hmm && g.keys.size() < ((size_t)1 << 29);
-    size_t per_run = std::max<size_t>(ctxs.size(), second_consumer ? 2 : 1);
+    // ... four on a single device while the graph is small enough for four copies of that: with the threads on one budget
+    // (below) a consumer's host phases take as long as they would alone, and the device runs the chains of four samples side by
+    // side at little more than one sample's latency (tools/gpu_hmm_pack.sh: 960 chains in 39.5 ms, 60 chains in 33.5 ms);
+    // eight chr20-scale samples, -t 10: 6.1 s with two consumers on fixed shares, 5.7 s on the budget, 4.5-5.1 s with four
+    const bool four = second_consumer && ctxs.size() == 1 && g.keys.size() < ((size_t)1 << 27);
+    size_t per_run = std::max<size_t>(ctxs.size(), four ? 4 : second_consumer ? 2 : 1);
     if (const char* e = getenv("VGH_HMM_CONSUMERS")) per_run = (size_t)std::max(1L, atol(e));      // A/B
     const size_t want_consumers = std::max<size_t>(1, std::min(samples.size(), per_run));
     bool independent = g.hap_names.size() <= o.hmm.haploid_num;

@@ -617,17 +617,12 @@ hipError_t launch_hmm_recursion(const HmmParams& P, uint32_t n_chains, hipStream
     // share a SIMD wait for each other's instructions (measured: 450 instead of 400 ms for the later parts).
     const size_t alone = 84 * 1024;
     const bool spread = n_chains <= 64 && plain_lds < alone;
-    size_t lds = spread ? alone : plain_lds;
+    const size_t lds = spread ? alone : plain_lds;
     uint32_t waves = spread ? 4u : 2u;
     if (const char* w = getenv("VGMI_HMM_WAVES")) waves = atoi(w) == 4 ? 4u : 2u;     // A/B
-    // several callers on one device (the samples of a run side by side): two workgroups of two wavefronts per CU -- a wavefront
-    // per SIMD still, twice the chains in flight (a claim between a third and half of a CU's 160 KB admits exactly two)
-    const size_t pair = 64 * 1024;
-    if (const char* w = getenv("VGMI_HMM_PACK"))
-        if (w[0] == '1' && plain_lds < pair) {
-            lds = pair;
-            waves = 2u;
-        }
+    // (Several callers on one device -- the samples of a run side by side -- need nothing special: a SIMD runs two of these
+    // wavefronts at little more than one's pace, a chain is latency; tools/gpu_hmm_pack.sh, 1 000 steps of 120 genotypes: 60 chains in
+    // one launch 33.5 ms, 480 chains 39.6 ms, 960 chains 39.5 ms in the dense layout -- and 78.7 ms packed two workgroups to a CU.)
     HmmParams Q = P;
     Q.dbg = vgmi_dbg_env();
     switch (P.ploidy) {
