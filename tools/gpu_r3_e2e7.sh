@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/r3e2e7; rm -rf $OUT; mkdir -p $OUT
-M="samples=8,t=10;samples=8,t=16;samples=8,t=10,VGH_HMM_CONSUMERS=2;samples=8,t=10,VGH_HMM_CONSUMERS=2,VGH_CPU_BUDGET=0,VGH_DEVICE_GRAPH2NODE=0;samples=1,t=10;samples=1,t=10,VGH_DEVICE_GRAPH2NODE=0"
+M="${1:-samples=8,t=10;samples=8,t=16;samples=8,t=10,VGH_HMM_CONSUMERS=2;samples=8,t=10,VGH_HMM_CONSUMERS=2,VGH_CPU_BUDGET=0,VGH_DEVICE_GRAPH2NODE=0;samples=1,t=10;samples=1,t=10,VGH_DEVICE_GRAPH2NODE=0}"
 VGH_TIMING=1 timeout 2400 python tools/bench_e2e.py --native-only --genome 60000000 --variants 500000 --pairs 6000000 --threads 10 --gpus 0 --repeat 2 --matrix "$M" > $OUT/matrix.json 2> $OUT/err.log
 python3 - <<'PY'
 import json
