@@ -18,7 +18,7 @@ def kernel_stats(db):
     return "\n".join(out)
 
 
-def pmc_stats(db, kernel_filter=("rows_kernel", "count27", "seq_kernel", "inflate", "fq_")):
+def pmc_stats(db, kernel_filter=("rows_kernel", "count27", "seq_kernel", "inflate", "fq_", "hmm_", "bloom_", "cov_kernel", "node_gather", "table_")):
     cur = sqlite3.connect(db).cursor()
     try:
         rows = cur.execute(
