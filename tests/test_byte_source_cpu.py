@@ -61,7 +61,10 @@ def test_skip_glue_and_reader_from_an_offset(kind, driver, files):
 
 def test_open_at_member_boundaries(driver, files):
     text = files["text"]
-    assert _run(driver, files["plain"], "at", 5000) == text[5000:]
+    # bytes that are not a gzip header are text only at the START of a file (gzopen's transparent mode); behind a compressed
+    # stream they are what gzread and the host block-gzip reader ignore (trailing garbage), so a take-over at an offset yields nothing
+    assert _run(driver, files["plain"], "at", 5000) == b""
+    assert _run(driver, files["plain"], "at", 0) == text
     raw = open(files["bgzf"], "rb").read()
     offs, pos = [], 0
     while pos < len(raw):
