@@ -336,6 +336,29 @@ def test_stl_order_map_iterates_like_unordered_map(tmp_path):
     assert r.returncode == 0 and "order identical" in r.stdout, r.stdout[-2000:]
 
 
+def test_graph2node_through_the_batched_lookup_equals_the_host_index(tmp_path):
+    """GraphIndex::graph2node (src/construct_index.cpp:710-751, 1572-1603) with its lookups served as ONE batch -- the hook the CLI
+    points at vgmi_table_lookup -- against its own host index, under AddressSanitizer + UBSan: the same node lists, including the
+    nodes that keep the 128 rarest of more than 128 k-mers (cohort_sv) and a hook that declines (the host index takes over)."""
+    import gzip
+    import subprocess
+    host_dir = os.path.join(ROOT, "varigraph_amd", "csrc", "host")
+    exe = str(tmp_path / "graph2node_check")
+    r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17", "-I", host_dir,
+                        "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "graph2node_check.cpp"),
+                        os.path.join(host_dir, "graph_index.cpp"), "-L", os.path.join(ROOT, "varigraph_amd"), "-lvgmi",
+                        "-Wl,-rpath," + os.path.join(ROOT, "varigraph_amd"), "-lz", "-lpthread", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    truncated = 0
+    for cohort in ("c1", "cohort_snp", "cohort_sv", "cohort_tetra", "cohort_k22"):
+        g = tmp_path / "graph.bin"
+        g.write_bytes(gzip.open(os.path.join(GOLDEN, cohort, "graph.bin.gz"), "rb").read())
+        r = subprocess.run([exe, str(g), "3"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.startswith("identical"), (cohort, r.stdout[-500:], r.stderr[-1500:])
+        truncated += int(r.stdout.split(" nodes of 128 entries")[0].split()[-1])
+    assert truncated > 0
+
+
 def test_vcf_writer_emits_block_gzip_independent_of_thread_count(tmp_path):
     """The CLI's output writer: valid BGZF (every member carries its size in the 'BC' field, EOF marker at the end), the
     content is the text, and the bytes do not depend on how many workers deflated the blocks."""
