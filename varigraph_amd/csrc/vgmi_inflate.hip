@@ -365,11 +365,12 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __rest
             // SIMD take 58 cycles per byte), so this loop keeps the scalar unit out of what the vector side can do: no exec
             // mask games (lanes without a byte store to an offset the buffer descriptor drops, and write their LDS byte
             // to a pad), no bounds branch (the descriptor ends at ISIZE; the position is checked once per run).
-            for (;;) {
-                need(32);     // a literal/length code (<= 15 bits) and its extra bits (<= 5)
-                const uint32_t mm = uni(t.multi[(uint32_t)bitbuf & vmask_lit]);
+            // (the loop is written with its exit test at the bottom: one compare and one branch per look-up, where the
+            // `for (;;) { ...; if (!n) break; ... }` form cost a compare, a select, two mask operations and two branches)
+            need(32);         // a literal/length code (<= 15 bits) and its extra bits (<= 5)
+            uint32_t mm = uni(t.multi[(uint32_t)bitbuf & vmask_lit]);
+            while ((mm >> 24) & 3u) {
                 const uint32_t n = (mm >> 24) & 3u;
-                if (!n) break;
                 const bool mine = lane < n;
                 const uint8_t b = (uint8_t)(mm >> (8u * (lane & 3u)));
                 __builtin_amdgcn_raw_buffer_store_b8(b, orsrc, mine ? op + lane : 0xFFFFFFFFu, 0, 0);
@@ -377,6 +378,8 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __rest
                 *cell = b;
                 op += n;
                 take(mm >> 26);
+                need(32);
+                mm = uni(t.multi[(uint32_t)bitbuf & vmask_lit]);
             }
             if (op > out_len) { err = 3; break; }
             uint32_t e = uni(t.lit[(uint32_t)bitbuf & vmask_lit]);
