@@ -1,6 +1,7 @@
 """BASELINE.json configurations through the product CLI at their stated sizes (-m gpu), VCFs byte for byte against the
 UNMODIFIED reference (oracle/_ref/varigraph_det) run on the same box on the same files:
 
+  C1  1 Mb reference + 1 k SNPs, one sample x 100 k read pairs: `construct` and `genotype`, graph.bin and VCF
   C3  chr20 scale: 60 Mb reference + 500 k variants, one sample at 30x = 12 M read pairs, `--use-depth`
   C5  (CLI side) tetraploid: 30 Mb reference + 100 k variants with indels and long insertions, `--vcf-ploidy 4` cohort,
       `--sample-ploidy 4 --use-depth`; the log must show the HMM's recursion on the device
@@ -121,6 +122,37 @@ def _native_genotype(d, graph, samples_cfg_text, extra, threads=16, timeout=600)
 
 def _vcf(d, name):
     return gzip.open(os.path.join(d, name + ".varigraph.vcf.gz"), "rb").read()
+
+
+def test_c1_at_its_stated_size_construct_and_genotype_identical(tmp_path_factory):
+    """BASELINE configs[0]: 1 Mb reference + 1 k SNP VCF, one sample x 100 k read pairs, k = 27, `construct` then `genotype`:
+    graph.bin and VCF byte for byte against the reference's own construct / genotype on the same files."""
+    _need_binaries()
+    work = str(tmp_path_factory.mktemp("c1"))
+    try:
+        ref = synth.make_reference(1_000_000)
+        variants, gts = synth.make_cohort(ref, 1000, n_samples=7, ploidy=2, seed=11)
+        fa, vcf = os.path.join(work, "ref.fa"), os.path.join(work, "in.vcf")
+        synth.write_fasta(fa, "chr1", ref)
+        synth.write_vcf(vcf, "chr1", len(ref), variants, gts, 7, 2)
+        graphs = {}
+        for name, exe, extra in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+            graphs[name] = os.path.join(work, f"graph_{name}.bin")
+            r = subprocess.run([exe, "construct", "-r", fa, "-v", vcf, "--save-graph", graphs[name], "-t", "10", "-k", "27"] + extra,
+                               cwd=work, capture_output=True, text=True, env=ENV, timeout=600)
+            assert r.returncode == 0, (name, r.stderr[-2000:])
+        assert open(graphs["native"], "rb").read() == open(graphs["cpu"], "rb").read()
+        haps = synth.sample_haplotypes(ref, variants, gts, 0, 2)
+        fq = _write_fastq(os.path.join(work, "s"), haps, 100_000, seed=1000)
+        cfg = "sample0 " + " ".join(fq) + "\n"
+        t_nat, log = _native_genotype(os.path.join(work, "native"), graphs["native"], cfg, ["--gpu", "0"], threads=10)
+        t_ref = _reference_genotype(os.path.join(work, "cpu"), graphs["cpu"], cfg, [], threads=10)
+        got, want = _vcf(os.path.join(work, "native"), "sample0"), _vcf(os.path.join(work, "cpu"), "sample0")
+        assert got == want and got.count(b"\n") > 500
+        assert "0.03 Gb sequenced" in log                       # 100 k pairs x 2 x 150 bp
+        print(f"C1 CLI: varigraph-mi genotype {t_nat:.2f} s, reference {t_ref:.1f} s, {got.count(10)} VCF lines identical")
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def test_c3_chr20_scale_12m_pairs_use_depth_vcf_identical(tmp_path_factory):
