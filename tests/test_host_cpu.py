@@ -359,6 +359,18 @@ def test_graph2node_through_the_batched_lookup_equals_the_host_index(tmp_path):
     assert truncated > 0
 
 
+def test_vcf_number_formatting_equals_the_stream(tmp_path):
+    """csrc/host/fixed1.hpp writes GQ / GPP / CAK without an ostringstream: the same characters as `<< std::fixed << std::setprecision(1)`
+    for six million floats (every tie and near-tie of the first decimals, every exponent, denormals, infinities, NaN)."""
+    import subprocess
+    exe = str(tmp_path / "fixed1_check")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "varigraph_amd", "csrc", "host"),
+                        os.path.join(ROOT, "tests", "native", "fixed1_check.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith(" 0 different"), r.stdout[-2000:]
+
+
 def test_vcf_writer_emits_block_gzip_independent_of_thread_count(tmp_path):
     """The CLI's output writer: valid BGZF (every member carries its size in the 'BC' field, EOF marker at the end), the
     content is the text, and the bytes do not depend on how many workers deflated the blocks."""

@@ -124,7 +124,7 @@ def main():
                         row["vcf_md5"] = sorted({hashlib.md5(gzip.open(os.path.join(d, f"sample{i}.varigraph.vcf.gz"), "rb").read().replace(
                             f"sample{i}".encode(), b"S")).hexdigest() for i in range(n_samples)})
                         row["same_as_first_run"] = hashlib.md5(vcfs.get("native_cli", b"").replace(b"sample0", b"S")).hexdigest() in row["vcf_md5"] and len(row["vcf_md5"]) == 1
-                        row["log"] = [ln for ln in lines if "thread-seconds" not in ln][-90:]
+                        row["log"] = [ln for ln in lines if "HMM part" not in ln][-110:]
                     else:
                         row["error"] = r.stderr[-300:]
                     out["matrix"].append(row)

@@ -31,6 +31,7 @@
 #include <unordered_set>
 
 #include "../vgmi_device.h"
+#include "fixed1.hpp"
 #include "mem_advice.hpp"
 #include "node_flanks.hpp"
 
@@ -40,6 +41,8 @@ namespace {
 std::mutex g_cpu_mu;
 std::condition_variable g_cpu_cv;
 unsigned g_cpu_limit = 0, g_cpu_used = 0;
+std::atomic<long long> g_cpu_wait_ns{0};        // VGH_TIMING: how long helpers stood in line for a token
+const bool g_cpu_timing = getenv("VGH_TIMING") != nullptr;
 }  // namespace
 
 void CpuBudget::set(unsigned tokens)
@@ -52,7 +55,13 @@ void CpuBudget::set(unsigned tokens)
 CpuBudget::Hold::Hold()
 {
     std::unique_lock<std::mutex> lk(g_cpu_mu);
-    g_cpu_cv.wait(lk, [] { return g_cpu_limit == 0 || g_cpu_used < g_cpu_limit; });
+    if (g_cpu_timing && g_cpu_limit != 0 && g_cpu_used >= g_cpu_limit) {
+        const auto t0 = std::chrono::steady_clock::now();
+        g_cpu_cv.wait(lk, [] { return g_cpu_limit == 0 || g_cpu_used < g_cpu_limit; });
+        g_cpu_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    } else {
+        g_cpu_cv.wait(lk, [] { return g_cpu_limit == 0 || g_cpu_used < g_cpu_limit; });
+    }
     ++g_cpu_used;
 }
 
@@ -388,6 +397,7 @@ std::pair<std::string, std::string> Genotyper::flanks(const Chrom& chr, uint32_t
 namespace {
 struct HmmPhases {
     std::atomic<long long> select{0}, states{0}, emit{0}, fwd{0}, bwd{0}, post{0};
+    std::atomic<long long> list{0}, pass_a{0}, pass_b{0}, pass_c{0}, fill{0}, text{0};     // the device-emission path's host work, thread-seconds
 };
 HmmPhases g_phase;
 const bool g_phase_on = getenv("VGH_TIMING") != nullptr;
@@ -1402,6 +1412,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
         std::vector<std::thread> fill;
         auto part = [&](size_t a, size_t b) {
             CpuBudget::Hold cpu;
+            PhaseTimer tt(g_phase.fill);
             if (first) {
                 for (size_t j = a; j < b; ++j) {
                     const size_t key = g_.node_key_index[j];
@@ -1534,43 +1545,54 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
     std::vector<uint8_t> piece_done(tasks.size(), 0);
     auto make_piece = [&](size_t t) {
         piece_done[t] = 1;
-        std::ostringstream oss;
-        oss << std::fixed << std::setprecision(1);
-        {
-            const Chrom& chr = *tasks[t].chr;
-            auto vc = g_.vcf_info.find(chr.name);
-            if (vc == g_.vcf_info.end()) return;
-            const auto& sites = vc->second;
-            oss.str(std::string());
-            for (uint32_t ni = tasks[t].first; ni < tasks[t].last; ++ni) {
-                const Node& node = chr.nodes[ni];
-                const SiteCall& call = node.call;
-                if (call.haps.empty()) continue;
-                auto site = sites.find(node.start);
-                if (site == sites.end()) continue;
-                const auto& fields = site->second;
-                std::vector<std::string> gt;
-                for (uint16_t hap : call.haps) gt.push_back(std::to_string(node.gn->hap_gt[hap]));
-                if (std::all_of(gt.begin(), gt.end(), [](const std::string& c) { return c == "0" || c == "."; })) continue;
-                for (size_t i = 0; i < 9; i++) {
-                    if (i == 0) oss << fields[i];
-                    else if (i == 6) oss << "\tPASS";
-                    else if (i < 8) oss << "\t" << fields[i];
-                    else oss << "\t" << "GT:GQ:GPP:NAK:CAK:UK";
-                }
-                const float gq = phred_scaled(call.probability);
-                if (gq < cfg.min_gq) std::fill(gt.begin(), gt.end(), ".");
-                oss << "\t";
-                for (size_t i = 0; i < gt.size(); ++i) oss << (i ? "/" : "") << gt[i];
-                oss << ":" << gq << ":" << call.probability << ":" << join_numbers(call.kmer_num, ",") << ":";
-                for (size_t i = 0; i < call.kmer_ave_cov.size(); i++) {
-                    if (i) oss << ",";
-                    oss << call.kmer_ave_cov[i];
-                }
-                oss << ":" << +call.unique_kmers << "\n";
+        const Chrom& chr = *tasks[t].chr;
+        auto vc = g_.vcf_info.find(chr.name);
+        if (vc == g_.vcf_info.end()) return;
+        const auto& sites = vc->second;
+        std::string out;
+        std::vector<std::string> gt;
+        for (uint32_t ni = tasks[t].first; ni < tasks[t].last; ++ni) {
+            const Node& node = chr.nodes[ni];
+            const SiteCall& call = node.call;
+            if (call.haps.empty()) continue;
+            auto site = sites.find(node.start);
+            if (site == sites.end()) continue;
+            const auto& fields = site->second;
+            gt.clear();
+            for (uint16_t hap : call.haps) gt.push_back(std::to_string(node.gn->hap_gt[hap]));
+            if (std::all_of(gt.begin(), gt.end(), [](const std::string& c) { return c == "0" || c == "."; })) continue;
+            for (size_t i = 0; i < 9; i++) {
+                if (i == 0) out += fields[i];
+                else if (i == 6) out += "\tPASS";
+                else if (i < 8) { out += '\t'; out += fields[i]; }
+                else out += "\tGT:GQ:GPP:NAK:CAK:UK";
             }
-            pieces[t] = oss.str();
+            const float gq = phred_scaled(call.probability);
+            if (gq < cfg.min_gq) std::fill(gt.begin(), gt.end(), ".");
+            out += '\t';
+            for (size_t i = 0; i < gt.size(); ++i) {
+                if (i) out += '/';
+                out += gt[i];
+            }
+            out += ':';
+            append_fixed1(out, gq);
+            out += ':';
+            append_fixed1(out, call.probability);
+            out += ':';
+            for (size_t i = 0; i < call.kmer_num.size(); ++i) {
+                if (i) out += ',';
+                append_uint(out, call.kmer_num[i]);
+            }
+            out += ':';
+            for (size_t i = 0; i < call.kmer_ave_cov.size(); i++) {
+                if (i) out += ',';
+                append_fixed1(out, call.kmer_ave_cov[i]);
+            }
+            out += ':';
+            append_uint(out, call.unique_kmers);
+            out += '\n';
         }
+        pieces[t] = std::move(out);
     };
     // ---- three kinds of work on one pool: a window is prepared (window()), the recursion and posterior of a PART of the
     // windows run on the device (one call per part, on a thread of its own that mostly waits), the calls of a part's windows
@@ -1764,16 +1786,30 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
             std::atomic<bool> broken{false};
             std::mutex err_mu;
             std::string err_text;
+            if (emit_cache_.size() != n_parts_e) {
+                emit_cache_.clear();
+                emit_cache_.resize(n_parts_e);
+            }
+            const std::string cache_key = std::to_string(tasks.size()) + "/" + std::to_string(per_part) + "/" + std::to_string(cfg.sv_only) + "/" +
+                                          std::to_string(cfg.sample_ploidy) + "/" + cfg.sample_type + "/" + std::to_string(n_gt) + "/" +
+                                          std::to_string(r.haploid_num) + "/" + std::to_string(cfg.chr_len_thread);
             auto part_fn = [&](size_t part) {
                 try {
                     const size_t t0 = part * per_part, t1 = std::min(tasks.size(), t0 + per_part);
-                    // rows: every node the HMM works on, window after window
+                    // rows: every node the HMM works on, window after window (the same for every sample: listed once)
                     auto cpu = std::make_unique<CpuBudget::Hold>();
-                    std::vector<uint64_t> e_begin;
-                    std::vector<uint32_t> e_count, row_node;
-                    std::vector<uint16_t> gt0;
-                    std::vector<size_t> win_row0(t1 - t0 + 1, 0);
-                    for (size_t t = t0; t < t1; ++t) {
+                    auto t_list = std::make_unique<PhaseTimer>(g_phase.list);
+                    EmitPartCache& pc = emit_cache_[part];
+                    const bool listed = pc.key == cache_key;
+                    if (!listed) {
+                        pc = EmitPartCache();
+                        pc.win_row0.assign(t1 - t0 + 1, 0);
+                    }
+                    std::vector<uint64_t>& e_begin = pc.e_begin;
+                    std::vector<uint32_t>&e_count = pc.e_count, &row_node = pc.row_node;
+                    std::vector<uint16_t>& gt0 = pc.gt0;
+                    std::vector<size_t>& win_row0 = pc.win_row0;
+                    for (size_t t = t0; t < t1 && !listed; ++t) {
                         Chrom& chr = *tasks[t].chr;
                         auto vcf_chr = g_.vcf_info.find(chr.name);
                         if (vcf_chr == g_.vcf_info.end()) throw std::runtime_error("'" + chr.name + "' does not exist in the VCF file.");
@@ -1800,12 +1836,19 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                         win_row0[t - t0 + 1] = e_begin.size();
                     }
                     const size_t n_rows = e_begin.size();
+                    if (!listed) {
+                        pc.gid.assign(n_rows * n_gt, 0);
+                        pc.order.assign(n_rows * n_gt, 0);
+                        pc.have.assign(n_rows ? n_rows : 1, 0);
+                        pc.key = cache_key;
+                    }
                     std::vector<uint32_t> n_kept(n_rows ? n_rows : 1);
                     std::vector<uint8_t> flags(n_rows ? n_rows : 1);
                     struct PartHandle {
                         vgmi_hmm_part* p = nullptr;
                         ~PartHandle() { vgmi_hmm_part_free(p); }
                     } ph;
+                    t_list.reset();
                     cpu.reset();
                     const int64_t ta = since_begin();
                     int64_t t_emit = 0, t_a = 0, t_rows = 0, t_b = 0, t_calls = 0;
@@ -1824,7 +1867,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                     // places A's counts give them.  Then recursion and posterior on the device.  C: the calls and the VCF lines.
                     const size_t nw = t1 - t0;
                     const size_t helpers = std::max<size_t>(1, std::min<size_t>(nw, n_threads / n_parts_e));
-                    auto over_windows = [&](const std::function<void(size_t)>& fn) {
+                    auto over_windows = [&](std::atomic<long long>& spent, const std::function<void(size_t)>& fn) {
                         std::atomic<size_t> nextw{0};
                         std::string herr;
                         std::mutex hmu;
@@ -1834,6 +1877,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                                 if (wi >= nw) return;
                                 try {
                                     CpuBudget::Hold cpu;
+                                    PhaseTimer tt(spent);
                                     fn(wi);
                                 } catch (const std::exception& e) {
                                     std::lock_guard<std::mutex> lock(hmu);
@@ -1852,8 +1896,8 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                     std::vector<std::vector<uint32_t>> win_nodes(nw), win_rows(nw);
                     std::vector<std::vector<uint64_t>> host_rows(nw);
                     std::vector<std::vector<long double>> host_obs(nw);
-                    std::vector<uint8_t> gid(n_rows * n_gt, 0), order(n_rows * n_gt, 0);
-                    over_windows([&](size_t wi) {
+                    std::vector<uint8_t>&gid = pc.gid, &order = pc.order;
+                    over_windows(g_phase.pass_a, [&](size_t wi) {
                         Chrom& chr = *tasks[t0 + wi].chr;
                         ScoreCtx sctx;
                         sctx.ave = ave;
@@ -1884,7 +1928,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                                 continue;
                             }
                             seen[wi].push_back(Seen{n_start, n_end, (int64_t)rr});
-                            {
+                            if (!pc.have[rr]) {      // (a row that had a score under an earlier sample keeps its strings)
                                 bool biallelic = true;
                                 for (uint16_t hap : used) biallelic = biallelic && n.gn->hap_gt[hap] <= 1;
                                 auto it = biallelic ? gs_memo.find(gt0[rr]) : gs_memo.end();
@@ -1895,6 +1939,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                                     (void)genotype_strings(n, genotypes, gid.data() + rr * n_gt, order.data() + rr * n_gt);     // <= 128 strings: always fits
                                     if (biallelic) gs_memo.emplace(gt0[rr], (uint32_t)rr);
                                 }
+                                pc.have[rr] = 1;
                             }
                             win_nodes[wi].push_back(row_node[rr]);
                             win_rows[wi].push_back((uint32_t)rr);
@@ -1927,7 +1972,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                         chains.push_back(vgmi_hmm_chain{win_step0[wi], m, 0, 0});
                         chains.push_back(vgmi_hmm_chain{win_step0[wi] + m, m, 0, 0});
                     }
-                    over_windows([&](size_t wi) {
+                    over_windows(g_phase.pass_b, [&](size_t wi) {
                         const size_t m = win_rows[wi].size();
                         if (!m) return;
                         const size_t step0 = win_step0[wi];
@@ -1987,7 +2032,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                                      (t_emit - ta) * 1e-9, (t_a - t_emit) * 1e-9, (t_rows - t_a) * 1e-9, (t_b - t_rows) * 1e-9, (t_calls - t_b) * 1e-9);
                     for (int64_t v = dev_first.load(); ta < v && !dev_first.compare_exchange_weak(v, ta);) {}
                     for (int64_t v = dev_last.load(); tbb > v && !dev_last.compare_exchange_weak(v, tbb);) {}
-                    over_windows([&](size_t wi) {
+                    over_windows(g_phase.pass_c, [&](size_t wi) {
                         WindowWork w;
                         w.chr = tasks[t0 + wi].chr;
                         w.n_gt = n_gt;
@@ -2043,6 +2088,11 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                      g_phase.select.exchange(0) * 1e-9, g_phase.states.exchange(0) * 1e-9, g_phase.emit.exchange(0) * 1e-9, g_phase.fwd.exchange(0) * 1e-9,
                      g_phase.bwd.exchange(0) * 1e-9, g_phase.post.exchange(0) * 1e-9, last_hmm_seconds, n_threads);
         if (last_device_seconds > 0) std::fprintf(stderr, "[varigraph-mi] HMM recursion on the device: %.2f s\n", last_device_seconds);
+        if (emitted_on_device)
+            std::fprintf(stderr, "[varigraph-mi] host thread-seconds around the device (all samples in flight since the last line of this kind): node lists %.2f, "
+                         "host-scored nodes + genotype strings %.2f, step tables %.2f, calls + VCF lines %.2f, coverage words %.2f, text joined %.2f, in line for a thread %.2f\n",
+                         g_phase.list.exchange(0) * 1e-9, g_phase.pass_a.exchange(0) * 1e-9, g_phase.pass_b.exchange(0) * 1e-9, g_phase.pass_c.exchange(0) * 1e-9,
+                         g_phase.fill.exchange(0) * 1e-9, g_phase.text.exchange(0) * 1e-9, g_cpu_wait_ns.exchange(0) * 1e-9);
     }
 
     // ---- the pieces that are not written yet (windows without a device call), then the whole text
@@ -2065,6 +2115,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
     }
     // the graph's chromosomes are a std::map like mVcfInfoMap: the tasks are already in the reference's output order
     CpuBudget::Hold cpu;
+    PhaseTimer t_text(g_phase.text);
     std::ostringstream oss;
     oss << g_.vcf_head + "\t" + sample_name + "\n";
     for (const auto& piece : pieces) oss << piece;

@@ -162,6 +162,18 @@ private:
 
     const GraphIndex& g_;
     std::vector<Chrom> chroms_;   // mGraphMap order
+    // What a part of the windows hands to the device and what does not depend on the sample: which nodes the HMM works on, their
+    // entry ranges and reference-allele masks, and the genotype strings of every node that ever had a score.  Listed for the first
+    // sample, kept for the next (one list per part; `key` names the options it was made under).
+    struct EmitPartCache {
+        std::string key;
+        std::vector<uint64_t> e_begin;
+        std::vector<uint32_t> e_count, row_node;
+        std::vector<uint16_t> gt0;
+        std::vector<size_t> win_row0;
+        std::vector<uint8_t> gid, order, have;      // per row: n_gt bytes each; have[row]: its strings are there
+    };
+    std::vector<EmitPartCache> emit_cache_;
     std::unique_ptr<uint32_t[]> kmer_pool_;   // what the nodes' KmerLists point into: place j of the node-ordered arrays at [j]
     vgmi_ctx* dev_ = nullptr;
     unsigned dev_parts_ = 4;
