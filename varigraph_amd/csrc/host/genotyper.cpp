@@ -1413,7 +1413,9 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
         auto part = [&](size_t a, size_t b) {
             CpuBudget::Hold cpu;
             PhaseTimer tt(g_phase.fill);
-            if (first) {
+            if (first && g_.entry_words.size() == n_entries) {      // the graph's half was gathered once for every Genotyper
+                for (size_t j = a; j < b; ++j) packed_[j] = g_.entry_words[j] | cov_node[j];
+            } else if (first) {
                 for (size_t j = a; j < b; ++j) {
                     const size_t key = g_.node_key_index[j];
                     uint64_t bits = 0;
@@ -1432,8 +1434,13 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
 
     for (auto& c : chroms_)
         for (auto& n : c.nodes) {
-            std::vector<HmmScore>().swap(n.hmm);
-            n.call = SiteCall();
+            if (n.hmm.capacity()) std::vector<HmmScore>().swap(n.hmm);
+            // (cleared, not replaced: the three small vectors of a call keep their storage from sample to sample)
+            n.call.probability = 0;
+            n.call.haps.clear();
+            n.call.kmer_num.clear();
+            n.call.kmer_ave_cov.clear();
+            n.call.unique_kmers = 0;
         }
 
     // windows of `chr_len_thread` bp over the node list of every chromosome (src/genotype.cpp:76-140)

@@ -443,6 +443,24 @@ void GraphIndex::load(const std::string& path)
 // keep the first 128.  The sort runs on a vector with the same length, initial order and
 // comparison outcomes as the reference's vector of map iterators, so libstdc++'s introsort
 // produces the same permutation.
+void GraphIndex::build_entry_words()
+{
+    entry_words.clear();
+    if (bitlen > 6) return;
+    const size_t n = node_key_index.size(), bl = bitlen;
+    entry_words.reserve(n);
+    advise_huge_pages(entry_words.data(), n * sizeof(uint64_t));
+    entry_words.resize(n);
+    parallel_chunks(n, threads, [&](size_t b, size_t e, unsigned) {
+        for (size_t j = b; j < e; ++j) {
+            const size_t key = node_key_index[j];
+            uint64_t bits = 0;
+            std::memcpy(&bits, &bitvec[key * bl], bl);
+            entry_words[j] = (uint64_t)(uint8_t)f[key] << 8 | bits << 16;
+        }
+    });
+}
+
 void GraphIndex::index_nodes()
 {
     graph_seq.clear();

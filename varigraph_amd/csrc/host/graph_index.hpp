@@ -39,6 +39,11 @@ struct GraphIndex {
     // Genotyper read the million nodes through it instead of chasing the tree again.  load() fills it as it reads the file
     std::map<std::string, std::vector<const GraphNode*>> graph_seq;
     void index_nodes();                                                            // rebuilds graph_seq from graph
+    // per entry of the node lists: multiplicity << 8 | haplotype bits << 16 (the graph's half of the word a Genotyper keeps per entry
+    // and sample; bitlen <= 6).  A gather over the key arrays: made once here when several Genotypers share the graph, else by the
+    // Genotyper itself
+    std::vector<uint64_t> entry_words;
+    void build_entry_words();
 
     // k-mer table, file record order
     std::vector<uint64_t> keys;

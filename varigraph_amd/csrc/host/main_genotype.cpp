@@ -335,6 +335,7 @@ int main_genotype(int argc, char** argv)
         }
     }
     const size_t n_consumers = independent ? want_consumers : 1;
+    if (n_consumers > 1) g.build_entry_words();      // the graph's half of the Genotypers' per-entry words, once instead of once each
     // -t is the budget of the whole run: counting threads (inflate workers) and HMM consumers that run side by side
     // share it instead of each taking all of it
     const unsigned count_threads = std::max<unsigned>(1, o.hmm.threads / (unsigned)std::max<size_t>(1, std::min(ctxs.size(), samples.size())));
