@@ -12,6 +12,11 @@ int main(int argc, char** argv)
     const unsigned threads = argc > 2 ? (unsigned)atoi(argv[2]) : 4;
     vgh::GraphIndex a, b, c;
     a.threads = b.threads = c.threads = threads;
+    size_t asked = 0;
+    a.batched_find = [&](const uint64_t*, size_t n, uint32_t*) {      // declines, but sees how many k-mers the nodes hold
+        asked = n;
+        return false;
+    };
     a.load(argv[1]);
     size_t calls = 0;
     b.batched_find = [&](const uint64_t* keys, size_t n, uint32_t* out) {
@@ -27,12 +32,7 @@ int main(int argc, char** argv)
     b.load(argv[1]);
     c.batched_find = [](const uint64_t*, size_t, uint32_t*) { return false; };      // cannot serve: the host index takes over
     c.load(argv[1]);
-    size_t over = 0, absent = 0, asked = 0;
-    for (const auto& [chr, nodes] : a.graph)
-        for (const auto& [start, nd] : nodes) {
-            if (nd.hap_gt.size() == 1) continue;
-            asked += nd.kmer_hash.size();
-        }
+    size_t over = 0, absent = 0;
     for (size_t v = 0; v + 1 < a.node_off.size(); ++v) over += a.node_off[v + 1] - a.node_off[v] == 128;
     absent = asked - a.node_key_index.size();
     for (const vgh::GraphIndex* g : {&b, &c}) {

@@ -298,9 +298,13 @@ void GraphIndex::load(const std::string& path)
                 for (uint32_t j = 0; j < n_sites; ++j) {
                     const uint32_t start = c.get<uint32_t>();
                     const uint32_t n_fields = c.get<uint32_t>();
+                    // CHROM .. INFO: what the VCF writer and --sv read (src/genotype.cpp:1579-1696, :600-610); the FORMAT column and the
+                    // cohort's genotype strings behind it are hopped over, not turned into strings (half of a site's sixteen)
                     std::vector<std::string> fields;
-                    fields.reserve(n_fields);
-                    for (uint32_t q = 0; q < n_fields; ++q) fields.push_back(c.str());
+                    const uint32_t keep = std::min<uint32_t>(n_fields, kVcfFieldsKept);
+                    fields.reserve(keep);
+                    for (uint32_t q = 0; q < keep; ++q) fields.push_back(c.str());
+                    for (uint32_t q = keep; q < n_fields; ++q) skip_str(c);
                     if (sites.empty() || std::prev(sites.end())->first < start) sites.emplace_hint(sites.end(), start, std::move(fields));
                     else sites[start] = std::move(fields);
                 }
@@ -341,8 +345,9 @@ void GraphIndex::load(const std::string& path)
                     c.bytes(nd.hap_gt.data(), sizeof(uint16_t) * n_gt);
                     const uint32_t n_km = c.get<uint32_t>();
                     c.need(sizeof(uint64_t) * (size_t)n_km);
-                    nd.kmer_hash.resize(n_km);
-                    c.bytes(nd.kmer_hash.data(), sizeof(uint64_t) * n_km);
+                    nd.kmer_file = n_km ? c.p : nullptr;        // read in place by graph2node (below, before the buffer goes)
+                    nd.kmer_file_n = n_km;
+                    c.p += sizeof(uint64_t) * (size_t)n_km;
                     const uint32_t st = nd.start;
                     // the writer walks its map: starts ascend, and a node goes behind the last one without a search of the tree
                     if (nodes.empty() || std::prev(nodes.end())->first < st) {
@@ -432,7 +437,7 @@ void GraphIndex::load(const std::string& path)
     if (err_nodes) std::rethrow_exception(err_nodes);
     if (!seq_in_order) index_nodes();
     lap("VCF lines, nodes");
-    graph2node();
+    graph2node();        // (forgets the nodes' places in the file buffer, which ends with this function)
     lap("graph2node");
     compute_hom_flags();
     lap("hom flags");
@@ -502,17 +507,29 @@ void GraphIndex::graph2node()
     }
     std::vector<std::vector<uint32_t>> kept_all(vnodes.size());
     const uint8_t* fp = f.data();
+    // a graph that load() is reading keeps its nodes' hashes in the file buffer: whichever way the lists are resolved, the
+    // nodes forget those places before this function returns (the buffer does not outlive load())
+    auto forget_file_places = [&]() {
+        parallel_chunks(vnodes.size(), threads, [&](size_t b, size_t e, unsigned) {
+            for (size_t v = b; v < e; ++v) {
+                GraphNode* nd = const_cast<GraphNode*>(vnodes[v]);
+                nd->kmer_file = nullptr;
+                nd->kmer_file_n = 0;
+            }
+        });
+    };
     if (batched_find) {
         // every node's k-mers in one array, one batched lookup (the device holds the table already), the answers written per node
         std::vector<uint64_t> q_off(vnodes.size() + 1, 0);
-        for (size_t v = 0; v < vnodes.size(); ++v) q_off[v + 1] = q_off[v] + vnodes[v]->kmer_hash.size();
+        for (size_t v = 0; v < vnodes.size(); ++v) q_off[v + 1] = q_off[v] + vnodes[v]->n_kmers();
         const size_t total_q = q_off.back();
         std::unique_ptr<uint64_t[]> flat(new uint64_t[total_q ? total_q : 1]);        // (no zero fill: every word is written below)
         std::unique_ptr<uint32_t[]> found(new uint32_t[total_q ? total_q : 1]);
         parallel_chunks(vnodes.size(), threads, [&](size_t b, size_t e, unsigned) {
             for (size_t v = b; v < e; ++v)
-                if (!vnodes[v]->kmer_hash.empty())
-                    std::memcpy(&flat[q_off[v]], vnodes[v]->kmer_hash.data(), vnodes[v]->kmer_hash.size() * 8);
+                if (vnodes[v]->n_kmers())
+                    std::memcpy(&flat[q_off[v]], vnodes[v]->kmer_file ? (const void*)vnodes[v]->kmer_file : (const void*)vnodes[v]->kmer_hash.data(),
+                                vnodes[v]->n_kmers() * 8);
         });
         lap("node k-mers listed");
         if (batched_find(flat.get(), total_q, found.get())) {
@@ -546,6 +563,7 @@ void GraphIndex::graph2node()
                 }
             });
             lap("node lists written");
+            forget_file_places();
             return;
         }
     }
@@ -556,14 +574,14 @@ void GraphIndex::graph2node()
         for (size_t v = b; v < e; ++v) {
             const GraphNode& nd = *vnodes[v];
             std::vector<uint32_t>& kept = kept_all[v];
-            kept.reserve(nd.kmer_hash.size());
-            const size_t nk = nd.kmer_hash.size();
-            for (size_t j = 0; j < nk && j < 16; ++j) index.prefetch(nd.kmer_hash[j]);
+            kept.reserve(nd.n_kmers());
+            const size_t nk = nd.n_kmers();
+            for (size_t j = 0; j < nk && j < 16; ++j) index.prefetch(nd.kmer(j));
             for (size_t j = 0; j < nk; ++j) {
-                if (j + 16 < nk) index.prefetch(nd.kmer_hash[j + 16]);
-                if (j + 8 < nk) index.prefetch_record(nd.kmer_hash[j + 8]);
+                if (j + 16 < nk) index.prefetch(nd.kmer(j + 16));
+                if (j + 8 < nk) index.prefetch_record(nd.kmer(j + 8));
                 uint32_t at;
-                if (index.find(nd.kmer_hash[j], at)) kept.push_back(at);
+                if (index.find(nd.kmer(j), at)) kept.push_back(at);
             }
             if (kept.size() > 128) {
                 std::sort(kept.begin(), kept.end(), [fp](uint32_t a, uint32_t b2) { return fp[a] < fp[b2]; });
@@ -581,6 +599,7 @@ void GraphIndex::graph2node()
             if (!kept_all[v].empty()) std::memcpy(&node_key_index[node_off[v]], kept_all[v].data(), kept_all[v].size() * 4);
     });
     lap("node lists joined");
+    forget_file_places();
 }
 
 // src/varigraph.cpp:263-287 without the per-sample `c == 0` test: f <= 1 and, for some VCF sample,

@@ -22,7 +22,19 @@ struct GraphNode {  // one nodeSrt (include/construct_index.hpp:105-121) without
     uint32_t start = 0;
     std::vector<std::string> seqs;      // seqVec
     std::vector<uint16_t> hap_gt;       // hapGtVec
-    std::vector<uint64_t> kmer_hash;    // kmerHashVec (graph.bin order)
+    std::vector<uint64_t> kmer_hash;    // kmerHashVec (graph.bin order) -- of a graph built in memory (`construct`)
+    // ... of a graph being loaded: the hashes are only ever read by graph2node, inside load(), so they stay where they are in the file
+    // buffer (unaligned, 8 bytes each) instead of a million small vectors; cleared when load() returns
+    const uint8_t* kmer_file = nullptr;
+    uint32_t kmer_file_n = 0;
+    size_t n_kmers() const { return kmer_file ? kmer_file_n : kmer_hash.size(); }
+    uint64_t kmer(size_t j) const
+    {
+        if (!kmer_file) return kmer_hash[j];
+        uint64_t v;
+        __builtin_memcpy(&v, kmer_file + 8 * j, 8);
+        return v;
+    }
 };
 
 struct GraphIndex {
@@ -30,7 +42,8 @@ struct GraphIndex {
     uint32_t k = 0, vcf_ploidy = 0;
     std::string vcf_head;
     std::map<std::string, uint32_t> chr_len;                                       // mFastaLenMap
-    std::map<std::string, std::map<uint32_t, std::vector<std::string>>> vcf_info;  // mVcfInfoMap
+    std::map<std::string, std::map<uint32_t, std::vector<std::string>>> vcf_info;  // mVcfInfoMap: per site its first kVcfFieldsKept columns
+    static constexpr uint32_t kVcfFieldsKept = 8;                                  // CHROM POS ID REF ALT QUAL FILTER INFO
     uint64_t genome_size = 0;
     uint16_t hap_num = 0;
     std::map<uint16_t, std::string> hap_names;                                     // mHapMap
