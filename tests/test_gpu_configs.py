@@ -155,6 +155,58 @@ def test_c1_at_its_stated_size_construct_and_genotype_identical(tmp_path_factory
         shutil.rmtree(work, ignore_errors=True)
 
 
+def test_three_chromosomes_in_another_order_than_their_names_identical(tmp_path_factory):
+    """Every fixture and BASELINE configuration has one chromosome; the reference keeps its graph, its VCF lines and its windows per
+    chromosome in maps ordered by NAME (mGraphMap, mVcfInfoMap).  Three chromosomes whose order in the FASTA and the VCF (chr2, chr10,
+    chr1) is not the order of their names (chr1 < chr10 < chr2), with SNPs, indels and a long insertion each, three samples in one run
+    (default consumers): graph.bin and the VCFs byte for byte against the reference's construct / genotype."""
+    _need_binaries()
+    work = str(tmp_path_factory.mktemp("chr3"))
+    try:
+        chroms = [("chr2", 400_000, 21), ("chr10", 250_000, 22), ("chr1", 350_000, 23)]
+        fa, vcf = os.path.join(work, "ref.fa"), os.path.join(work, "in.vcf")
+        haps = None
+        with open(fa, "wb") as f_fa, open(vcf, "w") as f_vcf:
+            f_vcf.write("##fileformat=VCFv4.2\n")
+            for name, length, _ in chroms:
+                f_vcf.write(f"##contig=<ID={name},length={length}>\n")
+            f_vcf.write('##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n')
+            f_vcf.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(f"S{i}" for i in range(5)) + "\n")
+            all_h = [[], []]
+            for name, length, seed in chroms:
+                ref = synth._ACGT[np.random.default_rng(seed).integers(0, 4, size=length)]
+                variants, gts = synth.make_cohort(ref, length // 500, n_samples=5, ploidy=2, seed=seed, indel_frac=0.1, sv_frac=0.01)
+                f_fa.write(b">" + name.encode() + b"\n")
+                b = ref.tobytes()
+                for i in range(0, len(b), 60):
+                    f_fa.write(b[i:i + 60] + b"\n")
+                for vi, (pos, ra, aa) in enumerate(variants):
+                    cols = ["|".join(str(int(x)) for x in gts[vi, s2 * 2:(s2 + 1) * 2]) for s2 in range(5)]
+                    f_vcf.write(f"{name}\t{pos + 1}\t{name}_{vi}\t{ra.decode()}\t{aa.decode()}\t.\tPASS\t.\tGT\t" + "\t".join(cols) + "\n")
+                for h, seq in zip(all_h, synth.sample_haplotypes(ref, variants, gts, 0, 2)):
+                    h.append(seq)
+            haps = [np.concatenate([np.concatenate([c, np.frombuffer(b"N" * 200, dtype=np.uint8)]) for c in h]) for h in all_h]
+        graphs = {}
+        for name, exe, extra in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+            graphs[name] = os.path.join(work, f"graph_{name}.bin")
+            r = subprocess.run([exe, "construct", "-r", fa, "-v", vcf, "--save-graph", graphs[name], "-t", "10"] + extra,
+                               cwd=work, capture_output=True, text=True, env=ENV, timeout=600)
+            assert r.returncode == 0, (name, r.stderr[-2000:])
+        assert open(graphs["native"], "rb").read() == open(graphs["cpu"], "rb").read()
+        fq = _write_fastq(os.path.join(work, "s"), haps, 100_000, seed=77)      # reads across the N spacers carry N: skipped k-mers
+        cfg = "".join(f"{n} " + " ".join(fq) + "\n" for n in ("a", "b", "c"))
+        t_nat, log = _native_genotype(os.path.join(work, "native"), graphs["native"], cfg, ["--gpu", "0"], threads=10)
+        _reference_genotype(os.path.join(work, "cpu"), graphs["cpu"], "a " + " ".join(fq) + "\n", [], threads=10)
+        want = _vcf(os.path.join(work, "cpu"), "a")
+        assert want.count(b"\n") > 1000 and all(want.count(c.encode() + b"\t") > 100 for c, _, _ in chroms)
+        lines = [ln.split(b"\t")[0] for ln in want.split(b"\n") if ln and not ln.startswith(b"#")]
+        assert lines.index(b"chr10") > lines.index(b"chr1") and lines.index(b"chr2") > lines.index(b"chr10")     # map order, not file order
+        for n in ("a", "b", "c"):
+            assert _vcf(os.path.join(work, "native"), n).replace(b"\t" + n.encode() + b"\n", b"\ta\n") == want, n
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def test_c3_chr20_scale_12m_pairs_use_depth_vcf_identical(tmp_path_factory):
     _need_binaries()
     work = str(tmp_path_factory.mktemp("c3"))
