@@ -177,6 +177,35 @@ def test_native_cli_two_samples_and_errors(tmp_path):
                           capture_output=True, timeout=300).returncode != 0
 
 
+def test_native_cli_samples_of_one_and_of_three_files(tmp_path):
+    """A sample line names any number of files (src/varigraph.cpp:104-146): one file (single-end), three files (a file twice: the
+    coverage doubles), the usual pair -- in ONE run, each VCF byte for byte against the reference run on that sample alone."""
+    if not os.path.exists(CLI):
+        _missing("varigraph-mi not built")
+    if not os.path.exists(REF):
+        _missing("oracle/_ref/varigraph_det")
+    d = os.path.join(GOLDEN, "cohort_sv")
+    graph = tmp_path / "graph.bin"
+    graph.write_bytes(gzip.open(os.path.join(d, "graph.bin.gz"), "rb").read())
+    one, two = (os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2))
+    plain = tmp_path / "reads_2.fq"
+    plain.write_bytes(gzip.open(two, "rb").read())
+    samples = {"single": [one], "triple": [one, str(plain), one], "pair": [one, two], "other": [str(plain)]}
+    (tmp_path / "samples.cfg").write_text("".join(f"{n} " + " ".join(f) + "\n" for n, f in samples.items()))
+    env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+    r = _run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "6", "--gpu", "0", "--use-depth"], cwd=tmp_path,
+             capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for n, f in samples.items():
+        cpu = tmp_path / ("cpu_" + n)
+        cpu.mkdir()
+        (cpu / "samples.cfg").write_text(f"{n} " + " ".join(f) + "\n")
+        r2 = _run([REF, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4", "--use-depth"], cwd=cpu, capture_output=True,
+                  text=True, timeout=300)
+        assert r2.returncode == 0, r2.stderr[-2000:]
+        assert gzip.open(tmp_path / f"{n}.varigraph.vcf.gz", "rb").read() == gzip.open(cpu / f"{n}.varigraph.vcf.gz", "rb").read(), n
+
+
 def test_native_cli_several_devices_keep_sample_order(tmp_path):
     """--gpus a,b: samples are counted on several device contexts in parallel (here the same GPU twice) while the
     HMM consumes them strictly in `-s` order -- its per-node state carries over from sample to sample, so the result
