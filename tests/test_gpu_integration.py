@@ -206,6 +206,32 @@ def test_native_cli_samples_of_one_and_of_three_files(tmp_path):
         assert gzip.open(tmp_path / f"{n}.varigraph.vcf.gz", "rb").read() == gzip.open(cpu / f"{n}.varigraph.vcf.gz", "rb").read(), n
 
 
+@pytest.mark.parametrize("ploidy,n", [(3, 7), (3, 15), (5, 4), (6, 4), (8, 3)])
+def test_native_cli_other_sample_ploidies(ploidy, n, tmp_path):
+    """`--sample-ploidy` 2..8 (main.cpp:355-357): triploid runs on the device (a stride of four powers per step), five and more
+    copies stay on the host's x87 recursion -- either way byte for byte the reference's VCF, on the tetraploid cohort's graph."""
+    if not os.path.exists(CLI):
+        _missing("varigraph-mi not built")
+    if not os.path.exists(REF):
+        _missing("oracle/_ref/varigraph_det")
+    d = os.path.join(GOLDEN, "cohort_tetra")
+    graph = tmp_path / "graph.bin"
+    graph.write_bytes(gzip.open(os.path.join(d, "graph.bin.gz"), "rb").read())
+    fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
+    extra = ["--sample-ploidy", str(ploidy), "-n", str(n), "--use-depth"]
+    env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+    outs = {}
+    for name, exe, more in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+        w = tmp_path / name
+        w.mkdir()
+        (w / "samples.cfg").write_text("s " + " ".join(fq) + "\n")
+        r = _run([exe, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4"] + extra + more, cwd=w, capture_output=True,
+                 text=True, env=env, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        outs[name] = gzip.open(w / "s.varigraph.vcf.gz", "rb").read()
+    assert outs["native"] == outs["cpu"] and outs["cpu"].count(b"\n") > 20
+
+
 def test_native_cli_several_devices_keep_sample_order(tmp_path):
     """--gpus a,b: samples are counted on several device contexts in parallel (here the same GPU twice) while the
     HMM consumes them strictly in `-s` order -- its per-node state carries over from sample to sample, so the result
