@@ -303,6 +303,32 @@ def test_native_construct_reproduces_reference_graph(cohort, tmp_path):
     assert got == want
 
 
+@pytest.mark.parametrize("opts", [["--fast"], ["--use-unique-kmers"], ["--fast", "--use-unique-kmers"], ["-k", "21", "--fast"]],
+                         ids=["fast", "unique", "fast-unique", "k21-fast"])
+@pytest.mark.parametrize("cohort", ["cohort_snp", "cohort_sv"])
+def test_native_construct_options_reproduce_reference_graph(cohort, opts, tmp_path):
+    """`construct --fast` / `--use-unique-kmers` (main.cpp:88-109, construct_index.cpp): graph.bin byte for byte the reference's,
+    built here by the reference itself with the same options."""
+    if not os.path.exists(CLI):
+        _missing("varigraph-mi not built")
+    if not os.path.exists(REF):
+        _missing("oracle/_ref/varigraph_det")
+    import json
+    from varigraph_amd import synth
+    d = os.path.join(GOLDEN, cohort)
+    meta = json.load(open(os.path.join(d, "meta.json")))
+    fa = tmp_path / "ref.fa"
+    synth.write_fasta(str(fa), "chr1", synth.make_reference(meta["ref_len"], seed=meta["ref_seed"]))
+    env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+    base = ["construct", "-r", str(fa), "-v", os.path.join(d, "in.vcf"), "--vcf-ploidy", str(meta["ploidy"])] + opts
+    r = _run([CLI] + base + ["--save-graph", "native.bin", "--gpu", "0"], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = _run([REF] + base + ["--save-graph", "cpu.bin"], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got, want = (tmp_path / "native.bin").read_bytes(), (tmp_path / "cpu.bin").read_bytes()
+    assert len(got) == len(want) and got == want
+
+
 def test_native_construct_then_genotype_and_errors(tmp_path):
     """construct -> genotype with nothing but this repo's binaries, against the reference's VCF; loud failures."""
     if not os.path.exists(CLI):
