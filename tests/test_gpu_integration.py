@@ -329,6 +329,49 @@ def test_native_construct_options_reproduce_reference_graph(cohort, opts, tmp_pa
     assert len(got) == len(want) and got == want
 
 
+def test_native_construct_soft_masked_reference_with_n_runs(tmp_path):
+    """A reference as assemblies come: soft-masked (lower-case) stretches and runs of N, some of them across variant sites.  Whatever
+    the reference makes of it -- a graph, or an error -- `varigraph-mi construct` makes the same."""
+    if not os.path.exists(CLI):
+        _missing("varigraph-mi not built")
+    if not os.path.exists(REF):
+        _missing("oracle/_ref/varigraph_det")
+    import json
+    from varigraph_amd import synth
+    d = os.path.join(GOLDEN, "cohort_sv")
+    meta = json.load(open(os.path.join(d, "meta.json")))
+    ref = synth.make_reference(meta["ref_len"], seed=meta["ref_seed"]).copy()
+    n = ref.size
+    pos = [int(ln.split("\t")[1]) - 1 for ln in open(os.path.join(d, "in.vcf")) if not ln.startswith("#")]
+    ref[n // 10: n // 5] |= 0x20                                   # soft-masked stretch, variant sites included
+    free = [p for p in range(1000, n - 1000, 997) if all(abs(p - q) > 400 for q in pos)][:6]
+    for p in free:
+        ref[p: p + 73] = ord("N")                                  # N runs away from the sites
+    near = pos[len(pos) // 2]
+    ref[near + 40: near + 45] = ord("n")                           # ... and one inside the k-mer reach of a site
+    fa = tmp_path / "ref.fa"
+    synth.write_fasta(str(fa), "chr1", ref)
+    env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+    base = ["construct", "-r", str(fa), "-v", os.path.join(d, "in.vcf"), "--vcf-ploidy", str(meta["ploidy"])]
+    r1 = _run([CLI] + base + ["--save-graph", "native.bin", "--gpu", "0"], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
+    r2 = _run([REF] + base + ["--save-graph", "cpu.bin"], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
+    assert (r1.returncode == 0) == (r2.returncode == 0), (r1.returncode, r2.returncode, r1.stderr[-800:], r2.stderr[-800:])
+    assert r2.returncode == 0          # (the reference takes this input: seven of the sites lie in the soft-masked stretch)
+    if r2.returncode == 0:
+        assert (tmp_path / "native.bin").read_bytes() == (tmp_path / "cpu.bin").read_bytes()
+        fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
+        outs = {}
+        for name, exe, more in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+            w = tmp_path / name
+            w.mkdir()
+            (w / "samples.cfg").write_text("s " + " ".join(fq) + "\n")
+            r = _run([exe, "genotype", "--load-graph", str(tmp_path / "cpu.bin"), "-s", "samples.cfg", "-t", "4"] + more, cwd=w, capture_output=True,
+                     text=True, env=env, timeout=600)
+            assert r.returncode == 0, (name, r.stderr[-2000:])
+            outs[name] = gzip.open(w / "s.varigraph.vcf.gz", "rb").read()
+        assert outs["native"] == outs["cpu"]
+
+
 def test_native_construct_then_genotype_and_errors(tmp_path):
     """construct -> genotype with nothing but this repo's binaries, against the reference's VCF; loud failures."""
     if not os.path.exists(CLI):
