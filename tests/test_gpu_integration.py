@@ -372,6 +372,84 @@ def test_native_construct_soft_masked_reference_with_n_runs(tmp_path):
         assert outs["native"] == outs["cpu"]
 
 
+def _odd_vcf(path, ref, flavour):
+    """A cohort VCF with what real call sets hold and the fixtures do not; `flavour` picks one kind of line (or "all")."""
+    acgt = b"ACGT"
+    n = ref.size
+    lines = []
+
+    def other(base, k=1):
+        return [bytes([c]) for c in acgt if c != base][:k]
+
+    sites = list(range(3000, n - 3000, 1900))
+    for i, p in enumerate(sites):
+        b = int(ref[p])
+        kind = ["multi_snp", "multi_indel", "missing", "unphased", "extra_format", "overlap", "plain"][i % 7]
+        if flavour != "all" and kind not in (flavour, "plain"):
+            kind = "plain"
+        r_ = bytes([b]).decode()
+        if kind == "multi_snp":
+            a1, a2 = (x.decode() for x in other(b, 2))
+            lines.append((p, r_, f"{a1},{a2}", "GT", ["0|1", "2|1", "0|2", "2|2"]))
+        elif kind == "multi_indel":
+            lines.append((p, r_, f"{r_}T,{r_}TTG", "GT", ["1|2", "0|1", "2|0", "0|0"]))
+        elif kind == "missing":
+            lines.append((p, r_, other(b)[0].decode(), "GT", [".|.", "0|1", ".", "1|1"]))
+        elif kind == "unphased":
+            lines.append((p, r_, other(b)[0].decode(), "GT", ["0/1", "1/1", "0|1", "1/0"]))
+        elif kind == "extra_format":
+            lines.append((p, r_, other(b)[0].decode(), "GT:DP:GQ", ["0|1:12:99", "1|1:7:40", "0|0:9:50", "1|0:3:10"]))
+        elif kind == "overlap":
+            lines.append((p, bytes(ref[p:p + 9]).decode(), r_, "GT", ["0|1", "0|0", "1|0", "0|1"]))       # a deletion ...
+            lines.append((p + 4, bytes([int(ref[p + 4])]).decode(), other(int(ref[p + 4]))[0].decode(), "GT", ["1|0", "0|1", "0|0", "1|1"]))   # ... across a SNP
+        else:
+            lines.append((p, r_, other(b)[0].decode(), "GT", ["0|1", "1|0", "1|1", "0|0"]))
+    with open(path, "w") as f:
+        f.write("##fileformat=VCFv4.2\n##contig=<ID=chr1,length=%d>\n" % n)
+        f.write('##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n')
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS0\tS1\tS2\tS3\n")
+        for i, (p, r_, a, fmt, gts) in enumerate(lines):
+            f.write(f"chr1\t{p + 1}\tx{i}\t{r_}\t{a}\t.\tPASS\t.\t{fmt}\t" + "\t".join(gts) + "\n")
+    return len(lines)
+
+
+@pytest.mark.parametrize("flavour", ["multi_snp", "multi_indel", "missing", "unphased", "extra_format", "overlap", "all"])
+def test_native_construct_call_set_oddities_like_the_reference(flavour, tmp_path):
+    """Multi-allelic sites, missing and unphased genotypes, FORMAT fields behind GT, a deletion across a SNP: whatever the reference
+    makes of such a cohort VCF -- a graph or an error -- `varigraph-mi` makes the same, and from the same graph the same calls."""
+    if not os.path.exists(CLI):
+        _missing("varigraph-mi not built")
+    if not os.path.exists(REF):
+        _missing("oracle/_ref/varigraph_det")
+    import json
+    from varigraph_amd import synth
+    d = os.path.join(GOLDEN, "cohort_snp")
+    meta = json.load(open(os.path.join(d, "meta.json")))
+    ref = synth.make_reference(meta["ref_len"], seed=meta["ref_seed"])
+    fa, vcf = tmp_path / "ref.fa", tmp_path / "odd.vcf"
+    synth.write_fasta(str(fa), "chr1", ref)
+    assert _odd_vcf(str(vcf), ref, flavour) > 20
+    env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+    base = ["construct", "-r", str(fa), "-v", str(vcf)]
+    r1 = _run([CLI] + base + ["--save-graph", "native.bin", "--gpu", "0"], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
+    r2 = _run([REF] + base + ["--save-graph", "cpu.bin"], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
+    assert (r1.returncode == 0) == (r2.returncode == 0), (flavour, r1.returncode, r2.returncode, r1.stderr[-800:], r2.stderr[-800:])
+    if r2.returncode != 0:
+        return
+    assert (tmp_path / "native.bin").read_bytes() == (tmp_path / "cpu.bin").read_bytes(), flavour
+    fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
+    outs = {}
+    for name, exe, more in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+        w = tmp_path / name
+        w.mkdir()
+        (w / "samples.cfg").write_text("s " + " ".join(fq) + "\n")
+        r = _run([exe, "genotype", "--load-graph", str(tmp_path / "cpu.bin"), "-s", "samples.cfg", "-t", "4"] + more, cwd=w, capture_output=True,
+                 text=True, env=env, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        outs[name] = gzip.open(w / "s.varigraph.vcf.gz", "rb").read()
+    assert outs["native"] == outs["cpu"], flavour
+
+
 def test_native_construct_then_genotype_and_errors(tmp_path):
     """construct -> genotype with nothing but this repo's binaries, against the reference's VCF; loud failures."""
     if not os.path.exists(CLI):
