@@ -13,6 +13,7 @@ import gzip
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 from conftest import GOLDEN, ROOT
@@ -230,6 +231,59 @@ def test_native_cli_other_sample_ploidies(ploidy, n, tmp_path):
         assert r.returncode == 0, (name, r.stderr[-2000:])
         outs[name] = gzip.open(w / "s.varigraph.vcf.gz", "rb").read()
     assert outs["native"] == outs["cpu"] and outs["cpu"].count(b"\n") > 20
+
+
+def test_native_cli_ragged_reads_with_n_and_lower_case(tmp_path):
+    """Reads as sequencers deliver them -- trimmed to any length (some shorter than k), with N calls, soft-clipped lower case -- as
+    plain, gzip and block-gzip files of one sample each: every VCF byte for byte the reference's on the same text."""
+    if not os.path.exists(CLI):
+        _missing("varigraph-mi not built")
+    if not os.path.exists(REF):
+        _missing("oracle/_ref/varigraph_det")
+    from varigraph_amd import synth
+    d = os.path.join(GOLDEN, "cohort_snp")
+    graph = tmp_path / "graph.bin"
+    graph.write_bytes(gzip.open(os.path.join(d, "graph.bin.gz"), "rb").read())
+    rng = np.random.default_rng(12)
+    files = []
+    for mate in (1, 2):
+        rec = gzip.open(os.path.join(d, f"reads_{mate}.fq.gz"), "rb").read().split(b"\n")
+        out = []
+        for i in range(0, len(rec) - 3, 4):
+            name, seq, qual = rec[i], bytearray(rec[i + 1]), rec[i + 3]
+            j = i // 4
+            if j % 3 == 0:
+                seq = seq[: int(rng.integers(5, len(seq) + 1))]
+            if j % 5 == 0 and len(seq) > 8:
+                for p_ in rng.integers(0, len(seq), size=2):
+                    seq[int(p_)] = ord("N")
+            if j % 7 == 0:
+                cut = int(rng.integers(0, len(seq)))
+                seq[cut:] = bytes(seq[cut:]).lower()
+            out += [name, bytes(seq), b"+", qual[: len(seq)]]
+        text = b"\n".join(out) + b"\n"
+        plain = tmp_path / f"r_{mate}.fq"
+        plain.write_bytes(text)
+        with gzip.open(tmp_path / f"r_{mate}.fq.gz", "wb", compresslevel=3) as f:
+            f.write(text)
+        synth.bgzf_compress_file(str(plain), str(tmp_path / f"r_{mate}.bgz.gz"), block=30000)
+        files.append({"plain": str(plain), "gzip": str(tmp_path / f"r_{mate}.fq.gz"), "bgzf": str(tmp_path / f"r_{mate}.bgz.gz")})
+    kinds = ("plain", "gzip", "bgzf")
+    (tmp_path / "samples.cfg").write_text("".join(f"{k} {files[0][k]} {files[1][k]}\n" for k in kinds))
+    env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+    r = _run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "6", "--gpu", "0", "--buffer", "8"], cwd=tmp_path,
+             capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cpu = tmp_path / "cpu"
+    cpu.mkdir()
+    (cpu / "samples.cfg").write_text(f"plain {files[0]['gzip']} {files[1]['gzip']}\n")
+    r2 = _run([REF, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4"], cwd=cpu, capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    want = gzip.open(cpu / "plain.varigraph.vcf.gz", "rb").read()
+    assert want.count(b"\n") > 30
+    for k in kinds:
+        got = gzip.open(tmp_path / f"{k}.varigraph.vcf.gz", "rb").read()
+        assert got.replace(b"\t" + k.encode() + b"\n", b"\tplain\n") == want, k
 
 
 def test_native_cli_several_devices_keep_sample_order(tmp_path):
