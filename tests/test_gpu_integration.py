@@ -286,6 +286,30 @@ def test_native_cli_ragged_reads_with_n_and_lower_case(tmp_path):
         assert got.replace(b"\t" + k.encode() + b"\n", b"\tplain\n") == want, k
 
 
+def test_native_cli_sample_without_depth_fails_like_the_reference(tmp_path):
+    """A sample of a dozen reads has no k-mer depth to speak of: the reference gives up ("Failed to retrieve depth information",
+    src/varigraph.cpp:308-362) with a non-zero status, and so does `varigraph-mi` -- with or without `--use-depth`."""
+    if not os.path.exists(CLI):
+        _missing("varigraph-mi not built")
+    if not os.path.exists(REF):
+        _missing("oracle/_ref/varigraph_det")
+    d = os.path.join(GOLDEN, "cohort_snp")
+    graph = tmp_path / "graph.bin"
+    graph.write_bytes(gzip.open(os.path.join(d, "graph.bin.gz"), "rb").read())
+    few = tmp_path / "few.fq"
+    few.write_bytes(b"\n".join(gzip.open(os.path.join(d, "reads_1.fq.gz"), "rb").read().split(b"\n")[:48]) + b"\n")
+    (tmp_path / "samples.cfg").write_text(f"s {few}\n")
+    env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+    for extra in ([], ["--use-depth"]):
+        r1 = _run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "2", "--gpu", "0"] + extra, cwd=tmp_path,
+                  capture_output=True, text=True, env=env, timeout=300)
+        r2 = _run([REF, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "2"] + extra, cwd=tmp_path, capture_output=True,
+                  text=True, timeout=300)
+        assert (r1.returncode == 0) == (r2.returncode == 0), (extra, r1.returncode, r2.returncode, r1.stderr[-600:], r2.stderr[-600:])
+        if r2.returncode == 0:      # (should the reference ever produce a VCF from this, so must we, and the same)
+            assert False, "the reference genotyped a dozen reads: compare the VCFs here"
+
+
 def test_native_cli_several_devices_keep_sample_order(tmp_path):
     """--gpus a,b: samples are counted on several device contexts in parallel (here the same GPU twice) while the
     HMM consumes them strictly in `-s` order -- its per-node state carries over from sample to sample, so the result
