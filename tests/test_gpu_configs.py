@@ -207,6 +207,52 @@ def test_three_chromosomes_in_another_order_than_their_names_identical(tmp_path_
         shutil.rmtree(work, ignore_errors=True)
 
 
+@pytest.mark.parametrize("vcf_ploidy,k,sample_ploidy,n", [(1, 27, 2, 15), (3, 27, 2, 15), (3, 27, 3, 6), (2, 15, 2, 15), (2, 28, 2, 15), (2, 13, 2, 15),
+                                                          (2, 27, 2, 1), (2, 27, 2, 40), (8, 27, 2, 15), (2, 3, 2, 15), (2, 5, 2, 15)])
+def test_other_cohort_ploidies_and_kmer_lengths_identical(vcf_ploidy, k, sample_ploidy, n, tmp_path_factory):
+    """`--vcf-ploidy` 1 (taken as 2: main.cpp:127), 3, 8, k-mer lengths 3 (taken as 5: main.cpp:131) to 28, `-n` 1 and beyond the panel:
+    construct and genotype through both CLIs on a 200 kb genome -- the same graph.bin and the same VCF, or the same refusal."""
+    _need_binaries()
+    work = str(tmp_path_factory.mktemp("misc"))
+    try:
+        ref = synth.make_reference(200_000)
+        n_s = 3 if vcf_ploidy >= 3 else 5
+        variants, gts = synth.make_cohort(ref, 300, n_samples=n_s, ploidy=vcf_ploidy, seed=3, indel_frac=0.1, sv_frac=0.01)
+        fa, vcf = os.path.join(work, "ref.fa"), os.path.join(work, "in.vcf")
+        synth.write_fasta(fa, "chr1", ref)
+        synth.write_vcf(vcf, "chr1", len(ref), variants, gts, n_s, vcf_ploidy)
+        graphs, rcs = {}, {}
+        for name, exe, extra in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+            graphs[name] = os.path.join(work, f"graph_{name}.bin")
+            r = subprocess.run([exe, "construct", "-r", fa, "-v", vcf, "--save-graph", graphs[name], "-t", "8", "-k", str(k), "--vcf-ploidy",
+                                str(vcf_ploidy)] + extra, cwd=work, capture_output=True, text=True, env=ENV, timeout=600)
+            rcs[name] = r.returncode
+        assert (rcs["native"] == 0) == (rcs["cpu"] == 0), rcs
+        if rcs["cpu"] != 0:
+            return
+        assert open(graphs["native"], "rb").read() == open(graphs["cpu"], "rb").read()
+        sp = min(sample_ploidy, vcf_ploidy) if vcf_ploidy < sample_ploidy else sample_ploidy
+        haps = synth.sample_haplotypes(ref, variants, gts, 0, vcf_ploidy)[: max(1, sp)]
+        fq = _write_fastq(os.path.join(work, "s"), haps, 30_000, seed=5)
+        cfg = "s " + " ".join(fq) + "\n"
+        extra = ["--sample-ploidy", str(sample_ploidy), "-n", str(n)]
+        outs, codes = {}, {}
+        for name, exe, more in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+            d = os.path.join(work, name)
+            os.makedirs(d, exist_ok=True)
+            open(os.path.join(d, "samples.cfg"), "w").write(cfg)
+            r = subprocess.run([exe, "genotype", "--load-graph", graphs["cpu"], "-s", "samples.cfg", "-t", "6"] + extra + more, cwd=d,
+                               capture_output=True, text=True, env=ENV, timeout=600)
+            codes[name] = r.returncode
+            if r.returncode == 0:
+                outs[name] = _vcf(d, "s")
+        assert (codes["native"] == 0) == (codes["cpu"] == 0), codes
+        if codes["cpu"] == 0:
+            assert outs["native"] == outs["cpu"]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def test_c3_chr20_scale_12m_pairs_use_depth_vcf_identical(tmp_path_factory):
     _need_binaries()
     work = str(tmp_path_factory.mktemp("c3"))

@@ -1334,6 +1334,11 @@ bool Genotyper::genotype_strings(const Node& n, const std::vector<std::vector<ui
 void Genotyper::window_finish(WindowWork& w, const long double* prob, const uint32_t* winner, const Run& r)
 {
     const uint64_t bl = g_.bitlen;
+    // posterior() tallies the SELECTED haplotypes (w.top); a called haplotype outside the selection -- the reference haplotype,
+    // which every genotype list may hold, when -n picked fewer haplotypes than the panel has -- reads as (0, 0) there and here
+    std::vector<uint8_t> selected(n_hap_, 0);
+    for (uint16_t hap : w.top)
+        if (hap < n_hap_) selected[hap] = 1;
     for (size_t j = 0; j < w.nodes.size(); ++j) {
         if (winner[j] >= w.n_gt) continue;            // no entry with a positive posterior: no call
         PhaseTimer t(g_phase.post);
@@ -1352,7 +1357,7 @@ void Genotyper::window_finish(WindowWork& w, const long double* prob, const uint
                 const uint8_t c = (uint8_t)word;
                 const uint64_t bits = word >> 16;
                 for (size_t q = 0; q < nc; ++q)
-                    if (called[q] < n_hap_ && ((bits >> called[q]) & 1u)) {
+                    if (called[q] < n_hap_ && selected[called[q]] && ((bits >> called[q]) & 1u)) {
                         ++num[q];
                         sum[q] += c;
                     }
@@ -1362,7 +1367,7 @@ void Genotyper::window_finish(WindowWork& w, const long double* prob, const uint
             if (g_.f[key] <= 1 && unique_kmers < UINT8_MAX) unique_kmers++;
             const uint8_t c = r.cov[pos];
             for (size_t q = 0; q < nc; ++q)
-                if (called[q] < n_hap_ && (((uint8_t)g_.bitvec[(size_t)key * bl + (called[q] >> 3)] >> (called[q] & 7)) & 1u)) {
+                if (called[q] < n_hap_ && selected[called[q]] && (((uint8_t)g_.bitvec[(size_t)key * bl + (called[q] >> 3)] >> (called[q] & 7)) & 1u)) {
                     ++num[q];
                     sum[q] += c;
                 }

@@ -490,8 +490,8 @@ int main_construct(int argc, char** argv)
         case 'r': c.reference = optarg; break;
         case 'v': c.vcf = optarg; break;
         case 1: c.out = optarg; break;
-        case 2: vcf_ploidy = opt_int("--vcf-ploidy", optarg); break;
-        case 'k': kmer = opt_int("-k", optarg); break;
+        case 2: vcf_ploidy = std::max(opt_int("--vcf-ploidy", optarg), 2); break;   // main.cpp:127: max(stoi, 2)
+        case 'k': kmer = std::max(opt_int("-k", optarg), 5); break;                  // main.cpp:131: max(stoi, 5)
         case 3: c.fast = true; break;
         case 4: c.use_unique_kmers = true; break;
         case 7: gpu = opt_int("--gpu", optarg); break;
