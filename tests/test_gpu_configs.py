@@ -253,6 +253,67 @@ def test_other_cohort_ploidies_and_kmer_lengths_identical(vcf_ploidy, k, sample_
         shutil.rmtree(work, ignore_errors=True)
 
 
+def _option_sets():
+    rng = np.random.default_rng(2024)
+    sets = []
+    for i in range(14):
+        o = []
+        o += ["-g", ["het", "hom"][int(rng.integers(0, 2))]]
+        o += ["-m", ["rec", "fre"][int(rng.integers(0, 2))]]
+        o += ["--sample-ploidy", str([2, 2, 3, 4][int(rng.integers(0, 4))])]
+        o += ["-n", str([2, 3, 5, 8, 12, 15, 30][int(rng.integers(0, 7))])]
+        if rng.random() < 0.3:
+            o += ["--sv"]
+        if rng.random() < 0.4:
+            o += ["--use-depth"]
+        if rng.random() < 0.3:
+            o += ["--min-support", str([10, 30, 60][int(rng.integers(0, 3))])]
+        if rng.random() < 0.5:
+            o += ["--granularity", str([0.005, 0.05, 0.3][int(rng.integers(0, 3))])]
+        sets.append(o)
+    return sets
+
+
+@pytest.fixture(scope="module")
+def option_cohort(tmp_path_factory):
+    """One 300 kb cohort (vcf ploidy 2, seven samples = 15 haplotypes; SNPs, indels, long insertions), its graph by the reference's
+    construct, 40 k read pairs of sample 0."""
+    _need_binaries()
+    work = str(tmp_path_factory.mktemp("opts"))
+    ref = synth.make_reference(300_000)
+    variants, gts = synth.make_cohort(ref, 500, n_samples=7, ploidy=2, seed=9, indel_frac=0.15, sv_frac=0.02)
+    fa, vcf = os.path.join(work, "ref.fa"), os.path.join(work, "in.vcf")
+    synth.write_fasta(fa, "chr1", ref)
+    synth.write_vcf(vcf, "chr1", len(ref), variants, gts, 7, 2)
+    graph = os.path.join(work, "graph.bin")
+    r = subprocess.run([REF, "construct", "-r", fa, "-v", vcf, "--save-graph", graph, "-t", "8"], cwd=work, capture_output=True, text=True, env=ENV, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    fq = _write_fastq(os.path.join(work, "s"), synth.sample_haplotypes(ref, variants, gts, 0, 2), 40_000, seed=5)
+    yield work, graph, fq
+    shutil.rmtree(work, ignore_errors=True)
+
+
+@pytest.mark.parametrize("opts", _option_sets(), ids=lambda o: "_".join(x.strip("-") for x in o))
+def test_genotype_option_combinations_identical(opts, option_cohort):
+    """Fourteen drawn combinations of -g / -m / --sample-ploidy / -n (below, at and beyond the panel's 15 haplotypes) / --sv /
+    --use-depth / --min-support / --granularity: the reference's VCF byte for byte, or its refusal."""
+    work, graph, fq = option_cohort
+    tag = "_".join(x.strip("-") for x in opts)
+    outs, codes = {}, {}
+    for name, exe, more in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+        d = os.path.join(work, name + "_" + tag)
+        os.makedirs(d, exist_ok=True)
+        open(os.path.join(d, "samples.cfg"), "w").write("s " + " ".join(fq) + "\n")
+        r = subprocess.run([exe, "genotype", "--load-graph", graph, "-s", "samples.cfg", "-t", "6"] + opts + more, cwd=d, capture_output=True,
+                           text=True, env=ENV, timeout=900)
+        codes[name] = r.returncode
+        if r.returncode == 0:
+            outs[name] = _vcf(d, "s")
+    assert (codes["native"] == 0) == (codes["cpu"] == 0), (opts, codes)
+    if codes["cpu"] == 0:
+        assert outs["native"] == outs["cpu"], opts
+
+
 def test_c3_chr20_scale_12m_pairs_use_depth_vcf_identical(tmp_path_factory):
     _need_binaries()
     work = str(tmp_path_factory.mktemp("c3"))
