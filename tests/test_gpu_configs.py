@@ -314,6 +314,40 @@ def test_genotype_option_combinations_identical(opts, option_cohort):
         assert outs["native"] == outs["cpu"], opts
 
 
+@pytest.mark.parametrize("extra", [[], ["-n", "60"], ["-n", "4", "--use-depth"]], ids=["n15", "n60", "n4-use-depth"])
+def test_wide_panel_of_53_haplotypes_identical(extra, tmp_path_factory):
+    """A cohort of 26 diploid samples: 53 haplotypes, seven bytes of haplotype bits per k-mer -- past the six a Genotyper packs into
+    its per-entry word, so the lists are read through the key arrays.  Construct and genotype through both CLIs."""
+    _need_binaries()
+    work = str(tmp_path_factory.mktemp("wide"))
+    try:
+        ref = synth.make_reference(150_000)
+        variants, gts = synth.make_cohort(ref, 250, n_samples=26, ploidy=2, seed=4, indel_frac=0.1, sv_frac=0.01)
+        fa, vcf = os.path.join(work, "ref.fa"), os.path.join(work, "in.vcf")
+        synth.write_fasta(fa, "chr1", ref)
+        synth.write_vcf(vcf, "chr1", len(ref), variants, gts, 26, 2)
+        graphs = {}
+        for name, exe, more in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+            graphs[name] = os.path.join(work, f"graph_{name}.bin")
+            r = subprocess.run([exe, "construct", "-r", fa, "-v", vcf, "--save-graph", graphs[name], "-t", "8"] + more, cwd=work, capture_output=True,
+                               text=True, env=ENV, timeout=600)
+            assert r.returncode == 0, (name, r.stderr[-2000:])
+        assert open(graphs["native"], "rb").read() == open(graphs["cpu"], "rb").read()
+        fq = _write_fastq(os.path.join(work, "s"), synth.sample_haplotypes(ref, variants, gts, 3, 2), 25_000, seed=8)
+        outs = {}
+        for name, exe, more in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+            d = os.path.join(work, name)
+            os.makedirs(d, exist_ok=True)
+            open(os.path.join(d, "samples.cfg"), "w").write("s " + " ".join(fq) + "\n")
+            r = subprocess.run([exe, "genotype", "--load-graph", graphs["cpu"], "-s", "samples.cfg", "-t", "6"] + extra + more, cwd=d, capture_output=True,
+                               text=True, env=ENV, timeout=1500)
+            assert r.returncode == 0, (name, r.stderr[-2000:])
+            outs[name] = _vcf(d, "s")
+        assert outs["native"] == outs["cpu"] and outs["cpu"].count(b"\n") > 100
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def test_c3_chr20_scale_12m_pairs_use_depth_vcf_identical(tmp_path_factory):
     _need_binaries()
     work = str(tmp_path_factory.mktemp("c3"))
