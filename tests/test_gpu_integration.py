@@ -235,7 +235,7 @@ def test_native_cli_other_sample_ploidies(ploidy, n, tmp_path):
 
 def test_native_cli_ragged_reads_with_n_and_lower_case(tmp_path):
     """Reads as sequencers deliver them -- trimmed to any length (some shorter than k), with N calls, soft-clipped lower case -- as
-    plain, gzip and block-gzip files of one sample each: every VCF byte for byte the reference's on the same text."""
+    plain, gzip and block-gzip FASTQ and as wrapped FASTA, one sample each: every VCF byte for byte the reference's on the same text."""
     if not os.path.exists(CLI):
         _missing("varigraph-mi not built")
     if not os.path.exists(REF):
@@ -267,8 +267,11 @@ def test_native_cli_ragged_reads_with_n_and_lower_case(tmp_path):
         with gzip.open(tmp_path / f"r_{mate}.fq.gz", "wb", compresslevel=3) as f:
             f.write(text)
         synth.bgzf_compress_file(str(plain), str(tmp_path / f"r_{mate}.bgz.gz"), block=30000)
-        files.append({"plain": str(plain), "gzip": str(tmp_path / f"r_{mate}.fq.gz"), "bgzf": str(tmp_path / f"r_{mate}.bgz.gz")})
-    kinds = ("plain", "gzip", "bgzf")
+        fasta = tmp_path / f"r_{mate}.fa"          # the same reads as FASTA records, sequences wrapped at 60 (kseq reads both)
+        fasta.write_bytes(b"".join(b">" + out[q][1:] + b"\n" + b"\n".join(out[q + 1][w:w + 60] for w in range(0, max(len(out[q + 1]), 1), 60)) + b"\n"
+                                   for q in range(0, len(out), 4)))
+        files.append({"plain": str(plain), "gzip": str(tmp_path / f"r_{mate}.fq.gz"), "bgzf": str(tmp_path / f"r_{mate}.bgz.gz"), "fasta": str(fasta)})
+    kinds = ("plain", "gzip", "bgzf", "fasta")
     (tmp_path / "samples.cfg").write_text("".join(f"{k} {files[0][k]} {files[1][k]}\n" for k in kinds))
     env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
     r = _run([CLI, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "6", "--gpu", "0", "--buffer", "8"], cwd=tmp_path,
