@@ -348,6 +348,72 @@ def test_wide_panel_of_53_haplotypes_identical(extra, tmp_path_factory):
         shutil.rmtree(work, ignore_errors=True)
 
 
+@pytest.mark.parametrize("case", ["chromosome_without_variants", "variants_on_an_unknown_chromosome", "unsorted_positions", "duplicate_position"])
+def test_construct_input_mismatches_like_the_reference(case, tmp_path_factory):
+    """A chromosome of the FASTA that the VCF never mentions, VCF lines on a chromosome the FASTA lacks, positions out of order, a
+    position twice: whatever the reference does with them -- a graph, or an exit status -- `varigraph-mi construct` does the same, and
+    genotyping from that graph gives the same VCF."""
+    _need_binaries()
+    work = str(tmp_path_factory.mktemp("mism"))
+    try:
+        rng = np.random.default_rng(31)
+        seqs = {c: synth._ACGT[rng.integers(0, 4, size=n)] for c, n in (("chrA", 120_000), ("chrB", 80_000), ("chrC", 100_000))}
+        lines = []
+        for c in ("chrA", "chrC") if case == "chromosome_without_variants" else ("chrA", "chrB", "chrC"):
+            pos = np.sort(rng.choice(np.arange(500, seqs[c].size - 500), size=60, replace=False))
+            for p_ in pos:
+                b = int(seqs[c][p_])
+                alt = bytes([x for x in b"ACGT" if x != b][:1]).decode()
+                lines.append([c, int(p_) + 1, chr(b), alt, ["0|1", "1|0", "1|1"]])
+        if case == "variants_on_an_unknown_chromosome":
+            lines += [["chrZ", 1000 + 50 * i, "A", "C", ["0|1", "1|1", "0|0"]] for i in range(5)]
+        if case == "unsorted_positions":
+            lines[3], lines[9] = lines[9], lines[3]
+        if case == "duplicate_position":
+            dup = list(lines[5])
+            dup[3] = bytes([x for x in b"ACGT" if chr(x) not in (lines[5][2], lines[5][3])][:1]).decode()
+            lines.insert(6, dup)
+        fa, vcf = os.path.join(work, "ref.fa"), os.path.join(work, "in.vcf")
+        with open(fa, "wb") as f:
+            for c, sq in seqs.items():
+                f.write(b">" + c.encode() + b"\n")
+                b2 = sq.tobytes()
+                for i in range(0, len(b2), 70):
+                    f.write(b2[i:i + 70] + b"\n")
+        with open(vcf, "w") as f:
+            f.write("##fileformat=VCFv4.2\n" + "".join(f"##contig=<ID={c},length={sq.size}>\n" for c, sq in seqs.items()))
+            f.write('##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS0\tS1\tS2\n')
+            for i, (c, p_, r_, a, g) in enumerate(lines):
+                f.write(f"{c}\t{p_}\tv{i}\t{r_}\t{a}\t.\tPASS\t.\tGT\t" + "\t".join(g) + "\n")
+        rcs, graphs = {}, {}
+        for name, exe, more in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+            graphs[name] = os.path.join(work, f"graph_{name}.bin")
+            r = subprocess.run([exe, "construct", "-r", fa, "-v", vcf, "--save-graph", graphs[name], "-t", "6"] + more, cwd=work, capture_output=True,
+                               text=True, env=ENV, timeout=600)
+            rcs[name] = r.returncode
+        assert (rcs["native"] == 0) == (rcs["cpu"] == 0), (case, rcs)
+        if rcs["cpu"] != 0:
+            return
+        assert open(graphs["native"], "rb").read() == open(graphs["cpu"], "rb").read(), case
+        hap = np.concatenate([np.concatenate([sq, np.frombuffer(b"N" * 200, dtype=np.uint8)]) for sq in seqs.values()])
+        fq = _write_fastq(os.path.join(work, "s"), [hap, hap], 40_000, seed=2)
+        outs, codes = {}, {}
+        for name, exe, more in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+            d = os.path.join(work, name)
+            os.makedirs(d, exist_ok=True)
+            open(os.path.join(d, "samples.cfg"), "w").write("s " + " ".join(fq) + "\n")
+            r = subprocess.run([exe, "genotype", "--load-graph", graphs["cpu"], "-s", "samples.cfg", "-t", "6"] + more, cwd=d, capture_output=True,
+                               text=True, env=ENV, timeout=900)
+            codes[name] = r.returncode
+            if r.returncode == 0:
+                outs[name] = _vcf(d, "s")
+        assert (codes["native"] == 0) == (codes["cpu"] == 0), (case, codes)
+        if codes["cpu"] == 0:
+            assert outs["native"] == outs["cpu"], case
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def test_c3_chr20_scale_12m_pairs_use_depth_vcf_identical(tmp_path_factory):
     _need_binaries()
     work = str(tmp_path_factory.mktemp("c3"))
