@@ -414,6 +414,42 @@ def test_construct_input_mismatches_like_the_reference(case, tmp_path_factory):
         shutil.rmtree(work, ignore_errors=True)
 
 
+@pytest.mark.parametrize("extra", [["-n", "5"], ["-n", "3", "--sample-ploidy", "3"], ["-n", "9", "--use-depth", "-g", "hom"]], ids=["n5", "n3-triploid", "n9-hom"])
+def test_three_different_samples_in_one_run_with_selection_identical(extra, tmp_path_factory):
+    """With `-n` below the panel's size the forward pass prunes a node's k-mer list to the selected haplotypes' k-mers and the pruned
+    list STAYS for the next sample (src/genotype.cpp:815-818): the samples of a run are not independent, their order matters.  Three
+    samples with reads of three different individuals in one `-s` list, against the reference's run of the same list."""
+    _need_binaries()
+    work = str(tmp_path_factory.mktemp("sel3"))
+    try:
+        ref = synth.make_reference(250_000)
+        variants, gts = synth.make_cohort(ref, 400, n_samples=7, ploidy=2, seed=6, indel_frac=0.1, sv_frac=0.01)
+        fa, vcf = os.path.join(work, "ref.fa"), os.path.join(work, "in.vcf")
+        synth.write_fasta(fa, "chr1", ref)
+        synth.write_vcf(vcf, "chr1", len(ref), variants, gts, 7, 2)
+        graph = os.path.join(work, "graph.bin")
+        r = subprocess.run([REF, "construct", "-r", fa, "-v", vcf, "--save-graph", graph, "-t", "8"], cwd=work, capture_output=True, text=True, env=ENV, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        cfg = ""
+        for i, who in enumerate((0, 3, 5)):
+            fq = _write_fastq(os.path.join(work, f"s{i}"), synth.sample_haplotypes(ref, variants, gts, who, 2), 30_000, seed=40 + i)
+            cfg += f"ind{i} " + " ".join(fq) + "\n"
+        outs = {}
+        for name, exe, more in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+            d = os.path.join(work, name)
+            os.makedirs(d, exist_ok=True)
+            open(os.path.join(d, "samples.cfg"), "w").write(cfg)
+            r = subprocess.run([exe, "genotype", "--load-graph", graph, "-s", "samples.cfg", "-t", "6"] + extra + more, cwd=d, capture_output=True,
+                               text=True, env=ENV, timeout=900)
+            assert r.returncode == 0, (name, r.stderr[-2000:])
+            outs[name] = [_vcf(d, f"ind{i}") for i in range(3)]
+        for i in range(3):
+            assert outs["native"][i] == outs["cpu"][i], (extra, i)
+        assert outs["cpu"][0] != outs["cpu"][1]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def test_c3_chr20_scale_12m_pairs_use_depth_vcf_identical(tmp_path_factory):
     _need_binaries()
     work = str(tmp_path_factory.mktemp("c3"))
