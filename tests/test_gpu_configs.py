@@ -450,6 +450,39 @@ def test_three_different_samples_in_one_run_with_selection_identical(extra, tmp_
         shutil.rmtree(work, ignore_errors=True)
 
 
+@pytest.mark.parametrize("extra", [[], ["--use-depth"]], ids=["default", "use-depth"])
+def test_saturated_sample_identical(extra, tmp_path_factory):
+    """3 000 x coverage: nearly every counter sits at the 255 clamp (src/fastq_kmer.cpp:128-139), the depth histogram is one spike
+    at its last bin, the emission scores are what a Poisson with a mean in the hundreds gives for 255.  Same VCF as the reference."""
+    _need_binaries()
+    work = str(tmp_path_factory.mktemp("sat"))
+    try:
+        ref = synth.make_reference(100_000)
+        variants, gts = synth.make_cohort(ref, 150, n_samples=5, ploidy=2, seed=8, indel_frac=0.1, sv_frac=0.01)
+        fa, vcf = os.path.join(work, "ref.fa"), os.path.join(work, "in.vcf")
+        synth.write_fasta(fa, "chr1", ref)
+        synth.write_vcf(vcf, "chr1", len(ref), variants, gts, 5, 2)
+        graph = os.path.join(work, "graph.bin")
+        r = subprocess.run([REF, "construct", "-r", fa, "-v", vcf, "--save-graph", graph, "-t", "8"], cwd=work, capture_output=True, text=True, env=ENV, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        fq = _write_fastq(os.path.join(work, "s"), synth.sample_haplotypes(ref, variants, gts, 1, 2), 1_000_000, seed=3)
+        outs, codes = {}, {}
+        for name, exe, more in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+            d = os.path.join(work, name)
+            os.makedirs(d, exist_ok=True)
+            open(os.path.join(d, "samples.cfg"), "w").write("s " + " ".join(fq) + "\n")
+            r = subprocess.run([exe, "genotype", "--load-graph", graph, "-s", "samples.cfg", "-t", "8"] + extra + more, cwd=d, capture_output=True,
+                               text=True, env=ENV, timeout=900)
+            codes[name] = r.returncode
+            if r.returncode == 0:
+                outs[name] = _vcf(d, "s")
+        assert (codes["native"] == 0) == (codes["cpu"] == 0), codes
+        if codes["cpu"] == 0:
+            assert outs["native"] == outs["cpu"]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def test_c3_chr20_scale_12m_pairs_use_depth_vcf_identical(tmp_path_factory):
     _need_binaries()
     work = str(tmp_path_factory.mktemp("c3"))
