@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""One case of tests/test_gpu_configs.py::test_other_cohort_ploidies_and_kmer_lengths_identical by hand, with the lines that differ:
+  diff_cli_case.py <vcf_ploidy> <k> <sample_ploidy> <n>
+runs the reference, `varigraph-mi genotype` and `varigraph-mi` with the HMM on the host (VGH_HMM_DEVICE=0) on the same files and prints
+the first VCF lines that differ (how the round found the tally of an unselected called haplotype)."""
 import os, sys, subprocess, gzip, shutil, tempfile
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
 import importlib.util
