@@ -483,6 +483,61 @@ def test_saturated_sample_identical(extra, tmp_path_factory):
         shutil.rmtree(work, ignore_errors=True)
 
 
+@pytest.mark.parametrize("copts", [[], ["--use-unique-kmers"], ["--fast"]], ids=["default", "unique-kmers", "fast"])
+def test_repeat_rich_genome_identical(copts, tmp_path_factory):
+    """A genome as genomes are: a third of it diverged copies of a few elements (300 copies of a 300-bp element at 3 % divergence,
+    40 copies of a 2-kb element at 1 %, a 5-kb segmental duplication, a microsatellite), variants inside and outside them.  The
+    reference Bloom filter's counts (k-mer multiplicities up to the clamp), the multiplicity field of graph.bin, `--use-unique-kmers`,
+    the 128 rarest k-mers of a long allele, the HMM over multi-copy k-mers: graph.bin and VCF byte for byte."""
+    _need_binaries()
+    work = str(tmp_path_factory.mktemp("rep"))
+    try:
+        rng = np.random.default_rng(77)
+        rnd = lambda n: synth._ACGT[rng.integers(0, 4, size=n)]
+
+        def diverged(unit, rate):
+            u = unit.copy()
+            m = rng.random(u.size) < rate
+            u[m] = synth._ACGT[(synth._CODE[u[m]] + rng.integers(1, 4, size=int(m.sum()))) % 4]
+            return u
+
+        alu, line1, segdup = rnd(300), rnd(2000), rnd(5000)
+        parts = []
+        for i in range(300):
+            parts += [rnd(int(rng.integers(200, 900))), diverged(alu, 0.03)]
+            if i % 8 == 0:
+                parts += [rnd(300), diverged(line1, 0.01)]
+            if i in (50, 200):
+                parts += [rnd(500), segdup]
+            if i == 120:
+                parts += [np.frombuffer(b"CAG" * 60, dtype=np.uint8)]
+        ref = np.concatenate(parts)
+        variants, gts = synth.make_cohort(ref, ref.size // 600, n_samples=5, ploidy=2, seed=13, indel_frac=0.1, sv_frac=0.01)
+        fa, vcf = os.path.join(work, "ref.fa"), os.path.join(work, "in.vcf")
+        synth.write_fasta(fa, "chr1", ref)
+        synth.write_vcf(vcf, "chr1", len(ref), variants, gts, 5, 2)
+        graphs = {}
+        for name, exe, more in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+            graphs[name] = os.path.join(work, f"graph_{name}.bin")
+            r = subprocess.run([exe, "construct", "-r", fa, "-v", vcf, "--save-graph", graphs[name], "-t", "8"] + copts + more, cwd=work,
+                               capture_output=True, text=True, env=ENV, timeout=600)
+            assert r.returncode == 0, (name, r.stderr[-2000:])
+        assert open(graphs["native"], "rb").read() == open(graphs["cpu"], "rb").read()
+        fq = _write_fastq(os.path.join(work, "s"), synth.sample_haplotypes(ref, variants, gts, 2, 2), 60_000, seed=21)
+        outs = {}
+        for name, exe, more in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+            d = os.path.join(work, name)
+            os.makedirs(d, exist_ok=True)
+            open(os.path.join(d, "samples.cfg"), "w").write("s " + " ".join(fq) + "\n")
+            r = subprocess.run([exe, "genotype", "--load-graph", graphs["cpu"], "-s", "samples.cfg", "-t", "6", "--use-depth"] + more, cwd=d,
+                               capture_output=True, text=True, env=ENV, timeout=900)
+            assert r.returncode == 0, (name, r.stderr[-2000:])
+            outs[name] = _vcf(d, "s")
+        assert outs["native"] == outs["cpu"] and outs["cpu"].count(b"\n") > 200
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def test_c3_chr20_scale_12m_pairs_use_depth_vcf_identical(tmp_path_factory):
     _need_binaries()
     work = str(tmp_path_factory.mktemp("c3"))
