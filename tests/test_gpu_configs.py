@@ -314,7 +314,7 @@ def test_genotype_option_combinations_identical(opts, option_cohort):
         assert outs["native"] == outs["cpu"], opts
 
 
-@pytest.mark.parametrize("extra", [[], ["-n", "60"], ["-n", "4", "--use-depth"]], ids=["n15", "n60", "n4-use-depth"])
+@pytest.mark.parametrize("extra", [[], ["-n", "28"], ["-n", "4", "--use-depth"]], ids=["n15", "n28", "n4-use-depth"])
 def test_wide_panel_of_53_haplotypes_identical(extra, tmp_path_factory):
     """A cohort of 26 diploid samples: 53 haplotypes, seven bytes of haplotype bits per k-mer -- past the six a Genotyper packs into
     its per-entry word, so the lists are read through the key arrays.  Construct and genotype through both CLIs."""
