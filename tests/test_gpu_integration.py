@@ -531,6 +531,45 @@ def test_native_construct_call_set_oddities_like_the_reference(flavour, tmp_path
     assert outs["native"] == outs["cpu"], flavour
 
 
+@pytest.mark.parametrize("what", ["fasta_crlf", "vcf_crlf", "fasta_lower_case_names_and_description", "vcf_gz_fasta_gz", "fasta_no_final_newline"])
+def test_native_construct_file_format_corners_like_the_reference(what, tmp_path):
+    """Files as other tools leave them: CRLF line ends in the FASTA or the VCF, a description behind the sequence name, gzip (not block
+    gzip) inputs, no newline at the end of the FASTA.  The same graph.bin as the reference's construct, or the same refusal."""
+    if not os.path.exists(CLI):
+        _missing("varigraph-mi not built")
+    if not os.path.exists(REF):
+        _missing("oracle/_ref/varigraph_det")
+    import json
+    from varigraph_amd import synth
+    d = os.path.join(GOLDEN, "cohort_sv")
+    meta = json.load(open(os.path.join(d, "meta.json")))
+    ref = synth.make_reference(meta["ref_len"], seed=meta["ref_seed"])
+    fa, vcf = tmp_path / "ref.fa", tmp_path / "in.vcf"
+    synth.write_fasta(str(fa), "chr1", ref)
+    vcf.write_bytes(open(os.path.join(d, "in.vcf"), "rb").read())
+    fa_arg, vcf_arg = str(fa), str(vcf)
+    if what == "fasta_crlf":
+        fa.write_bytes(fa.read_bytes().replace(b"\n", b"\r\n"))
+    elif what == "vcf_crlf":
+        vcf.write_bytes(vcf.read_bytes().replace(b"\n", b"\r\n"))
+    elif what == "fasta_lower_case_names_and_description":
+        fa.write_bytes(fa.read_bytes().replace(b">chr1\n", b">chr1 assembled by somebody, length=%d\n" % ref.size))
+    elif what == "vcf_gz_fasta_gz":
+        for p_ in (fa, vcf):
+            with gzip.open(str(p_) + ".gz", "wb") as f:
+                f.write(p_.read_bytes())
+        fa_arg, vcf_arg = str(fa) + ".gz", str(vcf) + ".gz"
+    elif what == "fasta_no_final_newline":
+        fa.write_bytes(fa.read_bytes().rstrip(b"\n"))
+    env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+    base = ["construct", "-r", fa_arg, "-v", vcf_arg, "--vcf-ploidy", str(meta["ploidy"])]
+    r1 = _run([CLI] + base + ["--save-graph", "native.bin", "--gpu", "0"], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
+    r2 = _run([REF] + base + ["--save-graph", "cpu.bin"], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
+    assert (r1.returncode == 0) == (r2.returncode == 0), (what, r1.returncode, r2.returncode, r1.stderr[-800:], r2.stderr[-800:])
+    if r2.returncode == 0:
+        assert (tmp_path / "native.bin").read_bytes() == (tmp_path / "cpu.bin").read_bytes(), what
+
+
 def test_native_construct_then_genotype_and_errors(tmp_path):
     """construct -> genotype with nothing but this repo's binaries, against the reference's VCF; loud failures."""
     if not os.path.exists(CLI):
