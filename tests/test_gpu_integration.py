@@ -568,6 +568,19 @@ def test_native_construct_file_format_corners_like_the_reference(what, tmp_path)
     assert (r1.returncode == 0) == (r2.returncode == 0), (what, r1.returncode, r2.returncode, r1.stderr[-800:], r2.stderr[-800:])
     if r2.returncode == 0:
         assert (tmp_path / "native.bin").read_bytes() == (tmp_path / "cpu.bin").read_bytes(), what
+    if r2.returncode == 0 and what == "vcf_crlf":
+        # the reference reads no variant out of a CRLF VCF and writes a graph of 53 bytes: genotyping from it must end the same way
+        fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
+        res = {}
+        for name, exe, more in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+            w = tmp_path / name
+            w.mkdir()
+            (w / "samples.cfg").write_text("s " + " ".join(fq) + "\n")
+            r = _run([exe, "genotype", "--load-graph", str(tmp_path / "cpu.bin"), "-s", "samples.cfg", "-t", "2"] + more, cwd=w, capture_output=True,
+                     text=True, env=env, timeout=300)
+            out = w / "s.varigraph.vcf.gz"
+            res[name] = (r.returncode == 0, gzip.open(out, "rb").read() if r.returncode == 0 and out.exists() else None)
+        assert res["native"] == res["cpu"], (res["native"][0], res["cpu"][0])
 
 
 def test_native_construct_then_genotype_and_errors(tmp_path):
