@@ -313,6 +313,31 @@ def test_native_cli_sample_without_depth_fails_like_the_reference(tmp_path):
             assert False, "the reference genotyped a dozen reads: compare the VCFs here"
 
 
+@pytest.mark.parametrize("extra", [["--sv"], ["--sv", "--use-depth", "-n", "7"], ["--sv", "--granularity", "0.003"]], ids=["sv", "sv-use-depth-n7", "sv-small-windows"])
+def test_native_cli_sv_only_over_a_graph_without_long_alleles(extra, tmp_path):
+    """`--sv` over a cohort of SNPs: no node is the HMM's business, the reference writes the header and nothing else -- and so must
+    `varigraph-mi` (a part of the windows without rows used to end the run with a device error; found by tools/fuzz_cli_parity.py)."""
+    if not os.path.exists(CLI):
+        _missing("varigraph-mi not built")
+    if not os.path.exists(REF):
+        _missing("oracle/_ref/varigraph_det")
+    d = os.path.join(GOLDEN, "cohort_snp")
+    graph = tmp_path / "graph.bin"
+    graph.write_bytes(gzip.open(os.path.join(d, "graph.bin.gz"), "rb").read())
+    fq = [os.path.join(d, f"reads_{i}.fq.gz") for i in (1, 2)]
+    env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022")
+    outs = {}
+    for name, exe, more in (("native", CLI, ["--gpu", "0"]), ("cpu", REF, [])):
+        w = tmp_path / name
+        w.mkdir()
+        (w / "samples.cfg").write_text("a " + " ".join(fq) + "\nb " + " ".join(fq) + "\n")
+        r = _run([exe, "genotype", "--load-graph", str(graph), "-s", "samples.cfg", "-t", "4"] + extra + more, cwd=w, capture_output=True, text=True,
+                 env=env, timeout=300)
+        assert r.returncode == 0, (name, r.stderr[-1500:])
+        outs[name] = [gzip.open(w / f"{n}.varigraph.vcf.gz", "rb").read() for n in ("a", "b")]
+    assert outs["native"] == outs["cpu"]
+
+
 def test_native_cli_several_devices_keep_sample_order(tmp_path):
     """--gpus a,b: samples are counted on several device contexts in parallel (here the same GPU twice) while the
     HMM consumes them strictly in `-s` order -- its per-node state carries over from sample to sample, so the result

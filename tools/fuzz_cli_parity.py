@@ -62,6 +62,8 @@ def case(seed):
             except subprocess.TimeoutExpired:
                 return f"TIMEOUT of {name}", desc
             codes[name] = r.returncode
+            if r.returncode != 0:
+                codes[name + "_stderr"] = r.stderr.strip().split("\n")[-1][:300]
             if r.returncode == 0:
                 outs[name] = [gzip.open(os.path.join(d, f"ind{i}.varigraph.vcf.gz"), "rb").read() for i in range(n_reads_samples)]
         if (codes["native"] == 0) != (codes["cpu"] == 0): return "GENOTYPE STATUS DIFFERS " + str(codes), desc

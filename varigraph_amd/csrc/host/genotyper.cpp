@@ -1854,6 +1854,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                         pc.have.assign(n_rows ? n_rows : 1, 0);
                         pc.key = cache_key;
                     }
+                    if (n_rows == 0) return;      // no node of this part is the HMM's business (--sv over a part without long alleles): no calls, no lines
                     std::vector<uint32_t> n_kept(n_rows ? n_rows : 1);
                     std::vector<uint8_t> flags(n_rows ? n_rows : 1);
                     struct PartHandle {

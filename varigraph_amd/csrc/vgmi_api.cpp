@@ -2084,7 +2084,8 @@ int vgmi_hmm_emissions(vgmi_ctx* c, uint32_t n_gt, uint32_t n_used, const uint8_
                        const uint64_t* entry_begin, const uint32_t* entry_count, const uint16_t* gt0, uint32_t* n_kept_out,
                        uint8_t* flags_out, vgmi_hmm_part** out)
 {
-    if (!c || !used || !pos_a || !pos_b || !tables || !entry_begin || !entry_count || !gt0 || !n_kept_out || !flags_out || !out) return VGMI_E_INVALID;
+    if (!c || !used || !pos_a || !pos_b || !tables || !out) return VGMI_E_INVALID;
+    if (n_rows && (!entry_begin || !entry_count || !gt0 || !n_kept_out || !flags_out)) return fail(c, VGMI_E_INVALID, "HMM emissions: rows without their arrays");
     if (n_gt < 1 || n_gt > 128 || n_used < 1 || n_used > 16 || bit_len < 1 || bit_len > 6) return fail(c, VGMI_E_INVALID, "HMM emissions: 1..128 pairs over 1..16 haplotypes, 1..6 bytes of haplotype bits");
     if (!c->d_hmm_entries) return fail(c, VGMI_E_STATE, "HMM emissions: upload the entries first");
     for (uint64_t r = 0; r < n_rows; ++r)
