@@ -164,7 +164,7 @@ def test_c1_at_its_stated_size_construct_and_genotype_identical(tmp_path_factory
         fq = _write_fastq(os.path.join(work, "s"), haps, 100_000, seed=1000)
         cfg = "sample0 " + " ".join(fq) + "\n"
         t_nat, log = _native_genotype(os.path.join(work, "native"), graphs["native"], cfg, ["--gpu", "0"], threads=10)
-        t_ref = _reference_genotype(os.path.join(work, "cpu"), graphs["cpu"], cfg, [], threads=10)
+        t_ref = _reference_genotype(os.path.join(work, "cpu"), graphs["cpu"], cfg, [], threads=10, timeout=120)
         got, want = _vcf(os.path.join(work, "native"), "sample0"), _vcf(os.path.join(work, "cpu"), "sample0")
         assert got == want and got.count(b"\n") > 500
         assert "0.03 Gb sequenced" in log                       # 100 k pairs x 2 x 150 bp
@@ -214,7 +214,7 @@ def test_three_chromosomes_in_another_order_than_their_names_identical(tmp_path_
         fq = _write_fastq(os.path.join(work, "s"), haps, 100_000, seed=77)      # reads across the N spacers carry N: skipped k-mers
         cfg = "".join(f"{n} " + " ".join(fq) + "\n" for n in ("a", "b", "c"))
         t_nat, log = _native_genotype(os.path.join(work, "native"), graphs["native"], cfg, ["--gpu", "0"], threads=10)
-        _reference_genotype(os.path.join(work, "cpu"), graphs["cpu"], "a " + " ".join(fq) + "\n", [], threads=10)
+        _reference_genotype(os.path.join(work, "cpu"), graphs["cpu"], "a " + " ".join(fq) + "\n", [], threads=10, timeout=120)
         want = _vcf(os.path.join(work, "cpu"), "a")
         assert want.count(b"\n") > 1000 and all(want.count(c.encode() + b"\t") > 100 for c, _, _ in chroms)
         lines = [ln.split(b"\t")[0] for ln in want.split(b"\n") if ln and not ln.startswith(b"#")]
@@ -570,7 +570,7 @@ def test_c3_chr20_scale_12m_pairs_use_depth_vcf_identical(tmp_path_factory):
         t_data = time.perf_counter() - t0
         cfg = "sample0 " + " ".join(fq) + "\n"
         t_nat, log = _native_genotype(os.path.join(work, "native"), graph, cfg, ["--use-depth", "--gpu", "0"])
-        t_ref = _reference_genotype(os.path.join(work, "cpu"), graph, cfg, ["--use-depth"])
+        t_ref = _reference_genotype(os.path.join(work, "cpu"), graph, cfg, ["--use-depth"], timeout=400)      # (it takes 100-120 s)
         got, want = _vcf(os.path.join(work, "native"), "sample0"), _vcf(os.path.join(work, "cpu"), "sample0")
         assert got == want
         assert got.count(b"\n") > 400_000                       # nearly every site of an all-het sample is called
@@ -594,7 +594,7 @@ def test_c5_tetraploid_30mb_use_depth_on_device_vcf_identical(tmp_path_factory):
         cfg = "sample0 " + " ".join(fq) + "\n"
         extra = ["--sample-ploidy", "4", "--use-depth"]
         t_nat, log = _native_genotype(os.path.join(work, "native"), graph, cfg, extra + ["--gpu", "0"])
-        t_ref = _reference_genotype(os.path.join(work, "cpu"), graph, cfg, extra)
+        t_ref = _reference_genotype(os.path.join(work, "cpu"), graph, cfg, extra, timeout=240)
         got, want = _vcf(os.path.join(work, "native"), "sample0"), _vcf(os.path.join(work, "cpu"), "sample0")
         assert got == want and got.count(b"\n") > 50_000
         # a tetraploid sample's genotypes are the blocks of four consecutive haplotypes (src/genotype.cpp:846-873): a handful
@@ -632,7 +632,7 @@ def test_c4_eight_samples_over_the_gpus_present_equal_single_sample_reference_ru
         t_ref = 0.0
         for s in range(8):
             d = os.path.join(work, f"cpu{s}")
-            t_ref += _reference_genotype(d, graph, cfg_lines[s], [], threads=16, timeout=300)
+            t_ref += _reference_genotype(d, graph, cfg_lines[s], [], threads=16, timeout=120)
             assert _vcf(os.path.join(work, "native"), f"sample{s}") == _vcf(d, f"sample{s}"), s
         assert len({_vcf(os.path.join(work, "native"), f"sample{s}") for s in range(8)}) >= 3     # the samples do differ
         print(f"C4: 8 samples over --gpus {gpus}: varigraph-mi {t_nat:.1f} s, 8 reference runs {t_ref:.0f} s")
@@ -651,7 +651,7 @@ def test_more_than_128_genotypes_run_on_the_device_vcf_identical(tmp_path_factor
         fq = _write_fastq(os.path.join(work, "s"), haps, 300_000, seed=77)
         cfg = "sample0 " + " ".join(fq) + "\n"
         t_nat, log = _native_genotype(os.path.join(work, "native"), graph, cfg, ["-n", "20", "--gpu", "0"])
-        t_ref = _reference_genotype(os.path.join(work, "cpu"), graph, cfg, ["-n", "20"], timeout=600)
+        t_ref = _reference_genotype(os.path.join(work, "cpu"), graph, cfg, ["-n", "20"], timeout=300)
         got, want = _vcf(os.path.join(work, "native"), "sample0"), _vcf(os.path.join(work, "cpu"), "sample0")
         assert got == want and got.count(b"\n") > 8_000
         line = [ln for ln in log.split("\n") if "windows on the device" in ln]
