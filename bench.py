@@ -40,6 +40,13 @@ K = 27
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def large_kernel_name():
+    """the count kernel of graphs that live in HBM (k = 27, > 65 536 k-mers), as the environment's A/B knobs select it"""
+    if os.environ.get("VGMI_XTABLE") == "0":
+        return "vgk::count27_kernel<false, true>"
+    return "vgk::count27x_kernel" if os.environ.get("VGMI_CTABLE") == "0" else "vgk::count27c_kernel"
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -461,7 +468,7 @@ def main():
             p3 = os.path.join(ROOT, "profiles", "hbm_traffic_c3.json")
             if os.path.exists(p3):
                 tj = json.load(open(p3))
-                if tj.get("reads_per_launch") == n3:
+                if tj.get("reads_per_launch") == n3 and tj.get("kernel") == large_kernel_name():      # a profile of THIS kernel only
                     tr3 = tj["bytes_per_launch"]
             c3 = {"workload": f"C3: chr20-class synthetic SNP graph (60 Mb, 500 k SNPs, {info3['n_keys']} k-mers), "
                               f"{n3 // 2} read pairs 2x150 bp per sample, one sample per GPU",
@@ -472,7 +479,7 @@ def main():
                   "roofline": {"bound": "hbm", "achieved": ach3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach3 / HBM_PEAK_GBS, "traffic": tr3,
                                "algorithmic_bytes_per_launch": b_read3 * n3, "bytes_per_read": b_read3,
-                               "kernel": ("vgk::count27_kernel<false, true>" if os.environ.get("VGMI_XTABLE") == "0" else "vgk::count27x_kernel"),
+                               "kernel": large_kernel_name(),
                                "kernel_ms": kms3,
                                "note": "SURVEY 8d: B_read = 150 (bases) + 124 x 8 (one key compare per k-mer) + 2 x hits "
                                        "+ amortised read-out; hits measured from this run's counters"},
@@ -493,7 +500,7 @@ def main():
         torch.cuda.synchronize()
         t_u = time.perf_counter() - t_u
         bcast_c5 = broadcast_table(ctx)
-        info5, xinfo5 = ctx.table_info(), ctx.xtable_info()
+        info5, xinfo5, cinfo5 = ctx.table_info(), ctx.xtable_info(), ctx.ctable_info()
         n5 = args.c5_reads
         d_block5 = generate(haps5, 4711 + rank, 0, n5)
         del haps5
@@ -534,19 +541,21 @@ def main():
             p5 = os.path.join(ROOT, "profiles", "hbm_traffic_c5.json")
             if os.path.exists(p5):
                 tj = json.load(open(p5))
-                if tj.get("reads_per_launch") == n5:
+                if tj.get("reads_per_launch") == n5 and tj.get("kernel") == large_kernel_name():
                     tr5 = tj["bytes_per_launch"]
             c5 = {"workload": f"C5 single-GPU slice: whole-genome-class synthetic SNP graph (3 Gb, 5 M SNPs, {info5['n_keys']} k-mers, "
                               f"graph index HBM-resident), {n5 // 2} read pairs 2x150 bp per sample, one sample per GPU",
                   "value": world * n5 * args.c5_steps / el5, "unit": "reads/s", "steps": args.c5_steps,
                   "ms_per_step": el5 / args.c5_steps * 1e3, "graph_kmers": info5["n_keys"], "table_slots": info5["n_slots"],
-                  "xtable_gb": xinfo5["n_lines"] * 128 / 1e9, "xtable_overflow_pairs": xinfo5["overflow_pairs"],
+                  "large_table_gb": (xinfo5["n_lines"] * 128 + cinfo5["n_buckets"] * 64) / 1e9,
+                  "context_table": cinfo5 if cinfo5["n_buckets"] else None,
+                  "xtable_overflow_pairs": xinfo5["overflow_pairs"],
                   "device_memory_in_use_gb": (total_b - free_b) / 1e9,
                   "graph_build_s": t_g, "table_upload_s": t_u, "table_broadcast": bcast_c5, "hits_per_read": hits5,
                   "keys_saturated": int((cov5 == 255).sum()),
                   "roofline": {"bound": "hbm", "achieved": ach5, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach5 / HBM_PEAK_GBS,
                                "traffic": tr5, "algorithmic_bytes_per_launch": b_read5 * n5, "bytes_per_read": b_read5,
-                               "kernel": "vgk::count27x_kernel", "kernel_ms": kms5,
+                               "kernel": large_kernel_name(), "kernel_ms": kms5,
                                "note": "same accounting as the c3 block (SURVEY 8d)"},
                   "verify": ver5}
         del d_block5, d_cov5

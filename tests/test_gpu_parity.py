@@ -483,13 +483,17 @@ def test_saturation_flags_do_not_travel_with_the_table_image(ctx):
                                          (27, {"VGMI_WIDE_SLOTS": "1"}), (27, {"VGMI_WIDE_SLOTS": "1", "VGMI_DENSE_COUNTS": "1"}),
                                          (27, {"VGMI_WIDE_SLOTS": "1", "VGMI_LOCALITY": "0"}),
                                          (27, {"VGMI_XTABLE": "0", "VGMI_SLOT_ORDER": "1", "VGMI_LOCALITY": "6"}),
-                                         (27, {"VGMI_XTABLE_ORDER": "0"}), (27, {"VGMI_XTABLE_LOAD": "60"})],
+                                         (27, {"VGMI_CTABLE": "0"}), (27, {"VGMI_CTABLE": "0", "VGMI_XTABLE_ORDER": "0"}),
+                                         (27, {"VGMI_CTABLE": "0", "VGMI_XTABLE_LOAD": "60"}), (27, {"VGMI_CTABLE_LOAD": "90"}),
+                                         (27, {"VGMI_CTABLE_LOAD": "10"})],
                          ids=["k27", "k25", "k27-minimiser-buckets", "k27-random-homes", "k27-buckets-of-8", "k27-16-byte-slots",
                               "k27-16-byte-slots-dense-counters", "k27-16-byte-slots-random-homes", "k27-slots-by-minimiser-offset",
-                              "k27-grid-table-ids-by-key-index", "k27-grid-table-crowded"])
+                              "k27-grid-table", "k27-grid-table-ids-by-key-index", "k27-grid-table-crowded", "k27-context-table-crowded",
+                              "k27-context-table-sparse"])
 def test_large_graph_grid_variant_matches_oracle(k, placement, monkeypatch):
-    """> 65 536 keys: k = 27 takes count27x_kernel over the grid-16-mer table (default; path-ordered counter ids) or, with
-    VGMI_XTABLE=0, count27_kernel<global grid bitmap> over the minimiser-bucket table (+ generic tail row either way), k = 25 the
+    """> 65 536 keys: k = 27 takes count27c_kernel over the context table (default since round 4; path-ordered counter ids), with
+    VGMI_CTABLE=0 count27x_kernel over round 2's grid-16-mer table, with
+    VGMI_XTABLE=0 count27_kernel<global grid bitmap> over the minimiser-bucket table (+ generic tail row either way), k = 25 the
     generic rows_kernel with the global blocked-Bloom prefilter.  Dense SNPs (1 per 60 bp) give ~35 %
     hit rate: exercises ring pressure, re-queued collision probes and unsaturated counters.  The k = 27 table has
     8-byte slots in minimiser buckets with per-slot counters by default; the other formats and placements stay covered."""
@@ -535,13 +539,17 @@ def test_large_graph_grid_variant_matches_oracle(k, placement, monkeypatch):
         c.close()
 
 
-@pytest.mark.parametrize("crowded", [False, True], ids=["default-load", "crowded"])
-def test_repeat_rich_graph_matches_oracle(crowded, monkeypatch):
+@pytest.mark.parametrize("form,crowded", [("ctable", False), ("ctable", True), ("xtable", False), ("xtable", True)],
+                         ids=["context-table", "context-table-crowded", "grid-table", "grid-table-crowded"])
+def test_repeat_rich_graph_matches_oracle(form, crowded, monkeypatch):
     """A reference made of thousands of diverged copies of one 400-bp element: every 16-mer of the element sits in hundreds
-    of different graph k-mers, far more than the home line of the grid-16-mer table and the lines behind it hold.  Those
-    k-mers must be served by the exact overflow table, and nothing may be matched by (offset, flank, tag) alone."""
+    of different contexts / graph k-mers, far more than its home bucket (line) of the context table (grid-16-mer table) and the
+    ones behind it hold.  Those k-mers must be served by the exact overflow table, and nothing may be matched by less than every base."""
+    if form == "xtable":
+        monkeypatch.setenv("VGMI_CTABLE", "0")
     if crowded:
         monkeypatch.setenv("VGMI_XTABLE_LOAD", "60")
+        monkeypatch.setenv("VGMI_CTABLE_LOAD", "80")
     from varigraph_amd import synth
     rng = np.random.default_rng(99)
     unit = synth.make_reference(400, seed=31)
@@ -562,8 +570,12 @@ def test_repeat_rich_graph_matches_oracle(crowded, monkeypatch):
     c = vgmi.Context(0, buffer_mib=16)
     try:
         c.table_upload(keys, 27)
-        x = c.xtable_info()
-        assert x["n_lines"] > 0 and x["overflow_pairs"] > 1000, x
+        if form == "xtable":
+            x = c.xtable_info()
+            assert x["n_lines"] > 0 and x["overflow_pairs"] > 1000, x
+        else:
+            x = c.ctable_info()
+            assert x["n_buckets"] > 0 and x["overflow_kmers"] > 1000 and c.xtable_info()["n_lines"] == 0, x
         c.counts_reset()
         c.reads_submit(block, n_reads)
         cov, _, _ = c.counts_finish()

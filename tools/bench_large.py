@@ -27,7 +27,9 @@ def main():
     keys, (ref, hap1) = synth.snp_graph(args.genome, args.variants)
     print(f"graph: {len(keys)} keys built in {time.time() - t0:.1f}s", file=sys.stderr)
     ctx = vgmi.Context(0, buffer_mib=64)
+    t0 = time.time()
     ctx.table_upload(keys, 27)
+    t_upload = time.time() - t0
     info = ctx.table_info()
     cat = np.concatenate([ref, hap1])
     off = np.array([0, len(ref), 2 * len(ref)], dtype=np.uint64)
@@ -54,7 +56,8 @@ def main():
     best = min(r[1] for r in res[1:])
     out = {"genome": args.genome, "variants": args.variants, "n_keys": int(len(keys)), "table_slots": info["n_slots"],
            "filter_bits": info["filter_bits"], "reads": n_reads, "kernel_ms": best, "reads_per_s": n_reads / best * 1e3,
-           "counted_hits_clamped": hits, "hits_per_read_lower_bound": hits / n_reads}
+           "counted_hits_clamped": hits, "hits_per_read_lower_bound": hits / n_reads, "table_upload_s": t_upload,
+           "context_table": ctx.ctable_info(), "grid_table": ctx.xtable_info(), "all_kernel_ms": [r[1] for r in res]}
     if args.check:
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
         import oracle_lib

@@ -81,6 +81,8 @@ struct vgmi_ctx {
     uint32_t* d_xt_counts = nullptr;
     uint32_t* d_xt_id = nullptr;                // key index -> counter id (path order), nullptr: identity
     ulonglong2* d_xt_over = nullptr;            // exact table of the k-mers that overflowed their lines (repeats), or nullptr
+    uint4* d_ct_buckets = nullptr;              // context table (vgmi_ctable.hip): the default form of the large-graph table
+    uint64_t ct_entries = 0, ct_unitigs = 0, ct_moved = 0;   // entries built, unitigs they came from, entries not in their home bucket
     unsigned long long* d_pt_index = nullptr;   // path table of small graphs (build_ptable): 12-mer -> places in the unitig sequence
     uint32_t *d_pt_S = nullptr, *d_pt_VB = nullptr, *d_pt_SB = nullptr, *d_pt_SLOT = nullptr;   // sequence, k-mer starts, saturation bits, slots
     size_t pt_sb_bytes = 0;
@@ -192,6 +194,9 @@ void free_table(vgmi_ctx* c)
     if (c->d_xt_over) (void)hipFree(c->d_xt_over);
     c->d_xt_over = nullptr;
     c->xt_over_keys = 0;
+    if (c->d_ct_buckets) (void)hipFree(c->d_ct_buckets);
+    c->d_ct_buckets = nullptr;
+    c->ct_entries = c->ct_unitigs = c->ct_moved = 0;
     for (void* q : {(void*)c->d_pt_index, (void*)c->d_pt_S, (void*)c->d_pt_VB, (void*)c->d_pt_SB, (void*)c->d_pt_SLOT})
         if (q) (void)hipFree(q);
     c->d_pt_index = nullptr;
@@ -385,10 +390,121 @@ static int xtable_fill(vgmi_ctx* c, XTableView& x, const uint32_t* id_of_key)
     return VGMI_OK;
 }
 
+// The context table (vgmi_ctable.h), built from the compact image like the grid-16-mer table it replaces: the device orders the
+// k-mers along their unitigs (vgmi_ptable.hip's numbering, which also numbers the counters), every occurrence of a 16-mer in a
+// unitig becomes one 16-byte entry, buckets of four at <= 40 % load (VGMI_CTABLE_LOAD=percent for A/B), entries that find
+// CT_HOPS + 1 buckets full send their k-mers to the exact overflow table.  VGMI_CTABLE=0 keeps the grid-16-mer table and
+// count27x_kernel of round 2 as the A/B reference.
+bool ctable_wanted(const ImageHeader& h)
+{
+    const char* e = getenv("VGMI_CTABLE");
+    return !(e && e[0] == '0') && h.n_keys < (1ULL << 31) - 16;
+}
+
+int build_ctable(vgmi_ctx* c)
+{
+    const ImageHeader& h = c->hdr;
+    const uint64_t n = h.n_keys;
+    XTableView x{};
+    uint32_t *key_of_slot = nullptr, *link = nullptr, *link2 = nullptr, *pos = nullptr, *mark = nullptr, *d_list = nullptr;
+    unsigned long long *cursor = nullptr, *okmer = nullptr;      // cursor[0] numbering, [1] unitigs, [2] overflowed k-mers, [3] moved entries
+    auto cleanup = [&]() {
+        for (void* q : {(void*)key_of_slot, (void*)link, (void*)link2, (void*)pos, (void*)mark, (void*)d_list, (void*)cursor, (void*)okmer})
+            if (q) (void)hipFree(q);
+    };
+    hipError_t he = hipMalloc(reinterpret_cast<void**>(&key_of_slot), h.cap * 4);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&link), n * 8);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&link2), n * 8);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&pos), n * 4);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&mark), n * 4);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&cursor), 32);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&okmer), n * 8);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&c->d_xt_id), n * 4);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&c->d_xt_counts), n * 4);
+    if (he == hipSuccess) he = hipMemsetAsync(c->d_xt_counts, 0, n * 4, c->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(pos, 0xFF, n * 4, c->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(mark, 0, n * 4, c->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(cursor, 0, 32, c->stream);
+    if (he == hipSuccess) he = launch_ptable_order(c->tv, c->d_key_slot, n, key_of_slot, link, link2, pos, cursor, mark, c->d_status, c->stream);
+    unsigned long long cur[4] = {0, 0, 0, 0};
+    uint32_t st = 0;
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    if (he == hipSuccess) he = hipMemcpy(cur, cursor, 32, hipMemcpyDeviceToHost);
+    if (he == hipSuccess) he = hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost);
+    // not a permutation (cannot happen): any numbering is correct, the key index is one -- every k-mer a unitig of its own
+    const bool identity = (st & 16u) || cur[0] != n;
+    if (he == hipSuccess && (st & 16u)) {
+        st &= ~16u;
+        he = hipMemcpy(c->d_status, &st, 4, hipMemcpyHostToDevice);
+    }
+    if (he == hipSuccess) he = launch_ctable_okmer(c->tv, c->d_key_slot, pos, link2, n, identity, okmer, c->d_xt_id, cursor + 1, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    if (he == hipSuccess) he = hipMemcpy(cur, cursor, 32, hipMemcpyDeviceToHost);
+    for (void* q : {(void*)key_of_slot, (void*)link, (void*)link2, (void*)pos, (void*)mark})
+        if (q) (void)hipFree(q);
+    key_of_slot = link = link2 = pos = mark = nullptr;
+    if (he != hipSuccess) {
+        cleanup();
+        HIPCHK(c, he);
+    }
+    c->ct_unitigs = cur[1];
+    c->ct_entries = n + 11 * cur[1];          // a unitig of L k-mers holds L + 11 occurrences (palindromic 16-mers: two entries, rare)
+    double load = 0.40;
+    if (const char* e = getenv("VGMI_CTABLE_LOAD")) load = atoi(e) >= 5 && atoi(e) <= 95 ? atoi(e) / 100.0 : load;
+    uint64_t n_buckets = (uint64_t)((double)c->ct_entries / (4.0 * load)) + 1;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && n_buckets * 64 > free_b / 2) n_buckets = free_b / 2 / 64;
+    if (n_buckets < (1u << 16)) n_buckets = 1u << 16;
+    if (n_buckets >= (1ULL << 32) - 8 || n_buckets * 4 < c->ct_entries + c->ct_entries / 8) {
+        cleanup();
+        return fail(c, VGMI_E_NOMEM, "not enough device memory for the context table");
+    }
+    he = hipMalloc(reinterpret_cast<void**>(&c->d_ct_buckets), (size_t)64 * (n_buckets + CT_HOPS));
+    x.cb = c->d_ct_buckets;
+    x.n_buckets = (uint32_t)n_buckets;
+    x.counts = c->d_xt_counts;
+    uint64_t cap = 1u << 16;
+    unsigned long long n_over = 0;
+    for (int pass = 0; he == hipSuccess && pass < 2; ++pass) {
+        he = hipMalloc(reinterpret_cast<void**>(&d_list), cap * 4);
+        if (he == hipSuccess) he = hipMemsetAsync(cursor + 2, 0, 16, c->stream);
+        if (he == hipSuccess) he = launch_ctable_build(x, okmer, n, d_list, (uint32_t)cap, cursor + 2, cursor + 3, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he == hipSuccess) he = hipMemcpy(cur, cursor, 32, hipMemcpyDeviceToHost);
+        n_over = cur[2];
+        if (he != hipSuccess || n_over <= cap) break;
+        // which entries overflow depends on the order the threads arrive in: leave room
+        (void)hipFree(d_list);
+        d_list = nullptr;
+        cap = n_over + n_over / 4 + 1024;
+        if (cap >= (1ULL << 32)) {
+            cleanup();
+            return fail(c, VGMI_E_NOMEM, "context table: too many k-mers of repeats");
+        }
+    }
+    if (he == hipSuccess && n_over > cap) he = hipErrorOutOfMemory;
+    c->ct_moved = cur[3];
+    c->xt_over_keys = n_over;
+    if (he == hipSuccess && n_over) {
+        uint64_t slots = 1024;
+        while (slots < 2 * n_over) slots <<= 1;
+        he = hipMalloc(reinterpret_cast<void**>(&c->d_xt_over), slots * 16);
+        if (he == hipSuccess) he = launch_ctable_over(c->d_xt_over, (uint32_t)(slots - 1), okmer, d_list, n_over, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        x.over = c->d_xt_over;
+        x.over_mask = (uint32_t)(slots - 1);
+    }
+    cleanup();
+    HIPCHK(c, he);
+    c->tv.xt = x;
+    return VGMI_OK;
+}
+
 int build_xtable(vgmi_ctx* c)
 {
     const ImageHeader& h = c->hdr;
     if (!xtable_wanted(h)) return VGMI_OK;
+    if (ctable_wanted(h)) return build_ctable(c);
     XTableView x{};
     // lines of 16 slots at 25 % load (measured, chr20 / WGS class: 31 % 11.4 / 45.9 ms, 25 % 10.1 / 43.4, 20 % 9.9 / 41.8;
     // VGMI_XTABLE_LOAD=percent for A/B); never more than half of the free device memory
@@ -690,10 +806,11 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
         if (!(k & 1)) return fail(c, VGMI_E_INVALID, "device-side block length: odd k only");
         uint32_t grid, block;
         rows_geometry(c, c->filter_in_lds, grid, block);
-        if (c->tv.xt.lines && !c->force_generic) {
+        if ((c->tv.xt.lines || c->tv.xt.cb) && !c->force_generic) {
             int rcx = xt_clamp_if_due(c, n_bytes, st);
             if (rcx) return rcx;
-            HIPCHK(c, launch_count27x(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
+            if (c->tv.xt.cb) HIPCHK(c, launch_count27c(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
+            else HIPCHK(c, launch_count27x(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
             p.tail27 = 2;
             HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, 1, block, st));
         } else if (c->fast27_small && !c->force_generic) {
@@ -713,14 +830,15 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
     } else if (k & 1) {
         uint32_t grid, block;
         rows_geometry(c, c->filter_in_lds, grid, block);
-        if (c->tv.xt.lines && !c->force_generic) {
-            // grid-16-mer table: complete 768-byte rows -> count27x_kernel, the ends behind them -> the generic kernel
+        if ((c->tv.xt.lines || c->tv.xt.cb) && !c->force_generic) {
+            // context table / grid-16-mer table: complete 768-byte rows -> count27c_kernel / count27x_kernel, the ends behind them -> the generic kernel
             const uint64_t rows = n_bytes / 768;
             uint64_t emit_from = 0;
             int rcx = xt_clamp_if_due(c, n_bytes, st);
             if (rcx) return rcx;
             if (rows) {
-                HIPCHK(c, launch_count27x(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
+                if (c->tv.xt.cb) HIPCHK(c, launch_count27c(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
+                else HIPCHK(c, launch_count27x(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
                 emit_from = rows * 768 - 1;
             }
             if (emit_from < n_bytes) {
@@ -1112,6 +1230,18 @@ int vgmi_xtable_info(vgmi_ctx* c, size_t* n_lines, size_t* overflow_pairs)
     return VGMI_OK;
 }
 
+int vgmi_ctable_info(vgmi_ctx* c, size_t* n_buckets, size_t* n_entries, size_t* n_unitigs, size_t* moved_entries, size_t* overflow_kmers)
+{
+    if (!c) return VGMI_E_INVALID;
+    const bool on = c->tv.xt.cb != nullptr;
+    if (n_buckets) *n_buckets = on ? c->tv.xt.n_buckets : 0;
+    if (n_entries) *n_entries = on ? c->ct_entries : 0;
+    if (n_unitigs) *n_unitigs = on ? c->ct_unitigs : 0;
+    if (moved_entries) *moved_entries = on ? c->ct_moved : 0;
+    if (overflow_kmers) *overflow_kmers = on ? c->xt_over_keys : 0;
+    return VGMI_OK;
+}
+
 int vgmi_table_info(vgmi_ctx* c, size_t* n_keys, uint32_t* k, size_t* n_slots, size_t* filter_bits)
 {
     if (!c) return VGMI_E_INVALID;
@@ -1165,9 +1295,9 @@ int vgmi_counts_reset(vgmi_ctx* c)
     if (rc) return rc;
     rc = collect_timing(c);
     if (rc) return rc;
-    if (c->tv.xt.lines) HIPCHK(c, hipMemsetAsync(c->d_xt_counts, 0, c->hdr.n_keys * 4, c->stream));
+    if (c->tv.xt.counts) HIPCHK(c, hipMemsetAsync(c->d_xt_counts, 0, c->hdr.n_keys * 4, c->stream));
     if (c->d_counts) HIPCHK(c, hipMemsetAsync(c->d_counts, 0, c->n_counts * 4, c->stream));
-    if (!c->tv.xt.lines && (!c->d_counts || c->tv.slots8)) HIPCHK(c, launch_counts_reset(c->tv, c->stream));   // in-slot counters / saturation flags
+    if (!c->tv.xt.counts && (!c->d_counts || c->tv.slots8)) HIPCHK(c, launch_counts_reset(c->tv, c->stream));   // in-slot counters / saturation flags
     if (c->tv.pt.SB) HIPCHK(c, hipMemsetAsync(c->d_pt_SB, 0, c->pt_sb_bytes, c->stream));                       // ... and their copies in the path table
     HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4, c->stream));
     // host blocks are counted on the stages' own (non-blocking) streams: their next launch waits for this reset
@@ -1273,7 +1403,7 @@ static int finish_common(vgmi_ctx* c, uint8_t* d_cov, uint8_t* d_cov_node, unsig
     for (auto& s : c->stage)
         if (s.busy) HIPCHK(c, hipStreamWaitEvent(c->stream, s.done, 0));
     if (d_hist) HIPCHK(c, hipMemsetAsync(d_hist, 0, 256 * 8, c->stream));
-    if (c->tv.xt.lines) HIPCHK(c, launch_xcov(c->tv.xt, c->d_xt_id, c->hdr.n_keys, c->d_flag, d_cov, d_hist, c->stream));
+    if (c->tv.xt.counts) HIPCHK(c, launch_xcov(c->tv.xt, c->d_xt_id, c->hdr.n_keys, c->d_flag, d_cov, d_hist, c->stream));
     else HIPCHK(c, launch_cov(c->tv, c->d_key_slot, c->hdr.n_keys, c->d_flag, d_cov, d_hist, c->stream));
     if (d_cov_node && c->n_node_entries)
         HIPCHK(c, launch_node_gather(d_cov, c->d_node_key_index, c->n_node_entries, d_cov_node, c->stream));
@@ -1329,7 +1459,7 @@ static int counts_xfer(vgmi_ctx* c, uint32_t* dev, bool import)
     HIPCHK(c, hipSetDevice(c->device));
     for (auto& s : c->stage)
         if (s.busy) HIPCHK(c, hipStreamWaitEvent(c->stream, s.done, 0));
-    if (c->tv.xt.lines) HIPCHK(c, launch_xcounts_xfer(c->tv.xt, c->d_xt_id, dev, c->hdr.n_keys, import, c->stream));
+    if (c->tv.xt.counts) HIPCHK(c, launch_xcounts_xfer(c->tv.xt, c->d_xt_id, dev, c->hdr.n_keys, import, c->stream));
     else HIPCHK(c, launch_counts_xfer(c->tv, c->d_key_slot, dev, c->hdr.n_keys, import, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return VGMI_OK;

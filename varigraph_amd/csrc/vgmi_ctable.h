@@ -1,0 +1,167 @@
+// vgmi_ctable.h -- the CONTEXT TABLE of large graphs (k = 27): entry algebra shared by the device code (vgmi_ctable.hip,
+// the generic kernels' tail lookups) and the host-side model the CPU suite runs (tests/native/ctable_model.cpp).
+//
+// Reference behaviour served: src/kmer.cpp:140-142 (exact membership of the canonical k-mer, one unordered_map::find per
+// k-mer), src/fastq_kmer.cpp:128-139 (saturating count).
+//
+// Why.  The grid-16-mer table of round 2 (vgmi_xtable.hip) answers a candidate run -- the twelve windows of a read around one
+// grid 16-mer X -- with one 128-byte line, but needs a filter word in front of it (one memory-side request per 12 bases: 12.6 of
+// the 21.8 requests per read the kernel is bound by) and stores every k-mer twelve times.  The twelve windows are
+// not independent: they are consecutive k-mers of one haplotype path, and so are the graph k-mers they may equal (the idea of
+// the small graphs' path table, vgmi_ptable.hip).  So the table stores, per OCCURRENCE of a 16-mer X in a unitig of the key set,
+// ONE 16-byte entry holding the occurrence's whole 38-base context:
+//     d0  X, canonical (32 bits; 0xFFFFFFFF cannot be canonical: the slot is empty)
+//     d1  L: the 11 bases in front of X (22 bits, the base next to X least significant) | mask bits 0..9 << 22
+//     d2  R: the 11 bases behind X (22 bits, the base next to X most significant) | mask bits 10..11 << 22 | dir << 24
+//         | CT_FLAG_MORE << 25 (slot 0 of a bucket only: some entry found this bucket full and went on to the next one)
+//     d3  id0
+// Window s (0..11) of the context takes s bases of L, X, and 11 - s bases of R.  mask bit s says the unitig holds that window
+// as a k-mer, and its counter is id0 - s (dir = 0) or id0 + s (dir = 1): counters are numbered along the unitigs, so the
+// windows of one entry are neighbours.  Bases of L / R the unitig does not have are zero and no masked window uses them.
+// A read position compares its own context base by base: the mismatch nearest to X on either side bounds the windows that
+// are equal -- two find-first-bit instructions answer all twelve windows, exactly, in ONE lane -- so there is no filter: the
+// bucket (four entries = one 64-byte memory-side request) is both the membership test and the answer, and a k-mer costs
+// (L_unitig + 11) / L_unitig entries instead of twelve.
+//
+// Exactly one (entry, s) per (graph k-mer, offset of X in it): every k-mer of a unitig at position u holds X-occurrences
+// u .. u + 11; the occurrence's entry lists the k-mers u - 11 .. u that contain it.  X is stored in its canonical
+// orientation; an occurrence that reads the other way is stored reverse-complemented (L and R swap, s -> 11 - s, the ids run
+// the other way); a 16-mer that is its own reverse complement is stored both ways, and no window can match both (that would
+// put a k-mer and its reverse complement -- one key -- at two places of one unitig).
+#ifndef VGMI_CTABLE_H
+#define VGMI_CTABLE_H
+
+#include <stdint.h>
+
+#include "vgmi_device.h"
+
+#define CT_HOPS 3u                 // an entry sits in its home bucket or one of the CT_HOPS buckets behind it
+#define CT_FLAG_MORE (1u << 25)
+#define CT_DIR (1u << 24)
+#define CT_M22 0x3FFFFFu
+
+struct CtEntry {
+    uint32_t d0, d1, d2, d3;
+};
+
+// bijection of 32 bits (bucket = (ct_hash(X) * n_buckets) >> 32)
+VG_HD uint32_t ct_hash(uint32_t cx)
+{
+    uint32_t h = cx * 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    h ^= h >> 13;
+    return h;
+}
+
+VG_HD uint32_t ct_rc11(uint32_t x) { return vg_revcomp16(x) >> 10; }      // 11 bases in the low 22 bits
+VG_HD uint32_t ct_rev12(uint32_t m)                                        // bit s -> bit 11 - s
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bitreverse32(m) >> 20;
+#else
+    uint32_t r = 0;
+    for (int s = 0; s < 12; ++s) r |= ((m >> s) & 1u) << (11 - s);
+    return r;
+#endif
+}
+VG_HD uint32_t ct_ctz(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_ctz(x);
+#else
+    uint32_t n = 0;
+    while (!((x >> n) & 1u)) ++n;
+    return n;
+#endif
+}
+VG_HD uint32_t ct_clz(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_clz(x);
+#else
+    uint32_t n = 0;
+    while (!((x << n) & 0x80000000u)) ++n;
+    return n;
+#endif
+}
+
+// A read position's context in the table's orientation.  x, l, r as read (l: the 11 bases in front of x, the one next to x
+// least significant; r: the 11 behind it, the one next to x most significant); vw bit w = the window that ends w bases
+// behind x's last base is made of bases only (the scan's numbering).  Out: canonical x, its flanks, vs bit s = window s valid.
+VG_HD void ct_orient(uint32_t x, uint32_t l, uint32_t r, uint32_t vw, uint32_t& cx, uint32_t& cl, uint32_t& cr, uint32_t& vs)
+{
+    const uint32_t rc = vg_revcomp16(x);
+    const bool as_is = x <= rc;
+    cx = as_is ? x : rc;
+    cl = as_is ? l : ct_rc11(r);
+    cr = as_is ? r : ct_rc11(l);
+    vs = as_is ? ct_rev12(vw) : vw;        // window w takes w bases behind x: s = 11 - w as read, s = w reversed
+}
+
+// windows of the context (cx, cl, cr) that equal k-mers of entry e: bit s
+VG_HD uint32_t ct_match(const CtEntry& e, uint32_t cx, uint32_t cl, uint32_t cr)
+{
+    if (e.d0 != cx) return 0u;
+    const uint32_t tl = ((e.d1 ^ cl) & CT_M22) | (1u << 22);
+    const uint32_t nl = ct_ctz(tl) >> 1;                           // bases of L equal next to X: 0..11
+    const uint32_t tr = (((e.d2 ^ cr) & CT_M22) << 10) | (1u << 9);
+    const uint32_t nr = ct_clz(tr) >> 1;                           // bases of R equal next to X: 0..11
+    const uint32_t range = ((2u << nl) - 1u) & ~((1u << (11u - nr)) - 1u);     // 11 - nr <= s <= nl
+    const uint32_t emask = (e.d1 >> 22) | ((e.d2 >> 12) & 0xC00u);
+    return range & emask;
+}
+VG_HD uint32_t ct_id(const CtEntry& e, uint32_t s) { return (e.d2 & CT_DIR) ? e.d3 + s : e.d3 - s; }
+
+// The entry of one occurrence, from the unitig as the numbering walks it: xu the 16-mer, lu / ru its flanks (missing bases
+// zero), mask bit s = the unitig holds window s, whose counter is id0 - s.  Returns 1 entry, or 2 when xu is its own
+// reverse complement (both readings).
+VG_HD int ct_make(uint32_t xu, uint32_t lu, uint32_t ru, uint32_t mask, uint32_t id0, CtEntry out[2])
+{
+    const uint32_t rc = vg_revcomp16(xu);
+    int n = 0;
+    if (xu <= rc) {
+        out[n].d0 = xu;
+        out[n].d1 = (lu & CT_M22) | (mask & 0x3FFu) << 22;
+        out[n].d2 = (ru & CT_M22) | ((mask >> 10) & 3u) << 22;
+        out[n].d3 = id0;
+        ++n;
+    }
+    if (xu >= rc) {
+        const uint32_t m = ct_rev12(mask);
+        out[n].d0 = rc;
+        out[n].d1 = ct_rc11(ru & CT_M22) | (m & 0x3FFu) << 22;
+        out[n].d2 = ct_rc11(lu & CT_M22) | ((m >> 10) & 3u) << 22 | CT_DIR;
+        out[n].d3 = id0 - 11u;
+        ++n;
+    }
+    return n;
+}
+
+// The occurrence led by the k-mer at unitig position u (kf, as walked) with X starting o bases into it (0..11): the k-mers
+// u .. u + n_win - 1 hold it (n_win = min(o, k-mers behind kf in the unitig) + 1; kl = the last of them, id p of kf).
+VG_HD int ct_make_from_unitig(uint64_t kf, uint64_t kl, uint32_t o, uint32_t n_win, uint32_t p, CtEntry out[2])
+{
+    const uint32_t xu = (uint32_t)(kf >> (2u * (11u - o)));
+    const uint32_t lu = o ? (uint32_t)(kf >> (2u * (27u - o))) : 0u;               // the o bases in front of X
+    const uint32_t n_r = n_win + 10u - o;                                           // bases behind X the last k-mer reaches: 0..11
+    const uint32_t ru = n_r ? ((uint32_t)kl & ((1u << (2u * n_r)) - 1u)) << (2u * (11u - n_r)) : 0u;
+    const uint32_t mask = ((1u << n_win) - 1u) << (o + 1u - n_win);                 // s = o - n_win + 1 .. o
+    return ct_make(xu, lu, ru, mask, p + o, out);
+}
+
+// A single k-mer as a one-window context: X = its last 16 bases, window s = 11 as read
+VG_HD void ct_orient_kmer(uint64_t kmer, uint32_t& cx, uint32_t& cl, uint32_t& cr, uint32_t& vs)
+{
+    ct_orient((uint32_t)kmer, (uint32_t)(kmer >> 32) & CT_M22, 0u, 1u, cx, cl, cr, vs);
+}
+
+// the k-mer (in the table's orientation) of window s of a context: for the exact overflow table
+VG_HD uint64_t ct_window_kmer(uint32_t cx, uint32_t cl, uint32_t cr, uint32_t s)
+{
+    const uint64_t left = s ? (uint64_t)(cl & ((1u << (2u * s)) - 1u)) : 0ull;
+    const uint64_t right = (uint64_t)(cr & CT_M22) >> (2u * s);          // the first 11 - s bases of R
+    return left << (2u * (27u - s)) | (uint64_t)cx << (2u * (11u - s)) | right;
+}
+
+#endif

@@ -1,0 +1,329 @@
+// vgmi_ctable.hip -- the large-graph read-counting kernel over the CONTEXT TABLE (k = 27, graphs of > 65 536 k-mers:
+// BASELINE configs 3-5).  Entry algebra and the reasons: vgmi_ctable.h.
+//
+// Same reference behaviour as every count kernel here: src/kmer.cpp:110-149 (emitter, odd k: a window counts iff its 27
+// bases are bases), :140-142 (membership), src/fastq_kmer.cpp:128-139 (saturating count).
+//
+// Memory-side requests per 150-base read (the quantity this regime is bound by): 1.2 of the row stream + 12.6
+// buckets (one 64-byte request per grid position: no filter in front, no table line behind) + the counter atomics of the hits,
+// against 1.2 + 12.6 filter words + 5.2 table lines + 2.8 atomic requests of count27x_kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vgmi_ctable.h"
+#include "vgmi_xtable.h"
+
+namespace vgk {
+
+#define CT_RUNQ 320u            // run ring per wavefront (records of 8 bytes): a row adds <= 256, a drain step takes 5
+#define CT_NONE 0xFFFFFFFFu
+#define CT_MASK54 ((1ULL << 54) - 1)
+
+// ---- build ----------------------------------------------------------------------------------------------------------
+__global__ void ct_clear_kernel(ulonglong2* cb, uint64_t n_entries)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_entries; i += stride) cb[i] = make_ulonglong2(XT_EMPTY, 0ULL);
+}
+
+// Per key, from the numbering of vgmi_ptable.hip (pos_of_key = place | walked-as-canonical << 31; link2 = the mutual unique
+// links): the k-mer as the walk reads it, whether it is the first of its unitig, and how many k-mers follow it there (capped
+// at 15) -- "unitig" meaning what the entries need: neighbours in the key set WITH consecutive places, whatever numbering was
+// used (keys on cycles, the identity fallback: chains of one).
+__global__ void ct_okmer_kernel(TableView t, const uint32_t* key_slot, const uint32_t* pos_of_key, const uint32_t* link2, uint64_t n,
+                                unsigned long long* okmer, uint32_t* id_of_key, unsigned long long* n_unitigs)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pk = pos_of_key[i], p = pk & 0x7FFFFFFFu, out = pk >> 31;
+    const uint64_t K = t.slots8[key_slot[i]] & CT_MASK54;
+    const uint64_t Kw = out ? K : vg_revcomp(K, 27);
+    bool first = true;
+    const uint32_t lb = link2[2 * i + (out ^ 1u)];
+    if (lb != CT_NONE) {
+        const uint32_t pkn = pos_of_key[lb & 0x7FFFFFFFu];
+        if ((pkn >> 31) == (lb >> 31) && (pkn & 0x7FFFFFFFu) + 1u == p) first = false;
+    }
+    uint32_t cur = (uint32_t)i, o = out, q = p, cnt = 0;
+    while (cnt < 15u) {
+        const uint32_t l = link2[2ull * cur + o];
+        if (l == CT_NONE) break;
+        const uint32_t nx = l & 0x7FFFFFFFu, nxo = (l >> 31) ^ 1u, pkx = pos_of_key[nx];
+        if ((pkx >> 31) != nxo || (pkx & 0x7FFFFFFFu) != q + 1u) break;
+        cur = nx;
+        o = nxo;
+        ++q;
+        ++cnt;
+    }
+    okmer[p] = Kw | (unsigned long long)first << 54 | (unsigned long long)cnt << 55;
+    id_of_key[i] = p;
+    if (first) atomicAdd(n_unitigs, 1ULL);
+}
+
+__global__ void ct_identity_kernel(uint32_t* pos_of_key, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pos_of_key[i] = (uint32_t)i | 1u << 31;
+}
+
+// one thread per (place p, offset o of X in the k-mer): the pair leads an occurrence iff o == 11 or the k-mer is the first of its
+// unitig.  An entry that finds its home bucket and the CT_HOPS buckets behind it full sends the k-mers of its windows to the exact
+// overflow table (their places go on over_list); every full bucket it passed is marked, so a lookup follows the same trail.
+__global__ void ct_insert_kernel(XTableView t, const unsigned long long* okmer, uint64_t n, uint32_t* over_list, uint32_t over_cap,
+                                 unsigned long long* over_n, unsigned long long* n_moved)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n * 12) return;
+    const uint64_t p = g / 12;
+    const uint32_t o = (uint32_t)(g - p * 12);
+    const unsigned long long ok = okmer[p];
+    const bool first = (ok >> 54) & 1ULL;
+    if (o != 11u && !first) return;
+    const uint32_t rem = (uint32_t)(ok >> 55) & 15u;
+    const uint32_t n_win = (o < rem ? o : rem) + 1u;
+    const uint64_t kf = ok & CT_MASK54, kl = okmer[p + n_win - 1] & CT_MASK54;
+    CtEntry e[2];
+    const int ne = ct_make_from_unitig(kf, kl, o, n_win, (uint32_t)p, e);
+    ulonglong2* const cb = reinterpret_cast<ulonglong2*>(const_cast<uint4*>(t.cb));
+    for (int q = 0; q < ne; ++q) {
+        const unsigned long long lo = (unsigned long long)e[q].d0 | (unsigned long long)e[q].d1 << 32;
+        const unsigned long long hi = (unsigned long long)e[q].d2 | (unsigned long long)e[q].d3 << 32;
+        const uint64_t b = ((uint64_t)ct_hash(e[q].d0) * t.n_buckets) >> 32;
+        bool placed = false;
+        for (uint32_t hop = 0; hop <= CT_HOPS && !placed; ++hop) {
+            ulonglong2* B = cb + ((b + hop) << 2);
+            for (uint32_t s = 0; s < 4 && !placed; ++s)
+                if (atomicCAS(&B[s].x, XT_EMPTY, lo) == XT_EMPTY) {
+                    atomicOr(&B[s].y, hi);          // the mark of slot 0 may already be there
+                    placed = true;
+                    if (hop) atomicAdd(n_moved, 1ULL);
+                }
+            if (!placed) atomicOr(&B[0].y, (unsigned long long)CT_FLAG_MORE);
+        }
+        if (!placed) {
+            const unsigned long long pos = atomicAdd(over_n, (unsigned long long)n_win);
+            for (uint32_t j = 0; j < n_win; ++j)
+                if (pos + j < over_cap) over_list[pos + j] = (uint32_t)(p + j);
+        }
+    }
+}
+
+// the overflow table: open addressing on the canonical k-mer (one cell per k-mer however many of its entries overflowed)
+__global__ void ct_over_kernel(ulonglong2* over, uint32_t over_mask, const unsigned long long* okmer, const uint32_t* over_list, uint64_t n_over)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_over) return;
+    const uint32_t id = over_list[g];
+    const uint64_t kw = okmer[id] & CT_MASK54, rc = vg_revcomp(kw, 27);
+    const unsigned long long canon = kw < rc ? kw : rc;
+    uint32_t s = xt_over_hash(canon) & over_mask;
+    for (;;) {
+        unsigned long long* cell = reinterpret_cast<unsigned long long*>(&over[s]);
+        const unsigned long long was = atomicCAS(cell, XT_EMPTY, canon);
+        if (was == XT_EMPTY) {
+            cell[1] = id;
+            return;
+        }
+        if (was == canon) return;
+        s = (s + 1) & over_mask;
+    }
+}
+
+__global__ void ct_over_clear_kernel(ulonglong2* over, uint32_t over_mask)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= over_mask) over[i] = make_ulonglong2(XT_EMPTY, 0ULL);
+}
+
+hipError_t launch_ctable_okmer(const TableView& t, const uint32_t* key_slot, uint32_t* pos_of_key, const uint32_t* link2, uint64_t n, bool identity,
+                               unsigned long long* okmer, uint32_t* id_of_key, unsigned long long* n_unitigs, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t g1 = (uint32_t)((n + 255) / 256);
+    if (identity) hipLaunchKernelGGL(ct_identity_kernel, dim3(g1), dim3(256), 0, st, pos_of_key, n);
+    hipLaunchKernelGGL(ct_okmer_kernel, dim3(g1), dim3(256), 0, st, t, key_slot, pos_of_key, link2, n, okmer, id_of_key, n_unitigs);
+    return hipGetLastError();
+}
+
+hipError_t launch_ctable_build(const XTableView& t, const unsigned long long* okmer, uint64_t n, uint32_t* over_list, uint32_t over_cap,
+                               unsigned long long* over_n, unsigned long long* n_moved, hipStream_t st)
+{
+    hipLaunchKernelGGL(ct_clear_kernel, dim3(4096), dim3(256), 0, st, reinterpret_cast<ulonglong2*>(const_cast<uint4*>(t.cb)),
+                       4ULL * ((uint64_t)t.n_buckets + CT_HOPS));
+    if (n) {
+        const uint64_t m = n * 12;
+        hipLaunchKernelGGL(ct_insert_kernel, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, st, t, okmer, n, over_list, over_cap, over_n, n_moved);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_ctable_over(ulonglong2* over, uint32_t over_mask, const unsigned long long* okmer, const uint32_t* over_list, uint64_t n_over,
+                              hipStream_t st)
+{
+    hipLaunchKernelGGL(ct_over_clear_kernel, dim3((over_mask + 256) / 256), dim3(256), 0, st, over, over_mask);
+    if (n_over)
+        hipLaunchKernelGGL(ct_over_kernel, dim3((uint32_t)((n_over + 255) / 256)), dim3(256), 0, st, over, over_mask, okmer, over_list, n_over);
+    return hipGetLastError();
+}
+
+// ---- counting ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 8) void count27c_kernel(RowParams p, XTableView xt)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_lut[2048];     // position LUT of count27_kernel (stage_lut27 layout)
+    __shared__ __attribute__((aligned(16))) uint2 s_runs[4][CT_RUNQ];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    for (uint32_t i = tid; i < 2048; i += blockDim.x) {
+        const uint32_t set = i >> 10, b = (i >> 8) & 3u, c = vg_nt4(i & 255u);
+        s_lut[i] = (uint16_t)(((c & 3u) << (2 * (3 - b))) | ((c >> 2) << ((set ? 12 : 8) + b)));
+    }
+    __syncthreads();
+    uint2* const runs = s_runs[wave];
+
+    const uint64_t n_bytes = p.n_bytes_dev ? *p.n_bytes_dev : p.n_bytes;
+    const uint64_t total_rows = n_bytes / 768;            // complete rows; the ragged tail goes to rows_kernel (launch_count)
+    const uint64_t total_waves = (uint64_t)gridDim.x * 4;
+    const uint64_t rpw = (total_rows + total_waves - 1) / total_waves;
+    const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t r0 = gw * rpw;
+    const uint64_t r1 = r0 + rpw < total_rows ? r0 + rpw : total_rows;
+    if (r0 >= r1) return;
+
+    const uint32_t my_run = lane / 12u, my_win = lane % 12u;
+    uint32_t run_head = 0, run_n = 0;
+    auto ring = [](uint32_t pos) -> uint32_t { return pos >= CT_RUNQ ? pos - CT_RUNQ : pos; };
+
+    // 12 ASCII bytes -> 24 bits of bases (first base most significant) + 12 non-base flags
+    auto encode12 = [&](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t& be, uint32_t& inv) {
+        auto enc4 = [&](uint32_t w, uint32_t set) -> uint32_t {
+            return (uint32_t)s_lut[set * 1024u + (w & 0xFFu)] | s_lut[set * 1024u + 256u + ((w >> 8) & 0xFFu)] |
+                   s_lut[set * 1024u + 512u + ((w >> 16) & 0xFFu)] | s_lut[set * 1024u + 768u + (w >> 24)];
+        };
+        const uint32_t g0 = enc4(w0, 0), g1 = enc4(w1, 1), g2 = enc4(w2, 0);
+        be = (g0 & 0xFFu) << 16 | (g1 & 0xFFu) << 8 | (g2 & 0xFFu);
+        inv = ((g0 | g1) >> 8) | (g2 & 0xF00u);       // g0: bits 8..11 -> 0..3, g1: 12..15 -> 4..7, g2: 8..11
+    };
+    auto ror1 = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xF, 0xF, false); };
+
+    // A drain step turns up to 5 queued runs {id0, hit windows | dir << 12} into counter updates, a lane per (run, window): the
+    // hits of a run -- and of the runs queued next to it, which continue the same unitig -- are neighbours in the counter array
+    // and leave as one or two atomic requests.  No return value: nothing waits for them.
+    auto drain = [&]() {
+        const uint32_t take = run_n < 5u ? run_n : 5u;
+        const bool have = my_run < take;
+        uint2 q = make_uint2(0, 0);
+        if (have) q = runs[ring(run_head + my_run)];
+        run_head = ring(run_head + take);
+        run_n -= take;
+        if (have && ((q.y >> my_win) & 1u)) {
+            const uint32_t id = (q.y & 0x1000u) ? q.x + my_win : q.x - my_win;
+            __hip_atomic_fetch_add(xt.counts + id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+
+    // halo: the row in front of the range
+    uint32_t pr1_be = 0, pr2_be = 0, pr3_be = 0, pr1_inv = 0xFFFu, pr2_inv = 0xFFFu, pr3_inv = 0xFFFu;
+    const uint8_t* const bases = p.bases;
+    const uint64_t rs = r0 > 0 ? r0 - 1 : r0;
+    auto load_row = [&](uint64_t r, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
+        // wave-uniform row base in scalar registers + a 32-bit lane offset: no 64-bit address held in vector registers
+        const uint64_t ro = r * 768;
+        const uint64_t rb = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ro) |
+                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ro >> 32)) << 32;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(bases + rb + lane * 12u);
+        w0 = __builtin_nontemporal_load(src);
+        w1 = __builtin_nontemporal_load(src + 1);
+        w2 = __builtin_nontemporal_load(src + 2);
+    };
+    uint32_t n0, n1, n2;
+    load_row(rs, n0, n1, n2);
+    for (uint64_t r = rs; r < r1; ++r) {
+        const uint32_t w0 = n0, w1 = n1, w2 = n2;
+        uint32_t be, inv;
+        encode12(w0, w1, w2, be, inv);
+        const uint32_t a1_be = ror1(be), a1_inv = ror1(inv);
+        const uint32_t a2_be = ror1(a1_be), a2_inv = ror1(a1_inv);
+        const uint32_t a3_be = ror1(a2_be), a3_inv = ror1(a2_inv);
+        const uint32_t be1 = lane >= 1 ? a1_be : pr1_be, be2 = lane >= 2 ? a2_be : pr2_be, be3 = lane >= 3 ? a3_be : pr3_be;
+        const uint32_t i1 = lane >= 1 ? a1_inv : pr1_inv, i2 = lane >= 2 ? a2_inv : pr2_inv, i3 = lane >= 3 ? a3_inv : pr3_inv;
+        pr1_be = a1_be; pr2_be = a2_be; pr3_be = a3_be; pr1_inv = a1_inv; pr2_inv = a2_inv; pr3_inv = a3_inv;
+        if (r + 1 < r1) load_row(r + 1, n0, n1, n2);     // the next row is in flight while this one is worked on
+        if (r < r0) continue;      // warm-up row: halo only
+
+        {   // empty-read check (reference: assert(len > 0), src/kmer.cpp:124): two adjacent non-bases are necessary
+            const uint32_t adj = inv & ((inv << 1) | (i1 >> 11));
+            if (__builtin_expect(__ballot(adj != 0) != 0, 0) && adj) {
+                const uint64_t base_off = r * 768 + lane * 12u;
+                for (uint32_t t = 0; t < 12; ++t) {
+                    if (!((adj >> t) & 1u)) continue;
+                    const uint64_t o = base_off + t;
+                    if (bases[o] == '\n' && (o == 0 || bases[o - 1] == '\n')) atomicOr(p.status, 1u);
+                }
+            }
+        }
+        // 48-base window (see count27_kernel::scan_probe): base e from the end of the own chunk at bits [2e, 2e + 2) of W2:W1:W0
+        // -- 0..11 own chunk, 12..27 the grid 16-mer X, 28..38 the 11 bases in front of it
+        const uint32_t W0 = (be1 << 24) | be, W1 = (be2 << 16) | (be1 >> 8), W2 = (be3 << 8) | (be2 >> 16);
+        const uint32_t B = (i3 >> 9) | (i2 << 3) | (i1 << 15);
+        const uint32_t a = (inv << 1) & 0xFFFu;
+        const uint32_t bad_b = B ? (0xFFFFFFFFu >> __builtin_clz(B)) : 0u;
+        const uint32_t vm = ~(a | (0u - a) | bad_b) & 0xFFFu;       // bit w: the window that ends w bases behind X is made of bases
+        bool act = B < 2048u && vm != 0;                             // X itself is 16 bases
+        uint32_t cx, cl, cr, vs;
+        ct_orient(__builtin_amdgcn_alignbit(W1, W0, 24), __builtin_amdgcn_alignbit(W2, W1, 24) & CT_M22, (W0 >> 2) & CT_M22, vm, cx, cl, cr, vs);
+        const uint64_t b0 = ((uint64_t)ct_hash(cx) * xt.n_buckets) >> 32;
+        uint32_t found = 0;
+        for (uint32_t hop = 0;; ++hop) {       // wave-uniform: ends when no lane has a marked bucket to follow
+            uint4 e0 = make_uint4(0xFFFFFFFFu, 0, 0, 0), e1 = e0, e2 = e0, e3 = e0;
+            if (act) {
+                const uint4* Bk = xt.cb + ((b0 + hop) << 2);
+                e0 = Bk[0];
+                e1 = Bk[1];
+                e2 = Bk[2];
+                e3 = Bk[3];
+            }
+            if (hop == 0)
+                while (run_n >= 5u) drain();     // the queued runs leave while the buckets are in flight
+            const CtEntry c0 = {e0.x, e0.y, e0.z, e0.w}, c1 = {e1.x, e1.y, e1.z, e1.w}, c2 = {e2.x, e2.y, e2.z, e2.w}, c3 = {e3.x, e3.y, e3.z, e3.w};
+            const uint32_t h0 = ct_match(c0, cx, cl, cr) & vs, h1 = ct_match(c1, cx, cl, cr) & vs;
+            const uint32_t h2 = ct_match(c2, cx, cl, cr) & vs, h3 = ct_match(c3, cx, cl, cr) & vs;
+            const uint64_t m0 = __ballot(h0 != 0), m1 = __ballot(h1 != 0), m2 = __ballot(h2 != 0), m3 = __ballot(h3 != 0);
+            const uint32_t n = (uint32_t)(__builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) + __builtin_popcountll(m3));
+            if (n) {
+                while (run_n + n > CT_RUNQ) drain();
+                // lane order: the entries of neighbouring grid positions (the same unitig, 12 counters on) stay neighbours in the ring
+                auto below = [](uint64_t m) -> uint32_t { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+                uint32_t pos = run_head + run_n + below(m0) + below(m1) + below(m2) + below(m3);
+                if (h0) runs[ring(pos++)] = make_uint2(e0.w, h0 | ((e0.z >> 12) & 0x1000u));
+                if (h1) runs[ring(pos++)] = make_uint2(e1.w, h1 | ((e1.z >> 12) & 0x1000u));
+                if (h2) runs[ring(pos++)] = make_uint2(e2.w, h2 | ((e2.z >> 12) & 0x1000u));
+                if (h3) runs[ring(pos++)] = make_uint2(e3.w, h3 | ((e3.z >> 12) & 0x1000u));
+                run_n += n;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+                __builtin_amdgcn_wave_barrier();
+            }
+            found |= h0 | h1 | h2 | h3;
+            const bool more = act && (e0.z & CT_FLAG_MORE);
+            if (more && hop == CT_HOPS) {       // CT_HOPS + 1 marked buckets: what is left may sit in the exact overflow table
+                uint32_t rest = vs & ~found;
+                while (rest) {
+                    const uint32_t s = (uint32_t)__builtin_ctz(rest);
+                    rest &= rest - 1u;
+                    const uint32_t id = xt_over_find(xt, ct_window_kmer(cx, cl, cr, s));
+                    if (id != CT_NONE) __hip_atomic_fetch_add(xt.counts + id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            act = more && hop < CT_HOPS;
+            if (__ballot(act) == 0) break;
+        }
+    }
+    while (run_n) drain();
+}
+
+hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t grid, hipStream_t st)
+{
+    hipLaunchKernelGGL(count27c_kernel, dim3(grid), dim3(256), 0, st, p, t);
+    return hipGetLastError();
+}
+
+}  // namespace vgk

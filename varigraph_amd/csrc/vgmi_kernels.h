@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "vgmi_ctable.h"
 #include "vgmi_device.h"
 
 // VGMI_DBG ablations change the arithmetic (wrong counters / genotypes): they exist only in a library built with
@@ -32,6 +33,10 @@ struct XTableView {
     const ulonglong2* over;      // {canonical k-mer | XT_EMPTY, id} of the k-mers some 16-mer of which found no room
                                  // (repeats), or nullptr: none
     uint32_t over_mask;          // its capacity - 1 (a power of two)
+    // the context table (vgmi_ctable.h; round 4, the default for these graphs): when cb is set, lines is not -- counts, the
+    // path-ordered ids and the exact overflow table are shared by both forms
+    const uint4* cb;             // 4 * (n_buckets + CT_HOPS) entries of 16 bytes, or nullptr: not in use
+    uint32_t n_buckets;          // home buckets of 64 bytes, any number: bucket = (ct_hash(X) * n_buckets) >> 32
 };
 
 // path table of small graphs (vgmi_ptable.hip, build_ptable in vgmi_api.cpp): what count27s_kernel<true> checks candidate runs against
@@ -208,6 +213,13 @@ hipError_t launch_xtable_number(const XTableView& t, const unsigned long long* s
                                 uint32_t* link2, uint32_t* id_of_key, unsigned long long* cursor, uint32_t* mark, uint32_t* status,
                                 hipStream_t st);
 hipError_t launch_count27x(const RowParams& p, const XTableView& t, uint32_t grid, hipStream_t st);
+hipError_t launch_ctable_okmer(const TableView& t, const uint32_t* key_slot, uint32_t* pos_of_key, const uint32_t* link2, uint64_t n, bool identity,
+                               unsigned long long* okmer, uint32_t* id_of_key, unsigned long long* n_unitigs, hipStream_t st);
+hipError_t launch_ctable_build(const XTableView& t, const unsigned long long* okmer, uint64_t n, uint32_t* over_list, uint32_t over_cap,
+                               unsigned long long* over_n, unsigned long long* n_moved, hipStream_t st);
+hipError_t launch_ctable_over(ulonglong2* over, uint32_t over_mask, const unsigned long long* okmer, const uint32_t* over_list, uint64_t n_over,
+                              hipStream_t st);
+hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t grid, hipStream_t st);
 hipError_t launch_xclamp(const XTableView& t, uint64_t n, hipStream_t st);
 hipError_t launch_xcov(const XTableView& t, const uint32_t* id_of_key, uint64_t n, const uint8_t* flag, uint8_t* cov, unsigned long long* hist,
                        hipStream_t st);

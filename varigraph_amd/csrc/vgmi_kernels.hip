@@ -149,6 +149,10 @@ __device__ __forceinline__ uint64_t table_home(const TableView& t, uint64_t cano
 
 __device__ __forceinline__ void table_count(const TableView& t, uint64_t canon)
 {
+    if (t.xt.cb) {      // context table: the k-mer as a one-window context
+        ct_count(t.xt, canon);
+        return;
+    }
     if (t.xt.lines) {   // grid-16-mer table: the k-mer's own first 16-mer (offset 0) is as good as any of the twelve
         xt_count(t.xt, canon, 0);
         return;

@@ -32,7 +32,8 @@ namespace vgk {
 // slot of a canonical k-mer in the compact table, or PT_NONE
 __device__ __forceinline__ uint32_t pt_find(const TableView& t, uint64_t canon)
 {
-    uint64_t s = vg_thash(canon) & t.cap_mask;
+    // (large graphs -- the context table's numbering -- keep their home slots in minimiser buckets)
+    uint64_t s = (t.home_bucket_log2 ? vg_thash_local(canon, vg_revcomp(canon, 27), t.home_bucket_log2, t.home_by_offset != 0) : vg_thash(canon)) & t.cap_mask;
     for (;;) {
         const uint64_t c = t.slots8[s];
         if (c == VG_EMPTY) return PT_NONE;

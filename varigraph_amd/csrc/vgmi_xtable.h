@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "vgmi_ctable.h"
 #include "vgmi_device.h"
 #include "vgmi_kernels.h"
 
@@ -136,6 +137,35 @@ __device__ __forceinline__ void xt_count(const XTableView& t, uint64_t kmer, uin
 
 // id of a k-mer (either strand), or 0xFFFFFFFF: the lookup of xt_count without the count
 __device__ __forceinline__ uint32_t xt_find(const XTableView& t, uint64_t kmer) { return xt_lookup(t, kmer, 0); }
+
+// ---- context table (vgmi_ctable.h, vgmi_ctable.hip): one k-mer looked up as a one-window context -----------------------
+// counter id of a k-mer (either strand), or 0xFFFFFFFF: the generic kernels' ragged tails count through the same table
+__device__ __forceinline__ uint32_t ct_find(const XTableView& t, uint64_t kmer)
+{
+    uint32_t cx, cl, cr, vs;
+    ct_orient_kmer(kmer, cx, cl, cr, vs);
+    const uint64_t b0 = ((uint64_t)ct_hash(cx) * t.n_buckets) >> 32;
+    for (uint32_t hop = 0; hop <= CT_HOPS; ++hop) {
+        const uint4* B = t.cb + ((b0 + hop) << 2);
+        uint32_t flag = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 v = B[q];
+            if (q == 0) flag = v.z & CT_FLAG_MORE;
+            const CtEntry e = {v.x, v.y, v.z, v.w};
+            const uint32_t h = ct_match(e, cx, cl, cr) & vs;
+            if (h) return ct_id(e, (uint32_t)__builtin_ctz(h));
+        }
+        if (!flag) return 0xFFFFFFFFu;
+    }
+    return xt_over_find(t, kmer);
+}
+
+__device__ __forceinline__ void ct_count(const XTableView& t, uint64_t kmer)
+{
+    const uint32_t id = ct_find(t, kmer);
+    if (id != 0xFFFFFFFFu) __hip_atomic_fetch_add(t.counts + id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 }  // namespace vgk
 #endif

@@ -44,6 +44,7 @@ def load_library():
         "vgmi_table_clone": (i32, [vp, vp]),
         "vgmi_table_info": (i32, [vp, C.POINTER(sz), C.POINTER(u32), C.POINTER(sz), C.POINTER(sz)]),
         "vgmi_xtable_info": (i32, [vp, C.POINTER(sz), C.POINTER(sz)]),
+        "vgmi_ctable_info": (i32, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
         "vgmi_table_lookup": (i32, [vp, vp, sz, vp]),
         "vgmi_nodes_upload": (i32, [vp, vp, vp, sz]),
         "vgmi_flags_upload": (i32, [vp, vp]),
@@ -241,6 +242,11 @@ class Context:
         n, o = C.c_size_t(), C.c_size_t()
         self._chk(self._l.vgmi_xtable_info(self._h, C.byref(n), C.byref(o)))
         return {"n_lines": n.value, "overflow_pairs": o.value}
+
+    def ctable_info(self):
+        v = [C.c_size_t() for _ in range(5)]
+        self._chk(self._l.vgmi_ctable_info(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("n_buckets", "n_entries", "n_unitigs", "moved_entries", "overflow_kmers"), (x.value for x in v)))
 
     def nodes_upload(self, node_off, key_index):
         node_off = np.ascontiguousarray(node_off, dtype=np.uint64)
