@@ -238,6 +238,84 @@ def sample_level(ctx, haps, cpu_ref, n_plain=8_000_000, n_packed=4_000_000):
     return out
 
 
+def c4_cli(n_samples, genome, variants, pairs, threads, repeats=2):
+    """BASELINE.json configs[3] at the level a user runs it: `varigraph-mi genotype` on n_samples chr20-scale samples in one `-s`
+    list over every device present (one device: its contexts share it), from plain FASTQ files, wall clock of the whole command --
+    graph load, counting, HMM, VCFs -- and the stages its own log reports (VGH_TIMING=1).  The counting kernels are a few per cent
+    of this; what it measures is what a node of eight GPUs would be bound by (the host's share per sample)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    import torch
+    from varigraph_amd import synth
+    cli = os.path.join(ROOT, "varigraph_amd", "bin", "varigraph-mi")
+    if not os.path.exists(cli):
+        return {"error": "varigraph_amd/bin/varigraph-mi is not built"}
+    work = tempfile.mkdtemp(prefix="vg_c4_")
+    env = dict(os.environ, VGH_RANDOM_DEVICE_VALUE="20241022", VGH_TIMING="1")
+    out = {"workload": f"C4 through the CLI: {n_samples} samples x {pairs} read pairs 2x150 bp ({2 * pairs * READ_LEN / genome:.0f}x) over a "
+                       f"{genome // 1_000_000} Mb / {variants} variant / 15-haplotype graph, `varigraph-mi genotype -t {threads}`, plain FASTQ",
+           "samples": n_samples, "threads": threads}
+    try:
+        t0 = time.perf_counter()
+        ref = synth.make_reference(genome)
+        var, gts = synth.make_cohort(ref, variants, n_samples=7, ploidy=2, seed=11)
+        fa, vcf = os.path.join(work, "ref.fa"), os.path.join(work, "in.vcf")
+        synth.write_fasta(fa, "chr1", ref)
+        synth.write_vcf(vcf, "chr1", len(ref), var, gts, 7, 2)
+        haps = synth.sample_haplotypes(ref, var, gts, 0, 2)
+        fq = synth.write_fastq_pair_device(os.path.join(work, "s"), haps, pairs, 1000)
+        out["files_s"] = time.perf_counter() - t0
+        graph = os.path.join(work, "graph.bin")
+        t0 = time.perf_counter()
+        r = subprocess.run([cli, "construct", "-r", fa, "-v", vcf, "--save-graph", graph, "-t", "32", "--gpu", "0"], cwd=work,
+                           capture_output=True, text=True, env=env)
+        out["construct_s"] = time.perf_counter() - t0
+        if r.returncode != 0:
+            out["error"] = r.stderr[-400:]
+            return out
+        n_dev = max(1, torch.cuda.device_count())
+        gpus = ",".join(str(i) for i in range(n_dev))
+        out["gpus"] = gpus
+        d = os.path.join(work, "run")
+        best = None
+        for _ in range(repeats):
+            shutil.rmtree(d, ignore_errors=True)
+            os.makedirs(d)
+            open(os.path.join(d, "samples.cfg"), "w").write("".join(f"sample{i} " + " ".join(fq) + "\n" for i in range(n_samples)))
+            t0 = time.perf_counter()
+            r = subprocess.run([cli, "genotype", "--load-graph", graph, "-s", "samples.cfg", "-t", str(threads), "--gpus", gpus], cwd=d,
+                               capture_output=True, text=True, env=env)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                out["error"] = r.stderr[-400:]
+                return out
+            log = r.stderr
+
+            def nums(pat):
+                return [float(x) for x in re.findall(pat, log)]
+            host = {"node_lists": sum(nums(r"node lists ([\d.]+),")), "host_scored_nodes_and_genotype_strings": sum(nums(r"genotype strings ([\d.]+),")),
+                    "step_tables": sum(nums(r"step tables ([\d.]+),")), "calls_and_vcf_lines": sum(nums(r"calls \+ VCF lines ([\d.]+),")),
+                    "hmm_preparation": sum(sum(nums(p)) for p in (r"selection ([\d.]+),", r"hidden states ([\d.]+),", r"emissions ([\d.]+), forward", r"posterior ([\d.]+) \("))}
+            run = {"genotype_wall_s": dt, "samples_per_s": n_samples / dt,
+                   "graph_load_s": (nums(r"graph loaded: .*\(([\d.]+) s\)") or [None])[0],
+                   "counting_wall_s_per_sample": float(np.mean(nums(r"counting ([\d.]+) s"))) if nums(r"counting ([\d.]+) s") else None,
+                   "count_kernel_s_per_sample": float(np.mean(nums(r"\(kernel ([\d.]+) s"))) if nums(r"\(kernel ([\d.]+) s") else None,
+                   "hmm_device_recursion_s_per_sample": float(np.mean(nums(r"HMM recursion on the device: ([\d.]+) s"))) if nums(r"HMM recursion on the device: ([\d.]+) s") else None,
+                   "genotyping_wall_s_per_sample": float(np.mean(nums(r"genotyping ([\d.]+) s"))) if nums(r"genotyping ([\d.]+) s") else None,
+                   "vcf_text_and_gzip_s_per_sample": float(np.mean([a + b for a, b in zip(nums(r"VCF text ([\d.]+),"), nums(r"gzip ([\d.]+)\)"))])) if nums(r"VCF text ([\d.]+),") else None,
+                   "host_thread_seconds": host, "host_thread_seconds_per_sample": sum(host.values()) / n_samples}
+            if best is None or dt < best["genotype_wall_s"]:
+                best = run
+        out.update(best)
+        out["note"] = ("best of %d runs; the %d samples read the same two FASTQ files (page cache); eight devices would each run one sample's "
+                       "counting + device HMM side by side, the host thread-seconds per sample are what they share" % (repeats, n_samples))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return out
+
+
 def measured_traffic(n_reads):
     """HBM-side bytes per launch of the count kernel from the committed rocprofv3 PMC passes
     (profiles/hbm_traffic.json, produced by tools/profile_r1.sh for the same workload)."""
@@ -291,6 +369,10 @@ def main():
     ap.add_argument("--c5-steps", type=int, default=10)
     ap.add_argument("--verify-reads", type=int, default=1_000_000, help="unsaturated prefix checked against the oracle")
     ap.add_argument("--no-sample-level", action="store_true", help="skip the FASTQ-files-to-counters leg")
+    ap.add_argument("--no-c4", action="store_true", help="skip the CLI-level eight-sample leg (BASELINE configs[3] through varigraph-mi)")
+    ap.add_argument("--c4-samples", type=int, default=8)
+    ap.add_argument("--c4-pairs", type=int, default=6_000_000)
+    ap.add_argument("--c4-threads", type=int, default=10)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
@@ -656,8 +738,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(haps, args.cpu_reads, cores)
         if world == 1 and not args.no_sample_level:
             out["sample_level"] = sample_level(ctx, haps, out.get("cpu_baseline"))
-        print(json.dumps(out), flush=True)
     ctx.close()
+    if rank == 0:
+        if world == 1 and not args.no_c4:
+            torch.cuda.empty_cache()
+            out["c4"] = c4_cli(args.c4_samples, 60_000_000, 500_000, args.c4_pairs, args.c4_threads)
+        print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()
 

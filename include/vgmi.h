@@ -51,7 +51,8 @@ int vgmi_device_count(void);
 int vgmi_create(int device, size_t buffer_mib, vgmi_ctx **out);
 void vgmi_destroy(vgmi_ctx *ctx);
 const char *vgmi_last_error(const vgmi_ctx *ctx); /* ctx may be NULL: error of the last failed vgmi_create */
-/* free / total bytes of the context's device right now (hipMemGetInfo): callers that size optional device work (the HMM
+/* free / total bytes of the context's device right now (hipMemGetInfo; free includes the working blocks this context keeps
+ * between HMM calls and is not using, which the next call reuses or releases): callers that size optional device work (the HMM
  * recursion's score arrays) decide from it instead of from a fixed bound.  No reference counterpart. */
 int vgmi_device_memory(vgmi_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
 /* the HIP stream every kernel of this context is launched on (hipStream_t), for event timing */

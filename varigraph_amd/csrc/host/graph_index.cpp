@@ -509,14 +509,18 @@ void GraphIndex::graph2node()
     const uint8_t* fp = f.data();
     // a graph that load() is reading keeps its nodes' hashes in the file buffer: whichever way the lists are resolved, the
     // nodes forget those places before this function returns (the buffer does not outlive load())
+    // (EVERY node: the ones with a single allele are not in vnodes, and their place would dangle just the same)
     auto forget_file_places = [&]() {
-        parallel_chunks(vnodes.size(), threads, [&](size_t b, size_t e, unsigned) {
-            for (size_t v = b; v < e; ++v) {
-                GraphNode* nd = const_cast<GraphNode*>(vnodes[v]);
-                nd->kmer_file = nullptr;
-                nd->kmer_file_n = 0;
-            }
-        });
+        for (auto& kv : graph_seq) {
+            auto& seq = kv.second;
+            parallel_chunks(seq.size(), threads, [&](size_t b, size_t e, unsigned) {
+                for (size_t v = b; v < e; ++v) {
+                    GraphNode* nd = const_cast<GraphNode*>(seq[v]);
+                    nd->kmer_file = nullptr;
+                    nd->kmer_file_n = 0;
+                }
+            });
+        }
     };
     if (batched_find) {
         // every node's k-mers in one array, one batched lookup (the device holds the table already), the answers written per node

@@ -455,7 +455,7 @@ int build_ctable(vgmi_ctx* c)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && n_buckets * 64 > free_b / 2) n_buckets = free_b / 2 / 64;
     if (n_buckets < (1u << 16)) n_buckets = 1u << 16;
-    if (n_buckets >= (1ULL << 32) - 8 || n_buckets * 4 < c->ct_entries + c->ct_entries / 8) {
+    if (n_buckets >= (1ULL << 32) - 8 || n_buckets * 8 < c->ct_entries) {      // (what does not fit goes to the overflow table; below half, that table is the table)
         cleanup();
         return fail(c, VGMI_E_NOMEM, "not enough device memory for the context table");
     }
@@ -809,7 +809,7 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
         if ((c->tv.xt.lines || c->tv.xt.cb) && !c->force_generic) {
             int rcx = xt_clamp_if_due(c, n_bytes, st);
             if (rcx) return rcx;
-            if (c->tv.xt.cb) HIPCHK(c, launch_count27c(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
+            if (c->tv.xt.cb) HIPCHK(c, launch_count27c(p, c->tv.xt, (uint32_t)c->n_cu, st));
             else HIPCHK(c, launch_count27x(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
             p.tail27 = 2;
             HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, 1, block, st));
@@ -837,7 +837,7 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
             int rcx = xt_clamp_if_due(c, n_bytes, st);
             if (rcx) return rcx;
             if (rows) {
-                if (c->tv.xt.cb) HIPCHK(c, launch_count27c(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
+                if (c->tv.xt.cb) HIPCHK(c, launch_count27c(p, c->tv.xt, (uint32_t)c->n_cu, st));
                 else HIPCHK(c, launch_count27x(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
                 emit_from = rows * 768 - 1;
             }
@@ -1179,9 +1179,11 @@ int vgmi_table_import(vgmi_ctx* c, const void* dev_src, size_t bytes)
     HIPCHK(c, launch_counts_reset(c->tv, c->stream));   // the exporter's per-sample state travels with the image
     HIPCHK(c, hipStreamSynchronize(c->stream));
     rc = build_xtable(c);
-    if (rc) return rc;
-    rc = build_ptable(c);
-    if (rc) return rc;
+    if (rc == VGMI_OK) rc = build_ptable(c);
+    if (rc) {
+        free_table(c);      // as vgmi_table_upload does: no half-built table behind an error code
+        return rc;
+    }
     c->read_base = 0;
     return VGMI_OK;
 }
@@ -1215,9 +1217,11 @@ int vgmi_table_clone(vgmi_ctx* dst, vgmi_ctx* src)
     HIPCHK(dst, launch_counts_reset(dst->tv, dst->stream));   // the source's per-sample state travels with the image
     HIPCHK(dst, hipStreamSynchronize(dst->stream));
     rc = build_xtable(dst);
-    if (rc) return rc;
-    rc = build_ptable(dst);
-    if (rc) return rc;
+    if (rc == VGMI_OK) rc = build_ptable(dst);
+    if (rc) {
+        free_table(dst);
+        return rc;
+    }
     dst->read_base = 0;
     return VGMI_OK;
 }
@@ -2342,6 +2346,10 @@ int vgmi_device_memory(vgmi_ctx* c, size_t* free_bytes, size_t* total_bytes)
     HIPCHK(c, hipSetDevice(c->device));
     size_t f = 0, t = 0;
     HIPCHK(c, hipMemGetInfo(&f, &t));
+    {   // blocks the context keeps between HMM calls and is not using: the next call takes them or frees them for a larger one
+        std::lock_guard<std::mutex> lock(c->hmm_mu);
+        for (const auto& b : c->hmm_blocks) f += b.second;
+    }
     if (free_bytes) *free_bytes = f;
     if (total_bytes) *total_bytes = t;
     return VGMI_OK;

@@ -35,7 +35,7 @@
 
 #include "vgmi_device.h"
 
-#define CT_HOPS 3u                 // an entry sits in its home bucket or one of the CT_HOPS buckets behind it
+#define CT_HOPS 7u                 // an entry sits in its home bucket or one of the CT_HOPS buckets behind it
 #define CT_FLAG_MORE (1u << 25)
 #define CT_DIR (1u << 24)
 #define CT_M22 0x3FFFFFu

@@ -9,6 +9,7 @@
 // against 1.2 + 12.6 filter words + 5.2 table lines + 2.8 atomic requests of count27x_kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "vgmi_ctable.h"
 #include "vgmi_xtable.h"
@@ -16,6 +17,7 @@
 namespace vgk {
 
 #define CT_RUNQ 320u            // run ring per wavefront (records of 8 bytes): a row adds <= 256, a drain step takes 5
+#define CT_PENDQ 128u           // contexts that go on to a next bucket (16 bytes): a row or a batch adds <= 64, a batch takes 64 once 64 wait
 #define CT_NONE 0xFFFFFFFFu
 #define CT_MASK54 ((1ULL << 54) - 1)
 
@@ -167,10 +169,17 @@ hipError_t launch_ctable_over(ulonglong2* over, uint32_t over_mask, const unsign
 }
 
 // ---- counting ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 8) void count27c_kernel(RowParams p, XTableView xt)
+// A grid position whose bucket is marked (some entry with this home went on to the next bucket) and whose windows are not all
+// answered yet does NOT chase the trail on the spot -- that made every row wait for two or three dependent memory round trips
+// on behalf of a handful of lanes (2.5 of 10.6 ms at chr20 class, VGMI_DBG=8 ablation).  It queues a 16-byte item {X, flanks,
+// windows still open, hop, next bucket} instead, and the wavefront looks 64 queued items up at a time, all lanes busy, one round
+// trip per batch; an item that meets another marked bucket is queued again, one that has seen CT_HOPS + 1 of them asks the exact
+// overflow table.
+__global__ __launch_bounds__(256, 7) void count27c_kernel(RowParams p, XTableView xt)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[2048];     // position LUT of count27_kernel (stage_lut27 layout)
     __shared__ __attribute__((aligned(16))) uint2 s_runs[4][CT_RUNQ];
+    __shared__ __attribute__((aligned(16))) uint4 s_pend[4][CT_PENDQ];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     for (uint32_t i = tid; i < 2048; i += blockDim.x) {
@@ -179,6 +188,7 @@ __global__ __launch_bounds__(256, 8) void count27c_kernel(RowParams p, XTableVie
     }
     __syncthreads();
     uint2* const runs = s_runs[wave];
+    uint4* const pend = s_pend[wave];
 
     const uint64_t n_bytes = p.n_bytes_dev ? *p.n_bytes_dev : p.n_bytes;
     const uint64_t total_rows = n_bytes / 768;            // complete rows; the ragged tail goes to rows_kernel (launch_count)
@@ -190,8 +200,9 @@ __global__ __launch_bounds__(256, 8) void count27c_kernel(RowParams p, XTableVie
     if (r0 >= r1) return;
 
     const uint32_t my_run = lane / 12u, my_win = lane % 12u;
-    uint32_t run_head = 0, run_n = 0;
+    uint32_t run_head = 0, run_n = 0, pend_head = 0, pend_n = 0;
     auto ring = [](uint32_t pos) -> uint32_t { return pos >= CT_RUNQ ? pos - CT_RUNQ : pos; };
+    auto below = [](uint64_t m) -> uint32_t { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
 
     // 12 ASCII bytes -> 24 bits of bases (first base most significant) + 12 non-base flags
     auto encode12 = [&](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t& be, uint32_t& inv) {
@@ -215,10 +226,85 @@ __global__ __launch_bounds__(256, 8) void count27c_kernel(RowParams p, XTableVie
         if (have) q = runs[ring(run_head + my_run)];
         run_head = ring(run_head + take);
         run_n -= take;
-        if (have && ((q.y >> my_win) & 1u)) {
+        if (have && ((q.y >> my_win) & 1u) && !(VG_DBG(p.dbg) & 2u)) {
             const uint32_t id = (q.y & 0x1000u) ? q.x + my_win : q.x - my_win;
             __hip_atomic_fetch_add(xt.counts + id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    };
+
+    // One bucket against one context per lane: the matching windows of each entry become a run; returns the windows answered and
+    // whether the bucket is marked.  `early`: called with the loads just issued -- the queued runs leave while they are in flight.
+    auto look = [&](bool act, uint64_t bucket, uint32_t cx, uint32_t cl, uint32_t cr, uint32_t vs, bool early, uint32_t& found, bool& marked) {
+        uint4 e0 = make_uint4(0xFFFFFFFFu, 0, 0, 0), e1 = e0, e2 = e0, e3 = e0;
+        if (act) {
+            const uint4* Bk = xt.cb + (bucket << 2);
+            e0 = Bk[0];
+            e1 = Bk[1];
+            e2 = Bk[2];
+            e3 = Bk[3];
+        }
+        if (early)
+            while (run_n >= 5u) drain();
+        const CtEntry c0 = {e0.x, e0.y, e0.z, e0.w}, c1 = {e1.x, e1.y, e1.z, e1.w}, c2 = {e2.x, e2.y, e2.z, e2.w}, c3 = {e3.x, e3.y, e3.z, e3.w};
+        const uint32_t h0 = ct_match(c0, cx, cl, cr) & vs, h1 = ct_match(c1, cx, cl, cr) & vs;
+        const uint32_t h2 = ct_match(c2, cx, cl, cr) & vs, h3 = ct_match(c3, cx, cl, cr) & vs;
+        const uint64_t m0 = __ballot(h0 != 0), m1 = __ballot(h1 != 0), m2 = __ballot(h2 != 0), m3 = __ballot(h3 != 0);
+        const uint32_t n = (uint32_t)(__builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) + __builtin_popcountll(m3));
+        if (n) {
+            while (run_n + n > CT_RUNQ) drain();
+            // lane order: the entries of neighbouring grid positions (the same unitig, 12 counters on) stay neighbours in the ring
+            uint32_t pos = run_head + run_n + below(m0) + below(m1) + below(m2) + below(m3);
+            if (h0) runs[ring(pos++)] = make_uint2(e0.w, h0 | ((e0.z >> 12) & 0x1000u));
+            if (h1) runs[ring(pos++)] = make_uint2(e1.w, h1 | ((e1.z >> 12) & 0x1000u));
+            if (h2) runs[ring(pos++)] = make_uint2(e2.w, h2 | ((e2.z >> 12) & 0x1000u));
+            if (h3) runs[ring(pos++)] = make_uint2(e3.w, h3 | ((e3.z >> 12) & 0x1000u));
+            run_n += n;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+        }
+        found = h0 | h1 | h2 | h3;
+        marked = act && (e0.z & CT_FLAG_MORE);
+    };
+    // queue the contexts that go on: {X, L | open windows 0..9 << 22, R | open windows 10..11 << 22 | hop << 24, bucket}
+    auto push = [&](bool on, uint32_t cx, uint32_t cl, uint32_t cr, uint32_t open, uint32_t hop, uint32_t bucket) {
+        const uint64_t m = __ballot(on);
+        if (m == 0) return;
+        if (on) {
+            uint32_t pos = pend_head + pend_n + below(m);
+            pos = pos >= CT_PENDQ ? pos - CT_PENDQ : pos;
+            pend[pos] = make_uint4(cx, cl | (open & 0x3FFu) << 22, cr | (open >> 10) << 22 | hop << 24, bucket);
+        }
+        pend_n += (uint32_t)__builtin_popcountll(m);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto pending_batch = [&]() {
+        const uint32_t take = pend_n < 64u ? pend_n : 64u;
+        const bool act = lane < take;
+        uint4 it = make_uint4(0, 0, 0, 0);
+        if (act) {
+            const uint32_t pos = pend_head + lane;
+            it = pend[pos >= CT_PENDQ ? pos - CT_PENDQ : pos];
+        }
+        pend_head = pend_head + take >= CT_PENDQ ? pend_head + take - CT_PENDQ : pend_head + take;
+        pend_n -= take;
+        const uint32_t cx = it.x, cl = it.y & CT_M22, cr = it.z & CT_M22, hop = (it.z >> 24) & 15u;
+        const uint32_t vs = (it.y >> 22) | ((it.z >> 12) & 0xC00u);
+        uint32_t found;
+        bool marked;
+        look(act, it.w, cx, cl, cr, vs, false, found, marked);
+        const uint32_t open = vs & ~found;
+        const bool on = marked && open != 0 && !(VG_DBG(p.dbg) & 8u);
+        if (on && hop == CT_HOPS && !(VG_DBG(p.dbg) & 4u)) {       // CT_HOPS + 1 marked buckets: what is left may sit in the exact overflow table
+            uint32_t rest = open;
+            while (rest) {
+                const uint32_t s = (uint32_t)__builtin_ctz(rest);
+                rest &= rest - 1u;
+                const uint32_t id = xt_over_find(xt, ct_window_kmer(cx, cl, cr, s));
+                if (id != CT_NONE) __hip_atomic_fetch_add(xt.counts + id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        push(on && hop < CT_HOPS, cx, cl, cr, open, hop + 1u, it.w + 1u);
     };
 
     // halo: the row in front of the range
@@ -268,61 +354,23 @@ __global__ __launch_bounds__(256, 8) void count27c_kernel(RowParams p, XTableVie
         const uint32_t a = (inv << 1) & 0xFFFu;
         const uint32_t bad_b = B ? (0xFFFFFFFFu >> __builtin_clz(B)) : 0u;
         const uint32_t vm = ~(a | (0u - a) | bad_b) & 0xFFFu;       // bit w: the window that ends w bases behind X is made of bases
-        bool act = B < 2048u && vm != 0;                             // X itself is 16 bases
+        const bool act = B < 2048u && vm != 0;                       // X itself is 16 bases
         uint32_t cx, cl, cr, vs;
         ct_orient(__builtin_amdgcn_alignbit(W1, W0, 24), __builtin_amdgcn_alignbit(W2, W1, 24) & CT_M22, (W0 >> 2) & CT_M22, vm, cx, cl, cr, vs);
-        const uint64_t b0 = ((uint64_t)ct_hash(cx) * xt.n_buckets) >> 32;
-        uint32_t found = 0;
-        for (uint32_t hop = 0;; ++hop) {       // wave-uniform: ends when no lane has a marked bucket to follow
-            uint4 e0 = make_uint4(0xFFFFFFFFu, 0, 0, 0), e1 = e0, e2 = e0, e3 = e0;
-            if (act) {
-                const uint4* Bk = xt.cb + ((b0 + hop) << 2);
-                e0 = Bk[0];
-                e1 = Bk[1];
-                e2 = Bk[2];
-                e3 = Bk[3];
-            }
-            if (hop == 0)
-                while (run_n >= 5u) drain();     // the queued runs leave while the buckets are in flight
-            const CtEntry c0 = {e0.x, e0.y, e0.z, e0.w}, c1 = {e1.x, e1.y, e1.z, e1.w}, c2 = {e2.x, e2.y, e2.z, e2.w}, c3 = {e3.x, e3.y, e3.z, e3.w};
-            const uint32_t h0 = ct_match(c0, cx, cl, cr) & vs, h1 = ct_match(c1, cx, cl, cr) & vs;
-            const uint32_t h2 = ct_match(c2, cx, cl, cr) & vs, h3 = ct_match(c3, cx, cl, cr) & vs;
-            const uint64_t m0 = __ballot(h0 != 0), m1 = __ballot(h1 != 0), m2 = __ballot(h2 != 0), m3 = __ballot(h3 != 0);
-            const uint32_t n = (uint32_t)(__builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) + __builtin_popcountll(m3));
-            if (n) {
-                while (run_n + n > CT_RUNQ) drain();
-                // lane order: the entries of neighbouring grid positions (the same unitig, 12 counters on) stay neighbours in the ring
-                auto below = [](uint64_t m) -> uint32_t { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
-                uint32_t pos = run_head + run_n + below(m0) + below(m1) + below(m2) + below(m3);
-                if (h0) runs[ring(pos++)] = make_uint2(e0.w, h0 | ((e0.z >> 12) & 0x1000u));
-                if (h1) runs[ring(pos++)] = make_uint2(e1.w, h1 | ((e1.z >> 12) & 0x1000u));
-                if (h2) runs[ring(pos++)] = make_uint2(e2.w, h2 | ((e2.z >> 12) & 0x1000u));
-                if (h3) runs[ring(pos++)] = make_uint2(e3.w, h3 | ((e3.z >> 12) & 0x1000u));
-                run_n += n;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-                __builtin_amdgcn_wave_barrier();
-            }
-            found |= h0 | h1 | h2 | h3;
-            const bool more = act && (e0.z & CT_FLAG_MORE);
-            if (more && hop == CT_HOPS) {       // CT_HOPS + 1 marked buckets: what is left may sit in the exact overflow table
-                uint32_t rest = vs & ~found;
-                while (rest) {
-                    const uint32_t s = (uint32_t)__builtin_ctz(rest);
-                    rest &= rest - 1u;
-                    const uint32_t id = xt_over_find(xt, ct_window_kmer(cx, cl, cr, s));
-                    if (id != CT_NONE) __hip_atomic_fetch_add(xt.counts + id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            act = more && hop < CT_HOPS;
-            if (__ballot(act) == 0) break;
-        }
+        const uint32_t b0 = (uint32_t)(((uint64_t)ct_hash(cx) * xt.n_buckets) >> 32);
+        uint32_t found;
+        bool marked;
+        look(act, b0, cx, cl, cr, vs, true, found, marked);
+        push(marked && (vs & ~found) != 0 && !(VG_DBG(p.dbg) & 8u), cx, cl, cr, vs & ~found, 1u, b0 + 1u);
+        while (pend_n >= 64u) pending_batch();
     }
+    while (pend_n) pending_batch();
     while (run_n) drain();
 }
 
-hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t grid, hipStream_t st)
+hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t n_cu, hipStream_t st)
 {
-    hipLaunchKernelGGL(count27c_kernel, dim3(grid), dim3(256), 0, st, p, t);
+    hipLaunchKernelGGL(count27c_kernel, dim3(n_cu * 7), dim3(256), 0, st, p, t);
     return hipGetLastError();
 }
 

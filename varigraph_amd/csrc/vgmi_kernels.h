@@ -219,7 +219,7 @@ hipError_t launch_ctable_build(const XTableView& t, const unsigned long long* ok
                                unsigned long long* over_n, unsigned long long* n_moved, hipStream_t st);
 hipError_t launch_ctable_over(ulonglong2* over, uint32_t over_mask, const unsigned long long* okmer, const uint32_t* over_list, uint64_t n_over,
                               hipStream_t st);
-hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t grid, hipStream_t st);
+hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t n_cu, hipStream_t st);
 hipError_t launch_xclamp(const XTableView& t, uint64_t n, hipStream_t st);
 hipError_t launch_xcov(const XTableView& t, const uint32_t* id_of_key, uint64_t n, const uint8_t* flag, uint8_t* cov, unsigned long long* hist,
                        hipStream_t st);
