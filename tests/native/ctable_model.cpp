@@ -31,7 +31,7 @@ struct Model {
     std::unordered_map<uint64_t, uint32_t> index;     // canonical k-mer -> key index
     std::vector<uint32_t> id_of_key;
     std::vector<uint64_t> okmer;
-    std::vector<CtEntry> cb;
+    std::vector<CtBucket> cb;
     uint64_t n_buckets = 0;
     std::unordered_map<uint64_t, uint32_t> over;      // canonical k-mer -> id
     uint64_t n_entries = 0, n_unitigs = 0, n_moved = 0, n_over = 0;
@@ -132,8 +132,10 @@ struct Model {
         const size_t n = keys.size();
         n_entries = n + 11 * n_unitigs;
         n_buckets = (uint64_t)((double)n_entries / (4.0 * load)) + 1;
-        CtEntry empty = {0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0};
-        cb.assign(4 * (n_buckets + CT_HOPS), empty);
+        CtBucket empty;
+        memset(&empty, 0, sizeof empty);
+        for (auto& x : empty.x) x = 0xFFFFFFFFu;
+        cb.assign(n_buckets + CT_HOPS, empty);
         for (size_t p = 0; p < n; ++p)
             for (uint32_t o = 0; o < 12; ++o) {
                 const uint64_t ok = okmer[p];
@@ -147,16 +149,17 @@ struct Model {
                     const uint64_t b = ((uint64_t)ct_hash(e[q].d0) * n_buckets) >> 32;
                     bool placed = false;
                     for (uint32_t hop = 0; hop <= CT_HOPS && !placed; ++hop) {
-                        CtEntry* B = &cb[(b + hop) * 4];
+                        CtBucket& B = cb[b + hop];
                         for (int s = 0; s < 4 && !placed; ++s)
-                            if (B[s].d0 == 0xFFFFFFFFu) {
-                                const uint32_t keep = B[s].d2;
-                                B[s] = e[q];
-                                B[s].d2 |= keep;
+                            if (B.x[s] == 0xFFFFFFFFu) {
+                                B.x[s] = e[q].d0;
+                                B.rest[s][0] = e[q].d1;
+                                B.rest[s][1] |= e[q].d2;
+                                B.rest[s][2] = e[q].d3;
                                 placed = true;
                                 n_moved += hop != 0;
                             }
-                        if (!placed) B[0].d2 |= CT_FLAG_MORE;
+                        if (!placed) B.rest[0][1] |= CT_FLAG_MORE;
                     }
                     if (!placed)
                         for (uint32_t j = 0; j < n_win; ++j) {
@@ -183,18 +186,20 @@ struct Model {
         const uint64_t b0 = ((uint64_t)ct_hash(cx) * n_buckets) >> 32;
         uint32_t found = 0;
         for (uint32_t hop = 0;; ++hop) {
-            const CtEntry* B = &cb[(b0 + hop) * 4];
+            const CtBucket& B = cb[b0 + hop];
             for (int q = 0; q < 4; ++q) {
-                uint32_t h = ct_match(B[q], cx, cl, cr) & vs;
+                if (B.x[q] != cx) continue;
+                const CtEntry e = {B.x[q], B.rest[q][0], B.rest[q][1], B.rest[q][2]};
+                uint32_t h = ct_match(e, cx, cl, cr) & vs;
                 if (h & found) { fprintf(stderr, "window matched twice\n"); exit(2); }
                 found |= h;
                 while (h) {
                     const uint32_t s = ct_ctz(h);
                     h &= h - 1;
-                    ++counts[ct_id(B[q], s)];
+                    ++counts[ct_id(e, s)];
                 }
             }
-            const bool more = B[0].d2 & CT_FLAG_MORE;
+            const bool more = B.x[3] != 0xFFFFFFFFu && (B.rest[0][1] & CT_FLAG_MORE) && (vs & ~found);
             if (more && hop == CT_HOPS) {
                 uint32_t rest = vs & ~found;
                 while (rest) {
@@ -215,12 +220,14 @@ struct Model {
         ct_orient_kmer(kmer, cx, cl, cr, vs);
         const uint64_t b0 = ((uint64_t)ct_hash(cx) * n_buckets) >> 32;
         for (uint32_t hop = 0; hop <= CT_HOPS; ++hop) {
-            const CtEntry* B = &cb[(b0 + hop) * 4];
+            const CtBucket& B = cb[b0 + hop];
             for (int q = 0; q < 4; ++q) {
-                const uint32_t h = ct_match(B[q], cx, cl, cr) & vs;
-                if (h) return ct_id(B[q], ct_ctz(h));
+                if (B.x[q] != cx) continue;
+                const CtEntry e = {B.x[q], B.rest[q][0], B.rest[q][1], B.rest[q][2]};
+                const uint32_t h = ct_match(e, cx, cl, cr) & vs;
+                if (h) return ct_id(e, ct_ctz(h));
             }
-            if (!(B[0].d2 & CT_FLAG_MORE)) return NONE;
+            if (B.x[3] == 0xFFFFFFFFu || !(B.rest[0][1] & CT_FLAG_MORE)) return NONE;
         }
         return over_find(kmer);
     }

@@ -157,7 +157,7 @@ def _oracle_counts_by_search(sorted_keys, block, n_reads):
 
 def test_c5_wgs_class_single_gpu_slice():
     """BASELINE config 5's single-GPU slice at its stated size: the whole-genome class graph (3 Gb reference, 5 M SNPs,
-    2.67e8 graph k-mers) resident in HBM -- compact image, context table at 40 % load (~15 GB) -- NEXT TO
+    2.67e8 graph k-mers) resident in HBM -- compact image, context table at 30 % load (~20 GB) -- NEXT TO
     the construct-side Bloom filter of a 3 Gb genome (28.8 GB), 2e7 reads generated on the device.  Checked: a prefix
     counter by counter against the oracle's emitted keys, whole == ragged split, monotone, nothing spilled past the table."""
     import torch
@@ -171,8 +171,8 @@ def test_c5_wgs_class_single_gpu_slice():
         ctx.table_upload(keys, 27)
         info, xinfo = ctx.table_info(), ctx.ctable_info()
         assert info["n_keys"] == keys.size and info["n_slots"] >= 1 << 31
-        # the default table of this class (context table at <= 40 % load), not the fallback for a short device
-        assert xinfo["n_buckets"] * 4 * 0.41 >= xinfo["n_entries"] > keys.size and xinfo["overflow_kmers"] < keys.size // 100
+        # the default table of this class (context table at <= 30 % load), not the fallback for a short device
+        assert xinfo["n_buckets"] * 4 * 0.31 >= xinfo["n_entries"] > keys.size and xinfo["overflow_kmers"] < keys.size // 100
         free_b, total_b = ctx.device_memory()
         assert total_b - free_b > 60e9            # image + context table + Bloom really are resident together
         n_reads = 20_000_000

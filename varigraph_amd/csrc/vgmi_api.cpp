@@ -392,7 +392,7 @@ static int xtable_fill(vgmi_ctx* c, XTableView& x, const uint32_t* id_of_key)
 
 // The context table (vgmi_ctable.h), built from the compact image like the grid-16-mer table it replaces: the device orders the
 // k-mers along their unitigs (vgmi_ptable.hip's numbering, which also numbers the counters), every occurrence of a 16-mer in a
-// unitig becomes one 16-byte entry, buckets of four at <= 40 % load (VGMI_CTABLE_LOAD=percent for A/B), entries that find
+// unitig becomes one 16-byte entry, buckets of four at <= 30 % load (VGMI_CTABLE_LOAD=percent for A/B), entries that find
 // CT_HOPS + 1 buckets full send their k-mers to the exact overflow table.  VGMI_CTABLE=0 keeps the grid-16-mer table and
 // count27x_kernel of round 2 as the A/B reference.
 bool ctable_wanted(const ImageHeader& h)
@@ -449,7 +449,7 @@ int build_ctable(vgmi_ctx* c)
     }
     c->ct_unitigs = cur[1];
     c->ct_entries = n + 11 * cur[1];          // a unitig of L k-mers holds L + 11 occurrences (palindromic 16-mers: two entries, rare)
-    double load = 0.40;
+    double load = 0.30;     // measured, chr20 / whole-genome class kernel ms: 25 % 8.25 / -, 30 % 8.17 / 30.1, 40 % 8.41 / 33.4 (gpurun_out/r4c)
     if (const char* e = getenv("VGMI_CTABLE_LOAD")) load = atoi(e) >= 5 && atoi(e) <= 95 ? atoi(e) / 100.0 : load;
     uint64_t n_buckets = (uint64_t)((double)c->ct_entries / (4.0 * load)) + 1;
     size_t free_b = 0, total_b = 0;

@@ -15,6 +15,9 @@
 //     d2  R: the 11 bases behind X (22 bits, the base next to X most significant) | mask bits 10..11 << 22 | dir << 24
 //         | CT_FLAG_MORE << 25 (slot 0 of a bucket only: some entry found this bucket full and went on to the next one)
 //     d3  id0
+// A bucket of four entries is laid out for the negative probe: the four X first (16 bytes: one load says whether anything in the
+// bucket concerns this position), then the four (d1, d2, d3) triples -- fetched only for the slots whose X matched, from a line
+// that is in the vector cache by then (CtBucket).
 // Window s (0..11) of the context takes s bases of L, X, and 11 - s bases of R.  mask bit s says the unitig holds that window
 // as a k-mer, and its counter is id0 - s (dir = 0) or id0 + s (dir = 1): counters are numbered along the unitigs, so the
 // windows of one entry are neighbours.  Bases of L / R the unitig does not have are zero and no masked window uses them.
@@ -42,6 +45,10 @@
 
 struct CtEntry {
     uint32_t d0, d1, d2, d3;
+};
+struct CtBucket {                  // 64 bytes
+    uint32_t x[4];                 // d0 of the four entries, 0xFFFFFFFF = empty; slots fill in order, so x[3] set = bucket full
+    uint32_t rest[4][3];           // their (d1, d2, d3); rest[0][1] carries CT_FLAG_MORE
 };
 
 // bijection of 32 bits (bucket = (ct_hash(X) * n_buckets) >> 32)

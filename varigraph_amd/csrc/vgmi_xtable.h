@@ -146,17 +146,17 @@ __device__ __forceinline__ uint32_t ct_find(const XTableView& t, uint64_t kmer)
     ct_orient_kmer(kmer, cx, cl, cr, vs);
     const uint64_t b0 = ((uint64_t)ct_hash(cx) * t.n_buckets) >> 32;
     for (uint32_t hop = 0; hop <= CT_HOPS; ++hop) {
-        const uint4* B = t.cb + ((b0 + hop) << 2);
-        uint32_t flag = 0;
+        const uint32_t* B = reinterpret_cast<const uint32_t*>(t.cb + ((b0 + hop) << 2));
+        const uint4 xs = *reinterpret_cast<const uint4*>(B);
+        const uint32_t x[4] = {xs.x, xs.y, xs.z, xs.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint4 v = B[q];
-            if (q == 0) flag = v.z & CT_FLAG_MORE;
-            const CtEntry e = {v.x, v.y, v.z, v.w};
+            if (x[q] != cx) continue;
+            const CtEntry e = {cx, B[4 + 3 * q], B[5 + 3 * q], B[6 + 3 * q]};
             const uint32_t h = ct_match(e, cx, cl, cr) & vs;
             if (h) return ct_id(e, (uint32_t)__builtin_ctz(h));
         }
-        if (!flag) return 0xFFFFFFFFu;
+        if (xs.w == 0xFFFFFFFFu || !(B[5] & CT_FLAG_MORE)) return 0xFFFFFFFFu;      // not full, or full and nothing went on
     }
     return xt_over_find(t, kmer);
 }
