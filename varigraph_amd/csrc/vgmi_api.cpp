@@ -77,6 +77,7 @@ struct vgmi_ctx {
     TableView tv{};
     uint32_t* d_key_slot = nullptr;
     uint64_t xt_bytes_since_clamp = 0;
+    uint64_t xt_n_counts = 0;                   // counters of the grid-16-mer / context table: n_keys, or more (chains aligned to sectors)
     unsigned long long* d_xt_lines = nullptr;   // table keyed by the grid 16-mer (vgmi_xtable.hip), VGMI_XTABLE=1
     uint32_t* d_xt_counts = nullptr;
     uint32_t* d_xt_id = nullptr;                // key index -> counter id (path order), nullptr: identity
@@ -416,27 +417,41 @@ int build_ctable(vgmi_ctx* c)
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&link), n * 8);
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&link2), n * 8);
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&pos), n * 4);
-    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&mark), n * 4);
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&cursor), 32);
-    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&okmer), n * 8);
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&c->d_xt_id), n * 4);
-    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&c->d_xt_counts), n * 4);
-    if (he == hipSuccess) he = hipMemsetAsync(c->d_xt_counts, 0, n * 4, c->stream);
     if (he == hipSuccess) he = hipMemsetAsync(pos, 0xFF, n * 4, c->stream);
-    if (he == hipSuccess) he = hipMemsetAsync(mark, 0, n * 4, c->stream);
     if (he == hipSuccess) he = hipMemsetAsync(cursor, 0, 32, c->stream);
-    if (he == hipSuccess) he = launch_ptable_order(c->tv, c->d_key_slot, n, key_of_slot, link, link2, pos, cursor, mark, c->d_status, c->stream);
+    // places along the unitigs.  VGMI_CTABLE_ALIGN=16 starts every chain at a multiple of 16, so that the counters of a chain's
+    // first 16 k-mers share a 64-byte sector (a read's hits on a site: 1.8 sectors instead of 2.3) -- built, measured, no gain
+    // (chr20 class 8.62 against 8.57 ms, gpurun_out/r4d: the atomics cost per lane operation, not per sector), so places are dense
+    uint32_t align = 1;
+    if (const char* e = getenv("VGMI_CTABLE_ALIGN")) align = atoi(e) >= 1 && atoi(e) <= 64 ? (uint32_t)atoi(e) : align;
+    if (he == hipSuccess) he = launch_ptable_order(c->tv, c->d_key_slot, n, key_of_slot, link, link2, pos, cursor, nullptr, c->d_status, c->stream, align);
     unsigned long long cur[4] = {0, 0, 0, 0};
     uint32_t st = 0;
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
     if (he == hipSuccess) he = hipMemcpy(cur, cursor, 32, hipMemcpyDeviceToHost);
-    if (he == hipSuccess) he = hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost);
-    // not a permutation (cannot happen): any numbering is correct, the key index is one -- every k-mer a unitig of its own
-    const bool identity = (st & 16u) || cur[0] != n;
-    if (he == hipSuccess && (st & 16u)) {
-        st &= ~16u;
-        he = hipMemcpy(c->d_status, &st, 4, hipMemcpyHostToDevice);
+    uint64_t total = cur[0];
+    bool identity = total < n || total >= (1ULL << 31) - 16;
+    if (he == hipSuccess && !identity) {
+        he = hipMalloc(reinterpret_cast<void**>(&mark), total * 4);
+        if (he == hipSuccess) he = hipMemsetAsync(mark, 0, total * 4, c->stream);
+        if (he == hipSuccess) he = launch_ptable_check(pos, n, total, mark, c->d_status, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he == hipSuccess) he = hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost);
+        // two keys on one place (cannot happen): any numbering is correct, the key index is one -- every k-mer a unitig of its own
+        if (he == hipSuccess && (st & 16u)) {
+            identity = true;
+            st &= ~16u;
+            he = hipMemcpy(c->d_status, &st, 4, hipMemcpyHostToDevice);
+        }
     }
+    if (identity) total = n;
+    c->xt_n_counts = total;
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&okmer), total * 8);
+    if (he == hipSuccess) he = hipMemsetAsync(okmer, 0xFF, total * 8, c->stream);       // places no k-mer has: bit 63 set
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&c->d_xt_counts), total * 4);
+    if (he == hipSuccess) he = hipMemsetAsync(c->d_xt_counts, 0, total * 4, c->stream);
     if (he == hipSuccess) he = launch_ctable_okmer(c->tv, c->d_key_slot, pos, link2, n, identity, okmer, c->d_xt_id, cursor + 1, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
     if (he == hipSuccess) he = hipMemcpy(cur, cursor, 32, hipMemcpyDeviceToHost);
@@ -468,7 +483,7 @@ int build_ctable(vgmi_ctx* c)
     for (int pass = 0; he == hipSuccess && pass < 2; ++pass) {
         he = hipMalloc(reinterpret_cast<void**>(&d_list), cap * 4);
         if (he == hipSuccess) he = hipMemsetAsync(cursor + 2, 0, 16, c->stream);
-        if (he == hipSuccess) he = launch_ctable_build(x, okmer, n, d_list, (uint32_t)cap, cursor + 2, cursor + 3, c->stream);
+        if (he == hipSuccess) he = launch_ctable_build(x, okmer, total, d_list, (uint32_t)cap, cursor + 2, cursor + 3, c->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         if (he == hipSuccess) he = hipMemcpy(cur, cursor, 32, hipMemcpyDeviceToHost);
         n_over = cur[2];
@@ -524,6 +539,7 @@ int build_xtable(vgmi_ctx* c)
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xt_lines), (size_t)128 * (n_lines + XT_HOPS)));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xt_counts), h.n_keys * 4));
     HIPCHK(c, hipMemsetAsync(c->d_xt_counts, 0, h.n_keys * 4, c->stream));
+    c->xt_n_counts = h.n_keys;
     x.lines = c->d_xt_lines;
     x.counts = c->d_xt_counts;
     int rc = xtable_fill(c, x, nullptr);
@@ -734,7 +750,7 @@ int xt_clamp_if_due(vgmi_ctx* c, size_t n_bytes, hipStream_t st)
             due = true;
         }
     }
-    if (due) HIPCHK(c, launch_xclamp(c->tv.xt, c->hdr.n_keys, st));
+    if (due) HIPCHK(c, launch_xclamp(c->tv.xt, c->xt_n_counts, st));
     return VGMI_OK;
 }
 
@@ -1299,7 +1315,7 @@ int vgmi_counts_reset(vgmi_ctx* c)
     if (rc) return rc;
     rc = collect_timing(c);
     if (rc) return rc;
-    if (c->tv.xt.counts) HIPCHK(c, hipMemsetAsync(c->d_xt_counts, 0, c->hdr.n_keys * 4, c->stream));
+    if (c->tv.xt.counts) HIPCHK(c, hipMemsetAsync(c->d_xt_counts, 0, c->xt_n_counts * 4, c->stream));
     if (c->d_counts) HIPCHK(c, hipMemsetAsync(c->d_counts, 0, c->n_counts * 4, c->stream));
     if (!c->tv.xt.counts && (!c->d_counts || c->tv.slots8)) HIPCHK(c, launch_counts_reset(c->tv, c->stream));   // in-slot counters / saturation flags
     if (c->tv.pt.SB) HIPCHK(c, hipMemsetAsync(c->d_pt_SB, 0, c->pt_sb_bytes, c->stream));                       // ... and their copies in the path table

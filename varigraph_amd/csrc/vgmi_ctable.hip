@@ -16,7 +16,7 @@
 
 namespace vgk {
 
-#define CT_RUNQ 320u            // run ring per wavefront (records of 8 bytes): a row adds <= 256, a drain step takes 5
+#define CT_RUNQ 256u            // run ring per wavefront (records of 8 bytes): a row adds <= 256, a drain step takes 5
 #define CT_PENDQ 128u           // contexts that go on to a next bucket (16 bytes): a row or a batch adds <= 64, a batch takes 64 once 64 wait
 #define CT_NONE 0xFFFFFFFFu
 #define CT_MASK54 ((1ULL << 54) - 1)
@@ -69,7 +69,7 @@ __global__ void ct_identity_kernel(uint32_t* pos_of_key, uint64_t n)
     if (i < n) pos_of_key[i] = (uint32_t)i | 1u << 31;
 }
 
-// one thread per (place p, offset o of X in the k-mer): the pair leads an occurrence iff o == 11 or the k-mer is the first of its
+// one thread per (place p of the numbering, offset o of X in the k-mer): the pair leads an occurrence iff o == 11 or the k-mer is the first of its
 // unitig.  An entry that finds its home bucket and the CT_HOPS buckets behind it full sends the k-mers of its windows to the exact
 // overflow table (their places go on over_list); every full bucket it passed is marked, so a lookup follows the same trail.
 __global__ void ct_insert_kernel(XTableView t, const unsigned long long* okmer, uint64_t n, uint32_t* over_list, uint32_t over_cap,
@@ -80,6 +80,7 @@ __global__ void ct_insert_kernel(XTableView t, const unsigned long long* okmer, 
     const uint64_t p = g / 12;
     const uint32_t o = (uint32_t)(g - p * 12);
     const unsigned long long ok = okmer[p];
+    if (ok >> 63) return;                  // a place no k-mer has (chains start at multiples of 16)
     const bool first = (ok >> 54) & 1ULL;
     if (o != 11u && !first) return;
     const uint32_t rem = (uint32_t)(ok >> 55) & 15u;
@@ -175,7 +176,7 @@ hipError_t launch_ctable_over(ulonglong2* over, uint32_t over_mask, const unsign
 // windows still open, hop, next bucket} instead, and the wavefront looks 64 queued items up at a time, all lanes busy, one round
 // trip per batch; an item that meets another marked bucket is queued again, one that has seen CT_HOPS + 1 of them asks the exact
 // overflow table.
-__global__ __launch_bounds__(256, 7) void count27c_kernel(RowParams p, XTableView xt)
+__global__ __launch_bounds__(256, 8) void count27c_kernel(RowParams p, XTableView xt)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[2048];     // position LUT of count27_kernel (stage_lut27 layout)
     __shared__ __attribute__((aligned(16))) uint2 s_runs[4][CT_RUNQ];
@@ -218,7 +219,9 @@ __global__ __launch_bounds__(256, 7) void count27c_kernel(RowParams p, XTableVie
 
     // A drain step turns up to 5 queued runs {id0, hit windows | dir << 12} into counter updates, a lane per (run, window): the
     // hits of a run -- and of the runs queued next to it, which continue the same unitig -- are neighbours in the counter array
-    // and leave as one or two atomic requests.  No return value: nothing waits for them.
+    // and leave as one or two atomic requests.  No return value: nothing waits for them.  (Tried and dropped, gpurun_out/r4d, r4e:
+    // chains of counters aligned to 64-byte sectors -- 8.62 against 8.57 ms at chr20 class; a lane per aligned PAIR of counters and
+    // one 64-bit add for both -- 9.23 against 8.31 ms, whole-genome class 34.5 against 29.7.)
     auto drain = [&]() {
         const uint32_t take = run_n < 5u ? run_n : 5u;
         const bool have = my_run < take;
@@ -372,7 +375,12 @@ __global__ __launch_bounds__(256, 7) void count27c_kernel(RowParams p, XTableVie
 
 hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t n_cu, hipStream_t st)
 {
-    hipLaunchKernelGGL(count27c_kernel, dim3(n_cu * 7), dim3(256), 0, st, p, t);
+    static const uint32_t wgs = [] {      // workgroups per CU (20 KB of LDS each: 8 fit); VGMI_CT_WGS for A/B
+        const char* e = getenv("VGMI_CT_WGS");
+        const int v = e ? atoi(e) : 6;      // measured, chr20 class kernel ms: 5 8.96, 6 8.31, 7 8.50, 8 8.62 (gpurun_out/r4d)
+        return (uint32_t)(v < 1 ? 1 : v > 8 ? 8 : v);
+    }();
+    hipLaunchKernelGGL(count27c_kernel, dim3(n_cu * wgs), dim3(256), 0, st, p, t);
     return hipGetLastError();
 }
 

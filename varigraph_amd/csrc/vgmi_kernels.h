@@ -215,7 +215,7 @@ hipError_t launch_xtable_number(const XTableView& t, const unsigned long long* s
 hipError_t launch_count27x(const RowParams& p, const XTableView& t, uint32_t grid, hipStream_t st);
 hipError_t launch_ctable_okmer(const TableView& t, const uint32_t* key_slot, uint32_t* pos_of_key, const uint32_t* link2, uint64_t n, bool identity,
                                unsigned long long* okmer, uint32_t* id_of_key, unsigned long long* n_unitigs, hipStream_t st);
-hipError_t launch_ctable_build(const XTableView& t, const unsigned long long* okmer, uint64_t n, uint32_t* over_list, uint32_t over_cap,
+hipError_t launch_ctable_build(const XTableView& t, const unsigned long long* okmer, uint64_t n_places, uint32_t* over_list, uint32_t over_cap,
                                unsigned long long* over_n, unsigned long long* n_moved, hipStream_t st);
 hipError_t launch_ctable_over(ulonglong2* over, uint32_t over_mask, const unsigned long long* okmer, const uint32_t* over_list, uint64_t n_over,
                               hipStream_t st);
@@ -227,7 +227,8 @@ hipError_t launch_xcounts_xfer(const XTableView& t, const uint32_t* id_of_key, u
 hipError_t launch_count27(bool lds_bitmap, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t launch_count27s(const RowParams& p, uint32_t grid, hipStream_t st);   // small graphs: 12-mer grid, 1 024-byte rows
 hipError_t launch_ptable_order(const TableView& t, const uint32_t* key_slot, uint64_t n, uint32_t* key_of_slot, uint32_t* link, uint32_t* link2,
-                               uint32_t* pos_of_key, unsigned long long* cursor, uint32_t* mark, uint32_t* status, hipStream_t st);
+                               uint32_t* pos_of_key, unsigned long long* cursor, uint32_t* mark, uint32_t* status, hipStream_t st, uint32_t align = 1);
+hipError_t launch_ptable_check(const uint32_t* pos_of_key, uint64_t n, uint64_t total, uint32_t* mark, uint32_t* status, hipStream_t st);
 hipError_t launch_ptable_fill(const TableView& t, const uint32_t* key_slot, const uint32_t* pos_of_key, uint64_t n, ulonglong2* P, hipStream_t st);
 hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t launch_bloom_even(const RowParams& p, hipStream_t st);   // even k, one long sequence (K3)

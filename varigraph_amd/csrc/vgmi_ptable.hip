@@ -90,7 +90,7 @@ __global__ void pt_mutual_kernel(const uint32_t* link, uint32_t* link2, uint64_t
 
 // one thread per (key, side) that is a chain end on that side: the end with the smaller key index lays the chain out.
 // pos_of_key[i] = place in P's first half | (the walk reads the canonical k-mer as it stands) << 31
-__global__ void pt_walk_kernel(const uint32_t* link2, uint64_t n, uint32_t* pos_of_key, unsigned long long* cursor)
+__global__ void pt_walk_kernel(const uint32_t* link2, uint64_t n, uint32_t* pos_of_key, unsigned long long* cursor, uint32_t align)
 {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= 2 * n) return;
@@ -107,7 +107,8 @@ __global__ void pt_walk_kernel(const uint32_t* link2, uint64_t n, uint32_t* pos_
     }
     const bool own = start < cur || (start == cur && (s0 == 0u || link2[2ull * start] != PT_NONE));
     if (!own || len > n) return;
-    const uint64_t base = atomicAdd(cursor, (unsigned long long)len);
+    // (align > 1: every chain starts at a multiple of it -- the context table's counters, a chain's first 16 in one 64-byte sector)
+    const uint64_t base = atomicAdd(cursor, (unsigned long long)((len + align - 1) / align * align));
     cur = start;
     out = s0 ^ 1u;
     for (uint64_t pos = 0; pos < len; ++pos) {
@@ -126,13 +127,14 @@ __global__ void pt_rest_kernel(uint64_t n, uint32_t* pos_of_key, unsigned long l
     if (pos_of_key[i] == PT_NONE) pos_of_key[i] = (uint32_t)atomicAdd(cursor, 1ULL) | 1u << 31;    // keys on cycles: chains of one
 }
 
-// every place in [0, n) exactly once?  (status bit 16 otherwise: the caller then lays the keys out by key index, chains of one)
-__global__ void pt_check_kernel(const uint32_t* pos_of_key, uint64_t n, uint32_t* mark, uint32_t* status)
+// every key a place of its own in [0, total)?  (total = n: a permutation.  status bit 16 otherwise: the caller then lays the keys
+// out by key index, chains of one)
+__global__ void pt_check_kernel(const uint32_t* pos_of_key, uint64_t n, uint64_t total, uint32_t* mark, uint32_t* status)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t pos = pos_of_key[i] & 0x7FFFFFFFu;
-    if (pos >= n || atomicAdd(&mark[pos], 1u) != 0u) atomicOr(status, 16u);
+    if (pos >= total || atomicAdd(&mark[pos], 1u) != 0u) atomicOr(status, 16u);
 }
 
 __global__ void pt_fill_kernel(TableView t, const uint32_t* key_slot, const uint32_t* pos_of_key, uint64_t n, ulonglong2* P)
@@ -148,17 +150,25 @@ __global__ void pt_fill_kernel(TableView t, const uint32_t* key_slot, const uint
     P[2 * n - 1 - pos] = make_ulonglong2(as_is ? R : K, slot);
 }
 
+// mark == nullptr: no check here (a caller that aligns the chains checks with launch_ptable_check once it knows the total)
 hipError_t launch_ptable_order(const TableView& t, const uint32_t* key_slot, uint64_t n, uint32_t* key_of_slot, uint32_t* link, uint32_t* link2,
-                               uint32_t* pos_of_key, unsigned long long* cursor, uint32_t* mark, uint32_t* status, hipStream_t st)
+                               uint32_t* pos_of_key, unsigned long long* cursor, uint32_t* mark, uint32_t* status, hipStream_t st, uint32_t align)
 {
     if (n == 0) return hipSuccess;
     const uint32_t g2 = (uint32_t)((2 * n + 255) / 256), g1 = (uint32_t)((n + 255) / 256);
     hipLaunchKernelGGL(pt_key_of_slot_kernel, dim3(g1), dim3(256), 0, st, key_slot, n, key_of_slot);
     hipLaunchKernelGGL(pt_links_kernel, dim3(g2), dim3(256), 0, st, t, key_slot, key_of_slot, n, link);
     hipLaunchKernelGGL(pt_mutual_kernel, dim3(g2), dim3(256), 0, st, link, link2, n);
-    hipLaunchKernelGGL(pt_walk_kernel, dim3(g2), dim3(256), 0, st, link2, n, pos_of_key, cursor);
+    hipLaunchKernelGGL(pt_walk_kernel, dim3(g2), dim3(256), 0, st, link2, n, pos_of_key, cursor, align ? align : 1u);
     hipLaunchKernelGGL(pt_rest_kernel, dim3(g1), dim3(256), 0, st, n, pos_of_key, cursor);
-    hipLaunchKernelGGL(pt_check_kernel, dim3(g1), dim3(256), 0, st, pos_of_key, n, mark, status);
+    if (mark) hipLaunchKernelGGL(pt_check_kernel, dim3(g1), dim3(256), 0, st, pos_of_key, n, n, mark, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_ptable_check(const uint32_t* pos_of_key, uint64_t n, uint64_t total, uint32_t* mark, uint32_t* status, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pt_check_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, pos_of_key, n, total, mark, status);
     return hipGetLastError();
 }
 
