@@ -159,7 +159,7 @@ struct Model {
                                 placed = true;
                                 n_moved += hop != 0;
                             }
-                        if (!placed) B.rest[0][1] |= CT_FLAG_MORE;
+                        if (!placed) B.rest[0][1] |= ct_mark(e[q].d0);
                     }
                     if (!placed)
                         for (uint32_t j = 0; j < n_win; ++j) {
@@ -199,7 +199,7 @@ struct Model {
                     ++counts[ct_id(e, s)];
                 }
             }
-            const bool more = B.x[3] != 0xFFFFFFFFu && (B.rest[0][1] & CT_FLAG_MORE) && (vs & ~found);
+            const bool more = B.x[3] != 0xFFFFFFFFu && (B.rest[0][1] & ct_mark(cx)) && (vs & ~found);
             if (more && hop == CT_HOPS) {
                 uint32_t rest = vs & ~found;
                 while (rest) {
@@ -227,7 +227,7 @@ struct Model {
                 const uint32_t h = ct_match(e, cx, cl, cr) & vs;
                 if (h) return ct_id(e, ct_ctz(h));
             }
-            if (B.x[3] == 0xFFFFFFFFu || !(B.rest[0][1] & CT_FLAG_MORE)) return NONE;
+            if (B.x[3] == 0xFFFFFFFFu || !(B.rest[0][1] & ct_mark(cx))) return NONE;
         }
         return over_find(kmer);
     }

@@ -13,7 +13,9 @@
 //     d0  X, canonical (32 bits; 0xFFFFFFFF cannot be canonical: the slot is empty)
 //     d1  L: the 11 bases in front of X (22 bits, the base next to X least significant) | mask bits 0..9 << 22
 //     d2  R: the 11 bases behind X (22 bits, the base next to X most significant) | mask bits 10..11 << 22 | dir << 24
-//         | CT_FLAG_MORE << 25 (slot 0 of a bucket only: some entry found this bucket full and went on to the next one)
+//         | marks in bits 26..31 (slot 0 of a bucket only): an entry that found this bucket full and went on to the next one set
+//           bit 26 + ct_mark(X) -- a position goes on only if the bit of ITS X is set (six bits: five in six of the positions that
+//           meet a full bucket with one displaced entry stop there)
 //     d3  id0
 // A bucket of four entries is laid out for the negative probe: the four X first (16 bytes: one load says whether anything in the
 // bucket concerns this position), then the four (d1, d2, d3) triples -- fetched only for the slots whose X matched, from a line
@@ -39,7 +41,7 @@
 #include "vgmi_device.h"
 
 #define CT_HOPS 7u                 // an entry sits in its home bucket or one of the CT_HOPS buckets behind it
-#define CT_FLAG_MORE (1u << 25)
+#define CT_MARKS 0xFC000000u
 #define CT_DIR (1u << 24)
 #define CT_M22 0x3FFFFFu
 
@@ -48,7 +50,7 @@ struct CtEntry {
 };
 struct CtBucket {                  // 64 bytes
     uint32_t x[4];                 // d0 of the four entries, 0xFFFFFFFF = empty; slots fill in order, so x[3] set = bucket full
-    uint32_t rest[4][3];           // their (d1, d2, d3); rest[0][1] carries CT_FLAG_MORE
+    uint32_t rest[4][3];           // their (d1, d2, d3); rest[0][1] carries the marks
 };
 
 // bijection of 32 bits (bucket = (ct_hash(X) * n_buckets) >> 32)
@@ -60,6 +62,9 @@ VG_HD uint32_t ct_hash(uint32_t cx)
     h ^= h >> 13;
     return h;
 }
+
+// which of the six marks of a full bucket an entry with this X sets when it goes on (the low half of the hash; the bucket comes from the top)
+VG_HD uint32_t ct_mark(uint32_t cx) { return 1u << (26u + (((ct_hash(cx) & 0xFFFFu) * 6u) >> 16)); }
 
 VG_HD uint32_t ct_rc11(uint32_t x) { return vg_revcomp16(x) >> 10; }      // 11 bases in the low 22 bits
 VG_HD uint32_t ct_rev12(uint32_t m)                                        // bit s -> bit 11 - s

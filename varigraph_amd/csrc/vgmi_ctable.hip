@@ -102,7 +102,7 @@ __global__ void ct_insert_kernel(XTableView t, const unsigned long long* okmer, 
                     placed = true;
                     if (hop) atomicAdd(n_moved, 1ULL);
                 }
-            if (!placed) atomicOr(&B[5], CT_FLAG_MORE);
+            if (!placed) atomicOr(&B[5], ct_mark(e[q].d0));
         }
         if (!placed) {
             const unsigned long long pos = atomicAdd(over_n, (unsigned long long)n_win);
@@ -219,9 +219,10 @@ __global__ __launch_bounds__(256, 8) void count27c_kernel(RowParams p, XTableVie
 
     // A drain step turns up to 5 queued runs {id0, hit windows | dir << 12} into counter updates, a lane per (run, window): the
     // hits of a run -- and of the runs queued next to it, which continue the same unitig -- are neighbours in the counter array
-    // and leave as one or two atomic requests.  No return value: nothing waits for them.  (Tried and dropped, gpurun_out/r4d, r4e:
-    // chains of counters aligned to 64-byte sectors -- 8.62 against 8.57 ms at chr20 class; a lane per aligned PAIR of counters and
-    // one 64-bit add for both -- 9.23 against 8.31 ms, whole-genome class 34.5 against 29.7.)
+    // and leave as one or two atomic requests.  No return value: nothing waits for them.  (Built, measured on the same box and
+    // dropped -- the plain form is the fastest: chains of counters aligned to 64-byte sectors 8.62 against 8.57 ms at chr20 class
+    // (gpurun_out/r4d); a lane per aligned PAIR of counters and one 64-bit add for both 9.19 = 9.19 (r4g); counters as a difference
+    // array over the places -- +1 / -1 at the two ends of a stretch of hits, prefix sums at read-out -- 8.82 against 8.44 (r4i).)
     auto drain = [&]() {
         const uint32_t take = run_n < 5u ? run_n : 5u;
         const bool have = my_run < take;
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256, 8) void count27c_kernel(RowParams p, XTableVie
             __builtin_amdgcn_wave_barrier();
         }
         found = h0 | h1 | h2 | h3;
-        marked = full && (c0.d2 & CT_FLAG_MORE);
+        marked = full && (c0.d2 & ct_mark(cx));
     };
     // queue the contexts that go on: {X, L | open windows 0..9 << 22, R | open windows 10..11 << 22 | hop << 24, bucket}
     auto push = [&](bool on, uint32_t cx, uint32_t cl, uint32_t cr, uint32_t open, uint32_t hop, uint32_t bucket) {

@@ -156,7 +156,7 @@ __device__ __forceinline__ uint32_t ct_find(const XTableView& t, uint64_t kmer)
             const uint32_t h = ct_match(e, cx, cl, cr) & vs;
             if (h) return ct_id(e, (uint32_t)__builtin_ctz(h));
         }
-        if (xs.w == 0xFFFFFFFFu || !(B[5] & CT_FLAG_MORE)) return 0xFFFFFFFFu;      // not full, or full and nothing went on
+        if (xs.w == 0xFFFFFFFFu || !(B[5] & ct_mark(cx))) return 0xFFFFFFFFu;      // not full, or full and nothing with this mark went on
     }
     return xt_over_find(t, kmer);
 }
