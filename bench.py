@@ -557,6 +557,7 @@ def main():
                   "value": world * n3 * args.c3_steps / el3, "unit": "reads/s", "steps": args.c3_steps,
                   "ms_per_step": el3 / args.c3_steps * 1e3, "graph_kmers": info3["n_keys"], "table_slots": info3["n_slots"],
                   "graph_build_s": t_g, "table_broadcast": bcast_c3,
+                  "context_table": ctx.ctable_info() if ctx.ctable_info()["n_buckets"] else None,
                   "hits_per_read": hits3, "keys_saturated": int((cov3 == 255).sum()),
                   "roofline": {"bound": "hbm", "achieved": ach3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach3 / HBM_PEAK_GBS, "traffic": tr3,

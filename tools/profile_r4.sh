@@ -16,7 +16,7 @@ for pm in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC
           "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum" \
           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU"; do
   i=$((i+1))
-  timeout 900 rocprofv3 --pmc $pm -d $OUT/pmc_$i -o r4 -- python3 $A > $OUT/b$i.json 2> $OUT/e$i.log
+  timeout 900 rocprofv3 --kernel-include-regex "count27" --pmc $pm -d $OUT/pmc_$i -o r4 -- python3 $A > $OUT/b$i.json 2> $OUT/e$i.log
 done
 python3 tools/rocprof_summary.py $OUT > $OUT/summary.txt
 find $OUT -name "*.db" -delete
