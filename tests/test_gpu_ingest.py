@@ -100,6 +100,34 @@ def _count(g, ctx, paths, host_parse, chunk_kb=None):
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("gz", [False, True], ids=["plain", "gzip"])
+def test_named_pipe_input_equals_file_input(gz, graph_ctx, tmp_path):
+    """The reference reads whatever gzopen opens -- a named pipe, `<(zcat x.gz)` -- in one pass (include/kseq.h:59-72,
+    src/fastq_kmer.cpp:74-78).  A non-seekable input takes the host reader from its first byte; same counters as the file."""
+    import gzip as _gz
+    import threading
+    g, ctx, cohort = graph_ctx
+    text = _fastq(_reads(3000, 77))
+    data = _gz.compress(text, 4) if gz else text
+    p = tmp_path / ("x.fq.gz" if gz else "x.fq")
+    p.write_bytes(data)
+    want = _count(g, ctx, [str(p)], host_parse=False)
+    fifo = str(tmp_path / "pipe.fq")
+    os.mkfifo(fifo)
+
+    def feed():
+        with open(fifo, "wb") as f:
+            f.write(data)
+    t = threading.Thread(target=feed)
+    t.start()
+    try:
+        got = _count(g, ctx, [fifo], host_parse=False)
+    finally:
+        t.join()
+    assert want["n_reads"] == 3000 and got["n_reads"] == 3000
+    assert np.array_equal(got["cov"], want["cov"]) and got["read_base"] == want["read_base"]
+
+
 @pytest.mark.parametrize("name", sorted(_cases()))
 def test_device_parser_equals_host_reader(name, graph_ctx, tmp_path):
     g, ctx, cohort = graph_ctx

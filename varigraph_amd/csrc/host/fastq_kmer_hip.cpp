@@ -158,6 +158,15 @@ DeviceFileResult device_file(vgmi_ctx* ctx, const std::string& path, size_t bloc
     if (fstat(fd, &sb) != 0) { ::close(fd); throw std::runtime_error("'" + path + "': cannot stat"); }
     const uint64_t file_size = (uint64_t)sb.st_size;
     struct FdGuard { int fd; ~FdGuard() { if (fd >= 0) ::close(fd); } } guard{fd};
+    // A named pipe or `<(zcat ...)` (the reference reads whatever gzopen opens, include/kseq.h:59-72): one pass, no offsets, so
+    // neither the side-by-side readers nor a host reader resuming in the middle apply -- the host reader takes the whole stream.
+    if (!S_ISREG(sb.st_mode)) {
+        ::close(guard.fd);
+        guard.fd = -1;
+        FastxReader rd(ByteSource::open(path, threads));
+        host_leg(ctx, rd, path, block_bytes, submit_mu, res.n_reads, res.read_base);
+        return res;
+    }
 
     // block gzip?  (the first member carries the 'BC' extra subfield: bgzip, htslib)
     bool bgzf = false;

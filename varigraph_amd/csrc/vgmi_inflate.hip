@@ -8,12 +8,16 @@
 // or CRC-32 (RFC 1952) -- is reported, the chunk is cut in front of it and the host decoder (csrc/host/fast_inflate.cpp,
 // pinned against zlib) takes the stream over there; nothing the device emits is unchecked.
 //
-// Shape of the kernel: DEFLATE decoding is serial inside a member, so the wavefront runs it as ONE scalar-like thread --
-// every quantity of the decoder (bit buffer, positions, the decoded symbol) is wave-uniform and lives in SGPRs; the 64
-// lanes do what can be wide: Huffman table construction, LZ77 copies (a match of length n from distance d is the
-// periodic extension of the d bytes before it, so lane i writes byte i from out[pos - d + i % d] -- no lane depends
-// on another), and the CRC-32 of the result (one slice per lane, combined with GF(2) arithmetic).  Thousands of members
-// are in flight per chunk; the kernel's rate is set by how many, not by one member's latency.
+// Shape of the kernel (round 4).  DEFLATE decoding is serial inside a member: where a symbol starts is known only once the
+// symbol before it is decoded.  Rounds 2-3 ran that chain one look-up at a time in scalar registers (one LDS round trip and
+// ~14 scalar instructions per one to three output bytes: latency-bound at 58 cycles per byte and SIMD).  Now a BATCH of 64 bit
+// positions is decoded at once: lane i decodes the symbol that would start at bit (position + i) -- one gather from the
+// literal/length table (entries hold up to three literals), one from the distance table -- and only then a short scalar walk
+// hops from symbol start to symbol start over the lanes' results (one v_readlane per symbol), handing every real symbol its
+// output offset.  Literals of the whole batch are written in one step; matches are copied one after the other, each copy
+// 64 bytes wide (a match of length n from distance d is the periodic extension of the d bytes before it).  Output goes to a
+// 2 KiB LDS ring (the LZ77 window for near matches) and leaves for global memory in aligned 256-byte blocks.  Codes longer
+// than the tables' index, stored blocks and block headers take a scalar path, one symbol at a time.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,45 +28,50 @@ namespace vgk {
 #define INF_LIT_BITS 10u
 #define INF_DIST_BITS 8u
 #define INF_MAXBITS 15
-#define INF_RING 2048u
+#define INF_RING 2048u          // bytes of output kept in LDS (a power of two)
+#define INF_BATCH_OUT 384u      // a batch stops taking symbols once it has produced this much
+#define INF_NEAR 1280u          // matches up to this far back read the ring (INF_NEAR + INF_BATCH_OUT < INF_RING: a batch's literals, written
+                                // first, never land on a source); farther ones read global memory, where everything older than the
+                                // 258 unflushed bytes already is (INF_NEAR - 258 > INF_BATCH_OUT + 258)
+#define INF_WAVES 4u            // wavefronts per workgroup (8.3 KB of LDS each: four workgroups = 16 wavefronts per CU)
 
 struct InfTables {                 // per wavefront, in LDS
-    uint32_t multi[1u << INF_LIT_BITS];   // up to three LITERALS decoded from the same index: bytes 0..2 | count << 24 | bits << 26
-    uint16_t lit[1u << INF_LIT_BITS];     // entry: symbol << 4 | code length (0 = code longer than INF_LIT_BITS or unused)
-    uint16_t dist[1u << INF_DIST_BITS];
+    uint32_t lit[1u << INF_LIT_BITS];     // while a table is built: symbol << 4 | code length (0: code longer than the index / unused);
+                                          // then packed (inf_pack_lit): bits 0..3 code bits taken, 4..5 kind (0 literals, 1 length, 2 end of block),
+                                          // literals: 6..7 how many (1..3), 8..31 the bytes; length: 6..8 extra bits, 9..17 base length
+    uint32_t dist[1u << INF_DIST_BITS];   // built likewise (also serves the code-length alphabet); packed: 0..3 code bits, 4..7 extra bits, 8..22 base
     uint8_t len[320];              // code lengths: 0..287 literal/length, 288..319 distance
     uint16_t sorted[320];          // symbols ordered by code (canonical decoding of the long codes)
     uint16_t count[2][INF_MAXBITS + 1];
     uint16_t offs[2][INF_MAXBITS + 1];
-    uint8_t ring[INF_RING];        // the last INF_RING output bytes: LZ77 sources come from here, not from global memory --
-                                   // a global read-back would wait (vmcnt) for every store still in flight
-    uint8_t pad[64];               // where the lanes that have no byte of a literal run write theirs
+    uint8_t ring[INF_RING];        // output byte p at ring[p % INF_RING]
+    uint8_t pad[64];
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-__device__ __forceinline__ uint64_t uni64(uint64_t v) { return (uint64_t)uni((uint32_t)(v >> 32)) << 32 | uni((uint32_t)v); }
-// The compressed input is read with SCALAR loads (constant address space, wave-uniform address): they count on lgkmcnt,
-// so a refill never waits behind the byte stores of the output (a vector load's vmcnt(0) drained every store in flight:
-// one memory round trip per 8 input bytes, most of the kernel's time in its first version)
-typedef __attribute__((address_space(4))) const uint64_t inf_cu64;
-__device__ __forceinline__ uint64_t ld64u(const uint64_t* p) { return *reinterpret_cast<inf_cu64*>((uintptr_t)p); }
+// The block headers and the one-symbol path read the input with SCALAR loads (constant address space, wave-uniform address)
 typedef __attribute__((address_space(4))) const uint32_t inf_cu32;
 __device__ __forceinline__ uint32_t ld32u(const uint32_t* p) { return *reinterpret_cast<inf_cu32*>((uintptr_t)p); }
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t code, uint32_t len) { return __builtin_bitreverse32(code) >> (32 - len); }
+
+__device__ __forceinline__ void inf_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 // Canonical Huffman tables of one alphabet from its code lengths (RFC 1951 3.2.2).  which: 0 literal/length, 1 distance.
 // Returns false for an over-subscribed set of lengths (incomplete sets are legal only in the one-code cases zlib accepts;
 // a code that is never assigned simply never matches and ends in the error path).
 __device__ bool inf_build(InfTables& t, uint32_t which, uint32_t first, uint32_t n, uint32_t lane)
 {
-    uint16_t* const tab = which ? t.dist : t.lit;
+    uint32_t* const tab = which ? t.dist : t.lit;
     const uint32_t bits = which ? INF_DIST_BITS : INF_LIT_BITS;
     for (uint32_t i = lane; i < (1u << bits); i += 64) tab[i] = 0;
     if (lane <= INF_MAXBITS) t.count[which][lane] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    inf_sync();
     // the counting and the canonical order are a few hundred steps: one lane
     uint32_t ok = 1;
     if (lane == 0) {
@@ -86,8 +95,7 @@ __device__ bool inf_build(InfTables& t, uint32_t which, uint32_t first, uint32_t
         }
     }
     ok = uni(ok);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    inf_sync();
     if (!ok) return false;
     // fast table: every code of at most `bits` bits, replicated over the unused high index bits -- one symbol per lane
     // (its canonical code = first code of its length + its rank among the symbols of that length)
@@ -106,32 +114,65 @@ __device__ bool inf_build(InfTables& t, uint32_t which, uint32_t first, uint32_t
         const uint32_t l = t.len[first + s];
         if (l > bits) continue;
         const uint32_t code = first_code[l] + (r - t.offs[which][l]);
-        const uint16_t e = (uint16_t)(s << 4 | l);
+        const uint32_t e = s << 4 | l;
         for (uint32_t i = bitrev(code, l); i < (1u << bits); i += 1u << l) tab[i] = e;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    inf_sync();
     return true;
 }
 
-// Sequence lines are runs of literals with 2-3 bit codes: one lookup yields as many literals as the index holds whole
-// codes of (at most three).  Built from the single-symbol table: entry i = the literals coded by the low bits of i.
-__device__ void inf_build_multi(InfTables& t, uint32_t lane)
+// symbol << 4 | length  ->  what a lane of a batch needs in one word.  Sequence lines are runs of literals with 2-3 bit codes:
+// an entry holds as many literals as the index has whole codes of (at most three).  Every lane reads its sixteen entries (and
+// the entries their remaining index bits select) before any is rewritten.
+__device__ void inf_pack_lit(InfTables& t, uint32_t lane)
 {
-    for (uint32_t i = lane; i < (1u << INF_LIT_BITS); i += 64) {
-        uint32_t pos = 0, n = 0, bytes = 0;
-        while (n < 3) {
-            const uint32_t e = t.lit[i >> pos];          // the bits above the index are unknown: only codes that fit count
-            const uint32_t l = e & 15u, sym = e >> 4;
-            if (!l || l > INF_LIT_BITS - pos || sym >= 256) break;
-            bytes |= sym << (8 * n);
-            ++n;
-            pos += l;
+    uint32_t out[(1u << INF_LIT_BITS) / 64];
+#pragma unroll
+    for (uint32_t j = 0; j < (1u << INF_LIT_BITS) / 64; ++j) {
+        const uint32_t i = lane + 64 * j;
+        const uint32_t e = t.lit[i], l = e & 15u, sym = e >> 4;
+        uint32_t r = 0;
+        if (l && sym < 256) {
+            uint32_t pos = l, n = 1, bytes = sym;
+            while (n < 3) {
+                const uint32_t e2 = t.lit[i >> pos];          // the bits above the index are unknown: only codes that fit count
+                const uint32_t l2 = e2 & 15u, s2 = e2 >> 4;
+                if (!l2 || l2 > INF_LIT_BITS - pos || s2 >= 256) break;
+                bytes |= s2 << (8 * n);
+                ++n;
+                pos += l2;
+            }
+            r = pos | n << 6 | bytes << 8;
+        } else if (l && sym == 256) {
+            r = l | 2u << 4;
+        } else if (l && sym - 257 < 29) {
+            // length codes 257..285 (RFC 1951 3.2.5) in closed form
+            const uint32_t c = sym - 257;
+            const uint32_t eb = c < 8 || c == 28 ? 0u : (c >> 2) - 1u;
+            const uint32_t base = c < 8 ? 3u + c : c == 28 ? 258u : ((4u + (c & 3u)) << eb) + 3u;
+            r = l | 1u << 4 | eb << 6 | base << 9;
         }
-        t.multi[i] = bytes | n << 24 | pos << 26;
+        out[j] = r;       // (0: a code longer than the index, an unused code, a reserved symbol -- the one-symbol path decides)
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    inf_sync();
+#pragma unroll
+    for (uint32_t j = 0; j < (1u << INF_LIT_BITS) / 64; ++j) t.lit[lane + 64 * j] = out[j];
+    inf_sync();
+}
+
+__device__ void inf_pack_dist(InfTables& t, uint32_t lane)
+{
+    for (uint32_t i = lane; i < (1u << INF_DIST_BITS); i += 64) {
+        const uint32_t e = t.dist[i], l = e & 15u, sym = e >> 4;
+        uint32_t r = 0;
+        if (l && sym < 30) {
+            const uint32_t eb = sym < 4 ? 0u : (sym >> 1) - 1u;
+            const uint32_t base = sym < 4 ? 1u + sym : ((2u + (sym & 1u)) << eb) + 1u;
+            r = l | eb << 4 | base << 8;
+        }
+        t.dist[i] = r;
+    }
+    inf_sync();
 }
 
 // a code longer than the fast table: canonical decoding bit by bit (RFC 1951 3.2.2; rare by construction)
@@ -179,17 +220,17 @@ __device__ __forceinline__ uint32_t gf2_x8n(uint32_t n)
 
 // One member per wavefront.  status[m]: 0 = good, else the reason (1 code lengths, 2 bad symbol / distance, 3 output or
 // input overrun, 4 length != ISIZE, 5 CRC-32, 6 stored-block header, 7 reserved block type).
-__global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const BgzfMember* __restrict__ members, uint32_t n_members,
-                                                           uint8_t* __restrict__ out_base, uint32_t* __restrict__ status,
-                                                           const uint32_t* __restrict__ crc_table)
+__global__ __launch_bounds__(64 * INF_WAVES, 4) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const BgzfMember* __restrict__ members, uint32_t n_members,
+                                                                     uint8_t* __restrict__ out_base, uint32_t* __restrict__ status,
+                                                                     const uint32_t* __restrict__ crc_table)
 {
-    __shared__ InfTables tabs[4];
+    __shared__ InfTables tabs[INF_WAVES];
     __shared__ uint32_t s_crc[256];
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_crc[i] = crc_table[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_in_block = uni(threadIdx.x >> 6);
-    const uint32_t m = blockIdx.x * 4u + wave_in_block;
+    const uint32_t m = blockIdx.x * INF_WAVES + wave_in_block;
     if (m >= n_members) return;
     InfTables& t = tabs[wave_in_block];
     const uint8_t* in = comp + uni(members[m].c_off);
@@ -197,24 +238,64 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __rest
     uint8_t* out = out_base + uni(members[m].u_off);
     const uint32_t out_len = uni(members[m].u_len);      // ISIZE
     const uint32_t want_crc = uni(members[m].crc);
-    // table indices are formed on the vector side (a mask the compiler cannot see through): the scalar unit is the busy one
-    uint32_t vmask_lit, vmask_dist;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(vmask_lit) : "s"((1u << INF_LIT_BITS) - 1u));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(vmask_dist) : "s"((1u << INF_DIST_BITS) - 1u));
     // stores at offsets >= ISIZE are dropped by the hardware
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)out_len, 0x00020000);
+    // the batches read the input as aligned 32-bit words: in4 + lead_bits is the member's first bit
+    const uint32_t* const in4 = reinterpret_cast<const uint32_t*>((uintptr_t)in & ~(uintptr_t)3);
+    const uint32_t lead_bits = 8u * (uint32_t)((uintptr_t)in & 3u);
+    uint32_t* const ring32 = reinterpret_cast<uint32_t*>(t.ring);
 
     // ---- wave-uniform decoder state ----
+    uint32_t bp = 0;            // bits of the member's deflate data consumed
+    uint32_t op = 0;            // output bytes produced (in the ring)
+    uint32_t flushed = 0;       // ... of which the first `flushed` are in global memory
+    uint32_t err = 0;
+    const uint32_t head = (4u - (uint32_t)((uintptr_t)out & 3u)) & 3u;      // bytes in front of the first aligned word of the output
+
+    // ring -> global memory: whole 256-byte blocks of aligned words (all of it at the end)
+    auto flush = [&](bool all) {
+        if (flushed < head && (op >= head || all)) {
+            const uint32_t n = op < head ? op : head;
+            if (lane < n) __builtin_amdgcn_raw_buffer_store_b8(t.ring[lane], orsrc, lane, 0, 0);
+            flushed = n;
+        }
+        while (flushed >= head && op - flushed >= 256u) {
+            const uint32_t r = (flushed + 4u * lane) & (INF_RING - 1u);
+            const uint32_t w0 = ring32[r >> 2], w1 = ring32[((r >> 2) + 1u) & (INF_RING / 4u - 1u)];
+            const uint32_t v = __builtin_amdgcn_alignbyte(w1, w0, r & 3u);
+            __builtin_amdgcn_raw_buffer_store_b32(v, orsrc, flushed + 4u * lane, 0, 0);
+            flushed += 256u;
+        }
+        if (all)
+            while (flushed < op) {
+                const uint32_t p = flushed + lane;
+                if (p < op) __builtin_amdgcn_raw_buffer_store_b8(t.ring[p & (INF_RING - 1u)], orsrc, p, 0, 0);
+                flushed = flushed + 64u < op ? flushed + 64u : op;
+            }
+    };
+    // one LZ77 match at output position P (every earlier byte is in the ring, or in global memory when far): 64 bytes per step
+    auto copy_match = [&](uint32_t P, uint32_t len, uint32_t dist) {
+        if (dist <= INF_NEAR) {
+            for (uint32_t i = lane; i < len; i += 64) {
+                const uint8_t b = t.ring[(P - dist + (dist >= len ? i : i % dist)) & (INF_RING - 1u)];
+                t.ring[(P + i) & (INF_RING - 1u)] = b;
+            }
+        } else {
+            // far: the source is in front of everything still unflushed (INF_NEAR > the ring's unflushed part + a batch); read
+            // it back once the stores have landed, with the vector cache's older copies of those lines dropped (the fence)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            const uint8_t* const src = out + P - dist;
+            for (uint32_t i = lane; i < len; i += 64) t.ring[(P + i) & (INF_RING - 1u)] = src[dist >= len ? i : i % dist];
+        }
+        inf_sync();
+    };
+
+    // ---- the scalar bit reader of block headers, stored blocks and the one-symbol path: (re)started at bit bp ----
     uint64_t bitbuf = 0;
-    uint32_t bitcnt = 0, ip = 0, op = 0, err = 0;
-    // Input: aligned 32-bit words appended whole to the 64-bit bit buffer whenever it holds 32 bits or fewer, fetched with
-    // scalar loads three words ahead of use, so a refill never waits for memory (and costs eight scalar instructions: the
-    // scalar unit is what this kernel is short of).  ip = input bytes appended so far.  The host pads every batch (>= 32
-    // readable bytes behind the last member); bytes past in_len are only consumed by a damaged stream, which the
-    // position check reports.
+    uint32_t bitcnt = 0, ip = 0;
     const uint32_t* wq;
     uint32_t wa, wb, wc;
-    auto reload = [&]() {          // (re)start at input byte ip: the bit buffer is empty
+    auto reload = [&]() {          // start at input byte ip: the bit buffer is empty
         const uint32_t lead = (uint32_t)((uint64_t)(in + ip) & 3u);
         wq = reinterpret_cast<const uint32_t*>((uint64_t)(in + ip) & ~3ULL);
         wa = ld32u(wq);
@@ -228,7 +309,6 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __rest
         wc = ld32u(wq + 3);
         ++wq;
     };
-    reload();
     auto refill = [&]() {          // leaves at least 33 bits
         if (bitcnt <= 32u) {
             bitbuf |= (uint64_t)wa << bitcnt;
@@ -247,9 +327,16 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __rest
         bitcnt -= n;
         return v;
     };
+    auto scalar_at_bp = [&]() {
+        ip = bp >> 3;
+        reload();
+        take(bp & 7u);
+    };
+    auto scalar_done = [&]() { bp = 8u * ip - bitcnt; };
 
     bool last = false;
     while (!last && !err) {
+        scalar_at_bp();
         refill();
         last = take(1) != 0;
         const uint32_t type = take(2);
@@ -258,61 +345,47 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __rest
             refill();
             const uint32_t len = take(16), nlen = take(16);
             if ((len ^ 0xFFFFu) != nlen) { err = 6; break; }
-            // the bytes still in the bit buffer come first
-            const uint32_t src = ip - (bitcnt >> 3);
+            const uint32_t src = ip - (bitcnt >> 3);      // the bytes still in the bit buffer come first
             if (src + len > in_len || op + len > out_len) { err = 3; break; }
-            for (uint32_t i = lane; i < len; i += 64) {
-                const uint8_t b = in[src + i];
-                out[op + i] = b;
-                t.ring[(op + i) & (INF_RING - 1u)] = b;
+            for (uint32_t done = 0; done < len;) {
+                const uint32_t n = len - done < 256u ? len - done : 256u;
+                for (uint32_t i = lane; i < n; i += 64) t.ring[(op + i) & (INF_RING - 1u)] = in[src + done + i];
+                inf_sync();
+                op += n;
+                done += n;
+                flush(false);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-            __builtin_amdgcn_wave_barrier();
-            op += len;
-            ip = src + len;
-            bitbuf = 0;
-            bitcnt = 0;
-            reload();
+            bp = 8u * (src + len);
             continue;
         }
         if (type == 3) { err = 7; break; }
         if (type == 1) {            // fixed Huffman codes (RFC 1951 3.2.6)
             for (uint32_t s = lane; s < 288; s += 64) t.len[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
             if (lane < 32) t.len[288 + lane] = 5;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            inf_sync();
             if (!inf_build(t, 0, 0, 288, lane) || !inf_build(t, 1, 288, 30, lane)) { err = 1; break; }
-            inf_build_multi(t, lane);
         } else {                    // dynamic codes: the code lengths are themselves Huffman coded
             const uint32_t hlit = take(5) + 257, hdist = take(5) + 1, hclen = take(4) + 4;
             if (hlit > 286 || hdist > 30) { err = 1; break; }
             refill();
             // code length alphabet: built in the distance slots (19 symbols), decoded through the distance table
             if (lane < 19) t.len[288 + lane] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            inf_sync();
             for (uint32_t i = 0; i < hclen; ++i) {
                 if (bitcnt < 3) refill();
                 const uint32_t v = take(3);
                 if (lane == 0) t.len[288 + uni(inf_clen_order[i])] = (uint8_t)v;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            inf_sync();
             if (!inf_build(t, 1, 288, 19, lane)) { err = 1; break; }
             // the hlit + hdist lengths, written to a staging area first (the code-length code occupies len[288..306])
             uint32_t idx = 0, prev = 0;
-            uint8_t* const stage = reinterpret_cast<uint8_t*>(t.multi);      // rebuilt below; 256 bytes, continued in sorted[] (unused until the next build)
-            uint8_t* const stage2 = reinterpret_cast<uint8_t*>(t.sorted);
-            auto put = [&](uint32_t i, uint32_t v) {
-                if (lane == 0) {
-                    if (i < 256) stage[i] = (uint8_t)v;
-                    else stage2[i - 256] = (uint8_t)v;
-                }
-            };
+            uint8_t* const stage = reinterpret_cast<uint8_t*>(t.lit);        // rebuilt below
+            auto put = [&](uint32_t i, uint32_t v) { if (lane == 0) stage[i] = (uint8_t)v; };
             while (idx < hlit + hdist && !err) {
                 refill();
-                uint32_t e = uni(t.dist[(uint32_t)bitbuf & vmask_dist]);
-                uint32_t l = e & 15u, sym = e >> 4;
+                const uint32_t e = uni(t.dist[(uint32_t)bitbuf & ((1u << INF_DIST_BITS) - 1u)]);
+                const uint32_t l = e & 15u, sym = e >> 4;
                 if (!l) { err = 1; break; }     // code-length codes are at most 7 bits: always in the fast table
                 take(l);
                 if (sym < 16) {
@@ -332,8 +405,7 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __rest
                 }
             }
             if (err) break;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            inf_sync();
             // staging -> len[]: literal/length 0..hlit-1 (rest 0), distance 288..288+hdist-1 (rest 0)
             uint8_t mine[5];
 #pragma unroll
@@ -341,146 +413,161 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint8_t* __rest
                 const uint32_t s = lane + 64 * q;      // 0..319
                 uint32_t v = 0;
                 if (s < 288) {
-                    if (s < hlit) v = s < 256 ? stage[s] : stage2[s - 256];
-                } else if (s - 288 < hdist) {
-                    const uint32_t i = hlit + (s - 288);
-                    v = i < 256 ? stage[i] : stage2[i - 256];
-                }
+                    if (s < hlit) v = stage[s];
+                } else if (s - 288 < hdist) v = stage[hlit + (s - 288)];
                 mine[q] = (uint8_t)v;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            inf_sync();
 #pragma unroll
             for (uint32_t q = 0; q < 5; ++q) t.len[lane + 64 * q] = mine[q];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            inf_sync();
             if (uni(t.len[256]) == 0) { err = 1; break; }    // no end-of-block code
             if (!inf_build(t, 0, 0, 288, lane) || !inf_build(t, 1, 288, 30, lane)) { err = 1; break; }
-            inf_build_multi(t, lane);
         }
-        // ---- symbols of this block ----
-        for (;;) {
-            // Runs of literals first: up to three per look-up, one byte per lane.  The kernel is bound by SCALAR issue
-            // (11.5 SALU + 3 branches per output byte, one scalar instruction per SIMD and four cycles: four members per
-            // SIMD take 58 cycles per byte), so this loop keeps the scalar unit out of what the vector side can do: no exec
-            // mask games (lanes without a byte store to an offset the buffer descriptor drops, and write their LDS byte
-            // to a pad), no bounds branch (the descriptor ends at ISIZE; the position is checked once per run).
-            // (the loop is written with its exit test at the bottom: one compare and one branch per look-up, where the
-            // `for (;;) { ...; if (!n) break; ... }` form cost a compare, a select, two mask operations and two branches)
-            need(32);         // a literal/length code (<= 15 bits) and its extra bits (<= 5)
-            uint32_t mm = uni(t.multi[(uint32_t)bitbuf & vmask_lit]);
-            while ((mm >> 24) & 3u) {
-                const uint32_t n = (mm >> 24) & 3u;
-                const bool mine = lane < n;
-                const uint8_t b = (uint8_t)(mm >> (8u * (lane & 3u)));
-                __builtin_amdgcn_raw_buffer_store_b8(b, orsrc, mine ? op + lane : 0xFFFFFFFFu, 0, 0);
-                uint8_t* const cell = mine ? &t.ring[(op + lane) & (INF_RING - 1u)] : &t.pad[lane];
-                *cell = b;
-                op += n;
-                take(mm >> 26);
-                need(32);
-                mm = uni(t.multi[(uint32_t)bitbuf & vmask_lit]);
+        inf_pack_lit(t, lane);
+        inf_pack_dist(t, lane);
+        scalar_done();
+
+        // ---- symbols of this block: batches of 64 bit positions ----
+        bool eob = false;
+        while (!eob && !err) {
+            // the 64 bits that start at bit bp + lane
+            const uint32_t b = lead_bits + bp + lane;
+            const uint32_t* const w = in4 + (b >> 5);
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, b & 31u), hi = __builtin_amdgcn_alignbit(w2, w1, b & 31u);
+            // what would start here
+            const uint32_t e = t.lit[lo & ((1u << INF_LIT_BITS) - 1u)];
+            const uint32_t cb = e & 15u, kind = (e >> 4) & 3u;
+            const uint32_t eb = (e >> 6) & 7u;
+            const uint32_t mlen = ((e >> 9) & 511u) + ((lo >> cb) & ((1u << eb) - 1u));
+            const uint32_t pd = cb + eb;                                    // <= 15
+            const uint32_t de = t.dist[(lo >> pd) & ((1u << INF_DIST_BITS) - 1u)];
+            const uint32_t dl = de & 15u, deb = (de >> 4) & 15u;
+            const uint32_t qd = pd + dl;                                    // <= 23
+            const uint32_t mdist = (de >> 8) + (__builtin_amdgcn_alignbit(hi, lo, qd) & ((1u << deb) - 1u));
+            // bits taken | output bytes << 6 | flags: 1 << 15 needs the one-symbol path, 1 << 16 end of block, 1 << 17 a match
+            uint32_t info;
+            if (cb == 0) info = 1u << 15;
+            else if (kind == 0) info = cb | ((e >> 6) & 3u) << 6;
+            else if (kind == 2) info = cb | 1u << 16;
+            else info = dl ? (qd + deb) | mlen << 6 | 1u << 17 : 1u << 15;
+            // the walk from symbol start to symbol start
+            uint32_t pos = 0, off = 0, offv = 0;
+            uint64_t lits = 0, matches = 0;
+            bool slow = false;
+            while (pos < 64u) {
+                const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)pos);
+                if (inf & (1u << 15)) { slow = true; break; }
+                const uint32_t ol = (inf >> 6) & 511u;
+                if (off && off + ol > INF_BATCH_OUT) break;
+                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(offv) : "s"(off), "s"(pos) : "m0");       // lane `pos` learns its output offset
+                if (inf & (1u << 17)) matches |= 1ull << pos;
+                else lits |= 1ull << pos;
+                off += ol;
+                pos += inf & 63u;
+                if (inf & (1u << 16)) { eob = true; break; }
             }
-            if (op > out_len) { err = 3; break; }
-            uint32_t e = uni(t.lit[(uint32_t)bitbuf & vmask_lit]);
-            uint32_t l = e & 15u;
-            int32_t sym = (int32_t)(e >> 4);
-            if (!l) {
-                sym = inf_slow(t, 0, bitbuf, l);
+            if (op + off > out_len || (bp >> 3) > in_len + 8u) { err = 3; break; }     // (a damaged stream must not run away over the input)
+            // literals: up to three bytes per lane
+            if ((lits >> lane) & 1ull) {
+                const uint32_t n = (e >> 6) & 3u, P = op + offv;
+                if (kind == 0) {
+                    t.ring[P & (INF_RING - 1u)] = (uint8_t)(e >> 8);
+                    if (n > 1) t.ring[(P + 1u) & (INF_RING - 1u)] = (uint8_t)(e >> 16);
+                    if (n > 2) t.ring[(P + 2u) & (INF_RING - 1u)] = (uint8_t)(e >> 24);
+                }
+            }
+            inf_sync();
+            // matches, in order
+            while (matches) {
+                const uint32_t ml = (uint32_t)__builtin_ctzll(matches);
+                matches &= matches - 1ull;
+                const uint32_t P = op + (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)ml);
+                const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)mlen, (int)ml);
+                const uint32_t dist = (uint32_t)__builtin_amdgcn_readlane((int)mdist, (int)ml);
+                if (dist > P) { err = 2; break; }
+                copy_match(P, len, dist);
+            }
+            if (err) break;
+            op += off;
+            bp += pos;
+            flush(false);
+            if (slow) {
+                // one symbol the tables do not hold whole (a code longer than the index): the scalar way
+                scalar_at_bp();
+                need(32);
+                uint32_t l;
+                int32_t sym = inf_slow(t, 0, bitbuf, l);
                 sym = (int32_t)uni((uint32_t)sym);
                 l = uni(l);
-                if (sym < 0) { err = 2; break; }
-            }
-            take(l);
-            if (sym < 256) {
-                if (op >= out_len) { err = 3; break; }
-                if (lane == 0) {
-                    out[op] = (uint8_t)sym;
-                    t.ring[op & (INF_RING - 1u)] = (uint8_t)sym;
+                {   // (a short code the packed table rejected -- a reserved length symbol -- decodes here too)
+                    if (sym < 0) { err = 2; break; }
                 }
-                ++op;
-                continue;
-            }
-            if (sym == 256) break;
-            sym -= 257;
-            if (sym >= 29) { err = 2; break; }
-            // length codes 257..285 (RFC 1951 3.2.5) in closed form: no table fetch on the serial path
-            uint32_t len;
-            if (sym < 8) len = 3 + (uint32_t)sym;
-            else if (sym == 28) len = 258;
-            else {
-                const uint32_t e = ((uint32_t)sym >> 2) - 1;
-                len = ((4u + ((uint32_t)sym & 3u)) << e) + 3u + take(e);
-            }
-            need(32);     // a distance code (<= 15 bits) and its extra bits (<= 13)
-            uint32_t de = uni(t.dist[(uint32_t)bitbuf & vmask_dist]);
-            uint32_t dl = de & 15u;
-            int32_t dsym = (int32_t)(de >> 4);
-            if (!dl) {
-                dsym = inf_slow(t, 1, bitbuf, dl);
-                dsym = (int32_t)uni((uint32_t)dsym);
-                dl = uni(dl);
-                if (dsym < 0) { err = 2; break; }
-            }
-            take(dl);
-            if (dsym >= 30) { err = 2; break; }
-            uint32_t dist;
-            if (dsym < 4) dist = 1 + (uint32_t)dsym;
-            else {
-                const uint32_t e = ((uint32_t)dsym >> 1) - 1;
-                dist = ((2u + ((uint32_t)dsym & 1u)) << e) + 1u + take(e);
-            }
-            if (dist > op) { err = 2; break; }
-            if (op + len > out_len) { err = 3; break; }
-            if (dist <= INF_RING - 258u) {
-                // sources from the LDS ring (the LDS pipe is in order per wavefront: earlier ring writes of any lane are seen)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-                __builtin_amdgcn_wave_barrier();
-                for (uint32_t i = lane; i < len; i += 64) {
-                    const uint8_t b = t.ring[(op - dist + (dist >= len ? i : i % dist)) & (INF_RING - 1u)];
-                    out[op + i] = b;
-                    t.ring[(op + i) & (INF_RING - 1u)] = b;
+                take(l);
+                if (sym < 256) {
+                    if (op >= out_len) { err = 3; break; }
+                    if (lane == 0) t.ring[op & (INF_RING - 1u)] = (uint8_t)sym;
+                    inf_sync();
+                    ++op;
+                } else if (sym == 256) {
+                    eob = true;
+                } else {
+                    sym -= 257;
+                    if (sym >= 29) { err = 2; break; }
+                    uint32_t len;
+                    if (sym < 8) len = 3 + (uint32_t)sym;
+                    else if (sym == 28) len = 258;
+                    else {
+                        const uint32_t x = ((uint32_t)sym >> 2) - 1;
+                        len = ((4u + ((uint32_t)sym & 3u)) << x) + 3u + take(x);
+                    }
+                    need(32);     // a distance code (<= 15 bits) and its extra bits (<= 13)
+                    uint32_t dl2;
+                    int32_t dsym = inf_slow(t, 1, bitbuf, dl2);
+                    dsym = (int32_t)uni((uint32_t)dsym);
+                    dl2 = uni(dl2);
+                    if (dsym < 0 || dsym >= 30) { err = 2; break; }
+                    take(dl2);
+                    uint32_t dist;
+                    if (dsym < 4) dist = 1 + (uint32_t)dsym;
+                    else {
+                        const uint32_t x = ((uint32_t)dsym >> 1) - 1;
+                        dist = ((2u + ((uint32_t)dsym & 1u)) << x) + 1u + take(x);
+                    }
+                    if (dist > op) { err = 2; break; }
+                    if (op + len > out_len) { err = 3; break; }
+                    copy_match(op, len, dist);
+                    op += len;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-                __builtin_amdgcn_wave_barrier();
-            } else {
-                // far match: read the output back; every earlier store of the wave must have landed
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const uint8_t* const src = out + op - dist;
-                for (uint32_t i = lane; i < len; i += 64) {
-                    const uint8_t b = src[dist >= len ? i : i % dist];
-                    out[op + i] = b;
-                    t.ring[(op + i) & (INF_RING - 1u)] = b;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                scalar_done();
+                flush(false);
             }
-            op += len;
         }
-        if (ip - (bitcnt >> 3) > in_len) err = 3;   // the block ran past the member's deflate bytes
+        if ((bp + 7u) / 8u > in_len) err = 3;   // the block ran past the member's deflate bytes
     }
     if (!err && op != out_len) err = 4;
+    flush(true);
     if (!err && out_len) {
-        // CRC-32 of the output: one slice per lane, then crc(A || B) = crc(A) * x^(8 |B|) + crc(B) in GF(2)[x] / p(x)
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        // CRC-32 of the output: one slice per lane, then crc(A || B) = crc(A) * x^(8 |B|) + crc(B) in GF(2)[x] / p(x).  The
+        // bytes are read back from global memory (stores landed, older cached copies dropped: the fence): what is checked is
+        // what the FASTQ kernels will read.
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
         const uint32_t slice = (out_len + 63u) / 64u;
         const uint32_t b = lane * slice < out_len ? lane * slice : out_len;
         const uint32_t e = b + slice < out_len ? b + slice : out_len;
         uint32_t c = 0xFFFFFFFFu;
         for (uint32_t i = b; i < e; ++i) c = s_crc[(c ^ out[i]) & 0xFFu] ^ (c >> 8);
-        t.multi[lane] = ~c;      // (the decode tables are no longer needed)
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        t.lit[lane] = ~c;      // (the decode tables are no longer needed)
+        inf_sync();
         if (lane == 0) {
             const uint32_t x_full = gf2_x8n(slice);
-            uint32_t crc = t.multi[0];
+            uint32_t crc = t.lit[0];
             for (uint32_t i = 1; i < 64; ++i) {
                 const uint32_t bi = i * slice;
                 if (bi >= out_len) break;
                 const uint32_t li = bi + slice <= out_len ? slice : out_len - bi;
-                crc = gf2_mul(li == slice ? x_full : gf2_x8n(li), crc) ^ t.multi[i];
+                crc = gf2_mul(li == slice ? x_full : gf2_x8n(li), crc) ^ t.lit[i];
             }
             if (crc != want_crc) err = 5;
         }
@@ -516,7 +603,9 @@ __global__ void bgzf_verdict_kernel(const BgzfMember* members, const uint32_t* s
 hipError_t launch_bgzf_inflate(const uint8_t* comp, const BgzfMember* members, uint32_t n_members, uint8_t* out_base, uint32_t* status,
                                const uint32_t* crc_table, BgzfVerdict* verdict, hipStream_t s)
 {
-    if (n_members) hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((n_members + 3) / 4), dim3(256), 0, s, comp, members, n_members, out_base, status, crc_table);
+    if (n_members)
+        hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((n_members + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), 0, s, comp, members, n_members, out_base, status,
+                           crc_table);
     hipLaunchKernelGGL(bgzf_verdict_kernel, dim3(1), dim3(256), 0, s, members, status, n_members, verdict);
     return hipGetLastError();
 }
