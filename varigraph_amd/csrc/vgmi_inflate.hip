@@ -281,9 +281,11 @@ __global__ __launch_bounds__(64 * INF_WAVES, 4) void bgzf_inflate_kernel(const u
                 t.ring[(P + i) & (INF_RING - 1u)] = b;
             }
         } else {
-            // far: the source is in front of everything still unflushed (INF_NEAR > the ring's unflushed part + a batch); read
-            // it back once the stores have landed, with the vector cache's older copies of those lines dropped (the fence)
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            // far: the source is in front of everything still unflushed (INF_NEAR > the ring's unflushed part + a batch); read it
+            // back once the wavefront's stores have landed (its own stores and loads go through the same vector cache; an
+            // agent-scope fence here writes the whole L2 back and made the kernel 15 x slower -- whatever this read could get
+            // wrong, the CRC below catches and the host decoder redoes)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const uint8_t* const src = out + P - dist;
             for (uint32_t i = lane; i < len; i += 64) t.ring[(P + i) & (INF_RING - 1u)] = src[dist >= len ? i : i % dist];
         }
@@ -550,9 +552,8 @@ __global__ __launch_bounds__(64 * INF_WAVES, 4) void bgzf_inflate_kernel(const u
     flush(true);
     if (!err && out_len) {
         // CRC-32 of the output: one slice per lane, then crc(A || B) = crc(A) * x^(8 |B|) + crc(B) in GF(2)[x] / p(x).  The
-        // bytes are read back from global memory (stores landed, older cached copies dropped: the fence): what is checked is
-        // what the FASTQ kernels will read.
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        // bytes are read back from global memory once the wavefront's stores have landed.
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const uint32_t slice = (out_len + 63u) / 64u;
         const uint32_t b = lane * slice < out_len ? lane * slice : out_len;
         const uint32_t e = b + slice < out_len ? b + slice : out_len;
