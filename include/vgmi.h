@@ -74,6 +74,12 @@ int vgmi_table_import(vgmi_ctx *ctx, const void *dev_src, size_t bytes);
  * copy of src's table image through one device-to-device transfer (xGMI peer copy between different devices); the table
  * is built once per run, not once per device. */
 int vgmi_table_clone(vgmi_ctx *dst, vgmi_ctx *src);
+/* ... and between the PROCESSES of one node, one per GPU: ONE RCCL broadcast of the image over xGMI (librccl is loaded on first use).
+ * Rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the others by any means it likes (`varigraph-mi genotype --procs`
+ * forks its ranks around a shared page); then every rank calls vgmi_table_broadcast with its own context: the root's holds the
+ * table, the others' adopt what arrives.  world = 1 is legal (a communicator of one).  No reference counterpart (single device). */
+int vgmi_rccl_unique_id(void *id128);
+int vgmi_table_broadcast(vgmi_ctx *ctx, int rank, int world, const void *id128);
 int vgmi_table_info(vgmi_ctx *ctx, size_t *n_keys, uint32_t *k, size_t *n_slots, size_t *filter_bits);
 /* Batched exact lookup, the table's `find`: index_out[i] = the index keys[i] has in the uploaded key array, 0xFFFFFFFF when
  * the table does not hold it.  Replaces the per-node loop of Varigraph graph2node (src/construct_index.cpp:710-751:

@@ -615,15 +615,37 @@ def test_c5_tetraploid_30mb_use_depth_on_device_vcf_identical(tmp_path_factory):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def test_c5_scaled_300mb_24_contigs_tetraploid_through_the_cli():
+    """BASELINE config 5's cohort shape at a tenth of its size -- 300 Mb in 24 contigs, 5e5 variants with indels and long insertions,
+    three tetraploid VCF samples, 1e7 read pairs streamed into `varigraph-mi genotype --sample-ploidy 4 --use-depth` through named
+    pipes (tools/wgs_cli_e2e.py; the full-size run is profiles/r4_e2e_wgs_tetraploid.json).  The reference cannot run this in suite
+    time: the counters of a read prefix are held against the oracle through the graph the CLI wrote, the called dosages against the
+    generator's truth."""
+    import json
+    import sys
+    _need_binaries()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wgs_cli_e2e.py"), "--genome", "300000000", "--contigs", "24", "--variants",
+                        "500000", "--pairs", "10000000"], capture_output=True, text=True, timeout=600, env=ENV)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().split("\n")[-1])
+    assert "error" not in d, d.get("error")
+    assert d["prefix_counters_equal_oracle"] and d["prefix_hits"] > 100_000
+    assert d["sites_called"] > 0.99 * d["sites"] and d["dosage_concordance"] > 0.99 and d["carrier_concordance"] > 0.999
+    assert d["context_table"]["n_buckets"] > 0 and d["reads_streamed_through_pipes"]
+    assert any("windows on the device" in ln and " 0 of " not in ln for ln in d["genotype_log"])
+    print(f"C5 scaled: construct {d['construct_s']:.1f} s, genotype {d['genotype_wall_s']:.1f} s, dosage concordance {d['dosage_concordance']:.4f}, "
+          f"peak RSS {d['genotype_peak_rss_gb']:.1f} GB")
+
+
 def test_c4_eight_samples_over_the_gpus_present_equal_single_sample_reference_runs(tmp_path_factory):
     _need_binaries()
     work = str(tmp_path_factory.mktemp("c4"))
     try:
-        ref, variants, gts, graph = _dataset(work, 8_000_000, 40_000, vcf_samples=3, ploidy=2)
+        ref, variants, gts, graph = _dataset(work, 30_000_000, 100_000, vcf_samples=3, ploidy=2)
         cfg_lines = []
         for s in range(8):
             haps = synth.sample_haplotypes(ref, variants, gts, s % 3, 2)
-            fq = _write_fastq(os.path.join(work, f"s{s}"), haps, 400_000, seed=2000 + s)    # 15x each, own reads
+            fq = _write_fastq(os.path.join(work, f"s{s}"), haps, 1_000_000, seed=2000 + s)    # 10x each, own reads
             cfg_lines.append(f"sample{s} " + " ".join(fq) + "\n")
         n_dev = max(1, vgmi.lib().vgmi_device_count())
         gpus = ",".join(str(d) for d in range(n_dev)) if n_dev > 1 else "0,0"      # one GPU: two contexts on it
@@ -632,9 +654,17 @@ def test_c4_eight_samples_over_the_gpus_present_equal_single_sample_reference_ru
         t_ref = 0.0
         for s in range(8):
             d = os.path.join(work, f"cpu{s}")
-            t_ref += _reference_genotype(d, graph, cfg_lines[s], [], threads=16, timeout=120)
+            t_ref += _reference_genotype(d, graph, cfg_lines[s], [], threads=16, timeout=240)
             assert _vcf(os.path.join(work, "native"), f"sample{s}") == _vcf(d, f"sample{s}"), s
         assert len({_vcf(os.path.join(work, "native"), f"sample{s}") for s in range(8)}) >= 3     # the samples do differ
+        # one PROCESS per device (--procs): the ranks take the samples round robin.  Every device present through one RCCL
+        # broadcast of the table image (a single device: a communicator of one); a device named twice: every rank builds its own
+        for tag, gl in (("procs_rccl", ",".join(str(d) for d in range(n_dev))), ("procs_twice", "0,0")):
+            t_p, log_p = _native_genotype(os.path.join(work, tag), graph, "".join(cfg_lines), ["--gpus", gl, "--procs"])
+            assert ("RCCL broadcast" in log_p) == (tag == "procs_rccl"), log_p[-1500:]
+            for s in range(8):
+                assert _vcf(os.path.join(work, tag), f"sample{s}") == _vcf(os.path.join(work, "native"), f"sample{s}"), (tag, s)
+            print(f"C4 --procs --gpus {gl}: {t_p:.1f} s")
         print(f"C4: 8 samples over --gpus {gpus}: varigraph-mi {t_nat:.1f} s, 8 reference runs {t_ref:.0f} s")
     finally:
         shutil.rmtree(work, ignore_errors=True)

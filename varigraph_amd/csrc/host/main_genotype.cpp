@@ -12,6 +12,10 @@
 #include <mutex>
 #include <random>
 #include <thread>
+#include <set>
+#include <unistd.h>
+#include <sys/wait.h>
+#include <sys/mman.h>
 #include <cstdio>
 #include <cstdlib>
 #include <filesystem>
@@ -36,7 +40,16 @@ struct Options {
     std::vector<int> gpus = {0};   // --gpu N, or --gpus a,b,c: samples are dealt to the devices, one
                                    // counting thread and one table replica per device
     int buffer_mib = 100;   // main.cu default
+    bool procs = false;     // --procs: one PROCESS per device of --gpus, the table image handed on by one RCCL broadcast
 };
+
+// --procs: what the ranks share (one page, mapped before the fork): rank 0's RCCL id, whether it is there, whether anyone gave up
+struct ProcShared {
+    char nccl_id[128];
+    std::atomic<int> id_ready;
+    std::atomic<int> failed;
+};
+ProcShared* g_shared = nullptr;
 
 void usage(const char* argv0)
 {
@@ -54,6 +67,8 @@ void usage(const char* argv0)
               << "    --use-depth            use the sequencing depth as the depth of homozygous k-mers\n"
               << "    --gpu           INT    device ordinal [0]\n"
               << "    --gpus          LIST   several devices, e.g. 0,1,2,3: samples are counted on them in parallel\n"
+              << "    --procs                one process per device of --gpus (samples dealt round robin, -t shared out); the table is\n"
+              << "                           built on the first device and reaches the others by one RCCL broadcast\n"
               << "    --buffer        INT    staging buffer in MiB [100]\n"
               << "    -D, --debug            single host thread, phase times on stderr\n"
               << "    -t, --threads   INT    host threads [10]\n";
@@ -61,6 +76,7 @@ void usage(const char* argv0)
 
 [[noreturn]] void die(const std::string& msg)
 {
+    if (g_shared) g_shared->failed = 1;       // ranks waiting for this one stop waiting
     std::cerr << "[varigraph-mi] " << msg << std::endl;
     std::fflush(nullptr);
     std::_Exit(1);   // other threads (parsers, device streams) may be mid-flight: no static destructors under them
@@ -141,6 +157,7 @@ int main_genotype(int argc, char** argv)
         {"gpu", required_argument, 0, 7},          {"buffer", required_argument, 0, 8},
         {"gpus", required_argument, 0, 9},         {"debug", no_argument, 0, 'D'},
         {"threads", required_argument, 0, 't'},    {"help", no_argument, 0, 'h'},
+        {"procs", no_argument, 0, 10},
         {0, 0, 0, 0}};
     for (;;) {
         int idx = 0;
@@ -167,6 +184,7 @@ int main_genotype(int argc, char** argv)
             break;
         }
         case 8: o.buffer_mib = opt_int("--buffer", optarg); break;
+        case 10: o.procs = true; break;
         case 't': o.hmm.threads = std::max(opt_int("-t", optarg), 1); break;
         case 'D': debug = true; break;
         default: usage(argv[0]); return 1;
@@ -192,7 +210,47 @@ int main_genotype(int argc, char** argv)
     const auto t0 = std::chrono::steady_clock::now();
     auto secs = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
 
-    const auto samples = parse_samples(o.samples);   // exits on a bad list before anything touches the device
+    auto samples = parse_samples(o.samples);   // exits on a bad list before anything touches the device
+    // --procs: the ranks are forked HERE, before anything touches a device (a process that has initialised the GPU must not
+    // fork).  Rank r takes device gpus[r], the samples r, r + n, ... of the list (independent units, src/varigraph.cpp:153-172)
+    // and its share of -t; rank 0 builds the table, every rank receives it in ONE ncclBroadcast (vgmi_table_broadcast) -- unless
+    // the list names a device twice (RCCL takes one rank per device): then every rank builds its own.
+    int proc_rank = -1, proc_world = 0;
+    bool proc_bcast = false;
+    if (o.procs) {
+        const size_t n = o.gpus.size();
+        g_shared = static_cast<ProcShared*>(mmap(nullptr, 4096, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0));
+        if (g_shared == MAP_FAILED) { g_shared = nullptr; die("--procs: cannot map the shared page"); }
+        new (g_shared) ProcShared{};
+        proc_bcast = std::set<int>(o.gpus.begin(), o.gpus.end()).size() == n;
+        std::fflush(nullptr);
+        std::vector<pid_t> kids;
+        for (size_t r = 0; r < n && proc_rank < 0; ++r) {
+            const pid_t pid = fork();
+            if (pid < 0) die("--procs: fork failed");
+            if (pid == 0) proc_rank = (int)r;
+            else kids.push_back(pid);
+        }
+        if (proc_rank < 0) {          // the parent only waits
+            int worst = 0;
+            for (pid_t k : kids) {
+                int st = 0;
+                while (waitpid(k, &st, 0) < 0 && errno == EINTR) {}
+                const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 1;
+                worst = std::max(worst, rc);
+            }
+            std::_Exit(worst);
+        }
+        proc_world = (int)n;
+        std::vector<std::tuple<std::string, std::vector<std::string>>> mine;
+        for (size_t i = (size_t)proc_rank; i < samples.size(); i += n) mine.push_back(samples[i]);
+        samples.swap(mine);
+        o.gpus = {o.gpus[(size_t)proc_rank]};
+        o.hmm.threads = std::max<uint32_t>(1, o.hmm.threads / (uint32_t)n);
+        std::cerr << "[varigraph-mi] rank " << proc_rank << " of " << proc_world << ": device " << o.gpus[0] << ", " << samples.size()
+                  << " samples, " << o.hmm.threads << " threads" << (proc_bcast ? "" : " (a device is named twice: every rank builds its table)")
+                  << std::endl;
+    }
     std::cerr << "[varigraph-mi] samples: " << samples.size() << ", graph: " << o.graph << ", devices: " << o.gpus.size() << std::endl;
     // the device contexts come up (HIP runtime start, staging buffers) while the graph is read
     std::vector<vgmi_ctx*> ctxs;
@@ -249,6 +307,27 @@ int main_genotype(int argc, char** argv)
             }
             ctxs.push_back(ctx);
         }
+        if (proc_bcast && proc_rank > 0) {
+            // the table arrives from rank 0 (no key upload, no build here): wait for its RCCL id, join the broadcast
+            const auto t_wait = std::chrono::steady_clock::now();
+            while (!g_shared->id_ready.load()) {
+                if (g_shared->failed.load() || getppid() == 1) { ctx_error = "--procs: another rank gave up"; return; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            }
+            if (vgmi_table_broadcast(ctxs[0], proc_rank, proc_world, g_shared->nccl_id) != VGMI_OK) {
+                ctx_error = vgmi_last_error(ctxs[0]);
+                return;
+            }
+            std::fprintf(stderr, "[varigraph-mi] rank %d: table image received by RCCL broadcast (%.3f s after its id)\n", proc_rank,
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count());
+            {
+                std::lock_guard<std::mutex> lk2(keys_mu);
+                table_state = 1;
+            }
+            keys_cv.notify_all();
+            warm_fastq(ctxs[0]);
+            return;
+        }
         std::unique_lock<std::mutex> lk(keys_mu);
         keys_cv.wait(lk, [&] { return keys_state != 0; });
         if (keys_state < 0) return;
@@ -257,6 +336,17 @@ int main_genotype(int argc, char** argv)
         if (vgmi_table_upload(ctxs[0], g.keys.data(), g.keys.size(), g.k) != VGMI_OK) {
             ctx_error = vgmi_last_error(ctxs[0]);
             return;
+        }
+        if (proc_bcast && proc_rank == 0) {
+            if (vgmi_rccl_unique_id(g_shared->nccl_id) != VGMI_OK) { ctx_error = vgmi_last_error(nullptr); return; }
+            g_shared->id_ready = 1;
+            if (vgmi_table_broadcast(ctxs[0], 0, proc_world, g_shared->nccl_id) != VGMI_OK) {
+                ctx_error = vgmi_last_error(ctxs[0]);
+                return;
+            }
+            size_t ib = 0;
+            (void)vgmi_table_image_bytes(ctxs[0], &ib);
+            std::fprintf(stderr, "[varigraph-mi] rank 0: table image of %.1f MB sent to %d ranks in one RCCL broadcast\n", ib / 1e6, proc_world - 1);
         }
         {
             std::lock_guard<std::mutex> lk2(keys_mu);
@@ -350,6 +440,9 @@ int main_genotype(int argc, char** argv)
             independent = any;
         }
     }
+    if (proc_world > 1 && !independent && g.hap_names.size() > o.hmm.haploid_num)
+        die("--procs deals the samples to several processes: that needs samples that are independent units (-n >= the number of "
+            "haplotypes of the graph, so that no sample's haplotype selection prunes the next one's k-mer lists)");
     const size_t n_consumers = independent ? want_consumers : 1;
     if (n_consumers > 1) g.build_entry_words();      // the graph's half of the Genotypers' per-entry words, once instead of once each
     // -t is the budget of the whole run: counting threads (inflate workers) and HMM consumers that run side by side

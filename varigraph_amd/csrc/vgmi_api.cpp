@@ -5,6 +5,7 @@
 // vgmi_create fails with VGMI_E_NO_DEVICE.
 #include "../../include/vgmi.h"
 
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -54,6 +55,8 @@ struct Stage {
 };
 
 }  // namespace
+
+struct ncclUniqueIdBytes { char internal[128]; };      // rccl.h: ncclUniqueId (passed by value to ncclCommInitRank)
 
 struct vgmi_ctx {
     int device = 0;
@@ -1202,6 +1205,98 @@ int vgmi_table_import(vgmi_ctx* c, const void* dev_src, size_t bytes)
     }
     c->read_base = 0;
     return VGMI_OK;
+}
+
+// ---- the table image over RCCL, for one process per GPU (the north_star's "single RCCL broadcast of the read-only graph index over
+// xGMI"; the reference is single-device: main.cu:221,444 select one).  librccl is loaded on first use: the library itself carries
+// no dependency on it, a node without RCCL still runs everything else.
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, ncclUniqueIdBytes, int) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+Rccl* rccl()
+{
+    static Rccl r = [] {
+        Rccl x;
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            x.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (x.lib) break;
+        }
+        if (!x.lib) {
+            x.err = std::string("librccl.so: ") + (dlerror() ? dlerror() : "not found");
+            return x;
+        }
+        x.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(x.lib, "ncclGetUniqueId"));
+        x.CommInitRank = reinterpret_cast<int (*)(void**, int, ncclUniqueIdBytes, int)>(dlsym(x.lib, "ncclCommInitRank"));
+        x.Broadcast = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(x.lib, "ncclBroadcast"));
+        x.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(x.lib, "ncclCommDestroy"));
+        x.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(x.lib, "ncclGetErrorString"));
+        if (!x.GetUniqueId || !x.CommInitRank || !x.Broadcast || !x.CommDestroy) x.err = "librccl.so lacks an entry point";
+        return x;
+    }();
+    return &r;
+}
+}  // namespace
+
+int vgmi_rccl_unique_id(void* id128)
+{
+    if (!id128) return VGMI_E_INVALID;
+    Rccl* r = rccl();
+    if (!r->err.empty()) return fail(nullptr, VGMI_E_STATE, r->err);
+    const int rc = r->GetUniqueId(id128);
+    if (rc) return fail(nullptr, VGMI_E_HIP, std::string("ncclGetUniqueId: ") + (r->GetErrorString ? r->GetErrorString(rc) : "failed"));
+    return VGMI_OK;
+}
+
+int vgmi_table_broadcast(vgmi_ctx* c, int rank, int world, const void* id128)
+{
+    if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return VGMI_E_INVALID;
+    if (rank == 0 && !c->has_table) return fail(c, VGMI_E_STATE, "the root has no table to broadcast");
+    Rccl* r = rccl();
+    if (!r->err.empty()) return fail(c, VGMI_E_STATE, r->err);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ncclUniqueIdBytes id;
+    memcpy(id.internal, id128, sizeof id.internal);
+    void* comm = nullptr;
+    auto nccl_fail = [&](const char* what, int rc) {
+        if (comm) (void)r->CommDestroy(comm);
+        return fail(c, VGMI_E_HIP, std::string(what) + ": " + (r->GetErrorString ? r->GetErrorString(rc) : "failed"));
+    };
+    int rc = r->CommInitRank(&comm, world, id, rank);
+    if (rc) return nccl_fail("ncclCommInitRank", rc);
+    // the image's size first (8 bytes), then the image: root sends its own allocation, the others receive into a buffer they adopt
+    unsigned long long* d_n = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_n), 8));
+    unsigned long long n = rank == 0 ? c->image_bytes : 0;
+    HIPCHK(c, hipMemcpy(d_n, &n, 8, hipMemcpyHostToDevice));
+    rc = r->Broadcast(d_n, d_n, 8, /* ncclChar */ 0, 0, comm, c->stream);
+    if (rc == 0 && hipStreamSynchronize(c->stream) != hipSuccess) rc = 1;
+    if (rc) { (void)hipFree(d_n); return nccl_fail("ncclBroadcast (size)", rc); }
+    HIPCHK(c, hipMemcpy(&n, d_n, 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_n);
+    uint8_t* d_buf = rank == 0 ? c->d_image : nullptr;
+    if (rank != 0 && hipMalloc(reinterpret_cast<void**>(&d_buf), n) != hipSuccess) return nccl_fail("hipMalloc (image)", 1);
+    rc = r->Broadcast(d_buf, d_buf, n, /* ncclChar */ 0, 0, comm, c->stream);
+    if (rc == 0 && hipStreamSynchronize(c->stream) != hipSuccess) rc = 1;
+    (void)r->CommDestroy(comm);
+    comm = nullptr;
+    if (rc) {
+        if (rank != 0) (void)hipFree(d_buf);
+        return nccl_fail("ncclBroadcast (image)", rc);
+    }
+    int out = VGMI_OK;
+    if (rank != 0) {
+        out = vgmi_table_import(c, d_buf, n);
+        (void)hipFree(d_buf);
+    }
+    return out;
 }
 
 int vgmi_table_clone(vgmi_ctx* dst, vgmi_ctx* src)

@@ -42,6 +42,8 @@ def load_library():
         "vgmi_table_export": (i32, [vp, vp, sz]),
         "vgmi_table_import": (i32, [vp, vp, sz]),
         "vgmi_table_clone": (i32, [vp, vp]),
+        "vgmi_rccl_unique_id": (i32, [vp]),
+        "vgmi_table_broadcast": (i32, [vp, i32, i32, vp]),
         "vgmi_table_info": (i32, [vp, C.POINTER(sz), C.POINTER(u32), C.POINTER(sz), C.POINTER(sz)]),
         "vgmi_xtable_info": (i32, [vp, C.POINTER(sz), C.POINTER(sz)]),
         "vgmi_ctable_info": (i32, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
