@@ -1,4 +1,6 @@
 #!/bin/bash
+# (ran against commit fec70cf's parent build: VGMI_CT_OPT=1 -- a lane per aligned pair of counters, 64-bit atomics -- was an A/B knob of
+# that build only; measured equal, the code is gone.  Kept as the record of how the same-box comparisons were run.)
 # same-box A/B: marks per X vs one mark, 32-bit vs paired 64-bit atomics, workgroups per CU -- each configuration twice, interleaved
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r4g

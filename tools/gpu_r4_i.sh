@@ -1,4 +1,6 @@
 #!/bin/bash
+# (ran against a working build with VGMI_CT_DIFF: counters as a difference array over the places; measured slower, 8.82 against 8.44 ms, the
+# code is gone.  Kept as the record of how the same-box comparisons were run: every configuration three times, interleaved.)
 # same-box A/B, interleaved, three rounds: difference counters vs plain, marks per X vs one, against round 2's table as the box's yardstick
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r4i
