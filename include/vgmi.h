@@ -175,6 +175,14 @@ int vgmi_fastq_text_capacity(vgmi_fastq *fq, size_t *text_bytes);
  *   not_bgzf  the bytes at `taken` are not a block-gzip member (plain gzip member, damage): the device path ends there
  * replaces: gzread's inflate under kseq (include/kseq.h:59-72, src/fastq_kmer.cpp:74-78). */
 int vgmi_fastq_commit_bgzf(vgmi_fastq *fq, size_t n_bytes, size_t *taken, size_t *n_text, int *not_bgzf);
+/* An ORDINARY gzip member (one DEFLATE stream: what `gzip` writes) inflated on the device, host memory to host memory: block starts are
+ * guessed every 32 KiB of compressed bytes, the stretches between them decoded side by side with placeholders for the window each
+ * cannot know, checked by having to end exactly where the next one starts, then resolved (vgmi_gunzip.hip; replaces zlib's inflate
+ * behind gzread, include/kseq.h:59-72).  n_out = text bytes written, consumed = compressed bytes they came from, member_end = the
+ * member's last block was reached; reason = why the device stopped earlier (0: it did not).  Whatever it does not take is the host
+ * decoder's.  Test and bench entry of the primitive. */
+int vgmi_gunzip_buffer(vgmi_ctx *ctx, const void *host_gz, size_t n, void *host_out, size_t cap, size_t *n_out, size_t *consumed,
+                       int *member_end, uint32_t *reason);
 /* After the last commit (waits): failed != 0 if a member did not inflate to its ISIZE / CRC-32; good_compressed_bytes =
  * compressed bytes in front of the first such member (all committed bytes if none failed): the text of those bytes went
  * through the parser, the host decoder takes the file over at that offset. */

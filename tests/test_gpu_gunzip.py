@@ -1,0 +1,73 @@
+"""Ordinary gzip members inflated on the device (vgmi_gunzip.hip through vgmi_gunzip_buffer) against zlib: FASTQ text of several
+shapes and sizes at several compression levels -- stretches between guessed block starts decoded side by side with placeholders for
+the window in front, chained, resolved.  What the device hands back must be a PREFIX of zlib's output ending at a block boundary,
+and the whole of it when it reports the member's end."""
+import gzip
+import zlib
+
+import numpy as np
+import pytest
+
+from varigraph_amd import vgmi
+
+pytestmark = pytest.mark.gpu
+
+
+def _fastq_text(n_reads, seed, qual="fixed", read_len=150):
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, size=200_000, dtype=np.uint8)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    parts = []
+    for i in range(n_reads):
+        s = int(rng.integers(0, genome.size - read_len))
+        seq = acgt[genome[s:s + read_len]].tobytes()
+        if qual == "fixed":
+            q = b"I" * read_len
+        else:
+            q = bytes((33 + rng.integers(2, 41, size=read_len)).astype(np.uint8))
+        parts.append(b"@read%09d/1 lane:%d\n" % (i, i % 8) + seq + b"\n+\n" + q + b"\n")
+    return b"".join(parts)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = vgmi.Context(0, buffer_mib=16)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n_reads,qual,level", [(300, "fixed", 6), (20_000, "fixed", 1), (20_000, "fixed", 6), (20_000, "random", 6),
+                                                 (20_000, "random", 9), (200_000, "fixed", 4), (200_000, "random", 6)])
+def test_device_gunzip_equals_zlib(ctx, n_reads, qual, level):
+    text = _fastq_text(n_reads, 7 + n_reads, qual)
+    comp = gzip.compress(text, level)
+    got, consumed, member_end, why = ctx.gunzip(comp, len(text) + 4096)
+    assert why == 0, why
+    assert member_end and got == text
+    assert consumed == len(comp) - 8          # everything but the trailer
+
+
+def test_device_gunzip_stored_and_fixed_blocks_and_garbage(ctx):
+    # incompressible bytes (stored blocks), a tiny member (fixed codes), and a damaged stream: a prefix, never wrong bytes
+    rng = np.random.default_rng(3)
+    noise = bytes(rng.integers(0, 256, size=300_000, dtype=np.uint8))
+    for data in (noise, b"ACGT" * 10, _fastq_text(5000, 1)):
+        comp = gzip.compress(data, 6)
+        got, consumed, member_end, why = ctx.gunzip(comp, len(data) + 4096)
+        assert got == data[:len(got)]
+        if member_end:
+            assert got == data
+    # a flipped byte in the middle: the device hands back a prefix of what zlib makes of the same (damaged) bytes, block by block
+    text = _fastq_text(50_000, 2)
+    for at in (0.5, 0.25, 0.9):
+        comp = bytearray(gzip.compress(text, 6))
+        comp[int(len(comp) * at)] ^= 0x55
+        got, consumed, member_end, why = ctx.gunzip(bytes(comp), len(text) + 65536)
+        d = zlib.decompressobj(-15)
+        want = b""
+        try:
+            for i in range(10, len(comp), 1 << 16):
+                want += d.decompress(bytes(comp[i:i + (1 << 16)]))
+        except zlib.error:
+            pass
+        assert len(got) > 0 and got == want[:len(got)]

@@ -1906,6 +1906,169 @@ int vgmi_fastq_commit_bgzf(vgmi_fastq* f, size_t n_bytes, size_t* taken, size_t*
     return VGMI_OK;
 }
 
+/* ---------------------------------------------------------------- ordinary gzip on the device (vgmi_gunzip.hip) */
+namespace {
+// RFC 1952 member header at p: bytes to the DEFLATE data, 0 if it is not one / does not fit n
+size_t gzip_header_len(const unsigned char* p, size_t n)
+{
+    if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0)) return 0;
+    const unsigned flg = p[3];
+    size_t q = 10;
+    if (flg & 4) {
+        if (q + 2 > n) return 0;
+        q += 2 + ((size_t)p[q] | (size_t)p[q + 1] << 8);
+    }
+    for (unsigned bit : {8u, 16u})
+        if (flg & bit) {
+            while (q < n && p[q]) ++q;
+            ++q;
+        }
+    if (flg & 2) q += 2;
+    return q < n ? q : 0;
+}
+
+// One piece of a DEFLATE stream, on the device: comp[0, n) (n + >= 64 readable zero bytes behind it), first_bit = where a block
+// starts (known), window = the 32 KiB of text in front (device; ignored at a member's start).  Decodes whole stretches into
+// d_text and reports how far: *end_bit = the bit behind the last block taken (a block start, or the member's end when *final),
+// *n_text its text.  Stretches the device cannot vouch for are left (end_bit says where they start).
+struct GzScratch {
+    uint32_t* d_starts = nullptr;
+    GzSegHost* d_segs = nullptr;
+    GzSegOutHost* d_outs = nullptr;
+    uint64_t* d_toff = nullptr;
+    uint16_t* d_pool = nullptr;
+    uint8_t* d_win = nullptr;
+    size_t cap_seg = 0, cap_pool = 0;
+    void release()
+    {
+        for (void* q : {(void*)d_starts, (void*)d_segs, (void*)d_outs, (void*)d_toff, (void*)d_pool, (void*)d_win})
+            if (q) (void)hipFree(q);
+        *this = GzScratch{};
+    }
+};
+constexpr uint32_t kGzSeg = 32768;        // compressed bytes per guessed start
+constexpr uint32_t kGzRatio = 12;         // symbols of room per compressed byte of a stretch (FASTQ: 4-6)
+
+int gz_piece(vgmi_ctx* c, GzScratch& g, const uint8_t* d_comp, uint32_t n, uint32_t first_bit, bool window_known, uint8_t* d_text, size_t text_cap,
+             hipStream_t st, uint32_t* end_bit, size_t* n_text, int* final_member, uint32_t* reason)
+{
+    *end_bit = first_bit;
+    *n_text = 0;
+    *final_member = 0;
+    *reason = 0;
+    if (n < 64 || (uint64_t)n * 8 >= (1ull << 32) - 4096) return VGMI_OK;
+    const uint32_t n_nom = (n + kGzSeg - 1) / kGzSeg;
+    const size_t pool_syms = (size_t)kGzRatio * n + (size_t)n_nom * 1024 + 65536;
+    if (g.cap_seg < n_nom + 1 || g.cap_pool < pool_syms) {
+        g.release();
+        g.cap_seg = n_nom + 1;
+        g.cap_pool = pool_syms;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_starts), g.cap_seg * 4));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_segs), g.cap_seg * sizeof(GzSegHost)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_outs), g.cap_seg * sizeof(GzSegOutHost)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_toff), g.cap_seg * 8));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_pool), g.cap_pool * 2));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_win), (g.cap_seg + 1) * 32768));
+    }
+    // 1. guessed block starts (the first is known)
+    HIPCHK(c, hipMemsetAsync(g.d_starts, 0xFF, (size_t)n_nom * 4, st));
+    HIPCHK(c, launch_gz_find(d_comp, n, kGzSeg, n_nom, g.d_starts, st));
+    std::vector<uint32_t> starts(n_nom);
+    HIPCHK(c, hipMemcpyAsync(starts.data(), g.d_starts, (size_t)n_nom * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    std::vector<GzSegHost> segs;
+    uint32_t at = first_bit;
+    segs.push_back(GzSegHost{first_bit, 0xFFFFFFFFu, 0, 0});
+    for (uint32_t j = 1; j < n_nom; ++j)
+        if (starts[j] != 0xFFFFFFFFu && starts[j] > at) {
+            segs.back().stop_bit = starts[j];
+            segs.push_back(GzSegHost{starts[j], 0xFFFFFFFFu, 0, 0});
+            at = starts[j];
+        }
+    // room in the symbol pool: by the compressed bytes of the stretch
+    size_t off = 0;
+    for (size_t i = 0; i < segs.size(); ++i) {
+        const uint32_t stop = segs[i].stop_bit != 0xFFFFFFFFu ? segs[i].stop_bit : n * 8u;
+        const size_t bytes = (stop - segs[i].start_bit + 7) / 8;
+        size_t cap = (size_t)kGzRatio * bytes + 1024;
+        cap = (cap + 1) & ~(size_t)1;
+        if (off + cap > g.cap_pool) cap = (g.cap_pool - off) & ~(size_t)1;
+        segs[i].sym_off = (uint32_t)off;
+        segs[i].sym_cap = (uint32_t)cap;
+        off += cap;
+        if (off >= (1ull << 32)) return fail(c, VGMI_E_INVALID, "gzip piece too large for the symbol pool");
+    }
+    const uint32_t n_seg = (uint32_t)segs.size();
+    // 2. decode
+    HIPCHK(c, hipMemcpyAsync(g.d_segs, segs.data(), n_seg * sizeof(GzSegHost), hipMemcpyHostToDevice, st));
+    HIPCHK(c, launch_gz_decode(d_comp, n, g.d_segs, n_seg, g.d_pool, g.d_outs, st));
+    std::vector<GzSegOutHost> outs(n_seg);
+    HIPCHK(c, hipMemcpyAsync(outs.data(), g.d_outs, n_seg * sizeof(GzSegOutHost), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    // the chain: a stretch counts when every one before it does and it ended exactly where the next starts (or with its member)
+    uint32_t n_ok = 0;
+    std::vector<uint64_t> toff(n_seg + 1, 0);
+    for (uint32_t i = 0; i < n_seg; ++i) {
+        const GzSegOutHost& o = outs[i];
+        if (o.status != 0) { *reason = o.status; break; }
+        if (toff[i] + o.n_sym > text_cap) { *reason = 3; break; }
+        toff[i + 1] = toff[i] + o.n_sym;
+        n_ok = i + 1;
+        *end_bit = o.end_bit;
+        if (o.final_block) { *final_member = 1; break; }
+    }
+    (void)window_known;
+    if (n_ok == 0) return VGMI_OK;
+    // 3. + 4. windows, then bytes
+    HIPCHK(c, hipMemcpyAsync(g.d_toff, toff.data(), (size_t)n_ok * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, launch_gz_resolve(g.d_pool, g.d_segs, g.d_outs, g.d_toff, n_ok, g.d_win, d_text, st));
+    *n_text = (size_t)toff[n_ok];
+    // the window behind the last stretch becomes the window in front of the next piece
+    HIPCHK(c, hipMemcpyAsync(g.d_win, g.d_win + (size_t)n_ok * 32768, 32768, hipMemcpyDeviceToDevice, st));
+    return VGMI_OK;
+}
+}  // namespace
+
+// A whole gzip file from host memory to host memory through the device pipeline (test and bench of the primitive; the streaming
+// form is vgmi_fastq_commit_gzip).  *consumed = compressed bytes the device took (whole file when it reached the member's end).
+int vgmi_gunzip_buffer(vgmi_ctx* c, const void* host_gz, size_t n, void* host_out, size_t cap, size_t* n_out, size_t* consumed, int* member_end,
+                       uint32_t* reason)
+{
+    if (!c || !host_gz || !host_out || !n_out) return VGMI_E_INVALID;
+    *n_out = 0;
+    if (consumed) *consumed = 0;
+    if (member_end) *member_end = 0;
+    if (reason) *reason = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    const unsigned char* p = static_cast<const unsigned char*>(host_gz);
+    const size_t hdr = gzip_header_len(p, n);
+    if (!hdr) return fail(c, VGMI_E_INVALID, "not a gzip member");
+    if (n >= (1u << 29)) return fail(c, VGMI_E_INVALID, "vgmi_gunzip_buffer: at most 512 MiB of compressed bytes per call");
+    uint8_t *d_comp = nullptr, *d_text = nullptr;
+    GzScratch g;
+    int rc = VGMI_OK;
+    hipError_t he = hipMalloc(reinterpret_cast<void**>(&d_comp), n + 4096);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&d_text), cap ? cap : 1);
+    if (he == hipSuccess) he = hipMemsetAsync(d_comp + n, 0, 4096, c->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(d_comp, host_gz, n, hipMemcpyHostToDevice, c->stream);
+    uint32_t end_bit = 0, why = 0;
+    size_t n_text = 0;
+    int fin = 0;
+    if (he == hipSuccess) rc = gz_piece(c, g, d_comp, (uint32_t)n, (uint32_t)hdr * 8u, false, d_text, cap, c->stream, &end_bit, &n_text, &fin, &why);
+    if (he == hipSuccess && rc == VGMI_OK) he = hipMemcpyAsync(host_out, d_text, n_text, hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    g.release();
+    if (d_comp) (void)hipFree(d_comp);
+    if (d_text) (void)hipFree(d_text);
+    HIPCHK(c, he);
+    if (rc) return rc;
+    *n_out = n_text;
+    if (consumed) *consumed = (end_bit + 7) / 8;
+    if (member_end) *member_end = fin;
+    if (reason) *reason = why;
+    return VGMI_OK;
+}
+
 int vgmi_fastq_bgzf_status(vgmi_fastq* f, int* failed, uint64_t* good_compressed_bytes, uint32_t* reason)
 {
     if (!f || !failed) return VGMI_E_INVALID;

@@ -1,0 +1,573 @@
+// vgmi_gunzip.hip -- ORDINARY gzip streams (one DEFLATE stream per file, what `gzip` and most sequencers write) inflated on the device.
+//
+// What it replaces: zlib's inflate behind gzread (include/kseq.h:59-72 over gzFile, src/fastq_kmer.cpp:74-78) -- one thread per
+// file in the reference, several host threads per file in rounds 2-3 (csrc/host/par_gunzip.cpp: 4e7 reads/s with sixteen of them,
+// a resource eight GPUs of a node share).  A DEFLATE stream has no member boundaries to split it at, so the scheme of
+// par_gunzip.cpp moves to the device:
+//   1. gz_find_kernel      a wavefront per 32 KiB of compressed bytes looks for the first position at or behind its offset where a
+//                          dynamic-code block can start: 64 bit positions per step against the cheap tests (BFINAL = 0, BTYPE = 2,
+//                          HLIT / HDIST in range, the code-length code's Kraft sum exact), survivors against the whole header
+//                          (literal/length and distance codes complete).
+//   2. gz_decode_kernel    a wavefront per stretch between two such starts decodes it the way vgmi_inflate.hip decodes a block-gzip
+//                          member (batches of 64 bit positions), but into 16-bit SYMBOLS: a back-reference that reaches in front
+//                          of the stretch -- into the 32 KiB window it cannot know -- yields placeholders 256 + (offset into that
+//                          window), which later copies propagate like bytes.  A stretch must END exactly where the next one starts:
+//                          that is the check of the guessed start (by induction from the stream's true first bit every start in an
+//                          unbroken chain is a true block start); a stretch that does not is where the device path ends.
+//   3. gz_window_kernel    the last 32 KiB of text behind every stretch, one after the other (each needs the one before)
+//   4. gz_resolve_kernel   every stretch's symbols -> bytes with its predecessor's window, written where the text chunk wants them
+// The host walks the gzip header, ships bytes, and reads back one small record per stretch.  Whatever the device cannot vouch for
+// -- a broken chain, a stretch that outgrows its room, the end of a member (trailer, a next member's header) -- ends the device path
+// at a known compressed offset and the host decoder (csrc/host/fast_inflate.cpp) goes on from there with the window it is handed.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vgmi_inflate_dev.h"
+#include "vgmi_kernels.h"
+
+namespace vgk {
+
+#define GZ_WAVES 4u
+#define GZ_WIN 32768u
+#define GZ_NONE 0xFFFFFFFFu
+
+typedef InfTablesT<uint16_t> GzTables;
+
+// ---- 1. block starts ---------------------------------------------------------------------------------------------------
+// starts[j] (j >= 1) = the first bit at or behind 8 * j * seg_bytes where a dynamic block's header stands, GZ_NONE if there is none
+// in front of 8 * (j + 2) * seg_bytes (or the data's end); starts[0] is the caller's (the stream's known position).
+__global__ __launch_bounds__(64 * GZ_WAVES, 3) void gz_find_kernel(const uint8_t* __restrict__ comp, uint32_t n_bytes, uint32_t seg_bytes, uint32_t n_seg,
+                                                                   uint32_t* __restrict__ starts)
+{
+    __shared__ GzTables tabs[GZ_WAVES];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_in_block = uni(threadIdx.x >> 6);
+    const uint32_t j = blockIdx.x * GZ_WAVES + wave_in_block + 1u;
+    if (j >= n_seg) return;
+    GzTables& t = tabs[wave_in_block];
+    const uint32_t* const in4 = reinterpret_cast<const uint32_t*>(comp);      // the batch buffer is 256-byte aligned
+    const uint32_t end_bits = n_bytes * 8u;
+    const uint32_t from = j * seg_bytes * 8u;
+    uint32_t to = from + 2u * seg_bytes * 8u;
+    if (to > end_bits - (end_bits < 2048u ? end_bits : 2048u)) to = end_bits - (end_bits < 2048u ? end_bits : 2048u);    // a header needs room
+    uint32_t found = GZ_NONE;
+
+    // scalar bit reader (vgmi_inflate.hip's), restarted per candidate
+    uint64_t bitbuf = 0;
+    uint32_t bitcnt = 0, ip = 0;
+    const uint32_t* wq;
+    uint32_t wa, wb, wc;
+    auto reload = [&]() {
+        const uint32_t lead = ip & 3u;
+        wq = in4 + (ip >> 2);
+        wa = ld32u(wq);
+        wb = ld32u(wq + 1);
+        wc = ld32u(wq + 2);
+        bitbuf = (uint64_t)(wa >> (8u * lead));
+        bitcnt = 32u - 8u * lead;
+        ip += 4u - lead;
+        wa = wb;
+        wb = wc;
+        wc = ld32u(wq + 3);
+        ++wq;
+    };
+    auto refill = [&]() {
+        if (bitcnt <= 32u) {
+            bitbuf |= (uint64_t)wa << bitcnt;
+            bitcnt += 32u;
+            ip += 4u;
+            wa = wb;
+            wb = wc;
+            wc = ld32u(wq + 3);
+            ++wq;
+        }
+    };
+    auto take = [&](uint32_t n) -> uint32_t {
+        const uint32_t v = (uint32_t)bitbuf & ((1u << n) - 1u);
+        bitbuf >>= n;
+        bitcnt -= n;
+        return v;
+    };
+    // the whole header at bit p: three complete codes (what every encoder writes)?
+    auto header_ok = [&](uint32_t p) -> bool {
+        ip = p >> 3;
+        reload();
+        take(p & 7u);
+        refill();
+        take(3);
+        const uint32_t hlit = take(5) + 257, hdist = take(5) + 1, hclen = take(4) + 4;
+        if (hlit > 286 || hdist > 30) return false;
+        refill();
+        if (lane < 19) t.len[288 + lane] = 0;
+        inf_sync();
+        for (uint32_t i = 0; i < hclen; ++i) {
+            if (bitcnt < 3) refill();
+            const uint32_t v = take(3);
+            if (lane == 0) t.len[288 + uni(inf_clen_order[i])] = (uint8_t)v;
+        }
+        inf_sync();
+        if (!inf_build(t, 1, 288, 19, lane)) return false;
+        uint32_t idx = 0, prev = 0;
+        bool bad = false;
+        uint8_t* const stage = reinterpret_cast<uint8_t*>(t.lit);
+        auto put = [&](uint32_t i, uint32_t v) { if (lane == 0) stage[i] = (uint8_t)v; };
+        while (idx < hlit + hdist) {
+            refill();
+            const uint32_t e = uni(t.dist[(uint32_t)bitbuf & ((1u << INF_DIST_BITS) - 1u)]);
+            const uint32_t l = e & 15u, sym = e >> 4;
+            if (!l) { bad = true; break; }
+            take(l);
+            if (sym < 16) {
+                put(idx++, sym);
+                prev = sym;
+            } else {
+                uint32_t rep, val = 0;
+                if (sym == 16) {
+                    if (idx == 0) { bad = true; break; }
+                    val = prev;
+                    rep = 3 + take(2);
+                } else if (sym == 17) rep = 3 + take(3);
+                else rep = 11 + take(7);
+                if (idx + rep > hlit + hdist) { bad = true; break; }
+                for (uint32_t r = 0; r < rep; ++r) put(idx++, val);
+                prev = val;
+            }
+        }
+        if (bad) return false;
+        inf_sync();
+        // Kraft sums of the two codes, 32768 = complete (a single distance code of one bit is what zlib tolerates)
+        uint32_t sl = 0, sd = 0, nd = 0, one = 0;
+        for (uint32_t s = lane; s < hlit + hdist; s += 64) {
+            const uint32_t l = stage[s];
+            if (!l) continue;
+            if (s < hlit) sl += 32768u >> l;
+            else {
+                sd += 32768u >> l;
+                ++nd;
+                one += l == 1;
+            }
+        }
+        for (uint32_t o = 32; o; o >>= 1) {
+            sl += (uint32_t)__shfl_xor((int)sl, (int)o, 64);
+            sd += (uint32_t)__shfl_xor((int)sd, (int)o, 64);
+            nd += (uint32_t)__shfl_xor((int)nd, (int)o, 64);
+            one += (uint32_t)__shfl_xor((int)one, (int)o, 64);
+        }
+        const uint32_t eob = uni(hlit > 256 ? stage[256] : 0u);
+        inf_sync();
+        return uni(sl) == 32768u && eob != 0 && (uni(sd) == 32768u || (uni(nd) == 1 && uni(one) == 1));
+    };
+
+    for (uint32_t base = from; base < to && found == GZ_NONE; base += 64u) {
+        // lane i looks at bit base + i: BFINAL 0, BTYPE 10, HLIT <= 29, HDIST <= 29, then the code-length code's Kraft sum
+        const uint32_t b = base + lane;
+        const uint32_t* const w = in4 + (b >> 5);
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, b & 31u), mid = __builtin_amdgcn_alignbit(w2, w1, b & 31u),
+                       hi = __builtin_amdgcn_alignbit(w3, w2, b & 31u);
+        bool cand = b < to && (lo & 7u) == 4u && ((lo >> 3) & 31u) <= 29u && ((lo >> 8) & 31u) <= 29u;
+        const uint32_t hclen = ((lo >> 13) & 15u) + 4u;
+        // the 3-bit lengths start at bit 17: 57 bits at most
+        const uint64_t f = ((uint64_t)__builtin_amdgcn_alignbit(hi, mid, 17) << 32 | __builtin_amdgcn_alignbit(mid, lo, 17)) & ((1ULL << (3u * hclen)) - 1ULL);
+        uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < 19; ++c) {
+            const uint32_t l = (uint32_t)(f >> (3u * c)) & 7u;
+            sum += l ? 128u >> l : 0u;
+        }
+        cand = cand && sum == 128u;
+        uint64_t m = __ballot(cand);
+        while (m && found == GZ_NONE) {
+            const uint32_t p = base + (uint32_t)__builtin_ctzll(m);
+            m &= m - 1ull;
+            if (header_ok(p)) found = p;
+        }
+    }
+    if (lane == 0) starts[j] = found;
+}
+
+// ---- 2. a stretch between two block starts -> symbols ------------------------------------------------------------------
+struct GzSeg {
+    uint32_t start_bit, stop_bit;     // decode blocks from start_bit until one ends at or behind stop_bit (GZ_NONE: to the data's end)
+    uint32_t sym_off, sym_cap;        // room in the symbol pool (symbols)
+};
+struct GzSegOut {
+    uint32_t n_sym;        // symbols written
+    uint32_t end_bit;      // where the last decoded block ended
+    uint32_t status;       // 0 good: end_bit == stop_bit.  1 code lengths, 2 bad symbol / distance, 3 room / input overrun, 6 stored header,
+                           // 7 reserved type, 8 ended behind stop_bit (a guessed start was no block start), 9 the data ended inside a block
+    uint32_t final_block;  // the last decoded block carried BFINAL: the member ends at end_bit
+};
+
+__global__ __launch_bounds__(64 * GZ_WAVES, 3) void gz_decode_kernel(const uint8_t* __restrict__ comp, uint32_t n_bytes, const GzSeg* __restrict__ segs,
+                                                                     uint32_t n_seg, uint16_t* __restrict__ pool, GzSegOut* __restrict__ outs)
+{
+    __shared__ GzTables tabs[GZ_WAVES];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_in_block = uni(threadIdx.x >> 6);
+    const uint32_t sg = blockIdx.x * GZ_WAVES + wave_in_block;
+    if (sg >= n_seg) return;
+    GzTables& t = tabs[wave_in_block];
+    const uint8_t* const in = comp;
+    const uint32_t* const in4 = reinterpret_cast<const uint32_t*>(comp);
+    const uint32_t end_bits = n_bytes * 8u;
+    const uint32_t stop_bit = uni(segs[sg].stop_bit);
+    uint16_t* const out = pool + uni(segs[sg].sym_off);
+    const uint32_t out_cap = uni(segs[sg].sym_cap);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(out_cap * 2u), 0x00020000);
+    uint32_t* const ring32 = reinterpret_cast<uint32_t*>(t.ring);
+
+    uint32_t bp = uni(segs[sg].start_bit);
+    uint32_t op = 0, flushed = 0, err = 0;
+
+    // ring -> global memory: whole blocks of 128 symbols (the pool slice is word aligned); all of it at the end
+    auto flush = [&](bool all) {
+        while (op - flushed >= 128u) {
+            const uint32_t r = (flushed + 2u * lane) & (INF_RING - 1u);
+            __builtin_amdgcn_raw_buffer_store_b32(ring32[r >> 1], orsrc, (flushed + 2u * lane) * 2u, 0, 0);
+            flushed += 128u;
+        }
+        if (all)
+            while (flushed < op) {
+                const uint32_t p = flushed + lane;
+                if (p < op) __builtin_amdgcn_raw_buffer_store_b16(t.ring[p & (INF_RING - 1u)], orsrc, p * 2u, 0, 0);
+                flushed = flushed + 64u < op ? flushed + 64u : op;
+            }
+    };
+    // one LZ77 match at output position P: sources in front of the stretch are placeholders for the window it does not know
+    auto copy_match = [&](uint32_t P, uint32_t len, uint32_t dist) {
+        const bool far = dist > INF_NEAR;
+        if (far) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // flushed symbols are read back (see vgmi_inflate.hip)
+        for (uint32_t i = lane; i < len; i += 64) {
+            const int32_t q = (int32_t)(P - dist + (dist >= len ? i : i % dist));
+            uint16_t v;
+            if (q < 0) v = (uint16_t)(256 + (int32_t)GZ_WIN + q);
+            else v = far ? out[q] : t.ring[(uint32_t)q & (INF_RING - 1u)];
+            t.ring[(P + i) & (INF_RING - 1u)] = v;
+        }
+        inf_sync();
+    };
+
+    uint64_t bitbuf = 0;
+    uint32_t bitcnt = 0, ip = 0;
+    const uint32_t* wq;
+    uint32_t wa, wb, wc;
+    auto reload = [&]() {
+        const uint32_t lead = ip & 3u;
+        wq = in4 + (ip >> 2);
+        wa = ld32u(wq);
+        wb = ld32u(wq + 1);
+        wc = ld32u(wq + 2);
+        bitbuf = (uint64_t)(wa >> (8u * lead));
+        bitcnt = 32u - 8u * lead;
+        ip += 4u - lead;
+        wa = wb;
+        wb = wc;
+        wc = ld32u(wq + 3);
+        ++wq;
+    };
+    auto refill = [&]() {
+        if (bitcnt <= 32u) {
+            bitbuf |= (uint64_t)wa << bitcnt;
+            bitcnt += 32u;
+            ip += 4u;
+            wa = wb;
+            wb = wc;
+            wc = ld32u(wq + 3);
+            ++wq;
+        }
+    };
+    auto need = [&](uint32_t n) { if (bitcnt < n) refill(); };
+    auto take = [&](uint32_t n) -> uint32_t {
+        const uint32_t v = (uint32_t)bitbuf & ((1u << n) - 1u);
+        bitbuf >>= n;
+        bitcnt -= n;
+        return v;
+    };
+    auto scalar_at_bp = [&]() {
+        ip = bp >> 3;
+        reload();
+        take(bp & 7u);
+    };
+    auto scalar_done = [&]() { bp = 8u * ip - bitcnt; };
+
+    bool last = false;
+    uint32_t block_end = bp;        // end of the last block decoded whole
+    while (!last && !err && bp < stop_bit) {
+        if (bp + 3u > end_bits) { err = 9; break; }
+        scalar_at_bp();
+        refill();
+        last = take(1) != 0;
+        const uint32_t type = take(2);
+        if (type == 0) {            // stored
+            take(bitcnt & 7u);
+            refill();
+            const uint32_t len = take(16), nlen = take(16);
+            if ((len ^ 0xFFFFu) != nlen) { err = 6; break; }
+            const uint32_t src = ip - (bitcnt >> 3);
+            if (src + len > n_bytes) { err = 9; break; }
+            if (op + len > out_cap) { err = 3; break; }
+            for (uint32_t done = 0; done < len;) {
+                const uint32_t n = len - done < 128u ? len - done : 128u;
+                for (uint32_t i = lane; i < n; i += 64) t.ring[(op + i) & (INF_RING - 1u)] = in[src + done + i];
+                inf_sync();
+                op += n;
+                done += n;
+                flush(false);
+            }
+            bp = 8u * (src + len);
+            block_end = bp;
+            continue;
+        }
+        if (type == 3) { err = 7; break; }
+        if (type == 1) {
+            for (uint32_t s = lane; s < 288; s += 64) t.len[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+            if (lane < 32) t.len[288 + lane] = 5;
+            inf_sync();
+            if (!inf_build(t, 0, 0, 288, lane) || !inf_build(t, 1, 288, 30, lane)) { err = 1; break; }
+        } else {
+            const uint32_t hlit = take(5) + 257, hdist = take(5) + 1, hclen = take(4) + 4;
+            if (hlit > 286 || hdist > 30) { err = 1; break; }
+            refill();
+            if (lane < 19) t.len[288 + lane] = 0;
+            inf_sync();
+            for (uint32_t i = 0; i < hclen; ++i) {
+                if (bitcnt < 3) refill();
+                const uint32_t v = take(3);
+                if (lane == 0) t.len[288 + uni(inf_clen_order[i])] = (uint8_t)v;
+            }
+            inf_sync();
+            if (!inf_build(t, 1, 288, 19, lane)) { err = 1; break; }
+            uint32_t idx = 0, prev = 0;
+            uint8_t* const stage = reinterpret_cast<uint8_t*>(t.lit);
+            auto put = [&](uint32_t i, uint32_t v) { if (lane == 0) stage[i] = (uint8_t)v; };
+            while (idx < hlit + hdist && !err) {
+                refill();
+                const uint32_t e = uni(t.dist[(uint32_t)bitbuf & ((1u << INF_DIST_BITS) - 1u)]);
+                const uint32_t l = e & 15u, sym = e >> 4;
+                if (!l) { err = 1; break; }
+                take(l);
+                if (sym < 16) {
+                    put(idx++, sym);
+                    prev = sym;
+                } else {
+                    uint32_t rep, val = 0;
+                    if (sym == 16) {
+                        if (idx == 0) { err = 1; break; }
+                        val = prev;
+                        rep = 3 + take(2);
+                    } else if (sym == 17) rep = 3 + take(3);
+                    else rep = 11 + take(7);
+                    if (idx + rep > hlit + hdist) { err = 1; break; }
+                    for (uint32_t r = 0; r < rep; ++r) put(idx++, val);
+                    prev = val;
+                }
+            }
+            if (err) break;
+            inf_sync();
+            uint8_t mine[5];
+#pragma unroll
+            for (uint32_t q = 0; q < 5; ++q) {
+                const uint32_t s = lane + 64 * q;
+                uint32_t v = 0;
+                if (s < 288) {
+                    if (s < hlit) v = stage[s];
+                } else if (s - 288 < hdist) v = stage[hlit + (s - 288)];
+                mine[q] = (uint8_t)v;
+            }
+            inf_sync();
+#pragma unroll
+            for (uint32_t q = 0; q < 5; ++q) t.len[lane + 64 * q] = mine[q];
+            inf_sync();
+            if (uni(t.len[256]) == 0) { err = 1; break; }
+            if (!inf_build(t, 0, 0, 288, lane) || !inf_build(t, 1, 288, 30, lane)) { err = 1; break; }
+        }
+        inf_pack_lit(t, lane);
+        inf_pack_dist(t, lane);
+        scalar_done();
+
+        bool eob = false;
+        while (!eob && !err) {
+            const uint32_t b = bp + lane;
+            const uint32_t* const w = in4 + (b >> 5);
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, b & 31u), hi = __builtin_amdgcn_alignbit(w2, w1, b & 31u);
+            const uint32_t e = t.lit[lo & ((1u << INF_LIT_BITS) - 1u)];
+            const uint32_t cb = e & 15u, kind = (e >> 4) & 3u;
+            const uint32_t eb = (e >> 6) & 7u;
+            const uint32_t mlen = ((e >> 9) & 511u) + ((lo >> cb) & ((1u << eb) - 1u));
+            const uint32_t pd = cb + eb;
+            const uint32_t de = t.dist[(lo >> pd) & ((1u << INF_DIST_BITS) - 1u)];
+            const uint32_t dl = de & 15u, deb = (de >> 4) & 15u;
+            const uint32_t qd = pd + dl;
+            const uint32_t mdist = (de >> 8) + (__builtin_amdgcn_alignbit(hi, lo, qd) & ((1u << deb) - 1u));
+            uint32_t info;
+            if (cb == 0) info = 1u << 15;
+            else if (kind == 0) info = cb | ((e >> 6) & 3u) << 6;
+            else if (kind == 2) info = cb | 1u << 16;
+            else info = dl ? (qd + deb) | mlen << 6 | 1u << 17 : 1u << 15;
+            uint32_t pos = 0, off = 0, offv = 0;
+            uint64_t lits = 0, matches = 0;
+            bool slow = false;
+            while (pos < 64u) {
+                const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)pos);
+                if (inf & (1u << 15)) { slow = true; break; }
+                const uint32_t ol = (inf >> 6) & 511u;
+                if (off && off + ol > INF_BATCH_OUT) break;
+                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(offv) : "s"(off), "s"(pos) : "m0");
+                if (inf & (1u << 17)) matches |= 1ull << pos;
+                else lits |= 1ull << pos;
+                off += ol;
+                pos += inf & 63u;
+                if (inf & (1u << 16)) { eob = true; break; }
+            }
+            if (op + off > out_cap) { err = 3; break; }
+            if (bp + pos > end_bits) { err = 9; break; }       // the symbols ran into the padding behind the data
+            if ((lits >> lane) & 1ull) {
+                const uint32_t n = (e >> 6) & 3u, P = op + offv;
+                if (kind == 0) {
+                    t.ring[P & (INF_RING - 1u)] = (uint16_t)((e >> 8) & 255u);
+                    if (n > 1) t.ring[(P + 1u) & (INF_RING - 1u)] = (uint16_t)((e >> 16) & 255u);
+                    if (n > 2) t.ring[(P + 2u) & (INF_RING - 1u)] = (uint16_t)(e >> 24);
+                }
+            }
+            inf_sync();
+            while (matches) {
+                const uint32_t ml = (uint32_t)__builtin_ctzll(matches);
+                matches &= matches - 1ull;
+                const uint32_t P = op + (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)ml);
+                const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)mlen, (int)ml);
+                const uint32_t dist = (uint32_t)__builtin_amdgcn_readlane((int)mdist, (int)ml);
+                if (dist > P + GZ_WIN) { err = 2; break; }
+                copy_match(P, len, dist);
+            }
+            if (err) break;
+            op += off;
+            bp += pos;
+            flush(false);
+            if (slow) {
+                scalar_at_bp();
+                need(32);
+                uint32_t l;
+                int32_t sym = inf_slow(t, 0, bitbuf, l);
+                sym = (int32_t)uni((uint32_t)sym);
+                l = uni(l);
+                if (sym < 0) { err = 2; break; }
+                take(l);
+                if (sym < 256) {
+                    if (op >= out_cap) { err = 3; break; }
+                    if (lane == 0) t.ring[op & (INF_RING - 1u)] = (uint16_t)sym;
+                    inf_sync();
+                    ++op;
+                } else if (sym == 256) {
+                    eob = true;
+                } else {
+                    sym -= 257;
+                    if (sym >= 29) { err = 2; break; }
+                    uint32_t len;
+                    if (sym < 8) len = 3 + (uint32_t)sym;
+                    else if (sym == 28) len = 258;
+                    else {
+                        const uint32_t x = ((uint32_t)sym >> 2) - 1;
+                        len = ((4u + ((uint32_t)sym & 3u)) << x) + 3u + take(x);
+                    }
+                    need(32);
+                    uint32_t dl2;
+                    int32_t dsym = inf_slow(t, 1, bitbuf, dl2);
+                    dsym = (int32_t)uni((uint32_t)dsym);
+                    dl2 = uni(dl2);
+                    if (dsym < 0 || dsym >= 30) { err = 2; break; }
+                    take(dl2);
+                    uint32_t dist;
+                    if (dsym < 4) dist = 1 + (uint32_t)dsym;
+                    else {
+                        const uint32_t x = ((uint32_t)dsym >> 1) - 1;
+                        dist = ((2u + ((uint32_t)dsym & 1u)) << x) + 1u + take(x);
+                    }
+                    if (dist > op + GZ_WIN) { err = 2; break; }
+                    if (op + len > out_cap) { err = 3; break; }
+                    copy_match(op, len, dist);
+                    op += len;
+                }
+                scalar_done();
+                if (bp > end_bits) { err = 9; break; }
+                flush(false);
+            }
+        }
+        if (!err) block_end = bp;
+    }
+    if (!err && !last && stop_bit != GZ_NONE && block_end != stop_bit) err = 8;
+    if (!err && !last && stop_bit == GZ_NONE) err = 9;        // the data ended between two blocks: the stream goes on in the next piece
+    // (a member that ends in front of stop_bit is no error of this stretch: the chain ends with it, final_block says so)
+    flush(true);
+    if (lane == 0) outs[sg] = GzSegOut{op, block_end, err, last ? 1u : 0u};
+}
+
+// ---- 3. the window behind every stretch, one after the other ------------------------------------------------------------
+// win[(j + 1) * GZ_WIN ..] = the last GZ_WIN bytes of text behind stretch j (win[0 .. GZ_WIN) = the window in front of stretch 0:
+// the carried one, or anything at a member's start, where no placeholder can exist)
+__global__ __launch_bounds__(1024) void gz_window_kernel(const uint16_t* __restrict__ pool, const GzSeg* __restrict__ segs, const GzSegOut* __restrict__ outs,
+                                                         uint32_t n_seg, uint8_t* __restrict__ win)
+{
+    for (uint32_t j = 0; j < n_seg; ++j) {
+        const uint8_t* const prev = win + (size_t)j * GZ_WIN;
+        uint8_t* const cur = win + (size_t)(j + 1) * GZ_WIN;
+        const uint16_t* const sym = pool + segs[j].sym_off;
+        const uint32_t n = outs[j].n_sym;
+        for (uint32_t x = threadIdx.x; x < GZ_WIN; x += blockDim.x) {
+            uint8_t v;
+            if (n < GZ_WIN && x < GZ_WIN - n) v = prev[x + n];
+            else {
+                const uint16_t s = sym[n >= GZ_WIN ? n - GZ_WIN + x : x - (GZ_WIN - n)];
+                v = s < 256 ? (uint8_t)s : prev[s - 256];
+            }
+            cur[x] = v;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// ---- 4. symbols -> bytes --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gz_resolve_kernel(const uint16_t* __restrict__ pool, const GzSeg* __restrict__ segs, const GzSegOut* __restrict__ outs,
+                                                         const uint64_t* __restrict__ text_off, uint32_t n_seg, const uint8_t* __restrict__ win,
+                                                         uint8_t* __restrict__ text)
+{
+    const uint32_t j = blockIdx.x / 16u, part = blockIdx.x % 16u;      // sixteen workgroups per stretch
+    if (j >= n_seg) return;
+    const uint8_t* const prev = win + (size_t)j * GZ_WIN;
+    const uint16_t* const sym = pool + segs[j].sym_off;
+    uint8_t* const dst = text + text_off[j];
+    const uint32_t n = outs[j].n_sym;
+    for (uint32_t x = part * 256u + threadIdx.x; x < n; x += 16u * 256u) {
+        const uint16_t s = sym[x];
+        dst[x] = s < 256 ? (uint8_t)s : prev[s - 256];
+    }
+}
+
+hipError_t launch_gz_find(const uint8_t* comp, uint32_t n_bytes, uint32_t seg_bytes, uint32_t n_seg, uint32_t* starts, hipStream_t st)
+{
+    if (n_seg > 1) hipLaunchKernelGGL(gz_find_kernel, dim3((n_seg - 1 + GZ_WAVES - 1) / GZ_WAVES), dim3(64 * GZ_WAVES), 0, st, comp, n_bytes, seg_bytes, n_seg, starts);
+    return hipGetLastError();
+}
+
+hipError_t launch_gz_decode(const uint8_t* comp, uint32_t n_bytes, const void* segs, uint32_t n_seg, uint16_t* pool, void* outs, hipStream_t st)
+{
+    if (n_seg)
+        hipLaunchKernelGGL(gz_decode_kernel, dim3((n_seg + GZ_WAVES - 1) / GZ_WAVES), dim3(64 * GZ_WAVES), 0, st, comp, n_bytes, static_cast<const GzSeg*>(segs), n_seg,
+                           pool, static_cast<GzSegOut*>(outs));
+    return hipGetLastError();
+}
+
+hipError_t launch_gz_resolve(const uint16_t* pool, const void* segs, const void* outs, const uint64_t* text_off, uint32_t n_seg, uint8_t* win, uint8_t* text,
+                             hipStream_t st)
+{
+    if (n_seg) {
+        hipLaunchKernelGGL(gz_window_kernel, dim3(1), dim3(1024), 0, st, pool, static_cast<const GzSeg*>(segs), static_cast<const GzSegOut*>(outs), n_seg, win);
+        hipLaunchKernelGGL(gz_resolve_kernel, dim3(n_seg * 16u), dim3(256), 0, st, pool, static_cast<const GzSeg*>(segs), static_cast<const GzSegOut*>(outs), text_off,
+                           n_seg, win, text);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace vgk

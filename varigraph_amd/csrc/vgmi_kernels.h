@@ -150,6 +150,19 @@ struct BgzfVerdict {         // device-resident, per stream
 hipError_t launch_bgzf_inflate(const uint8_t* comp, const BgzfMember* members, uint32_t n_members, uint8_t* out_base, uint32_t* status,
                                const uint32_t* crc_table, BgzfVerdict* verdict, hipStream_t s);
 
+// ordinary gzip streams inflated on the device (vgmi_gunzip.hip): block starts guessed per 32 KiB of compressed bytes, the stretches
+// between them decoded into symbols (bytes and placeholders for the window in front), windows propagated, symbols resolved
+struct GzSegHost {
+    uint32_t start_bit, stop_bit, sym_off, sym_cap;
+};
+struct GzSegOutHost {
+    uint32_t n_sym, end_bit, status, final_block;
+};
+hipError_t launch_gz_find(const uint8_t* comp, uint32_t n_bytes, uint32_t seg_bytes, uint32_t n_seg, uint32_t* starts, hipStream_t st);
+hipError_t launch_gz_decode(const uint8_t* comp, uint32_t n_bytes, const void* segs, uint32_t n_seg, uint16_t* pool, void* outs, hipStream_t st);
+hipError_t launch_gz_resolve(const uint16_t* pool, const void* segs, const void* outs, const uint64_t* text_off, uint32_t n_seg, uint8_t* win, uint8_t* text,
+                             hipStream_t st);
+
 // ---- HMM recursion (vgmi_hmm.hip) ----
 struct HmmChain {
     uint64_t first_step, n_steps;   // its steps in the step arrays, in the order they are taken

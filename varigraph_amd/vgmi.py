@@ -65,6 +65,7 @@ def load_library():
         "vgmi_fastq_commit": (i32, [vp, sz]),
         "vgmi_fastq_commit_bgzf": (i32, [vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(i32)]),
         "vgmi_fastq_bgzf_status": (i32, [vp, C.POINTER(i32), C.POINTER(u64), C.POINTER(u32)]),
+        "vgmi_gunzip_buffer": (i32, [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(i32), C.POINTER(u32)]),
         "vgmi_fastq_close": (i32, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(i32), vp, sz, C.POINTER(sz)]),
         "vgmi_sketch_keys": (i32, [vp, vp, sz, vp, sz, u32, vp]),
         "vgmi_bloom_params": (i32, [u64, C.c_double, C.POINTER(u64), C.POINTER(u32)]),
@@ -357,6 +358,15 @@ class Context:
         return {"n_records": nr.value, "n_bases": nbs.value, "consumed": cons.value, "stopped": bool(st.value),
                 "tail": tail.raw[:tl.value], "inflate_failed": bool(failed.value), "good_compressed_bytes": good.value,
                 "reason": reason.value, "taken": total_taken}
+
+    def gunzip(self, comp, cap):
+        """An ordinary gzip member through the device pipeline (vgmi_gunzip_buffer): (text bytes, compressed bytes consumed, member
+        end reached, reason the device stopped early)."""
+        comp = bytes(comp)
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        n_out, cons, fin, why = C.c_size_t(), C.c_size_t(), C.c_int(), C.c_uint32()
+        self._chk(self._l.vgmi_gunzip_buffer(self._h, comp, len(comp), _ptr(out), cap, C.byref(n_out), C.byref(cons), C.byref(fin), C.byref(why)))
+        return out[:n_out.value].tobytes(), cons.value, bool(fin.value), why.value
 
     def sketch_keys(self, block, n_reads, k, read_off=None):
         block = np.ascontiguousarray(block, dtype=np.uint8)
