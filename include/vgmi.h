@@ -183,6 +183,15 @@ int vgmi_fastq_commit_bgzf(vgmi_fastq *fq, size_t n_bytes, size_t *taken, size_t
  * decoder's.  Test and bench entry of the primitive. */
 int vgmi_gunzip_buffer(vgmi_ctx *ctx, const void *host_gz, size_t n, void *host_out, size_t cap, size_t *n_out, size_t *consumed,
                        int *member_end, uint32_t *reason);
+/* The same inside a FASTQ stream (vgmi_fastq_open / _acquire, then this instead of _commit): the staged bytes [0, n_bytes) continue an
+ * ordinary gzip stream -- at a member header when the stream stands at a member's start, else at the byte that holds the next block's
+ * first bit, i.e. what the previous call left untaken.  taken = staged bytes used up (present the rest again in front of what
+ * follows); n_text = text inflated, parsed and counted by this call.  stop: 0 go on; 1 the gzip data is over (a member ended and
+ * what follows is no member header: gzread ignores it too); 2 the device cannot take these bytes (vgmi_fastq_gzip_status: why) -- the
+ * host decoder carries on from the text the device parser has consumed (vgmi_fastq_close's `consumed`).  at_eof: the staged bytes
+ * are the file's last. */
+int vgmi_fastq_commit_gzip(vgmi_fastq *fq, size_t n_bytes, int at_eof, size_t *taken, size_t *n_text, int *stop);
+int vgmi_fastq_gzip_status(vgmi_fastq *fq, uint64_t *device_text_bytes, uint32_t *reason);
 /* After the last commit (waits): failed != 0 if a member did not inflate to its ISIZE / CRC-32; good_compressed_bytes =
  * compressed bytes in front of the first such member (all committed bytes if none failed): the text of those bytes went
  * through the parser, the host decoder takes the file over at that offset. */

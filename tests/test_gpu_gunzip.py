@@ -71,3 +71,67 @@ def test_device_gunzip_stored_and_fixed_blocks_and_garbage(ctx):
         except zlib.error:
             pass
         assert len(got) > 0 and got == want[:len(got)]
+
+
+def _graph_ctx():
+    import os
+    from conftest import get_cohort
+    from varigraph_amd import host
+    cohort = get_cohort("cohort_snp")
+    g = host.Graph(os.path.join(cohort.dir, "graph.bin.gz"))
+    c = vgmi.Context(0, buffer_mib=16)
+    g.upload(c)
+    return g, c, cohort
+
+
+def test_gzip_stream_through_the_device_parser_and_counters():
+    """vgmi_fastq_commit_gzip: an ordinary gzip FASTQ file inflated, parsed and counted on the device, whole and in pieces (what a piece
+    leaves untaken is presented again), two members back to back, and a stream the device must give up in the middle -- the counters
+    of what it took are those of the text's prefix it reports."""
+    import oracle_lib as o
+    g, c, cohort = _graph_ctx()
+    try:
+        hap = cohort.haplotypes()[1]
+        rng = np.random.default_rng(5)
+        reads = [hap[s:s + 150].tobytes() for s in rng.integers(0, len(hap) - 150, size=60_000)]
+        text = b"".join(b"@r%d\n" % i + r + b"\n+\n" + b"I" * 150 + b"\n" for i, r in enumerate(reads))
+        block = np.frombuffer(b"".join(r + b"\n" for r in reads), dtype=np.uint8)
+        t = o.Table(cohort.graph.keys)
+        t.count_block(block, cohort.k)
+        want = t.counts()
+        comp = gzip.compress(text, 6)
+        for piece in (None, 1 << 20, 300_000):
+            c.counts_reset()
+            r = c.fastq_gzip(comp, piece=piece)
+            got, _, _ = c.counts_finish()
+            assert r["stop"] == 1 and r["reason"] == 0 and not r["stopped"], (piece, r["stop"], r["reason"])
+            assert r["device_text_bytes"] == len(text) and r["taken"] == len(comp)
+            assert (r["n_records"], r["consumed"], r["tail"]) == (len(reads), len(text), b"")
+            assert np.array_equal(got, want), piece
+        # two members: gzread runs them together
+        half = len(reads) // 2
+        cut = text.index(b"@r%d\n" % half)
+        two = gzip.compress(text[:cut], 6) + gzip.compress(text[cut:], 1)
+        c.counts_reset()
+        r = c.fastq_gzip(two)
+        got, _, _ = c.counts_finish()
+        assert r["stop"] == 1 and r["n_records"] == len(reads) and np.array_equal(got, want)
+        # garbage behind the member is ignored; a damaged stream ends the device path with what was whole
+        c.counts_reset()
+        r = c.fastq_gzip(comp + b"not gzip at all" * 10)
+        got, _, _ = c.counts_finish()
+        assert r["stop"] == 1 and r["n_records"] == len(reads) and np.array_equal(got, want)
+        bad = bytearray(comp)
+        for k in range(len(bad) // 2, len(bad) // 2 + 64):
+            bad[k] = 0xFF
+        c.counts_reset()
+        r = c.fastq_gzip(bytes(bad))
+        c.counts_finish()
+        # (the damaged stretch either fails -- stop 2, the host decoder goes on from the text so far -- or decodes, as it would in zlib,
+        # into bytes that end in a "last" block: stop 1.  Whole files against the host path: tests/test_gpu_ingest.py.)
+        assert r["stop"] in (1, 2) and 0 < r["device_text_bytes"]
+        if r["stop"] == 2:
+            assert r["reason"] != 0 and r["device_text_bytes"] < len(text) and text[:r["consumed"]].count(b"\n") == 4 * r["n_records"]
+    finally:
+        c.close()
+        g.close()

@@ -177,6 +177,13 @@ DeviceFileResult device_file(vgmi_ctx* ctx, const std::string& path, size_t bloc
         if (off && off[0] == '1') bgzf = false;
     }
 
+    // ordinary gzip: inflated on the device too (vgmi_gunzip.hip; VGH_DEVICE_GUNZIP=0: by the host's inflate threads, the A/B and
+    // the path that takes over wherever the device gives a stream up)
+    bool dev_gunzip = !plain && !bgzf;
+    if (const char* e = std::getenv("VGH_DEVICE_GUNZIP"))
+        if (e[0] == '0') dev_gunzip = false;
+    bool gz_gave_up = false;
+
     vgmi_fastq* fq = nullptr;
     if (vgmi_fastq_open(ctx, &fq) != VGMI_OK) throw std::runtime_error(vgmi_last_error(ctx));
     uint64_t n_rec = 0, n_bases = 0, consumed = 0;
@@ -195,14 +202,14 @@ DeviceFileResult device_file(vgmi_ctx* ctx, const std::string& path, size_t bloc
     };
     try {
         std::unique_ptr<ByteSource> src;
-        if (!plain && !bgzf) src = ByteSource::open(path, threads);
+        if (!plain && !bgzf && !dev_gunzip) src = ByteSource::open(path, threads);
         uint64_t offset = 0;
         const unsigned char* left_p = nullptr;   // rest of a decoded chunk that did not fit the previous buffer
         size_t left_n = 0;
         std::vector<char> carry;                 // block gzip: the bytes behind the last whole member of the previous buffer
         double ratio = 5.0;                      // text bytes per compressed byte, tracked
         size_t text_cap = 0;
-        if (bgzf && vgmi_fastq_text_capacity(fq, &text_cap) != VGMI_OK) throw std::runtime_error(vgmi_last_error(ctx));
+        if ((bgzf || dev_gunzip) && vgmi_fastq_text_capacity(fq, &text_cap) != VGMI_OK) throw std::runtime_error(vgmi_last_error(ctx));
         for (;;) {
             char* buf = nullptr;
             size_t cap = 0;
@@ -231,6 +238,24 @@ DeviceFileResult device_file(vgmi_ctx* ctx, const std::string& path, size_t bloc
                 if (not_bgzf) break;                                  // the host decoder goes on at comp_taken
                 if (offset >= file_size && (taken == 0 || carry.empty())) break;   // end of the file (a cut-off member stays for the host)
                 if (taken == 0 && want >= cap) break;                 // cannot happen with 64 KiB members; never spin
+            } else if (dev_gunzip) {
+                // compressed bytes whose text fills about nine tenths of a chunk; what the device leaves untaken (the stretch that
+                // runs on into the bytes to come) is presented again in front of them
+                size_t want = (size_t)std::min<double>((double)cap, 0.9 * (double)text_cap / ratio);
+                want = std::max<size_t>(want, std::min<size_t>(cap, carry.size() + (1u << 20)));
+                memcpy(buf, carry.data(), carry.size());
+                n = carry.size();
+                const size_t got = fill_plain(fd, offset, file_size, buf + n, want - n, threads);
+                offset += got;
+                n += got;
+                const bool at_eof = offset >= file_size;
+                size_t taken = 0, n_text = 0;
+                int stop = 0;
+                if (vgmi_fastq_commit_gzip(fq, n, at_eof ? 1 : 0, &taken, &n_text, &stop) != VGMI_OK) throw std::runtime_error(vgmi_last_error(ctx));
+                carry.assign(buf + taken, buf + n);
+                if (taken && n_text) ratio = std::max(1.0, (double)n_text / (double)taken);
+                if (stop == 2 || (taken == 0 && (at_eof || want >= cap))) { gz_gave_up = true; break; }
+                if (stop == 1 || (at_eof && carry.empty())) break;
             } else {
                 for (;;) {
                     if (!left_n && !src->next_chunk(left_p, left_n)) break;
@@ -255,7 +280,7 @@ DeviceFileResult device_file(vgmi_ctx* ctx, const std::string& path, size_t bloc
     // what the device did not take: the text after the last complete record (an unterminated last line, or nothing), or
     // -- once it met a record that is not a regular four-line one -- the rest of the stream from that record on; for
     // block gzip also the file from the first member the device did not take or could not vouch for
-    if (stopped) {
+    if (stopped || gz_gave_up) {       // (the host decodes the file from its start and passes over the text the device has counted)
         FastxReader rd(ByteSource::skip(ByteSource::open(path, threads), consumed));
         host_leg(ctx, rd, path, block_bytes, submit_mu, res.n_reads, res.read_base);
     } else if (bgzf && (inflate_failed ? comp_good : comp_taken) < file_size) {

@@ -1621,14 +1621,25 @@ struct vgmi_fastq {
     uint32_t* d_crc = nullptr;
     BgzfVerdict* d_verdict = nullptr;
     uint32_t max_members = 0;
+    // ordinary gzip inflated on the device (vgmi_fastq_commit_gzip): scratch of the pipeline and where the stream stands
+    void* gz = nullptr;                              // GzScratch
+    bool gz_in_member = false;                       // false: the next staged byte is a member header (or the data is over)
+    uint32_t gz_bit = 0;                             // the next block starts this many bits into the first staged byte
+    uint32_t gz_avail = 0;                           // text bytes of this member so far, 32768 at most (the window that exists)
+    uint32_t gz_skip = 0;                            // bytes of a member's trailer still to be skipped at the front of the next piece
+    uint32_t gz_reason = 0;                          // why the device gave the stream up (GzSegOut::status), 0: it did not
+    uint64_t gz_text = 0;                            // text bytes the device produced
     std::vector<uint32_t> batch_members;             // members per committed batch
     std::vector<uint64_t> member_size;               // compressed size of every member committed, in stream order
 };
 
 namespace {
+void gz_scratch_free(void* g);
 void fastq_free(vgmi_fastq* f)
 {
     if (!f) return;
+    gz_scratch_free(f->gz);
+    f->gz = nullptr;
     for (int i = 0; i < 2; ++i) {
         if (f->h_stage[i]) (void)hipHostFree(f->h_stage[i]);
         if (f->h_done[i]) (void)hipEventDestroy(f->h_done[i]);
@@ -1674,6 +1685,9 @@ int vgmi_fastq_open(vgmi_ctx* c, vgmi_fastq** out)
             r->h_busy[0] = r->h_busy[1] = false;
             r->batch_members.clear();
             r->member_size.clear();
+            r->gz_in_member = false;
+            r->gz_bit = r->gz_avail = r->gz_skip = r->gz_reason = 0;
+            r->gz_text = 0;
             if (r->d_verdict) (void)hipMemsetAsync(r->d_verdict, 0xFF, 12, r->stream), (void)hipMemsetAsync(&r->d_verdict->good_bytes, 0, 8, r->stream);
             hipError_t e = launch_fastq_init(r->d_state, r->tail_max, r->stream);
             if (e == hipSuccess) e = hipStreamWaitEvent(r->stream, c->reset_done, 0);
@@ -1827,14 +1841,17 @@ int vgmi_fastq_commit_bgzf(vgmi_fastq* f, size_t n_bytes, size_t* taken, size_t*
     if (n_bytes > f->cap) return fail(c, VGMI_E_INVALID, "more bytes than the buffer holds");
     const int i = f->acquired;
     HIPCHK(c, hipSetDevice(c->device));
-    if (!f->d_comp) {
+    if (!f->d_members) {      // (d_comp may be there already: a stream of the pool that served an ordinary gzip file)
         f->max_members = (uint32_t)(f->text_cap / 4096) + 1024;     // bgzip members compress 64 KiB each; tiny ones are rare
         // 512 KiB of zeroed slack behind the staged bytes: inside one damaged DEFLATE block the decoder can run up to
         // ~390 KB past its member before the per-block bound stops it (65 536 symbols x 48 bits); those reads must stay
         // inside the allocation (and see zeros) whatever the last member of a full batch contains
         constexpr size_t kCompSlack = 512u << 10;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_comp), f->cap + kCompSlack);
-        if (e == hipSuccess) e = hipMemsetAsync(f->d_comp + f->cap, 0, kCompSlack, f->stream);
+        hipError_t e = hipSuccess;
+        if (!f->d_comp) {
+            e = hipMalloc(reinterpret_cast<void**>(&f->d_comp), f->cap + kCompSlack);
+            if (e == hipSuccess) e = hipMemsetAsync(f->d_comp + f->cap, 0, kCompSlack, f->stream);
+        }
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f->d_members), (size_t)f->max_members * sizeof(BgzfMember));
         for (int b = 0; b < 2 && e == hipSuccess; ++b)
             e = hipHostMalloc(reinterpret_cast<void**>(&f->h_members[b]), (size_t)f->max_members * sizeof(BgzfMember), hipHostMallocDefault);
@@ -1936,12 +1953,12 @@ struct GzScratch {
     GzSegHost* d_segs = nullptr;
     GzSegOutHost* d_outs = nullptr;
     uint64_t* d_toff = nullptr;
-    uint16_t* d_pool = nullptr;
-    uint8_t* d_win = nullptr;
+    uint16_t *d_pool = nullptr, *d_w1 = nullptr;      // symbols; the 16-bit window behind every stretch
+    uint8_t* d_win = nullptr;                         // byte windows: in front of the piece, then behind every group of stretches
     size_t cap_seg = 0, cap_pool = 0;
     void release()
     {
-        for (void* q : {(void*)d_starts, (void*)d_segs, (void*)d_outs, (void*)d_toff, (void*)d_pool, (void*)d_win})
+        for (void* q : {(void*)d_starts, (void*)d_segs, (void*)d_outs, (void*)d_toff, (void*)d_pool, (void*)d_win, (void*)d_w1})
             if (q) (void)hipFree(q);
         *this = GzScratch{};
     }
@@ -1949,7 +1966,7 @@ struct GzScratch {
 constexpr uint32_t kGzSeg = 32768;        // compressed bytes per guessed start
 constexpr uint32_t kGzRatio = 12;         // symbols of room per compressed byte of a stretch (FASTQ: 4-6)
 
-int gz_piece(vgmi_ctx* c, GzScratch& g, const uint8_t* d_comp, uint32_t n, uint32_t first_bit, bool window_known, uint8_t* d_text, size_t text_cap,
+int gz_piece(vgmi_ctx* c, GzScratch& g, const uint8_t* d_comp, uint32_t n, uint32_t first_bit, uint32_t win_avail, uint8_t* d_text, size_t text_cap,
              hipStream_t st, uint32_t* end_bit, size_t* n_text, int* final_member, uint32_t* reason)
 {
     *end_bit = first_bit;
@@ -1968,7 +1985,8 @@ int gz_piece(vgmi_ctx* c, GzScratch& g, const uint8_t* d_comp, uint32_t n, uint3
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_outs), g.cap_seg * sizeof(GzSegOutHost)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_toff), g.cap_seg * 8));
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_pool), g.cap_pool * 2));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_win), (g.cap_seg + 1) * 32768));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_win), ((size_t)gz_groups((uint32_t)g.cap_seg) + 2) * 32768));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_w1), g.cap_seg * 65536));
     }
     // 1. guessed block starts (the first is known)
     HIPCHK(c, hipMemsetAsync(g.d_starts, 0xFF, (size_t)n_nom * 4, st));
@@ -1978,11 +1996,12 @@ int gz_piece(vgmi_ctx* c, GzScratch& g, const uint8_t* d_comp, uint32_t n, uint3
     HIPCHK(c, hipStreamSynchronize(st));
     std::vector<GzSegHost> segs;
     uint32_t at = first_bit;
-    segs.push_back(GzSegHost{first_bit, 0xFFFFFFFFu, 0, 0});
+    segs.push_back(GzSegHost{first_bit, 0xFFFFFFFFu, 0, 0, win_avail, 0});
     for (uint32_t j = 1; j < n_nom; ++j)
         if (starts[j] != 0xFFFFFFFFu && starts[j] > at) {
             segs.back().stop_bit = starts[j];
-            segs.push_back(GzSegHost{starts[j], 0xFFFFFFFFu, 0, 0});
+            // (a stretch holds >= 32 KiB of compressed bytes, so behind the first there is a whole window of text)
+            segs.push_back(GzSegHost{starts[j], 0xFFFFFFFFu, 0, 0, 32768, 0});
             at = starts[j];
         }
     // room in the symbol pool: by the compressed bytes of the stretch
@@ -2010,6 +2029,7 @@ int gz_piece(vgmi_ctx* c, GzScratch& g, const uint8_t* d_comp, uint32_t n, uint3
     std::vector<uint64_t> toff(n_seg + 1, 0);
     for (uint32_t i = 0; i < n_seg; ++i) {
         const GzSegOutHost& o = outs[i];
+        // (9 on the last stretch: the data ends inside it -- the next piece brings the rest; 3: no room, here or in the text chunk)
         if (o.status != 0) { *reason = o.status; break; }
         if (toff[i] + o.n_sym > text_cap) { *reason = 3; break; }
         toff[i + 1] = toff[i] + o.n_sym;
@@ -2017,14 +2037,13 @@ int gz_piece(vgmi_ctx* c, GzScratch& g, const uint8_t* d_comp, uint32_t n, uint3
         *end_bit = o.end_bit;
         if (o.final_block) { *final_member = 1; break; }
     }
-    (void)window_known;
     if (n_ok == 0) return VGMI_OK;
     // 3. + 4. windows, then bytes
     HIPCHK(c, hipMemcpyAsync(g.d_toff, toff.data(), (size_t)n_ok * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(c, launch_gz_resolve(g.d_pool, g.d_segs, g.d_outs, g.d_toff, n_ok, g.d_win, d_text, st));
+    HIPCHK(c, launch_gz_resolve(g.d_pool, g.d_segs, g.d_outs, g.d_toff, n_ok, g.d_w1, g.d_win, d_text, st));
     *n_text = (size_t)toff[n_ok];
     // the window behind the last stretch becomes the window in front of the next piece
-    HIPCHK(c, hipMemcpyAsync(g.d_win, g.d_win + (size_t)n_ok * 32768, 32768, hipMemcpyDeviceToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(g.d_win, g.d_win + (size_t)gz_groups(n_ok) * 32768, 32768, hipMemcpyDeviceToDevice, st));
     return VGMI_OK;
 }
 }  // namespace
@@ -2054,7 +2073,7 @@ int vgmi_gunzip_buffer(vgmi_ctx* c, const void* host_gz, size_t n, void* host_ou
     uint32_t end_bit = 0, why = 0;
     size_t n_text = 0;
     int fin = 0;
-    if (he == hipSuccess) rc = gz_piece(c, g, d_comp, (uint32_t)n, (uint32_t)hdr * 8u, false, d_text, cap, c->stream, &end_bit, &n_text, &fin, &why);
+    if (he == hipSuccess) rc = gz_piece(c, g, d_comp, (uint32_t)n, (uint32_t)hdr * 8u, 0, d_text, cap, c->stream, &end_bit, &n_text, &fin, &why);
     if (he == hipSuccess && rc == VGMI_OK) he = hipMemcpyAsync(host_out, d_text, n_text, hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
     g.release();
@@ -2066,6 +2085,133 @@ int vgmi_gunzip_buffer(vgmi_ctx* c, const void* host_gz, size_t n, void* host_ou
     if (consumed) *consumed = (end_bit + 7) / 8;
     if (member_end) *member_end = fin;
     if (reason) *reason = why;
+    return VGMI_OK;
+}
+
+namespace {
+void gz_scratch_free(void* g)
+{
+    if (!g) return;
+    static_cast<GzScratch*>(g)->release();
+    delete static_cast<GzScratch*>(g);
+}
+}  // namespace
+
+// The streaming form: the staged bytes [0, n_bytes) of the acquired buffer continue an ordinary gzip stream -- at a member header
+// when the stream is at a member's start, else at the byte that holds the next block's first bit (what the previous call left
+// untaken).  Whole stretches between block starts are inflated into the chunk's text and parsed and counted like any text chunk.
+// *taken = staged bytes used up (the caller presents the rest again, in front of the bytes that follow).  *stop: 0 go on; 1 the gzip
+// data is over (a member ended and what follows is no member header: gzread ignores it); 2 the device cannot take these bytes
+// (vgmi_fastq_gzip_status says why): the host decoder carries on from the text the device parser has consumed.
+int vgmi_fastq_commit_gzip(vgmi_fastq* f, size_t n_bytes, int at_eof, size_t* taken, size_t* n_text, int* stop)
+{
+    if (!f || !taken || !stop) return VGMI_E_INVALID;
+    vgmi_ctx* c = f->c;
+    *taken = 0;
+    *stop = 0;
+    if (n_text) *n_text = 0;
+    if (f->acquired < 0) return fail(c, VGMI_E_STATE, "no buffer acquired");
+    if (n_bytes > f->cap) return fail(c, VGMI_E_INVALID, "more bytes than the buffer holds");
+    const int i = f->acquired;
+    f->acquired = -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(f->h_stage[i]);
+    size_t pos = 0;
+    if (f->gz_skip) {                      // the rest of the last member's trailer
+        const size_t k = std::min<size_t>(f->gz_skip, n_bytes);
+        f->gz_skip -= (uint32_t)k;
+        pos = k;
+        if (f->gz_skip) { *taken = n_bytes; if (at_eof) *stop = 1; return VGMI_OK; }
+    }
+    uint32_t first_bit;
+    if (!f->gz_in_member) {
+        if (n_bytes - pos < 2 || p[pos] != 0x1f || p[pos + 1] != 0x8b) {
+            if (n_bytes - pos >= 2 || at_eof) { *taken = n_bytes; *stop = 1; return VGMI_OK; }     // no further member: the data is over
+            *taken = pos;
+            return VGMI_OK;
+        }
+        const size_t hdr = gzip_header_len(p + pos, n_bytes - pos);
+        if (!hdr) {
+            if (n_bytes - pos >= 65536 + 64 || at_eof) { f->gz_reason = 10; *stop = 2; }      // a header that does not parse
+            *taken = pos;
+            return VGMI_OK;
+        }
+        first_bit = (uint32_t)(pos + hdr) * 8u;
+        f->gz_avail = 0;
+        f->gz_in_member = true;
+    } else first_bit = (uint32_t)pos * 8u + f->gz_bit;
+    if (!f->gz) f->gz = new (std::nothrow) GzScratch();
+    if (!f->gz) return fail(c, VGMI_E_NOMEM, "out of memory");
+    if (!f->d_comp) {
+        constexpr size_t kCompSlack = 512u << 10;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_comp), f->cap + kCompSlack);
+        if (e == hipSuccess) e = hipMemsetAsync(f->d_comp + f->cap, 0, kCompSlack, f->stream);
+        HIPCHK(c, e);
+    }
+    HIPCHK(c, hipMemcpyAsync(f->d_comp, f->h_stage[i], n_bytes, hipMemcpyHostToDevice, f->stream));
+    if (n_bytes < f->cap) HIPCHK(c, hipMemsetAsync(f->d_comp + n_bytes, 0, std::min<size_t>(4096, f->cap - n_bytes), f->stream));
+    HIPCHK(c, hipEventRecord(f->h_done[i], f->stream));
+    f->h_busy[i] = true;
+    uint32_t end_bit = 0, why = 0;
+    size_t text = 0;
+    int fin = 0;
+    int rc = gz_piece(c, *static_cast<GzScratch*>(f->gz), f->d_comp, (uint32_t)n_bytes, first_bit, f->gz_avail, f->d_raw[i] + f->tail_max, f->text_cap, f->stream,
+                      &end_bit, &text, &fin, &why);
+    if (rc) return rc;
+    const bool broken = why != 0 && why != 9 && why != 3;       // a stretch that does not decode / does not meet the next one
+    if (text == 0 && !fin) {
+        // no whole stretch in these bytes: more may help -- unless there are no more, the buffer is full already, or it is no DEFLATE
+        if (at_eof || n_bytes == f->cap || broken) {
+            f->gz_reason = why ? why : 9;
+            *stop = 2;
+        }
+        if (!f->gz_in_member || first_bit >= 8) *taken = (first_bit / 8u);      // (a header just read is taken; the block's byte stays)
+        f->gz_bit = first_bit & 7u;
+        return VGMI_OK;
+    }
+    f->gz_text += text;
+    f->gz_avail = (uint32_t)std::min<uint64_t>(32768, (uint64_t)f->gz_avail + text);
+    if (fin) {
+        const size_t after = (size_t)(end_bit + 7) / 8 + 8;        // CRC-32 and ISIZE are not checked: gzread reports them at the data's end
+        f->gz_in_member = false;
+        f->gz_bit = 0;
+        if (after > n_bytes) {
+            f->gz_skip = (uint32_t)(after - n_bytes);
+            *taken = n_bytes;
+        } else *taken = after;
+        if (at_eof && *taken == n_bytes) *stop = 1;
+    } else {
+        *taken = end_bit / 8u;
+        f->gz_bit = end_bit & 7u;
+        if (broken) { f->gz_reason = why; *stop = 2; }       // a stretch behind the ones taken went wrong: the host goes on from the text so far
+    }
+    if (n_text) *n_text = text;
+    if (text) {
+        FqBuffers b{};
+        b.raw = f->d_raw[i];
+        b.raw_next = f->d_raw[i ^ 1];
+        b.packed = f->d_packed;
+        b.tile = f->d_tile;
+        b.nlpos = f->d_nlpos;
+        b.rec_bytes = f->d_rec;
+        b.out_off = f->d_off;
+        b.block_sum = f->d_bsum;
+        b.state = f->d_state;
+        b.cap_lines = f->cap_lines;
+        b.tail_max = f->tail_max;
+        HIPCHK(c, launch_fastq_chunk(b, (uint32_t)text, f->stream));
+        rc = launch_count(c, reinterpret_cast<const char*>(f->d_packed), f->tail_max + text, nullptr, 0, f->stream, &f->d_state->packed_bytes);
+        if (rc) return rc;
+        f->next = i ^ 1;
+    }
+    return VGMI_OK;
+}
+
+int vgmi_fastq_gzip_status(vgmi_fastq* f, uint64_t* device_text_bytes, uint32_t* reason)
+{
+    if (!f) return VGMI_E_INVALID;
+    if (device_text_bytes) *device_text_bytes = f->gz_text;
+    if (reason) *reason = f->gz_reason;
     return VGMI_OK;
 }
 

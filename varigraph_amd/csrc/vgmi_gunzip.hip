@@ -14,7 +14,7 @@
 //                          window), which later copies propagate like bytes.  A stretch must END exactly where the next one starts:
 //                          that is the check of the guessed start (by induction from the stream's true first bit every start in an
 //                          unbroken chain is a true block start); a stretch that does not is where the device path ends.
-//   3. gz_window_kernel    the last 32 KiB of text behind every stretch, one after the other (each needs the one before)
+//   3. gz_window1/2_kernel the last 32 KiB of text behind every stretch: a chain, walked in two levels (groups side by side, then their tails)
 //   4. gz_resolve_kernel   every stretch's symbols -> bytes with its predecessor's window, written where the text chunk wants them
 // The host walks the gzip header, ships bytes, and reads back one small record per stretch.  Whatever the device cannot vouch for
 // -- a broken chain, a stretch that outgrows its room, the end of a member (trailer, a next member's header) -- ends the device path
@@ -27,24 +27,26 @@
 
 namespace vgk {
 
-#define GZ_WAVES 4u
+#define GZ_WAVES 5u             // decode: wavefronts per workgroup (10.3 KB of LDS each: three workgroups = 15 wavefronts per CU)
+#define GZ_FIND_WAVES 4u        // find: no output ring, 6.2 KB each: six workgroups = 24 wavefronts per CU
 #define GZ_WIN 32768u
 #define GZ_NONE 0xFFFFFFFFu
 
 typedef InfTablesT<uint16_t> GzTables;
+typedef InfTablesT<uint16_t, 8> GzFindTables;
 
 // ---- 1. block starts ---------------------------------------------------------------------------------------------------
 // starts[j] (j >= 1) = the first bit at or behind 8 * j * seg_bytes where a dynamic block's header stands, GZ_NONE if there is none
 // in front of 8 * (j + 2) * seg_bytes (or the data's end); starts[0] is the caller's (the stream's known position).
-__global__ __launch_bounds__(64 * GZ_WAVES, 3) void gz_find_kernel(const uint8_t* __restrict__ comp, uint32_t n_bytes, uint32_t seg_bytes, uint32_t n_seg,
+__global__ __launch_bounds__(64 * GZ_FIND_WAVES, 6) void gz_find_kernel(const uint8_t* __restrict__ comp, uint32_t n_bytes, uint32_t seg_bytes, uint32_t n_seg,
                                                                    uint32_t* __restrict__ starts)
 {
-    __shared__ GzTables tabs[GZ_WAVES];
+    __shared__ GzFindTables tabs[GZ_FIND_WAVES];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_in_block = uni(threadIdx.x >> 6);
-    const uint32_t j = blockIdx.x * GZ_WAVES + wave_in_block + 1u;
+    const uint32_t j = blockIdx.x * GZ_FIND_WAVES + wave_in_block + 1u;
     if (j >= n_seg) return;
-    GzTables& t = tabs[wave_in_block];
+    GzFindTables& t = tabs[wave_in_block];
     const uint32_t* const in4 = reinterpret_cast<const uint32_t*>(comp);      // the batch buffer is 256-byte aligned
     const uint32_t end_bits = n_bytes * 8u;
     const uint32_t from = j * seg_bytes * 8u;
@@ -190,6 +192,9 @@ __global__ __launch_bounds__(64 * GZ_WAVES, 3) void gz_find_kernel(const uint8_t
 struct GzSeg {
     uint32_t start_bit, stop_bit;     // decode blocks from start_bit until one ends at or behind stop_bit (GZ_NONE: to the data's end)
     uint32_t sym_off, sym_cap;        // room in the symbol pool (symbols)
+    uint32_t win_avail;               // bytes of text that exist in front of the stretch, GZ_WIN at most (0 at a member's start: a
+                                      // back-reference beyond them is "invalid distance too far back", as zlib has it)
+    uint32_t pad;
 };
 struct GzSegOut {
     uint32_t n_sym;        // symbols written
@@ -199,7 +204,7 @@ struct GzSegOut {
     uint32_t final_block;  // the last decoded block carried BFINAL: the member ends at end_bit
 };
 
-__global__ __launch_bounds__(64 * GZ_WAVES, 3) void gz_decode_kernel(const uint8_t* __restrict__ comp, uint32_t n_bytes, const GzSeg* __restrict__ segs,
+__global__ __launch_bounds__(64 * GZ_WAVES, 4) void gz_decode_kernel(const uint8_t* __restrict__ comp, uint32_t n_bytes, const GzSeg* __restrict__ segs,
                                                                      uint32_t n_seg, uint16_t* __restrict__ pool, GzSegOut* __restrict__ outs)
 {
     __shared__ GzTables tabs[GZ_WAVES];
@@ -218,6 +223,7 @@ __global__ __launch_bounds__(64 * GZ_WAVES, 3) void gz_decode_kernel(const uint8
     uint32_t* const ring32 = reinterpret_cast<uint32_t*>(t.ring);
 
     uint32_t bp = uni(segs[sg].start_bit);
+    const uint32_t win_avail = uni(segs[sg].win_avail);
     uint32_t op = 0, flushed = 0, err = 0;
 
     // ring -> global memory: whole blocks of 128 symbols (the pool slice is word aligned); all of it at the end
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(64 * GZ_WAVES, 3) void gz_decode_kernel(const uint8
                 const uint32_t P = op + (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)ml);
                 const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)mlen, (int)ml);
                 const uint32_t dist = (uint32_t)__builtin_amdgcn_readlane((int)mdist, (int)ml);
-                if (dist > P + GZ_WIN) { err = 2; break; }
+                if (dist > P + win_avail) { err = 2; break; }
                 copy_match(P, len, dist);
             }
             if (err) break;
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(64 * GZ_WAVES, 3) void gz_decode_kernel(const uint8
                         const uint32_t x = ((uint32_t)dsym >> 1) - 1;
                         dist = ((2u + ((uint32_t)dsym & 1u)) << x) + 1u + take(x);
                     }
-                    if (dist > op + GZ_WIN) { err = 2; break; }
+                    if (dist > op + win_avail) { err = 2; break; }
                     if (op + len > out_cap) { err = 3; break; }
                     copy_match(op, len, dist);
                     op += len;
@@ -503,25 +509,53 @@ __global__ __launch_bounds__(64 * GZ_WAVES, 3) void gz_decode_kernel(const uint8
     if (lane == 0) outs[sg] = GzSegOut{op, block_end, err, last ? 1u : 0u};
 }
 
-// ---- 3. the window behind every stretch, one after the other ------------------------------------------------------------
-// win[(j + 1) * GZ_WIN ..] = the last GZ_WIN bytes of text behind stretch j (win[0 .. GZ_WIN) = the window in front of stretch 0:
-// the carried one, or anything at a member's start, where no placeholder can exist)
-__global__ __launch_bounds__(1024) void gz_window_kernel(const uint16_t* __restrict__ pool, const GzSeg* __restrict__ segs, const GzSegOut* __restrict__ outs,
-                                                         uint32_t n_seg, uint8_t* __restrict__ win)
+// ---- 3. the window behind every stretch ------------------------------------------------------------------------------------
+// The last GZ_WIN bytes of text behind stretch j need the window behind stretch j - 1: a chain over all stretches, 20 us a link
+// when walked by one workgroup (75 of 114 ms for 3 350 stretches).  Two levels instead.  Stretches are taken in groups of
+// GZ_GROUP; (a) every group walks its own chain, all groups side by side, leaving placeholders for the window in front of the
+// GROUP in what it cannot know (16-bit windows w1); (b) one workgroup walks the chain of group tails, GZ_GROUP times shorter,
+// into byte windows t (t[0] = the window in front of the piece); (c) the resolve kernel looks a placeholder up in the 16-bit
+// window of the stretch before and, if that is a placeholder still, in the byte window of the group before.
+#define GZ_GROUP 64u
+
+__device__ __forceinline__ uint16_t gz_win_entry(const uint16_t* sym, uint32_t n, const uint16_t* prev, uint32_t x)
 {
-    for (uint32_t j = 0; j < n_seg; ++j) {
-        const uint8_t* const prev = win + (size_t)j * GZ_WIN;
-        uint8_t* const cur = win + (size_t)(j + 1) * GZ_WIN;
+    // entry x of the window behind a stretch of n symbols whose predecessor's window is prev (nullptr: the group's first stretch,
+    // whose predecessor is the unknown window itself: placeholder x stands for its entry x)
+    if (n < GZ_WIN && x < GZ_WIN - n) return prev ? prev[x + n] : (uint16_t)(256u + x + n);
+    const uint16_t s = sym[n >= GZ_WIN ? n - GZ_WIN + x : x - (GZ_WIN - n)];
+    return s < 256 || !prev ? s : prev[s - 256];
+}
+
+__global__ __launch_bounds__(1024) void gz_window1_kernel(const uint16_t* __restrict__ pool, const GzSeg* __restrict__ segs, const GzSegOut* __restrict__ outs,
+                                                          uint32_t n_seg, uint16_t* __restrict__ w1)
+{
+    const uint32_t j0 = blockIdx.x * GZ_GROUP, j1 = j0 + GZ_GROUP < n_seg ? j0 + GZ_GROUP : n_seg;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const uint16_t* const prev = j == j0 ? nullptr : w1 + (size_t)(j - 1) * GZ_WIN;
+        uint16_t* const cur = w1 + (size_t)j * GZ_WIN;
         const uint16_t* const sym = pool + segs[j].sym_off;
         const uint32_t n = outs[j].n_sym;
-        for (uint32_t x = threadIdx.x; x < GZ_WIN; x += blockDim.x) {
-            uint8_t v;
-            if (n < GZ_WIN && x < GZ_WIN - n) v = prev[x + n];
-            else {
-                const uint16_t s = sym[n >= GZ_WIN ? n - GZ_WIN + x : x - (GZ_WIN - n)];
-                v = s < 256 ? (uint8_t)s : prev[s - 256];
-            }
-            cur[x] = v;
+#pragma unroll 4
+        for (uint32_t x = threadIdx.x; x < GZ_WIN; x += 1024u) cur[x] = gz_win_entry(sym, n, prev, x);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// t[(g + 1) * GZ_WIN ..] = the text window behind group g's last stretch (t[0 .. GZ_WIN): in front of the piece)
+__global__ __launch_bounds__(1024) void gz_window2_kernel(const uint16_t* __restrict__ w1, uint32_t n_seg, uint8_t* __restrict__ t)
+{
+    const uint32_t n_groups = (n_seg + GZ_GROUP - 1) / GZ_GROUP;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint32_t last = ((g + 1) * GZ_GROUP < n_seg ? (g + 1) * GZ_GROUP : n_seg) - 1u;
+        const uint16_t* const w = w1 + (size_t)last * GZ_WIN;
+        const uint8_t* const prev = t + (size_t)g * GZ_WIN;
+        uint8_t* const cur = t + (size_t)(g + 1) * GZ_WIN;
+#pragma unroll 4
+        for (uint32_t x = threadIdx.x; x < GZ_WIN; x += 1024u) {
+            const uint16_t s = w[x];
+            cur[x] = s < 256 ? (uint8_t)s : prev[s - 256];
         }
         __threadfence_block();
         __syncthreads();
@@ -530,24 +564,29 @@ __global__ __launch_bounds__(1024) void gz_window_kernel(const uint16_t* __restr
 
 // ---- 4. symbols -> bytes --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gz_resolve_kernel(const uint16_t* __restrict__ pool, const GzSeg* __restrict__ segs, const GzSegOut* __restrict__ outs,
-                                                         const uint64_t* __restrict__ text_off, uint32_t n_seg, const uint8_t* __restrict__ win,
-                                                         uint8_t* __restrict__ text)
+                                                         const uint64_t* __restrict__ text_off, uint32_t n_seg, const uint16_t* __restrict__ w1,
+                                                         const uint8_t* __restrict__ t, uint8_t* __restrict__ text)
 {
     const uint32_t j = blockIdx.x / 16u, part = blockIdx.x % 16u;      // sixteen workgroups per stretch
     if (j >= n_seg) return;
-    const uint8_t* const prev = win + (size_t)j * GZ_WIN;
+    const uint32_t g = j / GZ_GROUP;
+    const uint8_t* const tg = t + (size_t)g * GZ_WIN;                  // the window in front of the stretch's group
+    const uint16_t* const prev = j % GZ_GROUP ? w1 + (size_t)(j - 1) * GZ_WIN : nullptr;
     const uint16_t* const sym = pool + segs[j].sym_off;
     uint8_t* const dst = text + text_off[j];
     const uint32_t n = outs[j].n_sym;
     for (uint32_t x = part * 256u + threadIdx.x; x < n; x += 16u * 256u) {
-        const uint16_t s = sym[x];
-        dst[x] = s < 256 ? (uint8_t)s : prev[s - 256];
+        uint16_t s = sym[x];
+        if (s >= 256 && prev) s = prev[s - 256];
+        dst[x] = s < 256 ? (uint8_t)s : tg[s - 256];
     }
 }
 
 hipError_t launch_gz_find(const uint8_t* comp, uint32_t n_bytes, uint32_t seg_bytes, uint32_t n_seg, uint32_t* starts, hipStream_t st)
 {
-    if (n_seg > 1) hipLaunchKernelGGL(gz_find_kernel, dim3((n_seg - 1 + GZ_WAVES - 1) / GZ_WAVES), dim3(64 * GZ_WAVES), 0, st, comp, n_bytes, seg_bytes, n_seg, starts);
+    if (n_seg > 1)
+        hipLaunchKernelGGL(gz_find_kernel, dim3((n_seg - 1 + GZ_FIND_WAVES - 1) / GZ_FIND_WAVES), dim3(64 * GZ_FIND_WAVES), 0, st, comp, n_bytes, seg_bytes, n_seg,
+                           starts);
     return hipGetLastError();
 }
 
@@ -559,15 +598,21 @@ hipError_t launch_gz_decode(const uint8_t* comp, uint32_t n_bytes, const void* s
     return hipGetLastError();
 }
 
-hipError_t launch_gz_resolve(const uint16_t* pool, const void* segs, const void* outs, const uint64_t* text_off, uint32_t n_seg, uint8_t* win, uint8_t* text,
-                             hipStream_t st)
+// w1: n_seg windows of GZ_WIN 16-bit entries; t: (n_groups + 1) windows of GZ_WIN bytes, t[0 .. GZ_WIN) = the window in front of the piece.
+// Behind the call t + n_groups * GZ_WIN is the window behind the last stretch.
+hipError_t launch_gz_resolve(const uint16_t* pool, const void* segs, const void* outs, const uint64_t* text_off, uint32_t n_seg, uint16_t* w1, uint8_t* t,
+                             uint8_t* text, hipStream_t st)
 {
     if (n_seg) {
-        hipLaunchKernelGGL(gz_window_kernel, dim3(1), dim3(1024), 0, st, pool, static_cast<const GzSeg*>(segs), static_cast<const GzSegOut*>(outs), n_seg, win);
+        const uint32_t n_groups = (n_seg + GZ_GROUP - 1) / GZ_GROUP;
+        hipLaunchKernelGGL(gz_window1_kernel, dim3(n_groups), dim3(1024), 0, st, pool, static_cast<const GzSeg*>(segs), static_cast<const GzSegOut*>(outs), n_seg, w1);
+        hipLaunchKernelGGL(gz_window2_kernel, dim3(1), dim3(1024), 0, st, w1, n_seg, t);
         hipLaunchKernelGGL(gz_resolve_kernel, dim3(n_seg * 16u), dim3(256), 0, st, pool, static_cast<const GzSeg*>(segs), static_cast<const GzSegOut*>(outs), text_off,
-                           n_seg, win, text);
+                           n_seg, w1, t, text);
     }
     return hipGetLastError();
 }
+
+uint32_t gz_groups(uint32_t n_seg) { return (n_seg + GZ_GROUP - 1) / GZ_GROUP; }
 
 }  // namespace vgk

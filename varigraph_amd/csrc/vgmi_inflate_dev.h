@@ -19,7 +19,7 @@ namespace vgk {
                                 // 258 unflushed bytes already is (INF_NEAR - 258 > INF_BATCH_OUT + 258)
 #define INF_WAVES 4u            // wavefronts per workgroup (8.3 KB of LDS each: four workgroups = 16 wavefronts per CU)
 
-template <class RingT>
+template <class RingT, uint32_t RING = INF_RING>
 struct InfTablesT {                // per wavefront, in LDS
     uint32_t lit[1u << INF_LIT_BITS];     // while a table is built: symbol << 4 | code length (0: code longer than the index / unused);
                                           // then packed (inf_pack_lit): bits 0..3 code bits taken, 4..5 kind (0 literals, 1 length, 2 end of block),
@@ -29,8 +29,7 @@ struct InfTablesT {                // per wavefront, in LDS
     uint16_t sorted[320];          // symbols ordered by code (canonical decoding of the long codes)
     uint16_t count[2][INF_MAXBITS + 1];
     uint16_t offs[2][INF_MAXBITS + 1];
-    RingT ring[INF_RING];          // output byte (or symbol: vgmi_gunzip.hip) p at ring[p % INF_RING]
-    uint8_t pad[64];
+    RingT ring[RING];              // output byte (or symbol: vgmi_gunzip.hip) p at ring[p % INF_RING]
 };
 typedef InfTablesT<uint8_t> InfTables;
 

@@ -153,15 +153,16 @@ hipError_t launch_bgzf_inflate(const uint8_t* comp, const BgzfMember* members, u
 // ordinary gzip streams inflated on the device (vgmi_gunzip.hip): block starts guessed per 32 KiB of compressed bytes, the stretches
 // between them decoded into symbols (bytes and placeholders for the window in front), windows propagated, symbols resolved
 struct GzSegHost {
-    uint32_t start_bit, stop_bit, sym_off, sym_cap;
+    uint32_t start_bit, stop_bit, sym_off, sym_cap, win_avail, pad;
 };
 struct GzSegOutHost {
     uint32_t n_sym, end_bit, status, final_block;
 };
 hipError_t launch_gz_find(const uint8_t* comp, uint32_t n_bytes, uint32_t seg_bytes, uint32_t n_seg, uint32_t* starts, hipStream_t st);
 hipError_t launch_gz_decode(const uint8_t* comp, uint32_t n_bytes, const void* segs, uint32_t n_seg, uint16_t* pool, void* outs, hipStream_t st);
-hipError_t launch_gz_resolve(const uint16_t* pool, const void* segs, const void* outs, const uint64_t* text_off, uint32_t n_seg, uint8_t* win, uint8_t* text,
-                             hipStream_t st);
+hipError_t launch_gz_resolve(const uint16_t* pool, const void* segs, const void* outs, const uint64_t* text_off, uint32_t n_seg, uint16_t* w1, uint8_t* t,
+                             uint8_t* text, hipStream_t st);
+uint32_t gz_groups(uint32_t n_seg);
 
 // ---- HMM recursion (vgmi_hmm.hip) ----
 struct HmmChain {

@@ -65,6 +65,8 @@ def load_library():
         "vgmi_fastq_commit": (i32, [vp, sz]),
         "vgmi_fastq_commit_bgzf": (i32, [vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(i32)]),
         "vgmi_fastq_bgzf_status": (i32, [vp, C.POINTER(i32), C.POINTER(u64), C.POINTER(u32)]),
+        "vgmi_fastq_commit_gzip": (i32, [vp, sz, i32, C.POINTER(sz), C.POINTER(sz), C.POINTER(i32)]),
+        "vgmi_fastq_gzip_status": (i32, [vp, C.POINTER(u64), C.POINTER(u32)]),
         "vgmi_gunzip_buffer": (i32, [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(i32), C.POINTER(u32)]),
         "vgmi_fastq_close": (i32, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(i32), vp, sz, C.POINTER(sz)]),
         "vgmi_sketch_keys": (i32, [vp, vp, sz, vp, sz, u32, vp]),
@@ -358,6 +360,39 @@ class Context:
         return {"n_records": nr.value, "n_bases": nbs.value, "consumed": cons.value, "stopped": bool(st.value),
                 "tail": tail.raw[:tl.value], "inflate_failed": bool(failed.value), "good_compressed_bytes": good.value,
                 "reason": reason.value, "taken": total_taken}
+
+    def fastq_gzip(self, comp, piece=None):
+        """Ordinary gzip bytes through the device inflate + parser (vgmi_fastq_commit_gzip).  Returns the dict of fastq_text plus stop
+        (1 data over, 2 the device gave up), device_text_bytes, reason, taken (compressed bytes used up)."""
+        fq = C.c_void_p()
+        self._chk(self._l.vgmi_fastq_open(self._h, C.byref(fq)))
+        comp = bytes(comp)
+        pos, carry, total_taken, stop = 0, b"", 0, 0
+        dtext, reason = C.c_uint64(), C.c_uint32()
+        try:
+            while True:
+                buf, cap = C.c_void_p(), C.c_size_t()
+                self._chk(self._l.vgmi_fastq_acquire(fq, C.byref(buf), C.byref(cap)))
+                room = (cap.value if piece is None else min(piece, cap.value)) - len(carry)
+                new = comp[pos:pos + max(room, 0)]
+                pos += len(new)
+                data = carry + new
+                C.memmove(buf, data, len(data))
+                taken, n_text, st = C.c_size_t(), C.c_size_t(), C.c_int()
+                self._chk(self._l.vgmi_fastq_commit_gzip(fq, len(data), int(pos >= len(comp)), C.byref(taken), C.byref(n_text), C.byref(st)))
+                total_taken += taken.value
+                carry = data[taken.value:]
+                stop = st.value
+                if stop or (pos >= len(comp) and taken.value == 0):
+                    break
+            self._chk(self._l.vgmi_fastq_gzip_status(fq, C.byref(dtext), C.byref(reason)))
+        finally:
+            nr, nbs, cons, sp, tl = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int(), C.c_size_t()
+            tail = C.create_string_buffer(1 << 20)
+            rc = self._l.vgmi_fastq_close(fq, C.byref(nr), C.byref(nbs), C.byref(cons), C.byref(sp), tail, 1 << 20, C.byref(tl))
+        self._chk(rc)
+        return {"n_records": nr.value, "n_bases": nbs.value, "consumed": cons.value, "stopped": bool(sp.value), "tail": tail.raw[:tl.value],
+                "stop": stop, "device_text_bytes": dtext.value, "reason": reason.value, "taken": total_taken}
 
     def gunzip(self, comp, cap):
         """An ordinary gzip member through the device pipeline (vgmi_gunzip_buffer): (text bytes, compressed bytes consumed, member
