@@ -186,12 +186,12 @@ def sample_level(ctx, haps, cpu_ref, n_plain=8_000_000, n_packed=4_000_000):
         out["bytes_per_read_plain"] = sum(os.path.getsize(p) for p in plain) / n_plain
         out["host_threads"] = threads
 
-        def rate(files, n, host_parse):
+        def rate(files, n, host_parse, n_threads=None):
             os.environ["VGH_HOST_PARSE"] = "1" if host_parse else "0"
             best, cov = None, None
             for _ in range(3):
                 t0 = time.perf_counter()
-                cov, _, _, st = g.sample_count(ctx, files, threads=threads, require_depth=False)
+                cov, _, _, st = g.sample_count(ctx, files, threads=n_threads or threads, require_depth=False)
                 dt = time.perf_counter() - t0
                 best = dt if best is None or dt < best else best
             return n / best, cov
@@ -200,8 +200,18 @@ def sample_level(ctx, haps, cpu_ref, n_plain=8_000_000, n_packed=4_000_000):
         out["plain_reads_per_s"] = r_plain
         out["plain_text_gb_per_s"] = r_plain * out["bytes_per_read_plain"] / 1e9
         out["plain_host_parser_reads_per_s"], cov_h = rate(plain, n_plain, True)
-        out["gzip_reads_per_s"], _ = rate(gz, n_packed, False)
+        # ordinary gzip: inflated on the device since round 4 (vgmi_gunzip.hip) -- the host threads only read the file; the rate with
+        # four threads in all (two per stream) is the one that matters for a node whose eight GPUs share the host, and
+        # VGH_DEVICE_GUNZIP=0 is rounds 2-3's path (several host inflate threads per stream) on the same files
+        out["gzip_reads_per_s"], cov_gz = rate(gz, n_packed, False)
+        out["gzip_reads_per_s_4_host_threads"], _ = rate(gz, n_packed, False, 4)
+        os.environ["VGH_DEVICE_GUNZIP"] = "0"
+        out["gzip_host_inflate_reads_per_s"], cov_gz_h = rate(gz, n_packed, False)
+        out["gzip_host_inflate_reads_per_s_4_host_threads"], _ = rate(gz, n_packed, False, 4)
+        os.environ.pop("VGH_DEVICE_GUNZIP", None)
+        out["gzip_counters_identical_device_vs_host_inflate"] = bool(np.array_equal(cov_gz, cov_gz_h))
         out["bgzf_reads_per_s"], _ = rate(bgz, n_packed, False)
+        out["bgzf_reads_per_s_4_host_threads"], _ = rate(bgz, n_packed, False, 4)
         out["counters_identical_device_vs_host_parser"] = bool(np.array_equal(cov_ref, cov_h))
         os.environ.pop("VGH_HOST_PARSE", None)
         # PCIe-inclusive: the packed read block handed over from host memory (vgmi_reads_submit: pinned staging + H2D)

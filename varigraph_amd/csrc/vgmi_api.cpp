@@ -1963,7 +1963,12 @@ struct GzScratch {
         *this = GzScratch{};
     }
 };
-constexpr uint32_t kGzSeg = 32768;        // compressed bytes per guessed start
+// compressed bytes per guessed start (VGMI_GZ_SEG_KB for A/B; >= 32 KiB of compressed bytes hold a window of text for sure)
+const uint32_t kGzSeg = [] {
+    const char* e = getenv("VGMI_GZ_SEG_KB");
+    const int v = e ? atoi(e) : 32;
+    return (uint32_t)(v < 8 ? 8 : v > 1024 ? 1024 : v) << 10;
+}();
 constexpr uint32_t kGzRatio = 12;         // symbols of room per compressed byte of a stretch (FASTQ: 4-6)
 
 int gz_piece(vgmi_ctx* c, GzScratch& g, const uint8_t* d_comp, uint32_t n, uint32_t first_bit, uint32_t win_avail, uint8_t* d_text, size_t text_cap,
@@ -2000,8 +2005,9 @@ int gz_piece(vgmi_ctx* c, GzScratch& g, const uint8_t* d_comp, uint32_t n, uint3
     for (uint32_t j = 1; j < n_nom; ++j)
         if (starts[j] != 0xFFFFFFFFu && starts[j] > at) {
             segs.back().stop_bit = starts[j];
-            // (a stretch holds >= 32 KiB of compressed bytes, so behind the first there is a whole window of text)
-            segs.push_back(GzSegHost{starts[j], 0xFFFFFFFFu, 0, 0, 32768, 0});
+            // (text in front of a later stretch: at least what the compressed bytes in front of it hold, a whole window almost always --
+            // an understatement only makes a legal far reference an error, i.e. hands the stretch to the host decoder)
+            segs.push_back(GzSegHost{starts[j], 0xFFFFFFFFu, 0, 0, (uint32_t)std::min<uint64_t>(32768, (uint64_t)win_avail + (starts[j] - first_bit) / 8), 0});
             at = starts[j];
         }
     // room in the symbol pool: by the compressed bytes of the stretch

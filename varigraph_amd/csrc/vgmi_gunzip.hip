@@ -398,40 +398,16 @@ __global__ __launch_bounds__(64 * GZ_WAVES, 4) void gz_decode_kernel(const uint8
             const uint32_t* const w = in4 + (b >> 5);
             const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
             const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, b & 31u), hi = __builtin_amdgcn_alignbit(w2, w1, b & 31u);
-            const uint32_t e = t.lit[lo & ((1u << INF_LIT_BITS) - 1u)];
-            const uint32_t cb = e & 15u, kind = (e >> 4) & 3u;
-            const uint32_t eb = (e >> 6) & 7u;
-            const uint32_t mlen = ((e >> 9) & 511u) + ((lo >> cb) & ((1u << eb) - 1u));
-            const uint32_t pd = cb + eb;
-            const uint32_t de = t.dist[(lo >> pd) & ((1u << INF_DIST_BITS) - 1u)];
-            const uint32_t dl = de & 15u, deb = (de >> 4) & 15u;
-            const uint32_t qd = pd + dl;
-            const uint32_t mdist = (de >> 8) + (__builtin_amdgcn_alignbit(hi, lo, qd) & ((1u << deb) - 1u));
-            uint32_t info;
-            if (cb == 0) info = 1u << 15;
-            else if (kind == 0) info = cb | ((e >> 6) & 3u) << 6;
-            else if (kind == 2) info = cb | 1u << 16;
-            else info = dl ? (qd + deb) | mlen << 6 | 1u << 17 : 1u << 15;
-            uint32_t pos = 0, off = 0, offv = 0;
-            uint64_t lits = 0, matches = 0;
-            bool slow = false;
-            while (pos < 64u) {
-                const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)pos);
-                if (inf & (1u << 15)) { slow = true; break; }
-                const uint32_t ol = (inf >> 6) & 511u;
-                if (off && off + ol > INF_BATCH_OUT) break;
-                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(offv) : "s"(off), "s"(pos) : "m0");
-                if (inf & (1u << 17)) matches |= 1ull << pos;
-                else lits |= 1ull << pos;
-                off += ol;
-                pos += inf & 63u;
-                if (inf & (1u << 16)) { eob = true; break; }
-            }
+            const InfBatch B = inf_batch(t, lo, hi, lane);
+            eob = B.eob;
+            const bool slow = B.slow;
+            const uint32_t off = B.out, pos = B.adv;
+            uint64_t matches = B.matches;
             if (op + off > out_cap) { err = 3; break; }
             if (bp + pos > end_bits) { err = 9; break; }       // the symbols ran into the padding behind the data
-            if ((lits >> lane) & 1ull) {
-                const uint32_t n = (e >> 6) & 3u, P = op + offv;
-                if (kind == 0) {
+            if ((B.lits >> lane) & 1ull) {
+                const uint32_t e = B.e, n = (e >> 6) & 3u, P = op + B.off;
+                if (((e >> 4) & 3u) == 0) {
                     t.ring[P & (INF_RING - 1u)] = (uint16_t)((e >> 8) & 255u);
                     if (n > 1) t.ring[(P + 1u) & (INF_RING - 1u)] = (uint16_t)((e >> 16) & 255u);
                     if (n > 2) t.ring[(P + 2u) & (INF_RING - 1u)] = (uint16_t)(e >> 24);
@@ -441,9 +417,9 @@ __global__ __launch_bounds__(64 * GZ_WAVES, 4) void gz_decode_kernel(const uint8
             while (matches) {
                 const uint32_t ml = (uint32_t)__builtin_ctzll(matches);
                 matches &= matches - 1ull;
-                const uint32_t P = op + (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)ml);
-                const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)mlen, (int)ml);
-                const uint32_t dist = (uint32_t)__builtin_amdgcn_readlane((int)mdist, (int)ml);
+                const uint32_t P = op + (uint32_t)__builtin_amdgcn_readlane((int)B.off, (int)ml);
+                const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)B.mlen, (int)ml);
+                const uint32_t dist = (uint32_t)__builtin_amdgcn_readlane((int)B.mdist, (int)ml);
                 if (dist > P + win_avail) { err = 2; break; }
                 copy_match(P, len, dist);
             }

@@ -184,5 +184,96 @@ __device__ __forceinline__ int32_t inf_slow(const T& t, uint32_t which, uint64_t
 
 static __device__ __constant__ uint8_t inf_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
+// ---- a batch: the symbols that start inside a window of 64 bit positions --------------------------------------------------
+// lo / hi: the 64 bits that start at bit (position + lane).  Every lane decodes the symbol that WOULD start at its bit -- two table
+// gathers -- and then the real symbol starts are picked out of the 64 candidates without a serial walk: with J[i] = where the symbol
+// behind candidate i starts, the n-th start is p_n = J^n(0), and the lanes learn p_0 .. p_31 by doubling (round k: lanes
+// 2^k .. 2^(k+1) - 1 take J^(2^k) of what lanes 0 .. 2^k - 1 hold, J^(2^(k+1)) = J^(2^k) o J^(2^k): three ds_bpermute a round).
+// Behind the call LANE n holds symbol n of the batch (its table entry, output offset, match length and distance), compacted.  The
+// scalar walk this replaces (one v_readlane and ~17 scalar instructions per symbol) was what the decoders were short of: a CU has
+// ONE scalar unit for its sixteen wavefronts.
+struct InfBatch {
+    uint32_t e;            // lane n: the literal/length table entry of symbol n (kind, literal bytes)
+    uint32_t off;          // lane n: where symbol n's output starts, from the batch's first byte
+    uint32_t mlen, mdist;  // lane n: a match's length and distance
+    uint64_t lits, matches;   // symbols of the batch that are literals (or the end-of-block code) / matches, by lane
+    uint32_t out, adv;     // output bytes and input bits of the batch
+    bool eob, slow;        // the batch ends with the end-of-block code / in front of a symbol the tables do not hold whole
+};
+
+__device__ __forceinline__ uint32_t inf_bperm(uint32_t v, uint32_t from_lane)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)v);
+}
+
+template <class T>
+__device__ __forceinline__ InfBatch inf_batch(const T& t, uint32_t lo, uint32_t hi, uint32_t lane)
+{
+    // what would start at this lane's bit
+    const uint32_t e = t.lit[lo & ((1u << INF_LIT_BITS) - 1u)];
+    const uint32_t cb = e & 15u, kind = (e >> 4) & 3u;
+    const uint32_t eb = (e >> 6) & 7u;
+    const uint32_t mlen = ((e >> 9) & 511u) + ((lo >> cb) & ((1u << eb) - 1u));
+    const uint32_t pd = cb + eb;                                    // <= 15
+    const uint32_t de = t.dist[(lo >> pd) & ((1u << INF_DIST_BITS) - 1u)];
+    const uint32_t dl = de & 15u, deb = (de >> 4) & 15u;
+    const uint32_t qd = pd + dl;                                    // <= 23
+    const uint32_t mdist = (de >> 8) + (__builtin_amdgcn_alignbit(hi, lo, qd) & ((1u << deb) - 1u));
+    uint32_t bits, ol, fl;     // input bits, output bytes, flags: 1 needs the one-symbol path, 2 end of block, 4 a match
+    if (cb == 0) { bits = 0; ol = 0; fl = 1; }
+    else if (kind == 0) { bits = cb; ol = (e >> 6) & 3u; fl = 0; }
+    else if (kind == 2) { bits = cb; ol = 0; fl = 2; }
+    else if (dl) { bits = qd + deb; ol = mlen; fl = 4; }
+    else { bits = 0; ol = 0; fl = 1; }
+    const uint32_t pinfo = bits | ol << 6 | fl << 15, pm = mlen | mdist << 9;
+    // J: 64 = nothing behind this candidate inside the window (or it ends the batch)
+    uint32_t Jk = (fl & 3u) || lane + bits > 63u ? 64u : lane + bits;
+    uint32_t P = lane == 0 ? 0u : 64u;
+#pragma unroll
+    for (uint32_t k = 0; k < 5; ++k) {
+        const uint32_t h = 1u << k;
+        const uint32_t q = inf_bperm(P, (lane - h) & 63u);
+        const uint32_t c = inf_bperm(Jk, q & 63u);
+        if (lane >= h && lane < 2u * h) P = q < 64u ? c : 64u;
+        if ((uint32_t)__builtin_amdgcn_readlane((int)P, (int)(2u * h - 1u)) >= 64u) break;      // the chain ended inside these lanes
+        const uint32_t jj = inf_bperm(Jk, Jk & 63u);
+        Jk = Jk < 64u ? jj : 64u;
+    }
+    // lane n <- symbol n
+    const bool valid = P < 64u;
+    const uint32_t si = inf_bperm(pinfo, P & 63u), sm = inf_bperm(pm, P & 63u);
+    InfBatch B;
+    B.e = inf_bperm(e, P & 63u);
+    const uint32_t sbits = si & 63u, sfl = si >> 15;
+    const uint64_t mvalid = __ballot(valid), mslow = __ballot(valid && (sfl & 1u)), meob = __ballot(valid && (sfl & 2u));
+    uint32_t n_sym = mvalid == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~mvalid);          // p_n grows with n: the valid lanes are a prefix
+    if (mslow) n_sym = min(n_sym, (uint32_t)__builtin_ctzll(mslow));
+    if (meob) n_sym = min(n_sym, (uint32_t)__builtin_ctzll(meob) + 1u);
+    // output offsets: prefix sums of the symbols' output bytes (within rows of 16 lanes, then across the rows)
+    const uint32_t own = lane < n_sym ? (si >> 6) & 511u : 0u;
+    uint32_t incl = own;
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, true);      // row_shr:1
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, true);      // row_shr:2
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, true);      // row_shr:4
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, true);      // row_shr:8
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, true);      // row_bcast:15 into rows 1 and 3
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, true);      // row_bcast:31 into rows 2 and 3
+    // no more symbols than leave the batch's output inside INF_BATCH_OUT bytes (the first always)
+    const uint64_t mfit = __ballot(lane < n_sym && (incl <= INF_BATCH_OUT || lane == 0));
+    n_sym = mfit == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~mfit);
+    B.off = incl - own;
+    B.mlen = sm & 511u;
+    B.mdist = sm >> 9;
+    const uint64_t mtaken = n_sym >= 64u ? ~0ull : (1ull << n_sym) - 1ull;
+    const uint64_t mmatch = __ballot(valid && (sfl & 4u));
+    B.matches = mmatch & mtaken;
+    B.lits = mtaken & ~mmatch;
+    B.out = n_sym ? (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(n_sym - 1u)) : 0u;
+    B.adv = n_sym ? (uint32_t)__builtin_amdgcn_readlane((int)(P + sbits), (int)(n_sym - 1u)) : 0u;
+    B.eob = n_sym && ((meob >> (n_sym - 1u)) & 1ull);
+    B.slow = n_sym < 64u && ((mslow >> n_sym) & 1ull);
+    return B;
+}
+
 }  // namespace vgk
 #endif
