@@ -1666,7 +1666,11 @@ int vgmi_fastq_open(vgmi_ctx* c, vgmi_fastq** out)
     // Text per chunk on the device.  Block-gzip input inflates one member (64 KiB of text) per wavefront: a chunk below
     // 256 MiB leaves wavefront slots empty (measured: 6.4e7 reads/s with 100 MiB chunks, 9.9e7 with 256 MiB), so the
     // device side is sized for that whatever the staging buffers are; plain text arrives in staging-buffer pieces.
-    size_t want_text = want_cap < ((size_t)256 << 20) ? ((size_t)256 << 20) : want_cap;
+    // (round 4: 512 MiB -- an ordinary gzip stream is inflated a stretch of ~160 KB of text per wavefront, and two streams of 256 MiB chunks
+    // leave a quarter of the device's wavefront slots empty: 4.2e7 reads/s with 256 MiB chunks, 5.9e7 with 512, 5.7e7 with 1 024)
+    size_t want_text = want_cap < ((size_t)512 << 20) ? ((size_t)512 << 20) : want_cap;
+    if (const char* e = getenv("VGMI_FASTQ_TEXT_MB"))    // A/B: text per chunk of compressed input (more members / stretches in flight per launch)
+        if (atoi(e) >= 256 && atoi(e) <= 4096) want_text = (size_t)atoi(e) << 20;
     if (const char* e = getenv("VGMI_FASTQ_CHUNK_KB"))   // tests: small chunks put every kind of record across a boundary
         if (atoi(e) >= 4) want_text = want_cap = (size_t)atoi(e) << 10;
     {   // a closed stream of the same geometry: its buffers are reused (pinned allocations cost more than a small file)
@@ -1674,7 +1678,7 @@ int vgmi_fastq_open(vgmi_ctx* c, vgmi_fastq** out)
         {
             std::lock_guard<std::mutex> lk(c->mu);
             for (size_t i = 0; i < c->fastq_pool.size() && !r; ++i)
-                if (c->fastq_pool[i]->cap == want_cap) {
+                if (c->fastq_pool[i]->cap == want_cap && c->fastq_pool[i]->text_cap == want_text) {
                     r = c->fastq_pool[i];
                     c->fastq_pool.erase(c->fastq_pool.begin() + (long)i);
                 }
