@@ -157,7 +157,7 @@ def cpu_baseline(haps, n_reads, cores):
         shutil.rmtree(work, ignore_errors=True)
 
 
-def sample_level(ctx, haps, cpu_ref, n_plain=8_000_000, n_packed=4_000_000):
+def sample_level(ctx, haps, cpu_ref, n_plain=8_000_000, n_packed=8_000_000):
     """SURVEY 8d level (ii): FASTQ FILES -> counters, through the product's FastqKmerHip (csrc/host): plain, gzip and
     block-gzip copies of one sample of the C2 workload, with the records found on the device (vgmi_fastq_*) and, for
     comparison, by the host parser; plus the PCIe-inclusive rate of the host-block entry point vgmi_reads_submit."""
