@@ -21,6 +21,9 @@
 // at a known compressed offset and the host decoder (csrc/host/fast_inflate.cpp) goes on from there with the window it is handed.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "vgmi_inflate_dev.h"
 #include "vgmi_kernels.h"
@@ -32,7 +35,6 @@ namespace vgk {
 #define GZ_WIN 32768u
 #define GZ_NONE 0xFFFFFFFFu
 
-typedef InfTablesT<uint16_t> GzTables;
 typedef InfTablesT<uint16_t, 8> GzFindTables;
 
 // ---- 1. block starts ---------------------------------------------------------------------------------------------------
@@ -204,9 +206,12 @@ struct GzSegOut {
     uint32_t final_block;  // the last decoded block carried BFINAL: the member ends at end_bit
 };
 
-__global__ __launch_bounds__(64 * GZ_WAVES, 4) void gz_decode_kernel(const uint8_t* __restrict__ comp, uint32_t n_bytes, const GzSeg* __restrict__ segs,
-                                                                     uint32_t n_seg, uint16_t* __restrict__ pool, GzSegOut* __restrict__ outs)
+template <bool WIDE>
+__global__ __launch_bounds__(64 * GZ_WAVES, WIDE ? 2 : 4) void gz_decode_kernel(const uint8_t* __restrict__ comp, uint32_t n_bytes, const GzSeg* __restrict__ segs,
+                                                                            uint32_t n_seg, uint16_t* __restrict__ pool, GzSegOut* __restrict__ outs)
 {
+    typedef typename std::conditional<WIDE, InfWideT<uint16_t>, InfTablesT<uint16_t>>::type GzTables;
+    constexpr uint32_t RING = WIDE ? INFW_RING : INF_RING, NEAR = WIDE ? INFW_NEAR : INF_NEAR;
     __shared__ GzTables tabs[GZ_WAVES];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_in_block = uni(threadIdx.x >> 6);
@@ -221,6 +226,7 @@ __global__ __launch_bounds__(64 * GZ_WAVES, 4) void gz_decode_kernel(const uint8
     const uint32_t out_cap = uni(segs[sg].sym_cap);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(out_cap * 2u), 0x00020000);
     uint32_t* const ring32 = reinterpret_cast<uint32_t*>(t.ring);
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(comp), 0, (int)((n_bytes + 3u) & ~3u), 0x00020000);
 
     uint32_t bp = uni(segs[sg].start_bit);
     const uint32_t win_avail = uni(segs[sg].win_avail);
@@ -229,27 +235,27 @@ __global__ __launch_bounds__(64 * GZ_WAVES, 4) void gz_decode_kernel(const uint8
     // ring -> global memory: whole blocks of 128 symbols (the pool slice is word aligned); all of it at the end
     auto flush = [&](bool all) {
         while (op - flushed >= 128u) {
-            const uint32_t r = (flushed + 2u * lane) & (INF_RING - 1u);
+            const uint32_t r = (flushed + 2u * lane) & (RING - 1u);
             __builtin_amdgcn_raw_buffer_store_b32(ring32[r >> 1], orsrc, (flushed + 2u * lane) * 2u, 0, 0);
             flushed += 128u;
         }
         if (all)
             while (flushed < op) {
                 const uint32_t p = flushed + lane;
-                if (p < op) __builtin_amdgcn_raw_buffer_store_b16(t.ring[p & (INF_RING - 1u)], orsrc, p * 2u, 0, 0);
+                if (p < op) __builtin_amdgcn_raw_buffer_store_b16(t.ring[p & (RING - 1u)], orsrc, p * 2u, 0, 0);
                 flushed = flushed + 64u < op ? flushed + 64u : op;
             }
     };
     // one LZ77 match at output position P: sources in front of the stretch are placeholders for the window it does not know
     auto copy_match = [&](uint32_t P, uint32_t len, uint32_t dist) {
-        const bool far = dist > INF_NEAR;
+        const bool far = dist > NEAR;
         if (far) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // flushed symbols are read back (see vgmi_inflate.hip)
         for (uint32_t i = lane; i < len; i += 64) {
             const int32_t q = (int32_t)(P - dist + (dist >= len ? i : i % dist));
             uint16_t v;
             if (q < 0) v = (uint16_t)(256 + (int32_t)GZ_WIN + q);
-            else v = far ? out[q] : t.ring[(uint32_t)q & (INF_RING - 1u)];
-            t.ring[(P + i) & (INF_RING - 1u)] = v;
+            else v = far ? out[q] : t.ring[(uint32_t)q & (RING - 1u)];
+            t.ring[(P + i) & (RING - 1u)] = v;
         }
         inf_sync();
     };
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(64 * GZ_WAVES, 4) void gz_decode_kernel(const uint8
             if (op + len > out_cap) { err = 3; break; }
             for (uint32_t done = 0; done < len;) {
                 const uint32_t n = len - done < 128u ? len - done : 128u;
-                for (uint32_t i = lane; i < n; i += 64) t.ring[(op + i) & (INF_RING - 1u)] = in[src + done + i];
+                for (uint32_t i = lane; i < n; i += 64) t.ring[(op + i) & (RING - 1u)] = in[src + done + i];
                 inf_sync();
                 op += n;
                 done += n;
@@ -388,11 +394,37 @@ __global__ __launch_bounds__(64 * GZ_WAVES, 4) void gz_decode_kernel(const uint8
             if (uni(t.len[256]) == 0) { err = 1; break; }
             if (!inf_build(t, 0, 0, 288, lane) || !inf_build(t, 1, 288, 30, lane)) { err = 1; break; }
         }
+        if constexpr (WIDE) {
+            infw_limits(t, 0, lane);
+            infw_limits(t, 1, lane);
+        }
         inf_pack_lit(t, lane);
         inf_pack_dist(t, lane);
         scalar_done();
 
         bool eob = false;
+        if constexpr (WIDE) {
+            uint32_t nl = 40;      // sub-blocks a batch looks at: what the batches before it got through, and a few
+            while (!eob && !err) {
+                const uint32_t g = bp + 64u * lane;
+                const uint32_t wo = (g >> 5) * 4u, sh = g & 31u;
+                const uint32_t x0 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo, 0, 0), x1 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo + 4u, 0, 0),
+                               x2 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo + 8u, 0, 0), x3 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo + 12u, 0, 0),
+                               x4 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo + 16u, 0, 0);
+                const uint32_t room = out_cap - op < INFW_CAP ? out_cap - op : INFW_CAP;
+                const InfWideOut B = inf_wide<GzTables, uint16_t>(t, __builtin_amdgcn_alignbit(x1, x0, sh), __builtin_amdgcn_alignbit(x2, x1, sh),
+                                                                  __builtin_amdgcn_alignbit(x3, x2, sh), __builtin_amdgcn_alignbit(x4, x3, sh), op, room, nl, lane);
+                if (B.bad) { err = 2; break; }
+                if (!B.adv) { err = 3; break; }                        // the stretch outgrows its room
+                if (bp + B.adv > end_bits) { err = 9; break; }         // the symbols ran into the padding behind the data
+                if (!infw_matches<GzTables, uint16_t, true>(t, B.n_match, op, out, win_avail, lane)) { err = 2; break; }
+                op += B.out;
+                bp += B.adv;
+                eob = B.eob != 0;
+                if (!eob) nl = B.last + 2u >= nl ? (nl + 8u < 64u ? nl + 8u : 64u) : B.last + 4u;
+                flush(false);
+            }
+        } else
         while (!eob && !err) {
             const uint32_t b = bp + lane;
             const uint32_t* const w = in4 + (b >> 5);
@@ -408,9 +440,9 @@ __global__ __launch_bounds__(64 * GZ_WAVES, 4) void gz_decode_kernel(const uint8
             if ((B.lits >> lane) & 1ull) {
                 const uint32_t e = B.e, n = (e >> 6) & 3u, P = op + B.off;
                 if (((e >> 4) & 3u) == 0) {
-                    t.ring[P & (INF_RING - 1u)] = (uint16_t)((e >> 8) & 255u);
-                    if (n > 1) t.ring[(P + 1u) & (INF_RING - 1u)] = (uint16_t)((e >> 16) & 255u);
-                    if (n > 2) t.ring[(P + 2u) & (INF_RING - 1u)] = (uint16_t)(e >> 24);
+                    t.ring[P & (RING - 1u)] = (uint16_t)((e >> 8) & 255u);
+                    if (n > 1) t.ring[(P + 1u) & (RING - 1u)] = (uint16_t)((e >> 16) & 255u);
+                    if (n > 2) t.ring[(P + 2u) & (RING - 1u)] = (uint16_t)(e >> 24);
                 }
             }
             inf_sync();
@@ -438,7 +470,7 @@ __global__ __launch_bounds__(64 * GZ_WAVES, 4) void gz_decode_kernel(const uint8
                 take(l);
                 if (sym < 256) {
                     if (op >= out_cap) { err = 3; break; }
-                    if (lane == 0) t.ring[op & (INF_RING - 1u)] = (uint16_t)sym;
+                    if (lane == 0) t.ring[op & (RING - 1u)] = (uint16_t)sym;
                     inf_sync();
                     ++op;
                 } else if (sym == 256) {
@@ -568,9 +600,12 @@ hipError_t launch_gz_find(const uint8_t* comp, uint32_t n_bytes, uint32_t seg_by
 
 hipError_t launch_gz_decode(const uint8_t* comp, uint32_t n_bytes, const void* segs, uint32_t n_seg, uint16_t* pool, void* outs, hipStream_t st)
 {
-    if (n_seg)
-        hipLaunchKernelGGL(gz_decode_kernel, dim3((n_seg + GZ_WAVES - 1) / GZ_WAVES), dim3(64 * GZ_WAVES), 0, st, comp, n_bytes, static_cast<const GzSeg*>(segs), n_seg,
-                           pool, static_cast<GzSegOut*>(outs));
+    if (n_seg) {
+        static const bool wide = !(getenv("VGMI_INFLATE_WIDE") && getenv("VGMI_INFLATE_WIDE")[0] == '0');
+        const dim3 grid((n_seg + GZ_WAVES - 1) / GZ_WAVES), block(64 * GZ_WAVES);
+        if (wide) hipLaunchKernelGGL(gz_decode_kernel<true>, grid, block, 0, st, comp, n_bytes, static_cast<const GzSeg*>(segs), n_seg, pool, static_cast<GzSegOut*>(outs));
+        else hipLaunchKernelGGL(gz_decode_kernel<false>, grid, block, 0, st, comp, n_bytes, static_cast<const GzSeg*>(segs), n_seg, pool, static_cast<GzSegOut*>(outs));
+    }
     return hipGetLastError();
 }
 

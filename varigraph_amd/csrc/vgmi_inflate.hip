@@ -20,6 +20,9 @@
 // than the tables' index, stored blocks and block headers take a scalar path, one symbol at a time.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "vgmi_kernels.h"
 
@@ -52,11 +55,14 @@ __device__ __forceinline__ uint32_t gf2_x8n(uint32_t n)
 
 // One member per wavefront.  status[m]: 0 = good, else the reason (1 code lengths, 2 bad symbol / distance, 3 output or
 // input overrun, 4 length != ISIZE, 5 CRC-32, 6 stored-block header, 7 reserved block type).
-__global__ __launch_bounds__(64 * INF_WAVES, 4) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const BgzfMember* __restrict__ members, uint32_t n_members,
-                                                                     uint8_t* __restrict__ out_base, uint32_t* __restrict__ status,
-                                                                     const uint32_t* __restrict__ crc_table)
+template <bool WIDE>
+__global__ __launch_bounds__(64 * INF_WAVES, WIDE ? 3 : 4) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const BgzfMember* __restrict__ members,
+                                                                                uint32_t n_members, uint8_t* __restrict__ out_base, uint32_t* __restrict__ status,
+                                                                                const uint32_t* __restrict__ crc_table)
 {
-    __shared__ InfTables tabs[INF_WAVES];
+    typedef typename std::conditional<WIDE, InfWideT<uint8_t>, InfTables>::type Tables;
+    constexpr uint32_t RING = WIDE ? INFW_RING : INF_RING, NEAR = WIDE ? INFW_NEAR : INF_NEAR;
+    __shared__ Tables tabs[INF_WAVES];
     __shared__ uint32_t s_crc[256];
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_crc[i] = crc_table[i];
     __syncthreads();
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(64 * INF_WAVES, 4) void bgzf_inflate_kernel(const u
     const uint32_t wave_in_block = uni(threadIdx.x >> 6);
     const uint32_t m = blockIdx.x * INF_WAVES + wave_in_block;
     if (m >= n_members) return;
-    InfTables& t = tabs[wave_in_block];
+    Tables& t = tabs[wave_in_block];
     const uint8_t* in = comp + uni(members[m].c_off);
     const uint32_t in_len = uni(members[m].c_len);       // deflate bytes (header and trailer stripped by the host walk)
     uint8_t* out = out_base + uni(members[m].u_off);
@@ -76,6 +82,8 @@ __global__ __launch_bounds__(64 * INF_WAVES, 4) void bgzf_inflate_kernel(const u
     const uint32_t* const in4 = reinterpret_cast<const uint32_t*>((uintptr_t)in & ~(uintptr_t)3);
     const uint32_t lead_bits = 8u * (uint32_t)((uintptr_t)in & 3u);
     uint32_t* const ring32 = reinterpret_cast<uint32_t*>(t.ring);
+    // the wide batches read the input through a descriptor: words behind the member's last read as zero
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(in4), 0, (int)((lead_bits / 8u + in_len + 3u) & ~3u), 0x00020000);
 
     // ---- wave-uniform decoder state ----
     uint32_t bp = 0;            // bits of the member's deflate data consumed
@@ -92,8 +100,8 @@ __global__ __launch_bounds__(64 * INF_WAVES, 4) void bgzf_inflate_kernel(const u
             flushed = n;
         }
         while (flushed >= head && op - flushed >= 256u) {
-            const uint32_t r = (flushed + 4u * lane) & (INF_RING - 1u);
-            const uint32_t w0 = ring32[r >> 2], w1 = ring32[((r >> 2) + 1u) & (INF_RING / 4u - 1u)];
+            const uint32_t r = (flushed + 4u * lane) & (RING - 1u);
+            const uint32_t w0 = ring32[r >> 2], w1 = ring32[((r >> 2) + 1u) & (RING / 4u - 1u)];
             const uint32_t v = __builtin_amdgcn_alignbyte(w1, w0, r & 3u);
             __builtin_amdgcn_raw_buffer_store_b32(v, orsrc, flushed + 4u * lane, 0, 0);
             flushed += 256u;
@@ -101,25 +109,25 @@ __global__ __launch_bounds__(64 * INF_WAVES, 4) void bgzf_inflate_kernel(const u
         if (all)
             while (flushed < op) {
                 const uint32_t p = flushed + lane;
-                if (p < op) __builtin_amdgcn_raw_buffer_store_b8(t.ring[p & (INF_RING - 1u)], orsrc, p, 0, 0);
+                if (p < op) __builtin_amdgcn_raw_buffer_store_b8(t.ring[p & (RING - 1u)], orsrc, p, 0, 0);
                 flushed = flushed + 64u < op ? flushed + 64u : op;
             }
     };
     // one LZ77 match at output position P (every earlier byte is in the ring, or in global memory when far): 64 bytes per step
     auto copy_match = [&](uint32_t P, uint32_t len, uint32_t dist) {
-        if (dist <= INF_NEAR) {
+        if (dist <= NEAR) {
             for (uint32_t i = lane; i < len; i += 64) {
-                const uint8_t b = t.ring[(P - dist + (dist >= len ? i : i % dist)) & (INF_RING - 1u)];
-                t.ring[(P + i) & (INF_RING - 1u)] = b;
+                const uint8_t b = t.ring[(P - dist + (dist >= len ? i : i % dist)) & (RING - 1u)];
+                t.ring[(P + i) & (RING - 1u)] = b;
             }
         } else {
-            // far: the source is in front of everything still unflushed (INF_NEAR > the ring's unflushed part + a batch); read it
+            // far: the source is in front of everything still unflushed (NEAR > the ring's unflushed part + a batch); read it
             // back once the wavefront's stores have landed (its own stores and loads go through the same vector cache; an
             // agent-scope fence here writes the whole L2 back and made the kernel 15 x slower -- whatever this read could get
             // wrong, the CRC below catches and the host decoder redoes)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const uint8_t* const src = out + P - dist;
-            for (uint32_t i = lane; i < len; i += 64) t.ring[(P + i) & (INF_RING - 1u)] = src[dist >= len ? i : i % dist];
+            for (uint32_t i = lane; i < len; i += 64) t.ring[(P + i) & (RING - 1u)] = src[dist >= len ? i : i % dist];
         }
         inf_sync();
     };
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(64 * INF_WAVES, 4) void bgzf_inflate_kernel(const u
             if (src + len > in_len || op + len > out_len) { err = 3; break; }
             for (uint32_t done = 0; done < len;) {
                 const uint32_t n = len - done < 256u ? len - done : 256u;
-                for (uint32_t i = lane; i < n; i += 64) t.ring[(op + i) & (INF_RING - 1u)] = in[src + done + i];
+                for (uint32_t i = lane; i < n; i += 64) t.ring[(op + i) & (RING - 1u)] = in[src + done + i];
                 inf_sync();
                 op += n;
                 done += n;
@@ -258,12 +266,41 @@ __global__ __launch_bounds__(64 * INF_WAVES, 4) void bgzf_inflate_kernel(const u
             if (uni(t.len[256]) == 0) { err = 1; break; }    // no end-of-block code
             if (!inf_build(t, 0, 0, 288, lane) || !inf_build(t, 1, 288, 30, lane)) { err = 1; break; }
         }
+        if constexpr (WIDE) {
+            infw_limits(t, 0, lane);
+            infw_limits(t, 1, lane);
+        }
         inf_pack_lit(t, lane);
         inf_pack_dist(t, lane);
         scalar_done();
 
-        // ---- symbols of this block: batches of 64 bit positions ----
         bool eob = false;
+        if constexpr (WIDE) {
+            uint32_t nl = 40;      // sub-blocks a batch looks at: what the batches before it got through, and a few
+            // ---- symbols of this block: batches of 64 sub-blocks of 64 bits (vgmi_inflate_dev.h: inf_wide) ----
+            while (!eob && !err) {
+                const uint32_t g = lead_bits + bp + 64u * lane;
+                const uint32_t wo = (g >> 5) * 4u, sh = g & 31u;
+                const uint32_t x0 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo, 0, 0), x1 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo + 4u, 0, 0),
+                               x2 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo + 8u, 0, 0), x3 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo + 12u, 0, 0),
+                               x4 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo + 16u, 0, 0);
+                const uint32_t room = out_len - op < INFW_CAP ? out_len - op : INFW_CAP;
+                const InfWideOut B = inf_wide<Tables, uint8_t>(t, __builtin_amdgcn_alignbit(x1, x0, sh), __builtin_amdgcn_alignbit(x2, x1, sh),
+                                                               __builtin_amdgcn_alignbit(x3, x2, sh), __builtin_amdgcn_alignbit(x4, x3, sh), op, room, nl, lane);
+#ifdef VGMI_ABLATION
+                if (m == 5 && lane == 0) printf("batch bp %u op %u: rounds %u last %u out %u adv %u matches %u eob %u\n", bp, op, B.rounds, B.last, B.out, B.adv, B.n_match, B.eob);
+#endif
+                if (B.bad) { err = 2; break; }
+                if (!B.adv || (bp >> 3) > in_len + 8u) { err = 3; break; }      // nothing fits: more text than ISIZE says; or a damaged stream running away
+                if (!infw_matches<Tables, uint8_t, false>(t, B.n_match, op, out, 0u, lane)) { err = 2; break; }
+                op += B.out;
+                bp += B.adv;
+                eob = B.eob != 0;
+                if (!eob) nl = B.last + 2u >= nl ? (nl + 8u < 64u ? nl + 8u : 64u) : B.last + 4u;
+                flush(false);
+            }
+        } else
+        // ---- symbols of this block: batches of 64 bit positions ----
         while (!eob && !err) {
             // the 64 bits that start at bit bp + lane
             const uint32_t b = lead_bits + bp + lane;
@@ -281,9 +318,9 @@ __global__ __launch_bounds__(64 * INF_WAVES, 4) void bgzf_inflate_kernel(const u
             if ((B.lits >> lane) & 1ull) {
                 const uint32_t e = B.e, n = (e >> 6) & 3u, P = op + B.off;
                 if (((e >> 4) & 3u) == 0) {
-                    t.ring[P & (INF_RING - 1u)] = (uint8_t)(e >> 8);
-                    if (n > 1) t.ring[(P + 1u) & (INF_RING - 1u)] = (uint8_t)(e >> 16);
-                    if (n > 2) t.ring[(P + 2u) & (INF_RING - 1u)] = (uint8_t)(e >> 24);
+                    t.ring[P & (RING - 1u)] = (uint8_t)(e >> 8);
+                    if (n > 1) t.ring[(P + 1u) & (RING - 1u)] = (uint8_t)(e >> 16);
+                    if (n > 2) t.ring[(P + 2u) & (RING - 1u)] = (uint8_t)(e >> 24);
                 }
             }
             inf_sync();
@@ -315,7 +352,7 @@ __global__ __launch_bounds__(64 * INF_WAVES, 4) void bgzf_inflate_kernel(const u
                 take(l);
                 if (sym < 256) {
                     if (op >= out_len) { err = 3; break; }
-                    if (lane == 0) t.ring[op & (INF_RING - 1u)] = (uint8_t)sym;
+                    if (lane == 0) t.ring[op & (RING - 1u)] = (uint8_t)sym;
                     inf_sync();
                     ++op;
                 } else if (sym == 256) {
@@ -410,9 +447,15 @@ __global__ void bgzf_verdict_kernel(const BgzfMember* members, const uint32_t* s
 hipError_t launch_bgzf_inflate(const uint8_t* comp, const BgzfMember* members, uint32_t n_members, uint8_t* out_base, uint32_t* status,
                                const uint32_t* crc_table, BgzfVerdict* verdict, hipStream_t s)
 {
-    if (n_members)
-        hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((n_members + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), 0, s, comp, members, n_members, out_base, status,
-                           crc_table);
+    static const bool wide = !(getenv("VGMI_INFLATE_WIDE") && getenv("VGMI_INFLATE_WIDE")[0] == '0');
+    if (n_members) {
+        if (wide)
+            hipLaunchKernelGGL(bgzf_inflate_kernel<true>, dim3((n_members + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), 0, s, comp, members, n_members, out_base,
+                               status, crc_table);
+        else
+            hipLaunchKernelGGL(bgzf_inflate_kernel<false>, dim3((n_members + INF_WAVES - 1) / INF_WAVES), dim3(64 * INF_WAVES), 0, s, comp, members, n_members, out_base,
+                               status, crc_table);
+    }
     hipLaunchKernelGGL(bgzf_verdict_kernel, dim3(1), dim3(256), 0, s, members, status, n_members, verdict);
     return hipGetLastError();
 }

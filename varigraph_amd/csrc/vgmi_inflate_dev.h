@@ -275,5 +275,381 @@ __device__ __forceinline__ InfBatch inf_batch(const T& t, uint32_t lo, uint32_t 
     return B;
 }
 
+// ---- a WIDE batch: 64 sub-blocks of 64 bits, one per lane, walked symbol by symbol (round 4, second form) ---------------------
+// inf_batch spends ~350 instructions of a whole wavefront on 64 CANDIDATE positions of which ~10 are symbol starts -- 30 bytes of
+// text.  Here every lane walks its OWN 64 bits of the window one symbol after the other (~45 instructions a step for up to 64
+// symbols of the wavefront), starting where the walk of the lane in front of it ends -- which nobody knows at first.  Huffman
+// streams re-synchronise: a walk started at a wrong bit falls in step with the true one after a few symbols, so every lane first
+// walks from bit 0 of its sub-block (lane 0's start is true), remembers the starts it visited as a 64-bit mask and where it left
+// the sub-block; then each lane is told where the lane in front of it really ends: a start its mask holds changes nothing behind
+// it, any other is walked until it meets the mask (or leaves the sub-block, which the next lane then hears of).  Repeated until no
+// lane changes -- lane k is final after k rounds at the latest, in practice after two or three -- every lane holds the true
+// symbol starts of its 64 bits.  A second walk counts output bytes and matches per lane (prefix sums give every lane its place in
+// the ring and in the match queue), a third writes the literals and queues the matches, which the caller copies in order.
+// Codes longer than the tables' index are decoded in the lane (canonical decoding against the per-length limits: infw_limits).
+#define INFW_RING 4096u         // ring entries
+#define INFW_CAP 1536u          // output of a batch at most
+#define INFW_NEAR 2560u         // matches this far back read the ring: INFW_CAP + 513 <= INFW_NEAR <= INFW_RING - INFW_CAP (a batch's
+                                // literals, written first, never land on a near source; a far source is in global memory already)
+#define INFW_MQ 192u            // matches of a batch at most
+#define INFW_SHORT 16u          // matches up to this long are copied by one lane each, all at once; longer ones by the wavefront, one after the other
+#define INFW_UNSET 0x1FFu
+#define INFW_END_EOB 0x100u
+#define INFW_END_BAD 0x101u
+#define INFW_END_OFF 0x102u
+
+template <class RingT>
+struct InfWideT {
+    uint32_t lit[1u << INF_LIT_BITS];
+    uint32_t dist[1u << INF_DIST_BITS];
+    uint8_t len[320];
+    uint16_t sorted[320];
+    uint16_t count[2][INF_MAXBITS + 1];
+    uint16_t offs[2][INF_MAXBITS + 1];
+    uint16_t lim[2][16];           // [l]: codes of l bits, left-aligned to 15 bits, are below this ([0] = 0)
+    int32_t sbase[2][16];          // [l]: index into sorted[] of a code of l bits = sbase + code
+    uint32_t mq[INFW_MQ];          // the batch's matches in order: (length - 3) << 15 | (distance - 1)
+    uint16_t mqp[INFW_MQ];         // ... and where they go, from the batch's first byte
+    RingT ring[INFW_RING];
+};
+
+// per-length limits of the canonical code `which` (after inf_build)
+template <class T>
+__device__ void infw_limits(T& t, uint32_t which, uint32_t lane)
+{
+    if (lane <= INF_MAXBITS) {
+        uint32_t code = 0;
+        for (uint32_t i = 1; i <= lane; ++i) code = (code + (i > 1 ? t.count[which][i - 1] : 0u)) << 1;
+        t.lim[which][lane] = lane ? (uint16_t)((code + t.count[which][lane]) << (INF_MAXBITS - lane)) : (uint16_t)0;
+        t.sbase[which][lane] = (int32_t)t.offs[which][lane] - (int32_t)code;
+    }
+    inf_sync();
+}
+
+// canonical decoding of the code at the low end of v: symbol or -1, its length in l
+template <class T>
+__device__ __forceinline__ int32_t infw_canon(const T& t, uint32_t which, uint32_t v, uint32_t& l)
+{
+    const uint32_t c15 = __builtin_bitreverse32(v) >> 17;
+    uint32_t n = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 16; ++i) n += c15 >= t.lim[which][i];
+    l = n;
+    if (n > INF_MAXBITS) return -1;      // (lim[15] = 32768 for a complete code: never reached then)
+    return (int32_t)t.sorted[which * 288 + (uint32_t)(t.sbase[which][n] + (int32_t)(c15 >> (INF_MAXBITS - n)))];
+}
+
+struct InfEnt {
+    uint32_t bits, ol, fl;      // input bits, output bytes, 0 literals / 2 end of block / 4 match / 8 no such code
+    uint32_t e;                 // literals: count in bits 6..7, bytes in 8..31
+    uint32_t mlen, mdist;
+};
+
+// the symbol (or run of up to three short literals) that starts at the low end of hi:lo
+template <class T>
+__device__ __forceinline__ InfEnt inf_entry(const T& t, uint32_t lo, uint32_t hi)
+{
+    InfEnt E;
+    const uint32_t e = t.lit[lo & ((1u << INF_LIT_BITS) - 1u)];
+    const uint32_t cb = e & 15u, kind = (e >> 4) & 3u, eb = (e >> 6) & 7u;
+    const uint32_t pd = cb + eb;
+    const uint32_t de = t.dist[(lo >> pd) & ((1u << INF_DIST_BITS) - 1u)];
+    const uint32_t dl = de & 15u, deb = (de >> 4) & 15u, qd = pd + dl;
+    E.e = e;
+    E.mlen = ((e >> 9) & 511u) + ((lo >> cb) & ((1u << eb) - 1u));
+    E.mdist = (de >> 8) + (__builtin_amdgcn_alignbit(hi, lo, qd) & ((1u << deb) - 1u));
+    if (cb && kind == 0) { E.bits = cb; E.ol = (e >> 6) & 3u; E.fl = 0; }
+    else if (cb && kind == 2) { E.bits = cb; E.ol = 0; E.fl = 2; }
+    else if (cb && dl) { E.bits = qd + deb; E.ol = E.mlen; E.fl = 4; }
+    else {
+        // a code the tables do not hold whole
+        const uint64_t bb = (uint64_t)hi << 32 | lo;
+        uint32_t l;
+        const int32_t sym = infw_canon(t, 0, lo, l);
+        E.bits = 0; E.ol = 0; E.fl = 8;
+        if (sym >= 0 && sym < 256) { E.bits = l; E.ol = 1; E.fl = 0; E.e = 1u << 6 | (uint32_t)sym << 8; }
+        else if (sym == 256) { E.bits = l; E.fl = 2; }
+        else if (sym > 256 && sym < 286) {
+            const uint32_t c = (uint32_t)sym - 257u;
+            const uint32_t x = c < 8 || c == 28 ? 0u : (c >> 2) - 1u;
+            const uint32_t base = c < 8 ? 3u + c : c == 28 ? 258u : ((4u + (c & 3u)) << x) + 3u;
+            const uint32_t len = base + ((uint32_t)(bb >> l) & ((1u << x) - 1u));
+            const uint32_t p2 = l + x;                                 // <= 20
+            const uint32_t v = (uint32_t)(bb >> p2);
+            const uint32_t d2 = t.dist[v & ((1u << INF_DIST_BITS) - 1u)];
+            uint32_t dbits = d2 & 15u, dx = (d2 >> 4) & 15u, dbase = d2 >> 8;
+            bool ok = dbits != 0;
+            if (!ok) {
+                const int32_t ds = infw_canon(t, 1, v, dbits);
+                if (ds >= 0 && ds < 30) {
+                    ok = true;
+                    dx = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;
+                    dbase = ds < 4 ? 1u + (uint32_t)ds : ((2u + ((uint32_t)ds & 1u)) << dx) + 1u;
+                }
+            }
+            if (ok) {
+                E.mlen = len;
+                E.mdist = dbase + ((uint32_t)(bb >> (p2 + dbits)) & ((1u << dx) - 1u));
+                E.bits = p2 + dbits + dx;                              // <= 48
+                E.ol = len;
+                E.fl = 4;
+            }
+        }
+    }
+    return E;
+}
+
+// inclusive prefix sum over the wavefront
+__device__ __forceinline__ uint32_t inf_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);      // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);      // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);      // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);      // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);      // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+struct InfWideOut {
+    uint32_t out, adv, n_match;     // output bytes, input bits, queued matches of the batch
+    uint32_t eob, bad;              // it ends with the end-of-block code / in front of bits that are no code
+    uint32_t last;                  // the last lane whose symbols were taken
+#ifdef VGMI_ABLATION
+    uint32_t rounds;                // (profiling builds) rounds until every lane knew its start
+#endif
+};
+
+// W0..W3: the 128 bits that start at bit (position + 64 * lane).  op: the ring position of the batch's first byte; room: output the
+// batch may produce (<= INFW_CAP); nl: lanes that take part (what the last batches used: the rounds are not spent on more).  Literals are in the ring and the matches in t.mq / t.mqp when it returns (behind an inf_sync).
+template <class T, class RingT>
+__device__ __forceinline__ InfWideOut inf_wide(T& t, uint32_t W0, uint32_t W1, uint32_t W2, uint32_t W3, uint32_t op, uint32_t room, uint32_t nl, uint32_t lane)
+{
+    auto bits_at = [&](uint32_t p, uint32_t& lo, uint32_t& hi) {
+        const bool up = p >= 32u;
+        const uint32_t a = up ? W1 : W0, b = up ? W2 : W1, c = up ? W3 : W2;
+        lo = __builtin_amdgcn_alignbit(b, a, p);
+        hi = __builtin_amdgcn_alignbit(c, b, p);
+    };
+    // a sub-block ends with the last SYMBOL that starts inside it: a run of literals that reaches over bit 64 is taken up to there
+    // only (where a lane leaves off must not depend on how its walk happened to group the literals)
+    auto lit_take = [&](uint32_t p, const InfEnt& E, uint32_t& n, uint32_t& adv) {
+        n = (E.e >> 6) & 3u;
+        adv = E.bits;
+        if (n > 1 && p + E.bits > 64u) {
+            const uint32_t l1 = t.len[(E.e >> 8) & 255u];
+            if (p + l1 >= 64u) { n = 1; adv = l1; }
+            else if (n > 2) {
+                const uint32_t l2 = l1 + t.len[(E.e >> 16) & 255u];
+                if (p + l2 >= 64u) { n = 2; adv = l2; }
+            }
+        }
+    };
+    // ---- the true symbol starts of every sub-block
+    uint64_t mask = 0;
+    uint32_t start = 0xFFFFu, endv = INFW_UNSET;
+#ifdef VGMI_ABLATION
+    uint32_t dbg_rounds = 0;
+#endif
+    for (;;) {
+#ifdef VGMI_ABLATION
+        ++dbg_rounds;
+#endif
+        uint32_t inc = inf_bperm(endv, (lane - 1u) & 63u);
+        if (lane == 0) inc = 0;
+        else if (inc == INFW_UNSET) inc = 0;                    // first round: every lane tries its bit 0
+        else if (inc >= INFW_END_EOB) inc = INFW_END_OFF;
+        if (lane >= nl) inc = INFW_END_OFF;
+        const bool changed = inc != start;
+        if (!__ballot(changed)) break;
+        if (changed) {
+            start = inc;
+            if (inc >= INFW_END_EOB) {
+                mask = 0;
+                endv = INFW_END_OFF;
+            } else if ((mask >> inc) & 1ull) {
+                mask &= ~0ull << inc;
+            } else {
+                uint64_t nm = 0;
+                uint32_t p = inc, ne = 0;
+                while (p < 64u && !((mask >> p) & 1ull)) {
+                    nm |= 1ull << p;
+                    uint32_t lo, hi;
+                    bits_at(p, lo, hi);
+                    const InfEnt E = inf_entry(t, lo, hi);
+                    if (E.fl & 10u) {
+                        ne = (E.fl & 2u) ? INFW_END_EOB : INFW_END_BAD;
+                        p = 1000u;
+                    } else {
+                        // the mask holds every SYMBOL start, also those inside a run of literals taken in one step: two walks over
+                        // the same symbols that group them differently must still meet
+                        uint32_t adv = E.bits;
+                        const uint32_t n = (E.e >> 6) & 3u;
+                        if (E.fl == 0 && n > 1) {
+                            const uint32_t l1 = t.len[(E.e >> 8) & 255u], s1 = p + l1;
+                            if (s1 >= 64u) adv = l1;
+                            else {
+                                nm |= 1ull << s1;
+                                if (n > 2) {
+                                    const uint32_t s2 = s1 + t.len[(E.e >> 16) & 255u];
+                                    if (s2 >= 64u) adv = s2 - p;
+                                    else nm |= 1ull << s2;
+                                }
+                            }
+                        }
+                        p += adv;
+                    }
+                }
+                if (p < 64u) mask = nm | (mask & (~0ull << p));      // met the old walk: what is behind stands
+                else {
+                    mask = nm;
+                    endv = ne ? ne : p - 64u;
+                }
+            }
+        }
+    }
+    const bool on = start < INFW_END_EOB;
+    // ---- output bytes and matches per lane
+    uint32_t n_out = 0, n_m = 0, c_bad = 0;
+    if (on) {
+        uint32_t p = start;
+        while (p < 64u) {
+            uint32_t lo, hi;
+            bits_at(p, lo, hi);
+            const InfEnt E = inf_entry(t, lo, hi);
+            if (E.fl & 8u) { c_bad = 1; break; }
+            if (E.fl & 2u) break;
+            uint32_t n = E.ol, adv = E.bits;
+            if (E.fl == 0) lit_take(p, E, n, adv);
+            n_out += n;
+            n_m += E.fl >> 2;
+            p += adv;
+        }
+    }
+    const uint32_t incl = inf_scan(n_out | n_m << 20);
+    const uint32_t incl_out = incl & 0xFFFFFu, incl_m = incl >> 20;
+    const uint64_t m_on = __ballot(on);
+    const uint64_t m_fit = __ballot(on && !c_bad && incl_out <= room && incl_m <= INFW_MQ);
+    const uint32_t n_full = m_fit == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m_fit);
+    const uint32_t last = n_full < 64u && ((m_on >> n_full) & 1ull) ? n_full : n_full - 1u;      // (lane 0 is always on)
+    // ---- literals into the ring, matches into the queue
+    const uint32_t ex_out = incl_out - n_out, ex_m = incl_m - n_m;
+    uint32_t o = 0, m = 0, p_end = 0, f_eob = 0, f_bad = 0;
+    if (on && lane <= last) {
+        const uint32_t lim_o = room - ex_out, lim_m = INFW_MQ - ex_m;       // (lanes in front of `last` never meet them)
+        uint32_t p = start;
+        while (p < 64u) {
+            uint32_t lo, hi;
+            bits_at(p, lo, hi);
+            const InfEnt E = inf_entry(t, lo, hi);
+            if (E.fl & 8u) { f_bad = 1; break; }
+            if (E.fl & 2u) { f_eob = 1; p += E.bits; break; }
+            uint32_t n = E.ol, adv = E.bits;
+            if (E.fl == 0) lit_take(p, E, n, adv);
+            if (o + n > lim_o) break;
+            const uint32_t P = op + ex_out + o;
+            if (E.fl & 4u) {
+                if (m >= lim_m) break;
+                t.mq[ex_m + m] = (E.mlen - 3u) << 15 | (E.mdist - 1u);
+                t.mqp[ex_m + m] = (uint16_t)(ex_out + o);
+                ++m;
+            } else {
+                const uint32_t e = E.e;
+                t.ring[P & (INFW_RING - 1u)] = (RingT)((e >> 8) & 255u);
+                if (n > 1) t.ring[(P + 1u) & (INFW_RING - 1u)] = (RingT)((e >> 16) & 255u);
+                if (n > 2) t.ring[(P + 2u) & (INFW_RING - 1u)] = (RingT)(e >> 24);
+            }
+            o += n;
+            p += adv;
+        }
+        p_end = p;
+    }
+    inf_sync();
+    InfWideOut B;
+    B.out = (uint32_t)__builtin_amdgcn_readlane((int)(ex_out + o), (int)last);
+    B.adv = 64u * last + (uint32_t)__builtin_amdgcn_readlane((int)p_end, (int)last);
+    B.n_match = (uint32_t)__builtin_amdgcn_readlane((int)(ex_m + m), (int)last);
+    B.eob = (uint32_t)__builtin_amdgcn_readlane((int)f_eob, (int)last);
+    B.bad = (uint32_t)__builtin_amdgcn_readlane((int)f_bad, (int)last);
+    B.last = last;
+#ifdef VGMI_ABLATION
+    B.rounds = dbg_rounds;
+#endif
+    return B;
+}
+
+// The matches a batch queued, copied.  A match's bytes come from the ring (near), from what the wavefront has flushed to global
+// memory (far: `out`, read back behind a wavefront-scope fence -- see vgmi_inflate.hip), or -- PH, ordinary gzip -- from in front of
+// the stretch, as placeholders.  Most matches of FASTQ text are short and reach far back (a 7-mer seen 20 KiB ago): copied one after
+// the other, each waits a memory round trip for a handful of bytes -- THAT is what bounded both decoders.  Here 64 queued matches are
+// taken at once, a lane each: a match may go as soon as everything it reads is final, i.e. lies in front of the first match still
+// waiting (literals are in place already; matches write only at or behind that point).  The first one waiting always may (a source
+// that overlaps its own output is copied in order by its lane).  Matches longer than INFW_SHORT go the old way, 64 bytes a step.
+// back_ok: how far in front of the output's first byte a distance may reach (0; the window a gzip stretch may assume).
+// Returns false for a distance beyond that.
+template <class T, class RingT, bool PH>
+__device__ __forceinline__ bool infw_matches(T& t, uint32_t n_match, uint32_t op, const RingT* __restrict__ out, uint32_t back_ok, uint32_t lane)
+{
+    constexpr uint32_t M = INFW_RING - 1u;
+    auto ph = [](int32_t q) -> RingT { return (RingT)(256 + 32768 + q); };
+    for (uint32_t c0 = 0; c0 < n_match; c0 += 64u) {
+        const uint32_t j = c0 + lane;
+        const bool have = j < n_match;
+        const uint32_t d = have ? t.mq[j] : 0u;
+        const uint32_t P = op + (have ? (uint32_t)t.mqp[j] : 0u);
+        const uint32_t len = (d >> 15) + 3u, dist = (d & 32767u) + 1u;
+        if (__ballot(have && dist > P + back_ok)) return false;
+        const int32_t q0 = (int32_t)(P - dist);
+        const int32_t src_end = dist < len ? (int32_t)P : q0 + (int32_t)len;
+        const bool far = dist > INFW_NEAR, is_long = len > INFW_SHORT;
+        uint64_t pend = __ballot(have);
+        if (__ballot(have && far)) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        while (pend) {
+            const uint32_t first = (uint32_t)__builtin_ctzll(pend);
+            const int32_t R0 = (int32_t)__builtin_amdgcn_readlane((int)P, (int)first);
+            const bool ready = ((pend >> lane) & 1ull) && src_end <= R0;
+            if (ready && !is_long) {
+                if (far) {
+                    for (uint32_t i = 0; i < len; i += 8u) {
+                        RingT v[8];
+#pragma unroll
+                        for (uint32_t k = 0; k < 8u; ++k) {
+                            const int32_t q = q0 + (int32_t)(i + k);
+                            v[k] = i + k < len ? (PH && q < 0 ? ph(q) : out[q]) : (RingT)0;
+                        }
+#pragma unroll
+                        for (uint32_t k = 0; k < 8u; ++k)
+                            if (i + k < len) t.ring[(P + i + k) & M] = v[k];
+                    }
+                } else {
+                    for (uint32_t i = 0; i < len; ++i) {
+                        const int32_t q = q0 + (int32_t)i;
+                        t.ring[(P + i) & M] = PH && q < 0 ? ph(q) : t.ring[(uint32_t)q & M];
+                    }
+                }
+            }
+            uint64_t lm = __ballot(ready && is_long);
+            while (lm) {
+                const uint32_t ml = (uint32_t)__builtin_ctzll(lm);
+                lm &= lm - 1ull;
+                const uint32_t Pl = (uint32_t)__builtin_amdgcn_readlane((int)P, (int)ml), ll = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)ml),
+                               dl = (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)ml);
+                const bool fl = dl > INFW_NEAR;
+                for (uint32_t i = lane; i < ll; i += 64u) {
+                    const int32_t q = (int32_t)(Pl - dl + (dl >= ll ? i : i % dl));
+                    RingT v;
+                    if (PH && q < 0) v = ph(q);
+                    else v = fl ? out[q] : t.ring[(uint32_t)q & M];
+                    t.ring[(Pl + i) & M] = v;
+                }
+                inf_sync();
+            }
+            inf_sync();
+            pend &= ~__ballot(ready);
+        }
+    }
+    return true;
+}
+
 }  // namespace vgk
 #endif
