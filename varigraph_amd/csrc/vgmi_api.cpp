@@ -1959,7 +1959,7 @@ struct GzScratch {
     uint64_t* d_toff = nullptr;
     uint16_t *d_pool = nullptr, *d_w1 = nullptr;      // symbols; the 16-bit window behind every stretch
     uint8_t* d_win = nullptr;                         // byte windows: in front of the piece, then behind every group of stretches
-    size_t cap_seg = 0, cap_pool = 0;
+    size_t cap_seg = 0, cap_pool = 0, cap_sub = 0;
     void release()
     {
         for (void* q : {(void*)d_starts, (void*)d_segs, (void*)d_outs, (void*)d_toff, (void*)d_pool, (void*)d_win, (void*)d_w1})
@@ -1971,9 +1971,10 @@ struct GzScratch {
 const uint32_t kGzSeg = [] {
     const char* e = getenv("VGMI_GZ_SEG_KB");
     const int v = e ? atoi(e) : 48;      // measured, reads/s with four host threads: 32 KiB 5.9e7, 48 KiB 6.3e7, 64 KiB 5.1e7 (gpurun_out/r4q)
-    return (uint32_t)(v < 32 ? 32 : v > 1024 ? 1024 : v) << 10;
+    return ((uint32_t)(v < 32 ? 32 : v > 1024 ? 1024 : v) + 7u) / 8u * 8u << 10;      // a multiple of the search's sub-ranges
 }();
 constexpr uint32_t kGzRatio = 12;         // symbols of room per compressed byte of a stretch (FASTQ: 4-6)
+constexpr uint32_t kGzSub = 8192;         // the block-start search: compressed bytes per wavefront (each reports the first start of its sub-range)
 
 int gz_piece(vgmi_ctx* c, GzScratch& g, const uint8_t* d_comp, uint32_t n, uint32_t first_bit, uint32_t win_avail, uint8_t* d_text, size_t text_cap,
              hipStream_t st, uint32_t* end_bit, size_t* n_text, int* final_member, uint32_t* reason)
@@ -1985,11 +1986,13 @@ int gz_piece(vgmi_ctx* c, GzScratch& g, const uint8_t* d_comp, uint32_t n, uint3
     if (n < 64 || (uint64_t)n * 8 >= (1ull << 32) - 4096) return VGMI_OK;
     const uint32_t n_nom = (n + kGzSeg - 1) / kGzSeg;
     const size_t pool_syms = (size_t)kGzRatio * n + (size_t)n_nom * 1024 + 65536;
-    if (g.cap_seg < n_nom + 1 || g.cap_pool < pool_syms) {
+    const uint32_t n_sub = (n + kGzSub - 1) / kGzSub;
+    if (g.cap_seg < n_nom + 1 || g.cap_pool < pool_syms || g.cap_sub < n_sub) {
         g.release();
         g.cap_seg = n_nom + 1;
         g.cap_pool = pool_syms;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_starts), g.cap_seg * 4));
+        g.cap_sub = n_sub;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_starts), g.cap_sub * 4));
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_segs), g.cap_seg * sizeof(GzSegHost)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_outs), g.cap_seg * sizeof(GzSegOutHost)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_toff), g.cap_seg * 8));
@@ -1997,23 +2000,30 @@ int gz_piece(vgmi_ctx* c, GzScratch& g, const uint8_t* d_comp, uint32_t n, uint3
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_win), ((size_t)gz_groups((uint32_t)g.cap_seg) + 2) * 32768));
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_w1), g.cap_seg * 65536));
     }
-    // 1. guessed block starts (the first is known)
-    HIPCHK(c, hipMemsetAsync(g.d_starts, 0xFF, (size_t)n_nom * 4, st));
-    HIPCHK(c, launch_gz_find(d_comp, n, kGzSeg, n_nom, g.d_starts, st));
-    std::vector<uint32_t> starts(n_nom);
-    HIPCHK(c, hipMemcpyAsync(starts.data(), g.d_starts, (size_t)n_nom * 4, hipMemcpyDeviceToHost, st));
+    // 1. guessed block starts: the first of every sub-range of kGzSub bytes; stretch j starts at the first one found at or behind
+    // j * kGzSeg (and in front of (j + 2) * kGzSeg), the piece's first start is known.  (Stretches that run from a start to the first
+    // one kGzSeg or more behind it come out half again as long -- DEFLATE blocks of FASTQ text are ~28 KiB apart -- and the decode
+    // kernel, a single round of wavefronts, is as slow as its longest stretch: 19 against 14 ms, gpurun_out/r4w3.)
+    HIPCHK(c, hipMemsetAsync(g.d_starts, 0xFF, (size_t)n_sub * 4, st));
+    HIPCHK(c, launch_gz_find(d_comp, n, kGzSub, n_sub, g.d_starts, st));
+    std::vector<uint32_t> starts(n_sub);
+    HIPCHK(c, hipMemcpyAsync(starts.data(), g.d_starts, (size_t)n_sub * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     std::vector<GzSegHost> segs;
     uint32_t at = first_bit;
     segs.push_back(GzSegHost{first_bit, 0xFFFFFFFFu, 0, 0, win_avail, 0});
-    for (uint32_t j = 1; j < n_nom; ++j)
-        if (starts[j] != 0xFFFFFFFFu && starts[j] > at) {
-            segs.back().stop_bit = starts[j];
-            // (text in front of a later stretch: at least what the compressed bytes in front of it hold, a whole window almost always --
-            // an understatement only makes a legal far reference an error, i.e. hands the stretch to the host decoder)
-            segs.push_back(GzSegHost{starts[j], 0xFFFFFFFFu, 0, 0, (uint32_t)std::min<uint64_t>(32768, (uint64_t)win_avail + (starts[j] - first_bit) / 8), 0});
-            at = starts[j];
-        }
+    const uint32_t per = kGzSeg / kGzSub;
+    for (uint32_t j = 1; j < n_nom; ++j) {
+        uint32_t i = j * per;
+        const uint32_t i_end = std::min<uint64_t>(n_sub, (uint64_t)(j + 2) * per);
+        while (i < i_end && starts[i] == 0xFFFFFFFFu) ++i;
+        if (i >= i_end || starts[i] <= at) continue;
+        segs.back().stop_bit = starts[i];
+        // (text in front of a later stretch: at least what the compressed bytes in front of it hold, a whole window almost always --
+        // an understatement only makes a legal far reference an error, i.e. hands the stretch to the host decoder)
+        segs.push_back(GzSegHost{starts[i], 0xFFFFFFFFu, 0, 0, (uint32_t)std::min<uint64_t>(32768, (uint64_t)win_avail + (starts[i] - first_bit) / 8), 0});
+        at = starts[i];
+    }
     // room in the symbol pool: by the compressed bytes of the stretch
     size_t off = 0;
     for (size_t i = 0; i < segs.size(); ++i) {

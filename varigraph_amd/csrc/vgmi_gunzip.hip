@@ -30,29 +30,36 @@
 
 namespace vgk {
 
-#define GZ_WAVES 5u             // decode: wavefronts per workgroup (10.3 KB of LDS each: three workgroups = 15 wavefronts per CU)
-#define GZ_FIND_WAVES 4u        // find: no output ring, 6.2 KB each: six workgroups = 24 wavefronts per CU
+#define GZ_WAVES 5u             // decode, batches of 64 bit positions: wavefronts per workgroup (10.3 KB of LDS each: three workgroups = 15 wavefronts per CU)
+#define GZW_WAVES 4u            // decode, wide batches: 16.4 KB of LDS each, two workgroups = 8 wavefronts per CU
+#define GZ_FIND_WAVES 4u        // find: 0.6 KB of LDS each
 #define GZ_WIN 32768u
 #define GZ_NONE 0xFFFFFFFFu
 
-typedef InfTablesT<uint16_t, 8> GzFindTables;
+struct GzFindTables {            // per wavefront: the code-length code's 7-bit decoding table, its symbols in canonical order
+    uint32_t dist[128];
+    uint16_t sorted[32];
+};
+// where symbol s of the code-length alphabet stands in the header's order (RFC 1951 3.2.7: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15)
+static __device__ __constant__ uint8_t gz_clen_inv[19] = {3, 17, 15, 13, 11, 9, 7, 5, 4, 6, 8, 10, 12, 14, 16, 18, 0, 1, 2};
 
 // ---- 1. block starts ---------------------------------------------------------------------------------------------------
-// starts[j] (j >= 1) = the first bit at or behind 8 * j * seg_bytes where a dynamic block's header stands, GZ_NONE if there is none
-// in front of 8 * (j + 2) * seg_bytes (or the data's end); starts[0] is the caller's (the stream's known position).
-__global__ __launch_bounds__(64 * GZ_FIND_WAVES, 6) void gz_find_kernel(const uint8_t* __restrict__ comp, uint32_t n_bytes, uint32_t seg_bytes, uint32_t n_seg,
+// starts[i] = the first bit of sub-range i -- [8 * i * sub_bytes, 8 * (i + 1) * sub_bytes) -- where a dynamic block's header stands, GZ_NONE
+// if there is none.  Every sub-range has its own wavefront (round 4: a wavefront per 48 KiB stretch that searched up to two stretches
+// far made the kernel as slow as its unluckiest wavefront, 5.6 ms of a piece's 25); the host picks the stretches' starts from the list.
+__global__ __launch_bounds__(64 * GZ_FIND_WAVES, 6) void gz_find_kernel(const uint8_t* __restrict__ comp, uint32_t n_bytes, uint32_t sub_bytes, uint32_t n_sub,
                                                                    uint32_t* __restrict__ starts)
 {
     __shared__ GzFindTables tabs[GZ_FIND_WAVES];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_in_block = uni(threadIdx.x >> 6);
-    const uint32_t j = blockIdx.x * GZ_FIND_WAVES + wave_in_block + 1u;
-    if (j >= n_seg) return;
+    const uint32_t j = blockIdx.x * GZ_FIND_WAVES + wave_in_block;
+    if (j >= n_sub) return;
     GzFindTables& t = tabs[wave_in_block];
     const uint32_t* const in4 = reinterpret_cast<const uint32_t*>(comp);      // the batch buffer is 256-byte aligned
     const uint32_t end_bits = n_bytes * 8u;
-    const uint32_t from = j * seg_bytes * 8u;
-    uint32_t to = from + 2u * seg_bytes * 8u;
+    const uint32_t from = j * sub_bytes * 8u;
+    uint32_t to = from + sub_bytes * 8u;
     if (to > end_bits - (end_bits < 2048u ? end_bits : 2048u)) to = end_bits - (end_bits < 2048u ? end_bits : 2048u);    // a header needs room
     uint32_t found = GZ_NONE;
 
@@ -101,23 +108,68 @@ __global__ __launch_bounds__(64 * GZ_FIND_WAVES, 6) void gz_find_kernel(const ui
         take(3);
         const uint32_t hlit = take(5) + 257, hdist = take(5) + 1, hclen = take(4) + 4;
         if (hlit > 286 || hdist > 30) return false;
+        // The code-length code (19 symbols, lengths of 3 bits in the order of RFC 1951 3.2.7), built in registers: lane s holds symbol
+        // s; counts per length by ballot, a symbol's canonical code = first code of its length + its rank among the symbols of that
+        // length; every lane then fills two of the 128 entries of the 7-bit decoding table.  (The general table builder -- serial
+        // loops of one lane over LDS -- cost 60 000 clock ticks a candidate, two thirds of this kernel: gpurun_out/r4w3.)
         refill();
-        if (lane < 19) t.len[288 + lane] = 0;
+        const uint32_t f_lo = take(30);
+        refill();
+        const uint64_t F = ((uint64_t)take(27) << 30 | f_lo) & ((1ull << (3u * hclen)) - 1ull);
+        const uint32_t my_i = lane < 19 ? (uint32_t)gz_clen_inv[lane] : 63u;
+        const uint32_t my_l = my_i < 19 ? (uint32_t)(F >> (3u * my_i)) & 7u : 0u;
+        uint32_t first[8], cnt[8], off[8], my_off = 0;
+        {
+            uint32_t fc = 0, o = 0;
+#pragma unroll
+            for (uint32_t l = 1; l < 8; ++l) {
+                const uint64_t bm = __ballot(my_l == l);
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                if (my_l == l) my_off = o + below;
+                first[l] = fc;
+                cnt[l] = (uint32_t)__builtin_popcountll(bm);
+                off[l] = o;
+                o += cnt[l];
+                fc = (fc + cnt[l]) << 1;
+            }
+        }
+        if (my_l) t.sorted[my_off] = (uint16_t)lane;
         inf_sync();
-        for (uint32_t i = 0; i < hclen; ++i) {
-            if (bitcnt < 3) refill();
-            const uint32_t v = take(3);
-            if (lane == 0) t.len[288 + uni(inf_clen_order[i])] = (uint8_t)v;
+#pragma unroll
+        for (uint32_t h = 0; h < 2; ++h) {
+            const uint32_t e = lane + 64u * h;
+            uint32_t at = 0, len = 0;
+#pragma unroll
+            for (uint32_t l = 1; l < 8; ++l) {
+                const uint32_t c = __builtin_bitreverse32(e) >> (32u - l);       // the first l bits of the index as a code
+                if (c >= first[l] && c - first[l] < cnt[l]) { at = off[l] + c - first[l]; len = l; }
+            }
+            t.dist[e] = len ? (uint32_t)t.sorted[at] << 4 | len : 0u;
         }
         inf_sync();
-        if (!inf_build(t, 1, 288, 19, lane)) return false;
-        uint32_t idx = 0, prev = 0;
+        // the reader goes on behind the 3-bit lengths
+        ip = (p + 17u + 3u * hclen) >> 3;
+        reload();
+        take((p + 17u + 3u * hclen) & 7u);
+        // the hlit + hdist code lengths, with the Kraft sums of the two codes kept as they come (32768 = complete): a candidate that
+        // is no header over-subscribes one of them within a few dozen lengths and ends there (decoding all ~300 lengths of every
+        // false candidate was two thirds of this kernel)
+        uint32_t idx = 0, prev = 0, sl = 0, sd = 0, nd = 0, one = 0, eob = 0;
         bool bad = false;
-        uint8_t* const stage = reinterpret_cast<uint8_t*>(t.lit);
-        auto put = [&](uint32_t i, uint32_t v) { if (lane == 0) stage[i] = (uint8_t)v; };
+        auto put = [&](uint32_t i, uint32_t v) {
+            if (!v) return;
+            if (i < hlit) {
+                sl += 32768u >> v;
+                if (i == 256) eob = v;
+            } else {
+                sd += 32768u >> v;
+                ++nd;
+                one += v == 1;
+            }
+        };
         while (idx < hlit + hdist) {
             refill();
-            const uint32_t e = uni(t.dist[(uint32_t)bitbuf & ((1u << INF_DIST_BITS) - 1u)]);
+            const uint32_t e = uni(t.dist[(uint32_t)bitbuf & 127u]);
             const uint32_t l = e & 15u, sym = e >> 4;
             if (!l) { bad = true; break; }
             take(l);
@@ -136,30 +188,11 @@ __global__ __launch_bounds__(64 * GZ_FIND_WAVES, 6) void gz_find_kernel(const ui
                 for (uint32_t r = 0; r < rep; ++r) put(idx++, val);
                 prev = val;
             }
+            if (sl > 32768u || sd > 32768u) { bad = true; break; }
         }
         if (bad) return false;
-        inf_sync();
-        // Kraft sums of the two codes, 32768 = complete (a single distance code of one bit is what zlib tolerates)
-        uint32_t sl = 0, sd = 0, nd = 0, one = 0;
-        for (uint32_t s = lane; s < hlit + hdist; s += 64) {
-            const uint32_t l = stage[s];
-            if (!l) continue;
-            if (s < hlit) sl += 32768u >> l;
-            else {
-                sd += 32768u >> l;
-                ++nd;
-                one += l == 1;
-            }
-        }
-        for (uint32_t o = 32; o; o >>= 1) {
-            sl += (uint32_t)__shfl_xor((int)sl, (int)o, 64);
-            sd += (uint32_t)__shfl_xor((int)sd, (int)o, 64);
-            nd += (uint32_t)__shfl_xor((int)nd, (int)o, 64);
-            one += (uint32_t)__shfl_xor((int)one, (int)o, 64);
-        }
-        const uint32_t eob = uni(hlit > 256 ? stage[256] : 0u);
-        inf_sync();
-        return uni(sl) == 32768u && eob != 0 && (uni(sd) == 32768u || (uni(nd) == 1 && uni(one) == 1));
+        // three complete codes (a single distance code of one bit is what zlib tolerates), the end-of-block code among them
+        return sl == 32768u && eob != 0 && (sd == 32768u || (nd == 1 && one == 1));
     };
 
     for (uint32_t base = from; base < to && found == GZ_NONE; base += 64u) {
@@ -207,15 +240,16 @@ struct GzSegOut {
 };
 
 template <bool WIDE>
-__global__ __launch_bounds__(64 * GZ_WAVES, WIDE ? 2 : 4) void gz_decode_kernel(const uint8_t* __restrict__ comp, uint32_t n_bytes, const GzSeg* __restrict__ segs,
+__global__ __launch_bounds__(64 * (WIDE ? GZW_WAVES : GZ_WAVES), WIDE ? 2 : 4) void gz_decode_kernel(const uint8_t* __restrict__ comp, uint32_t n_bytes, const GzSeg* __restrict__ segs,
                                                                             uint32_t n_seg, uint16_t* __restrict__ pool, GzSegOut* __restrict__ outs)
 {
     typedef typename std::conditional<WIDE, InfWideT<uint16_t>, InfTablesT<uint16_t>>::type GzTables;
     constexpr uint32_t RING = WIDE ? INFW_RING : INF_RING, NEAR = WIDE ? INFW_NEAR : INF_NEAR;
-    __shared__ GzTables tabs[GZ_WAVES];
+    constexpr uint32_t WAVES = WIDE ? GZW_WAVES : GZ_WAVES;
+    __shared__ GzTables tabs[WAVES];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_in_block = uni(threadIdx.x >> 6);
-    const uint32_t sg = blockIdx.x * GZ_WAVES + wave_in_block;
+    const uint32_t sg = blockIdx.x * WAVES + wave_in_block;
     if (sg >= n_seg) return;
     GzTables& t = tabs[wave_in_block];
     const uint8_t* const in = comp;
@@ -397,6 +431,7 @@ __global__ __launch_bounds__(64 * GZ_WAVES, WIDE ? 2 : 4) void gz_decode_kernel(
         if constexpr (WIDE) {
             infw_limits(t, 0, lane);
             infw_limits(t, 1, lane);
+            infw_pack_lit2(t, lane);
         }
         inf_pack_lit(t, lane);
         inf_pack_dist(t, lane);
@@ -590,11 +625,10 @@ __global__ __launch_bounds__(256) void gz_resolve_kernel(const uint16_t* __restr
     }
 }
 
-hipError_t launch_gz_find(const uint8_t* comp, uint32_t n_bytes, uint32_t seg_bytes, uint32_t n_seg, uint32_t* starts, hipStream_t st)
+hipError_t launch_gz_find(const uint8_t* comp, uint32_t n_bytes, uint32_t sub_bytes, uint32_t n_sub, uint32_t* starts, hipStream_t st)
 {
-    if (n_seg > 1)
-        hipLaunchKernelGGL(gz_find_kernel, dim3((n_seg - 1 + GZ_FIND_WAVES - 1) / GZ_FIND_WAVES), dim3(64 * GZ_FIND_WAVES), 0, st, comp, n_bytes, seg_bytes, n_seg,
-                           starts);
+    if (n_sub)
+        hipLaunchKernelGGL(gz_find_kernel, dim3((n_sub + GZ_FIND_WAVES - 1) / GZ_FIND_WAVES), dim3(64 * GZ_FIND_WAVES), 0, st, comp, n_bytes, sub_bytes, n_sub, starts);
     return hipGetLastError();
 }
 
@@ -602,7 +636,8 @@ hipError_t launch_gz_decode(const uint8_t* comp, uint32_t n_bytes, const void* s
 {
     if (n_seg) {
         static const bool wide = !(getenv("VGMI_INFLATE_WIDE") && getenv("VGMI_INFLATE_WIDE")[0] == '0');
-        const dim3 grid((n_seg + GZ_WAVES - 1) / GZ_WAVES), block(64 * GZ_WAVES);
+        const uint32_t waves = wide ? GZW_WAVES : GZ_WAVES;
+        const dim3 grid((n_seg + waves - 1) / waves), block(64 * waves);
         if (wide) hipLaunchKernelGGL(gz_decode_kernel<true>, grid, block, 0, st, comp, n_bytes, static_cast<const GzSeg*>(segs), n_seg, pool, static_cast<GzSegOut*>(outs));
         else hipLaunchKernelGGL(gz_decode_kernel<false>, grid, block, 0, st, comp, n_bytes, static_cast<const GzSeg*>(segs), n_seg, pool, static_cast<GzSegOut*>(outs));
     }

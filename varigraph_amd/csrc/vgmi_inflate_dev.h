@@ -50,58 +50,62 @@ __device__ __forceinline__ void inf_sync()
 // Canonical Huffman tables of one alphabet from its code lengths (RFC 1951 3.2.2).  which: 0 literal/length, 1 distance.
 // Returns false for an over-subscribed set of lengths (incomplete sets are legal only in the one-code cases zlib accepts;
 // a code that is never assigned simply never matches and ends in the error path).
+// All lanes at once: lane i holds symbols i, i + 64, ...; per code length, a ballot counts the symbols and ranks each among
+// those of its length in symbol order -- its canonical code is the first code of the length + the rank.  (One lane walking the
+// symbols through LDS, as rounds 2-3 had it, took ~0.1 ms a table: a tenth of a block-gzip member's time, and most of what a
+// candidate block header cost the start search of vgmi_gunzip.hip.)
 template <class T>
 __device__ bool inf_build(T& t, uint32_t which, uint32_t first, uint32_t n, uint32_t lane)
 {
     uint32_t* const tab = which ? t.dist : t.lit;
     const uint32_t bits = which ? INF_DIST_BITS : INF_LIT_BITS;
     for (uint32_t i = lane; i < (1u << bits); i += 64) tab[i] = 0;
-    if (lane <= INF_MAXBITS) t.count[which][lane] = 0;
-    inf_sync();
-    // the counting and the canonical order are a few hundred steps: one lane
-    uint32_t ok = 1;
-    if (lane == 0) {
-        for (uint32_t s = 0; s < n; ++s) t.count[which][t.len[first + s]]++;
-        t.count[which][0] = 0;
-        int32_t left = 1;
-        uint32_t o = 0;
-        for (uint32_t l = 1; l <= INF_MAXBITS; ++l) {
-            left = (left << 1) - (int32_t)t.count[which][l];
-            if (left < 0) ok = 0;
-            t.offs[which][l] = (uint16_t)o;
-            o += t.count[which][l];
-        }
-        if (ok) {
-            uint16_t next[INF_MAXBITS + 1];
-            for (uint32_t l = 1; l <= INF_MAXBITS; ++l) next[l] = t.offs[which][l];
-            for (uint32_t s = 0; s < n; ++s) {
-                const uint32_t l = t.len[first + s];
-                if (l) t.sorted[which * 288 + next[l]++] = (uint16_t)s;
-            }
-        }
+    uint32_t myl[5], code[5], pos[5];
+#pragma unroll
+    for (uint32_t k = 0; k < 5; ++k) {
+        const uint32_t s = lane + 64u * k;
+        myl[k] = s < n ? t.len[first + s] : 0u;
+        code[k] = pos[k] = 0;
     }
-    ok = uni(ok);
+    uint32_t fc = 0, o = 0;
+    int32_t left = 1;
+    bool ok = true;
+#pragma unroll
+    for (uint32_t l = 1; l <= INF_MAXBITS; ++l) {
+        uint32_t running = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 5; ++k) {
+            if (64u * k >= n) break;
+            const uint64_t bm = __ballot(myl[k] == l);
+            if (myl[k] == l) {
+                const uint32_t r = running + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                code[k] = fc + r;
+                pos[k] = o + r;
+            }
+            running += (uint32_t)__builtin_popcountll(bm);
+        }
+        left = (left << 1) - (int32_t)running;
+        if (left < 0) ok = false;
+        if (lane == 0) {
+            t.count[which][l] = (uint16_t)running;
+            t.offs[which][l] = (uint16_t)o;
+        }
+        o += running;
+        fc = (fc + running) << 1;
+    }
+    if (lane == 0) t.count[which][0] = 0;
     inf_sync();
     if (!ok) return false;
-    // fast table: every code of at most `bits` bits, replicated over the unused high index bits -- one symbol per lane
-    // (its canonical code = first code of its length + its rank among the symbols of that length)
-    uint32_t first_code[INF_MAXBITS + 2];
-    {
-        uint32_t code = 0;
-        first_code[0] = 0;
-        for (uint32_t l = 1; l <= INF_MAXBITS; ++l) {
-            code = (code + t.count[which][l - 1]) << 1;
-            first_code[l] = code;
-        }
-    }
-    const uint32_t total = t.offs[which][INF_MAXBITS] + t.count[which][INF_MAXBITS];
-    for (uint32_t r = lane; r < total; r += 64) {       // r = rank in canonical order
-        const uint32_t s = t.sorted[which * 288 + r];
-        const uint32_t l = t.len[first + s];
+    // symbols in canonical order; the fast table: every code of at most `bits` bits, replicated over the unused high index bits
+#pragma unroll
+    for (uint32_t k = 0; k < 5; ++k) {
+        if (64u * k >= n) break;
+        const uint32_t l = myl[k], sym = lane + 64u * k;
+        if (!l) continue;
+        t.sorted[which * 288 + pos[k]] = (uint16_t)sym;
         if (l > bits) continue;
-        const uint32_t code = first_code[l] + (r - t.offs[which][l]);
-        const uint32_t e = s << 4 | l;
-        for (uint32_t i = bitrev(code, l); i < (1u << bits); i += 1u << l) tab[i] = e;
+        const uint32_t e = sym << 4 | l;
+        for (uint32_t i = bitrev(code[k], l); i < (1u << bits); i += 1u << l) tab[i] = e;
     }
     inf_sync();
     return true;
@@ -306,6 +310,8 @@ struct InfWideT {
     uint16_t sorted[320];
     uint16_t count[2][INF_MAXBITS + 1];
     uint16_t offs[2][INF_MAXBITS + 1];
+    uint8_t lit2[1u << INF_LIT_BITS];     // beside lit[]: code bits of an entry's first literal | of its first two << 4 (where the symbols
+                                          // inside a run of literals start: infw_pack_lit2)
     uint16_t lim[2][16];           // [l]: codes of l bits, left-aligned to 15 bits, are below this ([0] = 0)
     int32_t sbase[2][16];          // [l]: index into sorted[] of a code of l bits = sbase + code
     uint32_t mq[INFW_MQ];          // the batch's matches in order: (length - 3) << 15 | (distance - 1)
@@ -322,6 +328,23 @@ __device__ void infw_limits(T& t, uint32_t which, uint32_t lane)
         for (uint32_t i = 1; i <= lane; ++i) code = (code + (i > 1 ? t.count[which][i - 1] : 0u)) << 1;
         t.lim[which][lane] = lane ? (uint16_t)((code + t.count[which][lane]) << (INF_MAXBITS - lane)) : (uint16_t)0;
         t.sbase[which][lane] = (int32_t)t.offs[which][lane] - (int32_t)code;
+    }
+    inf_sync();
+}
+
+// lit2[] from the unpacked table (symbol << 4 | length): call before inf_pack_lit, whose choice of literals it repeats
+template <class T>
+__device__ void infw_pack_lit2(T& t, uint32_t lane)
+{
+    for (uint32_t i = lane; i < (1u << INF_LIT_BITS); i += 64) {
+        const uint32_t e = t.lit[i], l = e & 15u;
+        uint32_t x = 0;
+        if (l && (e >> 4) < 256) {
+            x = l;
+            const uint32_t e2 = t.lit[i >> l], l2 = e2 & 15u;
+            if (l2 && l2 <= INF_LIT_BITS - l && (e2 >> 4) < 256) x |= (l + l2) << 4;
+        }
+        t.lit2[i] = (uint8_t)x;
     }
     inf_sync();
 }
@@ -415,9 +438,6 @@ struct InfWideOut {
     uint32_t out, adv, n_match;     // output bytes, input bits, queued matches of the batch
     uint32_t eob, bad;              // it ends with the end-of-block code / in front of bits that are no code
     uint32_t last;                  // the last lane whose symbols were taken
-#ifdef VGMI_ABLATION
-    uint32_t rounds;                // (profiling builds) rounds until every lane knew its start
-#endif
 };
 
 // W0..W3: the 128 bits that start at bit (position + 64 * lane).  op: the ring position of the batch's first byte; room: output the
@@ -433,28 +453,19 @@ __device__ __forceinline__ InfWideOut inf_wide(T& t, uint32_t W0, uint32_t W1, u
     };
     // a sub-block ends with the last SYMBOL that starts inside it: a run of literals that reaches over bit 64 is taken up to there
     // only (where a lane leaves off must not depend on how its walk happened to group the literals)
-    auto lit_take = [&](uint32_t p, const InfEnt& E, uint32_t& n, uint32_t& adv) {
+    auto lit_take = [&](uint32_t p, uint32_t lo, const InfEnt& E, uint32_t& n, uint32_t& adv) {
         n = (E.e >> 6) & 3u;
         adv = E.bits;
         if (n > 1 && p + E.bits > 64u) {
-            const uint32_t l1 = t.len[(E.e >> 8) & 255u];
+            const uint32_t x = t.lit2[lo & ((1u << INF_LIT_BITS) - 1u)], l1 = x & 15u, l2 = x >> 4;
             if (p + l1 >= 64u) { n = 1; adv = l1; }
-            else if (n > 2) {
-                const uint32_t l2 = l1 + t.len[(E.e >> 16) & 255u];
-                if (p + l2 >= 64u) { n = 2; adv = l2; }
-            }
+            else if (n > 2 && p + l2 >= 64u) { n = 2; adv = l2; }
         }
     };
     // ---- the true symbol starts of every sub-block
     uint64_t mask = 0;
     uint32_t start = 0xFFFFu, endv = INFW_UNSET;
-#ifdef VGMI_ABLATION
-    uint32_t dbg_rounds = 0;
-#endif
     for (;;) {
-#ifdef VGMI_ABLATION
-        ++dbg_rounds;
-#endif
         uint32_t inc = inf_bperm(endv, (lane - 1u) & 63u);
         if (lane == 0) inc = 0;
         else if (inc == INFW_UNSET) inc = 0;                    // first round: every lane tries its bit 0
@@ -473,32 +484,45 @@ __device__ __forceinline__ InfWideOut inf_wide(T& t, uint32_t W0, uint32_t W1, u
                 uint64_t nm = 0;
                 uint32_t p = inc, ne = 0;
                 while (p < 64u && !((mask >> p) & 1ull)) {
-                    nm |= 1ull << p;
-                    uint32_t lo, hi;
-                    bits_at(p, lo, hi);
-                    const InfEnt E = inf_entry(t, lo, hi);
-                    if (E.fl & 10u) {
-                        ne = (E.fl & 2u) ? INFW_END_EOB : INFW_END_BAD;
-                        p = 1000u;
-                    } else {
-                        // the mask holds every SYMBOL start, also those inside a run of literals taken in one step: two walks over
-                        // the same symbols that group them differently must still meet
-                        uint32_t adv = E.bits;
-                        const uint32_t n = (E.e >> 6) & 3u;
-                        if (E.fl == 0 && n > 1) {
-                            const uint32_t l1 = t.len[(E.e >> 8) & 255u], s1 = p + l1;
+                    // a step of the walk needs the symbol's BITS only: two gathers side by side (entry, its literals' inner
+                    // boundaries), the distance code's behind them, selects instead of branches; the mask takes every SYMBOL
+                    // start, also those inside a run of literals taken in one step (two walks over the same symbols that group
+                    // them differently must still meet)
+                    const bool up = p >= 32u;
+                    const uint32_t lo = __builtin_amdgcn_alignbit(up ? W2 : W1, up ? W1 : W0, p);
+                    const uint32_t ix = lo & ((1u << INF_LIT_BITS) - 1u);
+                    const uint32_t e = t.lit[ix], x = t.lit2[ix];
+                    const uint32_t cb = e & 15u, kind = (e >> 4) & 3u, pd = cb + ((e >> 6) & 7u);
+                    const uint32_t de = t.dist[(lo >> pd) & ((1u << INF_DIST_BITS) - 1u)];
+                    const uint32_t dl = de & 15u;
+                    uint32_t adv, fl;             // fl: 0 goes on, 2 end of block, 8 no such code
+                    uint64_t add = 1ull << p;
+                    if (cb && (kind == 0 || kind == 2 || dl)) {
+                        const uint32_t n = (e >> 6) & 3u, l1 = x & 15u, l2 = x >> 4;
+                        const uint32_t s1 = p + l1, s2 = p + l2;
+                        adv = kind == 1 ? pd + dl + ((de >> 4) & 15u) : cb;
+                        fl = kind == 2 ? 2u : 0u;
+                        if (kind == 0 && n > 1) {
                             if (s1 >= 64u) adv = l1;
                             else {
-                                nm |= 1ull << s1;
+                                add |= 1ull << s1;
                                 if (n > 2) {
-                                    const uint32_t s2 = s1 + t.len[(E.e >> 16) & 255u];
-                                    if (s2 >= 64u) adv = s2 - p;
-                                    else nm |= 1ull << s2;
+                                    if (s2 >= 64u) adv = l2;
+                                    else add |= 1ull << s2;
                                 }
                             }
                         }
-                        p += adv;
+                    } else {
+                        const uint32_t hi = __builtin_amdgcn_alignbit(up ? W3 : W2, up ? W2 : W1, p);
+                        const InfEnt E = inf_entry(t, lo, hi);
+                        adv = E.bits;
+                        fl = E.fl & 10u;
                     }
+                    nm |= add;
+                    if (fl) {
+                        ne = (fl & 2u) ? INFW_END_EOB : INFW_END_BAD;
+                        p = 1000u;
+                    } else p += adv;
                 }
                 if (p < 64u) mask = nm | (mask & (~0ull << p));      // met the old walk: what is behind stands
                 else {
@@ -520,7 +544,7 @@ __device__ __forceinline__ InfWideOut inf_wide(T& t, uint32_t W0, uint32_t W1, u
             if (E.fl & 8u) { c_bad = 1; break; }
             if (E.fl & 2u) break;
             uint32_t n = E.ol, adv = E.bits;
-            if (E.fl == 0) lit_take(p, E, n, adv);
+            if (E.fl == 0) lit_take(p, lo, E, n, adv);
             n_out += n;
             n_m += E.fl >> 2;
             p += adv;
@@ -545,7 +569,7 @@ __device__ __forceinline__ InfWideOut inf_wide(T& t, uint32_t W0, uint32_t W1, u
             if (E.fl & 8u) { f_bad = 1; break; }
             if (E.fl & 2u) { f_eob = 1; p += E.bits; break; }
             uint32_t n = E.ol, adv = E.bits;
-            if (E.fl == 0) lit_take(p, E, n, adv);
+            if (E.fl == 0) lit_take(p, lo, E, n, adv);
             if (o + n > lim_o) break;
             const uint32_t P = op + ex_out + o;
             if (E.fl & 4u) {
@@ -572,9 +596,6 @@ __device__ __forceinline__ InfWideOut inf_wide(T& t, uint32_t W0, uint32_t W1, u
     B.eob = (uint32_t)__builtin_amdgcn_readlane((int)f_eob, (int)last);
     B.bad = (uint32_t)__builtin_amdgcn_readlane((int)f_bad, (int)last);
     B.last = last;
-#ifdef VGMI_ABLATION
-    B.rounds = dbg_rounds;
-#endif
     return B;
 }
 

@@ -158,7 +158,7 @@ struct GzSegHost {
 struct GzSegOutHost {
     uint32_t n_sym, end_bit, status, final_block;
 };
-hipError_t launch_gz_find(const uint8_t* comp, uint32_t n_bytes, uint32_t seg_bytes, uint32_t n_seg, uint32_t* starts, hipStream_t st);
+hipError_t launch_gz_find(const uint8_t* comp, uint32_t n_bytes, uint32_t sub_bytes, uint32_t n_sub, uint32_t* starts, hipStream_t st);
 hipError_t launch_gz_decode(const uint8_t* comp, uint32_t n_bytes, const void* segs, uint32_t n_seg, uint16_t* pool, void* outs, hipStream_t st);
 hipError_t launch_gz_resolve(const uint16_t* pool, const void* segs, const void* outs, const uint64_t* text_off, uint32_t n_seg, uint16_t* w1, uint8_t* t,
                              uint8_t* text, hipStream_t st);
