@@ -167,6 +167,10 @@ int vgmi_fastq_commit(vgmi_fastq *fq, size_t n_bytes);
 /* Text one block-gzip commit may inflate to (>= the staging capacity: the device side is sized to keep every wavefront
  * busy with a member, whatever the staging buffers are). */
 int vgmi_fastq_text_capacity(vgmi_fastq *fq, size_t *text_bytes);
+/* Compressed bytes the next block-gzip commit would like to see (0: no preference yet): about a whole number of rounds of the
+ * inflate kernel's wavefronts, a member each, by the member sizes of the last commit.  A commit takes whole rounds only when
+ * it is given more than one; what it leaves comes again (`taken`). */
+int vgmi_fastq_bgzf_want(vgmi_fastq *fq, size_t *comp_bytes);
 /* Block-gzip (BGZF: bgzip, htslib) input: the staging buffer holds COMPRESSED file bytes, continuing where the previous
  * commit's `taken` ended.  The host walks the member headers; every whole member whose text fits the chunk is inflated
  * on the device (one wavefront per member, CRC-32 and ISIZE checked) into the text the FASTQ kernels parse.

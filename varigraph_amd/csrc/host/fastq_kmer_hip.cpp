@@ -222,7 +222,8 @@ DeviceFileResult device_file(vgmi_ctx* ctx, const std::string& path, size_t bloc
                 if (n < cap) break;   // end of the data
             } else if (bgzf) {
                 // compressed bytes whose text fills about nine tenths of a chunk
-                size_t want = (size_t)std::min<double>((double)cap, 0.9 * (double)text_cap / ratio);
+                size_t want = (size_t)std::min<double>((double)cap, 0.9 * (double)text_cap / ratio), round_want = 0;
+                if (vgmi_fastq_bgzf_want(fq, &round_want) == VGMI_OK && round_want) want = std::min(cap, round_want);   // whole rounds of wavefronts
                 want = std::max<size_t>(want, std::min<size_t>(cap, carry.size() + (256u << 10)));
                 memcpy(buf, carry.data(), carry.size());
                 n = carry.size();

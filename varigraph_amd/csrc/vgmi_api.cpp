@@ -1621,6 +1621,8 @@ struct vgmi_fastq {
     uint32_t* d_crc = nullptr;
     BgzfVerdict* d_verdict = nullptr;
     uint32_t max_members = 0;
+    uint32_t bgzf_round = 0;            // members the inflate kernel runs at once (0: unknown)
+    double bgzf_avg_c = 0, bgzf_avg_u = 0;      // compressed / text bytes per member of the last commit
     // ordinary gzip inflated on the device (vgmi_fastq_commit_gzip): scratch of the pipeline and where the stream stands
     void* gz = nullptr;                              // GzScratch
     bool gz_in_member = false;                       // false: the next staged byte is a member header (or the data is over)
@@ -1767,6 +1769,18 @@ int vgmi_fastq_text_capacity(vgmi_fastq* f, size_t* text_bytes)
     return VGMI_OK;
 }
 
+int vgmi_fastq_bgzf_want(vgmi_fastq* f, size_t* comp_bytes)
+{
+    if (!f || !comp_bytes) return VGMI_E_INVALID;
+    *comp_bytes = 0;
+    if (!f->bgzf_round || f->bgzf_avg_c <= 0 || f->bgzf_avg_u <= 0) return VGMI_OK;
+    const double per_round = (double)f->bgzf_round * f->bgzf_avg_u;
+    const double rounds = std::floor(0.9 * (double)f->text_cap / per_round);
+    if (rounds < 1) return VGMI_OK;
+    *comp_bytes = (size_t)(0.99 * rounds * (double)f->bgzf_round * f->bgzf_avg_c);
+    return VGMI_OK;
+}
+
 int vgmi_fastq_commit(vgmi_fastq* f, size_t n_bytes)
 {
     if (!f) return VGMI_E_INVALID;
@@ -1847,6 +1861,10 @@ int vgmi_fastq_commit_bgzf(vgmi_fastq* f, size_t n_bytes, size_t* taken, size_t*
     HIPCHK(c, hipSetDevice(c->device));
     if (!f->d_members) {      // (d_comp may be there already: a stream of the pool that served an ordinary gzip file)
         f->max_members = (uint32_t)(f->text_cap / 4096) + 1024;     // bgzip members compress 64 KiB each; tiny ones are rare
+        {
+            const char* e = getenv("VGMI_BGZF_ROUNDS");
+            f->bgzf_round = e && e[0] == '0' ? 0u : bgzf_wave_slots(c->n_cu);
+        }
         // 512 KiB of zeroed slack behind the staged bytes: inside one damaged DEFLATE block the decoder can run up to
         // ~390 KB past its member before the per-block bound stops it (65 536 symbols x 48 bits); those reads must stay
         // inside the allocation (and see zeros) whatever the last member of a full batch contains
@@ -1895,6 +1913,21 @@ int vgmi_fastq_commit_bgzf(vgmi_fastq* f, size_t n_bytes, size_t* taken, size_t*
         pos += total;
     }
     if (stop < 0 && not_bgzf) *not_bgzf = 1;
+    if (n_mem) {
+        f->bgzf_avg_c = (double)pos / n_mem;
+        f->bgzf_avg_u = (double)text / n_mem;
+    }
+    // no round of wavefronts for a handful of members: the caller asks for a little less than a whole number of rounds
+    // (vgmi_fastq_bgzf_want); the few members a commit holds beyond one come again with the next bytes
+    if (f->bgzf_round && n_mem > f->bgzf_round && n_mem % f->bgzf_round && n_mem % f->bgzf_round <= f->bgzf_round / 8 && !stop) {
+        const uint32_t keep = n_mem / f->bgzf_round * f->bgzf_round;
+        for (uint32_t k = keep; k < n_mem; ++k) {
+            pos -= f->member_size.back();
+            f->member_size.pop_back();
+        }
+        n_mem = keep;
+        text = tab[keep - 1].u_off + tab[keep - 1].u_len;
+    }
     f->acquired = -1;
     *taken = pos;
     if (n_text) *n_text = text;
@@ -1974,7 +2007,7 @@ const uint32_t kGzSeg = [] {
     return ((uint32_t)(v < 32 ? 32 : v > 1024 ? 1024 : v) + 7u) / 8u * 8u << 10;      // a multiple of the search's sub-ranges
 }();
 constexpr uint32_t kGzRatio = 12;         // symbols of room per compressed byte of a stretch (FASTQ: 4-6)
-constexpr uint32_t kGzSub = 8192;         // the block-start search: compressed bytes per wavefront (each reports the first start of its sub-range)
+constexpr uint32_t kGzSub = 2048;         // the block-start search: compressed bytes per wavefront (each reports the first start of its sub-range)
 
 int gz_piece(vgmi_ctx* c, GzScratch& g, const uint8_t* d_comp, uint32_t n, uint32_t first_bit, uint32_t win_avail, uint8_t* d_text, size_t text_cap,
              hipStream_t st, uint32_t* end_bit, size_t* n_text, int* final_member, uint32_t* reason)
@@ -2005,7 +2038,7 @@ int gz_piece(vgmi_ctx* c, GzScratch& g, const uint8_t* d_comp, uint32_t n, uint3
     // one kGzSeg or more behind it come out half again as long -- DEFLATE blocks of FASTQ text are ~28 KiB apart -- and the decode
     // kernel, a single round of wavefronts, is as slow as its longest stretch: 19 against 14 ms, gpurun_out/r4w3.)
     HIPCHK(c, hipMemsetAsync(g.d_starts, 0xFF, (size_t)n_sub * 4, st));
-    HIPCHK(c, launch_gz_find(d_comp, n, kGzSub, n_sub, g.d_starts, st));
+    HIPCHK(c, launch_gz_find(d_comp, n, kGzSub, n_sub, kGzSeg / kGzSub, g.d_starts, st));
     std::vector<uint32_t> starts(n_sub);
     HIPCHK(c, hipMemcpyAsync(starts.data(), g.d_starts, (size_t)n_sub * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));

@@ -36,25 +36,33 @@ namespace vgk {
 #define GZ_WIN 32768u
 #define GZ_NONE 0xFFFFFFFFu
 
-struct GzFindTables {            // per wavefront: the code-length code's 7-bit decoding table, its symbols in canonical order
-    uint32_t dist[128];
+struct GzFindTables {            // per wavefront: the code-length code's symbols in canonical order
     uint16_t sorted[32];
+    uint16_t queue[1024];         // positions of a step that passed the bit-parallel test (a third of 2048 at most)
 };
 // where symbol s of the code-length alphabet stands in the header's order (RFC 1951 3.2.7: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15)
 static __device__ __constant__ uint8_t gz_clen_inv[19] = {3, 17, 15, 13, 11, 9, 7, 5, 4, 6, 8, 10, 12, 14, 16, 18, 0, 1, 2};
 
 // ---- 1. block starts ---------------------------------------------------------------------------------------------------
 // starts[i] = the first bit of sub-range i -- [8 * i * sub_bytes, 8 * (i + 1) * sub_bytes) -- where a dynamic block's header stands, GZ_NONE
-// if there is none.  Every sub-range has its own wavefront (round 4: a wavefront per 48 KiB stretch that searched up to two stretches
-// far made the kernel as slow as its unluckiest wavefront, 5.6 ms of a piece's 25); the host picks the stretches' starts from the list.
-__global__ __launch_bounds__(64 * GZ_FIND_WAVES, 6) void gz_find_kernel(const uint8_t* __restrict__ comp, uint32_t n_bytes, uint32_t sub_bytes, uint32_t n_sub,
-                                                                   uint32_t* __restrict__ starts)
+// if there is none (or nobody looked).  Every sub-range has its own wavefront (round 4: a wavefront per 48 KiB stretch that searched
+// up to two stretches far made the kernel as slow as its unluckiest wavefront); the host picks the stretches' starts from the list:
+// the first one in the `per` sub-ranges behind j * per sub-ranges, else in the `per` behind those.  So the kernel is launched in
+// phases: phase p looks at sub-ranges p * pw .. p * pw + pw - 1 of every group of `per`, and only where the phases before found
+// nothing.  What a wavefront spends its time on is the ~220 code lengths of every candidate header that has a complete
+// code-length code (one in ~3000 positions), walked in scalar registers at ~250 ns a length: small sub-ranges keep that chain short,
+// and half of the positions never need looking at.
+__global__ __launch_bounds__(64 * GZ_FIND_WAVES, 8) void gz_find_kernel(const uint8_t* __restrict__ comp, uint32_t n_bytes, uint32_t sub_bytes, uint32_t n_sub,
+                                                                   uint32_t per, uint32_t pw, uint32_t phase, uint32_t* __restrict__ starts)
 {
     __shared__ GzFindTables tabs[GZ_FIND_WAVES];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_in_block = uni(threadIdx.x >> 6);
-    const uint32_t j = blockIdx.x * GZ_FIND_WAVES + wave_in_block;
-    if (j >= n_sub) return;
+    const uint32_t wv = blockIdx.x * GZ_FIND_WAVES + wave_in_block;
+    const uint32_t grp = wv / pw, sub = pw * phase + wv % pw;
+    const uint32_t j = grp * per + sub;
+    if (sub >= per || j >= n_sub) return;
+    if (__ballot(lane < pw * phase && starts[grp * per + lane] != GZ_NONE)) return;      // this group has its start (pw * phase <= 64)
     GzFindTables& t = tabs[wave_in_block];
     const uint32_t* const in4 = reinterpret_cast<const uint32_t*>(comp);      // the batch buffer is 256-byte aligned
     const uint32_t end_bits = n_bytes * 8u;
@@ -135,6 +143,7 @@ __global__ __launch_bounds__(64 * GZ_FIND_WAVES, 6) void gz_find_kernel(const ui
         }
         if (my_l) t.sorted[my_off] = (uint16_t)lane;
         inf_sync();
+        uint32_t ent[2];          // the table stays in registers: entry i in lane i % 64 of ent[i / 64], looked up with v_readlane
 #pragma unroll
         for (uint32_t h = 0; h < 2; ++h) {
             const uint32_t e = lane + 64u * h;
@@ -144,7 +153,7 @@ __global__ __launch_bounds__(64 * GZ_FIND_WAVES, 6) void gz_find_kernel(const ui
                 const uint32_t c = __builtin_bitreverse32(e) >> (32u - l);       // the first l bits of the index as a code
                 if (c >= first[l] && c - first[l] < cnt[l]) { at = off[l] + c - first[l]; len = l; }
             }
-            t.dist[e] = len ? (uint32_t)t.sorted[at] << 4 | len : 0u;
+            ent[h] = len ? (uint32_t)t.sorted[at] << 4 | len : 0u;
         }
         inf_sync();
         // the reader goes on behind the 3-bit lengths
@@ -169,7 +178,8 @@ __global__ __launch_bounds__(64 * GZ_FIND_WAVES, 6) void gz_find_kernel(const ui
         };
         while (idx < hlit + hdist) {
             refill();
-            const uint32_t e = uni(t.dist[(uint32_t)bitbuf & 127u]);
+            const uint32_t i7 = (uint32_t)bitbuf & 127u;
+            const uint32_t e = (i7 & 64u) ? (uint32_t)__builtin_amdgcn_readlane((int)ent[1], (int)(i7 & 63u)) : (uint32_t)__builtin_amdgcn_readlane((int)ent[0], (int)i7);
             const uint32_t l = e & 15u, sym = e >> 4;
             if (!l) { bad = true; break; }
             take(l);
@@ -195,30 +205,50 @@ __global__ __launch_bounds__(64 * GZ_FIND_WAVES, 6) void gz_find_kernel(const ui
         return sl == 32768u && eob != 0 && (sd == 32768u || (nd == 1 && one == 1));
     };
 
-    for (uint32_t base = from; base < to && found == GZ_NONE; base += 64u) {
-        // lane i looks at bit base + i: BFINAL 0, BTYPE 10, HLIT <= 29, HDIST <= 29, then the code-length code's Kraft sum
-        const uint32_t b = base + lane;
-        const uint32_t* const w = in4 + (b >> 5);
-        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, b & 31u), mid = __builtin_amdgcn_alignbit(w2, w1, b & 31u),
-                       hi = __builtin_amdgcn_alignbit(w3, w2, b & 31u);
-        bool cand = b < to && (lo & 7u) == 4u && ((lo >> 3) & 31u) <= 29u && ((lo >> 8) & 31u) <= 29u;
-        const uint32_t hclen = ((lo >> 13) & 15u) + 4u;
-        // the 3-bit lengths start at bit 17: 57 bits at most
-        const uint64_t f = ((uint64_t)__builtin_amdgcn_alignbit(hi, mid, 17) << 32 | __builtin_amdgcn_alignbit(mid, lo, 17)) & ((1ULL << (3u * hclen)) - 1ULL);
-        uint32_t sum = 0;
+    // 2048 bit positions a step.  Lane i holds word i of the step and tests its 32 positions AT ONCE, bit-parallel: BFINAL 0 and
+    // BTYPE 10 are the stream bits (0, 0, 1) at the position; HLIT <= 29 <=> not all of bits 4..7, HDIST <= 29 <=> not all of bits
+    // 9..12 (the five-bit fields start at bits 3 and 8, least significant bit first) -- one in nine positions passes.  Those go, in
+    // order, into a queue; the Kraft sum of the code-length code (19 three-bit lengths from bit 17 on: one in ~250 is complete)
+    // is then taken by 64 queued positions at a time, and what passes that gets the whole header.  (A lane per position, Kraft sum
+    // and all, was ~150 instructions per 64 positions; the search was issue-bound at 4.3 ms a piece.)
+    for (uint32_t wbase = 0; from + 32u * wbase < to && found == GZ_NONE; wbase += 64u) {
+        const uint32_t rel = 32u * (wbase + lane);                  // this lane's first position, from `from`
+        const uint32_t* const w = in4 + ((from + rel) >> 5);
+        const uint32_t w0 = w[0], w1 = w[1];
+        auto sh = [&](uint32_t k) { return __builtin_amdgcn_alignbit(w1, w0, k); };
+        uint32_t m = ~w0 & ~sh(1) & sh(2) & ~(sh(4) & sh(5) & sh(6) & sh(7)) & ~(sh(9) & sh(10) & sh(11) & sh(12));
+        if (from + rel >= to) m = 0;
+        const uint32_t cnt = (uint32_t)__builtin_popcount(m), incl = inf_scan(cnt);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        for (uint32_t q = incl - cnt; m; ++q) {
+            t.queue[q] = (uint16_t)(rel + (uint32_t)__builtin_ctz(m));
+            m &= m - 1u;
+        }
+        inf_sync();
+        for (uint32_t g = 0; g < total && found == GZ_NONE; g += 64u) {
+            const bool have = g + lane < total;
+            const uint32_t pos = have ? (uint32_t)t.queue[g + lane] : 0u, b = from + pos;
+            const uint32_t* const v = in4 + (b >> 5);
+            const uint32_t v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+            const uint32_t lo = __builtin_amdgcn_alignbit(v1, v0, b & 31u), mid = __builtin_amdgcn_alignbit(v2, v1, b & 31u),
+                           hi = __builtin_amdgcn_alignbit(v3, v2, b & 31u);
+            const uint32_t hclen = ((lo >> 13) & 15u) + 4u;
+            // the 3-bit lengths start at bit 17: 57 bits at most
+            const uint64_t f = ((uint64_t)__builtin_amdgcn_alignbit(hi, mid, 17) << 32 | __builtin_amdgcn_alignbit(mid, lo, 17)) & ((1ULL << (3u * hclen)) - 1ULL);
+            uint32_t sum = 0;
 #pragma unroll
-        for (uint32_t c = 0; c < 19; ++c) {
-            const uint32_t l = (uint32_t)(f >> (3u * c)) & 7u;
-            sum += l ? 128u >> l : 0u;
+            for (uint32_t c = 0; c < 19; ++c) {
+                const uint32_t l = (uint32_t)(f >> (3u * c)) & 7u;
+                sum += l ? 128u >> l : 0u;
+            }
+            uint64_t mm = __ballot(have && b < to && sum == 128u);
+            while (mm && found == GZ_NONE) {
+                const uint32_t p = from + (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)__builtin_ctzll(mm));
+                mm &= mm - 1ull;
+                if (header_ok(p)) found = p;
+            }
         }
-        cand = cand && sum == 128u;
-        uint64_t m = __ballot(cand);
-        while (m && found == GZ_NONE) {
-            const uint32_t p = base + (uint32_t)__builtin_ctzll(m);
-            m &= m - 1ull;
-            if (header_ok(p)) found = p;
-        }
+        inf_sync();
     }
     if (lane == 0) starts[j] = found;
 }
@@ -625,10 +655,14 @@ __global__ __launch_bounds__(256) void gz_resolve_kernel(const uint16_t* __restr
     }
 }
 
-hipError_t launch_gz_find(const uint8_t* comp, uint32_t n_bytes, uint32_t sub_bytes, uint32_t n_sub, uint32_t* starts, hipStream_t st)
+hipError_t launch_gz_find(const uint8_t* comp, uint32_t n_bytes, uint32_t sub_bytes, uint32_t n_sub, uint32_t per, uint32_t* starts, hipStream_t st)
 {
-    if (n_sub)
-        hipLaunchKernelGGL(gz_find_kernel, dim3((n_sub + GZ_FIND_WAVES - 1) / GZ_FIND_WAVES), dim3(64 * GZ_FIND_WAVES), 0, st, comp, n_bytes, sub_bytes, n_sub, starts);
+    if (!n_sub || !per) return hipSuccess;
+    const uint32_t pw = per > 96 ? 32u : (per + 2u) / 3u;      // three phases (more for very long stretches: a phase checks <= 64 earlier sub-ranges)
+    const uint32_t n_waves = pw * ((n_sub + per - 1) / per);
+    for (uint32_t phase = 0; pw * phase < per && pw * phase <= 64u; ++phase)
+        hipLaunchKernelGGL(gz_find_kernel, dim3((n_waves + GZ_FIND_WAVES - 1) / GZ_FIND_WAVES), dim3(64 * GZ_FIND_WAVES), 0, st, comp, n_bytes, sub_bytes, n_sub, per,
+                           pw, phase, starts);
     return hipGetLastError();
 }
 

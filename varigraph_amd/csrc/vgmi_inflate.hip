@@ -457,6 +457,21 @@ __global__ void bgzf_verdict_kernel(const BgzfMember* members, const uint32_t* s
     }
 }
 
+// wavefronts of the inflate kernel the device holds at once (a member each): a commit of a whole multiple leaves no round of
+// wavefronts half empty
+uint32_t bgzf_wave_slots(int n_cu)
+{
+    static const bool wide = !(getenv("VGMI_INFLATE_WIDE") && getenv("VGMI_INFLATE_WIDE")[0] == '0');
+    int nb = 0;
+    const hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bgzf_inflate_kernel<true>, 64 * INF_WAVES, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bgzf_inflate_kernel<false>, 64 * INF_WAVES, 0);
+    if (e != hipSuccess || nb <= 0) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return (uint32_t)nb * INF_WAVES * (uint32_t)n_cu;
+}
+
 hipError_t launch_bgzf_inflate(const uint8_t* comp, const BgzfMember* members, uint32_t n_members, uint8_t* out_base, uint32_t* status,
                                const uint32_t* crc_table, BgzfVerdict* verdict, hipStream_t s)
 {

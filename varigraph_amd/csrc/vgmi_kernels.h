@@ -147,6 +147,7 @@ struct BgzfVerdict {         // device-resident, per stream
     uint32_t good_bytes;     // of the batch just inflated: text in front of the first bad member
     uint32_t batches;
 };
+uint32_t bgzf_wave_slots(int n_cu);
 hipError_t launch_bgzf_inflate(const uint8_t* comp, const BgzfMember* members, uint32_t n_members, uint8_t* out_base, uint32_t* status,
                                const uint32_t* crc_table, BgzfVerdict* verdict, hipStream_t s);
 
@@ -158,7 +159,7 @@ struct GzSegHost {
 struct GzSegOutHost {
     uint32_t n_sym, end_bit, status, final_block;
 };
-hipError_t launch_gz_find(const uint8_t* comp, uint32_t n_bytes, uint32_t sub_bytes, uint32_t n_sub, uint32_t* starts, hipStream_t st);
+hipError_t launch_gz_find(const uint8_t* comp, uint32_t n_bytes, uint32_t sub_bytes, uint32_t n_sub, uint32_t per, uint32_t* starts, hipStream_t st);
 hipError_t launch_gz_decode(const uint8_t* comp, uint32_t n_bytes, const void* segs, uint32_t n_seg, uint16_t* pool, void* outs, hipStream_t st);
 hipError_t launch_gz_resolve(const uint16_t* pool, const void* segs, const void* outs, const uint64_t* text_off, uint32_t n_seg, uint16_t* w1, uint8_t* t,
                              uint8_t* text, hipStream_t st);
