@@ -283,6 +283,46 @@ def test_bloom_saturation_and_oracle(ctx, k):
     assert (got == 255).any()
 
 
+def test_bloom_binned_form_matches_oracle(ctx):
+    """Sequences of 4 Mi bases and more go through the binned form (vgmi_bloom_bin.hip: positions partitioned by 128 KiB chunk of
+    the filter, counters bumped in LDS): random bases, a tandem repeat that drives counters to the 255 clamp, N runs; the bytes must
+    equal the oracle's (BloomFilter::add, src/counting_bloom_filter.cpp:28-36)."""
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    unit = acgt[rng.integers(0, 4, size=300)]
+    seq = np.concatenate([acgt[rng.integers(0, 4, size=2_500_000)], np.tile(unit, 400), np.frombuffer(b"NNNNN", dtype=np.uint8),
+                          acgt[rng.integers(0, 4, size=2_400_000)], np.frombuffer(b"N", dtype=np.uint8), acgt[rng.integers(0, 4, size=100_000)]])
+    assert seq.size >= 4 << 20
+    k = 27
+    m, nh = vgmi.bloom_params(seq.size - k + 1, 0.01)
+    seeds = rng.integers(1, 1 << 63, size=nh).astype(np.uint64)
+    ctx.bloom_create(m, nh, seeds)
+    ctx.bloom_add_seq(seq, k)
+    ctx.bloom_add_seq(seq[:4_500_000], k)        # a second call onto the counters of the first
+    got = ctx.bloom_fetch()
+    want = np.zeros(m, dtype=np.uint8)
+    o.bloom_add_seq(want, seeds, seq, k)
+    o.bloom_add_seq(want, seeds, seq[:4_500_000], k)
+    assert np.array_equal(got, want)
+    assert (got == 255).any()
+
+
+def test_bloom_binned_form_one_kmer_everywhere(ctx):
+    """One k-mer repeated through the whole call lands in seven chunks: their room runs out, nothing is applied, the direct form
+    redoes the call -- seven counters at 255, everything else as the random tail leaves it."""
+    rng = np.random.default_rng(12)
+    seq = np.concatenate([np.full(4_300_000, ord("A"), dtype=np.uint8), np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=50_000)]])
+    k = 27
+    m, nh = vgmi.bloom_params(seq.size - k + 1, 0.01)
+    seeds = rng.integers(1, 1 << 63, size=nh).astype(np.uint64)
+    ctx.bloom_create(m, nh, seeds)
+    ctx.bloom_add_seq(seq, k)
+    got = ctx.bloom_fetch()
+    want = np.zeros(m, dtype=np.uint8)
+    o.bloom_add_seq(want, seeds, seq, k)
+    assert np.array_equal(got, want)
+
+
 # ----------------------------------------------------------------------------- tooling
 def test_synth_device_equals_host(ctx):
     import torch

@@ -34,7 +34,7 @@ def _hipcc():
 
 
 def build_vgmi(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, f) for f in ("vgmi_kernels.hip", "vgmi_xtable.hip", "vgmi_ctable.hip", "vgmi_ptable.hip", "vgmi_fastq.hip", "vgmi_inflate.hip", "vgmi_gunzip.hip", "vgmi_hmm.hip", "vgmi_api.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("vgmi_kernels.hip", "vgmi_xtable.hip", "vgmi_ctable.hip", "vgmi_ptable.hip", "vgmi_fastq.hip", "vgmi_inflate.hip", "vgmi_gunzip.hip", "vgmi_bloom_bin.hip", "vgmi_hmm.hip", "vgmi_api.cpp")]
     # every header and source of csrc/ (vg_x80.h defines the HMM kernels' arithmetic: editing it must rebuild the library)
     deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp"))) + [
         os.path.join(ROOT, "include", "vgmi.h")]

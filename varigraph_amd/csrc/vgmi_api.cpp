@@ -129,6 +129,8 @@ struct vgmi_ctx {
 
     // bloom
     bool has_bloom = false;
+    uint8_t* bb_scratch = nullptr;       // K3, binned form: k-mer keys + the two levels of binned positions (kept between calls)
+    size_t bb_cap = 0;
     BloomView bv{};
     uint64_t bloom_seeds64[VG_BLOOM_MAX_HASH] = {0};   // as handed in (the file format keeps all 64 bits)
     size_t bloom_alloc = 0;
@@ -1042,6 +1044,9 @@ void vgmi_destroy(vgmi_ctx* c)
     for (auto& pr : c->timed) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto& e : c->event_pool) (void)hipEventDestroy(e);
     if (c->bv.filter) (void)hipFree(c->bv.filter);
+    if (c->bb_scratch) (void)hipFree(c->bb_scratch);
+    c->bb_scratch = nullptr;
+    c->bb_cap = 0;
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_hist) (void)hipFree(c->d_hist);
     if (c->reset_done) (void)hipEventDestroy(c->reset_done);
@@ -2398,6 +2403,9 @@ int vgmi_bloom_create(vgmi_ctx* c, uint64_t m, uint32_t n_hash, const uint64_t* 
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->bv.filter) (void)hipFree(c->bv.filter);
+    if (c->bb_scratch) (void)hipFree(c->bb_scratch);
+    c->bb_scratch = nullptr;
+    c->bb_cap = 0;
     c->bv = BloomView{};
     c->has_bloom = false;
     c->bloom_alloc = ((m + 3) & ~3ULL) + 16;
@@ -2424,6 +2432,28 @@ int vgmi_bloom_add_seq_device(vgmi_ctx* c, const char* dev_bases, uint64_t len, 
     if (k & 1) {
         uint32_t grid, block;
         rows_geometry(c, false, grid, block);
+        // long sequences: positions binned by 128 KiB chunk of the filter and counted in LDS (vgmi_bloom_bin.hip) -- worth it when
+        // every chunk gets a few thousand positions; VGMI_BLOOM_BINNED=0 keeps the direct form
+        static const bool binned = !(getenv("VGMI_BLOOM_BINNED") && getenv("VGMI_BLOOM_BINNED")[0] == '0');
+        const BloomBinPlan plan = binned && len >= (4u << 20) ? bloom_bin_plan(c->bv.m, c->bv.n_hash, len) : BloomBinPlan{};
+        if (plan.ok && (double)len * c->bv.n_hash >= 2048.0 * plan.n_chunks) {
+            const size_t keys_bytes = (len * 8 + 255) & ~(size_t)255, need = keys_bytes + plan.scratch_bytes;
+            if (c->bb_cap < need) {
+                if (c->bb_scratch) (void)hipFree(c->bb_scratch);
+                c->bb_scratch = nullptr;
+                c->bb_cap = 0;
+                if (hipMalloc(reinterpret_cast<void**>(&c->bb_scratch), need) == hipSuccess) c->bb_cap = need;
+                else (void)hipGetLastError();          // no room: the direct form
+            }
+            if (c->bb_cap >= need) {
+                RowParams pk = p;
+                pk.keys_out = reinterpret_cast<uint64_t*>(c->bb_scratch);
+                HIPCHK(c, launch_rows(K_MODE_KEYS, false, pk, grid, block, c->stream));
+                int overflowed = 0;
+                HIPCHK(c, launch_bloom_binned(c->bv, pk.keys_out, len, plan, c->bb_scratch + keys_bytes, c->n_cu, c->stream, &overflowed));
+                if (!overflowed) return VGMI_OK;       // (a bin out of room -- one k-mer repeated through the call: nothing applied, the direct form does it)
+            }
+        }
         HIPCHK(c, launch_rows(K_MODE_BLOOM, false, p, grid, block, c->stream));
     } else {
         // even k: the sequential state machine, one lane per 1 KiB segment with its state rebuilt by look-back

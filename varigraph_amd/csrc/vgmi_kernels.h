@@ -147,6 +147,15 @@ struct BgzfVerdict {         // device-resident, per stream
     uint32_t good_bytes;     // of the batch just inflated: text in front of the first bad member
     uint32_t batches;
 };
+// K3 with the updates binned by filter chunk (vgmi_bloom_bin.hip)
+struct BloomBinPlan {
+    int ok;                          // 0: this filter / call is not for the binned form
+    uint32_t n_chunks, n_bins, n_sub, bin_shift, cap1, cap2;
+    size_t scratch_bytes;
+};
+BloomBinPlan bloom_bin_plan(uint64_t m, uint32_t n_hash, uint64_t n_keys_max);
+hipError_t launch_bloom_binned(const BloomView& b, const uint64_t* keys, uint64_t n_keys, const BloomBinPlan& plan, uint8_t* scratch, int n_cu, hipStream_t st,
+                               int* overflowed);
 uint32_t bgzf_wave_slots(int n_cu);
 hipError_t launch_bgzf_inflate(const uint8_t* comp, const BgzfMember* members, uint32_t n_members, uint8_t* out_base, uint32_t* status,
                                const uint32_t* crc_table, BgzfVerdict* verdict, hipStream_t s);
