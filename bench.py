@@ -676,20 +676,32 @@ def main():
         mn, nz = ctx.bloom_query(qk)                     # host keys in, host answers out (PCIe-inclusive, as construct calls it)
         t_q = time.perf_counter() - t0
         n_km = G - K + 1
+        binned = os.environ.get("VGMI_BLOOM_BINNED", "1") != "0"
         tb = None
         pb = os.path.join(ROOT, "profiles", "r3_bloom_traffic.json")
-        if os.path.exists(pb):
+        if os.path.exists(pb) and not binned:
             tb = json.load(open(pb))
+        # the binned form's own traffic, by construction: the k-mer keys written and read (8 B a position), the positions written and
+        # read at both levels of the partition (4 B each), the filter read and written once
+        est = 16.0 * G + 16.0 * nh_b * n_km + 2.0 * m_b
         bloom = {"workload": f"K3: every k-mer of a {G // 1_000_000} Mb random reference (resident in HBM) into BloomFilter(n = G - k + 1, p = 0.01): "
                              f"{m_b / 1e6:.0f} MB of saturating byte counters, {nh_b} MurmurHash3 positions per k-mer; K4: 1e7 random keys queried",
                  "add_kmers_per_s": n_km / best_add, "add_seconds": best_add,
                  "filter_updates_per_s": nh_b * n_km / best_add,
+                 "form": "binned by 128 KiB filter chunk, counted in LDS (vgmi_bloom_bin.hip)" if binned else "direct compare-and-swaps (VGMI_BLOOM_BINNED=0)",
                  "roofline": {"bound": "hbm", "achieved": 15.0 * n_km / best_add / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": 15.0 * n_km / best_add / 1e9 / HBM_PEAK_GBS, "traffic": tb.get("bytes_per_launch") if tb else None,
-                              "bytes_per_kmer": 15.0, "kernel": "vgk::rows_kernel<2, false>",
-                              "note": "SURVEY 8d accounting: 1 base + 7 byte read-modify-writes per k-mer.  The kernel is bound by random "
-                                      "32-bit compare-and-swaps on a filter far larger than the caches (one 64-byte sector per "
-                                      "byte counter), not by bytes: see DESIGN.md section 6"},
+                              "traffic_by_construction": est if binned else None,
+                              "bytes_per_kmer": 15.0,
+                              "kernel": "vgk::bb_scatter1_kernel + bb_scatter2_kernel + bb_accumulate_kernel (+ rows_kernel<1, false> for the k-mers)" if binned
+                                        else "vgk::rows_kernel<2, false>",
+                              "note": ("SURVEY 8d accounting: 1 base + 7 byte read-modify-writes per k-mer, over the whole call (four kernels: "
+                                       "profiles/r4_bloom_rocprofv3_summary.txt).  The direct form is bound by the device's atomic rate (2.3e10 "
+                                       "compare-and-swaps a second of 2.7e10); the binned form moves ~10 x the accounted bytes as streams instead: "
+                                       "DESIGN.md section 4.2b") if binned else
+                                      ("SURVEY 8d accounting: 1 base + 7 byte read-modify-writes per k-mer.  The kernel is bound by random "
+                                       "32-bit compare-and-swaps on a filter far larger than the caches (one 64-byte sector per "
+                                       "byte counter), not by bytes: see DESIGN.md section 6")},
                  "query_keys_per_s_pcie_inclusive": qk.size / t_q, "query_hits": int(nz.sum())}
         del seq
         torch.cuda.empty_cache()

@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--k", type=int, default=27)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--query", type=int, default=0, help="also time K4 (BloomFilter::count / ::find) on this many random keys")
+    ap.add_argument("--piece", type=int, default=0, help="add the sequence in pieces of this many bases (chromosomes), 0 = one call")
     args = ap.parse_args()
     import torch
     from varigraph_amd import vgmi
@@ -36,12 +37,16 @@ def main():
         ctx.bloom_create(m, nh, seeds)
         torch.cuda.synchronize()
         t = time.perf_counter()
-        ctx.bloom_add_seq_device(seq, G, k)
+        if args.piece:
+            for a in range(0, G, args.piece):
+                ctx.bloom_add_seq_device(seq[a:a + args.piece], min(args.piece, G - a), k)
+        else:
+            ctx.bloom_add_seq_device(seq, G, k)
         torch.cuda.synchronize()
         res.append(time.perf_counter() - t)
     best = min(res[1:])
     n_kmers = G - k + 1
-    out = {"genome": G, "k": k, "bloom_bytes": m, "n_hash": nh, "seconds": best, "kmers_per_s": n_kmers / best,
+    out = {"genome": G, "k": k, "piece": args.piece, "bloom_bytes": m, "n_hash": nh, "seconds": best, "kmers_per_s": n_kmers / best,
            "accounting_GBps": 15.0 * n_kmers / best / 1e9, "filter_updates_per_s": nh * n_kmers / best}
     if args.query:
         qk = (np.random.default_rng(3).integers(0, 1 << (2 * k), size=args.query, dtype=np.uint64) << np.uint64(8)) | np.uint64(k)
