@@ -2008,7 +2008,8 @@ struct GzScratch {
 // compressed bytes per guessed start (VGMI_GZ_SEG_KB for A/B; >= 32 KiB of compressed bytes hold a window of text for sure)
 const uint32_t kGzSeg = [] {
     const char* e = getenv("VGMI_GZ_SEG_KB");
-    const int v = e ? atoi(e) : 48;      // measured, reads/s with four host threads: 32 KiB 5.9e7, 48 KiB 6.3e7, 64 KiB 5.1e7 (gpurun_out/r4q)
+    const int v = e ? atoi(e) : 48;      // measured, reads/s with four host threads: 32 KiB 5.9e7, 48 KiB 6.3e7, 64 KiB 5.1e7 (first form of the decoder,
+                                         // gpurun_out/r4q); wide batches: 32 KiB 7.5e7, 40 KiB 7.8e7, 48 KiB 8.4e7 (with a 2 048-entry ring, gpurun_out/r4w12)
     return ((uint32_t)(v < 32 ? 32 : v > 1024 ? 1024 : v) + 7u) / 8u * 8u << 10;      // a multiple of the search's sub-ranges
 }();
 constexpr uint32_t kGzRatio = 12;         // symbols of room per compressed byte of a stretch (FASTQ: 4-6)

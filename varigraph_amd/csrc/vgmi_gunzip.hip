@@ -273,8 +273,10 @@ template <bool WIDE>
 __global__ __launch_bounds__(64 * (WIDE ? GZW_WAVES : GZ_WAVES), WIDE ? 2 : 4) void gz_decode_kernel(const uint8_t* __restrict__ comp, uint32_t n_bytes, const GzSeg* __restrict__ segs,
                                                                             uint32_t n_seg, uint16_t* __restrict__ pool, GzSegOut* __restrict__ outs)
 {
-    typedef typename std::conditional<WIDE, InfWideT<uint16_t>, InfTablesT<uint16_t>>::type GzTables;
-    constexpr uint32_t RING = WIDE ? INFW_RING : INF_RING, NEAR = WIDE ? INFW_NEAR : INF_NEAR;
+    typedef InfWideT<uint16_t, 4096> WideTables;      // (2 048 entries and batches of 704 symbols leave LDS for twelve wavefronts a CU
+                                                       // instead of eight, and cost 17.5 against 10.5 ms a piece: gpurun_out/r4w12)
+    typedef typename std::conditional<WIDE, WideTables, InfTablesT<uint16_t>>::type GzTables;
+    constexpr uint32_t RING = WIDE ? WideTables::kRing : INF_RING, NEAR = WIDE ? WideTables::kNear : INF_NEAR;
     constexpr uint32_t WAVES = WIDE ? GZW_WAVES : GZ_WAVES;
     __shared__ GzTables tabs[WAVES];
     const uint32_t lane = threadIdx.x & 63u;
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(64 * (WIDE ? GZW_WAVES : GZ_WAVES), WIDE ? 2 : 4) v
                 const uint32_t x0 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo, 0, 0), x1 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo + 4u, 0, 0),
                                x2 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo + 8u, 0, 0), x3 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo + 12u, 0, 0),
                                x4 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo + 16u, 0, 0);
-                const uint32_t room = out_cap - op < INFW_CAP ? out_cap - op : INFW_CAP;
+                const uint32_t room = out_cap - op < WideTables::kCap ? out_cap - op : WideTables::kCap;
                 const InfWideOut B = inf_wide<GzTables, uint16_t>(t, __builtin_amdgcn_alignbit(x1, x0, sh), __builtin_amdgcn_alignbit(x2, x1, sh),
                                                                   __builtin_amdgcn_alignbit(x3, x2, sh), __builtin_amdgcn_alignbit(x4, x3, sh), op, room, nl, lane);
                 if (B.bad) { err = 2; break; }

@@ -60,8 +60,9 @@ __global__ __launch_bounds__(64 * INF_WAVES, WIDE ? 3 : 4) void bgzf_inflate_ker
                                                                                 uint32_t n_members, uint8_t* __restrict__ out_base, uint32_t* __restrict__ status,
                                                                                 const uint32_t* __restrict__ crc_table)
 {
-    typedef typename std::conditional<WIDE, InfWideT<uint8_t>, InfTables>::type Tables;
-    constexpr uint32_t RING = WIDE ? INFW_RING : INF_RING, NEAR = WIDE ? INFW_NEAR : INF_NEAR;
+    typedef InfWideT<uint8_t, 4096> WideTables;
+    typedef typename std::conditional<WIDE, WideTables, InfTables>::type Tables;
+    constexpr uint32_t RING = WIDE ? WideTables::kRing : INF_RING, NEAR = WIDE ? WideTables::kNear : INF_NEAR;
     __shared__ Tables tabs[INF_WAVES];
     __shared__ uint32_t s_crc[256];
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_crc[i] = crc_table[i];
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(64 * INF_WAVES, WIDE ? 3 : 4) void bgzf_inflate_ker
                 const uint32_t x0 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo, 0, 0), x1 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo + 4u, 0, 0),
                                x2 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo + 8u, 0, 0), x3 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo + 12u, 0, 0),
                                x4 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, wo + 16u, 0, 0);
-                const uint32_t room = out_len - op < INFW_CAP ? out_len - op : INFW_CAP;
+                const uint32_t room = out_len - op < WideTables::kCap ? out_len - op : WideTables::kCap;
                 const InfWideOut B = inf_wide<Tables, uint8_t>(t, __builtin_amdgcn_alignbit(x1, x0, sh), __builtin_amdgcn_alignbit(x2, x1, sh),
                                                                __builtin_amdgcn_alignbit(x3, x2, sh), __builtin_amdgcn_alignbit(x4, x3, sh), op, room, nl, lane);
                 if (B.bad) { err = 2; break; }

@@ -291,10 +291,8 @@ __device__ __forceinline__ InfBatch inf_batch(const T& t, uint32_t lo, uint32_t 
 // symbol starts of its 64 bits.  A second walk counts output bytes and matches per lane (prefix sums give every lane its place in
 // the ring and in the match queue), a third writes the literals and queues the matches, which the caller copies in order.
 // Codes longer than the tables' index are decoded in the lane (canonical decoding against the per-length limits: infw_limits).
-#define INFW_RING 4096u         // ring entries
-#define INFW_CAP 1536u          // output of a batch at most
-#define INFW_NEAR 2560u         // matches this far back read the ring: INFW_CAP + 513 <= INFW_NEAR <= INFW_RING - INFW_CAP (a batch's
-                                // literals, written first, never land on a near source; a far source is in global memory already)
+// ring entries RING (4096 in both decoders), output of a batch at most kCap, matches up to kNear back read the ring: kCap + 513 <= kNear <= RING - kCap (a batch's literals, written first,
+// never land on a near source; a far source is in global memory already)
 #define INFW_MQ 192u            // matches of a batch at most
 #define INFW_SHORT 16u          // matches up to this long are copied by one lane each, all at once; longer ones by the wavefront, one after the other
 #define INFW_UNSET 0x1FFu
@@ -302,8 +300,10 @@ __device__ __forceinline__ InfBatch inf_batch(const T& t, uint32_t lo, uint32_t 
 #define INFW_END_BAD 0x101u
 #define INFW_END_OFF 0x102u
 
-template <class RingT>
+template <class RingT, uint32_t RING>
 struct InfWideT {
+    static constexpr uint32_t kRing = RING, kCap = RING >= 4096u ? 1536u : 704u, kNear = RING - kCap;
+    static_assert(kCap + 513u <= kNear && (RING & (RING - 1u)) == 0, "ring too small for its batches");
     uint32_t lit[1u << INF_LIT_BITS];
     uint32_t dist[1u << INF_DIST_BITS];
     uint8_t len[320];
@@ -316,7 +316,7 @@ struct InfWideT {
     int32_t sbase[2][16];          // [l]: index into sorted[] of a code of l bits = sbase + code
     uint32_t mq[INFW_MQ];          // the batch's matches in order: (length - 3) << 15 | (distance - 1)
     uint16_t mqp[INFW_MQ];         // ... and where they go, from the batch's first byte
-    RingT ring[INFW_RING];
+    RingT ring[RING];
 };
 
 // per-length limits of the canonical code `which` (after inf_build)
@@ -441,7 +441,7 @@ struct InfWideOut {
 };
 
 // W0..W3: the 128 bits that start at bit (position + 64 * lane).  op: the ring position of the batch's first byte; room: output the
-// batch may produce (<= INFW_CAP); nl: lanes that take part (what the last batches used: the rounds are not spent on more).  Literals are in the ring and the matches in t.mq / t.mqp when it returns (behind an inf_sync).
+// batch may produce (<= T::kCap); nl: lanes that take part (what the last batches used: the rounds are not spent on more).  Literals are in the ring and the matches in t.mq / t.mqp when it returns (behind an inf_sync).
 template <class T, class RingT>
 __device__ __forceinline__ InfWideOut inf_wide(T& t, uint32_t W0, uint32_t W1, uint32_t W2, uint32_t W3, uint32_t op, uint32_t room, uint32_t nl, uint32_t lane)
 {
@@ -579,9 +579,9 @@ __device__ __forceinline__ InfWideOut inf_wide(T& t, uint32_t W0, uint32_t W1, u
                 ++m;
             } else {
                 const uint32_t e = E.e;
-                t.ring[P & (INFW_RING - 1u)] = (RingT)((e >> 8) & 255u);
-                if (n > 1) t.ring[(P + 1u) & (INFW_RING - 1u)] = (RingT)((e >> 16) & 255u);
-                if (n > 2) t.ring[(P + 2u) & (INFW_RING - 1u)] = (RingT)(e >> 24);
+                t.ring[P & (T::kRing - 1u)] = (RingT)((e >> 8) & 255u);
+                if (n > 1) t.ring[(P + 1u) & (T::kRing - 1u)] = (RingT)((e >> 16) & 255u);
+                if (n > 2) t.ring[(P + 2u) & (T::kRing - 1u)] = (RingT)(e >> 24);
             }
             o += n;
             p += adv;
@@ -611,7 +611,7 @@ __device__ __forceinline__ InfWideOut inf_wide(T& t, uint32_t W0, uint32_t W1, u
 template <class T, class RingT, bool PH>
 __device__ __forceinline__ bool infw_matches(T& t, uint32_t n_match, uint32_t op, const RingT* __restrict__ out, uint32_t back_ok, uint32_t lane)
 {
-    constexpr uint32_t M = INFW_RING - 1u;
+    constexpr uint32_t M = T::kRing - 1u;
     auto ph = [](int32_t q) -> RingT { return (RingT)(256 + 32768 + q); };
     for (uint32_t c0 = 0; c0 < n_match; c0 += 64u) {
         const uint32_t j = c0 + lane;
@@ -622,7 +622,7 @@ __device__ __forceinline__ bool infw_matches(T& t, uint32_t n_match, uint32_t op
         if (__ballot(have && dist > P + back_ok)) return false;
         const int32_t q0 = (int32_t)(P - dist);
         const int32_t src_end = dist < len ? (int32_t)P : q0 + (int32_t)len;
-        const bool far = dist > INFW_NEAR, is_long = len > INFW_SHORT;
+        const bool far = dist > T::kNear, is_long = len > INFW_SHORT;
         uint64_t pend = __ballot(have);
         if (__ballot(have && far)) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         while (pend) {
@@ -655,7 +655,7 @@ __device__ __forceinline__ bool infw_matches(T& t, uint32_t n_match, uint32_t op
                 lm &= lm - 1ull;
                 const uint32_t Pl = (uint32_t)__builtin_amdgcn_readlane((int)P, (int)ml), ll = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)ml),
                                dl = (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)ml);
-                const bool fl = dl > INFW_NEAR;
+                const bool fl = dl > T::kNear;
                 for (uint32_t i = lane; i < ll; i += 64u) {
                     const int32_t q = (int32_t)(Pl - dl + (dl >= ll ? i : i % dl));
                     RingT v;
