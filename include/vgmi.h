@@ -299,6 +299,12 @@ int vgmi_hmm_part_calls(vgmi_hmm_part *part, uint32_t ploidy, const uint8_t *kee
                         const uint8_t *restart, const void *pow, uint64_t n_steps, const void *uniform, const vgmi_hmm_chain *chains,
                         uint32_t n_chains, const uint8_t *gid, const uint8_t *order, const uint64_t *fwd_step, const uint64_t *bwd_step,
                         void *prob, uint32_t *winner);
+/* The calls' k-mer tallies (src/genotype.cpp:1387-1414, read for the CALLED haplotypes): per row with winner[i] < n_gt, genotype
+ * winner[i] = the haplotypes (hap_ab[2 g], hap_ab[2 g + 1]); out[4 i ..] = k-mers of the node haplotype a carries, the sum of
+ * their coverages, the same for b (a haplotype >= n_hap or outside sel_mask: 0, 0); unique_out[i] = k-mers of multiplicity <= 1,
+ * at most 255.  Uses the entries and the sample's coverage uploaded for the emissions. */
+int vgmi_hmm_tallies(vgmi_ctx *ctx, uint64_t n_rows, const uint64_t *entry_begin, const uint32_t *entry_count, const uint32_t *winner,
+                     uint32_t n_gt, const uint8_t *hap_ab, uint32_t n_hap, uint64_t sel_mask, uint32_t *out, uint8_t *unique_out);
 /* the part's emission rows back on the host (n_rows x n_gt long doubles): tests and diagnostics */
 int vgmi_hmm_part_fetch(vgmi_hmm_part *part, void *obs_out);
 void vgmi_hmm_part_free(vgmi_hmm_part *part);

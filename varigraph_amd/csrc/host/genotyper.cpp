@@ -1331,7 +1331,9 @@ bool Genotyper::genotype_strings(const Node& n, const std::vector<std::vector<ui
 
 // the device's verdict on the nodes of a window prepared by window(): probability of the winning genotype string and the
 // entry that makes the call, per node; the rest of the call (k-mer counts of its haplotypes) as posterior() fills it
-void Genotyper::window_finish(WindowWork& w, const long double* prob, const uint32_t* winner, const Run& r)
+// tally / uniq (optional, diploid calls): per node of the window the device's tallies (vgmi_hmm_tallies) -- (k-mers, coverage sum) of
+// the two called haplotypes and the count of single-copy k-mers -- instead of the walk over the node's k-mer list
+void Genotyper::window_finish(WindowWork& w, const long double* prob, const uint32_t* winner, const Run& r, const uint32_t* tally, const uint8_t* uniq)
 {
     const uint64_t bl = g_.bitlen;
     // posterior() tallies the SELECTED haplotypes (w.top); a called haplotype outside the selection -- the reference haplotype,
@@ -1349,7 +1351,15 @@ void Genotyper::window_finish(WindowWork& w, const long double* prob, const uint
         uint64_t num[8] = {0}, sum[8] = {0};
         const size_t nc = std::min<size_t>(called.size(), 8);
         uint8_t unique_kmers = 0;
-        if (j + 1 < w.nodes.size()) prefetch_keys(w.chr->nodes[w.nodes[j + 1]], r);
+        const bool from_device = tally && called.size() == 2;
+        if (from_device) {
+            num[0] = tally[4 * j];
+            sum[0] = tally[4 * j + 1];
+            num[1] = tally[4 * j + 2];
+            sum[1] = tally[4 * j + 3];
+            unique_kmers = uniq[j];
+        } else if (j + 1 < w.nodes.size()) prefetch_keys(w.chr->nodes[w.nodes[j + 1]], r);
+        if (!from_device)
         for (uint32_t pos : n.kmers) {
             if (r.packed) {
                 const uint64_t word = r.packed[pos];
@@ -2045,6 +2055,30 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                                      (t_emit - ta) * 1e-9, (t_a - t_emit) * 1e-9, (t_rows - t_a) * 1e-9, (t_b - t_rows) * 1e-9, (t_calls - t_b) * 1e-9);
                     for (int64_t v = dev_first.load(); ta < v && !dev_first.compare_exchange_weak(v, ta);) {}
                     for (int64_t v = dev_last.load(); tbb > v && !dev_last.compare_exchange_weak(v, tbb);) {}
+                    // the calls' k-mer tallies on the device too (the node lists and the sample's coverage are there for the emissions):
+                    // per sample, the walk over every called node's k-mer list was 0.8 of 1.7 host thread-seconds (VGH_DEVICE_TALLIES=0: the walk)
+                    std::vector<uint32_t> tally;
+                    std::vector<uint8_t> tally_uniq;
+                    static const bool device_tallies = !(getenv("VGH_DEVICE_TALLIES") && getenv("VGH_DEVICE_TALLIES")[0] == '0');
+                    if (device_tallies && n_steps && cfg.sample_ploidy == 2 && n_hap_ <= 64 && n_gt <= 128) {
+                        std::vector<uint8_t> hap_ab(2 * n_gt, 0xFF);
+                        bool pairs = true;
+                        for (size_t g2 = 0; g2 < n_gt; ++g2) {
+                            if (genotypes[g2].size() != 2 || genotypes[g2][0] > 254 || genotypes[g2][1] > 254) { pairs = false; break; }
+                            hap_ab[2 * g2] = (uint8_t)genotypes[g2][0];
+                            hap_ab[2 * g2 + 1] = (uint8_t)genotypes[g2][1];
+                        }
+                        uint64_t sel = 0;
+                        for (uint16_t hap : top)
+                            if (hap < n_hap_ && hap < 64) sel |= 1ull << hap;
+                        if (pairs) {
+                            tally.resize(4 * n_rows);
+                            tally_uniq.resize(n_rows);
+                            if (vgmi_hmm_tallies(dev_, n_rows, e_begin.data(), e_count.data(), winner.data(), (uint32_t)n_gt, hap_ab.data(), n_hap_, sel, tally.data(),
+                                                 tally_uniq.data()) != VGMI_OK)
+                                throw std::runtime_error(std::string("device tallies: ") + vgmi_last_error(dev_));
+                        }
+                    }
                     over_windows(g_phase.pass_c, [&](size_t wi) {
                         WindowWork w;
                         w.chr = tasks[t0 + wi].chr;
@@ -2054,11 +2088,18 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                         w.nodes = win_nodes[wi];
                         std::vector<long double> pr(w.nodes.size());
                         std::vector<uint32_t> wn(w.nodes.size());
+                        std::vector<uint32_t> tl(tally.empty() ? 0 : 4 * w.nodes.size());
+                        std::vector<uint8_t> tu(tally.empty() ? 0 : w.nodes.size());
                         for (size_t q = 0; q < w.nodes.size(); ++q) {
-                            pr[q] = prob[win_rows[wi][q]];
-                            wn[q] = winner[win_rows[wi][q]];
+                            const size_t rw = win_rows[wi][q];
+                            pr[q] = prob[rw];
+                            wn[q] = winner[rw];
+                            if (!tally.empty()) {
+                                std::memcpy(&tl[4 * q], &tally[4 * rw], 16);
+                                tu[q] = tally_uniq[rw];
+                            }
                         }
-                        window_finish(w, pr.data(), wn.data(), r);
+                        window_finish(w, pr.data(), wn.data(), r, tally.empty() ? nullptr : tl.data(), tally.empty() ? nullptr : tu.data());
                         make_piece(t0 + wi);
                         emit_windows_done += !w.nodes.empty();
                     });

@@ -148,7 +148,8 @@ private:
     // back from the device path: same haplotypes, same pruned k-mer lists, nothing is drawn again)
     void window(Chrom& chr, uint32_t first, uint32_t last, const Run& r, WindowWork* work = nullptr,
                 const std::vector<uint16_t>* forced_top = nullptr);
-    void window_finish(WindowWork& w, const long double* prob, const uint32_t* winner, const Run& r);
+    void window_finish(WindowWork& w, const long double* prob, const uint32_t* winner, const Run& r, const uint32_t* tally = nullptr,
+                       const uint8_t* uniq = nullptr);
     // false: more than 255 distinct genotype strings at this node (the device's ids are bytes)
     bool genotype_strings(const Node& n, const std::vector<std::vector<uint16_t>>& genotypes, uint8_t* gid, uint8_t* order) const;
     NodeStates hidden_states(Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& top,

@@ -2828,6 +2828,39 @@ int vgmi_hmm_part_calls(vgmi_hmm_part* part, uint32_t ploidy, const uint8_t* kee
                    nullptr, gid, order, fwd_step, bwd_step, prob, winner, part->d_obs);
 }
 
+int vgmi_hmm_tallies(vgmi_ctx* c, uint64_t n_rows, const uint64_t* entry_begin, const uint32_t* entry_count, const uint32_t* winner, uint32_t n_gt,
+                     const uint8_t* hap_ab, uint32_t n_hap, uint64_t sel_mask, uint32_t* out, uint8_t* unique_out)
+{
+    if (!c || (n_rows && (!entry_begin || !entry_count || !winner || !hap_ab || !out || !unique_out)) || n_gt > 128) return VGMI_E_INVALID;
+    if (!c->d_hmm_entries || !c->d_hmm_cov) return fail(c, VGMI_E_STATE, "HMM tallies: upload the entries and the sample's coverage first");
+    if (n_rows == 0) return VGMI_OK;
+    for (uint64_t i = 0; i < n_rows; ++i)
+        if (entry_begin[i] + entry_count[i] > c->hmm_n_entries) return fail(c, VGMI_E_INVALID, "HMM tallies: a row's entries lie outside the uploaded lists");
+    HIPCHK(c, hipSetDevice(c->device));
+    // one block: entry_begin | entry_count | winner | out | unique | hap_ab
+    const size_t o_cnt = n_rows * 8, o_win = o_cnt + n_rows * 4, o_out = o_win + n_rows * 4, o_uni = o_out + n_rows * 16, o_hap = (o_uni + n_rows + 255) & ~(size_t)255;
+    size_t d_bytes = 0;
+    uint8_t* d = hmm_block_take(c, o_hap + 256, d_bytes);
+    if (!d) return fail(c, VGMI_E_NOMEM, "HMM tallies: not enough device memory");
+    hipStream_t st = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemcpyAsync(d, entry_begin, n_rows * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_cnt, entry_count, n_rows * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_win, winner, n_rows * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_hap, hap_ab, 2 * (size_t)n_gt, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = launch_hmm_tally(reinterpret_cast<const unsigned long long*>(c->d_hmm_entries), c->d_hmm_cov, reinterpret_cast<const uint64_t*>(d),
+                             reinterpret_cast<const uint32_t*>(d + o_cnt), reinterpret_cast<const uint32_t*>(d + o_win), d + o_hap, n_gt, n_hap, sel_mask, n_rows,
+                             reinterpret_cast<uint32_t*>(d + o_out), d + o_uni, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d + o_out, n_rows * 16, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(unique_out, d + o_uni, n_rows, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (st) (void)hipStreamDestroy(st);
+    hmm_block_give(c, d, d_bytes);
+    HIPCHK(c, e);
+    return VGMI_OK;
+}
+
 int vgmi_hmm_part_fetch(vgmi_hmm_part* part, void* obs_out)
 {
     if (!part || !obs_out) return VGMI_E_INVALID;

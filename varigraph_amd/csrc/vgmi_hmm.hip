@@ -520,6 +520,51 @@ __global__ __launch_bounds__(128) void hmm_scatter_rows_kernel(uint8_t* obs, con
         *reinterpret_cast<uint4*>(obs + (rows[blockIdx.x] * n_gt + g) * 16) = *reinterpret_cast<const uint4*>(src + ((size_t)blockIdx.x * n_gt + g) * 16);
 }
 
+// ---- a call's k-mer tallies (src/genotype.cpp:1387-1414 as posterior() reads them for the called haplotypes) -------------------
+// Per row (node) with a called genotype g = (hap_a[g], hap_b[g]): over the node's entries, how many k-mers each called haplotype
+// carries and the sum of their coverages (the caller divides), and how many k-mers have multiplicity <= 1 (clamped at 255).  A
+// haplotype outside the panel or the selection reads as (0, 0), as on the host.  One lane per row: the entries of a node are ~50
+// consecutive words.
+__global__ __launch_bounds__(256) void hmm_tally_kernel(const unsigned long long* __restrict__ packed, const uint8_t* __restrict__ cov,
+                                                        const uint64_t* __restrict__ entry_begin, const uint32_t* __restrict__ entry_count,
+                                                        const uint32_t* __restrict__ winner, const uint8_t* __restrict__ hap_ab, uint32_t n_gt, uint32_t n_hap,
+                                                        unsigned long long sel_mask, uint64_t n_rows, uint32_t* __restrict__ out, uint8_t* __restrict__ uniq)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (r >= n_rows) return;
+    uint32_t num_a = 0, sum_a = 0, num_b = 0, sum_b = 0, u = 0;
+    const uint32_t g = winner[r];
+    if (g < n_gt) {
+        const uint32_t ha = hap_ab[2u * g], hb = hap_ab[2u * g + 1u];
+        const bool ok_a = ha < n_hap && ((sel_mask >> ha) & 1ull), ok_b = hb < n_hap && ((sel_mask >> hb) & 1ull);
+        const uint64_t e0 = entry_begin[r];
+        const uint32_t cnt = entry_count[r];
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const unsigned long long w = packed[e0 + j];
+            const uint32_t c = cov[e0 + j];
+            const unsigned long long bits = w >> 16;
+            if (((uint32_t)(w >> 8) & 0xFFu) <= 1u && u < 255u) ++u;
+            if (ok_a && ((bits >> ha) & 1ull)) { ++num_a; sum_a += c; }
+            if (ok_b && ((bits >> hb) & 1ull)) { ++num_b; sum_b += c; }
+        }
+    }
+    out[4 * r] = num_a;
+    out[4 * r + 1] = sum_a;
+    out[4 * r + 2] = num_b;
+    out[4 * r + 3] = sum_b;
+    uniq[r] = (uint8_t)u;
+}
+
+hipError_t launch_hmm_tally(const unsigned long long* packed, const uint8_t* cov, const uint64_t* entry_begin, const uint32_t* entry_count, const uint32_t* winner,
+                            const uint8_t* hap_ab, uint32_t n_gt, uint32_t n_hap, unsigned long long sel_mask, uint64_t n_rows, uint32_t* out, uint8_t* uniq,
+                            hipStream_t st)
+{
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(hmm_tally_kernel, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, st, packed, cov, entry_begin, entry_count, winner, hap_ab, n_gt, n_hap,
+                       sel_mask, n_rows, out, uniq);
+    return hipGetLastError();
+}
+
 hipError_t launch_hmm_scatter_rows(uint8_t* obs, const uint64_t* rows, const uint8_t* src, uint32_t n_gt, uint64_t n, hipStream_t st)
 {
     if (n == 0) return hipSuccess;

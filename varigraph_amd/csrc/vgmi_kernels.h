@@ -228,6 +228,9 @@ struct HmmEmitParams {
 hipError_t launch_hmm_emissions(const HmmEmitParams& P, uint64_t n_rows, hipStream_t st);
 hipError_t launch_hmm_scatter_rows(uint8_t* obs, const uint64_t* rows, const uint8_t* src, uint32_t n_gt, uint64_t n, hipStream_t st);
 size_t hmm_lds_bytes(uint32_t n_gt, uint32_t ploidy);
+hipError_t launch_hmm_tally(const unsigned long long* packed, const uint8_t* cov, const uint64_t* entry_begin, const uint32_t* entry_count, const uint32_t* winner,
+                            const uint8_t* hap_ab, uint32_t n_gt, uint32_t n_hap, unsigned long long sel_mask, uint64_t n_rows, uint32_t* out, uint8_t* uniq,
+                            hipStream_t st);
 
 hipError_t launch_xtable_build(const XTableView& t, const unsigned long long* slots8, const uint32_t* key_slot, const uint32_t* id_of_key,
                                uint64_t n_keys, uint32_t* over_list, uint32_t over_cap, unsigned long long* over_n, hipStream_t st);
