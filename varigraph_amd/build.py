@@ -44,6 +44,8 @@ def build_vgmi(force=False, verbose=False):
            "-Wno-unused-function", *srcs, "-o", LIB]
     if os.environ.get("VGMI_ABLATION") == "1":   # profiling builds only: the VGMI_DBG ablations (wrong results on purpose)
         cmd.insert(1, "-DVGMI_ABLATION")
+    for d in os.environ.get("VGMI_HIPCC_DEFS", "").split():   # A/B builds of compile-time choices (e.g. -DINFW_WHOLE=0)
+        cmd.insert(1, d)
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=ROOT)
