@@ -252,6 +252,12 @@ def test_bgzf_inflated_on_the_device(level, block, graph_ctx, tmp_path):
         assert np.array_equal(got["cov"], want["cov"]) and got["read_base"] == want["read_base"] and got["n_reads"] == want["n_reads"]
     host_inflate = _count_env(g, ctx, [str(p)], {"VGH_HOST_PARSE": "0", "VGH_HOST_INFLATE": "1"})
     assert np.array_equal(host_inflate["cov"], want["cov"])
+    # commits cut to whole "rounds" of wavefronts (a round of 3 072 members on the device; of 5 and 16 here): what a commit leaves
+    # comes again with the next bytes
+    for rnd in ("5", "16"):
+        for chunk_kb in (96, 200):
+            got = _count_env(g, ctx, [str(p)], {"VGH_HOST_PARSE": "0", "VGMI_BGZF_ROUND_MEMBERS": rnd}, chunk_kb=chunk_kb)
+            assert np.array_equal(got["cov"], want["cov"]) and got["read_base"] == want["read_base"] and got["n_reads"] == want["n_reads"]
 
 
 @pytest.mark.parametrize("damage", ["flip_in_third_member", "truncated_mid_member", "gzip_member_after_bgzf", "crc_field", "no_eof_marker",

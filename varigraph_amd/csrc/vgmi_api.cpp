@@ -1924,8 +1924,10 @@ int vgmi_fastq_commit_bgzf(vgmi_fastq* f, size_t n_bytes, size_t* taken, size_t*
     }
     // no round of wavefronts for a handful of members: the caller asks for a little less than a whole number of rounds
     // (vgmi_fastq_bgzf_want); the few members a commit holds beyond one come again with the next bytes
-    if (f->bgzf_round && n_mem > f->bgzf_round && n_mem % f->bgzf_round && n_mem % f->bgzf_round <= f->bgzf_round / 8 && !stop) {
-        const uint32_t keep = n_mem / f->bgzf_round * f->bgzf_round;
+    uint32_t round = f->bgzf_round;
+    if (const char* e = getenv("VGMI_BGZF_ROUND_MEMBERS")) round = (uint32_t)atoi(e);      // tests: a round of a few members, so that small files are cut too
+    if (round && n_mem > round && n_mem % round && n_mem % round <= (round + 7) / 8 && !stop) {
+        const uint32_t keep = n_mem / round * round;
         for (uint32_t k = keep; k < n_mem; ++k) {
             pos -= f->member_size.back();
             f->member_size.pop_back();
