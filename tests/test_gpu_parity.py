@@ -307,6 +307,40 @@ def test_bloom_binned_form_matches_oracle(ctx):
     assert (got == 255).any()
 
 
+@pytest.mark.parametrize("shape", ["many_bins", "wide_bins"])
+def test_bloom_binned_form_large_filter_geometries(ctx, shape):
+    """The binned form's two levels at the geometries of large filters: `many_bins` -- a 1 GB filter (a 1.1e8-k-mer genome's), 125
+    level-1 bins of 64 chunks, fed 12 Mb; `wide_bins` -- level-1 bins of 512 chunks (what a whole-genome filter of 28.8 GB takes),
+    forced onto a small filter.  Bytes equal the oracle's."""
+    rng = np.random.default_rng(21)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    k = 27
+    if shape == "many_bins":
+        seq = acgt[rng.integers(0, 4, size=12_000_000)]
+        m, nh = vgmi.bloom_params(110_000_000, 0.01)
+        env = {}
+    else:
+        seq = np.concatenate([acgt[rng.integers(0, 4, size=4_400_000)], np.tile(acgt[rng.integers(0, 4, size=200)], 600)])
+        m, nh = vgmi.bloom_params(seq.size - k + 1, 0.01)
+        env = {"VGMI_BLOOM_SUB": "512"}
+    seeds = rng.integers(1, 1 << 63, size=nh).astype(np.uint64)
+    old = {kk: os.environ.get(kk) for kk in env}
+    os.environ.update(env)
+    try:
+        ctx.bloom_create(m, nh, seeds)
+        ctx.bloom_add_seq(seq, k)
+        got = ctx.bloom_fetch()
+    finally:
+        for kk, v in old.items():
+            if v is None:
+                os.environ.pop(kk, None)
+            else:
+                os.environ[kk] = v
+    want = np.zeros(m, dtype=np.uint8)
+    o.bloom_add_seq(want, seeds, seq, k)
+    assert np.array_equal(got, want)
+
+
 def test_bloom_binned_form_one_kmer_everywhere(ctx):
     """One k-mer repeated through the whole call lands in seven chunks: their room runs out, nothing is applied, the direct form
     redoes the call -- seven counters at 255, everything else as the random tail leaves it."""

@@ -19,6 +19,7 @@
 // the direct way (nothing has touched the filter before the overflow flag is read).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "vgmi_device.h"
 #include "vgmi_kernels.h"
@@ -192,6 +193,7 @@ BloomBinPlan bloom_bin_plan(uint64_t m, uint32_t n_hash, uint64_t n_keys_max)
     const uint64_t n_chunks = (m_padded + (1ull << BB_CH_LOG) - 1) >> BB_CH_LOG;
     if (n_hash < 1 || n_hash > 7 || n_chunks > (uint64_t)BB_MAX_BINS * BB_MAX_BINS) return p;
     uint32_t sub = 64;
+    if (const char* e = getenv("VGMI_BLOOM_SUB")) sub = (uint32_t)atoi(e) >= 512 ? 512u : (uint32_t)atoi(e) >= 256 ? 256u : (uint32_t)atoi(e) >= 128 ? 128u : 64u;      // tests
     while ((n_chunks + sub - 1) / sub > BB_MAX_BINS) sub <<= 1;       // chunks of a level-1 bin: a power of two
     p.n_chunks = (uint32_t)n_chunks;
     p.n_sub = sub;
