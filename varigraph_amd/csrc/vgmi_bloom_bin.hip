@@ -28,9 +28,11 @@ namespace vgk {
 
 #define BB_CH_LOG 17u                   // a chunk: 128 KiB of the filter
 #define BB_MAX_BINS 512u                // bins of a level
+#ifndef BB_TILE
 #define BB_TILE 7168u                   // records a workgroup sorts at once
-#define BB_KEYS 1024u                   // level 1: keys per tile (BB_TILE / 7: n_hash <= 7)
-#define BB_PER 28u                      // BB_TILE / 256
+#endif
+#define BB_KEYS (BB_TILE / 7u)           // level 1: keys per tile (n_hash <= 7)
+#define BB_PER (BB_TILE / 256u)
 
 __device__ __forceinline__ uint64_t bb_mod(uint64_t x, uint64_t m, uint64_t magic)
 {
@@ -55,15 +57,20 @@ __device__ __forceinline__ void bb_tile_out(BbTile& s, const uint32_t (&rec)[BB_
     const uint32_t t = threadIdx.x;
     // exclusive scan of hist[0 .. n_bins): two entries a thread, then a scan of the 256 pair sums
     const uint32_t a = 2u * t < n_bins ? s.hist[2u * t] : 0u, b = 2u * t + 1u < n_bins ? s.hist[2u * t + 1u] : 0u;
-    s.scan[t] = a + b;
+    // (inclusive scan inside the wavefront by DPP, the four wavefronts' totals through LDS: two barriers instead of eighteen)
+    uint32_t incl = a + b;
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, true);      // row_shr:1
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, true);      // row_shr:2
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, true);      // row_shr:4
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, true);      // row_shr:8
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, true);      // row_bcast:15 into rows 1 and 3
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, true);      // row_bcast:31 into rows 2 and 3
+    if ((t & 63u) == 63u) s.scan[t >> 6] = incl;
     __syncthreads();
-    for (uint32_t d = 1; d < 256u; d <<= 1) {
-        const uint32_t v = t >= d ? s.scan[t - d] : 0u;
-        __syncthreads();
-        s.scan[t] += v;
-        __syncthreads();
-    }
-    const uint32_t excl = s.scan[t] - (a + b), total = s.scan[255];
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < (t >> 6); ++w) before += s.scan[w];
+    const uint32_t total = s.scan[0] + s.scan[1] + s.scan[2] + s.scan[3];
+    const uint32_t excl = before + incl - (a + b);
     if (2u * t < n_bins) s.off[2u * t] = excl;
     if (2u * t + 1u < n_bins) s.off[2u * t + 1u] = excl + a;
     // room in the bins
