@@ -15,6 +15,9 @@ done; done
 cat $OUT/ingest.jsonl
 rocprofv3 --kernel-trace --stats -d $OUT/bgzf -o r -- python3 tools/bench_bgzf_only.py 4000000 4 512 > $OUT/kt_bgzf.json 2> $OUT/kt_bgzf.log
 rocprofv3 --kernel-trace --stats -d $OUT/gzip -o r -- python3 tools/bench_gzip_only.py 4000000 4 4 > $OUT/kt_gzip.json 2> $OUT/kt_gzip.log
+# instruction mix and stalls of the two decoders (their own --pmc passes)
+rocprofv3 --kernel-include-regex "bgzf_inflate" --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/pmc_bgzf -o r -- python3 tools/bench_bgzf_only.py 4000000 4 512 > /dev/null 2> $OUT/pmc_bgzf.log
+rocprofv3 --kernel-include-regex "gz_decode" --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/pmc_gzip -o r -- python3 tools/bench_gzip_only.py 4000000 4 4 > /dev/null 2> $OUT/pmc_gzip.log
 python3 tools/rocprof_summary.py $OUT > $OUT/summary.txt 2>&1
 find $OUT -name "*.db" -delete
-grep -i "inflate\|gz_" $OUT/summary.txt | cut -c1-130 | head -10
+grep -i "inflate\|gz_" $OUT/summary.txt | cut -c1-130 | head -30
