@@ -14,7 +14,7 @@ def main():
     work = tempfile.mkdtemp(prefix="vg_bgzf_")
     try:
         block = vgmi.synth_reads_host(1000, 0, n_reads, 150, haps)
-        plain = synth.write_fastq_pair_fast(os.path.join(work, "s"), block, n_reads, 150)
+        plain = synth.write_fastq_pair_fast(os.path.join(work, "s"), block, n_reads, 150, qual=os.environ.get("VG_BENCH_QUAL", "const"))
         bgz = [synth.bgzf_compress_file(p, p + ".bgz.gz", level=level) for p in plain]
         g = host.Graph(os.path.join(ROOT, "tests", "golden", "c1", "graph.bin.gz"))
         os.environ["VGH_HOST_PARSE"] = "0"

@@ -15,7 +15,7 @@ def main():
     work = tempfile.mkdtemp(prefix="vg_gz_")
     try:
         block = vgmi.synth_reads_host(1000, 0, n_reads, 150, haps)
-        plain = synth.write_fastq_pair_fast(os.path.join(work, "s"), block, n_reads, 150)
+        plain = synth.write_fastq_pair_fast(os.path.join(work, "s"), block, n_reads, 150, qual=os.environ.get("VG_BENCH_QUAL", "const"))
         gz = []
         for p in plain:
             with open(p, "rb") as fi, gzip.open(p + ".gz", "wb", compresslevel=level) as fo:

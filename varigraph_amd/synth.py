@@ -113,9 +113,11 @@ def write_fastq_pair(prefix, block, n_reads, read_len, gz=False):
     return paths
 
 
-def write_fastq_pair_fast(prefix, block, n_reads, read_len):
+def write_fastq_pair_fast(prefix, block, n_reads, read_len, qual="const"):
     """Same files as write_fastq_pair (plain), assembled as one byte matrix per mate instead of a Python loop: record =
-    '@r<9 digits>/<mate>' '\n' sequence '\n' '+' '\n' quality '\n' (fixed-width read numbers)."""
+    '@r<9 digits>/<mate>' '\n' sequence '\n' '+' '\n' quality '\n' (fixed-width read numbers).  qual: "const" ('I' throughout,
+    what the parity tests and the bench use) or "binned" (four quality values drawn 80 / 10 / 7 / 3 %, as a binned
+    instrument writes them: the DEFLATE stream of such a file is what a real .fastq.gz looks like to the inflate kernels)."""
     rec = block.reshape(n_reads, read_len + 1)[:, :read_len]
     paths = []
     for mate in (0, 1):
@@ -136,7 +138,11 @@ def write_fastq_pair_fast(prefix, block, n_reads, read_len):
         m[:, o] = 10
         m[:, o + 1] = ord("+")
         m[:, o + 2] = 10
-        m[:, o + 3:o + 3 + read_len] = ord("I")
+        if qual == "binned":
+            rng = np.random.default_rng(1234 + mate)
+            m[:, o + 3:o + 3 + read_len] = np.frombuffer(b"F:,#", dtype=np.uint8)[rng.choice(4, size=(n, read_len), p=[0.8, 0.1, 0.07, 0.03])]
+        else:
+            m[:, o + 3:o + 3 + read_len] = ord("I")
         m[:, o + 3 + read_len] = 10
         path = f"{prefix}_{mate + 1}.fq"
         m.tofile(path)
