@@ -12,4 +12,3 @@ d=json.loads(open('gpurun_out/r4p/bench_n1.json').read().strip().splitlines()[-1
 print('C2', d['roofline']['frac'], 'c3', d['c3']['roofline']['frac'], 'c5', d['c5']['roofline']['frac'], 'bloom', d['bloom']['add_kmers_per_s'])
 print({k:v for k,v in d['sample_level'].items() if 'reads_per_s' in k})
 "
-bash tools/profile_r4_ingest.sh

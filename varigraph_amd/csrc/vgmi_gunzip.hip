@@ -195,7 +195,15 @@ __global__ __launch_bounds__(64 * GZ_FIND_WAVES, 8) void gz_find_kernel(const ui
                 } else if (sym == 17) rep = 3 + take(3);
                 else rep = 11 + take(7);
                 if (idx + rep > hlit + hdist) { bad = true; break; }
-                for (uint32_t r = 0; r < rep; ++r) put(idx++, val);
+                if (val) {      // a run of equal lengths, taken whole: what falls in front of hlit is literal/length code, the rest distance code
+                    const uint32_t n_lit = idx < hlit ? (rep < hlit - idx ? rep : hlit - idx) : 0u, n_dist = rep - n_lit, c = 32768u >> val;
+                    sl += n_lit * c;
+                    sd += n_dist * c;
+                    nd += n_dist;
+                    if (val == 1) one += n_dist;
+                    if (idx <= 256u && 256u < idx + n_lit) eob = val;
+                }
+                idx += rep;
                 prev = val;
             }
             if (sl > 32768u || sd > 32768u) { bad = true; break; }
