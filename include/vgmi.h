@@ -80,6 +80,19 @@ int vgmi_table_clone(vgmi_ctx *dst, vgmi_ctx *src);
  * table, the others' adopt what arrives.  world = 1 is legal (a communicator of one).  No reference counterpart (single device). */
 int vgmi_rccl_unique_id(void *id128);
 int vgmi_table_broadcast(vgmi_ctx *ctx, int rank, int world, const void *id128);
+/* The same in two steps, so that the communicator -- seconds of ncclCommInitRank, which needs neither a context nor a table -- comes
+ * up BESIDE a rank's graph load and table build (its own thread), not behind them: vgmi_comm_create on `device` (every rank, any
+ * time after the id exists), then vgmi_table_broadcast_comm with the rank's context on that device (root = rank 0), then
+ * vgmi_comm_destroy.  A rank that cannot take part (the root without a table, a receiver without room for the image) tells the
+ * others inside the collectives: every rank returns an error, none waits.  vgmi_table_broadcast is the three calls in one. */
+typedef struct vgmi_comm vgmi_comm;
+int vgmi_comm_create(int device, int rank, int world, const void *id128, vgmi_comm **out);
+int vgmi_table_broadcast_comm(vgmi_ctx *ctx, vgmi_comm *comm);
+/* The root may take a snapshot of its image first (a device-to-device copy; no sample counted yet): the broadcast then sends the
+ * snapshot and frees it, on a stream of its own -- so the root starts counting (which sets per-sample bits inside the live image)
+ * without waiting for the communicator, and the broadcast leaves from a thread of the caller's whenever the communicator is up. */
+int vgmi_table_snapshot(vgmi_ctx *ctx);
+void vgmi_comm_destroy(vgmi_comm *comm);
 int vgmi_table_info(vgmi_ctx *ctx, size_t *n_keys, uint32_t *k, size_t *n_slots, size_t *filter_bits);
 /* Batched exact lookup, the table's `find`: index_out[i] = the index keys[i] has in the uploaded key array, 0xFFFFFFFF when
  * the table does not hold it.  Replaces the per-node loop of Varigraph graph2node (src/construct_index.cpp:710-751:

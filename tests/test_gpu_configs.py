@@ -131,12 +131,12 @@ def _reference_genotype(d, graph, samples_cfg_text, extra, threads=16, timeout=9
         return time.perf_counter() - t0
 
 
-def _native_genotype(d, graph, samples_cfg_text, extra, threads=16, timeout=600):
+def _native_genotype(d, graph, samples_cfg_text, extra, threads=16, timeout=600, env=None):
     os.makedirs(d, exist_ok=True)
     open(os.path.join(d, "samples.cfg"), "w").write(samples_cfg_text)
     t0 = time.perf_counter()
     r = subprocess.run([CLI, "genotype", "--load-graph", graph, "-s", "samples.cfg", "-t", str(threads)] + extra, cwd=d,
-                       capture_output=True, text=True, env=ENV, timeout=timeout)
+                       capture_output=True, text=True, env=dict(ENV, **(env or {})), timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     return time.perf_counter() - t0, r.stderr
 
@@ -662,12 +662,31 @@ def test_c4_eight_samples_over_the_gpus_present_equal_single_sample_reference_ru
         assert len({_vcf(os.path.join(work, "native"), f"sample{s}") for s in range(8)}) >= 3     # the samples do differ
         # one PROCESS per device (--procs): the ranks take the samples round robin.  Every device present through one RCCL
         # broadcast of the table image (a single device: a communicator of one); a device named twice: every rank builds its own
-        for tag, gl in (("procs_rccl", ",".join(str(d) for d in range(n_dev))), ("procs_twice", "0,0")):
-            t_p, log_p = _native_genotype(os.path.join(work, tag), graph, "".join(cfg_lines), ["--gpus", gl, "--procs"])
-            assert ("RCCL broadcast" in log_p) == (tag == "procs_rccl"), log_p[-1500:]
+        def mem(log):      # (peak RSS, PSS at exit) in GB, summed over the processes that report
+            rows = [ln for ln in log.split("\n") if "host memory: peak RSS" in ln]
+            return (sum(float(ln.split("peak RSS ")[1].split(" GB")[0]) for ln in rows), sum(float(ln.split("PSS at exit ")[1].split(" GB")[0]) for ln in rows), len(rows))
+        t_one, log_one = _native_genotype(os.path.join(work, "one"), graph, "".join(cfg_lines), ["--gpu", "0"])
+        rss_one, pss_one, _ = mem(log_one)
+        # one PROCESS per device (--procs): graph.bin is parsed once, before the fork; the ranks take the samples round robin.  Every
+        # device present through one RCCL broadcast of the table image (a single device: no communicator -- and, forced, the
+        # communicator of one); a device named twice: every rank builds its own
+        all_dev = ",".join(str(d) for d in range(n_dev))
+        for tag, gl, env in (("procs", all_dev, {}), ("procs_rccl", all_dev, {"VGH_PROCS_RCCL": "1"}), ("procs_twice", "0,0", {})):
+            t_p, log_p = _native_genotype(os.path.join(work, tag), graph, "".join(cfg_lines), ["--gpus", gl, "--procs"], env=env)
+            assert ("RCCL broadcast" in log_p) == (tag == "procs_rccl" or (tag == "procs" and n_dev > 1)), log_p[-1500:]
+            assert log_p.count("graph parsed once for") == 1 and "file read" not in log_p       # graph.bin read by the parent only
             for s in range(8):
                 assert _vcf(os.path.join(work, tag), f"sample{s}") == _vcf(os.path.join(work, "native"), f"sample{s}"), (tag, s)
-            print(f"C4 --procs --gpus {gl}: {t_p:.1f} s")
+            rss_p, pss_p, n_rows = mem(log_p)
+            assert n_rows == len(gl.split(","))
+            comm = [ln.split("communicator ")[1].split(" s")[0] for ln in log_p.split("\n") if "communicator " in ln]
+            # the ranks share the parsed graph copy-on-write: their proportional set sizes together stay near one process's
+            print(f"C4 --procs --gpus {gl} {env}: {t_p:.1f} s (one process, one device: {t_one:.1f} s); host memory of {n_rows} ranks: PSS {pss_p:.2f} GB, "
+                  f"peak RSS summed {rss_p:.2f} GB; one process PSS {pss_one:.2f} GB, peak RSS {rss_one:.2f} GB; ncclCommInitRank {comm} s")
+            if tag != "procs_rccl":      # (RCCL's own host buffers are gigabytes per rank)
+                assert pss_p <= 1.3 * pss_one + 0.7 * (n_rows - 1), (tag, pss_p, pss_one)      # (+ a HIP runtime's private pages per further rank)
+            if tag == "procs" and n_dev == 1:
+                assert t_p <= t_one + 1.0, (t_p, t_one)      # the review's gate (0.5 s at chr20 scale) is measured in the bench's c4 block
         print(f"C4: 8 samples over --gpus {gpus}: varigraph-mi {t_nat:.1f} s, 8 reference runs {t_ref:.0f} s")
     finally:
         shutil.rmtree(work, ignore_errors=True)

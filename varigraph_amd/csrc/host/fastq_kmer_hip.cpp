@@ -6,6 +6,8 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <cerrno>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -14,6 +16,7 @@
 #include <stdexcept>
 #include <thread>
 
+#include "fast_inflate.hpp"
 #include "fastx_reader.hpp"
 #include "vgmi.h"
 
@@ -141,6 +144,28 @@ size_t fill_plain(int fd, uint64_t offset, uint64_t file_size, char* buf, size_t
     return want;
 }
 
+// What the host decoder (fast_inflate.cpp: gzread's semantics) makes of the whole file: how it ends and how much text it yields
+GunzipEnd host_gunzip_verdict(const std::string& path, uint64_t& n_text)
+{
+    n_text = 0;
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return GunzipEnd::Truncated;
+    std::vector<unsigned char> out((size_t)32768 + ((size_t)4 << 20) + 512);      // window in front, slack behind (as byte_source.cpp's chunks)
+    GunzipIO io;
+    io.read = [&](unsigned char* dst, size_t n) -> size_t {
+        for (;;) {
+            const ssize_t r = ::read(fd, dst, n);
+            if (r < 0 && errno == EINTR) continue;
+            return r < 0 ? 0 : (size_t)r;
+        }
+    };
+    io.next_buffer = [&](size_t, size_t) { return out.data() + 32768; };
+    io.commit = [&](size_t n) { n_text += n; };
+    const GunzipEnd end = fast_gunzip(io, (size_t)4 << 20);
+    ::close(fd);
+    return end;
+}
+
 struct DeviceFileResult {
     uint64_t n_reads = 0, read_base = 0;
 };
@@ -255,6 +280,23 @@ DeviceFileResult device_file(vgmi_ctx* ctx, const std::string& path, size_t bloc
                 if (vgmi_fastq_commit_gzip(fq, n, at_eof ? 1 : 0, &taken, &n_text, &stop) != VGMI_OK) throw std::runtime_error(vgmi_last_error(ctx));
                 carry.assign(buf + taken, buf + n);
                 if (taken && n_text) ratio = std::max(1.0, (double)n_text / (double)taken);
+                if (stop == 2) {
+                    // reason 11: a member's text as the device resolved it fails the trailer's CRC-32 / ISIZE.  zlib delivers such a
+                    // member's text all the same and reports the damage at its end, which include/kseq.h:112 reads as the end of the
+                    // data -- what has happened here too, PROVIDED the fault is the file's: the host decoder says whether it is
+                    uint32_t why = 0;
+                    uint64_t dev_text = 0;
+                    if (vgmi_fastq_gzip_status(fq, &dev_text, &why) == VGMI_OK && why == 11) {
+                        uint64_t host_text = 0;
+                        const GunzipEnd end = host_gunzip_verdict(path, host_text);
+                        if (end != GunzipEnd::Corrupt || host_text != dev_text)
+                            throw std::runtime_error("'" + path + "': the device's gzip decoder produced text that fails the member's CRC-32 / length while the "
+                                                     "host decoder disagrees (internal error; VGH_DEVICE_GUNZIP=0 decodes on the host)");
+                        std::fprintf(stderr, "[varigraph-mi] warning: '%s': gzip stream is damaged (CRC-32 or length); only what decoded cleanly is used\n",
+                                     path.c_str());
+                        break;
+                    }
+                }
                 if (stop == 2 || (taken == 0 && (at_eof || want >= cap))) { gz_gave_up = true; break; }
                 if (stop == 1 || (at_eof && carry.empty())) break;
             } else {

@@ -5,6 +5,7 @@
 #include <getopt.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -14,10 +15,12 @@
 #include <thread>
 #include <set>
 #include <unistd.h>
+#include <signal.h>
 #include <sys/wait.h>
 #include <sys/mman.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <filesystem>
 #include <iostream>
 #include <sstream>
@@ -211,18 +214,35 @@ int main_genotype(int argc, char** argv)
     auto secs = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
 
     auto samples = parse_samples(o.samples);   // exits on a bad list before anything touches the device
-    // --procs: the ranks are forked HERE, before anything touches a device (a process that has initialised the GPU must not
-    // fork).  Rank r takes device gpus[r], the samples r, r + n, ... of the list (independent units, src/varigraph.cpp:153-172)
-    // and its share of -t; rank 0 builds the table, every rank receives it in ONE ncclBroadcast (vgmi_table_broadcast) -- unless
-    // the list names a device twice (RCCL takes one rank per device): then every rank builds its own.
+    vgh::GraphIndex g;
+    // --procs: graph.bin is parsed ONCE, here, by the parent and before anything touches a device (a process that has initialised
+    // the GPU must not fork): the ranks share the parsed graph copy-on-write -- one copy of its 25 GB at whole-genome scale, not
+    // one per rank -- and none of them reads the file again.  The node lists are resolved against the host's own key index (the
+    // device's batched lookup serves the one-process run, below).  Then the ranks are forked.  Rank r takes device gpus[r], the
+    // samples r, r + n, ... of the list (independent units, src/varigraph.cpp:153-172) and its share of -t; rank 0 builds the
+    // table, every rank receives it in ONE ncclBroadcast -- unless the list names a device twice (RCCL takes one rank per
+    // device): then every rank builds its own.  The communicator (seconds of ncclCommInitRank) comes up beside rank 0's table
+    // build: rank 0 makes the RCCL id as the first thing it does, every rank starts ncclCommInitRank as soon as it sees it.
     int proc_rank = -1, proc_world = 0;
     bool proc_bcast = false;
+    bool graph_loaded = false;
     if (o.procs) {
         const size_t n = o.gpus.size();
         g_shared = static_cast<ProcShared*>(mmap(nullptr, 4096, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0));
         if (g_shared == MAP_FAILED) { g_shared = nullptr; die("--procs: cannot map the shared page"); }
         new (g_shared) ProcShared{};
-        proc_bcast = std::set<int>(o.gpus.begin(), o.gpus.end()).size() == n;
+        // (one rank has nobody to send to: no communicator, unless VGH_PROCS_RCCL=1 asks for the communicator of one -- the test of the path on a single device)
+        const bool rccl_of_one = [] { const char* e = getenv("VGH_PROCS_RCCL"); return e && e[0] == '1'; }();
+        proc_bcast = std::set<int>(o.gpus.begin(), o.gpus.end()).size() == n && (n > 1 || rccl_of_one);
+        try {
+            g.threads = std::max(1u, o.hmm.threads);
+            g.load(o.graph);
+            if (samples.size() > n) g.build_entry_words();      // ranks with several samples run several Genotypers: their shared half, shared by all
+        } catch (const std::exception& e) {
+            die(e.what());
+        }
+        graph_loaded = true;
+        std::cerr << "[varigraph-mi] graph parsed once for " << n << " ranks: " << g.keys.size() << " k-mers (" << secs() << " s)" << std::endl;
         std::fflush(nullptr);
         std::vector<pid_t> kids;
         for (size_t r = 0; r < n && proc_rank < 0; ++r) {
@@ -231,12 +251,24 @@ int main_genotype(int argc, char** argv)
             if (pid == 0) proc_rank = (int)r;
             else kids.push_back(pid);
         }
-        if (proc_rank < 0) {          // the parent only waits
+        if (proc_rank < 0) {          // the parent only waits -- and ends the others when one rank gives up (they may be inside a collective)
             int worst = 0;
-            for (pid_t k : kids) {
+            size_t left = kids.size();
+            while (left) {
                 int st = 0;
-                while (waitpid(k, &st, 0) < 0 && errno == EINTR) {}
+                const pid_t k = waitpid(-1, &st, 0);
+                if (k < 0) {
+                    if (errno == EINTR) continue;
+                    break;
+                }
+                if (std::find(kids.begin(), kids.end(), k) == kids.end()) continue;
+                --left;
                 const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 1;
+                if (rc != 0 && worst == 0) {
+                    g_shared->failed = 1;
+                    for (pid_t other : kids)
+                        if (other != k) (void)kill(other, SIGTERM);
+                }
                 worst = std::max(worst, rc);
             }
             std::_Exit(worst);
@@ -247,9 +279,10 @@ int main_genotype(int argc, char** argv)
         samples.swap(mine);
         o.gpus = {o.gpus[(size_t)proc_rank]};
         o.hmm.threads = std::max<uint32_t>(1, o.hmm.threads / (uint32_t)n);
+        g.threads = o.hmm.threads;
         std::cerr << "[varigraph-mi] rank " << proc_rank << " of " << proc_world << ": device " << o.gpus[0] << ", " << samples.size()
-                  << " samples, " << o.hmm.threads << " threads" << (proc_bcast ? "" : " (a device is named twice: every rank builds its table)")
-                  << std::endl;
+                  << " samples, " << o.hmm.threads << " threads"
+                  << (proc_bcast ? "" : proc_world == 1 ? " (one rank: no broadcast)" : " (a device is named twice: every rank builds its table)") << std::endl;
     }
     std::cerr << "[varigraph-mi] samples: " << samples.size() << ", graph: " << o.graph << ", devices: " << o.gpus.size() << std::endl;
     // the device contexts come up (HIP runtime start, staging buffers) while the graph is read
@@ -257,29 +290,30 @@ int main_genotype(int argc, char** argv)
     std::string ctx_error;
     // ... and the first device builds its table as soon as the k-mer records are read, while the host still resolves the
     // node lists (graph2node)
-    vgh::GraphIndex g;
     std::mutex keys_mu;
     std::condition_variable keys_cv;
-    int keys_state = 0;   // 1: keys complete, -1: the load failed before that
+    int keys_state = graph_loaded ? 1 : 0;   // 1: keys complete, -1: the load failed before that
     int table_state = 0;  // 1: the first device holds the table, -1: it never will
-    g.on_keys = [&] {
-        {
-            std::lock_guard<std::mutex> lk(keys_mu);
-            keys_state = 1;
-        }
-        keys_cv.notify_all();
-    };
-    // graph2node's lookups (every k-mer of every variant node against the key set) go to that table as one batch
-    g.batched_find = [&](const uint64_t* keys, size_t n, uint32_t* index_out) {
-        if (const char* e = getenv("VGH_DEVICE_GRAPH2NODE"))
-            if (e[0] == '0') return false;
-        {
-            std::unique_lock<std::mutex> lk(keys_mu);
-            keys_cv.wait(lk, [&] { return table_state != 0; });
-            if (table_state < 0) return false;
-        }
-        return vgmi_table_lookup(ctxs[0], keys, n, index_out) == VGMI_OK;
-    };
+    if (!graph_loaded) {
+        g.on_keys = [&] {
+            {
+                std::lock_guard<std::mutex> lk(keys_mu);
+                keys_state = 1;
+            }
+            keys_cv.notify_all();
+        };
+        // graph2node's lookups (every k-mer of every variant node against the key set) go to that table as one batch
+        g.batched_find = [&](const uint64_t* keys, size_t n, uint32_t* index_out) {
+            if (const char* e = getenv("VGH_DEVICE_GRAPH2NODE"))
+                if (e[0] == '0') return false;
+            {
+                std::unique_lock<std::mutex> lk(keys_mu);
+                keys_cv.wait(lk, [&] { return table_state != 0; });
+                if (table_state < 0) return false;
+            }
+            return vgmi_table_lookup(ctxs[0], keys, n, index_out) == VGMI_OK;
+        };
+    }
     // The buffers of a sample's two FASTQ streams (1.5 GB of pinned staging and device text at the default --buffer) are allocated
     // while the graph still loads, not inside the first sample's counting (0.3 s for 12 M pairs, 0.15 s of it allocation): a stream
     // that is closed leaves its buffers in the context's pool
@@ -294,6 +328,26 @@ int main_genotype(int argc, char** argv)
         for (size_t i = 0; i < n_streams; ++i)
             if (fq[i]) (void)vgmi_fastq_close(fq[i], nullptr, nullptr, nullptr, nullptr, tail, sizeof tail, &tail_len);
     };
+    // --procs: the communicator, on a thread of its own from the moment the id is there
+    vgmi_comm* comm = nullptr;
+    std::string comm_error;
+    double comm_seconds = 0;
+    std::thread comm_up, bcast_thr;
+    if (proc_bcast) {
+        if (proc_rank == 0) {
+            if (vgmi_rccl_unique_id(g_shared->nccl_id) != VGMI_OK) die(vgmi_last_error(nullptr));
+            g_shared->id_ready = 1;
+        }
+        comm_up = std::thread([&] {
+            while (!g_shared->id_ready.load()) {
+                if (g_shared->failed.load() || getppid() == 1) { comm_error = "--procs: another rank gave up"; return; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            }
+            const auto t_c = std::chrono::steady_clock::now();
+            if (vgmi_comm_create(o.gpus[0], proc_rank, proc_world, g_shared->nccl_id, &comm) != VGMI_OK) comm_error = vgmi_last_error(nullptr);
+            comm_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c).count();
+        });
+    }
     std::thread bring_up([&] {
         struct TableFlag {      // whatever way this thread ends, a waiting graph2node hears of it
             std::mutex& mu; std::condition_variable& cv; int& state;
@@ -307,25 +361,26 @@ int main_genotype(int argc, char** argv)
             }
             ctxs.push_back(ctx);
         }
-        if (proc_bcast && proc_rank > 0) {
-            // the table arrives from rank 0 (no key upload, no build here): wait for its RCCL id, join the broadcast
-            const auto t_wait = std::chrono::steady_clock::now();
-            while (!g_shared->id_ready.load()) {
-                if (g_shared->failed.load() || getppid() == 1) { ctx_error = "--procs: another rank gave up"; return; }
-                std::this_thread::sleep_for(std::chrono::milliseconds(2));
-            }
-            if (vgmi_table_broadcast(ctxs[0], proc_rank, proc_world, g_shared->nccl_id) != VGMI_OK) {
-                ctx_error = vgmi_last_error(ctxs[0]);
-                return;
-            }
-            std::fprintf(stderr, "[varigraph-mi] rank %d: table image received by RCCL broadcast (%.3f s after its id)\n", proc_rank,
-                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count());
+        auto table_there = [&] {
             {
                 std::lock_guard<std::mutex> lk2(keys_mu);
                 table_state = 1;
             }
             keys_cv.notify_all();
             warm_fastq(ctxs[0]);
+        };
+        if (proc_bcast && proc_rank > 0) {
+            // the table arrives from rank 0 (no key upload, no build here): the communicator, then the broadcast
+            const auto t_wait = std::chrono::steady_clock::now();
+            comm_up.join();
+            if (!comm_error.empty()) { ctx_error = comm_error; return; }
+            if (vgmi_table_broadcast_comm(ctxs[0], comm) != VGMI_OK) {
+                ctx_error = vgmi_last_error(ctxs[0]);
+                return;
+            }
+            std::fprintf(stderr, "[varigraph-mi] rank %d: table image received by RCCL broadcast %.3f s after the context was up (communicator %.3f s)\n",
+                         proc_rank, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count(), comm_seconds);
+            table_there();
             return;
         }
         std::unique_lock<std::mutex> lk(keys_mu);
@@ -335,32 +390,42 @@ int main_genotype(int argc, char** argv)
         // ONE table build (first device)
         if (vgmi_table_upload(ctxs[0], g.keys.data(), g.keys.size(), g.k) != VGMI_OK) {
             ctx_error = vgmi_last_error(ctxs[0]);
+            // (the other ranks hear of it inside the broadcast: size 0)
+            if (proc_bcast && proc_rank == 0) {
+                comm_up.join();
+                if (comm) (void)vgmi_table_broadcast_comm(ctxs[0], comm);
+            }
             return;
         }
         if (proc_bcast && proc_rank == 0) {
-            if (vgmi_rccl_unique_id(g_shared->nccl_id) != VGMI_OK) { ctx_error = vgmi_last_error(nullptr); return; }
-            g_shared->id_ready = 1;
-            if (vgmi_table_broadcast(ctxs[0], 0, proc_world, g_shared->nccl_id) != VGMI_OK) {
+            // the others' copy leaves from a snapshot of the image, whenever the communicator is up: this rank does not wait for it
+            if (vgmi_table_snapshot(ctxs[0]) != VGMI_OK) {
                 ctx_error = vgmi_last_error(ctxs[0]);
                 return;
             }
-            size_t ib = 0;
-            (void)vgmi_table_image_bytes(ctxs[0], &ib);
-            std::fprintf(stderr, "[varigraph-mi] rank 0: table image of %.1f MB sent to %d ranks in one RCCL broadcast\n", ib / 1e6, proc_world - 1);
+            bcast_thr = std::thread([&] {
+                const auto t_wait = std::chrono::steady_clock::now();
+                comm_up.join();
+                if (!comm_error.empty()) die(comm_error);
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
+                if (vgmi_table_broadcast_comm(ctxs[0], comm) != VGMI_OK) die(vgmi_last_error(ctxs[0]));
+                size_t ib = 0;
+                (void)vgmi_table_image_bytes(ctxs[0], &ib);
+                std::fprintf(stderr, "[varigraph-mi] rank 0: table image of %.1f MB sent to %d ranks in one RCCL broadcast (communicator %.3f s beside the table build, "
+                                     "%.3f s of it after the table was there, broadcast %.3f s; rank 0 counted meanwhile)\n", ib / 1e6, proc_world - 1,
+                             comm_seconds, waited, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count() - waited);
+            });
         }
-        {
-            std::lock_guard<std::mutex> lk2(keys_mu);
-            table_state = 1;
-        }
-        keys_cv.notify_all();
-        warm_fastq(ctxs[0]);
+        table_there();
     });
     std::string load_error;
-    try {
-        g.threads = std::max(1u, o.hmm.threads);
-        g.load(o.graph);
-    } catch (const std::exception& e) {
-        load_error = e.what();
+    if (!graph_loaded) {
+        try {
+            g.threads = std::max(1u, o.hmm.threads);
+            g.load(o.graph);
+        } catch (const std::exception& e) {
+            load_error = e.what();
+        }
     }
     {
         std::lock_guard<std::mutex> lk(keys_mu);
@@ -368,6 +433,7 @@ int main_genotype(int argc, char** argv)
     }
     keys_cv.notify_all();
     bring_up.join();
+    if (!bcast_thr.joinable() && comm_up.joinable()) comm_up.join();      // (rank 0's broadcast thread joins it itself)
     if (!load_error.empty()) die(load_error);
     if (!ctx_error.empty()) die(ctx_error);
     // the image then goes device to device in a doubling tree (round r: the 2^r devices that hold it feed the next 2^r over
@@ -444,7 +510,7 @@ int main_genotype(int argc, char** argv)
         die("--procs deals the samples to several processes: that needs samples that are independent units (-n >= the number of "
             "haplotypes of the graph, so that no sample's haplotype selection prunes the next one's k-mer lists)");
     const size_t n_consumers = independent ? want_consumers : 1;
-    if (n_consumers > 1) g.build_entry_words();      // the graph's half of the Genotypers' per-entry words, once instead of once each
+    if (n_consumers > 1 && g.entry_words.empty()) g.build_entry_words();      // the graph's half of the Genotypers' per-entry words, once instead of once each
     // -t is the budget of the whole run: counting threads (inflate workers) and HMM consumers that run side by side
     // share it instead of each taking all of it
     const unsigned count_threads = std::max<unsigned>(1, o.hmm.threads / (unsigned)std::max<size_t>(1, std::min(ctxs.size(), samples.size())));
@@ -553,9 +619,28 @@ int main_genotype(int argc, char** argv)
     counter(0);
     for (auto& t : counters) t.join();
     for (auto& t : hmm_threads) t.join();
+    if (bcast_thr.joinable()) bcast_thr.join();
+    if (comm) { vgmi_comm_destroy(comm); comm = nullptr; }
     const double t_joined = secs();
     for (vgmi_ctx* ctx : ctxs) vgmi_destroy(ctx);
     if (getenv("VGH_TIMING")) std::fprintf(stderr, "[varigraph-mi] last sample written at %.2f s, devices released by %.2f s\n", t_joined, secs());
+    {   // what this process held: its own peak (VmHWM counts pages shared copy-on-write in full) and its proportional share (Pss)
+        double hwm = 0, pss = 0;
+        if (FILE* f = std::fopen("/proc/self/status", "r")) {
+            char line[256];
+            while (std::fgets(line, sizeof line, f))
+                if (std::strncmp(line, "VmHWM:", 6) == 0) hwm = std::atof(line + 6) / 1048576.0;
+            std::fclose(f);
+        }
+        if (FILE* f = std::fopen("/proc/self/smaps_rollup", "r")) {
+            char line[256];
+            while (std::fgets(line, sizeof line, f))
+                if (std::strncmp(line, "Pss:", 4) == 0) pss = std::atof(line + 4) / 1048576.0;
+            std::fclose(f);
+        }
+        if (proc_rank >= 0) std::fprintf(stderr, "[varigraph-mi] rank %d: host memory: peak RSS %.3f GB, PSS at exit %.3f GB\n", proc_rank, hwm, pss);
+        else std::fprintf(stderr, "[varigraph-mi] host memory: peak RSS %.3f GB, PSS at exit %.3f GB\n", hwm, pss);
+    }
     std::fprintf(stderr, "[varigraph-mi] done in %.2f s\n", secs());
     // every output file is closed and the devices are released: skip taking the graph (1e7s of small allocations) apart
     std::fflush(nullptr);

@@ -74,6 +74,7 @@ struct vgmi_ctx {
 
     // table image (one allocation) and views into it
     uint8_t* d_image = nullptr;
+    uint8_t* d_snapshot = nullptr;      // vgmi_table_snapshot: the image as uploaded, for a broadcast that leaves after counting has begun
     size_t image_bytes = 0;
     ImageHeader hdr{};
     bool has_table = false;
@@ -184,6 +185,8 @@ void free_table(vgmi_ctx* c)
 {
     if (c->d_image) (void)hipFree(c->d_image);
     c->d_image = nullptr;
+    if (c->d_snapshot) (void)hipFree(c->d_snapshot);
+    c->d_snapshot = nullptr;
     c->image_bytes = 0;
     c->has_table = false;
     if (c->d_cov) (void)hipFree(c->d_cov);
@@ -1180,6 +1183,21 @@ int vgmi_table_export(vgmi_ctx* c, void* dev_dst, size_t bytes)
     return VGMI_OK;
 }
 
+// A copy of the image as it stands (no sample counted yet): vgmi_table_broadcast_comm then sends the copy, so the root may start
+// counting -- which sets per-sample bits inside the image -- before the communicator is up.  Freed by the broadcast.
+int vgmi_table_snapshot(vgmi_ctx* c)
+{
+    if (!c) return VGMI_E_INVALID;
+    if (!c->has_table) return fail(c, VGMI_E_STATE, "no table");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->d_snapshot) (void)hipFree(c->d_snapshot);
+    c->d_snapshot = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_snapshot), c->image_bytes));
+    HIPCHK(c, hipMemcpyAsync(c->d_snapshot, c->d_image, c->image_bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VGMI_OK;
+}
+
 int vgmi_table_import(vgmi_ctx* c, const void* dev_src, size_t bytes)
 {
     if (!c || !dev_src) return VGMI_E_INVALID;
@@ -1221,6 +1239,7 @@ struct Rccl {
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, ncclUniqueIdBytes, int) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string err;
@@ -1234,15 +1253,17 @@ Rccl* rccl()
             if (x.lib) break;
         }
         if (!x.lib) {
-            x.err = std::string("librccl.so: ") + (dlerror() ? dlerror() : "not found");
+            const char* m = dlerror();      // (once: the call hands the message over and clears it)
+            x.err = std::string("librccl.so: ") + (m ? m : "not found");
             return x;
         }
         x.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(x.lib, "ncclGetUniqueId"));
         x.CommInitRank = reinterpret_cast<int (*)(void**, int, ncclUniqueIdBytes, int)>(dlsym(x.lib, "ncclCommInitRank"));
         x.Broadcast = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(x.lib, "ncclBroadcast"));
+        x.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(x.lib, "ncclAllReduce"));
         x.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(x.lib, "ncclCommDestroy"));
         x.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(x.lib, "ncclGetErrorString"));
-        if (!x.GetUniqueId || !x.CommInitRank || !x.Broadcast || !x.CommDestroy) x.err = "librccl.so lacks an entry point";
+        if (!x.GetUniqueId || !x.CommInitRank || !x.Broadcast || !x.AllReduce || !x.CommDestroy) x.err = "librccl.so lacks an entry point";
         return x;
     }();
     return &r;
@@ -1259,48 +1280,112 @@ int vgmi_rccl_unique_id(void* id128)
     return VGMI_OK;
 }
 
+// The communicator on its own: ncclCommInitRank takes seconds (topology, kernels of every rank's device) and needs neither a
+// table nor a context -- a rank calls it beside its graph load / table build, and joins the broadcast when both are there.
+struct vgmi_comm {
+    void* comm = nullptr;
+    int device = 0, rank = 0, world = 1;
+};
+
+int vgmi_comm_create(int device, int rank, int world, const void* id128, vgmi_comm** out)
+{
+    if (!out) return VGMI_E_INVALID;
+    *out = nullptr;
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return VGMI_E_INVALID;
+    Rccl* r = rccl();
+    if (!r->err.empty()) return fail(nullptr, VGMI_E_STATE, r->err);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, VGMI_E_HIP, "vgmi_comm_create: hipSetDevice failed");
+    ncclUniqueIdBytes id;
+    memcpy(id.internal, id128, sizeof id.internal);
+    vgmi_comm* m = new (std::nothrow) vgmi_comm();
+    if (!m) return fail(nullptr, VGMI_E_NOMEM, "out of memory");
+    m->device = device;
+    m->rank = rank;
+    m->world = world;
+    const int rc = r->CommInitRank(&m->comm, world, id, rank);
+    if (rc) {
+        delete m;
+        return fail(nullptr, VGMI_E_HIP, std::string("ncclCommInitRank: ") + (r->GetErrorString ? r->GetErrorString(rc) : "failed"));
+    }
+    *out = m;
+    return VGMI_OK;
+}
+
+void vgmi_comm_destroy(vgmi_comm* m)
+{
+    if (!m) return;
+    if (m->comm) {
+        (void)hipSetDevice(m->device);
+        (void)rccl()->CommDestroy(m->comm);
+    }
+    delete m;
+}
+
+// Root = rank 0.  Every rank goes through the same three collectives whatever happens on its side -- the image's size (0: the
+// root has none to give), an agreement that every receiver has its buffer (all-reduce, minimum), the image -- so that a rank that
+// cannot go on says so to the others instead of leaving them inside a collective.
+int vgmi_table_broadcast_comm(vgmi_ctx* c, vgmi_comm* m)
+{
+    if (!c || !m || !m->comm) return VGMI_E_INVALID;
+    if (m->device != c->device) return fail(c, VGMI_E_INVALID, "vgmi_table_broadcast_comm: the communicator is on another device than the context");
+    Rccl* r = rccl();
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rank = m->rank;
+    // a stream of its own: a root that sends a snapshot may be counting on the context's streams meanwhile
+    hipStream_t st = nullptr;
+    HIPCHK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    unsigned long long* d_n = nullptr;      // [0] the size, [1] the receivers' agreement
+    uint8_t* d_recv = nullptr;
+    struct Cleanup {
+        hipStream_t& st; unsigned long long*& d_n; uint8_t*& d_recv;
+        ~Cleanup() { if (d_n) (void)hipFree(d_n); if (d_recv) (void)hipFree(d_recv); if (st) (void)hipStreamDestroy(st); }
+    } cleanup{st, d_n, d_recv};
+    if (!(rank == 0 && c->d_snapshot)) HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto nccl_text = [&](const char* what, int rc) { return std::string(what) + ": " + (r->GetErrorString ? r->GetErrorString(rc) : "failed"); };
+    // (16 bytes: if even that fails the device is gone, and so is this rank's part in the collectives)
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_n), 16));
+    unsigned long long h[2] = {rank == 0 && c->has_table ? (unsigned long long)c->image_bytes : 0ull, 1ull};
+    HIPCHK(c, hipMemcpy(d_n, h, 16, hipMemcpyHostToDevice));
+    int rc = r->Broadcast(d_n, d_n, 8, /* ncclChar */ 0, 0, m->comm, st);
+    if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = 1;
+    if (rc) return fail(c, VGMI_E_HIP, nccl_text("ncclBroadcast (size)", rc));
+    HIPCHK(c, hipMemcpy(h, d_n, 8, hipMemcpyDeviceToHost));
+    const unsigned long long n = h[0];
+    if (n == 0) return fail(c, VGMI_E_STATE, "the root has no table to broadcast");
+    uint8_t* d_buf = rank == 0 ? (c->d_snapshot ? c->d_snapshot : c->d_image) : nullptr;
+    if (rank != 0) {
+        if (hipMalloc(reinterpret_cast<void**>(&d_recv), n) != hipSuccess) {
+            d_recv = nullptr;
+            h[1] = 0;
+            (void)hipGetLastError();
+            HIPCHK(c, hipMemcpy(d_n + 1, h + 1, 8, hipMemcpyHostToDevice));
+        }
+        d_buf = d_recv;
+    }
+    rc = r->AllReduce(d_n + 1, d_n + 1, 1, /* ncclUint64 */ 5, /* ncclMin */ 3, m->comm, st);
+    if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = 1;
+    unsigned long long all_ready = 0;
+    if (rc == 0 && hipMemcpy(&all_ready, d_n + 1, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = 1;
+    if (rc) return fail(c, VGMI_E_HIP, nccl_text("ncclAllReduce (buffers)", rc));
+    if (!all_ready) return fail(c, VGMI_E_NOMEM, "vgmi_table_broadcast_comm: a rank has no room for the table image");
+    rc = r->Broadcast(d_buf, d_buf, n, /* ncclChar */ 0, 0, m->comm, st);
+    if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = 1;
+    if (rc) return fail(c, VGMI_E_HIP, nccl_text("ncclBroadcast (image)", rc));
+    if (rank == 0 && c->d_snapshot) {
+        (void)hipFree(c->d_snapshot);
+        c->d_snapshot = nullptr;
+    }
+    return rank != 0 ? vgmi_table_import(c, d_recv, n) : VGMI_OK;
+}
+
 int vgmi_table_broadcast(vgmi_ctx* c, int rank, int world, const void* id128)
 {
     if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return VGMI_E_INVALID;
-    if (rank == 0 && !c->has_table) return fail(c, VGMI_E_STATE, "the root has no table to broadcast");
-    Rccl* r = rccl();
-    if (!r->err.empty()) return fail(c, VGMI_E_STATE, r->err);
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    ncclUniqueIdBytes id;
-    memcpy(id.internal, id128, sizeof id.internal);
-    void* comm = nullptr;
-    auto nccl_fail = [&](const char* what, int rc) {
-        if (comm) (void)r->CommDestroy(comm);
-        return fail(c, VGMI_E_HIP, std::string(what) + ": " + (r->GetErrorString ? r->GetErrorString(rc) : "failed"));
-    };
-    int rc = r->CommInitRank(&comm, world, id, rank);
-    if (rc) return nccl_fail("ncclCommInitRank", rc);
-    // the image's size first (8 bytes), then the image: root sends its own allocation, the others receive into a buffer they adopt
-    unsigned long long* d_n = nullptr;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_n), 8));
-    unsigned long long n = rank == 0 ? c->image_bytes : 0;
-    HIPCHK(c, hipMemcpy(d_n, &n, 8, hipMemcpyHostToDevice));
-    rc = r->Broadcast(d_n, d_n, 8, /* ncclChar */ 0, 0, comm, c->stream);
-    if (rc == 0 && hipStreamSynchronize(c->stream) != hipSuccess) rc = 1;
-    if (rc) { (void)hipFree(d_n); return nccl_fail("ncclBroadcast (size)", rc); }
-    HIPCHK(c, hipMemcpy(&n, d_n, 8, hipMemcpyDeviceToHost));
-    (void)hipFree(d_n);
-    uint8_t* d_buf = rank == 0 ? c->d_image : nullptr;
-    if (rank != 0 && hipMalloc(reinterpret_cast<void**>(&d_buf), n) != hipSuccess) return nccl_fail("hipMalloc (image)", 1);
-    rc = r->Broadcast(d_buf, d_buf, n, /* ncclChar */ 0, 0, comm, c->stream);
-    if (rc == 0 && hipStreamSynchronize(c->stream) != hipSuccess) rc = 1;
-    (void)r->CommDestroy(comm);
-    comm = nullptr;
-    if (rc) {
-        if (rank != 0) (void)hipFree(d_buf);
-        return nccl_fail("ncclBroadcast (image)", rc);
-    }
-    int out = VGMI_OK;
-    if (rank != 0) {
-        out = vgmi_table_import(c, d_buf, n);
-        (void)hipFree(d_buf);
-    }
+    vgmi_comm* m = nullptr;
+    const int rc = vgmi_comm_create(c->device, rank, world, id128, &m);
+    if (rc) return fail(c, rc, vgmi_last_error(nullptr));
+    const int out = vgmi_table_broadcast_comm(c, m);
+    vgmi_comm_destroy(m);
     return out;
 }
 
@@ -1633,7 +1718,9 @@ struct vgmi_fastq {
     bool gz_in_member = false;                       // false: the next staged byte is a member header (or the data is over)
     uint32_t gz_bit = 0;                             // the next block starts this many bits into the first staged byte
     uint32_t gz_avail = 0;                           // text bytes of this member so far, 32768 at most (the window that exists)
-    uint32_t gz_skip = 0;                            // bytes of a member's trailer still to be skipped at the front of the next piece
+    uint32_t gz_skip = 0;                            // bytes of a member's trailer still to come (the front of the next piece)
+    unsigned char gz_trailer[8] = {0};               // the trailer as it arrives: CRC-32, ISIZE
+    uint64_t gz_member_text = 0;                     // text bytes of the member being decoded
     uint32_t gz_reason = 0;                          // why the device gave the stream up (GzSegOut::status), 0: it did not
     uint64_t gz_text = 0;                            // text bytes the device produced
     std::vector<uint32_t> batch_members;             // members per committed batch
@@ -1999,12 +2086,26 @@ struct GzScratch {
     uint64_t* d_toff = nullptr;
     uint16_t *d_pool = nullptr, *d_w1 = nullptr;      // symbols; the 16-bit window behind every stretch
     uint8_t* d_win = nullptr;                         // byte windows: in front of the piece, then behind every group of stretches
-    size_t cap_seg = 0, cap_pool = 0, cap_sub = 0;
+    uint32_t* d_chunk_r = nullptr;                    // CRC remainders of the text's 16 KiB chunks
+    GzCrcState* d_crc = nullptr;                      // the member's running remainder and length: kept when the scratch grows
+    size_t cap_seg = 0, cap_pool = 0, cap_sub = 0, cap_crc = 0;
+    // everything but what a member carries from piece to piece (its CRC state; the window in front is handed back to the caller)
+    uint8_t* release_scratch()
+    {
+        uint8_t* const win = d_win;
+        for (void* q : {(void*)d_starts, (void*)d_segs, (void*)d_outs, (void*)d_toff, (void*)d_pool, (void*)d_w1, (void*)d_chunk_r})
+            if (q) (void)hipFree(q);
+        GzCrcState* const keep = d_crc;
+        *this = GzScratch{};
+        d_crc = keep;
+        return win;
+    }
     void release()
     {
-        for (void* q : {(void*)d_starts, (void*)d_segs, (void*)d_outs, (void*)d_toff, (void*)d_pool, (void*)d_win, (void*)d_w1})
-            if (q) (void)hipFree(q);
-        *this = GzScratch{};
+        uint8_t* const win = release_scratch();
+        if (win) (void)hipFree(win);
+        if (d_crc) (void)hipFree(d_crc);
+        d_crc = nullptr;
     }
 };
 // compressed bytes per guessed start (VGMI_GZ_SEG_KB for A/B; >= 32 KiB of compressed bytes hold a window of text for sure)
@@ -2014,11 +2115,19 @@ const uint32_t kGzSeg = [] {
                                          // gpurun_out/r4q); wide batches: 32 KiB 7.5e7, 40 KiB 7.8e7, 48 KiB 8.4e7 (with a 2 048-entry ring, gpurun_out/r4w12)
     return ((uint32_t)(v < 32 ? 32 : v > 1024 ? 1024 : v) + 7u) / 8u * 8u << 10;      // a multiple of the search's sub-ranges
 }();
+// the scratch of a stream sized once for the largest piece its buffer can stage (VGMI_GZ_RESERVE=0: grown piece by piece -- the test of that path)
+bool gz_reserve()
+{
+    const char* e = getenv("VGMI_GZ_RESERVE");
+    return !(e && e[0] == '0');
+}
 constexpr uint32_t kGzRatio = 12;         // symbols of room per compressed byte of a stretch (FASTQ: 4-6)
 constexpr uint32_t kGzSub = 2048;         // the block-start search: compressed bytes per wavefront (each reports the first start of its sub-range)
 
+// n_reserve: the largest piece this stream will present (the scratch is sized once); member_start: the piece opens a member (its CRC
+// state starts over, there is no window in front).
 int gz_piece(vgmi_ctx* c, GzScratch& g, const uint8_t* d_comp, uint32_t n, uint32_t first_bit, uint32_t win_avail, uint8_t* d_text, size_t text_cap,
-             hipStream_t st, uint32_t* end_bit, size_t* n_text, int* final_member, uint32_t* reason)
+             hipStream_t st, uint32_t* end_bit, size_t* n_text, int* final_member, uint32_t* reason, size_t n_reserve = 0, bool member_start = true)
 {
     *end_bit = first_bit;
     *n_text = 0;
@@ -2028,19 +2137,37 @@ int gz_piece(vgmi_ctx* c, GzScratch& g, const uint8_t* d_comp, uint32_t n, uint3
     const uint32_t n_nom = (n + kGzSeg - 1) / kGzSeg;
     const size_t pool_syms = (size_t)kGzRatio * n + (size_t)n_nom * 1024 + 65536;
     const uint32_t n_sub = (n + kGzSub - 1) / kGzSub;
-    if (g.cap_seg < n_nom + 1 || g.cap_pool < pool_syms || g.cap_sub < n_sub) {
-        g.release();
-        g.cap_seg = n_nom + 1;
-        g.cap_pool = pool_syms;
-        g.cap_sub = n_sub;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_starts), g.cap_sub * 4));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_segs), g.cap_seg * sizeof(GzSegHost)));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_outs), g.cap_seg * sizeof(GzSegOutHost)));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_toff), g.cap_seg * 8));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_pool), g.cap_pool * 2));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_win), ((size_t)gz_groups((uint32_t)g.cap_seg) + 2) * 32768));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&g.d_w1), g.cap_seg * 65536));
+    const size_t n_crc = gz_crc_chunks(text_cap) + 1;
+    if (g.cap_seg < n_nom + 1 || g.cap_pool < pool_syms || g.cap_sub < n_sub || g.cap_crc < n_crc) {
+        // (a piece larger than any before it: the window in front of it is the one thing in the scratch that the member still
+        // needs -- it moves to the new allocation; the CRC state is not part of the scratch)
+        const size_t m = std::max<size_t>(n, std::min<size_t>(n_reserve, (1ull << 29) - 4096));
+        const uint32_t m_nom = (uint32_t)((m + kGzSeg - 1) / kGzSeg);
+        uint8_t* const old_win = g.release_scratch();
+        g.cap_seg = m_nom + 1;
+        g.cap_pool = (size_t)kGzRatio * m + (size_t)m_nom * 1024 + 65536;
+        g.cap_sub = (m + kGzSub - 1) / kGzSub;
+        g.cap_crc = n_crc;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&g.d_starts), g.cap_sub * 4);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g.d_segs), g.cap_seg * sizeof(GzSegHost));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g.d_outs), g.cap_seg * sizeof(GzSegOutHost));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g.d_toff), g.cap_seg * 8);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g.d_pool), g.cap_pool * 2);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g.d_win), ((size_t)gz_groups((uint32_t)g.cap_seg) + 2) * 32768);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g.d_w1), g.cap_seg * 65536);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g.d_chunk_r), g.cap_crc * 4);
+        if (e == hipSuccess && !g.d_crc) {
+            e = hipMalloc(reinterpret_cast<void**>(&g.d_crc), sizeof(GzCrcState));
+            if (e == hipSuccess) e = hipMemsetAsync(g.d_crc, 0, sizeof(GzCrcState), st);
+        }
+        if (e == hipSuccess && old_win) {
+            e = hipMemcpyAsync(g.d_win, old_win, 32768, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
+        if (old_win) (void)hipFree(old_win);
+        HIPCHK(c, e);
     }
+    if (member_start) HIPCHK(c, hipMemsetAsync(g.d_crc, 0, sizeof(GzCrcState), st));
     // 1. guessed block starts: the first of every sub-range of kGzSub bytes; stretch j starts at the first one found at or behind
     // j * kGzSeg (and in front of (j + 2) * kGzSeg), the piece's first start is known.  (Stretches that run from a start to the first
     // one kGzSeg or more behind it come out half again as long -- DEFLATE blocks of FASTQ text are ~28 KiB apart -- and the decode
@@ -2103,8 +2230,23 @@ int gz_piece(vgmi_ctx* c, GzScratch& g, const uint8_t* d_comp, uint32_t n, uint3
     HIPCHK(c, hipMemcpyAsync(g.d_toff, toff.data(), (size_t)n_ok * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, launch_gz_resolve(g.d_pool, g.d_segs, g.d_outs, g.d_toff, n_ok, g.d_w1, g.d_win, d_text, st));
     *n_text = (size_t)toff[n_ok];
+    HIPCHK(c, launch_gz_crc(d_text, (uint64_t)toff[n_ok], g.d_chunk_r, g.d_crc, st));
     // the window behind the last stretch becomes the window in front of the next piece
     HIPCHK(c, hipMemcpyAsync(g.d_win, g.d_win + (size_t)gz_groups(n_ok) * 32768, 32768, hipMemcpyDeviceToDevice, st));
+    return VGMI_OK;
+}
+
+// A member's trailer (CRC-32, ISIZE; RFC 1952) against the text the device resolved for it: what zlib checks behind gzread.
+int gz_check_trailer(vgmi_ctx* c, GzScratch& g, const unsigned char* tr, hipStream_t st, bool* ok)
+{
+    *ok = true;
+    if (!g.d_crc) return VGMI_OK;      // (a member without a single decoded piece never gets here)
+    GzCrcState h;
+    HIPCHK(c, hipMemcpyAsync(&h, g.d_crc, sizeof h, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const uint32_t want_crc = (uint32_t)tr[0] | (uint32_t)tr[1] << 8 | (uint32_t)tr[2] << 16 | (uint32_t)tr[3] << 24;
+    const uint32_t want_len = (uint32_t)tr[4] | (uint32_t)tr[5] << 8 | (uint32_t)tr[6] << 16 | (uint32_t)tr[7] << 24;
+    *ok = gz_crc_finish(h.r, h.len) == want_crc && (uint32_t)h.len == want_len;
     return VGMI_OK;
 }
 }  // namespace
@@ -2137,6 +2279,11 @@ int vgmi_gunzip_buffer(vgmi_ctx* c, const void* host_gz, size_t n, void* host_ou
     if (he == hipSuccess) rc = gz_piece(c, g, d_comp, (uint32_t)n, (uint32_t)hdr * 8u, 0, d_text, cap, c->stream, &end_bit, &n_text, &fin, &why);
     if (he == hipSuccess && rc == VGMI_OK) he = hipMemcpyAsync(host_out, d_text, n_text, hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    if (he == hipSuccess && rc == VGMI_OK && fin && (size_t)(end_bit + 7) / 8 + 8 <= n) {      // reason 11: CRC-32 / ISIZE of the text
+        bool ok = true;
+        rc = gz_check_trailer(c, g, p + (size_t)(end_bit + 7) / 8, c->stream, &ok);
+        if (rc == VGMI_OK && !ok) why = 11;
+    }
     g.release();
     if (d_comp) (void)hipFree(d_comp);
     if (d_text) (void)hipFree(d_text);
@@ -2160,10 +2307,12 @@ void gz_scratch_free(void* g)
 
 // The streaming form: the staged bytes [0, n_bytes) of the acquired buffer continue an ordinary gzip stream -- at a member header
 // when the stream is at a member's start, else at the byte that holds the next block's first bit (what the previous call left
-// untaken).  Whole stretches between block starts are inflated into the chunk's text and parsed and counted like any text chunk.
-// *taken = staged bytes used up (the caller presents the rest again, in front of the bytes that follow).  *stop: 0 go on; 1 the gzip
-// data is over (a member ended and what follows is no member header: gzread ignores it); 2 the device cannot take these bytes
-// (vgmi_fastq_gzip_status says why): the host decoder carries on from the text the device parser has consumed.
+// untaken).  Whole stretches between block starts are inflated into the chunk's text and parsed and counted like any text chunk;
+// a member that ends inside the staged bytes is checked against its trailer (CRC-32, ISIZE) and the member behind it follows in the
+// same call, as gzread runs members together.  *taken = staged bytes used up (the caller presents the rest again, in front of the
+// bytes that follow).  *stop: 0 go on; 1 the gzip data is over (a member ended and what follows is no member header: gzread ignores
+// it); 2 the device cannot take these bytes (vgmi_fastq_gzip_status says why; reason 11: the text of a member does not match its
+// trailer): the host decoder carries on from the text the device parser has consumed.
 int vgmi_fastq_commit_gzip(vgmi_fastq* f, size_t n_bytes, int at_eof, size_t* taken, size_t* n_text, int* stop)
 {
     if (!f || !taken || !stop) return VGMI_E_INVALID;
@@ -2177,77 +2326,103 @@ int vgmi_fastq_commit_gzip(vgmi_fastq* f, size_t n_bytes, int at_eof, size_t* ta
     f->acquired = -1;
     HIPCHK(c, hipSetDevice(c->device));
     const unsigned char* p = reinterpret_cast<const unsigned char*>(f->h_stage[i]);
-    size_t pos = 0;
-    if (f->gz_skip) {                      // the rest of the last member's trailer
-        const size_t k = std::min<size_t>(f->gz_skip, n_bytes);
-        f->gz_skip -= (uint32_t)k;
-        pos = k;
-        if (f->gz_skip) { *taken = n_bytes; if (at_eof) *stop = 1; return VGMI_OK; }
-    }
-    uint32_t first_bit;
-    if (!f->gz_in_member) {
-        if (n_bytes - pos < 2 || p[pos] != 0x1f || p[pos + 1] != 0x8b) {
-            if (n_bytes - pos >= 2 || at_eof) { *taken = n_bytes; *stop = 1; return VGMI_OK; }     // no further member: the data is over
-            *taken = pos;
-            return VGMI_OK;
+    size_t pos = 0;               // staged bytes dealt with
+    size_t text_total = 0;        // text of this call, behind one another in the chunk
+    bool staged = false;          // the bytes are on the device
+    uint32_t members_ended = 0;
+    for (;;) {
+        if (f->gz_skip) {                      // the rest of the last member's trailer
+            const size_t k = std::min<size_t>(f->gz_skip, n_bytes - pos);
+            memcpy(f->gz_trailer + (8 - f->gz_skip), p + pos, k);
+            f->gz_skip -= (uint32_t)k;
+            pos += k;
+            if (f->gz_skip) {                  // (a trailer the file cuts short: the data is over, as for gzread)
+                *taken = n_bytes;
+                if (at_eof) *stop = 1;
+                break;
+            }
+            bool ok = true;
+            const int rc = f->gz ? gz_check_trailer(c, *static_cast<GzScratch*>(f->gz), f->gz_trailer, f->stream, &ok) : VGMI_OK;
+            if (rc) return rc;
+            if (!ok) { f->gz_reason = 11; *taken = pos; *stop = 2; break; }
         }
-        const size_t hdr = gzip_header_len(p + pos, n_bytes - pos);
-        if (!hdr) {
-            if (n_bytes - pos >= 65536 + 64 || at_eof) { f->gz_reason = 10; *stop = 2; }      // a header that does not parse
-            *taken = pos;
-            return VGMI_OK;
+        uint32_t first_bit;
+        if (!f->gz_in_member) {
+            if (n_bytes - pos < 2 || p[pos] != 0x1f || p[pos + 1] != 0x8b) {
+                if (n_bytes - pos >= 2 || at_eof) { *taken = n_bytes; *stop = 1; }      // no further member: the data is over
+                else *taken = pos;
+                break;
+            }
+            // (members of a few kilobytes each, one after another: a piece per member is launch-bound -- the host decoder's case)
+            if (members_ended >= 8 && text_total < ((size_t)members_ended << 20)) { f->gz_reason = 12; *taken = pos; *stop = 2; break; }
+            const size_t hdr = gzip_header_len(p + pos, n_bytes - pos);
+            if (!hdr) {
+                if (n_bytes - pos >= 65536 + 64 || at_eof) { f->gz_reason = 10; *stop = 2; }      // a header that does not parse
+                *taken = pos;
+                break;
+            }
+            first_bit = (uint32_t)(pos + hdr) * 8u;
+            f->gz_avail = 0;
+            f->gz_member_text = 0;
+            f->gz_in_member = true;
+        } else first_bit = (uint32_t)pos * 8u + f->gz_bit;
+        if (!f->gz) f->gz = new (std::nothrow) GzScratch();
+        if (!f->gz) return fail(c, VGMI_E_NOMEM, "out of memory");
+        if (!staged) {
+            if (!f->d_comp) {
+                constexpr size_t kCompSlack = 512u << 10;
+                hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_comp), f->cap + kCompSlack);
+                if (e == hipSuccess) e = hipMemsetAsync(f->d_comp + f->cap, 0, kCompSlack, f->stream);
+                HIPCHK(c, e);
+            }
+            HIPCHK(c, hipMemcpyAsync(f->d_comp, f->h_stage[i], n_bytes, hipMemcpyHostToDevice, f->stream));
+            if (n_bytes < f->cap) HIPCHK(c, hipMemsetAsync(f->d_comp + n_bytes, 0, std::min<size_t>(4096, f->cap - n_bytes), f->stream));
+            HIPCHK(c, hipEventRecord(f->h_done[i], f->stream));
+            f->h_busy[i] = true;
+            staged = true;
         }
-        first_bit = (uint32_t)(pos + hdr) * 8u;
-        f->gz_avail = 0;
-        f->gz_in_member = true;
-    } else first_bit = (uint32_t)pos * 8u + f->gz_bit;
-    if (!f->gz) f->gz = new (std::nothrow) GzScratch();
-    if (!f->gz) return fail(c, VGMI_E_NOMEM, "out of memory");
-    if (!f->d_comp) {
-        constexpr size_t kCompSlack = 512u << 10;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_comp), f->cap + kCompSlack);
-        if (e == hipSuccess) e = hipMemsetAsync(f->d_comp + f->cap, 0, kCompSlack, f->stream);
-        HIPCHK(c, e);
-    }
-    HIPCHK(c, hipMemcpyAsync(f->d_comp, f->h_stage[i], n_bytes, hipMemcpyHostToDevice, f->stream));
-    if (n_bytes < f->cap) HIPCHK(c, hipMemsetAsync(f->d_comp + n_bytes, 0, std::min<size_t>(4096, f->cap - n_bytes), f->stream));
-    HIPCHK(c, hipEventRecord(f->h_done[i], f->stream));
-    f->h_busy[i] = true;
-    uint32_t end_bit = 0, why = 0;
-    size_t text = 0;
-    int fin = 0;
-    int rc = gz_piece(c, *static_cast<GzScratch*>(f->gz), f->d_comp, (uint32_t)n_bytes, first_bit, f->gz_avail, f->d_raw[i] + f->tail_max, f->text_cap, f->stream,
-                      &end_bit, &text, &fin, &why);
-    if (rc) return rc;
-    const bool broken = why != 0 && why != 9 && why != 3;       // a stretch that does not decode / does not meet the next one
-    if (text == 0 && !fin) {
-        // no whole stretch in these bytes: more may help -- unless there are no more, the buffer is full already, or it is no DEFLATE
-        if (at_eof || n_bytes == f->cap || broken) {
-            f->gz_reason = why ? why : 9;
-            *stop = 2;
+        // a member behind the call's first: the piece starts at the (aligned) bytes it starts in
+        const size_t base = members_ended ? (size_t)(first_bit / 8u) / kGzSub * kGzSub : 0;
+        uint32_t end_bit = 0, why = 0;
+        size_t text = 0;
+        int fin = 0;
+        int rc = gz_piece(c, *static_cast<GzScratch*>(f->gz), f->d_comp + base, (uint32_t)(n_bytes - base), first_bit - (uint32_t)base * 8u, f->gz_avail,
+                          f->d_raw[i] + f->tail_max + text_total, f->text_cap - text_total, f->stream, &end_bit, &text, &fin, &why, gz_reserve() ? f->cap : 0,
+                          f->gz_member_text == 0);
+        if (rc) return rc;
+        end_bit += (uint32_t)base * 8u;
+        const bool broken = why != 0 && why != 9 && why != 3;       // a stretch that does not decode / does not meet the next one
+        if (text == 0 && !fin) {
+            // no whole stretch in these bytes: more may help -- unless there are no more, the buffer is full already, or it is no DEFLATE
+            // (behind a member that ended in this call: the caller presents the rest again, and the question is asked then)
+            if ((at_eof || n_bytes == f->cap || broken) && members_ended == 0) {
+                f->gz_reason = why ? why : 9;
+                *stop = 2;
+            }
+            *taken = first_bit / 8u;      // (a header just read is taken; the block's byte stays)
+            f->gz_bit = first_bit & 7u;
+            break;
         }
-        if (!f->gz_in_member || first_bit >= 8) *taken = (first_bit / 8u);      // (a header just read is taken; the block's byte stays)
-        f->gz_bit = first_bit & 7u;
-        return VGMI_OK;
-    }
-    f->gz_text += text;
-    f->gz_avail = (uint32_t)std::min<uint64_t>(32768, (uint64_t)f->gz_avail + text);
-    if (fin) {
-        const size_t after = (size_t)(end_bit + 7) / 8 + 8;        // CRC-32 and ISIZE are not checked: gzread reports them at the data's end
+        f->gz_text += text;
+        f->gz_member_text += text;
+        text_total += text;
+        f->gz_avail = (uint32_t)std::min<uint64_t>(32768, (uint64_t)f->gz_avail + text);
+        if (!fin) {
+            *taken = end_bit / 8u;
+            f->gz_bit = end_bit & 7u;
+            if (broken) { f->gz_reason = why; *stop = 2; }       // a stretch behind the ones taken went wrong: the host goes on from the text so far
+            break;
+        }
+        // the member's end: its trailer (the part of it that is here), then whatever follows
         f->gz_in_member = false;
         f->gz_bit = 0;
-        if (after > n_bytes) {
-            f->gz_skip = (uint32_t)(after - n_bytes);
-            *taken = n_bytes;
-        } else *taken = after;
-        if (at_eof && *taken == n_bytes) *stop = 1;
-    } else {
-        *taken = end_bit / 8u;
-        f->gz_bit = end_bit & 7u;
-        if (broken) { f->gz_reason = why; *stop = 2; }       // a stretch behind the ones taken went wrong: the host goes on from the text so far
+        f->gz_skip = 8;
+        pos = (size_t)(end_bit + 7) / 8;
+        ++members_ended;
+        if (pos >= n_bytes && !at_eof) { *taken = n_bytes; break; }
     }
-    if (n_text) *n_text = text;
-    if (text) {
+    if (n_text) *n_text = text_total;
+    if (text_total) {
         FqBuffers b{};
         b.raw = f->d_raw[i];
         b.raw_next = f->d_raw[i ^ 1];
@@ -2260,8 +2435,8 @@ int vgmi_fastq_commit_gzip(vgmi_fastq* f, size_t n_bytes, int at_eof, size_t* ta
         b.state = f->d_state;
         b.cap_lines = f->cap_lines;
         b.tail_max = f->tail_max;
-        HIPCHK(c, launch_fastq_chunk(b, (uint32_t)text, f->stream));
-        rc = launch_count(c, reinterpret_cast<const char*>(f->d_packed), f->tail_max + text, nullptr, 0, f->stream, &f->d_state->packed_bytes);
+        HIPCHK(c, launch_fastq_chunk(b, (uint32_t)text_total, f->stream));
+        const int rc = launch_count(c, reinterpret_cast<const char*>(f->d_packed), f->tail_max + text_total, nullptr, 0, f->stream, &f->d_state->packed_bytes);
         if (rc) return rc;
         f->next = i ^ 1;
     }

@@ -665,6 +665,132 @@ __global__ __launch_bounds__(256) void gz_resolve_kernel(const uint16_t* __restr
     }
 }
 
+// ---- 5. CRC-32 of the resolved text -------------------------------------------------------------------------------------------
+// What zlib checks at a member's trailer (gzread behind include/kseq.h:59-72): the chain of block starts proves the stretches'
+// boundaries, not the windows and placeholders behind them -- the CRC does.  Computed in the LINEAR form R(M) = M(x) x^32 mod p
+// (register starts at 0, no final inversion): R ignores zero bytes in front, so the text is cut into pieces counted from its END
+// and every piece but a virtual zero-filled first one is whole -- one constant multiplier per level of every tree:
+//     R(A || B) = R(A) x^(8 |B|) + R(B),        crc32(M) = R(M) ^ 0xFFFFFFFF x^(8 |M|) ^ 0xFFFFFFFF.
+// gz_crc_kernel: a workgroup per GZ_CRC_CHUNK bytes, a lane per 64 of them out of LDS; gz_crc_fold_kernel: one workgroup folds the
+// chunks' remainders and appends the piece to the member's running remainder and length (GzCrcState, device-resident across pieces).
+#define GZ_POLY 0xEDB88320u
+#define GZ_CRC_CHUNK 16384u
+__host__ __device__ constexpr uint32_t gz_gf2_mul(uint32_t a, uint32_t b)      // a(x) b(x) mod p(x); bit 31 = x^0
+{
+    uint32_t p = 0;
+    for (uint32_t m = 1u << 31; m; m >>= 1) {
+        if (a & m) p ^= b;
+        b = (b & 1u) ? (b >> 1) ^ GZ_POLY : b >> 1;
+    }
+    return p;
+}
+__host__ __device__ constexpr uint32_t gz_gf2_x8n(uint64_t n)                  // x^(8 n) mod p(x)
+{
+    uint32_t p = 1u << 31, sq = 0x00800000u;
+    for (; n; n >>= 1) {
+        if (n & 1u) p = gz_gf2_mul(sq, p);
+        sq = gz_gf2_mul(sq, sq);
+    }
+    return p;
+}
+template <uint32_t B>
+__device__ __forceinline__ uint32_t gz_mul_const(uint32_t a)                   // a(x) B(x): B's 32 shifts are immediates
+{
+    uint32_t p = 0, b = B;
+#pragma unroll
+    for (uint32_t j = 0; j < 32; ++j) {
+        p ^= (a >> (31u - j) & 1u) ? b : 0u;
+        b = (b & 1u) ? (b >> 1) ^ GZ_POLY : b >> 1;
+    }
+    return p;
+}
+template <uint32_t LVL>
+__device__ __forceinline__ void gz_crc_tree(uint32_t* s, uint32_t lane)         // s[0] = R of 256 slices of 64 bytes
+{
+    if constexpr (LVL < 8) {
+        constexpr uint32_t step = 1u << LVL;
+        if ((lane & (2u * step - 1u)) == 0) s[lane] = gz_mul_const<gz_gf2_x8n(64ull * step)>(s[lane]) ^ s[lane + step];
+        __syncthreads();
+        gz_crc_tree<LVL + 1>(s, lane);
+    }
+}
+
+__global__ __launch_bounds__(256) void gz_crc_kernel(const uint8_t* __restrict__ text, uint64_t n, uint32_t n_chunks, uint32_t* __restrict__ chunk_r)
+{
+    __shared__ uint32_t s_tab[256];
+    __shared__ uint32_t s_data[256 * 17];      // a lane's 16 words + one of padding (bank = lane + word)
+    __shared__ uint32_t s_r[256];
+    const uint32_t lane = threadIdx.x;
+    {
+        uint32_t c = lane;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ GZ_POLY : c >> 1;
+        s_tab[lane] = c;
+    }
+    // chunk b holds the bytes [n - (n_chunks - b) CHUNK, + CHUNK); what lies in front of byte 0 reads as zero
+    const int64_t base = (int64_t)n - (int64_t)(n_chunks - blockIdx.x) * (int64_t)GZ_CRC_CHUNK;
+    for (uint32_t w = lane; w < GZ_CRC_CHUNK / 4u; w += 256u) {
+        const int64_t at = base + 4 * (int64_t)w;
+        uint32_t v = 0;
+        if (at >= 0 && !(reinterpret_cast<uintptr_t>(text + at) & 3u)) v = *reinterpret_cast<const uint32_t*>(text + at);
+        else
+            for (int k = 0; k < 4; ++k)
+                if (at + k >= 0) v |= (uint32_t)text[at + k] << (8 * k);
+        s_data[(w >> 4) * 17u + (w & 15u)] = v;
+    }
+    __syncthreads();
+    uint32_t c = 0;
+#pragma unroll 4
+    for (uint32_t w = 0; w < 16; ++w) {
+        const uint32_t v = s_data[lane * 17u + w];
+        c = s_tab[(c ^ v) & 0xFFu] ^ (c >> 8);
+        c = s_tab[(c ^ (v >> 8)) & 0xFFu] ^ (c >> 8);
+        c = s_tab[(c ^ (v >> 16)) & 0xFFu] ^ (c >> 8);
+        c = s_tab[(c ^ (v >> 24)) & 0xFFu] ^ (c >> 8);
+    }
+    s_r[lane] = c;
+    __syncthreads();
+    gz_crc_tree<0>(s_r, lane);
+    if (lane == 0) chunk_r[blockIdx.x] = s_r[0];
+}
+
+__global__ __launch_bounds__(1024) void gz_crc_fold_kernel(const uint32_t* __restrict__ chunk_r, uint32_t n_chunks, uint64_t n, GzCrcState* __restrict__ state)
+{
+    __shared__ uint32_t s_r[1024];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t per = (n_chunks + 1023u) / 1024u;
+    // lane l folds the chunks [n_chunks - (1024 - l) per, + per): counted from the end again, chunks in front of the first are zero
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < per; ++i) {
+        const int64_t b = (int64_t)n_chunks - (int64_t)(1024u - lane) * per + i;
+        r = gz_mul_const<gz_gf2_x8n(GZ_CRC_CHUNK)>(r) ^ (b >= 0 ? chunk_r[b] : 0u);
+    }
+    s_r[lane] = r;
+    __syncthreads();
+    uint32_t x = gz_gf2_x8n((uint64_t)GZ_CRC_CHUNK * per);
+    for (uint32_t step = 1; step < 1024u; step <<= 1) {
+        if ((lane & (2u * step - 1u)) == 0) s_r[lane] = gz_gf2_mul(s_r[lane], x) ^ s_r[lane + step];
+        x = gz_gf2_mul(x, x);
+        __syncthreads();
+    }
+    if (lane == 0) {
+        state->r = gz_gf2_mul(state->r, gz_gf2_x8n(n)) ^ s_r[0];
+        state->len += n;
+    }
+}
+
+hipError_t launch_gz_crc(const uint8_t* text, uint64_t n, uint32_t* chunk_r, GzCrcState* state, hipStream_t st)
+{
+    if (!n) return hipSuccess;
+    const uint32_t n_chunks = (uint32_t)((n + GZ_CRC_CHUNK - 1) / GZ_CRC_CHUNK);
+    hipLaunchKernelGGL(gz_crc_kernel, dim3(n_chunks), dim3(256), 0, st, text, n, n_chunks, chunk_r);
+    hipLaunchKernelGGL(gz_crc_fold_kernel, dim3(1), dim3(1024), 0, st, chunk_r, n_chunks, n, state);
+    return hipGetLastError();
+}
+size_t gz_crc_chunks(size_t n_text) { return (n_text + GZ_CRC_CHUNK - 1) / GZ_CRC_CHUNK; }
+// the member's CRC-32 from its running remainder and length
+uint32_t gz_crc_finish(uint32_t r, uint64_t len) { return r ^ gz_gf2_mul(0xFFFFFFFFu, gz_gf2_x8n(len)) ^ 0xFFFFFFFFu; }
+
 hipError_t launch_gz_find(const uint8_t* comp, uint32_t n_bytes, uint32_t sub_bytes, uint32_t n_sub, uint32_t per, uint32_t* starts, hipStream_t st)
 {
     if (!n_sub || !per) return hipSuccess;

@@ -173,6 +173,14 @@ hipError_t launch_gz_decode(const uint8_t* comp, uint32_t n_bytes, const void* s
 hipError_t launch_gz_resolve(const uint16_t* pool, const void* segs, const void* outs, const uint64_t* text_off, uint32_t n_seg, uint16_t* w1, uint8_t* t,
                              uint8_t* text, hipStream_t st);
 uint32_t gz_groups(uint32_t n_seg);
+// CRC-32 / ISIZE of a member's text as the pieces are resolved: the running remainder (linear form) and length, device-resident
+struct GzCrcState {
+    uint32_t r, pad;
+    uint64_t len;
+};
+hipError_t launch_gz_crc(const uint8_t* text, uint64_t n, uint32_t* chunk_r, GzCrcState* state, hipStream_t st);
+size_t gz_crc_chunks(size_t n_text);
+uint32_t gz_crc_finish(uint32_t r, uint64_t len);
 
 // ---- HMM recursion (vgmi_hmm.hip) ----
 struct HmmChain {

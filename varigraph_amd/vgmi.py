@@ -44,6 +44,10 @@ def load_library():
         "vgmi_table_clone": (i32, [vp, vp]),
         "vgmi_rccl_unique_id": (i32, [vp]),
         "vgmi_table_broadcast": (i32, [vp, i32, i32, vp]),
+        "vgmi_comm_create": (i32, [i32, i32, i32, vp, C.POINTER(vp)]),
+        "vgmi_table_broadcast_comm": (i32, [vp, vp]),
+        "vgmi_table_snapshot": (i32, [vp]),
+        "vgmi_comm_destroy": (None, [vp]),
         "vgmi_table_info": (i32, [vp, C.POINTER(sz), C.POINTER(u32), C.POINTER(sz), C.POINTER(sz)]),
         "vgmi_xtable_info": (i32, [vp, C.POINTER(sz), C.POINTER(sz)]),
         "vgmi_ctable_info": (i32, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
@@ -340,7 +344,12 @@ class Context:
             while True:
                 buf, cap = C.c_void_p(), C.c_size_t()
                 self._chk(self._l.vgmi_fastq_acquire(fq, C.byref(buf), C.byref(cap)))
-                room = (cap.value if piece is None else min(piece, cap.value)) - len(carry)
+                if isinstance(piece, (list, tuple)):      # a size per call (the last one from there on)
+                    want = piece[min(n_call, len(piece) - 1)]
+                else:
+                    want = piece
+                n_call += 1
+                room = (cap.value if want is None else min(want, cap.value)) - len(carry)
                 new = comp[pos:pos + max(room, 0)]
                 pos += len(new)
                 data = carry + new
@@ -367,13 +376,18 @@ class Context:
         fq = C.c_void_p()
         self._chk(self._l.vgmi_fastq_open(self._h, C.byref(fq)))
         comp = bytes(comp)
-        pos, carry, total_taken, stop = 0, b"", 0, 0
+        pos, carry, total_taken, stop, n_call = 0, b"", 0, 0, 0
         dtext, reason = C.c_uint64(), C.c_uint32()
         try:
             while True:
                 buf, cap = C.c_void_p(), C.c_size_t()
                 self._chk(self._l.vgmi_fastq_acquire(fq, C.byref(buf), C.byref(cap)))
-                room = (cap.value if piece is None else min(piece, cap.value)) - len(carry)
+                if isinstance(piece, (list, tuple)):      # a size per call (the last one from there on)
+                    want = piece[min(n_call, len(piece) - 1)]
+                else:
+                    want = piece
+                n_call += 1
+                room = (cap.value if want is None else min(want, cap.value)) - len(carry)
                 new = comp[pos:pos + max(room, 0)]
                 pos += len(new)
                 data = carry + new
