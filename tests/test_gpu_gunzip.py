@@ -157,8 +157,8 @@ def test_gzip_stream_scratch_grows_in_the_middle_of_a_member(monkeypatch):
         t.count_block(block, cohort.k)
         want = t.counts()
         comp = gzip.compress(text, 6)
-        assert len(comp) > 6_000_000
-        for sizes in ([150_000, 600_000, 6_000_000], [100_000, 200_000, 400_000, 800_000, 1_600_000, 3_200_000, 8_000_000]):
+        assert len(comp) > 5_000_000
+        for sizes in ([150_000, 600_000, 6_000_000], [100_000, 200_000, 400_000, 800_000, 1_600_000, 8_000_000]):
             c.counts_reset()
             r = c.fastq_gzip(comp, piece=sizes)
             got, _, _ = c.counts_finish()

@@ -862,7 +862,7 @@ def test_bloom_even_k_segmented_matches_sequential_oracle(ctx, k):
 # Small graphs (<= 65 536 k-mers): count27s_kernel and the path table (vgmi_ptable.hip).  The golden cohorts above run through
 # the default (12-mer grid + path table) in every test of this file; these add the shapes the path table has rare paths for and
 # keep the two A/B variants (hash-table drain, round 2's 16-mer kernel) in the matrix.
-def _small_graph(kind, rng):
+def _small_graph(kind, rng, k=27):
     from varigraph_amd import synth
     if kind == "repeats":
         # 120 diverged copies of one 300-bp element: every 12-mer of the element has dozens of places (> 4: the run goes to the
@@ -881,7 +881,7 @@ def _small_graph(kind, rng):
         n_var = 400
     pos = np.sort(rng.choice(np.arange(100, ref.size - 100), size=n_var, replace=False))
     alts = synth._ACGT[(synth._CODE[ref[pos]] + rng.integers(1, 4, size=n_var)) % 4]
-    keys = np.unique(vgmi.synth_snp_keys(ref, pos, alts, 27))
+    keys = np.unique(vgmi.synth_snp_keys(ref, pos, alts, k))
     hap1 = ref.copy()
     hap1[pos] = alts
     return keys, [ref, hap1]
@@ -1056,5 +1056,123 @@ def test_small_graph_saturation_through_the_path_table():
         t.reset()
         t.count_block(small, 27)
         assert np.array_equal(shallow, t.counts()) and shallow.max() < 255
+    finally:
+        c.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Round 5: small graphs of odd k = 19 .. 25 through count27s_kernel<true, K> (the grid of 8: two grid 12-mers per lane and row, runs of
+# K + 7 bases, 8 windows each) and the path table laid out for k.  VGMI_SMALLK=0 keeps the generic row kernel: the A/B reference.
+@pytest.mark.parametrize("kind", ["plain", "repeats", "dense-sites"])
+@pytest.mark.parametrize("k", [19, 21, 23, 25])
+def test_small_graph_other_odd_k_fast_path_matches_oracle(kind, k):
+    rng = np.random.default_rng({"plain": 1, "repeats": 2, "dense-sites": 3}[kind] + k)
+    keys, haps = _small_graph(kind, rng, k)
+    assert 1000 < keys.size <= 65536, keys.size
+    n_reads = 60_000
+    block = vgmi.synth_reads_host(23 + k, 0, n_reads, 150, haps)
+    b2 = block.copy()
+    idx = rng.choice(b2.size, size=3000, replace=False)
+    idx = idx[b2[idx] != 10]
+    b2[idx[:1500]] = ord("N")
+    b2[idx[1500:]] |= 0x20
+    c = vgmi.Context(0, buffer_mib=16)
+    try:
+        import torch
+        c.table_upload(keys, k)
+        t = o.Table(keys)
+        for blk in (block, b2):
+            c.counts_reset()
+            cuts = [0, 16 * 1000, 16 * 1000 + 16 * 37, n_reads]
+            for a, e in zip(cuts[:-1], cuts[1:]):
+                c.reads_submit(blk[a * 151:e * 151], e - a)
+            cov, _, _ = c.counts_finish()
+            t.reset()
+            t.count_block(blk, k)
+            want = t.counts()
+            assert np.array_equal(cov, want), (kind, k, int((cov != want).sum()))
+            # the same block resident on the device (the kernel reads its length from device memory on the FASTQ path; here the host's)
+            c.counts_reset()
+            d = torch.from_numpy(blk).cuda()
+            c.reads_submit_device(d, d.numel(), n_reads)
+            cov_d, _, _ = c.counts_finish()
+            assert np.array_equal(cov_d, want), (kind, k, "device")
+        assert int(cov.astype(np.int64).sum()) > 50_000
+        ms, launches = c.count_kernel_ms()
+        assert launches > 0
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("k", [19, 25])
+def test_small_graph_other_odd_k_every_kmer_counted_once_at_any_alignment(k):
+    """The alignment matrix of test_every_kmer_counted_once_at_any_alignment for the grid of 8: a 400-base sequence whose k-mers are
+    all graph k-mers at assorted stream offsets -- row and row-pair boundaries, the last positions in front of the ragged tail (the
+    fast kernel covers every end inside its complete row pairs, the generic kernel starts at the first byte behind them)."""
+    rng = np.random.default_rng(k)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    S = acgt[rng.integers(0, 4, size=400)].tobytes()
+    keys_pos = o.sketch(S, k)
+    uk, inv = np.unique(keys_pos, return_inverse=True)
+    want = np.bincount(inv, minlength=uk.size).astype(np.uint8)
+    c = vgmi.Context(0)
+    try:
+        c.table_upload(uk, k)
+        for pre in [0, 1, 5, 7, 8, 9, 13, 100, 1000, 1019, 1023, 1024, 1025, 1500, 1630, 1640, 1647, 1648, 1649, 2040, 2047, 2048, 2049, 3000, 4090, 5000]:
+            for post in [0, 3000]:
+                filler = (b"N" * pre + b"\n") if pre else b""
+                tail = (b"N" * post + b"\n") if post else b""
+                blk = np.frombuffer(filler + S + b"\n" + tail, dtype=np.uint8)
+                c.counts_reset()
+                c.reads_submit(blk, 1 + (1 if pre else 0) + (1 if post else 0))
+                cov, _, _ = c.counts_finish()
+                assert np.array_equal(cov, want), (k, pre, post, int((cov != want).sum()))
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("k", [21, 23])
+def test_small_graph_other_odd_k_low_complexity_and_saturation(k, monkeypatch):
+    """Homopolymers, dinucleotide repeats, an element and its reverse complement: 12-mers with many places, palindromic 12-mers, k-mers
+    next to their own reverse complement -- and enough reads that counters pass 254 -> 255 (saturation bits at both places of the
+    path table, cleared by the reset).  The generic row kernel on the same table (VGMI_GENERIC_KERNEL through force_generic) agrees."""
+    rng = np.random.default_rng(9 + k)
+    seq = _low_complexity_sequence(rng)
+    keys = np.unique(o.sketch(seq, k))
+    assert 3000 < keys.size <= 65536, keys.size
+    from varigraph_amd import synth
+    other = seq.copy()
+    mut = rng.random(other.size) < 0.02
+    other[mut] = synth._ACGT[(synth._CODE[other[mut]] + rng.integers(1, 4, size=int(mut.sum()))) % 4]
+    n_reads = 40_000
+    block = vgmi.synth_reads_host(31 + k, 0, n_reads, 150, [seq, other])
+    c = vgmi.Context(0, buffer_mib=16)
+    try:
+        c.table_upload(keys, k)
+        t = o.Table(keys)
+        t.count_block(block, k)
+        want = t.counts()
+        for rep in range(2):      # the second pass starts from a reset: saturation flags of the first are gone
+            c.counts_reset()
+            c.reads_submit(block, n_reads)
+            cov, _, _ = c.counts_finish()
+            assert np.array_equal(cov, want), (k, rep, int((cov != want).sum()))
+        assert (cov == 255).any() and (cov < 255).any() and int(cov.astype(np.int64).sum()) > 500_000
+        c.counts_reset()
+        c.reads_submit(block[:151 * 2000], 2000)
+        shallow, _, _ = c.counts_finish()
+        t.reset()
+        t.count_block(block[:151 * 2000], k)
+        assert np.array_equal(shallow, t.counts())
+    finally:
+        c.close()
+    monkeypatch.setenv("VGMI_SMALLK", "0")
+    c = vgmi.Context(0, buffer_mib=16)
+    try:
+        c.table_upload(keys, k)
+        c.counts_reset()
+        c.reads_submit(block, n_reads)
+        cov, _, _ = c.counts_finish()
+        assert np.array_equal(cov, want)
     finally:
         c.close()

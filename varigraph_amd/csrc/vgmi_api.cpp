@@ -102,6 +102,7 @@ struct vgmi_ctx {
     bool fast27 = false;         // k = 27: count27_kernel
     bool fast27_lds = false;     // ... with the 128 KiB grid filter resident in LDS
     bool fast27_small = false;   // ... over 12-mers: count27s_kernel (the default for graphs of <= 65 536 k-mers)
+    bool fastk_small = false;    // odd k = 19 .. 25, graphs of <= 65 536 k-mers: the same kernel on a grid of 8 (two grid 12-mers per lane and row)
     uint32_t wgs_per_cu = 0;     // VGMI_WGS_PER_CU: tuning override for the global-bitmap variant
     bool force_generic = false;  // VGMI_GENERIC_KERNEL=1: take the generic row kernel (A/B testing)
 
@@ -235,7 +236,10 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     h.n_keys = n_keys;
     // k = 27: compact 8-byte slots (a minimiser bucket of 32 is two 128-byte lines, its counters one); small graphs
     // spend the same bytes on twice the slots
-    const bool compact = k == 27 && !getenv("VGMI_WIDE_SLOTS");   // 8-byte k-mer words + per-slot counters
+    // ... and so do small graphs of odd k = 19 .. 25: the 12-mer grid and the path table serve them too (count27s_kernel<true, K>, round 5;
+    // VGMI_SMALLK=0 keeps them on the generic row kernel, the A/B reference)
+    const bool smallk = (k & 1) && k >= 19 && k <= 25 && n_keys <= VG_GRID_LDS_MAX_KEYS && !(getenv("VGMI_SMALLK") && getenv("VGMI_SMALLK")[0] == '0');
+    const bool compact = (k == 27 || smallk) && !getenv("VGMI_WIDE_SLOTS");   // 8-byte k-mer words + per-slot counters
     h.slot_bytes = compact ? 8 : 16;
     uint64_t cap = 64;
     uint64_t lf_mul = compact ? 8 : 4;   // load factor <= 0.125 / 0.25: nearly every probe ends at the first slot
@@ -268,7 +272,7 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     h.grid_words_log2 = 0;
     h.off_grid = 0;
     uint64_t end = h.off_filter + (4ULL << h.filter_words_log2);
-    if (k == 27) {
+    if (k == 27 || (smallk && compact)) {
         uint32_t b = VG_GRID_LDS_WORDS_LOG2;
         uint64_t entry_bytes = 4;
         if (n_keys > VG_GRID_LDS_MAX_KEYS) {
@@ -315,6 +319,8 @@ int adopt_image(vgmi_ctx* c)
                                                                   // slots, or global (64-bit entry) filter + 16-byte slots
     c->fast27_lds = c->fast27 && lds_grid;
     c->fast27_small = c->fast27_lds && h.grid_mer == 12;   // count27s_kernel
+    c->fastk_small = h.k != 27 && compact && h.off_grid && lds_grid && h.grid_mer == 12;   // count27s_kernel<true, K>, K = 19 .. 25
+    c->tv.k = h.k;
     c->d_key_slot = reinterpret_cast<uint32_t*>(c->d_image + h.off_key_slot);
     c->filter_in_lds = filter_fits_lds(h.filter_words_log2);
     HIPCHK(c, hipMalloc(&c->d_cov, h.n_keys ? h.n_keys : 1));
@@ -595,7 +601,10 @@ int build_ptable(vgmi_ctx* c)
 {
     const ImageHeader& h = c->hdr;
     c->tv.pt = PathView{};
-    if (!c->fast27_small || h.n_keys == 0) return VGMI_OK;
+    if (!(c->fast27_small || c->fastk_small) || h.n_keys == 0) return VGMI_OK;
+    const uint32_t K = h.k;                     // 27, or 19 .. 25 (the grid of 8)
+    // the run a lane compares: lead bases in front of the grid 12-mer, the 12-mer, the bases behind it (vgmi_kernels.hip)
+    const uint32_t lead = K == 27 ? 15u : K - 12u;
     if (const char* e = getenv("VGMI_PTABLE"))
         if (e[0] == '0') return VGMI_OK;
     const uint64_t n = h.n_keys;
@@ -635,17 +644,17 @@ int build_ptable(vgmi_ctx* c)
     HIPCHK(c, he);
 
     // ---- layout (host).  P[0, n): the k-mers chain after chain, each in the orientation its chain is walked in; P[2n - 1 - i] is
-    // the reverse complement of P[i].  A chain of L k-mers is L + 26 bases; the chains follow each other without a gap, the
+    // the reverse complement of P[i].  A chain of L k-mers is L + k - 1 bases; the chains follow each other without a gap, the
     // second half of S is the reverse complement of the first, 32 bases of padding at either end.
-    const uint64_t M54 = (1ULL << 54) - 1;
+    const uint64_t M54 = (1ULL << (2 * K)) - 1;      // (the k-mer's 2k bits)
     std::vector<uint32_t> kpos(n);
     uint64_t chains = 0;
     for (uint64_t i = 0; i < n; ++i) {
         const uint64_t a = i ? (uint64_t)P[i - 1].x & M54 : 0, b = (uint64_t)P[i].x & M54;
         if (i == 0 || (b >> 2) != (a & (M54 >> 2))) ++chains;
-        kpos[i] = (uint32_t)(i + 26 * (chains - 1));
+        kpos[i] = (uint32_t)(i + (K - 1) * (chains - 1));
     }
-    const uint64_t Th = n + 26 * chains, T = 2 * Th, Tp = T + 64;
+    const uint64_t Th = n + (K - 1) * chains, T = 2 * Th, Tp = T + 64;
     if (Tp + 64 >= (1u << 19) - 1) return VGMI_OK;      // places are 19-bit fields: a graph of very many very short chains keeps the hash table
     std::vector<uint8_t> base(Tp, 0), vb(Tp, 0);
     std::vector<uint32_t> slot(Tp, 0), chain_end(Tp, 0);       // chain_end[start of a chain's span] = its end (first half, unpadded)
@@ -653,15 +662,15 @@ int build_ptable(vgmi_ctx* c)
         uint64_t span_start = 0;
         for (uint64_t i = 0; i < n; ++i) {
             const uint64_t km = (uint64_t)P[i].x & M54;
-            for (uint32_t t = 0; t < 27; ++t) base[32 + kpos[i] + t] = (uint8_t)((km >> (2 * (26 - t))) & 3u);
+            for (uint32_t t = 0; t < K; ++t) base[32 + kpos[i] + t] = (uint8_t)((km >> (2 * (K - 1 - t))) & 3u);
             vb[32 + kpos[i]] = 1;
             slot[32 + kpos[i]] = (uint32_t)P[i].y;
-            vb[32 + T - 27 - kpos[i]] = 1;
-            slot[32 + T - 27 - kpos[i]] = (uint32_t)P[i].y;
+            vb[32 + T - K - kpos[i]] = 1;
+            slot[32 + T - K - kpos[i]] = (uint32_t)P[i].y;
             const bool last_of_chain = i + 1 == n || kpos[i + 1] != kpos[i] + 1;
             if (last_of_chain) {
-                chain_end[span_start] = (uint32_t)(kpos[i] + 27);
-                span_start = kpos[i] + 27;
+                chain_end[span_start] = (uint32_t)(kpos[i] + K);
+                span_start = kpos[i] + K;
             }
         }
         for (uint64_t j = 0; j < Th; ++j) base[32 + T - 1 - j] = (uint8_t)(3u - base[32 + j]);
@@ -674,7 +683,7 @@ int build_ptable(vgmi_ctx* c)
         if (vb[j]) VB[j >> 5] |= 1u << (j & 31);
     }
     // index: every occurrence of a 12-mer inside a chain's span that reads as its canonical form lists the place of the run's
-    // first base (15 bases in front of it); the occurrence on the other strand is listed from the mirrored half
+    // first base (`lead` bases in front of it); the occurrence on the other strand is listed from the mirrored half
     // bucket = two 16-byte entries.  Entry: word 0 = 12-mer | place 0 << 24 | place 1 << 43 | (first entry only) "a 12-mer found no
     // entry here" << 62; word 1 = place 2 | place 3 << 19 | "more than four places" << 38.  Place 0 = 0: the entry is free.
     std::vector<unsigned long long> index((size_t)4 << bucket_log2, 0ULL);
@@ -712,7 +721,7 @@ int build_ptable(vgmi_ctx* c)
                 x = ((x << 2) | base[32 + b]) & 0xFFFFFFu;
                 if (b + 1 < lo + 12) continue;
                 const uint64_t first = b + 1 - 12;                       // the 12-mer is bases first .. first + 11
-                if (x <= vg_revcomp12(x)) add(x, (uint32_t)(32 + first - 15));
+                if (x <= vg_revcomp12(x)) add(x, (uint32_t)(32 + first - lead));
             }
         }
         s0 = e0;
@@ -837,9 +846,9 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
             else HIPCHK(c, launch_count27x(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
             p.tail27 = 2;
             HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, 1, block, st));
-        } else if (c->fast27_small && !c->force_generic) {
+        } else if ((c->fast27_small || (c->fastk_small && c->tv.pt.index)) && !c->force_generic) {
             HIPCHK(c, launch_count27s(p, (uint32_t)c->n_cu, st));
-            p.tail27 = 3;
+            p.tail27 = c->fast27_small ? 3 : 4;
             HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, 1, block, st));
         } else if (c->fast27 && !c->force_generic) {
             uint32_t g27, b27;
@@ -870,15 +879,15 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
                 p.row_begin = emit_from >> 10;
                 HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, 1, block, st));
             }
-        } else if (c->fast27_small && !c->force_generic) {
+        } else if ((c->fast27_small || (c->fastk_small && c->tv.pt.index)) && !c->force_generic) {
             // complete pairs of 1 024-byte rows -> count27s_kernel: lane L of a row covers the k-mers ending at stream positions
-            // 16 L - 1 .. 16 L + 14 of the row; the generic kernel takes the ends behind the last pair, from the last position of
-            // the last full row on
+            // 16 L - 1 .. 16 L + 14 of the row (k < 27, the grid of 8: 16 L .. 16 L + 15); the generic kernel takes the ends behind
+            // the last pair, from the last position of the last full row on (k < 27: from the first position behind it)
             p.row_end = (n_bytes / 2048) * 2;
             uint64_t emit_from = 0;
             if (p.row_end) {
                 HIPCHK(c, launch_count27s(p, (uint32_t)c->n_cu, st));
-                emit_from = p.row_end * 1024 - 1;
+                emit_from = p.row_end * 1024 - (c->fast27_small ? 1 : 0);
             }
             if (emit_from < n_bytes) {
                 p.emit_from = emit_from;

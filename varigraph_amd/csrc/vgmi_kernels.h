@@ -54,6 +54,7 @@ struct TableView {
     VgSlot* slots;              // cap entries (16-byte format) or nullptr
     unsigned long long* slots8; // cap k-mer words (compact 8-byte format) or nullptr
     uint64_t cap_mask;          // cap - 1 (cap is a power of two)
+    uint32_t k;                 // the k-mer length of the keys
     uint32_t home_bucket_log2;  // 0: home slot = vg_thash; else minimiser buckets of 1 << this slots (vg_thash_local)
     uint32_t home_by_offset;    // place inside the bucket from the minimiser's offset (neighbouring k-mers -> neighbouring slots)
     const uint32_t* filter;     // blocked-Bloom prefilter, 1 << filter_words_log2 words
@@ -93,7 +94,7 @@ struct RowParams {
     const unsigned long long* n_bytes_dev;   // count kernels: when set, the block's length is read from device memory (the
                           // device-side FASTQ parser knows it, the host does not) and n_bytes / row_end / row_begin /
                           // emit_from are derived from it in the kernel; tail27 tells rows_kernel it runs behind count27_kernel
-    uint32_t tail27;      // 1 behind count27_kernel, 2 behind count27x_kernel, 3 behind count27s_kernel
+    uint32_t tail27;      // 1 behind count27_kernel, 2 behind count27x_kernel, 3 behind count27s_kernel, 4 behind count27s_kernel<true, K < 27> (it covers every end inside its rows)
     uint32_t l1_min;      // count27s_kernel<true>: queued runs that start a round of the path-table look-up (VGMI_L1_MIN; default 60, at most 64: one lane per run)
     TableView table;      // MODE_COUNT
     uint64_t* keys_out;   // MODE_KEYS

@@ -298,9 +298,9 @@ __global__ __launch_bounds__(1024) void rows_kernel(RowParams p)
         emit_from = 0;
         if (p.tail27) {   // behind count27_kernel: the ends it does not cover (see launch_count in vgmi_api.cpp)
             // 1: count27_kernel (pairs of 768-byte rows), 2: count27x_kernel (single rows), 3: count27s_kernel (pairs of 1 024-byte rows)
-            const uint64_t row_bytes = p.tail27 == 3 ? 1024u : 768u;
+            const uint64_t row_bytes = p.tail27 >= 3 ? 1024u : 768u;
             const uint64_t row_end27 = p.tail27 == 2 ? n_bytes / 768 : (n_bytes / (2 * row_bytes)) * 2;
-            emit_from = row_end27 ? row_end27 * row_bytes - 1 : 0;
+            emit_from = row_end27 ? row_end27 * row_bytes - (p.tail27 == 4 ? 0u : 1u) : 0;
         }
         row_begin = emit_from >> 10;
         if (emit_from >= n_bytes) return;
@@ -1133,10 +1133,17 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
 #define VG_ROW27S 1024u
 #define VG_RUN_BATCH_S 4u
 
-template <bool PT>   // PT: candidate runs are looked up in the path table (vgmi_ptable.hip); else k-mer by k-mer in the hash table
+// K < 27 (odd, 19 .. 25; round 5, path table only): a k-mer of fewer than 27 bases need not contain a grid 12-mer of a grid of 16, so
+// the grid is 8 -- the SAME rows, loads, encode and neighbour exchange, but every lane looks at TWO grid positions per row, g = its
+// own base 0 and its own base 8, and each owns the 8 k-mers that end at g .. g + 7 (all of them contain the 12-mer that ends at g:
+// K - 12 >= 7).  A run is the K + 7 bases q[g - K + 1, g + 7] (<= 32 bases: two words), K - 12 in front of the 12-mer and 7 behind
+// it; the path table lists a 12-mer's places K - 12 bases in front of it (build_ptable), a read that carries it reversed is
+// compared at Tp - (2 K - 12) - place.  A lane of a row covers the ends 16 L .. 16 L + 15: every end inside the rows (tail27 = 4).
+template <bool PT, uint32_t K = 27>   // PT: candidate runs are looked up in the path table (vgmi_ptable.hip); else k-mer by k-mer in the hash table
 __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
 {
-    constexpr uint32_t MASK_HI = (1u << (2 * 27 - 32)) - 1;
+    static_assert(K == 27 || (PT && (K & 1u) && K >= 19 && K <= 25), "count27s_kernel: k = 27, or the path-table form for odd k = 19 .. 25");
+    constexpr uint32_t MASK_HI = (1u << (2 * K - 32)) - 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -1196,7 +1203,7 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
     };
 
     auto probe_issue = [&](bool act, uint64_t kmer, uint64_t dist) __attribute__((always_inline)) {
-        const uint64_t rc = vg_revcomp(kmer, 27);
+        const uint64_t rc = vg_revcomp(kmer, K);
         const uint64_t canon = kmer < rc ? kmer : rc;   // idempotent for re-queued (already canonical) entries
         b_canon = canon | (dist << 54);
         b_slot = (vg_thash(canon) + dist) & cap_mask;
@@ -1239,7 +1246,7 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
     };
     auto slow_count = [&](uint32_t klo, uint32_t khi) __attribute__((always_inline)) {
         // a window of a run whose 12-mer the index does not cover: through the hash table, on the spot (rare)
-        const uint64_t kmer = (uint64_t)khi << 32 | klo, rc = vg_revcomp(kmer, 27);
+        const uint64_t kmer = (uint64_t)khi << 32 | klo, rc = vg_revcomp(kmer, K);
         const uint64_t canon = kmer < rc ? kmer : rc;
         uint64_t sl = vg_thash(canon) & cap_mask;
         for (;;) {
@@ -1290,7 +1297,7 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
         // more places than the entry holds, or a 12-mer that found no entry in its bucket: the hash table decides, window by window
         l1_slow = act && (found ? more : ((e0.y >> 30) & 1u) != 0);
         const bool ok = act && found && !more;
-        const uint32_t flip = pt_Tp - 42u;
+        const uint32_t flip = pt_Tp - (K == 27 ? 42u : 2u * K - 12u);      // the run's length less the lead's asymmetry (build_ptable)
         pl[0] = ok ? (as_is ? q0 : flip - q0) : 0u;
         pl[1] = ok && q1 != 0 ? (as_is ? q1 : flip - q1) : 0u;
         pl[2] = ok && q2 != 0 ? (as_is ? q2 : flip - q2) : 0u;
@@ -1316,6 +1323,26 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
     };
     // phase 3, per place: the windows of the run that equal the k-mers starting at place .. place + 15, less the saturated ones
     auto windows_at = [&](uint32_t place, const uint4 sq, const uint4 bits, uint32_t vm16, uint32_t& hits) __attribute__((always_inline)) -> uint32_t {
+        if constexpr (K != 27) {
+            // the K + 7 bases from `place` on, aligned like the run's 2 (K + 7) bits (base r at bits 2 (K + 6 - r)): the 128-bit
+            // big-endian stream sq.x : y : z : w shifted right by 128 - 2 (K + 7) - 2 (place mod 16) = 34 .. 76
+            const uint32_t sh = 128u - 2u * (K + 7u) - 2u * (place & 15u);
+            const bool far = sh >= 64u;
+            const uint32_t x0 = funnel(far ? sq.x : sq.y, far ? sq.y : sq.z, sh & 31u);
+            const uint32_t x1 = funnel(far ? 0u : sq.x, far ? sq.x : sq.y, sh & 31u);
+            const uint32_t d0 = x0 ^ l1_run.x, d1 = (x1 ^ l1_run.y) & ((K + 7u == 32u) ? 0xFFFFFFFFu : (1u << ((2u * (K + 7u) - 32u) & 31u)) - 1u);
+            // the 7 bases behind the 12-mer are bits [0, 14): the mismatch nearest to it (highest bit) ends the windows
+            const uint32_t tr = (d0 | (d0 >> 1)) & 0x1555u;
+            const uint32_t mask_r = tr ? (1u << (7u - ((31u - (uint32_t)__builtin_clz(tr)) >> 1))) - 1u : 0xFFu;
+            // the K - 12 bases in front of it are bits [38, 2 K + 14): the mismatch nearest to it (lowest bit) starts them
+            const uint32_t fl = d1 >> 6;
+            const uint32_t tl = (fl | (fl >> 1)) & 0x1555555u;
+            const uint32_t mask_l = tl ? ~((2u << (K - 13u - ((uint32_t)__builtin_ctz(tl) >> 1))) - 1u) & 0xFFu : 0xFFu;
+            const uint32_t starts = funnel(bits.y, bits.x, place & 31u) & 0xFFu;
+            const uint32_t sats = funnel(bits.w, bits.z, place & 31u) & 0xFFu;
+            hits = mask_l & mask_r & starts & vm16;
+            return hits & ~sats;
+        }
         // the 42 bases from `place` on, aligned like the run's 84 bits: the 128-bit big-endian stream sq.x : y : z : w shifted
         // right by 44 - 2 (place mod 16)
         const uint32_t sh = 44u - 2u * (place & 15u);
@@ -1361,7 +1388,7 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
                         // and the slow path look there) and at both of its places in the path table
                         vm_atomic_or_sync(reinterpret_cast<uint32_t*>(&slots8[sl[q]]) + 1, (uint32_t)(VG_SLOT_SAT >> 32));
                         vm_store_byte_sync(p.table.sat_dirty + (sl[q] >> VG_SAT_REGION_LOG2), 1u);
-                        const uint32_t mir = pt_Tp - 27u - pos[q];
+                        const uint32_t mir = pt_Tp - K - pos[q];
                         vm_atomic_or_sync(ptSB + (pos[q] >> 5), 1u << (pos[q] & 31u));
                         vm_atomic_or_sync(ptSB + (mir >> 5), 1u << (mir & 31u));
                     }
@@ -1371,7 +1398,7 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
     };
     auto resolve_compare = [&]() __attribute__((always_inline)) {
         vm_wait4(n_after_seq);
-        const uint32_t vm16 = (l1_run.z >> 20) | ((l1_run.w >> 28) << 12);
+        const uint32_t vm16 = K == 27 ? (l1_run.z >> 20) | ((l1_run.w >> 28) << 12) : l1_run.z & 0xFFu;      // (K < 27: 8 windows, kept in z)
         uint32_t hits = 0, todo[4] = {0u, 0u, 0u, 0u};
         if (pl[0] != 0) todo[0] = windows_at(pl[0], vmp_seq_value<0>(), vmp_bits_value<0>(), vm16, hits);
         if (pl[1] != 0) todo[1] = windows_at(pl[1], vmp_seq_value<1>(), vmp_bits_value<1>(), vm16, hits);
@@ -1396,6 +1423,14 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
                 left &= left - 1;
                 const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)l1_run.x, (int)src), ry = (uint32_t)__builtin_amdgcn_readlane((int)l1_run.y, (int)src);
                 const uint32_t rz = (uint32_t)__builtin_amdgcn_readlane((int)l1_run.z, (int)src), rw = (uint32_t)__builtin_amdgcn_readlane((int)l1_run.w, (int)src);
+                if constexpr (K != 27) {
+                    // (window j = the K bases from run base j on: bits [2 (7 - j), + 2 K) of the run's two words)
+                    if (lane < 8u && (((rz & 0xFFu) >> lane) & 1u)) {
+                        const uint32_t sh2 = 2u * (7u - lane);
+                        slow_count(funnel(ry, rx, sh2), (ry >> sh2) & MASK_HI);
+                    }
+                    continue;
+                }
                 const uint32_t v16 = (rz >> 20) | ((rw >> 28) << 12);
                 if (lane < 16u && ((v16 >> lane) & 1u)) {
                     const uint32_t sh2 = 2u * (15u - lane);
@@ -1542,6 +1577,38 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
                 *reinterpret_cast<lds_u4_rw*>((uintptr_t)(runs_base + ring_slot(pos) * 16u)) = u32x4{d0, d1, d2, r.vm};
         }
     };
+    // K < 27: grid position H (0: g = the lane's own base 0, 1: its base 8) of one row.  g = q 32 + 8 H of the 48-base window; B bit i =
+    // base q g - K + 1 + i is no base (the span of the k-mer ending at g), a bit j = base g + j is none (j = 1 .. 7).  H is
+    // wave-uniform: every shift amount is a scalar.
+    auto scan_probe_k = [&](uint32_t be, uint32_t inv, uint32_t be1, uint32_t be2, uint32_t i1, uint32_t i2, uint32_t H) __attribute__((always_inline)) -> RowScan {
+        RowScan r;
+        r.W0 = be;
+        r.W1 = be1;
+        r.W2 = be2;
+        const uint32_t g = 32u + 8u * H;
+        const uint64_t I = (uint64_t)i2 | (uint64_t)i1 << 16 | (uint64_t)inv << 32;
+        const uint32_t B = (uint32_t)(I >> (g + 1u - K)) & ((1u << K) - 1u);
+        const uint32_t a = (uint32_t)(I >> g) & 0xFEu;
+        const uint32_t bad_b = B ? (0xFFFFFFFFu >> __builtin_clz(B)) : 0u;
+        r.vm = ~(a | (0u - a) | bad_b) & 0xFFu;
+        const uint32_t mer = funnel(be1, be, 30u - 16u * H) & 0xFFFFFFu, rcm = vg_revcomp12(mer);
+        const uint32_t cm = mer < rcm ? mer : rcm;
+        r.cm = cm | (mer <= rcm ? 1u << 24 : 0u);
+        const uint32_t h1 = vg_mul24(cm, 0x9E3779u), h2 = vg_mul24(cm, 0x85EBCBu);
+        r.gm = (1u << (h2 >> 27)) | (1u << ((h2 >> 22) & 31u)) | (1u << ((h2 >> 17) & 31u));
+        r.gw32 = *reinterpret_cast<lds_u32*>((uintptr_t)(((h1 >> (32 - VG_GRID_LDS_WORDS_LOG2)) << 2) + VG_LUT27_BYTES));
+        return r;
+    };
+    // ... its run: the 2 (K + 7) bits of q[g - K + 1, g + 7] | validity bits in z | canonical 12-mer and its orientation in w[0:25)
+    auto enqueue_k = [&](const RowScan& r, uint64_t ball, uint32_t tail, uint32_t H) __attribute__((always_inline)) {
+        if (__builtin_amdgcn_inverse_ballot_w64(ball)) {
+            const uint32_t sh = 16u - 16u * H;
+            const uint32_t d0 = funnel(r.W1, r.W0, sh);
+            const uint32_t d1 = funnel(r.W2, r.W1, sh) & ((K + 7u == 32u) ? 0xFFFFFFFFu : (1u << ((2u * (K + 7u) - 32u) & 31u)) - 1u);
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, tail));
+            *reinterpret_cast<lds_u4_rw*>((uintptr_t)(rq_base + rq_wrap(pos) * 16u)) = u32x4{d0, d1, r.vm, r.cm};
+        }
+    };
     auto empty_read_check = [&](uint32_t adj, const uint8_t* row) __attribute__((always_inline)) {
         // reference: assert(len > 0), src/kmer.cpp:124 -- two adjacent non-bases are necessary; exact test on the bytes
         if (adj) {
@@ -1607,6 +1674,24 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
             }
         }
 
+        if constexpr (K != 27) {
+            // the four grid positions of the pair, one after the other (one copy of the code: h is wave-uniform)
+#pragma unroll 1
+            for (uint32_t h = 0; h < 4u; ++h) {
+                const bool second = h >= 2u;
+                const RowScan sc = scan_probe_k(second ? beB : beA, second ? invB : invA, second ? beB1 : beA1, second ? beB2 : beA2,
+                                                second ? iB1 : iA1, second ? iB2 : iA2, h & 1u);
+                const uint64_t ball = __builtin_amdgcn_ballot_w64((sc.gw32 & sc.gm) == sc.gm && sc.vm != 0);
+                if (VG_DBG(p.dbg) & 1u) continue;
+                const uint32_t nh = (uint32_t)__builtin_popcountll(ball);
+                if (run_n + nh > RQ) make_room();
+                enqueue_k(sc, ball, run_head + run_n, h & 1u);
+                run_n += nh;
+            }
+            l1_advance();
+            if (l1_phase == 0 && run_n >= l1_min) resolve_issue();
+            continue;
+        }
         const RowScan sa = scan_probe(beA, invA, beA1, beA2, iA1, iA2);
         const RowScan sb = scan_probe(beB, invB, beB1, beB2, iB1, iB2);
         const uint64_t ballA = __builtin_amdgcn_ballot_w64((sa.gw32 & sa.gm) == sa.gm && sa.vm != 0);
@@ -1851,8 +1936,8 @@ __global__ void table_insert_kernel(TableView t, const uint64_t* keys, uint64_t 
     if (!t.slots8) t.slots[s].key_index = (uint32_t)i;
     key_slot[i] = (uint32_t)s;
     atomicOr(&filter_rw[vg_fhash_word(canon) >> t.filter_shift], vg_fhash_bits(canon, t.filter_words_log2));
-    if (grid_rw && grid12) {   // small graphs: the 16 twelve-mers of the k-mer (vgmi_device.h, VG_GRID12_*)
-        for (uint32_t off = 0; off < VG_GRID12_STEP; ++off) {
+    if (grid_rw && grid12) {   // small graphs: the k - 11 twelve-mers of the k-mer (16 at k = 27; vgmi_device.h, VG_GRID12_*)
+        for (uint32_t off = 0; off + 11u < k; ++off) {
             uint32_t w, m;
             vg_grid12_probe((uint32_t)(canon >> (2 * off)) & 0xFFFFFFu, w, m);
             atomicOr(&grid_rw[w], m);
@@ -2039,9 +2124,28 @@ static hipError_t launch_count27_t(const RowParams& p, uint32_t grid, uint32_t b
     return hipGetLastError();
 }
 
+template <uint32_t K>
+static hipError_t launch_countks_t(const RowParams& p, uint32_t grid, size_t lds, hipStream_t st)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&count27s_kernel<true, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((count27s_kernel<true, K>), dim3(grid), dim3(1024), lds, st, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_count27s(const RowParams& p, uint32_t grid, hipStream_t st)
 {
     const size_t lds = (size_t)VG_GRID_LDS_WORDS * 4 + (size_t)16 * (VG_RUNQ * 16 + VG_REQ * 8) + VG_LUT27_BYTES;
+    if (p.k != 27) {      // small graphs of odd k = 19 .. 25: the path-table form on the grid of 8
+        if (!p.table.pt.index) return hipErrorInvalidValue;
+        switch (p.k) {
+        case 19: return launch_countks_t<19>(p, grid, lds, st);
+        case 21: return launch_countks_t<21>(p, grid, lds, st);
+        case 23: return launch_countks_t<23>(p, grid, lds, st);
+        case 25: return launch_countks_t<25>(p, grid, lds, st);
+        default: return hipErrorInvalidValue;
+        }
+    }
     const void* fn = p.table.pt.index ? reinterpret_cast<const void*>(&count27s_kernel<true>) : reinterpret_cast<const void*>(&count27s_kernel<false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

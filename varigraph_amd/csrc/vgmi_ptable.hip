@@ -1,5 +1,5 @@
-// vgmi_ptable.hip -- the PATH TABLE of small graphs (k = 27, <= 65 536 k-mers: BASELINE config 2, the bench): what
-// count27s_kernel (vgmi_kernels.hip) looks candidate runs up in.
+// vgmi_ptable.hip -- the PATH TABLE of small graphs (k = 27, <= 65 536 k-mers: BASELINE config 2, the bench; round 5: odd k = 19 .. 25
+// as well, TableView::k): what count27s_kernel (vgmi_kernels.hip) looks candidate runs up in.  (The text below speaks of k = 27.)
 //
 // Same reference behaviour as every count kernel here: src/kmer.cpp:140-142 (exact membership of the canonical k-mer),
 // src/fastq_kmer.cpp:128-139 (saturating count).
@@ -33,7 +33,7 @@ namespace vgk {
 __device__ __forceinline__ uint32_t pt_find(const TableView& t, uint64_t canon)
 {
     // (large graphs -- the context table's numbering -- keep their home slots in minimiser buckets)
-    uint64_t s = (t.home_bucket_log2 ? vg_thash_local(canon, vg_revcomp(canon, 27), t.home_bucket_log2, t.home_by_offset != 0) : vg_thash(canon)) & t.cap_mask;
+    uint64_t s = (t.home_bucket_log2 ? vg_thash_local(canon, vg_revcomp(canon, t.k), t.home_bucket_log2, t.home_by_offset != 0) : vg_thash(canon)) & t.cap_mask;
     for (;;) {
         const uint64_t c = t.slots8[s];
         if (c == VG_EMPTY) return PT_NONE;
@@ -58,10 +58,11 @@ __global__ void pt_links_kernel(TableView t, const uint32_t* key_slot, const uin
     const uint64_t i = g >> 1;
     const uint32_t side = (uint32_t)g & 1u;
     const uint64_t K = t.slots8[key_slot[i]] & PT_MASK54;
+    const uint64_t kmask = (1ULL << (2 * t.k)) - 1;      // (k = 27 for the context table's numbering; 19 .. 27 for the path table)
     uint32_t found = PT_NONE, cnt = 0, enter = 0;
     for (uint64_t b = 0; b < 4; ++b) {
-        const uint64_t N = side ? ((K << 2) | b) & PT_MASK54 : (K >> 2) | (b << 52);
-        const uint64_t rc = vg_revcomp(N, 27);
+        const uint64_t N = side ? ((K << 2) | b) & kmask : (K >> 2) | (b << (2 * t.k - 2));
+        const uint64_t rc = vg_revcomp(N, t.k);
         const bool flipped = N > rc;
         const uint32_t s = pt_find(t, flipped ? rc : N);
         if (s == PT_NONE) continue;
@@ -142,7 +143,7 @@ __global__ void pt_fill_kernel(TableView t, const uint32_t* key_slot, const uint
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t slot = key_slot[i];
-    const uint64_t K = t.slots8[slot] & PT_MASK54, R = vg_revcomp(K, 27);
+    const uint64_t K = t.slots8[slot] & PT_MASK54, R = vg_revcomp(K, t.k);
     const uint32_t pk = pos_of_key ? pos_of_key[i] : ((uint32_t)i | 1u << 31);
     const uint64_t pos = pk & 0x7FFFFFFFu;
     const bool as_is = (pk >> 31) != 0;
