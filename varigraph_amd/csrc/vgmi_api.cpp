@@ -236,9 +236,10 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     h.n_keys = n_keys;
     // k = 27: compact 8-byte slots (a minimiser bucket of 32 is two 128-byte lines, its counters one); small graphs
     // spend the same bytes on twice the slots
-    // ... and so do small graphs of odd k = 19 .. 25: the 12-mer grid and the path table serve them too (count27s_kernel<true, K>, round 5;
+    // ... and so do small graphs of k = 19 .. 26: the 12-mer grid and the path table serve them too (count27s_kernel<true, K>, round 5;
     // VGMI_SMALLK=0 keeps them on the generic row kernel, the A/B reference)
-    const bool smallk = (k & 1) && k >= 19 && k <= 25 && n_keys <= VG_GRID_LDS_MAX_KEYS && !(getenv("VGMI_SMALLK") && getenv("VGMI_SMALLK")[0] == '0');
+    // (even k = 20 .. 26 as well: the kernel's rule is the odd one, seq_kernel<MODE_DEBIT> runs ahead of it with the reference's)
+    const bool smallk = k >= 19 && k <= 26 && n_keys <= VG_GRID_LDS_MAX_KEYS && !(getenv("VGMI_SMALLK") && getenv("VGMI_SMALLK")[0] == '0');
     const bool compact = (k == 27 || smallk) && !getenv("VGMI_WIDE_SLOTS");   // 8-byte k-mer words + per-slot counters
     h.slot_bytes = compact ? 8 : 16;
     uint64_t cap = 64;
@@ -663,9 +664,16 @@ int build_ptable(vgmi_ctx* c)
         for (uint64_t i = 0; i < n; ++i) {
             const uint64_t km = (uint64_t)P[i].x & M54;
             for (uint32_t t = 0; t < K; ++t) base[32 + kpos[i] + t] = (uint8_t)((km >> (2 * (K - 1 - t))) & 3u);
-            vb[32 + kpos[i]] = 1;
+            // (even k: a k-mer that is its own reverse complement is never emitted, src/kmer.cpp:134 -- no start bit, never counted)
+            bool own_rc = false;
+            if (!(K & 1u)) {
+                uint64_t r = 0;
+                for (uint32_t t = 0; t < K; ++t) r |= (3ull - ((km >> (2 * t)) & 3ull)) << (2 * (K - 1 - t));
+                own_rc = r == km;
+            }
+            vb[32 + kpos[i]] = !own_rc;
             slot[32 + kpos[i]] = (uint32_t)P[i].y;
-            vb[32 + T - K - kpos[i]] = 1;
+            vb[32 + T - K - kpos[i]] = !own_rc;
             slot[32 + T - K - kpos[i]] = (uint32_t)P[i].y;
             const bool last_of_chain = i + 1 == n || kpos[i + 1] != kpos[i] + 1;
             if (last_of_chain) {
@@ -923,7 +931,18 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
         }
     } else {
         if (!d_read_off) return fail(c, VGMI_E_INVALID, "even k needs read offsets");
-        HIPCHK(c, launch_seq(K_MODE_COUNT, p, d_read_off, n_reads, st));
+        if (c->fastk_small && c->tv.pt.index && !c->force_generic && n_bytes >= 2048) {
+            // k = 20 .. 26 on a small graph: the windows of k bases through count27s_kernel<true, K> (complete pairs of rows), in front of
+            // it the pass that takes back what the reference's run counter suppresses, behind it the literal state machine for the
+            // ends the rows do not cover
+            p.row_end = (n_bytes / 2048) * 2;
+            p.emit_from = p.row_end * 1024;
+            HIPCHK(c, launch_seq(K_MODE_DEBIT, p, d_read_off, n_reads, st));
+            HIPCHK(c, launch_count27s(p, (uint32_t)c->n_cu, st));
+            if (p.emit_from < n_bytes) HIPCHK(c, launch_seq(K_MODE_COUNT, p, d_read_off, n_reads, st));
+        } else {
+            HIPCHK(c, launch_seq(K_MODE_COUNT, p, d_read_off, n_reads, st));
+        }
     }
     HIPCHK(c, hipEventRecord(e1, st));
     std::lock_guard<std::mutex> lk(c->mu);

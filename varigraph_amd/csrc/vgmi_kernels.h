@@ -19,7 +19,7 @@ uint32_t vgmi_dbg_env();
 
 namespace vgk {
 
-enum { K_MODE_COUNT = 0, K_MODE_KEYS = 1, K_MODE_BLOOM = 2 };
+enum { K_MODE_COUNT = 0, K_MODE_KEYS = 1, K_MODE_BLOOM = 2, K_MODE_DEBIT = 3 };
 
 // table keyed by the read's grid 16-mer (vgmi_xtable.hip): lines of 16 entries, dense counters by id
 #define XT_HOPS 3u          // a k-mer sits in its home line or one of the XT_HOPS lines behind it (the table ends in XT_HOPS lines of slack)

@@ -184,6 +184,23 @@ __device__ __forceinline__ void table_count(const TableView& t, uint64_t canon)
     }
 }
 
+// the count of one canonical k-mer taken back by one (compact format of small graphs only: seq_kernel<MODE_DEBIT>)
+__device__ __forceinline__ void table_debit(const TableView& t, uint64_t canon)
+{
+    if (!t.slots8) return;
+    uint64_t s = table_home(t, canon);
+    for (;;) {
+        const uint64_t c = t.slots8[s];
+        if (c == VG_EMPTY) return;
+        if ((c & VG_SLOT_KMER_MASK) == canon) {
+            atomicSub(&t.counts[s], 1u);
+            return;
+        }
+        if (!(c & VG_SLOT_CHAIN)) return;
+        s = (s + 1) & t.cap_mask;
+    }
+}
+
 __device__ __forceinline__ bool filter_test_global(const TableView& t, uint64_t canon)
 {
     const uint32_t w = t.filter[vg_fhash_word(canon) >> t.filter_shift];
@@ -194,7 +211,7 @@ __device__ __forceinline__ bool filter_test_global(const TableView& t, uint64_t 
 // ------------------------------------------------------------------------------------------
 // row kernel: position-parallel emitter for ODD k, three sinks
 // ------------------------------------------------------------------------------------------
-enum { MODE_COUNT = 0, MODE_KEYS = 1, MODE_BLOOM = 2 };
+enum { MODE_COUNT = 0, MODE_KEYS = 1, MODE_BLOOM = 2, MODE_DEBIT = 3 };
 
 #define VG_QCAP 128u  // per-wave pass queue entries (power of two, >= 2*64)
 
@@ -1142,7 +1159,10 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
 template <bool PT, uint32_t K = 27>   // PT: candidate runs are looked up in the path table (vgmi_ptable.hip); else k-mer by k-mer in the hash table
 __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
 {
-    static_assert(K == 27 || (PT && (K & 1u) && K >= 19 && K <= 25), "count27s_kernel: k = 27, or the path-table form for odd k = 19 .. 25");
+    // (even k = 20 .. 26 too: the windows of k bases are counted, as for odd k -- a k-mer that is its own reverse complement is never
+    // emitted by the reference and never counted here: its start bit is not set in the path table, the hash-table fallback skips
+    // it -- and seq_kernel<MODE_DEBIT> has taken back, ahead of this kernel, the few windows the reference's run counter suppresses)
+    static_assert(K == 27 || (PT && K >= 19 && K <= 26), "count27s_kernel: k = 27, or the path-table form for k = 19 .. 26");
     constexpr uint32_t MASK_HI = (1u << (2 * K - 32)) - 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
@@ -1247,6 +1267,7 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
     auto slow_count = [&](uint32_t klo, uint32_t khi) __attribute__((always_inline)) {
         // a window of a run whose 12-mer the index does not cover: through the hash table, on the spot (rare)
         const uint64_t kmer = (uint64_t)khi << 32 | klo, rc = vg_revcomp(kmer, K);
+        if (!(K & 1u) && kmer == rc) return;      // src/kmer.cpp:134
         const uint64_t canon = kmer < rc ? kmer : rc;
         uint64_t sl = vg_thash(canon) & cap_mask;
         for (;;) {
@@ -1753,6 +1774,10 @@ __global__ __launch_bounds__(256) void seq_kernel(RowParams p, const uint64_t* r
     if (r_first < n_reads) {
         const uint64_t r_last = r_first + 64 < n_reads ? r_first + 64 : n_reads;
         const uint64_t b = read_off[r_first] & ~15ULL, e = read_off[r_last];
+        // (the exact tail behind a fast kernel: reads that end in front of emit_from have nothing to count; the debit pass in front of
+        // one: reads that start at or behind it have nothing to take back)
+        if (MODE == MODE_COUNT && e <= p.emit_from) return;
+        if (MODE == MODE_DEBIT && read_off[r_first] >= p.emit_from) return;
         if (e - b <= VG_SEQ_LDS && e <= ((p.n_bytes + 15) & ~15ULL)) {
             for (uint64_t o = b + lane * 16u; o < e; o += 1024)
                 *reinterpret_cast<uint4*>(&s_text[wave][o - b]) = load_chunk(p.bases, p.n_bytes, o);
@@ -1773,6 +1798,50 @@ __global__ __launch_bounds__(256) void seq_kernel(RowParams p, const uint64_t* r
     const uint64_t mask = (1ULL << (2 * K)) - 1, shift1 = 2 * (uint64_t)(K - 1);
     uint64_t fwd = 0, rc = 0;
     uint32_t l = 0;
+    if (MODE == MODE_DEBIT) {
+        // Even k behind count27s_kernel<true, K> (round 5).  That kernel counts a window iff its k bases are bases -- the rule of odd k.
+        // The reference's rule (src/kmer.cpp:132-146) differs where a window that is its own reverse complement -- of the registers'
+        // content, stale bases across a non-base and the zeros in front of the read included -- was met while l < k: l then lags
+        // behind the run of bases, and the positions with  run >= k > l  are not emitted.  One window in 4^(k/2), and only in the
+        // first k-odd bases behind a read's start or a non-base: this pass finds them (the literal state machine while l < k, a
+        // scan for the next non-base once l = k) and takes their k-mers' counts back BEFORE the fast kernel adds them (the
+        // counters are 32-bit and wrap: every debit is followed by its increment in the same stream; a saturation flag is set by
+        // the increment that takes the running value -- never above the true one -- from 254 to 255, and the read-out of even k
+        // honours the flag).  Positions at or behind emit_from belong to the exact tail launch (MODE_COUNT), not to the fast kernel.
+        uint32_t run = 0;
+        const uint64_t stop = e < p.emit_from ? e : p.emit_from;
+        for (uint64_t i = s; i < stop; ++i) {
+            const uint32_t c = vg_nt4(staged ? s_text[wave][i - stage_base] : p.bases[i]);
+            if (c >= 4) {
+                if (l >= K) {
+                    // the registers were left alone since l reached k: the k bytes in front of this one are bases (l >= k means
+                    // k of them in a row) -- the registers' content as the reference has it here
+                    fwd = 0;
+                    rc = 0;
+                    for (uint64_t j = i - K; j < i; ++j) {
+                        const uint32_t cj = vg_nt4(staged ? s_text[wave][j - stage_base] : p.bases[j]);
+                        fwd = (fwd << 2 | cj) & mask;
+                        rc = (rc >> 2) | (uint64_t)(3u ^ cj) << shift1;
+                    }
+                }
+                l = 0;
+                run = 0;
+                continue;
+            }
+            if (l >= K) continue;      // (nothing can be suppressed until the next non-base, and the registers are rebuilt there)
+            fwd = (fwd << 2 | c) & mask;
+            rc = (rc >> 2) | (uint64_t)(3u ^ c) << shift1;
+            if (run < K) ++run;
+            if (fwd != rc) {
+                ++l;
+                if (run >= K && l < K) {      // the fast kernel counts this window, the reference does not
+                    const uint64_t canon = fwd < rc ? fwd : rc;
+                    if (filter_test_global(p.table, canon)) table_debit(p.table, canon);
+                }
+            }
+        }
+        return;
+    }
     for (uint64_t i = s; i < e; ++i) {
         const uint32_t c = vg_nt4(staged ? s_text[wave][i - stage_base] : p.bases[i]);
         uint64_t out = ~0ULL;
@@ -1784,7 +1853,7 @@ __global__ __launch_bounds__(256) void seq_kernel(RowParams p, const uint64_t* r
                 if (l >= K) {
                     const uint64_t canon = fwd < rc ? fwd : rc;
                     if (MODE == MODE_COUNT) {
-                        if (filter_test_global(p.table, canon)) table_count(p.table, canon);
+                        if (i >= p.emit_from && filter_test_global(p.table, canon)) table_count(p.table, canon);
                     } else if (MODE == MODE_BLOOM) {
                         bloom_add_key(p.bloom, vg_hash64(canon, mask) << 8 | K);
                     } else {
@@ -2031,7 +2100,10 @@ __global__ void cov_kernel(TableView t, const uint32_t* key_slot, uint64_t n, co
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint32_t c32 = *count_cell(t, key_slot[i], (uint32_t)i);
-        const uint32_t c = c32 < 255u ? c32 : 255u;
+        uint32_t c = c32 < 255u ? c32 : 255u;
+        // (even k on the fast path: the counter of a saturated k-mer may stand below the clamp -- a debit of seq_kernel<MODE_DEBIT> whose
+        // increment the saturation flag then skipped; the flag says the sum reached it)
+        if (t.slots8 && !(t.k & 1u) && (t.slots8[key_slot[i]] & VG_SLOT_SAT)) c = 255u;
         cov[i] = (uint8_t)c;
         if (hist && c != 0 && flag && flag[i]) atomicAdd(&s_hist[c], 1u);
     }
@@ -2048,7 +2120,11 @@ __global__ void counts_xfer_kernel(TableView t, const uint32_t* key_slot, uint32
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         uint32_t* cell = count_cell(t, key_slot[i], (uint32_t)i);
         if (import) *cell = ext[i];
-        else ext[i] = *cell;
+        else {
+            uint32_t v = *cell;
+            if (t.slots8 && !(t.k & 1u) && (t.slots8[key_slot[i]] & VG_SLOT_SAT) && v < 255u) v = 255u;      // (even k, fast path: see cov_kernel)
+            ext[i] = v;
+        }
     }
 }
 
@@ -2143,6 +2219,10 @@ hipError_t launch_count27s(const RowParams& p, uint32_t grid, hipStream_t st)
         case 21: return launch_countks_t<21>(p, grid, lds, st);
         case 23: return launch_countks_t<23>(p, grid, lds, st);
         case 25: return launch_countks_t<25>(p, grid, lds, st);
+        case 20: return launch_countks_t<20>(p, grid, lds, st);
+        case 22: return launch_countks_t<22>(p, grid, lds, st);
+        case 24: return launch_countks_t<24>(p, grid, lds, st);
+        case 26: return launch_countks_t<26>(p, grid, lds, st);
         default: return hipErrorInvalidValue;
         }
     }
@@ -2175,6 +2255,7 @@ hipError_t launch_seq(int mode, const RowParams& p, const uint64_t* read_off, ui
     if (grid == 0) return hipSuccess;
     if (mode == MODE_COUNT) hipLaunchKernelGGL((seq_kernel<MODE_COUNT>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
     else if (mode == MODE_KEYS) hipLaunchKernelGGL((seq_kernel<MODE_KEYS>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
+    else if (mode == MODE_DEBIT) hipLaunchKernelGGL((seq_kernel<MODE_DEBIT>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
     else hipLaunchKernelGGL((seq_kernel<MODE_BLOOM>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
     return hipGetLastError();
 }
