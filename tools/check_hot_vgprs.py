@@ -29,7 +29,7 @@ def main():
         limit = 76 if "count27s_kernelILb1" in name else 116     # the path-table variant also hand-manages v76..v115
         if top >= limit or n_hot == 0 or n_scratch:
             bad += 1
-    if found != 13 or bad:      # count27_kernel x 3, count27s_kernel<false / true, 27>, count27s_kernel<true, 19 .. 26>
+    if found != 12 or bad:      # count27_kernel x 3, count27s_kernel<false / true, 27>, count27s_kernel<true, 19 .. 25>
         print("FAILED")
         return 1
     print("OK")

@@ -236,10 +236,10 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     h.n_keys = n_keys;
     // k = 27: compact 8-byte slots (a minimiser bucket of 32 is two 128-byte lines, its counters one); small graphs
     // spend the same bytes on twice the slots
-    // ... and so do small graphs of k = 19 .. 26: the 12-mer grid and the path table serve them too (count27s_kernel<true, K>, round 5;
+    // ... and so do small graphs of k = 19 .. 25: the 12-mer grid and the path table serve them too (count27s_kernel<true, K>, round 5;
     // VGMI_SMALLK=0 keeps them on the generic row kernel, the A/B reference)
-    // (even k = 20 .. 26 as well: the kernel's rule is the odd one, seq_kernel<MODE_DEBIT> runs ahead of it with the reference's)
-    const bool smallk = k >= 19 && k <= 26 && n_keys <= VG_GRID_LDS_MAX_KEYS && !(getenv("VGMI_SMALLK") && getenv("VGMI_SMALLK")[0] == '0');
+    // (even k = 20 .. 24 as well: the kernel's rule is the odd one, the debit pass runs ahead of it with the reference's)
+    const bool smallk = k >= 19 && k <= 25 && n_keys <= VG_GRID_LDS_MAX_KEYS && !(getenv("VGMI_SMALLK") && getenv("VGMI_SMALLK")[0] == '0');
     const bool compact = (k == 27 || smallk) && !getenv("VGMI_WIDE_SLOTS");   // 8-byte k-mer words + per-slot counters
     h.slot_bytes = compact ? 8 : 16;
     uint64_t cap = 64;
@@ -932,7 +932,7 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
     } else {
         if (!d_read_off) return fail(c, VGMI_E_INVALID, "even k needs read offsets");
         if (c->fastk_small && c->tv.pt.index && !c->force_generic && n_bytes >= 2048) {
-            // k = 20 .. 26 on a small graph: the windows of k bases through count27s_kernel<true, K> (complete pairs of rows), in front of
+            // k = 20 .. 24 on a small graph: the windows of k bases through count27s_kernel<true, K> (complete pairs of rows), in front of
             // it the pass that takes back what the reference's run counter suppresses, behind it the literal state machine for the
             // ends the rows do not cover
             p.row_end = (n_bytes / 2048) * 2;

@@ -1159,10 +1159,10 @@ __global__ __launch_bounds__(LDS_BM ? 1024 : 256) void count27_kernel(RowParams 
 template <bool PT, uint32_t K = 27>   // PT: candidate runs are looked up in the path table (vgmi_ptable.hip); else k-mer by k-mer in the hash table
 __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
 {
-    // (even k = 20 .. 26 too: the windows of k bases are counted, as for odd k -- a k-mer that is its own reverse complement is never
+    // (even k = 20 .. 24 too: the windows of k bases are counted, as for odd k -- a k-mer that is its own reverse complement is never
     // emitted by the reference and never counted here: its start bit is not set in the path table, the hash-table fallback skips
     // it -- and seq_kernel<MODE_DEBIT> has taken back, ahead of this kernel, the few windows the reference's run counter suppresses)
-    static_assert(K == 27 || (PT && K >= 19 && K <= 26), "count27s_kernel: k = 27, or the path-table form for k = 19 .. 26");
+    static_assert(K == 27 || (PT && K >= 19 && K <= 25), "count27s_kernel: k = 27, or the path-table form for k = 19 .. 25 (a run of k + 7 bases is two words)");
     constexpr uint32_t MASK_HI = (1u << (2 * K - 32)) - 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
@@ -1774,10 +1774,8 @@ __global__ __launch_bounds__(256) void seq_kernel(RowParams p, const uint64_t* r
     if (r_first < n_reads) {
         const uint64_t r_last = r_first + 64 < n_reads ? r_first + 64 : n_reads;
         const uint64_t b = read_off[r_first] & ~15ULL, e = read_off[r_last];
-        // (the exact tail behind a fast kernel: reads that end in front of emit_from have nothing to count; the debit pass in front of
-        // one: reads that start at or behind it have nothing to take back)
+        // (the exact tail behind a fast kernel: reads that end in front of emit_from have nothing to count)
         if (MODE == MODE_COUNT && e <= p.emit_from) return;
-        if (MODE == MODE_DEBIT && read_off[r_first] >= p.emit_from) return;
         if (e - b <= VG_SEQ_LDS && e <= ((p.n_bytes + 15) & ~15ULL)) {
             for (uint64_t o = b + lane * 16u; o < e; o += 1024)
                 *reinterpret_cast<uint4*>(&s_text[wave][o - b]) = load_chunk(p.bases, p.n_bytes, o);
@@ -1798,50 +1796,6 @@ __global__ __launch_bounds__(256) void seq_kernel(RowParams p, const uint64_t* r
     const uint64_t mask = (1ULL << (2 * K)) - 1, shift1 = 2 * (uint64_t)(K - 1);
     uint64_t fwd = 0, rc = 0;
     uint32_t l = 0;
-    if (MODE == MODE_DEBIT) {
-        // Even k behind count27s_kernel<true, K> (round 5).  That kernel counts a window iff its k bases are bases -- the rule of odd k.
-        // The reference's rule (src/kmer.cpp:132-146) differs where a window that is its own reverse complement -- of the registers'
-        // content, stale bases across a non-base and the zeros in front of the read included -- was met while l < k: l then lags
-        // behind the run of bases, and the positions with  run >= k > l  are not emitted.  One window in 4^(k/2), and only in the
-        // first k-odd bases behind a read's start or a non-base: this pass finds them (the literal state machine while l < k, a
-        // scan for the next non-base once l = k) and takes their k-mers' counts back BEFORE the fast kernel adds them (the
-        // counters are 32-bit and wrap: every debit is followed by its increment in the same stream; a saturation flag is set by
-        // the increment that takes the running value -- never above the true one -- from 254 to 255, and the read-out of even k
-        // honours the flag).  Positions at or behind emit_from belong to the exact tail launch (MODE_COUNT), not to the fast kernel.
-        uint32_t run = 0;
-        const uint64_t stop = e < p.emit_from ? e : p.emit_from;
-        for (uint64_t i = s; i < stop; ++i) {
-            const uint32_t c = vg_nt4(staged ? s_text[wave][i - stage_base] : p.bases[i]);
-            if (c >= 4) {
-                if (l >= K) {
-                    // the registers were left alone since l reached k: the k bytes in front of this one are bases (l >= k means
-                    // k of them in a row) -- the registers' content as the reference has it here
-                    fwd = 0;
-                    rc = 0;
-                    for (uint64_t j = i - K; j < i; ++j) {
-                        const uint32_t cj = vg_nt4(staged ? s_text[wave][j - stage_base] : p.bases[j]);
-                        fwd = (fwd << 2 | cj) & mask;
-                        rc = (rc >> 2) | (uint64_t)(3u ^ cj) << shift1;
-                    }
-                }
-                l = 0;
-                run = 0;
-                continue;
-            }
-            if (l >= K) continue;      // (nothing can be suppressed until the next non-base, and the registers are rebuilt there)
-            fwd = (fwd << 2 | c) & mask;
-            rc = (rc >> 2) | (uint64_t)(3u ^ c) << shift1;
-            if (run < K) ++run;
-            if (fwd != rc) {
-                ++l;
-                if (run >= K && l < K) {      // the fast kernel counts this window, the reference does not
-                    const uint64_t canon = fwd < rc ? fwd : rc;
-                    if (filter_test_global(p.table, canon)) table_debit(p.table, canon);
-                }
-            }
-        }
-        return;
-    }
     for (uint64_t i = s; i < e; ++i) {
         const uint32_t c = vg_nt4(staged ? s_text[wave][i - stage_base] : p.bases[i]);
         uint64_t out = ~0ULL;
@@ -1867,6 +1821,92 @@ __global__ __launch_bounds__(256) void seq_kernel(RowParams p, const uint64_t* r
         if (MODE == MODE_KEYS) p.keys_out[i] = out;
     }
     if (MODE == MODE_KEYS) p.keys_out[e] = ~0ULL;  // the separator position
+}
+
+// ------------------------------------------------------------------------------------------
+// even k = 20 .. 24 on a small graph, ahead of count27s_kernel<true, K> (round 5): what the reference's run counter suppresses.
+// That kernel counts a window iff its k bases are bases -- the rule of odd k.  The reference (src/kmer.cpp:132-146) does not advance
+// l on a window that is its own reverse complement -- of the REGISTERS' content: stale bases across a non-base (:145 resets l only)
+// and the zeros in front of the read included -- so behind such a window, met while l < k, l lags behind the run of bases and the
+// positions with  run >= k > l  are not emitted.  One window in 4^(k/2), and only within the first k-odd bases behind a read's start or
+// a non-base.  A lane per read: the literal state machine while l < k, a scan for the next non-base once l = k (16 bytes per step,
+// every byte one of ACGT: nothing to do); the k-mer of a suppressed position loses one count BEFORE the fast kernel adds it -- the
+// counters are 32-bit and wrap; every debit is followed by its increment in the same stream; a saturation flag is set by the increment
+// that takes the running value, which never exceeds the true one, from 254 to 255, and the read-out of even k honours the flag
+// (cov_kernel).  Positions at or behind emit_from belong to the exact tail launch (seq_kernel<MODE_COUNT>).
+// The text comes straight from global memory in aligned 16-byte pieces, the next piece in flight while this one is walked
+// (seq_kernel's staging through LDS holds two workgroups per CU and one dependent byte load per step: 15 ms per 2e7 reads).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t swar_zero_bytes(uint32_t x)      // bit 7 of every byte of x that is zero (exact)
+{
+    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
+__device__ __forceinline__ bool swar_all_acgt(uint32_t v)
+{
+    const uint32_t m = swar_zero_bytes(v ^ 0x41414141u) | swar_zero_bytes(v ^ 0x43434343u) | swar_zero_bytes(v ^ 0x47474747u) | swar_zero_bytes(v ^ 0x54545454u);
+    return m == 0x80808080u;
+}
+
+__global__ __launch_bounds__(256) void even_debit_kernel(RowParams p, const uint64_t* __restrict__ read_off, uint64_t n_reads)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint64_t s = read_off[r];
+    uint64_t e = read_off[r + 1] - 1;      // the read's '\n'
+    if (s >= p.emit_from || e <= s) return;
+    if (e > p.emit_from) e = p.emit_from;
+    const uint32_t K = p.k;
+    const uint64_t mask = (1ULL << (2 * K)) - 1, shift1 = 2 * (uint64_t)(K - 1);
+    uint64_t fwd = 0, rc = 0;
+    uint32_t l = 0, run = 0;
+    const uint8_t* const bases = p.bases;
+    const uint64_t n_al = (p.n_bytes + 15) & ~15ULL;      // (the block's allocation is padded to 16 bytes: vgmi_reads_submit*)
+    auto piece = [&](uint64_t a) -> uint4 {
+        if (a + 16 <= n_al && a + 16 <= p.n_bytes) return __builtin_nontemporal_load(reinterpret_cast<const uint4*>(bases + a));
+        return load_chunk(bases, p.n_bytes, a);
+    };
+    uint64_t a = s & ~15ULL;
+    uint4 cur = piece(a);
+    for (; a < e; a += 16) {
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        if (a + 16 < e) nxt = piece(a + 16);
+        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+        cur = nxt;
+        if (l >= K && a >= s && a + 16 <= e && swar_all_acgt(w[0]) && swar_all_acgt(w[1]) && swar_all_acgt(w[2]) && swar_all_acgt(w[3])) continue;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) {
+            const uint64_t i = a + j;
+            if (i < s || i >= e) continue;
+            const uint32_t c = vg_nt4((w[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+            if (c >= 4) {
+                if (l >= K) {
+                    // the registers were left alone since l reached k: the k bytes in front of this one are bases (l >= k means k of
+                    // them in a row) -- the registers' content as the reference has it here
+                    fwd = 0;
+                    rc = 0;
+                    for (uint64_t q = i - K; q < i; ++q) {
+                        const uint32_t cq = vg_nt4(bases[q]);
+                        fwd = (fwd << 2 | cq) & mask;
+                        rc = (rc >> 2) | (uint64_t)(3u ^ cq) << shift1;
+                    }
+                }
+                l = 0;
+                run = 0;
+                continue;
+            }
+            if (l >= K) continue;      // (nothing can be suppressed until the next non-base, and the registers are rebuilt there)
+            fwd = (fwd << 2 | c) & mask;
+            rc = (rc >> 2) | (uint64_t)(3u ^ c) << shift1;
+            if (run < K) ++run;
+            if (fwd != rc) {
+                ++l;
+                if (run >= K && l < K) {      // the fast kernel counts this window, the reference does not
+                    const uint64_t canon = fwd < rc ? fwd : rc;
+                    if (filter_test_global(p.table, canon)) table_debit(p.table, canon);
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2222,7 +2262,6 @@ hipError_t launch_count27s(const RowParams& p, uint32_t grid, hipStream_t st)
         case 20: return launch_countks_t<20>(p, grid, lds, st);
         case 22: return launch_countks_t<22>(p, grid, lds, st);
         case 24: return launch_countks_t<24>(p, grid, lds, st);
-        case 26: return launch_countks_t<26>(p, grid, lds, st);
         default: return hipErrorInvalidValue;
         }
     }
@@ -2255,7 +2294,7 @@ hipError_t launch_seq(int mode, const RowParams& p, const uint64_t* read_off, ui
     if (grid == 0) return hipSuccess;
     if (mode == MODE_COUNT) hipLaunchKernelGGL((seq_kernel<MODE_COUNT>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
     else if (mode == MODE_KEYS) hipLaunchKernelGGL((seq_kernel<MODE_KEYS>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
-    else if (mode == MODE_DEBIT) hipLaunchKernelGGL((seq_kernel<MODE_DEBIT>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
+    else if (mode == MODE_DEBIT) hipLaunchKernelGGL(even_debit_kernel, dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
     else hipLaunchKernelGGL((seq_kernel<MODE_BLOOM>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
     return hipGetLastError();
 }
