@@ -1860,9 +1860,12 @@ __global__ __launch_bounds__(256) void even_debit_kernel(RowParams p, const uint
     uint64_t fwd = 0, rc = 0;
     uint32_t l = 0, run = 0;
     const uint8_t* const bases = p.bases;
-    const uint64_t n_al = (p.n_bytes + 15) & ~15ULL;      // (the block's allocation is padded to 16 bytes: vgmi_reads_submit*)
     auto piece = [&](uint64_t a) -> uint4 {
-        if (a + 16 <= n_al && a + 16 <= p.n_bytes) return __builtin_nontemporal_load(reinterpret_cast<const uint4*>(bases + a));
+        if (a + 16 <= p.n_bytes) {
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(bases + a));
+            return make_uint4(v.x, v.y, v.z, v.w);
+        }
         return load_chunk(bases, p.n_bytes, a);
     };
     uint64_t a = s & ~15ULL;
