@@ -308,6 +308,12 @@ int vgmi_hmm_emissions(vgmi_ctx *ctx, uint32_t n_gt, uint32_t n_used, const uint
                        uint64_t n_rows, const uint64_t *entry_begin, const uint32_t *entry_count, const uint16_t *gt0,
                        uint32_t *n_kept_out, uint8_t *flags_out, vgmi_hmm_part **out);
 int vgmi_hmm_part_set_rows(vgmi_hmm_part *part, uint64_t n, const uint64_t *rows, const void *obs_rows /* n x n_gt long doubles */);
+/* ... or, for the rows flagged with bit 0, leave the products on the device (round 5): the host consults the haplotypes' sequences
+ * (strings: src/genotype.cpp:760-800) and says which entries of a row lose which haplotypes -- entry fix_j[i] of row rows[r]
+ * (fix_off[r] <= i < fix_off[r + 1], ascending in fix_j) loses the haplotypes of fix_mask[i] (bits over the `used` list) -- and the
+ * rows are scored again by the emission kernel with those bits cleared. */
+int vgmi_hmm_part_fix_rows(vgmi_hmm_part *part, uint64_t n, const uint64_t *rows, const uint32_t *fix_off, const uint16_t *fix_j,
+                           const uint16_t *fix_mask);
 int vgmi_hmm_part_calls(vgmi_hmm_part *part, uint32_t ploidy, const uint8_t *keep, uint32_t n_windows, const uint32_t *row,
                         const uint8_t *restart, const void *pow, uint64_t n_steps, const void *uniform, const vgmi_hmm_chain *chains,
                         uint32_t n_chains, const uint8_t *gid, const uint8_t *order, const uint64_t *fwd_step, const uint64_t *bwd_step,

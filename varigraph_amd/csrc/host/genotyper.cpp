@@ -620,6 +620,71 @@ Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, cons
     return ns;
 }
 
+// The sequence check of hidden_states() on its own (same conditions, same sets, same strings), for a node whose products stay on the
+// device: which entries of the node's list lose which haplotypes.  The fast path's reading of an entry (one 64-bit word: coverage,
+// multiplicity, haplotype bits) -- the device's emission kernel reads the same word the same way.
+void Genotyper::sequence_fixes(const Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& used, uint16_t gt0_mask, double lower, double upper,
+                               const Run& r, std::vector<uint16_t>& fix_j, std::vector<uint16_t>& fix_mask) const
+{
+    const Node& node = chr.nodes[node_i];
+    const std::vector<uint16_t>& hap_gt = node.gn->hap_gt;
+    const uint64_t bl = g_.bitlen;
+    const uint32_t* const key_of = g_.node_key_index.data();
+    auto carried = [&](uint64_t w, uint32_t& low_multi) -> uint32_t {      // bits over `used`: the haplotypes that count as carrying the k-mer
+        const uint8_t c = (uint8_t)w, f = (uint8_t)(w >> 8);
+        const uint64_t bits = w >> 16;
+        const int lb = (int)((bits >> (8 * bl - 1)) & 1u);
+        const bool in_interval = lb == 1 && c >= lower && c <= upper;
+        uint32_t om = 0;
+        for (size_t p = 0; p < used.size(); ++p) om |= (uint32_t)((in_interval && ((gt0_mask >> p) & 1u)) ? 1u : (uint32_t)((bits >> used[p]) & 1u)) << p;
+        low_multi = (c < lower && f >= 2) ? 2u : (!(c > lower || f <= 1)) ? 1u : 0u;      // 2: asks for the sequences; 1: is checked once they are there
+        return om;
+    };
+    uint32_t need = 0;
+    for (uint32_t pos : node.kmers) {
+        uint32_t lm;
+        const uint32_t om = carried(r.packed[pos], lm);
+        if (lm == 2u) need |= om;
+    }
+    if (!need) return;
+    // the needed haplotypes' sequences; haplotypes with the same allele and the same flanks share one (two sequences at most nodes)
+    std::vector<std::pair<std::string, std::unordered_set<uint64_t>>> seqs;
+    uint8_t which[16] = {0};
+    for (size_t p = 0; p < used.size(); ++p) {
+        if (!((need >> p) & 1u)) continue;
+        const uint16_t hap = used[p], gt = hap_gt[hap];
+        if (gt >= node.gn->seqs.size())
+            throw std::runtime_error("Node '" + chr.name + "-" + std::to_string(node.start) + "' does not contain sequence information for haplotype " +
+                                     std::to_string(gt) + ".");
+        std::string seq = node.gn->seqs[gt];
+        const auto fl = flanks(chr, node_i, hap, gt, seq, g_.k - 1);
+        seq = fl.first + seq + fl.second;
+        size_t at = 0;
+        while (at < seqs.size() && seqs[at].first != seq) ++at;
+        if (at == seqs.size()) {
+            std::unordered_set<uint64_t> keys = sequence_keys(seq, g_.k);
+            seqs.emplace_back(std::move(seq), std::move(keys));
+        }
+        which[p] = (uint8_t)at;
+    }
+    uint16_t j = 0;
+    for (uint32_t pos : node.kmers) {
+        uint32_t lm;
+        const uint32_t om = carried(r.packed[pos], lm) & need;
+        if (lm != 0u && om != 0u) {
+            const uint64_t key_hash = g_.keys[key_of[pos]];
+            uint32_t drop = 0;
+            for (size_t p = 0; p < used.size(); ++p)
+                if (((om >> p) & 1u) && seqs[which[p]].second.find(key_hash) == seqs[which[p]].second.end()) drop |= 1u << p;
+            if (drop) {
+                fix_j.push_back(j);
+                fix_mask.push_back((uint16_t)drop);
+            }
+        }
+        ++j;
+    }
+}
+
 // ---------------------------------------------------------------- posterior of one node (src/genotype.cpp:1387-1522)
 void Genotyper::posterior(Node& n, const std::vector<uint16_t>& top, const Run& r) const
 {
@@ -1886,6 +1951,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                     cpu.reset();
                     const int64_t ta = since_begin();
                     int64_t t_emit = 0, t_a = 0, t_rows = 0, t_b = 0, t_calls = 0;
+                    size_t n_fixed_rows = 0;
                     if (vgmi_hmm_emissions(dev_, (uint32_t)n_gt, (uint32_t)used.size(), used8.data(), glist.pos_a.data(), glist.pos_b.data(), top_mask,
                                            (uint32_t)g_.bitlen, ave, lower, upper, tab.data(), n_rows, e_begin.data(), e_count.data(), gt0.data(), n_kept.data(),
                                            flags.data(), &ph.p) != VGMI_OK)
@@ -1930,6 +1996,10 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                     std::vector<std::vector<uint32_t>> win_nodes(nw), win_rows(nw);
                     std::vector<std::vector<uint64_t>> host_rows(nw);
                     std::vector<std::vector<long double>> host_obs(nw);
+                    static const bool fix_on_device = !(getenv("VGH_HMM_FIX_DEVICE") && getenv("VGH_HMM_FIX_DEVICE")[0] == '0');
+                    std::vector<std::vector<uint64_t>> fix_rows(nw);
+                    std::vector<std::vector<uint32_t>> fix_cnt(nw);
+                    std::vector<std::vector<uint16_t>> fix_j(nw), fix_mask(nw);
                     std::vector<uint8_t>&gid = pc.gid, &order = pc.order;
                     over_windows(g_phase.pass_a, [&](size_t wi) {
                         Chrom& chr = *tasks[t0 + wi].chr;
@@ -1943,8 +2013,19 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                         for (size_t rr = win_row0[wi]; rr < win_row0[wi + 1]; ++rr) {
                             Node& n = chr.nodes[row_node[rr]];
                             const uint32_t n_start = n.start, n_end = (uint32_t)(n_start + n.gn->seqs[0].size() - 1);
-                            if (flags[rr] & 1u) {
-                                // a multi-copy, under-covered, carried k-mer: the reference consults the haplotype's sequence (:760-800)
+                            if ((flags[rr] & 1u) && fix_on_device) {
+                                // a multi-copy, under-covered, carried k-mer: the reference consults the haplotype's sequence (:760-800).
+                                // The strings are the host's; the row's products stay on the device, scored again below with the
+                                // haplotypes the sequences rule out taken off the entries concerned
+                                PhaseTimer tt(g_phase.states);
+                                const size_t before = fix_j[wi].size();
+                                sequence_fixes(chr, row_node[rr], used, gt0[rr], lower, upper, r, fix_j[wi], fix_mask[wi]);
+                                if (fix_j[wi].size() != before) {
+                                    fix_rows[wi].push_back(rr);
+                                    fix_cnt[wi].push_back((uint32_t)(fix_j[wi].size() - before));
+                                }
+                            } else if (flags[rr] & 1u) {
+                                // ... VGH_HMM_FIX_DEVICE=0: scored by the host (hidden states, products in x87 arithmetic), handed in as rows
                                 {
                                     PhaseTimer tt(g_phase.states);
                                     st = hidden_states(chr, row_node[rr], top, genotypes, used, glist, lower, upper, true, r, std::move(st), nullptr);
@@ -1989,6 +2070,18 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                             std::vector<long double>().swap(host_obs[wi]);
                         }
                         if (!all_rows.empty() && vgmi_hmm_part_set_rows(ph.p, all_rows.size(), all_rows.data(), all_obs.data()) != VGMI_OK)
+                            throw std::runtime_error(std::string("device HMM emissions: ") + vgmi_last_error(dev_));
+                        std::vector<uint64_t> f_rows;
+                        std::vector<uint32_t> f_off(1, 0);
+                        std::vector<uint16_t> f_j, f_m;
+                        for (size_t wi = 0; wi < nw; ++wi) {
+                            f_rows.insert(f_rows.end(), fix_rows[wi].begin(), fix_rows[wi].end());
+                            for (uint32_t cnt2 : fix_cnt[wi]) f_off.push_back(f_off.back() + cnt2);
+                            f_j.insert(f_j.end(), fix_j[wi].begin(), fix_j[wi].end());
+                            f_m.insert(f_m.end(), fix_mask[wi].begin(), fix_mask[wi].end());
+                        }
+                        n_fixed_rows = f_rows.size();
+                        if (!f_rows.empty() && vgmi_hmm_part_fix_rows(ph.p, f_rows.size(), f_rows.data(), f_off.data(), f_j.data(), f_m.data()) != VGMI_OK)
                             throw std::runtime_error(std::string("device HMM emissions: ") + vgmi_last_error(dev_));
                     }
                     t_rows = since_begin();
@@ -2060,9 +2153,9 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                     const int64_t tbb = since_begin();
                     t_calls = tbb;
                     if (g_phase_on)
-                        std::fprintf(stderr, "[varigraph-mi] HMM part %zu (windows %zu-%zu): emissions, recursion and posterior on the device from %.3f to %.3f s (%zu of %zu nodes scored by the host): "
+                        std::fprintf(stderr, "[varigraph-mi] HMM part %zu (windows %zu-%zu): emissions, recursion and posterior on the device from %.3f to %.3f s (%zu of %zu nodes scored by the host, %zu scored again on the device): "
                                      "emission kernel %.3f, host-scored nodes + strings %.3f, rows handed in %.3f, step tables %.3f, recursion + posterior %.3f\n",
-                                     part, t0, t1 - 1, ta * 1e-9, tbb * 1e-9, [&] { size_t c2 = 0; for (auto& v : host_rows) c2 += v.size(); return c2; }(), n_rows,
+                                     part, t0, t1 - 1, ta * 1e-9, tbb * 1e-9, [&] { size_t c2 = 0; for (auto& v : host_rows) c2 += v.size(); return c2; }(), n_rows, n_fixed_rows,
                                      (t_emit - ta) * 1e-9, (t_a - t_emit) * 1e-9, (t_rows - t_a) * 1e-9, (t_b - t_rows) * 1e-9, (t_calls - t_b) * 1e-9);
                     for (int64_t v = dev_first.load(); ta < v && !dev_first.compare_exchange_weak(v, ta);) {}
                     for (int64_t v = dev_last.load(); tbb > v && !dev_last.compare_exchange_weak(v, tbb);) {}

@@ -494,7 +494,11 @@ int main_genotype(int argc, char** argv)
     // side at little more than one sample's latency (tools/gpu_hmm_pack.sh: 960 chains in 39.5 ms, 60 chains in 33.5 ms);
     // eight chr20-scale samples, -t 10: 6.1 s with two consumers on fixed shares, 5.7 s on the budget, 4.5-5.1 s with four
     const bool four = second_consumer && ctxs.size() == 1 && g.keys.size() < ((size_t)1 << 27);
-    size_t per_run = std::max<size_t>(ctxs.size(), four ? 4 : second_consumer ? 2 : 1);
+    // ... eight where there are eight samples or more (round 5): a sample's device time is the latency of its chains -- 0.45-0.55 s at
+    // chr20 scale whether one sample's 120 chains or eight samples' 960 are on the device -- and four consumers took eight samples in
+    // two rounds of it (4.3-4.5 s, profiles/r5_c4_stages.txt)
+    const size_t eight = four && samples.size() >= 8 ? 8 : 4;
+    size_t per_run = std::max<size_t>(ctxs.size(), four ? eight : second_consumer ? 2 : 1);
     if (const char* e = getenv("VGH_HMM_CONSUMERS")) per_run = (size_t)std::max(1L, atol(e));      // A/B
     const size_t want_consumers = std::max<size_t>(1, std::min(samples.size(), per_run));
     bool independent = g.hap_names.size() <= o.hmm.haploid_num;

@@ -2895,6 +2895,11 @@ struct vgmi_hmm_part {
     size_t obs_bytes = 0;      // of the block d_obs came as
     uint64_t n_rows = 0;
     uint32_t n_gt = 0;
+    // the emission launch's arguments and the block its row arrays and tables live in: vgmi_hmm_part_fix_rows scores rows again
+    HmmEmitParams emit{};
+    uint8_t* d_small = nullptr;
+    size_t small_bytes = 0;
+    std::vector<uint32_t> entry_count;      // (host copy: fix_j is checked against it)
 };
 
 int vgmi_hmm_entries_upload(vgmi_ctx* c, const uint64_t* entries, size_t n)
@@ -2985,18 +2990,66 @@ int vgmi_hmm_emissions(vgmi_ctx* c, uint32_t n_gt, uint32_t n_used, const uint8_
         P.n_kept = reinterpret_cast<uint32_t*>(d_small + o_nk);
         P.flags = d_small + o_fl;
         e = launch_hmm_emissions(P, n_rows, st);
+        part->emit = P;
     }
     if (e == hipSuccess && n_rows) e = hipMemcpyAsync(n_kept_out, d_small + o_nk, n_rows * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess && n_rows) e = hipMemcpyAsync(flags_out, d_small + o_fl, n_rows, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (st) (void)hipStreamDestroy(st);
-    hmm_block_give(c, d_small, small_bytes);
     if (e != hipSuccess) {
+        hmm_block_give(c, d_small, small_bytes);
         hmm_block_give(c, part->d_obs, part->obs_bytes);
         delete part;
         HIPCHK(c, e);
     }
+    part->d_small = d_small;
+    part->small_bytes = small_bytes;
+    part->entry_count.assign(entry_count, entry_count + n_rows);
     *out = part;
+    return VGMI_OK;
+}
+
+// Rows the emission launch flagged (bit 0: an under-covered multi-copy k-mer that a haplotype of the window carries -- the reference
+// then consults the haplotype's sequence, src/genotype.cpp:760-800), scored again with what the host found there: entry fix_j[i] of
+// row rows[r] (fix_off[r] <= i < fix_off[r + 1], ascending) loses the haplotypes of fix_mask[i] (bits over the `used` list).  The
+// sequences are strings on the host; the products stay on the device.
+int vgmi_hmm_part_fix_rows(vgmi_hmm_part* part, uint64_t n, const uint64_t* rows, const uint32_t* fix_off, const uint16_t* fix_j, const uint16_t* fix_mask)
+{
+    if (!part || (n && (!rows || !fix_off))) return VGMI_E_INVALID;
+    vgmi_ctx* c = part->c;
+    if (n == 0) return VGMI_OK;
+    const uint32_t n_fix = fix_off[n];
+    if (n_fix && (!fix_j || !fix_mask)) return VGMI_E_INVALID;
+    for (uint64_t r = 0; r < n; ++r) {
+        if (rows[r] >= part->n_rows || fix_off[r] > fix_off[r + 1]) return fail(c, VGMI_E_INVALID, "HMM emissions: a fixed row outside the part");
+        for (uint32_t i = fix_off[r]; i < fix_off[r + 1]; ++i)
+            if (fix_j[i] >= part->entry_count[rows[r]] || (i > fix_off[r] && fix_j[i] <= fix_j[i - 1]))
+                return fail(c, VGMI_E_INVALID, "HMM emissions: a row's fixes must name its entries in ascending order");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_off = up(n * 8), o_j = up(o_off + (n + 1) * 4), o_m = up(o_j + (size_t)n_fix * 2), total = up(o_m + (size_t)n_fix * 2) + 256;
+    size_t d_bytes = 0;
+    uint8_t* d = hmm_block_take(c, total, d_bytes);
+    if (!d) return fail(c, VGMI_E_NOMEM, "HMM emissions: not enough device memory");
+    hipStream_t st = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemcpyAsync(d, rows, n * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_off, fix_off, (n + 1) * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n_fix) e = hipMemcpyAsync(d + o_j, fix_j, (size_t)n_fix * 2, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n_fix) e = hipMemcpyAsync(d + o_m, fix_mask, (size_t)n_fix * 2, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        HmmEmitParams P = part->emit;
+        P.fix_rows = reinterpret_cast<const uint64_t*>(d);
+        P.fix_off = reinterpret_cast<const uint32_t*>(d + o_off);
+        P.fix_j = reinterpret_cast<const uint16_t*>(d + o_j);
+        P.fix_mask = reinterpret_cast<const uint16_t*>(d + o_m);
+        e = launch_hmm_emissions(P, n, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (st) (void)hipStreamDestroy(st);
+    hmm_block_give(c, d, d_bytes);
+    HIPCHK(c, e);
     return VGMI_OK;
 }
 
@@ -3079,6 +3132,7 @@ void vgmi_hmm_part_free(vgmi_hmm_part* part)
 {
     if (!part) return;
     hmm_block_give(part->c, part->d_obs, part->obs_bytes);      // kept for the next part / sample (hipFree would wait for every stream)
+    hmm_block_give(part->c, part->d_small, part->small_bytes);
     delete part;
 }
 

@@ -470,7 +470,9 @@ __global__ __launch_bounds__(128) void hmm_emissions_kernel(HmmEmitParams P)
         s_te[i] = t.e;
     }
     __syncthreads();
-    const uint64_t rowi = P.row_lo + blockIdx.x;
+    const uint64_t rowi = P.fix_rows ? P.fix_rows[blockIdx.x] : P.row_lo + blockIdx.x;
+    uint32_t fp = P.fix_rows ? P.fix_off[blockIdx.x] : 0u;
+    const uint32_t fe = P.fix_rows ? P.fix_off[blockIdx.x + 1] : 0u;
     const uint64_t e0 = P.entry_begin[rowi];
     const uint32_t cnt = P.entry_count[rowi], gt0 = P.gt0[rowi];
     const bool active = g < P.n_gt;
@@ -496,6 +498,10 @@ __global__ __launch_bounds__(128) void hmm_emissions_kernel(HmmEmitParams P)
             om |= one << p;
         }
         if ((double)c < P.lower && f >= 2u && om != 0) flag |= 1u;
+        if (fp < fe && P.fix_j[fp] == j) {      // (the second launch: haplotypes whose sequence does not hold this k-mer do not carry it)
+            om &= ~(uint32_t)P.fix_mask[fp];
+            ++fp;
+        }
         const uint32_t fj = (lb == 1u && f == 1u) ? 2u : f;
         const uint32_t h = ((om >> pa) & 1u) + ((om >> pb) & 1u);
         const uint32_t cc = hmm_most_likely_depth(h, c, fj, P.ave, P.upper);
@@ -506,7 +512,7 @@ __global__ __launch_bounds__(128) void hmm_emissions_kernel(HmmEmitParams P)
         prod = n80_mul(prod, t);
     }
     if (active) x80_store(P.obs + (rowi * P.n_gt + g) * 16, n80_to(prod));
-    if (g == 0) {
+    if (g == 0 && !P.fix_rows) {
         P.n_kept[rowi] = kept;
         P.flags[rowi] = (uint8_t)flag;
     }

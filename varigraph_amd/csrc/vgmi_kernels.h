@@ -233,6 +233,13 @@ struct HmmEmitParams {
     uint8_t* obs;                       // out, per row: n_gt scores
     uint32_t* n_kept;                   // out, per row: k-mers that took part
     uint8_t* flags;                     // out, per row: bit 0 the host must score this node (a haplotype's sequence has to be checked), bit 1 a k-mer no selected haplotype carries
+    // the second launch over the flagged rows (round 5): what the haplotypes' SEQUENCES said (src/genotype.cpp:760-800).  Workgroup b
+    // scores row fix_rows[b] again; entry fix_j of the row loses the haplotypes of fix_mask (bits over `used`): the host found that
+    // their sequence does not hold this under-covered multi-copy k-mer.  Null in the first launch.
+    const uint64_t* fix_rows;
+    const uint32_t* fix_off;            // per fixed row: its stretch of (fix_j, fix_mask), ascending in fix_j
+    const uint16_t* fix_j;
+    const uint16_t* fix_mask;
 };
 hipError_t launch_hmm_emissions(const HmmEmitParams& P, uint64_t n_rows, hipStream_t st);
 hipError_t launch_hmm_scatter_rows(uint8_t* obs, const uint64_t* rows, const uint8_t* src, uint32_t n_gt, uint64_t n, hipStream_t st);
