@@ -57,6 +57,7 @@ const char *vgmi_last_error(const vgmi_ctx *ctx); /* ctx may be NULL: error of t
 int vgmi_device_memory(vgmi_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
 /* the HIP stream every kernel of this context is launched on (hipStream_t), for event timing */
 void *vgmi_stream(vgmi_ctx *ctx);
+int vgmi_device_of(vgmi_ctx *ctx, int *device);      /* the ordinal the context was created on */
 
 /* ---- graph k-mer table (immutable after upload) -----------------------------------------
  * replaces: the `unordered_map<uint64_t,kmerCovFreBitVec>& GraphKmerHashHapStrMap` argument of
@@ -322,6 +323,18 @@ int vgmi_hmm_part_calls(vgmi_hmm_part *part, uint32_t ploidy, const uint8_t *kee
  * winner[i] = the haplotypes (hap_ab[2 g], hap_ab[2 g + 1]); out[4 i ..] = k-mers of the node haplotype a carries, the sum of
  * their coverages, the same for b (a haplotype >= n_hap or outside sel_mask: 0, 0); unique_out[i] = k-mers of multiplicity <= 1,
  * at most 255.  Uses the entries and the sample's coverage uploaded for the emissions. */
+/* A part's recursion inputs kept on the device (round 5): everything vgmi_hmm_part_calls uploads -- keep matrix, step tables, rows,
+ * restarts, chains, genotype strings' ids and order, the rows' steps -- is a function of the graph and the options, not of the sample.
+ * A plan holds it (plain device memory: any context of the device may use it, and it outlives them), made once by
+ * vgmi_hmm_plan_create with the arguments of vgmi_hmm_part_calls; vgmi_hmm_part_calls_plan then runs a part's recursion and
+ * posterior on the plan's inputs and the part's own emission scores. */
+typedef struct vgmi_hmm_plan vgmi_hmm_plan;
+int vgmi_hmm_plan_create(vgmi_ctx *ctx, uint32_t n_gt, uint32_t ploidy, const uint8_t *keep, uint32_t n_windows, uint64_t n_rows,
+                         const uint32_t *row, const uint8_t *restart, const void *pow, uint64_t n_steps, const void *uniform,
+                         const vgmi_hmm_chain *chains, uint32_t n_chains, const uint8_t *gid, const uint8_t *order, const uint64_t *fwd_step,
+                         const uint64_t *bwd_step, vgmi_hmm_plan **out);
+int vgmi_hmm_part_calls_plan(vgmi_hmm_part *part, const vgmi_hmm_plan *plan, void *prob, uint32_t *winner);
+void vgmi_hmm_plan_free(vgmi_hmm_plan *plan);
 int vgmi_hmm_tallies(vgmi_ctx *ctx, uint64_t n_rows, const uint64_t *entry_begin, const uint32_t *entry_count, const uint32_t *winner,
                      uint32_t n_gt, const uint8_t *hap_ab, uint32_t n_hap, uint64_t sel_mask, uint32_t *out, uint8_t *unique_out);
 /* the part's emission rows back on the host (n_rows x n_gt long doubles): tests and diagnostics */

@@ -409,3 +409,109 @@ def test_emission_scores_on_the_device_equal_the_host_arithmetic():
         assert np.array_equal(obs[r], prod), (r, int(np.argmax(obs[r] != prod)))
         n_flagged += flag
     assert 20 < n_flagged < n_rows and (obs == 0).any() and (obs > 0).any()
+
+
+def test_flagged_rows_scored_again_on_the_device_and_plans():
+    """Round 5.  (a) vgmi_hmm_part_fix_rows: rows scored again with haplotypes taken off entries (what the host's sequence check rules
+    out, src/genotype.cpp:760-800) equal the product spelled out here with those haplotypes' bits cleared; rows that are not named keep
+    their scores.  (b) vgmi_hmm_plan: a part's recursion and posterior on device-resident inputs give the bits of vgmi_hmm_part_calls
+    with host arrays, call after call."""
+    rng = np.random.default_rng(77)
+    n_hap, bit_len = 9, 2
+    used = np.arange(n_hap, dtype=np.uint8)
+    pairs = list(itertools.combinations_with_replacement(range(n_hap), 2))
+    pos_a = np.array([a for a, _ in pairs], dtype=np.uint8)
+    pos_b = np.array([b for _, b in pairs], dtype=np.uint8)
+    n_gt = len(pairs)
+    top_mask = (1 << n_hap) - 1
+    ave = np.float32(23.5)
+    lower, upper = float(ave) - 1.96 * float(np.sqrt(np.float64(ave))), float(ave) + 1.96 * float(np.sqrt(np.float64(ave)))
+    tables = (rng.random(768).astype(LD) + LD(0.05)) * np.power(LD(10), rng.integers(-40, 1, size=768).astype(LD))
+    n_rows = 120
+    counts = rng.integers(1, 60, size=n_rows)
+    entry_begin = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
+    n_entries = int(counts.sum())
+    f = rng.choice([1, 1, 2, 3], size=n_entries).astype(np.uint64)
+    bits = rng.integers(1, 1 << n_hap, size=n_entries).astype(np.uint64)
+    lb = rng.integers(0, 2, size=n_entries).astype(np.uint64)
+    bits |= lb << np.uint64(8 * bit_len - 1)
+    cov = rng.choice([0, 1, 5, 14, 15, 20, 23, 24, 30, 60], size=n_entries).astype(np.uint8)
+    entries = (f << np.uint64(8)) | (bits << np.uint64(16))
+    gt0 = rng.integers(0, 1 << n_hap, size=n_rows).astype(np.uint16)
+    # fixes on every third row: a few entries each, ascending, random masks
+    f_rows, f_off, f_j, f_m = [], [0], [], []
+    drop = {}
+    for r in range(0, n_rows, 3):
+        js = np.sort(rng.choice(int(counts[r]), size=min(int(counts[r]), int(rng.integers(1, 5))), replace=False))
+        f_rows.append(r)
+        for j in js:
+            m = int(rng.integers(1, 1 << n_hap))
+            f_j.append(int(j))
+            f_m.append(m)
+            drop[(r, int(j))] = m
+        f_off.append(len(f_j))
+    # a chain over the rows in both directions (one window), random step tables and strings
+    stride = 3
+    n_steps = 2 * n_rows
+    row = np.concatenate([np.arange(n_rows), np.arange(n_rows)[::-1]]).astype(np.uint32)
+    restart = np.zeros(n_steps, dtype=np.uint8)
+    restart[0] = restart[n_rows] = 1
+    pw = (rng.random((n_steps, 2 * stride)).astype(LD) * LD(0.5) + LD(0.25))
+    keep = np.array([[len({a, b} & {c, d}) + (a == b == c == d) for (c, d) in pairs] for (a, b) in pairs], dtype=np.uint8)
+    keep = np.minimum(keep, 2).astype(np.uint8)
+    keep = np.maximum(keep, keep.T)
+    gid = rng.integers(0, 6, size=(n_rows, n_gt)).astype(np.uint8)
+    order = np.tile(np.arange(n_gt, dtype=np.uint8), (n_rows, 1))
+    for r in range(n_rows):      # order: the distinct ids of the row, then padding (as genotype_strings lays them out)
+        ids = np.unique(gid[r])
+        order[r, :ids.size] = ids
+        order[r, ids.size:] = 0xFF
+    fwd = np.arange(n_rows, dtype=np.uint64)
+    bwd = (n_rows + (n_rows - 1 - np.arange(n_rows))).astype(np.uint64)
+    calls = dict(ploidy=2, keep=keep[None], row=row, restart=restart, pow=pw, uniform=LD(1) / LD(n_gt), chains=[(0, n_rows, 0), (n_rows, n_rows, 0)],
+                 gid=gid, order=order, fwd=fwd, bwd=bwd)
+    ctx = vgmi.Context(0, buffer_mib=16)
+    try:
+        obs0, n_kept, flags = ctx.hmm_emissions(entries, cov, used, pos_a, pos_b, top_mask, bit_len, ave, lower, upper, tables, entry_begin, counts, gt0)
+        obs1, n_kept1, flags1, both = ctx.hmm_emissions(entries, cov, used, pos_a, pos_b, top_mask, bit_len, ave, lower, upper, tables, entry_begin, counts, gt0,
+                                                        fixes=(f_rows, f_off, f_j, f_m), calls=calls)
+    finally:
+        ctx.close()
+    assert np.array_equal(n_kept, n_kept1) and np.array_equal(flags, flags1)
+
+    def mld(h, c, ff):
+        if ff == 1:
+            return c
+        cf = np.float32(c)
+        if h > 0 and cf > ave * np.float32(h):
+            return int(ave * np.float32(h)) & 0xFF
+        if h == 0 and cf > ave:
+            return 0 if float(ff) > float(cf) / upper else int(cf / np.float32(ff)) & 0xFF
+        if h == 0:
+            return int(cf / np.float32(ff)) & 0xFF
+        return c
+    changed = 0
+    for r in range(n_rows):
+        if r % 3:
+            assert np.array_equal(obs1[r], obs0[r]), r
+            continue
+        prod = np.ones(n_gt, dtype=LD)
+        for jj in range(int(counts[r])):
+            j = int(entry_begin[r]) + jj
+            c, ff, b = int(cov[j]), int(f[j]), int(bits[j])
+            l = (b >> (8 * bit_len - 1)) & 1
+            in_interval = l == 1 and lower <= c <= upper
+            one = [1 if (in_interval and (int(gt0[r]) >> p) & 1) else (b >> p) & 1 for p in range(n_hap)]
+            m = drop.get((r, jj), 0)
+            one = [o if not (m >> p) & 1 else 0 for p, o in enumerate(one)]
+            fj = 2 if (l == 1 and ff == 1) else ff
+            term = {h: tables[h * 256 + mld(h, c, fj)] for h in (0, 1, 2)}
+            hs = np.array([one[a] + one[b2] for a, b2 in pairs])
+            prod = prod * np.where(hs == 0, term[0], np.where(hs == 1, term[1], term[2]))
+        assert np.array_equal(obs1[r], prod), r
+        changed += not np.array_equal(obs1[r], obs0[r])
+    assert changed > n_rows // 6
+    (p1, w1), (p2, w2), (p3, w3) = both
+    assert np.array_equal(p1.view(np.uint8), p2.view(np.uint8)) and np.array_equal(w1, w2)
+    assert np.array_equal(p1.view(np.uint8), p3.view(np.uint8)) and np.array_equal(w1, w3)
+    assert (w1 != 0xFFFFFFFF).sum() > n_rows // 2

@@ -620,6 +620,8 @@ Genotyper::NodeStates Genotyper::hidden_states(Chrom& chr, uint32_t node_i, cons
     return ns;
 }
 
+Genotyper::EmitPartPlan::~EmitPartPlan() { vgmi_hmm_plan_free(plan); }
+
 // The sequence check of hidden_states() on its own (same conditions, same sets, same strings), for a node whose products stay on the
 // device: which entries of the node's list lose which haplotypes.  The fast path's reading of an entry (one 64-bit word: coverage,
 // multiplicity, haplotype bits) -- the device's emission kernel reads the same word the same way.
@@ -1884,62 +1886,73 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
             std::atomic<bool> broken{false};
             std::mutex err_mu;
             std::string err_text;
+            const std::string cache_key = std::to_string(tasks.size()) + "/" + std::to_string(per_part) + "/" + std::to_string(cfg.sv_only) + "/" +
+                                          std::to_string(cfg.sample_ploidy) + "/" + cfg.sample_type + "/" + std::to_string(n_gt) + "/" +
+                                          std::to_string(r.haploid_num) + "/" + std::to_string(cfg.chr_len_thread);
+            // What a part's device calls need beyond a sample's coverage is a function of the graph and the options: the rows (entry
+            // ranges, reference-allele masks), and the PLAN -- genotype strings, which rows have a score, the step tables (libm), chains,
+            // all of it resident on the device (vgmi_hmm_plan).  Made by the first sample that gets there, kept with the graph, shared
+            // by every Genotyper of the run (eight consumers of one device built eight of everything in round 4).
+            int dev_id = 0;
+            (void)vgmi_device_of(dev_, &dev_id);
             if (emit_cache_.size() != n_parts_e) {
                 emit_cache_.clear();
                 emit_cache_.resize(n_parts_e);
             }
-            const std::string cache_key = std::to_string(tasks.size()) + "/" + std::to_string(per_part) + "/" + std::to_string(cfg.sv_only) + "/" +
-                                          std::to_string(cfg.sample_ploidy) + "/" + cfg.sample_type + "/" + std::to_string(n_gt) + "/" +
-                                          std::to_string(r.haploid_num) + "/" + std::to_string(cfg.chr_len_thread);
+            for (size_t part = 0; part < n_parts_e; ++part) {
+                const std::string slot = "emit/" + std::to_string(dev_id) + "/" + std::to_string(n_parts_e) + "/" + std::to_string(part) + "/" + cache_key;
+                std::lock_guard<std::mutex> lock(g_.shared_mu);
+                auto it = g_.shared_slots.find(slot);
+                if (it == g_.shared_slots.end()) it = g_.shared_slots.emplace(slot, std::static_pointer_cast<void>(std::make_shared<EmitPartCache>())).first;
+                emit_cache_[part] = std::static_pointer_cast<EmitPartCache>(it->second);
+            }
             auto part_fn = [&](size_t part) {
                 try {
                     const size_t t0 = part * per_part, t1 = std::min(tasks.size(), t0 + per_part);
-                    // rows: every node the HMM works on, window after window (the same for every sample: listed once)
-                    auto cpu = std::make_unique<CpuBudget::Hold>();
-                    auto t_list = std::make_unique<PhaseTimer>(g_phase.list);
-                    EmitPartCache& pc = emit_cache_[part];
-                    const bool listed = pc.key == cache_key;
-                    if (!listed) {
-                        pc = EmitPartCache();
-                        pc.win_row0.assign(t1 - t0 + 1, 0);
-                    }
-                    std::vector<uint64_t>& e_begin = pc.e_begin;
-                    std::vector<uint32_t>&e_count = pc.e_count, &row_node = pc.row_node;
-                    std::vector<uint16_t>& gt0 = pc.gt0;
-                    std::vector<size_t>& win_row0 = pc.win_row0;
-                    for (size_t t = t0; t < t1 && !listed; ++t) {
-                        Chrom& chr = *tasks[t].chr;
-                        auto vcf_chr = g_.vcf_info.find(chr.name);
-                        if (vcf_chr == g_.vcf_info.end()) throw std::runtime_error("'" + chr.name + "' does not exist in the VCF file.");
-                        for (uint32_t i = tasks[t].first; i < tasks[t].last; ++i) {
-                            const Node& n = chr.nodes[i];
-                            if (n.gn->hap_gt.size() <= 1) continue;
-                            if (cfg.sv_only) {
-                                auto site = vcf_chr->second.find(n.start);
-                                if (site == vcf_chr->second.end())
-                                    throw std::runtime_error("'" + chr.name + ":" + std::to_string(n.start) + "' does not exist in the VCF file.");
-                                if (site->second[3].size() < 50 && site->second[4].size() < 50) continue;
+                    EmitPartCache& pc = *emit_cache_[part];
+                    // rows: every node the HMM works on, window after window (the same for every sample and every Genotyper: listed once)
+                    {
+                        std::lock_guard<std::mutex> lock(pc.mu);
+                        if (pc.key != cache_key) {
+                            CpuBudget::Hold cpu;
+                            PhaseTimer t_list(g_phase.list);
+                            pc.e_begin.clear(); pc.e_count.clear(); pc.row_node.clear(); pc.gt0.clear();
+                            pc.plan.reset();
+                            pc.win_row0.assign(t1 - t0 + 1, 0);
+                            for (size_t t = t0; t < t1; ++t) {
+                                Chrom& chr = *tasks[t].chr;
+                                auto vcf_chr = g_.vcf_info.find(chr.name);
+                                if (vcf_chr == g_.vcf_info.end()) throw std::runtime_error("'" + chr.name + "' does not exist in the VCF file.");
+                                for (uint32_t i = tasks[t].first; i < tasks[t].last; ++i) {
+                                    const Node& n = chr.nodes[i];
+                                    if (n.gn->hap_gt.size() <= 1) continue;
+                                    if (cfg.sv_only) {
+                                        auto site = vcf_chr->second.find(n.start);
+                                        if (site == vcf_chr->second.end())
+                                            throw std::runtime_error("'" + chr.name + ":" + std::to_string(n.start) + "' does not exist in the VCF file.");
+                                        if (site->second[3].size() < 50 && site->second[4].size() < 50) continue;
+                                    }
+                                    if (!n.kmers.empty() && (size_t)(n.kmers.back() - n.kmers.front()) + 1 != n.kmers.size()) {
+                                        broken = true;      // a pruned list after all: the host path
+                                        return;
+                                    }
+                                    pc.e_begin.push_back(n.kmers.empty() ? 0 : n.kmers.front());
+                                    pc.e_count.push_back((uint32_t)n.kmers.size());
+                                    uint16_t m = 0;
+                                    for (size_t p2 = 0; p2 < used.size(); ++p2) m |= (uint16_t)((n.gn->hap_gt[used[p2]] == 0) << p2);
+                                    pc.gt0.push_back(m);
+                                    pc.row_node.push_back(i);
+                                }
+                                pc.win_row0[t - t0 + 1] = pc.e_begin.size();
                             }
-                            if (!n.kmers.empty() && (size_t)(n.kmers.back() - n.kmers.front()) + 1 != n.kmers.size()) {
-                                broken = true;      // a pruned list after all: the host path
-                                return;
-                            }
-                            e_begin.push_back(n.kmers.empty() ? 0 : n.kmers.front());
-                            e_count.push_back((uint32_t)n.kmers.size());
-                            uint16_t m = 0;
-                            for (size_t p2 = 0; p2 < used.size(); ++p2) m |= (uint16_t)((n.gn->hap_gt[used[p2]] == 0) << p2);
-                            gt0.push_back(m);
-                            row_node.push_back(i);
+                            pc.key = cache_key;
                         }
-                        win_row0[t - t0 + 1] = e_begin.size();
                     }
+                    const std::vector<uint64_t>& e_begin = pc.e_begin;
+                    const std::vector<uint32_t>&e_count = pc.e_count, &row_node = pc.row_node;
+                    const std::vector<uint16_t>& gt0 = pc.gt0;
+                    const std::vector<size_t>& win_row0 = pc.win_row0;
                     const size_t n_rows = e_begin.size();
-                    if (!listed) {
-                        pc.gid.assign(n_rows * n_gt, 0);
-                        pc.order.assign(n_rows * n_gt, 0);
-                        pc.have.assign(n_rows ? n_rows : 1, 0);
-                        pc.key = cache_key;
-                    }
                     if (n_rows == 0) return;      // no node of this part is the HMM's business (--sv over a part without long alleles): no calls, no lines
                     std::vector<uint32_t> n_kept(n_rows ? n_rows : 1);
                     std::vector<uint8_t> flags(n_rows ? n_rows : 1);
@@ -1947,8 +1960,6 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                         vgmi_hmm_part* p = nullptr;
                         ~PartHandle() { vgmi_hmm_part_free(p); }
                     } ph;
-                    t_list.reset();
-                    cpu.reset();
                     const int64_t ta = since_begin();
                     int64_t t_emit = 0, t_a = 0, t_rows = 0, t_b = 0, t_calls = 0;
                     size_t n_fixed_rows = 0;
@@ -1962,9 +1973,10 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                             broken = true;          // a k-mer no haplotype carries: the host path prunes it
                             return;
                         }
-                    // The part's windows on `helpers` threads, three passes.  A: the nodes the host must score itself (their scores are
-                    // handed in as one block), the genotype strings, which nodes have a score at all.  B: the step tables (libm) at the
-                    // places A's counts give them.  Then recursion and posterior on the device.  C: the calls and the VCF lines.
+                    // The part's windows on `helpers` threads.  A: the nodes whose haplotype sequences must be consulted -- which entries
+                    // lose which haplotypes, for the device to score those rows again.  (Once per graph, under the part's lock: the
+                    // genotype strings, which nodes have a score at all, B: the step tables (libm) -- the plan.)  Then recursion and
+                    // posterior on the device.  C: the calls and the VCF lines.
                     const size_t nw = t1 - t0;
                     const size_t helpers = std::max<size_t>(1, std::min<size_t>(nw, n_threads / n_parts_e));
                     auto over_windows = [&](std::atomic<long long>& spent, const std::function<void(size_t)>& fn) {
@@ -1991,29 +2003,21 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                         for (auto& th : hs) th.join();
                         if (!herr.empty()) throw std::runtime_error(herr);
                     };
-                    struct Seen { uint32_t start, end; int64_t row; };
-                    std::vector<std::vector<Seen>> seen(nw);
-                    std::vector<std::vector<uint32_t>> win_nodes(nw), win_rows(nw);
                     std::vector<std::vector<uint64_t>> host_rows(nw);
                     std::vector<std::vector<long double>> host_obs(nw);
                     static const bool fix_on_device = !(getenv("VGH_HMM_FIX_DEVICE") && getenv("VGH_HMM_FIX_DEVICE")[0] == '0');
                     std::vector<std::vector<uint64_t>> fix_rows(nw);
                     std::vector<std::vector<uint32_t>> fix_cnt(nw);
                     std::vector<std::vector<uint16_t>> fix_j(nw), fix_mask(nw);
-                    std::vector<uint8_t>&gid = pc.gid, &order = pc.order;
                     over_windows(g_phase.pass_a, [&](size_t wi) {
                         Chrom& chr = *tasks[t0 + wi].chr;
                         ScoreCtx sctx;
                         sctx.ave = ave;
                         sctx.score_up = upper;
                         NodeStates st;
-                        // the genotype strings of a node with two alleles depend on which haplotypes carry the reference allele only:
-                        // one evaluation per distinct mask (the strings themselves as genotype_strings builds them)
-                        std::unordered_map<uint32_t, uint32_t> gs_memo;      // mask -> a row that holds the pattern
                         for (size_t rr = win_row0[wi]; rr < win_row0[wi + 1]; ++rr) {
-                            Node& n = chr.nodes[row_node[rr]];
-                            const uint32_t n_start = n.start, n_end = (uint32_t)(n_start + n.gn->seqs[0].size() - 1);
-                            if ((flags[rr] & 1u) && fix_on_device) {
+                            if (!(flags[rr] & 1u)) continue;
+                            if (fix_on_device) {
                                 // a multi-copy, under-covered, carried k-mer: the reference consults the haplotype's sequence (:760-800).
                                 // The strings are the host's; the row's products stay on the device, scored again below with the
                                 // haplotypes the sequences rule out taken off the entries concerned
@@ -2024,7 +2028,7 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                                     fix_rows[wi].push_back(rr);
                                     fix_cnt[wi].push_back((uint32_t)(fix_j[wi].size() - before));
                                 }
-                            } else if (flags[rr] & 1u) {
+                            } else {
                                 // ... VGH_HMM_FIX_DEVICE=0: scored by the host (hidden states, products in x87 arithmetic), handed in as rows
                                 {
                                     PhaseTimer tt(g_phase.states);
@@ -2038,26 +2042,6 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                                     host_obs[wi].insert(host_obs[wi].end(), obs.begin(), obs.end());
                                 }
                             }
-                            if (n_kept[rr] == 0) {
-                                seen[wi].push_back(Seen{n_start, n_end, -1});
-                                continue;
-                            }
-                            seen[wi].push_back(Seen{n_start, n_end, (int64_t)rr});
-                            if (!pc.have[rr]) {      // (a row that had a score under an earlier sample keeps its strings)
-                                bool biallelic = true;
-                                for (uint16_t hap : used) biallelic = biallelic && n.gn->hap_gt[hap] <= 1;
-                                auto it = biallelic ? gs_memo.find(gt0[rr]) : gs_memo.end();
-                                if (it != gs_memo.end()) {
-                                    std::memcpy(gid.data() + rr * n_gt, gid.data() + (size_t)it->second * n_gt, n_gt);
-                                    std::memcpy(order.data() + rr * n_gt, order.data() + (size_t)it->second * n_gt, n_gt);
-                                } else {
-                                    (void)genotype_strings(n, genotypes, gid.data() + rr * n_gt, order.data() + rr * n_gt);     // <= 128 strings: always fits
-                                    if (biallelic) gs_memo.emplace(gt0[rr], (uint32_t)rr);
-                                }
-                                pc.have[rr] = 1;
-                            }
-                            win_nodes[wi].push_back(row_node[rr]);
-                            win_rows[wi].push_back((uint32_t)rr);
                         }
                     });
                     t_a = since_begin();
@@ -2085,76 +2069,126 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                             throw std::runtime_error(std::string("device HMM emissions: ") + vgmi_last_error(dev_));
                     }
                     t_rows = since_begin();
-                    std::vector<size_t> win_step0(nw + 1, 0);
-                    for (size_t wi = 0; wi < nw; ++wi) win_step0[wi + 1] = win_step0[wi] + 2 * win_rows[wi].size();
-                    const size_t n_steps = win_step0[nw];
-                    std::vector<long double> pw((n_steps ? n_steps : 1) * 2 * stride);
-                    std::vector<uint32_t> row(n_steps ? n_steps : 1, 0);
-                    std::vector<uint8_t> restart(n_steps ? n_steps : 1, 0);
-                    std::vector<uint64_t> fwd(n_rows ? n_rows : 1, 0), bwd(n_rows ? n_rows : 1, 0);
-                    std::vector<vgmi_hmm_chain> chains;
-                    for (size_t wi = 0; wi < nw; ++wi) {
-                        const size_t m = win_rows[wi].size();
-                        if (!m) continue;
-                        chains.push_back(vgmi_hmm_chain{win_step0[wi], m, 0, 0});
-                        chains.push_back(vgmi_hmm_chain{win_step0[wi] + m, m, 0, 0});
-                    }
-                    over_windows(g_phase.pass_b, [&](size_t wi) {
-                        const size_t m = win_rows[wi].size();
-                        if (!m) return;
-                        const size_t step0 = win_step0[wi];
-                        // the tables of powers are a function of the distance alone: neighbouring nodes are tens to hundreds of bases
-                        // apart, so a window's few thousand steps share a few hundred distinct tables (same libm calls, each made once)
-                        constexpr uint32_t kMemo = 4096;
-                        std::vector<long double> memo((size_t)kMemo * 2 * stride);
-                        std::vector<uint8_t> memo_have(kMemo, 0);
-                        auto powers = [&](long double* dst, uint32_t distance) {
-                            if (distance < kMemo && memo_have[distance]) {
-                                std::memcpy(dst, &memo[(size_t)distance * 2 * stride], 2 * stride * sizeof(long double));
-                                return;
+                    // ---- the plan: for the rows that have a score -- the same for every sample of this path (a row's kept k-mers are
+                    // those some haplotype carries, and every haplotype is selected); held against the pattern all the same
+                    std::vector<uint8_t> scored(n_rows);
+                    for (size_t rr = 0; rr < n_rows; ++rr) scored[rr] = n_kept[rr] != 0;
+                    std::shared_ptr<EmitPartPlan> plan;
+                    {
+                        std::lock_guard<std::mutex> lock(pc.mu);
+                        if (!pc.plan || pc.plan->scored != scored) {
+                            auto np = std::make_shared<EmitPartPlan>();
+                            np->scored = scored;
+                            np->win_nodes.resize(nw);
+                            np->win_rows.resize(nw);
+                            struct Seen { uint32_t start, end; int64_t row; };
+                            std::vector<std::vector<Seen>> seen(nw);
+                            std::vector<uint8_t> gid(n_rows * n_gt, 0), order(n_rows * n_gt, 0);
+                            over_windows(g_phase.pass_a, [&](size_t wi) {
+                                Chrom& chr = *tasks[t0 + wi].chr;
+                                // the genotype strings of a node with two alleles depend on which haplotypes carry the reference allele only:
+                                // one evaluation per distinct mask (the strings themselves as genotype_strings builds them)
+                                std::unordered_map<uint32_t, uint32_t> gs_memo;      // mask -> a row that holds the pattern
+                                for (size_t rr = win_row0[wi]; rr < win_row0[wi + 1]; ++rr) {
+                                    Node& n = chr.nodes[row_node[rr]];
+                                    const uint32_t n_start = n.start, n_end = (uint32_t)(n_start + n.gn->seqs[0].size() - 1);
+                                    if (!scored[rr]) {
+                                        seen[wi].push_back(Seen{n_start, n_end, -1});
+                                        continue;
+                                    }
+                                    seen[wi].push_back(Seen{n_start, n_end, (int64_t)rr});
+                                    bool biallelic = true;
+                                    for (uint16_t hap : used) biallelic = biallelic && n.gn->hap_gt[hap] <= 1;
+                                    auto it = biallelic ? gs_memo.find(gt0[rr]) : gs_memo.end();
+                                    if (it != gs_memo.end()) {
+                                        std::memcpy(gid.data() + rr * n_gt, gid.data() + (size_t)it->second * n_gt, n_gt);
+                                        std::memcpy(order.data() + rr * n_gt, order.data() + (size_t)it->second * n_gt, n_gt);
+                                    } else {
+                                        (void)genotype_strings(n, genotypes, gid.data() + rr * n_gt, order.data() + rr * n_gt);     // <= 128 strings: always fits
+                                        if (biallelic) gs_memo.emplace(gt0[rr], (uint32_t)rr);
+                                    }
+                                    np->win_nodes[wi].push_back(row_node[rr]);
+                                    np->win_rows[wi].push_back((uint32_t)rr);
+                                }
+                            });
+                            std::vector<size_t> win_step0(nw + 1, 0);
+                            for (size_t wi = 0; wi < nw; ++wi) win_step0[wi + 1] = win_step0[wi] + 2 * np->win_rows[wi].size();
+                            const size_t n_steps = win_step0[nw];
+                            np->n_steps = n_steps;
+                            if (n_steps) {
+                                std::vector<long double> pw(n_steps * 2 * stride);
+                                std::vector<uint32_t> row(n_steps, 0);
+                                std::vector<uint8_t> restart(n_steps, 0);
+                                std::vector<uint64_t> fwd(n_rows, 0), bwd(n_rows, 0);
+                                std::vector<vgmi_hmm_chain> chains;
+                                for (size_t wi = 0; wi < nw; ++wi) {
+                                    const size_t m = np->win_rows[wi].size();
+                                    if (!m) continue;
+                                    chains.push_back(vgmi_hmm_chain{win_step0[wi], m, 0, 0});
+                                    chains.push_back(vgmi_hmm_chain{win_step0[wi] + m, m, 0, 0});
+                                }
+                                over_windows(g_phase.pass_b, [&](size_t wi) {
+                                    const size_t m = np->win_rows[wi].size();
+                                    if (!m) return;
+                                    const size_t step0 = win_step0[wi];
+                                    // the tables of powers are a function of the distance alone: neighbouring nodes are tens to hundreds of bases
+                                    // apart, so a window's few thousand steps share a few hundred distinct tables (same libm calls, each made once)
+                                    constexpr uint32_t kMemo = 4096;
+                                    std::vector<long double> memo((size_t)kMemo * 2 * stride);
+                                    std::vector<uint8_t> memo_have(kMemo, 0);
+                                    auto powers = [&](long double* dst, uint32_t distance) {
+                                        if (distance < kMemo && memo_have[distance]) {
+                                            std::memcpy(dst, &memo[(size_t)distance * 2 * stride], 2 * stride * sizeof(long double));
+                                            return;
+                                        }
+                                        long double recomb, no_recomb;
+                                        std::tie(recomb, no_recomb) = transition_probabilities(distance, (uint16_t)n_hap_);
+                                        for (uint32_t k = 0; k < stride; ++k) {
+                                            dst[k] = std::pow(no_recomb, (int32_t)k);
+                                            dst[stride + k] = std::pow(recomb, (int32_t)k);
+                                        }
+                                        if (distance < kMemo) {
+                                            std::memcpy(&memo[(size_t)distance * 2 * stride], dst, 2 * stride * sizeof(long double));
+                                            memo_have[distance] = 1;
+                                        }
+                                    };
+                                    const std::vector<Seen>& sn = seen[wi];
+                                    size_t j = 0;
+                                    for (size_t q = 0; q < sn.size(); ++q) {
+                                        if (sn[q].row < 0) continue;
+                                        const size_t fs = step0 + j, bs = step0 + m + (m - 1 - j);
+                                        powers(pw.data() + fs * 2 * stride, sn[q].start - (q ? sn[q - 1].end : 0u));
+                                        restart[fs] = (q == 0 || sn[q - 1].row < 0) ? 1 : 0;
+                                        row[fs] = (uint32_t)sn[q].row;
+                                        powers(pw.data() + bs * 2 * stride, (q + 1 < sn.size() ? sn[q + 1].start : 0u) - sn[q].end);
+                                        restart[bs] = (q + 1 == sn.size() || sn[q + 1].row < 0) ? 1 : 0;
+                                        row[bs] = (uint32_t)sn[q].row;
+                                        fwd[sn[q].row] = fs;
+                                        bwd[sn[q].row] = bs;
+                                        ++j;
+                                    }
+                                });
+                                const long double uniform = 1.0L / (long double)n_gt;
+                                if (vgmi_hmm_plan_create(dev_, (uint32_t)n_gt, cfg.sample_ploidy, keep_mat.data(), 1, n_rows, row.data(), restart.data(), pw.data(), n_steps,
+                                                         &uniform, chains.data(), (uint32_t)chains.size(), gid.data(), order.data(), fwd.data(), bwd.data(), &np->plan) != VGMI_OK)
+                                    throw std::runtime_error(std::string("device HMM plan: ") + vgmi_last_error(dev_));
                             }
-                            long double recomb, no_recomb;
-                            std::tie(recomb, no_recomb) = transition_probabilities(distance, (uint16_t)n_hap_);
-                            for (uint32_t k = 0; k < stride; ++k) {
-                                dst[k] = std::pow(no_recomb, (int32_t)k);
-                                dst[stride + k] = std::pow(recomb, (int32_t)k);
-                            }
-                            if (distance < kMemo) {
-                                std::memcpy(&memo[(size_t)distance * 2 * stride], dst, 2 * stride * sizeof(long double));
-                                memo_have[distance] = 1;
-                            }
-                        };
-                        const std::vector<Seen>& sn = seen[wi];
-                        size_t j = 0;
-                        for (size_t q = 0; q < sn.size(); ++q) {
-                            if (sn[q].row < 0) continue;
-                            const size_t fs = step0 + j, bs = step0 + m + (m - 1 - j);
-                            powers(pw.data() + fs * 2 * stride, sn[q].start - (q ? sn[q - 1].end : 0u));
-                            restart[fs] = (q == 0 || sn[q - 1].row < 0) ? 1 : 0;
-                            row[fs] = (uint32_t)sn[q].row;
-                            powers(pw.data() + bs * 2 * stride, (q + 1 < sn.size() ? sn[q + 1].start : 0u) - sn[q].end);
-                            restart[bs] = (q + 1 == sn.size() || sn[q + 1].row < 0) ? 1 : 0;
-                            row[bs] = (uint32_t)sn[q].row;
-                            fwd[sn[q].row] = fs;
-                            bwd[sn[q].row] = bs;
-                            ++j;
+                            pc.plan = np;
                         }
-                    });
+                        plan = pc.plan;
+                    }
+                    const std::vector<std::vector<uint32_t>>&win_nodes = plan->win_nodes, &win_rows = plan->win_rows;
+                    const size_t n_steps = plan->n_steps;
                     t_b = since_begin();
                     std::vector<long double> prob(n_rows ? n_rows : 1);
                     std::vector<uint32_t> winner(n_rows ? n_rows : 1, 0xFFFFFFFFu);
-                    if (n_steps) {
-                        const long double uniform = 1.0L / (long double)n_gt;
-                        if (vgmi_hmm_part_calls(ph.p, cfg.sample_ploidy, keep_mat.data(), 1, row.data(), restart.data(), pw.data(), n_steps, &uniform,
-                                                chains.data(), (uint32_t)chains.size(), gid.data(), order.data(), fwd.data(), bwd.data(), prob.data(),
-                                                winner.data()) != VGMI_OK)
-                            throw std::runtime_error(std::string("device HMM recursion: ") + vgmi_last_error(dev_));
-                    }
+                    if (n_steps && vgmi_hmm_part_calls_plan(ph.p, plan->plan, prob.data(), winner.data()) != VGMI_OK)
+                        throw std::runtime_error(std::string("device HMM recursion: ") + vgmi_last_error(dev_));
                     const int64_t tbb = since_begin();
                     t_calls = tbb;
                     if (g_phase_on)
                         std::fprintf(stderr, "[varigraph-mi] HMM part %zu (windows %zu-%zu): emissions, recursion and posterior on the device from %.3f to %.3f s (%zu of %zu nodes scored by the host, %zu scored again on the device): "
-                                     "emission kernel %.3f, host-scored nodes + strings %.3f, rows handed in %.3f, step tables %.3f, recursion + posterior %.3f\n",
+                                     "emission kernel %.3f, sequence checks (host) %.3f, rows fixed on the device %.3f, plan (strings + step tables: once per graph) %.3f, recursion + posterior %.3f\n",
                                      part, t0, t1 - 1, ta * 1e-9, tbb * 1e-9, [&] { size_t c2 = 0; for (auto& v : host_rows) c2 += v.size(); return c2; }(), n_rows, n_fixed_rows,
                                      (t_emit - ta) * 1e-9, (t_a - t_emit) * 1e-9, (t_rows - t_a) * 1e-9, (t_b - t_rows) * 1e-9, (t_calls - t_b) * 1e-9);
                     for (int64_t v = dev_first.load(); ta < v && !dev_first.compare_exchange_weak(v, ta);) {}

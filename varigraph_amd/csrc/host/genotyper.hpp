@@ -20,6 +20,7 @@
 #include <atomic>
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -170,15 +171,23 @@ private:
     // What a part of the windows hands to the device and what does not depend on the sample: which nodes the HMM works on, their
     // entry ranges and reference-allele masks, and the genotype strings of every node that ever had a score.  Listed for the first
     // sample, kept for the next (one list per part; `key` names the options it was made under).
-    struct EmitPartCache {
+    struct EmitPartPlan {      // made for one pattern of scored rows; immutable once made; the device block goes with the last holder
+        std::vector<uint8_t> scored;
+        std::vector<std::vector<uint32_t>> win_nodes, win_rows;      // per window: the scored nodes and their rows
+        vgmi_hmm_plan* plan = nullptr;
+        size_t n_steps = 0;
+        ~EmitPartPlan();
+    };
+    struct EmitPartCache {     // shared by the Genotypers of a graph (GraphIndex::shared_slots); `mu` guards the listing and the plan's making
+        std::mutex mu;
         std::string key;
         std::vector<uint64_t> e_begin;
         std::vector<uint32_t> e_count, row_node;
         std::vector<uint16_t> gt0;
         std::vector<size_t> win_row0;
-        std::vector<uint8_t> gid, order, have;      // per row: n_gt bytes each; have[row]: its strings are there
+        std::shared_ptr<EmitPartPlan> plan;
     };
-    std::vector<EmitPartCache> emit_cache_;
+    std::vector<std::shared_ptr<EmitPartCache>> emit_cache_;
     std::unique_ptr<uint32_t[]> kmer_pool_;   // what the nodes' KmerLists point into: place j of the node-ordered arrays at [j]
     vgmi_ctx* dev_ = nullptr;
     unsigned dev_parts_ = 4;

@@ -11,6 +11,8 @@
 #include <cstdint>
 #include <functional>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -73,6 +75,11 @@ struct GraphIndex {
     std::vector<uint32_t> node_key_index;
 
     unsigned threads = 1;   // host threads of load(): key index build and node resolution (graph2node)
+
+    // what the users of one graph share beyond the graph itself, by name (the Genotypers of a run: per part of the windows the row
+    // lists and the device-resident recursion inputs, genotyper.cpp); lives and dies with the graph
+    mutable std::mutex shared_mu;
+    mutable std::map<std::string, std::shared_ptr<void>> shared_slots;
 
     // throws std::runtime_error
     void load(const std::string& path);

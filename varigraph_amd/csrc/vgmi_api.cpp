@@ -3086,6 +3086,146 @@ int vgmi_hmm_part_calls(vgmi_hmm_part* part, uint32_t ploidy, const uint8_t* kee
                    nullptr, gid, order, fwd_step, bwd_step, prob, winner, part->d_obs);
 }
 
+// ---- a part's recursion inputs kept on the device (round 5).  Everything hmm_run uploads but the emission scores -- keep matrix, step
+// tables (pow), rows, restarts, chains, genotype strings' ids and order, the rows' steps: 230 MB per chr20-scale sample -- is a
+// function of the graph and the options, not of the sample: a plan holds it on the device, made once, used by every sample (and every
+// context of the device: the block is plain device memory, not a context's pool).
+struct vgmi_hmm_plan {
+    int device = 0;
+    uint8_t* d = nullptr;
+    uint32_t n_gt = 0, ploidy = 0, n_chains = 0;
+    uint64_t n_rows = 0, n_steps = 0;
+    size_t o_keep = 0, o_row = 0, o_rs = 0, o_pow = 0, o_uni = 0, o_ch = 0, o_gid = 0, o_ord = 0, o_fs = 0, o_bs = 0, bytes = 0;
+};
+
+int vgmi_hmm_plan_create(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, const uint8_t* keep, uint32_t n_windows, uint64_t n_rows, const uint32_t* row,
+                         const uint8_t* restart, const void* pow, uint64_t n_steps, const void* uniform, const vgmi_hmm_chain* chains, uint32_t n_chains,
+                         const uint8_t* gid, const uint8_t* order, const uint64_t* fwd_step, const uint64_t* bwd_step, vgmi_hmm_plan** out)
+{
+    if (!c || !out) return VGMI_E_INVALID;
+    *out = nullptr;
+    if (!keep || !row || !restart || !pow || !uniform || !chains || !gid || !order || !fwd_step || !bwd_step) return VGMI_E_INVALID;
+    if (n_gt < 1 || n_gt > VGMI_HMM_MAX_GT || ploidy < 1 || ploidy > 4) return fail(c, VGMI_E_INVALID, "HMM plan: 1..2048 genotypes of 1..4 haplotypes");
+    if (n_gt > 128)
+        for (uint32_t w = 0; w < n_windows; ++w) {
+            const uint8_t* m = keep + (size_t)w * n_gt * n_gt;
+            for (uint32_t i = 0; i < n_gt; ++i)
+                for (uint32_t j = i + 1; j < n_gt; ++j)
+                    if (m[(size_t)i * n_gt + j] != m[(size_t)j * n_gt + i]) return fail(c, VGMI_E_INVALID, "HMM plan: keep matrix not symmetric");
+        }
+    if (n_steps == 0 || n_chains == 0 || n_rows == 0) return fail(c, VGMI_E_INVALID, "HMM plan: nothing to plan");
+    for (uint32_t i = 0; i < n_chains; ++i)
+        if (chains[i].keep_index >= n_windows || chains[i].first_step + chains[i].n_steps > n_steps) return fail(c, VGMI_E_INVALID, "HMM plan: a chain points outside its arrays");
+    for (uint64_t s = 0; s < n_steps; ++s)
+        if (row[s] >= n_rows) return fail(c, VGMI_E_INVALID, "HMM plan: a step points outside the emission rows");
+    for (uint64_t i = 0; i < n_rows; ++i)
+        if (fwd_step[i] >= n_steps || bwd_step[i] >= n_steps) return fail(c, VGMI_E_INVALID, "HMM plan: a row points outside the steps");
+    HIPCHK(c, hipSetDevice(c->device));
+    auto* pl = new vgmi_hmm_plan;
+    pl->device = c->device;
+    pl->n_gt = n_gt;
+    pl->ploidy = ploidy;
+    pl->n_chains = n_chains;
+    pl->n_rows = n_rows;
+    pl->n_steps = n_steps;
+    const uint32_t stride = ploidy + 1;
+    const size_t b_keep = (size_t)n_windows * n_gt * n_gt, b_row = (size_t)n_steps * 4, w_pow = (size_t)2 * stride * 16, b_pow = (size_t)n_steps * w_pow,
+                 b_ch = (size_t)n_chains * sizeof(vgmi_hmm_chain), b_gid = (size_t)n_rows * n_gt, b_fs = (size_t)n_rows * 8;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    pl->o_keep = 0;
+    pl->o_row = up(pl->o_keep + b_keep);
+    pl->o_rs = up(pl->o_row + b_row);
+    pl->o_pow = up(pl->o_rs + n_steps);
+    pl->o_uni = up(pl->o_pow + b_pow);
+    pl->o_ch = pl->o_uni + 256;
+    pl->o_gid = up(pl->o_ch + b_ch);
+    pl->o_ord = up(pl->o_gid + b_gid);
+    pl->o_fs = up(pl->o_ord + b_gid);
+    pl->o_bs = up(pl->o_fs + b_fs);
+    pl->bytes = up(pl->o_bs + b_fs);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&pl->d), pl->bytes);
+    if (e != hipSuccess) {
+        delete pl;
+        (void)hipGetLastError();
+        return fail(c, VGMI_E_NOMEM, "HMM plan: not enough device memory");
+    }
+    e = hipMemcpy(pl->d + pl->o_keep, keep, b_keep, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl->d + pl->o_row, row, b_row, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl->d + pl->o_rs, restart, n_steps, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl->d + pl->o_pow, pow, b_pow, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl->d + pl->o_uni, uniform, 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl->d + pl->o_ch, chains, b_ch, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl->d + pl->o_gid, gid, b_gid, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl->d + pl->o_ord, order, b_gid, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl->d + pl->o_fs, fwd_step, b_fs, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl->d + pl->o_bs, bwd_step, b_fs, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(pl->d);
+        delete pl;
+        HIPCHK(c, e);
+    }
+    *out = pl;
+    return VGMI_OK;
+}
+
+void vgmi_hmm_plan_free(vgmi_hmm_plan* pl)
+{
+    if (!pl) return;
+    if (pl->d && hipSetDevice(pl->device) == hipSuccess) (void)hipFree(pl->d);
+    delete pl;
+}
+
+// recursion and posterior of a part on the inputs of a plan and the part's own emission scores: what comes back is the calls
+int vgmi_hmm_part_calls_plan(vgmi_hmm_part* part, const vgmi_hmm_plan* pl, void* prob, uint32_t* winner)
+{
+    if (!part || !pl || !prob || !winner) return VGMI_E_INVALID;
+    vgmi_ctx* c = part->c;
+    if (pl->device != c->device || pl->n_gt != part->n_gt || pl->n_rows != part->n_rows) return fail(c, VGMI_E_INVALID, "HMM plan: made for another part");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t w_obs = (size_t)pl->n_gt * 16, b_out = (size_t)pl->n_steps * w_obs, b_prob = (size_t)pl->n_rows * 16, b_win = (size_t)pl->n_rows * 4;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_prob = up(b_out), o_win = up(o_prob + b_prob), total = up(o_win + b_win);
+    size_t d_bytes = 0;
+    uint8_t* d = hmm_block_take(c, total, d_bytes);
+    if (!d) return fail(c, VGMI_E_NOMEM, "HMM recursion: not enough device memory");
+    hipStream_t st = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        HmmParams P{};
+        P.n_gt = pl->n_gt;
+        P.ploidy = pl->ploidy;
+        P.keep = pl->d + pl->o_keep;
+        P.obs = part->d_obs;
+        P.row = reinterpret_cast<const uint32_t*>(pl->d + pl->o_row);
+        P.restart = pl->d + pl->o_rs;
+        P.pow = pl->d + pl->o_pow;
+        P.uniform = pl->d + pl->o_uni;
+        P.chains = reinterpret_cast<const HmmChain*>(pl->d + pl->o_ch);
+        P.out = d;
+        e = launch_hmm_recursion(P, pl->n_chains, st);
+    }
+    if (e == hipSuccess) {
+        HmmPostParams Q{};
+        Q.n_gt = pl->n_gt;
+        Q.row0 = 0;
+        Q.ab = d;
+        Q.fwd_step = reinterpret_cast<const uint64_t*>(pl->d + pl->o_fs);
+        Q.bwd_step = reinterpret_cast<const uint64_t*>(pl->d + pl->o_bs);
+        Q.gid = pl->d + pl->o_gid;
+        Q.order = pl->d + pl->o_ord;
+        Q.prob = d + o_prob;
+        Q.winner = reinterpret_cast<uint32_t*>(d + o_win);
+        e = launch_hmm_posterior(Q, pl->n_rows, st);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(prob, d + o_prob, b_prob, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(winner, d + o_win, b_win, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (st) (void)hipStreamDestroy(st);
+    hmm_block_give(c, d, d_bytes);
+    HIPCHK(c, e);
+    return VGMI_OK;
+}
+
 int vgmi_hmm_tallies(vgmi_ctx* c, uint64_t n_rows, const uint64_t* entry_begin, const uint32_t* entry_count, const uint32_t* winner, uint32_t n_gt,
                      const uint8_t* hap_ab, uint32_t n_hap, uint64_t sel_mask, uint32_t* out, uint8_t* unique_out)
 {
@@ -3134,6 +3274,13 @@ void vgmi_hmm_part_free(vgmi_hmm_part* part)
     hmm_block_give(part->c, part->d_obs, part->obs_bytes);      // kept for the next part / sample (hipFree would wait for every stream)
     hmm_block_give(part->c, part->d_small, part->small_bytes);
     delete part;
+}
+
+int vgmi_device_of(vgmi_ctx* c, int* device)
+{
+    if (!c || !device) return VGMI_E_INVALID;
+    *device = c->device;
+    return VGMI_OK;
 }
 
 int vgmi_device_memory(vgmi_ctx* c, size_t* free_bytes, size_t* total_bytes)

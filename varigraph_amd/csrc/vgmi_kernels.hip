@@ -1847,31 +1847,11 @@ __device__ __forceinline__ bool swar_all_acgt(uint32_t v)
     return m == 0x80808080u;
 }
 
-#define VG_DEBIT_LDS 10240u      // bytes of read text a wavefront stages: 64 reads of up to ~155 bases (four wavefronts a workgroup, four workgroups a CU)
 __global__ __launch_bounds__(256) void even_debit_kernel(RowParams p, const uint64_t* __restrict__ read_off, uint64_t n_reads)
 {
-    // The 64 reads of a wavefront are one contiguous stretch of the block: copied into LDS with coalesced 16-byte loads (a lane per
-    // read straight from global memory is 64 memory-side requests per load instruction: 6 ms per 2e7 reads, request-bound), then every
-    // lane walks ITS read there in aligned 16-byte pieces.  Longer stretches are read in place.
-    __shared__ __attribute__((aligned(16))) uint8_t s_text[4][VG_DEBIT_LDS];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // (the text straight from global memory, 16 aligned bytes per lane and step: 7.6 ms per 2e7 reads; staged through LDS with
+    // coalesced loads first -- seq_kernel's way -- 9.1 ms: the per-byte state machine of a read's first k-odd bases is what it costs)
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t r_first = r - lane;
-    bool staged = false;
-    uint64_t stage_base = 0;
-    if (r_first < n_reads) {
-        const uint64_t r_last = r_first + 64 < n_reads ? r_first + 64 : n_reads;
-        const uint64_t b = read_off[r_first] & ~15ULL, e_st = read_off[r_last];
-        if (read_off[r_first] >= p.emit_from) return;
-        if (e_st - b <= VG_DEBIT_LDS) {
-            for (uint64_t o = b + lane * 16u; o < e_st; o += 1024)
-                *reinterpret_cast<uint4*>(&s_text[wave][o - b]) = load_chunk(p.bases, p.n_bytes, o);
-            staged = true;
-            stage_base = b;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     if (r >= n_reads) return;
     const uint64_t s = read_off[r];
     uint64_t e = read_off[r + 1] - 1;      // the read's '\n'
@@ -1883,7 +1863,6 @@ __global__ __launch_bounds__(256) void even_debit_kernel(RowParams p, const uint
     uint32_t l = 0, run = 0;
     const uint8_t* const bases = p.bases;
     auto piece = [&](uint64_t a) -> uint4 {
-        if (staged) return *reinterpret_cast<const uint4*>(&s_text[wave][a - stage_base]);
         if (a + 16 <= p.n_bytes) {
             typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
             const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(bases + a));

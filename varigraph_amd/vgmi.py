@@ -36,6 +36,7 @@ def load_library():
         "vgmi_destroy": (None, [vp]),
         "vgmi_last_error": (C.c_char_p, [vp]),
         "vgmi_stream": (vp, [vp]),
+        "vgmi_device_of": (i32, [vp, C.POINTER(i32)]),
         "vgmi_device_memory": (i32, [vp, C.POINTER(sz), C.POINTER(sz)]),
         "vgmi_table_upload": (i32, [vp, vp, sz, u32]),
         "vgmi_table_image_bytes": (i32, [vp, C.POINTER(sz)]),
@@ -87,6 +88,10 @@ def load_library():
         "vgmi_hmm_emissions": (i32, [vp, u32, u32, vp, vp, vp, C.c_uint64, u32, C.c_float, C.c_double, C.c_double, vp, C.c_uint64, vp, vp, vp, vp, vp,
                                       C.POINTER(vp)]),
         "vgmi_hmm_part_set_rows": (i32, [vp, C.c_uint64, vp, vp]),
+        "vgmi_hmm_part_fix_rows": (i32, [vp, C.c_uint64, vp, vp, vp, vp]),
+        "vgmi_hmm_plan_create": (i32, [vp, u32, u32, vp, u32, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp, u32, vp, vp, vp, vp, C.POINTER(vp)]),
+        "vgmi_hmm_part_calls_plan": (i32, [vp, vp, vp, vp]),
+        "vgmi_hmm_plan_free": (None, [vp]),
         "vgmi_hmm_part_calls": (i32, [vp, u32, vp, u32, vp, vp, vp, C.c_uint64, vp, vp, u32, vp, vp, vp, vp, vp, vp]),
         "vgmi_hmm_part_fetch": (i32, [vp, vp]),
         "vgmi_hmm_part_free": (None, [vp]),
@@ -483,8 +488,12 @@ class Context:
                                           _ptr(bwd_step), _ptr(prob), _ptr(winner), _ptr(ab)))
         return prob, winner, ab
 
-    def hmm_emissions(self, entries, cov_node, used, pos_a, pos_b, top_mask, bit_len, ave, lower, upper, tables, entry_begin, entry_count, gt0):
-        """vgmi_hmm_entries_upload + _sample_upload + _emissions + _part_fetch: returns (obs (rows, n_gt) longdouble, n_kept, flags)."""
+    def hmm_emissions(self, entries, cov_node, used, pos_a, pos_b, top_mask, bit_len, ave, lower, upper, tables, entry_begin, entry_count, gt0,
+                      fixes=None, calls=None):
+        """vgmi_hmm_entries_upload + _sample_upload + _emissions + _part_fetch: returns (obs (rows, n_gt) longdouble, n_kept, flags).
+        fixes = (rows, off, j, mask): vgmi_hmm_part_fix_rows before the fetch.  calls = dict(ploidy, keep, row, restart, pow, uniform,
+        chains, gid, order, fwd, bwd): the part's recursion and posterior both ways -- vgmi_hmm_part_calls with host arrays and
+        vgmi_hmm_plan_create + vgmi_hmm_part_calls_plan -- returned as a fourth item ((prob, winner), (prob, winner))."""
         entries = np.ascontiguousarray(entries, dtype=np.uint64)
         cov_node = np.ascontiguousarray(cov_node, dtype=np.uint8)
         used = np.ascontiguousarray(used, dtype=np.uint8)
@@ -504,11 +513,45 @@ class Context:
         self._chk(self._l.vgmi_hmm_emissions(self._h, n_gt, used.size, _ptr(used), _ptr(pos_a), _ptr(pos_b), int(top_mask), bit_len, float(ave), float(lower),
                                               float(upper), _ptr(tables), n_rows, _ptr(entry_begin), _ptr(entry_count), _ptr(gt0), _ptr(n_kept), _ptr(flags),
                                               C.byref(part)))
+        both = None
         try:
+            if fixes is not None:
+                f_rows, f_off, f_j, f_m = (np.ascontiguousarray(a, dtype=t) for a, t in zip(fixes, (np.uint64, np.uint32, np.uint16, np.uint16)))
+                self._chk(self._l.vgmi_hmm_part_fix_rows(part, f_rows.size, _ptr(f_rows), _ptr(f_off), _ptr(f_j), _ptr(f_m)))
             obs = np.zeros((n_rows, n_gt), dtype=np.longdouble)
             self._chk(self._l.vgmi_hmm_part_fetch(part, _ptr(obs)))
+            if calls is not None:
+                keep = np.ascontiguousarray(calls["keep"], dtype=np.uint8)
+                row = np.ascontiguousarray(calls["row"], dtype=np.uint32)
+                restart = np.ascontiguousarray(calls["restart"], dtype=np.uint8)
+                pw = np.ascontiguousarray(calls["pow"], dtype=np.longdouble)
+                uni = np.ascontiguousarray([calls["uniform"]], dtype=np.longdouble)
+                ch = np.zeros((len(calls["chains"]), 3), dtype=np.uint64)
+                for i, (f, n, k) in enumerate(calls["chains"]):
+                    ch[i] = (f, n, k)
+                gid = np.ascontiguousarray(calls["gid"], dtype=np.uint8)
+                order = np.ascontiguousarray(calls["order"], dtype=np.uint8)
+                fwd = np.ascontiguousarray(calls["fwd"], dtype=np.uint64)
+                bwd = np.ascontiguousarray(calls["bwd"], dtype=np.uint64)
+                out = []
+                p1, w1 = np.zeros(n_rows, dtype=np.longdouble), np.zeros(n_rows, dtype=np.uint32)
+                self._chk(self._l.vgmi_hmm_part_calls(part, calls["ploidy"], _ptr(keep), 1, _ptr(row), _ptr(restart), _ptr(pw), row.size, _ptr(uni), _ptr(ch),
+                                                       len(calls["chains"]), _ptr(gid), _ptr(order), _ptr(fwd), _ptr(bwd), _ptr(p1), _ptr(w1)))
+                plan = C.c_void_p()
+                self._chk(self._l.vgmi_hmm_plan_create(self._h, n_gt, calls["ploidy"], _ptr(keep), 1, n_rows, _ptr(row), _ptr(restart), _ptr(pw), row.size, _ptr(uni),
+                                                        _ptr(ch), len(calls["chains"]), _ptr(gid), _ptr(order), _ptr(fwd), _ptr(bwd), C.byref(plan)))
+                try:
+                    for _ in range(2):      # a plan serves any number of calls
+                        p2, w2 = np.zeros(n_rows, dtype=np.longdouble), np.zeros(n_rows, dtype=np.uint32)
+                        self._chk(self._l.vgmi_hmm_part_calls_plan(part, plan, _ptr(p2), _ptr(w2)))
+                        out.append((p2, w2))
+                finally:
+                    self._l.vgmi_hmm_plan_free(plan)
+                both = ((p1, w1), out[0], out[1])
         finally:
             self._l.vgmi_hmm_part_free(part)
+        if both is not None:
+            return obs, n_kept[:n_rows], flags[:n_rows], both
         return obs, n_kept[:n_rows], flags[:n_rows]
 
     def hmm_calls_part(self, keep, obs, row, restart, pow_tables, uniform, chains, ploidy, gid, order, fwd_step, bwd_step, rows, steps,
