@@ -61,6 +61,39 @@ int main()
         if (a != by_stream(x)) ++bad;
         ++n;
     }
+    {   // long double (the calls' posteriors): ties and near-ties of every tenth, random values in [0, 1] and beyond, tiny ones, the library's cases
+        auto check_ld = [&](long double x) {
+            std::string a;
+            vgh::append_fixed1(a, x);
+            if (a != by_stream(x)) {
+                if (bad < 10) std::printf("long double %La: %s vs %s\n", x, a.c_str(), by_stream(x).c_str());
+                ++bad;
+            }
+            ++n;
+        };
+        for (int k = 0; k <= 4000; ++k) {
+            long double x = (long double)k / 20.0L;
+            check_ld(x);
+            long double lo = x, hi = x;
+            for (int d = 0; d < 3; ++d) {
+                lo = std::nextafterl(lo, -1.0L);
+                hi = std::nextafterl(hi, 1e9L);
+                if (lo >= 0) check_ld(lo);
+                check_ld(hi);
+            }
+        }
+        std::uniform_real_distribution<double> u01(0.0, 1.0);
+        for (int i = 0; i < 2000000; ++i) {
+            const long double x = (long double)u01(rng) + (long double)u01(rng) * 0x1p-53L;      // all 64 bits of the significand in play
+            check_ld(x);
+            check_ld(x * 0.01L);
+            check_ld(x * 1234.5L);
+        }
+        for (int e = -16445; e <= 60; e += (e < -80 || e > 0) ? 37 : 1) { check_ld(std::ldexp(1.0L, e)); check_ld(std::ldexp(1.9999999999999999999L, e)); }
+        for (long double x : {1e15L, 9.99999e14L, -0.0L, -1.0L, 1e300L, std::numeric_limits<long double>::infinity(), std::numeric_limits<long double>::quiet_NaN(),
+                              std::numeric_limits<long double>::denorm_min(), 0.95L, 0.05L, 0.15L, 0.25L, 0.35L, 0.45L, 0.55L, 0.65L, 0.75L, 0.85L})
+            check_ld(x);
+    }
     for (uint64_t v : {0ull, 9ull, 10ull, 255ull, 18446744073709551615ull}) {
         std::string a;
         vgh::append_uint(a, v);

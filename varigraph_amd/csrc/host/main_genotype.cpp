@@ -212,6 +212,11 @@ int main_genotype(int argc, char** argv)
 
     const auto t0 = std::chrono::steady_clock::now();
     auto secs = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    // The runtime gives a process four hardware queues by default and lets the streams beyond them share one: a sample's counting
+    // then waits behind another sample's recursion kernel for its whole length (0.4-0.6 s at chr20 scale; with eight samples in
+    // flight the later samples' counting took 0.6-0.75 s instead of 0.1, and the run two rounds instead of one:
+    // profiles/r5_c4_stages.txt).  Asked for before anything touches the device; a value the user has set stays.
+    setenv("GPU_MAX_HW_QUEUES", "24", 0);
 
     auto samples = parse_samples(o.samples);   // exits on a bad list before anything touches the device
     vgh::GraphIndex g;
