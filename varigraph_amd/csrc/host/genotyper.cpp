@@ -2111,6 +2111,47 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                                     np->win_rows[wi].push_back((uint32_t)rr);
                                 }
                             });
+                            {   // the lines' shared heads, window by window (one walk along the chromosome's site map per window)
+                                std::vector<std::string> heads(nw);
+                                std::vector<std::vector<uint32_t>> head_len(nw);
+                                over_windows(g_phase.pass_a, [&](size_t wi) {
+                                    const Chrom& chr = *tasks[t0 + wi].chr;
+                                    auto vc = g_.vcf_info.find(chr.name);
+                                    std::string& out = heads[wi];
+                                    head_len[wi].assign(win_row0[wi + 1] - win_row0[wi], 0);
+                                    if (vc == g_.vcf_info.end()) return;
+                                    const auto& sites = vc->second;
+                                    auto site = win_row0[wi] < win_row0[wi + 1] ? sites.lower_bound(chr.nodes[row_node[win_row0[wi]]].start) : sites.end();
+                                    uint32_t prev_start = 0;
+                                    for (size_t rr = win_row0[wi]; rr < win_row0[wi + 1]; ++rr) {
+                                        const Node& node = chr.nodes[row_node[rr]];
+                                        if (node.start < prev_start) site = sites.lower_bound(node.start);
+                                        prev_start = node.start;
+                                        while (site != sites.end() && site->first < node.start) ++site;
+                                        if (site == sites.end() || site->first != node.start) continue;
+                                        const auto& fields = site->second;
+                                        const size_t before = out.size();
+                                        for (size_t i = 0; i < 9; i++) {
+                                            if (i == 0) out += fields[i];
+                                            else if (i == 6) out += "\tPASS";
+                                            else if (i < 8) { out += '\t'; out += fields[i]; }
+                                            else out += "\tGT:GQ:GPP:NAK:CAK:UK";
+                                        }
+                                        out += '\t';
+                                        head_len[wi][rr - win_row0[wi]] = (uint32_t)(out.size() - before);
+                                    }
+                                });
+                                np->line_head_off.assign(n_rows + 1, 0);
+                                size_t total = 0;
+                                for (size_t wi = 0; wi < nw; ++wi) total += heads[wi].size();
+                                np->line_head.reserve(total);
+                                for (size_t wi = 0; wi < nw; ++wi) {
+                                    for (size_t rr = win_row0[wi]; rr < win_row0[wi + 1]; ++rr)
+                                        np->line_head_off[rr + 1] = np->line_head_off[rr] + head_len[wi][rr - win_row0[wi]];
+                                    np->line_head += heads[wi];
+                                    std::string().swap(heads[wi]);
+                                }
+                            }
                             std::vector<size_t> win_step0(nw + 1, 0);
                             for (size_t wi = 0; wi < nw; ++wi) win_step0[wi + 1] = win_step0[wi] + 2 * np->win_rows[wi].size();
                             const size_t n_steps = win_step0[nw];
@@ -2238,7 +2279,53 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                             }
                         }
                         window_finish(w, pr.data(), wn.data(), r, tally.empty() ? nullptr : tl.data(), tally.empty() ? nullptr : tu.data());
-                        make_piece(t0 + wi);
+                        // the window's lines (make_piece's, for the scored nodes -- no other node has a call -- with the head of every
+                        // line taken from the plan instead of the site map)
+                        {
+                            piece_done[t0 + wi] = 1;
+                            const Chrom& chr = *tasks[t0 + wi].chr;
+                            std::string out;
+                            size_t room = 0;
+                            for (size_t q = 0; q < w.nodes.size(); ++q) room += (size_t)(plan->line_head_off[win_rows[wi][q] + 1] - plan->line_head_off[win_rows[wi][q]]) + 48;
+                            out.reserve(room);
+                            for (size_t q = 0; q < w.nodes.size(); ++q) {
+                                const Node& node = chr.nodes[w.nodes[q]];
+                                const SiteCall& call = node.call;
+                                if (call.haps.empty()) continue;
+                                const size_t rw = win_rows[wi][q];
+                                const uint64_t h0 = plan->line_head_off[rw], h1 = plan->line_head_off[rw + 1];
+                                if (h0 == h1) continue;      // no such site in the VCF
+                                bool all_ref = true;
+                                for (uint16_t hap : call.haps) all_ref = all_ref && node.gn->hap_gt[hap] == 0;
+                                if (all_ref) continue;
+                                out.append(plan->line_head, h0, h1 - h0);
+                                const float gq = phred_scaled(call.probability);
+                                const bool no_call = gq < cfg.min_gq;
+                                for (size_t i = 0; i < call.haps.size(); ++i) {
+                                    if (i) out += '/';
+                                    if (no_call) out += '.';
+                                    else append_uint(out, (uint64_t)node.gn->hap_gt[call.haps[i]]);
+                                }
+                                out += ':';
+                                append_fixed1(out, gq);
+                                out += ':';
+                                append_fixed1(out, call.probability);
+                                out += ':';
+                                for (size_t i = 0; i < call.kmer_num.size(); ++i) {
+                                    if (i) out += ',';
+                                    append_uint(out, call.kmer_num[i]);
+                                }
+                                out += ':';
+                                for (size_t i = 0; i < call.kmer_ave_cov.size(); i++) {
+                                    if (i) out += ',';
+                                    append_fixed1(out, call.kmer_ave_cov[i]);
+                                }
+                                out += ':';
+                                append_uint(out, call.unique_kmers);
+                                out += '\n';
+                            }
+                            pieces[t0 + wi] = std::move(out);
+                        }
                         emit_windows_done += !w.nodes.empty();
                     });
                 } catch (const std::exception& e) {

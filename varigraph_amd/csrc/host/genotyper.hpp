@@ -174,6 +174,10 @@ private:
     struct EmitPartPlan {      // made for one pattern of scored rows; immutable once made; the device block goes with the last holder
         std::vector<uint8_t> scored;
         std::vector<std::vector<uint32_t>> win_nodes, win_rows;      // per window: the scored nodes and their rows
+        // the part of a site's VCF line that every sample shares (CHROM .. INFO with FILTER forced PASS, FORMAT and the tab behind it:
+        // src/genotype.cpp:1628-1640), per row of the part, end to end; a row without a site in the VCF has none
+        std::string line_head;
+        std::vector<uint64_t> line_head_off;                         // n_rows + 1
         vgmi_hmm_plan* plan = nullptr;
         size_t n_steps = 0;
         ~EmitPartPlan();

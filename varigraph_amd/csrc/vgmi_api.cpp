@@ -87,6 +87,8 @@ struct vgmi_ctx {
     uint32_t* d_xt_id = nullptr;                // key index -> counter id (path order), nullptr: identity
     ulonglong2* d_xt_over = nullptr;            // exact table of the k-mers that overflowed their lines (repeats), or nullptr
     uint4* d_ct_buckets = nullptr;              // context table (vgmi_ctable.hip): the default form of the large-graph table
+    size_t ct_vmm_bytes = 0;                    // non-zero: d_ct_buckets is a mapping made by big_alloc (virtual memory API), of this size
+    hipMemGenericAllocationHandle_t ct_vmm_handle{};
     uint64_t ct_entries = 0, ct_unitigs = 0, ct_moved = 0;   // entries built, unitigs they came from, entries not in their home bucket
     unsigned long long* d_pt_index = nullptr;   // path table of small graphs (build_ptable): 12-mer -> places in the unitig sequence
     uint32_t *d_pt_S = nullptr, *d_pt_VB = nullptr, *d_pt_SB = nullptr, *d_pt_SLOT = nullptr;   // sequence, k-mer starts, saturation bits, slots
@@ -204,7 +206,12 @@ void free_table(vgmi_ctx* c)
     if (c->d_xt_over) (void)hipFree(c->d_xt_over);
     c->d_xt_over = nullptr;
     c->xt_over_keys = 0;
-    if (c->d_ct_buckets) (void)hipFree(c->d_ct_buckets);
+    if (c->d_ct_buckets && c->ct_vmm_bytes) {
+        (void)hipMemUnmap(c->d_ct_buckets, c->ct_vmm_bytes);
+        (void)hipMemRelease(c->ct_vmm_handle);
+        (void)hipMemAddressFree(c->d_ct_buckets, c->ct_vmm_bytes);
+        c->ct_vmm_bytes = 0;
+    } else if (c->d_ct_buckets) (void)hipFree(c->d_ct_buckets);
     c->d_ct_buckets = nullptr;
     c->ct_entries = c->ct_unitigs = c->ct_moved = 0;
     for (void* q : {(void*)c->d_pt_index, (void*)c->d_pt_S, (void*)c->d_pt_VB, (void*)c->d_pt_SB, (void*)c->d_pt_SLOT})
@@ -489,7 +496,47 @@ int build_ctable(vgmi_ctx* c)
         cleanup();
         return fail(c, VGMI_E_NOMEM, "not enough device memory for the context table");
     }
-    he = hipMalloc(reinterpret_cast<void**>(&c->d_ct_buckets), (size_t)64 * (n_buckets + CT_HOPS));
+    // VGMI_CT_VMM=<MiB>: the table as ONE physical allocation mapped at a virtual address aligned to that many MiB (the virtual-memory
+    // API), instead of hipMalloc's placement -- the experiment on the process-to-process spread of the whole-genome-class kernel
+    // (29-34 ms in round 4: 20 GB of random 64-byte reads are one address translation each)
+    {
+        const size_t want = (size_t)64 * (n_buckets + CT_HOPS);
+        const char* ev = getenv("VGMI_CT_VMM");
+        const size_t align_mib = ev ? (size_t)atol(ev) : 0;
+        bool done = false;
+        if (align_mib >= 2) {
+            hipMemAllocationProp prop{};
+            prop.type = hipMemAllocationTypePinned;
+            prop.location.type = hipMemLocationTypeDevice;
+            prop.location.id = c->device;
+            size_t gran = 0;
+            if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran) {
+                const size_t bytes = (want + gran - 1) / gran * gran;
+                void* va = nullptr;
+                hipMemGenericAllocationHandle_t h{};
+                if (hipMemAddressReserve(&va, bytes, align_mib << 20, nullptr, 0) == hipSuccess) {
+                    if (hipMemCreate(&h, bytes, &prop, 0) == hipSuccess) {
+                        hipMemAccessDesc acc{};
+                        acc.location = prop.location;
+                        acc.flags = hipMemAccessFlagsProtReadWrite;
+                        if (hipMemMap(va, bytes, 0, h, 0) == hipSuccess && hipMemSetAccess(va, bytes, &acc, 1) == hipSuccess) {
+                            c->d_ct_buckets = static_cast<uint4*>(va);
+                            c->ct_vmm_bytes = bytes;
+                            c->ct_vmm_handle = h;
+                            done = true;
+                            if (getenv("VGMI_VERBOSE")) fprintf(stderr, "[vgmi] context table: %zu bytes mapped at %p (granularity %zu)\n", bytes, va, gran);
+                        } else {
+                            (void)hipMemRelease(h);
+                            (void)hipMemAddressFree(va, bytes);
+                        }
+                    } else (void)hipMemAddressFree(va, bytes);
+                }
+                (void)hipGetLastError();
+            }
+        }
+        he = done ? hipSuccess : hipMalloc(reinterpret_cast<void**>(&c->d_ct_buckets), want);
+        if (!done && getenv("VGMI_VERBOSE")) fprintf(stderr, "[vgmi] context table: %zu bytes by hipMalloc at %p\n", want, (void*)c->d_ct_buckets);
+    }
     x.cb = c->d_ct_buckets;
     x.n_buckets = (uint32_t)n_buckets;
     x.counts = c->d_xt_counts;
