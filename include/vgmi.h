@@ -308,6 +308,13 @@ int vgmi_hmm_emissions(vgmi_ctx *ctx, uint32_t n_gt, uint32_t n_used, const uint
                        uint64_t top_mask, uint32_t bit_len, float ave, double lower, double upper, const void *tables,
                        uint64_t n_rows, const uint64_t *entry_begin, const uint32_t *entry_count, const uint16_t *gt0,
                        uint32_t *n_kept_out, uint8_t *flags_out, vgmi_hmm_part **out);
+/* ... the same for genotypes of `ploidy` haplotypes, 2 .. 4 (a polyploid sample's genotypes are blocks of consecutive haplotypes,
+ * src/genotype.cpp:846-873): pos[g * ploidy + q] = the place in `used` of genotype g's q-th haplotype; tables holds (ploidy + 1) x 256
+ * terms (geometric for h = 0, Poisson(ave * h) for h = 1 .. ploidy).  vgmi_hmm_emissions is this with ploidy 2. */
+int vgmi_hmm_emissions_ploidy(vgmi_ctx *ctx, uint32_t n_gt, uint32_t ploidy, uint32_t n_used, const uint8_t *used, const uint8_t *pos,
+                              uint64_t top_mask, uint32_t bit_len, float ave, double lower, double upper, const void *tables, uint64_t n_rows,
+                              const uint64_t *entry_begin, const uint32_t *entry_count, const uint16_t *gt0, uint32_t *n_kept_out,
+                              uint8_t *flags_out, vgmi_hmm_part **out);
 int vgmi_hmm_part_set_rows(vgmi_hmm_part *part, uint64_t n, const uint64_t *rows, const void *obs_rows /* n x n_gt long doubles */);
 /* ... or, for the rows flagged with bit 0, leave the products on the device (round 5): the host consults the haplotypes' sequences
  * (strings: src/genotype.cpp:760-800) and says which entries of a row lose which haplotypes -- entry fix_j[i] of row rows[r]

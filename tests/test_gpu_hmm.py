@@ -515,3 +515,63 @@ def test_flagged_rows_scored_again_on_the_device_and_plans():
     assert np.array_equal(p1.view(np.uint8), p2.view(np.uint8)) and np.array_equal(w1, w2)
     assert np.array_equal(p1.view(np.uint8), p3.view(np.uint8)) and np.array_equal(w1, w3)
     assert (w1 != 0xFFFFFFFF).sum() > n_rows // 2
+
+
+@pytest.mark.parametrize("ploidy", [3, 4])
+def test_emission_scores_of_polyploid_genotypes_on_the_device(ploidy):
+    """vgmi_hmm_emissions_ploidy (round 5): genotypes of three and four haplotypes -- a polyploid sample's are blocks of consecutive
+    haplotypes of the panel (src/genotype.cpp:846-873), a haplotype may stand in a genotype more than once -- against the product spelled
+    out in numpy.longdouble: copy numbers 0 .. ploidy, Poisson terms per copy number."""
+    rng = np.random.default_rng(900 + ploidy)
+    n_hap, bit_len = 13, 2
+    used = np.arange(n_hap, dtype=np.uint8)
+    blocks = [[(b + q) % n_hap for q in range(ploidy)] for b in range(0, n_hap - 1, ploidy)] + [[0] * ploidy, [1, 1] + [2] * (ploidy - 2)]
+    pos = np.array(blocks, dtype=np.uint8)
+    n_gt = pos.shape[0]
+    top_mask = (1 << n_hap) - 1
+    ave = np.float32(11.25)
+    lower, upper = float(ave) - 1.96 * float(np.sqrt(np.float64(ave))), float(ave) + 1.96 * float(np.sqrt(np.float64(ave)))
+    tables = (rng.random((ploidy + 1) * 256).astype(LD) + LD(0.05)) * np.power(LD(10), rng.integers(-200, 1, size=(ploidy + 1) * 256).astype(LD))
+    n_rows = 150
+    counts = rng.integers(0, 70, size=n_rows)
+    entry_begin = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
+    n_entries = int(counts.sum())
+    f = rng.choice([1, 1, 1, 2, 3], size=n_entries).astype(np.uint64)
+    bits = rng.integers(1, 1 << n_hap, size=n_entries).astype(np.uint64)
+    lb = rng.integers(0, 2, size=n_entries).astype(np.uint64)
+    bits |= lb << np.uint64(8 * bit_len - 1)
+    cov = rng.choice([0, 1, 4, 5, 8, 11, 12, 17, 18, 30, 255], size=n_entries).astype(np.uint8)
+    entries = (f << np.uint64(8)) | (bits << np.uint64(16))
+    gt0 = rng.integers(0, 1 << n_hap, size=n_rows).astype(np.uint16)
+    ctx = vgmi.Context(0, buffer_mib=16)
+    try:
+        obs, n_kept, flags = ctx.hmm_emissions(entries, cov, used, None, None, top_mask, bit_len, ave, lower, upper, tables, entry_begin, counts, gt0, pos=pos)
+    finally:
+        ctx.close()
+
+    def mld(h, c, ff):
+        if ff == 1:
+            return c
+        cf = np.float32(c)
+        if h > 0 and cf > ave * np.float32(h):
+            return int(ave * np.float32(h)) & 0xFF
+        if h == 0 and cf > ave:
+            return 0 if float(ff) > float(cf) / upper else int(cf / np.float32(ff)) & 0xFF
+        if h == 0:
+            return int(cf / np.float32(ff)) & 0xFF
+        return c
+    seen_h = set()
+    for r in range(n_rows):
+        prod = np.ones(n_gt, dtype=LD)
+        for j in range(int(entry_begin[r]), int(entry_begin[r]) + int(counts[r])):
+            c, ff, b = int(cov[j]), int(f[j]), int(bits[j])
+            l = (b >> (8 * bit_len - 1)) & 1
+            in_interval = l == 1 and lower <= c <= upper
+            one = [1 if (in_interval and (int(gt0[r]) >> p) & 1) else (b >> p) & 1 for p in range(n_hap)]
+            fj = 2 if (l == 1 and ff == 1) else ff
+            hs = np.array([sum(one[p] for p in blk) for blk in blocks])
+            seen_h.update(hs.tolist())
+            prod = prod * np.array([tables[h * 256 + mld(h, c, fj)] for h in hs], dtype=LD)
+        assert n_kept[r] == counts[r], r
+        assert np.array_equal(obs[r], prod), (r, int(np.argmax(obs[r] != prod)))
+    assert seen_h == set(range(ploidy + 1))

@@ -1590,7 +1590,8 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
         }
         const bool device_ok = fits_device && dev_n_gt >= 1 && dev_n_gt <= 2048 && total_room && total_room * dev_n_gt * sizeof(long double) <= (score_gib << 30);
         // the emission scores can be computed on the device as well (below): a diploid sample, every haplotype selected, whole lists
-        dev_emit = device_ok && !emit_device_off_ && r.packed != nullptr && cfg.sample_ploidy == 2 && n_hap_ <= r.haploid_num && n_hap_ <= 16 &&
+        // (round 5: polyploid samples too -- their genotypes are blocks of `ploidy` consecutive haplotypes, :846-873, a handful per window)
+        dev_emit = device_ok && !emit_device_off_ && r.packed != nullptr && cfg.sample_ploidy >= 2 && cfg.sample_ploidy <= 4 && n_hap_ <= r.haploid_num && n_hap_ <= 16 &&
                    dev_n_gt <= 128 && lists_whole_.load() && [] { const char* e = getenv("VGH_HMM_EMIT_DEVICE"); return !(e && e[0] == '0'); }();
         if (device_ok && !dev_emit) {
             raw_obs.p = std::malloc(total_room * dev_n_gt * sizeof(long double));
@@ -1836,8 +1837,8 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
         for (const auto& gtv : genotypes) used.insert(used.end(), gtv.begin(), gtv.end());
         std::sort(used.begin(), used.end());
         used.erase(std::unique(used.begin(), used.end()), used.end());
-        bool pairs = true;
-        for (const auto& gtv : genotypes) pairs = pairs && gtv.size() == 2;
+        bool pairs = true;      // (every genotype holds `ploidy` haplotypes: pairs for a diploid sample)
+        for (const auto& gtv : genotypes) pairs = pairs && gtv.size() == cfg.sample_ploidy;
         if (pairs && n_gt >= 1 && n_gt <= 128 && used.size() <= 16) {
             GenotypeList glist;
             glist.off.assign(n_gt + 1, 0);
@@ -1848,11 +1849,18 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
             }
             glist.pos_a.resize(n_gt);
             glist.pos_b.resize(n_gt);
+            glist.pairs = cfg.sample_ploidy == 2;
+            std::vector<uint8_t> pos_all(n_gt * cfg.sample_ploidy);      // per genotype its haplotypes' places in `used`
             for (size_t gi = 0; gi < n_gt; ++gi) {
                 glist.flat.insert(glist.flat.end(), genotypes[gi].begin(), genotypes[gi].end());
                 glist.off[gi + 1] = (uint32_t)glist.flat.size();
                 glist.pos_a[gi] = where[genotypes[gi][0]];
                 glist.pos_b[gi] = where[genotypes[gi][1]];
+                for (uint32_t q = 0; q < cfg.sample_ploidy; ++q) pos_all[gi * cfg.sample_ploidy + q] = where[genotypes[gi][q]];
+            }
+            if (cfg.sample_ploidy != 2) {      // (hidden_states' pair shuffle is for pairs; the host-scored path of VGH_HMM_FIX_DEVICE=0 takes the general loop)
+                glist.pos_a.clear();
+                glist.pos_b.clear();
             }
             auto shared2 = [](const std::vector<uint16_t>& a, const std::vector<uint16_t>& b) -> uint8_t {
                 uint8_t n2 = 0;
@@ -1868,11 +1876,11 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                 for (size_t j = 0; j < n_gt; ++j) keep_mat[i * n_gt + j] = shared2(genotypes[i], genotypes[j]);
             uint64_t top_mask = 0;
             for (uint16_t hap : top) top_mask |= 1ULL << hap;
-            // the sample's libm values: geometric(error_param(ave), c) for h = 0, poisson(ave * h, c) for h = 1, 2
-            std::vector<long double> tab(768);
+            // the sample's libm values: geometric(error_param(ave), c) for h = 0, poisson(ave * h, c) for h = 1 .. ploidy
+            std::vector<long double> tab((size_t)(cfg.sample_ploidy + 1) * 256);
             for (int c2 = 0; c2 < 256; ++c2) {
                 tab[c2] = geometric(error_param(ave), (uint8_t)c2);
-                for (uint8_t h = 1; h <= 2; ++h) tab[(size_t)h * 256 + c2] = poisson_pmf(ave * h, (uint8_t)c2);
+                for (uint8_t h = 1; h <= cfg.sample_ploidy; ++h) tab[(size_t)h * 256 + c2] = poisson_pmf(ave * h, (uint8_t)c2);
             }
             if (!entries_uploaded_) {
                 if (vgmi_hmm_entries_upload(dev_, packed_.data(), packed_.size()) != VGMI_OK) throw std::runtime_error(std::string("device HMM emissions: ") + vgmi_last_error(dev_));
@@ -1963,9 +1971,9 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                     const int64_t ta = since_begin();
                     int64_t t_emit = 0, t_a = 0, t_rows = 0, t_b = 0, t_calls = 0;
                     size_t n_fixed_rows = 0;
-                    if (vgmi_hmm_emissions(dev_, (uint32_t)n_gt, (uint32_t)used.size(), used8.data(), glist.pos_a.data(), glist.pos_b.data(), top_mask,
-                                           (uint32_t)g_.bitlen, ave, lower, upper, tab.data(), n_rows, e_begin.data(), e_count.data(), gt0.data(), n_kept.data(),
-                                           flags.data(), &ph.p) != VGMI_OK)
+                    if (vgmi_hmm_emissions_ploidy(dev_, (uint32_t)n_gt, cfg.sample_ploidy, (uint32_t)used.size(), used8.data(), pos_all.data(), top_mask,
+                                                  (uint32_t)g_.bitlen, ave, lower, upper, tab.data(), n_rows, e_begin.data(), e_count.data(), gt0.data(), n_kept.data(),
+                                                  flags.data(), &ph.p) != VGMI_OK)
                         throw std::runtime_error(std::string("device HMM emissions: ") + vgmi_last_error(dev_));
                     t_emit = since_begin();
                     for (size_t rr = 0; rr < n_rows; ++rr)

@@ -2979,14 +2979,41 @@ int vgmi_hmm_emissions(vgmi_ctx* c, uint32_t n_gt, uint32_t n_used, const uint8_
                        const uint64_t* entry_begin, const uint32_t* entry_count, const uint16_t* gt0, uint32_t* n_kept_out,
                        uint8_t* flags_out, vgmi_hmm_part** out)
 {
-    if (!c || !used || !pos_a || !pos_b || !tables || !out) return VGMI_E_INVALID;
+    if (!pos_a || !pos_b || n_gt < 1 || n_gt > 128) return VGMI_E_INVALID;
+    std::vector<uint8_t> pos(2 * (size_t)n_gt);
+    for (uint32_t g = 0; g < n_gt; ++g) {
+        pos[2 * g] = pos_a[g];
+        pos[2 * g + 1] = pos_b[g];
+    }
+    return vgmi_hmm_emissions_ploidy(c, n_gt, 2, n_used, used, pos.data(), top_mask, bit_len, ave, lower, upper, tables, n_rows, entry_begin, entry_count, gt0,
+                                     n_kept_out, flags_out, out);
+}
+
+// ... for genotypes of `ploidy` haplotypes (2 .. 4): pos[g * ploidy + q] = the place in `used` of genotype g's q-th haplotype; tables holds
+// (ploidy + 1) x 256 terms (geometric for h = 0, Poisson(ave * h) for h = 1 .. ploidy)
+int vgmi_hmm_emissions_ploidy(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, uint32_t n_used, const uint8_t* used, const uint8_t* pos, uint64_t top_mask,
+                              uint32_t bit_len, float ave, double lower, double upper, const void* tables, uint64_t n_rows, const uint64_t* entry_begin,
+                              const uint32_t* entry_count, const uint16_t* gt0, uint32_t* n_kept_out, uint8_t* flags_out, vgmi_hmm_part** out)
+{
+    if (!c || !used || !pos || !tables || !out) return VGMI_E_INVALID;
+    if (ploidy < 2 || ploidy > 4) return fail(c, VGMI_E_INVALID, "HMM emissions: genotypes of 2..4 haplotypes");
+    if (n_gt < 1 || n_gt > 128) return fail(c, VGMI_E_INVALID, "HMM emissions: 1..128 genotypes");
+    uint8_t pos_a_buf[128], pos_b_buf[128], pos_more_buf[2][128];
+    memset(pos_more_buf, 0, sizeof pos_more_buf);
+    for (uint32_t g = 0; g < n_gt; ++g) {
+        pos_a_buf[g] = pos[(size_t)g * ploidy];
+        pos_b_buf[g] = pos[(size_t)g * ploidy + 1];
+        for (uint32_t q = 2; q < ploidy; ++q) pos_more_buf[q - 2][g] = pos[(size_t)g * ploidy + q];
+        for (uint32_t q = 0; q < ploidy; ++q)
+            if (pos[(size_t)g * ploidy + q] >= n_used) return fail(c, VGMI_E_INVALID, "HMM emissions: a genotype names a haplotype outside the list");
+    }
+    const uint8_t *pos_a = pos_a_buf, *pos_b = pos_b_buf;
+    const size_t n_tab = (size_t)(ploidy + 1) * 256;
     if (n_rows && (!entry_begin || !entry_count || !gt0 || !n_kept_out || !flags_out)) return fail(c, VGMI_E_INVALID, "HMM emissions: rows without their arrays");
-    if (n_gt < 1 || n_gt > 128 || n_used < 1 || n_used > 16 || bit_len < 1 || bit_len > 6) return fail(c, VGMI_E_INVALID, "HMM emissions: 1..128 pairs over 1..16 haplotypes, 1..6 bytes of haplotype bits");
+    if (n_used < 1 || n_used > 16 || bit_len < 1 || bit_len > 6) return fail(c, VGMI_E_INVALID, "HMM emissions: 1..128 genotypes over 1..16 haplotypes, 1..6 bytes of haplotype bits");
     if (!c->d_hmm_entries) return fail(c, VGMI_E_STATE, "HMM emissions: upload the entries first");
     for (uint64_t r = 0; r < n_rows; ++r)
         if (entry_begin[r] + entry_count[r] > c->hmm_n_entries) return fail(c, VGMI_E_INVALID, "HMM emissions: a row points outside the entries");
-    for (uint32_t g = 0; g < n_gt; ++g)
-        if (pos_a[g] >= n_used || pos_b[g] >= n_used) return fail(c, VGMI_E_INVALID, "HMM emissions: a genotype names a haplotype outside the list");
     *out = nullptr;
     HIPCHK(c, hipSetDevice(c->device));
     auto* part = new vgmi_hmm_part;
@@ -2996,7 +3023,7 @@ int vgmi_hmm_emissions(vgmi_ctx* c, uint32_t n_gt, uint32_t n_used, const uint8_
     const size_t b_obs = (size_t)(n_rows ? n_rows : 1) * n_gt * 16;
     uint8_t* d_small = nullptr;     // entry_begin | entry_count | gt0 | tables | n_kept | flags
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_eb = 0, o_ec = up(o_eb + n_rows * 8), o_g0 = up(o_ec + n_rows * 4), o_tab = up(o_g0 + n_rows * 2), o_nk = up(o_tab + 768 * 16),
+    const size_t o_eb = 0, o_ec = up(o_eb + n_rows * 8), o_g0 = up(o_ec + n_rows * 4), o_tab = up(o_g0 + n_rows * 2), o_nk = up(o_tab + n_tab * 16),
                  o_fl = up(o_nk + n_rows * 4), total = up(o_fl + n_rows) + 256;
     hipStream_t st = nullptr;
     size_t small_bytes = 0;
@@ -3013,7 +3040,7 @@ int vgmi_hmm_emissions(vgmi_ctx* c, uint32_t n_gt, uint32_t n_used, const uint8_
     if (e == hipSuccess) e = hipMemcpyAsync(d_small + o_eb, entry_begin, n_rows * 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_small + o_ec, entry_count, n_rows * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_small + o_g0, gt0, n_rows * 2, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_small + o_tab, tables, 768 * 16, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_small + o_tab, tables, n_tab * 16, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         HmmEmitParams P{};
         P.packed = c->d_hmm_entries;
@@ -3028,6 +3055,8 @@ int vgmi_hmm_emissions(vgmi_ctx* c, uint32_t n_gt, uint32_t n_used, const uint8_
         memcpy(P.used, used, n_used);
         memcpy(P.pos_a, pos_a, n_gt);
         memcpy(P.pos_b, pos_b, n_gt);
+        memcpy(P.pos_more, pos_more_buf, sizeof pos_more_buf);
+        P.ploidy = ploidy;
         P.top_mask = top_mask;
         P.ave = ave;
         P.lower = lower;

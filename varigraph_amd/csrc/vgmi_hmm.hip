@@ -442,7 +442,8 @@ __global__ __launch_bounds__(256) void hmm_posterior_big_kernel(HmmPostParams P)
 }
 
 // ---- emission scores of a node: hidden states (src/genotype.cpp:640-830) and observable states (:960-1000) --------------------
-// One workgroup of 128 lanes per node, lane g = genotype g = a PAIR of haplotypes (used[pos_a[g]], used[pos_b[g]]).  Per k-mer of
+// One workgroup of 128 lanes per node, lane g = genotype g = a PAIR of haplotypes (used[pos_a[g]], used[pos_b[g]]) -- or three or four
+// of them (a polyploid sample's genotypes are blocks of `ploidy` consecutive haplotypes, src/genotype.cpp:846-873; round 5).  Per k-mer of
 // the node, in list order: coverage c, multiplicity f and the haplotype bits decide, the same for every lane, which of the
 // <= 16 haplotypes count as carrying the k-mer; the lane's copy number h is the sum over its two; (h, c, f) go through
 // most_likely_depth (:1118-1145, float and double arithmetic as the host's SSE code does it) and select the term -- geometric for
@@ -461,10 +462,10 @@ __device__ __forceinline__ uint32_t hmm_most_likely_depth(uint32_t h, uint32_t c
 
 __global__ __launch_bounds__(128) void hmm_emissions_kernel(HmmEmitParams P)
 {
-    __shared__ uint64_t s_tm[768];
-    __shared__ int32_t s_te[768];
+    __shared__ uint64_t s_tm[1280];      // (ploidy + 1) x 256 terms: up to four haplotypes per genotype
+    __shared__ int32_t s_te[1280];
     const uint32_t g = threadIdx.x;
-    for (uint32_t i = g; i < 768u; i += 128u) {
+    for (uint32_t i = g; i < (P.ploidy + 1u) * 256u; i += 128u) {
         const VgN80 t = n80_from(x80_load(P.tables + (size_t)i * 16));
         s_tm[i] = t.m;
         s_te[i] = t.e;
@@ -477,6 +478,7 @@ __global__ __launch_bounds__(128) void hmm_emissions_kernel(HmmEmitParams P)
     const uint32_t cnt = P.entry_count[rowi], gt0 = P.gt0[rowi];
     const bool active = g < P.n_gt;
     const uint32_t pa = P.pos_a[active ? g : 0u], pb = P.pos_b[active ? g : 0u];
+    const uint32_t pc = P.ploidy > 2u ? P.pos_more[0][active ? g : 0u] : 0u, pd = P.ploidy > 3u ? P.pos_more[1][active ? g : 0u] : 0u;
     VgN80 prod;
     prod.m = 1ULL << 63;      // 1.0L
     prod.e = VG_X80_BIAS;
@@ -503,7 +505,9 @@ __global__ __launch_bounds__(128) void hmm_emissions_kernel(HmmEmitParams P)
             ++fp;
         }
         const uint32_t fj = (lb == 1u && f == 1u) ? 2u : f;
-        const uint32_t h = ((om >> pa) & 1u) + ((om >> pb) & 1u);
+        uint32_t h = ((om >> pa) & 1u) + ((om >> pb) & 1u);
+        if (P.ploidy > 2u) h += (om >> pc) & 1u;
+        if (P.ploidy > 3u) h += (om >> pd) & 1u;
         const uint32_t cc = hmm_most_likely_depth(h, c, fj, P.ave, P.upper);
         const uint32_t ti = h * 256u + cc;
         VgN80 t;

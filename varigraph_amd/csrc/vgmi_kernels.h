@@ -226,10 +226,12 @@ struct HmmEmitParams {
     uint64_t row_lo;                    // the launch's first row (workgroup b takes row_lo + b)
     uint32_t n_gt, n_used, bl8;         // genotypes (<= 128), haplotypes in them (<= 16), bit length of a k-mer's haplotype bits (8 * bitlen)
     uint8_t used[16], pos_a[128], pos_b[128];
+    uint8_t pos_more[2][128];           // genotypes of three or four haplotypes (ploidy): the third and the fourth one's places in `used`
+    uint32_t ploidy;                    // 2 .. 4: haplotypes per genotype
     unsigned long long top_mask;
     float ave;
     double lower, upper;
-    const uint8_t* tables;              // 256 geometric terms (h = 0), then 256 Poisson terms per h = 1, 2: 16-byte long doubles
+    const uint8_t* tables;              // 256 geometric terms (h = 0), then 256 Poisson terms per h = 1 .. ploidy: 16-byte long doubles
     uint8_t* obs;                       // out, per row: n_gt scores
     uint32_t* n_kept;                   // out, per row: k-mers that took part
     uint8_t* flags;                     // out, per row: bit 0 the host must score this node (a haplotype's sequence has to be checked), bit 1 a k-mer no selected haplotype carries

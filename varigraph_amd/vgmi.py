@@ -87,6 +87,8 @@ def load_library():
         "vgmi_hmm_sample_upload": (i32, [vp, vp, sz]),
         "vgmi_hmm_emissions": (i32, [vp, u32, u32, vp, vp, vp, C.c_uint64, u32, C.c_float, C.c_double, C.c_double, vp, C.c_uint64, vp, vp, vp, vp, vp,
                                       C.POINTER(vp)]),
+        "vgmi_hmm_emissions_ploidy": (i32, [vp, u32, u32, u32, vp, vp, C.c_uint64, u32, C.c_float, C.c_double, C.c_double, vp, C.c_uint64, vp, vp, vp, vp, vp,
+                                      C.POINTER(vp)]),
         "vgmi_hmm_part_set_rows": (i32, [vp, C.c_uint64, vp, vp]),
         "vgmi_hmm_part_fix_rows": (i32, [vp, C.c_uint64, vp, vp, vp, vp]),
         "vgmi_hmm_plan_create": (i32, [vp, u32, u32, vp, u32, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp, u32, vp, vp, vp, vp, C.POINTER(vp)]),
@@ -489,7 +491,7 @@ class Context:
         return prob, winner, ab
 
     def hmm_emissions(self, entries, cov_node, used, pos_a, pos_b, top_mask, bit_len, ave, lower, upper, tables, entry_begin, entry_count, gt0,
-                      fixes=None, calls=None):
+                      fixes=None, calls=None, pos=None):
         """vgmi_hmm_entries_upload + _sample_upload + _emissions + _part_fetch: returns (obs (rows, n_gt) longdouble, n_kept, flags).
         fixes = (rows, off, j, mask): vgmi_hmm_part_fix_rows before the fetch.  calls = dict(ploidy, keep, row, restart, pow, uniform,
         chains, gid, order, fwd, bwd): the part's recursion and posterior both ways -- vgmi_hmm_part_calls with host arrays and
@@ -503,16 +505,25 @@ class Context:
         entry_begin = np.ascontiguousarray(entry_begin, dtype=np.uint64)
         entry_count = np.ascontiguousarray(entry_count, dtype=np.uint32)
         gt0 = np.ascontiguousarray(gt0, dtype=np.uint16)
-        assert tables.size == 768
-        n_rows, n_gt = entry_begin.size, pos_a.size
+        ploidy = 2
+        if pos is not None:      # genotypes of 2 .. 4 haplotypes: pos (n_gt, ploidy) -> vgmi_hmm_emissions_ploidy
+            pos = np.ascontiguousarray(pos, dtype=np.uint8)
+            ploidy = pos.shape[1]
+        assert tables.size == (ploidy + 1) * 256
+        n_rows, n_gt = entry_begin.size, (pos.shape[0] if pos is not None else pos_a.size)
         self._chk(self._l.vgmi_hmm_entries_upload(self._h, _ptr(entries), entries.size))
         self._chk(self._l.vgmi_hmm_sample_upload(self._h, _ptr(cov_node), cov_node.size))
         n_kept = np.zeros(max(n_rows, 1), dtype=np.uint32)
         flags = np.zeros(max(n_rows, 1), dtype=np.uint8)
         part = C.c_void_p()
-        self._chk(self._l.vgmi_hmm_emissions(self._h, n_gt, used.size, _ptr(used), _ptr(pos_a), _ptr(pos_b), int(top_mask), bit_len, float(ave), float(lower),
-                                              float(upper), _ptr(tables), n_rows, _ptr(entry_begin), _ptr(entry_count), _ptr(gt0), _ptr(n_kept), _ptr(flags),
-                                              C.byref(part)))
+        if pos is not None:
+            self._chk(self._l.vgmi_hmm_emissions_ploidy(self._h, n_gt, ploidy, used.size, _ptr(used), _ptr(pos), int(top_mask), bit_len, float(ave), float(lower),
+                                                         float(upper), _ptr(tables), n_rows, _ptr(entry_begin), _ptr(entry_count), _ptr(gt0), _ptr(n_kept),
+                                                         _ptr(flags), C.byref(part)))
+        else:
+            self._chk(self._l.vgmi_hmm_emissions(self._h, n_gt, used.size, _ptr(used), _ptr(pos_a), _ptr(pos_b), int(top_mask), bit_len, float(ave), float(lower),
+                                                  float(upper), _ptr(tables), n_rows, _ptr(entry_begin), _ptr(entry_count), _ptr(gt0), _ptr(n_kept), _ptr(flags),
+                                                  C.byref(part)))
         both = None
         try:
             if fixes is not None:
