@@ -499,8 +499,9 @@ class Context:
         entries = np.ascontiguousarray(entries, dtype=np.uint64)
         cov_node = np.ascontiguousarray(cov_node, dtype=np.uint8)
         used = np.ascontiguousarray(used, dtype=np.uint8)
-        pos_a = np.ascontiguousarray(pos_a, dtype=np.uint8)
-        pos_b = np.ascontiguousarray(pos_b, dtype=np.uint8)
+        if pos is None:
+            pos_a = np.ascontiguousarray(pos_a, dtype=np.uint8)
+            pos_b = np.ascontiguousarray(pos_b, dtype=np.uint8)
         tables = np.ascontiguousarray(tables, dtype=np.longdouble)
         entry_begin = np.ascontiguousarray(entry_begin, dtype=np.uint64)
         entry_count = np.ascontiguousarray(entry_count, dtype=np.uint32)
