@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--sv", type=float, default=0.001)
     ap.add_argument("--prefix-reads", type=int, default=100_000)
     ap.add_argument("--files", action="store_true", help="write the FASTQ files instead of streaming them through named pipes")
+    ap.add_argument("--bgzf", action="store_true", help="with --files: block-gzip files (level 1, 64 KiB members, compressed by a pool of threads)")
+    ap.add_argument("--samples", type=int, default=1, help="sample names in the -s list; they all name the same two files (round 5: several whole-genome "
+                                                              "samples back to back through one process)")
     ap.add_argument("--keep", default="")
     args = ap.parse_args()
     import torch
@@ -169,6 +172,21 @@ def main():
             m[:, 17 + 2 * L] = 10
             return m.tobytes()
 
+        import struct
+        import zlib
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max(2, args.threads)) if args.bgzf else None
+
+        def bgzf_member(d):
+            c = zlib.compressobj(1, zlib.DEFLATED, -15)
+            cd = c.compress(d) + c.flush()
+            return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(cd) + 25) + cd + struct.pack("<II", zlib.crc32(d), len(d)))
+
+        def bgzf_bytes(b):
+            mv = memoryview(b)
+            blocks = [mv[i:i + 0xff00] for i in range(0, len(mv), 0xff00)]
+            return b"".join(pool.map(bgzf_member, blocks, chunksize=64))
+
         def produce(files):
             for first in range(0, n_reads, chunk):
                 n = min(chunk, n_reads - first)
@@ -178,17 +196,25 @@ def main():
                 if first == 0:
                     prefix_block.append(rec[: min(n, args.prefix_reads)].copy().reshape(-1))
                 a, b = records(rec, first, 0), records(rec, first, 1)
+                if args.bgzf:
+                    a, b = bgzf_bytes(a), bgzf_bytes(b)
                 ts = [threading.Thread(target=files[0].write, args=(a,)), threading.Thread(target=files[1].write, args=(b,))]
                 for t in ts:
                     t.start()
                 for t in ts:
                     t.join()
+            if args.bgzf:
+                eof = b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0\x1b\0\x03\0\0\0\0\0\0\0\0\0"
+                for f in files:
+                    f.write(eof)
             for f in files:
                 f.close()
 
+        if args.bgzf:
+            fq = [p + ".gz" for p in fq]
         d = os.path.join(work, "run")
         os.makedirs(d)
-        open(os.path.join(d, "samples.cfg"), "w").write("sample0 " + " ".join(fq) + "\n")
+        open(os.path.join(d, "samples.cfg"), "w").write("".join(f"sample{i} " + " ".join(fq) + "\n" for i in range(args.samples)))
         cmd = [cli, "genotype", "--load-graph", graph, "-s", "samples.cfg", "-t", str(args.threads), "--gpu", "0"]
         if args.ploidy != 2:
             cmd += ["--sample-ploidy", str(args.ploidy), "--use-depth"]
@@ -196,6 +222,8 @@ def main():
         if args.files:
             produce([open(p, "wb") for p in fq])
             out["fastq_files_s"] = time.perf_counter() - t0
+            out["fastq_file_bytes"] = [os.path.getsize(p) for p in fq]
+            out["samples"] = args.samples
             t0 = time.perf_counter()
             r = subprocess.run(cmd, cwd=d, capture_output=True, text=True, env=env)
         else:
@@ -233,7 +261,14 @@ def main():
             print(json.dumps(out))
             return
         log = [ln for ln in r.stderr.strip().split("\n") if "varigraph-mi]" in ln or "graph_index]" in ln]
-        out["genotype_log"] = [ln for ln in log if "HMM part" not in ln][-60:]
+        out["genotype_log"] = [ln for ln in log if "HMM part" not in ln][-(60 + 12 * args.samples):]
+        import re
+        cnt = [(float(a), float(b)) for a, b in re.findall(r"counting ([\d.]+) s \(kernel ([\d.]+) s", r.stderr)]
+        if cnt:
+            out["counting_wall_s_per_sample"] = [c[0] for c in cnt]
+            out["count_kernel_s_per_sample"] = [c[1] for c in cnt]
+            out["counting_reads_per_s"] = [n_reads / c[0] for c in cnt]
+        out["genotyping_wall_s_per_sample"] = [float(x) for x in re.findall(r"genotyping ([\d.]+) s", r.stderr)]
         # ---- called genotypes against the generator's truth
         called = same = het_ok = 0
         with gzip.open(os.path.join(d, "sample0.varigraph.vcf.gz"), "rt") as f:
