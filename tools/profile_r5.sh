@@ -28,7 +28,7 @@ for w in $W; do
   hmm)
     D=/tmp/vg_c4_files; rm -rf $D
     RUN=$(python3 tools/make_c4_dataset.py $D 2> $OUT/make.err | tail -1)
-    ( cd $RUN && VGH_RANDOM_DEVICE_VALUE=20241022 VGH_TIMING=1 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/kt" -o r -- "$OLDPWD/varigraph_amd/bin/varigraph-mi" genotype --load-graph $D/graph.bin -s samples.cfg -t 10 --gpus 0 > "$OLDPWD/$OUT/cli.out" 2> "$OLDPWD/$OUT/cli.err" )
+    ( cd $RUN && VGH_ATEXIT=1 VGH_RANDOM_DEVICE_VALUE=20241022 VGH_TIMING=1 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/kt" -o r -- "$OLDPWD/varigraph_amd/bin/varigraph-mi" genotype --load-graph $D/graph.bin -s samples.cfg -t 10 --gpus 0 > "$OLDPWD/$OUT/cli.out" 2> "$OLDPWD/$OUT/cli.err" )
     grep "done in" $OUT/cli.err
     rm -rf $D
     ;;

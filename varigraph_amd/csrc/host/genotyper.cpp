@@ -2267,6 +2267,57 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                         }
                     }
                     over_windows(g_phase.pass_c, [&](size_t wi) {
+                        if (!tally.empty()) {
+                            // a diploid sample with the calls' tallies from the device: the line is written straight from what came back
+                            // -- the called genotype's two haplotypes, their k-mer counts and coverage sums, the posterior -- without the
+                            // detour through the nodes' call records (window_finish writes them, make_piece reads them back: two walks over
+                            // half a million scattered nodes per sample)
+                            piece_done[t0 + wi] = 1;
+                            const Chrom& chr = *tasks[t0 + wi].chr;
+                            const std::vector<uint32_t>&nodes_w = win_nodes[wi], &rows_w = win_rows[wi];
+                            std::string out;
+                            size_t room = 0;
+                            for (size_t q = 0; q < rows_w.size(); ++q) room += (size_t)(plan->line_head_off[rows_w[q] + 1] - plan->line_head_off[rows_w[q]]) + 48;
+                            out.reserve(room);
+                            for (size_t q = 0; q < rows_w.size(); ++q) {
+                                const size_t rw = rows_w[q];
+                                if (winner[rw] >= n_gt) continue;            // no entry with a positive posterior: no call
+                                const uint64_t h0 = plan->line_head_off[rw], h1 = plan->line_head_off[rw + 1];
+                                if (h0 == h1) continue;                      // no such site in the VCF
+                                const Node& node = chr.nodes[nodes_w[q]];
+                                const std::vector<uint16_t>& called = genotypes[winner[rw]];
+                                const uint64_t ga = node.gn->hap_gt[called[0]], gb = node.gn->hap_gt[called[1]];
+                                if (ga == 0 && gb == 0) continue;
+                                out.append(plan->line_head, h0, h1 - h0);
+                                const long double pr = prob[rw];
+                                const float gq = phred_scaled(pr);
+                                if (gq < cfg.min_gq) out += "./.";
+                                else {
+                                    append_uint(out, ga);
+                                    out += '/';
+                                    append_uint(out, gb);
+                                }
+                                out += ':';
+                                append_fixed1(out, gq);
+                                out += ':';
+                                append_fixed1(out, pr);
+                                out += ':';
+                                const uint32_t* tl = &tally[4 * rw];
+                                append_uint(out, tl[0]);
+                                out += ',';
+                                append_uint(out, tl[2]);
+                                out += ':';
+                                append_fixed1(out, tl[0] ? static_cast<float>((uint64_t)tl[1]) / (float)(uint64_t)tl[0] : 0.0f);
+                                out += ',';
+                                append_fixed1(out, tl[2] ? static_cast<float>((uint64_t)tl[3]) / (float)(uint64_t)tl[2] : 0.0f);
+                                out += ':';
+                                append_uint(out, tally_uniq[rw]);
+                                out += '\n';
+                            }
+                            pieces[t0 + wi] = std::move(out);
+                            emit_windows_done += !nodes_w.empty();
+                            return;
+                        }
                         WindowWork w;
                         w.chr = tasks[t0 + wi].chr;
                         w.n_gt = n_gt;
