@@ -91,7 +91,7 @@ struct vgmi_ctx {
     hipMemGenericAllocationHandle_t ct_vmm_handle{};
     uint64_t ct_entries = 0, ct_unitigs = 0, ct_moved = 0;   // entries built, unitigs they came from, entries not in their home bucket
     unsigned long long* d_pt_index = nullptr;   // path table of small graphs (build_ptable): 12-mer -> places in the unitig sequence
-    uint32_t *d_pt_S = nullptr, *d_pt_VB = nullptr, *d_pt_SB = nullptr, *d_pt_SLOT = nullptr;   // sequence, k-mer starts, saturation bits, slots
+    uint32_t *d_pt_S = nullptr, *d_pt_VB = nullptr, *d_pt_SB = nullptr, *d_pt_SLOT = nullptr, *d_pt_PLACE = nullptr;   // sequence, k-mer starts, saturation bits, slots, places by slot
     size_t pt_sb_bytes = 0;
     uint64_t pt_slow_cx = 0, pt_bucket_ovf = 0;  // 12-mers with more than two places / buckets with a third 12-mer (those runs take the hash table)
     uint64_t xt_over_keys = 0;                  // pairs (key, 16-mer) that overflowed in the last build
@@ -214,10 +214,10 @@ void free_table(vgmi_ctx* c)
     } else if (c->d_ct_buckets) (void)hipFree(c->d_ct_buckets);
     c->d_ct_buckets = nullptr;
     c->ct_entries = c->ct_unitigs = c->ct_moved = 0;
-    for (void* q : {(void*)c->d_pt_index, (void*)c->d_pt_S, (void*)c->d_pt_VB, (void*)c->d_pt_SB, (void*)c->d_pt_SLOT})
+    for (void* q : {(void*)c->d_pt_index, (void*)c->d_pt_S, (void*)c->d_pt_VB, (void*)c->d_pt_SB, (void*)c->d_pt_SLOT, (void*)c->d_pt_PLACE})
         if (q) (void)hipFree(q);
     c->d_pt_index = nullptr;
-    c->d_pt_S = c->d_pt_VB = c->d_pt_SB = c->d_pt_SLOT = nullptr;
+    c->d_pt_S = c->d_pt_VB = c->d_pt_SB = c->d_pt_SLOT = c->d_pt_PLACE = nullptr;
     c->tv.pt = PathView{};
     c->d_xt_lines = nullptr;
     c->d_xt_counts = nullptr;
@@ -794,6 +794,13 @@ int build_ptable(vgmi_ctx* c)
     if (he == hipSuccess) he = hipMemset(c->d_pt_SB, 0, VB.size() * 4);
     if (he == hipSuccess) he = hipMemset(c->d_pt_SLOT, 0, (size_t)(Tp + 64) * 4);
     if (he == hipSuccess) he = hipMemcpy(c->d_pt_SLOT, slot.data(), (size_t)Tp * 4, hipMemcpyHostToDevice);
+    {   // slot -> place: the slow paths -- the hash-table fallback of runs the index does not cover, the generic kernel on the
+        // ragged tail -- know a k-mer by its slot; the increment of theirs that takes a counter to the clamp sets the path table's bits too
+        std::vector<uint32_t> place_of_slot(h.cap, 0u);
+        for (uint64_t i = 0; i < n; ++i) place_of_slot[(uint32_t)P[i].y] = (uint32_t)(32 + kpos[i]);
+        if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&c->d_pt_PLACE), h.cap * 4);
+        if (he == hipSuccess) he = hipMemcpy(c->d_pt_PLACE, place_of_slot.data(), h.cap * 4, hipMemcpyHostToDevice);
+    }
     HIPCHK(c, he);
     c->pt_sb_bytes = VB.size() * 4;
     if (getenv("VGMI_VERBOSE"))
@@ -804,6 +811,7 @@ int build_ptable(vgmi_ctx* c)
     c->tv.pt.VB = c->d_pt_VB;
     c->tv.pt.SB = c->d_pt_SB;
     c->tv.pt.SLOT = c->d_pt_SLOT;
+    c->tv.pt.PLACE = c->d_pt_PLACE;
     c->tv.pt.bucket_log2 = bucket_log2;
     c->tv.pt.Tp = (uint32_t)Tp;
     return VGMI_OK;

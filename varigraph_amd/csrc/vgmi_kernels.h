@@ -46,6 +46,7 @@ struct PathView {
     const uint32_t* VB;                // bit per base position: a graph k-mer starts here
     uint32_t* SB;                      // bit per base position: ... and its counter has reached the clamp (per sample)
     const uint32_t* SLOT;              // per base position: the hash-table slot of the k-mer that starts here
+    const uint32_t* PLACE;             // per hash-table slot: the place (first half of S) where its k-mer starts, 0: none -- for the slow paths' saturation bits
     uint32_t bucket_log2;
     uint32_t Tp;                       // bases in S, pads included: S[Tp - 1 - j] is the complement of S[j]
 };

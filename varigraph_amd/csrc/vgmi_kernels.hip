@@ -163,7 +163,20 @@ __device__ __forceinline__ void table_count(const TableView& t, uint64_t canon)
             const uint64_t c = t.slots8[s];
             if (c == VG_EMPTY) return;
             if ((c & VG_SLOT_KMER_MASK) == canon) {
-                if (!(c & VG_SLOT_SAT)) atomicAdd(&t.counts[s], 1u);
+                if (!(c & VG_SLOT_SAT) && atomicAdd(&t.counts[s], 1u) == 254u) {
+                    // the increment that takes the counter to the clamp flags the k-mer as the fast kernels do: in the slot,
+                    // for the per-sample reset, and -- small graphs -- at both of its places in the path table
+                    atomicOr(reinterpret_cast<unsigned int*>(&t.slots8[s]) + 1, (unsigned int)(VG_SLOT_SAT >> 32));
+                    if (t.sat_dirty) t.sat_dirty[s >> 11] = 1;      // (VG_SAT_REGION_LOG2)
+                    if (t.pt.PLACE) {
+                        const uint32_t pos = t.pt.PLACE[s];
+                        if (pos != 0u) {
+                            const uint32_t mir = t.pt.Tp - t.k - pos;
+                            atomicOr(&t.pt.SB[pos >> 5], 1u << (pos & 31u));
+                            atomicOr(&t.pt.SB[mir >> 5], 1u << (mir & 31u));
+                        }
+                    }
+                }
                 return;
             }
             if (!(c & VG_SLOT_CHAIN)) return;
@@ -1278,6 +1291,13 @@ __global__ __launch_bounds__(1024) void count27s_kernel(RowParams p)
                 if (!(c & VG_SLOT_SAT) && vm_atomic_inc_sync(&counts[sl], one) == 254u) {
                     vm_atomic_or_sync(reinterpret_cast<uint32_t*>(&slots8[sl]) + 1, (uint32_t)(VG_SLOT_SAT >> 32));
                     vm_store_byte_sync(p.table.sat_dirty + (sl >> VG_SAT_REGION_LOG2), 1u);
+                    // ... and at both of the k-mer's places in the path table, as bump_all does: later hits through the table skip their atomic
+                    const uint32_t pos = vm_load_dword_sync(p.table.pt.PLACE + sl);
+                    if (pos != 0u) {
+                        const uint32_t mir = pt_Tp - K - pos;
+                        vm_atomic_or_sync(ptSB + (pos >> 5), 1u << (pos & 31u));
+                        vm_atomic_or_sync(ptSB + (mir >> 5), 1u << (mir & 31u));
+                    }
                 }
                 break;
             }

@@ -345,7 +345,7 @@ class Context:
         fq = C.c_void_p()
         self._chk(self._l.vgmi_fastq_open(self._h, C.byref(fq)))
         comp = bytes(comp)
-        pos, carry, total_taken = 0, b"", 0
+        pos, carry, total_taken, n_call = 0, b"", 0, 0
         failed, good, reason = C.c_int(), C.c_uint64(), C.c_uint32()
         try:
             while True:
