@@ -778,14 +778,14 @@ def main():
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": b_stream * n_reads,
-                         "kernel": "vgk::count27s_kernel<true>", "kernel_ms": avg_kernel_s * 1e3,
+                         "kernel": "vgk::count27s_kernel<true, 27u>", "kernel_ms": avg_kernel_s * 1e3,
+                         # (the configurations whose table lives in HBM, inside the object the driver's record keeps: their own blocks carry the rest)
+                         **({} if c3 is None else {"c3_frac_kernel": c3["roofline"]["frac"], "c3_kernel_ms": c3["roofline"]["kernel_ms"]}),
+                         **({} if c5 is None else {"c5_frac_kernel": c5["roofline"]["frac"], "c5_kernel_ms": c5["roofline"]["kernel_ms"]}),
                          "bytes_per_read": b_stream,
                          "note": "C2's 0.43 MB table is on-chip, so the compulsory HBM traffic is the ASCII "
                                  "read stream only (SURVEY 8d B_stream); the kernel is instruction-issue bound "
                                  "(VALU + LDS; scan 2.7 ms, path-table drain 1.5 ms: DESIGN.md section 6.0.1)"},
-            # (the configurations whose table lives in HBM, inside the object the driver's record keeps: their own blocks below carry the rest)
-            **({} if c3 is None else {"c3_frac_kernel": c3["roofline"]["frac"], "c3_kernel_ms": c3["roofline"]["kernel_ms"]}),
-            **({} if c5 is None else {"c5_frac_kernel": c5["roofline"]["frac"], "c5_kernel_ms": c5["roofline"]["kernel_ms"]}),
             "probe_inclusive_rate": {"achieved": ach_probe, "unit": "GB/s", "bytes_per_read": b_stream + b_probe,
                                      "hits_per_read_measured": hits_per_read,
                                      "note": "SURVEY 8d B_stream+B_probe bytes over the same kernel time, for comparison "

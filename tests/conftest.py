@@ -19,11 +19,25 @@ def pytest_configure(config):
         config.option.durations = 15
 
 
+_LONG_REFERENCE_TESTS = ("test_more_than_128_genotypes_run_on_the_device_vcf_identical", "test_c3_chr20_scale_12m_pairs_use_depth_vcf_identical",
+                         "test_c4_eight_samples_over_the_gpus_present_equal_single_sample_reference_runs")
+
+
+def pytest_collection_modifyitems(config, items):
+    """The tests that wait for the long all-CPU reference runs go to the END of the session (in the order their runs finish): the runs
+    start with the session (pytest_collection_finish below) and are done by the time the rest of the suite is."""
+    def rank(it):
+        name = it.name.split("[")[0]
+        return _LONG_REFERENCE_TESTS.index(name) + 1 if name in _LONG_REFERENCE_TESTS else 0
+    items.sort(key=rank)      # stable: everything else keeps its order
+
+
 def pytest_collection_finish(session):
     """The GPU suite's two long all-CPU reference runs (tests/test_gpu_configs.py: C3, C4) start now, on a background thread, when
     their tests are among the selected ones: they then run beside the rest of the suite instead of inside its wall clock."""
     names = {it.name.split("[")[0] for it in session.items}
-    which = [n for n, t in (("c3", "test_c3_chr20_scale_12m_pairs_use_depth_vcf_identical"),
+    which = [n for n, t in (("n20", "test_more_than_128_genotypes_run_on_the_device_vcf_identical"),
+                            ("c3", "test_c3_chr20_scale_12m_pairs_use_depth_vcf_identical"),
                             ("c4", "test_c4_eight_samples_over_the_gpus_present_equal_single_sample_reference_runs")) if t in names]
     if not which or session.config.option.collectonly or os.environ.get("VG_TEST_NO_EARLY"):
         return

@@ -83,7 +83,7 @@ def test_bench_starts_its_own_ranks():
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--reads", "4000000", "--no-sample-level",
-                        "--steps", "3", "--warmup", "1", "--no-c3", "--verify-reads", "200000"],
+                        "--steps", "3", "--warmup", "1", "--no-c3", "--no-c5", "--verify-reads", "200000"],      # (the c3 / c5 legs of two ranks on one device: 45 s of this suite's clock for what tests/test_gpu_large.py holds)
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
