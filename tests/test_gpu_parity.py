@@ -1205,7 +1205,10 @@ def test_small_graph_even_k_run_counter_lag_is_taken_back(k):
         body = genome[50 * i:50 * i + 110]
         specials += [b"T" * (k // 2) + body, own_rc() + body, body[:30] + b"N" + own_rc() + body[30:], own_rc() + own_rc() + body,
                      body[:40] + b"N" + b"T" * (k // 2 - 3) + body[40:], b"A" * 5 + b"T" * (k // 2) + body, own_rc()[: k - 1] + b"N" + body,
-                     body[:k + 3] + own_rc() + body[k + 3:]]
+                     body[:k + 3] + own_rc() + body[k + 3:],
+                     # (the scan form of the pass: non-bases in a row, two within k bases of each other, one at the read's end, lower case)
+                     body[:30] + b"NN" + own_rc() + body[30:], body[:20] + b"N" + own_rc()[:5] + b"n" + own_rc() + body[20:], body + b"N",
+                     (body[:30] + b"N" + own_rc() + body[30:]).lower(), body[:35] + b"." + own_rc()[1:] + body[35:]]
     plain = [genome[s:s + 150] for s in rng.integers(0, len(genome) - 150, size=3000)]
     # the key set: every window the literal state machine emits for the reads, for the reads less their first base, and with a base in front
     keysets = [o.sketch(r, k) for r in specials] + [o.sketch(r[1:], k) for r in specials] + [o.sketch(b"G" + r, k) for r in specials] + [o.sketch(genome, k)]

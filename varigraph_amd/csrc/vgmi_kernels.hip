@@ -1847,89 +1847,108 @@ __global__ __launch_bounds__(256) void seq_kernel(RowParams p, const uint64_t* r
 // even k = 20 .. 24 on a small graph, ahead of count27s_kernel<true, K> (round 5): what the reference's run counter suppresses.
 // That kernel counts a window iff its k bases are bases -- the rule of odd k.  The reference (src/kmer.cpp:132-146) does not advance
 // l on a window that is its own reverse complement -- of the REGISTERS' content: stale bases across a non-base (:145 resets l only)
-// and the zeros in front of the read included -- so behind such a window, met while l < k, l lags behind the run of bases and the
-// positions with  run >= k > l  are not emitted.  One window in 4^(k/2), and only within the first k-odd bases behind a read's start or
-// a non-base.  A lane per read: the literal state machine while l < k, a scan for the next non-base once l = k (16 bytes per step,
-// every byte one of ACGT: nothing to do); the k-mer of a suppressed position loses one count BEFORE the fast kernel adds it -- the
-// counters are 32-bit and wrap; every debit is followed by its increment in the same stream; a saturation flag is set by the increment
-// that takes the running value, which never exceeds the true one, from 254 to 255, and the read-out of even k honours the flag
-// (cov_kernel).  Positions at or behind emit_from belong to the exact tail launch (seq_kernel<MODE_COUNT>).
-// The text comes straight from global memory in aligned 16-byte pieces, the next piece in flight while this one is walked
-// (seq_kernel's staging through LDS holds two workgroups per CU and one dependent byte load per step: 15 ms per 2e7 reads).
+// and the zeros in front of the read included -- so behind such a position, met while l < k, l lags behind the run of bases and the
+// positions with  run >= k > l  are not emitted.
+//
+// Only a non-base can start such a lag.  From a read's start the registers are zero, and with j + 1 < k bases shifted in the two
+// registers cannot be equal: field 0 of rc is still zero, which asks for base j = A, and field k - 1 of fwd is still zero, which asks
+// for base j = T.  So l counts every base up to the first whole window, and from there on a window that is not counted is a palindrome,
+// which the fast kernel does not count either (no path-table bit).  Behind a non-base the registers keep the bases in front of it, l
+// starts again at zero, and a palindrome of old and new bases makes the lag.  Hence this pass (second form; the first walked every
+// read's first k-odd bases through the state machine, a lane per read: 4.6 of an even k's 6.0 ms per 1.5e7 reads):
+//   * the text is SCANNED for bytes that are neither ACGT nor a newline, 16 bytes per lane, coalesced, four pieces in flight: per
+//     word  sel = (w >> 1) & 07070707  is distinct for 'A' 'C' 'T' 'G' '\n' (0 1 2 3 5), one v_perm_b32 turns it back into the byte it
+//     stands for, and any difference from w is a byte to look at.  That is the whole cost for reads of bases: the text at HBM speed.
+//   * a lane that holds such a byte -- a real non-base, not a lower-case base (vg_nt4 knows those), with a base behind it -- finds its
+//     read (binary search in the offsets), rebuilds the registers from the k bases in front (fewer at a read's start: zeros, as the
+//     reference has them; older non-bases skipped, as the reference skips them) and walks the state machine until l = k, the next
+//     non-base (which has its own lane) or the read's end.
+// The k-mer of a suppressed position loses one count BEFORE the fast kernel adds it -- the counters are 32-bit and wrap; every debit
+// is followed by its increment in the same stream; a saturation flag is set by the increment that takes the running value, which never
+// exceeds the true one, from 254 to 255, and the read-out of even k honours the flag (cov_kernel).  Positions at or behind emit_from
+// belong to the exact tail launch (seq_kernel<MODE_COUNT>).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t swar_zero_bytes(uint32_t x)      // bit 7 of every byte of x that is zero (exact)
+__device__ __forceinline__ uint32_t debit_odd_bytes(uint32_t w)      // non-zero iff a byte of w is none of 'A' 'C' 'G' 'T' '\n'
 {
-    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+    // v_perm_b32: selector 0..3 = byte of the second operand, 4..7 = byte of the first; slots 4, 6, 7 hold 0, which no byte with such
+    // a selector is (0 has selector 0)
+    return __builtin_amdgcn_perm(0x00000A00u, 0x47544341u, (w >> 1) & 0x07070707u) ^ w;
 }
-__device__ __forceinline__ bool swar_all_acgt(uint32_t v)
+
+__device__ __noinline__ void debit_behind_non_base(const RowParams& p, const uint64_t* __restrict__ read_off, uint64_t n_reads, uint64_t i,
+                                                   uint64_t limit)
 {
-    const uint32_t m = swar_zero_bytes(v ^ 0x41414141u) | swar_zero_bytes(v ^ 0x43434343u) | swar_zero_bytes(v ^ 0x47474747u) | swar_zero_bytes(v ^ 0x54545454u);
-    return m == 0x80808080u;
+    const uint8_t* const bases = p.bases;
+    if (i + 1 >= limit || vg_nt4(bases[i + 1]) >= 4) return;      // nothing behind it that could be counted
+    if (n_reads == 0 || read_off[0] > i) return;
+    uint64_t lo = 0, hi = n_reads;                                // the last read that starts at or before i
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (read_off[mid] <= i) lo = mid;
+        else hi = mid;
+    }
+    const uint64_t s = read_off[lo];
+    uint64_t e = read_off[lo + 1] - 1;                            // the read's '\n'
+    if (i >= e) return;
+    if (e > limit) e = limit;
+    const uint32_t K = p.k;
+    const uint64_t mask = (1ULL << (2 * K)) - 1, shift1 = 2 * (uint64_t)(K - 1);
+    uint64_t q = i;
+    for (uint32_t got = 0; q > s && got < K;) {
+        --q;
+        if (vg_nt4(bases[q]) < 4) ++got;
+    }
+    uint64_t fwd = 0, rc = 0;
+    for (; q < i; ++q) {
+        const uint32_t c = vg_nt4(bases[q]);
+        if (c >= 4) continue;
+        fwd = (fwd << 2 | c) & mask;
+        rc = (rc >> 2) | (uint64_t)(3u ^ c) << shift1;
+    }
+    uint32_t l = 0, run = 0;
+    for (uint64_t x = i + 1; x < e; ++x) {
+        const uint32_t c = vg_nt4(bases[x]);
+        if (c >= 4) return;
+        fwd = (fwd << 2 | c) & mask;
+        rc = (rc >> 2) | (uint64_t)(3u ^ c) << shift1;
+        if (run < K) ++run;
+        if (fwd == rc) continue;
+        if (++l >= K) return;
+        if (run >= K) {      // the fast kernel counts this window, the reference does not
+            const uint64_t canon = fwd < rc ? fwd : rc;
+            if (filter_test_global(p.table, canon)) table_debit(p.table, canon);
+        }
+    }
 }
+
+constexpr uint32_t VG_DEBIT_PIECES = 4;      // 16-byte pieces per lane: a workgroup scans 16 KiB
 
 __global__ __launch_bounds__(256) void even_debit_kernel(RowParams p, const uint64_t* __restrict__ read_off, uint64_t n_reads)
 {
-    // (the text straight from global memory, 16 aligned bytes per lane and step: 7.6 ms per 2e7 reads; staged through LDS with
-    // coalesced loads first -- seq_kernel's way -- 9.1 ms: the per-byte state machine of a read's first k-odd bases is what it costs)
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
-    const uint64_t s = read_off[r];
-    uint64_t e = read_off[r + 1] - 1;      // the read's '\n'
-    if (s >= p.emit_from || e <= s) return;
-    if (e > p.emit_from) e = p.emit_from;
-    const uint32_t K = p.k;
-    const uint64_t mask = (1ULL << (2 * K)) - 1, shift1 = 2 * (uint64_t)(K - 1);
-    uint64_t fwd = 0, rc = 0;
-    uint32_t l = 0, run = 0;
-    const uint8_t* const bases = p.bases;
-    auto piece = [&](uint64_t a) -> uint4 {
-        if (a + 16 <= p.n_bytes) {
-            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-            const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(bases + a));
-            return make_uint4(v.x, v.y, v.z, v.w);
-        }
-        return load_chunk(bases, p.n_bytes, a);
-    };
-    uint64_t a = s & ~15ULL;
-    uint4 cur = piece(a);
-    for (; a < e; a += 16) {
-        uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (a + 16 < e) nxt = piece(a + 16);
-        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
-        cur = nxt;
-        if (l >= K && a >= s && a + 16 <= e && swar_all_acgt(w[0]) && swar_all_acgt(w[1]) && swar_all_acgt(w[2]) && swar_all_acgt(w[3])) continue;
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const uint64_t limit = p.emit_from < p.n_bytes ? p.emit_from : p.n_bytes;
+    const uint64_t base = (uint64_t)blockIdx.x * (256u * 16u * VG_DEBIT_PIECES) + threadIdx.x * 16u;
+    u32x4_t v[VG_DEBIT_PIECES];
 #pragma unroll
+    for (uint32_t t = 0; t < VG_DEBIT_PIECES; ++t) {
+        const uint64_t a = base + (uint64_t)t * 4096u;
+        if (a + 16 <= p.n_bytes) v[t] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p.bases + a));
+        else {
+            const uint4 c = a < limit ? load_chunk(p.bases, p.n_bytes, a) : make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+            v[t] = u32x4_t{c.x, c.y, c.z, c.w};
+        }
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < VG_DEBIT_PIECES; ++t) {
+        const uint32_t odd = debit_odd_bytes(v[t].x) | debit_odd_bytes(v[t].y) | debit_odd_bytes(v[t].z) | debit_odd_bytes(v[t].w);
+        if (odd == 0) continue;
+        const uint64_t a = base + (uint64_t)t * 4096u;
+        const uint32_t w[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
         for (uint32_t j = 0; j < 16; ++j) {
-            const uint64_t i = a + j;
-            if (i < s || i >= e) continue;
-            const uint32_t c = vg_nt4((w[j >> 2] >> (8 * (j & 3))) & 0xFFu);
-            if (c >= 4) {
-                if (l >= K) {
-                    // the registers were left alone since l reached k: the k bytes in front of this one are bases (l >= k means k of
-                    // them in a row) -- the registers' content as the reference has it here
-                    fwd = 0;
-                    rc = 0;
-                    for (uint64_t q = i - K; q < i; ++q) {
-                        const uint32_t cq = vg_nt4(bases[q]);
-                        fwd = (fwd << 2 | cq) & mask;
-                        rc = (rc >> 2) | (uint64_t)(3u ^ cq) << shift1;
-                    }
-                }
-                l = 0;
-                run = 0;
-                continue;
-            }
-            if (l >= K) continue;      // (nothing can be suppressed until the next non-base, and the registers are rebuilt there)
-            fwd = (fwd << 2 | c) & mask;
-            rc = (rc >> 2) | (uint64_t)(3u ^ c) << shift1;
-            if (run < K) ++run;
-            if (fwd != rc) {
-                ++l;
-                if (run >= K && l < K) {      // the fast kernel counts this window, the reference does not
-                    const uint64_t canon = fwd < rc ? fwd : rc;
-                    if (filter_test_global(p.table, canon)) table_debit(p.table, canon);
-                }
-            }
+            const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            if (a + j >= limit) break;
+            if (b == '\n' || vg_nt4(b) < 4) continue;
+            debit_behind_non_base(p, read_off, n_reads, a + j, limit);
         }
     }
 }
@@ -2319,7 +2338,11 @@ hipError_t launch_seq(int mode, const RowParams& p, const uint64_t* read_off, ui
     if (grid == 0) return hipSuccess;
     if (mode == MODE_COUNT) hipLaunchKernelGGL((seq_kernel<MODE_COUNT>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
     else if (mode == MODE_KEYS) hipLaunchKernelGGL((seq_kernel<MODE_KEYS>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
-    else if (mode == MODE_DEBIT) hipLaunchKernelGGL(even_debit_kernel, dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
+    else if (mode == MODE_DEBIT) {
+        const uint64_t limit = p.emit_from < p.n_bytes ? p.emit_from : p.n_bytes, per_wg = 256u * 16u * VG_DEBIT_PIECES;
+        if (limit == 0) return hipSuccess;
+        hipLaunchKernelGGL(even_debit_kernel, dim3((uint32_t)((limit + per_wg - 1) / per_wg)), dim3(block), 0, st, p, read_off, n_reads);
+    }
     else hipLaunchKernelGGL((seq_kernel<MODE_BLOOM>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
     return hipGetLastError();
 }
