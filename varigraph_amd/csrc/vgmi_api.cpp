@@ -1020,30 +1020,12 @@ int collect_timing(vgmi_ctx* c)
     return VGMI_OK;
 }
 
-namespace {
-// A stream of the counting side (a context's own, its staging buffers', a FASTQ stream's): the highest priority the device offers.
-// One device counts a sample while the HMM kernels of the samples before it run -- an emission launch is half a million workgroups --
-// and a count launch that queues for compute units behind those is what a run of many samples waits for: the next sample's genotyping
-// starts when its counting ends.  VGMI_COUNT_PRIORITY=0: plain streams (the A/B).
-hipError_t counting_stream(hipStream_t* st)
-{
-    static const bool plain = [] {
-        const char* e = getenv("VGMI_COUNT_PRIORITY");
-        return e && e[0] == '0';
-    }();
-    int least = 0, greatest = 0;
-    if (plain || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest)
-        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest);
-}
-}  // namespace
-
 int ensure_stage(vgmi_ctx* c, Stage& s)
 {
     if (s.h) return VGMI_OK;
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&s.h), c->buffer_bytes, hipHostMallocDefault));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&s.d), c->buffer_bytes + 16));
-    HIPCHK(c, counting_stream(&s.stream));
+    HIPCHK(c, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     return VGMI_OK;
 }
@@ -1120,7 +1102,7 @@ int vgmi_create(int device, size_t buffer_mib, vgmi_ctx** out)
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* g = getenv("VGMI_GENERIC_KERNEL")) c->force_generic = g[0] == '1';
     if (const char* g = getenv("VGMI_WGS_PER_CU")) c->wgs_per_cu = (uint32_t)atoi(g);
-    if ((e = counting_stream(&c->stream)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipMalloc(&c->d_status, 4)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(c->d_status, 0, 4)) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipMalloc(&c->d_hist, 256 * 8)) != hipSuccess) return bail("hipMalloc", e);
@@ -1910,7 +1892,7 @@ int vgmi_fastq_open(vgmi_ctx* c, vgmi_fastq** out)
     const size_t raw_bytes = f->tail_max + f->text_cap + 256;
     const uint32_t n_tiles = (uint32_t)((raw_bytes + 4095) / 4096) + 1;
     const uint32_t cap_rec = f->cap_lines / 4 + 1;
-    hipError_t e = counting_stream(&f->stream);
+    hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = hipHostMalloc(reinterpret_cast<void**>(&f->h_stage[i]), f->cap, hipHostMallocDefault);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&f->h_done[i], hipEventDisableTiming);
