@@ -5,7 +5,9 @@
 // product code; the kernels (vgmi_ctable.hip) are checked against the oracle on the GPU (tests/test_gpu_large.py,
 // test_gpu_parity.py).
 //
-//   ctable_model <seed> <genome> <variants> <reads> <load percent> [repeat copies]
+//   ctable_model <seed> <genome> <variants> <reads> <load percent> [repeat copies] [k = 27 | 19 | 21 | 23 | 25]
+// k < 27 (round 5): flanks of F = k - 16 bases, F + 1 windows per entry, and the read's side looks a 16-mer up every G = 6 (k = 19: 4)
+// bases for the G windows that end in those G bases, with the bases behind X that a lane of the kernel does not have set to zero.
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -19,6 +21,8 @@
 #include "vgmi_ctable.h"
 
 static const uint64_t M54 = (1ULL << 54) - 1;
+static uint32_t KK = 27, FF = 11, GG = 12;      // k, flank bases, grid spacing
+static uint64_t MK = M54;                       // 2 k bits
 static const uint32_t NONE = 0xFFFFFFFFu;
 
 static int code(char c)
@@ -38,7 +42,7 @@ struct Model {
 
     uint32_t find(uint64_t k) const
     {
-        const uint64_t rc = vg_revcomp(k, 27);
+        const uint64_t rc = vg_revcomp(k, KK);
         auto it = index.find(k < rc ? k : rc);
         return it == index.end() ? NONE : it->second;
     }
@@ -53,8 +57,8 @@ struct Model {
                 const uint64_t K = keys[i];
                 uint32_t found = NONE, cnt = 0, enter = 0;
                 for (uint64_t b = 0; b < 4; ++b) {
-                    const uint64_t N = side ? ((K << 2) | b) & M54 : (K >> 2) | (b << 52);
-                    const uint64_t rc = vg_revcomp(N, 27);
+                    const uint64_t N = side ? ((K << 2) | b) & MK : (K >> 2) | (b << (2 * KK - 2));
+                    const uint64_t rc = vg_revcomp(N, KK);
                     const bool flipped = N > rc;
                     const uint32_t f = find(N);
                     if (f == NONE) continue;
@@ -105,7 +109,7 @@ struct Model {
         id_of_key.assign(n, 0);
         for (size_t i = 0; i < n; ++i) {
             const uint32_t pk = pos[i], p = pk & 0x7FFFFFFFu, out = pk >> 31;
-            const uint64_t Kw = out ? keys[i] : vg_revcomp(keys[i], 27);
+            const uint64_t Kw = out ? keys[i] : vg_revcomp(keys[i], KK);
             bool first = true;
             const uint32_t lb = link2[2 * i + (out ^ 1u)];
             if (lb != NONE) {
@@ -130,21 +134,21 @@ struct Model {
     void build(double load)
     {
         const size_t n = keys.size();
-        n_entries = n + 11 * n_unitigs;
+        n_entries = n + FF * n_unitigs;
         n_buckets = (uint64_t)((double)n_entries / (4.0 * load)) + 1;
         CtBucket empty;
         memset(&empty, 0, sizeof empty);
         for (auto& x : empty.x) x = 0xFFFFFFFFu;
         cb.assign(n_buckets + CT_HOPS, empty);
         for (size_t p = 0; p < n; ++p)
-            for (uint32_t o = 0; o < 12; ++o) {
+            for (uint32_t o = 0; o <= FF; ++o) {
                 const uint64_t ok = okmer[p];
                 const bool first = (ok >> 54) & 1;
-                if (o != 11 && !first) continue;
+                if (o != FF && !first) continue;
                 const uint32_t rem = (uint32_t)(ok >> 55) & 15u;
                 const uint32_t n_win = (o < rem ? o : rem) + 1u;
                 CtEntry e[2];
-                const int ne = ct_make_from_unitig(ok & M54, okmer[p + n_win - 1] & M54, o, n_win, (uint32_t)p, e);
+                const int ne = ct_make_from_unitig(ok & M54, okmer[p + n_win - 1] & M54, o, n_win, (uint32_t)p, e, KK);
                 for (int q = 0; q < ne; ++q) {
                     const uint64_t b = ((uint64_t)ct_hash(e[q].d0) * n_buckets) >> 32;
                     bool placed = false;
@@ -163,7 +167,7 @@ struct Model {
                     }
                     if (!placed)
                         for (uint32_t j = 0; j < n_win; ++j) {
-                            const uint64_t kw = okmer[p + j] & M54, rc = vg_revcomp(kw, 27);
+                            const uint64_t kw = okmer[p + j] & M54, rc = vg_revcomp(kw, KK);
                             over[kw < rc ? kw : rc] = (uint32_t)(p + j);
                             ++n_over;
                         }
@@ -173,7 +177,7 @@ struct Model {
 
     uint32_t over_find(uint64_t k) const
     {
-        const uint64_t rc = vg_revcomp(k, 27);
+        const uint64_t rc = vg_revcomp(k, KK);
         auto it = over.find(k < rc ? k : rc);
         return it == over.end() ? NONE : it->second;
     }
@@ -182,7 +186,7 @@ struct Model {
     void probe(uint32_t x, uint32_t l, uint32_t r, uint32_t vw, std::vector<uint32_t>& counts) const
     {
         uint32_t cx, cl, cr, vs;
-        ct_orient(x, l, r, vw, cx, cl, cr, vs);
+        ct_orient(x, l, r, vw, cx, cl, cr, vs, FF);
         const uint64_t b0 = ((uint64_t)ct_hash(cx) * n_buckets) >> 32;
         uint32_t found = 0;
         for (uint32_t hop = 0;; ++hop) {
@@ -190,7 +194,7 @@ struct Model {
             for (int q = 0; q < 4; ++q) {
                 if (B.x[q] != cx) continue;
                 const CtEntry e = {B.x[q], B.rest[q][0], B.rest[q][1], B.rest[q][2]};
-                uint32_t h = ct_match(e, cx, cl, cr) & vs;
+                uint32_t h = ct_match(e, cx, cl, cr, FF) & vs;
                 if (h & found) { fprintf(stderr, "window matched twice\n"); exit(2); }
                 found |= h;
                 while (h) {
@@ -205,7 +209,7 @@ struct Model {
                 while (rest) {
                     const uint32_t s = ct_ctz(rest);
                     rest &= rest - 1;
-                    const uint32_t id = over_find(ct_window_kmer(cx, cl, cr, s));
+                    const uint32_t id = over_find(ct_window_kmer(cx, cl, cr, s, KK));
                     if (id != NONE) ++counts[id];
                 }
             }
@@ -217,14 +221,14 @@ struct Model {
     uint32_t find_ct(uint64_t kmer) const
     {
         uint32_t cx, cl, cr, vs;
-        ct_orient_kmer(kmer, cx, cl, cr, vs);
+        ct_orient_kmer(kmer, cx, cl, cr, vs, KK);
         const uint64_t b0 = ((uint64_t)ct_hash(cx) * n_buckets) >> 32;
         for (uint32_t hop = 0; hop <= CT_HOPS; ++hop) {
             const CtBucket& B = cb[b0 + hop];
             for (int q = 0; q < 4; ++q) {
                 if (B.x[q] != cx) continue;
                 const CtEntry e = {B.x[q], B.rest[q][0], B.rest[q][1], B.rest[q][2]};
-                const uint32_t h = ct_match(e, cx, cl, cr) & vs;
+                const uint32_t h = ct_match(e, cx, cl, cr, FF) & vs;
                 if (h) return ct_id(e, ct_ctz(h));
             }
             if (B.x[3] == 0xFFFFFFFFu || !(B.rest[0][1] & ct_mark(cx))) return NONE;
@@ -240,9 +244,9 @@ static void add_kmers(const std::string& s, std::vector<uint64_t>& out)
     for (char c : s) {
         const int b = code(c);
         if (b > 3) { len = 0; continue; }
-        f = ((f << 2) | (uint64_t)b) & M54;
-        if (++len >= 27) {
-            const uint64_t rc = vg_revcomp(f, 27);
+        f = ((f << 2) | (uint64_t)b) & MK;
+        if (++len >= (int)KK) {
+            const uint64_t rc = vg_revcomp(f, KK);
             out.push_back(f < rc ? f : rc);
         }
     }
@@ -256,6 +260,11 @@ int main(int argc, char** argv)
     const size_t R = argc > 4 ? strtoull(argv[4], 0, 10) : 2000;
     const double load = (argc > 5 ? atoi(argv[5]) : 40) / 100.0;
     const size_t copies = argc > 6 ? strtoull(argv[6], 0, 10) : 0;
+    if (argc > 7) KK = (uint32_t)atoi(argv[7]);
+    if (KK != 27 && KK != 25 && KK != 23 && KK != 21 && KK != 19) { fprintf(stderr, "k = 19, 21, 23, 25 or 27\n"); return 2; }
+    FF = KK - 16;
+    GG = KK == 27 ? 12 : KK == 19 ? 4 : 6;
+    MK = (1ULL << (2 * KK)) - 1;
     std::mt19937_64 rng(seed);
     const char ACGT[] = "ACGT";
     std::string ref(G, 'A');
@@ -286,13 +295,13 @@ int main(int argc, char** argv)
     for (size_t p : vpos) {
         char alt = ACGT[(code(ref[p]) + 1 + rng() % 3) & 3];
         hap[p] = alt;
-        const size_t a = p >= 26 ? p - 26 : 0, b = std::min(G, p + 27);
+        const size_t a = p >= KK - 1 ? p - (KK - 1) : 0, b = std::min(G, p + KK);
         std::string w = ref.substr(a, b - a);
         add_kmers(w, ks);
         w[p - a] = alt;
         add_kmers(w, ks);
         if (rng() % 10 == 0) {           // a deletion of 1..5 bases behind the site, as a third allele
-            std::string d = ref.substr(a, p + 1 - a) + ref.substr(std::min(G, p + 1 + 1 + rng() % 5), 26);
+            std::string d = ref.substr(a, p + 1 - a) + ref.substr(std::min(G, p + 1 + 1 + rng() % 5), KK - 1);
             add_kmers(d, ks);
         }
     }
@@ -308,7 +317,7 @@ int main(int argc, char** argv)
     std::string stream;
     for (size_t i = 0; i < R; ++i) {
         const std::string& h = (rng() & 1) ? hap : ref;
-        const size_t len = (rng() % 8 == 0) ? 27 + rng() % 200 : 150;
+        const size_t len = (rng() % 8 == 0) ? KK + rng() % 200 : 150;
         const size_t at = rng() % (G - std::min(len, G - 1));
         std::string rd = h.substr(at, len);
         if (rng() & 1) {
@@ -334,8 +343,8 @@ int main(int argc, char** argv)
         int len = 0;
         for (size_t i = 0; i < n; ++i) {
             if (cd[i] > 3) { len = 0; continue; }
-            f = ((f << 2) | cd[i]) & M54;
-            if (++len >= 27) {
+            f = ((f << 2) | cd[i]) & MK;
+            if (++len >= (int)KK) {
                 const uint32_t k = m.find(f);
                 if (k != NONE) ++want[k];
                 const uint32_t id = m.find_ct(f);       // the generic kernels' tail lookup, on every k-mer
@@ -343,21 +352,23 @@ int main(int argc, char** argv)
             }
         }
     }
-    // the grid walk: X = the 16 bases ending at stream position e = 11 (mod 12); window w ends at e + w
-    for (size_t e = 11; e < n; e += 12) {
+    // the grid walk: X = the 16 bases ending at stream position e = G - 1 (mod G); window w (0 .. G - 1) ends at e + w.  A lane of the
+    // kernel owns twelve bytes and has, behind the X of its sub-position, only what is left of them: avail bases (11 for G = 12)
+    for (size_t e = GG - 1; e < n; e += GG) {
         if (e < 15) continue;
         uint32_t x = 0, l = 0, r = 0, vw = 0;
         bool okx = true;
         for (size_t j = e - 15; j <= e; ++j) { okx &= cd[j] < 4; x = (x << 2) | (cd[j] & 3u); }
         if (!okx) continue;
-        for (int j = 11; j >= 1; --j) {           // bases e - 15 - j: in front of X
+        for (int j = (int)FF; j >= 1; --j) {           // bases e - 15 - j: in front of X
             const long q = (long)e - 15 - j;
             l = (l << 2) | (q >= 0 ? cd[q] & 3u : 0u);
         }
-        for (int j = 1; j <= 11; ++j) r = (r << 2) | (e + j < n ? cd[e + j] & 3u : 0u);
-        for (uint32_t w = 0; w < 12; ++w) {
-            bool ok = e + w < n && e + w >= 26;
-            for (size_t j = 0; ok && j < 27; ++j) ok = cd[e + w - j] < 4;
+        const uint32_t avail = e % 12 == 11 ? 11u : 10u - (uint32_t)(e % 12);
+        for (uint32_t j = 1; j <= FF; ++j) r = (r << 2) | (j <= avail && e + j < n ? cd[e + j] & 3u : 0u);
+        for (uint32_t w = 0; w < GG; ++w) {
+            bool ok = e + w < n && e + w >= KK - 1;
+            for (size_t j = 0; ok && j < KK; ++j) ok = cd[e + w - j] < 4;
             vw |= (uint32_t)ok << w;
         }
         if (vw) m.probe(x, l, r, vw, got_by_id);

@@ -552,7 +552,8 @@ def test_saturation_flags_do_not_travel_with_the_table_image(ctx):
 
 
 # ----------------------------------------------------------------------------- large graphs (global grid bitmap)
-@pytest.mark.parametrize("k,placement", [(27, None), (25, None), (27, {"VGMI_XTABLE": "0"}), (27, {"VGMI_XTABLE": "0", "VGMI_LOCALITY": "0"}),
+@pytest.mark.parametrize("k,placement", [(27, None), (25, None), (23, None), (21, None), (19, None), (25, {"VGMI_CTABLE_K": "0"}),
+                                         (21, {"VGMI_CTABLE_LOAD": "90"}), (23, {"VGMI_CTABLE_LOAD": "10"}), (27, {"VGMI_XTABLE": "0"}), (27, {"VGMI_XTABLE": "0", "VGMI_LOCALITY": "0"}),
                                          (27, {"VGMI_XTABLE": "0", "VGMI_LOCALITY": "3"}),
                                          (27, {"VGMI_WIDE_SLOTS": "1"}), (27, {"VGMI_WIDE_SLOTS": "1", "VGMI_DENSE_COUNTS": "1"}),
                                          (27, {"VGMI_WIDE_SLOTS": "1", "VGMI_LOCALITY": "0"}),
@@ -560,15 +561,16 @@ def test_saturation_flags_do_not_travel_with_the_table_image(ctx):
                                          (27, {"VGMI_CTABLE": "0"}), (27, {"VGMI_CTABLE": "0", "VGMI_XTABLE_ORDER": "0"}),
                                          (27, {"VGMI_CTABLE": "0", "VGMI_XTABLE_LOAD": "60"}), (27, {"VGMI_CTABLE_LOAD": "90"}),
                                          (27, {"VGMI_CTABLE_LOAD": "10"})],
-                         ids=["k27", "k25", "k27-minimiser-buckets", "k27-random-homes", "k27-buckets-of-8", "k27-16-byte-slots",
+                         ids=["k27", "k25", "k23", "k21", "k19", "k25-generic-kernel", "k21-context-table-crowded", "k23-context-table-sparse", "k27-minimiser-buckets", "k27-random-homes", "k27-buckets-of-8", "k27-16-byte-slots",
                               "k27-16-byte-slots-dense-counters", "k27-16-byte-slots-random-homes", "k27-slots-by-minimiser-offset",
                               "k27-grid-table", "k27-grid-table-ids-by-key-index", "k27-grid-table-crowded", "k27-context-table-crowded",
                               "k27-context-table-sparse"])
 def test_large_graph_grid_variant_matches_oracle(k, placement, monkeypatch):
     """> 65 536 keys: k = 27 takes count27c_kernel over the context table (default since round 4; path-ordered counter ids), with
     VGMI_CTABLE=0 count27x_kernel over round 2's grid-16-mer table, with
-    VGMI_XTABLE=0 count27_kernel<global grid bitmap> over the minimiser-bucket table (+ generic tail row either way), k = 25 the
-    generic rows_kernel with the global blocked-Bloom prefilter.  Dense SNPs (1 per 60 bp) give ~35 %
+    VGMI_XTABLE=0 count27_kernel<global grid bitmap> over the minimiser-bucket table (+ generic tail row either way); k = 19 .. 25
+    the context table with flanks of k - 16 bases and countkc_kernel<K> (round 5: a 16-mer looked up every 6 or 4 bases), with
+    VGMI_CTABLE_K=0 the generic rows_kernel with the global blocked-Bloom prefilter.  Dense SNPs (1 per 60 bp) give ~35 %
     hit rate: exercises ring pressure, re-queued collision probes and unsaturated counters.  The k = 27 table has
     8-byte slots in minimiser buckets with per-slot counters by default; the other formats and placements stay covered."""
     import torch
@@ -595,6 +597,12 @@ def test_large_graph_grid_variant_matches_oracle(k, placement, monkeypatch):
         c.table_upload(keys, k)
         info = c.table_info()
         assert info["n_keys"] == keys.size
+        if k != 27:
+            x = c.ctable_info()
+            if placement and placement.get("VGMI_CTABLE_K") == "0":
+                assert x["n_buckets"] == 0, x
+            else:
+                assert x["n_buckets"] > 0 and x["n_entries"] == keys.size + (k - 16) * x["n_unitigs"], x
         c.counts_reset()
         c.reads_submit(block, n_reads)               # chunked through the 16 MiB staging buffers
         cov, _, _ = c.counts_finish()
@@ -613,9 +621,11 @@ def test_large_graph_grid_variant_matches_oracle(k, placement, monkeypatch):
         c.close()
 
 
-@pytest.mark.parametrize("form,crowded", [("ctable", False), ("ctable", True), ("xtable", False), ("xtable", True)],
-                         ids=["context-table", "context-table-crowded", "grid-table", "grid-table-crowded"])
-def test_repeat_rich_graph_matches_oracle(form, crowded, monkeypatch):
+@pytest.mark.parametrize("form,crowded,k", [("ctable", False, 27), ("ctable", True, 27), ("xtable", False, 27), ("xtable", True, 27),
+                                           ("ctable", False, 25), ("ctable", True, 21), ("ctable", False, 19)],
+                         ids=["context-table", "context-table-crowded", "grid-table", "grid-table-crowded", "context-table-k25",
+                              "context-table-crowded-k21", "context-table-k19"])
+def test_repeat_rich_graph_matches_oracle(form, crowded, k, monkeypatch):
     """A reference made of thousands of diverged copies of one 400-bp element: every 16-mer of the element sits in hundreds
     of different contexts / graph k-mers, far more than its home bucket (line) of the context table (grid-16-mer table) and the
     ones behind it hold.  Those k-mers must be served by the exact overflow table, and nothing may be matched by less than every base."""
@@ -635,15 +645,15 @@ def test_repeat_rich_graph_matches_oracle(form, crowded, monkeypatch):
     V = 60_000
     pos = np.sort(rng.choice(np.arange(100, G - 100), size=V, replace=False))
     alts = synth._ACGT[(synth._CODE[ref[pos]] + rng.integers(1, 4, size=V)) % 4]
-    keys = np.unique(vgmi.synth_snp_keys(ref, pos, alts, 27))
-    assert keys.size > 300_000
+    keys = np.unique(vgmi.synth_snp_keys(ref, pos, alts, k))
+    assert keys.size > 200_000
     hap1 = ref.copy()
     hap1[pos] = alts
     n_reads = 120_000
     block = vgmi.synth_reads_host(11, 0, n_reads, 150, [ref, hap1])
     c = vgmi.Context(0, buffer_mib=16)
     try:
-        c.table_upload(keys, 27)
+        c.table_upload(keys, k)
         if form == "xtable":
             x = c.xtable_info()
             assert x["n_lines"] > 0 and x["overflow_pairs"] > 1000, x
@@ -654,7 +664,7 @@ def test_repeat_rich_graph_matches_oracle(form, crowded, monkeypatch):
         c.reads_submit(block, n_reads)
         cov, _, _ = c.counts_finish()
         t = o.Table(keys)
-        t.count_block(block, 27)
+        t.count_block(block, k)
         assert np.array_equal(cov, t.counts())
         assert int(cov.astype(np.int64).sum()) > 1_000_000
     finally:

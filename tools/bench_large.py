@@ -20,15 +20,16 @@ def main():
     ap.add_argument("--reads", type=int, default=24_000_000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--check", type=int, default=0, help="verify against the oracle on this many reads")
+    ap.add_argument("--k", type=int, default=27, help="27, or 19 .. 25 (round 5: the context table with flanks of k - 16 bases; VGMI_CTABLE_K=0: the generic kernel)")
     args = ap.parse_args()
     import torch
     from varigraph_amd import synth, vgmi
     t0 = time.time()
-    keys, (ref, hap1) = synth.snp_graph(args.genome, args.variants)
+    keys, (ref, hap1) = synth.snp_graph(args.genome, args.variants, k=args.k)
     print(f"graph: {len(keys)} keys built in {time.time() - t0:.1f}s", file=sys.stderr)
     ctx = vgmi.Context(0, buffer_mib=64)
     t0 = time.time()
-    ctx.table_upload(keys, 27)
+    ctx.table_upload(keys, args.k)
     t_upload = time.time() - t0
     info = ctx.table_info()
     cat = np.concatenate([ref, hap1])
@@ -54,7 +55,7 @@ def main():
     cov = d_cov.cpu().numpy()
     hits = int(cov.astype(np.int64).sum())
     best = min(r[1] for r in res[1:])
-    out = {"genome": args.genome, "variants": args.variants, "n_keys": int(len(keys)), "table_slots": info["n_slots"],
+    out = {"k": args.k, "genome": args.genome, "variants": args.variants, "n_keys": int(len(keys)), "table_slots": info["n_slots"],
            "filter_bits": info["filter_bits"], "reads": n_reads, "kernel_ms": best, "reads_per_s": n_reads / best * 1e3,
            "counted_hits_clamped": hits, "hits_per_read_lower_bound": hits / n_reads, "table_upload_s": t_upload,
            "context_table": ctx.ctable_info(), "grid_table": ctx.xtable_info(), "all_kernel_ms": [r[1] for r in res]}
@@ -66,7 +67,7 @@ def main():
         ctx.reads_submit_device(d_block, m * 151, m)
         c2, _, _ = ctx.counts_finish()
         t = oracle_lib.Table(keys)
-        t.count_block(d_block[: m * 151].cpu().numpy(), 27)
+        t.count_block(d_block[: m * 151].cpu().numpy(), args.k)
         out["oracle_match"] = bool(np.array_equal(c2, t.counts()))
     print(json.dumps(out))
 

@@ -13,13 +13,55 @@ tc = importlib.util.module_from_spec(spec); spec.loader.exec_module(tc)
 from varigraph_amd import synth
 
 
+def dress(path, rng):
+    """A FASTQ file as sequencers and pipelines leave them (round 5): some reads with N, some in lower case, some cut short (ragged
+    lengths), then plain / gzip at a drawn level / gzip of several members / block gzip.  Returns the path to put into samples.cfg."""
+    import zlib
+    lines = open(path, "rb").read().split(b"\n")
+    n_rec = len(lines) // 4
+    for r in rng.choice(n_rec, size=max(1, n_rec // 40), replace=False):
+        seq, qual = bytearray(lines[4 * r + 1]), lines[4 * r + 3]
+        what = int(rng.integers(0, 4))
+        if what == 0:
+            for pos in rng.integers(0, len(seq), size=int(rng.integers(1, 4))): seq[int(pos)] = ord("N")
+        elif what == 1:
+            seq = bytearray(bytes(seq).lower())
+        elif what == 2:
+            cut = int(rng.integers(1, len(seq)))
+            seq, qual = seq[:cut], qual[:cut]
+        else:
+            a = int(rng.integers(0, len(seq) - 2))
+            seq[a:a + 2] = b"NN"
+        lines[4 * r + 1], lines[4 * r + 3] = bytes(seq), qual
+    text = b"\n".join(lines)
+    form = int(rng.integers(0, 5))
+    if form == 0:
+        open(path, "wb").write(text)
+        return path
+    if form == 1 or form == 2:
+        level = int(rng.integers(1, 10))
+        open(path + ".gz", "wb").write(gzip.compress(text, compresslevel=level))
+        os.remove(path)
+        return path + ".gz"
+    if form == 3:      # several members, cut anywhere
+        cuts = sorted(set([0, len(text)] + [int(x) for x in rng.integers(0, len(text), size=int(rng.integers(1, 6)))]))
+        with open(path + ".gz", "wb") as f:
+            for a, b in zip(cuts[:-1], cuts[1:]): f.write(gzip.compress(text[a:b], compresslevel=6))
+        os.remove(path)
+        return path + ".gz"
+    open(path, "wb").write(text)
+    synth.bgzf_compress_file(path, path + ".gz", level=int(rng.integers(1, 10)), block=int(rng.integers(2000, 0xff01)))
+    os.remove(path)
+    return path + ".gz"
+
+
 def case(seed):
     rng = np.random.default_rng(seed)
     pick = lambda xs: xs[int(rng.integers(0, len(xs)))]
     genome = int(pick([40_000, 90_000, 200_000, 400_000]))
     vploidy = pick([2, 2, 2, 3, 4])
     n_samples = pick([1, 2, 3, 5, 7]) if vploidy <= 2 else pick([1, 2, 3])
-    k = pick([27, 27, 27, 21, 25, 22, 28, 15, 11])
+    k = pick([27, 27, 27, 21, 25, 22, 28, 15, 11, 19, 23, 20, 24, 26])
     copts = pick([[], [], ["--fast"], ["--use-unique-kmers"]])
     n_var = max(5, genome // pick([300, 600, 1500]))
     indel, sv = pick([0.0, 0.1, 0.3]), pick([0.0, 0.01, 0.05])
@@ -52,6 +94,7 @@ def case(seed):
             who = int(rng.integers(0, n_samples))
             haps = synth.sample_haplotypes(ref, variants, gts, who, vploidy)
             fq = tc._write_fastq(os.path.join(work, f"s{i}"), haps, pairs, seed=int(seed) * 10 + i)
+            fq = [dress(f, rng) for f in fq]
             cfg += f"ind{i} " + " ".join(fq) + "\n"
         outs, codes = {}, {}
         for name, exe, more in (("native", tc.CLI, ["--gpu", "0"]), ("cpu", tc.REF, [])):

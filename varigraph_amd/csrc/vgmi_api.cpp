@@ -145,6 +145,7 @@ namespace {
 void fastq_free(vgmi_fastq* f);
 struct ImageHeader;
 bool xtable_wanted(const ImageHeader& h);
+bool ctable_wanted(const ImageHeader& h);
 
 int fail(vgmi_ctx* c, int code, const std::string& msg)
 {
@@ -247,7 +248,11 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     // VGMI_SMALLK=0 keeps them on the generic row kernel, the A/B reference)
     // (even k = 20 .. 24 as well: the kernel's rule is the odd one, the debit pass runs ahead of it with the reference's)
     const bool smallk = k >= 19 && k <= 25 && n_keys <= VG_GRID_LDS_MAX_KEYS && !(getenv("VGMI_SMALLK") && getenv("VGMI_SMALLK")[0] == '0');
-    const bool compact = (k == 27 || smallk) && !getenv("VGMI_WIDE_SLOTS");   // 8-byte k-mer words + per-slot counters
+    // ... and graphs of k = 19 .. 25 too large for that: the context table is built from the compact image (xtable_wanted)
+    const bool off_k = (getenv("VGMI_CTABLE_K") && getenv("VGMI_CTABLE_K")[0] == '0') || (getenv("VGMI_CTABLE") && getenv("VGMI_CTABLE")[0] == '0') ||
+                       (getenv("VGMI_XTABLE") && getenv("VGMI_XTABLE")[0] == '0');
+    const bool largek = (k == 19 || k == 21 || k == 23 || k == 25) && n_keys > VG_GRID_LDS_MAX_KEYS && n_keys < (1ULL << 31) - 16 && !off_k;
+    const bool compact = (k == 27 || smallk || largek) && !getenv("VGMI_WIDE_SLOTS");   // 8-byte k-mer words + per-slot counters
     h.slot_bytes = compact ? 8 : 16;
     uint64_t cap = 64;
     uint64_t lf_mul = compact ? 8 : 4;   // load factor <= 0.125 / 0.25: nearly every probe ends at the first slot
@@ -335,7 +340,7 @@ int adopt_image(vgmi_ctx* c)
     c->tv.counts = nullptr;
     c->n_counts = 0;
     if (compact && !xtable_wanted(h)) c->n_counts = h.cap;              // per-slot counters (the grid-16-mer table has its own, per key)
-    else if (h.n_keys > VG_GRID_LDS_MAX_KEYS && (h.home_bucket_log2 == 0 || getenv("VGMI_DENSE_COUNTS")))
+    else if (h.n_keys > VG_GRID_LDS_MAX_KEYS && (h.home_bucket_log2 == 0 || getenv("VGMI_DENSE_COUNTS")) && !(h.k != 27 && xtable_wanted(h)))
         c->n_counts = h.n_keys;   // randomly placed slots: 4 B/key dense counters stay Infinity-Cache resident
     // (minimiser buckets: the counter lives in the slot, the atomic hits the line its probe has just fetched)
     if (c->n_counts) {
@@ -362,7 +367,13 @@ int adopt_image(vgmi_ctx* c)
 bool xtable_wanted(const ImageHeader& h)
 {
     const char* e = getenv("VGMI_XTABLE");
-    return !(e && e[0] == '0') && h.k == 27 && h.slot_bytes == 8 && h.n_keys > VG_GRID_LDS_MAX_KEYS;
+    if ((e && e[0] == '0') || h.slot_bytes != 8 || h.n_keys <= VG_GRID_LDS_MAX_KEYS) return false;
+    // k = 19 .. 25, odd (round 5): the context table only (flanks of k - 16 bases, vgmi_ctable.h); VGMI_CTABLE_K=0 keeps them on the generic kernel (A/B)
+    if (h.k == 19 || h.k == 21 || h.k == 23 || h.k == 25) {
+        const char* o = getenv("VGMI_CTABLE_K");
+        return !(o && o[0] == '0') && ctable_wanted(h);
+    }
+    return h.k == 27;
 }
 
 // lines + overflow table of one numbering of the keys (id_of_key, or the key index).  The (key, 16-mer) pairs that find no
@@ -485,7 +496,7 @@ int build_ctable(vgmi_ctx* c)
         HIPCHK(c, he);
     }
     c->ct_unitigs = cur[1];
-    c->ct_entries = n + 11 * cur[1];          // a unitig of L k-mers holds L + 11 occurrences (palindromic 16-mers: two entries, rare)
+    c->ct_entries = n + (h.k - 16) * cur[1];  // a unitig of L k-mers holds L + k - 16 occurrences (palindromic 16-mers: two entries, rare)
     double load = 0.30;     // measured, chr20 / whole-genome class kernel ms: 25 % 8.25 / -, 30 % 8.17 / 30.1, 40 % 8.41 / 33.4 (gpurun_out/r4c)
     if (const char* e = getenv("VGMI_CTABLE_LOAD")) load = atoi(e) >= 5 && atoi(e) <= 95 ? atoi(e) / 100.0 : load;
     uint64_t n_buckets = (uint64_t)((double)c->ct_entries / (4.0 * load)) + 1;
@@ -538,6 +549,7 @@ int build_ctable(vgmi_ctx* c)
         if (!done && getenv("VGMI_VERBOSE")) fprintf(stderr, "[vgmi] context table: %zu bytes by hipMalloc at %p\n", want, (void*)c->d_ct_buckets);
     }
     x.cb = c->d_ct_buckets;
+    x.k = h.k;
     x.n_buckets = (uint32_t)n_buckets;
     x.counts = c->d_xt_counts;
     uint64_t cap = 1u << 16;
@@ -566,7 +578,7 @@ int build_ctable(vgmi_ctx* c)
         uint64_t slots = 1024;
         while (slots < 2 * n_over) slots <<= 1;
         he = hipMalloc(reinterpret_cast<void**>(&c->d_xt_over), slots * 16);
-        if (he == hipSuccess) he = launch_ctable_over(c->d_xt_over, (uint32_t)(slots - 1), okmer, d_list, n_over, c->stream);
+        if (he == hipSuccess) he = launch_ctable_over(c->d_xt_over, (uint32_t)(slots - 1), okmer, d_list, n_over, h.k, c->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         x.over = c->d_xt_over;
         x.over_mask = (uint32_t)(slots - 1);
@@ -593,6 +605,7 @@ int build_xtable(vgmi_ctx* c)
     if (n_lines < (1u << 20)) n_lines = 1u << 20;
     if (n_lines >= (1ULL << 31) || n_lines * 16 < h.n_keys * 13) return fail(c, VGMI_E_NOMEM, "not enough device memory for the grid-16-mer table");
     x.n_lines = (uint32_t)n_lines;
+    x.k = 27;
     // an entry found in line P has its home in P - XT_HOPS .. P: at most (XT_HOPS + 1) * ceil(2^32 / n_lines) + 1 consecutive
     // h-values, told apart by their low tag_bits
     x.tag_bits = ceil_log2((XT_HOPS + 1) * (((1ULL << 32) + n_lines - 1) / n_lines) + 1);

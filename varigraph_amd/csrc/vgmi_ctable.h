@@ -33,6 +33,12 @@
 // orientation; an occurrence that reads the other way is stored reverse-complemented (L and R swap, s -> 11 - s, the ids run
 // the other way); a 16-mer that is its own reverse complement is stored both ways, and no window can match both (that would
 // put a k-mer and its reverse complement -- one key -- at two places of one unitig).
+//
+// Other odd k (19 .. 25; round 5).  The algebra does not depend on 27: with F = k - 16 flank bases on either side an entry holds the
+// F + 1 windows of k bases around its X (window s: s bases of L, X, F - s of R), and every function below takes F (or k) next to the
+// values -- 11 / 27 by default.  The fields keep their places (22 bits per flank, twelve mask bits), the upper ones stay zero.  What
+// changes is on the read's side: a 16-mer every TWELVE bases no longer meets every window of k < 27 bases, so the count kernel looks
+// one up every G bases, G = 6 (k = 21 .. 25) or 4 (k = 19), and asks each only for the G windows that end in its own G bases.
 #ifndef VGMI_CTABLE_H
 #define VGMI_CTABLE_H
 
@@ -66,14 +72,14 @@ VG_HD uint32_t ct_hash(uint32_t cx)
 // which of the six marks of a full bucket an entry with this X sets when it goes on (the low half of the hash; the bucket comes from the top)
 VG_HD uint32_t ct_mark(uint32_t cx) { return 1u << (26u + (((ct_hash(cx) & 0xFFFFu) * 6u) >> 16)); }
 
-VG_HD uint32_t ct_rc11(uint32_t x) { return vg_revcomp16(x) >> 10; }      // 11 bases in the low 22 bits
-VG_HD uint32_t ct_rev12(uint32_t m)                                        // bit s -> bit 11 - s
+VG_HD uint32_t ct_rc11(uint32_t x, uint32_t f = 11u) { return vg_revcomp16(x) >> (32u - 2u * f); }      // f bases in the low 2 f bits
+VG_HD uint32_t ct_rev12(uint32_t m, uint32_t f = 11u)                                                    // bit s -> bit f - s
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_bitreverse32(m) >> 20;
+    return __builtin_bitreverse32(m) >> (31u - f);
 #else
     uint32_t r = 0;
-    for (int s = 0; s < 12; ++s) r |= ((m >> s) & 1u) << (11 - s);
+    for (uint32_t s = 0; s <= f; ++s) r |= ((m >> s) & 1u) << (f - s);
     return r;
 #endif
 }
@@ -101,79 +107,83 @@ VG_HD uint32_t ct_clz(uint32_t x)
 // A read position's context in the table's orientation.  x, l, r as read (l: the 11 bases in front of x, the one next to x
 // least significant; r: the 11 behind it, the one next to x most significant); vw bit w = the window that ends w bases
 // behind x's last base is made of bases only (the scan's numbering).  Out: canonical x, its flanks, vs bit s = window s valid.
-VG_HD void ct_orient(uint32_t x, uint32_t l, uint32_t r, uint32_t vw, uint32_t& cx, uint32_t& cl, uint32_t& cr, uint32_t& vs)
+VG_HD void ct_orient(uint32_t x, uint32_t l, uint32_t r, uint32_t vw, uint32_t& cx, uint32_t& cl, uint32_t& cr, uint32_t& vs, uint32_t f = 11u)
 {
     const uint32_t rc = vg_revcomp16(x);
     const bool as_is = x <= rc;
     cx = as_is ? x : rc;
-    cl = as_is ? l : ct_rc11(r);
-    cr = as_is ? r : ct_rc11(l);
-    vs = as_is ? ct_rev12(vw) : vw;        // window w takes w bases behind x: s = 11 - w as read, s = w reversed
+    cl = as_is ? l : ct_rc11(r, f);
+    cr = as_is ? r : ct_rc11(l, f);
+    vs = as_is ? ct_rev12(vw, f) : vw;     // window w takes w bases behind x: s = f - w as read, s = w reversed
 }
 
 // windows of the context (cx, cl, cr) that equal k-mers of entry e: bit s
-VG_HD uint32_t ct_match(const CtEntry& e, uint32_t cx, uint32_t cl, uint32_t cr)
+VG_HD uint32_t ct_match(const CtEntry& e, uint32_t cx, uint32_t cl, uint32_t cr, uint32_t f = 11u)
 {
     if (e.d0 != cx) return 0u;
-    const uint32_t tl = ((e.d1 ^ cl) & CT_M22) | (1u << 22);
-    const uint32_t nl = ct_ctz(tl) >> 1;                           // bases of L equal next to X: 0..11
-    const uint32_t tr = (((e.d2 ^ cr) & CT_M22) << 10) | (1u << 9);
-    const uint32_t nr = ct_clz(tr) >> 1;                           // bases of R equal next to X: 0..11
-    const uint32_t range = ((2u << nl) - 1u) & ~((1u << (11u - nr)) - 1u);     // 11 - nr <= s <= nl
+    const uint32_t mf = (1u << (2u * f)) - 1u;
+    const uint32_t tl = ((e.d1 ^ cl) & mf) | (1u << (2u * f));
+    const uint32_t nl = ct_ctz(tl) >> 1;                           // bases of L equal next to X: 0..f
+    const uint32_t tr = (((e.d2 ^ cr) & mf) << (32u - 2u * f)) | (1u << (31u - 2u * f));
+    const uint32_t nr = ct_clz(tr) >> 1;                           // bases of R equal next to X: 0..f
+    const uint32_t range = ((2u << nl) - 1u) & ~((1u << (f - nr)) - 1u);       // f - nr <= s <= nl
     const uint32_t emask = (e.d1 >> 22) | ((e.d2 >> 12) & 0xC00u);
     return range & emask;
 }
-VG_HD uint32_t ct_id(const CtEntry& e, uint32_t s) { return (e.d2 & CT_DIR) ? e.d3 + s : e.d3 - s; }
+VG_HD uint32_t ct_id(const CtEntry& e, uint32_t s) { return (e.d2 & CT_DIR) ? e.d3 + s : e.d3 - s; }      // (any f)
 
 // The entry of one occurrence, from the unitig as the numbering walks it: xu the 16-mer, lu / ru its flanks (missing bases
 // zero), mask bit s = the unitig holds window s, whose counter is id0 - s.  Returns 1 entry, or 2 when xu is its own
 // reverse complement (both readings).
-VG_HD int ct_make(uint32_t xu, uint32_t lu, uint32_t ru, uint32_t mask, uint32_t id0, CtEntry out[2])
+VG_HD int ct_make(uint32_t xu, uint32_t lu, uint32_t ru, uint32_t mask, uint32_t id0, CtEntry out[2], uint32_t f = 11u)
 {
-    const uint32_t rc = vg_revcomp16(xu);
+    const uint32_t rc = vg_revcomp16(xu), mf = (1u << (2u * f)) - 1u;
     int n = 0;
     if (xu <= rc) {
         out[n].d0 = xu;
-        out[n].d1 = (lu & CT_M22) | (mask & 0x3FFu) << 22;
-        out[n].d2 = (ru & CT_M22) | ((mask >> 10) & 3u) << 22;
+        out[n].d1 = (lu & mf) | (mask & 0x3FFu) << 22;
+        out[n].d2 = (ru & mf) | ((mask >> 10) & 3u) << 22;
         out[n].d3 = id0;
         ++n;
     }
     if (xu >= rc) {
-        const uint32_t m = ct_rev12(mask);
+        const uint32_t m = ct_rev12(mask, f);
         out[n].d0 = rc;
-        out[n].d1 = ct_rc11(ru & CT_M22) | (m & 0x3FFu) << 22;
-        out[n].d2 = ct_rc11(lu & CT_M22) | ((m >> 10) & 3u) << 22 | CT_DIR;
-        out[n].d3 = id0 - 11u;
+        out[n].d1 = ct_rc11(ru & mf, f) | (m & 0x3FFu) << 22;
+        out[n].d2 = ct_rc11(lu & mf, f) | ((m >> 10) & 3u) << 22 | CT_DIR;
+        out[n].d3 = id0 - f;
         ++n;
     }
     return n;
 }
 
-// The occurrence led by the k-mer at unitig position u (kf, as walked) with X starting o bases into it (0..11): the k-mers
+// The occurrence led by the k-mer at unitig position u (kf, as walked) with X starting o bases into it (0..f): the k-mers
 // u .. u + n_win - 1 hold it (n_win = min(o, k-mers behind kf in the unitig) + 1; kl = the last of them, id p of kf).
-VG_HD int ct_make_from_unitig(uint64_t kf, uint64_t kl, uint32_t o, uint32_t n_win, uint32_t p, CtEntry out[2])
+VG_HD int ct_make_from_unitig(uint64_t kf, uint64_t kl, uint32_t o, uint32_t n_win, uint32_t p, CtEntry out[2], uint32_t k = 27u)
 {
-    const uint32_t xu = (uint32_t)(kf >> (2u * (11u - o)));
-    const uint32_t lu = o ? (uint32_t)(kf >> (2u * (27u - o))) : 0u;               // the o bases in front of X
-    const uint32_t n_r = n_win + 10u - o;                                           // bases behind X the last k-mer reaches: 0..11
-    const uint32_t ru = n_r ? ((uint32_t)kl & ((1u << (2u * n_r)) - 1u)) << (2u * (11u - n_r)) : 0u;
+    const uint32_t f = k - 16u;
+    const uint32_t xu = (uint32_t)(kf >> (2u * (f - o)));
+    const uint32_t lu = o ? (uint32_t)(kf >> (2u * (k - o))) : 0u;                  // the o bases in front of X
+    const uint32_t n_r = n_win + f - 1u - o;                                        // bases behind X the last k-mer reaches: 0..f
+    const uint32_t ru = n_r ? ((uint32_t)kl & ((1u << (2u * n_r)) - 1u)) << (2u * (f - n_r)) : 0u;
     const uint32_t mask = ((1u << n_win) - 1u) << (o + 1u - n_win);                 // s = o - n_win + 1 .. o
-    return ct_make(xu, lu, ru, mask, p + o, out);
+    return ct_make(xu, lu, ru, mask, p + o, out, f);
 }
 
-// A single k-mer as a one-window context: X = its last 16 bases, window s = 11 as read
-VG_HD void ct_orient_kmer(uint64_t kmer, uint32_t& cx, uint32_t& cl, uint32_t& cr, uint32_t& vs)
+// A single k-mer as a one-window context: X = its last 16 bases, window s = f as read
+VG_HD void ct_orient_kmer(uint64_t kmer, uint32_t& cx, uint32_t& cl, uint32_t& cr, uint32_t& vs, uint32_t k = 27u)
 {
-    ct_orient((uint32_t)kmer, (uint32_t)(kmer >> 32) & CT_M22, 0u, 1u, cx, cl, cr, vs);
+    const uint32_t f = k - 16u;
+    ct_orient((uint32_t)kmer, (uint32_t)(kmer >> 32) & ((1u << (2u * f)) - 1u), 0u, 1u, cx, cl, cr, vs, f);
 }
 
 // the k-mer (in the table's orientation) of window s of a context: for the exact overflow table
-VG_HD uint64_t ct_window_kmer(uint32_t cx, uint32_t cl, uint32_t cr, uint32_t s)
+VG_HD uint64_t ct_window_kmer(uint32_t cx, uint32_t cl, uint32_t cr, uint32_t s, uint32_t k = 27u)
 {
+    const uint32_t f = k - 16u;
     const uint64_t left = s ? (uint64_t)(cl & ((1u << (2u * s)) - 1u)) : 0ull;
-    const uint64_t right = (uint64_t)(cr & CT_M22) >> (2u * s);          // the first 11 - s bases of R
-    return left << (2u * (27u - s)) | (uint64_t)cx << (2u * (11u - s)) | right;
+    const uint64_t right = (uint64_t)(cr & ((1u << (2u * f)) - 1u)) >> (2u * s);          // the first f - s bases of R
+    return left << (2u * (k - s)) | (uint64_t)cx << (2u * (f - s)) | right;
 }
 
 #endif

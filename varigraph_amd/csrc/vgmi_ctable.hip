@@ -40,7 +40,7 @@ __global__ void ct_okmer_kernel(TableView t, const uint32_t* key_slot, const uin
     if (i >= n) return;
     const uint32_t pk = pos_of_key[i], p = pk & 0x7FFFFFFFu, out = pk >> 31;
     const uint64_t K = t.slots8[key_slot[i]] & CT_MASK54;
-    const uint64_t Kw = out ? K : vg_revcomp(K, 27);
+    const uint64_t Kw = out ? K : vg_revcomp(K, t.k);
     bool first = true;
     const uint32_t lb = link2[2 * i + (out ^ 1u)];
     if (lb != CT_NONE) {
@@ -69,25 +69,26 @@ __global__ void ct_identity_kernel(uint32_t* pos_of_key, uint64_t n)
     if (i < n) pos_of_key[i] = (uint32_t)i | 1u << 31;
 }
 
-// one thread per (place p of the numbering, offset o of X in the k-mer): the pair leads an occurrence iff o == 11 or the k-mer is the first of its
+// one thread per (place p of the numbering, offset o of X in the k-mer: 0 .. k - 16): the pair leads an occurrence iff o == k - 16 or the k-mer is the first of its
 // unitig.  An entry that finds its home bucket and the CT_HOPS buckets behind it full sends the k-mers of its windows to the exact
 // overflow table (their places go on over_list); every full bucket it passed is marked, so a lookup follows the same trail.
 __global__ void ct_insert_kernel(XTableView t, const unsigned long long* okmer, uint64_t n, uint32_t* over_list, uint32_t over_cap,
                                  unsigned long long* over_n, unsigned long long* n_moved)
 {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n * 12) return;
-    const uint64_t p = g / 12;
-    const uint32_t o = (uint32_t)(g - p * 12);
+    const uint32_t f = t.k - 16u;          // 11; k = 19 .. 25: 3 .. 9
+    if (g >= n * (f + 1u)) return;
+    const uint64_t p = g / (f + 1u);
+    const uint32_t o = (uint32_t)(g - p * (f + 1u));
     const unsigned long long ok = okmer[p];
     if (ok >> 63) return;                  // a place no k-mer has (chains start at multiples of 16)
     const bool first = (ok >> 54) & 1ULL;
-    if (o != 11u && !first) return;
+    if (o != f && !first) return;
     const uint32_t rem = (uint32_t)(ok >> 55) & 15u;
     const uint32_t n_win = (o < rem ? o : rem) + 1u;
     const uint64_t kf = ok & CT_MASK54, kl = okmer[p + n_win - 1] & CT_MASK54;
     CtEntry e[2];
-    const int ne = ct_make_from_unitig(kf, kl, o, n_win, (uint32_t)p, e);
+    const int ne = ct_make_from_unitig(kf, kl, o, n_win, (uint32_t)p, e, t.k);
     uint32_t* const cb = reinterpret_cast<uint32_t*>(const_cast<uint4*>(t.cb));
     for (int q = 0; q < ne; ++q) {
         const uint64_t b = ((uint64_t)ct_hash(e[q].d0) * t.n_buckets) >> 32;
@@ -113,12 +114,12 @@ __global__ void ct_insert_kernel(XTableView t, const unsigned long long* okmer, 
 }
 
 // the overflow table: open addressing on the canonical k-mer (one cell per k-mer however many of its entries overflowed)
-__global__ void ct_over_kernel(ulonglong2* over, uint32_t over_mask, const unsigned long long* okmer, const uint32_t* over_list, uint64_t n_over)
+__global__ void ct_over_kernel(ulonglong2* over, uint32_t over_mask, const unsigned long long* okmer, const uint32_t* over_list, uint64_t n_over, uint32_t k)
 {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_over) return;
     const uint32_t id = over_list[g];
-    const uint64_t kw = okmer[id] & CT_MASK54, rc = vg_revcomp(kw, 27);
+    const uint64_t kw = okmer[id] & CT_MASK54, rc = vg_revcomp(kw, k);
     const unsigned long long canon = kw < rc ? kw : rc;
     uint32_t s = xt_over_hash(canon) & over_mask;
     for (;;) {
@@ -154,18 +155,18 @@ hipError_t launch_ctable_build(const XTableView& t, const unsigned long long* ok
 {
     hipLaunchKernelGGL(ct_clear_kernel, dim3(4096), dim3(256), 0, st, const_cast<uint4*>(t.cb), (uint64_t)t.n_buckets + CT_HOPS);
     if (n) {
-        const uint64_t m = n * 12;
+        const uint64_t m = n * (t.k - 15u);
         hipLaunchKernelGGL(ct_insert_kernel, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, st, t, okmer, n, over_list, over_cap, over_n, n_moved);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_ctable_over(ulonglong2* over, uint32_t over_mask, const unsigned long long* okmer, const uint32_t* over_list, uint64_t n_over,
-                              hipStream_t st)
+                              uint32_t k, hipStream_t st)
 {
     hipLaunchKernelGGL(ct_over_clear_kernel, dim3((over_mask + 256) / 256), dim3(256), 0, st, over, over_mask);
     if (n_over)
-        hipLaunchKernelGGL(ct_over_kernel, dim3((uint32_t)((n_over + 255) / 256)), dim3(256), 0, st, over, over_mask, okmer, over_list, n_over);
+        hipLaunchKernelGGL(ct_over_kernel, dim3((uint32_t)((n_over + 255) / 256)), dim3(256), 0, st, over, over_mask, okmer, over_list, n_over, k);
     return hipGetLastError();
 }
 
@@ -176,8 +177,16 @@ hipError_t launch_ctable_over(ulonglong2* over, uint32_t over_mask, const unsign
 // windows still open, hop, next bucket} instead, and the wavefront looks 64 queued items up at a time, all lanes busy, one round
 // trip per batch; an item that meets another marked bucket is queued again, one that has seen CT_HOPS + 1 of them asks the exact
 // overflow table.
-__global__ __launch_bounds__(256, 8) void count27c_kernel(RowParams p, XTableView xt)
+//
+// K = 19 .. 25 (round 5): the same rows, the same twelve bytes per lane, the same queues; a lane looks a 16-mer up every G = 6 (K = 19: 4)
+// of its bases instead of once -- the 16 bases that end G j bases into the lane's stretch, j = 0 .. 12 / G - 1 -- and asks each for the G
+// windows of K bases that end in the G bases behind it.  Flanks of F = K - 16 bases; the bases behind a later X that belong to the next
+// lane are zeros (no window asked for reaches them).  The ends covered are those of K = 27: stream positions 12 L - 1 .. 12 L + 10.
+template <uint32_t K>
+__device__ __forceinline__ void countc_body(const RowParams& p, const XTableView& xt)
 {
+    constexpr uint32_t F = K - 16u, G = K == 27u ? 12u : (K == 19u ? 4u : 6u), NP = 12u / G, MF = (1u << (2u * F)) - 1u;
+    static_assert(K == 27u || K == 25u || K == 23u || K == 21u || K == 19u, "context table: k = 19 .. 27, odd");
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[2048];     // position LUT of count27_kernel (stage_lut27 layout)
     __shared__ __attribute__((aligned(16))) uint2 s_runs[4][CT_RUNQ];
     __shared__ __attribute__((aligned(16))) uint4 s_pend[4][CT_PENDQ];
@@ -252,8 +261,8 @@ __global__ __launch_bounds__(256, 8) void count27c_kernel(RowParams p, XTableVie
         if (q1) c1 = CtEntry{xs.y, Bk[7], Bk[8], Bk[9]};
         if (q2) c2 = CtEntry{xs.z, Bk[10], Bk[11], Bk[12]};
         if (q3) c3 = CtEntry{xs.w, Bk[13], Bk[14], Bk[15]};
-        const uint32_t h0 = ct_match(c0, cx, cl, cr) & vs, h1 = ct_match(c1, cx, cl, cr) & vs;
-        const uint32_t h2 = ct_match(c2, cx, cl, cr) & vs, h3 = ct_match(c3, cx, cl, cr) & vs;
+        const uint32_t h0 = ct_match(c0, cx, cl, cr, F) & vs, h1 = ct_match(c1, cx, cl, cr, F) & vs;
+        const uint32_t h2 = ct_match(c2, cx, cl, cr, F) & vs, h3 = ct_match(c3, cx, cl, cr, F) & vs;
         const uint64_t m0 = __ballot(h0 != 0), m1 = __ballot(h1 != 0), m2 = __ballot(h2 != 0), m3 = __ballot(h3 != 0);
         const uint32_t n = (uint32_t)(__builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) + __builtin_popcountll(m3));
         if (n) {
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(256, 8) void count27c_kernel(RowParams p, XTableVie
             while (rest) {
                 const uint32_t s = (uint32_t)__builtin_ctz(rest);
                 rest &= rest - 1u;
-                const uint32_t id = xt_over_find(xt, ct_window_kmer(cx, cl, cr, s));
+                const uint32_t id = xt_over_find(xt, ct_window_kmer(cx, cl, cr, s, K));
                 if (id != CT_NONE) __hip_atomic_fetch_add(xt.counts + id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -356,23 +365,51 @@ __global__ __launch_bounds__(256, 8) void count27c_kernel(RowParams p, XTableVie
         // 48-base window (see count27_kernel::scan_probe): base e from the end of the own chunk at bits [2e, 2e + 2) of W2:W1:W0
         // -- 0..11 own chunk, 12..27 the grid 16-mer X, 28..38 the 11 bases in front of it
         const uint32_t W0 = (be1 << 24) | be, W1 = (be2 << 16) | (be1 >> 8), W2 = (be3 << 8) | (be2 >> 16);
-        const uint32_t B = (i3 >> 9) | (i2 << 3) | (i1 << 15);
-        const uint32_t a = (inv << 1) & 0xFFFu;
-        const uint32_t bad_b = B ? (0xFFFFFFFFu >> __builtin_clz(B)) : 0u;
-        const uint32_t vm = ~(a | (0u - a) | bad_b) & 0xFFFu;       // bit w: the window that ends w bases behind X is made of bases
-        const bool act = B < 2048u && vm != 0;                       // X itself is 16 bases
-        uint32_t cx, cl, cr, vs;
-        ct_orient(__builtin_amdgcn_alignbit(W1, W0, 24), __builtin_amdgcn_alignbit(W2, W1, 24) & CT_M22, (W0 >> 2) & CT_M22, vm, cx, cl, cr, vs);
-        const uint32_t b0 = (uint32_t)(((uint64_t)ct_hash(cx) * xt.n_buckets) >> 32);
-        uint32_t found;
-        bool marked;
-        look(act, b0, cx, cl, cr, vs, true, found, marked);
-        push(marked && (vs & ~found) != 0 && !(VG_DBG(p.dbg) & 8u), cx, cl, cr, vs & ~found, 1u, b0 + 1u);
-        while (pend_n >= 64u) pending_batch();
+        if constexpr (K == 27u) {
+            const uint32_t B = (i3 >> 9) | (i2 << 3) | (i1 << 15);
+            const uint32_t a = (inv << 1) & 0xFFFu;
+            const uint32_t bad_b = B ? (0xFFFFFFFFu >> __builtin_clz(B)) : 0u;
+            const uint32_t vm = ~(a | (0u - a) | bad_b) & 0xFFFu;       // bit w: the window that ends w bases behind X is made of bases
+            const bool act = B < 2048u && vm != 0;                       // X itself is 16 bases
+            uint32_t cx, cl, cr, vs;
+            ct_orient(__builtin_amdgcn_alignbit(W1, W0, 24), __builtin_amdgcn_alignbit(W2, W1, 24) & CT_M22, (W0 >> 2) & CT_M22, vm, cx, cl, cr, vs);
+            const uint32_t b0 = (uint32_t)(((uint64_t)ct_hash(cx) * xt.n_buckets) >> 32);
+            uint32_t found;
+            bool marked;
+            look(act, b0, cx, cl, cr, vs, true, found, marked);
+            push(marked && (vs & ~found) != 0 && !(VG_DBG(p.dbg) & 8u), cx, cl, cr, vs & ~found, 1u, b0 + 1u);
+            while (pend_n >= 64u) pending_batch();
+        } else {
+            // the non-base flags of the 48 bases, oldest first (bit u = 47 - e): the window that ends w bases behind the X of sub-position
+            // j spans bits  36 + G j + w - K  ..  35 + G j + w
+            const uint64_t U = (uint64_t)(i3 | i2 << 12 | (i1 & 0xFFu) << 24) | (uint64_t)((i1 >> 8) | inv << 4) << 32;
+#pragma unroll
+            for (uint32_t j = 0; j < NP; ++j) {
+                const uint32_t d = G * j, sh = 24u - 2u * d;
+                const uint32_t Uj = (uint32_t)(U >> (36u + d - K));
+                const uint32_t A = Uj & ((1u << K) - 1u), a = ((Uj >> K) & ((1u << (G - 1u)) - 1u)) << 1;
+                const uint32_t bad_b = A ? (0xFFFFFFFFu >> __builtin_clz(A)) : 0u;
+                const uint32_t vm = ~(a | (0u - a) | bad_b) & ((1u << G) - 1u);
+                const uint32_t xr = __builtin_amdgcn_alignbit(W1, W0, sh), lr = __builtin_amdgcn_alignbit(W2, W1, sh) & MF;
+                const uint32_t rr = (sh >= 2u * F ? W0 >> (sh >= 2u * F ? sh - 2u * F : 0u) : W0 << (sh < 2u * F ? 2u * F - sh : 0u)) & MF;
+                uint32_t cx, cl, cr, vs;
+                ct_orient(xr, lr, rr, vm, cx, cl, cr, vs, F);
+                const uint32_t b0 = (uint32_t)(((uint64_t)ct_hash(cx) * xt.n_buckets) >> 32);
+                uint32_t found;
+                bool marked;
+                look(vm != 0, b0, cx, cl, cr, vs, true, found, marked);
+                push(marked && (vs & ~found) != 0 && !(VG_DBG(p.dbg) & 8u), cx, cl, cr, vs & ~found, 1u, b0 + 1u);
+                while (pend_n >= 64u) pending_batch();
+            }
+        }
     }
     while (pend_n) pending_batch();
     while (run_n) drain();
 }
+
+__global__ __launch_bounds__(256, 8) void count27c_kernel(RowParams p, XTableView xt) { countc_body<27u>(p, xt); }
+template <uint32_t K>
+__global__ __launch_bounds__(256, 8) void countkc_kernel(RowParams p, XTableView xt) { countc_body<K>(p, xt); }
 
 hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t n_cu, hipStream_t st)
 {
@@ -381,7 +418,14 @@ hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t n_c
         const int v = e ? atoi(e) : 6;      // measured, chr20 class kernel ms: 5 8.96, 6 8.31, 7 8.50, 8 8.62 (gpurun_out/r4d)
         return (uint32_t)(v < 1 ? 1 : v > 8 ? 8 : v);
     }();
-    hipLaunchKernelGGL(count27c_kernel, dim3(n_cu * wgs), dim3(256), 0, st, p, t);
+    switch (t.k) {
+        case 27: hipLaunchKernelGGL(count27c_kernel, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
+        case 25: hipLaunchKernelGGL(countkc_kernel<25u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
+        case 23: hipLaunchKernelGGL(countkc_kernel<23u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
+        case 21: hipLaunchKernelGGL(countkc_kernel<21u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
+        case 19: hipLaunchKernelGGL(countkc_kernel<19u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -37,6 +37,7 @@ struct XTableView {
     // path-ordered ids and the exact overflow table are shared by both forms
     const uint4* cb;             // 4 * (n_buckets + CT_HOPS) entries of 16 bytes, or nullptr: not in use
     uint32_t n_buckets;          // home buckets of 64 bytes, any number: bucket = (ct_hash(X) * n_buckets) >> 32
+    uint32_t k;                  // 27, or 19 .. 25 (context table only; round 5): flanks of k - 16 bases
 };
 
 // path table of small graphs (vgmi_ptable.hip, build_ptable in vgmi_api.cpp): what count27s_kernel<true> checks candidate runs against
@@ -264,7 +265,7 @@ hipError_t launch_ctable_okmer(const TableView& t, const uint32_t* key_slot, uin
 hipError_t launch_ctable_build(const XTableView& t, const unsigned long long* okmer, uint64_t n_places, uint32_t* over_list, uint32_t over_cap,
                                unsigned long long* over_n, unsigned long long* n_moved, hipStream_t st);
 hipError_t launch_ctable_over(ulonglong2* over, uint32_t over_mask, const unsigned long long* okmer, const uint32_t* over_list, uint64_t n_over,
-                              hipStream_t st);
+                              uint32_t k, hipStream_t st);
 hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t n_cu, hipStream_t st);
 hipError_t launch_xclamp(const XTableView& t, uint64_t n, hipStream_t st);
 hipError_t launch_xcov(const XTableView& t, const uint32_t* id_of_key, uint64_t n, const uint8_t* flag, uint8_t* cov, unsigned long long* hist,

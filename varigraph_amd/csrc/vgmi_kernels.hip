@@ -1875,51 +1875,107 @@ __device__ __forceinline__ uint32_t debit_odd_bytes(uint32_t w)      // non-zero
     return __builtin_amdgcn_perm(0x00000A00u, 0x47544341u, (w >> 1) & 0x07070707u) ^ w;
 }
 
-// (inlined: as a call it takes RowParams by address, and the kernel then keeps its 464 bytes of arguments in scratch, written by every lane
-// of the scan -- 8 ms per 2e7 reads instead of the text's 0.5)
-__device__ __forceinline__ void debit_behind_non_base(const RowParams& p, const uint64_t* __restrict__ read_off, uint64_t n_reads, uint64_t i,
-                                                      uint64_t limit)
+// What happens behind the non-base at byte i (rare in a wavefront's 4 KiB, not in a workgroup's 16 KiB: reads carry an N per ten
+// thousand bases, one read in seventy has one).  Nothing here may wait for one load after another -- found by a binary search over the
+// offsets and walked byte by byte, a non-base cost ~80 dependent round trips and the pass 6 ms per 2e7 reads, as much as the state
+// machine over every read's head had: the 32 bytes on either side come as four 16-byte loads in flight together (byte-aligned
+// addresses: the memory path takes them), are turned into 2-bit codes and flag words, and are walked in registers.  A read's '\n' on
+// either side ends the walk, so the read's offsets are not needed; only what lies further than 32 bytes away (more than eight older
+// non-bases among the k bases in front, more than eight palindromes behind) or next to the text's ends is read byte by byte.
+// (Inlined, once: as a call it takes RowParams by address, and the kernel then keeps its 464 bytes of arguments in scratch, written by
+// every lane of the scan.)
+typedef uint32_t vg_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void debit_codes16(const vg_u32x4 v, uint32_t t0, bool backward, uint64_t& code, uint32_t& bad, uint32_t& nl)
+{
+#pragma unroll 1
+    for (uint32_t q = 0; q < 4; ++q) {      // (rolled, the word picked by selects: this runs once per non-base, the registers it would take unrolled
+                                            // are the occupancy of the scan)
+        uint32_t w = q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
+#pragma unroll 1
+        for (uint32_t j = 4 * q; j < 4 * q + 4; ++j, w >>= 8) {
+            const uint32_t b = w & 0xFFu, c = vg_nt4(b), t = t0 + (backward ? 15 - j : j);
+            code |= (uint64_t)(c & 3u) << (2 * t);
+            bad |= (c >> 2) << t;
+            nl |= (uint32_t)(b == '\n') << t;
+        }
+    }
+}
+
+__device__ __forceinline__ void debit_behind_non_base(const RowParams& p, uint64_t i, uint64_t lo, uint64_t hi)
 {
     const uint8_t* const bases = p.bases;
-    if (i + 1 >= limit || vg_nt4(bases[i + 1]) >= 4) return;      // nothing behind it that could be counted
-    if (n_reads == 0 || read_off[0] > i) return;
-    uint64_t lo = 0, hi = n_reads;                                // the last read that starts at or before i
-    while (hi - lo > 1) {
-        const uint64_t mid = lo + (hi - lo) / 2;
-        if (read_off[mid] <= i) lo = mid;
-        else hi = mid;
-    }
-    const uint64_t s = read_off[lo];
-    uint64_t e = read_off[lo + 1] - 1;                            // the read's '\n'
-    if (i >= e) return;
-    if (e > limit) e = limit;
     const uint32_t K = p.k;
     const uint64_t mask = (1ULL << (2 * K)) - 1, shift1 = 2 * (uint64_t)(K - 1);
-    uint64_t q = i;
-    for (uint32_t got = 0; q > s && got < K;) {
-        --q;
-        if (vg_nt4(bases[q]) < 4) ++got;
-    }
     uint64_t fwd = 0, rc = 0;
-    for (; q < i; ++q) {
-        const uint32_t c = vg_nt4(bases[q]);
-        if (c >= 4) continue;
-        fwd = (fwd << 2 | c) & mask;
-        rc = (rc >> 2) | (uint64_t)(3u ^ c) << shift1;
-    }
-    uint32_t l = 0, run = 0;
-    for (uint64_t x = i + 1; x < e; ++x) {
-        const uint32_t c = vg_nt4(bases[x]);
-        if (c >= 4) return;
+    uint32_t l = 0, run = 0, idx = 0;
+    auto older = [&](uint32_t c) -> bool {      // a base in front of i, nearest first; false: the registers are full
+        fwd |= (uint64_t)c << (2 * idx);
+        rc |= (uint64_t)(3u ^ c) << (2 * (K - 1 - idx));
+        return ++idx < K;
+    };
+    auto step = [&](uint32_t c) -> bool {       // a base behind i; false: l has reached k
         fwd = (fwd << 2 | c) & mask;
         rc = (rc >> 2) | (uint64_t)(3u ^ c) << shift1;
         if (run < K) ++run;
-        if (fwd == rc) continue;
-        if (++l >= K) return;
+        if (fwd == rc) return true;
+        if (++l >= K) return false;
         if (run >= K) {      // the fast kernel counts this window, the reference does not
             const uint64_t canon = fwd < rc ? fwd : rc;
             if (filter_test_global(p.table, canon)) table_debit(p.table, canon);
         }
+        return true;
+    };
+    uint64_t back_from = i, on_from = i + 1;      // where the byte-by-byte walks take over
+    bool more = true;
+    if (i >= 32 && i + 33 <= p.n_bytes) {
+        vg_u32x4 f0, f1, b0, b1;
+        __builtin_memcpy(&f0, bases + i + 1, 16);
+        __builtin_memcpy(&f1, bases + i + 17, 16);
+        __builtin_memcpy(&b0, bases + i - 16, 16);
+        __builtin_memcpy(&b1, bases + i - 32, 16);
+        uint64_t fcode = 0, bcode = 0;
+        uint32_t fbad = 0, bbad = 0, fnl = 0, bnl = 0;      // bit t: the byte t + 1 behind / in front of i is no base; ... is a '\n'
+        debit_codes16(f0, 0, false, fcode, fbad, fnl);
+        debit_codes16(f1, 16, false, fcode, fbad, fnl);
+        debit_codes16(b0, 0, true, bcode, bbad, bnl);
+        debit_codes16(b1, 16, true, bcode, bbad, bnl);
+        // bytes outside the text of the reads end the walks like a read's end does
+        const uint64_t nf = hi - i - 1, nb = i - lo;
+        if (nf < 32) fbad |= ~0u << nf;
+        if (nb < 32) bnl |= ~0u << nb;
+        if (fbad & 1u) return;      // a non-base or the read's end next: nothing behind it that could be counted
+        // the registers as the reference has them here: the last k bases of the read in front of i (fewer: zeros in front of them)
+        for (uint32_t t = 0; t < 32 && more; ++t) {
+            if ((bnl >> t) & 1u) more = false;
+            else if (!((bbad >> t) & 1u)) more = older((uint32_t)(bcode >> (2 * t)) & 3u);
+        }
+        back_from = i - 32;
+        if (more) {
+            for (uint64_t q = back_from; q > lo;) {
+                --q;
+                const uint32_t b = bases[q], c = vg_nt4(b);
+                if (b == '\n') break;
+                if (c < 4 && !older(c)) break;
+            }
+        }
+        for (uint32_t t = 0; t < 32; ++t) {
+            if ((fbad >> t) & 1u) return;
+            if (!step((uint32_t)(fcode >> (2 * t)) & 3u)) return;
+        }
+        on_from = i + 33;
+    } else {
+        if (i + 1 >= hi || vg_nt4(bases[i + 1]) >= 4) return;
+        for (uint64_t q = back_from; q > lo;) {
+            --q;
+            const uint32_t b = bases[q], c = vg_nt4(b);
+            if (b == '\n') break;
+            if (c < 4 && !older(c)) break;
+        }
+    }
+    for (uint64_t x = on_from; x < hi; ++x) {
+        const uint32_t c = vg_nt4(bases[x]);
+        if (c >= 4 || !step(c)) return;
     }
 }
 
@@ -1927,30 +1983,39 @@ constexpr uint32_t VG_DEBIT_PIECES = 4;      // 16-byte pieces per lane: a workg
 
 __global__ __launch_bounds__(256) void even_debit_kernel(RowParams p, const uint64_t* __restrict__ read_off, uint64_t n_reads)
 {
-    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
     const uint64_t limit = p.emit_from < p.n_bytes ? p.emit_from : p.n_bytes;
     const uint64_t base = (uint64_t)blockIdx.x * (256u * 16u * VG_DEBIT_PIECES) + threadIdx.x * 16u;
-    u32x4_t v[VG_DEBIT_PIECES];
+    vg_u32x4 v[VG_DEBIT_PIECES];
 #pragma unroll
     for (uint32_t t = 0; t < VG_DEBIT_PIECES; ++t) {
         const uint64_t a = base + (uint64_t)t * 4096u;
-        if (a + 16 <= p.n_bytes) v[t] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p.bases + a));
+        if (a + 16 <= p.n_bytes) v[t] = __builtin_nontemporal_load(reinterpret_cast<const vg_u32x4*>(p.bases + a));
         else {
             const uint4 c = a < limit ? load_chunk(p.bases, p.n_bytes, a) : make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
-            v[t] = u32x4_t{c.x, c.y, c.z, c.w};
+            v[t] = vg_u32x4{c.x, c.y, c.z, c.w};
         }
     }
+    uint32_t any = 0;
 #pragma unroll
-    for (uint32_t t = 0; t < VG_DEBIT_PIECES; ++t) {
-        const uint32_t odd = debit_odd_bytes(v[t].x) | debit_odd_bytes(v[t].y) | debit_odd_bytes(v[t].z) | debit_odd_bytes(v[t].w);
-        if (odd == 0) continue;
-        const uint64_t a = base + (uint64_t)t * 4096u;
-        const uint32_t w[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
-        for (uint32_t j = 0; j < 16; ++j) {
-            const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            if (a + j >= limit) break;
-            if (b == '\n' || vg_nt4(b) < 4) continue;
-            debit_behind_non_base(p, read_off, n_reads, a + j, limit);
+    for (uint32_t t = 0; t < VG_DEBIT_PIECES; ++t)
+        any |= debit_odd_bytes(v[t].x) | debit_odd_bytes(v[t].y) | debit_odd_bytes(v[t].z) | debit_odd_bytes(v[t].w);
+    if (any == 0 || n_reads == 0) return;
+    // the text of the reads: [lo, hi); positions at or behind emit_from are the tail launch's
+    const uint64_t lo = read_off[0], hi = read_off[n_reads] < limit ? read_off[n_reads] : limit;
+    static_assert(VG_DEBIT_PIECES == 4, "the selects below");
+#pragma unroll 1
+    for (uint32_t tq = 0; tq < 4 * VG_DEBIT_PIECES; ++tq) {      // (rolled: ONE copy of the walk in the kernel; the words picked by selects, not by address)
+        const uint32_t t = tq >> 2, q = tq & 3u;
+        const vg_u32x4 vt = t == 0 ? v[0] : t == 1 ? v[1] : t == 2 ? v[2] : v[3];
+        const uint32_t w = q == 0 ? vt.x : q == 1 ? vt.y : q == 2 ? vt.z : vt.w;
+        uint32_t m = debit_odd_bytes(w);
+        while (m) {
+            const uint32_t j = (uint32_t)__builtin_ctz(m) >> 3;
+            m &= ~(0xFFu << (8 * j));
+            const uint64_t i = base + (uint64_t)t * 4096u + 4 * q + j;
+            const uint32_t b = (w >> (8 * j)) & 0xFFu;
+            if (i < lo || i >= hi || vg_nt4(b) < 4) continue;      // (lower case and 'U' are bases)
+            debit_behind_non_base(p, i, lo, hi);
         }
     }
 }
