@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -117,6 +118,7 @@ struct vgmi_ctx {
     uint8_t* d_cov_node = nullptr;
     unsigned long long* d_hist = nullptr;
     uint32_t* d_status = nullptr;
+    std::map<hipStream_t, unsigned long long*> debit_lists;      // even k on the fast path: per stream that counts, VG_DEBIT_LIST positions + a counter
 
     // per-sample state
     std::mutex mu;                 // event list / counters below when several FASTQ streams submit from their own threads
@@ -1005,7 +1007,18 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
             // ends the rows do not cover
             p.row_end = (n_bytes / 2048) * 2;
             p.emit_from = p.row_end * 1024;
-            HIPCHK(c, launch_seq(K_MODE_DEBIT, p, d_read_off, n_reads, st));
+            unsigned long long* list = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(c->mu);
+                auto it = c->debit_lists.find(st);
+                if (it != c->debit_lists.end()) list = it->second;
+            }
+            if (!list) {
+                HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&list), (size_t)VG_DEBIT_LIST * 8 + 256));
+                std::lock_guard<std::mutex> lk(c->mu);
+                c->debit_lists[st] = list;
+            }
+            HIPCHK(c, launch_even_debit(p, d_read_off, n_reads, list, VG_DEBIT_LIST, st));
             HIPCHK(c, launch_count27s(p, (uint32_t)c->n_cu, st));
             if (p.emit_from < n_bytes) HIPCHK(c, launch_seq(K_MODE_COUNT, p, d_read_off, n_reads, st));
         } else {
@@ -1147,6 +1160,7 @@ void vgmi_destroy(vgmi_ctx* c)
     c->bb_scratch = nullptr;
     c->bb_cap = 0;
     if (c->d_status) (void)hipFree(c->d_status);
+    for (auto& kv : c->debit_lists) (void)hipFree(kv.second);
     if (c->d_hist) (void)hipFree(c->d_hist);
     if (c->reset_done) (void)hipEventDestroy(c->reset_done);
     for (auto& b : c->hmm_blocks) (void)hipFree(b.first);

@@ -1981,7 +1981,11 @@ __device__ __forceinline__ void debit_behind_non_base(const RowParams& p, uint64
 
 constexpr uint32_t VG_DEBIT_PIECES = 4;      // 16-byte pieces per lane: a workgroup scans 16 KiB
 
-__global__ __launch_bounds__(256) void even_debit_kernel(RowParams p, const uint64_t* __restrict__ read_off, uint64_t n_reads)
+// (the list: a non-base with a base behind it is work for ONE lane -- 10-20 us of it, four loads and a hundred steps -- and a workgroup of
+// the scan meets 1.6 of them in its 16 KiB: walked where they are found, the scan ran at 0.6 TB/s, every workgroup waiting for a lane.
+// The scan only writes their positions down, a second launch walks them a lane each; what does not fit the list is walked on the spot.)
+__global__ __launch_bounds__(256) void even_debit_kernel(RowParams p, const uint64_t* __restrict__ read_off, uint64_t n_reads,
+                                                         unsigned long long* __restrict__ list, uint32_t list_cap, unsigned int* list_n)
 {
     const uint64_t limit = p.emit_from < p.n_bytes ? p.emit_from : p.n_bytes;
     const uint64_t base = (uint64_t)blockIdx.x * (256u * 16u * VG_DEBIT_PIECES) + threadIdx.x * 16u;
@@ -2014,10 +2018,23 @@ __global__ __launch_bounds__(256) void even_debit_kernel(RowParams p, const uint
             m &= ~(0xFFu << (8 * j));
             const uint64_t i = base + (uint64_t)t * 4096u + 4 * q + j;
             const uint32_t b = (w >> (8 * j)) & 0xFFu;
-            if (i < lo || i >= hi || vg_nt4(b) < 4) continue;      // (lower case and 'U' are bases)
-            debit_behind_non_base(p, i, lo, hi);
+            if (i < lo || i + 1 >= hi || vg_nt4(b) < 4) continue;      // (lower case and 'U' are bases)
+            const uint32_t at = atomicAdd(list_n, 1u);
+            if (at < list_cap) list[at] = i;
+            else debit_behind_non_base(p, i, lo, hi);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void even_debit_walk_kernel(RowParams p, const uint64_t* __restrict__ read_off, uint64_t n_reads,
+                                                              const unsigned long long* __restrict__ list, uint32_t list_cap,
+                                                              const unsigned int* __restrict__ list_n)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, n = *list_n < list_cap ? *list_n : list_cap;
+    if (g >= n || n_reads == 0) return;
+    const uint64_t limit = p.emit_from < p.n_bytes ? p.emit_from : p.n_bytes;
+    const uint64_t lo = read_off[0], hi = read_off[n_reads] < limit ? read_off[n_reads] : limit;
+    debit_behind_non_base(p, list[g], lo, hi);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2405,12 +2422,21 @@ hipError_t launch_seq(int mode, const RowParams& p, const uint64_t* read_off, ui
     if (grid == 0) return hipSuccess;
     if (mode == MODE_COUNT) hipLaunchKernelGGL((seq_kernel<MODE_COUNT>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
     else if (mode == MODE_KEYS) hipLaunchKernelGGL((seq_kernel<MODE_KEYS>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
-    else if (mode == MODE_DEBIT) {
-        const uint64_t limit = p.emit_from < p.n_bytes ? p.emit_from : p.n_bytes, per_wg = 256u * 16u * VG_DEBIT_PIECES;
-        if (limit == 0) return hipSuccess;
-        hipLaunchKernelGGL(even_debit_kernel, dim3((uint32_t)((limit + per_wg - 1) / per_wg)), dim3(block), 0, st, p, read_off, n_reads);
-    }
+    else if (mode == MODE_DEBIT) return hipErrorInvalidValue;      // launch_even_debit
     else hipLaunchKernelGGL((seq_kernel<MODE_BLOOM>), dim3(grid), dim3(block), 0, st, p, read_off, n_reads);
+    return hipGetLastError();
+}
+
+// list: list_cap positions and, behind them, the counter (one allocation per stream that counts even k: vgmi_api.cpp)
+hipError_t launch_even_debit(const RowParams& p, const uint64_t* read_off, uint64_t n_reads, unsigned long long* list, uint32_t list_cap, hipStream_t st)
+{
+    const uint64_t limit = p.emit_from < p.n_bytes ? p.emit_from : p.n_bytes, per_wg = 256u * 16u * VG_DEBIT_PIECES;
+    if (limit == 0 || n_reads == 0) return hipSuccess;
+    unsigned int* const list_n = reinterpret_cast<unsigned int*>(list + list_cap);
+    hipError_t e = hipMemsetAsync(list_n, 0, 4, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(even_debit_kernel, dim3((uint32_t)((limit + per_wg - 1) / per_wg)), dim3(256), 0, st, p, read_off, n_reads, list, list_cap, list_n);
+    hipLaunchKernelGGL(even_debit_walk_kernel, dim3((list_cap + 255) / 256), dim3(256), 0, st, p, read_off, n_reads, list, list_cap, list_n);
     return hipGetLastError();
 }
 
