@@ -1014,7 +1014,7 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
                 if (it != c->debit_lists.end()) list = it->second;
             }
             if (!list) {
-                HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&list), (size_t)VG_DEBIT_LIST * 8 + 256));
+                HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&list), (size_t)VG_DEBIT_LIST * 8 + (size_t)VG_DEBIT_SUBLISTS * 64));
                 std::lock_guard<std::mutex> lk(c->mu);
                 c->debit_lists[st] = list;
             }

@@ -280,7 +280,8 @@ hipError_t launch_ptable_fill(const TableView& t, const uint32_t* key_slot, cons
 hipError_t launch_rows(int mode, bool flds, const RowParams& p, uint32_t grid, uint32_t block, hipStream_t st);
 hipError_t launch_bloom_even(const RowParams& p, hipStream_t st);   // even k, one long sequence (K3)
 hipError_t launch_seq(int mode, const RowParams& p, const uint64_t* read_off, uint64_t n_reads, hipStream_t st);
-#define VG_DEBIT_LIST (1u << 19)      // positions of non-bases one launch can hand to its walk launch (4 MiB per stream; the rest is walked in the scan)
+#define VG_DEBIT_LIST (1u << 20)      // positions of non-bases one launch can hand to its walk launch (8 MiB per stream; the rest is walked in the scan)
+#define VG_DEBIT_SUBLISTS 256u       // ... in that many lists of equal size, one counter each (64 bytes apart, behind the positions)
 hipError_t launch_even_debit(const RowParams& p, const uint64_t* read_off, uint64_t n_reads, unsigned long long* list, uint32_t list_cap, hipStream_t st);
 hipError_t launch_table_clear(const TableView& t, hipStream_t st);
 hipError_t launch_table_insert(const TableView& t, const uint64_t* keys, uint64_t n, uint32_t k, uint32_t* key_slot,
