@@ -552,7 +552,7 @@ def test_saturation_flags_do_not_travel_with_the_table_image(ctx):
 
 
 # ----------------------------------------------------------------------------- large graphs (global grid bitmap)
-@pytest.mark.parametrize("k,placement", [(27, None), (25, None), (23, None), (21, None), (19, None), (25, {"VGMI_CTABLE_K": "0"}),
+@pytest.mark.parametrize("k,placement", [(27, None), (25, None), (23, None), (21, None), (19, None), (24, None), (22, None), (20, None), (25, {"VGMI_CTABLE_K": "0"}),
                                          (21, {"VGMI_CTABLE_LOAD": "90"}), (23, {"VGMI_CTABLE_LOAD": "10"}), (27, {"VGMI_XTABLE": "0"}), (27, {"VGMI_XTABLE": "0", "VGMI_LOCALITY": "0"}),
                                          (27, {"VGMI_XTABLE": "0", "VGMI_LOCALITY": "3"}),
                                          (27, {"VGMI_WIDE_SLOTS": "1"}), (27, {"VGMI_WIDE_SLOTS": "1", "VGMI_DENSE_COUNTS": "1"}),
@@ -561,7 +561,7 @@ def test_saturation_flags_do_not_travel_with_the_table_image(ctx):
                                          (27, {"VGMI_CTABLE": "0"}), (27, {"VGMI_CTABLE": "0", "VGMI_XTABLE_ORDER": "0"}),
                                          (27, {"VGMI_CTABLE": "0", "VGMI_XTABLE_LOAD": "60"}), (27, {"VGMI_CTABLE_LOAD": "90"}),
                                          (27, {"VGMI_CTABLE_LOAD": "10"})],
-                         ids=["k27", "k25", "k23", "k21", "k19", "k25-generic-kernel", "k21-context-table-crowded", "k23-context-table-sparse", "k27-minimiser-buckets", "k27-random-homes", "k27-buckets-of-8", "k27-16-byte-slots",
+                         ids=["k27", "k25", "k23", "k21", "k19", "k24", "k22", "k20", "k25-generic-kernel", "k21-context-table-crowded", "k23-context-table-sparse", "k27-minimiser-buckets", "k27-random-homes", "k27-buckets-of-8", "k27-16-byte-slots",
                               "k27-16-byte-slots-dense-counters", "k27-16-byte-slots-random-homes", "k27-slots-by-minimiser-offset",
                               "k27-grid-table", "k27-grid-table-ids-by-key-index", "k27-grid-table-crowded", "k27-context-table-crowded",
                               "k27-context-table-sparse"])
@@ -1189,8 +1189,9 @@ def test_small_graph_other_odd_k_low_complexity_and_saturation(k, monkeypatch):
         c.close()
 
 
-@pytest.mark.parametrize("k", [20, 22, 24])
-def test_small_graph_even_k_run_counter_lag_is_taken_back(k):
+@pytest.mark.parametrize("k,big", [(20, False), (22, False), (24, False), (20, True), (22, True), (24, True)],
+                         ids=["20", "22", "24", "20-context-table", "22-context-table", "24-context-table"])
+def test_small_graph_even_k_run_counter_lag_is_taken_back(k, big):
     """Even k on the fast path (round 5).  The reference does not advance its run counter on a window that is its own reverse
     complement (src/kmer.cpp:134, `continue` before `++l`), registers included that still hold bases from in front of a non-base or the
     zeros in front of the read (:145 resets l only): the windows with  run of bases >= k > l  are not emitted.  Reads built to meet
@@ -1205,9 +1206,12 @@ def test_small_graph_even_k_run_counter_lag_is_taken_back(k):
     def rnd(n):
         return acgt[rng.integers(0, 4, size=n)].tobytes()
 
+    pals = []
+
     def own_rc():
         h = rnd(k // 2)
-        return h + bytes(comp[b] for b in reversed(h))
+        pals.append(h + bytes(comp[b] for b in reversed(h)))
+        return pals[-1]
 
     genome = rnd(3000)
     specials = []
@@ -1224,7 +1228,19 @@ def test_small_graph_even_k_run_counter_lag_is_taken_back(k):
     keysets = [o.sketch(r, k) for r in specials] + [o.sketch(r[1:], k) for r in specials] + [o.sketch(b"G" + r, k) for r in specials] + [o.sketch(genome, k)]
     keys = np.unique(np.concatenate(keysets))
     keys = keys[keys != np.uint64(0xFFFFFFFFFFFFFFFF)]
+    # ... and the k-mers that are their own reverse complement as keys (a key set of another emitter may hold them; the reference never
+    # emits such a window, so their counters stay zero: no bit in the path table, no window bit in the context table)
+    from varigraph_amd import synth
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    pal_codes = np.array([sum(code[b] << (2 * (k - 1 - i)) for i, b in enumerate(q)) for q in pals[:60]], dtype=np.uint64)
+    keys = np.unique(np.concatenate([keys, (synth.hash64_np(pal_codes, k) << np.uint64(8)) | np.uint64(k)]))
     assert 1000 < keys.size <= 65536
+    if big:
+        # the same on a graph of more than 65 536 k-mers: countkc_kernel<K> over the context table behind the same pass (its debits go to
+        # the table's counters by id); the extra keys are the emitter's own for another random sequence
+        keys = np.unique(np.concatenate([keys, o.sketch(rnd(90_000), k)]))
+        keys = keys[keys != np.uint64(0xFFFFFFFFFFFFFFFF)]
+        assert keys.size > 80_000
     reads = (specials * 12 + plain)
     order = rng.permutation(len(reads))
     reads = [reads[i] for i in order]
@@ -1243,18 +1259,21 @@ def test_small_graph_even_k_run_counter_lag_is_taken_back(k):
         c.reads_submit_device(d, d.numel(), len(reads), d_off)
         cov, _, _ = c.counts_finish()
         assert np.array_equal(cov, want), (k, int((cov != want).sum()), np.flatnonzero(cov != want)[:5], cov[cov != want][:5], want[cov != want][:5])
-        # what the windows-of-bases rule alone would have counted is more: the pass in front of the kernel had work to do
+        assert (c.ctable_info()["n_buckets"] > 0) == big
+        # the literal kernel on the same keys (the A/B)
         import os
-        os.environ["VGMI_SMALLK"] = "0"
+        knob = "VGMI_CTABLE_K" if big else "VGMI_SMALLK"
+        os.environ[knob] = "0"
         try:
             g = vgmi.Context(0, buffer_mib=16)
             g.table_upload(keys, k)
+            assert g.ctable_info()["n_buckets"] == 0
             g.counts_reset()
             g.reads_submit_device(d, d.numel(), len(reads), d_off)
             cov_g, _, _ = g.counts_finish()
             g.close()
         finally:
-            os.environ.pop("VGMI_SMALLK")
+            os.environ.pop(knob)
         assert np.array_equal(cov_g, want)
         # deep: the same reads 30 times over -- counters pass the clamp with debits and increments of many launches in flight
         c.counts_reset()

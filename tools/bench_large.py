@@ -42,12 +42,13 @@ def main():
         n = min(chunk, n_reads - first)
         ctx.synth_reads_device(99, first, n, 150, d_cat, off, d_block[first * 151:])
     d_cov = torch.empty(len(keys), dtype=torch.uint8, device="cuda")
+    d_off = (torch.arange(n_reads + 1, dtype=torch.int64, device="cuda") * 151) if args.k % 2 == 0 else None      # even k: the reads' offsets
     res = []
     for _ in range(args.steps + 1):
         ctx.counts_reset()
         torch.cuda.synchronize()
         t = time.perf_counter()
-        ctx.reads_submit_device(d_block, n_reads * 151, n_reads)
+        ctx.reads_submit_device(d_block, n_reads * 151, n_reads, d_off)
         ctx.counts_finish_device(d_cov, None, None)
         dt = time.perf_counter() - t
         ms, _ = ctx.count_kernel_ms()
@@ -64,7 +65,7 @@ def main():
         import oracle_lib
         m = args.check
         ctx.counts_reset()
-        ctx.reads_submit_device(d_block, m * 151, m)
+        ctx.reads_submit_device(d_block, m * 151, m, d_off[: m + 1] if d_off is not None else None)
         c2, _, _ = ctx.counts_finish()
         t = oracle_lib.Table(keys)
         t.count_block(d_block[: m * 151].cpu().numpy(), args.k)

@@ -253,7 +253,7 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     // ... and graphs of k = 19 .. 25 too large for that: the context table is built from the compact image (xtable_wanted)
     const bool off_k = (getenv("VGMI_CTABLE_K") && getenv("VGMI_CTABLE_K")[0] == '0') || (getenv("VGMI_CTABLE") && getenv("VGMI_CTABLE")[0] == '0') ||
                        (getenv("VGMI_XTABLE") && getenv("VGMI_XTABLE")[0] == '0');
-    const bool largek = (k == 19 || k == 21 || k == 23 || k == 25) && n_keys > VG_GRID_LDS_MAX_KEYS && n_keys < (1ULL << 31) - 16 && !off_k;
+    const bool largek = k >= 19 && k <= 25 && n_keys > VG_GRID_LDS_MAX_KEYS && n_keys < (1ULL << 31) - 16 && !off_k;
     const bool compact = (k == 27 || smallk || largek) && !getenv("VGMI_WIDE_SLOTS");   // 8-byte k-mer words + per-slot counters
     h.slot_bytes = compact ? 8 : 16;
     uint64_t cap = 64;
@@ -371,7 +371,7 @@ bool xtable_wanted(const ImageHeader& h)
     const char* e = getenv("VGMI_XTABLE");
     if ((e && e[0] == '0') || h.slot_bytes != 8 || h.n_keys <= VG_GRID_LDS_MAX_KEYS) return false;
     // k = 19 .. 25, odd (round 5): the context table only (flanks of k - 16 bases, vgmi_ctable.h); VGMI_CTABLE_K=0 keeps them on the generic kernel (A/B)
-    if (h.k == 19 || h.k == 21 || h.k == 23 || h.k == 25) {
+    if (h.k >= 19 && h.k <= 25) {      // (even k too: the pass that takes back what the reference's run counter suppresses runs ahead of the kernel)
         const char* o = getenv("VGMI_CTABLE_K");
         return !(o && o[0] == '0') && ctable_wanted(h);
     }
@@ -1001,7 +1001,28 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
         }
     } else {
         if (!d_read_off) return fail(c, VGMI_E_INVALID, "even k needs read offsets");
-        if (c->fastk_small && c->tv.pt.index && !c->force_generic && n_bytes >= 2048) {
+        if (c->tv.xt.cb && !c->force_generic && n_bytes >= 768) {
+            // k = 20 .. 24 on a large graph: complete 768-byte rows through countkc_kernel<K> over the context table, the debit pass ahead of it,
+            // the literal state machine for the ends behind the rows (its lookups go through the same table: table_count)
+            const uint64_t rows = n_bytes / 768;
+            p.emit_from = rows * 768 - 1;
+            int rcx = xt_clamp_if_due(c, n_bytes, st);
+            if (rcx) return rcx;
+            unsigned long long* list = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(c->mu);
+                auto it = c->debit_lists.find(st);
+                if (it != c->debit_lists.end()) list = it->second;
+            }
+            if (!list) {
+                HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&list), (size_t)VG_DEBIT_LIST * 8 + (size_t)VG_DEBIT_SUBLISTS * 64));
+                std::lock_guard<std::mutex> lk(c->mu);
+                c->debit_lists[st] = list;
+            }
+            HIPCHK(c, launch_even_debit(p, d_read_off, n_reads, list, VG_DEBIT_LIST, st));
+            HIPCHK(c, launch_count27c(p, c->tv.xt, (uint32_t)c->n_cu, st));
+            HIPCHK(c, launch_seq(K_MODE_COUNT, p, d_read_off, n_reads, st));
+        } else if (c->fastk_small && c->tv.pt.index && !c->force_generic && n_bytes >= 2048) {
             // k = 20 .. 24 on a small graph: the windows of k bases through count27s_kernel<true, K> (complete pairs of rows), in front of
             // it the pass that takes back what the reference's run counter suppresses, behind it the literal state machine for the
             // ends the rows do not cover

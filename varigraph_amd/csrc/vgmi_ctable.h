@@ -159,14 +159,16 @@ VG_HD int ct_make(uint32_t xu, uint32_t lu, uint32_t ru, uint32_t mask, uint32_t
 
 // The occurrence led by the k-mer at unitig position u (kf, as walked) with X starting o bases into it (0..f): the k-mers
 // u .. u + n_win - 1 hold it (n_win = min(o, k-mers behind kf in the unitig) + 1; kl = the last of them, id p of kf).
-VG_HD int ct_make_from_unitig(uint64_t kf, uint64_t kl, uint32_t o, uint32_t n_win, uint32_t p, CtEntry out[2], uint32_t k = 27u)
+// keep: window bits that may be set (even k: not those of k-mers that are their own reverse complement, which the reference never emits)
+VG_HD int ct_make_from_unitig(uint64_t kf, uint64_t kl, uint32_t o, uint32_t n_win, uint32_t p, CtEntry out[2], uint32_t k = 27u, uint32_t keep = 0xFFFu)
 {
     const uint32_t f = k - 16u;
     const uint32_t xu = (uint32_t)(kf >> (2u * (f - o)));
     const uint32_t lu = o ? (uint32_t)(kf >> (2u * (k - o))) : 0u;                  // the o bases in front of X
     const uint32_t n_r = n_win + f - 1u - o;                                        // bases behind X the last k-mer reaches: 0..f
     const uint32_t ru = n_r ? ((uint32_t)kl & ((1u << (2u * n_r)) - 1u)) << (2u * (f - n_r)) : 0u;
-    const uint32_t mask = ((1u << n_win) - 1u) << (o + 1u - n_win);                 // s = o - n_win + 1 .. o
+    const uint32_t mask = (((1u << n_win) - 1u) << (o + 1u - n_win)) & keep;        // s = o - n_win + 1 .. o
+    if (!mask) return 0;
     return ct_make(xu, lu, ru, mask, p + o, out, f);
 }
 

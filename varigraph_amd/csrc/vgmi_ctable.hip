@@ -88,7 +88,13 @@ __global__ void ct_insert_kernel(XTableView t, const unsigned long long* okmer, 
     const uint32_t n_win = (o < rem ? o : rem) + 1u;
     const uint64_t kf = ok & CT_MASK54, kl = okmer[p + n_win - 1] & CT_MASK54;
     CtEntry e[2];
-    const int ne = ct_make_from_unitig(kf, kl, o, n_win, (uint32_t)p, e, t.k);
+    uint32_t keep = 0xFFFu;
+    if (!(t.k & 1u))      // even k: the k-mer j places on is window o - j
+        for (uint32_t j = 0; j < n_win; ++j) {
+            const uint64_t kw = okmer[p + j] & CT_MASK54;
+            if (kw == vg_revcomp(kw, t.k)) keep &= ~(1u << (o - j));
+        }
+    const int ne = ct_make_from_unitig(kf, kl, o, n_win, (uint32_t)p, e, t.k, keep);
     uint32_t* const cb = reinterpret_cast<uint32_t*>(const_cast<uint4*>(t.cb));
     for (int q = 0; q < ne; ++q) {
         const uint64_t b = ((uint64_t)ct_hash(e[q].d0) * t.n_buckets) >> 32;
@@ -120,6 +126,7 @@ __global__ void ct_over_kernel(ulonglong2* over, uint32_t over_mask, const unsig
     if (g >= n_over) return;
     const uint32_t id = over_list[g];
     const uint64_t kw = okmer[id] & CT_MASK54, rc = vg_revcomp(kw, k);
+    if (kw == rc) return;      // (even k: never emitted, never counted)
     const unsigned long long canon = kw < rc ? kw : rc;
     uint32_t s = xt_over_hash(canon) & over_mask;
     for (;;) {
@@ -178,15 +185,15 @@ hipError_t launch_ctable_over(ulonglong2* over, uint32_t over_mask, const unsign
 // trip per batch; an item that meets another marked bucket is queued again, one that has seen CT_HOPS + 1 of them asks the exact
 // overflow table.
 //
-// K = 19 .. 25 (round 5): the same rows, the same twelve bytes per lane, the same queues; a lane looks a 16-mer up every G = 6 (K = 19: 4)
+// K = 19 .. 25 (round 5): the same rows, the same twelve bytes per lane, the same queues; a lane looks a 16-mer up every G = 6 (K = 19, 20: 4)
 // of its bases instead of once -- the 16 bases that end G j bases into the lane's stretch, j = 0 .. 12 / G - 1 -- and asks each for the G
 // windows of K bases that end in the G bases behind it.  Flanks of F = K - 16 bases; the bases behind a later X that belong to the next
 // lane are zeros (no window asked for reaches them).  The ends covered are those of K = 27: stream positions 12 L - 1 .. 12 L + 10.
 template <uint32_t K>
 __device__ __forceinline__ void countc_body(const RowParams& p, const XTableView& xt)
 {
-    constexpr uint32_t F = K - 16u, G = K == 27u ? 12u : (K == 19u ? 4u : 6u), NP = 12u / G, MF = (1u << (2u * F)) - 1u;
-    static_assert(K == 27u || K == 25u || K == 23u || K == 21u || K == 19u, "context table: k = 19 .. 27, odd");
+    constexpr uint32_t F = K - 16u, G = K == 27u ? 12u : (K <= 20u ? 4u : 6u), NP = 12u / G, MF = (1u << (2u * F)) - 1u;
+    static_assert(K == 27u || (K >= 19u && K <= 25u), "context table: k = 19 .. 25 and 27");
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[2048];     // position LUT of count27_kernel (stage_lut27 layout)
     __shared__ __attribute__((aligned(16))) uint2 s_runs[4][CT_RUNQ];
     __shared__ __attribute__((aligned(16))) uint4 s_pend[4][CT_PENDQ];
@@ -424,6 +431,10 @@ hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t n_c
         case 23: hipLaunchKernelGGL(countkc_kernel<23u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
         case 21: hipLaunchKernelGGL(countkc_kernel<21u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
         case 19: hipLaunchKernelGGL(countkc_kernel<19u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
+        // even k: the windows-of-bases rule here, the reference's run counter in the pass ahead of this launch (even_debit_kernel, vgmi_kernels.hip)
+        case 24: hipLaunchKernelGGL(countkc_kernel<24u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
+        case 22: hipLaunchKernelGGL(countkc_kernel<22u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
+        case 20: hipLaunchKernelGGL(countkc_kernel<20u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

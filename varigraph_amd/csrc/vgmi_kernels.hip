@@ -197,9 +197,14 @@ __device__ __forceinline__ void table_count(const TableView& t, uint64_t canon)
     }
 }
 
-// the count of one canonical k-mer taken back by one (compact format of small graphs only: seq_kernel<MODE_DEBIT>)
+// the count of one canonical k-mer taken back by one (even k on the fast paths: even_debit_kernel)
 __device__ __forceinline__ void table_debit(const TableView& t, uint64_t canon)
 {
+    if (t.xt.cb) {      // large graphs of even k (round 5): the counter of the context table's id
+        const uint32_t id = ct_find(t.xt, canon);
+        if (id != 0xFFFFFFFFu) atomicSub(t.xt.counts + id, 1u);
+        return;
+    }
     if (!t.slots8) return;
     uint64_t s = table_home(t, canon);
     for (;;) {

@@ -403,7 +403,7 @@ __global__ void xclamp_kernel(uint32_t* counts, uint64_t n)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        if (counts[i] > 0x40000000u) counts[i] = 0x40000000u;
+        if (counts[i] > 0x40000000u && counts[i] < 0x80000000u) counts[i] = 0x40000000u;      // (above: an even k's debit whose increment is still to come on another stream)
 }
 
 hipError_t launch_xclamp(const XTableView& t, uint64_t n, hipStream_t st)
