@@ -108,7 +108,8 @@ int vgmi_xtable_info(vgmi_ctx *ctx, size_t *n_lines, size_t *overflow_pairs);
 /* Since round 4 the default table of those graphs is the CONTEXT TABLE (VGMI_CTABLE=0 keeps the grid-16-mer
  * table): one 16-byte entry per occurrence of a 16-mer in a unitig of the key set, four to a 64-byte bucket.  Its number of
  * buckets (0: not in use), entries, the unitigs they came from, entries that sit behind their home bucket, and k-mers served by
- * the exact overflow table (16-mers of repeats).  Diagnostic only; no reference counterpart. */
+ * the exact overflow table (16-mers of repeats).  Since round 5 also the table of such graphs with k = 19 .. 25 (flanks of k - 16
+ * bases; VGMI_CTABLE_K=0 keeps them on the generic / literal kernels).  Diagnostic only; no reference counterpart. */
 int vgmi_ctable_info(vgmi_ctx *ctx, size_t *n_buckets, size_t *n_entries, size_t *n_unitigs, size_t *moved_entries,
                      size_t *overflow_kmers);
 

@@ -614,7 +614,11 @@ def test_large_graph_grid_variant_matches_oracle(k, placement, monkeypatch):
         # device-resident single launch gives the same
         c.counts_reset()
         d = torch.from_numpy(block).cuda()
-        c.reads_submit_device(d, block.size, n_reads)
+        d_off = None
+        if k % 2 == 0:      # even k: the reads' offsets come with the block
+            d_off = torch.from_numpy(np.concatenate([[0], np.flatnonzero(block == 10) + 1]).astype(np.int64)).cuda()
+            assert d_off.numel() == n_reads + 1
+        c.reads_submit_device(d, block.size, n_reads, d_off)
         cov2, _, _ = c.counts_finish()
         assert np.array_equal(cov2, want)
     finally:
