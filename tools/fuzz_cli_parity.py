@@ -58,7 +58,7 @@ def dress(path, rng):
 def case(seed):
     rng = np.random.default_rng(seed)
     pick = lambda xs: xs[int(rng.integers(0, len(xs)))]
-    genome = int(pick([40_000, 90_000, 200_000, 400_000]))
+    genome = int(pick([40_000, 90_000, 200_000, 400_000, 1_500_000, 1_500_000]))      # (the last: more than 65 536 k-mers with dense variants -- the context table at any k)
     vploidy = pick([2, 2, 2, 3, 4])
     n_samples = pick([1, 2, 3, 5, 7]) if vploidy <= 2 else pick([1, 2, 3])
     k = pick([27, 27, 27, 21, 25, 22, 28, 15, 11, 19, 23, 20, 24, 26])
