@@ -412,6 +412,7 @@ def main():
                     help="strong scaling: ONE sample of --reads reads sharded over the ranks, raw counters summed "
                          "with one RCCL all-reduce per step (default: one sample per rank, weak scaling)")
     ap.add_argument("--no-c3", action="store_true", help="skip the chr20-class (table in HBM) leg")
+    ap.add_argument("--no-other-k", action="store_true", help="skip the k = 25 / 21 / 22 sub-block of the chr20-class leg")
     ap.add_argument("--c3-reads", type=int, default=24_000_000)
     ap.add_argument("--c3-steps", type=int, default=20)
     ap.add_argument("--no-c5", action="store_true", help="skip the whole-genome-class (3 Gb, 5 M SNPs) leg")
@@ -512,17 +513,17 @@ def main():
         timed.repeats = repeats
         return total / repeats, kernel_ms / max(launches, 1)
 
-    def verify(keys, d_block, n_check):
+    def verify(keys, d_block, n_check, k=K, d_off=None):
         """An unsaturated prefix of the sample, counter by counter against the oracle (the checker; outside every
         timed region).  A kernel that merely touches every key often enough cannot pass this."""
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
         n_check = min(n_check, d_block.numel() // (READ_LEN + 1))
         ctx.counts_reset()
-        ctx.reads_submit_device(d_block, n_check * (READ_LEN + 1), n_check)
+        ctx.reads_submit_device(d_block, n_check * (READ_LEN + 1), n_check, d_off[: n_check + 1] if d_off is not None else None)
         got, _, _ = ctx.counts_finish()
         t = oracle_lib.Table(keys)
-        t.count_block(d_block[: n_check * (READ_LEN + 1)].cpu().numpy(), K)
+        t.count_block(d_block[: n_check * (READ_LEN + 1)].cpu().numpy(), k)
         want = t.counts()
         ok = bool(np.array_equal(got, want))
         return {"reads": n_check, "oracle_match": ok, "cov_sum": int(got.astype(np.int64).sum()),
@@ -618,6 +619,28 @@ def main():
                                "note": "SURVEY 8d: B_read = 150 (bases) + 124 x 8 (one key compare per k-mer) + 2 x hits "
                                        "+ amortised read-out; hits measured from this run's counters"},
                   "verify": verify(keys3, d_block3, args.verify_reads) if args.verify_reads else None}
+        # the same reads over the graph built for other k (round 5: the context table with flanks of k - 16 bases; even k behind the
+        # pass that takes back what the reference's run counter suppresses): rates next to the k = 27 one above, each oracle-checked
+        if rank == 0 and world == 1 and not args.no_other_k:
+            other = {}
+            for kk in (25, 21, 22):
+                keys_k, _ = synth.snp_graph(60_000_000, 500_000, k=kk)
+                ctx.table_upload(keys_k, kk)
+                d_off_k = (torch.arange(n3 + 1, dtype=torch.int64, device="cuda") * (READ_LEN + 1)) if kk % 2 == 0 else None
+                d_cov_k = torch.empty(len(keys_k), dtype=torch.uint8, device="cuda")
+
+                def step_k():
+                    ctx.counts_reset()
+                    ctx.reads_submit_device(d_block3, n3 * (READ_LEN + 1), n3, d_off_k)
+                    ctx.counts_finish_device(d_cov_k, None, None)
+
+                el_k, kms_k = timed(step_k, 2, 1, min_seconds=0.2)
+                cinfo_k = ctx.ctable_info()
+                other[str(kk)] = {"reads_per_s": n3 * 2 / el_k, "kernel_ms": kms_k, "graph_kmers": int(len(keys_k)),
+                                  "context_table_buckets": cinfo_k["n_buckets"],
+                                  "verify": verify(keys_k, d_block3, min(args.verify_reads, 200_000), kk, d_off_k) if args.verify_reads else None}
+                del d_cov_k
+            c3["other_k"] = other
         del d_block3, d_cov3
 
     # ================= C5: the whole-genome-class graph, BASELINE.json configs[4] (single-GPU slice per rank) =================

@@ -33,7 +33,7 @@ def test_context_table_model_counts_equal_dictionary(exe, args):
         assert d["over_kmers"] > 0          # the overflow trail was walked
 
 
-@pytest.mark.parametrize("k", [19, 21, 23, 25])
+@pytest.mark.parametrize("k", [19, 21, 23, 25, 20, 22, 24, 26])      # (even k: no window bit for a k-mer that is its own reverse complement)
 @pytest.mark.parametrize("args", [(1, 20000, 400, 2000, 40, 0), (3, 30000, 1500, 3000, 90, 0), (4, 30000, 300, 3000, 40, 100), (6, 6000, 60, 500, 95, 0)],
                          ids=["dense", "crowded", "repeats", "tiny-crowded"])
 def test_context_table_model_other_odd_k(exe, args, k):

@@ -552,7 +552,7 @@ def test_saturation_flags_do_not_travel_with_the_table_image(ctx):
 
 
 # ----------------------------------------------------------------------------- large graphs (global grid bitmap)
-@pytest.mark.parametrize("k,placement", [(27, None), (25, None), (23, None), (21, None), (19, None), (24, None), (22, None), (20, None), (25, {"VGMI_CTABLE_K": "0"}),
+@pytest.mark.parametrize("k,placement", [(27, None), (25, None), (23, None), (21, None), (19, None), (24, None), (22, None), (20, None), (26, None), (25, {"VGMI_CTABLE_K": "0"}),
                                          (21, {"VGMI_CTABLE_LOAD": "90"}), (23, {"VGMI_CTABLE_LOAD": "10"}), (27, {"VGMI_XTABLE": "0"}), (27, {"VGMI_XTABLE": "0", "VGMI_LOCALITY": "0"}),
                                          (27, {"VGMI_XTABLE": "0", "VGMI_LOCALITY": "3"}),
                                          (27, {"VGMI_WIDE_SLOTS": "1"}), (27, {"VGMI_WIDE_SLOTS": "1", "VGMI_DENSE_COUNTS": "1"}),
@@ -561,7 +561,7 @@ def test_saturation_flags_do_not_travel_with_the_table_image(ctx):
                                          (27, {"VGMI_CTABLE": "0"}), (27, {"VGMI_CTABLE": "0", "VGMI_XTABLE_ORDER": "0"}),
                                          (27, {"VGMI_CTABLE": "0", "VGMI_XTABLE_LOAD": "60"}), (27, {"VGMI_CTABLE_LOAD": "90"}),
                                          (27, {"VGMI_CTABLE_LOAD": "10"})],
-                         ids=["k27", "k25", "k23", "k21", "k19", "k24", "k22", "k20", "k25-generic-kernel", "k21-context-table-crowded", "k23-context-table-sparse", "k27-minimiser-buckets", "k27-random-homes", "k27-buckets-of-8", "k27-16-byte-slots",
+                         ids=["k27", "k25", "k23", "k21", "k19", "k24", "k22", "k20", "k26", "k25-generic-kernel", "k21-context-table-crowded", "k23-context-table-sparse", "k27-minimiser-buckets", "k27-random-homes", "k27-buckets-of-8", "k27-16-byte-slots",
                               "k27-16-byte-slots-dense-counters", "k27-16-byte-slots-random-homes", "k27-slots-by-minimiser-offset",
                               "k27-grid-table", "k27-grid-table-ids-by-key-index", "k27-grid-table-crowded", "k27-context-table-crowded",
                               "k27-context-table-sparse"])
@@ -1078,7 +1078,7 @@ def test_small_graph_saturation_through_the_path_table():
 # Round 5: small graphs of odd k = 19 .. 25 through count27s_kernel<true, K> (the grid of 8: two grid 12-mers per lane and row, runs of
 # K + 7 bases, 8 windows each) and the path table laid out for k.  VGMI_SMALLK=0 keeps the generic row kernel: the A/B reference.
 @pytest.mark.parametrize("kind", ["plain", "repeats", "dense-sites"])
-@pytest.mark.parametrize("k", [19, 21, 23, 25, 20, 22, 24, 26])      # (26: k + 7 bases do not fit a run -- the literal kernel, as before)
+@pytest.mark.parametrize("k", [19, 21, 23, 25, 20, 22, 24, 26])      # (26: k + 7 bases do not fit a run -- the context table at any size, flanks of 10)
 def test_small_graph_other_odd_k_fast_path_matches_oracle(kind, k):
     rng = np.random.default_rng({"plain": 1, "repeats": 2, "dense-sites": 3}[kind] + k)
     keys, haps = _small_graph(kind, rng, k)
@@ -1094,6 +1094,7 @@ def test_small_graph_other_odd_k_fast_path_matches_oracle(kind, k):
     try:
         import torch
         c.table_upload(keys, k)
+        assert (c.ctable_info()["n_buckets"] > 0) == (k == 26)
         t = o.Table(keys)
         for blk in (block, b2):
             c.counts_reset()
@@ -1193,8 +1194,8 @@ def test_small_graph_other_odd_k_low_complexity_and_saturation(k, monkeypatch):
         c.close()
 
 
-@pytest.mark.parametrize("k,big", [(20, False), (22, False), (24, False), (20, True), (22, True), (24, True)],
-                         ids=["20", "22", "24", "20-context-table", "22-context-table", "24-context-table"])
+@pytest.mark.parametrize("k,big", [(20, False), (22, False), (24, False), (20, True), (22, True), (24, True), (26, False), (26, True)],
+                         ids=["20", "22", "24", "20-context-table", "22-context-table", "24-context-table", "26-context-table-small", "26-context-table"])
 def test_small_graph_even_k_run_counter_lag_is_taken_back(k, big):
     """Even k on the fast path (round 5).  The reference does not advance its run counter on a window that is its own reverse
     complement (src/kmer.cpp:134, `continue` before `++l`), registers included that still hold bases from in front of a non-base or the
@@ -1263,10 +1264,10 @@ def test_small_graph_even_k_run_counter_lag_is_taken_back(k, big):
         c.reads_submit_device(d, d.numel(), len(reads), d_off)
         cov, _, _ = c.counts_finish()
         assert np.array_equal(cov, want), (k, int((cov != want).sum()), np.flatnonzero(cov != want)[:5], cov[cov != want][:5], want[cov != want][:5])
-        assert (c.ctable_info()["n_buckets"] > 0) == big
+        assert (c.ctable_info()["n_buckets"] > 0) == (big or k == 26)
         # the literal kernel on the same keys (the A/B)
         import os
-        knob = "VGMI_CTABLE_K" if big else "VGMI_SMALLK"
+        knob = "VGMI_CTABLE_K" if big or k == 26 else "VGMI_SMALLK"
         os.environ[knob] = "0"
         try:
             g = vgmi.Context(0, buffer_mib=16)

@@ -62,6 +62,7 @@ def case(seed):
     vploidy = pick([2, 2, 2, 3, 4])
     n_samples = pick([1, 2, 3, 5, 7]) if vploidy <= 2 else pick([1, 2, 3])
     k = pick([27, 27, 27, 21, 25, 22, 28, 15, 11, 19, 23, 20, 24, 26])
+    if k < 19 and genome > 400_000: genome = 400_000      # (the reference takes minutes over 1.5 Mb of 11- and 15-mers)
     copts = pick([[], [], ["--fast"], ["--use-unique-kmers"]])
     n_var = max(5, genome // pick([300, 600, 1500]))
     indel, sv = pick([0.0, 0.1, 0.3]), pick([0.0, 0.01, 0.05])
@@ -83,8 +84,11 @@ def case(seed):
         graphs, rcs = {}, {}
         for name, exe, more in (("native", tc.CLI, ["--gpu", "0"]), ("cpu", tc.REF, [])):
             graphs[name] = os.path.join(work, f"g_{name}.bin")
-            r = subprocess.run([exe, "construct", "-r", fa, "-v", vcf, "--save-graph", graphs[name], "-t", "6", "-k", str(k), "--vcf-ploidy", str(vploidy)] + copts + more,
-                               cwd=work, capture_output=True, text=True, env=tc.ENV, timeout=600)
+            try:
+                r = subprocess.run([exe, "construct", "-r", fa, "-v", vcf, "--save-graph", graphs[name], "-t", "6", "-k", str(k), "--vcf-ploidy", str(vploidy)] + copts + more,
+                                   cwd=work, capture_output=True, text=True, env=tc.ENV, timeout=150)
+            except subprocess.TimeoutExpired:
+                return f"TIMEOUT of {name} (construct)", desc
             rcs[name] = r.returncode
         if (rcs["native"] == 0) != (rcs["cpu"] == 0): return "CONSTRUCT STATUS DIFFERS " + str(rcs), desc
         if rcs["cpu"] != 0: return "both refuse construct", desc
@@ -101,7 +105,7 @@ def case(seed):
             d = os.path.join(work, name); os.makedirs(d)
             open(os.path.join(d, "samples.cfg"), "w").write(cfg)
             try:
-                r = subprocess.run([exe, "genotype", "--load-graph", graphs["cpu"], "-s", "samples.cfg", "-t", "6"] + gopts + more, cwd=d, capture_output=True, text=True, env=tc.ENV, timeout=600)
+                r = subprocess.run([exe, "genotype", "--load-graph", graphs["cpu"], "-s", "samples.cfg", "-t", "6"] + gopts + more, cwd=d, capture_output=True, text=True, env=tc.ENV, timeout=150)
             except subprocess.TimeoutExpired:
                 return f"TIMEOUT of {name}", desc
             codes[name] = r.returncode
@@ -127,7 +131,7 @@ if __name__ == "__main__":
     for s in range(first, first + n):
         t0 = time.time()
         verdict, desc = case(s)
-        flag = verdict.isupper() or "DIFFERS" in verdict or "TIMEOUT" in verdict
+        flag = verdict.isupper() or "DIFFERS" in verdict or "TIMEOUT of native" in verdict      # (the reference's own pool loses a wake-up now and then: skipped, not a difference)
         bad += flag
         print(("!! " if flag else "ok ") + verdict + f" [{time.time() - t0:.1f} s] -- " + desc, flush=True)
     print(f"{n} cases, {bad} differences")

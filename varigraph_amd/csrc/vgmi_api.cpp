@@ -253,7 +253,8 @@ void layout_image(ImageHeader& h, uint32_t k, uint64_t n_keys)
     // ... and graphs of k = 19 .. 25 too large for that: the context table is built from the compact image (xtable_wanted)
     const bool off_k = (getenv("VGMI_CTABLE_K") && getenv("VGMI_CTABLE_K")[0] == '0') || (getenv("VGMI_CTABLE") && getenv("VGMI_CTABLE")[0] == '0') ||
                        (getenv("VGMI_XTABLE") && getenv("VGMI_XTABLE")[0] == '0');
-    const bool largek = k >= 19 && k <= 25 && n_keys > VG_GRID_LDS_MAX_KEYS && n_keys < (1ULL << 31) - 16 && !off_k;
+    // ... and k = 26 at any size: its runs of k + 7 bases do not fit the path-table kernel's two words, the context table's flanks of 10 do
+    const bool largek = ((k >= 19 && k <= 25 && n_keys > VG_GRID_LDS_MAX_KEYS) || (k == 26 && n_keys > 0)) && n_keys < (1ULL << 31) - 16 && !off_k;
     const bool compact = (k == 27 || smallk || largek) && !getenv("VGMI_WIDE_SLOTS");   // 8-byte k-mer words + per-slot counters
     h.slot_bytes = compact ? 8 : 16;
     uint64_t cap = 64;
@@ -369,9 +370,9 @@ int adopt_image(vgmi_ctx* c)
 bool xtable_wanted(const ImageHeader& h)
 {
     const char* e = getenv("VGMI_XTABLE");
-    if ((e && e[0] == '0') || h.slot_bytes != 8 || h.n_keys <= VG_GRID_LDS_MAX_KEYS) return false;
+    if ((e && e[0] == '0') || h.slot_bytes != 8 || (h.n_keys <= VG_GRID_LDS_MAX_KEYS && !(h.k == 26 && h.n_keys > 0))) return false;
     // k = 19 .. 25, odd (round 5): the context table only (flanks of k - 16 bases, vgmi_ctable.h); VGMI_CTABLE_K=0 keeps them on the generic kernel (A/B)
-    if (h.k >= 19 && h.k <= 25) {      // (even k too: the pass that takes back what the reference's run counter suppresses runs ahead of the kernel)
+    if (h.k >= 19 && h.k <= 26) {      // (even k too: the pass that takes back what the reference's run counter suppresses runs ahead of the kernel)
         const char* o = getenv("VGMI_CTABLE_K");
         return !(o && o[0] == '0') && ctable_wanted(h);
     }

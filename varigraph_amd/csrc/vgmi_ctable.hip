@@ -193,7 +193,7 @@ template <uint32_t K>
 __device__ __forceinline__ void countc_body(const RowParams& p, const XTableView& xt)
 {
     constexpr uint32_t F = K - 16u, G = K == 27u ? 12u : (K <= 20u ? 4u : 6u), NP = 12u / G, MF = (1u << (2u * F)) - 1u;
-    static_assert(K == 27u || (K >= 19u && K <= 25u), "context table: k = 19 .. 25 and 27");
+    static_assert(K >= 19u && K <= 27u, "context table: k = 19 .. 27");
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[2048];     // position LUT of count27_kernel (stage_lut27 layout)
     __shared__ __attribute__((aligned(16))) uint2 s_runs[4][CT_RUNQ];
     __shared__ __attribute__((aligned(16))) uint4 s_pend[4][CT_PENDQ];
@@ -432,6 +432,7 @@ hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t n_c
         case 21: hipLaunchKernelGGL(countkc_kernel<21u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
         case 19: hipLaunchKernelGGL(countkc_kernel<19u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
         // even k: the windows-of-bases rule here, the reference's run counter in the pass ahead of this launch (even_debit_kernel, vgmi_kernels.hip)
+        case 26: hipLaunchKernelGGL(countkc_kernel<26u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
         case 24: hipLaunchKernelGGL(countkc_kernel<24u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
         case 22: hipLaunchKernelGGL(countkc_kernel<22u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
         case 20: hipLaunchKernelGGL(countkc_kernel<20u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
