@@ -15,6 +15,7 @@ print("cpu_baseline", d.get("cpu_baseline"))
 sl = d.get("sample_level", {})
 print("sample_level", {k: (round(v / 1e6, 1) if isinstance(v, float) and v > 1e5 else v) for k, v in sl.items() if "reads_per_s" in k or "identical" in k or k == "compressed_bytes_per_read"})
 c4 = d.get("c4", {})
+print("other_k", {k: (round(v["reads_per_s"] / 1e9, 2), v["verify"]["oracle_match"] if v.get("verify") else None) for k, v in ((d.get("c3") or {}).get("other_k") or {}).items()})
 print("c4", {k: c4.get(k) for k in ("genotype_wall_s", "host_thread_seconds_per_sample", "counting_wall_s_per_sample", "hmm_device_recursion_s_per_sample", "procs", "host_memory")})
 print("bloom", (d.get("bloom") or {}).get("value"), "verify", d.get("verify"), "c3 verify", (d.get("c3") or {}).get("verify"), "c5 verify", (d.get("c5") or {}).get("verify"))
 PY
