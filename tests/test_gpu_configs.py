@@ -37,13 +37,13 @@ L = 150
 def _run(cmd, **kw):
     """subprocess.run for the small cases of this file.  The reference's thread pool can lose a wake-up and sleep forever
     (include/ThreadPool.hpp notifies without the mutex; seen once in ~500 runs of tools/fuzz_cli_parity.py, twice in ~30 on a 256-thread
-    host, three times in a row on one loaded box of the pool): its genotype runs here take seconds, so they are bounded at one minute and
-    tried six times; varigraph-mi gets neither."""
+    host, three times in a row on one loaded box of the pool): its genotype runs here take seconds, so they are bounded at 25 s and
+    tried eight times (a lost wake-up then costs the suite 25 s, not a minute); varigraph-mi gets neither."""
     is_ref = str(cmd[0]) == REF
     quick = is_ref and len(cmd) > 1 and cmd[1] == "genotype"      # (construct runs of this file take up to a minute: two minutes, four times)
-    attempts = (6 if quick else 4) if is_ref else 1
+    attempts = (8 if quick else 4) if is_ref else 1
     if is_ref:
-        cap = 60 if quick else 120
+        cap = 25 if quick else 120
         kw = dict(kw, timeout=min(kw.get("timeout", cap), cap))
     for attempt in range(attempts):
         try:
