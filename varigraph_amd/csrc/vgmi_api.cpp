@@ -835,6 +835,25 @@ int build_ptable(vgmi_ctx* c)
 
 // grid-16-mer table: counters are bumped without a return value; before any could wrap (2^32 hits need > 2^31 submitted
 // bytes), counters far above the read-out clamp are pulled back
+// even k on the fast paths: the stream's list of non-base positions (launch_even_debit), made on first use
+int debit_list_of(vgmi_ctx* c, hipStream_t st, unsigned long long** out)
+{
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        auto it = c->debit_lists.find(st);
+        if (it != c->debit_lists.end()) {
+            *out = it->second;
+            return VGMI_OK;
+        }
+    }
+    unsigned long long* list = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&list), (size_t)VG_DEBIT_LIST * 8 + (size_t)VG_DEBIT_SUBLISTS * 64));
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->debit_lists[st] = list;
+    *out = list;
+    return VGMI_OK;
+}
+
 int xt_clamp_if_due(vgmi_ctx* c, size_t n_bytes, hipStream_t st)
 {
     bool due = false;
@@ -1010,16 +1029,8 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
             int rcx = xt_clamp_if_due(c, n_bytes, st);
             if (rcx) return rcx;
             unsigned long long* list = nullptr;
-            {
-                std::lock_guard<std::mutex> lk(c->mu);
-                auto it = c->debit_lists.find(st);
-                if (it != c->debit_lists.end()) list = it->second;
-            }
-            if (!list) {
-                HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&list), (size_t)VG_DEBIT_LIST * 8 + (size_t)VG_DEBIT_SUBLISTS * 64));
-                std::lock_guard<std::mutex> lk(c->mu);
-                c->debit_lists[st] = list;
-            }
+            int rcl = debit_list_of(c, st, &list);
+            if (rcl) return rcl;
             HIPCHK(c, launch_even_debit(p, d_read_off, n_reads, list, VG_DEBIT_LIST, st));
             HIPCHK(c, launch_count27c(p, c->tv.xt, (uint32_t)c->n_cu, st));
             HIPCHK(c, launch_seq(K_MODE_COUNT, p, d_read_off, n_reads, st));
@@ -1030,16 +1041,8 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
             p.row_end = (n_bytes / 2048) * 2;
             p.emit_from = p.row_end * 1024;
             unsigned long long* list = nullptr;
-            {
-                std::lock_guard<std::mutex> lk(c->mu);
-                auto it = c->debit_lists.find(st);
-                if (it != c->debit_lists.end()) list = it->second;
-            }
-            if (!list) {
-                HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&list), (size_t)VG_DEBIT_LIST * 8 + (size_t)VG_DEBIT_SUBLISTS * 64));
-                std::lock_guard<std::mutex> lk(c->mu);
-                c->debit_lists[st] = list;
-            }
+            int rcl = debit_list_of(c, st, &list);
+            if (rcl) return rcl;
             HIPCHK(c, launch_even_debit(p, d_read_off, n_reads, list, VG_DEBIT_LIST, st));
             HIPCHK(c, launch_count27s(p, (uint32_t)c->n_cu, st));
             if (p.emit_from < n_bytes) HIPCHK(c, launch_seq(K_MODE_COUNT, p, d_read_off, n_reads, st));
