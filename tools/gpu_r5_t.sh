@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/r5t
 VGMI_HMM_SPLIT=1 python -m pytest tests/test_gpu_hmm.py tests/test_gpu_integration.py -q -m gpu -x > gpurun_out/r5t/pytest.log 2>&1
 tail -n 3 gpurun_out/r5t/pytest.log | cut -c1-200
-for v in 0 1 1; do
+for v in 0 1 0 1; do
   for ns in 8 1; do
     VGMI_HMM_SPLIT=$v VG_BENCH_C4_LOG=1 python bench.py --no-c3 --no-c5 --no-bloom --no-sample-level --no-cpu-baseline --steps 3 --reads 20000000 --c4-samples $ns > gpurun_out/r5t/c4_split${v}_$ns.json 2> gpurun_out/r5t/c4_split${v}_$ns.err
     python - "$v" "$ns" <<'PY'

@@ -238,47 +238,35 @@ __global__ __launch_bounds__(256) void hmm_recursion_split_kernel(HmmParams P)
             }
             __syncthreads();
             for (uint32_t c = 0; c <= n_blocks; ++c) {
-                // (a block's LDS reads all at once, ahead of its arithmetic: one wavefront per SIMD hides nothing, and the compiler cannot
-                // move a read over a write into the same array on its own)
                 if (producer) {
                     if (c < n_blocks && active) {
                         uint64_t* const out_m = s_p_m + (size_t)((c & 1u) * B) * 128u + g;
                         int32_t* const out_e = s_p_e + (size_t)((c & 1u) * B) * 128u + g;
-                        const uint32_t p0 = c * B;
-                        uint32_t at[B];
-                        VgN80 st[B], t[B];
-#pragma unroll
-                        for (uint32_t j = 0; j < B; ++j) at[j] = (p0 + j < n ? p0 + j : n - 1u) * stride + my_keep[p0 + j < n ? p0 + j : n - 1u];
-#pragma unroll
-                        for (uint32_t j = 0; j < B; ++j) {
-                            st[j].m = s_step_m[at[j]];
-                            st[j].e = s_step_e[at[j]];
-                        }
-#pragma unroll
-                        for (uint32_t j = 0; j < B; ++j) t[j] = n80_mul_bf(st[j], o);
-#pragma unroll
-                        for (uint32_t j = 0; j < B; ++j) {
-                            out_m[j * 128u] = t[j].m;
-                            out_e[j * 128u] = t[j].e;
+                        const uint32_t p0 = c * B, pe = p0 + B < n ? p0 + B : n;
+#pragma unroll 2
+                        for (uint32_t p = p0; p < pe; ++p) {
+                            const uint32_t at = p * stride + my_keep[p];
+                            VgN80 st;
+                            st.m = s_step_m[at];
+                            st.e = s_step_e[at];
+                            const VgN80 t = n80_mul_bf(st, o);
+                            out_m[(p - p0) * 128u] = t.m;
+                            out_e[(p - p0) * 128u] = t.e;
                         }
                     }
                 } else if (c >= 1u && active) {
                     const uint64_t* const in_m = s_p_m + (size_t)(((c - 1u) & 1u) * B) * 128u + g;
                     const int32_t* const in_e = s_p_e + (size_t)(((c - 1u) & 1u) * B) * 128u + g;
-                    const uint32_t p0 = (c - 1u) * B;
-                    VgN80 t[B];
-#pragma unroll
-                    for (uint32_t j = 0; j < B; ++j) {
-                        t[j].m = in_m[j * 128u];
-                        t[j].e = in_e[j * 128u];
-                    }
-#pragma unroll
-                    for (uint32_t j = 0; j < B; ++j) {
+                    const uint32_t p0 = (c - 1u) * B, pe = p0 + B < n ? p0 + B : n;
+                    for (uint32_t p = p0; p < pe; ++p) {
+                        VgN80 t;
+                        t.m = in_m[(p - p0) * 128u];
+                        t.e = in_e[(p - p0) * 128u];
                         // a term more than 64 binades below the sum so far leaves it as it is; when that holds for every genotype of the
-                        // wavefront the addition is not made (n80_sum would return r).  (Terms behind the last one: the block's rest.)
-                        const bool nothing = p0 + j >= n || t[j].m == 0 || (r.m != 0 && r.e - t[j].e > 64);
+                        // wavefront the addition is not made (n80_sum would return r)
+                        const bool nothing = t.m == 0 || (r.m != 0 && r.e - t.e > 64);
                         if (__builtin_amdgcn_ballot_w64(!nothing) == 0) continue;
-                        if (p0 + j < n) r = n80_sum(r, t[j]);
+                        r = n80_sum(r, t);
                     }
                 }
                 __syncthreads();
