@@ -1,6 +1,7 @@
 #!/bin/bash
-# round 5: the HMM recursion with the products made by wavefronts of their own (VGMI_HMM_SPLIT=1): parity, then the CLI's eight-sample
-# and one-sample runs against the shipped kernel, same box
+# round 5: the HMM recursion with the products made by wavefronts of their own (VGMI_HMM_SPLIT=1; the kernel lives in the history only:
+# commit "HMM recursion with the products made by wavefronts of their own", taken out after this measurement -- DESIGN.md section 9):
+# parity, then the CLI's eight-sample and one-sample runs against the shipped kernel, same box
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/r5t
 VGMI_HMM_SPLIT=1 python -m pytest tests/test_gpu_hmm.py tests/test_gpu_integration.py -q -m gpu -x > gpurun_out/r5t/pytest.log 2>&1

@@ -354,31 +354,6 @@ VG_X80_HD VgN80 n80_div(VgN80 a, VgN80 b)    // b != 0
     return n80_round(q, ((uint64_t)guard << 63) | (r2 != 0 ? 1u : 0u), e);
 }
 
-// s * o without branches for the case that is all but universal in the recursion (a normal product): the first half of n80_muladd below,
-// for the form of the recursion in which other wavefronts make the products (vgmi_hmm.hip: hmm_recursion_split_kernel)
-VG_X80_HD VgN80 n80_mul_bf(VgN80 s, VgN80 o)
-{
-    const uint64_t half = 1ULL << 63;
-    const bool zero = s.m == 0 || o.m == 0;
-    uint64_t hi, lo;
-    x80_mul64(s.m, o.m, hi, lo);
-    const bool up = (hi >> 63) != 0;                 // product of the significands in [2^127, 2^128)
-    int32_t te = s.e + o.e - VG_X80_BIAS + (up ? 1 : 0);
-    const uint64_t hi1 = (hi << 1) | (lo >> 63), lo1 = lo << 1;
-    hi = up ? hi : hi1;
-    lo = up ? lo : lo1;
-    const uint64_t inc = (lo | (hi & 1u)) > half ? 1u : 0u;
-    uint64_t tm = hi + inc;
-    const bool over = tm < inc;
-    tm = over ? half : tm;
-    te += over ? 1 : 0;
-    VgN80 out;
-    out.m = zero ? 0u : tm;
-    out.e = zero ? 0 : te;
-    if (!zero && te < 1) out = n80_mul(s, o);
-    return out;
-}
-
 // r + s * o  (the product rounded, then the sum rounded) -- the recursion's term.  Written without branches for the case
 // that is all but universal there (the product and the sum are normal numbers): selects instead of per-lane jumps, which on
 // the device cost more than the arithmetic they skip.  Anything else takes the two functions above.

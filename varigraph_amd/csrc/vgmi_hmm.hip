@@ -158,156 +158,6 @@ __global__ __launch_bounds__(64 * WAVES) void hmm_recursion_kernel(HmmParams P)
     }
 }
 
-// ---- the same recursion with the PRODUCTS made by other wavefronts (round 5) ---------------------------------------------------
-// A term is  r <- round(r + round(s * o)).  The sum is serial by the reference's order of additions; the rounded product does not
-// depend on r.  Four wavefronts per chain: two hold the genotypes' running sums (consumers), two make the products of the same
-// genotypes (producers) a block of B terms ahead, into one of two LDS buffers; a workgroup barrier per block hands a buffer over.
-// The consumers' chain per node is then 120 additions (n80_sum) instead of 120 multiply-adds, and the producers run on SIMDs that
-// idle otherwise (a sample's 120 chains cover 240 of 1 024).  n80_sum(r, n80_mul_bf(s, o)) is n80_muladd(r, s, o) bit for bit
-// (tests/native/x80_check.cpp holds the two against each other and against the x87 unit).  Everything else -- the step table, the
-// restart rows, the total in genotype order, the division -- is the kernel above, on the consumers.
-#define VG_HMM_SPLIT_B 8u
-size_t hmm_lds_bytes(uint32_t n_gt, uint32_t ploidy);
-
-template <uint32_t STRIDE>
-__global__ __launch_bounds__(256) void hmm_recursion_split_kernel(HmmParams P)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t hmm_smem[];
-    constexpr uint32_t stride = STRIDE, B = VG_HMM_SPLIT_B;
-    const uint32_t n = P.n_gt, g0 = threadIdx.x & 127u;
-    const bool producer = threadIdx.x >= 128u, active = g0 < n;
-    const uint32_t g = active ? g0 : 0u;      // an idle lane reads genotype 0's inputs and writes nothing
-    uint8_t* const s_keep = hmm_smem;                                              // n * n
-    uint64_t* const s_step_m = reinterpret_cast<uint64_t*>(hmm_smem + ((n * n + 15u) & ~15u));   // 128 * stride
-    int32_t* const s_step_e = reinterpret_cast<int32_t*>(s_step_m + 128u * stride);
-    uint64_t* const s_r_m = reinterpret_cast<uint64_t*>(s_step_e + 128u * stride);
-    int32_t* const s_r_e = reinterpret_cast<int32_t*>(s_r_m + 128);
-    uint64_t* const s_p_m = reinterpret_cast<uint64_t*>(s_r_e + 128);               // 2 * B * 128
-    int32_t* const s_p_e = reinterpret_cast<int32_t*>(s_p_m + 2u * B * 128u);
-
-    const HmmChain ch = P.chains[blockIdx.x];
-    const uint8_t* keep_g = P.keep + (size_t)ch.keep_index * n * n;
-    for (uint32_t i = threadIdx.x; i < n * n; i += blockDim.x) s_keep[i] = keep_g[i];
-    __syncthreads();
-    const uint8_t* const my_keep = s_keep + (size_t)g * n;
-    const VgX80 uniform = x80_load(P.uniform);
-    if (ch.n_steps == 0) return;
-
-    uint32_t lane_zero = 0;
-    asm volatile("" : "+v"(lane_zero));
-    auto fetch = [&](uint64_t s, uint32_t row_s, HmmStepIn<STRIDE>& in) {
-        if (!producer) {
-            const uint8_t* pw = P.pow + s * (size_t)(2 * stride) * 16 + lane_zero;
-            for (uint32_t k = 0; k < stride; ++k) {
-                in.keep_pow[k] = x80_load(pw + (size_t)k * 16);
-                in.change_pow[k] = x80_load(pw + (size_t)(stride + (stride - 1 - k)) * 16);
-            }
-        }
-        in.obs = x80_load(P.obs + ((size_t)row_s * n + g) * 16);
-        in.restart = P.restart[s + lane_zero];
-    };
-    const uint64_t s_end = ch.first_step + ch.n_steps;
-    HmmStepIn<STRIDE> cur;
-    for (uint32_t k = 0; k < stride; ++k) cur.keep_pow[k] = cur.change_pow[k] = uniform;      // (producers never read them)
-    fetch(ch.first_step, P.row[ch.first_step], cur);
-    uint32_t row_next = ch.n_steps > 1 ? P.row[ch.first_step + 1] : 0u;
-    const uint32_t n_blocks = (n + B - 1u) / B;
-
-    VgN80 prev = {0, 0};
-    for (uint64_t s = ch.first_step; s < s_end; ++s) {
-        HmmStepIn<STRIDE> nx = cur;
-        uint32_t row_after = 0;
-        if (s + 1 < s_end) fetch(s + 1, row_next, nx);
-        if (s + 2 < s_end) row_after = P.row[s + 2 + lane_zero];
-
-        const bool restart = __builtin_amdgcn_readfirstlane(cur.restart) != 0;
-        VgN80 o = {0, 0};
-        if (active) o = n80_from(cur.obs);
-        VgN80 r = {0, 0};
-        if (restart) {
-            r = o;
-        } else {
-            if (!producer) {
-                for (uint32_t k = 0; k < stride; ++k) {
-                    const VgN80 st = n80_mul(n80_mul(prev, n80_from(cur.keep_pow[k])), n80_from(cur.change_pow[k]));
-                    if (active) {
-                        s_step_m[g * stride + k] = st.m;
-                        s_step_e[g * stride + k] = st.e;
-                    }
-                }
-            }
-            __syncthreads();
-            for (uint32_t c = 0; c <= n_blocks; ++c) {
-                if (producer) {
-                    if (c < n_blocks && active) {
-                        uint64_t* const out_m = s_p_m + (size_t)((c & 1u) * B) * 128u + g;
-                        int32_t* const out_e = s_p_e + (size_t)((c & 1u) * B) * 128u + g;
-                        const uint32_t p0 = c * B, pe = p0 + B < n ? p0 + B : n;
-#pragma unroll 2
-                        for (uint32_t p = p0; p < pe; ++p) {
-                            const uint32_t at = p * stride + my_keep[p];
-                            VgN80 st;
-                            st.m = s_step_m[at];
-                            st.e = s_step_e[at];
-                            const VgN80 t = n80_mul_bf(st, o);
-                            out_m[(p - p0) * 128u] = t.m;
-                            out_e[(p - p0) * 128u] = t.e;
-                        }
-                    }
-                } else if (c >= 1u && active) {
-                    const uint64_t* const in_m = s_p_m + (size_t)(((c - 1u) & 1u) * B) * 128u + g;
-                    const int32_t* const in_e = s_p_e + (size_t)(((c - 1u) & 1u) * B) * 128u + g;
-                    const uint32_t p0 = (c - 1u) * B, pe = p0 + B < n ? p0 + B : n;
-                    for (uint32_t p = p0; p < pe; ++p) {
-                        VgN80 t;
-                        t.m = in_m[(p - p0) * 128u];
-                        t.e = in_e[(p - p0) * 128u];
-                        // a term more than 64 binades below the sum so far leaves it as it is; when that holds for every genotype of the
-                        // wavefront the addition is not made (n80_sum would return r)
-                        const bool nothing = t.m == 0 || (r.m != 0 && r.e - t.e > 64);
-                        if (__builtin_amdgcn_ballot_w64(!nothing) == 0) continue;
-                        r = n80_sum(r, t);
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        if (!producer && active) {
-            s_r_m[g] = r.m;
-            s_r_e[g] = r.e;
-        }
-        __syncthreads();
-        if (!producer) {
-            VgN80 total = {0, 0};
-            VgN80 tn;
-            tn.m = s_r_m[lane_zero];
-            tn.e = s_r_e[lane_zero];
-            for (uint32_t p = 0; p < n; ++p) {
-                const VgN80 t = tn;
-                if (p + 1 < n) {
-                    tn.m = s_r_m[p + 1 + lane_zero];
-                    tn.e = s_r_e[p + 1 + lane_zero];
-                }
-                if (t.m == 0 || (total.m != 0 && total.e - t.e > 64)) continue;
-                total = n80_sum(total, t);
-            }
-            VgX80 out = uniform;
-            if (total.m != 0) {
-                prev = n80_div(r, total);
-                out = n80_to(prev);
-            } else {
-                prev = n80_from(uniform);
-            }
-            if (active) x80_store(P.out + (s * n + g) * 16, out);
-        }
-        __syncthreads();
-        cur = nx;
-        row_next = row_after;
-    }
-}
-
-size_t hmm_split_lds_bytes(uint32_t n_gt, uint32_t ploidy) { return hmm_lds_bytes(n_gt, ploidy) + (size_t)2 * VG_HMM_SPLIT_B * 128 * 12; }
-
 // ---- posterior of a node (src/genotype.cpp:1387-1522) from the alpha / beta rows the recursion left on the device --------
 //   denominator = sum of a_g * b_g in entry order;  post_g = (a_g * b_g) / denominator;  per genotype STRING (gid, made by the
 //   host: alleles as decimal strings, sorted as strings) the sum of its entries' posts in entry order;  the first maximum in
@@ -773,23 +623,8 @@ hipError_t launch_recursion_as(const HmmParams& Q, uint32_t n_chains, size_t lds
     return hipGetLastError();
 }
 template <uint32_t STRIDE>
-hipError_t launch_recursion_split(const HmmParams& Q, uint32_t n_chains, hipStream_t st)
-{
-    size_t lds = hmm_split_lds_bytes(Q.n_gt, Q.ploidy);
-    if (n_chains <= 256 && lds < 84 * 1024) lds = 84 * 1024;      // a launch the device has a CU per workgroup for: its four wavefronts then have a SIMD each
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hmm_recursion_split_kernel<STRIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((hmm_recursion_split_kernel<STRIDE>), dim3(n_chains), dim3(256), lds, st, Q);
-    return hipGetLastError();
-}
-template <uint32_t STRIDE>
 hipError_t launch_recursion_waves(uint32_t waves, const HmmParams& Q, uint32_t n_chains, size_t lds, size_t plain_lds, hipStream_t st)
 {
-    static const bool split = [] {      // VGMI_HMM_SPLIT=1: the products by wavefronts of their own (hmm_recursion_split_kernel); A/B
-        const char* e = getenv("VGMI_HMM_SPLIT");
-        return e && e[0] == '1';
-    }();
-    if (split && !Q.dbg) return launch_recursion_split<STRIDE>(Q, n_chains, st);
     switch (waves) {
         case 4: return launch_recursion_as<STRIDE, 4>(Q, n_chains, lds, plain_lds, st);
         default: return launch_recursion_as<STRIDE, 2>(Q, n_chains, lds, plain_lds, st);
