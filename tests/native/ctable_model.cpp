@@ -360,26 +360,39 @@ int main(int argc, char** argv)
             }
         }
     }
-    // the grid walk: X = the 16 bases ending at stream position e = G - 1 (mod G); window w (0 .. G - 1) ends at e + w.  A lane of the
-    // kernel owns twelve bytes and has, behind the X of its sub-position, only what is left of them: avail bases (11 for G = 12)
-    for (size_t e = GG - 1; e < n; e += GG) {
-        if (e < 15) continue;
-        uint32_t x = 0, l = 0, r = 0, vw = 0;
-        bool okx = true;
-        for (size_t j = e - 15; j <= e; ++j) { okx &= cd[j] < 4; x = (x << 2) | (cd[j] & 3u); }
-        if (!okx) continue;
-        for (int j = (int)FF; j >= 1; --j) {           // bases e - 15 - j: in front of X
-            const long q = (long)e - 15 - j;
-            l = (l << 2) | (q >= 0 ? cd[q] & 3u : 0u);
+    // the grid walk, as countc_body schedules it.  K = 27: X = the 16 bases ending at stream position 11 (mod 12), twelve windows.  K = 19 .. 22:
+    // an X every G bases, G windows each.  K = 23 .. 26: three lookups per PAIR of lanes (24 bytes) -- the even lane's X (ends at 23 mod 24)
+    // with NW = K - 15 windows, the odd lane's first X 12 - NW bases in front of its stretch (NW windows: the even lane's last ends and its
+    // own first ones), its second for the rest.  Window w ends at e + w; `avail` = the bases behind X the lane has (the rest are zeros).
+    struct Pos { uint32_t at, period, n_win, avail; };
+    std::vector<Pos> sched;
+    if (KK == 27) sched.push_back({11, 12, 12, 11});
+    else if (KK <= 22) for (uint32_t j = 0; j < 12 / GG; ++j) sched.push_back({(GG * j + 11) % 12, 12, GG, std::min(FF, 12 - GG * j)});
+    else {
+        const uint32_t NW = FF + 1;
+        sched.push_back({23, 24, NW, FF});
+        sched.push_back({11 - (12 - NW), 24, NW, FF});
+        sched.push_back({2 * NW - 1, 24, 24 - 2 * NW, std::min(FF, 24 - 2 * NW)});
+    }
+    for (size_t e = 15; e < n; ++e) {
+        for (const Pos& ps : sched) {
+            if (e % ps.period != ps.at) continue;
+            uint32_t x = 0, l = 0, r = 0, vw = 0;
+            bool okx = true;
+            for (size_t j = e - 15; j <= e; ++j) { okx &= cd[j] < 4; x = (x << 2) | (cd[j] & 3u); }
+            if (!okx) continue;
+            for (int j = (int)FF; j >= 1; --j) {           // bases e - 15 - j: in front of X
+                const long q = (long)e - 15 - j;
+                l = (l << 2) | (q >= 0 ? cd[q] & 3u : 0u);
+            }
+            for (uint32_t j = 1; j <= FF; ++j) r = (r << 2) | (j <= ps.avail && e + j < n ? cd[e + j] & 3u : 0u);
+            for (uint32_t w = 0; w < ps.n_win; ++w) {
+                bool ok = e + w < n && e + w >= KK - 1;
+                for (size_t j = 0; ok && j < KK; ++j) ok = cd[e + w - j] < 4;
+                vw |= (uint32_t)ok << w;
+            }
+            if (vw) m.probe(x, l, r, vw, got_by_id);
         }
-        const uint32_t avail = e % 12 == 11 ? 11u : 10u - (uint32_t)(e % 12);
-        for (uint32_t j = 1; j <= FF; ++j) r = (r << 2) | (j <= avail && e + j < n ? cd[e + j] & 3u : 0u);
-        for (uint32_t w = 0; w < GG; ++w) {
-            bool ok = e + w < n && e + w >= KK - 1;
-            for (size_t j = 0; ok && j < KK; ++j) ok = cd[e + w - j] < 4;
-            vw |= (uint32_t)ok << w;
-        }
-        if (vw) m.probe(x, l, r, vw, got_by_id);
     }
     // the first stream positions (e < 15 never happens for e = 11 only when n is tiny) are covered: windows ending before 26 do not exist
     size_t bad = 0, hits = 0;

@@ -188,11 +188,35 @@ hipError_t launch_ctable_over(ulonglong2* over, uint32_t over_mask, const unsign
 // K = 19 .. 25 (round 5): the same rows, the same twelve bytes per lane, the same queues; a lane looks a 16-mer up every G = 6 (K = 19, 20: 4)
 // of its bases instead of once -- the 16 bases that end G j bases into the lane's stretch, j = 0 .. 12 / G - 1 -- and asks each for the G
 // windows of K bases that end in the G bases behind it.  Flanks of F = K - 16 bases; the bases behind a later X that belong to the next
-// lane are zeros (no window asked for reaches them).  The ends covered are those of K = 27: stream positions 12 L - 1 .. 12 L + 10.
+// lane are zeros (no window asked for reaches them).  The ends covered are those of K = 27: stream positions 12 L - 1 .. 12 L + 10
+// (K = 23 .. 26: by the pair of lanes together, three lookups per pair -- see the loop).
+// One lookup position of a lane for K < 27: the 16-mer that ends D bases into the lane's twelve (D < 0: that many bases in front of them)
+// and the G windows of K bases that end in the G bases behind it.  W2:W1:W0 = the lane's 48-base window (base e from the end of its
+// stretch at bits [2e, 2e + 2)), U = the non-base flags of those bases, oldest first (bit 47 - e).  Every shift is a compile-time constant.
+template <uint32_t K, int D, uint32_t G>
+__device__ __forceinline__ void ct_position(uint32_t W0, uint32_t W1, uint32_t W2, uint64_t U, uint32_t& x, uint32_t& l, uint32_t& r, uint32_t& vm)
+{
+    constexpr uint32_t F = K - 16u, MF = (1u << (2u * F)) - 1u, sh = (uint32_t)(24 - 2 * D), ub = (uint32_t)(36 + D - (int)K);
+    static_assert(sh >= 2u && sh <= 32u && G >= 1u && G <= F + 1u && 36 + D - (int)K >= 0, "position outside the lane's window");
+    const uint64_t Uj = U >> ub;                    // the window that ends w bases behind X spans bits w .. w + K - 1
+    const uint32_t A = (uint32_t)Uj & ((1u << K) - 1u), a = ((uint32_t)(Uj >> K) & ((1u << (G - 1u)) - 1u)) << 1;
+    const uint32_t bad_b = A ? (0xFFFFFFFFu >> __builtin_clz(A)) : 0u;
+    vm = ~(a | (0u - a) | bad_b) & ((1u << G) - 1u);
+    if constexpr (sh < 32u) {
+        x = __builtin_amdgcn_alignbit(W1, W0, sh);
+        l = __builtin_amdgcn_alignbit(W2, W1, sh) & MF;
+    } else {
+        x = W1;
+        l = W2 & MF;
+    }
+    if constexpr (sh >= 2u * F) r = (W0 >> (sh - 2u * F)) & MF;
+    else r = (W0 << (2u * F - sh)) & MF;             // the bases behind X that belong to the next lane: zeros (no window asked for reaches them)
+}
+
 template <uint32_t K>
 __device__ __forceinline__ void countc_body(const RowParams& p, const XTableView& xt)
 {
-    constexpr uint32_t F = K - 16u, G = K == 27u ? 12u : (K <= 20u ? 4u : 6u), NP = 12u / G, MF = (1u << (2u * F)) - 1u;
+    constexpr uint32_t F = K - 16u, G = K == 27u ? 12u : (K <= 20u ? 4u : 6u), NP = 12u / G;
     static_assert(K >= 19u && K <= 27u, "context table: k = 19 .. 27");
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[2048];     // position LUT of count27_kernel (stage_lut27 layout)
     __shared__ __attribute__((aligned(16))) uint2 s_runs[4][CT_RUNQ];
@@ -387,18 +411,9 @@ __device__ __forceinline__ void countc_body(const RowParams& p, const XTableView
             push(marked && (vs & ~found) != 0 && !(VG_DBG(p.dbg) & 8u), cx, cl, cr, vs & ~found, 1u, b0 + 1u);
             while (pend_n >= 64u) pending_batch();
         } else {
-            // the non-base flags of the 48 bases, oldest first (bit u = 47 - e): the window that ends w bases behind the X of sub-position
-            // j spans bits  36 + G j + w - K  ..  35 + G j + w
+            // the non-base flags of the 48 bases, oldest first (bit u = 47 - e)
             const uint64_t U = (uint64_t)(i3 | i2 << 12 | (i1 & 0xFFu) << 24) | (uint64_t)((i1 >> 8) | inv << 4) << 32;
-#pragma unroll
-            for (uint32_t j = 0; j < NP; ++j) {
-                const uint32_t d = G * j, sh = 24u - 2u * d;
-                const uint32_t Uj = (uint32_t)(U >> (36u + d - K));
-                const uint32_t A = Uj & ((1u << K) - 1u), a = ((Uj >> K) & ((1u << (G - 1u)) - 1u)) << 1;
-                const uint32_t bad_b = A ? (0xFFFFFFFFu >> __builtin_clz(A)) : 0u;
-                const uint32_t vm = ~(a | (0u - a) | bad_b) & ((1u << G) - 1u);
-                const uint32_t xr = __builtin_amdgcn_alignbit(W1, W0, sh), lr = __builtin_amdgcn_alignbit(W2, W1, sh) & MF;
-                const uint32_t rr = (sh >= 2u * F ? W0 >> (sh >= 2u * F ? sh - 2u * F : 0u) : W0 << (sh < 2u * F ? 2u * F - sh : 0u)) & MF;
+            auto probe = [&](uint32_t xr, uint32_t lr, uint32_t rr, uint32_t vm) {
                 uint32_t cx, cl, cr, vs;
                 ct_orient(xr, lr, rr, vm, cx, cl, cr, vs, F);
                 const uint32_t b0 = (uint32_t)(((uint64_t)ct_hash(cx) * xt.n_buckets) >> 32);
@@ -407,6 +422,32 @@ __device__ __forceinline__ void countc_body(const RowParams& p, const XTableView
                 look(vm != 0, b0, cx, cl, cr, vs, true, found, marked);
                 push(marked && (vs & ~found) != 0 && !(VG_DBG(p.dbg) & 8u), cx, cl, cr, vs & ~found, 1u, b0 + 1u);
                 while (pend_n >= 64u) pending_batch();
+            };
+            if constexpr (K >= 23u) {
+                // K = 23 .. 26: an entry answers NW = K - 15 >= 8 windows, so a PAIR of lanes (24 ends) needs three lookups, not four: the
+                // even lane asks for the NW ends from the top of its twelve, the odd lane first for the even lane's 12 - NW last ends
+                // together with its own first ones (the 16-mer that ends 12 - NW bases in front of its stretch: all of it is in the odd
+                // lane's window), then for what is left of its own twelve
+                constexpr uint32_t NW = F + 1u, G1 = 24u - 2u * NW;
+                constexpr int BACK = 12 - (int)NW, D1 = 2 * (int)NW - 12;
+                const bool odd_lane = (lane & 1u) != 0;
+                uint32_t xe, le, re, ve, xo, lo_, ro, vo;
+                ct_position<K, 0, NW>(W0, W1, W2, U, xe, le, re, ve);
+                ct_position<K, -BACK, NW>(W0, W1, W2, U, xo, lo_, ro, vo);
+                probe(odd_lane ? xo : xe, odd_lane ? lo_ : le, odd_lane ? ro : re, odd_lane ? vo : ve);
+                ct_position<K, D1, G1>(W0, W1, W2, U, xo, lo_, ro, vo);
+                probe(xo, lo_, ro, odd_lane ? vo : 0u);
+            } else {
+                // K = 19 .. 22: a 16-mer every G = 6 (K <= 20: 4) of the lane's bases
+                uint32_t xr, lr, rr, vm;
+                ct_position<K, 0, G>(W0, W1, W2, U, xr, lr, rr, vm);
+                probe(xr, lr, rr, vm);
+                ct_position<K, (int)G, G>(W0, W1, W2, U, xr, lr, rr, vm);
+                probe(xr, lr, rr, vm);
+                if constexpr (NP == 3u) {
+                    ct_position<K, 2 * (int)G, G>(W0, W1, W2, U, xr, lr, rr, vm);
+                    probe(xr, lr, rr, vm);
+                }
             }
         }
     }
