@@ -321,7 +321,7 @@ int vgmi_hmm_part_set_rows(vgmi_hmm_part *part, uint64_t n, const uint64_t *rows
  * (strings: src/genotype.cpp:760-800) and says which entries of a row lose which haplotypes -- entry fix_j[i] of row rows[r]
  * (fix_off[r] <= i < fix_off[r + 1], ascending in fix_j) loses the haplotypes of fix_mask[i] (bits over the `used` list) -- and the
  * rows are scored again by the emission kernel with those bits cleared. */
-int vgmi_hmm_part_fix_rows(vgmi_hmm_part *part, uint64_t n, const uint64_t *rows, const uint32_t *fix_off, const uint16_t *fix_j,
+int vgmi_hmm_part_fix_rows(vgmi_hmm_part *part, uint64_t n, const uint64_t *rows, const uint32_t *fix_off, const uint32_t *fix_j,
                            const uint16_t *fix_mask);
 int vgmi_hmm_part_calls(vgmi_hmm_part *part, uint32_t ploidy, const uint8_t *keep, uint32_t n_windows, const uint32_t *row,
                         const uint8_t *restart, const void *pow, uint64_t n_steps, const void *uniform, const vgmi_hmm_chain *chains,

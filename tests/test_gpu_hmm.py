@@ -517,6 +517,71 @@ def test_flagged_rows_scored_again_on_the_device_and_plans():
     assert (w1 != 0xFFFFFFFF).sum() > n_rows // 2
 
 
+def test_fix_of_an_entry_beyond_65535_of_its_row():
+    """an entry's index inside its row is 32 bits from sequence_fixes through vgmi_hmm_part_fix_rows to the kernel's test
+    (it was uint16_t: a row of more than 65 535 entries -- the API takes any entry_count; graph2node keeps 128 a node,
+    src/construct_index.cpp:1592-1596 -- had its late fixes refused or applied to entry j mod 65 536).  One row of 70 000 entries, fixes at
+    entries 3, 65 536 + 3 and 69 990: the product spelled out with those haplotypes' bits cleared (src/genotype.cpp:760-800)."""
+    rng = np.random.default_rng(65536)
+    n_hap, bit_len = 5, 1
+    used = np.arange(n_hap, dtype=np.uint8)
+    pairs = list(itertools.combinations_with_replacement(range(n_hap), 2))
+    pos_a = np.array([a for a, _ in pairs], dtype=np.uint8)
+    pos_b = np.array([b for _, b in pairs], dtype=np.uint8)
+    n_gt = len(pairs)
+    top_mask = (1 << n_hap) - 1
+    ave = np.float32(23.5)
+    lower, upper = float(ave) - 1.96 * float(np.sqrt(np.float64(ave))), float(ave) + 1.96 * float(np.sqrt(np.float64(ave)))
+    tables = LD(1) - rng.random(768).astype(LD) * LD(1e-4)          # 70 000 factors stay in range
+    counts = np.array([70000, 40], dtype=np.int64)
+    entry_begin = np.array([0, 70000], dtype=np.uint64)
+    n_entries = int(counts.sum())
+    f = rng.choice([2, 3], size=n_entries).astype(np.uint64)
+    bits = rng.integers(1, 1 << n_hap, size=n_entries).astype(np.uint64)      # bit 7 (the interval flag of bit_len 1) stays clear
+    cov = rng.choice([0, 1, 5, 14, 20, 23, 30, 60], size=n_entries).astype(np.uint8)
+    entries = (f << np.uint64(8)) | (bits << np.uint64(16))
+    gt0 = np.zeros(2, dtype=np.uint16)
+    drop = {3: 0b00101, 65536 + 3: 0b11000, 69990: 0b00011}
+    for j, m in drop.items():
+        bits[j] |= np.uint64(m)                                                 # the haplotypes taken off really carry the k-mer
+    entries = (f << np.uint64(8)) | (bits << np.uint64(16))
+    f_j = np.array(sorted(drop), dtype=np.uint32)
+    fixes = ([0], [0, f_j.size], f_j, [drop[int(j)] for j in f_j])
+    ctx = vgmi.Context(0, buffer_mib=16)
+    try:
+        obs0, n_kept, flags = ctx.hmm_emissions(entries, cov, used, pos_a, pos_b, top_mask, bit_len, ave, lower, upper, tables, entry_begin, counts, gt0)
+        obs1, n_kept1, flags1 = ctx.hmm_emissions(entries, cov, used, pos_a, pos_b, top_mask, bit_len, ave, lower, upper, tables, entry_begin, counts, gt0,
+                                                  fixes=fixes)[:3]
+        with pytest.raises(RuntimeError):      # an index behind the row's last entry is refused, whatever its low 16 bits say
+            ctx.hmm_emissions(entries, cov, used, pos_a, pos_b, top_mask, bit_len, ave, lower, upper, tables, entry_begin, counts, gt0,
+                              fixes=([0], [0, 1], [70000 + 3], [1]))
+    finally:
+        ctx.close()
+    assert np.array_equal(n_kept, n_kept1) and np.array_equal(obs1[1], obs0[1])
+
+    def mld(h, c, ff):
+        cf = np.float32(c)
+        if h > 0 and cf > ave * np.float32(h):
+            return int(ave * np.float32(h)) & 0xFF
+        if h == 0 and cf > ave:
+            return 0 if float(ff) > float(cf) / upper else int(cf / np.float32(ff)) & 0xFF
+        if h == 0:
+            return int(cf / np.float32(ff)) & 0xFF
+        return c
+    pa, pb = pos_a.astype(np.int64), pos_b.astype(np.int64)
+    for fixed, obs in ((False, obs0), (True, obs1)):
+        prod = np.ones(n_gt, dtype=LD)
+        for j in range(70000):
+            c, ff, b = int(cov[j]), int(f[j]), int(bits[j])
+            if fixed:
+                b &= ~drop.get(j, 0)
+            hs = ((b >> pa) & 1) + ((b >> pb) & 1)
+            t = np.array([tables[h * 256 + mld(h, c, ff)] for h in (0, 1, 2)], dtype=LD)
+            prod = prod * t[hs]
+        assert np.array_equal(obs[0], prod), fixed
+    assert not np.array_equal(obs0[0], obs1[0])
+
+
 @pytest.mark.parametrize("ploidy", [3, 4])
 def test_emission_scores_of_polyploid_genotypes_on_the_device(ploidy):
     """vgmi_hmm_emissions_ploidy (round 5): genotypes of three and four haplotypes -- a polyploid sample's are blocks of consecutive

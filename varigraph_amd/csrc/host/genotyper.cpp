@@ -626,7 +626,7 @@ Genotyper::EmitPartPlan::~EmitPartPlan() { vgmi_hmm_plan_free(plan); }
 // device: which entries of the node's list lose which haplotypes.  The fast path's reading of an entry (one 64-bit word: coverage,
 // multiplicity, haplotype bits) -- the device's emission kernel reads the same word the same way.
 void Genotyper::sequence_fixes(const Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& used, uint16_t gt0_mask, double lower, double upper,
-                               const Run& r, std::vector<uint16_t>& fix_j, std::vector<uint16_t>& fix_mask) const
+                               const Run& r, std::vector<uint32_t>& fix_j, std::vector<uint16_t>& fix_mask) const
 {
     const Node& node = chr.nodes[node_i];
     const std::vector<uint16_t>& hap_gt = node.gn->hap_gt;
@@ -669,7 +669,7 @@ void Genotyper::sequence_fixes(const Chrom& chr, uint32_t node_i, const std::vec
         }
         which[p] = (uint8_t)at;
     }
-    uint16_t j = 0;
+    uint32_t j = 0;      // (an entry's index: 32 bits end to end, like entry_count -- graph2node keeps 128 k-mers a node, src/construct_index.cpp:1592-1596, but nothing here relies on it)
     for (uint32_t pos : node.kmers) {
         uint32_t lm;
         const uint32_t om = carried(r.packed[pos], lm) & need;
@@ -2016,7 +2016,8 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                     static const bool fix_on_device = !(getenv("VGH_HMM_FIX_DEVICE") && getenv("VGH_HMM_FIX_DEVICE")[0] == '0');
                     std::vector<std::vector<uint64_t>> fix_rows(nw);
                     std::vector<std::vector<uint32_t>> fix_cnt(nw);
-                    std::vector<std::vector<uint16_t>> fix_j(nw), fix_mask(nw);
+                    std::vector<std::vector<uint32_t>> fix_j(nw);
+                    std::vector<std::vector<uint16_t>> fix_mask(nw);
                     over_windows(g_phase.pass_a, [&](size_t wi) {
                         Chrom& chr = *tasks[t0 + wi].chr;
                         ScoreCtx sctx;
@@ -2065,7 +2066,8 @@ std::string Genotyper::run(const uint8_t* cov, float hap_kmer_coverage, const st
                             throw std::runtime_error(std::string("device HMM emissions: ") + vgmi_last_error(dev_));
                         std::vector<uint64_t> f_rows;
                         std::vector<uint32_t> f_off(1, 0);
-                        std::vector<uint16_t> f_j, f_m;
+                        std::vector<uint32_t> f_j;
+                        std::vector<uint16_t> f_m;
                         for (size_t wi = 0; wi < nw; ++wi) {
                             f_rows.insert(f_rows.end(), fix_rows[wi].begin(), fix_rows[wi].end());
                             for (uint32_t cnt2 : fix_cnt[wi]) f_off.push_back(f_off.back() + cnt2);

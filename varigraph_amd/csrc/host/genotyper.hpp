@@ -160,7 +160,7 @@ private:
     // what the haplotypes' sequences say about a node's under-covered multi-copy k-mers (src/genotype.cpp:760-800), as the entries
     // of the node's list that lose haplotypes (bits over `used`): for the device's second emission launch (vgmi_hmm_part_fix_rows)
     void sequence_fixes(const Chrom& chr, uint32_t node_i, const std::vector<uint16_t>& used, uint16_t gt0_mask, double lower, double upper,
-                        const Run& r, std::vector<uint16_t>& fix_j, std::vector<uint16_t>& fix_mask) const;
+                        const Run& r, std::vector<uint32_t>& fix_j, std::vector<uint16_t>& fix_mask) const;
     std::pair<std::string, std::string> flanks(const Chrom& chr, uint32_t node_i, uint16_t hap, uint16_t alt_gt,
                                                std::string& alt_seq, uint32_t want) const;
     void posterior(Node& n, const std::vector<uint16_t>& top, const Run& r) const;

@@ -3149,7 +3149,7 @@ int vgmi_hmm_emissions_ploidy(vgmi_ctx* c, uint32_t n_gt, uint32_t ploidy, uint3
 // then consults the haplotype's sequence, src/genotype.cpp:760-800), scored again with what the host found there: entry fix_j[i] of
 // row rows[r] (fix_off[r] <= i < fix_off[r + 1], ascending) loses the haplotypes of fix_mask[i] (bits over the `used` list).  The
 // sequences are strings on the host; the products stay on the device.
-int vgmi_hmm_part_fix_rows(vgmi_hmm_part* part, uint64_t n, const uint64_t* rows, const uint32_t* fix_off, const uint16_t* fix_j, const uint16_t* fix_mask)
+int vgmi_hmm_part_fix_rows(vgmi_hmm_part* part, uint64_t n, const uint64_t* rows, const uint32_t* fix_off, const uint32_t* fix_j, const uint16_t* fix_mask)
 {
     if (!part || (n && (!rows || !fix_off))) return VGMI_E_INVALID;
     vgmi_ctx* c = part->c;
@@ -3164,7 +3164,7 @@ int vgmi_hmm_part_fix_rows(vgmi_hmm_part* part, uint64_t n, const uint64_t* rows
     }
     HIPCHK(c, hipSetDevice(c->device));
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_off = up(n * 8), o_j = up(o_off + (n + 1) * 4), o_m = up(o_j + (size_t)n_fix * 2), total = up(o_m + (size_t)n_fix * 2) + 256;
+    const size_t o_off = up(n * 8), o_j = up(o_off + (n + 1) * 4), o_m = up(o_j + (size_t)n_fix * 4), total = up(o_m + (size_t)n_fix * 2) + 256;
     size_t d_bytes = 0;
     uint8_t* d = hmm_block_take(c, total, d_bytes);
     if (!d) return fail(c, VGMI_E_NOMEM, "HMM emissions: not enough device memory");
@@ -3172,13 +3172,13 @@ int vgmi_hmm_part_fix_rows(vgmi_hmm_part* part, uint64_t n, const uint64_t* rows
     hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMemcpyAsync(d, rows, n * 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_off, fix_off, (n + 1) * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && n_fix) e = hipMemcpyAsync(d + o_j, fix_j, (size_t)n_fix * 2, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n_fix) e = hipMemcpyAsync(d + o_j, fix_j, (size_t)n_fix * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess && n_fix) e = hipMemcpyAsync(d + o_m, fix_mask, (size_t)n_fix * 2, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         HmmEmitParams P = part->emit;
         P.fix_rows = reinterpret_cast<const uint64_t*>(d);
         P.fix_off = reinterpret_cast<const uint32_t*>(d + o_off);
-        P.fix_j = reinterpret_cast<const uint16_t*>(d + o_j);
+        P.fix_j = reinterpret_cast<const uint32_t*>(d + o_j);
         P.fix_mask = reinterpret_cast<const uint16_t*>(d + o_m);
         e = launch_hmm_emissions(P, n, st);
     }

@@ -242,7 +242,7 @@ struct HmmEmitParams {
     // their sequence does not hold this under-covered multi-copy k-mer.  Null in the first launch.
     const uint64_t* fix_rows;
     const uint32_t* fix_off;            // per fixed row: its stretch of (fix_j, fix_mask), ascending in fix_j
-    const uint16_t* fix_j;
+    const uint32_t* fix_j;              // 32 bits like entry_count and the kernel's j
     const uint16_t* fix_mask;
 };
 hipError_t launch_hmm_emissions(const HmmEmitParams& P, uint64_t n_rows, hipStream_t st);

@@ -528,7 +528,7 @@ class Context:
         both = None
         try:
             if fixes is not None:
-                f_rows, f_off, f_j, f_m = (np.ascontiguousarray(a, dtype=t) for a, t in zip(fixes, (np.uint64, np.uint32, np.uint16, np.uint16)))
+                f_rows, f_off, f_j, f_m = (np.ascontiguousarray(a, dtype=t) for a, t in zip(fixes, (np.uint64, np.uint32, np.uint32, np.uint16)))
                 self._chk(self._l.vgmi_hmm_part_fix_rows(part, f_rows.size, _ptr(f_rows), _ptr(f_off), _ptr(f_j), _ptr(f_m)))
             obs = np.zeros((n_rows, n_gt), dtype=np.longdouble)
             self._chk(self._l.vgmi_hmm_part_fetch(part, _ptr(obs)))
