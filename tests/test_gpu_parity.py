@@ -560,11 +560,17 @@ def test_saturation_flags_do_not_travel_with_the_table_image(ctx):
                                          (27, {"VGMI_XTABLE": "0", "VGMI_SLOT_ORDER": "1", "VGMI_LOCALITY": "6"}),
                                          (27, {"VGMI_CTABLE": "0"}), (27, {"VGMI_CTABLE": "0", "VGMI_XTABLE_ORDER": "0"}),
                                          (27, {"VGMI_CTABLE": "0", "VGMI_XTABLE_LOAD": "60"}), (27, {"VGMI_CTABLE_LOAD": "90"}),
-                                         (27, {"VGMI_CTABLE_LOAD": "10"})],
+                                         (27, {"VGMI_CTABLE_LOAD": "10"}),
+                                         (27, {"VGMI_CT_DEFER": "1", "VGMI_CT_DEFER_MIN": "0"}), (25, {"VGMI_CT_DEFER": "1", "VGMI_CT_DEFER_MIN": "0"}),
+                                         (22, {"VGMI_CT_DEFER": "1", "VGMI_CT_DEFER_MIN": "0"}), (19, {"VGMI_CT_DEFER": "1", "VGMI_CT_DEFER_MIN": "0"}),
+                                         (27, {"VGMI_CT_DEFER": "1", "VGMI_CT_DEFER_MIN": "0", "VGMI_CT_DEFER_CAP": "40000"}),
+                                         (27, {"VGMI_CT_DEFER": "1", "VGMI_CT_DEFER_MIN": "0", "VGMI_CT_DEFER_ROOM": "500"}),
+                                         (27, {"VGMI_CT_DEFER": "0"})],
                          ids=["k27", "k25", "k23", "k21", "k19", "k24", "k22", "k20", "k26", "k25-generic-kernel", "k21-context-table-crowded", "k23-context-table-sparse", "k27-minimiser-buckets", "k27-random-homes", "k27-buckets-of-8", "k27-16-byte-slots",
                               "k27-16-byte-slots-dense-counters", "k27-16-byte-slots-random-homes", "k27-slots-by-minimiser-offset",
                               "k27-grid-table", "k27-grid-table-ids-by-key-index", "k27-grid-table-crowded", "k27-context-table-crowded",
-                              "k27-context-table-sparse"])
+                              "k27-context-table-sparse", "k27-deferred-counts", "k25-deferred-counts", "k22-deferred-counts", "k19-deferred-counts",
+                              "k27-deferred-counts-buffer-fills-up", "k27-deferred-counts-rooms-fill-up", "k27-counts-in-the-row-loop"])
 def test_large_graph_grid_variant_matches_oracle(k, placement, monkeypatch):
     """> 65 536 keys: k = 27 takes count27c_kernel over the context table (default since round 4; path-ordered counter ids), with
     VGMI_CTABLE=0 count27x_kernel over round 2's grid-16-mer table, with
@@ -572,7 +578,9 @@ def test_large_graph_grid_variant_matches_oracle(k, placement, monkeypatch):
     the context table with flanks of k - 16 bases and countkc_kernel<K> (round 5: a 16-mer looked up every 6 or 4 bases), with
     VGMI_CTABLE_K=0 the generic rows_kernel with the global blocked-Bloom prefilter.  Dense SNPs (1 per 60 bp) give ~35 %
     hit rate: exercises ring pressure, re-queued collision probes and unsaturated counters.  The k = 27 table has
-    8-byte slots in minimiser buckets with per-slot counters by default; the other formats and placements stay covered."""
+    8-byte slots in minimiser buckets with per-slot counters by default; the other formats and placements stay covered.
+    Round 6: VGMI_CT_DEFER=1 -- the context-table kernels write their runs of hits out and two kernels behind them count them by counter
+    region in LDS (vgmi_ctdefer.hip); also with a record buffer and with rooms far too small (the rest is counted by plain atomics)."""
     import torch
     for name, val in (placement or {}).items():
         monkeypatch.setenv(name, val)
@@ -626,15 +634,18 @@ def test_large_graph_grid_variant_matches_oracle(k, placement, monkeypatch):
 
 
 @pytest.mark.parametrize("form,crowded,k", [("ctable", False, 27), ("ctable", True, 27), ("xtable", False, 27), ("xtable", True, 27),
-                                           ("ctable", False, 25), ("ctable", True, 21), ("ctable", False, 19)],
+                                           ("ctable", False, 25), ("ctable", True, 21), ("ctable", False, 19), ("ctable-deferred", False, 27), ("ctable-deferred", True, 23)],
                          ids=["context-table", "context-table-crowded", "grid-table", "grid-table-crowded", "context-table-k25",
-                              "context-table-crowded-k21", "context-table-k19"])
+                              "context-table-crowded-k21", "context-table-k19", "context-table-deferred-counts", "context-table-crowded-k23-deferred-counts"])
 def test_repeat_rich_graph_matches_oracle(form, crowded, k, monkeypatch):
     """A reference made of thousands of diverged copies of one 400-bp element: every 16-mer of the element sits in hundreds
     of different contexts / graph k-mers, far more than its home bucket (line) of the context table (grid-16-mer table) and the
     ones behind it hold.  Those k-mers must be served by the exact overflow table, and nothing may be matched by less than every base."""
     if form == "xtable":
         monkeypatch.setenv("VGMI_CTABLE", "0")
+    if form == "ctable-deferred":      # (round 6: reads of a repeat pile onto few counter regions)
+        monkeypatch.setenv("VGMI_CT_DEFER", "1")
+        monkeypatch.setenv("VGMI_CT_DEFER_MIN", "0")
     if crowded:
         monkeypatch.setenv("VGMI_XTABLE_LOAD", "60")
         monkeypatch.setenv("VGMI_CTABLE_LOAD", "80")

@@ -33,22 +33,42 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the HIP extension cannot be built")
 
 
+VGMI_SOURCES = ("vgmi_kernels.hip", "vgmi_xtable.hip", "vgmi_ctable.hip", "vgmi_ctdefer.hip", "vgmi_ptable.hip", "vgmi_fastq.hip", "vgmi_inflate.hip",
+                "vgmi_gunzip.hip", "vgmi_bloom_bin.hip", "vgmi_hmm.hip", "vgmi_api.cpp")
+
+
 def build_vgmi(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, f) for f in ("vgmi_kernels.hip", "vgmi_xtable.hip", "vgmi_ctable.hip", "vgmi_ptable.hip", "vgmi_fastq.hip", "vgmi_inflate.hip", "vgmi_gunzip.hip", "vgmi_bloom_bin.hip", "vgmi_hmm.hip", "vgmi_api.cpp")]
-    # every header and source of csrc/ (vg_x80.h defines the HMM kernels' arithmetic: editing it must rebuild the library)
-    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp"))) + [
-        os.path.join(ROOT, "include", "vgmi.h")]
-    if not force and not _newer(LIB, deps):
-        return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
-           "-Wno-unused-function", *srcs, "-o", LIB]
+    """One object per source (in parallel, under build/obj; an object is rebuilt when its source or ANY header of csrc/ is newer --
+    vg_x80.h defines the HMM kernels' arithmetic: editing it must rebuild the library), then the link."""
+    from concurrent.futures import ThreadPoolExecutor
+    srcs = [os.path.join(CSRC, f) for f in VGMI_SOURCES]
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(ROOT, "include", "vgmi.h")]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
     if os.environ.get("VGMI_ABLATION") == "1":   # profiling builds only: the VGMI_DBG ablations (wrong results on purpose)
-        cmd.insert(1, "-DVGMI_ABLATION")
-    for d in os.environ.get("VGMI_HIPCC_DEFS", "").split():   # A/B builds of compile-time choices (e.g. -DINFW_WHOLE=0)
-        cmd.insert(1, d)
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, cwd=ROOT)
+        flags.append("-DVGMI_ABLATION")
+    flags += os.environ.get("VGMI_HIPCC_DEFS", "").split()   # A/B builds of compile-time choices (e.g. -DINFW_WHOLE=0)
+    objdir = os.path.join(ROOT, "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    stamp = os.path.join(objdir, "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True
+    todo, objs = [], []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src] + hdrs):
+            todo.append([_hipcc(), *flags, "-c", src, "-o", obj])
+    if not todo and not _newer(LIB, objs):
+        return LIB
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True, cwd=ROOT)
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        list(ex.map(run, todo))
+    open(stamp, "w").write(" ".join(flags))
+    run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
     return LIB
 
 

@@ -118,6 +118,7 @@ struct vgmi_ctx {
     uint8_t* d_cov_node = nullptr;
     unsigned long long* d_hist = nullptr;
     uint32_t* d_status = nullptr;
+    std::map<hipStream_t, std::pair<uint8_t*, size_t>> ctd_scratch;      // deferred counter updates (vgmi_ctdefer.hip): per stream that counts, records + rooms
     std::map<hipStream_t, unsigned long long*> debit_lists;      // even k on the fast path: per stream that counts, VG_DEBIT_LIST positions + a counter
 
     // per-sample state
@@ -854,6 +855,62 @@ int debit_list_of(vgmi_ctx* c, hipStream_t st, unsigned long long** out)
     return VGMI_OK;
 }
 
+// Deferred counter updates of the context-table kernels (vgmi_ctdefer.hip): whether this launch uses them, and the stream's scratch.
+// VGMI_CT_DEFER=0|1 (A/B), VGMI_CT_DEFER_MIN: the smallest block in bytes that defers (smaller ones are not worth two more launches).
+int ctd_prepare(vgmi_ctx* c, size_t n_bytes, hipStream_t st, CtDefer* d)
+{
+    // (read per launch: the test matrix switches them inside one process)
+    const char* const e_on = getenv("VGMI_CT_DEFER");
+    const int on = e_on ? atoi(e_on) : VGMI_CT_DEFER_DEFAULT;
+    const char* const e_min = getenv("VGMI_CT_DEFER_MIN");
+    const size_t min_bytes = e_min ? (size_t)atoll(e_min) : (size_t)8 << 20;
+    *d = CtDefer{};
+    if (!on || !c->tv.xt.cb || n_bytes < min_bytes) return VGMI_OK;
+    const size_t need = ctd_scratch_bytes(n_bytes, c->xt_n_counts, (uint32_t)c->n_cu, d);
+    if (!need) return VGMI_OK;
+    uint8_t* buf = nullptr;
+    size_t have = 0;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        auto it = c->ctd_scratch.find(st);
+        if (it != c->ctd_scratch.end()) {
+            buf = it->second.first;
+            have = it->second.second;
+        }
+    }
+    if (have < need) {
+        // a larger block than this stream has seen: its scratch grows (what is queued on the stream may still use the old one)
+        if (buf) {
+            HIPCHK(c, hipStreamSynchronize(st));
+            (void)hipFree(buf);
+            buf = nullptr;
+        }
+        if (hipMalloc(reinterpret_cast<void**>(&buf), need) != hipSuccess) {      // no memory for it: the plain kernel
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> lk(c->mu);
+            c->ctd_scratch.erase(st);
+            *d = CtDefer{};
+            return VGMI_OK;
+        }
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->ctd_scratch[st] = std::make_pair(buf, need);
+    }
+    ctd_layout(buf, d);
+    HIPCHK(c, launch_ctd_reset(*d, st));
+    return VGMI_OK;
+}
+
+// the count kernel over the context table with or without deferred counter updates
+int launch_ctable_count(vgmi_ctx* c, const RowParams& p, size_t n_bytes, hipStream_t st)
+{
+    CtDefer d;
+    int rc = ctd_prepare(c, n_bytes, st, &d);
+    if (rc) return rc;
+    HIPCHK(c, launch_count27c(p, c->tv.xt, (uint32_t)c->n_cu, st, &d));
+    if (d.rec) HIPCHK(c, launch_ctd_apply(c->tv.xt, d, (uint32_t)c->n_cu, st));
+    return VGMI_OK;
+}
+
 int xt_clamp_if_due(vgmi_ctx* c, size_t n_bytes, hipStream_t st)
 {
     bool due = false;
@@ -940,7 +997,7 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
         if ((c->tv.xt.lines || c->tv.xt.cb) && !c->force_generic) {
             int rcx = xt_clamp_if_due(c, n_bytes, st);
             if (rcx) return rcx;
-            if (c->tv.xt.cb) HIPCHK(c, launch_count27c(p, c->tv.xt, (uint32_t)c->n_cu, st));
+            if (c->tv.xt.cb) { int rcc = launch_ctable_count(c, p, n_bytes, st); if (rcc) return rcc; }
             else HIPCHK(c, launch_count27x(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
             p.tail27 = 2;
             HIPCHK(c, launch_rows(K_MODE_COUNT, c->filter_in_lds, p, 1, block, st));
@@ -968,7 +1025,7 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
             int rcx = xt_clamp_if_due(c, n_bytes, st);
             if (rcx) return rcx;
             if (rows) {
-                if (c->tv.xt.cb) HIPCHK(c, launch_count27c(p, c->tv.xt, (uint32_t)c->n_cu, st));
+                if (c->tv.xt.cb) { int rcc = launch_ctable_count(c, p, n_bytes, st); if (rcc) return rcc; }
                 else HIPCHK(c, launch_count27x(p, c->tv.xt, (uint32_t)c->n_cu * 8, st));
                 emit_from = rows * 768 - 1;
             }
@@ -1032,7 +1089,7 @@ int launch_count(vgmi_ctx* c, const char* d_bases, size_t n_bytes, const uint64_
             int rcl = debit_list_of(c, st, &list);
             if (rcl) return rcl;
             HIPCHK(c, launch_even_debit(p, d_read_off, n_reads, list, VG_DEBIT_LIST, st));
-            HIPCHK(c, launch_count27c(p, c->tv.xt, (uint32_t)c->n_cu, st));
+            { int rcc = launch_ctable_count(c, p, n_bytes, st); if (rcc) return rcc; }
             HIPCHK(c, launch_seq(K_MODE_COUNT, p, d_read_off, n_reads, st));
         } else if (c->fastk_small && c->tv.pt.index && !c->force_generic && n_bytes >= 2048) {
             // k = 20 .. 24 on a small graph: the windows of k bases through count27s_kernel<true, K> (complete pairs of rows), in front of
@@ -1186,6 +1243,7 @@ void vgmi_destroy(vgmi_ctx* c)
     c->bb_cap = 0;
     if (c->d_status) (void)hipFree(c->d_status);
     for (auto& kv : c->debit_lists) (void)hipFree(kv.second);
+    for (auto& kv : c->ctd_scratch) (void)hipFree(kv.second.first);
     if (c->d_hist) (void)hipFree(c->d_hist);
     if (c->reset_done) (void)hipEventDestroy(c->reset_done);
     for (auto& b : c->hmm_blocks) (void)hipFree(b.first);

@@ -213,8 +213,8 @@ __device__ __forceinline__ void ct_position(uint32_t W0, uint32_t W1, uint32_t W
     else r = (W0 << (2u * F - sh)) & MF;             // the bases behind X that belong to the next lane: zeros (no window asked for reaches them)
 }
 
-template <uint32_t K>
-__device__ __forceinline__ void countc_body(const RowParams& p, const XTableView& xt)
+template <uint32_t K, bool DEFER>
+__device__ __forceinline__ void countc_body(const RowParams& p, const XTableView& xt, const CtDefer& df)
 {
     constexpr uint32_t F = K - 16u, G = K == 27u ? 12u : (K <= 20u ? 4u : 6u), NP = 12u / G;
     static_assert(K >= 19u && K <= 27u, "context table: k = 19 .. 27");
@@ -263,6 +263,13 @@ __device__ __forceinline__ void countc_body(const RowParams& p, const XTableView
     // dropped -- the plain form is the fastest: chains of counters aligned to 64-byte sectors 8.62 against 8.57 ms at chr20 class
     // (gpurun_out/r4d); a lane per aligned PAIR of counters and one 64-bit add for both 9.19 = 9.19 (r4g); counters as a difference
     // array over the places -- +1 / -1 at the two ends of a stretch of hits, prefix sums at read-out -- 8.82 against 8.44 (r4i).)
+    // DEFER (round 6; VERDICT r5 #1b): the queued runs do not become atomics here.  They leave the wavefront's ring 64 at a time as ONE
+    // coalesced 512-byte store into a chunk of CTD_CHUNK records the wavefront reserved in `df.rec` (one returning atomic per chunk);
+    // ctd_scatter_kernel / ctd_accumulate_kernel (vgmi_ctdefer.hip) add them up behind this kernel, by counter region, in LDS.
+    // c = min(255, sum) does not depend on the order (src/fastq_kmer.cpp:128-139), so the counters are the same.  A chunk that does not
+    // fit the buffer any more is not written: from then on this wavefront's runs leave as atomics, as in the plain kernel.
+    uint32_t chunk_at = 0, chunk_used = CTD_CHUNK;
+    bool nofit = false;
     auto drain = [&]() {
         const uint32_t take = run_n < 5u ? run_n : 5u;
         const bool have = my_run < take;
@@ -275,6 +282,39 @@ __device__ __forceinline__ void countc_body(const RowParams& p, const XTableView
             __hip_atomic_fetch_add(xt.counts + id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
+    // up to 64 queued runs -> the wavefront's chunk (lanes without a run write a null record: no window set)
+    auto flush = [&]() {
+        if (chunk_used == CTD_CHUNK && !nofit) {
+            uint32_t at = 0;
+            if (lane == 0) at = __hip_atomic_fetch_add(df.cursor, CTD_CHUNK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+            if (at > df.cap - CTD_CHUNK) nofit = true;      // (cap is a multiple of CTD_CHUNK and >= CTD_CHUNK; a cursor that wrapped 2^32 cannot happen: cap + waves * CTD_CHUNK < 2^32, ctd_scratch_bytes)
+            else {
+                chunk_at = at;
+                chunk_used = 0;
+            }
+        }
+        if (nofit) {
+            drain();
+            return;
+        }
+        const uint32_t take = run_n < 64u ? run_n : 64u;
+        uint2 q = make_uint2(0, 0);
+        if (lane < take) q = runs[ring(run_head + lane)];
+        df.rec[chunk_at + chunk_used + lane] = q;
+        run_head = ring(run_head + take);
+        run_n -= take;
+        chunk_used += 64u;
+    };
+    // the three places the plain kernel drains at: with the loads just issued (keep the ring short), for room in the ring, at the end
+    auto relieve_early = [&]() {
+        if constexpr (DEFER) { while (run_n >= 64u) flush(); }
+        else { while (run_n >= 5u) drain(); }
+    };
+    auto relieve_for = [&](uint32_t n) {
+        if constexpr (DEFER) { while (run_n + n > CT_RUNQ) flush(); }
+        else { while (run_n + n > CT_RUNQ) drain(); }
+    };
 
     // One bucket against one context per lane: the matching windows of each entry become a run; returns the windows answered and
     // whether the bucket is marked.  `early`: called with the loads just issued -- the queued runs leave while they are in flight.
@@ -283,8 +323,7 @@ __device__ __forceinline__ void countc_body(const RowParams& p, const XTableView
         const uint32_t* const Bk = reinterpret_cast<const uint32_t*>(xt.cb + (bucket << 2));
         uint4 xs = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         if (act) xs = *reinterpret_cast<const uint4*>(Bk);
-        if (early)
-            while (run_n >= 5u) drain();
+        if (early) relieve_early();
         // ... the rest of the entries whose X is this one (the line is in the vector cache now), and slot 0's of a full bucket for its mark
         const bool q0 = xs.x == cx, q1 = xs.y == cx, q2 = xs.z == cx, q3 = xs.w == cx, full = xs.w != 0xFFFFFFFFu;
         CtEntry c0 = {0xFFFFFFFFu, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
@@ -297,7 +336,7 @@ __device__ __forceinline__ void countc_body(const RowParams& p, const XTableView
         const uint64_t m0 = __ballot(h0 != 0), m1 = __ballot(h1 != 0), m2 = __ballot(h2 != 0), m3 = __ballot(h3 != 0);
         const uint32_t n = (uint32_t)(__builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) + __builtin_popcountll(m3));
         if (n) {
-            while (run_n + n > CT_RUNQ) drain();
+            relieve_for(n);
             // lane order: the entries of neighbouring grid positions (the same unitig, 12 counters on) stay neighbours in the ring
             uint32_t pos = run_head + run_n + below(m0) + below(m1) + below(m2) + below(m3);
             if (h0) runs[ring(pos++)] = make_uint2(c0.d3, h0 | ((c0.d2 >> 12) & 0x1000u));
@@ -452,20 +491,50 @@ __device__ __forceinline__ void countc_body(const RowParams& p, const XTableView
         }
     }
     while (pend_n) pending_batch();
-    while (run_n) drain();
+    if constexpr (DEFER) {
+        while (run_n) flush();
+        if (!nofit)      // the rest of the wavefront's last chunk: null records
+            for (; chunk_used < CTD_CHUNK; chunk_used += 64u) df.rec[chunk_at + chunk_used + lane] = make_uint2(0, 0);
+    } else {
+        while (run_n) drain();
+    }
 }
 
-__global__ __launch_bounds__(256, 8) void count27c_kernel(RowParams p, XTableView xt) { countc_body<27u>(p, xt); }
+__global__ __launch_bounds__(256, 8) void count27c_kernel(RowParams p, XTableView xt) { countc_body<27u, false>(p, xt, CtDefer{}); }
 template <uint32_t K>
-__global__ __launch_bounds__(256, 8) void countkc_kernel(RowParams p, XTableView xt) { countc_body<K>(p, xt); }
+__global__ __launch_bounds__(256, 8) void countkc_kernel(RowParams p, XTableView xt) { countc_body<K, false>(p, xt, CtDefer{}); }
+// the same kernels with their runs of hits written out instead of counted (the counting: vgmi_ctdefer.hip)
+template <uint32_t K>
+__global__ __launch_bounds__(256, 8) void countkc_defer_kernel(RowParams p, XTableView xt, CtDefer df) { countc_body<K, true>(p, xt, df); }
 
-hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t n_cu, hipStream_t st)
+template <uint32_t K>
+static void launch_defer_k(const RowParams& p, const XTableView& t, uint32_t grid, hipStream_t st, const CtDefer& d)
+{
+    hipLaunchKernelGGL(countkc_defer_kernel<K>, dim3(grid), dim3(256), 0, st, p, t, d);
+}
+
+hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t n_cu, hipStream_t st, const CtDefer* defer)
 {
     static const uint32_t wgs = [] {      // workgroups per CU (20 KB of LDS each: 8 fit); VGMI_CT_WGS for A/B
         const char* e = getenv("VGMI_CT_WGS");
         const int v = e ? atoi(e) : 6;      // measured, chr20 class kernel ms: 5 8.96, 6 8.31, 7 8.50, 8 8.62 (gpurun_out/r4d)
         return (uint32_t)(v < 1 ? 1 : v > 8 ? 8 : v);
     }();
+    if (defer && defer->rec) {
+        switch (t.k) {
+            case 27: launch_defer_k<27u>(p, t, n_cu * wgs, st, *defer); break;
+            case 26: launch_defer_k<26u>(p, t, n_cu * wgs, st, *defer); break;
+            case 25: launch_defer_k<25u>(p, t, n_cu * wgs, st, *defer); break;
+            case 24: launch_defer_k<24u>(p, t, n_cu * wgs, st, *defer); break;
+            case 23: launch_defer_k<23u>(p, t, n_cu * wgs, st, *defer); break;
+            case 22: launch_defer_k<22u>(p, t, n_cu * wgs, st, *defer); break;
+            case 21: launch_defer_k<21u>(p, t, n_cu * wgs, st, *defer); break;
+            case 20: launch_defer_k<20u>(p, t, n_cu * wgs, st, *defer); break;
+            case 19: launch_defer_k<19u>(p, t, n_cu * wgs, st, *defer); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (t.k) {
         case 27: hipLaunchKernelGGL(count27c_kernel, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
         case 25: hipLaunchKernelGGL(countkc_kernel<25u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;

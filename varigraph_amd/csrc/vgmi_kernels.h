@@ -266,7 +266,31 @@ hipError_t launch_ctable_build(const XTableView& t, const unsigned long long* ok
                                unsigned long long* over_n, unsigned long long* n_moved, hipStream_t st);
 hipError_t launch_ctable_over(ulonglong2* over, uint32_t over_mask, const unsigned long long* okmer, const uint32_t* over_list, uint64_t n_over,
                               uint32_t k, hipStream_t st);
-hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t n_cu, hipStream_t st);
+// Deferred counter updates of the context-table kernels (round 6, vgmi_ctdefer.hip): the count kernel writes its runs of hits {id0, windows | dir
+// << 12} to `rec` in chunks of CTD_CHUNK records a wavefront reserves (`cursor`, records reserved so far) instead of issuing the atomics in
+// its row loop; ctd_scatter_kernel partitions them by 32 768-counter region (`bin_cursor`, `binned`: n_bins rooms of `room` 4-byte
+// records), ctd_accumulate_kernel adds a region's runs up in LDS and hands the sums to the counters.  rec == nullptr: the plain kernel.
+#define CTD_CHUNK 256u
+#ifndef VGMI_CT_DEFER_DEFAULT
+#define VGMI_CT_DEFER_DEFAULT 1      // (round 6 A/B, chr20 class, nine pairs of processes on three boxes: 7.68-7.78 ms deferred, 7.79-8.37 ms in the row loop)
+#endif
+#define CTD_MAX_BINS 2048u
+struct CtDefer {
+    uint2* rec;
+    uint32_t cap;                 // records `rec` holds, a multiple of CTD_CHUNK
+    unsigned int* cursor;         // records reserved (may pass cap: a chunk that does not fit is not written, its runs leave as atomics)
+    uint32_t n_bins, room;
+    unsigned int* bin_cursor;     // [n_bins * n_wg]: records in the room of (bin, workgroup of the scatter kernel)
+    uint32_t* binned;             // [n_bins * n_wg * room]
+    uint64_t n_counts;
+    uint32_t region, inv;         // counters a region, 2^32 / region rounded up
+    uint32_t n_wg;                // workgroups of the scatter kernel = rooms a bin
+};
+hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t n_cu, hipStream_t st, const CtDefer* defer = nullptr);
+size_t ctd_scratch_bytes(uint64_t n_bytes, uint64_t n_counts, uint32_t n_cu, CtDefer* layout);      // 0: the table has too many counters for one level of bins
+void ctd_layout(uint8_t* scratch, CtDefer* d);
+hipError_t launch_ctd_reset(const CtDefer& d, hipStream_t st);
+hipError_t launch_ctd_apply(const XTableView& t, const CtDefer& d, uint32_t n_cu, hipStream_t st);
 hipError_t launch_xclamp(const XTableView& t, uint64_t n, hipStream_t st);
 hipError_t launch_xcov(const XTableView& t, const uint32_t* id_of_key, uint64_t n, const uint8_t* flag, uint8_t* cov, unsigned long long* hist,
                        hipStream_t st);
