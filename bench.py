@@ -8,7 +8,7 @@ gather + coverage histogram, results left on the device.
 Workload at N=1 (BASELINE.json configs[1], "C2"): the 1 Mb / 1 k SNP / 15-haplotype graph
 (tests/golden/c1/graph.bin.gz, built by the real reference `construct`), one sample of
 50 M 2x150 bp read pairs = 1e8 reads, k = 27, generated on the device by the seeded generator
-(varigraph_amd/csrc/vg_synth.h).  With --gpus N every rank processes its own sample (seed
+(varigraph_amd/csrc/bench/vg_synth.h: libvgsynth.so, bench / test tooling).  With --gpus N every rank processes its own sample (seed
 1000+rank) after ONE RCCL broadcast of the table image from rank 0: weak scaling, no data-path
 collective.
 
@@ -367,16 +367,21 @@ def c4_cli(n_samples, genome, variants, pairs, threads, repeats=2):
     return out
 
 
-def measured_traffic(n_reads):
-    """HBM-side bytes per launch of the count kernel from the committed rocprofv3 PMC passes
-    (profiles/hbm_traffic.json, produced by tools/profile_r1.sh for the same workload)."""
-    p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+def measured_traffic(which, n_reads, kernel):
+    """HBM-side bytes per launch of a count pass from the committed rocprofv3 PMC passes (profiles/hbm_traffic[_c3|_c5|_bloom].json,
+    written by tools/profile_r6.sh + tools/make_traffic_json_r6.py) -- ONLY when the file was measured on this code (sha256 of the
+    library or of its sources), on this kernel and on a launch of this size; anything else is a claim about another build: None."""
+    from varigraph_amd import build
+    p = os.path.join(ROOT, "profiles", {"c2": "hbm_traffic.json"}.get(which, f"hbm_traffic_{which}.json"))
     if not os.path.exists(p):
         return None, None
     t = json.load(open(p))
-    if t.get("reads_per_launch") != n_reads:
+    if t.get("reads_per_launch") != n_reads or (kernel and t.get("kernel") != kernel):
         return None, None
-    return t["bytes_per_launch"], t
+    if t.get("libvgmi_sha256") != build.lib_digest() and t.get("source_sha256") != build.source_digest():
+        return None, None
+    return t["bytes_per_launch"], {k: t.get(k) for k in ("kernel", "libvgmi_sha256", "source_sha256", "fetch_size_kb_raw", "write_size_kb_raw",
+                                                        "breakdown_bytes", "memory_side_requests_per_read", "count_pass_us_per_launch_rocprofv3")}
 
 
 def spawn_ranks(n):
@@ -412,22 +417,32 @@ def main():
                     help="strong scaling: ONE sample of --reads reads sharded over the ranks, raw counters summed "
                          "with one RCCL all-reduce per step (default: one sample per rank, weak scaling)")
     ap.add_argument("--no-c3", action="store_true", help="skip the chr20-class (table in HBM) leg")
-    ap.add_argument("--no-other-k", action="store_true", help="skip the k = 25 / 21 / 22 sub-block of the chr20-class leg")
+    ap.add_argument("--no-other-k", action="store_true", help="skip the k = 25 / 21 / 22 / 28 sub-block of the chr20-class leg")
     ap.add_argument("--c3-reads", type=int, default=24_000_000)
     ap.add_argument("--c3-steps", type=int, default=20)
+    ap.add_argument("--c3-genome", type=int, default=60_000_000, help="(reduced sizes: multi-rank recipes on one GPU)")
+    ap.add_argument("--c3-variants", type=int, default=500_000)
+    ap.add_argument("--c3-contexts", type=int, default=5, help="fresh contexts the chr20-class kernel time is taken over (median, min, max)")
     ap.add_argument("--no-c5", action="store_true", help="skip the whole-genome-class (3 Gb, 5 M SNPs) leg")
     ap.add_argument("--no-bloom", action="store_true", help="skip the construct-side Bloom leg")
     ap.add_argument("--c5-reads", type=int, default=100_000_000)
     ap.add_argument("--c5-steps", type=int, default=10)
+    ap.add_argument("--c5-genome", type=int, default=3_000_000_000)
+    ap.add_argument("--c5-variants", type=int, default=5_000_000)
+    ap.add_argument("--c5-contexts", type=int, default=3)
     ap.add_argument("--verify-reads", type=int, default=1_000_000, help="unsaturated prefix checked against the oracle")
+    ap.add_argument("--unsaturated-reads", type=int, default=3_000_000, help="C2: the first launch of this many reads after a reset (roofline.unsaturated)")
     ap.add_argument("--no-sample-level", action="store_true", help="skip the FASTQ-files-to-counters leg")
     ap.add_argument("--no-c4", action="store_true", help="skip the CLI-level eight-sample leg (BASELINE configs[3] through varigraph-mi)")
     ap.add_argument("--c4-samples", type=int, default=8)
-    ap.add_argument("--c4-pairs", type=int, default=6_000_000)
+    ap.add_argument("--c4-pairs", type=int, default=12_000_000, help="read pairs per sample (SURVEY 8: 30x of 60 Mb = 12 M pairs)")
     ap.add_argument("--c4-threads", type=int, default=10)
+    ap.add_argument("--budget-s", type=float, default=480.0,
+                    help="wall clock for the whole command: a leg whose estimate does not fit what is left is skipped ({'skipped': 'budget'}), the headline never")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
+    t_start = time.perf_counter()
 
     import torch
     from varigraph_amd import build, vgmi
@@ -442,12 +457,15 @@ def main():
     torch.cuda.set_device(local)
     comm_dev = torch.device("cuda", local) if args.backend == "nccl" else torch.device("cpu")
     ctx_dev = torch.device("cuda", local)
+    t_init = None
     if world > 1:
         import torch.distributed as dist
+        t0 = time.perf_counter()
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=ctx_dev)
         else:
             dist.init_process_group("gloo")
+        t_init = time.perf_counter() - t0
     if rank == 0:
         build.build_vgmi()
         build.build_host()
@@ -458,10 +476,60 @@ def main():
     ctx = vgmi.Context(local, buffer_mib=256)
     shard = args.shard_reads and world > 1
 
+    # ---- the line: built up leg by leg; printed ONCE, at the end -- or by the handler below if the command is told to stop earlier
+    out = {}
+    printed = [False]
+
+    def emit():
+        if rank == 0 and out and not printed[0]:
+            printed[0] = True
+            print(json.dumps(out), flush=True)
+
+    if rank == 0:
+        import atexit
+        import signal
+
+        def on_term(signum, frame):
+            out.setdefault("interrupted", f"signal {signum} after {time.perf_counter() - t_start:.0f} s: the legs still to come are absent")
+            emit()
+            os._exit(0 if "value" in out else 1)
+        signal.signal(signal.SIGTERM, on_term)
+        atexit.register(emit)
+
     def fence():
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def agree_max(x):
+        return vdist.max_over_ranks(float(x), dist, comm_dev) if dist else float(x)
+
+    def run_leg(name, estimate_s, fn, where=None):
+        """One optional leg: skipped when its estimate does not fit the budget (the same decision on every rank), a failure inside it is
+        recorded in its block instead of costing the line."""
+        where = out if where is None else where
+        used = agree_max(time.perf_counter() - t_start)
+        if used + estimate_s > args.budget_s:
+            if rank == 0:
+                where[name] = {"skipped": "budget", "seconds_used": round(used, 1), "estimate_s": estimate_s, "budget_s": args.budget_s}
+                log(f"[bench] {name}: skipped (budget)")
+            return None
+        t0 = time.perf_counter()
+        try:
+            res = fn()
+        except Exception as e:      # noqa: BLE001 -- a late leg must not lose the headline
+            import traceback
+            res = {"error": f"{type(e).__name__}: {e}"[:600], "traceback": traceback.format_exc()[-1200:]} if rank == 0 else None
+            try:
+                torch.cuda.empty_cache()
+            except Exception:      # noqa: BLE001
+                pass
+        if rank == 0 and res is not None:
+            if isinstance(res, dict):
+                res.setdefault("leg_seconds", round(time.perf_counter() - t0, 2))
+            where[name] = res
+            log(f"[bench] {name}: {json.dumps(res)[:1500]}")
+        return res
 
     def broadcast_table(ctx):
         """ONE broadcast of the read-only table image from the rank that built it (RCCL over xGMI)."""
@@ -471,35 +539,59 @@ def main():
         t0 = time.perf_counter()
         nbytes = vdist.broadcast_table_image(ctx, dist, rank, comm_dev, ctx_device=ctx_dev)
         fence()
-        return {"bytes": nbytes, "seconds": time.perf_counter() - t0, "backend": "rccl" if args.backend == "nccl" else "gloo"}
+        dt = time.perf_counter() - t0
+        return {"bytes": nbytes, "seconds": dt, "gb_per_s": nbytes / dt / 1e9, "backend": "rccl" if args.backend == "nccl" else "gloo"}
 
-    def generate(haps, seed, first_read, n_reads):
-        cat = np.concatenate(haps)
-        hap_off = np.concatenate([[0], np.cumsum([len(h) for h in haps])]).astype(np.uint64)
-        d_cat = torch.from_numpy(cat).cuda()
+    def haps_to_device(haps):
+        """The sample's haplotypes as one device tensor + offsets.  With several ranks they are built ONCE, on rank 0, and handed on with one
+        broadcast next to the table image's (every rank building the 3 Gb haplotypes on its own was 11 s and 9 GB of host memory per rank)."""
+        if rank == 0:
+            lens = np.array([len(h) for h in haps], dtype=np.int64)
+        if dist:
+            meta = torch.zeros(9, dtype=torch.int64, device=comm_dev)
+            if rank == 0:
+                meta[0] = len(lens)
+                meta[1:1 + len(lens)] = torch.from_numpy(lens)
+            dist.broadcast(meta, src=0)
+            lens = meta[1:1 + int(meta[0])].cpu().numpy()
+        hap_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        d_cat = torch.empty(int(hap_off[-1]), dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            for h, o in zip(haps, hap_off[:-1]):
+                d_cat[int(o):int(o) + len(h)] = torch.from_numpy(h).cuda()
+        if dist:
+            if args.backend == "nccl":
+                dist.broadcast(d_cat, src=0)
+            else:
+                h_cat = d_cat.cpu()
+                dist.broadcast(h_cat, src=0)
+                d_cat.copy_(h_cat)
+        return d_cat, hap_off
+
+    def generate(d_cat, hap_off, seed, first_read, n_reads, on_ctx=None):
         d_block = torch.empty(n_reads * (READ_LEN + 1), dtype=torch.uint8, device="cuda")
         chunk = 8_000_000
         for first in range(0, n_reads, chunk):
             n = min(chunk, n_reads - first)
-            ctx.synth_reads_device(seed, first_read + first, n, READ_LEN, d_cat, hap_off, d_block[first * (READ_LEN + 1):])
-        del d_cat
+            (on_ctx or ctx).synth_reads_device(seed, first_read + first, n, READ_LEN, d_cat, hap_off, d_block[first * (READ_LEN + 1):])
         return d_block
 
-    def timed(step, steps, warmup, min_seconds=1.0):
+    def timed(step, steps, warmup, min_seconds=1.0, on_ctx=None):
         """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.  A timed
         region shorter than `min_seconds` (the caller's --steps of a 5 ms step) is never the whole measurement: the K-step
         region is then repeated and the reported time is the mean over the repeats -- still K steps' worth, each repeat
         bracketed the same way."""
+        c = on_ctx or ctx
         for _ in range(warmup):
             step()
-        ctx.count_kernel_ms()
+        c.count_kernel_ms()
         kernel_ms, launches, total, repeats = 0.0, 0, 0.0, 0
         while True:
             fence()
             t0 = time.perf_counter()
             for _ in range(steps):
                 step()
-                ms, n = ctx.count_kernel_ms()   # HIP events on the stream the count kernel runs on
+                ms, n = c.count_kernel_ms()   # HIP events on the stream the count kernels run on, around the whole count pass of a launch
                 kernel_ms += ms
                 launches += n
             fence()
@@ -512,6 +604,12 @@ def main():
                 break
         timed.repeats = repeats
         return total / repeats, kernel_ms / max(launches, 1)
+
+    def per_rank(x):
+        """a per-rank figure as (min, max) over the ranks"""
+        if not dist:
+            return [x, x]
+        return [-vdist.max_over_ranks(-float(x), dist, comm_dev), vdist.max_over_ranks(float(x), dist, comm_dev)]
 
     def verify(keys, d_block, n_check, k=K, d_off=None):
         """An unsaturated prefix of the sample, counter by counter against the oracle (the checker; outside every
@@ -530,7 +628,40 @@ def main():
                 "keys_nonzero": int((got != 0).sum()), "keys_saturated": int((got == 255).sum()),
                 "distinct_counter_values": int(np.unique(got).size)}
 
-    # ================= C2: the 1 Mb graph (table on-chip), BASELINE.json configs[1] =================
+    def large_kernel():
+        """the count pass of graphs that live in HBM as this build and environment run it"""
+        name = large_kernel_name()
+        if name == "vgk::count27c_kernel" and os.environ.get("VGMI_CT_DEFER", "1") != "0":
+            return "vgk::countkc_defer_kernel<27u>"
+        return name
+
+    def spread_over_contexts(keys, d_block, n, n_ctx, steps):
+        """The count pass's time per launch on FRESH contexts (each its own allocations and table build): the large-table kernels land
+        on one of a few times per placement of their memory, so one context's figure is one draw."""
+        vals = []
+        for _ in range(n_ctx):
+            c2 = vgmi.Context(local, buffer_mib=16)
+            try:
+                if rank == 0 or not dist:
+                    c2.table_upload(keys, K)
+                else:
+                    c2.table_clone_from(ctx)
+                d_cov = torch.empty(c2.table_info()["n_keys"], dtype=torch.uint8, device="cuda")
+                best = []
+                for i in range(steps + 1):
+                    c2.counts_reset()
+                    c2.reads_submit_device(d_block, n * (READ_LEN + 1), n)
+                    c2.counts_finish_device(d_cov, None, None)
+                    ms, _ = c2.count_kernel_ms()
+                    if i:
+                        best.append(ms)
+                vals.append(float(np.mean(best)))
+                del d_cov
+            finally:
+                c2.close()
+        return vals
+
+    # ================= C2: the 1 Mb graph (table on-chip), BASELINE.json configs[1] -- the headline =================
     g = load_graph() if rank == 0 else None
     if rank == 0:
         ctx.table_upload(g["keys"], g["k"])
@@ -546,10 +677,11 @@ def main():
     ctx.flags_upload(hom_flag)
     info = ctx.table_info()
 
-    haps = cohort_haplotypes()
+    haps = cohort_haplotypes() if rank == 0 else None
+    d_cat2, hap_off2 = haps_to_device(haps)
     n_reads = args.reads // world if shard else args.reads
     first_read = rank * n_reads if shard else 0
-    d_block = generate(haps, 1000 if shard else 1000 + rank, first_read, n_reads)
+    d_block = generate(d_cat2, hap_off2, 1000 if shard else 1000 + rank, first_read, n_reads)
     n_bytes = n_reads * (READ_LEN + 1)
     d_cov = torch.empty(max(info["n_keys"], 1), dtype=torch.uint8, device="cuda")
     d_cov_node = torch.empty(max(int(node_off[-1]), 1), dtype=torch.uint8, device="cuda")
@@ -564,27 +696,113 @@ def main():
 
     elapsed, kernel_ms = timed(step, args.steps, args.warmup)
     c2_repeats = timed.repeats
+    kernel_ms_ranks = per_rank(kernel_ms)
     cov_sum = int(d_cov.to(torch.int64).sum().item())
     hist = d_hist.cpu().numpy()
+    # the UNSATURATED rate: the first launch after a reset, short enough that no counter is near the clamp for most of it (the timed
+    # steps above run 15 000 x deep: every counter passes 255 within the first few per cent of a launch, and from then on a hit is
+    # done at its saturation bit -- no slot fetch, no atomic; that steady state IS the configuration BASELINE names, but not the only one)
+    unsat = None
+    if args.unsaturated_reads and not shard:
+        unsat = []
+        for n_u in sorted({min(args.unsaturated_reads, n_reads), min(20_000_000, n_reads)}):
+            vals = []
+            for _ in range(5):
+                ctx.counts_reset()
+                ctx.count_kernel_ms()
+                ctx.reads_submit_device(d_block, n_u * (READ_LEN + 1), n_u)
+                ctx.counts_finish_device(d_cov, d_cov_node, d_hist)
+                ms, _ = ctx.count_kernel_ms()
+                vals.append(ms)
+            unsat.append({"reads": n_u, "kernel_ms": float(np.median(vals)), "kernel_ms_min_max": [min(vals), max(vals)],
+                          "keys_saturated_at_the_end": int((d_cov == 255).sum().item()), "keys": int(info["n_keys"])})
     # hits per read on an unsaturated stretch (the counters clamp at 255): measured, for B_probe
     ver_c2 = verify(g["keys"], d_block, args.verify_reads) if rank == 0 and args.verify_reads else None
     del d_block
     torch.cuda.empty_cache()
 
+    if rank == 0:
+        total_reads = world * n_reads * args.steps
+        value = total_reads / elapsed
+        avg_kernel_s = kernel_ms / 1e3
+        n_node = int(node_off[-1])
+        b_stream = READ_LEN + (info["n_keys"] + n_node) / n_reads   # SURVEY 8d: bases + amortised read-out
+        # hits per read for B_probe: measured on the unsaturated verification prefix (the full sample clamps)
+        hits_per_read = ver_c2["cov_sum"] / ver_c2["reads"] if ver_c2 and not ver_c2["keys_saturated"] else None
+        b_probe = (READ_LEN - K + 1) * 8 + 2 * (hits_per_read if hits_per_read is not None else 0.0)
+        ach = b_stream * n_reads / avg_kernel_s / 1e9
+        ach_probe = (b_stream + b_probe) * n_reads / avg_kernel_s / 1e9
+        traffic, traffic_src = measured_traffic("c2", n_reads, "vgk::count27s_kernel<true, 27u>")
+        for u in unsat or []:
+            b_u = READ_LEN + (info["n_keys"] + n_node) / u["reads"]
+            u["achieved"] = b_u * u["reads"] / (u["kernel_ms"] * 1e-3) / 1e9
+            u["frac"] = u["achieved"] / HBM_PEAK_GBS
+            u["reads_per_s"] = u["reads"] / (u["kernel_ms"] * 1e-3)
+            u["note"] = ("median of 5 first launches after a reset; same B_stream accounting as `frac`; a launch stages its 128 KiB filter once per "
+                         "workgroup (~0.3 ms whatever the block's size), and a graph of 5e4 k-mers saturates under ANY sample of this depth: 3e6 reads "
+                         "leave no counter at the clamp, 2e7 reads most of them")
+        out.update({
+            "metric": "150 bp reads/sec genotyped (k=27)",
+            "value": value, "unit": "reads/s", "n_gpus": world, "world_size": dist.get_world_size() if dist else 1,
+            "steps": args.steps, "warmup": args.warmup,
+            "timed_region": {"repeats_of_the_k_step_region": c2_repeats, "seconds_in_all": elapsed * c2_repeats,
+                             "note": "a K-step region shorter than 1 s is repeated (each repeat bracketed by barrier + "
+                                     "synchronize) and ms_per_step is the mean over the repeats"},
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if shard else "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "C2: 1 Mb ref + 1 k SNP graph (15 haplotypes, 53 734 k-mers), "
+                                   f"{n_reads // 2} read pairs 2x150 bp per sample, k=27, one sample per GPU",
+                       "reads_per_sample": n_reads, "graph_kmers": info["n_keys"], "table_slots": info["n_slots"],
+                       "prefilter_bits": info["filter_bits"], "parallelism": (f"one sample, reads sharded x{world} + all-reduce" if shard else f"sample-per-gpu x{world}")},
+            "table_broadcast": bcast_c2,
+            "rccl": None if not dist else {"nranks": dist.get_world_size(), "backend": "rccl" if args.backend == "nccl" else "gloo",
+                                           "init_process_group_s": t_init, "kernel_ms_min_max_over_ranks": kernel_ms_ranks,
+                                           "table_broadcast_gb_per_s": bcast_c2["gb_per_s"] if bcast_c2 else None},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": b_stream * n_reads,
+                         "kernel": "vgk::count27s_kernel<true, 27u>", "kernel_ms": avg_kernel_s * 1e3,
+                         "unsaturated": unsat,
+                         "bytes_per_read": b_stream,
+                         "note": "C2's 0.43 MB table is on-chip, so the compulsory HBM traffic is the ASCII read stream only (SURVEY 8d B_stream); "
+                                 "the kernel is instruction-issue bound (VALU + LDS; scan 2.7 ms, path-table drain 1.5 ms: DESIGN.md 4.1).  `frac` is the "
+                                 "SATURATED steady state of a 15 000 x sample (every counter at the clamp after the first few per cent of a launch: a hit "
+                                 "ends at its saturation bit); `unsaturated` lists first launches after a reset (3e6 and 2e7 reads), where hits fetch their slots and "
+                                 "bump their counters"},
+            "probe_inclusive_rate": {"achieved": ach_probe, "unit": "GB/s", "bytes_per_read": b_stream + b_probe,
+                                     "hits_per_read_measured": hits_per_read,
+                                     "note": "SURVEY 8d B_stream+B_probe bytes over the same kernel time, for comparison "
+                                             "with the c3 block only: the probes are served on-chip here, so this is NOT "
+                                             "an HBM fraction"},
+            "check": {"cov_sum": cov_sum, "hist_nonzero_bins": int((hist > 0).sum())},
+            "verify": ver_c2,
+            "library": {"libvgmi_sha256": build.lib_digest(), "source_sha256": build.source_digest()},
+        })
+        log("[bench] c2: " + json.dumps({k: out[k] for k in ("value", "ms_per_step", "n_gpus")} | {"frac": out["roofline"]["frac"], "kernel_ms": out["roofline"]["kernel_ms"],
+                                                                                                   "unsaturated": unsat}))
+    del d_cat2
+
     # ================= C3 / C4: the chr20-class graph (table in HBM), BASELINE.json configs[2], [3] =================
-    c3 = None
-    if not args.no_c3 and not shard:
+    state = {}
+
+    def leg_c3():
         from varigraph_amd import synth
         t_g = time.perf_counter()
-        keys3, haps3 = synth.snp_graph(60_000_000, 500_000)   # every rank needs the haplotypes for its sample; the
-        t_g = time.perf_counter() - t_g                        # table itself is built on rank 0 only
+        keys3, haps3 = synth.snp_graph(args.c3_genome, args.c3_variants) if rank == 0 else (None, None)      # built once; the other ranks
+        t_g = time.perf_counter() - t_g                                                                        # receive table image and haplotypes
         if rank == 0:
             ctx.table_upload(keys3, K)
         bcast_c3 = broadcast_table(ctx)
+        t_h = time.perf_counter()
+        d_cat3, hap_off3 = haps_to_device(haps3)
+        t_h = time.perf_counter() - t_h
         info3 = ctx.table_info()
         n3 = args.c3_reads
-        d_block3 = generate(haps3, 99 + rank, 0, n3)
+        d_block3 = generate(d_cat3, hap_off3, 99 + rank, 0, n3)
+        del d_cat3
         d_cov3 = torch.empty(info3["n_keys"], dtype=torch.uint8, device="cuda")
+        state.update(keys3=keys3, d_block3=d_block3, n3=n3)
 
         def step3():
             ctx.counts_reset()
@@ -592,64 +810,77 @@ def main():
             ctx.counts_finish_device(d_cov3, None, None)
 
         el3, kms3 = timed(step3, args.c3_steps, 1)
+        kms3_ranks = per_rank(kms3)
         cov3 = d_cov3.cpu().numpy()
-        if rank == 0:
-            # hits per read, measured: the clamped counters of the full sample (30x: nothing near 255) summed
-            hits3 = float(cov3.astype(np.int64).sum()) / n3
-            b_read3 = READ_LEN + (READ_LEN - K + 1) * 8 + 2 * hits3 + info3["n_keys"] / n3
-            ach3 = b_read3 * n3 / (kms3 * 1e-3) / 1e9
-            tr3 = None
-            p3 = os.path.join(ROOT, "profiles", "hbm_traffic_c3.json")
-            if os.path.exists(p3):
-                tj = json.load(open(p3))
-                if tj.get("reads_per_launch") == n3 and tj.get("kernel") == large_kernel_name():      # a profile of THIS kernel only
-                    tr3 = tj["bytes_per_launch"]
-            c3 = {"workload": f"C3: chr20-class synthetic SNP graph (60 Mb, 500 k SNPs, {info3['n_keys']} k-mers), "
-                              f"{n3 // 2} read pairs 2x150 bp per sample, one sample per GPU",
-                  "value": world * n3 * args.c3_steps / el3, "unit": "reads/s", "steps": args.c3_steps,
-                  "ms_per_step": el3 / args.c3_steps * 1e3, "graph_kmers": info3["n_keys"], "table_slots": info3["n_slots"],
-                  "graph_build_s": t_g, "table_broadcast": bcast_c3,
-                  "context_table": ctx.ctable_info() if ctx.ctable_info()["n_buckets"] else None,
-                  "hits_per_read": hits3, "keys_saturated": int((cov3 == 255).sum()),
-                  "roofline": {"bound": "hbm", "achieved": ach3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach3 / HBM_PEAK_GBS, "traffic": tr3,
-                               "algorithmic_bytes_per_launch": b_read3 * n3, "bytes_per_read": b_read3,
-                               "kernel": large_kernel_name(),
-                               "kernel_ms": kms3,
-                               "note": "SURVEY 8d: B_read = 150 (bases) + 124 x 8 (one key compare per k-mer) + 2 x hits "
-                                       "+ amortised read-out; hits measured from this run's counters"},
-                  "verify": verify(keys3, d_block3, args.verify_reads) if args.verify_reads else None}
-        # the same reads over the graph built for other k (round 5: the context table with flanks of k - 16 bases; even k behind the
-        # pass that takes back what the reference's run counter suppresses): rates next to the k = 27 one above, each oracle-checked
-        if rank == 0 and world == 1 and not args.no_other_k:
-            other = {}
-            for kk in (25, 21, 22):
-                keys_k, _ = synth.snp_graph(60_000_000, 500_000, k=kk)
-                ctx.table_upload(keys_k, kk)
-                d_off_k = (torch.arange(n3 + 1, dtype=torch.int64, device="cuda") * (READ_LEN + 1)) if kk % 2 == 0 else None
-                d_cov_k = torch.empty(len(keys_k), dtype=torch.uint8, device="cuda")
+        del d_cov3
+        # the same launch on fresh contexts: median, min, max (this context's own figure is one of the draws)
+        draws = [kms3] + (spread_over_contexts(keys3, d_block3, n3, args.c3_contexts - 1, 3) if args.c3_contexts > 1 and not dist else [])
+        if rank != 0:
+            return None
+        # hits per read, measured: the clamped counters of the full sample (30x: nothing near 255) summed
+        hits3 = float(cov3.astype(np.int64).sum()) / n3
+        b_read3 = READ_LEN + (READ_LEN - K + 1) * 8 + 2 * hits3 + info3["n_keys"] / n3
+        med3 = float(np.median(draws))
+        ach3 = b_read3 * n3 / (med3 * 1e-3) / 1e9
+        tr3, tr3_src = measured_traffic("c3", n3, large_kernel())
+        return {"workload": f"C3: chr20-class synthetic SNP graph ({args.c3_genome // 1_000_000} Mb, {args.c3_variants} SNPs, {info3['n_keys']} k-mers), "
+                            f"{n3 // 2} read pairs 2x150 bp per sample, one sample per GPU",
+                "value": world * n3 * args.c3_steps / el3, "unit": "reads/s", "steps": args.c3_steps,
+                "ms_per_step": el3 / args.c3_steps * 1e3, "graph_kmers": info3["n_keys"], "table_slots": info3["n_slots"],
+                "graph_build_s": t_g, "table_broadcast": bcast_c3, "haplotypes_to_the_ranks_s": t_h,
+                "context_table": ctx.ctable_info() if ctx.ctable_info()["n_buckets"] else None,
+                "hits_per_read": hits3, "keys_saturated": int((cov3 == 255).sum()),
+                "roofline": {"bound": "hbm", "achieved": ach3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": ach3 / HBM_PEAK_GBS, "traffic": tr3, "traffic_source": tr3_src,
+                             "algorithmic_bytes_per_launch": b_read3 * n3, "bytes_per_read": b_read3,
+                             "kernel": large_kernel(),
+                             "kernel_ms": med3, "kernel_ms_min_max": [min(draws), max(draws)], "kernel_ms_by_context": draws,
+                             "kernel_ms_min_max_over_ranks": kms3_ranks,
+                             "frac_min_max": [b_read3 * n3 / (max(draws) * 1e-3) / 1e9 / HBM_PEAK_GBS, b_read3 * n3 / (min(draws) * 1e-3) / 1e9 / HBM_PEAK_GBS],
+                             "note": "SURVEY 8d: B_read = 150 (bases) + 124 x 8 (one key compare per k-mer) + 2 x hits + amortised read-out; hits measured "
+                                     "from this run's counters.  kernel_ms = HIP events around the WHOLE count pass of a launch (the count kernel, since round 6 "
+                                     "the two kernels that add its runs of hits up by counter region, the ragged tail), median over the timed context and "
+                                     f"{max(0, len(draws) - 1)} fresh ones"},
+                "verify": verify(keys3, d_block3, args.verify_reads) if args.verify_reads else None}
 
-                def step_k():
-                    ctx.counts_reset()
-                    ctx.reads_submit_device(d_block3, n3 * (READ_LEN + 1), n3, d_off_k)
-                    ctx.counts_finish_device(d_cov_k, None, None)
+    def leg_other_k():
+        # the same reads over the graph built for other k (the context table with flanks of k - 16 bases; even k behind the pass that takes
+        # back what the reference's run counter suppresses; k = 28 since round 6): rates next to the k = 27 one above, each oracle-checked
+        from varigraph_amd import synth
+        d_block3, n3 = state["d_block3"], state["n3"]
+        other = {}
+        for kk in (25, 21, 22, 28):
+            keys_k, _ = synth.snp_graph(args.c3_genome, args.c3_variants, k=kk)
+            ctx.table_upload(keys_k, kk)
+            d_off_k = (torch.arange(n3 + 1, dtype=torch.int64, device="cuda") * (READ_LEN + 1)) if kk % 2 == 0 else None
+            d_cov_k = torch.empty(len(keys_k), dtype=torch.uint8, device="cuda")
 
-                el_k, kms_k = timed(step_k, 2, 1, min_seconds=0.2)
-                cinfo_k = ctx.ctable_info()
-                other[str(kk)] = {"reads_per_s": n3 * 2 / el_k, "kernel_ms": kms_k, "graph_kmers": int(len(keys_k)),
-                                  "context_table_buckets": cinfo_k["n_buckets"],
-                                  "verify": verify(keys_k, d_block3, min(args.verify_reads, 200_000), kk, d_off_k) if args.verify_reads else None}
-                del d_cov_k
-            c3["other_k"] = other
-        del d_block3, d_cov3
+            def step_k():
+                ctx.counts_reset()
+                ctx.reads_submit_device(d_block3, n3 * (READ_LEN + 1), n3, d_off_k)
+                ctx.counts_finish_device(d_cov_k, None, None)
+
+            el_k, kms_k = timed(step_k, 2, 1, min_seconds=0.2)
+            cinfo_k = ctx.ctable_info()
+            other[str(kk)] = {"reads_per_s": n3 * 2 / el_k, "kernel_ms": kms_k, "graph_kmers": int(len(keys_k)),
+                              "context_table_buckets": cinfo_k["n_buckets"],
+                              "verify": verify(keys_k, d_block3, min(args.verify_reads, 200_000), kk, d_off_k) if args.verify_reads else None}
+            del d_cov_k
+        return other
+
+    if not args.no_c3 and not shard:
+        run_leg("c3", 25, leg_c3)
+        if rank == 0 and world == 1 and not args.no_other_k and isinstance(out.get("c3"), dict) and "roofline" in out["c3"]:
+            run_leg("other_k", 30, leg_other_k, where=out["c3"])
+        state.clear()
+        torch.cuda.empty_cache()
 
     # ================= C5: the whole-genome-class graph, BASELINE.json configs[4] (single-GPU slice per rank) =================
-    c5 = None
-    if not args.no_c5 and not shard:
+    def leg_c5():
         from varigraph_amd import synth
         torch.cuda.empty_cache()
         t_g = time.perf_counter()
-        keys5, haps5 = synth.snp_graph(3_000_000_000, 5_000_000, want_keys=(rank == 0))
+        keys5, haps5 = synth.snp_graph(args.c5_genome, args.c5_variants) if rank == 0 else (None, None)
         t_g = time.perf_counter() - t_g
         t_u = time.perf_counter()
         if rank == 0:
@@ -657,10 +888,14 @@ def main():
         torch.cuda.synchronize()
         t_u = time.perf_counter() - t_u
         bcast_c5 = broadcast_table(ctx)
+        t_h = time.perf_counter()
+        d_cat5, hap_off5 = haps_to_device(haps5)
+        t_h = time.perf_counter() - t_h
+        del haps5
         info5, xinfo5, cinfo5 = ctx.table_info(), ctx.xtable_info(), ctx.ctable_info()
         n5 = args.c5_reads
-        d_block5 = generate(haps5, 4711 + rank, 0, n5)
-        del haps5
+        d_block5 = generate(d_cat5, hap_off5, 4711 + rank, 0, n5)
+        del d_cat5
         d_cov5 = torch.empty(info5["n_keys"], dtype=torch.uint8, device="cuda")
 
         def step5():
@@ -669,58 +904,61 @@ def main():
             ctx.counts_finish_device(d_cov5, None, None)
 
         el5, kms5 = timed(step5, args.c5_steps, 1)
-        if rank == 0:
-            cov5 = d_cov5.cpu().numpy()
-            hits5 = float(cov5.astype(np.int64).sum()) / n5
-            b_read5 = READ_LEN + (READ_LEN - K + 1) * 8 + 2 * hits5 + info5["n_keys"] / n5
-            ach5 = b_read5 * n5 / (kms5 * 1e-3) / 1e9
-            free_b, total_b = ctx.device_memory()
-            ver5 = None
-            if args.verify_reads:
-                # the oracle's emitted keys of a prefix (vgo_sketch: the reference's state machine), looked up by binary
-                # search in the sorted key list -- a CPU hash table over 2.7e8 keys is not needed for the check
-                sys.path.insert(0, os.path.join(ROOT, "tests"))
-                import oracle_lib
-                m = min(100_000, args.verify_reads, n5)
-                ctx.counts_reset()
-                ctx.reads_submit_device(d_block5, m * (READ_LEN + 1), m)
-                got5, _, _ = ctx.counts_finish()
-                rows = d_block5[: m * (READ_LEN + 1)].cpu().numpy().reshape(m, READ_LEN + 1)
-                emitted = np.concatenate([oracle_lib.sketch(rows[i, :READ_LEN].tobytes(), K) for i in range(m)])
-                pos = np.searchsorted(keys5, emitted)      # np.unique output: sorted
-                pos[pos == keys5.size] = 0
-                idx, cnt = np.unique(pos[keys5[pos] == emitted], return_counts=True)
-                want5 = np.zeros(keys5.size, dtype=np.uint8)
-                want5[idx] = np.minimum(cnt, 255).astype(np.uint8)
-                ver5 = {"reads": m, "oracle_match": bool(np.array_equal(got5, want5)), "cov_sum": int(got5.astype(np.int64).sum()),
-                        "keys_nonzero": int((got5 != 0).sum()), "method": "oracle sketch per read + binary search in the sorted key list"}
-            tr5 = None
-            p5 = os.path.join(ROOT, "profiles", "hbm_traffic_c5.json")
-            if os.path.exists(p5):
-                tj = json.load(open(p5))
-                if tj.get("reads_per_launch") == n5 and tj.get("kernel") == large_kernel_name():
-                    tr5 = tj["bytes_per_launch"]
-            c5 = {"workload": f"C5 single-GPU slice: whole-genome-class synthetic SNP graph (3 Gb, 5 M SNPs, {info5['n_keys']} k-mers, "
-                              f"graph index HBM-resident), {n5 // 2} read pairs 2x150 bp per sample, one sample per GPU",
-                  "value": world * n5 * args.c5_steps / el5, "unit": "reads/s", "steps": args.c5_steps,
-                  "ms_per_step": el5 / args.c5_steps * 1e3, "graph_kmers": info5["n_keys"], "table_slots": info5["n_slots"],
-                  "large_table_gb": (xinfo5["n_lines"] * 128 + cinfo5["n_buckets"] * 64) / 1e9,
-                  "context_table": cinfo5 if cinfo5["n_buckets"] else None,
-                  "xtable_overflow_pairs": xinfo5["overflow_pairs"],
-                  "device_memory_in_use_gb": (total_b - free_b) / 1e9,
-                  "graph_build_s": t_g, "table_upload_s": t_u, "table_broadcast": bcast_c5, "hits_per_read": hits5,
-                  "keys_saturated": int((cov5 == 255).sum()),
-                  "roofline": {"bound": "hbm", "achieved": ach5, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach5 / HBM_PEAK_GBS,
-                               "traffic": tr5, "algorithmic_bytes_per_launch": b_read5 * n5, "bytes_per_read": b_read5,
-                               "kernel": large_kernel_name(), "kernel_ms": kms5,
-                               "note": "same accounting as the c3 block (SURVEY 8d)"},
-                  "verify": ver5}
-        del d_block5, d_cov5
+        kms5_ranks = per_rank(kms5)
+        cov5 = d_cov5.cpu().numpy() if rank == 0 else None
+        del d_cov5
+        free_b, total_b = ctx.device_memory()
+        draws = [kms5] + (spread_over_contexts(keys5, d_block5, n5, args.c5_contexts - 1, 2) if args.c5_contexts > 1 and not dist else [])
+        if rank != 0:
+            return None
+        hits5 = float(cov5.astype(np.int64).sum()) / n5
+        b_read5 = READ_LEN + (READ_LEN - K + 1) * 8 + 2 * hits5 + info5["n_keys"] / n5
+        med5 = float(np.median(draws))
+        ach5 = b_read5 * n5 / (med5 * 1e-3) / 1e9
+        ver5 = None
+        if args.verify_reads:
+            # the oracle's emitted keys of a prefix (vgo_sketch: the reference's state machine), looked up by binary
+            # search in the sorted key list -- a CPU hash table over 2.7e8 keys is not needed for the check
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib
+            m = min(100_000, args.verify_reads, n5)
+            ctx.counts_reset()
+            ctx.reads_submit_device(d_block5, m * (READ_LEN + 1), m)
+            got5, _, _ = ctx.counts_finish()
+            rows = d_block5[: m * (READ_LEN + 1)].cpu().numpy().reshape(m, READ_LEN + 1)
+            emitted = np.concatenate([oracle_lib.sketch(rows[i, :READ_LEN].tobytes(), K) for i in range(m)])
+            pos = np.searchsorted(keys5, emitted)      # np.unique output: sorted
+            pos[pos == keys5.size] = 0
+            idx, cnt = np.unique(pos[keys5[pos] == emitted], return_counts=True)
+            want5 = np.zeros(keys5.size, dtype=np.uint8)
+            want5[idx] = np.minimum(cnt, 255).astype(np.uint8)
+            ver5 = {"reads": m, "oracle_match": bool(np.array_equal(got5, want5)), "cov_sum": int(got5.astype(np.int64).sum()),
+                    "keys_nonzero": int((got5 != 0).sum()), "method": "oracle sketch per read + binary search in the sorted key list"}
+        tr5, tr5_src = measured_traffic("c5", n5, large_kernel_name())
+        return {"workload": f"C5 single-GPU slice: whole-genome-class synthetic SNP graph ({args.c5_genome / 1e9:g} Gb, {args.c5_variants} SNPs, {info5['n_keys']} k-mers, "
+                            f"graph index HBM-resident), {n5 // 2} read pairs 2x150 bp per sample, one sample per GPU",
+                "value": world * n5 * args.c5_steps / el5, "unit": "reads/s", "steps": args.c5_steps,
+                "ms_per_step": el5 / args.c5_steps * 1e3, "graph_kmers": info5["n_keys"], "table_slots": info5["n_slots"],
+                "large_table_gb": (xinfo5["n_lines"] * 128 + cinfo5["n_buckets"] * 64) / 1e9,
+                "context_table": cinfo5 if cinfo5["n_buckets"] else None,
+                "xtable_overflow_pairs": xinfo5["overflow_pairs"],
+                "device_memory_in_use_gb": (total_b - free_b) / 1e9,
+                "graph_build_s": t_g, "table_upload_s": t_u, "table_broadcast": bcast_c5, "haplotypes_to_the_ranks_s": t_h, "hits_per_read": hits5,
+                "keys_saturated": int((cov5 == 255).sum()),
+                "roofline": {"bound": "hbm", "achieved": ach5, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach5 / HBM_PEAK_GBS,
+                             "traffic": tr5, "traffic_source": tr5_src, "algorithmic_bytes_per_launch": b_read5 * n5, "bytes_per_read": b_read5,
+                             "kernel": large_kernel_name(), "kernel_ms": med5, "kernel_ms_min_max": [min(draws), max(draws)], "kernel_ms_by_context": draws,
+                             "kernel_ms_min_max_over_ranks": kms5_ranks,
+                             "note": "same accounting as the c3 block (SURVEY 8d); a table of this many counters keeps its counter updates in the row loop "
+                                     "(vgmi_ctdefer.hip serves up to 6.7e7 counters)"},
+                "verify": ver5}
+
+    if not args.no_c5 and not shard:
+        run_leg("c5", 75, leg_c5)
         torch.cuda.empty_cache()
 
     # ================= construct side: K3 counting-Bloom update and K4 query (15 B per reference k-mer) =================
-    bloom = None
-    if rank == 0 and world == 1 and not args.no_bloom:
+    def leg_bloom():
         G = 60_000_000                                   # the chr20-class reference of config 3 / 4
         m_b, nh_b = vgmi.bloom_params(G - K + 1, 0.01)
         gen = torch.Generator(device="cuda").manual_seed(7)
@@ -741,99 +979,51 @@ def main():
         t_q = time.perf_counter() - t0
         n_km = G - K + 1
         binned = os.environ.get("VGMI_BLOOM_BINNED", "1") != "0"
-        tb = None
-        pb = os.path.join(ROOT, "profiles", "r3_bloom_traffic.json")
-        if os.path.exists(pb) and not binned:
-            tb = json.load(open(pb))
+        tb, tb_src = measured_traffic("bloom", n_km, None) if binned else (None, None)
         # the binned form's own traffic, by construction: the k-mer keys written and read (8 B a position), the positions written and
         # read at both levels of the partition (4 B each), the filter read and written once
         est = 16.0 * G + 16.0 * nh_b * n_km + 2.0 * m_b
-        bloom = {"workload": f"K3: every k-mer of a {G // 1_000_000} Mb random reference (resident in HBM) into BloomFilter(n = G - k + 1, p = 0.01): "
-                             f"{m_b / 1e6:.0f} MB of saturating byte counters, {nh_b} MurmurHash3 positions per k-mer; K4: 1e7 random keys queried",
-                 "add_kmers_per_s": n_km / best_add, "add_seconds": best_add,
-                 "filter_updates_per_s": nh_b * n_km / best_add,
-                 "form": "binned by 128 KiB filter chunk, counted in LDS (vgmi_bloom_bin.hip)" if binned else "direct compare-and-swaps (VGMI_BLOOM_BINNED=0)",
-                 "roofline": {"bound": "hbm", "achieved": 15.0 * n_km / best_add / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": 15.0 * n_km / best_add / 1e9 / HBM_PEAK_GBS, "traffic": tb.get("bytes_per_launch") if tb else None,
-                              "traffic_by_construction": est if binned else None,
-                              "bytes_per_kmer": 15.0,
-                              "kernel": "vgk::bb_scatter1_kernel + bb_scatter2_kernel + bb_accumulate_kernel (+ rows_kernel<1, false> for the k-mers)" if binned
-                                        else "vgk::rows_kernel<2, false>",
-                              "note": ("SURVEY 8d accounting: 1 base + 7 byte read-modify-writes per k-mer, over the whole call (four kernels: "
-                                       "profiles/r4_bloom_rocprofv3_summary.txt).  The direct form is bound by the device's atomic rate (2.3e10 "
-                                       "compare-and-swaps a second of 2.7e10); the binned form moves ~10 x the accounted bytes as streams instead: "
-                                       "DESIGN.md section 4.2b") if binned else
-                                      ("SURVEY 8d accounting: 1 base + 7 byte read-modify-writes per k-mer.  The kernel is bound by random "
-                                       "32-bit compare-and-swaps on a filter far larger than the caches (one 64-byte sector per "
-                                       "byte counter), not by bytes: see DESIGN.md section 6")},
-                 "query_keys_per_s_pcie_inclusive": qk.size / t_q, "query_hits": int(nz.sum())}
         del seq
         torch.cuda.empty_cache()
+        return {"workload": f"K3: every k-mer of a {G // 1_000_000} Mb random reference (resident in HBM) into BloomFilter(n = G - k + 1, p = 0.01): "
+                            f"{m_b / 1e6:.0f} MB of saturating byte counters, {nh_b} MurmurHash3 positions per k-mer; K4: 1e7 random keys queried",
+                "add_kmers_per_s": n_km / best_add, "add_seconds": best_add,
+                "filter_updates_per_s": nh_b * n_km / best_add,
+                "form": "binned by 128 KiB filter chunk, counted in LDS (vgmi_bloom_bin.hip)" if binned else "direct compare-and-swaps (VGMI_BLOOM_BINNED=0)",
+                "roofline": {"bound": "hbm", "achieved": 15.0 * n_km / best_add / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": 15.0 * n_km / best_add / 1e9 / HBM_PEAK_GBS, "traffic": tb, "traffic_source": tb_src,
+                             "traffic_by_construction": est if binned else None,
+                             "bytes_per_kmer": 15.0,
+                             "kernel": "vgk::bb_scatter1_kernel + bb_scatter2_kernel + bb_accumulate_kernel (+ rows_kernel<1, false> for the k-mers)" if binned
+                                       else "vgk::rows_kernel<2, false>",
+                             "note": ("SURVEY 8d accounting: 1 base + 7 byte read-modify-writes per k-mer, over the whole call.  The direct form is bound by "
+                                      "the device's atomic rate (2.3e10 compare-and-swaps a second of 2.7e10); the binned form moves several times the accounted "
+                                      "bytes as streams instead: DESIGN.md 4.3b") if binned else
+                                     ("SURVEY 8d accounting: 1 base + 7 byte read-modify-writes per k-mer.  The kernel is bound by random "
+                                      "32-bit compare-and-swaps on a filter far larger than the caches (one 64-byte sector per "
+                                      "byte counter), not by bytes: see DESIGN.md section 6")},
+                "query_keys_per_s_pcie_inclusive": qk.size / t_q, "query_hits": int(nz.sum())}
 
-    if rank == 0:
-        total_reads = world * n_reads * args.steps
-        value = total_reads / elapsed
-        avg_kernel_s = kernel_ms / 1e3
-        n_node = int(node_off[-1])
-        b_stream = READ_LEN + (info["n_keys"] + n_node) / n_reads   # SURVEY 8d: bases + amortised read-out
-        # hits per read for B_probe: measured on the unsaturated verification prefix (the full sample clamps)
-        hits_per_read = ver_c2["cov_sum"] / ver_c2["reads"] if ver_c2 and not ver_c2["keys_saturated"] else None
-        b_probe = (READ_LEN - K + 1) * 8 + 2 * (hits_per_read if hits_per_read is not None else 0.0)
-        ach = b_stream * n_reads / avg_kernel_s / 1e9
-        ach_probe = (b_stream + b_probe) * n_reads / avg_kernel_s / 1e9
-        traffic, traffic_src = measured_traffic(n_reads)
-        out = {
-            "metric": "150 bp reads/sec genotyped (k=27)",
-            "value": value, "unit": "reads/s", "n_gpus": world, "world_size": dist.get_world_size() if dist else 1,
-            "steps": args.steps, "warmup": args.warmup,
-            "timed_region": {"repeats_of_the_k_step_region": c2_repeats, "seconds_in_all": elapsed * c2_repeats,
-                             "note": "a K-step region shorter than 1 s is repeated (each repeat bracketed by barrier + "
-                                     "synchronize) and ms_per_step is the mean over the repeats"},
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if shard else "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "C2: 1 Mb ref + 1 k SNP graph (15 haplotypes, 53 734 k-mers), "
-                                   f"{n_reads // 2} read pairs 2x150 bp per sample, k=27, one sample per GPU"
-                                   + ("" if c3 is None else "; c3 block: chr20-class graph (60 Mb, 500 k SNPs), 12 M pairs per sample"),
-                       "reads_per_sample": n_reads, "graph_kmers": info["n_keys"], "table_slots": info["n_slots"],
-                       "prefilter_bits": info["filter_bits"], "parallelism": (f"one sample, reads sharded x{world} + all-reduce" if shard else f"sample-per-gpu x{world}")},
-            "table_broadcast": bcast_c2,
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": b_stream * n_reads,
-                         "kernel": "vgk::count27s_kernel<true, 27u>", "kernel_ms": avg_kernel_s * 1e3,
-                         # (the configurations whose table lives in HBM, inside the object the driver's record keeps: their own blocks carry the rest)
-                         **({} if c3 is None else {"c3_frac_kernel": c3["roofline"]["frac"], "c3_kernel_ms": c3["roofline"]["kernel_ms"]}),
-                         **({} if c5 is None else {"c5_frac_kernel": c5["roofline"]["frac"], "c5_kernel_ms": c5["roofline"]["kernel_ms"]}),
-                         "bytes_per_read": b_stream,
-                         "note": "C2's 0.43 MB table is on-chip, so the compulsory HBM traffic is the ASCII "
-                                 "read stream only (SURVEY 8d B_stream); the kernel is instruction-issue bound "
-                                 "(VALU + LDS; scan 2.7 ms, path-table drain 1.5 ms: DESIGN.md section 6.0.1)"},
-            "probe_inclusive_rate": {"achieved": ach_probe, "unit": "GB/s", "bytes_per_read": b_stream + b_probe,
-                                     "hits_per_read_measured": hits_per_read,
-                                     "note": "SURVEY 8d B_stream+B_probe bytes over the same kernel time, for comparison "
-                                             "with the c3 block only: the probes are served on-chip here, so this is NOT "
-                                             "an HBM fraction"},
-            "check": {"cov_sum": cov_sum, "hist_nonzero_bins": int((hist > 0).sum())},
-            "verify": ver_c2,
-        }
-        if c3 is not None:
-            out["c3"] = c3
-        if c5 is not None:
-            out["c5"] = c5
-        if bloom is not None:
-            out["bloom"] = bloom
-        if world == 1 and not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
-            out["cpu_baseline"] = cpu_baseline(haps, args.cpu_reads, cores)
-        if world == 1 and not args.no_sample_level:
-            out["sample_level"] = sample_level(ctx, haps, out.get("cpu_baseline"))
+    if rank == 0 and world == 1 and not args.no_bloom:
+        run_leg("bloom", 10, leg_bloom)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        run_leg("cpu_baseline", 50, lambda: cpu_baseline(haps, args.cpu_reads, os.cpu_count() or 1))
+    if rank == 0 and world == 1 and not args.no_sample_level:
+        run_leg("sample_level", 45, lambda: sample_level(ctx, haps, out.get("cpu_baseline") if isinstance(out.get("cpu_baseline"), dict) else None))
     ctx.close()
     if rank == 0:
+        for w in ("c3", "c5"):      # (the configurations whose table lives in HBM, inside the object the driver's record keeps: their own blocks carry the rest)
+            b = out.get(w)
+            if isinstance(b, dict) and "roofline" in b:
+                out["roofline"][f"{w}_frac_kernel"] = b["roofline"]["frac"]
+                out["roofline"][f"{w}_kernel_ms"] = b["roofline"]["kernel_ms"]
+                out["roofline"][f"{w}_kernel_ms_min_max"] = b["roofline"]["kernel_ms_min_max"]
         if world == 1 and not args.no_c4:
             torch.cuda.empty_cache()
-            out["c4"] = c4_cli(args.c4_samples, 60_000_000, 500_000, args.c4_pairs, args.c4_threads)
-        print(json.dumps(out), flush=True)
+            run_leg("c4", 20 + 3 * args.c4_pairs / 1e6, lambda: c4_cli(args.c4_samples, 60_000_000, 500_000, args.c4_pairs, args.c4_threads))
+        out["wall_s"] = round(time.perf_counter() - t_start, 1)
+        emit()
     if dist:
         dist.destroy_process_group()
 

@@ -349,22 +349,7 @@ int vgmi_hmm_tallies(vgmi_ctx *ctx, uint64_t n_rows, const uint64_t *entry_begin
 int vgmi_hmm_part_fetch(vgmi_hmm_part *part, void *obs_out);
 void vgmi_hmm_part_free(vgmi_hmm_part *part);
 
-/* ---- bench / test tooling (not part of the reference seam) -------------------------------
- * Seeded synthetic reads (varigraph_amd/csrc/vg_synth.h) written straight into device memory:
- * reads [first_read, first_read+n_reads) of the stream `seed`, each `read_len` bases + '\n'.
- * dev_haps: n_hap device pointers' worth of ASCII haplotypes, given as one concatenated device
- * buffer `dev_hap_cat` with offsets hap_off[n_hap+1] (host array). */
-int vgmi_synth_reads_device(vgmi_ctx *ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads,
-                            uint32_t read_len, const char *dev_hap_cat, const uint64_t *host_hap_off,
-                            uint32_t n_hap, char *dev_out);
-/* same generator on the host (no device needed; ctx may be NULL) */
-int vgmi_synth_reads_host(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
-                          const char *hap_cat, const uint64_t *hap_off, uint32_t n_hap, char *out);
-int vgmi_synth_reference_host(uint64_t seed, uint64_t len, char *out);
-/* keys (hash64(canonical) << 8 | k) of the 2k k-mers covering each SNP site, reference allele then alternative:
- * keys_out[(2 * site + allele) * k + w]; neighbouring sites stay on the reference (large-table workloads) */
-int vgmi_synth_snp_keys_host(const char *ref, uint64_t ref_len, const uint64_t *pos, const char *alts,
-                             uint64_t n_sites, uint32_t k, uint64_t *keys_out);
+/* (bench / test tooling -- the seeded synthetic workloads -- lives in libvgsynth.so, varigraph_amd/csrc/bench/vgsynth.h: not part of this ABI) */
 
 #ifdef __cplusplus
 }

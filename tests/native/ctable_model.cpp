@@ -20,8 +20,9 @@
 
 #include "vgmi_ctable.h"
 
-static const uint64_t M54 = (1ULL << 54) - 1;
-static uint32_t KK = 27, FF = 11, GG = 12;      // k, flank bases, grid spacing
+static const uint64_t M54 = (1ULL << 56) - 1;      // the k-mer bits of an okmer word (k <= 28; 54 until round 6)
+static const uint32_t OKF = 56;                     // ... first of its unitig at bit 56, k-mers behind it from bit 57
+static uint32_t KK = 27, FF = 11, GG = 12, FT = 11, EX = 0;      // k, flank bases an entry stores, grid spacing, k - 16, k - 16 - FF (k = 28: 1)
 static uint64_t MK = M54;                       // 2 k bits
 static const uint32_t NONE = 0xFFFFFFFFu;
 
@@ -124,7 +125,7 @@ struct Model {
                 if ((pkx >> 31) != nxo || (pkx & 0x7FFFFFFFu) != q + 1u) break;
                 cur = nx; o = nxo; ++q; ++cnt;
             }
-            okmer[p] = Kw | (uint64_t)first << 54 | (uint64_t)cnt << 55;
+            okmer[p] = Kw | (uint64_t)first << OKF | (uint64_t)cnt << (OKF + 1);
             id_of_key[i] = p;
             n_unitigs += first;
         }
@@ -134,21 +135,21 @@ struct Model {
     void build(double load)
     {
         const size_t n = keys.size();
-        n_entries = n + FF * n_unitigs;
+        n_entries = n + (KK == 28 ? 10 : FT) * n_unitigs;      // (k = 28: a unitig's first and last occurrence have no window an entry can hold)
         n_buckets = (uint64_t)((double)n_entries / (4.0 * load)) + 1;
         CtBucket empty;
         memset(&empty, 0, sizeof empty);
         for (auto& x : empty.x) x = 0xFFFFFFFFu;
         cb.assign(n_buckets + CT_HOPS, empty);
         for (size_t p = 0; p < n; ++p)
-            for (uint32_t o = 0; o <= FF; ++o) {
+            for (uint32_t o = 0; o <= FT; ++o) {
                 const uint64_t ok = okmer[p];
-                const bool first = (ok >> 54) & 1;
-                if (o != FF && !first) continue;
-                const uint32_t rem = (uint32_t)(ok >> 55) & 15u;
+                const bool first = (ok >> OKF) & 1;
+                if (o != FT && !first) continue;
+                const uint32_t rem = (uint32_t)(ok >> (OKF + 1)) & 15u;
                 const uint32_t n_win = (o < rem ? o : rem) + 1u;
                 CtEntry e[2];
-                uint32_t keep = 0xFFFu;      // ct_insert_kernel: even k, no window bit for a k-mer that is its own reverse complement
+                uint32_t keep = 0x1FFFu;      // ct_insert_kernel: even k, no window bit for a k-mer that is its own reverse complement
                 if (!(KK & 1u))
                     for (uint32_t j = 0; j < n_win; ++j) {
                         const uint64_t kw = okmer[p + j] & M54;
@@ -193,7 +194,7 @@ struct Model {
     void probe(uint32_t x, uint32_t l, uint32_t r, uint32_t vw, std::vector<uint32_t>& counts) const
     {
         uint32_t cx, cl, cr, vs;
-        ct_orient(x, l, r, vw, cx, cl, cr, vs, FF);
+        ct_orient(x, l, r, vw, cx, cl, cr, vs, FF, EX);
         const uint64_t b0 = ((uint64_t)ct_hash(cx) * n_buckets) >> 32;
         uint32_t found = 0;
         for (uint32_t hop = 0;; ++hop) {
@@ -201,7 +202,7 @@ struct Model {
             for (int q = 0; q < 4; ++q) {
                 if (B.x[q] != cx) continue;
                 const CtEntry e = {B.x[q], B.rest[q][0], B.rest[q][1], B.rest[q][2]};
-                uint32_t h = ct_match(e, cx, cl, cr, FF) & vs;
+                uint32_t h = ct_match(e, cx, cl, cr, FF, EX) & vs;
                 if (h & found) { fprintf(stderr, "window matched twice\n"); exit(2); }
                 found |= h;
                 while (h) {
@@ -235,7 +236,7 @@ struct Model {
             for (int q = 0; q < 4; ++q) {
                 if (B.x[q] != cx) continue;
                 const CtEntry e = {B.x[q], B.rest[q][0], B.rest[q][1], B.rest[q][2]};
-                const uint32_t h = ct_match(e, cx, cl, cr, FF) & vs;
+                const uint32_t h = ct_match(e, cx, cl, cr, FF, EX) & vs;
                 if (h) return ct_id(e, ct_ctz(h));
             }
             if (B.x[3] == 0xFFFFFFFFu || !(B.rest[0][1] & ct_mark(cx))) return NONE;
@@ -268,8 +269,10 @@ int main(int argc, char** argv)
     const double load = (argc > 5 ? atoi(argv[5]) : 40) / 100.0;
     const size_t copies = argc > 6 ? strtoull(argv[6], 0, 10) : 0;
     if (argc > 7) KK = (uint32_t)atoi(argv[7]);
-    if (KK < 19 || KK > 27) { fprintf(stderr, "k = 19 .. 27\n"); return 2; }
-    FF = KK - 16;
+    if (KK < 19 || KK > 28) { fprintf(stderr, "k = 19 .. 28\n"); return 2; }
+    FT = KK - 16;
+    FF = ct_flank(KK);
+    EX = ct_excess(KK);
     GG = KK == 27 ? 12 : KK <= 20 ? 4 : 6;      // (even k: the table's algebra under the windows-of-bases rule; the reference's run counter is the device pass's business)
     MK = (1ULL << (2 * KK)) - 1;
     std::mt19937_64 rng(seed);
@@ -367,7 +370,11 @@ int main(int argc, char** argv)
     struct Pos { uint32_t at, period, n_win, avail; };
     std::vector<Pos> sched;
     if (KK == 27) sched.push_back({11, 12, 12, 11});
-    else if (KK <= 22) for (uint32_t j = 0; j < 12 / GG; ++j) sched.push_back({(GG * j + 11) % 12, 12, GG, std::min(FF, 12 - GG * j)});
+    else if (KK == 28) {      // windows 1 .. 11 behind an X: the schedule of K = 26 with every X one base earlier
+        sched.push_back({22, 24, 12, 11});
+        sched.push_back({9, 24, 12, 11});
+        sched.push_back({20, 24, 3, 3});
+    } else if (KK <= 22) for (uint32_t j = 0; j < 12 / GG; ++j) sched.push_back({(GG * j + 11) % 12, 12, GG, std::min(FF, 12 - GG * j)});
     else {
         const uint32_t NW = FF + 1;
         sched.push_back({23, 24, NW, FF});
@@ -391,6 +398,7 @@ int main(int argc, char** argv)
                 for (size_t j = 0; ok && j < KK; ++j) ok = cd[e + w - j] < 4;
                 vw |= (uint32_t)ok << w;
             }
+            vw &= ~((1u << EX) - 1u);      // (k = 28: no window ends at X's last base)
             if (vw) m.probe(x, l, r, vw, got_by_id);
         }
     }

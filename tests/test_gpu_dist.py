@@ -82,8 +82,12 @@ def test_bench_starts_its_own_ranks():
     env = dict(os.environ, VGMI_BENCH_DEVICE="0")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
+    # (round 6: the chr20-class and whole-genome-class legs run on both ranks too, at reduced size -- graph and haplotypes built on rank 0
+    # only, table image and haplotypes handed on; at their stated sizes they are tests/test_gpu_large.py's and the default bench line's)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--reads", "4000000", "--no-sample-level",
-                        "--steps", "3", "--warmup", "1", "--no-c3", "--no-c5", "--verify-reads", "200000"],      # (the c3 / c5 legs of two ranks on one device: 45 s of this suite's clock for what tests/test_gpu_large.py holds)
+                        "--steps", "3", "--warmup", "1", "--verify-reads", "200000",
+                        "--c3-genome", "4000000", "--c3-variants", "66000", "--c3-reads", "1000000", "--c3-steps", "2",
+                        "--c5-genome", "8000000", "--c5-variants", "100000", "--c5-reads", "1000000", "--c5-steps", "2"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -92,4 +96,9 @@ def test_bench_starts_its_own_ranks():
     assert out["n_gpus"] == 2 and out["world_size"] == 2
     assert out["table_broadcast"]["bytes"] > 1_000_000
     assert out["verify"]["oracle_match"] is True
+    assert out["rccl"]["nranks"] == 2 and len(out["rccl"]["kernel_ms_min_max_over_ranks"]) == 2
+    for leg in ("c3", "c5"):
+        assert "error" not in out[leg] and "skipped" not in out[leg], out[leg]
+        assert out[leg]["verify"]["oracle_match"] is True and out[leg]["table_broadcast"]["bytes"] > 1_000_000
+        assert out[leg]["value"] > 0 and out[leg]["roofline"]["kernel_ms"] > 0
     assert out["value"] > 0 and out["scaling"] == "weak"

@@ -552,7 +552,7 @@ def test_saturation_flags_do_not_travel_with_the_table_image(ctx):
 
 
 # ----------------------------------------------------------------------------- large graphs (global grid bitmap)
-@pytest.mark.parametrize("k,placement", [(27, None), (25, None), (23, None), (21, None), (19, None), (24, None), (22, None), (20, None), (26, None), (25, {"VGMI_CTABLE_K": "0"}),
+@pytest.mark.parametrize("k,placement", [(27, None), (25, None), (23, None), (21, None), (19, None), (24, None), (22, None), (20, None), (26, None), (28, None), (28, {"VGMI_CTABLE_LOAD": "90"}), (28, {"VGMI_CT_DEFER": "0"}), (25, {"VGMI_CTABLE_K": "0"}),
                                          (21, {"VGMI_CTABLE_LOAD": "90"}), (23, {"VGMI_CTABLE_LOAD": "10"}), (27, {"VGMI_XTABLE": "0"}), (27, {"VGMI_XTABLE": "0", "VGMI_LOCALITY": "0"}),
                                          (27, {"VGMI_XTABLE": "0", "VGMI_LOCALITY": "3"}),
                                          (27, {"VGMI_WIDE_SLOTS": "1"}), (27, {"VGMI_WIDE_SLOTS": "1", "VGMI_DENSE_COUNTS": "1"}),
@@ -566,7 +566,7 @@ def test_saturation_flags_do_not_travel_with_the_table_image(ctx):
                                          (27, {"VGMI_CT_DEFER": "1", "VGMI_CT_DEFER_MIN": "0", "VGMI_CT_DEFER_CAP": "40000"}),
                                          (27, {"VGMI_CT_DEFER": "1", "VGMI_CT_DEFER_MIN": "0", "VGMI_CT_DEFER_ROOM": "500"}),
                                          (27, {"VGMI_CT_DEFER": "0"})],
-                         ids=["k27", "k25", "k23", "k21", "k19", "k24", "k22", "k20", "k26", "k25-generic-kernel", "k21-context-table-crowded", "k23-context-table-sparse", "k27-minimiser-buckets", "k27-random-homes", "k27-buckets-of-8", "k27-16-byte-slots",
+                         ids=["k27", "k25", "k23", "k21", "k19", "k24", "k22", "k20", "k26", "k28", "k28-context-table-crowded", "k28-counts-in-the-row-loop", "k25-generic-kernel", "k21-context-table-crowded", "k23-context-table-sparse", "k27-minimiser-buckets", "k27-random-homes", "k27-buckets-of-8", "k27-16-byte-slots",
                               "k27-16-byte-slots-dense-counters", "k27-16-byte-slots-random-homes", "k27-slots-by-minimiser-offset",
                               "k27-grid-table", "k27-grid-table-ids-by-key-index", "k27-grid-table-crowded", "k27-context-table-crowded",
                               "k27-context-table-sparse", "k27-deferred-counts", "k25-deferred-counts", "k22-deferred-counts", "k19-deferred-counts",
@@ -609,8 +609,8 @@ def test_large_graph_grid_variant_matches_oracle(k, placement, monkeypatch):
             x = c.ctable_info()
             if placement and placement.get("VGMI_CTABLE_K") == "0":
                 assert x["n_buckets"] == 0, x
-            else:
-                assert x["n_buckets"] > 0 and x["n_entries"] == keys.size + (k - 16) * x["n_unitigs"], x
+            else:      # (k = 28, round 6: a unitig's first and last sixteen-mer have no window an entry of 11 + 16 + 11 bases can hold)
+                assert x["n_buckets"] > 0 and x["n_entries"] == keys.size + (10 if k == 28 else k - 16) * x["n_unitigs"], x
         c.counts_reset()
         c.reads_submit(block, n_reads)               # chunked through the 16 MiB staging buffers
         cov, _, _ = c.counts_finish()
@@ -634,9 +634,9 @@ def test_large_graph_grid_variant_matches_oracle(k, placement, monkeypatch):
 
 
 @pytest.mark.parametrize("form,crowded,k", [("ctable", False, 27), ("ctable", True, 27), ("xtable", False, 27), ("xtable", True, 27),
-                                           ("ctable", False, 25), ("ctable", True, 21), ("ctable", False, 19), ("ctable-deferred", False, 27), ("ctable-deferred", True, 23)],
+                                           ("ctable", False, 25), ("ctable", True, 21), ("ctable", False, 19), ("ctable-deferred", False, 27), ("ctable-deferred", True, 23), ("ctable", False, 28), ("ctable", True, 28)],
                          ids=["context-table", "context-table-crowded", "grid-table", "grid-table-crowded", "context-table-k25",
-                              "context-table-crowded-k21", "context-table-k19", "context-table-deferred-counts", "context-table-crowded-k23-deferred-counts"])
+                              "context-table-crowded-k21", "context-table-k19", "context-table-deferred-counts", "context-table-crowded-k23-deferred-counts", "context-table-k28", "context-table-crowded-k28"])
 def test_repeat_rich_graph_matches_oracle(form, crowded, k, monkeypatch):
     """A reference made of thousands of diverged copies of one 400-bp element: every 16-mer of the element sits in hundreds
     of different contexts / graph k-mers, far more than its home bucket (line) of the context table (grid-16-mer table) and the
@@ -1089,7 +1089,7 @@ def test_small_graph_saturation_through_the_path_table():
 # Round 5: small graphs of odd k = 19 .. 25 through count27s_kernel<true, K> (the grid of 8: two grid 12-mers per lane and row, runs of
 # K + 7 bases, 8 windows each) and the path table laid out for k.  VGMI_SMALLK=0 keeps the generic row kernel: the A/B reference.
 @pytest.mark.parametrize("kind", ["plain", "repeats", "dense-sites"])
-@pytest.mark.parametrize("k", [19, 21, 23, 25, 20, 22, 24, 26])      # (26: k + 7 bases do not fit a run -- the context table at any size, flanks of 10)
+@pytest.mark.parametrize("k", [19, 21, 23, 25, 20, 22, 24, 26, 28])      # (26, 28: k + 7 bases do not fit a run -- the context table at any size, flanks of 10 / 11)
 def test_small_graph_other_odd_k_fast_path_matches_oracle(kind, k):
     rng = np.random.default_rng({"plain": 1, "repeats": 2, "dense-sites": 3}[kind] + k)
     keys, haps = _small_graph(kind, rng, k)
@@ -1105,7 +1105,7 @@ def test_small_graph_other_odd_k_fast_path_matches_oracle(kind, k):
     try:
         import torch
         c.table_upload(keys, k)
-        assert (c.ctable_info()["n_buckets"] > 0) == (k == 26)
+        assert (c.ctable_info()["n_buckets"] > 0) == (k in (26, 28))
         t = o.Table(keys)
         for blk in (block, b2):
             c.counts_reset()
@@ -1205,8 +1205,8 @@ def test_small_graph_other_odd_k_low_complexity_and_saturation(k, monkeypatch):
         c.close()
 
 
-@pytest.mark.parametrize("k,big", [(20, False), (22, False), (24, False), (20, True), (22, True), (24, True), (26, False), (26, True)],
-                         ids=["20", "22", "24", "20-context-table", "22-context-table", "24-context-table", "26-context-table-small", "26-context-table"])
+@pytest.mark.parametrize("k,big", [(20, False), (22, False), (24, False), (20, True), (22, True), (24, True), (26, False), (26, True), (28, False), (28, True)],
+                         ids=["20", "22", "24", "20-context-table", "22-context-table", "24-context-table", "26-context-table-small", "26-context-table", "28-context-table-small", "28-context-table"])
 def test_small_graph_even_k_run_counter_lag_is_taken_back(k, big):
     """Even k on the fast path (round 5).  The reference does not advance its run counter on a window that is its own reverse
     complement (src/kmer.cpp:134, `continue` before `++l`), registers included that still hold bases from in front of a non-base or the
@@ -1275,10 +1275,10 @@ def test_small_graph_even_k_run_counter_lag_is_taken_back(k, big):
         c.reads_submit_device(d, d.numel(), len(reads), d_off)
         cov, _, _ = c.counts_finish()
         assert np.array_equal(cov, want), (k, int((cov != want).sum()), np.flatnonzero(cov != want)[:5], cov[cov != want][:5], want[cov != want][:5])
-        assert (c.ctable_info()["n_buckets"] > 0) == (big or k == 26)
+        assert (c.ctable_info()["n_buckets"] > 0) == (big or k in (26, 28))
         # the literal kernel on the same keys (the A/B)
         import os
-        knob = "VGMI_CTABLE_K" if big or k == 26 else "VGMI_SMALLK"
+        knob = "VGMI_CTABLE_K" if big or k in (26, 28) else "VGMI_SMALLK"
         os.environ[knob] = "0"
         try:
             g = vgmi.Context(0, buffer_mib=16)

@@ -10,6 +10,7 @@ overflow table -- is taken raw, as is WRITE_SIZE (counter atomics, queued run re
 (`kernels`: name -> calls, average us, counters); `kernel` is the dominant one.  The file carries the sha256 of the libvgmi.so the
 passes ran: bench.py reports it as `roofline.traffic` only for that library and that kernel."""
 import json
+import os
 import re
 import sys
 
@@ -48,6 +49,7 @@ def main():
     fetch, write = tot["FETCH_SIZE"] * 1024, tot["WRITE_SIZE"] * 1024
     under = stream * (1 - 1 / CAL)
     d = {"reads_per_launch": n_reads, "kernel": short(dom), "libvgmi_sha256": open(f"{out}/libvgmi.sha256").read().strip(),
+         "source_sha256": open(f"{out}/source.sha256").read().strip() if os.path.exists(f"{out}/source.sha256") else None,
          "fetch_size_kb_raw": tot["FETCH_SIZE"], "write_size_kb_raw": tot["WRITE_SIZE"], "stream_bytes_known": stream,
          "fetch_size_calibration_factor_streaming": CAL,
          "kernel_avg_us_rocprofv3": trace[dom][1], "kernel_calls_rocprofv3": trace[dom][0], "count_pass_us_per_launch_rocprofv3": pass_us,

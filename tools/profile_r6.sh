@@ -28,6 +28,7 @@ for W in ${*:-c3 c5 c2}; do
   python3 tools/rocprof_summary.py $OUT > $OUT/summary.txt
   find $OUT -name "*.db" -delete
   sha256sum varigraph_amd/libvgmi.so | cut -d' ' -f1 > $OUT/libvgmi.sha256
+  python3 -c "from varigraph_amd import build; print(build.source_digest())" > $OUT/source.sha256
   python3 tools/make_traffic_json_r6.py $W $N $OUT
   grep -v "^$" $OUT/summary.txt | grep "$RX\|PMC\|kernel-trace\|calls" | cut -c1-160 | head -40
 done

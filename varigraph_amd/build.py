@@ -34,7 +34,26 @@ def _hipcc():
 
 
 VGMI_SOURCES = ("vgmi_kernels.hip", "vgmi_xtable.hip", "vgmi_ctable.hip", "vgmi_ctdefer.hip", "vgmi_ptable.hip", "vgmi_fastq.hip", "vgmi_inflate.hip",
-                "vgmi_gunzip.hip", "vgmi_bloom_bin.hip", "vgmi_hmm.hip", "vgmi_api.cpp")
+                "vgmi_gunzip.hip", "vgmi_bloom_bin.hip", "vgmi_hmm.hip", "vgmi_api.cpp", "vgmi_api_table.cpp", "vgmi_api_rccl.cpp",
+                "vgmi_api_fastq.cpp", "vgmi_api_bloom.cpp", "vgmi_api_hmm.cpp")
+
+
+def source_digest():
+    """sha256 over the sources libvgmi.so is built from (names and bytes, in a fixed order): what a committed counter profile names, so
+    that bench.py reports it as `roofline.traffic` for this code only."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in VGMI_SOURCES] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
+        os.path.join(ROOT, "include", "vgmi.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def lib_digest():
+    import hashlib
+    return hashlib.sha256(open(LIB, "rb").read()).hexdigest() if os.path.exists(LIB) else None
 
 
 def build_vgmi(force=False, verbose=False):
@@ -70,6 +89,23 @@ def build_vgmi(force=False, verbose=False):
     open(stamp, "w").write(" ".join(flags))
     run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
     return LIB
+
+
+SYNTHLIB = os.path.join(ROOT, "varigraph_amd", "libvgsynth.so")
+
+
+def build_synth(force=False, verbose=False):
+    """libvgsynth.so: bench / test tooling (csrc/bench/vgsynth.h) -- the seeded synthetic workloads.  Not part of the product library."""
+    bdir = os.path.join(CSRC, "bench")
+    src = os.path.join(bdir, "vgsynth.hip")
+    deps = [src, os.path.join(bdir, "vgsynth.h"), os.path.join(bdir, "vg_synth.h"), os.path.join(CSRC, "vgmi_device.h")]
+    if not force and not _newer(SYNTHLIB, deps):
+        return SYNTHLIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unused-function", src, "-o", SYNTHLIB]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=ROOT)
+    return SYNTHLIB
 
 
 def build_host(force=False, verbose=False):
@@ -126,6 +162,7 @@ def build_oracle(force=False, with_ref=None):
 
 def build_all(force=False, verbose=False):
     build_vgmi(force, verbose)
+    build_synth(force, verbose)
     build_host(force, verbose)
     build_cli(force, verbose)
     build_oracle(force)

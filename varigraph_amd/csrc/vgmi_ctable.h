@@ -39,6 +39,13 @@
 // values -- 11 / 27 by default.  The fields keep their places (22 bits per flank, twelve mask bits), the upper ones stay zero.  What
 // changes is on the read's side: a 16-mer every TWELVE bases no longer meets every window of k < 27 bases, so the count kernel looks
 // one up every G bases, G = 6 (k = 21 .. 25) or 4 (k = 19), and asks each only for the G windows that end in its own G bases.
+//
+// k = 28 (round 6; the reference's upper bound, main.cpp:187).  A k-mer of 28 bases has 12 bases around a 16-mer, an entry has room for
+// flanks of 11 -- so an entry of k = 28 keeps 11 + 11 flank bases and answers the ELEVEN windows that fit its 38-base context: window s
+// (0 .. 10) takes s + 1 bases of L, X, and 11 - s bases of R.  The two windows of an occurrence it cannot hold (X at the very start or the
+// very end of the k-mer) are windows 0 / 10 of the occurrences next to it, so every k-mer still has an entry for 11 of its 13 sixteen-mers
+// and a read finds it through any of them.  In the functions below: f = bases of flank stored (ct_flank(k): 11 for k >= 27), ex = k - 16 - f
+// (ct_excess(k): 1 for k = 28, else 0) -- window s takes s + ex bases of L and f - s of R, s = 0 .. f - ex.
 #ifndef VGMI_CTABLE_H
 #define VGMI_CTABLE_H
 
@@ -50,6 +57,9 @@
 #define CT_MARKS 0xFC000000u
 #define CT_DIR (1u << 24)
 #define CT_M22 0x3FFFFFu
+
+VG_HD uint32_t ct_flank(uint32_t k) { return k - 16u > 11u ? 11u : k - 16u; }
+VG_HD uint32_t ct_excess(uint32_t k) { return k - 16u - ct_flank(k); }
 
 struct CtEntry {
     uint32_t d0, d1, d2, d3;
@@ -107,18 +117,19 @@ VG_HD uint32_t ct_clz(uint32_t x)
 // A read position's context in the table's orientation.  x, l, r as read (l: the 11 bases in front of x, the one next to x
 // least significant; r: the 11 behind it, the one next to x most significant); vw bit w = the window that ends w bases
 // behind x's last base is made of bases only (the scan's numbering).  Out: canonical x, its flanks, vs bit s = window s valid.
-VG_HD void ct_orient(uint32_t x, uint32_t l, uint32_t r, uint32_t vw, uint32_t& cx, uint32_t& cl, uint32_t& cr, uint32_t& vs, uint32_t f = 11u)
+// (ex > 0: the windows that end fewer than ex bases behind x do not exist; bit w of vw for them is ignored)
+VG_HD void ct_orient(uint32_t x, uint32_t l, uint32_t r, uint32_t vw, uint32_t& cx, uint32_t& cl, uint32_t& cr, uint32_t& vs, uint32_t f = 11u, uint32_t ex = 0u)
 {
     const uint32_t rc = vg_revcomp16(x);
     const bool as_is = x <= rc;
     cx = as_is ? x : rc;
     cl = as_is ? l : ct_rc11(r, f);
     cr = as_is ? r : ct_rc11(l, f);
-    vs = as_is ? ct_rev12(vw, f) : vw;     // window w takes w bases behind x: s = f - w as read, s = w reversed
+    vs = as_is ? ct_rev12(vw, f) & ((2u << (f - ex)) - 1u) : vw >> ex;     // window w takes w bases behind x: s = f - w as read, s = w - ex reversed
 }
 
 // windows of the context (cx, cl, cr) that equal k-mers of entry e: bit s
-VG_HD uint32_t ct_match(const CtEntry& e, uint32_t cx, uint32_t cl, uint32_t cr, uint32_t f = 11u)
+VG_HD uint32_t ct_match(const CtEntry& e, uint32_t cx, uint32_t cl, uint32_t cr, uint32_t f = 11u, uint32_t ex = 0u)
 {
     if (e.d0 != cx) return 0u;
     const uint32_t mf = (1u << (2u * f)) - 1u;
@@ -126,7 +137,7 @@ VG_HD uint32_t ct_match(const CtEntry& e, uint32_t cx, uint32_t cl, uint32_t cr,
     const uint32_t nl = ct_ctz(tl) >> 1;                           // bases of L equal next to X: 0..f
     const uint32_t tr = (((e.d2 ^ cr) & mf) << (32u - 2u * f)) | (1u << (31u - 2u * f));
     const uint32_t nr = ct_clz(tr) >> 1;                           // bases of R equal next to X: 0..f
-    const uint32_t range = ((2u << nl) - 1u) & ~((1u << (f - nr)) - 1u);       // f - nr <= s <= nl
+    const uint32_t range = (((2u << nl) >> ex) - 1u) & ~((1u << (f - nr)) - 1u);       // f - nr <= s <= nl - ex
     const uint32_t emask = (e.d1 >> 22) | ((e.d2 >> 12) & 0xC00u);
     return range & emask;
 }
@@ -135,7 +146,7 @@ VG_HD uint32_t ct_id(const CtEntry& e, uint32_t s) { return (e.d2 & CT_DIR) ? e.
 // The entry of one occurrence, from the unitig as the numbering walks it: xu the 16-mer, lu / ru its flanks (missing bases
 // zero), mask bit s = the unitig holds window s, whose counter is id0 - s.  Returns 1 entry, or 2 when xu is its own
 // reverse complement (both readings).
-VG_HD int ct_make(uint32_t xu, uint32_t lu, uint32_t ru, uint32_t mask, uint32_t id0, CtEntry out[2], uint32_t f = 11u)
+VG_HD int ct_make(uint32_t xu, uint32_t lu, uint32_t ru, uint32_t mask, uint32_t id0, CtEntry out[2], uint32_t f = 11u, uint32_t ex = 0u)
 {
     const uint32_t rc = vg_revcomp16(xu), mf = (1u << (2u * f)) - 1u;
     int n = 0;
@@ -147,11 +158,11 @@ VG_HD int ct_make(uint32_t xu, uint32_t lu, uint32_t ru, uint32_t mask, uint32_t
         ++n;
     }
     if (xu >= rc) {
-        const uint32_t m = ct_rev12(mask, f);
+        const uint32_t m = ct_rev12(mask, f - ex);      // window s reads as window f - ex - s the other way
         out[n].d0 = rc;
         out[n].d1 = ct_rc11(ru & mf, f) | (m & 0x3FFu) << 22;
         out[n].d2 = ct_rc11(lu & mf, f) | ((m >> 10) & 3u) << 22 | CT_DIR;
-        out[n].d3 = id0 - f;
+        out[n].d3 = id0 - (f - ex);
         ++n;
     }
     return n;
@@ -160,32 +171,34 @@ VG_HD int ct_make(uint32_t xu, uint32_t lu, uint32_t ru, uint32_t mask, uint32_t
 // The occurrence led by the k-mer at unitig position u (kf, as walked) with X starting o bases into it (0..f): the k-mers
 // u .. u + n_win - 1 hold it (n_win = min(o, k-mers behind kf in the unitig) + 1; kl = the last of them, id p of kf).
 // keep: window bits that may be set (even k: not those of k-mers that are their own reverse complement, which the reference never emits)
-VG_HD int ct_make_from_unitig(uint64_t kf, uint64_t kl, uint32_t o, uint32_t n_win, uint32_t p, CtEntry out[2], uint32_t k = 27u, uint32_t keep = 0xFFFu)
+VG_HD int ct_make_from_unitig(uint64_t kf, uint64_t kl, uint32_t o, uint32_t n_win, uint32_t p, CtEntry out[2], uint32_t k = 27u, uint32_t keep = 0x1FFFu)
 {
-    const uint32_t f = k - 16u;
-    const uint32_t xu = (uint32_t)(kf >> (2u * (f - o)));
-    const uint32_t lu = o ? (uint32_t)(kf >> (2u * (k - o))) : 0u;                  // the o bases in front of X
-    const uint32_t n_r = n_win + f - 1u - o;                                        // bases behind X the last k-mer reaches: 0..f
-    const uint32_t ru = n_r ? ((uint32_t)kl & ((1u << (2u * n_r)) - 1u)) << (2u * (f - n_r)) : 0u;
-    const uint32_t mask = (((1u << n_win) - 1u) << (o + 1u - n_win)) & keep;        // s = o - n_win + 1 .. o
+    const uint32_t ft = k - 16u, f = ct_flank(k), ex = ft - f;      // keep: bits by X's offset in the k-mer, 0 .. ft
+    const uint32_t xu = (uint32_t)(kf >> (2u * (ft - o)));
+    const uint32_t lu = o ? (uint32_t)(kf >> (2u * (k - o))) : 0u;                  // the o bases in front of X (ct_make keeps the f next to X)
+    const uint32_t n_r = n_win + ft - 1u - o;                                       // bases behind X the last k-mer reaches: 0..ft
+    const uint32_t ru = n_r ? (((uint32_t)kl & ((1u << (2u * n_r)) - 1u)) << (2u * (ft - n_r))) >> (2u * ex) : 0u;      // ... the f next to X
+    const uint32_t by_off = (((1u << n_win) - 1u) << (o + 1u - n_win)) & keep;      // X's offset in the k-mers that hold the occurrence: o - n_win + 1 .. o
+    const uint32_t mask = (by_off >> ex) & ((2u << (f - ex)) - 1u);                 // window s = offset - ex; offsets below ex and above f have no window here
     if (!mask) return 0;
-    return ct_make(xu, lu, ru, mask, p + o, out, f);
+    return ct_make(xu, lu, ru, mask, p + o - ex, out, f, ex);
 }
 
 // A single k-mer as a one-window context: X = its last 16 bases, window s = f as read
 VG_HD void ct_orient_kmer(uint64_t kmer, uint32_t& cx, uint32_t& cl, uint32_t& cr, uint32_t& vs, uint32_t k = 27u)
 {
-    const uint32_t f = k - 16u;
-    ct_orient((uint32_t)kmer, (uint32_t)(kmer >> 32) & ((1u << (2u * f)) - 1u), 0u, 1u, cx, cl, cr, vs, f);
+    const uint32_t f = ct_flank(k), ex = ct_excess(k);      // (ex = 1: X = the 16 bases in front of the k-mer's last base)
+    ct_orient((uint32_t)(kmer >> (2u * ex)), (uint32_t)(kmer >> (32u + 2u * ex)) & ((1u << (2u * f)) - 1u),
+              ex ? ((uint32_t)kmer & ((1u << (2u * ex)) - 1u)) << (2u * (f - ex)) : 0u, 1u << ex, cx, cl, cr, vs, f, ex);
 }
 
 // the k-mer (in the table's orientation) of window s of a context: for the exact overflow table
 VG_HD uint64_t ct_window_kmer(uint32_t cx, uint32_t cl, uint32_t cr, uint32_t s, uint32_t k = 27u)
 {
-    const uint32_t f = k - 16u;
-    const uint64_t left = s ? (uint64_t)(cl & ((1u << (2u * s)) - 1u)) : 0ull;
+    const uint32_t f = ct_flank(k), ex = ct_excess(k);
+    const uint64_t left = (uint64_t)(cl & ((1u << (2u * (s + ex))) - 1u));                 // the s + ex bases of L next to X
     const uint64_t right = (uint64_t)(cr & ((1u << (2u * f)) - 1u)) >> (2u * s);          // the first f - s bases of R
-    return left << (2u * (k - s)) | (uint64_t)cx << (2u * (f - s)) | right;
+    return left << (2u * (16u + f - s)) | (uint64_t)cx << (2u * (f - s)) | right;
 }
 
 #endif

@@ -19,7 +19,8 @@ namespace vgk {
 #define CT_RUNQ 256u            // run ring per wavefront (records of 8 bytes): a row adds <= 256, a drain step takes 5
 #define CT_PENDQ 128u           // contexts that go on to a next bucket (16 bytes): a row or a batch adds <= 64, a batch takes 64 once 64 wait
 #define CT_NONE 0xFFFFFFFFu
-#define CT_MASK54 ((1ULL << 54) - 1)
+#define CT_MASK54 VG_SLOT_KMER_MASK      // the k-mer bits of a compact slot and of an okmer word: 56 (k <= 28)
+#define CT_OK_FIRST 56u               // okmer word: k-mer | first of its unitig << 56 | k-mers behind it there (capped at 15) << 57; bit 63: no k-mer at this place
 
 // ---- build ----------------------------------------------------------------------------------------------------------
 __global__ void ct_clear_kernel(uint4* cb, uint64_t n_buckets)
@@ -58,7 +59,7 @@ __global__ void ct_okmer_kernel(TableView t, const uint32_t* key_slot, const uin
         ++q;
         ++cnt;
     }
-    okmer[p] = Kw | (unsigned long long)first << 54 | (unsigned long long)cnt << 55;
+    okmer[p] = Kw | (unsigned long long)first << CT_OK_FIRST | (unsigned long long)cnt << (CT_OK_FIRST + 1u);
     id_of_key[i] = p;
     if (first) atomicAdd(n_unitigs, 1ULL);
 }
@@ -76,20 +77,20 @@ __global__ void ct_insert_kernel(XTableView t, const unsigned long long* okmer, 
                                  unsigned long long* over_n, unsigned long long* n_moved)
 {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t f = t.k - 16u;          // 11; k = 19 .. 25: 3 .. 9
+    const uint32_t f = t.k - 16u;          // X's offsets in a k-mer: 0 .. f (11; k = 19 .. 26: 3 .. 10; k = 28: 12, of which an entry holds 1 .. 11)
     if (g >= n * (f + 1u)) return;
     const uint64_t p = g / (f + 1u);
     const uint32_t o = (uint32_t)(g - p * (f + 1u));
     const unsigned long long ok = okmer[p];
     if (ok >> 63) return;                  // a place no k-mer has (chains start at multiples of 16)
-    const bool first = (ok >> 54) & 1ULL;
+    const bool first = (ok >> CT_OK_FIRST) & 1ULL;
     if (o != f && !first) return;
-    const uint32_t rem = (uint32_t)(ok >> 55) & 15u;
+    const uint32_t rem = (uint32_t)(ok >> (CT_OK_FIRST + 1u)) & 15u;
     const uint32_t n_win = (o < rem ? o : rem) + 1u;
     const uint64_t kf = ok & CT_MASK54, kl = okmer[p + n_win - 1] & CT_MASK54;
     CtEntry e[2];
-    uint32_t keep = 0xFFFu;
-    if (!(t.k & 1u))      // even k: the k-mer j places on is window o - j
+    uint32_t keep = 0x1FFFu;
+    if (!(t.k & 1u))      // even k: the k-mer j places on has X at offset o - j
         for (uint32_t j = 0; j < n_win; ++j) {
             const uint64_t kw = okmer[p + j] & CT_MASK54;
             if (kw == vg_revcomp(kw, t.k)) keep &= ~(1u << (o - j));
@@ -196,7 +197,7 @@ hipError_t launch_ctable_over(ulonglong2* over, uint32_t over_mask, const unsign
 template <uint32_t K, int D, uint32_t G>
 __device__ __forceinline__ void ct_position(uint32_t W0, uint32_t W1, uint32_t W2, uint64_t U, uint32_t& x, uint32_t& l, uint32_t& r, uint32_t& vm)
 {
-    constexpr uint32_t F = K - 16u, MF = (1u << (2u * F)) - 1u, sh = (uint32_t)(24 - 2 * D), ub = (uint32_t)(36 + D - (int)K);
+    constexpr uint32_t F = K - 16u > 11u ? 11u : K - 16u, MF = (1u << (2u * F)) - 1u, sh = (uint32_t)(24 - 2 * D), ub = (uint32_t)(36 + D - (int)K);
     static_assert(sh >= 2u && sh <= 32u && G >= 1u && G <= F + 1u && 36 + D - (int)K >= 0, "position outside the lane's window");
     const uint64_t Uj = U >> ub;                    // the window that ends w bases behind X spans bits w .. w + K - 1
     const uint32_t A = (uint32_t)Uj & ((1u << K) - 1u), a = ((uint32_t)(Uj >> K) & ((1u << (G - 1u)) - 1u)) << 1;
@@ -216,8 +217,9 @@ __device__ __forceinline__ void ct_position(uint32_t W0, uint32_t W1, uint32_t W
 template <uint32_t K, bool DEFER>
 __device__ __forceinline__ void countc_body(const RowParams& p, const XTableView& xt, const CtDefer& df)
 {
-    constexpr uint32_t F = K - 16u, G = K == 27u ? 12u : (K <= 20u ? 4u : 6u), NP = 12u / G;
-    static_assert(K >= 19u && K <= 27u, "context table: k = 19 .. 27");
+    constexpr uint32_t F = K - 16u > 11u ? 11u : K - 16u, EX = K - 16u - F;      // ct_flank(K), ct_excess(K): k = 28 keeps flanks of 11 and answers 11 windows an entry
+    constexpr uint32_t G = K == 27u ? 12u : (K <= 20u ? 4u : 6u), NP = 12u / G;
+    static_assert(K >= 19u && K <= 28u, "context table: k = 19 .. 28");
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[2048];     // position LUT of count27_kernel (stage_lut27 layout)
     __shared__ __attribute__((aligned(16))) uint2 s_runs[4][CT_RUNQ];
     __shared__ __attribute__((aligned(16))) uint4 s_pend[4][CT_PENDQ];
@@ -331,8 +333,8 @@ __device__ __forceinline__ void countc_body(const RowParams& p, const XTableView
         if (q1) c1 = CtEntry{xs.y, Bk[7], Bk[8], Bk[9]};
         if (q2) c2 = CtEntry{xs.z, Bk[10], Bk[11], Bk[12]};
         if (q3) c3 = CtEntry{xs.w, Bk[13], Bk[14], Bk[15]};
-        const uint32_t h0 = ct_match(c0, cx, cl, cr, F) & vs, h1 = ct_match(c1, cx, cl, cr, F) & vs;
-        const uint32_t h2 = ct_match(c2, cx, cl, cr, F) & vs, h3 = ct_match(c3, cx, cl, cr, F) & vs;
+        const uint32_t h0 = ct_match(c0, cx, cl, cr, F, EX) & vs, h1 = ct_match(c1, cx, cl, cr, F, EX) & vs;
+        const uint32_t h2 = ct_match(c2, cx, cl, cr, F, EX) & vs, h3 = ct_match(c3, cx, cl, cr, F, EX) & vs;
         const uint64_t m0 = __ballot(h0 != 0), m1 = __ballot(h1 != 0), m2 = __ballot(h2 != 0), m3 = __ballot(h3 != 0);
         const uint32_t n = (uint32_t)(__builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) + __builtin_popcountll(m3));
         if (n) {
@@ -454,7 +456,7 @@ __device__ __forceinline__ void countc_body(const RowParams& p, const XTableView
             const uint64_t U = (uint64_t)(i3 | i2 << 12 | (i1 & 0xFFu) << 24) | (uint64_t)((i1 >> 8) | inv << 4) << 32;
             auto probe = [&](uint32_t xr, uint32_t lr, uint32_t rr, uint32_t vm) {
                 uint32_t cx, cl, cr, vs;
-                ct_orient(xr, lr, rr, vm, cx, cl, cr, vs, F);
+                ct_orient(xr, lr, rr, vm, cx, cl, cr, vs, F, EX);
                 const uint32_t b0 = (uint32_t)(((uint64_t)ct_hash(cx) * xt.n_buckets) >> 32);
                 uint32_t found;
                 bool marked;
@@ -462,7 +464,19 @@ __device__ __forceinline__ void countc_body(const RowParams& p, const XTableView
                 push(marked && (vs & ~found) != 0 && !(VG_DBG(p.dbg) & 8u), cx, cl, cr, vs & ~found, 1u, b0 + 1u);
                 while (pend_n >= 64u) pending_batch();
             };
-            if constexpr (K >= 23u) {
+            if constexpr (K == 28u) {
+                // K = 28: an entry answers the eleven windows that end 1 .. 11 bases behind its X, so the schedule of K = 26 (eleven windows too,
+                // ending 0 .. 10 behind) with every X one base earlier: the even lane's X ends 2 bases in front of its twelve (ends 12 L - 1 ..
+                // 12 L + 9), the odd lane's first one 3 bases in front of its own (the even lane's last two ends and its own first nine), its
+                // second one at its own base 8 (its last two ends)
+                const bool odd_lane = (lane & 1u) != 0;
+                uint32_t xe, le, re, ve, xo, lo_, ro, vo;
+                ct_position<K, -1, 12u>(W0, W1, W2, U, xe, le, re, ve);
+                ct_position<K, -2, 12u>(W0, W1, W2, U, xo, lo_, ro, vo);
+                probe(odd_lane ? xo : xe, odd_lane ? lo_ : le, odd_lane ? ro : re, (odd_lane ? vo : ve) & ~1u);
+                ct_position<K, 9, 3u>(W0, W1, W2, U, xo, lo_, ro, vo);
+                probe(xo, lo_, ro, odd_lane ? vo & ~1u : 0u);
+            } else if constexpr (K >= 23u) {
                 // K = 23 .. 26: an entry answers NW = K - 15 >= 8 windows, so a PAIR of lanes (24 ends) needs three lookups, not four: the
                 // even lane asks for the NW ends from the top of its twelve, the odd lane first for the even lane's 12 - NW last ends
                 // together with its own first ones (the 16-mer that ends 12 - NW bases in front of its stretch: all of it is in the odd
@@ -523,6 +537,7 @@ hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t n_c
     if (defer && defer->rec) {
         switch (t.k) {
             case 27: launch_defer_k<27u>(p, t, n_cu * wgs, st, *defer); break;
+            case 28: launch_defer_k<28u>(p, t, n_cu * wgs, st, *defer); break;
             case 26: launch_defer_k<26u>(p, t, n_cu * wgs, st, *defer); break;
             case 25: launch_defer_k<25u>(p, t, n_cu * wgs, st, *defer); break;
             case 24: launch_defer_k<24u>(p, t, n_cu * wgs, st, *defer); break;
@@ -542,6 +557,7 @@ hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t n_c
         case 21: hipLaunchKernelGGL(countkc_kernel<21u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
         case 19: hipLaunchKernelGGL(countkc_kernel<19u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
         // even k: the windows-of-bases rule here, the reference's run counter in the pass ahead of this launch (even_debit_kernel, vgmi_kernels.hip)
+        case 28: hipLaunchKernelGGL(countkc_kernel<28u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
         case 26: hipLaunchKernelGGL(countkc_kernel<26u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
         case 24: hipLaunchKernelGGL(countkc_kernel<24u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;
         case 22: hipLaunchKernelGGL(countkc_kernel<22u>, dim3(n_cu * wgs), dim3(256), 0, st, p, t); break;

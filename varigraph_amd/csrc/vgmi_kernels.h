@@ -40,7 +40,7 @@ struct XTableView {
     uint32_t k;                  // 27, or 19 .. 25 (context table only; round 5): flanks of k - 16 bases
 };
 
-// path table of small graphs (vgmi_ptable.hip, build_ptable in vgmi_api.cpp): what count27s_kernel<true> checks candidate runs against
+// path table of small graphs (vgmi_ptable.hip, build_ptable in vgmi_api_table.cpp): what count27s_kernel<true> checks candidate runs against
 struct PathView {
     const unsigned long long* index;   // 2 << bucket_log2 entries {12-mer : 24, place a : 19, place b : 19}, or nullptr: not in use
     const uint32_t* S;                 // the graph's unitigs, both orientations, 2 bits per base, 16 bases per word (first base most significant)
@@ -101,13 +101,6 @@ struct RowParams {
     TableView table;      // MODE_COUNT
     uint64_t* keys_out;   // MODE_KEYS
     BloomView bloom;      // MODE_BLOOM
-};
-
-#define VG_SYNTH_MAX_HAPS 8
-struct SynthHaps {
-    uint32_t n;
-    uint64_t off[VG_SYNTH_MAX_HAPS];
-    uint64_t len[VG_SYNTH_MAX_HAPS];
 };
 
 // device-side FASTQ parsing (vgmi_fastq.hip)
@@ -321,8 +314,6 @@ hipError_t launch_counts_xfer(const TableView& t, const uint32_t* key_slot, uint
 hipError_t launch_node_gather(const uint8_t* cov, const uint32_t* key_index, uint64_t n, uint8_t* cov_node, hipStream_t st);
 hipError_t launch_bloom_query(const BloomView& b, const uint64_t* keys, uint64_t n, uint8_t* min_out, uint8_t* nz_out,
                               hipStream_t st);
-hipError_t launch_synth_reads(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, const char* hap_cat,
-                              const SynthHaps& haps, char* out, hipStream_t st);
 
 }  // namespace vgk
 #endif

@@ -27,7 +27,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "vg_synth.h"
 #include "vgmi_device.h"
 #include "vgmi_kernels.h"
 #include "vgmi_xtable.h"
@@ -2326,23 +2325,8 @@ __global__ void bloom_query_kernel(BloomView b, const uint64_t* keys, uint64_t n
     if (nz_out) nz_out[i] = (uint8_t)nz;
 }
 
-// bench/test tooling: seeded synthetic read block (vg_synth.h)
-__global__ void synth_reads_kernel(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
-                                   const char* hap_cat, SynthHaps haps, char* out)
-{
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t total = n_reads * (read_len + 1);
-    const char* hp[VG_SYNTH_MAX_HAPS];
-    for (uint32_t h = 0; h < haps.n; ++h) hp[h] = hap_cat + haps.off[h];
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const uint64_t r = i / (read_len + 1);
-        const uint32_t j = (uint32_t)(i - r * (read_len + 1));
-        out[i] = j == read_len ? '\n' : vgs_read_base(seed, first_read + r, j, read_len, hp, haps.len, haps.n);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// launch wrappers (called from vgmi_api.cpp through vgmi_kernels.h)
+// launch wrappers (called from vgmi_api*.cpp through vgmi_kernels.h)
 // ------------------------------------------------------------------------------------------
 static size_t rows_lds_bytes(int mode, bool flds, uint32_t filter_words_log2, uint32_t block)
 {
@@ -2527,15 +2511,6 @@ hipError_t launch_bloom_query(const BloomView& b, const uint64_t* keys, uint64_t
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(bloom_query_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, b, keys, n, min_out, nz_out);
-    return hipGetLastError();
-}
-
-hipError_t launch_synth_reads(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, const char* hap_cat,
-                              const SynthHaps& haps, char* out, hipStream_t st)
-{
-    if (n_reads == 0) return hipSuccess;
-    hipLaunchKernelGGL(synth_reads_kernel, dim3(grid_for(n_reads * (read_len + 1), 256, 8192)), dim3(256), 0, st, seed,
-                       first_read, n_reads, read_len, hap_cat, haps, out);
     return hipGetLastError();
 }
 

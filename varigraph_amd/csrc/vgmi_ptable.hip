@@ -17,7 +17,7 @@
 // says whether a graph k-mer starts there (VB), another whether its counter is saturated (SB, per sample), and SLOT holds its
 // hash-table slot: counters stay per table slot, so read-out, the generic kernels (ragged tails, k != 27) and the image format
 // do not change.  This file orders the k-mers (device kernels, as vgmi_xtable.hip numbers counters along paths);
-// build_ptable (vgmi_api.cpp) lays S, VB, SLOT and the index out on the host -- at most 65 536 k-mers.
+// build_ptable (vgmi_api_table.cpp) lays S, VB, SLOT and the index out on the host -- at most 65 536 k-mers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -27,7 +27,7 @@
 namespace vgk {
 
 #define PT_NONE 0xFFFFFFFFu
-#define PT_MASK54 ((1ULL << 54) - 1)
+#define PT_MASK54 VG_SLOT_KMER_MASK      // (the k-mer bits of a compact slot: 56, k <= 28)
 
 // slot of a canonical k-mer in the compact table, or PT_NONE
 __device__ __forceinline__ uint32_t pt_find(const TableView& t, uint64_t canon)

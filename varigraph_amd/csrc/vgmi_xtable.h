@@ -144,7 +144,7 @@ __device__ __forceinline__ uint32_t ct_find(const XTableView& t, uint64_t kmer)
 {
     uint32_t cx, cl, cr, vs;
     ct_orient_kmer(kmer, cx, cl, cr, vs, t.k);
-    const uint32_t f = t.k - 16u;
+    const uint32_t f = ct_flank(t.k), ex = ct_excess(t.k);
     const uint64_t b0 = ((uint64_t)ct_hash(cx) * t.n_buckets) >> 32;
     for (uint32_t hop = 0; hop <= CT_HOPS; ++hop) {
         const uint32_t* B = reinterpret_cast<const uint32_t*>(t.cb + ((b0 + hop) << 2));
@@ -154,7 +154,7 @@ __device__ __forceinline__ uint32_t ct_find(const XTableView& t, uint64_t kmer)
         for (int q = 0; q < 4; ++q) {
             if (x[q] != cx) continue;
             const CtEntry e = {cx, B[4 + 3 * q], B[5 + 3 * q], B[6 + 3 * q]};
-            const uint32_t h = ct_match(e, cx, cl, cr, f) & vs;
+            const uint32_t h = ct_match(e, cx, cl, cr, f, ex) & vs;
             if (h) return ct_id(e, (uint32_t)__builtin_ctz(h));
         }
         if (xs.w == 0xFFFFFFFFu || !(B[5] & ct_mark(cx))) return 0xFFFFFFFFu;      // not full, or full and nothing with this mark went on

@@ -102,10 +102,6 @@ def load_library():
         "vgmi_bloom_load_file": (i32, [vp, C.c_char_p]),
         "vgmi_bloom_load": (i32, [vp, vp]),
         "vgmi_bloom_query": (i32, [vp, vp, sz, vp, vp]),
-        "vgmi_synth_reads_device": (i32, [vp, u64, u64, u64, u32, vp, vp, u32, vp]),
-        "vgmi_synth_reads_host": (i32, [u64, u64, u64, u32, vp, vp, u32, vp]),
-        "vgmi_synth_reference_host": (i32, [u64, u64, vp]),
-        "vgmi_synth_snp_keys_host": (i32, [vp, u64, vp, vp, u64, u32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
@@ -147,36 +143,20 @@ def bloom_params(n, p):
     return m.value, nh.value
 
 
+# ---- tooling: the seeded synthetic workloads (libvgsynth.so, varigraph_amd/synthlib.py -- NOT part of the product library)
 def synth_reference(seed, length):
-    out = np.empty(length, dtype=np.uint8)
-    rc = lib().vgmi_synth_reference_host(seed, length, _ptr(out))
-    if rc:
-        raise VgmiError(rc, "synth_reference")
-    return out
+    from . import synthlib
+    return synthlib.reference(seed, length)
 
 
 def synth_snp_keys(ref, pos, alts, k=27):
-    """Unsorted, possibly repeated keys of the k-mers covering SNP sites (see include/vgmi.h)."""
-    ref = np.ascontiguousarray(ref, dtype=np.uint8)
-    pos = np.ascontiguousarray(pos, dtype=np.uint64)
-    alts = np.ascontiguousarray(alts, dtype=np.uint8)
-    out = np.empty(2 * k * pos.size, dtype=np.uint64)
-    rc = lib().vgmi_synth_snp_keys_host(_ptr(ref), ref.size, _ptr(pos), _ptr(alts), pos.size, k, _ptr(out))
-    if rc:
-        raise VgmiError(rc, "synth_snp_keys")
-    return out
+    from . import synthlib
+    return synthlib.snp_keys(ref, pos, alts, k)
 
 
 def synth_reads_host(seed, first_read, n_reads, read_len, haps):
-    """haps: list of uint8 arrays (ASCII haplotypes). Returns the '\\n'-joined read block (uint8)."""
-    cat = np.ascontiguousarray(np.concatenate(haps))
-    off = np.zeros(len(haps) + 1, dtype=np.uint64)
-    off[1:] = np.cumsum([len(h) for h in haps])
-    out = np.empty(n_reads * (read_len + 1), dtype=np.uint8)
-    rc = lib().vgmi_synth_reads_host(seed, first_read, n_reads, read_len, _ptr(cat), _ptr(off), len(haps), _ptr(out))
-    if rc:
-        raise VgmiError(rc, "synth_reads_host")
-    return out
+    from . import synthlib
+    return synthlib.reads_host(seed, first_read, n_reads, read_len, haps)
 
 
 class Context:
@@ -610,6 +590,8 @@ class Context:
 
     # ---- tooling
     def synth_reads_device(self, seed, first_read, n_reads, read_len, dev_hap_cat, hap_off, dev_out):
-        hap_off = np.ascontiguousarray(hap_off, dtype=np.uint64)
-        self._chk(self._l.vgmi_synth_reads_device(self._h, seed, first_read, n_reads, read_len, _ptr(dev_hap_cat),
-                                                  _ptr(hap_off), hap_off.size - 1, _ptr(dev_out)))
+        """(libvgsynth.so, on this context's device and main stream)"""
+        from . import synthlib
+        dev = C.c_int()
+        self._chk(self._l.vgmi_device_of(self._h, C.byref(dev)))
+        synthlib.reads_device(dev.value, self.stream, seed, first_read, n_reads, read_len, dev_hap_cat, hap_off, dev_out)
