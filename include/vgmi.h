@@ -50,7 +50,9 @@ typedef enum vgmi_status {
 int vgmi_device_count(void);
 int vgmi_create(int device, size_t buffer_mib, vgmi_ctx **out);
 void vgmi_destroy(vgmi_ctx *ctx);
-const char *vgmi_last_error(const vgmi_ctx *ctx); /* ctx may be NULL: error of the last failed vgmi_create */
+/* ctx may be NULL: error of the last failed vgmi_create.  A context serves several threads at once (FASTQ streams, HMM parts, a broadcast
+ * thread): the text is the CALLING thread's own last failure on this context when it has one, else the context's last. */
+const char *vgmi_last_error(const vgmi_ctx *ctx);
 /* free / total bytes of the context's device right now (hipMemGetInfo; free includes the working blocks this context keeps
  * between HMM calls and is not using, which the next call reuses or releases): callers that size optional device work (the HMM
  * recursion's score arrays) decide from it instead of from a fixed bound.  No reference counterpart. */
@@ -85,7 +87,9 @@ int vgmi_table_broadcast(vgmi_ctx *ctx, int rank, int world, const void *id128);
  * up BESIDE a rank's graph load and table build (its own thread), not behind them: vgmi_comm_create on `device` (every rank, any
  * time after the id exists), then vgmi_table_broadcast_comm with the rank's context on that device (root = rank 0), then
  * vgmi_comm_destroy.  A rank that cannot take part (the root without a table, a receiver without room for the image) tells the
- * others inside the collectives: every rank returns an error, none waits.  vgmi_table_broadcast is the three calls in one. */
+ * others inside the collectives: every rank returns an error, none waits.  A rank that fails on its own between the collectives (a HIP
+ * call, a collective's own error) aborts the communicator on its way out (ncclCommAbort), which ends its peers' pending collectives with
+ * an error; the communicator is then good for vgmi_comm_destroy only.  vgmi_table_broadcast is the three calls in one. */
 typedef struct vgmi_comm vgmi_comm;
 int vgmi_comm_create(int device, int rank, int world, const void *id128, vgmi_comm **out);
 int vgmi_table_broadcast_comm(vgmi_ctx *ctx, vgmi_comm *comm);

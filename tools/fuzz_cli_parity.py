@@ -55,6 +55,9 @@ def dress(path, rng):
     return path + ".gz"
 
 
+FORCE = {}      # --k K / --genome G on the command line: the drawn value replaced (round 6: campaigns of k = 28 over graphs on either side of 65 536 k-mers)
+
+
 def case(seed):
     rng = np.random.default_rng(seed)
     pick = lambda xs: xs[int(rng.integers(0, len(xs)))]
@@ -62,6 +65,8 @@ def case(seed):
     vploidy = pick([2, 2, 2, 3, 4])
     n_samples = pick([1, 2, 3, 5, 7]) if vploidy <= 2 else pick([1, 2, 3])
     k = pick([27, 27, 27, 21, 25, 22, 28, 15, 11, 19, 23, 20, 24, 26])
+    k = FORCE.get("k", k)
+    genome = FORCE.get("genome", genome)
     if k < 19 and genome > 400_000: genome = 400_000      # (the reference takes minutes over 1.5 Mb of 11- and 15-mers)
     copts = pick([[], [], ["--fast"], ["--use-unique-kmers"]])
     n_var = max(5, genome // pick([300, 600, 1500]))
@@ -127,6 +132,8 @@ def case(seed):
 
 if __name__ == "__main__":
     first, n = int(sys.argv[1]), int(sys.argv[2])
+    for i, a in enumerate(sys.argv):
+        if a in ("--k", "--genome"): FORCE[a[2:]] = int(sys.argv[i + 1])
     bad = 0
     for s in range(first, first + n):
         t0 = time.time()

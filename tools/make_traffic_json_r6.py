@@ -19,7 +19,8 @@ CAL = 2.0036931669084184      # profiles/r1: FETCH_SIZE calibration on the same 
 
 def main():
     w, n_reads, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
-    rx = re.compile(r"count27|countkc|ctd_")
+    rx = re.compile(sys.argv[4] if len(sys.argv) > 4 else r"count27|countkc|ctd_")
+    known_stream = w != "bloom"      # the read block of the count kernels: the calibrated 12- / 16-byte-per-lane row loads (K3: no calibrated stream, everything raw)
     pmc, trace = {}, {}
     for ln in open(f"{out}/summary.txt"):
         m = re.match(r"\s*(\d+)\s+[\d.]+\s+([\d.]+)\s+([A-Z]\S+)\s+(.*)$", ln)          # dispatches sum per_dispatch counter kernel
@@ -45,10 +46,10 @@ def main():
             tot[c] = tot.get(c, 0.0) + per * nd / dom_nd
         kernels[short(name)[:80]] = {c: per for c, (nd, per) in cs.items()}
     pass_us = sum(t[2] for t in trace.values()) / steps_trace
-    stream = n_reads * 151
+    stream = n_reads * 151 if known_stream else 0
     fetch, write = tot["FETCH_SIZE"] * 1024, tot["WRITE_SIZE"] * 1024
     under = stream * (1 - 1 / CAL)
-    d = {"reads_per_launch": n_reads, "kernel": short(dom), "libvgmi_sha256": open(f"{out}/libvgmi.sha256").read().strip(),
+    d = {"reads_per_launch": n_reads, "kernel": short(dom) if known_stream else None, "libvgmi_sha256": open(f"{out}/libvgmi.sha256").read().strip(),
          "source_sha256": open(f"{out}/source.sha256").read().strip() if os.path.exists(f"{out}/source.sha256") else None,
          "fetch_size_kb_raw": tot["FETCH_SIZE"], "write_size_kb_raw": tot["WRITE_SIZE"], "stream_bytes_known": stream,
          "fetch_size_calibration_factor_streaming": CAL,

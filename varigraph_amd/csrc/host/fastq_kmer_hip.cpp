@@ -292,12 +292,25 @@ DeviceFileResult device_file(vgmi_ctx* ctx, const std::string& path, size_t bloc
                         if (end != GunzipEnd::Corrupt || host_text != dev_text)
                             throw std::runtime_error("'" + path + "': the device's gzip decoder produced text that fails the member's CRC-32 / length while the "
                                                      "host decoder disagrees (internal error; VGH_DEVICE_GUNZIP=0 decodes on the host)");
-                        std::fprintf(stderr, "[varigraph-mi] warning: '%s': gzip stream is damaged (CRC-32 or length); only what decoded cleanly is used\n",
-                                     path.c_str());
+                        // (Where this differs from the reference on a DAMAGED file: zlib's gzread hands kseq nothing of its last call once the trailer
+                        // check fails -- up to 16 KiB of the member's text, include/kseq.h's buffer -- while the member's whole text is counted here.
+                        // Files that pass their own checks are byte-identical)
+                        std::fprintf(stderr, "[varigraph-mi] warning: '%s': gzip stream is damaged (CRC-32 or length): the damaged member's text is used up to its "
+                                             "end (the reference drops the last <= 16 KiB of it)\n", path.c_str());
                         break;
                     }
                 }
-                if (stop == 2 || (taken == 0 && (at_eof || want >= cap))) { gz_gave_up = true; break; }
+                if (stop == 2 || (taken == 0 && (at_eof || want >= cap))) {
+                    gz_gave_up = true;
+                    uint32_t why = 0;
+                    uint64_t dev_text = 0;
+                    // (the hand-over is said, not silent -- reason 12 is a file of many small members, e.g. pigz -i or per-lane files joined:
+                    // a piece per member is launch-bound on the device, and the stream stays with the host decoder from here on)
+                    if (vgmi_fastq_gzip_status(fq, &dev_text, &why) == VGMI_OK && why == 12)
+                        std::fprintf(stderr, "[varigraph-mi] note: '%s': gzip members of under 1 MiB of text each: decoded by the host's threads from byte %llu of the text on\n",
+                                     path.c_str(), (unsigned long long)dev_text);
+                    break;
+                }
                 if (stop == 1 || (at_eof && carry.empty())) break;
             } else {
                 for (;;) {

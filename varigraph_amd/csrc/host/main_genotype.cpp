@@ -405,7 +405,13 @@ int main_genotype(int argc, char** argv)
         if (proc_bcast && proc_rank == 0) {
             // the others' copy leaves from a snapshot of the image, whenever the communicator is up: this rank does not wait for it
             if (vgmi_table_snapshot(ctxs[0]) != VGMI_OK) {
-                ctx_error = vgmi_last_error(ctxs[0]);
+                // no room for a second copy of the image: the broadcast leaves from the image itself, before this rank counts (the
+                // other ranks are inside the collective either way -- returning here left them there)
+                comm_up.join();
+                if (!comm_error.empty()) { ctx_error = comm_error; return; }
+                if (vgmi_table_broadcast_comm(ctxs[0], comm) != VGMI_OK) { ctx_error = vgmi_last_error(ctxs[0]); return; }
+                std::fprintf(stderr, "[varigraph-mi] rank 0: no memory for a snapshot of the table image: sent to %d ranks before counting\n", proc_world - 1);
+                table_there();
                 return;
             }
             bcast_thr = std::thread([&] {

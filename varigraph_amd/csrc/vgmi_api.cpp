@@ -9,11 +9,21 @@ namespace vgapi {
 
 thread_local std::string g_create_error;
 
+// The last error of a context is read by the thread that got the failing return code -- and a context serves several threads at once
+// (FASTQ streams, HMM parts, the --procs broadcast thread): the message is kept per THREAD as well as in the context (the
+// broadcast thread's text no longer lands where a counting thread's vgmi_last_error may be reading).
+thread_local const vgmi_ctx* t_err_ctx = nullptr;
+thread_local std::string t_err_msg;
+
 int fail(vgmi_ctx* c, int code, const std::string& msg)
 {
     static std::mutex mu;       // vgmi_hmm_calls_part may fail on several threads of one context
     std::lock_guard<std::mutex> lock(mu);
-    if (c) c->err = msg; else g_create_error = msg;
+    if (c) {
+        c->err = msg;
+        t_err_ctx = c;
+        t_err_msg = msg;
+    } else g_create_error = msg;
     return code;
 }
 
@@ -507,7 +517,12 @@ void vgmi_destroy(vgmi_ctx* c)
     delete c;
 }
 
-const char* vgmi_last_error(const vgmi_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+const char* vgmi_last_error(const vgmi_ctx* c)
+{
+    if (!c) return g_create_error.c_str();
+    if (t_err_ctx == c && !t_err_msg.empty()) return t_err_msg.c_str();      // this thread's own last failure on this context
+    return c->err.c_str();
+}
 
 void* vgmi_stream(vgmi_ctx* c) { return c ? (void*)c->stream : nullptr; }
 

@@ -14,6 +14,7 @@ struct Rccl {
     int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommAbort)(void*) = nullptr;      // (optional: a rank that cannot go on ends its peers' collectives with it)
     const char* (*GetErrorString)(int) = nullptr;
     std::string err;
 };
@@ -35,6 +36,7 @@ Rccl* rccl()
         x.Broadcast = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(x.lib, "ncclBroadcast"));
         x.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(x.lib, "ncclAllReduce"));
         x.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(x.lib, "ncclCommDestroy"));
+        x.CommAbort = reinterpret_cast<int (*)(void*)>(dlsym(x.lib, "ncclCommAbort"));
         x.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(x.lib, "ncclGetErrorString"));
         if (!x.GetUniqueId || !x.CommInitRank || !x.Broadcast || !x.AllReduce || !x.CommDestroy) x.err = "librccl.so lacks an entry point";
         return x;
@@ -94,14 +96,21 @@ void vgmi_comm_destroy(vgmi_comm* m)
     delete m;
 }
 
-// Root = rank 0.  Every rank goes through the same three collectives whatever happens on its side -- the image's size (0: the
-// root has none to give), an agreement that every receiver has its buffer (all-reduce, minimum), the image -- so that a rank that
-// cannot go on says so to the others instead of leaving them inside a collective.
+// Root = rank 0.  Every rank goes through the same three collectives -- the image's size (0: the root has none to give), an agreement
+// that every receiver has its buffer (all-reduce, minimum), the image -- so that a rank that cannot go on says so to the others instead
+// of leaving them inside a collective: "no table" and "no room" are told INSIDE the collectives and every rank returns together.  A rank
+// that fails on its own between them (a HIP call, a collective's own error) ABORTS the communicator (ncclCommAbort) on its way out: its
+// peers' pending collectives end with an error instead of waiting for it.  The communicator is unusable after that
+// (vgmi_comm_destroy still takes it).
 int vgmi_table_broadcast_comm(vgmi_ctx* c, vgmi_comm* m)
 {
     if (!c || !m || !m->comm) return VGMI_E_INVALID;
     if (m->device != c->device) return fail(c, VGMI_E_INVALID, "vgmi_table_broadcast_comm: the communicator is on another device than the context");
     Rccl* r = rccl();
+    struct AbortGuard {      // armed until this rank has said what it has to say inside the collectives
+        Rccl* r; vgmi_comm* m; bool armed;
+        ~AbortGuard() { if (armed && m->comm && r->CommAbort) { (void)r->CommAbort(m->comm); m->comm = nullptr; } }
+    } guard{r, m, true};
     HIPCHK(c, hipSetDevice(c->device));
     const int rank = m->rank;
     // a stream of its own: a root that sends a snapshot may be counting on the context's streams meanwhile
@@ -124,7 +133,10 @@ int vgmi_table_broadcast_comm(vgmi_ctx* c, vgmi_comm* m)
     if (rc) return fail(c, VGMI_E_HIP, nccl_text("ncclBroadcast (size)", rc));
     HIPCHK(c, hipMemcpy(h, d_n, 8, hipMemcpyDeviceToHost));
     const unsigned long long n = h[0];
-    if (n == 0) return fail(c, VGMI_E_STATE, "the root has no table to broadcast");
+    if (n == 0) {      // (every rank reads the same size and leaves here)
+        guard.armed = false;
+        return fail(c, VGMI_E_STATE, "the root has no table to broadcast");
+    }
     uint8_t* d_buf = rank == 0 ? (c->d_snapshot ? c->d_snapshot : c->d_image) : nullptr;
     if (rank != 0) {
         if (hipMalloc(reinterpret_cast<void**>(&d_recv), n) != hipSuccess) {
@@ -140,10 +152,14 @@ int vgmi_table_broadcast_comm(vgmi_ctx* c, vgmi_comm* m)
     unsigned long long all_ready = 0;
     if (rc == 0 && hipMemcpy(&all_ready, d_n + 1, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = 1;
     if (rc) return fail(c, VGMI_E_HIP, nccl_text("ncclAllReduce (buffers)", rc));
-    if (!all_ready) return fail(c, VGMI_E_NOMEM, "vgmi_table_broadcast_comm: a rank has no room for the table image");
+    if (!all_ready) {      // (likewise)
+        guard.armed = false;
+        return fail(c, VGMI_E_NOMEM, "vgmi_table_broadcast_comm: a rank has no room for the table image");
+    }
     rc = r->Broadcast(d_buf, d_buf, n, /* ncclChar */ 0, 0, m->comm, st);
     if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = 1;
     if (rc) return fail(c, VGMI_E_HIP, nccl_text("ncclBroadcast (image)", rc));
+    guard.armed = false;
     if (rank == 0 && c->d_snapshot) {
         (void)hipFree(c->d_snapshot);
         c->d_snapshot = nullptr;
