@@ -294,7 +294,7 @@ DeviceFileResult device_file(vgmi_ctx* ctx, const std::string& path, size_t bloc
                                                      "host decoder disagrees (internal error; VGH_DEVICE_GUNZIP=0 decodes on the host)");
                         // (Where this differs from the reference on a DAMAGED file: zlib's gzread hands kseq nothing of its last call once the trailer
                         // check fails -- up to 16 KiB of the member's text, include/kseq.h's buffer -- while the member's whole text is counted here.
-                        // Files that pass their own checks are byte-identical)
+                        // Files that pass their own checks are byte-identical; ADVICE r5 #3, DESIGN_INGEST_HMM.md 4.8.)
                         std::fprintf(stderr, "[varigraph-mi] warning: '%s': gzip stream is damaged (CRC-32 or length): the damaged member's text is used up to its "
                                              "end (the reference drops the last <= 16 KiB of it)\n", path.c_str());
                         break;
