@@ -62,7 +62,7 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     import hashlib
     lines = []
     for rel in ("oracle/_ref/varigraph_det", "oracle/_ref/varigraph_ref", "oracle/_ref/ref_harness_det", "oracle/_ref/ref_harness", "oracle/_ref/varigraph_hip", "oracle/liboracle.so",
-                "varigraph_amd/libvgmi.so", "varigraph_amd/libvghost.so", "varigraph_amd/bin/varigraph-mi"):
+                "varigraph_amd/libvgmi.so", "varigraph_amd/libvghost.so", "varigraph_amd/libvgsynth.so", "varigraph_amd/bin/varigraph-mi"):
         path = os.path.join(ROOT, rel)
         if os.path.exists(path):
             h = hashlib.sha256()

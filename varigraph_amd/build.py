@@ -69,7 +69,13 @@ def build_vgmi(force=False, verbose=False):
     objdir = os.path.join(ROOT, "build", "obj")
     os.makedirs(objdir, exist_ok=True)
     stamp = os.path.join(objdir, "flags.txt")
-    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+    # a library newer than every source and header, built with these flags, is up to date WHATEVER the object directory holds: build/ does
+    # not travel to the GPU box, the library does -- a fresh box must not spend a minute compiling what it was sent
+    custom = os.environ.get("VGMI_ABLATION") == "1" or bool(os.environ.get("VGMI_HIPCC_DEFS", "").split())
+    stamp_ok = (open(stamp).read() == " ".join(flags)) if os.path.exists(stamp) else not custom
+    if not force and stamp_ok and not _newer(LIB, srcs + hdrs):
+        return LIB
+    if not stamp_ok:
         force = True
     todo, objs = [], []
     for src in srcs:
