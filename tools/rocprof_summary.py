@@ -21,7 +21,7 @@ def kernel_stats(db):
 # (round 5: "bb_" and "gz_" were missing from this list until now -- the Bloom partition kernels' and the gzip decoder's counter rows
 # were collected in round 4 and dropped HERE, which profiles/README.md then reported as "returned no rows on this pool")
 def pmc_stats(db, kernel_filter=("rows_kernel", "count27", "seq_kernel", "inflate", "fq_", "hmm_", "bloom_", "cov_kernel", "node_gather", "table_", "bb_",
-                                 "gz_", "even_debit", "countkc", "ct_", "xt_", "pt_")):
+                                 "gz_", "even_debit", "countkc", "ct_", "ctd_", "xt_", "pt_")):      # (round 6: "ctd_" added -- the deferred pass's two kernels were dropped here at first)
     cur = sqlite3.connect(db).cursor()
     try:
         rows = cur.execute(
