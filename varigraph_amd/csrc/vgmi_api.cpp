@@ -119,14 +119,19 @@ int debit_list_of(vgmi_ctx* c, hipStream_t st, unsigned long long** out)
 }
 
 // Deferred counter updates of the context-table kernels (vgmi_ctdefer.hip): whether this launch uses them, and the stream's scratch.
-// VGMI_CT_DEFER=0|1 (A/B), VGMI_CT_DEFER_MIN: the smallest block in bytes that defers (smaller ones are not worth two more launches).
+// VGMI_CT_DEFER=0|1 (A/B), VGMI_CT_DEFER_MIN: the smallest block in bytes that defers (default 512 MiB: below).
 int ctd_prepare(vgmi_ctx* c, size_t n_bytes, hipStream_t st, CtDefer* d)
 {
     // (read per launch: the test matrix switches them inside one process)
     const char* const e_on = getenv("VGMI_CT_DEFER");
     const int on = e_on ? atoi(e_on) : VGMI_CT_DEFER_DEFAULT;
     const char* const e_min = getenv("VGMI_CT_DEFER_MIN");
-    const size_t min_bytes = e_min ? (size_t)atoll(e_min) : (size_t)8 << 20;
+    // the smallest block that defers: the second pass costs ~70 us whatever the block holds (three launches; 1 280 regions zeroed, added up and
+    // scanned) and saves a tenth of the row loop's time, 0.03 us per thousand reads -- even at ~2.6e6 reads = 0.4 GB of packed reads.  Measured
+    // through the CLI (tools/gpu_r6_d.sh, eight chr20 samples, ~100 MiB pieces on two streams): count passes of a sample 0.020-0.027 s in the
+    // row loop, 0.045-0.056 s deferred; the command's wall is the same (counting is ingest-bound).  So pieces of a FASTQ stream keep their
+    // atomics and blocks of half a gigabyte or more -- a sample resident in HBM -- defer them.
+    const size_t min_bytes = e_min ? (size_t)atoll(e_min) : (size_t)512 << 20;
     *d = CtDefer{};
     if (!on || !c->tv.xt.cb || n_bytes < min_bytes) return VGMI_OK;
     const size_t need = ctd_scratch_bytes(n_bytes, c->xt_n_counts, (uint32_t)c->n_cu, d);

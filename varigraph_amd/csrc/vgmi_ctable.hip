@@ -529,11 +529,15 @@ static void launch_defer_k(const RowParams& p, const XTableView& t, uint32_t gri
 
 hipError_t launch_count27c(const RowParams& p, const XTableView& t, uint32_t n_cu, hipStream_t st, const CtDefer* defer)
 {
-    static const uint32_t wgs = [] {      // workgroups per CU (20 KB of LDS each: 8 fit); VGMI_CT_WGS for A/B
+    static const int wgs_env = [] {      // workgroups per CU (20 KB of LDS each: 8 fit); VGMI_CT_WGS for A/B
         const char* e = getenv("VGMI_CT_WGS");
-        const int v = e ? atoi(e) : 6;      // measured, chr20 class kernel ms: 5 8.96, 6 8.31, 7 8.50, 8 8.62 (gpurun_out/r4d)
-        return (uint32_t)(v < 1 ? 1 : v > 8 ? 8 : v);
+        const int v = e ? atoi(e) : 0;
+        return v < 1 ? 0 : v > 8 ? 8 : v;
     }();
+    // measured, kernel ms: chr20 class (2 GB of buckets) 5 8.96, 6 8.31, 7 8.50, 8 8.62 (gpurun_out/r4d) -- a table in HBM is bound by requests
+    // in flight, not by wavefronts; a table of a few megabytes (k = 26 / 28 on a small graph: it lives in the L2s) is bound by instruction
+    // issue and wants every slot: k = 28, 2e7 reads 4 4.59, 5 4.23, 6 4.05, 7 3.93, 8 3.87 (round 6)
+    const uint32_t wgs = wgs_env ? (uint32_t)wgs_env : ((uint64_t)t.n_buckets * 64u <= (32u << 20) ? 8u : 6u);
     if (defer && defer->rec) {
         switch (t.k) {
             case 27: launch_defer_k<27u>(p, t, n_cu * wgs, st, *defer); break;

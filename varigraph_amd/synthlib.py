@@ -17,6 +17,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             from . import build
             build.build_synth()
+        # torch wheels bundle their own libamdhip64; load torch FIRST so the process ends up with one HIP runtime (as vgmi.load_library
+        # does): a process that loaded this library before torch found "No HIP GPUs are available" afterwards
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         l = C.CDLL(LIB_PATH)
         i32, u32, u64, vp = C.c_int, C.c_uint32, C.c_uint64, C.c_void_p
         for name, args in {"vgs_reads_device": [i32, vp, u64, u64, u64, u32, vp, vp, u32, vp], "vgs_reads_host": [u64, u64, u64, u32, vp, vp, u32, vp],
