@@ -783,6 +783,10 @@ def main():
                                                                                                    "unsaturated": unsat}))
     del d_cat2
 
+    # the reference's CPU path on this box's cores (a required block of the line: it comes straight behind the headline, ahead of every optional leg)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        run_leg("cpu_baseline", 50, lambda: cpu_baseline(haps, args.cpu_reads, os.cpu_count() or 1))
+
     # ================= C3 / C4: the chr20-class graph (table in HBM), BASELINE.json configs[2], [3] =================
     state = {}
 
@@ -1007,8 +1011,6 @@ def main():
     if rank == 0 and world == 1 and not args.no_bloom:
         run_leg("bloom", 10, leg_bloom)
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        run_leg("cpu_baseline", 50, lambda: cpu_baseline(haps, args.cpu_reads, os.cpu_count() or 1))
     if rank == 0 and world == 1 and not args.no_sample_level:
         run_leg("sample_level", 45, lambda: sample_level(ctx, haps, out.get("cpu_baseline") if isinstance(out.get("cpu_baseline"), dict) else None))
     ctx.close()

@@ -8,16 +8,18 @@
 // executed in a per-XCD L2) -- cost 1.8 of its ~8.4 ms at chr20 class (VGMI_DBG=2 ablation).  With DEFER the row loop writes its runs
 // of hits {id0, windows | dir << 12} out as 8-byte records, 64 per coalesced store; two small kernels behind it turn them into counts:
 //   1. ctd_scatter_kernel: a tile sort in LDS (histogram by LDS atomics whose return value is the record's rank in its bin, exclusive
-//      scan, records placed by bin, ONE reservation per (tile, bin), whole runs written out -- the machinery of vgmi_bloom_bin.hip)
-//      partitions the records by REGION of up to 32 768 consecutive counters.  A record leaves as 27 bits: the lowest counter it touches,
-//      inside its region, and the up to twelve counters from there on as a bit mask (a run's counters are neighbours either way:
-//      id0 - s or id0 + s, vgmi_ctable.h).
-//   2. ctd_accumulate_kernel: a workgroup per region adds its records up in 128 KiB of LDS (ds_add_u32, no return value) and hands
-//      the non-zero sums to the counters with one atomic per counter and launch -- coalesced, 1/24 of the row loop's atomic requests.
-// Exact under every load: a record whose bin has no room left (a sample whose reads pile onto one region: rooms are twice the mean
-// plus slack), a counter beyond its record's region and a run that found the record buffer full are counted by plain atomics where
-// they are met.  Tables of more than CTD_MAX_BINS regions (6.7e7 counters: whole-genome class, where a read makes ~1 run and the
-// atomics are not what the kernel waits for) keep the plain kernel.
+//      scan, records placed by bin, whole runs written out -- the machinery of vgmi_bloom_bin.hip) partitions the records by REGION
+//      of up to 32 768 consecutive counters; every workgroup has a room of its own in every region, so nothing is reserved in global
+//      memory.  A record leaves as 27 bits: the lowest counter it touches, inside its region, and the up to twelve counters from there on
+//      as a bit mask (a run's counters are neighbours either way: id0 - s or id0 + s, vgmi_ctable.h).
+//   2. ctd_accumulate_kernel: a workgroup per region adds its records up in LDS (twelve ds_add_u32 at constant offsets a record, no
+//      return value) and hands the non-zero sums to the counters with one atomic per counter and launch -- coalesced, 1.9e6 atomic
+//      requests a chr20-class launch where the row loop made 7.0e7.
+// Exact under every load: a record whose room is full (a sample whose reads pile onto one region: a room is a workgroup's share of a
+// FULL record buffer plus slack), a counter beyond its record's region and a run that found the record buffer full are counted by
+// plain atomics where they are met.  Tables of more than CTD_MAX_BINS regions (6.7e7 counters: whole-genome class, where a read makes
+// ~1 run and the atomics are a tenth of the kernel's requests) and blocks below VGMI_CT_DEFER_MIN (512 MiB: the pieces of a FASTQ
+// stream do not earn the second pass's fixed cost back) keep the plain kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
