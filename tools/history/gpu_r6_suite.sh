@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6: the whole GPU suite as the driver runs it (wall clock, slowest tests, binaries' sha256), then the default bench line
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r6_suite
 ( time python -m pytest tests/ -x -q -m gpu ) > gpurun_out/r6_suite/suite.log 2>&1
 tail -n 30 gpurun_out/r6_suite/suite.log | cut -c1-200

@@ -128,7 +128,7 @@ int ctd_prepare(vgmi_ctx* c, size_t n_bytes, hipStream_t st, CtDefer* d)
     const char* const e_min = getenv("VGMI_CT_DEFER_MIN");
     // the smallest block that defers: the second pass costs ~70 us whatever the block holds (three launches; 1 280 regions zeroed, added up and
     // scanned) and saves a tenth of the row loop's time, 0.03 us per thousand reads -- even at ~2.6e6 reads = 0.4 GB of packed reads.  Measured
-    // through the CLI (tools/gpu_r6_d.sh, eight chr20 samples, ~100 MiB pieces on two streams): count passes of a sample 0.020-0.027 s in the
+    // through the CLI (tools/history/gpu_r6_d.sh, eight chr20 samples, ~100 MiB pieces on two streams): count passes of a sample 0.020-0.027 s in the
     // row loop, 0.045-0.056 s deferred; the command's wall is the same (counting is ingest-bound).  So pieces of a FASTQ stream keep their
     // atomics and blocks of half a gigabyte or more -- a sample resident in HBM -- defer them.
     const size_t min_bytes = e_min ? (size_t)atoll(e_min) : (size_t)512 << 20;
