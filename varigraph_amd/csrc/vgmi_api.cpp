@@ -12,7 +12,7 @@ thread_local std::string g_create_error;
 // The last error of a context is read by the thread that got the failing return code -- and a context serves several threads at once
 // (FASTQ streams, HMM parts, the --procs broadcast thread): the message is kept per THREAD as well as in the context (the
 // broadcast thread's text no longer lands where a counting thread's vgmi_last_error may be reading).
-thread_local const vgmi_ctx* t_err_ctx = nullptr;
+thread_local uint64_t t_err_ctx = 0;      // vgmi_ctx::id (not the address: a later context may be allocated where an earlier one was)
 thread_local std::string t_err_msg;
 
 int fail(vgmi_ctx* c, int code, const std::string& msg)
@@ -21,7 +21,7 @@ int fail(vgmi_ctx* c, int code, const std::string& msg)
     std::lock_guard<std::mutex> lock(mu);
     if (c) {
         c->err = msg;
-        t_err_ctx = c;
+        t_err_ctx = c->id;
         t_err_msg = msg;
     } else g_create_error = msg;
     return code;
@@ -464,6 +464,8 @@ int vgmi_create(int device, size_t buffer_mib, vgmi_ctx** out)
     if (device < 0 || device >= n) return fail(nullptr, VGMI_E_NO_DEVICE, "device ordinal out of range");
     vgmi_ctx* c = new (std::nothrow) vgmi_ctx();
     if (!c) return fail(nullptr, VGMI_E_NOMEM, "out of host memory");
+    static std::atomic<uint64_t> next_id{1};
+    c->id = next_id.fetch_add(1);
     c->device = device;
     if (buffer_mib == 0) buffer_mib = 100;  // reference default --buffer 100 (include/varigraph.cuh:28)
     c->buffer_bytes = buffer_mib << 20;
@@ -525,7 +527,7 @@ void vgmi_destroy(vgmi_ctx* c)
 const char* vgmi_last_error(const vgmi_ctx* c)
 {
     if (!c) return g_create_error.c_str();
-    if (t_err_ctx == c && !t_err_msg.empty()) return t_err_msg.c_str();      // this thread's own last failure on this context
+    if (t_err_ctx == c->id && !t_err_msg.empty()) return t_err_msg.c_str();      // this thread's own last failure on this context
     return c->err.c_str();
 }
 

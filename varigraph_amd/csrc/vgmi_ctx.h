@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -59,6 +60,7 @@ struct Stage {
 struct ncclUniqueIdBytes { char internal[128]; };      // rccl.h: ncclUniqueId (passed by value to ncclCommInitRank)
 
 struct vgmi_ctx {
+    uint64_t id = 0;               // never repeats in a process: what a thread's own last error is matched against (an address may come back)
     int device = 0;
     int n_cu = 0;
     size_t buffer_bytes = 0;
