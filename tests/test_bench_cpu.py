@@ -74,3 +74,28 @@ def test_synthetic_workloads_have_a_library_of_their_own():
     assert np.array_equal(whole[20 * 151:30 * 151], part) and set(np.unique(whole)) <= set(b"ACGTN\n")
     with pytest.raises(RuntimeError):
         synthlib.reads_host(3, 0, 4, 150, [ref[:100]])          # a haplotype shorter than the insert
+
+
+@pytest.mark.parametrize("which,n,rx,summary", [("c3", 24_000_000, "count27|countkc|ctd_", "r6_c3_rocprofv3_summary.txt"), ("c5", 100_000_000, "count27|countkc|ctd_", "r6_c5_rocprofv3_summary.txt"),
+                                               ("c2", 100_000_000, "count27|countkc|ctd_", "r6_rocprofv3_summary.txt"), ("bloom", 59_999_974, "bb_|rows_kernel", "r6_bloom_rocprofv3_summary.txt")])
+def test_committed_traffic_files_follow_from_the_committed_rocprofv3_summaries(which, n, rx, summary, tmp_path):
+    """profiles/hbm_traffic*.json are what tools/make_traffic_json_r6.py makes of the round's committed rocprofv3 summaries (kernel table + FETCH_SIZE /
+    WRITE_SIZE / request counters per kernel of the count pass): every figure of `roofline.traffic` can be recomputed from profiles/ alone."""
+    import shutil
+    import subprocess
+    name = {"c2": "hbm_traffic.json"}.get(which, f"hbm_traffic_{which}.json")
+    want = json.load(open(os.path.join(ROOT, "profiles", name)))
+    shutil.copy(os.path.join(ROOT, "profiles", summary), tmp_path / "summary.txt")
+    (tmp_path / "libvgmi.sha256").write_text(want["libvgmi_sha256"] + "\n")
+    (tmp_path / "source.sha256").write_text((want.get("source_sha256") or "") + "\n")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_traffic_json_r6.py"), which, str(n), str(tmp_path), rx], check=True, capture_output=True)
+    got = json.load(open(tmp_path / "traffic.json"))
+    for key in ("reads_per_launch", "kernel", "bytes_per_launch", "breakdown_bytes", "kernel_table", "count_pass_us_per_launch_rocprofv3", "libvgmi_sha256"):
+        assert got[key] == want[key], key
+    # ... and the pass the profile timed is the pass the committed bench line timed (same library; another box: within a fifth)
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r6_bench_n1.json")).read())
+    assert line["library"]["libvgmi_sha256"] == want["libvgmi_sha256"]
+    live_ms = {"c2": line["roofline"]["kernel_ms"], "c3": line["c3"]["roofline"]["kernel_ms"], "c5": line["c5"]["roofline"]["kernel_ms"], "bloom": line["bloom"]["add_seconds"] * 1e3}[which]
+    assert abs(want["count_pass_us_per_launch_rocprofv3"] / 1e3 - live_ms) / live_ms < 0.2, (want["count_pass_us_per_launch_rocprofv3"], live_ms)
+    traffic = {"c2": line["roofline"]["traffic"], "c3": line["c3"]["roofline"]["traffic"], "c5": line["c5"]["roofline"]["traffic"], "bloom": line["bloom"]["roofline"]["traffic"]}[which]
+    assert traffic == want["bytes_per_launch"]
